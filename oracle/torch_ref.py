@@ -1,0 +1,576 @@
+"""Differentiable CPU restatement (torch, any float dtype) of the photometric FLAME-fit hot
+path -- TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+Every function cites the reference lines it restates (paths relative to /root/reference).
+The four raster ops restate the published nvdiffrast algorithm (un-vendored third-party
+dependency, pyproject.toml:30; PARITY UNPINNED -- conventions in oracle/raster_oracle.c).
+Visibility (triangle ids) always comes from the C oracle; everything here is smooth arithmetic
+on top of fixed ids, so torch autograd of these functions is the backward oracle.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# --------------------------------------------------------------------------------------
+# FLAME / LBS  (vhap/model/lbs.py, vhap/model/flame.py:571-646)
+# --------------------------------------------------------------------------------------
+
+
+def batch_rodrigues(rot_vecs):
+    """lbs.py:25-57 -- angle = ||r + 1e-8||, K = skew(r/angle), R = I + sin K + (1-cos) K^2."""
+    n = rot_vecs.shape[0]
+    angle = torch.norm(rot_vecs + 1e-8, dim=1, keepdim=True)
+    d = rot_vecs / angle
+    cos = torch.cos(angle)[:, None]
+    sin = torch.sin(angle)[:, None]
+    rx, ry, rz = d[:, 0:1], d[:, 1:2], d[:, 2:3]
+    z = torch.zeros_like(rx)
+    K = torch.cat([z, -rz, ry, rz, z, -rx, -ry, rx, z], dim=1).view(n, 3, 3)
+    eye = torch.eye(3, dtype=rot_vecs.dtype, device=rot_vecs.device)[None]
+    return eye + sin * K + (1 - cos) * torch.bmm(K, K)
+
+
+def batch_rigid_transform(rot_mats, joints, parents):
+    """lbs.py:254-304 -- kinematic chain, returns posed joints and relative transforms."""
+    B, J = joints.shape[:2]
+    rel = joints.clone()
+    rel[:, 1:] = joints[:, 1:] - joints[:, parents[1:]]
+    Tm = torch.zeros(B, J, 4, 4, dtype=joints.dtype, device=joints.device)
+    Tm[:, :, :3, :3] = rot_mats
+    Tm[:, :, :3, 3] = rel
+    Tm[:, :, 3, 3] = 1
+    chain = [Tm[:, 0]]
+    for i in range(1, J):
+        chain.append(chain[int(parents[i])] @ Tm[:, i])
+    G = torch.stack(chain, dim=1)
+    posed = G[:, :, :3, 3]
+    jh = F.pad(joints, [0, 1])[..., None]                     # [B,J,4,1] with 0 in w
+    corr = F.pad(G @ jh, [3, 0])                              # put G*[J;0] in the last column
+    return posed, G - corr
+
+
+def lbs(pose, v_shaped, posedirs, J_regressor, parents, lbs_weights):
+    """lbs.py:101-195."""
+    B = pose.shape[0]
+    J = torch.einsum("bik,ji->bjk", v_shaped, J_regressor)                       # lbs.py:198-215
+    R = batch_rodrigues(pose.reshape(-1, 3)).view(B, -1, 3, 3)
+    eye = torch.eye(3, dtype=pose.dtype, device=pose.device)
+    pose_feature = (R[:, 1:] - eye).reshape(B, -1)
+    v_posed = v_shaped + (pose_feature @ posedirs).view(B, -1, 3)
+    J_t, A = batch_rigid_transform(R, J, parents)
+    T = (lbs_weights[None] @ A.view(B, -1, 16)).view(B, -1, 4, 4)
+    vh = F.pad(v_posed, [0, 1], value=1.0)
+    verts = (T @ vh[..., None])[:, :, :3, 0]
+    return verts, J_t, A[:, 1]
+
+
+def vertices2landmarks(vertices, faces, lmk_faces_idx, lmk_bary_coords):
+    """lbs.py:60-98 (shared embedding for every batch element)."""
+    lf = faces[lmk_faces_idx]                                  # [L,3]
+    lv = vertices[:, lf]                                       # [B,L,3,3]
+    return torch.einsum("blfi,lf->bli", lv, lmk_bary_coords.to(vertices.dtype))
+
+
+def flame_forward(model, shape, expr, rotation, neck, jaw, eyes, translation,
+                  static_offset=None, dynamic_offset=None):
+    """flame.py:571-646 with zero_centered_at_root_node=False, return_verts_cano=True.
+    `model` is a dict of tensors: v_template, shapedirs [V,3,NB], posedirs [36,3V],
+    J_regressor [5,V], parents, lbs_weights [V,5], faces, lmk_faces_idx, lmk_bary_coords."""
+    betas = torch.cat([shape, expr], dim=1)
+    full_pose = torch.cat([rotation, neck, jaw, eyes], dim=1)
+    v_shaped = model["v_template"][None] + torch.einsum("bl,mkl->bmk", betas, model["shapedirs"])
+    if static_offset is not None:
+        v_shaped = v_shaped + static_offset
+    if dynamic_offset is not None:
+        v_shaped = v_shaped + dynamic_offset
+    verts, J, _ = lbs(full_pose, v_shaped, model["posedirs"], model["J_regressor"],
+                      model["parents"], model["lbs_weights"])
+    verts = verts + translation[:, None, :]
+    lmks = vertices2landmarks(verts, model["faces"], model["lmk_faces_idx"], model["lmk_bary_coords"])
+    return verts, v_shaped, lmks
+
+
+# --------------------------------------------------------------------------------------
+# Camera  (vhap/util/render_nvdiffrast.py:102-214)
+# --------------------------------------------------------------------------------------
+
+
+def projection_from_intrinsics(K, image_size, near=0.1, far=10.0):
+    """render_nvdiffrast.py:117-160."""
+    h, w = image_size
+    if K.shape[-2:] == (3, 3):
+        fx, fy, cx, cy = K[..., 0, 0], K[..., 1, 1], K[..., 0, 2], K[..., 1, 2]
+    elif K.shape[-1] == 4:
+        fx, fy, cx, cy = K[..., 0], K[..., 1], K[..., 2], K[..., 3]
+    else:
+        raise ValueError(f"Expected K to be (N, 3, 3) or (N, 4) but got: {K.shape}")
+    P = torch.zeros(K.shape[0], 4, 4, dtype=K.dtype, device=K.device)
+    P[:, 0, 0] = fx * 2 / w
+    P[:, 1, 1] = fy * 2 / h
+    P[:, 0, 2] = (w - 2 * cx) / w
+    P[:, 1, 2] = (h - 2 * cy) / h
+    P[:, 2, 2] = -(far + near) / (far - near)
+    P[:, 2, 3] = -2 * far * near / (far - near)
+    P[:, 3, 2] = -1
+    return P
+
+
+def _mv(RT):
+    if RT.shape[-2] == 3:
+        mv = F.pad(RT, [0, 0, 0, 1]).clone()
+        mv[..., 3, 3] = 1
+        return mv
+    return RT
+
+
+def world_to_camera(vtx, RT):
+    """render_nvdiffrast.py:162-179."""
+    posw = F.pad(vtx, [0, 1], value=1.0) if vtx.shape[-1] == 3 else vtx
+    return posw @ _mv(RT).transpose(-1, -2)
+
+
+def camera_to_clip(vtx, K, image_size):
+    """render_nvdiffrast.py:181-197."""
+    P = projection_from_intrinsics(K, image_size)
+    posw = F.pad(vtx, [0, 1], value=1.0) if vtx.shape[-1] == 3 else vtx
+    if P.shape[0] < posw.shape[0]:
+        P = P.expand(posw.shape[0], -1, -1)
+    return posw @ P.transpose(-1, -2)
+
+
+def world_to_clip(vtx, RT, K, image_size):
+    """render_nvdiffrast.py:199-206."""
+    P = projection_from_intrinsics(K, image_size)
+    mv = _mv(RT)
+    if P.shape[0] < mv.shape[0]:
+        P = P.expand(mv.shape[0], -1, -1)
+    return F.pad(vtx, [0, 1], value=1.0) @ (P @ mv).transpose(-1, -2)
+
+
+def world_to_ndc(vtx, RT, K, image_size, flip_y=False):
+    """render_nvdiffrast.py:208-214."""
+    c = world_to_clip(vtx, RT, K, image_size)
+    ndc = c[:, :, :3] / c[:, :, 3:]
+    if flip_y:
+        ndc = ndc * torch.tensor([1.0, -1.0, 1.0], dtype=ndc.dtype, device=ndc.device)
+    return ndc
+
+
+# --------------------------------------------------------------------------------------
+# Normals + SH shading  (render_nvdiffrast.py:19-53, 297-316; util/vector_ops.py)
+# --------------------------------------------------------------------------------------
+
+
+def safe_normalize(x, eps=1e-20):
+    return x / torch.sqrt(torch.clamp((x * x).sum(-1, keepdim=True), min=eps))
+
+
+def compute_v_normals(verts, faces):
+    """render_nvdiffrast.py:297-316 (area-weighted, fallback (0,0,1), safe_normalize)."""
+    i0, i1, i2 = faces[:, 0].long(), faces[:, 1].long(), faces[:, 2].long()
+    v0, v1, v2 = verts[:, i0], verts[:, i1], verts[:, i2]
+    fn = torch.cross(v1 - v0, v2 - v0, dim=-1)
+    vn = torch.zeros_like(verts)
+    for idx in (i0, i1, i2):
+        vn = vn.index_add(1, idx, fn)
+    fallback = torch.tensor([0.0, 0.0, 1.0], dtype=verts.dtype, device=verts.device)
+    vn = torch.where((vn * vn).sum(-1, keepdim=True) > 1e-20, vn, fallback)
+    return safe_normalize(vn)
+
+
+def sh_const(dtype=torch.float32, device="cpu"):
+    """render_nvdiffrast.py:83-96."""
+    pi = math.pi
+    return torch.tensor([
+        1 / math.sqrt(4 * pi),
+        ((2 * pi) / 3) * math.sqrt(3 / (4 * pi)),
+        ((2 * pi) / 3) * math.sqrt(3 / (4 * pi)),
+        ((2 * pi) / 3) * math.sqrt(3 / (4 * pi)),
+        (pi / 4) * 3 * math.sqrt(5 / (12 * pi)),
+        (pi / 4) * 3 * math.sqrt(5 / (12 * pi)),
+        (pi / 4) * 3 * math.sqrt(5 / (12 * pi)),
+        (pi / 4) * (3 / 2) * math.sqrt(5 / (12 * pi)),
+        (pi / 4) * (1 / 2) * math.sqrt(5 / (4 * pi)),
+    ], dtype=dtype, device=device)
+
+
+def get_SH_shading(normals, sh_coefficients, const):
+    """render_nvdiffrast.py:19-53.  normals [...,3], sh_coefficients [N,9,3] -> [...,3]."""
+    N = normals
+    sh = torch.stack([
+        N[..., 0] * 0.0 + 1.0, N[..., 0], N[..., 1], N[..., 2],
+        N[..., 0] * N[..., 1], N[..., 0] * N[..., 2], N[..., 1] * N[..., 2],
+        N[..., 0] ** 2 - N[..., 1] ** 2, 3 * (N[..., 2] ** 2) - 1,
+    ], dim=-1) * const
+    return torch.sum(sh_coefficients[:, None, None, :, :] * sh[..., None], dim=3)
+
+
+# --------------------------------------------------------------------------------------
+# Raster ops on fixed visibility (nvdiffrast semantics, see raster_oracle.c header)
+# --------------------------------------------------------------------------------------
+
+
+def rast_from_ids(pos, tri, tri_id, resolution):
+    """Differentiable (u, v, z/w, id+1) and (du/dX, du/dY, dv/dX, dv/dY) for FIXED triangle ids.
+    pos [B,V,4], tri [F,3] long, tri_id [B,H,W] long (-1 = empty).  Same formula as
+    shade_frag() in raster_oracle.c (smooth part only)."""
+    B, H, W = tri_id.shape
+    dt, dev = pos.dtype, pos.device
+    valid = tri_id >= 0
+    t = tri_id.clamp(min=0)
+    vi = tri[t]                                                     # [B,H,W,3]
+    bidx = torch.arange(B, device=dev)[:, None, None]
+    p0, p1, p2 = pos[bidx, vi[..., 0]], pos[bidx, vi[..., 1]], pos[bidx, vi[..., 2]]
+    xs, xo = 2.0 / W, 1.0 / W - 1.0
+    ys, yo = 2.0 / H, 1.0 / H - 1.0
+    fx = (xs * torch.arange(W, dtype=dt, device=dev) + xo)[None, None, :]
+    fy = (ys * torch.arange(H, dtype=dt, device=dev) + yo)[None, :, None]
+    p0x, p0y = p0[..., 0] - fx * p0[..., 3], p0[..., 1] - fy * p0[..., 3]
+    p1x, p1y = p1[..., 0] - fx * p1[..., 3], p1[..., 1] - fy * p1[..., 3]
+    p2x, p2y = p2[..., 0] - fx * p2[..., 3], p2[..., 1] - fy * p2[..., 3]
+    a0 = p1x * p2y - p1y * p2x
+    a1 = p2x * p0y - p2y * p0x
+    a2 = p0x * p1y - p0y * p1x
+    at = a0 + a1 + a2
+    at = torch.where(valid, at, torch.ones_like(at))
+    iw = 1.0 / at
+    b0 = (a0 * iw).clamp(0, 1)
+    b1 = (a1 * iw).clamp(0, 1)
+    z = p0[..., 2] * a0 + p1[..., 2] * a1 + p2[..., 2] * a2
+    w = p0[..., 3] * a0 + p1[..., 3] * a1 + p2[..., 3] * a2
+    w = torch.where(valid, w, torch.ones_like(w))
+    zw = (z / w).clamp(-1, 1)
+    idf = (tri_id + 1).to(dt)
+    vf = valid.to(dt)
+    rast = torch.stack([b0 * vf, b1 * vf, zw * vf, idf], dim=-1)
+    da0dx = p2[..., 1] * p1[..., 3] - p1[..., 1] * p2[..., 3]
+    da0dy = p1[..., 0] * p2[..., 3] - p2[..., 0] * p1[..., 3]
+    da1dx = p0[..., 1] * p2[..., 3] - p2[..., 1] * p0[..., 3]
+    da1dy = p2[..., 0] * p0[..., 3] - p0[..., 0] * p2[..., 3]
+    da2dx = p1[..., 1] * p0[..., 3] - p0[..., 1] * p1[..., 3]
+    da2dy = p0[..., 0] * p1[..., 3] - p1[..., 0] * p0[..., 3]
+    datdx = da0dx + da1dx + da2dx
+    datdy = da0dy + da1dy + da2dy
+    dfxdx, dfydy = xs * iw, ys * iw
+    db = torch.stack([dfxdx * (b0 * datdx - da0dx), dfydy * (b0 * datdy - da0dy),
+                      dfxdx * (b1 * datdx - da1dx), dfydy * (b1 * datdy - da1dy)], dim=-1)
+    return rast, db * vf[..., None]
+
+
+def interpolate(attr, rast, tri, rast_db=None, diff_attrs=None):
+    """dr.interpolate (render_nvdiffrast.py:384,389).  attr [1|B,V,A], tri [F,3] long."""
+    B, H, W, _ = rast.shape
+    tid = rast[..., 3].detach().long() - 1
+    valid = (tid >= 0)
+    t = tid.clamp(min=0)
+    vi = tri[t]
+    if attr.shape[0] == 1:
+        a0, a1, a2 = attr[0][vi[..., 0]], attr[0][vi[..., 1]], attr[0][vi[..., 2]]
+    else:
+        bidx = torch.arange(B, device=attr.device)[:, None, None]
+        a0, a1, a2 = attr[bidx, vi[..., 0]], attr[bidx, vi[..., 1]], attr[bidx, vi[..., 2]]
+    b0, b1 = rast[..., 0:1], rast[..., 1:2]
+    b2 = (1.0 - b0) - b1
+    vf = valid[..., None].to(rast.dtype)
+    out = (b0 * a0 + b1 * a1 + b2 * a2) * vf
+    if rast_db is None or diff_attrs is None:
+        return out, None
+    e0, e1 = a0 - a2, a1 - a2
+    dx = rast_db[..., 0:1] * e0 + rast_db[..., 2:3] * e1
+    dy = rast_db[..., 1:2] * e0 + rast_db[..., 3:4] * e1
+    da = torch.stack([dx, dy], dim=-1).reshape(B, H, W, -1) * vf      # (da0/dX, da0/dY, da1/dX, ...)
+    return out, da
+
+
+def build_mips(tex):
+    """Full 2x2 box-filter chain down to 1x1.  tex [N,H,W,C] -> list of levels."""
+    mips = [tex]
+    while mips[-1].shape[1] > 1 and mips[-1].shape[2] > 1 and mips[-1].shape[1] % 2 == 0 and mips[-1].shape[2] % 2 == 0:
+        t = mips[-1]
+        mips.append(((t[:, 0::2, 0::2] + t[:, 0::2, 1::2]) + (t[:, 1::2, 0::2] + t[:, 1::2, 1::2])) * 0.25)
+    return mips
+
+
+def _bilinear_wrap(tex_l, uv):
+    """tex_l [N,h,w,C] (N==1 broadcast), uv [B,H,W,2] -> [B,H,W,C]; 'wrap' boundary, texel centres
+    at half-integers."""
+    N, h, w, C = tex_l.shape
+    B = uv.shape[0]
+    u = uv[..., 0] - torch.floor(uv[..., 0])
+    v = uv[..., 1] - torch.floor(uv[..., 1])
+    x = u * w - 0.5
+    y = v * h - 0.5
+    x0f, y0f = torch.floor(x), torch.floor(y)
+    fx, fy = (x - x0f)[..., None], (y - y0f)[..., None]
+    x0, y0 = x0f.long(), y0f.long()
+    x1, y1 = x0 + 1, y0 + 1
+    x0 = torch.where(x0 < 0, x0 + w, x0)
+    y0 = torch.where(y0 < 0, y0 + h, y0)
+    x1 = torch.where(x1 >= w, x1 - w, x1)
+    y1 = torch.where(y1 >= h, y1 - h, y1)
+    n = torch.zeros(B, 1, 1, dtype=torch.long, device=uv.device) if N == 1 else torch.arange(B, device=uv.device)[:, None, None]
+    a00, a10 = tex_l[n, y0, x0], tex_l[n, y0, x1]
+    a01, a11 = tex_l[n, y1, x0], tex_l[n, y1, x1]
+    top = a00 + fx * (a10 - a00)
+    bot = a01 + fx * (a11 - a01)
+    return top + fy * (bot - top)
+
+
+def texture(tex, uv, uv_da=None, filter_mode="linear-mipmap-linear", mips=None):
+    """dr.texture (render_nvdiffrast.py:399), boundary 'wrap', max_mip_level=None.
+    tex [1|B,Ht,Wt,C]; uv [B,H,W,2]; uv_da [B,H,W,4] = (du/dX, du/dY, dv/dX, dv/dY)."""
+    if filter_mode == "linear":
+        return _bilinear_wrap(tex, uv)
+    assert filter_mode == "linear-mipmap-linear" and uv_da is not None
+    if mips is None:
+        mips = build_mips(tex)
+    Ht, Wt = tex.shape[1], tex.shape[2]
+    dsdx, dsdy = uv_da[..., 0] * Wt, uv_da[..., 1] * Wt
+    dtdx, dtdy = uv_da[..., 2] * Ht, uv_da[..., 3] * Ht
+    A = dsdx * dsdx + dtdx * dtdx
+    Bq = dsdy * dsdy + dtdy * dtdy
+    Cq = dsdx * dsdy + dtdx * dtdy
+    l2b = 0.5 * (A + Bq)
+    l2n = 0.25 * (A - Bq) * (A - Bq) + Cq * Cq
+    len_major_sqr = l2b + torch.sqrt(l2n)
+    lmax = len(mips) - 1
+    level = 0.5 * torch.log2(len_major_sqr.clamp(min=1e-30))
+    level = level.clamp(0, float(lmax))
+    l0 = torch.floor(level).clamp(max=max(lmax - 1, 0)).long()
+    f = (level - l0.to(level.dtype))[..., None]
+    out = None
+    for l in range(lmax + 1):
+        sel0 = (l0 == l)[..., None]
+        sel1 = ((l0 + 1) == l)[..., None] if lmax > 0 else None
+        if not sel0.any() and (sel1 is None or not sel1.any()):
+            continue
+        c = _bilinear_wrap(mips[l], uv)
+        contrib = torch.where(sel0, (1 - f) * c, torch.zeros_like(c))
+        if sel1 is not None:
+            contrib = contrib + torch.where(sel1, f * c, torch.zeros_like(c))
+        out = contrib if out is None else out + contrib
+    return out
+
+
+def build_opposite_table(tri_np, V=None):
+    """Static edge -> opposite-vertex table (replaces nvdiffrast's per-call edge hash).
+    opp[t, i] = the vertex opposite edge i of triangle t in the (first) other triangle sharing
+    that edge, or -1 for a boundary edge.  Edge i is opposite vertex i: (v[(i+1)%3], v[(i+2)%3])."""
+    tri_np = np.asarray(tri_np, np.int64)
+    Fn = tri_np.shape[0]
+    edges = {}
+    for t in range(Fn):
+        for i in range(3):
+            a, b = int(tri_np[t, (i + 1) % 3]), int(tri_np[t, (i + 2) % 3])
+            edges.setdefault((min(a, b), max(a, b)), []).append((t, i))
+    opp = -np.ones((Fn, 3), np.int32)
+    for lst in edges.values():
+        if len(lst) >= 2:
+            (t0, i0), (t1, i1) = lst[0], lst[1]
+            opp[t0, i0] = tri_np[t1, i1]
+            opp[t1, i1] = tri_np[t0, i0]
+            for (t, i) in lst[2:]:                       # non-manifold extras see the first triangle
+                opp[t, i] = tri_np[t0, i0]
+    return opp
+
+
+def antialias(color, rast, pos, tri, opp):
+    """dr.antialias (render_nvdiffrast.py:465).  color [B,H,W,C], rast [B,H,W,4], pos [B,V,4],
+    tri [F,3] long, opp [F,3] long (build_opposite_table).  Differentiable w.r.t. color and pos."""
+    B, H, W, C = color.shape
+    dt, dev = color.dtype, color.device
+    tid = rast[..., 3].detach().long() - 1
+    zw = rast[..., 2].detach()
+    out = color.clone()
+    xh, yh = W * 0.5, H * 0.5
+    for d in (0, 1):                                   # 0: horizontal pair (px,py)-(px+1,py); 1: vertical
+        if d == 0:
+            t0, t1 = tid[:, :, :-1], tid[:, :, 1:]
+            z0, z1 = zw[:, :, :-1], zw[:, :, 1:]
+        else:
+            t0, t1 = tid[:, :-1, :], tid[:, 1:, :]
+            z0, z1 = zw[:, :-1, :], zw[:, 1:, :]
+        sel = (t0 != t1)
+        bb_, py0, px0 = torch.nonzero(sel, as_tuple=True)
+        if bb_.numel() == 0:
+            continue
+        tt0, tt1 = t0[bb_, py0, px0], t1[bb_, py0, px0]
+        zz0, zz1 = z0[bb_, py0, px0], z1[bb_, py0, px0]
+        tri_sel = torch.where(tt0 >= 0, tt0, tt1)
+        both = (tt0 >= 0) & (tt1 >= 0)
+        tri_sel = torch.where(both, torch.where(zz0 < zz1, tt0, tt1), tri_sel)
+        use1 = tri_sel == tt1
+        px1 = px0 + (1 if d == 0 else 0)
+        py1 = py0 + (1 if d == 1 else 0)
+        pxc = torch.where(use1, px1, px0).to(dt)
+        pyc = torch.where(use1, py1, py0).to(dt)
+        vi = tri[tri_sel]                                           # [N,3]
+        op = opp[tri_sel]
+        op = torch.where(op >= 0, op, vi)                           # boundary: vertex itself
+        P = pos[bb_[:, None], vi]                                   # [N,3,4]
+        O = pos[bb_[:, None], op]
+        fx = (pxc + 0.5 - xh)[:, None]
+        fy = (pyc + 0.5 - yh)[:, None]
+        x = P[..., 0] / P[..., 3] * xh - fx                         # [N,3]
+        y = P[..., 1] / P[..., 3] * yh - fy
+        ox = (O[..., 0] / O[..., 3] * xh - fx).detach()
+        oy = (O[..., 1] / O[..., 3] * yh - fy).detach()
+        xd, yd = x.detach(), y.detach()
+        x0_, x1_, x2_ = xd[:, 0], xd[:, 1], xd[:, 2]
+        y0_, y1_, y2_ = yd[:, 0], yd[:, 1], yd[:, 2]
+        bbv = (x1_ - x0_) * (y2_ - y0_) - (x2_ - x0_) * (y1_ - y0_)
+        a0 = (x1_ - ox[:, 0]) * (y2_ - oy[:, 0]) - (x2_ - ox[:, 0]) * (y1_ - oy[:, 0])
+        a1 = (x2_ - ox[:, 1]) * (y0_ - oy[:, 1]) - (x0_ - ox[:, 1]) * (y2_ - oy[:, 1])
+        a2 = (x0_ - ox[:, 2]) * (y1_ - oy[:, 2]) - (x1_ - ox[:, 2]) * (y0_ - oy[:, 2])
+        neg = lambda v: v < 0
+        sil = torch.stack([neg(a0) == neg(bbv), neg(a1) == neg(bbv), neg(a2) == neg(bbv)], dim=1)
+        if d == 1:
+            x, y = y, x                                             # XY flip for vertical pairs
+        # edge i runs from vertex (i+1)%3 to (i+2)%3
+        xa = torch.stack([x[:, 1], x[:, 2], x[:, 0]], dim=1)
+        ya = torch.stack([y[:, 1], y[:, 2], y[:, 0]], dim=1)
+        xb = torch.stack([x[:, 2], x[:, 0], x[:, 1]], dim=1)
+        yb = torch.stack([y[:, 2], y[:, 0], y[:, 1]], dim=1)
+        dx, dy = xb - xa, yb - ya
+        ds = torch.where(use1, -torch.ones_like(pxc), torch.ones_like(pxc))[:, None]
+        straddle = neg(ya.detach()) != neg(yb.detach())
+        dy_safe = torch.where(straddle, dy, torch.ones_like(dy))
+        dcs = ds * (xa * dy - ya * dx) / dy_safe                    # crossing position per edge
+        score = torch.where(straddle, dcs.detach(), torch.full_like(dcs, -float("inf")))
+        di = torch.argmax(score, dim=1)                             # first max -> lowest index on ties
+        rows = torch.arange(di.shape[0], device=dev)
+        ok = straddle[rows, di] & sil[rows, di] & (dy.detach().abs()[rows, di] >= dx.detach().abs()[rows, di])
+        dc = dcs[rows, di]
+        eps = 0.0625
+        ok = ok & (dc.detach() > -eps) & (dc.detach() < 1.0 + eps)
+        dc = dc.clamp(0.0, 1.0)
+        alpha = ds[:, 0] * (0.5 - dc)
+        c0 = color[bb_, py0, px0]
+        c1 = color[bb_, py1, px1]
+        contrib = alpha[:, None] * (c1 - c0)
+        contrib = torch.where(ok[:, None], contrib, torch.zeros_like(contrib))
+        to0 = (alpha.detach() > 0)
+        ty = torch.where(to0, py0, py1)
+        tx = torch.where(to0, px0, px1)
+        flat = (bb_ * H + ty) * W + tx
+        out = out.reshape(-1, C).index_add(0, flat, contrib).reshape(B, H, W, C)
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# Render assembly + energies (render_nvdiffrast.py:354-484, tracker.py:347-478, 480-690)
+# --------------------------------------------------------------------------------------
+
+
+def render_rgba(rast, rast_db, verts, verts_clip, faces, verts_uv, faces_uv, tex, lights, background,
+                opp, const, tex_detach_mask=None, aa_detach_vid=None, disturb=None):
+    """render_nvdiffrast.py:354-484 (lighting_type='SH', lighting_space='world').
+    tex [1|B,T,T,3] channel-last; background [B,H,W,3] (image-space, y down) or list of 3.
+    tex_detach_mask: bool [F+1] (True = detach texc, :390-396). aa_detach_vid: long idx (:463-464).
+    disturb: None or dict(w_fg,w_bg int [B,H,W,1], fid2cid [F+1] long, idx list of 9 long [B*H*W])
+    -- injected randomness for the colour-disturbance block (:424-460).
+    All outputs are in renderer space (row 0 = bottom) *before* the final flips; `rgba_aa_flipped`
+    etc. are returned flipped like the reference."""
+    B, H, W, _ = rast.shape
+    fg = (rast[..., 3:4] > 0)
+    v_normal = compute_v_normals(verts, faces)
+    normal, _ = interpolate(v_normal, rast, faces)
+    normal = safe_normalize(normal)
+    texc, texd = interpolate(verts_uv[None], rast, faces_uv, rast_db, "all")
+    if tex_detach_mask is not None:
+        m = tex_detach_mask[rast[..., 3].detach().long()][..., None]
+        texc = torch.where(m, texc.detach(), texc)
+    albedo = texture(tex, texc, texd)
+    diffuse = get_SH_shading(normal, lights, const)
+    diffuse_dn = get_SH_shading(normal.detach(), lights, const)
+    rgb = albedo * diffuse
+    rgba = torch.cat([rgb, fg.to(rgb.dtype)], dim=-1)
+    if isinstance(background, (list, tuple)):
+        bg = torch.tensor(list(background) + [0.0], dtype=rgba.dtype, device=rgba.device).expand_as(rgba)
+    else:
+        bg = torch.cat([background, torch.zeros_like(background[..., :1])], dim=-1)
+    bg = bg.flip(1)
+    rgba = torch.where(fg, rgba, bg)
+    cid = None
+    if disturb is not None:
+        fid = rast[..., 3].detach().long()
+        cid = disturb["fid2cid"][fid][..., None]
+        ncl = int(disturb["fid2cid"].max()) + 1
+        acc = torch.zeros_like(rgba)
+        for i in range(ncl):
+            c_rgba = bg if i == 0 else rgba
+            w = (disturb["w_bg"] if i == 0 else disturb["w_fg"]).to(rgba.dtype)
+            cm = (cid == i)
+            pool = c_rgba[cm.expand(-1, -1, -1, 4)].reshape(-1, 4).detach()
+            if i != 1:
+                if pool.shape[0] > 0:
+                    idx = disturb["idx"][i] % pool.shape[0]
+                    samp = pool[idx].reshape(B, H, W, 4)
+                    acc = acc + cm * (samp * w + c_rgba * (1 - w))
+            else:
+                acc = acc + cm * c_rgba
+        rgba = acc
+    vc = verts_clip
+    if aa_detach_vid is not None:
+        vc = verts_clip.clone()
+        vc[:, aa_detach_vid] = verts_clip[:, aa_detach_vid].detach()
+    rgba_aa = antialias(rgba, rast, vc, faces, opp)
+    return dict(albedo=albedo.flip(1), normal=normal.flip(1), diffuse=diffuse.flip(1),
+                diffuse_detach_normal=diffuse_dn.flip(1), rgba=rgba_aa.flip(1), rgba_noaa=rgba.flip(1),
+                texc=texc, texd=texd, cid=None if cid is None else cid.flip(1))
+
+
+def landmark_energy(pred_lmks, lmk2d, RT, K, image_size, use_jawline=True):
+    """tracker.py:347-389 + util/mesh.py:41-51.  lmk2d [B,68+,3] = (u_px, v_px, conf)."""
+    H, W = image_size
+    gt = lmk2d[:, :, :2].clone()
+    conf = lmk2d[:, :, 2].clone()
+    gt = torch.stack([2 * (gt[..., 0] - W / 2.0) / W, 2 * (gt[..., 1] - H / 2.0) / H], dim=-1)
+    pred = world_to_ndc(pred_lmks, RT, K, image_size, flip_y=True)[:, :, :2]
+    if use_jawline:
+        diff = gt[:, :68] - pred[:, :68]
+        conf = conf[:, :68].clone()
+        conf[:, 27:36] = conf[:, 27:36] * 10
+    else:
+        diff = gt[:, 17:68] - pred[:, 17:68]
+        conf = conf[:, 17:68]
+    return (diff.abs().sum(-1) * conf).mean()
+
+
+def photometric_energy(gt_rgb_nchw, rgba_nhwc_flipped):
+    """tracker.py:430-439: sum|gt - pred| / (3 * #{alpha > 0})."""
+    pred = rgba_nhwc_flipped.permute(0, 3, 1, 2)
+    mask = (pred[:, 3:4].detach() > 0).expand(-1, 3, -1, -1)
+    return (gt_rgb_nchw - pred[:, :3]).abs().sum() / mask.sum()
+
+
+def tex_tv_energy(tex_chw):
+    """tracker.py:526-531 (mean over [3, (T-1)*T] of tv_y + tv_x)."""
+    tv_y = (tex_chw[..., :-1, :] - tex_chw[..., 1:, :]) ** 2
+    tv_x = (tex_chw[..., :, :-1] - tex_chw[..., :, 1:]) ** 2
+    return (tv_y.reshape(tv_y.shape[0], -1) + tv_x.reshape(tv_x.shape[0], -1)).mean()
+
+
+def uniform_laplacian(num_verts, faces_np):
+    """pytorch3d Meshes.laplacian_packed (flame.py:196): L = D^-1 A - I, diag -1 for every row."""
+    f = np.asarray(faces_np, np.int64)
+    e = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]], 0)
+    e = np.unique(np.sort(e, 1), axis=0)
+    L = np.zeros((num_verts, num_verts), np.float64)
+    L[e[:, 0], e[:, 1]] = 1
+    L[e[:, 1], e[:, 0]] = 1
+    deg = L.sum(1)
+    L = L / np.where(deg > 0, deg, 1)[:, None]
+    L[np.arange(num_verts), np.arange(num_verts)] = -1
+    return L
+
+
+def laplacian_energy(L, verts_wo, verts_w, weights=None):
+    """tracker.py:682-690 + :561-573.  Returns mean( w * sum_k (L(v+o) - L v)^2 )."""
+    diff = ((L @ verts_w) - (L @ verts_wo).detach()) ** 2
+    diff = diff.sum(-1, keepdim=True)
+    if weights is not None:
+        diff = diff * weights
+    return diff.mean()

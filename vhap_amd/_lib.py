@@ -1,0 +1,53 @@
+"""ctypes binding of libvhap_hip.so (the C ABI declared in include/vhap_hip.h).
+
+There is NO fallback: if the shared library is missing or fails to load, importing this module's
+`lib()` raises -- the product path never silently runs anything but the HIP kernels.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "lib", "libvhap_hip.so")
+
+c_fp = ctypes.c_void_p   # device pointers travel as integers (tensor.data_ptr())
+c_i = ctypes.c_int
+c_sz = ctypes.c_size_t
+
+# name -> (restype, [argtypes]) ; must list EVERY symbol declared in include/vhap_hip.h
+SIGNATURES = {
+    "vhap_abi_version": (c_i, []),
+    "vhap_strerror": (ctypes.c_char_p, [c_i]),
+    "vhap_raster_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_sz]),
+    "vhap_raster_fwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_sz, c_sz, c_fp]),
+    "vhap_raster_interp_fwd": (c_i, [c_fp] * 5 + [c_i] * 6 + [c_fp] * 5 + [c_fp, c_sz, c_sz, c_fp]),
+}
+
+_lib = None
+
+
+class VhapHipError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise VhapHipError(
+                f"{SO_PATH} not found: build it with `python -m vhap_amd.build` "
+                "(there is no CPU / eager fallback for the hot path)")
+        L = ctypes.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)          # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        if L.vhap_abi_version() != 1:
+            raise VhapHipError("libvhap_hip.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(code, what=""):
+    if code != 0:
+        msg = lib().vhap_strerror(code).decode()
+        raise VhapHipError(f"{what}: {msg} ({code})")

@@ -1,0 +1,30 @@
+// Shared helpers for the gfx950 kernels (internal, not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vhap_hip.h"
+
+#define VHAP_LAUNCH_CHECK()                                    \
+    do {                                                       \
+        if (hipGetLastError() != hipSuccess) return VHAP_E_HIP; \
+    } while (0)
+
+static inline hipStream_t vhap_stream(vhap_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline int vhap_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// XCD-aware logical block id: the dispatcher places hardware block b on XCD b % 8 (observed, used
+// for L2 affinity only).  Give every XCD a CONTIGUOUS slice of the logical grid so that the
+// blocks sharing one frame's geometry hit the same L2.
+__device__ __forceinline__ unsigned vhap_xcd_remap(unsigned bid, unsigned nblocks) {
+    constexpr unsigned NXCD = 8;
+    if (nblocks % NXCD) return bid;
+    return (bid % NXCD) * (nblocks / NXCD) + bid / NXCD;
+}
+
+__device__ __forceinline__ float vhap_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}

@@ -1,0 +1,16 @@
+// ABI bookkeeping entry points.
+#include "common.h"
+
+extern "C" int vhap_abi_version(void) { return VHAP_ABI_VERSION; }
+
+extern "C" const char* vhap_strerror(int code) {
+    switch (code) {
+        case VHAP_OK: return "ok";
+        case VHAP_E_NULLPTR: return "required pointer is NULL";
+        case VHAP_E_BADDIM: return "dimension out of range";
+        case VHAP_E_WORKSPACE: return "workspace too small";
+        case VHAP_E_HIP: return "HIP runtime / launch failure";
+        case VHAP_E_UNSUPPORTED: return "unsupported configuration";
+        default: return "unknown error";
+    }
+}

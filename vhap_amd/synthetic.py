@@ -1,0 +1,181 @@
+"""Seeded synthetic FLAME-shaped model and scenes.
+
+The licensed FLAME weights (flame2023.pkl, FLAME_masks.pkl; vhap/model/flame.py:38-40) are not
+redistributable, so benchmarks and tests run a *synthetic* linear model on the true FLAME
+topology / UV layout / landmark embedding: random shape/expression/pose bases of the right shape,
+smooth skinning weights, 5 joints with the FLAME kinematic tree.  All arrays are float32 numpy.
+"""
+import numpy as np
+
+from .topology import FlameTopology
+
+N_SHAPE, N_EXPR = 300, 100
+PARENTS = np.array([-1, 0, 1, 1, 1], np.int64)          # root, neck, jaw, eye_L, eye_R
+
+
+def _teeth_vertices(v, topo):
+    """Restates the geometric construction of FlameHead.add_teeth (flame.py:206-260)."""
+    up = v[topo.v_regions["lip_outside_ring_upper"]]
+    lo = v[topo.v_regions["lip_outside_ring_lower"]]
+    mean_dist = np.linalg.norm(up - lo, axis=-1).mean()
+    mid = (up + lo) / 2
+    mid[:, 1] = mid[:, 1].mean()
+    mid[:, 2] -= mean_dist * 1.5
+    ey = np.array([[0, mean_dist, 0]], np.float32)
+    ez = np.array([[0, 0, mean_dist]], np.float32)
+    upper_edge = mid + ey * 0.1
+    upper_root = upper_edge + ey * 2
+    lower_edge = mid - ey * 0.1 - ez * 0.4
+    lower_root = lower_edge - ey * 2
+    th = np.array([[0, 0, mean_dist * 1.0]], np.float32)
+    return np.concatenate([upper_root, lower_root, upper_edge, lower_edge,
+                           upper_root - th, upper_edge - th, lower_root - th, lower_edge - th], 0).astype(np.float32)
+
+
+def make_flame_model(seed=0, add_teeth=True, n_shape=N_SHAPE, n_expr=N_EXPR, topo=None):
+    """Returns (model dict of numpy arrays, FlameTopology)."""
+    rng = np.random.default_rng(seed)
+    topo = topo or FlameTopology(add_teeth=add_teeth)
+    v = topo.v_template_obj.copy()
+    v -= v.mean(0, keepdims=True)                                     # centre the head
+    nv0 = v.shape[0]
+    NB = n_shape + n_expr
+    # smooth random bases: low-frequency Fourier features of the vertex position, so that shape /
+    # expression / pose-corrective displacements deform the head smoothly (mesh stays mesh-like)
+    def smooth_basis(n, amp, fmin, fmax):
+        Wf = rng.standard_normal((n, 3, 3)).astype(np.float32)
+        Wf *= (2 * np.pi / 0.25) * rng.uniform(fmin, fmax, (n, 1, 1)).astype(np.float32) / np.sqrt(3)
+        ph = rng.uniform(0, 2 * np.pi, (n, 3)).astype(np.float32)
+        a = (rng.standard_normal((n, 3)) * amp).astype(np.float32)
+        return a[None] * np.sin(np.einsum("vk,nck->vnc", v, Wf) + ph[None])         # [V,n,3]
+    shapedirs = np.concatenate([smooth_basis(n_shape, 2e-3, 0.3, 2.0), smooth_basis(n_expr, 2e-3, 0.5, 3.0)], 1)
+    shapedirs = np.ascontiguousarray(shapedirs.transpose(0, 2, 1)).astype(np.float32)      # [V,3,NB]
+    posedirs = np.ascontiguousarray(smooth_basis(36, 3e-3, 0.3, 2.0).transpose(1, 0, 2)).reshape(36, nv0 * 3).astype(np.float32)
+
+    # joints: anchor points in the centred template frame (x right, y up, z front)
+    ymin, ymax = v[:, 1].min(), v[:, 1].max()
+    h = ymax - ymin
+    eye_l = v[topo.v_regions["left_eyeball"]].mean(0) if "left_eyeball" in topo.v_regions else np.array([0.03, 0.03, 0.05])
+    eye_r = v[topo.v_regions["right_eyeball"]].mean(0) if "right_eyeball" in topo.v_regions else np.array([-0.03, 0.03, 0.05])
+    anchors = np.array([
+        [0.0, ymin + 0.10 * h, -0.02],     # root (neck base)
+        [0.0, ymin + 0.30 * h, -0.01],     # neck
+        [0.0, ymin + 0.48 * h, 0.00],      # jaw hinge
+        eye_l, eye_r,
+    ], np.float32)
+    J_regressor = np.zeros((5, nv0), np.float32)
+    for j in range(5):
+        d2 = ((v - anchors[j]) ** 2).sum(1)
+        nn = np.argsort(d2)[:32]
+        w = rng.random(32).astype(np.float32) + 0.1
+        J_regressor[j, nn] = w / w.sum()
+    joints = J_regressor @ v
+    # skinning: eyeballs rigid to their joint, the rest a smooth blend of root / neck / jaw
+    d2 = ((v[:, None, :] - joints[None, :3, :]) ** 2).sum(-1)
+    logits = -d2 / (2 * (0.06 ** 2))
+    logits[:, 1] += 1.0                                               # most of the head follows the neck
+    e = np.exp(logits - logits.max(1, keepdims=True))
+    w3 = e / e.sum(1, keepdims=True)
+    lbs_weights = np.zeros((nv0, 5), np.float32)
+    lbs_weights[:, :3] = w3
+    for j, name in ((3, "left_eyeball"), (4, "right_eyeball")):
+        if name in topo.v_regions:
+            idx = topo.v_regions[name]
+            lbs_weights[idx] = 0
+            lbs_weights[idx, j] = 1
+
+    if topo.has_teeth:                                                # flame.py:302-325
+        vt = _teeth_vertices(v, topo)
+        up, lo = topo.v_regions["lip_outside_ring_upper"], topo.v_regions["lip_outside_ring_lower"]
+        sd_mean = (shapedirs[up, :, :n_shape] + shapedirs[lo, :, :n_shape]) / 2        # [15,3,n_shape]
+        sd_t = np.zeros((120, 3, NB), np.float32)
+        for r in range(8):
+            sd_t[15 * r:15 * (r + 1), :, :n_shape] = sd_mean
+        shapedirs = np.concatenate([shapedirs, sd_t], 0)
+        pd = posedirs.reshape(4, 9, nv0, 3)
+        pd = np.concatenate([pd, np.zeros((4, 9, 120, 3), np.float32)], 2)
+        posedirs = pd.reshape(36, (nv0 + 120) * 3)
+        J_regressor = np.concatenate([J_regressor, np.zeros((5, 120), np.float32)], 1)
+        lw_t = np.zeros((120, 5), np.float32)
+        lw_t[topo.v_regions["teeth_upper"] - nv0, 1] = 1
+        lw_t[topo.v_regions["teeth_lower"] - nv0, 2] = 1
+        lbs_weights = np.concatenate([lbs_weights, lw_t], 0)
+        v = np.concatenate([v, vt], 0)
+
+    model = dict(
+        v_template=v.astype(np.float32), shapedirs=shapedirs, posedirs=posedirs,
+        J_regressor=J_regressor, parents=PARENTS.copy(), lbs_weights=lbs_weights,
+        faces=topo.faces.astype(np.int64), faces_uv=topo.faces_uv.astype(np.int64),
+        verts_uvs=topo.verts_uvs.copy(),
+        lmk_faces_idx=topo.lmk_faces_idx.copy(), lmk_bary_coords=topo.lmk_bary_coords.copy(),
+    )
+    return model, topo
+
+
+def smooth_noise(rng, shape, octaves=4):
+    """Cheap smooth value noise in [0,1] of shape [..., H, W] via bilinear upsampling of coarse grids."""
+    *lead, H, W = shape
+    out = np.zeros(shape, np.float32)
+    amp, tot = 1.0, 0.0
+    for o in range(octaves):
+        n = 4 * (2 ** o)
+        g = rng.random((*lead, n + 1, n + 1)).astype(np.float32)
+        ys = np.linspace(0, n, H, endpoint=False)
+        xs = np.linspace(0, n, W, endpoint=False)
+        y0, x0 = ys.astype(int), xs.astype(int)
+        fy, fx = (ys - y0)[:, None], (xs - x0)[None, :]
+        a = g[..., y0][..., :, x0]
+        b = g[..., y0][..., :, x0 + 1]
+        c = g[..., y0 + 1][..., :, x0]
+        d = g[..., y0 + 1][..., :, x0 + 1]
+        out += amp * ((a * (1 - fx) + b * fx) * (1 - fy) + (c * (1 - fx) + d * fx) * fy)
+        tot += amp
+        amp *= 0.5
+    return out / tot
+
+
+def make_texture(seed=0, size=2048):
+    """Procedural stand-in for asset/flame/tex_mean_painted.png: [3,size,size] in [0,1]."""
+    rng = np.random.default_rng(seed + 1000)
+    base = np.array([0.78, 0.60, 0.52], np.float32)[:, None, None]
+    n = smooth_noise(rng, (3, size, size), octaves=6)
+    return np.clip(base + 0.35 * (n - 0.5), 0, 1).astype(np.float32)
+
+
+def make_scene_params(n_frames, seed=0, image_size=(512, 512), translation_z=0.45, n_shape=N_SHAPE, n_expr=N_EXPR):
+    """Ground-truth per-frame FLAME parameters of a synthetic monocular video."""
+    rng = np.random.default_rng(seed + 2000)
+    t = np.linspace(0, 1, n_frames, dtype=np.float32)[:, None]
+    ph = rng.random((1, 3)).astype(np.float32) * 6.28
+    rotation = 0.3 * np.sin(2 * np.pi * t * np.array([[1.0, 0.7, 0.5]], np.float32) + ph)
+    jaw = np.zeros((n_frames, 3), np.float32)
+    jaw[:, 0] = 0.1 + 0.1 * np.sin(2 * np.pi * 2 * t[:, 0] + 1.0)
+    return dict(
+        shape=(rng.standard_normal(n_shape) * 0.5).astype(np.float32),
+        expr=(rng.standard_normal((n_frames, n_expr)) * 0.5).astype(np.float32),
+        rotation=rotation.astype(np.float32),
+        neck_pose=(rng.standard_normal((n_frames, 3)) * 0.03).astype(np.float32),
+        jaw_pose=jaw,
+        eyes_pose=(rng.standard_normal((n_frames, 6)) * 0.05).astype(np.float32),
+        translation=(rng.standard_normal((n_frames, 3)) * 0.01 + np.array([0, 0, translation_z])).astype(np.float32),
+        lights=_lights(rng),
+        focal_length=np.array([1.5], np.float32),
+        image_size=np.array(image_size, np.int64),
+    )
+
+
+def _lights(rng):
+    l = np.zeros((9, 3), np.float32)
+    l[0] = np.sqrt(4 * np.pi)
+    return (l + rng.standard_normal((9, 3)).astype(np.float32) * 0.1).astype(np.float32)
+
+
+def monocular_camera(n, image_size, focal_length=1.5):
+    """Uncalibrated camera of tracker.py:141-157,1335-1337: K=[f,f,cx,cy], RT=[I|(0,0,-1)]."""
+    H, W = image_size
+    f = focal_length * max(H, W)
+    K = np.tile(np.array([[f, f, 0.5 * W, 0.5 * H]], np.float32), (n, 1))
+    RT = np.zeros((n, 3, 4), np.float32)
+    RT[:, :3, :3] = np.eye(3)
+    RT[:, 2, 3] = -1
+    return K, RT
