@@ -37,6 +37,9 @@ typedef void* vhap_stream_t;
 
 int vhap_abi_version(void);
 const char* vhap_strerror(int code);
+/* Profiling-only ablation switches (bit 0: rasterizer skips triangle work, bit 1: skips stores).
+ * Never set in production; 0 restores normal behaviour. */
+void vhap_debug_set_flags(int flags);
 
 /* ---------------------------------------------------------------------------------------------
  * Rasterize: replaces dr.rasterize(glctx, pos, tri, resolution)  (render_nvdiffrast.py:254,257)

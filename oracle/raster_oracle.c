@@ -26,9 +26,14 @@
  *   - coverage uses exact integer edge functions on the snapped coordinates; a pixel on an edge
  *     (E == 0) is inside iff A > 0 || (A == 0 && B > 0) for E = A*x + B*y + C
  *   - back-face culling: snapped signed area <= 0 is culled (CCW = front in y-up NDC)
- *   - depth = z/w evaluated with the float formula below; fragments with z/w outside [-1,1] or
- *     a non-finite / zero barycentric denominator are discarded; nearest z/w wins,
- *     exact ties go to the LOWEST triangle index
+ *   - depth TEST value: z/w is affine in screen space, so it is evaluated from the plane through
+ *     the three snapped vertices carrying zw_i = z_i / w_i, anchored at the origin of the
+ *     aligned 8x8-pixel block that contains the pixel (depth_plane() below: double-precision
+ *     setup from the exact integer edge functions, rounded to float, then two float FMAs per
+ *     pixel); fragments whose test value is outside [-1,1] (or NaN) are discarded; the nearest
+ *     value wins, exact ties go to the LOWEST triangle index
+ *   - the z/w that is OUTPUT (rast[...,2]) is recomputed for the winner with the perspective
+ *     formula below (shade_frag) and clamped to [-1,1]
  *   - output rast = (u, v, z/w, float(tri+1)), u weights vertex 0, v vertex 1; empty = 0
  * All float arithmetic is written with explicit fmaf() and compiled with -ffp-contract=off so
  * that it is bit-reproducible on any IEEE-754 machine (the HIP kernel uses the same op order).
@@ -62,11 +67,11 @@ static int snap_tri(const float* p0, const float* p1, const float* p2, int H, in
     return 1;
 }
 
-/* fragment arithmetic shared by depth test and output (one formula, see header) */
-typedef struct { float b0, b1, zw, iw; int valid; } frag_t;
+/* winner arithmetic (output values) */
+typedef struct { float b0, b1, zw, iw; } frag_t;
 
 static inline frag_t shade_frag(const float* p0, const float* p1, const float* p2, float fx, float fy) {
-    frag_t r; r.valid = 0;
+    frag_t r;
     float p0x = fmaf(-fx, p0[3], p0[0]), p0y = fmaf(-fy, p0[3], p0[1]);
     float p1x = fmaf(-fx, p1[3], p1[0]), p1y = fmaf(-fy, p1[3], p1[1]);
     float p2x = fmaf(-fx, p2[3], p2[0]), p2y = fmaf(-fy, p2[3], p2[1]);
@@ -74,15 +79,35 @@ static inline frag_t shade_frag(const float* p0, const float* p1, const float* p
     float a1 = fmaf(p2x, p0y, -(p2y * p0x));
     float a2 = fmaf(p0x, p1y, -(p0y * p1x));
     float at = (a0 + a1) + a2;
-    if (!(fabsf(at) > 0.0f) || !isfinite(at)) return r;
-    float iw = 1.0f / at;
+    float iw = (fabsf(at) > 0.0f) ? 1.0f / at : 0.0f;
     float z = fmaf(p0[2], a0, fmaf(p1[2], a1, p2[2] * a2));
     float w = fmaf(p0[3], a0, fmaf(p1[3], a1, p2[3] * a2));
     float zw = z / w;
-    if (!(zw >= -1.0f && zw <= 1.0f)) return r;
     r.b0 = fminf(fmaxf(a0 * iw, 0.0f), 1.0f);
     r.b1 = fminf(fmaxf(a1 * iw, 0.0f), 1.0f);
-    r.zw = zw; r.iw = iw; r.valid = 1;
+    r.zw = fminf(fmaxf(zw, -1.0f), 1.0f);
+    r.iw = iw;
+    return r;
+}
+
+/* depth-test plane of one triangle anchored at block origin (bx0,by0) (multiples of 8 pixels).
+ * A1,B1 / A2,B2: coefficients of the edge functions opposite vertex 1 / 2 (weights of v1 / v2). */
+typedef struct { float zwc, gx, gy; } zplane_t;
+
+static inline zplane_t depth_plane(const float* p0, const float* p1, const float* p2, const snapped_t* s,
+                                   int64_t area, int bx0, int by0) {
+    zplane_t r;
+    float zw0 = p0[2] / p0[3], zw1 = p1[2] / p1[3], zw2 = p2[2] / p2[3];
+    int64_t cx = 16 * (int64_t)bx0 + 8, cy = 16 * (int64_t)by0 + 8;
+    int64_t A1 = (int64_t)s->y[2] - s->y[0], B1 = (int64_t)s->x[0] - s->x[2];
+    int64_t A2 = (int64_t)s->y[0] - s->y[1], B2 = (int64_t)s->x[1] - s->x[0];
+    int64_t E1 = A1 * (cx - s->x[2]) + B1 * (cy - s->y[2]);
+    int64_t E2 = A2 * (cx - s->x[0]) + B2 * (cy - s->y[0]);
+    double d1 = (double)zw1 - (double)zw0, d2 = (double)zw2 - (double)zw0;
+    double inv = 1.0 / (double)area;
+    r.zwc = (float)((double)zw0 + ((double)E1 * d1 + (double)E2 * d2) * inv);
+    r.gx = (float)((((double)A1 * d1 + (double)A2 * d2) * 16.0) * inv);
+    r.gy = (float)((((double)B1 * d1 + (double)B2 * d2) * 16.0) * inv);
     return r;
 }
 
@@ -135,10 +160,10 @@ int oracle_rasterize(const float* pos, const int32_t* tri, int B, int V, int F, 
                         else if (E == 0 && !(A[i] > 0 || (A[i] == 0 && Bc[i] > 0))) inside = 0;
                     }
                     if (!inside) continue;
-                    float fx = fmaf(xs, (float)px, xo), fy = fmaf(ys, (float)py, yo);
-                    frag_t fr = shade_frag(p0, p1, p2, fx, fy);
-                    if (!fr.valid) continue;
-                    uint64_t key = ((uint64_t)f2ord(fr.zw) << 32) | (uint32_t)t;
+                    zplane_t zp = depth_plane(p0, p1, p2, &s, area, px & ~7, py & ~7);
+                    float zt = fmaf(zp.gx, (float)(px & 7), fmaf(zp.gy, (float)(py & 7), zp.zwc));
+                    if (!(zt >= -1.0f && zt <= 1.0f)) continue;
+                    uint64_t key = ((uint64_t)f2ord(zt) << 32) | (uint32_t)t;
                     uint64_t* dst = &vis[(size_t)py * W + px];
                     if (key < *dst) *dst = key;
                 }

@@ -76,7 +76,7 @@ def test_brute_force_fallback_when_bins_overflow(flame_model):
     pos = sc["clip"].numpy().astype(np.float32)
     tri = topo.faces.astype(np.int32)
     ref = oracle.rasterize(pos, tri, (H, W))
-    ctx = ops.RasterizeHipContext(pairs_per_triangle=0)        # capacity 0 -> every tile brute-forces
+    ctx = ops.RasterizeHipContext(pairs_per_triangle=0, pairs_per_block=0)        # capacity 0 -> every tile brute-forces
     rast, db = ops.raster_fwd(ctx, torch.from_numpy(pos).cuda(), torch.from_numpy(tri).cuda(), (H, W))
     _assert_raster_equal((rast.cpu().numpy(), db.cpu().numpy()), ref, "fallback")
 

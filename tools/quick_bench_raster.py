@@ -1,7 +1,7 @@
 """Ad-hoc timing of the RI-fwd pass (used during development; bench.py is the contract)."""
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vhap_amd import ops
 from vhap_amd.synthetic import make_flame_model
 from tests.scenes import head_scene
@@ -16,6 +16,8 @@ tri, tri_uv = c(topo.faces.astype(np.int32)), c(topo.faces_uv.astype(np.int32))
 uv = c(topo.verts_uvs.astype(np.float32))
 vn = R.compute_v_normals(sc["verts"], torch.from_numpy(topo.faces.astype(np.int64))).float().cuda()
 ctx = ops.RasterizeHipContext()
+from vhap_amd import _lib
+_lib.lib().vhap_debug_set_flags(int(os.environ.get('VHAP_DEBUG', '0')))
 for fused in (False, True):
     f = (lambda: ops.raster_interp_fwd(ctx, pos, tri, vn, uv, tri_uv, (H, W))) if fused else (lambda: ops.raster_fwd(ctx, pos, tri, (H, W)))
     for _ in range(5): f()

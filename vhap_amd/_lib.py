@@ -17,6 +17,7 @@ c_sz = ctypes.c_size_t
 SIGNATURES = {
     "vhap_abi_version": (c_i, []),
     "vhap_strerror": (ctypes.c_char_p, [c_i]),
+    "vhap_debug_set_flags": (None, [c_i]),
     "vhap_raster_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_sz]),
     "vhap_raster_fwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_sz, c_sz, c_fp]),
     "vhap_raster_interp_fwd": (c_i, [c_fp] * 5 + [c_i] * 6 + [c_fp] * 5 + [c_fp, c_sz, c_sz, c_fp]),

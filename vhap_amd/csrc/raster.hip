@@ -1,34 +1,50 @@
-// Tile-binned triangle rasteriser + fused barycentric/attribute interpolation for gfx950.
+// Block-binned triangle rasteriser + fused barycentric/attribute interpolation for gfx950.
 //
 // Replaces dr.rasterize / dr.interpolate of the reference (vhap/util/render_nvdiffrast.py:254,
 // 384, 389).  Conventions are specified in DESIGN.md section 3 and restated independently in
 // oracle/raster_oracle.c, against which this file is checked bit-for-bit (triangle ids, z/w, u, v).
 //
-// Structure (one frame batch = 4 small launches + 1 big one):
-//   bin_count  : 1 thread / (frame, triangle): snap to 1/16 px, cull, pixel bbox -> tile range,
-//                atomic per-tile counters
-//   bin_scan   : per-256-tile block exclusive scan + one atomic per block -> list offsets
-//   bin_fill   : 1 thread / (frame, triangle): append the triangle to every tile list it touches
-//   raster     : 1 workgroup (4 waves) / 32x8-pixel tile, each wave owns an 8x8 pixel block.
+// Structure (one frame batch = memset + 3 small launches + 1 big one):
+//   bin_count  : 1 thread / (frame, triangle): snap to 1/16 px, cull, pixel bbox -> range of 8x8
+//                pixel BLOCKS; histogram in LDS, one global atomic per touched block per workgroup
+//   bin_scan   : per-256-block exclusive scan + one atomic per workgroup -> list offsets
+//   bin_fill   : same LDS aggregation, writes (tri id, 3 vertex indices) into the block lists
+//   raster     : 1 workgroup = 4 waves = 32x8 pixels, each WAVE owns one 8x8 block and its list.
 //                Per 64-triangle chunk every lane sets up ONE triangle (exact integer edge
-//                functions relative to the block origin), a wave ballot keeps the triangles whose
-//                bbox meets the block, v_readlane broadcasts each survivor through SGPRs and every
-//                lane (= pixel) evaluates coverage + z/w and keeps the smallest (depth, id) key in
-//                registers.  No LDS, no barriers, no atomics in the resolve; the winner is
-//                independent of list order.  The same lane then shades its pixel (u, v, z/w,
+//                functions and the z/w test plane, both relative to the block origin), v_readlane
+//                broadcasts each triangle through SGPRs and every lane (= pixel) evaluates coverage
+//                (3 integer mads) and the depth plane (2 FMAs) and keeps the smallest (depth, id)
+//                key in registers.  No LDS, no barriers, no atomics in the resolve; the winner is
+//                independent of list order.  The lane then shades its pixel once (u, v, z/w,
 //                derivatives, normal, uv, uv derivatives) and writes the G-buffer.
 #include "common.h"
 
-#pragma clang fp contract(off)  // bit-exact op order vs the oracle: only explicit fmaf() fuses
+#pragma clang fp contract(off)  // bit-exact op order vs the oracle: only explicit fma() fuses
 
 namespace {
 
-constexpr int TILE_W = 32;
-constexpr int TILE_H = 8;
-constexpr float GUARD = 1048576.0f;  // 2^20 sub-pixel units
+constexpr int BLK = 8;              // bin = 8x8 pixels = one wave
+constexpr int WG_BLOCKS = 4;        // 4 horizontally adjacent bins per workgroup (32x8 pixels)
+constexpr float GUARD = 1048576.0f; // 2^20 sub-pixel units
+constexpr unsigned TRANGE_NONE = 0xffffffffu;
+constexpr int LDS_BIN_LIMIT = 16384;  // dense per-workgroup bin histogram (<= 2 x 64 KiB of LDS)
+constexpr int BIN_THREADS = 1024;     // fat workgroups: fewer LDS-histogram flushes per frame
+
+// Per-(frame, triangle) setup record written once by bin_count (80 B, five 16-byte quads): everything
+// the raster kernel needs that does not depend on the 8x8 block -- snapped vertices, pixel bbox, the
+// per-vertex z/w, 1/area (double) and the vertex / uv-vertex indices.  All the divisions of the setup
+// happen once per triangle here instead of once per (triangle, block, wave) in the raster kernel.
+struct TriRecord {
+    int4 q0;    // sx0, sy0, sx1, sy1                       (1/16-pixel units)
+    int4 q1;    // sx2, sy2, px0 | px1 << 16, py0 | py1 << 16 (inclusive pixel bbox)
+    float4 q2;  // zw0, zw1, zw2, unused
+    int4 q3;    // 1/area as double (lo, hi), i0, i1
+    int4 q4;    // i2, j0, j1, j2
+};
+static_assert(sizeof(TriRecord) == 80, "record layout");
 
 struct BinHeader {
-    unsigned total;  // number of (triangle, tile) pairs of this batch
+    unsigned total;  // number of (triangle, block) pairs of this batch
     unsigned pad[15];
 };
 
@@ -44,12 +60,13 @@ __device__ __forceinline__ bool snap_vertex(const float4 p, float hw, float hh, 
 
 // Snap + cull + pixel bbox (inclusive, clipped to the image).  Returns false when nothing to draw.
 __device__ __forceinline__ bool tri_bbox(const float4 p0, const float4 p1, const float4 p2, int H, int W,
-                                         int (&sx)[3], int (&sy)[3], int& px0, int& px1, int& py0, int& py1) {
+                                         int (&sx)[3], int (&sy)[3], long long& area, int& px0, int& px1, int& py0,
+                                         int& py1) {
     const float hw = 8.0f * (float)W, hh = 8.0f * (float)H;
     if (!snap_vertex(p0, hw, hh, sx[0], sy[0])) return false;
     if (!snap_vertex(p1, hw, hh, sx[1], sy[1])) return false;
     if (!snap_vertex(p2, hw, hh, sx[2], sy[2])) return false;
-    const long long area = (long long)(sx[1] - sx[0]) * (sy[2] - sy[0]) - (long long)(sx[2] - sx[0]) * (sy[1] - sy[0]);
+    area = (long long)(sx[1] - sx[0]) * (sy[2] - sy[0]) - (long long)(sx[2] - sx[0]) * (sy[1] - sy[0]);
     if (area <= 0) return false;  // back-facing or degenerate
     const int minx = min(sx[0], min(sx[1], sx[2])), maxx = max(sx[0], max(sx[1], sx[2]));
     const int miny = min(sy[0], min(sy[1], sy[2])), maxy = max(sy[0], max(sy[1], sy[2]));
@@ -60,42 +77,82 @@ __device__ __forceinline__ bool tri_bbox(const float4 p0, const float4 p1, const
     return px0 <= px1 && py0 <= py1;
 }
 
-__device__ __forceinline__ bool load_tri(const float* __restrict__ pos, const int* __restrict__ tri, int b, int V,
-                                         int t, float4& p0, float4& p1, float4& p2) {
+// Block range of one (frame, triangle): bx0 | bx1<<9 | by0<<18 | span<<27 with span = by1-by0, 31 =
+// "up to the last block row" (conservative; the raster kernel re-tests the bbox).  H,W <= 4096 -> < 512.
+// Also fills the triangle's setup record.
+__device__ __forceinline__ unsigned block_range(const float* __restrict__ pos, const int* __restrict__ tri,
+                                                const int* __restrict__ tri_uv, int b, int V, int t, int H, int W,
+                                                TriRecord& rec) {
     const int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
-    if ((unsigned)i0 >= (unsigned)V || (unsigned)i1 >= (unsigned)V || (unsigned)i2 >= (unsigned)V) return false;
+    if ((unsigned)i0 >= (unsigned)V || (unsigned)i1 >= (unsigned)V || (unsigned)i2 >= (unsigned)V) return TRANGE_NONE;
     const float4* P = reinterpret_cast<const float4*>(pos) + (size_t)b * V;
-    p0 = P[i0];
-    p1 = P[i1];
-    p2 = P[i2];
-    return true;
+    const float4 p0 = P[i0], p1 = P[i1], p2 = P[i2];
+    int sx[3], sy[3], px0, px1, py0, py1;
+    long long area;
+    if (!tri_bbox(p0, p1, p2, H, W, sx, sy, area, px0, px1, py0, py1)) return TRANGE_NONE;
+    const double inv = 1.0 / (double)area;
+    rec.q0 = make_int4(sx[0], sy[0], sx[1], sy[1]);
+    rec.q1 = make_int4(sx[2], sy[2], px0 | (px1 << 16), py0 | (py1 << 16));
+    rec.q2 = make_float4(__fdiv_rn(p0.z, p0.w), __fdiv_rn(p1.z, p1.w), __fdiv_rn(p2.z, p2.w), 0.0f);
+    rec.q3 = make_int4(__double2loint(inv), __double2hiint(inv), i0, i1);
+    int j0 = 0, j1 = 0, j2 = 0;
+    if (tri_uv) { j0 = tri_uv[3 * t]; j1 = tri_uv[3 * t + 1]; j2 = tri_uv[3 * t + 2]; }
+    rec.q4 = make_int4(i2, j0, j1, j2);
+    const int bx0 = px0 / BLK, bx1 = px1 / BLK, by0 = py0 / BLK, by1 = py1 / BLK;
+    const int span = by1 - by0;
+    return (unsigned)bx0 | ((unsigned)bx1 << 9) | ((unsigned)by0 << 18) | ((unsigned)(span > 30 ? 31 : span) << 27);
 }
 
-constexpr unsigned TRANGE_NONE = 0xffffffffu;
+struct BlockRange {
+    int bx0, bx1, by0, by1;
+};
+__device__ __forceinline__ BlockRange decode_range(unsigned tr, int nby) {
+    BlockRange r;
+    r.bx0 = tr & 511; r.bx1 = (tr >> 9) & 511; r.by0 = (tr >> 18) & 511;
+    const int span = tr >> 27;
+    r.by1 = span == 31 ? nby - 1 : r.by0 + span;
+    return r;
+}
 
-__global__ __launch_bounds__(256) void bin_count_kernel(const float* __restrict__ pos, const int* __restrict__ tri,
-                                                        int B, int V, int F, int H, int W, int ntx, int nty,
-                                                        unsigned* __restrict__ counts, unsigned* __restrict__ trange) {
-    const int g = blockIdx.x * 256 + threadIdx.x;
-    if (g >= B * F) return;
-    const int b = g / F, t = g - b * F;
+// The mesh is spatially coherent in triangle order, so the 256 triangles of a workgroup hit a handful
+// of bins.  Global atomics on a few hot counters serialise in the L2 (measured: 30 us for 150 k adds);
+// instead every workgroup histograms into LDS and flushes ONE global atomic per touched bin.
+// grid = (ceil(F/256), B); dynamic LDS = nbin * 4 bytes when nbin <= LDS_BIN_LIMIT, else direct atomics.
+__global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(const float* __restrict__ pos, const int* __restrict__ tri,
+                                                                const int* __restrict__ tri_uv, int V, int F, int H, int W,
+                                                                int nbx, int nby, unsigned* __restrict__ counts,
+                                                                unsigned* __restrict__ trange, TriRecord* __restrict__ records) {
+    extern __shared__ __attribute__((aligned(16))) unsigned lds_cnt[];
+    const int nbin = nbx * nby;
+    const bool use_lds = nbin <= LDS_BIN_LIMIT;
+    const int b = blockIdx.y, t = blockIdx.x * BIN_THREADS + threadIdx.x;
+    if (use_lds) {
+        for (int i = threadIdx.x; i < nbin; i += BIN_THREADS) lds_cnt[i] = 0u;
+        __syncthreads();
+    }
+    unsigned* c = counts + (size_t)b * nbin;
     unsigned tr = TRANGE_NONE;
-    float4 p0, p1, p2;
-    if (load_tri(pos, tri, b, V, t, p0, p1, p2)) {
-        int sx[3], sy[3], px0, px1, py0, py1;
-        if (tri_bbox(p0, p1, p2, H, W, sx, sy, px0, px1, py0, py1)) {
-            const int tx0 = px0 / TILE_W, tx1 = px1 / TILE_W, ty0 = py0 / TILE_H, ty1 = py1 / TILE_H;
-            // W,H <= 4096 -> tx <= 127 (8 bits), ty <= 511 (10 bits); the row span is stored in 6 bits,
-            // 63 meaning "up to the last tile row" (conservative: the raster kernel re-tests the bbox).
-            const int span = ty1 - ty0;
-            tr = (unsigned)tx0 | ((unsigned)tx1 << 8) | ((unsigned)ty0 << 16) | ((unsigned)(span > 62 ? 63 : span) << 26);
-            unsigned* c = counts + (size_t)b * ntx * nty;
-            const int ty1e = span > 62 ? nty - 1 : ty1;
-            for (int ty = ty0; ty <= ty1e; ty++)
-                for (int tx = tx0; tx <= tx1; tx++) atomicAdd(&c[ty * ntx + tx], 1u);
+    if (t < F) {
+        TriRecord rec;
+        tr = block_range(pos, tri, tri_uv, b, V, t, H, W, rec);
+        trange[(size_t)b * F + t] = tr;
+        if (tr != TRANGE_NONE) records[(size_t)b * F + t] = rec;
+    }
+    if (tr != TRANGE_NONE) {
+        const BlockRange r = decode_range(tr, nby);
+        for (int y = r.by0; y <= r.by1; y++)
+            for (int x = r.bx0; x <= r.bx1; x++) {
+                if (use_lds) atomicAdd(&lds_cnt[y * nbx + x], 1u);
+                else atomicAdd(&c[y * nbx + x], 1u);
+            }
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < nbin; i += BIN_THREADS) {
+            const unsigned n = lds_cnt[i];
+            if (n) atomicAdd(&c[i], n);
         }
     }
-    trange[g] = tr;
 }
 
 __global__ __launch_bounds__(256) void bin_scan_kernel(const unsigned* __restrict__ counts, unsigned* __restrict__ offsets,
@@ -115,7 +172,7 @@ __global__ __launch_bounds__(256) void bin_scan_kernel(const unsigned* __restric
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned s = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        base = atomicAdd(&hdr->total, s);
+        base = s ? atomicAdd(&hdr->total, s) : 0u;
     }
     __syncthreads();
     unsigned pre = base;
@@ -123,37 +180,56 @@ __global__ __launch_bounds__(256) void bin_scan_kernel(const unsigned* __restric
     if (i < n) offsets[i] = pre + v - c;
 }
 
-__global__ __launch_bounds__(256) void bin_fill_kernel(const unsigned* __restrict__ trange, int B, int F, int ntx, int nty,
-                                                       const unsigned* __restrict__ offsets, unsigned* __restrict__ cursors,
-                                                       unsigned* __restrict__ list, const BinHeader* __restrict__ hdr,
-                                                       unsigned capacity) {
-    if (hdr->total > capacity) return;  // raster kernel brute-forces instead
-    const int g = blockIdx.x * 256 + threadIdx.x;
-    if (g >= B * F) return;
-    const unsigned tr = trange[g];
-    if (tr == TRANGE_NONE) return;
-    const int b = g / F, t = g - b * F;
-    const int tx0 = tr & 255, tx1 = (tr >> 8) & 255, ty0 = (tr >> 16) & 1023, span = tr >> 26;
-    const int ty1 = span == 63 ? nty - 1 : ty0 + span;
-    const size_t tb = (size_t)b * ntx * nty;
-    for (int ty = ty0; ty <= ty1; ty++)
-        for (int tx = tx0; tx <= tx1; tx++) {
-            const size_t ti = tb + ty * ntx + tx;
-            const unsigned slot = atomicAdd(&cursors[ti], 1u);
-            list[offsets[ti] + slot] = (unsigned)t;
+__global__ __launch_bounds__(BIN_THREADS) void bin_fill_kernel(const unsigned* __restrict__ trange, int F, int nbx, int nby,
+                                                               const unsigned* __restrict__ offsets,
+                                                               unsigned* __restrict__ cursors, unsigned* __restrict__ list,
+                                                               const BinHeader* __restrict__ hdr, unsigned capacity) {
+    extern __shared__ __attribute__((aligned(16))) unsigned lds_fill[];
+    if (hdr->total > capacity) return;  // the raster kernel brute-forces instead (uniform exit)
+    const int nbin = nbx * nby;
+    const bool use_lds = nbin <= LDS_BIN_LIMIT;
+    unsigned* lcnt = lds_fill;
+    unsigned* lbase = lds_fill + nbin;
+    const int b = blockIdx.y, t = blockIdx.x * BIN_THREADS + threadIdx.x;
+    const size_t tb = (size_t)b * nbin;
+    const unsigned tr = t < F ? trange[(size_t)b * F + t] : TRANGE_NONE;
+    BlockRange r{0, -1, 0, -1};
+    if (tr != TRANGE_NONE) r = decode_range(tr, nby);
+    if (!use_lds) {
+        for (int y = r.by0; y <= r.by1; y++)
+            for (int x = r.bx0; x <= r.bx1; x++) {
+                const size_t bi = tb + y * nbx + x;
+                list[offsets[bi] + atomicAdd(&cursors[bi], 1u)] = (unsigned)t;
+            }
+        return;
+    }
+    for (int i = threadIdx.x; i < nbin; i += BIN_THREADS) lcnt[i] = 0u;
+    __syncthreads();
+    for (int y = r.by0; y <= r.by1; y++)
+        for (int x = r.bx0; x <= r.bx1; x++) atomicAdd(&lcnt[y * nbx + x], 1u);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nbin; i += BIN_THREADS) {
+        const unsigned n = lcnt[i];
+        if (n) {
+            lbase[i] = offsets[tb + i] + atomicAdd(&cursors[tb + i], n);
+            lcnt[i] = 0u;
+        }
+    }
+    __syncthreads();
+    for (int y = r.by0; y <= r.by1; y++)
+        for (int x = r.bx0; x <= r.bx1; x++) {
+            const int bi = y * nbx + x;
+            list[lbase[bi] + atomicAdd(&lcnt[bi], 1u)] = (unsigned)t;
         }
 }
 
-// ---- fragment arithmetic (same op order as shade_frag() in the oracle) ----
+// ---- winner arithmetic (same op order as shade_frag() in the oracle) ----
 struct Frag {
     float b0, b1, zw, iw;
-    bool valid;
 };
 
 __device__ __forceinline__ Frag shade_frag(const float4 p0, const float4 p1, const float4 p2, float fx, float fy) {
     Frag r;
-    r.valid = false;
-    r.b0 = r.b1 = r.zw = r.iw = 0.0f;
     const float p0x = __fmaf_rn(-fx, p0.w, p0.x), p0y = __fmaf_rn(-fy, p0.w, p0.y);
     const float p1x = __fmaf_rn(-fx, p1.w, p1.x), p1y = __fmaf_rn(-fy, p1.w, p1.y);
     const float p2x = __fmaf_rn(-fx, p2.w, p2.x), p2y = __fmaf_rn(-fy, p2.w, p2.y);
@@ -161,18 +237,14 @@ __device__ __forceinline__ Frag shade_frag(const float4 p0, const float4 p1, con
     const float a1 = __fmaf_rn(p2x, p0y, -(p2y * p0x));
     const float a2 = __fmaf_rn(p0x, p1y, -(p0y * p1x));
     const float at = (a0 + a1) + a2;
-    const float aat = fabsf(at);
-    if (!(aat > 0.0f) || !(aat < INFINITY)) return r;
-    const float iw = __fdiv_rn(1.0f, at);
+    const float iw = (fabsf(at) > 0.0f) ? __fdiv_rn(1.0f, at) : 0.0f;
     const float z = __fmaf_rn(p0.z, a0, __fmaf_rn(p1.z, a1, p2.z * a2));
     const float w = __fmaf_rn(p0.w, a0, __fmaf_rn(p1.w, a1, p2.w * a2));
     const float zw = __fdiv_rn(z, w);
-    if (!(zw >= -1.0f && zw <= 1.0f)) return r;
     r.b0 = fminf(fmaxf(a0 * iw, 0.0f), 1.0f);
     r.b1 = fminf(fmaxf(a1 * iw, 0.0f), 1.0f);
-    r.zw = zw;
+    r.zw = fminf(fmaxf(zw, -1.0f), 1.0f);
     r.iw = iw;
-    r.valid = true;
     return r;
 }
 
@@ -186,7 +258,9 @@ __device__ __forceinline__ int sat30(long long e) {
     return (int)(e > lim ? lim : (e < -lim ? -lim : e));
 }
 
-__device__ __forceinline__ float rl(float v, int lane) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane)); }
+__device__ __forceinline__ float rl(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
 __device__ __forceinline__ int rli(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 
 struct RasterParams {
@@ -195,12 +269,15 @@ struct RasterParams {
     const float* vnormal;  // [B,V,3]   (INTERP only)
     const float* uv;       // [VT,2]
     const int* tri_uv;     // [F,3]
-    int B, V, VT, F, H, W, ntx, nty;
+    int B, V, VT, F, H, W, nbx, nby, nwx;  // nwx = workgroups per block row
     const unsigned* counts;
     const unsigned* offsets;
     const unsigned* list;
+    const unsigned* trange;
+    const TriRecord* records;
     const BinHeader* hdr;
     unsigned capacity;
+    int debug;  // ablation switches for profiling only (vhap_debug_set_flags)
     float* rast;
     float* rast_db;
     float* normal;
@@ -210,101 +287,144 @@ struct RasterParams {
 
 template <bool INTERP>
 __global__ __launch_bounds__(256) void raster_kernel(const RasterParams P) {
-    const unsigned nblocks = gridDim.x;
-    const unsigned L = vhap_xcd_remap(blockIdx.x, nblocks);
-    const int ntile = P.ntx * P.nty;
-    const int b = L / ntile, tile = L - b * ntile;
-    const int ty = tile / P.ntx, tx = tile - ty * P.ntx;
+    const unsigned L = vhap_xcd_remap(blockIdx.x, gridDim.x);
+    const int nwg = P.nwx * P.nby;  // workgroups per frame
+    const int b = L / nwg, wgi = L - b * nwg;
+    const int wy = wgi / P.nwx, wx = wgi - wy * P.nwx;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int bx0 = tx * TILE_W + wave * 8, by0 = ty * TILE_H;  // this wave's 8x8 pixel block
+    const int bx = wx * WG_BLOCKS + wave, by = wy;  // this wave's 8x8 block
+    if (bx >= P.nbx) return;                        // whole wave outside the image
+    const int bx0 = bx * BLK, by0 = by * BLK;
     const int dxp = lane & 7, dyp = lane >> 3;
     const int px = bx0 + dxp, py = by0 + dyp;
     const bool in_img = px < P.W && py < P.H;
     const int H = P.H, W = P.W;
 
-    const float xs = __fdiv_rn(2.0f, (float)W), xo = __fdiv_rn(1.0f, (float)W) - 1.0f;
-    const float ys = __fdiv_rn(2.0f, (float)H), yo = __fdiv_rn(1.0f, (float)H) - 1.0f;
-    const float fx = __fmaf_rn(xs, (float)px, xo), fy = __fmaf_rn(ys, (float)py, yo);
-
     const bool use_list = P.hdr->total <= P.capacity;
-    const unsigned n = use_list ? P.counts[L] : (unsigned)P.F;
-    const unsigned off = use_list ? P.offsets[L] : 0u;
+    const size_t bin = (size_t)b * P.nbx * P.nby + (size_t)by * P.nbx + bx;
+    const unsigned n = (P.debug & 1) ? 0u : (use_list ? P.counts[bin] : (unsigned)P.F);
+    const unsigned off = use_list ? P.offsets[bin] : 0u;
 
-    unsigned long long best = ~0ull;
-    float bb0 = 0.f, bb1 = 0.f, bzw = 0.f, biw = 0.f;
+    unsigned long long best = ~0ull;  // (ordered z/w test value << 32) | triangle id
 
-    // block bbox in pixels (inclusive)
-    const int bx1 = bx0 + 7, by1 = by0 + 7;
-    const long long cx = 16ll * bx0 + 8, cy = 16ll * by0 + 8;  // sub-pixel position of the block-origin pixel centre
+    const int bx1 = bx0 + BLK - 1, by1 = by0 + BLK - 1;
+    const int cx = 16 * bx0 + 8, cy = 16 * by0 + 8;  // sub-pixel position of the block-origin pixel centre
     const int dx16 = dxp * 16, dy16 = dyp * 16;
+    const float fdx = (float)dxp, fdy = (float)dyp;
+    const TriRecord* REC = P.records + (size_t)b * P.F;
+    const unsigned* TR = P.trange + (size_t)b * P.F;
+
+    __shared__ int4 sd[4][3][64];  // per-wave broadcast staging of the current chunk (3 KiB per wave)
+    typedef short short2_t __attribute__((ext_vector_type(2)));
+    const short2_t dxy = __builtin_bit_cast(short2_t, dx16 | (dy16 << 16));
 
     for (unsigned base = 0; base < n; base += 64) {
         const unsigned k = base + lane;
-        bool hit = false;
+        bool hit = false, small = true;
         int t = 0;
-        float4 p0, p1, p2;
-        int A0 = 0, B0 = 0, C0 = 0, A1 = 0, B1 = 0, C1 = 0, A2 = 0, B2 = 0, C2 = 0;
-        p0 = p1 = p2 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < n) {
+        int AB0 = 0, AB1 = 0, AB2 = 0, C0 = 0, C1 = 0, C2 = 0;  // AB = A (low 16) | B (high 16)
+        float zwc = 0.f, gx = 0.f, gy = 0.f;
+        if (k < n && !(P.debug & 8)) {
             t = use_list ? (int)P.list[off + k] : (int)k;
-            if (load_tri(P.pos, P.tri, b, P.V, t, p0, p1, p2)) {
-                int sx[3], sy[3], qx0, qx1, qy0, qy1;
-                if (tri_bbox(p0, p1, p2, H, W, sx, sy, qx0, qx1, qy0, qy1)) {
-                    hit = !(qx1 < bx0 || qx0 > bx1 || qy1 < by0 || qy0 > by1);
-                    if (hit) {
-                        // edge i is opposite vertex i: a = v[(i+1)%3], b = v[(i+2)%3]
-                        // E = A*x + B*y + C', inside iff E > 0 or (E == 0 and top-left); fold the tie rule
-                        // and a -1 into the constant so that inside <=> (E0|E1|E2) >= 0.
-                        A0 = sy[1] - sy[2]; B0 = sx[2] - sx[1];
-                        A1 = sy[2] - sy[0]; B1 = sx[0] - sx[2];
-                        A2 = sy[0] - sy[1]; B2 = sx[1] - sx[0];
-                        const int tl0 = (A0 > 0 || (A0 == 0 && B0 > 0)) ? 1 : 0;
-                        const int tl1 = (A1 > 0 || (A1 == 0 && B1 > 0)) ? 1 : 0;
-                        const int tl2 = (A2 > 0 || (A2 == 0 && B2 > 0)) ? 1 : 0;
-                        C0 = sat30((long long)A0 * (cx - sx[1]) + (long long)B0 * (cy - sy[1]) + tl0 - 1);
-                        C1 = sat30((long long)A1 * (cx - sx[2]) + (long long)B1 * (cy - sy[2]) + tl1 - 1);
-                        C2 = sat30((long long)A2 * (cx - sx[0]) + (long long)B2 * (cy - sy[0]) + tl2 - 1);
-                    }
+            if (use_list || TR[t] != TRANGE_NONE) {  // brute-force mode: skip culled triangles (no record)
+                const TriRecord* rp = REC + t;
+                const int4 q0 = rp->q0, q1 = rp->q1;
+                const int qx0 = q1.z & 0xffff, qx1 = q1.z >> 16, qy0 = q1.w & 0xffff, qy1 = q1.w >> 16;
+                hit = !(qx1 < bx0 || qx0 > bx1 || qy1 < by0 || qy0 > by1);
+                if (hit) {
+                    const float4 q2 = rp->q2;
+                    const int4 q3 = rp->q3;
+                    const int sx0 = q0.x, sy0 = q0.y, sx1 = q0.z, sy1 = q0.w, sx2 = q1.x, sy2 = q1.y;
+                    // edge i is opposite vertex i: a = v[(i+1)%3], b = v[(i+2)%3];  E = A*x + B*y + C,
+                    // inside iff E > 0 or (E == 0 and top-left).  Fold the tie rule and a -1 into the
+                    // constant so that inside <=> (E0|E1|E2) >= 0; saturate at +-2^30 (the value varies
+                    // by < 2^30 over an 8x8 block, so the sign of every pixel survives).
+                    const int A0 = sy1 - sy2, B0 = sx2 - sx1;
+                    const int A1 = sy2 - sy0, B1 = sx0 - sx2;
+                    const int A2 = sy0 - sy1, B2 = sx1 - sx0;
+                    const int tl0 = (A0 > 0 || (A0 == 0 && B0 > 0)) ? 1 : 0;
+                    const int tl1 = (A1 > 0 || (A1 == 0 && B1 > 0)) ? 1 : 0;
+                    const int tl2 = (A2 > 0 || (A2 == 0 && B2 > 0)) ? 1 : 0;
+                    const long long E0 = (long long)A0 * (cx - sx1) + (long long)B0 * (cy - sy1);
+                    const long long E1 = (long long)A1 * (cx - sx2) + (long long)B1 * (cy - sy2);
+                    const long long E2 = (long long)A2 * (cx - sx0) + (long long)B2 * (cy - sy0);
+                    C0 = sat30(E0 + tl0 - 1);
+                    C1 = sat30(E1 + tl1 - 1);
+                    C2 = sat30(E2 + tl2 - 1);
+                    // edges shorter than 2048 px: A, B fit int16 -> one v_dot2c_i32_i16 per edge and pixel
+                    const int amax = max(max(abs(A0), abs(B0)), max(max(abs(A1), abs(B1)), max(abs(A2), abs(B2))));
+                    small = amax < 32768;
+                    AB0 = (A0 & 0xffff) | (B0 << 16);
+                    AB1 = (A1 & 0xffff) | (B1 << 16);
+                    AB2 = (A2 & 0xffff) | (B2 << 16);
+                    // z/w test plane anchored at the block origin (depth_plane() in the oracle)
+                    const double d1 = (double)q2.y - (double)q2.x, d2 = (double)q2.z - (double)q2.x;
+                    const double inv = __hiloint2double(q3.y, q3.x);
+                    zwc = (float)((double)q2.x + ((double)E1 * d1 + (double)E2 * d2) * inv);
+                    gx = (float)((((double)A1 * d1 + (double)A2 * d2) * 16.0) * inv);
+                    gy = (float)((((double)B1 * d1 + (double)B2 * d2) * 16.0) * inv);
                 }
             }
         }
-        unsigned long long mask = __ballot(hit);
+        if (P.debug & 4) hit = false;
+        // Publish this chunk's per-triangle constants in LDS; every pixel lane then reads triangle j with
+        // three broadcast ds_read_b128 (measured: 10 v_readlane cost ~57 cycles per triangle on gfx950,
+        // the LDS broadcast hides completely behind the VALU work).  Same-wave DS ops execute in order,
+        // so no barrier is needed.
+        sd[wave][0][lane] = make_int4(AB0, AB1, AB2, C0);
+        sd[wave][1][lane] = make_int4(C1, C2, __float_as_int(zwc), __float_as_int(gx));
+        sd[wave][2][lane] = make_int4(__float_as_int(gy), t, 0, 0);
+        unsigned long long mask = __ballot(hit && small);
         while (mask) {
             const int j = __builtin_ctzll(mask);
             mask &= mask - 1;
-            const int e0 = rli(C0, j) + __mul24(rli(A0, j), dx16) + __mul24(rli(B0, j), dy16);
-            const int e1 = rli(C1, j) + __mul24(rli(A1, j), dx16) + __mul24(rli(B1, j), dy16);
-            const int e2 = rli(C2, j) + __mul24(rli(A2, j), dx16) + __mul24(rli(B2, j), dy16);
-            const bool inside = in_img && ((e0 | e1 | e2) >= 0);
-            if (__ballot(inside)) {
-                const float4 q0 = make_float4(rl(p0.x, j), rl(p0.y, j), rl(p0.z, j), rl(p0.w, j));
-                const float4 q1 = make_float4(rl(p1.x, j), rl(p1.y, j), rl(p1.z, j), rl(p1.w, j));
-                const float4 q2 = make_float4(rl(p2.x, j), rl(p2.y, j), rl(p2.z, j), rl(p2.w, j));
-                const int tj = rli(t, j);
-                if (inside) {
-                    const Frag fr = shade_frag(q0, q1, q2, fx, fy);
-                    if (fr.valid) {
-                        const unsigned long long key = ((unsigned long long)f2ord(fr.zw) << 32) | (unsigned)tj;
-                        if (key < best) {
-                            best = key;
-                            bb0 = fr.b0; bb1 = fr.b1; bzw = fr.zw; biw = fr.iw;
-                        }
-                    }
-                }
-            }
+            const int4 x = sd[wave][0][j], y = sd[wave][1][j], z = sd[wave][2][j];
+            const int e0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, x.x), dxy, x.w, false);
+            const int e1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, x.y), dxy, y.x, false);
+            const int e2 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, x.z), dxy, y.y, false);
+            const float zt = __fmaf_rn(__int_as_float(y.w), fdx, __fmaf_rn(__int_as_float(z.x), fdy, __int_as_float(y.z)));
+            const bool inside = ((e0 | e1 | e2) >= 0) && (zt >= -1.0f && zt <= 1.0f);
+            const unsigned long long key = ((unsigned long long)f2ord(zt) << 32) | (unsigned)z.y;
+            if (inside && key < best) best = key;
+        }
+        // rare: triangles with an edge longer than 2048 px -- exact 64-bit edge functions per pixel
+        unsigned long long mbig = __ballot(hit && !small);
+        while (mbig) {
+            const int j = __builtin_ctzll(mbig);
+            mbig &= mbig - 1;
+            const int tj = rli(t, j);
+            const int4 q0 = REC[tj].q0, q1 = REC[tj].q1;
+            const int sx0 = q0.x, sy0 = q0.y, sx1 = q0.z, sy1 = q0.w, sx2 = q1.x, sy2 = q1.y;
+            const int A0 = sy1 - sy2, B0 = sx2 - sx1, A1 = sy2 - sy0, B1 = sx0 - sx2, A2 = sy0 - sy1, B2 = sx1 - sx0;
+            const int pcx = 16 * px + 8, pcy = 16 * py + 8;
+            const long long E0 = (long long)A0 * (pcx - sx1) + (long long)B0 * (pcy - sy1) + ((A0 > 0 || (A0 == 0 && B0 > 0)) ? 0 : -1);
+            const long long E1 = (long long)A1 * (pcx - sx2) + (long long)B1 * (pcy - sy2) + ((A1 > 0 || (A1 == 0 && B1 > 0)) ? 0 : -1);
+            const long long E2 = (long long)A2 * (pcx - sx0) + (long long)B2 * (pcy - sy0) + ((A2 > 0 || (A2 == 0 && B2 > 0)) ? 0 : -1);
+            const float zt = __fmaf_rn(rl(gx, j), fdx, __fmaf_rn(rl(gy, j), fdy, rl(zwc, j)));
+            const bool inside = ((E0 | E1 | E2) >= 0) && (zt >= -1.0f && zt <= 1.0f);
+            const unsigned long long key = ((unsigned long long)f2ord(zt) << 32) | (unsigned)tj;
+            if (inside && key < best) best = key;
         }
     }
 
+    if ((P.debug & 2) && best != 12345ull) return;  // ablation: no stores
     if (!in_img) return;
     const size_t pidx = ((size_t)b * H + py) * W + px;
     float4 o_rast = make_float4(0.f, 0.f, 0.f, 0.f), o_db = o_rast, o_td = o_rast;
     float n0 = 0.f, n1 = 0.f, n2 = 0.f, tu = 0.f, tv = 0.f;
     if (best != ~0ull) {
         const int t = (int)(unsigned)best;
-        float4 p0, p1, p2;
-        load_tri(P.pos, P.tri, b, P.V, t, p0, p1, p2);
-        o_rast = make_float4(bb0, bb1, bzw, (float)(t + 1));
-        const float dfxdx = xs * biw, dfydy = ys * biw;
+        const TriRecord* rp = REC + t;
+        const int4 q3 = rp->q3, q4 = rp->q4;
+        const int i0 = q3.z, i1 = q3.w, i2 = q4.x;
+        const float4* PV = reinterpret_cast<const float4*>(P.pos) + (size_t)b * P.V;
+        const float4 p0 = PV[i0], p1 = PV[i1], p2 = PV[i2];
+        const float xs = __fdiv_rn(2.0f, (float)W), xo = __fdiv_rn(1.0f, (float)W) - 1.0f;
+        const float ys = __fdiv_rn(2.0f, (float)H), yo = __fdiv_rn(1.0f, (float)H) - 1.0f;
+        const float fx = __fmaf_rn(xs, (float)px, xo), fy = __fmaf_rn(ys, (float)py, yo);
+        const Frag fr = shade_frag(p0, p1, p2, fx, fy);
+        o_rast = make_float4(fr.b0, fr.b1, fr.zw, (float)(t + 1));
+        const float dfxdx = xs * fr.iw, dfydy = ys * fr.iw;
         const float da0dx = __fmaf_rn(p2.y, p1.w, -(p1.y * p2.w));
         const float da0dy = __fmaf_rn(p1.x, p2.w, -(p2.x * p1.w));
         const float da1dx = __fmaf_rn(p0.y, p2.w, -(p2.y * p0.w));
@@ -313,22 +433,20 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterParams P) {
         const float da2dy = __fmaf_rn(p0.x, p1.w, -(p1.x * p0.w));
         const float datdx = (da0dx + da1dx) + da2dx;
         const float datdy = (da0dy + da1dy) + da2dy;
-        o_db.x = dfxdx * __fmaf_rn(bb0, datdx, -da0dx);
-        o_db.y = dfydy * __fmaf_rn(bb0, datdy, -da0dy);
-        o_db.z = dfxdx * __fmaf_rn(bb1, datdx, -da1dx);
-        o_db.w = dfydy * __fmaf_rn(bb1, datdy, -da1dy);
+        o_db.x = dfxdx * __fmaf_rn(fr.b0, datdx, -da0dx);
+        o_db.y = dfydy * __fmaf_rn(fr.b0, datdy, -da0dy);
+        o_db.z = dfxdx * __fmaf_rn(fr.b1, datdx, -da1dx);
+        o_db.w = dfydy * __fmaf_rn(fr.b1, datdy, -da1dy);
         if constexpr (INTERP) {
-            const float b2 = (1.0f - bb0) - bb1;
-            const int i0 = P.tri[3 * t], i1 = P.tri[3 * t + 1], i2 = P.tri[3 * t + 2];
+            const float b2 = (1.0f - fr.b0) - fr.b1;
             const float* N = P.vnormal + (size_t)b * P.V * 3;
-            n0 = __fmaf_rn(bb0, N[3 * i0 + 0], __fmaf_rn(bb1, N[3 * i1 + 0], b2 * N[3 * i2 + 0]));
-            n1 = __fmaf_rn(bb0, N[3 * i0 + 1], __fmaf_rn(bb1, N[3 * i1 + 1], b2 * N[3 * i2 + 1]));
-            n2 = __fmaf_rn(bb0, N[3 * i0 + 2], __fmaf_rn(bb1, N[3 * i1 + 2], b2 * N[3 * i2 + 2]));
-            const int j0 = P.tri_uv[3 * t], j1 = P.tri_uv[3 * t + 1], j2 = P.tri_uv[3 * t + 2];
+            n0 = __fmaf_rn(fr.b0, N[3 * i0 + 0], __fmaf_rn(fr.b1, N[3 * i1 + 0], b2 * N[3 * i2 + 0]));
+            n1 = __fmaf_rn(fr.b0, N[3 * i0 + 1], __fmaf_rn(fr.b1, N[3 * i1 + 1], b2 * N[3 * i2 + 1]));
+            n2 = __fmaf_rn(fr.b0, N[3 * i0 + 2], __fmaf_rn(fr.b1, N[3 * i1 + 2], b2 * N[3 * i2 + 2]));
             const float2* UV = reinterpret_cast<const float2*>(P.uv);
-            const float2 u0 = UV[j0], u1 = UV[j1], u2 = UV[j2];
-            tu = __fmaf_rn(bb0, u0.x, __fmaf_rn(bb1, u1.x, b2 * u2.x));
-            tv = __fmaf_rn(bb0, u0.y, __fmaf_rn(bb1, u1.y, b2 * u2.y));
+            const float2 u0 = UV[q4.y], u1 = UV[q4.z], u2 = UV[q4.w];
+            tu = __fmaf_rn(fr.b0, u0.x, __fmaf_rn(fr.b1, u1.x, b2 * u2.x));
+            tv = __fmaf_rn(fr.b0, u0.y, __fmaf_rn(fr.b1, u1.y, b2 * u2.y));
             const float eu0 = u0.x - u2.x, eu1 = u1.x - u2.x, ev0 = u0.y - u2.y, ev1 = u1.y - u2.y;
             o_td.x = __fmaf_rn(o_db.x, eu0, o_db.z * eu1);
             o_td.y = __fmaf_rn(o_db.y, eu0, o_db.w * eu1);
@@ -346,19 +464,22 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterParams P) {
     }
 }
 
+int g_debug_flags = 0;
+
 struct WsLayout {
-    size_t hdr, counts, cursors, offsets, trange, list, total;
+    size_t hdr, counts, cursors, offsets, trange, records, list, total;
 };
 
-WsLayout ws_layout(int B, int F, int ntile, size_t cap) {
+WsLayout ws_layout(int B, int F, int nbin, size_t cap) {
     WsLayout l;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t o = 0;
     l.hdr = o; o = al(o + sizeof(BinHeader));
-    l.counts = o; o = al(o + sizeof(unsigned) * (size_t)B * ntile);
-    l.cursors = o; o = al(o + sizeof(unsigned) * (size_t)B * ntile);
-    l.offsets = o; o = al(o + sizeof(unsigned) * (size_t)B * ntile);
+    l.counts = o; o = al(o + sizeof(unsigned) * (size_t)B * nbin);
+    l.cursors = o; o = al(o + sizeof(unsigned) * (size_t)B * nbin);
+    l.offsets = o; o = al(o + sizeof(unsigned) * (size_t)B * nbin);
     l.trange = o; o = al(o + sizeof(unsigned) * (size_t)B * F);
+    l.records = o; o = al(o + sizeof(TriRecord) * (size_t)B * F);
     l.list = o; o = al(o + sizeof(unsigned) * (cap ? cap : 1));
     l.total = o;
     return l;
@@ -367,18 +488,19 @@ WsLayout ws_layout(int B, int F, int ntile, size_t cap) {
 int check_dims(int B, int V, int F, int H, int W) {
     if (B <= 0 || V <= 0 || F <= 0 || H <= 0 || W <= 0) return VHAP_E_BADDIM;
     if (H > 4096 || W > 4096 || F >= (1 << 24)) return VHAP_E_BADDIM;
-    if ((long long)B * F >= (1ll << 31)) return VHAP_E_BADDIM;
+    if ((long long)B * F >= (1ll << 31) || B > 65535) return VHAP_E_BADDIM;
     return VHAP_OK;
 }
 
 template <bool INTERP>
 int launch_raster(RasterParams P, void* ws, size_t ws_bytes, size_t cap, hipStream_t st) {
     const int B = P.B, F = P.F;
-    P.ntx = (P.W + TILE_W - 1) / TILE_W;
-    P.nty = (P.H + TILE_H - 1) / TILE_H;
-    const int ntile = P.ntx * P.nty;
-    if ((long long)B * ntile >= (1ll << 31) || cap > 0xfffffff0u) return VHAP_E_BADDIM;
-    const WsLayout l = ws_layout(B, F, ntile, cap);
+    P.nbx = (P.W + BLK - 1) / BLK;
+    P.nby = (P.H + BLK - 1) / BLK;
+    P.nwx = (P.nbx + WG_BLOCKS - 1) / WG_BLOCKS;
+    const int nbin = P.nbx * P.nby;
+    if ((long long)B * nbin >= (1ll << 31) || cap > 0xfffffff0u) return VHAP_E_BADDIM;
+    const WsLayout l = ws_layout(B, F, nbin, cap);
     if (!ws) return VHAP_E_NULLPTR;
     if (ws_bytes < l.total) return VHAP_E_WORKSPACE;
     char* w = static_cast<char*>(ws);
@@ -388,31 +510,45 @@ int launch_raster(RasterParams P, void* ws, size_t ws_bytes, size_t cap, hipStre
     unsigned* offsets = reinterpret_cast<unsigned*>(w + l.offsets);
     unsigned* trange = reinterpret_cast<unsigned*>(w + l.trange);
     unsigned* list = reinterpret_cast<unsigned*>(w + l.list);
+    TriRecord* records = reinterpret_cast<TriRecord*>(w + l.records);
     // header, counts and cursors are contiguous: one memset node
     if (hipMemsetAsync(w + l.hdr, 0, l.offsets - l.hdr, st) != hipSuccess) return VHAP_E_HIP;
-    const int nbt = vhap_cdiv((long long)B * F, 256);
-    bin_count_kernel<<<nbt, 256, 0, st>>>(P.pos, P.tri, B, P.V, F, P.H, P.W, P.ntx, P.nty, counts, trange);
+    const dim3 gbin(vhap_cdiv(F, BIN_THREADS), B);
+    const bool use_lds = nbin <= LDS_BIN_LIMIT;
+    const size_t fill_lds = use_lds ? 2 * sizeof(unsigned) * nbin : 0;
+    if (fill_lds > 65536) {  // raise the dynamic-LDS cap (160 KiB per CU on gfx950)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(bin_fill_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)fill_lds) != hipSuccess)
+            return VHAP_E_HIP;
+    }
+    bin_count_kernel<<<gbin, BIN_THREADS, use_lds ? sizeof(unsigned) * nbin : 0, st>>>(P.pos, P.tri, P.tri_uv, P.V, F, P.H, P.W, P.nbx,
+                                                                                    P.nby, counts, trange, records);
     VHAP_LAUNCH_CHECK();
-    bin_scan_kernel<<<vhap_cdiv((long long)B * ntile, 256), 256, 0, st>>>(counts, offsets, B * ntile, hdr);
+    bin_scan_kernel<<<vhap_cdiv((long long)B * nbin, 256), 256, 0, st>>>(counts, offsets, B * nbin, hdr);
     VHAP_LAUNCH_CHECK();
-    bin_fill_kernel<<<nbt, 256, 0, st>>>(trange, B, F, P.ntx, P.nty, offsets, cursors, list, hdr, (unsigned)cap);
+    bin_fill_kernel<<<gbin, BIN_THREADS, fill_lds, st>>>(trange, F, P.nbx, P.nby, offsets, cursors, list, hdr, (unsigned)cap);
     VHAP_LAUNCH_CHECK();
     P.counts = counts;
     P.offsets = offsets;
     P.list = list;
+    P.trange = trange;
+    P.records = records;
     P.hdr = hdr;
     P.capacity = (unsigned)cap;
-    raster_kernel<INTERP><<<B * ntile, 256, 0, st>>>(P);
+    P.debug = g_debug_flags;
+    raster_kernel<INTERP><<<B * P.nwx * P.nby, 256, 0, st>>>(P);
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;
 }
 
 }  // namespace
 
+extern "C" void vhap_debug_set_flags(int flags) { g_debug_flags = flags; }
+
 extern "C" size_t vhap_raster_workspace_bytes(int B, int F, int H, int W, size_t pair_capacity) {
     if (check_dims(B, 1, F, H, W) != VHAP_OK) return 0;
-    const int ntile = ((W + TILE_W - 1) / TILE_W) * ((H + TILE_H - 1) / TILE_H);
-    return ws_layout(B, F, ntile, pair_capacity).total;
+    const int nbin = ((W + BLK - 1) / BLK) * ((H + BLK - 1) / BLK);
+    return ws_layout(B, F, nbin, pair_capacity).total;
 }
 
 extern "C" int vhap_raster_fwd(const float* pos, const int32_t* tri, int B, int V, int F, int H, int W, float* rast,

@@ -48,11 +48,14 @@ class RasterizeHipContext:
     """Stands in for dr.RasterizeCudaContext().  Holds only sizing policy (no device state, so it is
     safe to share between threads -- the reference's log_media thread may render concurrently)."""
 
-    def __init__(self, pairs_per_triangle=4):
+    def __init__(self, pairs_per_triangle=8, pairs_per_block=8):
         self.pairs_per_triangle = pairs_per_triangle
+        self.pairs_per_block = pairs_per_block
 
     def workspace(self, B, F, H, W, device):
-        cap = int(B) * int(F) * self.pairs_per_triangle
+        # capacity of the (triangle, 8x8-block) lists; exceeding it is still correct (brute-force path)
+        nblk = ((int(H) + 7) // 8) * ((int(W) + 7) // 8)
+        cap = int(B) * (int(F) * self.pairs_per_triangle + nblk * self.pairs_per_block)
         nbytes = _lib.lib().vhap_raster_workspace_bytes(B, F, H, W, cap)
         if nbytes == 0:
             raise ValueError(f"rasterize: dimensions out of range (B={B}, F={F}, H={H}, W={W})")
