@@ -128,9 +128,9 @@ int vhap_antialias_fwd(const float* color, const float* rast, const float* pos,
                        const int32_t* tri, const int32_t* opp, int B, int H, int W, int C, int V,
                        int F, float* out, int32_t* work, vhap_stream_t stream);
 int vhap_antialias_bwd(const float* color, const float* rast, const float* pos,
-                       const int32_t* tri, const float* d_out, const int32_t* work, int B, int H,
-                       int W, int C, int V, int F, float* d_color, float* d_pos,
-                       vhap_stream_t stream);
+                       const int32_t* tri, const int32_t* opp, const float* d_out,
+                       const int32_t* work, int B, int H, int W, int C, int V, int F,
+                       float* d_color, float* d_pos, vhap_stream_t stream);
 
 #ifdef __cplusplus
 }

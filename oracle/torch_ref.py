@@ -332,12 +332,18 @@ def texture(tex, uv, uv_da=None, filter_mode="linear-mipmap-linear", mips=None):
     A = dsdx * dsdx + dtdx * dtdx
     Bq = dsdy * dsdy + dtdy * dtdy
     Cq = dsdx * dsdy + dtdx * dtdy
-    l2b = 0.5 * (A + Bq)
-    l2n = 0.25 * (A - Bq) * (A - Bq) + Cq * Cq
-    len_major_sqr = l2b + torch.sqrt(l2n)
     lmax = len(mips) - 1
-    level = 0.5 * torch.log2(len_major_sqr.clamp(min=1e-30))
-    level = level.clamp(0, float(lmax))
+    with torch.no_grad():
+        lam_raw = 0.5 * (A + Bq) + torch.sqrt(0.25 * (A - Bq) * (A - Bq) + Cq * Cq)
+        lev_raw = 0.5 * torch.log2(lam_raw.clamp(min=1e-30))
+        inside = (lev_raw > 0) & (lev_raw < lmax)
+    # differentiable only where the level is strictly inside (0, L); safe operands elsewhere
+    one = torch.ones_like(A)
+    As, Bs, Cs = torch.where(inside, A, one), torch.where(inside, Bq, one), torch.where(inside, Cq, one)
+    l2b = 0.5 * (As + Bs)
+    l2n = 0.25 * (As - Bs) * (As - Bs) + Cs * Cs
+    len_major_sqr = l2b + torch.sqrt(l2n)
+    level = torch.where(inside, 0.5 * torch.log2(len_major_sqr), lev_raw.clamp(0, float(lmax)))
     l0 = torch.floor(level).clamp(max=max(lmax - 1, 0)).long()
     f = (level - l0.to(level.dtype))[..., None]
     out = None

@@ -1,0 +1,175 @@
+"""GPU parity of the differentiable raster ops (forward values and gradients) vs the torch oracle.
+
+Tolerances (float32 kernels vs the float64 torch oracle on fixed visibility):
+  - (u, v, z/w) and everything interpolated from them: <= 5e-4 abs.  The perspective barycentric
+    formula cancels heavily for pixel-sized triangles; the measured fp32-vs-fp64 spread of the
+    formula itself on these scenes is 1.1e-4 (the bit-exact check against the fp32 C oracle is in
+    test_raster_gpu.py).
+  - texture / antialias on identical inputs: <= 2e-5 abs.
+  - gradients: relative to the gradient's max-norm, <= 1e-2 where they pass through the raster
+    formula, <= 2e-3 otherwise (fp32 atomics in arbitrary order)."""
+RAST_ATOL = 5e-4
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import torch_ref as R
+from tests.scenes import head_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def scene(flame_model):
+    model, topo = flame_model
+    B, H, W = 2, 160, 128
+    sc = head_scene(model, B, H, W, seed=21, dtype=torch.float64)
+    pos = sc["clip"]
+    tri = torch.from_numpy(topo.faces.astype(np.int64))
+    rast_np, db_np = oracle.rasterize(pos.float().numpy(), topo.faces.astype(np.int32), (H, W))
+    tid = torch.from_numpy(rast_np[..., 3].astype(np.int64) - 1)
+    return dict(B=B, H=H, W=W, pos=pos, tri=tri, tid=tid, topo=topo, sc=sc, model=model)
+
+
+def test_rasterize_backward(scene):
+    from vhap_amd import ops
+    B, H, W = scene["B"], scene["H"], scene["W"]
+    g = torch.Generator().manual_seed(0)
+    w_r = torch.randn(B, H, W, 2, generator=g, dtype=torch.float64)
+    w_d = torch.randn(B, H, W, 4, generator=g, dtype=torch.float64) * 0.1
+    pos_o = scene["pos"].clone().requires_grad_()
+    rast_o, db_o = R.rast_from_ids(pos_o, scene["tri"], scene["tid"], (H, W))
+    ((rast_o[..., :2] * w_r).sum() + (db_o * w_d).sum()).backward()
+    pos_g = scene["pos"].float().cuda().requires_grad_()
+    rast, db = ops.rasterize(ops.RasterizeHipContext(), pos_g, scene["tri"].int().cuda(), (H, W))
+    assert np.array_equal(rast[..., 3].detach().cpu().numpy(), (scene["tid"] + 1).float().numpy())
+    assert (rast[..., :3].detach().cpu().double() - rast_o[..., :3].detach()).abs().max() < RAST_ATOL
+    assert _rel(db.detach(), db_o.detach()) < 1e-3
+    ((rast[..., :2] * w_r.float().cuda()).sum() + (db * w_d.float().cuda()).sum()).backward()
+    assert _rel(pos_g.grad, pos_o.grad) < 1e-2
+
+
+def test_interpolate_forward_backward(scene):
+    from vhap_amd import ops
+    B, H, W = scene["B"], scene["H"], scene["W"]
+    g = torch.Generator().manual_seed(1)
+    V = scene["pos"].shape[1]
+    for AB, A, use_db in ((B, 3, False), (1, 2, True), (B, 5, True)):
+        attr = torch.randn(AB, V, A, generator=g, dtype=torch.float64)
+        w_o = torch.randn(B, H, W, A, generator=g, dtype=torch.float64)
+        w_da = torch.randn(B, H, W, 2 * A, generator=g, dtype=torch.float64)
+        pos_o = scene["pos"].clone().requires_grad_()
+        attr_o = attr.clone().requires_grad_()
+        rast_o, db_o = R.rast_from_ids(pos_o, scene["tri"], scene["tid"], (H, W))
+        out_o, da_o = R.interpolate(attr_o, rast_o, scene["tri"], db_o if use_db else None, "all" if use_db else None)
+        loss = (out_o * w_o).sum() + ((da_o * w_da).sum() if use_db else 0)
+        loss.backward()
+
+        pos_g = scene["pos"].float().cuda().requires_grad_()
+        attr_g = attr.float().cuda().requires_grad_()
+        tri_g = scene["tri"].int().cuda()
+        rast, db = ops.rasterize(ops.RasterizeHipContext(), pos_g, tri_g, (H, W))
+        out, da = ops.interpolate(attr_g, rast, tri_g, rast_db=db if use_db else None, diff_attrs="all" if use_db else None)
+        assert (out.detach().cpu().double() - out_o.detach()).abs().max() < RAST_ATOL * 5   # |attr| up to ~5
+        loss = (out * w_o.float().cuda()).sum()
+        if use_db:
+            assert _rel(da.detach(), da_o.detach()) < 1e-3
+            loss = loss + (da * w_da.float().cuda()).sum()
+        loss.backward()
+        assert _rel(attr_g.grad, attr_o.grad) < 2e-3
+        assert _rel(pos_g.grad, pos_o.grad) < 1e-2
+
+
+@pytest.mark.parametrize("TB,T,C", [(1, 64, 3), (2, 32, 4), (1, 256, 1)])
+def test_texture_forward_backward(TB, T, C):
+    from vhap_amd import ops
+    g = torch.Generator().manual_seed(2)
+    B, H, W = 2, 48, 40
+    tex = torch.rand(TB, T, T, C, generator=g, dtype=torch.float64)
+    uv = torch.rand(B, H, W, 2, generator=g, dtype=torch.float64) * 1.4 - 0.2          # exercises wrap
+    scale = torch.exp(torch.rand(B, H, W, 1, generator=g, dtype=torch.float64) * 6 - 7)  # levels from 0 to coarse
+    da = torch.randn(B, H, W, 4, generator=g, dtype=torch.float64) * scale
+    da[0, 0, :4] = 0                                                                # background-like pixels
+    w = torch.randn(B, H, W, C, generator=g, dtype=torch.float64)
+    t_o, uv_o, da_o = tex.clone().requires_grad_(), uv.clone().requires_grad_(), da.clone().requires_grad_()
+    out_o = R.texture(t_o, uv_o, da_o)
+    (out_o * w).sum().backward()
+    t_g, uv_g, da_g = (x.float().cuda().requires_grad_() for x in (tex, uv, da))
+    out = ops.texture(t_g, uv_g, da_g, filter_mode="linear-mipmap-linear")
+    assert (out.detach().cpu().double() - out_o.detach()).abs().max() < 2e-5
+    (out * w.float().cuda()).sum().backward()
+    assert _rel(t_g.grad, t_o.grad) < 1e-3
+    assert _rel(uv_g.grad, uv_o.grad) < 2e-3
+    assert _rel(da_g.grad, da_o.grad) < 2e-3
+    # plain bilinear
+    out_l = ops.texture(t_g, uv_g, None, filter_mode="linear")
+    assert (out_l.detach().cpu().double() - R.texture(tex, uv, None, filter_mode="linear")).abs().max() < 2e-5
+
+
+def test_texture_constant_and_box_known_answers():
+    from vhap_amd import ops
+    T = 64
+    tex = torch.full((1, T, T, 3), 0.37, device="cuda")
+    uv = torch.rand(1, 8, 8, 2, device="cuda")
+    for s in (1e-4, 1e-2, 0.1, 1.0):
+        da = torch.full((1, 8, 8, 4), s, device="cuda")
+        assert torch.allclose(ops.texture(tex, uv, da), torch.full((1, 8, 8, 3), 0.37, device="cuda"), atol=1e-6)
+    # checkerboard: level 1 is exactly the box-filtered texture (0.5 everywhere)
+    yy, xx = torch.meshgrid(torch.arange(T), torch.arange(T), indexing="ij")
+    cb = ((xx + yy) % 2).float()[None, :, :, None].cuda().contiguous()
+    da = torch.zeros(1, 8, 8, 4, device="cuda")
+    da[..., 0] = 2.0 / T                      # lambda = 4 -> level exactly 1
+    da[..., 3] = 2.0 / T
+    assert torch.allclose(ops.texture(cb, uv, da), torch.full((1, 8, 8, 1), 0.5, device="cuda"), atol=1e-6)
+
+
+def test_antialias_forward_backward(scene):
+    from vhap_amd import ops
+    B, H, W = scene["B"], scene["H"], scene["W"]
+    topo = scene["topo"]
+    g = torch.Generator().manual_seed(3)
+    color = torch.rand(B, H, W, 4, generator=g, dtype=torch.float64)
+    w = torch.randn(B, H, W, 4, generator=g, dtype=torch.float64)
+    opp = torch.from_numpy(topo.opp.astype(np.int64))
+    pos_o = scene["pos"].clone().requires_grad_()
+    col_o = color.clone().requires_grad_()
+    rast_o, _ = R.rast_from_ids(pos_o.detach(), scene["tri"], scene["tid"], (H, W))
+    out_o = R.antialias(col_o, rast_o, pos_o, scene["tri"], opp)
+    (out_o * w).sum().backward()
+    n_changed = int(((out_o.detach() - color).abs().sum(-1) > 0).sum())
+    assert n_changed > 200                                               # silhouettes were found
+
+    pos_g = scene["pos"].float().cuda().requires_grad_()
+    col_g = color.float().cuda().requires_grad_()
+    tri_g = scene["tri"].int().cuda()
+    rast_g = rast_o.float().cuda()
+    out = ops.antialias(col_g, rast_g, pos_g, tri_g, opp=opp.int().cuda())
+    diff = (out.detach().cpu().double() - out_o.detach()).abs()
+    # fp32-vs-fp64 decisions can differ on a handful of knife-edge pairs; require near-total agreement
+    assert float((diff.amax(-1) > 1e-4).float().mean()) < 2e-4
+    (out * w.float().cuda()).sum().backward()
+    assert _rel(col_g.grad, col_o.grad) < 2e-2
+    gp, go = pos_g.grad.double().cpu(), pos_o.grad
+    assert float((gp - go).norm() / go.norm()) < 5e-2
+
+
+def test_antialias_vertical_edge_known_answer():
+    """A vertical silhouette at x = k + 0.25 px blends the two pixels with weights 0.25 / 0.75."""
+    from vhap_amd import ops
+    H = W = 16
+    xe = (8.25 / W) * 2 - 1                                   # edge at pixel x = 8.25
+    pos = torch.tensor([[[-1.0, -1.0, 0, 1], [xe, -1.0, 0, 1], [xe, 1.0, 0, 1], [-1.0, 1.0, 0, 1]]], device="cuda")
+    tri = torch.tensor([[0, 1, 2], [0, 2, 3]], dtype=torch.int32, device="cuda")
+    rast, _ = ops.rasterize(ops.RasterizeHipContext(), pos, tri, (H, W))
+    fg = (rast[..., 3:] > 0).float()
+    color = fg.expand(-1, -1, -1, 3).contiguous()               # white mesh on black
+    out = ops.antialias(color, rast, pos, tri)
+    row = out[0, 8, :, 0].cpu()
+    assert torch.allclose(row[:8], torch.ones(8)) and torch.allclose(row[9:], torch.zeros(7))
+    assert abs(float(row[8]) - 0.25) < 1e-5                     # pixel 8 (centre 8.5) is 25 % covered

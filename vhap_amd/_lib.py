@@ -21,6 +21,18 @@ SIGNATURES = {
     "vhap_raster_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_sz]),
     "vhap_raster_fwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_sz, c_sz, c_fp]),
     "vhap_raster_interp_fwd": (c_i, [c_fp] * 5 + [c_i] * 6 + [c_fp] * 5 + [c_fp, c_sz, c_sz, c_fp]),
+    "vhap_raster_bwd": (c_i, [c_fp] * 5 + [c_i] * 5 + [c_fp, c_fp]),
+    "vhap_interp_fwd": (c_i, [c_fp, c_i, c_fp, c_fp, c_fp] + [c_i] * 6 + [c_fp, c_fp, c_fp]),
+    "vhap_interp_bwd": (c_i, [c_fp, c_i, c_fp, c_fp, c_fp, c_fp, c_fp] + [c_i] * 6 + [c_fp] * 4),
+    "vhap_texture_num_levels": (c_i, [c_i, c_i]),
+    "vhap_texture_mip_floats": (c_sz, [c_i] * 4),
+    "vhap_texture_mip_build": (c_i, [c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp]),
+    "vhap_texture_fwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp]),
+    "vhap_texture_bwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_i] + [c_fp] * 5),
+    "vhap_texture_mip_fold": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp]),
+    "vhap_antialias_work_ints": (c_sz, [c_i] * 3),
+    "vhap_antialias_fwd": (c_i, [c_fp] * 5 + [c_i] * 6 + [c_fp, c_fp, c_fp]),
+    "vhap_antialias_bwd": (c_i, [c_fp] * 7 + [c_i] * 6 + [c_fp, c_fp, c_fp]),
 }
 
 _lib = None

@@ -106,3 +106,215 @@ def raster_interp_fwd(ctx, pos, tri, vnormal, uv, tri_uv, resolution):
                                            _p(rast), _p(db), _p(normal), _p(texc), _p(texd), _p(ws), nbytes, cap, _stream())
     _lib.check(rc, "vhap_raster_interp_fwd")
     return rast, db, normal, texc, texd
+
+
+# ------------------------------------------------------------------------------------------------
+# autograd Functions (b2 shim): rasterize / interpolate / texture / antialias
+# ------------------------------------------------------------------------------------------------
+
+
+class _Rasterize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, glctx, pos, tri, resolution):
+        rast, db = raster_fwd(glctx, pos, tri, resolution, with_db=True)
+        ctx.save_for_backward(pos, tri, rast)
+        ctx.res = (int(resolution[0]), int(resolution[1]))
+        return rast, db
+
+    @staticmethod
+    def backward(ctx, d_rast, d_db):
+        pos, tri, rast = ctx.saved_tensors
+        H, W = ctx.res
+        B, V, _ = pos.shape
+        d_pos = torch.zeros_like(pos)
+        d_rast = _f32c(d_rast)
+        d_db = _f32c(d_db) if d_db is not None else None
+        rc = _lib.lib().vhap_raster_bwd(_p(pos), _p(tri), _p(rast), _p(d_rast), _p(d_db), B, V, tri.shape[0], H, W,
+                                        _p(d_pos), _stream())
+        _lib.check(rc, "vhap_raster_bwd")
+        return None, d_pos, None, None
+
+
+def rasterize(glctx, pos, tri, resolution, ranges=None, grad_db=True):
+    """dr.rasterize(glctx, pos, tri, resolution) -> (rast [B,H,W,4], rast_db [B,H,W,4]).
+    Differentiable w.r.t. pos through (u, v) and the pixel differentials, like nvdiffrast."""
+    if ranges is not None:
+        raise NotImplementedError("range mode is not used by the reference and not implemented")
+    _chk_cuda(pos, tri)
+    _check_raster_args(pos, tri, resolution)
+    pos, tri = _f32c(pos), _i32c(tri)
+    if pos.requires_grad and torch.is_grad_enabled():
+        return _Rasterize.apply(glctx, pos, tri, tuple(resolution))
+    return raster_fwd(glctx, pos, tri, resolution, with_db=True)
+
+
+class _Interpolate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, attr, rast, tri, rast_db):
+        AB, V, A = attr.shape
+        B, H, W, _ = rast.shape
+        out = torch.empty(B, H, W, A, dtype=torch.float32, device=rast.device)
+        out_da = torch.empty(B, H, W, 2 * A, dtype=torch.float32, device=rast.device) if rast_db is not None else None
+        rc = _lib.lib().vhap_interp_fwd(_p(attr), AB, _p(rast), _p(tri), _p(rast_db), B, H, W, V, tri.shape[0], A,
+                                        _p(out), _p(out_da), _stream())
+        _lib.check(rc, "vhap_interp_fwd")
+        ctx.save_for_backward(attr, rast, tri, rast_db)
+        ctx.has_da = rast_db is not None
+        if out_da is None:
+            out_da = torch.empty(0, device=rast.device)
+            ctx.mark_non_differentiable(out_da)
+        return out, out_da
+
+    @staticmethod
+    def backward(ctx, d_out, d_da):
+        attr, rast, tri, rast_db = ctx.saved_tensors
+        AB, V, A = attr.shape
+        B, H, W, _ = rast.shape
+        need_attr, need_rast, _, need_db = ctx.needs_input_grad
+        d_attr = torch.zeros_like(attr) if need_attr else None
+        d_rast = torch.empty_like(rast) if need_rast else None
+        d_db = torch.empty_like(rast_db) if (ctx.has_da and need_db) else None
+        d_out = _f32c(d_out)
+        d_da = _f32c(d_da) if (ctx.has_da and d_da is not None) else None
+        rc = _lib.lib().vhap_interp_bwd(_p(attr), AB, _p(rast), _p(tri), _p(rast_db), _p(d_out), _p(d_da), B, H, W, V,
+                                        tri.shape[0], A, _p(d_attr), _p(d_rast), _p(d_db), _stream())
+        _lib.check(rc, "vhap_interp_bwd")
+        return d_attr, d_rast, None, d_db
+
+
+def interpolate(attr, rast, tri, rast_db=None, diff_attrs=None):
+    """dr.interpolate(attr, rast, tri, rast_db=None, diff_attrs=None) -> (out, out_da).
+    attr [1|B,V,A]; diff_attrs must be None or 'all' (the only forms the reference uses)."""
+    _chk_cuda(attr, rast, tri, rast_db)
+    if attr.dim() != 3:
+        raise ValueError("attr must have shape [1|B, V, A]")
+    if diff_attrs not in (None, "all"):
+        raise NotImplementedError("diff_attrs must be None or 'all'")
+    attr, rast, tri = _f32c(attr), _f32c(rast), _i32c(tri)
+    if attr.shape[0] not in (1, rast.shape[0]):
+        raise ValueError("attr batch dimension must be 1 or match rast")
+    use_db = rast_db is not None and diff_attrs == "all"
+    db = _f32c(rast_db) if use_db else None
+    out, out_da = _Interpolate.apply(attr, rast, tri, db)
+    return out, (out_da if use_db else None)
+
+
+def build_mips(tex):
+    """Build the mip pyramid buffer (levels 1..L) of tex [TB,Ht,Wt,C]; no autograd."""
+    TB, Ht, Wt, C = tex.shape
+    n = _lib.lib().vhap_texture_mip_floats(TB, Ht, Wt, C)
+    mips = torch.empty(max(n, 1), dtype=torch.float32, device=tex.device)
+    rc = _lib.lib().vhap_texture_mip_build(_p(tex), TB, Ht, Wt, C, _p(mips), _stream())
+    _lib.check(rc, "vhap_texture_mip_build")
+    return mips
+
+
+class _Texture(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tex, uv, uv_da):
+        TB, Ht, Wt, C = tex.shape
+        B, H, W, _ = uv.shape
+        mips = build_mips(tex) if uv_da is not None else None
+        out = torch.empty(B, H, W, C, dtype=torch.float32, device=uv.device)
+        rc = _lib.lib().vhap_texture_fwd(_p(tex), _p(mips), TB, Ht, Wt, C, _p(uv), _p(uv_da), B, H, W, _p(out), _stream())
+        _lib.check(rc, "vhap_texture_fwd")
+        ctx.save_for_backward(tex, uv, uv_da, mips)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        tex, uv, uv_da, mips = ctx.saved_tensors
+        TB, Ht, Wt, C = tex.shape
+        B, H, W, _ = uv.shape
+        need_tex, need_uv, need_da = ctx.needs_input_grad
+        d_tex = torch.zeros_like(tex) if need_tex else None
+        d_mips = torch.zeros_like(mips) if (need_tex and mips is not None) else None
+        d_uv = torch.empty_like(uv) if need_uv else None
+        d_da = torch.empty_like(uv_da) if (need_da and uv_da is not None) else None
+        d_out = _f32c(d_out)
+        rc = _lib.lib().vhap_texture_bwd(_p(tex), _p(mips), TB, Ht, Wt, C, _p(uv), _p(uv_da), _p(d_out), B, H, W,
+                                         _p(d_tex), _p(d_mips), _p(d_uv), _p(d_da), _stream())
+        _lib.check(rc, "vhap_texture_bwd")
+        if d_mips is not None:
+            rc = _lib.lib().vhap_texture_mip_fold(_p(d_tex), _p(d_mips), TB, Ht, Wt, C, _stream())
+            _lib.check(rc, "vhap_texture_mip_fold")
+        return d_tex, d_uv, d_da
+
+
+def texture(tex, uv, uv_da=None, mip_level_bias=None, mip=None, filter_mode="auto", boundary_mode="wrap", max_mip_level=None):
+    """dr.texture(tex [1|B,Ht,Wt,C], uv [B,H,W,2], uv_da [B,H,W,4], filter_mode=...) -> [B,H,W,C].
+    Supported (= what the reference uses): boundary 'wrap'; 'linear-mipmap-linear' with uv_da, or 'linear'."""
+    _chk_cuda(tex, uv, uv_da)
+    if filter_mode == "auto":
+        filter_mode = "linear-mipmap-linear" if uv_da is not None else "linear"
+    if filter_mode not in ("linear", "linear-mipmap-linear"):
+        raise NotImplementedError(f"filter_mode {filter_mode!r} is not implemented")
+    if boundary_mode != "wrap" or mip_level_bias is not None or mip is not None or max_mip_level is not None:
+        raise NotImplementedError("only boundary_mode='wrap' with the full default mip chain is implemented")
+    if tex.dim() != 4 or tex.shape[-1] > 4:
+        raise ValueError("tex must have shape [1|B, Ht, Wt, C<=4]")
+    if tex.shape[0] not in (1, uv.shape[0]):
+        raise ValueError("tex batch dimension must be 1 or match uv")
+    tex, uv = _f32c(tex), _f32c(uv)
+    da = None
+    if filter_mode == "linear-mipmap-linear":
+        if uv_da is None:
+            raise ValueError("linear-mipmap-linear needs uv_da")
+        da = _f32c(uv_da)
+    return _Texture.apply(tex, uv, da)
+
+
+_OPP_CACHE = {}
+
+
+def opposite_table(tri):
+    """Static edge -> opposite-vertex table for `tri` (cached per tensor storage / content hash)."""
+    from .topology import build_opposite_table
+    key = (tri.data_ptr(), tuple(tri.shape), str(tri.device))
+    hit = _OPP_CACHE.get(key)
+    if hit is None:
+        opp = torch.from_numpy(build_opposite_table(tri.detach().cpu().numpy())).to(tri.device)
+        _OPP_CACHE.clear() if len(_OPP_CACHE) > 8 else None
+        _OPP_CACHE[key] = hit = (tri, opp)      # keep tri alive so data_ptr stays unique
+    return hit[1]
+
+
+class _Antialias(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, color, rast, pos, tri, opp):
+        B, H, W, C = color.shape
+        V, F = pos.shape[1], tri.shape[0]
+        out = torch.empty_like(color)
+        work = torch.empty(_lib.lib().vhap_antialias_work_ints(B, H, W), dtype=torch.int32, device=color.device)
+        rc = _lib.lib().vhap_antialias_fwd(_p(color), _p(rast), _p(pos), _p(tri), _p(opp), B, H, W, C, V, F, _p(out),
+                                           _p(work), _stream())
+        _lib.check(rc, "vhap_antialias_fwd")
+        ctx.save_for_backward(color, rast, pos, tri, opp, work)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        color, rast, pos, tri, opp, work = ctx.saved_tensors
+        B, H, W, C = color.shape
+        V, F = pos.shape[1], tri.shape[0]
+        need_color, _, need_pos, _, _ = ctx.needs_input_grad
+        d_out = _f32c(d_out)
+        d_color = torch.empty_like(color) if need_color else None
+        d_pos = torch.zeros_like(pos) if need_pos else None
+        rc = _lib.lib().vhap_antialias_bwd(_p(color), _p(rast), _p(pos), _p(tri), _p(opp), _p(d_out), _p(work), B, H, W, C,
+                                           V, F, _p(d_color), _p(d_pos), _stream())
+        _lib.check(rc, "vhap_antialias_bwd")
+        return d_color, None, d_pos, None, None
+
+
+def antialias(color, rast, pos, tri, topology_hash=None, pos_gradient_boost=1.0, opp=None):
+    """dr.antialias(color [B,H,W,C], rast, pos [B,V,4], tri) -> [B,H,W,C]."""
+    _chk_cuda(color, rast, pos, tri)
+    if pos_gradient_boost != 1.0:
+        raise NotImplementedError("pos_gradient_boost != 1 is not used by the reference")
+    if color.shape[-1] not in (1, 3, 4):
+        raise ValueError("antialias supports 1, 3 or 4 channels")
+    color, rast, pos, tri = _f32c(color), _f32c(rast), _f32c(pos), _i32c(tri)
+    if opp is None:
+        opp = opposite_table(tri)
+    return _Antialias.apply(color, rast, pos, tri, _i32c(opp))
