@@ -1,0 +1,103 @@
+"""Frame-sharded data parallelism for the photometric fit (new in this build: the reference is
+single-process, single-GPU -- SURVEY.md section 2 rows 16-17, section 8(e)).
+
+One process per GPU.  Every rank holds a replica of all parameters and optimiser state and works on
+a contiguous slice of the frame batch (monocular: frames; NeRSemble: views).  Per Adam step:
+  1. one scalar all-reduce for the batch-global photometric normaliser #(alpha > 0)
+     (tracker.py:439 divides by the count over the WHOLE batch), issued before backward;
+  2. ONE all-reduce (average) of a flat bucket holding every trained gradient -- tex_extra
+     (50.3 MB at T=2048) dominates, static_offset / shape / lights / focal / per-frame rows ride along.
+The per-rank energy is defined so that its mean over ranks equals the single-GPU energy (equal
+shards): batch means become local means, the photometric numerator is multiplied by world_size
+through the normaliser.  Replicas stay bit-identical because every rank applies the same averaged
+gradient with the same Adam state.  The colour disturbance draws its pools from the local shard only.
+Backend: 'nccl' (= RCCL over xGMI on ROCm) on GPUs, 'gloo' in the CPU tests.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+class FrameShardContext:
+    def __init__(self, group=None):
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world_size = dist.get_world_size(group)
+        self._flat = None
+
+    # ---- sharding ----
+    def shard_slice(self, n):
+        """Contiguous split of n frames; the remainder goes to the first ranks."""
+        base, rem = divmod(n, self.world_size)
+        start = self.rank * base + min(self.rank, rem)
+        return slice(start, start + base + (1 if self.rank < rem else 0))
+
+    def shard_sample(self, sample):
+        n = len(sample["timestep_index"])
+        if n % self.world_size:
+            raise ValueError(f"batch of {n} frames does not split evenly over {self.world_size} ranks")
+        sl = self.shard_slice(n)
+        out = {}
+        for k, v in sample.items():
+            if isinstance(v, (torch.Tensor, np.ndarray)) and len(v) == n:
+                out[k] = v[sl]
+            else:
+                out[k] = v
+        return out
+
+    # ---- collectives ----
+    def all_reduce_sum(self, t):
+        t = t.clone()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def average_gradients(self, params):
+        """One flat-bucket all-reduce of every gradient (missing grads count as zero)."""
+        params = [p for p in params if p.requires_grad]
+        total = sum(p.numel() for p in params)
+        if total == 0:
+            return
+        if self._flat is None or self._flat.numel() != total or self._flat.device != params[0].device:
+            self._flat = torch.empty(total, dtype=torch.float32, device=params[0].device)
+        flat, o = self._flat, 0
+        for p in params:
+            n = p.numel()
+            if p.grad is None:
+                flat[o:o + n].zero_()
+            else:
+                flat[o:o + n].copy_(p.grad.reshape(-1))
+            o += n
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        flat.mul_(1.0 / self.world_size)
+        o = 0
+        for p in params:
+            n = p.numel()
+            if p.grad is None:
+                p.grad = flat[o:o + n].view_as(p).clone()
+            else:
+                p.grad.copy_(flat[o:o + n].view_as(p))
+            o += n
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun); returns (rank, world, local_rank)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def attach(tracker, group=None):
+    """Turn a tracker into one rank of a frame-sharded job."""
+    tracker.dist = FrameShardContext(group)
+    return tracker.dist

@@ -1,0 +1,135 @@
+"""FLAME head model -- host-side mirror of vhap/model/flame.py (FlameHead :64, FlameTexPainted
+:649, FlameUvMask :1057, FlameMask :719) for the MI355X path.
+
+`FlameHead.forward` keeps the reference signature and return convention (flame.py:571-646).  The
+model tensors come from a dict (synthetic model of vhap_amd.synthetic, or a user-supplied FLAME
+pickle via `FlameHead.from_flame_pickle`) instead of the licensed pkl hard-wired at flame.py:38.
+Everything topological lives in vhap_amd.topology.FlameTopology.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import lbs as L
+from .topology import FlameTopology
+
+
+class FlameMask:
+    """Region -> index lookups (flame.py:999-1054), backed by FlameTopology, cached on device."""
+
+    def __init__(self, topo, device="cpu"):
+        self.topo = topo
+        self.device = device
+        self._cache = {}
+        self.fid2cid = torch.from_numpy(topo.fid2cid[1:].astype(np.int64))   # unpadded, like FlameMask.fid2cid
+
+    def _get(self, kind, regions):
+        if isinstance(regions, str):
+            regions = [regions]
+        key = (kind, tuple(regions), str(self.device))
+        if key not in self._cache:
+            fn = self.topo.get_vid_by_region if kind == "v" else self.topo.get_fid_by_region
+            self._cache[key] = torch.from_numpy(fn(list(regions))).long().to(self.device)
+        return self._cache[key]
+
+    def get_vid_by_region(self, regions, keep_order=False):
+        return self._get("v", regions)
+
+    def get_fid_by_region(self, regions):
+        return self._get("f", regions)
+
+    def to(self, device):
+        self.device = device
+        return self
+
+
+class FlameHead(nn.Module):
+    def __init__(self, model, topo: FlameTopology, shape_params=300, expr_params=100):
+        super().__init__()
+        self.n_shape_params, self.n_expr_params = shape_params, expr_params
+        self.topo = topo
+        t = lambda k, dt=torch.float32: torch.as_tensor(np.asarray(model[k])).to(dt)
+        self.register_buffer("v_template", t("v_template"))
+        self.register_buffer("shapedirs", t("shapedirs"))                       # [V,3,NB]
+        self.register_buffer("posedirs", t("posedirs"))                         # [36,3V]
+        self.register_buffer("J_regressor", t("J_regressor"))
+        self.register_buffer("parents", t("parents", torch.long))
+        self.register_buffer("lbs_weights", t("lbs_weights"))
+        self.register_buffer("faces", t("faces", torch.long), persistent=False)
+        self.register_buffer("textures_idx", t("faces_uv", torch.long), persistent=False)
+        self.register_buffer("verts_uvs", t("verts_uvs"), persistent=False)
+        self.register_buffer("full_lmk_faces_idx", t("lmk_faces_idx", torch.long)[None])
+        self.register_buffer("full_lmk_bary_coords", t("lmk_bary_coords")[None])
+        # sparse uniform Laplacian (the reference keeps it dense: flame.py:196-201)
+        self.register_buffer("lap_ptr", torch.from_numpy(topo.lap_ptr.astype(np.int64)), persistent=False)
+        self.register_buffer("lap_col", torch.from_numpy(topo.lap_col.astype(np.int64)), persistent=False)
+        self.register_buffer("lap_val", torch.from_numpy(topo.lap_val), persistent=False)
+        rows = np.repeat(np.arange(topo.num_verts), np.diff(topo.lap_ptr))
+        self.register_buffer("lap_row", torch.from_numpy(rows.astype(np.int64)), persistent=False)
+        self.mask = FlameMask(topo)
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self.mask.to(self.v_template.device)
+        return out
+
+    @property
+    def laplacian_matrix(self):
+        """Sparse COO form of flame.py:196 `laplacian_matrix` ([V,V])."""
+        V = self.v_template.shape[0]
+        return torch.sparse_coo_tensor(torch.stack([self.lap_row, self.lap_col]), self.lap_val, (V, V))
+
+    def laplacian_apply(self, x):
+        """L @ x for x [B,V,3] without the dense [V,V] matrix (tracker.py:682-690 uses 2 dense bmm)."""
+        contrib = self.lap_val[None, :, None] * x[:, self.lap_col]
+        return torch.zeros_like(x).index_add_(1, self.lap_row, contrib)
+
+    def forward(self, shape, expr, rotation, neck, jaw, eyes, translation, zero_centered_at_root_node=False,
+                return_landmarks=True, return_verts_cano=False, static_offset=None, dynamic_offset=None):
+        betas = torch.cat([shape, expr], dim=1)
+        full_pose = torch.cat([rotation, neck, jaw, eyes], dim=1)
+        v_shaped = self.v_template[None] + L.blend_shapes(betas, self.shapedirs)
+        if static_offset is not None:
+            v_shaped = v_shaped + static_offset
+        if dynamic_offset is not None:
+            v_shaped = v_shaped + dynamic_offset
+        vertices, J, _ = L.lbs(full_pose, v_shaped, self.posedirs, self.J_regressor, self.parents, self.lbs_weights)
+        if zero_centered_at_root_node:
+            vertices = vertices - J[:, [0]]
+        vertices = vertices + translation[:, None, :]
+        ret = [vertices]
+        if return_verts_cano:
+            ret.append(v_shaped)
+        if return_landmarks:
+            ret.append(L.vertices2landmarks(vertices, self.faces, self.full_lmk_faces_idx, self.full_lmk_bary_coords))
+        return ret if len(ret) > 1 else ret[0]
+
+
+class FlameTexPainted(nn.Module):
+    """flame.py:649-662 -- a fixed base texture [1,3,T,T]; here supplied as an array (the painted PNG of
+    the reference, or the procedural stand-in of vhap_amd.synthetic.make_texture)."""
+
+    def __init__(self, tex_chw):
+        super().__init__()
+        self.register_buffer("tex_painted", torch.as_tensor(np.asarray(tex_chw), dtype=torch.float32)[None])
+        self.tex_size = self.tex_painted.shape[-1]
+
+    def forward(self):
+        return self.tex_painted
+
+
+class FlameUvMask(nn.Module):
+    """flame.py:1057-1070."""
+
+    def __init__(self, topo):
+        super().__init__()
+        for k, m in topo.uvmasks.items():
+            self.register_buffer(k, torch.from_numpy(m))
+
+    def get_uvmask_by_region(self, regions):
+        if isinstance(regions, str):
+            regions = [regions]
+        m = getattr(self, regions[0])
+        for r in regions[1:]:
+            m = m | getattr(self, r)
+        return m

@@ -124,10 +124,9 @@ def smooth_noise(rng, shape, octaves=4):
         xs = np.linspace(0, n, W, endpoint=False)
         y0, x0 = ys.astype(int), xs.astype(int)
         fy, fx = (ys - y0)[:, None], (xs - x0)[None, :]
-        a = g[..., y0][..., :, x0]
-        b = g[..., y0][..., :, x0 + 1]
-        c = g[..., y0 + 1][..., :, x0]
-        d = g[..., y0 + 1][..., :, x0 + 1]
+        Y0, X0 = y0[:, None], x0[None, :]
+        a, b = g[..., Y0, X0], g[..., Y0, X0 + 1]
+        c, d = g[..., Y0 + 1, X0], g[..., Y0 + 1, X0 + 1]
         out += amp * ((a * (1 - fx) + b * fx) * (1 - fy) + (c * (1 - fx) + d * fx) * fy)
         tot += amp
         amp *= 0.5
@@ -179,3 +178,31 @@ def monocular_camera(n, image_size, focal_length=1.5):
     RT[:, :3, :3] = np.eye(3)
     RT[:, 2, 3] = -1
     return K, RT
+
+
+def make_dataset(tracker_like_render, flame_head, gt, image_size, device, seed=0, lmk_noise_px=1.0, tex=None):
+    """Render a synthetic monocular video from ground-truth parameters with the product renderer.
+    Returns the in-memory dataset dict GlobalTracker expects: rgb [N,3,H,W], lmk2d [N,70,3]."""
+    import torch
+    H, W = image_size
+    N = gt["expr"].shape[0]
+    rng = np.random.default_rng(seed + 3000)
+    g = lambda k: torch.from_numpy(gt[k]).to(device)
+    with torch.no_grad():
+        verts, lmks = flame_head(g("shape")[None].expand(N, -1), g("expr"), g("rotation"), g("neck_pose"), g("jaw_pose"),
+                                 g("eyes_pose"), g("translation"))
+        K, RT = monocular_camera(N, image_size, float(gt["focal_length"][0]))
+        K, RT = torch.from_numpy(K).to(device), torch.from_numpy(RT).to(device)
+        r = tracker_like_render
+        bg = torch.from_numpy(smooth_noise(rng, (N, 3, H, W), octaves=4)).to(device).permute(0, 2, 3, 1).contiguous()
+        rast = r.rasterize(verts, flame_head.faces, RT, K, image_size)
+        uv = flame_head.verts_uvs.clone()
+        uv[:, 1] = 1 - uv[:, 1]
+        tex_t = torch.from_numpy(tex if tex is not None else make_texture(seed, 512)).to(device)[None]
+        out = r.render_rgba(rast, verts, flame_head.faces, uv, flame_head.textures_idx, tex_t, g("lights")[None], bg)
+        rgb = out["rgba"][..., :3].permute(0, 3, 1, 2).clamp(0, 1).contiguous()
+        ndc = r.world_to_ndc(lmks, RT, K, image_size, flip_y=True)
+        u = (ndc[..., 0] * 0.5 + 0.5) * W + torch.from_numpy(rng.standard_normal((N, lmks.shape[1])).astype(np.float32)).to(device) * lmk_noise_px
+        v = (ndc[..., 1] * 0.5 + 0.5) * H + torch.from_numpy(rng.standard_normal((N, lmks.shape[1])).astype(np.float32)).to(device) * lmk_noise_px
+        lmk2d = torch.stack([u, v, torch.ones_like(u)], dim=-1)
+    return {"rgb": rgb, "lmk2d": lmk2d}

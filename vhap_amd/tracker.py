@@ -1,0 +1,498 @@
+"""Photometric FLAME tracker -- MI355X-side mirror of vhap/model/tracker.py.
+
+Keeps the reference's entry points, attribute names and dictionaries for the hot path:
+FlameTracker.{forward_flame :213, get_albedo :247, rasterize_flame :260, render_rgba :305,
+compute_lmk_energy :347, compute_photometric_energy :391, compute_regularization_energy :480,
+compute_energy :692, configure_optimizer :159} and GlobalTracker.{init_params :1279,
+optimize_stage :1391, optimize_iter :1418, get_train_parameters :1465, initialize_next_timtestep
+:1515, save_result :1152}.  What changes is underneath: the renderer is HipDiffRenderer, region
+lookups are cached per stage, the dense [V,V] Laplacian bmm (tracker.py:682-690, 1.7 GB at B=16)
+is a sparse apply, the B-fold texture copy is gone, and frame batches can be sharded across GPUs
+with one all-reduce per Adam step (vhap_amd.dist).  Logging / TensorBoard / landmark detection /
+dataset IO of the reference are out of scope.
+"""
+from collections import defaultdict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .config import BaseTrackingConfig, PhotometricStageConfig
+from .flame import FlameHead, FlameTexPainted, FlameUvMask
+from .lbs import batch_rodrigues
+from .render_hip import HipDiffRenderer
+
+
+def normalize_image_points(u, v, resolution):
+    """util/mesh.py:41-51: pixel coordinates -> [-1, 1]."""
+    return 2 * (u - resolution[1] / 2.0) / resolution[1], 2 * (v - resolution[0] / 2.0) / resolution[0]
+
+
+class FlameTracker:
+    def __init__(self, cfg: BaseTrackingConfig, flame_model, topo, base_texture):
+        self.cfg = cfg
+        self.device = cfg.device
+        self.flame = FlameHead(flame_model, topo, cfg.model.n_shape, cfg.model.n_expr).to(self.device)
+        self.flame_tex_painted = FlameTexPainted(base_texture).to(self.device)
+        self.flame_uvmask = FlameUvMask(topo).to(self.device)
+        if cfg.render.backend != "hip":
+            raise NotImplementedError(f"Unknown renderer backend: {cfg.render.backend}")
+        self.render = HipDiffRenderer(
+            use_opengl=cfg.render.use_opengl, lighting_type=cfg.render.lighting_type,
+            lighting_space=cfg.render.lighting_space, disturb_rate_fg=cfg.render.disturb_rate_fg,
+            disturb_rate_bg=cfg.render.disturb_rate_bg, fid2cid=self.flame.mask.fid2cid,
+        ).to(self.device)
+        self.render._ncl = int(self.flame.mask.fid2cid.max()) + 1
+        uv = self.flame.verts_uvs.clone()
+        uv[:, 1] = 1 - uv[:, 1]                                  # tracker.py:315-316 (constant: hoisted)
+        self._verts_uv_flipped = uv.contiguous()
+        self._faces_i32 = self.flame.faces.int().contiguous()
+        self._region_cache = {}
+        self.dist = None                                          # set by vhap_amd.dist.attach()
+        self.opt_dict = defaultdict(bool)
+
+    # ---- helpers ----
+    def clear_cache(self):
+        self.render.clear_cache()
+
+    def _regions(self, stage):
+        """Stage -> (align_texture_except_fid, align_boundary_except_vid); the reference rebuilds these
+        with cat+unique on every step (tracker.py:417-422)."""
+        if stage not in self._region_cache:
+            st = self.cfg.pipeline[stage]
+            self._region_cache[stage] = (self.flame.mask.get_fid_by_region(st.align_texture_except),
+                                         self.flame.mask.get_vid_by_region(st.align_boundary_except))
+        return self._region_cache[stage]
+
+    def fill_cam_params_into_sample(self, sample):
+        """tracker.py:141-157."""
+        if self.calibrated:
+            assert "intrinsic" in sample and "extrinsic" in sample
+        else:
+            b, _, h, w = sample["rgb"].shape
+            f = self.focal_length * max(h, w)
+            cx = torch.full_like(f, 0.5 * w)
+            cy = torch.full_like(f, 0.5 * h)
+            sample["intrinsic"] = torch.stack([f, f, cx, cy], dim=1)
+            sample["extrinsic"] = self.RT[None, ...].expand(b, -1, -1)
+
+    def configure_optimizer(self, params, lr_scale=1.0):
+        """tracker.py:159-211: Adam, per-group learning rates."""
+        params = dict(params)
+        lr = self.cfg.lr
+        group_lr = {"translation": lr.translation, "expr": lr.expr, "lights": lr.light}
+        if not self.calibrated:
+            group_lr["cam"] = lr.camera
+        if self.cfg.model.use_static_offset:
+            group_lr["static_offset"] = lr.static_offset
+        if self.cfg.model.use_dynamic_offset:
+            group_lr["dynamic_offset"] = lr.dynamic_offset
+        groups = []
+        for key, g_lr in group_lr.items():
+            sel = params.pop(key, [])
+            if len(sel) > 0:
+                groups.append({"params": sel, "lr": g_lr * lr_scale})
+        rest = [p for v in params.values() for p in v]
+        groups.append({"params": rest})
+        return torch.optim.Adam(groups, lr=lr.base * lr_scale)
+
+    # ---- model ----
+    def forward_flame(self, timesteps):
+        dyn = self.dynamic_offset[timesteps] if self.cfg.model.use_dynamic_offset else None
+        verts, verts_cano, lmks = self.flame(
+            self.shape[None, ...].expand(len(timesteps), -1), self.expr[timesteps], self.rotation[timesteps],
+            self.neck_pose[timesteps], self.jaw_pose[timesteps], self.eyes_pose[timesteps],
+            self.translation[timesteps], return_verts_cano=True, static_offset=self.static_offset,
+            dynamic_offset=dyn)
+        albedos = self.get_albedo().expand(len(timesteps), -1, -1, -1)
+        return verts, verts_cano, lmks, albedos
+
+    def get_base_texture(self):
+        if self.cfg.model.tex_extra and not self.cfg.model.residual_tex:
+            return self.tex_extra[None, ...]
+        return self.flame_tex_painted()
+
+    def get_albedo(self):
+        base = self.get_base_texture()
+        if self.cfg.model.tex_extra and self.cfg.model.residual_tex:
+            res = self.tex_extra[None, :]
+            if base.shape[-2:] != res.shape[-2:]:
+                base = F.interpolate(base, res.shape[-2:], mode="bilinear")
+            return base + res
+        return base
+
+    def rasterize_flame(self, sample, verts, faces, camera_index=None, train_mode=False):
+        K = sample["intrinsic"].to(self.device)
+        RT = sample["extrinsic"].to(self.device)
+        if camera_index is not None:
+            K, RT = K[[camera_index]], RT[[camera_index]]
+        return self.render.rasterize(verts, faces, RT, K, tuple(self.image_size), False, train_mode)
+
+    @torch.no_grad()
+    def get_background_color(self, gt_rgb, gt_alpha, stage):
+        background = self.cfg.render.background_eval if stage is None else self.cfg.render.background_train
+        if background == "target":
+            return gt_rgb.permute(0, 2, 3, 1)
+        if background == "white":
+            return [1, 1, 1]
+        if background == "black":
+            return [0, 0, 0]
+        raise NotImplementedError(f"Unknown background mode: {background}")
+
+    def render_rgba(self, rast_dict, verts, faces, albedos, lights, background_color=[1, 1, 1],
+                    align_texture_except_fid=None, align_boundary_except_vid=None, enable_disturbance=False,
+                    disturbance=None):
+        out = self.render.render_rgba(rast_dict, verts, faces, self._verts_uv_flipped, self.flame.textures_idx, albedos,
+                                      lights, background_color, align_texture_except_fid, align_boundary_except_vid,
+                                      enable_disturbance, disturbance=disturbance)
+        return {k: v.permute(0, 3, 1, 2) for k, v in out.items()}
+
+    # ---- energies ----
+    def compute_lmk_energy(self, sample, pred_lmks, disable_jawline_landmarks=False):
+        """tracker.py:347-389."""
+        img_size = sample["rgb"].shape[-2:]
+        lmk2d = sample["lmk2d"].to(pred_lmks)
+        conf = lmk2d[:, :, 2]
+        gu, gv = normalize_image_points(lmk2d[:, :, 0], lmk2d[:, :, 1], img_size)
+        gt = torch.stack([gu, gv], dim=-1)
+        pred = self.render.world_to_ndc(pred_lmks, sample["extrinsic"].to(self.device), sample["intrinsic"].to(self.device),
+                                        img_size, flip_y=True)[:, :, :2]
+        if not self.cfg.w.always_enable_jawline_landmarks and disable_jawline_landmarks:
+            diff, conf = gt[:, 17:68] - pred[:, 17:68], conf[:, 17:68]
+        else:
+            diff = gt[:, :68] - pred[:, :68]
+            boost = torch.ones(68, dtype=conf.dtype, device=conf.device)
+            boost[27:36] = 10                                    # nose landmarks are robust
+            conf = conf[:, :68] * boost
+        loss = diff.abs().sum(dim=2) * conf
+        return loss.mean(), {"gt_lmk2d": gt, "pred_lmk2d": pred}
+
+    def compute_photometric_energy(self, sample, verts, faces, albedos, rast_dict, step_i=None, stage=None,
+                                   disturbance=None):
+        """tracker.py:391-478: sum|gt - pred| / (3 * #{alpha > 0})."""
+        gt_rgb = sample["rgb"].to(verts)
+        lights = self.lights[None] if self.lights is not None else None
+        bg_color = self.get_background_color(gt_rgb, None, stage)
+        fid, vid = self._regions(stage) if stage is not None else (None, None)
+        render_out = self.render_rgba(rast_dict, verts, faces, albedos, lights, bg_color, fid, vid,
+                                      enable_disturbance=stage is not None, disturbance=disturbance)
+        pred_rgb = render_out["rgba"][:, :3]
+        pred_alpha = render_out["rgba"][:, 3:]
+        n_mask = (pred_alpha.detach() > 0).sum() * 3
+        error_rgb = gt_rgb - pred_rgb
+        abs_sum = error_rgb.abs().sum()
+        if self.dist is not None:                                  # batch-global normaliser
+            n_mask = self.dist.all_reduce_sum(n_mask.to(abs_sum.dtype)) / self.dist.world_size
+        render_out.update({"gt_rgb": gt_rgb, "pred_rgb": pred_rgb, "error_rgb": error_rgb, "pred_alpha": pred_alpha})
+        return abs_sum / n_mask, render_out
+
+    def compute_regularization_energy(self, result_dict, verts, verts_cano, lmks, albedos, timesteps, stage):
+        """tracker.py:480-605."""
+        w = self.cfg.w
+        log = {}
+        tracking = "tracking" in stage
+        if self.opt_dict["pose"] and tracking:
+            log["smooth_pose"] = self.compute_pose_smooth_energy(timesteps)
+        if self.opt_dict["joints"]:
+            log["reg_joint"] = self.compute_joint_L2_energy(timesteps)
+            if tracking:
+                log["smooth_joint"] = self.compute_joint_smooth_energy(timesteps)
+        if self.opt_dict["expr"]:
+            log["reg_expr"] = w.reg_expr * (self.expr[timesteps] ** 2).mean()
+            if tracking:
+                log["smooth_expr"] = self.compute_expr_smooth_energy(timesteps)
+        if self.opt_dict["shape"]:
+            log["reg_shape"] = w.reg_shape * (self.shape ** 2).mean()
+        if self.opt_dict["texture"] and self.cfg.model.tex_extra and self.cfg.model.residual_tex:
+            if w.reg_tex_tv is not None:
+                tex = self.get_albedo()[0]
+                tv_y = (tex[..., :-1, :] - tex[..., 1:, :]) ** 2
+                tv_x = (tex[..., :, :-1] - tex[..., :, 1:]) ** 2
+                tv = tv_y.reshape(tv_y.shape[0], -1) + tv_x.reshape(tv_x.shape[0], -1)
+                w_tv = w.reg_tex_tv * self.cfg.data.scale_factor ** 2
+                if self.cfg.data.n_downsample_rgb is not None:
+                    w_tv /= self.cfg.data.n_downsample_rgb ** 2
+                log["reg_tex_tv"] = w_tv * tv.mean()
+            if w.reg_tex_res_clusters is not None:
+                m = self._uvmask_res()
+                log["reg_tex_res_clusters"] = w.reg_tex_res_clusters * (self.tex_extra ** 2 * m).mean()
+        if self.opt_dict["lights"] and self.lights is not None:
+            if w.reg_light is not None:
+                log["reg_light"] = w.reg_light * ((self.lights - self.lights_uniform) ** 2).mean()
+            if w.reg_diffuse is not None:
+                diffuse = result_dict["diffuse_detach_normal"]
+                log["reg_diffuse"] = w.reg_diffuse * (F.relu(diffuse.max() - 1) + diffuse.var(dim=1).mean())
+        if (self.opt_dict["static_offset"] or self.opt_dict["dynamic_offset"]) and \
+                (self.static_offset is not None or self.dynamic_offset is not None):
+            offset = 0
+            if self.static_offset is not None:
+                offset = offset + self.static_offset
+            if self.dynamic_offset is not None:
+                offset = offset + self.dynamic_offset[timesteps]
+            if w.reg_offset_lap is not None:
+                v0 = (verts_cano - offset).detach()
+                lap = self.compute_laplacian_smoothing_loss(v0, v0 + offset)
+                if len(w.reg_offset_lap_relax_for) > 0:
+                    lap = lap * self._vertex_weights("lap", w.reg_offset_lap_relax_coef, w.reg_offset_lap_relax_for)
+                log["reg_offset_lap"] = w.reg_offset_lap * lap.mean()
+            if w.reg_offset is not None:
+                ro = offset.abs()
+                if len(w.reg_offset_relax_for) > 0:
+                    ro = ro * self._vertex_weights("off", w.reg_offset_relax_coef, w.reg_offset_relax_for)
+                log["reg_offset"] = w.reg_offset * ro.mean()
+            if w.reg_offset_rigid is not None:
+                rigid = 0
+                for region in w.reg_offset_rigid_for:
+                    vids = self.flame.mask.get_vid_by_region([region])
+                    rigid = rigid + offset[:, vids, :].var(dim=-2).mean()
+                log["reg_offset_rigid"] = w.reg_offset_rigid * rigid
+            if w.reg_offset_dynamic is not None and self.dynamic_offset is not None and self.opt_dict["dynamic_offset"]:
+                prev = np.clip(timesteps - 1, 0, self.n_timesteps - 1)
+                log["reg_offset_dynamic"] = w.reg_offset_dynamic * \
+                    ((self.dynamic_offset[timesteps] - self.dynamic_offset[prev]) ** 2).mean()
+        return log
+
+    def _uvmask_res(self):
+        if not hasattr(self, "_uvmask_res_cache"):
+            m = self.flame_uvmask.get_uvmask_by_region(self.cfg.w.reg_tex_res_for)[None, :, :].float()
+            T = self.tex_extra.shape[-1]
+            if m.shape[-1] != T:
+                m = F.interpolate(m[None], (T, T), mode="nearest")[0]
+            self._uvmask_res_cache = m
+        return self._uvmask_res_cache
+
+    def _vertex_weights(self, key, scale_factor, region):
+        """tracker.py:607-614 with blur_iter = 0 (the default): per-vertex weights [1,V,1], cached."""
+        ck = ("vw", key)
+        if ck not in self._region_cache:
+            wv = torch.ones(1, self.flame.v_template.shape[0], 1, device=self.device)
+            wv[:, self.flame.mask.get_vid_by_region(list(region))] *= scale_factor
+            if self.cfg.w.blur_iter:
+                raise NotImplementedError("blur_iter > 0 is not implemented (default is 0)")
+            self._region_cache[ck] = wv
+        return self._region_cache[ck]
+
+    def _prev(self, idx):
+        return np.clip(idx - 1, 0, self.n_timesteps - 1)
+
+    def compute_pose_smooth_energy(self, timesteps):
+        p = self._prev(timesteps)
+        return ((self.translation[timesteps] - self.translation[p].detach()) ** 2).mean() * self.cfg.w.smooth_trans + \
+            ((self.rotation[timesteps] - self.rotation[p].detach()) ** 2).mean() * self.cfg.w.smooth_rot
+
+    def compute_joint_smooth_energy(self, timesteps):
+        p = self._prev(timesteps)
+        w = self.cfg.w
+        return ((self.neck_pose[timesteps] - self.neck_pose[p].detach()) ** 2).mean() * w.smooth_neck + \
+            ((self.jaw_pose[timesteps] - self.jaw_pose[p].detach()) ** 2).mean() * w.smooth_jaw + \
+            ((self.eyes_pose[timesteps] - self.eyes_pose[p].detach()) ** 2).mean() * w.smooth_eyes
+
+    def compute_expr_smooth_energy(self, timesteps):
+        p = self._prev(timesteps)
+        return ((self.expr[timesteps] - self.expr[p].detach()) ** 2).mean() * self.cfg.w.smooth_expr
+
+    def compute_joint_L2_energy(self, timesteps):
+        """tracker.py:650-680: mean((R(0) - R(pose))^2) per joint + plausibility terms."""
+        neck, jaw = self.neck_pose[timesteps], self.jaw_pose[timesteps]
+        eye_l, eye_r = self.eyes_pose[timesteps, :3], self.eyes_pose[timesteps, 3:]
+        B = neck.shape[0]
+        R = batch_rodrigues(torch.cat([neck, jaw, eye_l, eye_r, torch.zeros_like(neck[:1])], dim=0))
+        R0 = R[-1:]
+        # reference quirk kept for parity (tracker.py:665-666): it stacks B identity rotations in front of
+        # the B pose rotations and averages over rows 1..2B-1, i.e. over (2B-1)*9 entries, B-1 of them zero
+        d = lambda i: ((R0 - R[i * B:(i + 1) * B]) ** 2).sum() / (9 * (2 * B - 1))
+        w = self.cfg.w
+        e = d(0) * w.reg_neck
+        e = e + (d(1) + F.relu(-jaw[:, 0]).mean() * 10 + (jaw[:, 1:] ** 2).mean() * 3) * w.reg_jaw
+        eye_diff = ((eye_l - eye_r) ** 2).mean()
+        e = e + (d(2) + eye_diff) * w.reg_eyes + (d(3) + eye_diff) * w.reg_eyes
+        return e
+
+    def compute_laplacian_smoothing_loss(self, verts, offset_verts):
+        """tracker.py:682-690 with a sparse Laplacian: sum_k (L(v+o) - L v)_k^2 per vertex."""
+        basis = self.flame.laplacian_apply(verts).detach()
+        off = self.flame.laplacian_apply(offset_verts)
+        return ((off - basis) ** 2).sum(dim=-1, keepdim=True)
+
+    def compute_energy(self, sample, step_i=None, stage=None, disturbance=None):
+        """tracker.py:692-750."""
+        log_dict = {}
+        result_dict = {"gt_rgb": sample["rgb"]}
+        timesteps = sample["timestep_index"]
+        verts, verts_cano, lmks, albedos = self.forward_flame(timesteps)
+        faces = self.flame.faces
+        if self.cfg.w.landmark is not None:
+            disable_jaw = (not self.cfg.w.always_enable_jawline_landmarks and stage is not None and
+                           self.cfg.pipeline[stage]["disable_jawline_landmarks"])
+            E_lmk, rd = self.compute_lmk_energy(sample, lmks, disable_jaw)
+            log_dict["lmk"] = self.cfg.w.landmark * E_lmk
+            result_dict.update(rd)
+        if stage is None or isinstance(self.cfg.pipeline[stage], PhotometricStageConfig):
+            if self.cfg.w.photo is not None:
+                rast_dict = self.rasterize_flame(sample, verts, faces, train_mode=True)
+                E_photo, rd = self.compute_photometric_energy(sample, verts, faces, albedos, rast_dict, step_i, stage,
+                                                              disturbance=disturbance)
+                result_dict.update(rd)
+                log_dict["photo"] = self.cfg.w.photo * E_photo
+        if stage is not None:
+            log_dict.update(self.compute_regularization_energy(result_dict, verts, verts_cano, lmks, albedos, timesteps, stage))
+        E_total = torch.stack([v for v in log_dict.values()]).sum()
+        log_dict["total"] = E_total
+        return E_total, log_dict, verts, faces, lmks, albedos, result_dict
+
+
+class GlobalTracker(FlameTracker):
+    """tracker.py:1221-1529 on an in-memory dataset (list/tensor of frames).  `dataset` must provide
+    `rgb` [N,3,H,W] float in [0,1], `lmk2d` [N,68+,3] (pixel u, v, confidence) and, if calibrated,
+    `intrinsic` / `extrinsic`."""
+
+    def __init__(self, cfg, flame_model, topo, base_texture, dataset):
+        super().__init__(cfg, flame_model, topo, base_texture)
+        self.calibrated = cfg.data.calibrated
+        self.dataset = dataset
+        self.image_size = tuple(dataset["rgb"].shape[-2:])
+        self.n_timesteps = dataset["rgb"].shape[0]
+        self.global_step = 0
+        self.init_params()
+
+    def init_params(self):
+        """tracker.py:1279-1341."""
+        dev, m = self.device, self.cfg.model
+        N = self.n_timesteps
+        z = lambda *s: torch.zeros(*s, device=dev)
+        self.shape = z(m.n_shape)
+        self.expr = z(N, m.n_expr)
+        self.neck_pose, self.jaw_pose, self.eyes_pose = z(N, 3), z(N, 3), z(N, 6)
+        self.translation, self.rotation = z(N, 3), z(N, 3)
+        self.tex_pca = z(m.n_tex)
+        train = [self.shape, self.translation, self.rotation, self.neck_pose, self.jaw_pose, self.eyes_pose, self.expr]
+        self.tex_extra = None
+        if m.tex_extra:
+            self.tex_extra = z(3, m.tex_resolution, m.tex_resolution)
+            train.append(self.tex_extra)
+        if self.cfg.render.lighting_type == "SH":
+            self.lights_uniform = z(9, 3)
+            self.lights_uniform[0] = float(np.sqrt(4 * np.pi))
+            self.lights = self.lights_uniform.clone()
+            train.append(self.lights)
+        else:
+            self.lights = None
+        V = self.flame.v_template.shape[0]
+        self.static_offset = z(1, V, 3) if m.use_static_offset else None
+        if self.static_offset is not None:
+            train.append(self.static_offset)
+        self.dynamic_offset = z(N, V, 3) if m.use_dynamic_offset else None
+        if self.dynamic_offset is not None:
+            train.append(self.dynamic_offset)
+        if not self.calibrated:
+            self.focal_length = torch.tensor([1.5], device=dev)
+            self.RT = torch.eye(3, 4, device=dev)
+            self.RT[2, 3] = -1
+            train.append(self.focal_length)
+        for t in train:
+            t.requires_grad = True
+        self._train_tensors = train
+
+    def get_train_parameters(self, stage):
+        """tracker.py:1465-1513."""
+        self.opt_dict = defaultdict(bool)
+        for p in self.cfg.pipeline[stage].optimizable_params:
+            self.opt_dict[p] = True
+        o, m = self.opt_dict, self.cfg.model
+        params = defaultdict(list)
+        if o["cam"] and not self.calibrated:
+            params["cam"] = [self.focal_length]
+        if o["shape"]:
+            params["shape"] = [self.shape]
+        if o["texture"] and m.tex_extra:
+            params["tex_extra"] = [self.tex_extra]
+        if o["static_offset"] and m.use_static_offset:
+            params["static_offset"] = [self.static_offset]
+        if o["lights"] and self.lights is not None:
+            params["lights"] = [self.lights]
+        if o["pose"]:
+            params["translation"].append(self.translation)
+            params["rotation"].append(self.rotation)
+        if o["joints"]:
+            params["eyes"].append(self.eyes_pose)
+            params["neck"].append(self.neck_pose)
+            params["jaw"].append(self.jaw_pose)
+        if o["expr"]:
+            params["expr"].append(self.expr)
+        if o["dynamic_offset"] and m.use_dynamic_offset:
+            params["dynamic_offset"].append(self.dynamic_offset)
+        return params
+
+    def get_sample(self, timesteps):
+        ts = np.asarray(timesteps)
+        idx = torch.as_tensor(ts, device=self.dataset["rgb"].device)
+        s = {"rgb": self.dataset["rgb"][idx], "lmk2d": self.dataset["lmk2d"][idx], "timestep_index": ts}
+        for k in ("intrinsic", "extrinsic"):
+            if k in self.dataset:
+                s[k] = self.dataset[k][idx]
+        return s
+
+    def optimize_stage(self, stage, sample=None, dataloader=None, lr_scale=1.0, num_steps=None):
+        """tracker.py:1391-1416."""
+        optimizer = self.configure_optimizer(self.get_train_parameters(stage), lr_scale=lr_scale)
+        if sample is not None:
+            n = self.cfg.pipeline[stage].num_steps if num_steps is None else num_steps
+            for _ in range(n):
+                self.optimize_iter(sample, optimizer, stage)
+        else:
+            assert dataloader is not None
+            sched = torch.optim.lr_scheduler.ExponentialLR(optimizer, gamma=0.9)
+            for _ in range(self.cfg.pipeline[stage].num_epochs):
+                for s in dataloader:
+                    self.optimize_iter(s, optimizer, stage)
+                sched.step()
+        return optimizer
+
+    def optimize_iter(self, sample, optimizer, stage, disturbance=None):
+        """tracker.py:1418-1462 without the logging branches."""
+        self.clear_cache()
+        self.fill_cam_params_into_sample(sample)
+        E_total, log_dict, *_ = self.compute_energy(sample, stage=stage, disturbance=disturbance)
+        optimizer.zero_grad()
+        E_total.backward()
+        if self.dist is not None:
+            self.dist.average_gradients([p for g in optimizer.param_groups for p in g["params"]])
+        optimizer.step()
+        self.global_step += 1
+        return log_dict
+
+    def initialize_next_timtestep(self, timesteps):
+        """tracker.py:1515-1529 (including its skip of the last frame)."""
+        stride = int(timesteps[-1]) - int(timesteps[0]) + 1
+        t_src = int(timesteps[-1])
+        with torch.no_grad():
+            for s in range(stride):
+                t_tgt = t_src + s + 1
+                if t_tgt < self.n_timesteps - 1:
+                    for p in (self.translation, self.rotation, self.neck_pose, self.jaw_pose, self.eyes_pose, self.expr):
+                        p[t_tgt].copy_(p[t_src])
+                    if self.cfg.model.use_dynamic_offset:
+                        self.dynamic_offset[t_tgt].copy_(self.dynamic_offset[t_src])
+
+    def save_result(self, path=None):
+        """tracker.py:1152-1218: the npz schema consumed by export_as_nerf_dataset.py / GaussianAvatars."""
+        c = lambda t: t.detach().cpu().numpy()
+        out = {
+            "rotation": c(self.rotation), "translation": c(self.translation), "neck_pose": c(self.neck_pose),
+            "jaw_pose": c(self.jaw_pose), "eyes_pose": c(self.eyes_pose), "shape": c(self.shape), "expr": c(self.expr),
+            "timestep_id": np.arange(self.n_timesteps), "n_processed_frames": np.array(self.n_timesteps),
+            "image_size": np.array(self.image_size),
+        }
+        if not self.calibrated:
+            out["focal_length"] = c(self.focal_length)
+        if self.cfg.model.tex_extra:
+            out["tex_extra"] = c(self.tex_extra)
+        if self.lights is not None:
+            out["lights"] = c(self.lights)
+        if self.static_offset is not None:
+            out["static_offset"] = c(self.static_offset)
+        if self.dynamic_offset is not None:
+            out["dynamic_offset"] = c(self.dynamic_offset)
+        if path is not None:
+            np.savez(path, **out)
+        return out
