@@ -9,6 +9,15 @@ import oracle
 from . import torch_ref as R
 
 
+_LAP = {}
+
+
+def _laplacian(V, topo):
+    if V not in _LAP:
+        _LAP[V] = torch.from_numpy(R.uniform_laplacian(V, topo.faces[: topo.num_faces_orig]))
+    return _LAP[V]
+
+
 def joint_l2(neck, jaw, eyes, w):
     """tracker.py:650-680."""
     e = 0
@@ -93,7 +102,7 @@ def total_energy(P, model, topo, cfg, sample, stage, tex_painted, uvmask_res, im
         if ("static_offset" in opt or "dynamic_offset" in opt) and P.get("static_offset") is not None:
             off = P["static_offset"]
             V = off.shape[1]
-            L = torch.from_numpy(R.uniform_laplacian(V, topo.faces[: topo.num_faces_orig])).to(dtype)
+            L = _laplacian(V, topo).to(dtype)
             v0 = (v_cano - off).detach()
             wl = torch.ones(1, V, 1, dtype=dtype)
             wl[:, torch.from_numpy(topo.get_vid_by_region(list(w.reg_offset_lap_relax_for)))] *= w.reg_offset_lap_relax_coef

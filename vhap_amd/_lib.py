@@ -6,6 +6,9 @@ There is NO fallback: if the shared library is missing or fails to load, importi
 import ctypes
 import os
 
+import torch  # noqa: F401  -- MUST precede the CDLL below: torch ships its own libamdhip64; loading ours first
+               # would put a second HIP runtime in the process and torch.cuda would report no device
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "lib", "libvhap_hip.so")
 

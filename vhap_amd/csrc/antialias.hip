@@ -234,6 +234,7 @@ extern "C" size_t vhap_antialias_work_ints(int B, int H, int W) {
 extern "C" int vhap_antialias_fwd(const float* color, const float* rast, const float* pos, const int32_t* tri,
                                   const int32_t* opp, int B, int H, int W, int C, int V, int F, float* out, int32_t* work,
                                   vhap_stream_t stream) {
+    VHAP_ENTER();
     if (!color || !rast || !pos || !tri || !opp || !out || !work) return VHAP_E_NULLPTR;
     if (B <= 0 || H <= 0 || W <= 0 || V <= 0 || F <= 0 || (long long)B * H * W >= (1ll << 31)) return VHAP_E_BADDIM;
     const long long npix = (long long)B * H * W, n = npix * C, n4 = n / 4;
@@ -256,6 +257,7 @@ extern "C" int vhap_antialias_fwd(const float* color, const float* rast, const f
 extern "C" int vhap_antialias_bwd(const float* color, const float* rast, const float* pos, const int32_t* tri,
                                    const int32_t* opp, const float* d_out, const int32_t* work, int B, int H, int W, int C,
                                    int V, int F, float* d_color, float* d_pos, vhap_stream_t stream) {
+    VHAP_ENTER();
     if (!color || !rast || !pos || !tri || !opp || !d_out || !work) return VHAP_E_NULLPTR;
     if (B <= 0 || H <= 0 || W <= 0 || V <= 0 || F <= 0) return VHAP_E_BADDIM;
     hipStream_t st = vhap_stream(stream);

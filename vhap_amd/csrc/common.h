@@ -5,9 +5,14 @@
 
 #include "vhap_hip.h"
 
-#define VHAP_LAUNCH_CHECK()                                    \
-    do {                                                       \
-        if (hipGetLastError() != hipSuccess) return VHAP_E_HIP; \
+// hipGetLastError() is sticky and process-wide: an earlier hipEventQuery()/hipStreamQuery() of the host
+// framework legitimately leaves hipErrorNotReady behind.  Every entry point therefore clears the slot on
+// entry (VHAP_ENTER) and only then attributes a non-success value to its own launches.
+#define VHAP_ENTER() (void)hipGetLastError()
+#define VHAP_LAUNCH_CHECK()                                                  \
+    do {                                                                     \
+        const hipError_t vhap_e_ = hipGetLastError();                        \
+        if (vhap_e_ != hipSuccess && vhap_e_ != hipErrorNotReady) return VHAP_E_HIP; \
     } while (0)
 
 static inline hipStream_t vhap_stream(vhap_stream_t s) { return reinterpret_cast<hipStream_t>(s); }

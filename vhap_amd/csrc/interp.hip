@@ -178,6 +178,7 @@ __global__ __launch_bounds__(256) void raster_bwd_kernel(const float4* __restric
 
 extern "C" int vhap_interp_fwd(const float* attr, int AB, const float* rast, const int32_t* tri, const float* rast_db, int B,
                                int H, int W, int V, int F, int A, float* out, float* out_da, vhap_stream_t stream) {
+    VHAP_ENTER();
     if (!attr || !rast || !tri || !out) return VHAP_E_NULLPTR;
     if (B <= 0 || H <= 0 || W <= 0 || V <= 0 || F <= 0 || A <= 0 || A > MAX_ATTR || (AB != 1 && AB != B)) return VHAP_E_BADDIM;
     if ((out_da != nullptr) != (rast_db != nullptr) && out_da) return VHAP_E_NULLPTR;
@@ -192,6 +193,7 @@ extern "C" int vhap_interp_fwd(const float* attr, int AB, const float* rast, con
 extern "C" int vhap_interp_bwd(const float* attr, int AB, const float* rast, const int32_t* tri, const float* rast_db,
                                const float* d_out, const float* d_out_da, int B, int H, int W, int V, int F, int A,
                                float* d_attr, float* d_rast, float* d_rast_db, vhap_stream_t stream) {
+    VHAP_ENTER();
     if (!attr || !rast || !tri || !d_out) return VHAP_E_NULLPTR;
     if (B <= 0 || H <= 0 || W <= 0 || V <= 0 || F <= 0 || A <= 0 || A > MAX_ATTR || (AB != 1 && AB != B)) return VHAP_E_BADDIM;
     const long long npix = (long long)B * H * W;
@@ -204,6 +206,7 @@ extern "C" int vhap_interp_bwd(const float* attr, int AB, const float* rast, con
 
 extern "C" int vhap_raster_bwd(const float* pos, const int32_t* tri, const float* rast, const float* d_rast,
                                const float* d_rast_db, int B, int V, int F, int H, int W, float* d_pos, vhap_stream_t stream) {
+    VHAP_ENTER();
     if (!pos || !tri || !rast || !d_rast || !d_pos) return VHAP_E_NULLPTR;
     if (B <= 0 || H <= 0 || W <= 0 || V <= 0 || F <= 0) return VHAP_E_BADDIM;
     const long long npix = (long long)B * H * W;

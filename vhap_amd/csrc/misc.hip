@@ -1,7 +1,8 @@
 // ABI bookkeeping entry points.
 #include "common.h"
 
-extern "C" int vhap_abi_version(void) { return VHAP_ABI_VERSION; }
+extern "C" int vhap_abi_version(void) {
+    VHAP_ENTER(); return VHAP_ABI_VERSION; }
 
 extern "C" const char* vhap_strerror(int code) {
     switch (code) {

@@ -554,6 +554,7 @@ extern "C" size_t vhap_raster_workspace_bytes(int B, int F, int H, int W, size_t
 extern "C" int vhap_raster_fwd(const float* pos, const int32_t* tri, int B, int V, int F, int H, int W, float* rast,
                                float* rast_db, void* workspace, size_t workspace_bytes, size_t pair_capacity,
                                vhap_stream_t stream) {
+    VHAP_ENTER();
     if (!pos || !tri || !rast) return VHAP_E_NULLPTR;
     if (int e = check_dims(B, V, F, H, W)) return e;
     RasterParams P{};
@@ -566,6 +567,7 @@ extern "C" int vhap_raster_interp_fwd(const float* pos, const int32_t* tri, cons
                                       const int32_t* tri_uv, int B, int V, int VT, int F, int H, int W, float* rast,
                                       float* rast_db, float* normal, float* texc, float* texd, void* workspace,
                                       size_t workspace_bytes, size_t pair_capacity, vhap_stream_t stream) {
+    VHAP_ENTER();
     if (!pos || !tri || !vnormal || !uv || !tri_uv || !rast || !rast_db || !normal || !texc || !texd) return VHAP_E_NULLPTR;
     if (int e = check_dims(B, V, F, H, W)) return e;
     if (VT <= 0) return VHAP_E_BADDIM;

@@ -301,7 +301,8 @@ int check_tex(int TB, int Ht, int Wt, int C) {
 
 }  // namespace
 
-extern "C" int vhap_texture_num_levels(int Ht, int Wt) { return num_levels(Ht, Wt); }
+extern "C" int vhap_texture_num_levels(int Ht, int Wt) {
+    VHAP_ENTER(); return num_levels(Ht, Wt); }
 
 extern "C" size_t vhap_texture_mip_floats(int TB, int Ht, int Wt, int C) {
     if (check_tex(TB, Ht, Wt, C) != VHAP_OK) return 0;
@@ -309,6 +310,7 @@ extern "C" size_t vhap_texture_mip_floats(int TB, int Ht, int Wt, int C) {
 }
 
 extern "C" int vhap_texture_mip_build(const float* tex, int TB, int Ht, int Wt, int C, float* mips, vhap_stream_t stream) {
+    VHAP_ENTER();
     if (int e = check_tex(TB, Ht, Wt, C)) return e;
     const TexDesc D = make_desc(TB, Ht, Wt, C);
     if (D.L == 0) return VHAP_OK;
@@ -325,6 +327,7 @@ extern "C" int vhap_texture_mip_build(const float* tex, int TB, int Ht, int Wt, 
 }
 
 extern "C" int vhap_texture_mip_fold(float* d_tex, float* d_mips, int TB, int Ht, int Wt, int C, vhap_stream_t stream) {
+    VHAP_ENTER();
     if (int e = check_tex(TB, Ht, Wt, C)) return e;
     const TexDesc D = make_desc(TB, Ht, Wt, C);
     if (D.L == 0) return VHAP_OK;
@@ -342,6 +345,7 @@ extern "C" int vhap_texture_mip_fold(float* d_tex, float* d_mips, int TB, int Ht
 
 extern "C" int vhap_texture_fwd(const float* tex, const float* mips, int TB, int Ht, int Wt, int C, const float* uv,
                                 const float* uv_da, int B, int H, int W, float* out, vhap_stream_t stream) {
+    VHAP_ENTER();
     if (!tex || !uv || !out) return VHAP_E_NULLPTR;
     if (int e = check_tex(TB, Ht, Wt, C)) return e;
     if (B <= 0 || H <= 0 || W <= 0 || (TB != 1 && TB != B)) return VHAP_E_BADDIM;
@@ -359,6 +363,7 @@ extern "C" int vhap_texture_fwd(const float* tex, const float* mips, int TB, int
 extern "C" int vhap_texture_bwd(const float* tex, const float* mips, int TB, int Ht, int Wt, int C, const float* uv,
                                 const float* uv_da, const float* d_out, int B, int H, int W, float* d_tex, float* d_mips,
                                 float* d_uv, float* d_uv_da, vhap_stream_t stream) {
+    VHAP_ENTER();
     if (!tex || !uv || !d_out) return VHAP_E_NULLPTR;
     if (int e = check_tex(TB, Ht, Wt, C)) return e;
     if (B <= 0 || H <= 0 || W <= 0 || (TB != 1 && TB != B)) return VHAP_E_BADDIM;

@@ -22,6 +22,16 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# Optional profiling hook: bench.py installs a callable (name, phase) -> None that records HIP events on
+# torch's current stream right before ('begin') and after ('end') a C-ABI launch sequence.
+PROFILE_HOOK = None
+
+
+def _hook(name, phase):
+    if PROFILE_HOOK is not None:
+        PROFILE_HOOK(name, phase)
+
+
 def _chk_cuda(*ts):
     for t in ts:
         if t is not None and not t.is_cuda:
@@ -102,8 +112,10 @@ def raster_interp_fwd(ctx, pos, tri, vnormal, uv, tri_uv, resolution):
     normal = torch.empty(B, H, W, 3, dtype=torch.float32, device=dev)
     texc = torch.empty(B, H, W, 2, dtype=torch.float32, device=dev)
     texd = torch.empty_like(rast)
+    _hook("raster_interp_fwd", "begin")
     rc = _lib.lib().vhap_raster_interp_fwd(_p(pos), _p(tri), _p(vnormal), _p(uv), _p(tri_uv), B, V, uv.shape[0], F, H, W,
                                            _p(rast), _p(db), _p(normal), _p(texc), _p(texd), _p(ws), nbytes, cap, _stream())
+    _hook("raster_interp_fwd", "end")
     _lib.check(rc, "vhap_raster_interp_fwd")
     return rast, db, normal, texc, texd
 
@@ -318,3 +330,48 @@ def antialias(color, rast, pos, tri, topology_hash=None, pos_gradient_boost=1.0,
     if opp is None:
         opp = opposite_table(tri)
     return _Antialias.apply(color, rast, pos, tri, _i32c(opp))
+
+
+class _RasterInterp(torch.autograd.Function):
+    """Fused G-buffer pass: dr.rasterize + dr.interpolate(normals) + dr.interpolate(uv, 'all') in one launch;
+    the backward chains the two interpolate backwards into the rasterize backward."""
+
+    @staticmethod
+    def forward(ctx, glctx, pos, tri, vnormal, uv, tri_uv, resolution):
+        rast, db, normal, texc, texd = raster_interp_fwd(glctx, pos, tri, vnormal, uv, tri_uv, resolution)
+        ctx.save_for_backward(pos, tri, vnormal, uv, tri_uv, rast, db)
+        ctx.res = (int(resolution[0]), int(resolution[1]))
+        return rast, db, normal, texc, texd
+
+    @staticmethod
+    def backward(ctx, d_rast, d_db, d_normal, d_texc, d_texd):
+        pos, tri, vnormal, uv, tri_uv, rast, db = ctx.saved_tensors
+        H, W = ctx.res
+        B, V, _ = pos.shape
+        F = tri.shape[0]
+        L = _lib.lib()
+        need_pos, need_n = ctx.needs_input_grad[1], ctx.needs_input_grad[3]
+        d_vn = torch.zeros_like(vnormal) if need_n else None
+        g_rast_n = torch.empty_like(rast)
+        _lib.check(L.vhap_interp_bwd(_p(vnormal), B, _p(rast), _p(tri), 0, _p(_f32c(d_normal)), 0, B, H, W, V, F, 3,
+                                     _p(d_vn), _p(g_rast_n), 0, _stream()), "vhap_interp_bwd(normal)")
+        d_pos = None
+        if need_pos:
+            g_rast_uv, g_db_uv = torch.empty_like(rast), torch.empty_like(db)
+            uv3 = uv[None] if uv.dim() == 2 else uv
+            _lib.check(L.vhap_interp_bwd(_p(uv3), 1, _p(rast), _p(tri_uv), _p(db), _p(_f32c(d_texc)), _p(_f32c(d_texd)),
+                                         B, H, W, uv3.shape[1], F, 2, 0, _p(g_rast_uv), _p(g_db_uv), _stream()),
+                       "vhap_interp_bwd(uv)")
+            g_rast = d_rast + g_rast_n + g_rast_uv
+            g_db = d_db + g_db_uv
+            d_pos = torch.zeros_like(pos)
+            _lib.check(L.vhap_raster_bwd(_p(pos), _p(tri), _p(rast), _p(g_rast), _p(g_db), B, V, F, H, W, _p(d_pos),
+                                         _stream()), "vhap_raster_bwd")
+        return None, d_pos, None, d_vn, None, None, None
+
+
+def raster_interp(glctx, pos, tri, vnormal, uv, tri_uv, resolution):
+    """Differentiable fused pass -> (rast, rast_db, normal [B,H,W,3], texc [B,H,W,2], texd [B,H,W,4])."""
+    _chk_cuda(pos, tri, vnormal, uv, tri_uv)
+    _check_raster_args(pos, tri, resolution)
+    return _RasterInterp.apply(glctx, _f32c(pos), _i32c(tri), _f32c(vnormal), _f32c(uv), _i32c(tri_uv), tuple(resolution))

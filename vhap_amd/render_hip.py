@@ -123,9 +123,14 @@ class HipDiffRenderer(torch.nn.Module):
         return ndc
 
     # ---- rasterize (render_nvdiffrast.py:216-260) ----
-    def rasterize(self, verts, faces, RT, K, image_size, use_cache=False, require_grad=False):
+    def rasterize(self, verts, faces, RT, K, image_size, use_cache=False, require_grad=False, defer=False):
+        """`defer=True` (MI355X extension): only transform the vertices; render_rgba() then runs the fused
+        rasterize + interpolate kernel (one launch for the whole G-buffer) instead of three ops."""
         verts_camera = self.world_to_camera(verts, RT)
         verts_clip = self.camera_to_clip(verts_camera, K, image_size)
+        if defer:
+            return {"rast_out": None, "rast_out_db": None, "verts": verts, "verts_camera": verts_camera[..., :3],
+                    "verts_clip": verts_clip, "image_size": tuple(image_size), "require_grad": require_grad}
         rast_out, rast_out_db = self.rasterize_fragments(verts_clip, faces.int(), image_size, use_cache, require_grad)
         return {"rast_out": rast_out, "rast_out_db": rast_out_db, "verts": verts,
                 "verts_camera": verts_camera[..., :3], "verts_clip": verts_clip}
@@ -235,14 +240,19 @@ class HipDiffRenderer(torch.nn.Module):
         rast_out, rast_out_db = rast_dict["rast_out"], rast_dict["rast_out_db"]
         verts, verts_camera, verts_clip = rast_dict["verts"], rast_dict["verts_camera"], rast_dict["verts_clip"]
         tri, tri_uv = faces.int(), faces_uv.int()
-        fg_mask = rast_out[..., 3:4] > 0
         out_dict = {}
 
         v_normal = self._vertex_normals_for(verts, verts_camera, faces)
-        normal, _ = ops.interpolate(v_normal, rast_out, tri)
+        if rast_out is None:    # deferred: fused rasterize + interpolate(normal) + interpolate(uv, 'all')
+            pos = verts_clip if rast_dict.get("require_grad", True) else verts_clip.detach()
+            rast_out, rast_out_db, normal, texc, texd = ops.raster_interp(self.glctx, pos, tri, v_normal, verts_uv, tri_uv,
+                                                                          rast_dict["image_size"])
+            rast_dict["rast_out"], rast_dict["rast_out_db"] = rast_out, rast_out_db
+        else:
+            normal, _ = ops.interpolate(v_normal, rast_out, tri)
+            texc, texd = ops.interpolate(verts_uv[None, ...], rast_out, tri_uv, rast_db=rast_out_db, diff_attrs="all")
+        fg_mask = rast_out[..., 3:4] > 0
         normal = safe_normalize(normal)
-
-        texc, texd = ops.interpolate(verts_uv[None, ...], rast_out, tri_uv, rast_db=rast_out_db, diff_attrs="all")
         if align_texture_except_fid is not None:
             mask = torch.zeros(faces.shape[0] + 1, dtype=torch.bool, device=rast_out.device)
             mask[align_texture_except_fid + 1] = True

@@ -49,6 +49,7 @@ class FlameTracker:
         self._faces_i32 = self.flame.faces.int().contiguous()
         self._region_cache = {}
         self.dist = None                                          # set by vhap_amd.dist.attach()
+        self.fused_gbuffer = True                                 # one launch for rasterize + both interpolates
         self.opt_dict = defaultdict(bool)
 
     # ---- helpers ----
@@ -126,7 +127,7 @@ class FlameTracker:
         RT = sample["extrinsic"].to(self.device)
         if camera_index is not None:
             K, RT = K[[camera_index]], RT[[camera_index]]
-        return self.render.rasterize(verts, faces, RT, K, tuple(self.image_size), False, train_mode)
+        return self.render.rasterize(verts, faces, RT, K, tuple(self.image_size), False, train_mode, defer=self.fused_gbuffer)
 
     @torch.no_grad()
     def get_background_color(self, gt_rgb, gt_alpha, stage):
