@@ -1,0 +1,113 @@
+"""CPU tests of the host logic: C-ABI surface, topology tables, config plumbing, error behaviour."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "vhap_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(vhap_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from vhap_amd import _lib
+    assert os.path.exists(_lib.SO_PATH), "build it: python -m vhap_amd.build"
+    L = ctypes.CDLL(_lib.SO_PATH)
+    syms = _declared_symbols()
+    assert len(syms) >= 15
+    for name in syms:
+        assert hasattr(L, name), f"{name} declared in include/vhap_hip.h but not exported"
+    missing = set(syms) - set(_lib.SIGNATURES)
+    assert not missing, f"ctypes signatures missing for {missing}"
+    L2 = _lib.lib()
+    assert L2.vhap_abi_version() == 1
+    assert L2.vhap_strerror(-3) == b"workspace too small"
+    assert L2.vhap_raster_workspace_bytes(16, 10144, 512, 512, 1000) > 0
+    assert L2.vhap_raster_workspace_bytes(1, 10, 5000, 64, 10) == 0          # H beyond the limit
+    assert L2.vhap_texture_num_levels(2048, 2048) == 11
+    assert L2.vhap_texture_mip_floats(1, 2048, 2048, 3) == sum((2048 >> l) ** 2 * 3 for l in range(1, 12))
+
+
+def test_ops_refuse_cpu_tensors_and_missing_library(monkeypatch):
+    from vhap_amd import _lib, ops
+    ctx = ops.RasterizeHipContext()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.rasterize(ctx, torch.zeros(1, 3, 4), torch.zeros(1, 3, dtype=torch.int32), (8, 8))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.texture(torch.zeros(1, 4, 4, 3), torch.zeros(1, 2, 2, 2), torch.zeros(1, 2, 2, 4))
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "SO_PATH", "/nonexistent/libvhap_hip.so")
+    with pytest.raises(_lib.VhapHipError, match="no CPU / eager fallback"):
+        _lib.lib()
+
+
+def test_topology_tables(flame_model):
+    model, topo = flame_model
+    assert (topo.num_verts, topo.num_faces, topo.verts_uvs.shape[0]) == (5143, 10144, 5238)
+    F = topo.faces
+    # opposite-vertex table: symmetric, and the opposite vertex really shares the edge's triangle
+    from oracle.torch_ref import build_opposite_table as ref_table
+    assert np.array_equal(topo.opp, ref_table(F))
+    t, i = 1234, 1
+    o = topo.opp[t, i]
+    a, b = F[t, (i + 1) % 3], F[t, (i + 2) % 3]
+    nb = [k for k in range(F.shape[0]) if k != t and a in F[k] and b in F[k]]
+    assert (o == -1 and not nb) or o in F[nb[0]]
+    # vertex->corner CSR
+    ptr, idx = topo.vc_ptr, topo.vc_idx
+    assert ptr[-1] == 3 * F.shape[0]
+    v = 777
+    assert all(F.reshape(-1)[c] == v for c in idx[ptr[v]:ptr[v + 1]])
+    # sparse Laplacian == dense pytorch3d-style Laplacian
+    from oracle.torch_ref import uniform_laplacian
+    Ld = uniform_laplacian(topo.num_verts, F[: topo.num_faces_orig])
+    Ls = np.zeros_like(Ld)
+    rows = np.repeat(np.arange(topo.num_verts), np.diff(topo.lap_ptr))
+    Ls[rows, topo.lap_col] = topo.lap_val
+    assert np.allclose(Ls, Ld, atol=1e-7)
+    assert topo.lap_ptr[-1] == 35013 + 120                                   # 35013 nnz + teeth diagonals
+    # clusters: 0 background + 1 unclustered + 7 named
+    assert topo.fid2cid[0] == 0 and topo.fid2cid.max() == 8
+
+
+def test_flame_head_laplacian_apply_and_forward_cpu(flame_model):
+    from vhap_amd.flame import FlameHead
+    from oracle import torch_ref as R
+    model, topo = flame_model
+    head = FlameHead(model, topo)
+    x = torch.randn(2, topo.num_verts, 3)
+    dense = torch.from_numpy(R.uniform_laplacian(topo.num_verts, topo.faces[: topo.num_faces_orig])).float()
+    assert torch.allclose(head.laplacian_apply(x), dense @ x, atol=1e-5)
+    g = torch.Generator().manual_seed(0)
+    B = 2
+    args = [torch.randn(B, 300, generator=g) * 0.3, torch.randn(B, 100, generator=g) * 0.3] + \
+           [torch.randn(B, 3, generator=g) * 0.1 for _ in range(3)] + [torch.randn(B, 6, generator=g) * 0.1, torch.randn(B, 3, generator=g) * 0.01]
+    off = torch.randn(1, topo.num_verts, 3, generator=g) * 1e-3
+    verts, cano, lmks = head(*args, return_verts_cano=True, static_offset=off)
+    tm = {k: torch.from_numpy(np.asarray(v)) for k, v in model.items()}
+    v2, c2, l2 = R.flame_forward(tm, *args, static_offset=off)
+    assert torch.allclose(verts, v2, atol=2e-6) and torch.allclose(cano, c2, atol=1e-6) and torch.allclose(lmks, l2, atol=2e-6)
+
+
+def test_config_mirrors_reference_defaults():
+    from vhap_amd.config import BaseTrackingConfig, PhotometricStageConfig, nersemble_config
+    cfg = BaseTrackingConfig()
+    assert (cfg.w.landmark, cfg.w.photo, cfg.w.reg_tex_tv, cfg.lr.expr, cfg.batch_size) == (10.0, 30.0, 1e4, 5e-2, 16)
+    assert cfg.pipeline["rgb_init_texture"].align_texture_except == ("hair", "boundary", "neck")
+    assert cfg.w["reg_neck"] == 0.3
+    assert isinstance(cfg.pipeline["rgb_global_tracking"], PhotometricStageConfig)
+    with pytest.raises(AttributeError):
+        cfg.pipeline["nope"]
+    c2 = BaseTrackingConfig()
+    c2.model.use_static_offset = False
+    c2.__post_init__()
+    assert "hair" in c2.pipeline.rgb_init_all.align_boundary_except            # base.py:341-347
+    n = nersemble_config()
+    assert n.w.landmark == 3.0 and n.data.calibrated and "texture" not in n.pipeline.rgb_sequential_tracking.optimizable_params

@@ -1,0 +1,175 @@
+"""CPU tests: the oracle and the product's host-side mirrors against golden vectors produced by the
+reference's own Python code (tools/make_golden.py), plus the known-answer tests we had to author for the
+raster conventions (the reference has none -- SURVEY.md section 4)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import torch_ref as R
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_golden.npz"))
+T = lambda k: torch.from_numpy(GOLD[k])
+
+
+@pytest.mark.parametrize("impl", ["oracle", "product"])
+def test_lbs_matches_reference_lbs_py(impl):
+    if impl == "oracle":
+        rod, lbs_fn, lm_fn = R.batch_rodrigues, R.lbs, R.vertices2landmarks
+        bs = lambda b, s: torch.einsum("bl,mkl->bmk", b, s)
+    else:
+        from vhap_amd import lbs as L
+        rod, lbs_fn, lm_fn, bs = L.batch_rodrigues, L.lbs, L.vertices2landmarks, L.blend_shapes
+    assert torch.allclose(rod(T("pose").view(-1, 3)), T("rodrigues"), atol=1e-6)
+    v_shaped = T("v_template")[None] + bs(T("betas"), T("shapedirs"))
+    assert torch.allclose(v_shaped, T("v_shaped"), atol=1e-6)
+    verts, Jt, A1 = lbs_fn(T("pose"), v_shaped, T("posedirs"), T("J_regressor"), T("parents"), T("lbs_weights"))
+    assert torch.allclose(verts, T("verts"), atol=2e-6)
+    assert torch.allclose(Jt, T("J_transformed"), atol=2e-6)
+    assert torch.allclose(A1, T("A1"), atol=2e-6)
+    if impl == "oracle":
+        lm = lm_fn(T("verts"), T("faces"), T("lmk_idx")[0], T("lmk_bary")[0])
+    else:
+        lm = lm_fn(T("verts"), T("faces"), T("lmk_idx"), T("lmk_bary"))
+    assert torch.allclose(lm, T("lmks"), atol=1e-6)
+
+
+def test_lbs_identity_known_answer():
+    z = torch.zeros(2, 15)
+    v = T("v_template")[None].repeat(2, 1, 1)
+    verts, _, _ = R.lbs(z, v, T("posedirs"), T("J_regressor"), T("parents"), T("lbs_weights"))
+    assert torch.allclose(verts, v, atol=1e-6)                 # zero pose -> template (to the 1e-8 epsilon)
+
+
+def test_rodrigues_matches_scipy():
+    from scipy.spatial.transform import Rotation
+    r = torch.randn(20, 3, dtype=torch.float64, generator=torch.Generator().manual_seed(0))
+    assert np.allclose(R.batch_rodrigues(r).numpy(), Rotation.from_rotvec(r.numpy()).as_matrix(), atol=1e-6)
+
+
+@pytest.mark.parametrize("impl", ["oracle", "product"])
+def test_camera_and_sh_match_reference(impl):
+    if impl == "oracle":
+        proj = R.projection_from_intrinsics
+        sh = lambda n, l: R.get_SH_shading(n, l, T("sh_const"))
+        mvp = lambda RT, K, s: R.projection_from_intrinsics(K, s) @ R._mv(RT)
+    else:
+        from vhap_amd.render_hip import HipDiffRenderer, get_SH_shading
+        r = HipDiffRenderer(lighting_type="SH")
+        proj, mvp = r.projection_from_intrinsics, r.mvp_from_camera_param
+        sh = lambda n, l: get_SH_shading(n, l, r.sh_const)
+        assert torch.allclose(r.sh_const, T("sh_const"), atol=1e-7)
+    assert torch.allclose(proj(T("K4"), (512, 512)), T("P4"), atol=1e-6)
+    assert torch.allclose(proj(T("K33"), (550, 802)), T("P33"), atol=1e-6)
+    assert torch.allclose(mvp(T("RT"), T("K4"), (512, 512)), T("mvp"), atol=1e-5)
+    assert torch.allclose(sh(T("normals"), T("lights")), T("sh"), atol=1e-5)
+    with pytest.raises(ValueError):
+        proj(torch.zeros(1, 5), (4, 4))
+
+
+def test_sh_uniform_light_is_one_and_projection_values():
+    lights = torch.zeros(1, 9, 3)
+    lights[0, 0] = np.sqrt(4 * np.pi)
+    n = torch.nn.functional.normalize(torch.randn(1, 3, 3, 3), dim=-1)
+    assert torch.allclose(R.get_SH_shading(n, lights, R.sh_const()), torch.ones(1, 3, 3, 3), atol=1e-6)
+    P = R.projection_from_intrinsics(torch.tensor([[768.0, 768.0, 256.0, 256.0]]), (512, 512))
+    assert abs(float(P[0, 0, 0]) - 3.0) < 1e-6 and abs(float(P[0, 2, 2]) + 1.0202) < 1e-4 and abs(float(P[0, 2, 3]) + 0.20202) < 1e-4
+
+
+def test_normalize_image_points_matches_reference():
+    from vhap_amd.tracker import normalize_image_points
+    u, v = normalize_image_points(torch.tensor([0.0, 100.0, 512.0]), torch.tensor([10.0, 256.0, 300.0]), (512, 400))
+    assert torch.allclose(u, T("norm_u")) and torch.allclose(v, T("norm_v"))
+
+
+# ---- raster known answers (conventions of oracle/raster_oracle.c) ----
+
+def _tri(pos, tri, res):
+    return oracle.rasterize(np.asarray(pos, np.float32)[None], np.asarray(tri, np.int32), res)
+
+
+def test_raster_single_triangle_analytic():
+    H = W = 32
+    pos = [[-0.5, -0.5, 0.25, 1], [0.5, -0.5, 0.25, 1], [-0.5, 0.5, 0.25, 1]]
+    rast, db = _tri(pos, [[0, 1, 2]], (H, W))
+    ys, xs = np.nonzero(rast[0, :, :, 3])
+    fx, fy = (2 * xs + 1) / W - 1, (2 * ys + 1) / H - 1
+    # coverage: pixel centres with x > -0.5, y > -0.5, x + y < 0 (edges excluded/included by the fill rule)
+    inside = (fx > -0.5) & (fy > -0.5) & (fx + fy < 0)
+    assert inside.all()
+    u, v = rast[0, ys, xs, 0], rast[0, ys, xs, 1]
+    assert np.allclose(u, 1 - (fx + 0.5) - (fy + 0.5), atol=1e-6)      # weight of vertex 0
+    assert np.allclose(v, fx + 0.5, atol=1e-6)                          # weight of vertex 1
+    assert np.allclose(rast[0, ys, xs, 2], 0.25, atol=1e-7)
+    assert np.allclose(db[0, ys, xs], [-2 / W, -2 / H, 2 / W, 0], atol=1e-7)
+
+
+def test_raster_tiebreak_cull_depth_and_watertight():
+    H = W = 64
+    quad = [[-1, -1, 0.9, 1], [1, -1, 0.9, 1], [1, 1, 0.9, 1], [-1, 1, 0.9, 1]]
+    rast, _ = _tri(quad, [[0, 1, 2], [0, 2, 3]], (H, W))
+    ids = rast[0, :, :, 3]
+    assert (ids > 0).all() and set(np.unique(ids)) == {1.0, 2.0}        # no holes, no double hits by construction
+    rast, _ = _tri(quad, [[0, 2, 1]], (H, W))
+    assert (rast[0, :, :, 3] == 0).all()                               # clockwise = back-facing = culled
+    two = quad + [[-1, -1, 0.1, 1], [1, -1, 0.1, 1], [1, 1, 0.1, 1]]
+    rast, _ = _tri(two, [[0, 1, 2], [4, 5, 6], [4, 5, 6]], (H, W))
+    ids = rast[0, :, :, 3]
+    assert (ids > 0).sum() > H * W // 3 and set(np.unique(ids[ids > 0])) == {2.0}   # nearer wins; exact tie -> lowest id
+    far = [[-1, -1, 1.5, 1], [1, -1, 1.5, 1], [1, 1, 1.5, 1]]
+    rast, _ = _tri(far, [[0, 1, 2]], (H, W))
+    assert (rast[0, :, :, 3] == 0).all()                               # beyond the far plane
+
+
+def test_raster_shared_edge_random_meshes_have_no_double_coverage():
+    rng = np.random.default_rng(0)
+    H, W = 48, 40
+    for _ in range(5):
+        n = 8
+        gx, gy = np.meshgrid(np.linspace(-0.9, 0.9, n), np.linspace(-0.9, 0.9, n))
+        p = np.stack([gx + rng.normal(0, 0.03, gx.shape), gy + rng.normal(0, 0.03, gy.shape)], -1).reshape(-1, 2)
+        pos = np.concatenate([p, np.zeros((n * n, 1)), np.ones((n * n, 1))], 1)
+        tri = []
+        for j in range(n - 1):
+            for i in range(n - 1):
+                a = j * n + i
+                tri += [[a, a + 1, a + n + 1], [a, a + n + 1, a + n]]
+        rast, _ = _tri(pos, tri, (H, W))
+        # every triangle alone covers a set; the sets must partition the union exactly (no overlap)
+        cover = np.zeros((H, W), int)
+        for t in tri:
+            r1, _ = _tri(pos, [t], (H, W))
+            cover += (r1[0, :, :, 3] > 0)
+        assert cover.max() == 1
+        assert ((cover > 0) == (rast[0, :, :, 3] > 0)).all()
+
+
+def test_texture_known_answers_oracle():
+    tex = torch.full((1, 16, 16, 3), 0.37, dtype=torch.float64)
+    uv = torch.rand(1, 4, 4, 2, dtype=torch.float64)
+    for s in (1e-4, 1e-2, 0.1, 1.0):
+        da = torch.full((1, 4, 4, 4), s, dtype=torch.float64)
+        assert torch.allclose(R.texture(tex, uv, da), torch.full((1, 4, 4, 3), 0.37, dtype=torch.float64))
+    yy, xx = torch.meshgrid(torch.arange(16), torch.arange(16), indexing="ij")
+    cb = ((xx + yy) % 2).double()[None, :, :, None]
+    da = torch.zeros(1, 4, 4, 4, dtype=torch.float64)
+    da[..., 0] = 2.0 / 16
+    da[..., 3] = 2.0 / 16
+    assert torch.allclose(R.texture(cb, uv, da), torch.full((1, 4, 4, 1), 0.5, dtype=torch.float64))
+
+
+def test_oracle_backward_matches_finite_differences():
+    """fp64 finite differences of the differentiable oracle ops (the backward oracle is autograd of these)."""
+    g = torch.Generator().manual_seed(0)
+    tex = torch.rand(1, 8, 8, 2, dtype=torch.float64, generator=g).requires_grad_()
+    uv = (torch.rand(1, 3, 3, 2, dtype=torch.float64, generator=g) * 0.8 + 0.1).requires_grad_()
+    da = (torch.rand(1, 3, 3, 4, dtype=torch.float64, generator=g) * 0.2 + 0.15).requires_grad_()
+    assert torch.autograd.gradcheck(lambda t, u, d: R.texture(t, u, d), (tex, uv, da), eps=1e-7, atol=1e-5)
+    pos = torch.tensor([[[-0.8, -0.7, 0.1, 1.0], [0.9, -0.6, 0.2, 1.2], [0.1, 0.8, 0.3, 0.9]]], dtype=torch.float64, requires_grad=True)
+    tri = torch.tensor([[0, 1, 2]])
+    r_np, _ = oracle.rasterize(pos.detach().float().numpy(), tri.int().numpy(), (6, 6))
+    tid = torch.from_numpy(r_np[..., 3].astype(np.int64) - 1)
+    f = lambda p: torch.cat([x[..., :3] if i == 0 else x for i, x in enumerate(R.rast_from_ids(p, tri, tid, (6, 6)))], -1)
+    assert torch.autograd.gradcheck(f, (pos,), eps=1e-7, atol=1e-5)
