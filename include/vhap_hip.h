@@ -132,6 +132,66 @@ int vhap_antialias_bwd(const float* color, const float* rast, const float* pos,
                        const int32_t* work, int B, int H, int W, int C, int V, int F,
                        float* d_color, float* d_pos, vhap_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Per-pixel shading / compositing and the photometric sum (vhap_amd/csrc/pixel.hip).
+ * Replace render_nvdiffrast.py:386 (safe_normalize), :402-421 (SH shade, rgb = albedo*diffuse, alpha,
+ * background composite with the y-flip of :419) and tracker.py:430-439 / :547-550.
+ *   normal_raw, albedo [B,H,W,3]; rast [B,H,W,4]; bg_image [B,3,H,W] in IMAGE space (row 0 = top) or
+ *   NULL, in which case bg_color (HOST pointer to 3 floats) is used; lights [9,3]; sh_const [9].
+ *   rgba [B,H,W,4] in renderer space.  stats (2 words, may be NULL): [0] = max(diffuse) as an
+ *   order-preserving uint, [1] = sum over pixels of the unbiased variance of diffuse across RGB.
+ * Backward: d_albedo / d_normal_raw [B,H,W,3] overwritten (either may be NULL); d_lights [9,3]
+ * ACCUMULATED (may be NULL).  d_reg (device scalar, may be NULL) is the upstream gradient of
+ * reg = relu(max(diffuse) - 1) + mean(var); it reaches d_lights only, like the reference's
+ * shade(normal.detach()).
+ * ------------------------------------------------------------------------------------------- */
+int vhap_shade_fwd(const float* normal_raw, const float* albedo, const float* rast,
+                   const float* bg_image, const float* bg_color, const float* lights,
+                   const float* sh_const, int B, int H, int W, float* rgba, float* stats,
+                   vhap_stream_t stream);
+int vhap_shade_bwd(const float* normal_raw, const float* albedo, const float* rast,
+                   const float* lights, const float* sh_const, const float* d_rgba,
+                   const float* d_reg, const float* stats, int B, int H, int W, float* d_albedo,
+                   float* d_normal_raw, float* d_lights, vhap_stream_t stream);
+/* out2[0] = sum |gt - pred_rgb|, out2[1] = #(pred_alpha > 0); pred [B,H,W,4] renderer space,
+ * gt [B,3,H,W] image space.  Backward: d_pred.rgb = -sign(gt - pred) * d_sum[0] (device scalar). */
+int vhap_photo_fwd(const float* pred_rgba, const float* gt_nchw, int B, int H, int W, float* out2,
+                   vhap_stream_t stream);
+int vhap_photo_bwd(const float* pred_rgba, const float* gt_nchw, const float* d_sum, int B, int H,
+                   int W, float* d_pred, vhap_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * FLAME geometry (vhap_amd/csrc/flame.hip): replaces lbs.blend_shapes (vhap/model/lbs.py:218-239), the
+ * pose-corrective matmul (:164-166) and the skinning (:182-193) of FlameHead.forward
+ * (vhap/model/flame.py:595-634); world->clip (render_nvdiffrast.py:162-206); compute_v_normals (:297-316).
+ *   coef  [Bp,Kp]  per-frame coefficients (shape|expr|pose_feature), rows padded to 16, zero-filled
+ *   basis [3,K,Vp] K-major per component; basisT [3,Vp,Kp] vertex-major (backward); Vp % 64 == 0
+ *   A [B,5,12] relative joint transforms (3x4 row-major); Kb = number of shape+expr rows
+ * skin_bwd: d_coef [Bp,Kp] overwritten, d_A [B,5,12] / d_transl [B,3] ACCUMULATED (caller zero-fills),
+ *   g_posed / g_shaped [B,V,3] scratch (g_shaped = gradient w.r.t. v_shaped incl. d_vshaped),
+ *   partials: vhap_flame_bwd_partial_floats() floats.
+ * ------------------------------------------------------------------------------------------- */
+int vhap_flame_skin_fwd(const float* coef, const float* basis, const float* A,
+                        const float* lbs_weights, const float* v_template, const float* offset,
+                        const float* transl, int B, int V, int Vp, int K, int Kb, int Kp,
+                        float* verts, float* v_shaped, float* v_posed, vhap_stream_t stream);
+size_t vhap_flame_bwd_partial_floats(int B, int Vp, int Kp);
+int vhap_flame_skin_bwd(const float* d_verts, const float* d_vshaped, const float* v_posed,
+                        const float* A, const float* lbs_weights, const float* basisT, int B, int V,
+                        int Vp, int Kb, int Kp, float* g_posed, float* g_shaped, float* partials,
+                        float* d_coef, float* d_A, float* d_transl, vhap_stream_t stream);
+/* clip [B,V,4] = [verts;1] @ M^T, M [B,4,4]; backward: d_verts (= or += when accumulate), d_M ACCUMULATED */
+int vhap_transform_fwd(const float* verts, const float* M, int B, int V, float* clip,
+                       vhap_stream_t stream);
+int vhap_transform_bwd(const float* verts, const float* M, const float* d_clip, int B, int V,
+                       int accumulate, float* d_verts, float* d_M, vhap_stream_t stream);
+/* vertex normals over the static vertex->corner CSR (vc_ptr [V+1], vc_idx [3F]); scratch [B,V,3] */
+int vhap_vnormal_fwd(const float* verts, const int32_t* tri, const int32_t* vc_ptr,
+                     const int32_t* vc_idx, int B, int V, float* vn, vhap_stream_t stream);
+int vhap_vnormal_bwd(const float* verts, const int32_t* tri, const int32_t* vc_ptr,
+                     const int32_t* vc_idx, const float* d_vn, int B, int V, int accumulate,
+                     float* scratch, float* d_verts, vhap_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,110 @@
+"""GPU parity of the fused stages (vhap_amd.fused) against the host-side torch ops they replace (which are
+themselves checked against the oracle in test_energy_gpu.py): values to 1e-5, gradients to 2e-3 relative."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def _head(flame_model, fused):
+    from vhap_amd.flame import FlameHead
+    model, topo = flame_model
+    h = FlameHead(model, topo).cuda()
+    h.fused = fused
+    return h
+
+
+@pytest.mark.parametrize("B", [16, 5, 19])
+def test_flame_forward_backward_matches_host_ops(flame_model, B):
+    g = torch.Generator().manual_seed(B)
+    r = lambda *s: torch.randn(*s, generator=g)
+    args0 = [r(B, 300) * 0.3, r(B, 100) * 0.3, r(B, 3) * 0.2, r(B, 3) * 0.05, r(B, 3) * 0.1, r(B, 6) * 0.05, r(B, 3) * 0.01]
+    off0 = r(1, 5143, 3) * 1e-3
+    w_v, w_c, w_l = r(B, 5143, 3), r(B, 5143, 3), r(B, 70, 3)
+    res = []
+    for fused in (False, True):
+        head = _head(flame_model, fused)
+        args = [a.clone().cuda().requires_grad_() for a in args0]
+        off = off0.clone().cuda().requires_grad_()
+        verts, cano, lmks = head(*args, return_verts_cano=True, static_offset=off)
+        ((verts * w_v.cuda()).sum() + (cano * w_c.cuda()).sum() * 0.1 + (lmks * w_l.cuda()).sum()).backward()
+        res.append((verts.detach(), cano.detach(), lmks.detach(), [a.grad for a in args] + [off.grad]))
+    (v0, c0, l0, g0), (v1, c1, l1, g1) = res
+    assert (v0 - v1).abs().max() < 2e-6 and (c0 - c1).abs().max() < 1e-6 and (l0 - l1).abs().max() < 2e-6
+    for a, b in zip(g1, g0):
+        assert _rel(a, b) < 2e-3
+
+
+def test_transform_and_vertex_normals_match_host_ops(flame_model):
+    from vhap_amd import fused as FU
+    from vhap_amd.render_hip import HipDiffRenderer
+    model, topo = flame_model
+    g = torch.Generator().manual_seed(0)
+    B, V = 3, topo.num_verts
+    verts0 = (torch.from_numpy(model["v_template"])[None] + torch.randn(B, V, 3, generator=g) * 1e-3).cuda()
+    faces = torch.from_numpy(topo.faces.astype(np.int64)).cuda()
+    M0 = torch.randn(B, 4, 4, generator=g).cuda()
+    w4, w3 = torch.randn(B, V, 4, generator=g).cuda(), torch.randn(B, V, 3, generator=g).cuda()
+    out = []
+    for fused in (False, True):
+        r = HipDiffRenderer(lighting_type="SH").cuda()
+        r.fused = fused
+        verts = verts0.clone().requires_grad_()
+        M = M0.clone().requires_grad_()
+        clip = FU.transform(verts, M) if fused else torch.matmul(torch.nn.functional.pad(verts, [0, 1], value=1.0), M.transpose(-1, -2))
+        vn = r.compute_v_normals(verts, faces)
+        ((clip * w4).sum() + (vn * w3).sum()).backward()
+        out.append((clip.detach(), vn.detach(), verts.grad, M.grad))
+    for a, b in zip(out[1], out[0]):
+        assert _rel(a, b) < 2e-3
+    assert (out[0][1] - out[1][1]).abs().max() < 1e-5
+
+
+def test_shade_and_photo_match_host_ops():
+    from vhap_amd import fused as FU
+    from vhap_amd.render_hip import HipDiffRenderer, get_SH_shading, safe_normalize
+    g = torch.Generator().manual_seed(1)
+    B, H, W = 2, 40, 24
+    nraw0 = torch.randn(B, H, W, 3, generator=g).cuda() * 0.5
+    nraw0[0, 0, :3] = 0                                          # zero-length normals hit the eps clamp
+    alb0 = torch.rand(B, H, W, 3, generator=g).cuda()
+    lights0 = (torch.randn(1, 9, 3, generator=g) * 0.2).cuda()
+    lights0[0, 0] += 3.5449
+    rast = torch.zeros(B, H, W, 4).cuda()
+    rast[..., 3] = (torch.rand(B, H, W, generator=g) > 0.4).float().cuda() * 7
+    gt = torch.rand(B, 3, H, W, generator=g).cuda()
+    wgt = torch.randn(B, H, W, 4, generator=g).cuda()
+    r = HipDiffRenderer(lighting_type="SH").cuda()
+    outs = []
+    for fused in (False, True):
+        nraw, alb, lights = nraw0.clone().requires_grad_(), alb0.clone().requires_grad_(), lights0.clone().requires_grad_()
+        if fused:
+            rgba, reg = FU.shade(nraw, alb, lights, rast, gt.permute(0, 2, 3, 1), r.sh_const, want_reg=True)
+            S, N = FU.photo_sum(rgba, gt)
+        else:
+            n = safe_normalize(nraw)
+            d = get_SH_shading(n, lights, r.sh_const)
+            dd = get_SH_shading(n.detach(), lights, r.sh_const)
+            fg = rast[..., 3:4] > 0
+            rgba = torch.where(fg, torch.cat([alb * d, fg.float()], -1), torch.cat([gt.permute(0, 2, 3, 1), torch.zeros(B, H, W, 1).cuda()], -1).flip(1))
+            ddn = dd.permute(0, 3, 1, 2)
+            reg = torch.relu(ddn.max() - 1) + ddn.var(dim=1).mean()
+            pred = rgba.flip(1).permute(0, 3, 1, 2)
+            S = (gt - pred[:, :3]).abs().sum()
+            N = (pred[:, 3:] > 0).sum().float()
+        ((rgba * wgt).sum() + 100.0 * reg + 0.3 * S / (3 * N)).backward()
+        outs.append((rgba.detach(), reg.detach(), S.detach(), N.detach(), nraw.grad, alb.grad, lights.grad))
+    a, b = outs[1], outs[0]
+    assert (a[0] - b[0]).abs().max() < 1e-5 and abs(float(a[1] - b[1])) < 1e-5 * max(1, abs(float(b[1])))
+    assert abs(float(a[2] - b[2])) < 1e-4 * float(b[2]) and float(a[3]) == float(b[3])
+    msk = torch.ones_like(a[4], dtype=torch.bool)
+    msk[0, 0, :3] = False                                        # 1e10-scaled gradients of the clamped normals: compare separately
+    assert _rel(a[4][msk], b[4][msk]) < 2e-3
+    assert _rel(a[4][~msk], b[4][~msk]) < 2e-3 or float(b[4][~msk].abs().max()) == 0
+    assert _rel(a[5], b[5]) < 2e-3 and _rel(a[6], b[6]) < 2e-3

@@ -36,6 +36,17 @@ SIGNATURES = {
     "vhap_antialias_work_ints": (c_sz, [c_i] * 3),
     "vhap_antialias_fwd": (c_i, [c_fp] * 5 + [c_i] * 6 + [c_fp, c_fp, c_fp]),
     "vhap_antialias_bwd": (c_i, [c_fp] * 7 + [c_i] * 6 + [c_fp, c_fp, c_fp]),
+    "vhap_shade_fwd": (c_i, [c_fp] * 7 + [c_i] * 3 + [c_fp] * 3),
+    "vhap_shade_bwd": (c_i, [c_fp] * 8 + [c_i] * 3 + [c_fp] * 4),
+    "vhap_photo_fwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp]),
+    "vhap_photo_bwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp]),
+    "vhap_flame_skin_fwd": (c_i, [c_fp] * 7 + [c_i] * 6 + [c_fp] * 4),
+    "vhap_flame_bwd_partial_floats": (c_sz, [c_i] * 3),
+    "vhap_flame_skin_bwd": (c_i, [c_fp] * 6 + [c_i] * 5 + [c_fp] * 7),
+    "vhap_transform_fwd": (c_i, [c_fp, c_fp, c_i, c_i, c_fp, c_fp]),
+    "vhap_transform_bwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
+    "vhap_vnormal_fwd": (c_i, [c_fp] * 4 + [c_i, c_i, c_fp, c_fp]),
+    "vhap_vnormal_bwd": (c_i, [c_fp] * 5 + [c_i, c_i, c_i, c_fp, c_fp, c_fp]),
 }
 
 _lib = None

@@ -1,0 +1,443 @@
+// FLAME geometry kernels for gfx950: blendshapes + pose correctives + linear blend skinning
+// (vhap/model/flame.py:595-634, vhap/model/lbs.py:218-239 blend_shapes, :164-166 pose offsets,
+// :182-193 skinning), camera transform (vhap/util/render_nvdiffrast.py:162-206) and area-weighted
+// vertex normals (:297-316), each with its backward.
+//
+// The two dense contractions -- [B,436] x [436,3V] forward and its transpose [B,3V] x [3V,436]
+// backward -- run on the matrix cores with the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32): 16 frames are
+// the M dimension, so one wave produces a 16-frame x 16-vertex tile per component and keeps x, y, z of a
+// vertex in the SAME lane, which lets the skinning epilogue run in registers (the reference materialises
+// [B,V,4,4] transforms).  The basis is stored once per component, K-major for the forward
+// ([3][K][Vp]) and vertex-major for the backward ([3][Vp][Kp]), so every MFMA operand load is a 64-byte
+// run and consecutive tiles are contiguous.  Everything else is one thread per (frame, vertex).
+// The tiny per-frame algebra (Rodrigues, joint regression, kinematic chain) stays on the host side.
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int NJ = 5;  // FLAME joints
+
+// grid (Vp/64, ceil(B/16)), 64 threads.  coef [Bp,Kp] (rows padded to 16, zero-filled), basis [3][K][Vp],
+// A [B,5,12] (row-major 3x4 per joint), w [V,5], templ [V,3], offset [V,3] or null, transl [B,3]
+__global__ __launch_bounds__(64) void flame_skin_fwd_kernel(const float* __restrict__ coef, const float* __restrict__ basis,
+                                                            const float* __restrict__ A, const float* __restrict__ w,
+                                                            const float* __restrict__ templ, const float* __restrict__ offset,
+                                                            const float* __restrict__ transl, int B, int V, int Vp, int K,
+                                                            int Kb, int Kp, float* __restrict__ verts,
+                                                            float* __restrict__ v_shaped, float* __restrict__ v_posed) {
+    __shared__ float sA[16 * NJ * 12];
+    __shared__ float sT[16 * 3];
+    const int lane = threadIdx.x;
+    const int v0 = blockIdx.x * 64, b0 = blockIdx.y * 16;
+    for (int i = lane; i < 16 * NJ * 12; i += 64) {
+        const int f = i / (NJ * 12);
+        sA[i] = (b0 + f < B) ? A[(size_t)(b0 + f) * NJ * 12 + (i - f * NJ * 12)] : 0.f;
+    }
+    if (lane < 48) sT[lane] = (b0 + lane / 3 < B) ? transl[(size_t)(b0 + lane / 3) * 3 + lane % 3] : 0.f;
+    __syncthreads();
+    const int li = lane & 15, lk = lane >> 4;
+    const float* cf = coef + (size_t)(b0 + li) * Kp + lk;
+    f32x4 acc[4][3];
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const size_t cs = (size_t)K * Vp;  // component stride
+    auto run = [&](int k_begin, int k_end) {
+        for (int k = k_begin; k < k_end; k += 4) {
+            const float a = cf[k];
+            const float* bp = basis + (size_t)(k + lk) * Vp + v0 + li;
+#pragma unroll
+            for (int t = 0; t < 4; t++)
+#pragma unroll
+                for (int c = 0; c < 3; c++)
+                    acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bp[c * cs + 16 * t], acc[t][c], 0, 0, 0);
+        }
+    };
+    run(0, Kb);  // shape + expression (Kb is a multiple of 4)
+    float vs[4][4][3];  // [tile][frame r][component]
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int v = v0 + 16 * t + li;
+        float tx = 0.f, ty = 0.f, tz = 0.f;
+        if (v < V) {
+            tx = templ[3 * v]; ty = templ[3 * v + 1]; tz = templ[3 * v + 2];
+            if (offset) { tx += offset[3 * v]; ty += offset[3 * v + 1]; tz += offset[3 * v + 2]; }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            vs[t][r][0] = tx + acc[t][0][r]; vs[t][r][1] = ty + acc[t][1][r]; vs[t][r][2] = tz + acc[t][2][r];
+            const int f = b0 + lk * 4 + r;
+            if (v < V && f < B) {
+                float* o = v_shaped + ((size_t)f * V + v) * 3;
+                o[0] = vs[t][r][0]; o[1] = vs[t][r][1]; o[2] = vs[t][r][2];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    run(Kb, K);  // pose correctives
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        const int v = v0 + 16 * t + li;
+        if (v >= V) continue;
+        float wj[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; j++) wj[j] = w[(size_t)v * NJ + j];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int fl = lk * 4 + r, f = b0 + fl;
+            if (f >= B) continue;
+            const float px = vs[t][r][0] + acc[t][0][r], py = vs[t][r][1] + acc[t][1][r], pz = vs[t][r][2] + acc[t][2][r];
+            float T[12];
+#pragma unroll
+            for (int q = 0; q < 12; q++) {
+                float s = 0.f;
+#pragma unroll
+                for (int j = 0; j < NJ; j++) s += wj[j] * sA[(fl * NJ + j) * 12 + q];
+                T[q] = s;
+            }
+            const size_t o = ((size_t)f * V + v) * 3;
+            v_posed[o] = px; v_posed[o + 1] = py; v_posed[o + 2] = pz;
+            verts[o] = T[0] * px + T[1] * py + T[2] * pz + T[3] + sT[fl * 3];
+            verts[o + 1] = T[4] * px + T[5] * py + T[6] * pz + T[7] + sT[fl * 3 + 1];
+            verts[o + 2] = T[8] * px + T[9] * py + T[10] * pz + T[11] + sT[fl * 3 + 2];
+        }
+    }
+}
+
+// grid (ceil(V/256), B).  d_verts -> G_posed (= T_R^T d_vert), d_A [B,5,12] (atomics), d_transl [B,3] (atomics),
+// G_shaped = G_posed + d_vshaped (if given)
+__global__ __launch_bounds__(256) void flame_skin_bwd_kernel(const float* __restrict__ d_verts, const float* __restrict__ d_vshaped,
+                                                             const float* __restrict__ v_posed, const float* __restrict__ A,
+                                                             const float* __restrict__ w, int B, int V,
+                                                             float* __restrict__ g_posed, float* __restrict__ g_shaped,
+                                                             float* __restrict__ d_A, float* __restrict__ d_transl) {
+    __shared__ float sA[NJ * 12];
+    __shared__ float red[4][NJ * 12 + 3];
+    const int b = blockIdx.y, v = blockIdx.x * 256 + threadIdx.x;
+    if (threadIdx.x < NJ * 12) sA[threadIdx.x] = A[(size_t)b * NJ * 12 + threadIdx.x];
+    __syncthreads();
+    float gA[NJ * 12 + 3];
+#pragma unroll
+    for (int i = 0; i < NJ * 12 + 3; i++) gA[i] = 0.f;
+    if (v < V) {
+        const size_t o = ((size_t)b * V + v) * 3;
+        const float gx = d_verts[o], gy = d_verts[o + 1], gz = d_verts[o + 2];
+        const float px = v_posed[o], py = v_posed[o + 1], pz = v_posed[o + 2];
+        float wj[NJ], T[12];
+#pragma unroll
+        for (int j = 0; j < NJ; j++) wj[j] = w[(size_t)v * NJ + j];
+#pragma unroll
+        for (int q = 0; q < 12; q++) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < NJ; j++) s += wj[j] * sA[j * 12 + q];
+            T[q] = s;
+        }
+        const float hx = T[0] * gx + T[4] * gy + T[8] * gz;
+        const float hy = T[1] * gx + T[5] * gy + T[9] * gz;
+        const float hz = T[2] * gx + T[6] * gy + T[10] * gz;
+        g_posed[o] = hx; g_posed[o + 1] = hy; g_posed[o + 2] = hz;
+        if (g_shaped) {
+            g_shaped[o] = hx + (d_vshaped ? d_vshaped[o] : 0.f);
+            g_shaped[o + 1] = hy + (d_vshaped ? d_vshaped[o + 1] : 0.f);
+            g_shaped[o + 2] = hz + (d_vshaped ? d_vshaped[o + 2] : 0.f);
+        }
+        const float dT[12] = {gx * px, gx * py, gx * pz, gx, gy * px, gy * py, gy * pz, gy, gz * px, gz * py, gz * pz, gz};
+#pragma unroll
+        for (int j = 0; j < NJ; j++)
+#pragma unroll
+            for (int q = 0; q < 12; q++) gA[j * 12 + q] = wj[j] * dT[q];
+        gA[NJ * 12] = gx; gA[NJ * 12 + 1] = gy; gA[NJ * 12 + 2] = gz;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NJ * 12 + 3; i++) {
+        const float s = vhap_wave_sum(gA[i]);
+        if (lane == 0) red[wave][i] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NJ * 12 + 3) {
+        const float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        if (threadIdx.x < NJ * 12) atomicAdd(&d_A[(size_t)b * NJ * 12 + threadIdx.x], s);
+        else atomicAdd(&d_transl[(size_t)b * 3 + threadIdx.x - NJ * 12], s);
+    }
+}
+
+// d_coef partials: grid (Vp/64, ceil(B/16)), 256 threads = 4 waves; wave w owns n-tiles [7w, 7w+7) of Kp/16 = 28.
+// part [gridDim.x][Bp][Kp]
+__global__ __launch_bounds__(256) void flame_coef_bwd_kernel(const float* __restrict__ g_shaped, const float* __restrict__ g_posed,
+                                                             const float* __restrict__ basisT, int B, int V, int Vp, int Kb,
+                                                             int Kp, int ntile_per_wave, float* __restrict__ part) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int v0 = blockIdx.x * 64, b0 = blockIdx.y * 16;
+    const int Bp = gridDim.y * 16;
+    const int nt0 = wave * ntile_per_wave;
+    const int ntiles = Kp / 16;
+    f32x4 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool bvalid = b0 + li < B;
+    const size_t cs = (size_t)Vp * Kp;
+    for (int ks = 0; ks < 16; ks++) {
+        const int v = v0 + ks * 4 + lk;
+        const bool ok = bvalid && v < V;
+        const size_t go = ((size_t)(b0 + li) * V + v) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float as = ok ? g_shaped[go + c] : 0.f;
+            const float ap = ok ? g_posed[go + c] : 0.f;
+            const float* bp = basisT + c * cs + (size_t)v * Kp + li;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int nt = nt0 + i;
+                if (i < ntile_per_wave && nt < ntiles) {
+                    const float a = (nt * 16 < Kb) ? as : ap;   // tiles never straddle Kb (Kb is a multiple of 16)
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bp[nt * 16], acc[i], 0, 0, 0);
+                }
+            }
+        }
+    }
+    float* out = part + (size_t)blockIdx.x * Bp * Kp;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const int nt = nt0 + i;
+        if (i < ntile_per_wave && nt < ntiles) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) out[(size_t)(b0 + lk * 4 + r) * Kp + nt * 16 + li] = acc[i][r];
+        }
+    }
+}
+
+// sum partials over the leading dimension: out [n] = sum_p part[p][n]
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int P, int n, float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int p = 0; p < P; p++) s += part[(size_t)p * n + i];
+    out[i] = s;
+}
+
+// clip = [v;1] @ M^T with M [B,4,4] row-major (clip_r = M[r][0..2].v + M[r][3])
+__global__ __launch_bounds__(256) void transform_fwd_kernel(const float* __restrict__ verts, const float* __restrict__ M, int V,
+                                                            float4* __restrict__ clip) {
+    __shared__ float sM[16];
+    const int b = blockIdx.y, v = blockIdx.x * 256 + threadIdx.x;
+    if (threadIdx.x < 16) sM[threadIdx.x] = M[(size_t)b * 16 + threadIdx.x];
+    __syncthreads();
+    if (v >= V) return;
+    const float* p = verts + ((size_t)b * V + v) * 3;
+    const float x = p[0], y = p[1], z = p[2];
+    clip[(size_t)b * V + v] = make_float4(sM[0] * x + sM[1] * y + sM[2] * z + sM[3], sM[4] * x + sM[5] * y + sM[6] * z + sM[7],
+                                           sM[8] * x + sM[9] * y + sM[10] * z + sM[11], sM[12] * x + sM[13] * y + sM[14] * z + sM[15]);
+}
+
+// d_clip -> d_verts (+= or =) and d_M [B,4,4] (atomics)
+__global__ __launch_bounds__(256) void transform_bwd_kernel(const float* __restrict__ verts, const float* __restrict__ M,
+                                                            const float4* __restrict__ d_clip, int V, int accumulate,
+                                                            float* __restrict__ d_verts, float* __restrict__ d_M) {
+    __shared__ float sM[16];
+    __shared__ float red[4][16];
+    const int b = blockIdx.y, v = blockIdx.x * 256 + threadIdx.x;
+    if (threadIdx.x < 16) sM[threadIdx.x] = M[(size_t)b * 16 + threadIdx.x];
+    __syncthreads();
+    float gm[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) gm[i] = 0.f;
+    if (v < V) {
+        const size_t o = ((size_t)b * V + v) * 3;
+        const float4 g = d_clip[(size_t)b * V + v];
+        const float gx = sM[0] * g.x + sM[4] * g.y + sM[8] * g.z + sM[12] * g.w;
+        const float gy = sM[1] * g.x + sM[5] * g.y + sM[9] * g.z + sM[13] * g.w;
+        const float gz = sM[2] * g.x + sM[6] * g.y + sM[10] * g.z + sM[14] * g.w;
+        if (accumulate) { d_verts[o] += gx; d_verts[o + 1] += gy; d_verts[o + 2] += gz; }
+        else { d_verts[o] = gx; d_verts[o + 1] = gy; d_verts[o + 2] = gz; }
+        if (d_M) {
+            const float x = verts[o], y = verts[o + 1], z = verts[o + 2];
+            const float gg[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+            for (int r = 0; r < 4; r++) { gm[4 * r] = gg[r] * x; gm[4 * r + 1] = gg[r] * y; gm[4 * r + 2] = gg[r] * z; gm[4 * r + 3] = gg[r]; }
+        }
+    }
+    if (d_M) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const float s = vhap_wave_sum(gm[i]);
+            if (lane == 0) red[wave][i] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < 16) atomicAdd(&d_M[(size_t)b * 16 + threadIdx.x], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+    }
+}
+
+// Area-weighted vertex normals by GATHER over the static vertex->corner CSR (deterministic, no atomics):
+// n_raw[v] = sum over incident faces of (v1-v0) x (v2-v0); fallback (0,0,1) if |n|^2 <= 1e-20; normalise.
+__global__ __launch_bounds__(256) void vnormal_fwd_kernel(const float* __restrict__ verts, const int* __restrict__ tri,
+                                                          const int* __restrict__ vc_ptr, const int* __restrict__ vc_idx, int V,
+                                                          float* __restrict__ vn) {
+    const int b = blockIdx.y, v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= V) return;
+    const float* P = verts + (size_t)b * V * 3;
+    float nx = 0.f, ny = 0.f, nz = 0.f;
+    for (int k = vc_ptr[v]; k < vc_ptr[v + 1]; k++) {
+        const int t = vc_idx[k] / 3;
+        const int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
+        const float ax = P[3 * i1] - P[3 * i0], ay = P[3 * i1 + 1] - P[3 * i0 + 1], az = P[3 * i1 + 2] - P[3 * i0 + 2];
+        const float bx = P[3 * i2] - P[3 * i0], by = P[3 * i2 + 1] - P[3 * i0 + 1], bz = P[3 * i2 + 2] - P[3 * i0 + 2];
+        nx += ay * bz - az * by; ny += az * bx - ax * bz; nz += ax * by - ay * bx;
+    }
+    float l2 = nx * nx + ny * ny + nz * nz;
+    if (!(l2 > 1e-20f)) { nx = 0.f; ny = 0.f; nz = 1.f; l2 = 1.f; }
+    const float inv = 1.0f / sqrtf(fmaxf(l2, 1e-20f));
+    float* o = vn + ((size_t)b * V + v) * 3;
+    o[0] = nx * inv; o[1] = ny * inv; o[2] = nz * inv;
+}
+
+// pass 1: d_vn -> d_nraw (through the normalisation; zero where the fallback was taken)
+__global__ __launch_bounds__(256) void vnormal_bwd1_kernel(const float* __restrict__ verts, const int* __restrict__ tri,
+                                                           const int* __restrict__ vc_ptr, const int* __restrict__ vc_idx,
+                                                           const float* __restrict__ d_vn, int V, float* __restrict__ d_nraw) {
+    const int b = blockIdx.y, v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= V) return;
+    const float* P = verts + (size_t)b * V * 3;
+    float nx = 0.f, ny = 0.f, nz = 0.f;
+    for (int k = vc_ptr[v]; k < vc_ptr[v + 1]; k++) {
+        const int t = vc_idx[k] / 3;
+        const int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
+        const float ax = P[3 * i1] - P[3 * i0], ay = P[3 * i1 + 1] - P[3 * i0 + 1], az = P[3 * i1 + 2] - P[3 * i0 + 2];
+        const float bx = P[3 * i2] - P[3 * i0], by = P[3 * i2 + 1] - P[3 * i0 + 1], bz = P[3 * i2 + 2] - P[3 * i0 + 2];
+        nx += ay * bz - az * by; ny += az * bx - ax * bz; nz += ax * by - ay * bx;
+    }
+    const size_t o = ((size_t)b * V + v) * 3;
+    const float l2 = nx * nx + ny * ny + nz * nz;
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    if (l2 > 1e-20f) {
+        const float inv = 1.0f / sqrtf(l2);
+        const float ux = nx * inv, uy = ny * inv, uz = nz * inv;
+        const float dx = d_vn[o], dy = d_vn[o + 1], dz = d_vn[o + 2];
+        const float dot = ux * dx + uy * dy + uz * dz;
+        gx = (dx - ux * dot) * inv; gy = (dy - uy * dot) * inv; gz = (dz - uz * dot) * inv;
+    }
+    d_nraw[o] = gx; d_nraw[o + 1] = gy; d_nraw[o + 2] = gz;
+}
+
+// pass 2 (gather again): for every corner (t,i) incident to v, g = d_nraw[i0]+d_nraw[i1]+d_nraw[i2];
+// fn = e1 x e2 (e1 = v1-v0, e2 = v2-v0): d e1 = e2 x g, d e2 = g x e1; corner 0 gets -(d e1 + d e2), 1 gets d e1, 2 gets d e2
+__global__ __launch_bounds__(256) void vnormal_bwd2_kernel(const float* __restrict__ verts, const int* __restrict__ tri,
+                                                           const int* __restrict__ vc_ptr, const int* __restrict__ vc_idx,
+                                                           const float* __restrict__ d_nraw, int V, int accumulate,
+                                                           float* __restrict__ d_verts) {
+    const int b = blockIdx.y, v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= V) return;
+    const float* P = verts + (size_t)b * V * 3;
+    const float* G = d_nraw + (size_t)b * V * 3;
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int k = vc_ptr[v]; k < vc_ptr[v + 1]; k++) {
+        const int c = vc_idx[k], t = c / 3, i = c - 3 * t;
+        const int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
+        const float gx = G[3 * i0] + G[3 * i1] + G[3 * i2], gy = G[3 * i0 + 1] + G[3 * i1 + 1] + G[3 * i2 + 1],
+                    gz = G[3 * i0 + 2] + G[3 * i1 + 2] + G[3 * i2 + 2];
+        const float ax = P[3 * i1] - P[3 * i0], ay = P[3 * i1 + 1] - P[3 * i0 + 1], az = P[3 * i1 + 2] - P[3 * i0 + 2];
+        const float bx = P[3 * i2] - P[3 * i0], by = P[3 * i2 + 1] - P[3 * i0 + 1], bz = P[3 * i2 + 2] - P[3 * i0 + 2];
+        const float d1x = by * gz - bz * gy, d1y = bz * gx - bx * gz, d1z = bx * gy - by * gx;   // e2 x g
+        const float d2x = gy * az - gz * ay, d2y = gz * ax - gx * az, d2z = gx * ay - gy * ax;   // g x e1
+        if (i == 0) { sx -= d1x + d2x; sy -= d1y + d2y; sz -= d1z + d2z; }
+        else if (i == 1) { sx += d1x; sy += d1y; sz += d1z; }
+        else { sx += d2x; sy += d2y; sz += d2z; }
+    }
+    const size_t o = ((size_t)b * V + v) * 3;
+    if (accumulate) { d_verts[o] += sx; d_verts[o + 1] += sy; d_verts[o + 2] += sz; }
+    else { d_verts[o] = sx; d_verts[o + 1] = sy; d_verts[o + 2] = sz; }
+}
+
+}  // namespace
+
+extern "C" int vhap_flame_skin_fwd(const float* coef, const float* basis, const float* A, const float* lbs_weights,
+                                   const float* v_template, const float* offset, const float* transl, int B, int V, int Vp,
+                                   int K, int Kb, int Kp, float* verts, float* v_shaped, float* v_posed, vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!coef || !basis || !A || !lbs_weights || !v_template || !transl || !verts || !v_shaped || !v_posed) return VHAP_E_NULLPTR;
+    if (B <= 0 || V <= 0 || Vp < V || Vp % 64 || K <= 0 || K % 4 || Kb % 4 || Kb > K || Kp < K) return VHAP_E_BADDIM;
+    flame_skin_fwd_kernel<<<dim3(Vp / 64, (B + 15) / 16), 64, 0, vhap_stream(stream)>>>(coef, basis, A, lbs_weights, v_template, offset,
+                                                                                        transl, B, V, Vp, K, Kb, Kp, verts, v_shaped,
+                                                                                        v_posed);
+    VHAP_LAUNCH_CHECK();
+    return VHAP_OK;
+}
+
+extern "C" size_t vhap_flame_bwd_partial_floats(int B, int Vp, int Kp) {
+    if (B <= 0 || Vp <= 0 || Kp <= 0) return 0;
+    return (size_t)(Vp / 64) * (size_t)(((B + 15) / 16) * 16) * Kp;
+}
+
+extern "C" int vhap_flame_skin_bwd(const float* d_verts, const float* d_vshaped, const float* v_posed, const float* A,
+                                   const float* lbs_weights, const float* basisT, int B, int V, int Vp, int Kb, int Kp,
+                                   float* g_posed, float* g_shaped, float* partials, float* d_coef, float* d_A, float* d_transl,
+                                   vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!d_verts || !v_posed || !A || !lbs_weights || !basisT || !g_posed || !g_shaped || !partials || !d_coef || !d_A || !d_transl)
+        return VHAP_E_NULLPTR;
+    if (B <= 0 || V <= 0 || Vp < V || Vp % 64 || Kb % 16 || Kp % 16 || Kp / 16 > 32) return VHAP_E_BADDIM;
+    hipStream_t st = vhap_stream(stream);
+    flame_skin_bwd_kernel<<<dim3(vhap_cdiv(V, 256), B), 256, 0, st>>>(d_verts, d_vshaped, v_posed, A, lbs_weights, B, V, g_posed, g_shaped,
+                                                                      d_A, d_transl);
+    VHAP_LAUNCH_CHECK();
+    const int ntiles = Kp / 16, per_wave = (ntiles + 3) / 4;
+    const dim3 grid(Vp / 64, (B + 15) / 16);
+    flame_coef_bwd_kernel<<<grid, 256, 0, st>>>(g_shaped, g_posed, basisT, B, V, Vp, Kb, Kp, per_wave, partials);
+    VHAP_LAUNCH_CHECK();
+    const int n = grid.y * 16 * Kp;
+    reduce_partials_kernel<<<vhap_cdiv(n, 256), 256, 0, st>>>(partials, grid.x, n, d_coef);
+    VHAP_LAUNCH_CHECK();
+    return VHAP_OK;
+}
+
+extern "C" int vhap_transform_fwd(const float* verts, const float* M, int B, int V, float* clip, vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!verts || !M || !clip) return VHAP_E_NULLPTR;
+    if (B <= 0 || V <= 0 || B > 65535) return VHAP_E_BADDIM;
+    transform_fwd_kernel<<<dim3(vhap_cdiv(V, 256), B), 256, 0, vhap_stream(stream)>>>(verts, M, V, reinterpret_cast<float4*>(clip));
+    VHAP_LAUNCH_CHECK();
+    return VHAP_OK;
+}
+
+extern "C" int vhap_transform_bwd(const float* verts, const float* M, const float* d_clip, int B, int V, int accumulate,
+                                  float* d_verts, float* d_M, vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!verts || !M || !d_clip || !d_verts) return VHAP_E_NULLPTR;
+    if (B <= 0 || V <= 0 || B > 65535) return VHAP_E_BADDIM;
+    transform_bwd_kernel<<<dim3(vhap_cdiv(V, 256), B), 256, 0, vhap_stream(stream)>>>(verts, M, reinterpret_cast<const float4*>(d_clip), V,
+                                                                                      accumulate, d_verts, d_M);
+    VHAP_LAUNCH_CHECK();
+    return VHAP_OK;
+}
+
+extern "C" int vhap_vnormal_fwd(const float* verts, const int32_t* tri, const int32_t* vc_ptr, const int32_t* vc_idx, int B, int V,
+                                float* vn, vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!verts || !tri || !vc_ptr || !vc_idx || !vn) return VHAP_E_NULLPTR;
+    if (B <= 0 || V <= 0 || B > 65535) return VHAP_E_BADDIM;
+    vnormal_fwd_kernel<<<dim3(vhap_cdiv(V, 256), B), 256, 0, vhap_stream(stream)>>>(verts, tri, vc_ptr, vc_idx, V, vn);
+    VHAP_LAUNCH_CHECK();
+    return VHAP_OK;
+}
+
+extern "C" int vhap_vnormal_bwd(const float* verts, const int32_t* tri, const int32_t* vc_ptr, const int32_t* vc_idx,
+                                const float* d_vn, int B, int V, int accumulate, float* scratch, float* d_verts,
+                                vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!verts || !tri || !vc_ptr || !vc_idx || !d_vn || !scratch || !d_verts) return VHAP_E_NULLPTR;
+    if (B <= 0 || V <= 0 || B > 65535) return VHAP_E_BADDIM;
+    hipStream_t st = vhap_stream(stream);
+    const dim3 grid(vhap_cdiv(V, 256), B);
+    vnormal_bwd1_kernel<<<grid, 256, 0, st>>>(verts, tri, vc_ptr, vc_idx, d_vn, V, scratch);
+    VHAP_LAUNCH_CHECK();
+    vnormal_bwd2_kernel<<<grid, 256, 0, st>>>(verts, tri, vc_ptr, vc_idx, scratch, V, accumulate, d_verts);
+    VHAP_LAUNCH_CHECK();
+    return VHAP_OK;
+}

@@ -1,0 +1,314 @@
+// Fused per-pixel stages of the photometric energy for gfx950:
+//   shade_fwd / shade_bwd : safe-normalise the interpolated normal, 9-band SH diffuse shading,
+//                           rgb = albedo * diffuse, alpha = coverage, composite over the background
+//                           (constant colour or the target image, flipped to the renderer's y-up
+//                           frame), plus the statistics of the diffuse regulariser.
+//                           Replaces render_nvdiffrast.py:386 (safe_normalize), :402-421
+//                           (shade x2, rgb, alpha, background where) and tracker.py:547-550
+//                           (reg_diffuse: relu(max(diffuse) - 1) + mean(var_channels(diffuse))),
+//                           ~25 eager kernels and 340 MB of [B,H,W,9,3] temporaries in the reference.
+//   photo_fwd / photo_bwd : sum |gt - pred| and #(alpha > 0) (tracker.py:430-439) and its gradient.
+// One thread per pixel, 16-byte accesses where the layout allows, block reduction + one atomic per
+// block for the scalar / [9,3] outputs.
+#include "common.h"
+
+namespace {
+
+__constant__ float c_dummy;
+
+struct SH9 {
+    float v[9];
+};
+
+__device__ __forceinline__ void sh_basis(float x, float y, float z, const float* __restrict__ sc, SH9& b) {
+    b.v[0] = sc[0];
+    b.v[1] = x * sc[1];
+    b.v[2] = y * sc[2];
+    b.v[3] = z * sc[3];
+    b.v[4] = x * y * sc[4];
+    b.v[5] = x * z * sc[5];
+    b.v[6] = y * z * sc[6];
+    b.v[7] = (x * x - y * y) * sc[7];
+    b.v[8] = (3.0f * z * z - 1.0f) * sc[8];
+}
+
+__device__ __forceinline__ unsigned f2ord(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+struct ShadeParams {
+    const float* normal_raw;  // [B,H,W,3]
+    const float* albedo;      // [B,H,W,3]
+    const float4* rast;       // [B,H,W,4]
+    const float* bg_image;    // [B,3,H,W] image space (row 0 = top) or nullptr
+    float bg_r, bg_g, bg_b;   // constant background when bg_image == nullptr
+    const float* lights;      // [9,3]
+    const float* sh_const;    // [9]
+    int B, H, W;
+};
+
+// stats[0] = ordered-uint max of diffuse (atomicMax), stats[1] = float sum over pixels of var_channels(diffuse)
+__global__ __launch_bounds__(256) void shade_fwd_kernel(const ShadeParams P, float4* __restrict__ rgba,
+                                                        unsigned* __restrict__ stats) {
+    __shared__ float s_l[27], s_c[9];
+    __shared__ float red_var[4];
+    __shared__ unsigned red_max[4];
+    if (threadIdx.x < 27) s_l[threadIdx.x] = P.lights[threadIdx.x];
+    if (threadIdx.x < 9) s_c[threadIdx.x] = P.sh_const[threadIdx.x];
+    __syncthreads();
+    const long long npix = (long long)P.B * P.H * P.W;
+    const long long pi = (long long)blockIdx.x * 256 + threadIdx.x;
+    float var = 0.f;
+    unsigned mx = 0u;
+    if (pi < npix) {
+        const float* nr = P.normal_raw + 3 * pi;
+        const float nx = nr[0], ny = nr[1], nz = nr[2];
+        const float inv = 1.0f / sqrtf(fmaxf(nx * nx + ny * ny + nz * nz, 1e-20f));
+        SH9 b;
+        sh_basis(nx * inv, ny * inv, nz * inv, s_c, b);
+        float d[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            d[0] += b.v[k] * s_l[3 * k]; d[1] += b.v[k] * s_l[3 * k + 1]; d[2] += b.v[k] * s_l[3 * k + 2];
+        }
+        const float mean = (d[0] + d[1] + d[2]) * (1.0f / 3.0f);
+        var = 0.5f * ((d[0] - mean) * (d[0] - mean) + (d[1] - mean) * (d[1] - mean) + (d[2] - mean) * (d[2] - mean));
+        mx = f2ord(fmaxf(d[0], fmaxf(d[1], d[2])));
+        const bool fg = P.rast[pi].w > 0.0f;
+        float4 o;
+        if (fg) {
+            const float* al = P.albedo + 3 * pi;
+            o = make_float4(al[0] * d[0], al[1] * d[1], al[2] * d[2], 1.0f);
+        } else if (P.bg_image) {
+            const int HW = P.H * P.W;
+            const int bI = (int)(pi / HW), rem = (int)(pi - (long long)bI * HW);
+            const int y = rem / P.W, x = rem - y * P.W;
+            const float* g = P.bg_image + (size_t)bI * 3 * HW + (size_t)(P.H - 1 - y) * P.W + x;
+            o = make_float4(g[0], g[HW], g[2 * HW], 0.0f);
+        } else {
+            o = make_float4(P.bg_r, P.bg_g, P.bg_b, 0.0f);
+        }
+        rgba[pi] = o;
+    }
+    if (stats) {
+        var = vhap_wave_sum(var);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o, 64));
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (lane == 0) { red_var[wave] = var; red_max[wave] = mx; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            atomicAdd(reinterpret_cast<float*>(stats) + 1, red_var[0] + red_var[1] + red_var[2] + red_var[3]);
+            atomicMax(stats, max(max(red_max[0], red_max[1]), max(red_max[2], red_max[3])));
+        }
+    }
+}
+
+// d_rgba -> d_albedo, d_normal_raw, d_lights (accumulated).  reg: gradient of the diffuse regulariser w.r.t.
+// lights only (the reference computes it on shade(normal.detach())):
+//   g_var = d_reg / npix  (coefficient of d var / d diffuse_c = diffuse_c - mean)
+//   g_max = d_reg if max(diffuse) > 1 else 0, applied where diffuse_c equals the max (stats[0]).
+__global__ __launch_bounds__(256) void shade_bwd_kernel(const ShadeParams P, const float4* __restrict__ d_rgba,
+                                                        const float* __restrict__ d_reg, const unsigned* __restrict__ stats,
+                                                        float* __restrict__ d_albedo, float* __restrict__ d_normal_raw,
+                                                        float* __restrict__ d_lights) {
+    __shared__ float s_l[27], s_c[9];
+    __shared__ float red[4][27];
+    if (threadIdx.x < 27) s_l[threadIdx.x] = P.lights[threadIdx.x];
+    if (threadIdx.x < 9) s_c[threadIdx.x] = P.sh_const[threadIdx.x];
+    __syncthreads();
+    const long long npix = (long long)P.B * P.H * P.W;
+    const long long pi = (long long)blockIdx.x * 256 + threadIdx.x;
+    float gl[27];
+#pragma unroll
+    for (int i = 0; i < 27; i++) gl[i] = 0.f;
+    float g_var = 0.f, g_max = 0.f;
+    unsigned mx_ord = 0u;
+    if (d_reg && stats) {
+        const float dr = d_reg[0];
+        g_var = dr / (float)npix;
+        mx_ord = stats[0];
+        const unsigned u = (mx_ord & 0x80000000u) ? (mx_ord & 0x7fffffffu) : ~mx_ord;
+        g_max = __uint_as_float(u) > 1.0f ? dr : 0.f;
+    }
+    if (pi < npix) {
+        const float* nr = P.normal_raw + 3 * pi;
+        const float rx = nr[0], ry = nr[1], rz = nr[2];
+        const float l2 = rx * rx + ry * ry + rz * rz;
+        const bool clampd = !(l2 > 1e-20f);
+        const float inv = 1.0f / sqrtf(fmaxf(l2, 1e-20f));
+        const float x = rx * inv, y = ry * inv, z = rz * inv;
+        SH9 b;
+        sh_basis(x, y, z, s_c, b);
+        float d[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            d[0] += b.v[k] * s_l[3 * k]; d[1] += b.v[k] * s_l[3 * k + 1]; d[2] += b.v[k] * s_l[3 * k + 2];
+        }
+        const bool fg = P.rast[pi].w > 0.0f;
+        float gd[3] = {0.f, 0.f, 0.f};   // photometric part of d(diffuse): flows to lights AND normal
+        float ga[3] = {0.f, 0.f, 0.f};
+        if (fg) {
+            const float4 g = d_rgba[pi];
+            const float* al = P.albedo + 3 * pi;
+            ga[0] = g.x * d[0]; ga[1] = g.y * d[1]; ga[2] = g.z * d[2];
+            gd[0] = g.x * al[0]; gd[1] = g.y * al[1]; gd[2] = g.z * al[2];
+        }
+        if (d_albedo) { d_albedo[3 * pi] = ga[0]; d_albedo[3 * pi + 1] = ga[1]; d_albedo[3 * pi + 2] = ga[2]; }
+        // regulariser part: lights only
+        float gr[3] = {0.f, 0.f, 0.f};
+        if (g_var != 0.f || g_max != 0.f) {
+            const float mean = (d[0] + d[1] + d[2]) * (1.0f / 3.0f);
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                gr[c] = g_var * (d[c] - mean);
+                if (g_max != 0.f && f2ord(d[c]) == mx_ord) gr[c] += g_max;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            gl[3 * k] = b.v[k] * (gd[0] + gr[0]); gl[3 * k + 1] = b.v[k] * (gd[1] + gr[1]); gl[3 * k + 2] = b.v[k] * (gd[2] + gr[2]);
+        }
+        if (d_normal_raw) {
+            float gnx = 0.f, gny = 0.f, gnz = 0.f;
+            if (fg) {
+                float gb[9];   // d L / d(basis_k / const_k)
+#pragma unroll
+                for (int k = 0; k < 9; k++) gb[k] = s_c[k] * (s_l[3 * k] * gd[0] + s_l[3 * k + 1] * gd[1] + s_l[3 * k + 2] * gd[2]);
+                gnx = gb[1] + y * gb[4] + z * gb[5] + 2.f * x * gb[7];
+                gny = gb[2] + x * gb[4] + z * gb[6] - 2.f * y * gb[7];
+                gnz = gb[3] + x * gb[5] + y * gb[6] + 6.f * z * gb[8];
+                // n = r / max(|r|, 1e-10):  d r = (d n - n (n . d n)) / |r|   (or d n / 1e-10 when clamped)
+                if (!clampd) {
+                    const float dot = x * gnx + y * gny + z * gnz;
+                    gnx = (gnx - x * dot) * inv; gny = (gny - y * dot) * inv; gnz = (gnz - z * dot) * inv;
+                } else {
+                    gnx *= inv; gny *= inv; gnz *= inv;
+                }
+            }
+            d_normal_raw[3 * pi] = gnx; d_normal_raw[3 * pi + 1] = gny; d_normal_raw[3 * pi + 2] = gnz;
+        }
+    }
+    if (d_lights) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int i = 0; i < 27; i++) {
+            const float s = vhap_wave_sum(gl[i]);
+            if (lane == 0) red[wave][i] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < 27) {
+            const float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+            if (s != 0.f) atomicAdd(&d_lights[threadIdx.x], s);
+        }
+    }
+}
+
+// pred rgba [B,H,W,4] (renderer space, row 0 = bottom) vs gt [B,3,H,W] (image space).
+// out[0] += sum |gt - pred_rgb|, out[1] += #(alpha > 0) (as float, exact below 2^24 per block partial)
+__global__ __launch_bounds__(256) void photo_fwd_kernel(const float4* __restrict__ pred, const float* __restrict__ gt, int B, int H,
+                                                        int W, float* __restrict__ out) {
+    __shared__ float rs[4], rn[4];
+    const long long npix = (long long)B * H * W;
+    const long long pi = (long long)blockIdx.x * 256 + threadIdx.x;
+    float s = 0.f, n = 0.f;
+    if (pi < npix) {
+        const int HW = H * W;
+        const int b = (int)(pi / HW), rem = (int)(pi - (long long)b * HW);
+        const int y = rem / W, x = rem - y * W;
+        const float* g = gt + (size_t)b * 3 * HW + (size_t)(H - 1 - y) * W + x;
+        const float4 p = pred[pi];
+        s = fabsf(g[0] - p.x) + fabsf(g[HW] - p.y) + fabsf(g[2 * HW] - p.z);
+        n = p.w > 0.0f ? 1.0f : 0.0f;
+    }
+    s = vhap_wave_sum(s);
+    n = vhap_wave_sum(n);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { rs[wave] = s; rn[wave] = n; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&out[0], rs[0] + rs[1] + rs[2] + rs[3]);
+        atomicAdd(&out[1], rn[0] + rn[1] + rn[2] + rn[3]);
+    }
+}
+
+// d_pred.rgb = -sign(gt - pred) * d_sum[0]; d_pred.a = 0
+__global__ __launch_bounds__(256) void photo_bwd_kernel(const float4* __restrict__ pred, const float* __restrict__ gt,
+                                                        const float* __restrict__ d_sum, int B, int H, int W,
+                                                        float4* __restrict__ d_pred) {
+    const long long npix = (long long)B * H * W;
+    const long long pi = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (pi >= npix) return;
+    const float gs = d_sum[0];
+    const int HW = H * W;
+    const int b = (int)(pi / HW), rem = (int)(pi - (long long)b * HW);
+    const int y = rem / W, x = rem - y * W;
+    const float* g = gt + (size_t)b * 3 * HW + (size_t)(H - 1 - y) * W + x;
+    const float4 p = pred[pi];
+    auto sg = [](float e) { return e > 0.f ? 1.0f : (e < 0.f ? -1.0f : 0.0f); };
+    d_pred[pi] = make_float4(-sg(g[0] - p.x) * gs, -sg(g[HW] - p.y) * gs, -sg(g[2 * HW] - p.z) * gs, 0.0f);
+}
+
+int check_img(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0 || (long long)B * H * W >= (1ll << 31)) return VHAP_E_BADDIM;
+    return VHAP_OK;
+}
+
+}  // namespace
+
+extern "C" int vhap_shade_fwd(const float* normal_raw, const float* albedo, const float* rast, const float* bg_image,
+                              const float* bg_color, const float* lights, const float* sh_const, int B, int H, int W,
+                              float* rgba, float* stats, vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!normal_raw || !albedo || !rast || !lights || !sh_const || !rgba) return VHAP_E_NULLPTR;
+    if (!bg_image && !bg_color) return VHAP_E_NULLPTR;
+    if (int e = check_img(B, H, W)) return e;
+    ShadeParams P{normal_raw, albedo, reinterpret_cast<const float4*>(rast), bg_image, 0.f, 0.f, 0.f, lights, sh_const, B, H, W};
+    if (!bg_image) { P.bg_r = bg_color[0]; P.bg_g = bg_color[1]; P.bg_b = bg_color[2]; }
+    hipStream_t st = vhap_stream(stream);
+    if (stats && hipMemsetAsync(stats, 0, 8, st) != hipSuccess) return VHAP_E_HIP;
+    const long long npix = (long long)B * H * W;
+    shade_fwd_kernel<<<vhap_cdiv(npix, 256), 256, 0, st>>>(P, reinterpret_cast<float4*>(rgba), reinterpret_cast<unsigned*>(stats));
+    VHAP_LAUNCH_CHECK();
+    return VHAP_OK;
+}
+
+extern "C" int vhap_shade_bwd(const float* normal_raw, const float* albedo, const float* rast, const float* lights,
+                              const float* sh_const, const float* d_rgba, const float* d_reg, const float* stats, int B, int H,
+                              int W, float* d_albedo, float* d_normal_raw, float* d_lights, vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!normal_raw || !albedo || !rast || !lights || !sh_const || !d_rgba) return VHAP_E_NULLPTR;
+    if (int e = check_img(B, H, W)) return e;
+    ShadeParams P{normal_raw, albedo, reinterpret_cast<const float4*>(rast), nullptr, 0.f, 0.f, 0.f, lights, sh_const, B, H, W};
+    const long long npix = (long long)B * H * W;
+    shade_bwd_kernel<<<vhap_cdiv(npix, 256), 256, 0, vhap_stream(stream)>>>(
+        P, reinterpret_cast<const float4*>(d_rgba), d_reg, reinterpret_cast<const unsigned*>(stats), d_albedo, d_normal_raw, d_lights);
+    VHAP_LAUNCH_CHECK();
+    return VHAP_OK;
+}
+
+extern "C" int vhap_photo_fwd(const float* pred_rgba, const float* gt_nchw, int B, int H, int W, float* out2,
+                              vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!pred_rgba || !gt_nchw || !out2) return VHAP_E_NULLPTR;
+    if (int e = check_img(B, H, W)) return e;
+    hipStream_t st = vhap_stream(stream);
+    if (hipMemsetAsync(out2, 0, 8, st) != hipSuccess) return VHAP_E_HIP;
+    const long long npix = (long long)B * H * W;
+    photo_fwd_kernel<<<vhap_cdiv(npix, 256), 256, 0, st>>>(reinterpret_cast<const float4*>(pred_rgba), gt_nchw, B, H, W, out2);
+    VHAP_LAUNCH_CHECK();
+    return VHAP_OK;
+}
+
+extern "C" int vhap_photo_bwd(const float* pred_rgba, const float* gt_nchw, const float* d_sum, int B, int H, int W,
+                              float* d_pred, vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!pred_rgba || !gt_nchw || !d_sum || !d_pred) return VHAP_E_NULLPTR;
+    if (int e = check_img(B, H, W)) return e;
+    const long long npix = (long long)B * H * W;
+    photo_bwd_kernel<<<vhap_cdiv(npix, 256), 256, 0, vhap_stream(stream)>>>(reinterpret_cast<const float4*>(pred_rgba), gt_nchw,
+                                                                           d_sum, B, H, W, reinterpret_cast<float4*>(d_pred));
+    VHAP_LAUNCH_CHECK();
+    return VHAP_OK;
+}

@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 
 from . import lbs as L
+from . import fused as FU
 from .topology import FlameTopology
 
 
@@ -67,6 +68,8 @@ class FlameHead(nn.Module):
         rows = np.repeat(np.arange(topo.num_verts), np.diff(topo.lap_ptr))
         self.register_buffer("lap_row", torch.from_numpy(rows.astype(np.int64)), persistent=False)
         self.mask = FlameMask(topo)
+        self.fused = True          # MFMA blend+skin kernels on a HIP device (False: host-side torch ops only)
+        self._fb = None
 
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
@@ -88,21 +91,51 @@ class FlameHead(nn.Module):
                 return_landmarks=True, return_verts_cano=False, static_offset=None, dynamic_offset=None):
         betas = torch.cat([shape, expr], dim=1)
         full_pose = torch.cat([rotation, neck, jaw, eyes], dim=1)
-        v_shaped = self.v_template[None] + L.blend_shapes(betas, self.shapedirs)
-        if static_offset is not None:
-            v_shaped = v_shaped + static_offset
-        if dynamic_offset is not None:
-            v_shaped = v_shaped + dynamic_offset
-        vertices, J, _ = L.lbs(full_pose, v_shaped, self.posedirs, self.J_regressor, self.parents, self.lbs_weights)
+        translated = False
+        if self.fused and betas.is_cuda and dynamic_offset is None:
+            translated = not zero_centered_at_root_node          # the kernel adds the translation itself
+            vertices, v_shaped, J = self._forward_fused(betas, full_pose, static_offset, translation if translated else None)
+        else:
+            v_shaped = self.v_template[None] + L.blend_shapes(betas, self.shapedirs)
+            if static_offset is not None:
+                v_shaped = v_shaped + static_offset
+            if dynamic_offset is not None:
+                v_shaped = v_shaped + dynamic_offset
+            vertices, J, _ = L.lbs(full_pose, v_shaped, self.posedirs, self.J_regressor, self.parents, self.lbs_weights)
         if zero_centered_at_root_node:
             vertices = vertices - J[:, [0]]
-        vertices = vertices + translation[:, None, :]
+        if not translated:
+            vertices = vertices + translation[:, None, :]
         ret = [vertices]
         if return_verts_cano:
             ret.append(v_shaped)
         if return_landmarks:
             ret.append(L.vertices2landmarks(vertices, self.faces, self.full_lmk_faces_idx, self.full_lmk_bary_coords))
         return ret if len(ret) > 1 else ret[0]
+
+
+    def _forward_fused(self, betas, full_pose, static_offset, translation=None):
+        """Blendshapes, pose correctives and skinning on the matrix cores (vhap_amd/csrc/flame.hip); the per-frame
+        5-joint algebra (Rodrigues, joint regression through the pre-contracted J_regressor @ shapedirs, chain)
+        stays here as a few tiny host-side ops."""
+        if self._fb is None or self._fb.basis.device != betas.device:
+            self._fb = FU.FlameBasis(self.shapedirs, self.posedirs, self.J_regressor, self.v_template, self.lbs_weights)
+        fb = self._fb
+        B = betas.shape[0]
+        R = L.batch_rodrigues(full_pose.reshape(-1, 3)).view(B, -1, 3, 3)
+        eye = torch.eye(3, dtype=betas.dtype, device=betas.device)
+        pose_feature = (R[:, 1:] - eye).reshape(B, -1)
+        J = fb.JT[None] + (betas @ fb.JS.t()).view(B, -1, 3)
+        if static_offset is not None:
+            J = J + (self.J_regressor[:, :, None] * static_offset.reshape(1, -1, 3)).sum(dim=1)[None]
+        J_posed, A = L.batch_rigid_transform(R, J, self.parents)
+        coef = torch.cat([betas, pose_feature], dim=1)
+        Bp = (B + 15) // 16 * 16
+        coef = torch.nn.functional.pad(coef, [0, fb.Kp - coef.shape[1], 0, Bp - B])
+        if translation is None:
+            translation = torch.zeros(B, 3, dtype=betas.dtype, device=betas.device)
+        vertices, v_shaped = FU.flame_skin(fb, coef, A[:, :, :3, :].reshape(B, -1, 12), translation, static_offset)
+        return vertices, v_shaped, J_posed
 
 
 class FlameTexPainted(nn.Module):

@@ -15,6 +15,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from . import fused as FU
 from . import ops
 
 
@@ -53,6 +54,8 @@ class HipDiffRenderer(torch.nn.Module):
         self.disturb_rate_bg = disturb_rate_bg
         self.shade_smooth = shade_smooth
         self.glctx = ops.RasterizeHipContext()
+        self.fused = True           # fused HIP kernels for transform / normals / shading (False: host-side torch ops)
+        self._csr_cache = {}
         self.fragment_cache = None
         if fid2cid is not None:
             self.register_buffer("fid2cid", F.pad(fid2cid, [1, 0], value=0), persistent=False)   # 0 = background
@@ -126,6 +129,11 @@ class HipDiffRenderer(torch.nn.Module):
     def rasterize(self, verts, faces, RT, K, image_size, use_cache=False, require_grad=False, defer=False):
         """`defer=True` (MI355X extension): only transform the vertices; render_rgba() then runs the fused
         rasterize + interpolate kernel (one launch for the whole G-buffer) instead of three ops."""
+        if self.fused and verts.is_cuda and defer and self.lighting_space == "world":
+            # one kernel for [v;1] @ (P MV)^T; camera-space vertices are not needed on this path
+            verts_clip = FU.transform(verts, self.mvp_from_camera_param(self._t(RT, verts), self._t(K, verts), image_size))
+            return {"rast_out": None, "rast_out_db": None, "verts": verts, "verts_camera": None, "verts_clip": verts_clip,
+                    "image_size": tuple(image_size), "require_grad": require_grad}
         verts_camera = self.world_to_camera(verts, RT)
         verts_clip = self.camera_to_clip(verts_camera, K, image_size)
         if defer:
@@ -147,6 +155,11 @@ class HipDiffRenderer(torch.nn.Module):
 
     # ---- normals / shading (render_nvdiffrast.py:297-347) ----
     def compute_v_normals(self, verts, faces):
+        if self.fused and verts.is_cuda:
+            key = (faces.data_ptr(), tuple(faces.shape))
+            if key not in self._csr_cache:
+                self._csr_cache[key] = (faces, FU.MeshCSR.from_faces(faces))       # keep `faces` alive: the key is its address
+            return FU.vertex_normals(verts, self._csr_cache[key][1])
         f = faces.long()
         v0, v1, v2 = verts[:, f[:, 0]], verts[:, f[:, 1]], verts[:, f[:, 2]]
         fn = torch.cross(v1 - v0, v2 - v0, dim=-1)
@@ -236,7 +249,10 @@ class HipDiffRenderer(torch.nn.Module):
     # ---- render (render_nvdiffrast.py:354-484) ----
     def render_rgba(self, rast_dict, verts, faces, verts_uv, faces_uv, tex, lights, background_color=[1., 1., 1.],
                     align_texture_except_fid=None, align_boundary_except_vid=None, enable_disturbance=False,
-                    disturbance=None):
+                    disturbance=None, outputs="all", want_reg_diffuse=False):
+        """`outputs="loss"` (MI355X extension): return only what the photometric energy needs --
+        {'rgba_rs': antialiased RGBA in RENDERER space (row 0 = bottom, not flipped), 'reg_diffuse': scalar} -- through
+        the fused shading kernel; `outputs="all"` reproduces the reference's dictionary."""
         rast_out, rast_out_db = rast_dict["rast_out"], rast_dict["rast_out_db"]
         verts, verts_camera, verts_clip = rast_dict["verts"], rast_dict["verts_camera"], rast_dict["verts_clip"]
         tri, tri_uv = faces.int(), faces_uv.int()
@@ -252,7 +268,8 @@ class HipDiffRenderer(torch.nn.Module):
             normal, _ = ops.interpolate(v_normal, rast_out, tri)
             texc, texd = ops.interpolate(verts_uv[None, ...], rast_out, tri_uv, rast_db=rast_out_db, diff_attrs="all")
         fg_mask = rast_out[..., 3:4] > 0
-        normal = safe_normalize(normal)
+        normal_raw = normal
+        normal = safe_normalize(normal) if not (outputs == "loss" and self.fused and self.lighting_type == "SH") else None
         if align_texture_except_fid is not None:
             mask = torch.zeros(faces.shape[0] + 1, dtype=torch.bool, device=rast_out.device)
             mask[align_texture_except_fid + 1] = True
@@ -266,21 +283,31 @@ class HipDiffRenderer(torch.nn.Module):
         tex_cl = tex.permute(0, 2, 3, 1).contiguous()
         albedo = ops.texture(tex_cl, texc, texd, filter_mode="linear-mipmap-linear")
 
-        diffuse = self.shade(normal, lights)
-        diffuse_detach_normal = self.shade(normal.detach(), lights)
-        rgba = torch.cat([albedo * diffuse, fg_mask.to(albedo.dtype)], dim=-1)
-        rgba_bg = self._background(background_color, rgba)
-        rgba = torch.where(fg_mask, rgba, rgba_bg)
+        fast = outputs == "loss" and self.fused and self.lighting_type == "SH"
+        if fast:
+            rgba, reg_diffuse = FU.shade(normal_raw, albedo, lights, rast_out, background_color, self.sh_const, want_reg_diffuse)
+            rgba_bg = None
+        else:
+            diffuse = self.shade(normal, lights)
+            diffuse_detach_normal = self.shade(normal.detach(), lights)
+            rgba = torch.cat([albedo * diffuse, fg_mask.to(albedo.dtype)], dim=-1)
+            rgba_bg = self._background(background_color, rgba)
+            rgba = torch.where(fg_mask, rgba, rgba_bg)
 
         if enable_disturbance:
             if disturbance is None:
                 disturbance = self.make_disturbance(rgba.shape[:3], rgba.device)
+            if rgba_bg is None:
+                rgba_bg = self._background(background_color, rgba)
             rgba, cid = self.disturb(rgba, rgba_bg, rast_out, disturbance)
             out_dict["cid"] = cid.flip(1)
 
         if align_boundary_except_vid is not None:
             verts_clip = self.detach_by_indices(verts_clip, align_boundary_except_vid)
         rgba_aa = ops.antialias(rgba, rast_out, verts_clip, tri)
+        if fast:
+            out_dict.update({"rgba_rs": rgba_aa, "reg_diffuse": reg_diffuse})
+            return out_dict
         aa = ((rgba - rgba_aa) != 0).any(dim=-1, keepdim=True).expand(-1, -1, -1, 3)
 
         out_dict.update({

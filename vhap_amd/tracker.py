@@ -18,6 +18,7 @@ import torch
 import torch.nn.functional as F
 
 from .config import BaseTrackingConfig, PhotometricStageConfig
+from . import fused as FU
 from .flame import FlameHead, FlameTexPainted, FlameUvMask
 from .lbs import batch_rodrigues
 from .render_hip import HipDiffRenderer
@@ -50,6 +51,7 @@ class FlameTracker:
         self._region_cache = {}
         self.dist = None                                          # set by vhap_amd.dist.attach()
         self.fused_gbuffer = True                                 # one launch for rasterize + both interpolates
+        self.fused = True                                         # fused shading / loss kernels (False: reference-shaped torch ops)
         self.opt_dict = defaultdict(bool)
 
     # ---- helpers ----
@@ -175,6 +177,16 @@ class FlameTracker:
         lights = self.lights[None] if self.lights is not None else None
         bg_color = self.get_background_color(gt_rgb, None, stage)
         fid, vid = self._regions(stage) if stage is not None else (None, None)
+        if self.fused and stage is not None and self.render.lighting_type == "SH":
+            want_reg = bool(self.opt_dict["lights"]) and self.cfg.w.reg_diffuse is not None
+            out = self.render.render_rgba(rast_dict, verts, faces, self._verts_uv_flipped, self.flame.textures_idx, albedos, lights,
+                                          bg_color, fid, vid, True, disturbance=disturbance, outputs="loss",
+                                          want_reg_diffuse=want_reg)
+            abs_sum, n_alpha = FU.photo_sum(out["rgba_rs"], gt_rgb)
+            n_mask = n_alpha * 3
+            if self.dist is not None:
+                n_mask = self.dist.all_reduce_sum(n_mask) / self.dist.world_size
+            return abs_sum / n_mask, {"gt_rgb": gt_rgb, "rgba_rs": out["rgba_rs"], "reg_diffuse_value": out["reg_diffuse"]}
         render_out = self.render_rgba(rast_dict, verts, faces, albedos, lights, bg_color, fid, vid,
                                       enable_disturbance=stage is not None, disturbance=disturbance)
         pred_rgb = render_out["rgba"][:, :3]
@@ -221,8 +233,11 @@ class FlameTracker:
             if w.reg_light is not None:
                 log["reg_light"] = w.reg_light * ((self.lights - self.lights_uniform) ** 2).mean()
             if w.reg_diffuse is not None:
-                diffuse = result_dict["diffuse_detach_normal"]
-                log["reg_diffuse"] = w.reg_diffuse * (F.relu(diffuse.max() - 1) + diffuse.var(dim=1).mean())
+                if "reg_diffuse_value" in result_dict:            # computed inside the fused shading kernel
+                    log["reg_diffuse"] = w.reg_diffuse * result_dict["reg_diffuse_value"]
+                else:
+                    diffuse = result_dict["diffuse_detach_normal"]
+                    log["reg_diffuse"] = w.reg_diffuse * (F.relu(diffuse.max() - 1) + diffuse.var(dim=1).mean())
         if (self.opt_dict["static_offset"] or self.opt_dict["dynamic_offset"]) and \
                 (self.static_offset is not None or self.dynamic_offset is not None):
             offset = 0
