@@ -192,6 +192,21 @@ int vhap_vnormal_bwd(const float* verts, const int32_t* tri, const int32_t* vc_p
                      const int32_t* vc_idx, const float* d_vn, int B, int V, int accumulate,
                      float* scratch, float* d_verts, vhap_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Colour disturbance (vhap_amd/csrc/disturb.hip): replaces render_nvdiffrast.py:424-460.
+ *   rgba [B,H,W,4] composited image (background pixels hold the background colour), rast [B,H,W,4],
+ *   fid2cid [nfid] int32 (index = triangle id + 1, 0 = background), ncl clusters (<= 16),
+ *   w_fg / w_bg [B,H,W] int32 Bernoulli masks, idx [B*H*W] int64 non-negative random integers.
+ *   out [B,H,W,4]; keep [B,H,W] = 1 where the pixel kept its own colour (backward mask).
+ *   workspace: vhap_disturb_workspace_ints() int32.
+ * ------------------------------------------------------------------------------------------- */
+size_t vhap_disturb_workspace_ints(int B, int H, int W);
+int vhap_disturb_fwd(const float* rgba, const float* rast, const int32_t* fid2cid, int nfid, int ncl,
+                     const int32_t* w_fg, const int32_t* w_bg, const int64_t* idx, int B, int H,
+                     int W, int32_t* workspace, float* out, float* keep, vhap_stream_t stream);
+int vhap_disturb_bwd(const float* d_out, const float* keep, int B, int H, int W, float* d_rgba,
+                     vhap_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

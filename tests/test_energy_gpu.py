@@ -115,3 +115,52 @@ def test_short_fit_reduces_energy_and_exports_npz(setup, tmp_path):
               "n_processed_frames", "focal_length", "tex_extra", "lights", "static_offset", "image_size"):
         assert k in rep.files
     assert rep["expr"].shape == (N, 100) and rep["tex_extra"].shape == (3, T, T) and rep["lights"].shape == (9, 3)
+
+
+def test_graphed_step_matches_eager_steps(flame_model):
+    """Three optimiser steps replayed from the captured hipGraphs == three eager optimize_iter calls."""
+    from vhap_amd.config import BaseTrackingConfig
+    from vhap_amd.flame import FlameHead
+    from vhap_amd.render_hip import HipDiffRenderer
+    from vhap_amd.synthetic import make_dataset, make_scene_params, make_texture
+    from vhap_amd.tracker import GlobalTracker, GraphedStep
+    model, topo = flame_model
+    gt = make_scene_params(N, seed=9, image_size=(H, W))
+    head, rend = FlameHead(model, topo).cuda(), HipDiffRenderer(lighting_type="SH").cuda()
+    data = make_dataset(rend, head, gt, (H, W), "cuda", seed=9, tex=make_texture(9, T))
+    finals = []
+    for graphed in (False, True):
+        cfg = BaseTrackingConfig()
+        cfg.model.tex_resolution = T
+        cfg.render.disturb_rate_fg = cfg.render.disturb_rate_bg = None      # disturbance weights 0: deterministic
+        tr = GlobalTracker(cfg, model, topo, make_texture(0, T), data)
+        with torch.no_grad():
+            tr.translation[:, 2] = 0.45
+            tr.expr.add_(0.05)
+        stage = "rgb_global_tracking"
+        opt = tr.configure_optimizer(tr.get_train_parameters(stage), lr_scale=0.1)
+        sample = tr.get_sample(np.array([0, 1]), device_index=True)
+        n_steps = 3
+        if graphed:
+            st = GraphedStep(tr, sample, opt, stage, warmup=0)
+            for _ in range(n_steps):
+                st()
+        else:
+            for _ in range(n_steps):
+                tr.optimize_iter(dict(sample), opt, stage)
+        torch.cuda.synchronize()
+        finals.append({k: getattr(tr, k).detach().clone() for k in ("shape", "expr", "rotation", "translation", "jaw_pose",
+                                                                   "tex_extra", "lights", "static_offset", "focal_length")})
+    # Adam's first steps are ~lr*sign(g): components whose gradient is at the fp32-atomics noise floor may flip, so the
+    # parameter trajectories are compared as vectors (direction and length), not element by element
+    for k in finals[0]:
+        a, b = finals[1][k].double().reshape(-1), finals[0][k].double().reshape(-1)
+        if k == "translation":
+            a, b = a.clone(), b.clone()
+            a[2::3] -= 0.45
+            b[2::3] -= 0.45
+        if float(b.norm()) == 0:
+            assert float(a.norm()) == 0, k
+            continue
+        cos = float((a @ b) / (a.norm() * b.norm()))
+        assert cos > 0.995 and abs(float(a.norm() / b.norm()) - 1) < 0.03, (k, cos)

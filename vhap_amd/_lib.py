@@ -36,6 +36,9 @@ SIGNATURES = {
     "vhap_antialias_work_ints": (c_sz, [c_i] * 3),
     "vhap_antialias_fwd": (c_i, [c_fp] * 5 + [c_i] * 6 + [c_fp, c_fp, c_fp]),
     "vhap_antialias_bwd": (c_i, [c_fp] * 7 + [c_i] * 6 + [c_fp, c_fp, c_fp]),
+    "vhap_disturb_workspace_ints": (c_sz, [c_i] * 3),
+    "vhap_disturb_fwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
+    "vhap_disturb_bwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp]),
     "vhap_shade_fwd": (c_i, [c_fp] * 7 + [c_i] * 3 + [c_fp] * 3),
     "vhap_shade_bwd": (c_i, [c_fp] * 8 + [c_i] * 3 + [c_fp] * 4),
     "vhap_photo_fwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp]),

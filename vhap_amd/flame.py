@@ -55,6 +55,7 @@ class FlameHead(nn.Module):
         self.register_buffer("posedirs", t("posedirs"))                         # [36,3V]
         self.register_buffer("J_regressor", t("J_regressor"))
         self.register_buffer("parents", t("parents", torch.long))
+        self._parents = [int(x) for x in np.asarray(model["parents"])]           # host copy: indexing with it never syncs
         self.register_buffer("lbs_weights", t("lbs_weights"))
         self.register_buffer("faces", t("faces", torch.long), persistent=False)
         self.register_buffer("textures_idx", t("faces_uv", torch.long), persistent=False)
@@ -101,7 +102,7 @@ class FlameHead(nn.Module):
                 v_shaped = v_shaped + static_offset
             if dynamic_offset is not None:
                 v_shaped = v_shaped + dynamic_offset
-            vertices, J, _ = L.lbs(full_pose, v_shaped, self.posedirs, self.J_regressor, self.parents, self.lbs_weights)
+            vertices, J, _ = L.lbs(full_pose, v_shaped, self.posedirs, self.J_regressor, self._parents, self.lbs_weights)
         if zero_centered_at_root_node:
             vertices = vertices - J[:, [0]]
         if not translated:
@@ -128,7 +129,7 @@ class FlameHead(nn.Module):
         J = fb.JT[None] + (betas @ fb.JS.t()).view(B, -1, 3)
         if static_offset is not None:
             J = J + (self.J_regressor[:, :, None] * static_offset.reshape(1, -1, 3)).sum(dim=1)[None]
-        J_posed, A = L.batch_rigid_transform(R, J, self.parents)
+        J_posed, A = L.batch_rigid_transform(R, J, self._parents)
         coef = torch.cat([betas, pose_feature], dim=1)
         Bp = (B + 15) // 16 * 16
         coef = torch.nn.functional.pad(coef, [0, fb.Kp - coef.shape[1], 0, Bp - B])

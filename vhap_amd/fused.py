@@ -235,3 +235,31 @@ class _PhotoSum(torch.autograd.Function):
 def photo_sum(pred_rgba_renderer_space, gt_nchw):
     """-> (sum |gt - pred_rgb|, #(alpha > 0)) ; pred [B,H,W,4] row 0 = bottom, gt [B,3,H,W] image space."""
     return _PhotoSum.apply(_f32c(pred_rgba_renderer_space), _f32c(gt_nchw))
+
+
+# ------------------------------------------------------------------------------------------------
+class _Disturb(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rgba, rast, fid2cid, ncl, w_fg, w_bg, idx):
+        B, H, W, _ = rgba.shape
+        L = _lib.lib()
+        ws = torch.empty(L.vhap_disturb_workspace_ints(B, H, W), dtype=torch.int32, device=rgba.device)
+        out = torch.empty_like(rgba)
+        keep = torch.empty(B, H, W, dtype=torch.float32, device=rgba.device)
+        _chk(L.vhap_disturb_fwd(_p(rgba), _p(rast), _p(fid2cid), fid2cid.numel(), ncl, _p(w_fg), _p(w_bg), _p(idx), B, H, W, _p(ws),
+                                _p(out), _p(keep), _stream()), "vhap_disturb_fwd")
+        ctx.save_for_backward(keep)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        (keep,) = ctx.saved_tensors
+        B, H, W = keep.shape
+        d = torch.empty(B, H, W, 4, dtype=torch.float32, device=keep.device)
+        _chk(_lib.lib().vhap_disturb_bwd(_p(_f32c(d_out)), _p(keep), B, H, W, _p(d), _stream()), "vhap_disturb_bwd")
+        return d, None, None, None, None, None, None
+
+
+def disturb(rgba, rast, fid2cid_i32, ncl, w_fg, w_bg, idx):
+    """Cluster-wise colour disturbance of the composited image; w_fg / w_bg int32 [B,H,W(,1)], idx int64 [B*H*W]."""
+    return _Disturb.apply(_f32c(rgba), _f32c(rast), fid2cid_i32, int(ncl), w_fg.contiguous(), w_bg.contiguous(), idx.contiguous())

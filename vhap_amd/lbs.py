@@ -46,7 +46,7 @@ def vertices2landmarks(vertices, faces, lmk_faces_idx, lmk_bary_coords):
 def batch_rigid_transform(rot_mats, joints, parents, dtype=torch.float32):
     """rot_mats [B,J,3,3], joints [B,J,3] -> posed joints [B,J,3], relative transforms [B,J,4,4]."""
     B, J = joints.shape[:2]
-    par = [int(p) for p in parents]
+    par = parents if isinstance(parents, (list, tuple)) else [int(p) for p in parents]   # pass a list: no device sync
     rel_t = joints.clone()
     for j in range(1, J):
         rel_t[:, j] = joints[:, j] - joints[:, par[j]]

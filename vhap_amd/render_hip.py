@@ -84,7 +84,8 @@ class HipDiffRenderer(torch.nn.Module):
     def _modelview(RT):
         if RT.shape[-2] == 4:
             return RT
-        last = torch.tensor([0.0, 0.0, 0.0, 1.0], dtype=RT.dtype, device=RT.device).expand(*RT.shape[:-2], 1, 4)
+        last = torch.zeros(*RT.shape[:-2], 1, 4, dtype=RT.dtype, device=RT.device)     # device-side fills only:
+        last[..., 3] = 1                                                                # the step is graph-capturable
         return torch.cat([RT, last], dim=-2)
 
     @staticmethod
@@ -122,7 +123,7 @@ class HipDiffRenderer(torch.nn.Module):
         clip = self.world_to_clip(vtx, RT, K, image_size)
         ndc = clip[:, :, :3] / clip[:, :, 3:]
         if flip_y:
-            ndc = ndc * torch.tensor([1.0, -1.0, 1.0], dtype=ndc.dtype, device=ndc.device)
+            ndc = torch.cat([ndc[..., :1], -ndc[..., 1:2], ndc[..., 2:]], dim=-1)
         return ndc
 
     # ---- rasterize (render_nvdiffrast.py:216-260) ----
@@ -139,7 +140,7 @@ class HipDiffRenderer(torch.nn.Module):
         if defer:
             return {"rast_out": None, "rast_out_db": None, "verts": verts, "verts_camera": verts_camera[..., :3],
                     "verts_clip": verts_clip, "image_size": tuple(image_size), "require_grad": require_grad}
-        rast_out, rast_out_db = self.rasterize_fragments(verts_clip, faces.int(), image_size, use_cache, require_grad)
+        rast_out, rast_out_db = self.rasterize_fragments(verts_clip, self._tri32(faces), image_size, use_cache, require_grad)
         return {"rast_out": rast_out, "rast_out_db": rast_out_db, "verts": verts,
                 "verts_camera": verts_camera[..., :3], "verts_clip": verts_clip}
 
@@ -154,12 +155,30 @@ class HipDiffRenderer(torch.nn.Module):
         return self.fragment_cache
 
     # ---- normals / shading (render_nvdiffrast.py:297-347) ----
+    def _mesh(self, faces):
+        """Static per-topology tables (int32 triangles, opposite-vertex table, vertex->corner CSR), built once per
+        `faces` tensor.  The cache key is the tensor's address, so the entry keeps the tensor alive."""
+        key = (faces.data_ptr(), tuple(faces.shape), faces.dtype)
+        hit = self._csr_cache.get(key)
+        if hit is None:
+            from .topology import build_opposite_table
+            tri = faces.int().contiguous()
+            opp = torch.from_numpy(build_opposite_table(faces.detach().cpu().numpy())).to(faces.device)
+            hit = {"faces": faces, "tri": tri, "opp": opp, "csr": FU.MeshCSR.from_faces(faces) if faces.is_cuda else None}
+            self._csr_cache[key] = hit
+        return hit
+
+    def _tri32(self, faces):
+        key = ("i32", faces.data_ptr(), tuple(faces.shape), faces.dtype)
+        hit = self._csr_cache.get(key)
+        if hit is None:
+            hit = (faces, faces.int().contiguous())
+            self._csr_cache[key] = hit
+        return hit[1]
+
     def compute_v_normals(self, verts, faces):
         if self.fused and verts.is_cuda:
-            key = (faces.data_ptr(), tuple(faces.shape))
-            if key not in self._csr_cache:
-                self._csr_cache[key] = (faces, FU.MeshCSR.from_faces(faces))       # keep `faces` alive: the key is its address
-            return FU.vertex_normals(verts, self._csr_cache[key][1])
+            return FU.vertex_normals(verts, self._mesh(faces)["csr"])
         f = faces.long()
         v0, v1, v2 = verts[:, f[:, 0]], verts[:, f[:, 1]], verts[:, f[:, 2]]
         fn = torch.cross(v1 - v0, v2 - v0, dim=-1)
@@ -188,7 +207,7 @@ class HipDiffRenderer(torch.nn.Module):
 
     def detach_by_indices(self, x, indices):
         keep = torch.ones(x.shape[1], dtype=torch.bool, device=x.device)
-        keep[indices] = False
+        keep.index_fill_(0, indices, False)
         return torch.where(keep[None, :, None], x, x.detach())
 
     def _vertex_normals_for(self, verts, verts_camera, faces):
@@ -226,6 +245,12 @@ class HipDiffRenderer(torch.nn.Module):
         `rnd['idx']` is either one index stream [B*H*W] or a list with one stream per cluster."""
         B, H, W, _ = rgba.shape
         n = B * H * W
+        idx_in = rnd["idx"]
+        if self.fused and rgba.is_cuda and not isinstance(idx_in, (list, tuple)):
+            if not hasattr(self, "_fid2cid_i32") or self._fid2cid_i32.device != rgba.device:
+                self._fid2cid_i32 = self.fid2cid.int().contiguous()
+            out = FU.disturb(rgba, rast_out, self._fid2cid_i32, self._ncl, rnd["w_fg"].int(), rnd["w_bg"].int(), idx_in.long())
+            return out, None
         fid = rast_out[..., 3].long().reshape(n)
         cid = self.fid2cid[fid]                                          # [n]
         ncl = self._ncl if hasattr(self, "_ncl") else int(self.fid2cid.max().item()) + 1
@@ -255,7 +280,8 @@ class HipDiffRenderer(torch.nn.Module):
         the fused shading kernel; `outputs="all"` reproduces the reference's dictionary."""
         rast_out, rast_out_db = rast_dict["rast_out"], rast_dict["rast_out_db"]
         verts, verts_camera, verts_clip = rast_dict["verts"], rast_dict["verts_camera"], rast_dict["verts_clip"]
-        tri, tri_uv = faces.int(), faces_uv.int()
+        mesh = self._mesh(faces)
+        tri, tri_uv = mesh["tri"], self._tri32(faces_uv)
         out_dict = {}
 
         v_normal = self._vertex_normals_for(verts, verts_camera, faces)
@@ -272,7 +298,7 @@ class HipDiffRenderer(torch.nn.Module):
         normal = safe_normalize(normal) if not (outputs == "loss" and self.fused and self.lighting_type == "SH") else None
         if align_texture_except_fid is not None:
             mask = torch.zeros(faces.shape[0] + 1, dtype=torch.bool, device=rast_out.device)
-            mask[align_texture_except_fid + 1] = True
+            mask.index_fill_(0, align_texture_except_fid + 1, True)        # (scalar fill: no host->device copy, graph-safe)
             rast_mask = mask[rast_out[..., 3].long()][..., None]
             texc = torch.where(rast_mask, texc.detach(), texc)
 
@@ -297,14 +323,15 @@ class HipDiffRenderer(torch.nn.Module):
         if enable_disturbance:
             if disturbance is None:
                 disturbance = self.make_disturbance(rgba.shape[:3], rgba.device)
-            if rgba_bg is None:
+            if rgba_bg is None and not (self.fused and rgba.is_cuda and not isinstance(disturbance["idx"], (list, tuple))):
                 rgba_bg = self._background(background_color, rgba)
             rgba, cid = self.disturb(rgba, rgba_bg, rast_out, disturbance)
-            out_dict["cid"] = cid.flip(1)
+            if cid is not None:
+                out_dict["cid"] = cid.flip(1)
 
         if align_boundary_except_vid is not None:
             verts_clip = self.detach_by_indices(verts_clip, align_boundary_except_vid)
-        rgba_aa = ops.antialias(rgba, rast_out, verts_clip, tri)
+        rgba_aa = ops.antialias(rgba, rast_out, verts_clip, tri, opp=mesh["opp"])
         if fast:
             out_dict.update({"rgba_rs": rgba_aa, "reg_diffuse": reg_diffuse})
             return out_dict

@@ -53,6 +53,7 @@ class FlameTracker:
         self.fused_gbuffer = True                                 # one launch for rasterize + both interpolates
         self.fused = True                                         # fused shading / loss kernels (False: reference-shaped torch ops)
         self.opt_dict = defaultdict(bool)
+        self._split = None
 
     # ---- helpers ----
     def clear_cache(self):
@@ -97,7 +98,8 @@ class FlameTracker:
                 groups.append({"params": sel, "lr": g_lr * lr_scale})
         rest = [p for v in params.values() for p in v]
         groups.append({"params": rest})
-        return torch.optim.Adam(groups, lr=lr.base * lr_scale)
+        capturable = str(self.device).startswith("cuda")          # step counter on the device: the step can be graph-captured
+        return torch.optim.Adam(groups, lr=lr.base * lr_scale, capturable=capturable)
 
     # ---- model ----
     def forward_flame(self, timesteps):
@@ -183,6 +185,9 @@ class FlameTracker:
                                           bg_color, fid, vid, True, disturbance=disturbance, outputs="loss",
                                           want_reg_diffuse=want_reg)
             abs_sum, n_alpha = FU.photo_sum(out["rgba_rs"], gt_rgb)
+            if self._split is not None:                            # graphed step: the normaliser is applied later (GraphedStep)
+                self._split["S"], self._split["N"] = abs_sum, n_alpha
+                return abs_sum * 0.0, {"gt_rgb": gt_rgb, "rgba_rs": out["rgba_rs"], "reg_diffuse_value": out["reg_diffuse"]}
             n_mask = n_alpha * 3
             if self.dist is not None:
                 n_mask = self.dist.all_reduce_sum(n_mask) / self.dist.world_size
@@ -263,7 +268,7 @@ class FlameTracker:
                     rigid = rigid + offset[:, vids, :].var(dim=-2).mean()
                 log["reg_offset_rigid"] = w.reg_offset_rigid * rigid
             if w.reg_offset_dynamic is not None and self.dynamic_offset is not None and self.opt_dict["dynamic_offset"]:
-                prev = np.clip(timesteps - 1, 0, self.n_timesteps - 1)
+                prev = self._prev(timesteps)
                 log["reg_offset_dynamic"] = w.reg_offset_dynamic * \
                     ((self.dynamic_offset[timesteps] - self.dynamic_offset[prev]) ** 2).mean()
         return log
@@ -289,6 +294,8 @@ class FlameTracker:
         return self._region_cache[ck]
 
     def _prev(self, idx):
+        if torch.is_tensor(idx):
+            return torch.clamp(idx - 1, 0, self.n_timesteps - 1)
         return np.clip(idx - 1, 0, self.n_timesteps - 1)
 
     def compute_pose_smooth_energy(self, timesteps):
@@ -439,10 +446,12 @@ class GlobalTracker(FlameTracker):
             params["dynamic_offset"].append(self.dynamic_offset)
         return params
 
-    def get_sample(self, timesteps):
+    def get_sample(self, timesteps, device_index=False):
+        """`device_index=True` keeps `timestep_index` as a device LongTensor (needed for graph capture: a numpy
+        index would be re-uploaded on every step)."""
         ts = np.asarray(timesteps)
         idx = torch.as_tensor(ts, device=self.dataset["rgb"].device)
-        s = {"rgb": self.dataset["rgb"][idx], "lmk2d": self.dataset["lmk2d"][idx], "timestep_index": ts}
+        s = {"rgb": self.dataset["rgb"][idx], "lmk2d": self.dataset["lmk2d"][idx], "timestep_index": idx if device_index else ts}
         for k in ("intrinsic", "extrinsic"):
             if k in self.dataset:
                 s[k] = self.dataset[k][idx]
@@ -512,3 +521,88 @@ class GlobalTracker(FlameTracker):
         if path is not None:
             np.savez(path, **out)
         return out
+
+
+class GraphedStep:
+    """One optimiser step captured in hipGraphs (the 50-500 identical steps of a
+    stage are launch-bound in eager mode -- ~1300 launches per step).  Three graphs with the two frame-sharding
+    collectives in between, so that RCCL calls stay ordinary eager calls:
+
+        F : forward -> every energy term, photometric numerator S and alpha count N     (autograd tape built once)
+            [all-reduce N over ranks]  inv_n = world / (3 N_global)
+        B : E = terms + w_photo * S * inv_n ; backward into static .grad buffers
+            [all-reduce (average) of the flat gradient bucket]
+        A : Adam
+
+    Everything the graphs touch is static: the sample tensors, the parameters, their .grad and the Adam state.
+    A new batch is fed by copying into `self.sample` (same shapes) -- exactly the sequential-tracking pattern."""
+
+    def __init__(self, tracker, sample, optimizer, stage, warmup=2):
+        assert tracker.fused, "graph capture needs the fused (sync-free) path"
+        self.tr, self.opt, self.stage = tracker, optimizer, stage
+        dev = tracker.device
+        self.params = [p for g in optimizer.param_groups for p in g["params"]]
+        ts = sample["timestep_index"]
+        ts = ts if torch.is_tensor(ts) else torch.as_tensor(np.asarray(ts), device=dev)
+        self.sample = {"rgb": sample["rgb"].clone(), "lmk2d": sample["lmk2d"].clone(), "timestep_index": ts.clone()}
+        for k in ("intrinsic", "extrinsic"):
+            if k in sample and tracker.calibrated:
+                self.sample[k] = sample[k].clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):                                # optional real steps before the capture
+                tracker.optimize_iter(dict(self.sample), optimizer, stage)
+            # dry pass: populate every lazy cache (region tables, mesh tables, FLAME bases) outside the capture ...
+            s = dict(self.sample)
+            tracker.fill_cam_params_into_sample(s)
+            tracker.compute_energy(s, stage=stage)
+            # ... and create the Adam state with a zero-gradient step (a no-op on the parameters), then rewind its counter
+            for p in self.params:
+                p.grad = torch.zeros_like(p)
+            had_state = len(optimizer.state) > 0
+            if not had_state:
+                optimizer.step()
+                for st in optimizer.state.values():
+                    st["step"].zero_()
+        torch.cuda.current_stream().wait_stream(side)
+        self.inv_n = torch.zeros((), device=dev)
+        self.gF, self.gB, self.gA = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        tracker._split = {}
+        try:
+            with torch.cuda.graph(self.gF):
+                s = dict(self.sample)
+                tracker.clear_cache()
+                tracker.fill_cam_params_into_sample(s)
+                E_rest, self.log_dict, *_ = tracker.compute_energy(s, stage=stage)
+                self.S, self.N = tracker._split["S"], tracker._split["N"]
+            pool = self.gF.pool()
+            with torch.cuda.graph(self.gB, pool=pool):
+                E = E_rest + tracker.cfg.w.photo * self.S * self.inv_n
+                grads = torch.autograd.grad(E, self.params, allow_unused=True)
+                for p, g in zip(self.params, grads):
+                    if g is None:
+                        p.grad.zero_()
+                    else:
+                        p.grad.copy_(g)
+                self.E = E.detach()
+            with torch.cuda.graph(self.gA, pool=pool):
+                optimizer.step()
+        finally:
+            tracker._split = None
+
+    def __call__(self):
+        tr = self.tr
+        self.gF.replay()
+        n = self.N
+        world = 1
+        if tr.dist is not None:
+            world = tr.dist.world_size
+            n = tr.dist.all_reduce_sum(n)
+        self.inv_n.copy_(world / (3.0 * n))
+        self.gB.replay()
+        if tr.dist is not None:
+            tr.dist.average_gradients(self.params)
+        self.gA.replay()
+        tr.global_step += 1
+        return self.E
