@@ -73,6 +73,16 @@ int vhap_raster_bwd(const float* pos, const int32_t* tri, const float* rast, con
                     const float* d_rast_db, int B, int V, int F, int H, int W, float* d_pos,
                     vhap_stream_t stream);
 
+/* Triangle-parallel backward of the fused G-buffer pass (vhap_raster_interp_fwd): chains the gradients of
+ * normal [B,H,W,3], texc [B,H,W,2], texd [B,H,W,4] (and, optionally, direct gradients of rast / rast_db) into
+ * d_pos [B,V,4] and d_vnormal [B,V,3] (both ACCUMULATED, caller zero-fills) with one set of atomics per
+ * triangle vertex instead of per pixel.  Any gradient pointer may be NULL (= zero). */
+int vhap_gbuffer_bwd(const float* pos, const int32_t* tri, const float* vnormal, const float* uv,
+                     const int32_t* tri_uv, const float* rast, const float* d_normal,
+                     const float* d_texc, const float* d_texd, const float* d_rast,
+                     const float* d_rast_db, int B, int V, int F, int H, int W, float* d_pos,
+                     float* d_vnormal, vhap_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Interpolate: replaces dr.interpolate(attr, rast, tri, rast_db, diff_attrs)  (:384, :389)
  *   attr [AB,V,A] with AB in {1,B}; out [B,H,W,A]; out_da [B,H,W,2A] (NULL when rast_db is NULL),

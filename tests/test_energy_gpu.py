@@ -117,8 +117,9 @@ def test_short_fit_reduces_energy_and_exports_npz(setup, tmp_path):
     assert rep["expr"].shape == (N, 100) and rep["tex_extra"].shape == (3, T, T) and rep["lights"].shape == (9, 3)
 
 
-def test_graphed_step_matches_eager_steps(flame_model):
-    """Three optimiser steps replayed from the captured hipGraphs == three eager optimize_iter calls."""
+def test_graphed_step_matches_eager_step(flame_model):
+    """The captured hipGraph step == the eager optimize_iter: same energy, same gradients (to fp32-atomics noise), and the
+    parameters move; replaying keeps lowering the energy."""
     from vhap_amd.config import BaseTrackingConfig
     from vhap_amd.flame import FlameHead
     from vhap_amd.render_hip import HipDiffRenderer
@@ -128,8 +129,10 @@ def test_graphed_step_matches_eager_steps(flame_model):
     gt = make_scene_params(N, seed=9, image_size=(H, W))
     head, rend = FlameHead(model, topo).cuda(), HipDiffRenderer(lighting_type="SH").cuda()
     data = make_dataset(rend, head, gt, (H, W), "cuda", seed=9, tex=make_texture(9, T))
-    finals = []
-    for graphed in (False, True):
+    stage = "rgb_global_tracking"
+    names = ("shape", "expr", "rotation", "translation", "jaw_pose", "tex_extra", "lights", "static_offset", "focal_length")
+
+    def make():
         cfg = BaseTrackingConfig()
         cfg.model.tex_resolution = T
         cfg.render.disturb_rate_fg = cfg.render.disturb_rate_bg = None      # disturbance weights 0: deterministic
@@ -137,30 +140,27 @@ def test_graphed_step_matches_eager_steps(flame_model):
         with torch.no_grad():
             tr.translation[:, 2] = 0.45
             tr.expr.add_(0.05)
-        stage = "rgb_global_tracking"
+            tr.static_offset.add_(torch.randn(tr.static_offset.shape, generator=torch.Generator().manual_seed(2)).cuda() * 1e-4)
         opt = tr.configure_optimizer(tr.get_train_parameters(stage), lr_scale=0.1)
-        sample = tr.get_sample(np.array([0, 1]), device_index=True)
-        n_steps = 3
-        if graphed:
-            st = GraphedStep(tr, sample, opt, stage, warmup=0)
-            for _ in range(n_steps):
-                st()
-        else:
-            for _ in range(n_steps):
-                tr.optimize_iter(dict(sample), opt, stage)
-        torch.cuda.synchronize()
-        finals.append({k: getattr(tr, k).detach().clone() for k in ("shape", "expr", "rotation", "translation", "jaw_pose",
-                                                                   "tex_extra", "lights", "static_offset", "focal_length")})
-    # Adam's first steps are ~lr*sign(g): components whose gradient is at the fp32-atomics noise floor may flip, so the
-    # parameter trajectories are compared as vectors (direction and length), not element by element
-    for k in finals[0]:
-        a, b = finals[1][k].double().reshape(-1), finals[0][k].double().reshape(-1)
-        if k == "translation":
-            a, b = a.clone(), b.clone()
-            a[2::3] -= 0.45
-            b[2::3] -= 0.45
-        if float(b.norm()) == 0:
-            assert float(a.norm()) == 0, k
-            continue
-        cos = float((a @ b) / (a.norm() * b.norm()))
-        assert cos > 0.995 and abs(float(a.norm() / b.norm()) - 1) < 0.03, (k, cos)
+        return tr, opt, tr.get_sample(np.array([0, 1]), device_index=True)
+
+    tr_e, opt_e, sample = make()
+    s = dict(sample)
+    tr_e.fill_cam_params_into_sample(s)
+    E_e, *_ = tr_e.compute_energy(s, stage=stage)
+    E_e.backward()
+    g_e = {k: getattr(tr_e, k).grad.clone() for k in names}
+
+    tr_g, opt_g, sample = make()
+    before = {k: getattr(tr_g, k).detach().clone() for k in names}
+    st = GraphedStep(tr_g, sample, opt_g, stage, warmup=0)
+    E0 = float(st())
+    torch.cuda.synchronize()
+    assert abs(E0 - float(E_e)) <= 1e-4 * abs(float(E_e))
+    for k in names:
+        a, b = getattr(tr_g, k).grad.double().reshape(-1), g_e[k].double().reshape(-1)
+        assert float((a - b).abs().max()) <= 2e-3 * float(b.abs().max()) + 1e-12, k
+        assert not torch.equal(getattr(tr_g, k).detach(), before[k]), f"{k} did not move"
+    for _ in range(10):
+        E1 = float(st())
+    assert E1 < E0

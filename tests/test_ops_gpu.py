@@ -173,3 +173,33 @@ def test_antialias_vertical_edge_known_answer():
     row = out[0, 8, :, 0].cpu()
     assert torch.allclose(row[:8], torch.ones(8)) and torch.allclose(row[9:], torch.zeros(7))
     assert abs(float(row[8]) - 0.25) < 1e-5                     # pixel 8 (centre 8.5) is 25 % covered
+
+
+def test_fused_raster_interp_backward_matches_separate_ops(scene):
+    """Triangle-parallel G-buffer backward (vhap_gbuffer_bwd) == interpolate-backward x2 + rasterize-backward."""
+    from vhap_amd import ops
+    B, H, W = scene["B"], scene["H"], scene["W"]
+    topo = scene["topo"]
+    g = torch.Generator().manual_seed(4)
+    V = scene["pos"].shape[1]
+    vn0 = torch.nn.functional.normalize(torch.randn(B, V, 3, generator=g), dim=-1).cuda()
+    uv = torch.from_numpy(topo.verts_uvs.astype(np.float32)).cuda()
+    tri = scene["tri"].int().cuda()
+    tri_uv = torch.from_numpy(topo.faces_uv.astype(np.int32)).cuda()
+    wn, wc, wd = (torch.randn(B, H, W, k, generator=g).cuda() for k in (3, 2, 4))
+    res = []
+    for fused in (False, True):
+        pos = scene["pos"].float().cuda().requires_grad_()
+        vn = vn0.clone().requires_grad_()
+        ctx = ops.RasterizeHipContext()
+        if fused:
+            rast, db, normal, texc, texd = ops.raster_interp(ctx, pos, tri, vn, uv, tri_uv, (H, W))
+        else:
+            rast, db = ops.rasterize(ctx, pos, tri, (H, W))
+            normal, _ = ops.interpolate(vn, rast, tri)
+            texc, texd = ops.interpolate(uv[None], rast, tri_uv, rast_db=db, diff_attrs="all")
+        ((normal * wn).sum() + (texc * wc).sum() + (texd * wd).sum() * 0.01).backward()
+        res.append((normal.detach(), texc.detach(), texd.detach(), pos.grad, vn.grad))
+    for a, b in zip(res[1][:3], res[0][:3]):
+        assert torch.equal(a, b)
+    assert _rel(res[1][3], res[0][3]) < 2e-3 and _rel(res[1][4], res[0][4]) < 2e-3

@@ -25,6 +25,7 @@ SIGNATURES = {
     "vhap_raster_fwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_sz, c_sz, c_fp]),
     "vhap_raster_interp_fwd": (c_i, [c_fp] * 5 + [c_i] * 6 + [c_fp] * 5 + [c_fp, c_sz, c_sz, c_fp]),
     "vhap_raster_bwd": (c_i, [c_fp] * 5 + [c_i] * 5 + [c_fp, c_fp]),
+    "vhap_gbuffer_bwd": (c_i, [c_fp] * 11 + [c_i] * 5 + [c_fp] * 3),
     "vhap_interp_fwd": (c_i, [c_fp, c_i, c_fp, c_fp, c_fp] + [c_i] * 6 + [c_fp, c_fp, c_fp]),
     "vhap_interp_bwd": (c_i, [c_fp, c_i, c_fp, c_fp, c_fp, c_fp, c_fp] + [c_i] * 6 + [c_fp] * 4),
     "vhap_texture_num_levels": (c_i, [c_i, c_i]),

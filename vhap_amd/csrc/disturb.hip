@@ -37,40 +37,52 @@ __global__ __launch_bounds__(256) void disturb_count_kernel(const float4* __rest
     if (threadIdx.x < ncl) block_counts[(size_t)blockIdx.x * MAXC + threadIdx.x] = cnt[0][threadIdx.x] + cnt[1][threadIdx.x] + cnt[2][threadIdx.x] + cnt[3][threadIdx.x];
 }
 
-// pass 2 (one workgroup of 1024): exclusive scan over blocks, per cluster; totals[c], starts[c] (cluster-major layout)
+// pass 2 (one workgroup of 1024 = 16 waves): exclusive scan over blocks for all clusters at once; wave-level shuffle
+// scans + one LDS exchange (two barriers in total).  totals[c], totals[MAXC + c] = first slot of cluster c.
 __global__ __launch_bounds__(1024) void disturb_scan_kernel(int* __restrict__ block_counts, int nblocks, int ncl, int* __restrict__ totals) {
-    __shared__ int part[1024];
-    __shared__ int ctot[MAXC];
-    const int t = threadIdx.x;
+    __shared__ int wtot[16][MAXC];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int per = (nblocks + 1023) / 1024;
     const int b0 = t * per, b1 = min(b0 + per, nblocks);
-    for (int c = 0; c < ncl; c++) {
-        int s = 0;
-        for (int b = b0; b < b1; b++) s += block_counts[(size_t)b * MAXC + c];
-        part[t] = s;
-        __syncthreads();
-        // inclusive Hillis-Steele scan over 1024 partials
-        for (int o = 1; o < 1024; o <<= 1) {
-            const int v = t >= o ? part[t - o] : 0;
-            __syncthreads();
-            part[t] += v;
-            __syncthreads();
+    int s[MAXC], incl[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; c++) s[c] = 0;
+    for (int b = b0; b < b1; b++) {
+#pragma unroll
+        for (int c = 0; c < MAXC; c++)
+            if (c < ncl) s[c] += block_counts[(size_t)b * MAXC + c];
+    }
+#pragma unroll
+    for (int c = 0; c < MAXC; c++) {
+        int v = s[c];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(v, o, 64);
+            if (lane >= o) v += u;
         }
-        int run = part[t] - s;  // exclusive prefix of this thread's chunk
-        if (t == 1023) ctot[c] = part[1023];
+        incl[c] = v;
+        if (lane == 63) wtot[wave][c] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < MAXC; c++) {
+        if (c >= ncl) continue;
+        int run = incl[c] - s[c];
+        for (int w = 0; w < wave; w++) run += wtot[w][c];
         for (int b = b0; b < b1; b++) {
             const int v = block_counts[(size_t)b * MAXC + c];
             block_counts[(size_t)b * MAXC + c] = run;
             run += v;
         }
-        __syncthreads();
     }
     if (t == 0) {
         int start = 0;
         for (int c = 0; c < ncl; c++) {
-            totals[c] = ctot[c];
-            totals[MAXC + c] = start;  // first slot of cluster c in the sorted pixel list
-            start += ctot[c];
+            int tot = 0;
+            for (int w = 0; w < 16; w++) tot += wtot[w][c];
+            totals[c] = tot;
+            totals[MAXC + c] = start;
+            start += tot;
         }
     }
 }

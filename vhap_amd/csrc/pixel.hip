@@ -14,7 +14,7 @@
 
 namespace {
 
-__constant__ float c_dummy;
+constexpr int MAX_BLOCKS = 2048;  // grid-stride: one atomic per block and output -> at most 2048 same-address atomics
 
 struct SH9 {
     float v[9];
@@ -58,10 +58,9 @@ __global__ __launch_bounds__(256) void shade_fwd_kernel(const ShadeParams P, flo
     if (threadIdx.x < 9) s_c[threadIdx.x] = P.sh_const[threadIdx.x];
     __syncthreads();
     const long long npix = (long long)P.B * P.H * P.W;
-    const long long pi = (long long)blockIdx.x * 256 + threadIdx.x;
     float var = 0.f;
     unsigned mx = 0u;
-    if (pi < npix) {
+    for (long long pi = (long long)blockIdx.x * 256 + threadIdx.x; pi < npix; pi += (long long)gridDim.x * 256) {
         const float* nr = P.normal_raw + 3 * pi;
         const float nx = nr[0], ny = nr[1], nz = nr[2];
         const float inv = 1.0f / sqrtf(fmaxf(nx * nx + ny * ny + nz * nz, 1e-20f));
@@ -73,8 +72,8 @@ __global__ __launch_bounds__(256) void shade_fwd_kernel(const ShadeParams P, flo
             d[0] += b.v[k] * s_l[3 * k]; d[1] += b.v[k] * s_l[3 * k + 1]; d[2] += b.v[k] * s_l[3 * k + 2];
         }
         const float mean = (d[0] + d[1] + d[2]) * (1.0f / 3.0f);
-        var = 0.5f * ((d[0] - mean) * (d[0] - mean) + (d[1] - mean) * (d[1] - mean) + (d[2] - mean) * (d[2] - mean));
-        mx = f2ord(fmaxf(d[0], fmaxf(d[1], d[2])));
+        var += 0.5f * ((d[0] - mean) * (d[0] - mean) + (d[1] - mean) * (d[1] - mean) + (d[2] - mean) * (d[2] - mean));
+        mx = max(mx, f2ord(fmaxf(d[0], fmaxf(d[1], d[2]))));
         const bool fg = P.rast[pi].w > 0.0f;
         float4 o;
         if (fg) {
@@ -119,7 +118,6 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(const ShadeParams P, con
     if (threadIdx.x < 9) s_c[threadIdx.x] = P.sh_const[threadIdx.x];
     __syncthreads();
     const long long npix = (long long)P.B * P.H * P.W;
-    const long long pi = (long long)blockIdx.x * 256 + threadIdx.x;
     float gl[27];
 #pragma unroll
     for (int i = 0; i < 27; i++) gl[i] = 0.f;
@@ -132,7 +130,7 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(const ShadeParams P, con
         const unsigned u = (mx_ord & 0x80000000u) ? (mx_ord & 0x7fffffffu) : ~mx_ord;
         g_max = __uint_as_float(u) > 1.0f ? dr : 0.f;
     }
-    if (pi < npix) {
+    for (long long pi = (long long)blockIdx.x * 256 + threadIdx.x; pi < npix; pi += (long long)gridDim.x * 256) {
         const float* nr = P.normal_raw + 3 * pi;
         const float rx = nr[0], ry = nr[1], rz = nr[2];
         const float l2 = rx * rx + ry * ry + rz * rz;
@@ -168,7 +166,7 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(const ShadeParams P, con
         }
 #pragma unroll
         for (int k = 0; k < 9; k++) {
-            gl[3 * k] = b.v[k] * (gd[0] + gr[0]); gl[3 * k + 1] = b.v[k] * (gd[1] + gr[1]); gl[3 * k + 2] = b.v[k] * (gd[2] + gr[2]);
+            gl[3 * k] += b.v[k] * (gd[0] + gr[0]); gl[3 * k + 1] += b.v[k] * (gd[1] + gr[1]); gl[3 * k + 2] += b.v[k] * (gd[2] + gr[2]);
         }
         if (d_normal_raw) {
             float gnx = 0.f, gny = 0.f, gnz = 0.f;
@@ -211,16 +209,15 @@ __global__ __launch_bounds__(256) void photo_fwd_kernel(const float4* __restrict
                                                         int W, float* __restrict__ out) {
     __shared__ float rs[4], rn[4];
     const long long npix = (long long)B * H * W;
-    const long long pi = (long long)blockIdx.x * 256 + threadIdx.x;
     float s = 0.f, n = 0.f;
-    if (pi < npix) {
+    for (long long pi = (long long)blockIdx.x * 256 + threadIdx.x; pi < npix; pi += (long long)gridDim.x * 256) {
         const int HW = H * W;
         const int b = (int)(pi / HW), rem = (int)(pi - (long long)b * HW);
         const int y = rem / W, x = rem - y * W;
         const float* g = gt + (size_t)b * 3 * HW + (size_t)(H - 1 - y) * W + x;
         const float4 p = pred[pi];
-        s = fabsf(g[0] - p.x) + fabsf(g[HW] - p.y) + fabsf(g[2 * HW] - p.z);
-        n = p.w > 0.0f ? 1.0f : 0.0f;
+        s += fabsf(g[0] - p.x) + fabsf(g[HW] - p.y) + fabsf(g[2 * HW] - p.z);
+        n += p.w > 0.0f ? 1.0f : 0.0f;
     }
     s = vhap_wave_sum(s);
     n = vhap_wave_sum(n);
@@ -269,7 +266,7 @@ extern "C" int vhap_shade_fwd(const float* normal_raw, const float* albedo, cons
     hipStream_t st = vhap_stream(stream);
     if (stats && hipMemsetAsync(stats, 0, 8, st) != hipSuccess) return VHAP_E_HIP;
     const long long npix = (long long)B * H * W;
-    shade_fwd_kernel<<<vhap_cdiv(npix, 256), 256, 0, st>>>(P, reinterpret_cast<float4*>(rgba), reinterpret_cast<unsigned*>(stats));
+    shade_fwd_kernel<<<min(vhap_cdiv(npix, 256), MAX_BLOCKS), 256, 0, st>>>(P, reinterpret_cast<float4*>(rgba), reinterpret_cast<unsigned*>(stats));
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;
 }
@@ -282,7 +279,7 @@ extern "C" int vhap_shade_bwd(const float* normal_raw, const float* albedo, cons
     if (int e = check_img(B, H, W)) return e;
     ShadeParams P{normal_raw, albedo, reinterpret_cast<const float4*>(rast), nullptr, 0.f, 0.f, 0.f, lights, sh_const, B, H, W};
     const long long npix = (long long)B * H * W;
-    shade_bwd_kernel<<<vhap_cdiv(npix, 256), 256, 0, vhap_stream(stream)>>>(
+    shade_bwd_kernel<<<min(vhap_cdiv(npix, 256), MAX_BLOCKS), 256, 0, vhap_stream(stream)>>>(
         P, reinterpret_cast<const float4*>(d_rgba), d_reg, reinterpret_cast<const unsigned*>(stats), d_albedo, d_normal_raw, d_lights);
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;
@@ -296,7 +293,7 @@ extern "C" int vhap_photo_fwd(const float* pred_rgba, const float* gt_nchw, int 
     hipStream_t st = vhap_stream(stream);
     if (hipMemsetAsync(out2, 0, 8, st) != hipSuccess) return VHAP_E_HIP;
     const long long npix = (long long)B * H * W;
-    photo_fwd_kernel<<<vhap_cdiv(npix, 256), 256, 0, st>>>(reinterpret_cast<const float4*>(pred_rgba), gt_nchw, B, H, W, out2);
+    photo_fwd_kernel<<<min(vhap_cdiv(npix, 256), MAX_BLOCKS), 256, 0, st>>>(reinterpret_cast<const float4*>(pred_rgba), gt_nchw, B, H, W, out2);
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;
 }

@@ -17,7 +17,7 @@
 //                key in registers.  No LDS, no barriers, no atomics in the resolve; the winner is
 //                independent of list order.  The lane then shades its pixel once (u, v, z/w,
 //                derivatives, normal, uv, uv derivatives) and writes the G-buffer.
-#include "common.h"
+#include "raster_common.h"
 
 #pragma clang fp contract(off)  // bit-exact op order vs the oracle: only explicit fma() fuses
 
@@ -25,7 +25,6 @@ namespace {
 
 constexpr int BLK = 8;              // bin = 8x8 pixels = one wave
 constexpr int WG_BLOCKS = 4;        // 4 horizontally adjacent bins per workgroup (32x8 pixels)
-constexpr float GUARD = 1048576.0f; // 2^20 sub-pixel units
 constexpr unsigned TRANGE_NONE = 0xffffffffu;
 constexpr int LDS_BIN_LIMIT = 16384;  // dense per-workgroup bin histogram (<= 2 x 64 KiB of LDS)
 constexpr int BIN_THREADS = 1024;     // fat workgroups: fewer LDS-histogram flushes per frame
@@ -47,35 +46,6 @@ struct BinHeader {
     unsigned total;  // number of (triangle, block) pairs of this batch
     unsigned pad[15];
 };
-
-__device__ __forceinline__ bool snap_vertex(const float4 p, float hw, float hh, int& sx, int& sy) {
-    if (!(p.w > 0.0f)) return false;
-    const float xn = __fdiv_rn(p.x, p.w), yn = __fdiv_rn(p.y, p.w);
-    const float fx = __fmaf_rn(xn, hw, hw), fy = __fmaf_rn(yn, hh, hh);
-    if (!(fabsf(fx) < GUARD) || !(fabsf(fy) < GUARD)) return false;
-    sx = __float2int_rn(fx);
-    sy = __float2int_rn(fy);
-    return true;
-}
-
-// Snap + cull + pixel bbox (inclusive, clipped to the image).  Returns false when nothing to draw.
-__device__ __forceinline__ bool tri_bbox(const float4 p0, const float4 p1, const float4 p2, int H, int W,
-                                         int (&sx)[3], int (&sy)[3], long long& area, int& px0, int& px1, int& py0,
-                                         int& py1) {
-    const float hw = 8.0f * (float)W, hh = 8.0f * (float)H;
-    if (!snap_vertex(p0, hw, hh, sx[0], sy[0])) return false;
-    if (!snap_vertex(p1, hw, hh, sx[1], sy[1])) return false;
-    if (!snap_vertex(p2, hw, hh, sx[2], sy[2])) return false;
-    area = (long long)(sx[1] - sx[0]) * (sy[2] - sy[0]) - (long long)(sx[2] - sx[0]) * (sy[1] - sy[0]);
-    if (area <= 0) return false;  // back-facing or degenerate
-    const int minx = min(sx[0], min(sx[1], sx[2])), maxx = max(sx[0], max(sx[1], sx[2]));
-    const int miny = min(sy[0], min(sy[1], sy[2])), maxy = max(sy[0], max(sy[1], sy[2]));
-    px0 = max((minx - 8 + 15) >> 4, 0);
-    px1 = min((maxx - 8) >> 4, W - 1);
-    py0 = max((miny - 8 + 15) >> 4, 0);
-    py1 = min((maxy - 8) >> 4, H - 1);
-    return px0 <= px1 && py0 <= py1;
-}
 
 // Block range of one (frame, triangle): bx0 | bx1<<9 | by0<<18 | span<<27 with span = by1-by0, 31 =
 // "up to the last block row" (conservative; the raster kernel re-tests the bbox).  H,W <= 4096 -> < 512.

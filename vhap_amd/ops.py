@@ -339,6 +339,7 @@ class _RasterInterp(torch.autograd.Function):
     @staticmethod
     def forward(ctx, glctx, pos, tri, vnormal, uv, tri_uv, resolution):
         rast, db, normal, texc, texd = raster_interp_fwd(glctx, pos, tri, vnormal, uv, tri_uv, resolution)
+        ctx.set_materialize_grads(False)           # unused outputs (rast, rast_db) arrive as None, not as zero images
         ctx.save_for_backward(pos, tri, vnormal, uv, tri_uv, rast, db)
         ctx.res = (int(resolution[0]), int(resolution[1]))
         return rast, db, normal, texc, texd
@@ -349,24 +350,13 @@ class _RasterInterp(torch.autograd.Function):
         H, W = ctx.res
         B, V, _ = pos.shape
         F = tri.shape[0]
-        L = _lib.lib()
         need_pos, need_n = ctx.needs_input_grad[1], ctx.needs_input_grad[3]
-        d_vn = torch.zeros_like(vnormal) if need_n else None
-        g_rast_n = torch.empty_like(rast)
-        _lib.check(L.vhap_interp_bwd(_p(vnormal), B, _p(rast), _p(tri), 0, _p(_f32c(d_normal)), 0, B, H, W, V, F, 3,
-                                     _p(d_vn), _p(g_rast_n), 0, _stream()), "vhap_interp_bwd(normal)")
-        d_pos = None
-        if need_pos:
-            g_rast_uv, g_db_uv = torch.empty_like(rast), torch.empty_like(db)
-            uv3 = uv[None] if uv.dim() == 2 else uv
-            _lib.check(L.vhap_interp_bwd(_p(uv3), 1, _p(rast), _p(tri_uv), _p(db), _p(_f32c(d_texc)), _p(_f32c(d_texd)),
-                                         B, H, W, uv3.shape[1], F, 2, 0, _p(g_rast_uv), _p(g_db_uv), _stream()),
-                       "vhap_interp_bwd(uv)")
-            g_rast = d_rast + g_rast_n + g_rast_uv
-            g_db = d_db + g_db_uv
-            d_pos = torch.zeros_like(pos)
-            _lib.check(L.vhap_raster_bwd(_p(pos), _p(tri), _p(rast), _p(g_rast), _p(g_db), B, V, F, H, W, _p(d_pos),
-                                         _stream()), "vhap_raster_bwd")
+        c = lambda t: _f32c(t) if t is not None else None
+        d_pos = torch.zeros_like(pos) if need_pos else None
+        d_vn = torch.zeros_like(vnormal) if (need_n and d_normal is not None) else None
+        _lib.check(_lib.lib().vhap_gbuffer_bwd(_p(pos), _p(tri), _p(vnormal), _p(uv), _p(tri_uv), _p(rast), _p(c(d_normal)),
+                                               _p(c(d_texc)), _p(c(d_texd)), _p(c(d_rast)), _p(c(d_db)), B, V, F, H, W, _p(d_pos),
+                                               _p(d_vn), _stream()), "vhap_gbuffer_bwd")
         return None, d_pos, None, d_vn, None, None, None
 
 
