@@ -50,10 +50,14 @@ void vhap_debug_set_flags(int flags);
  * (triangle,tile) pairs the lists can hold; if a batch needs more the kernel falls back to a
  * brute-force per-tile scan (slower, same result), so any capacity >= 0 is correct.
  * ------------------------------------------------------------------------------------------- */
+/* flags: VHAP_RASTER_WS_CLEAN -- the caller guarantees that `workspace` was zero-filled once and has since been used only
+ * by COMPLETED calls of vhap_raster_fwd / vhap_raster_interp_fwd with the same (B, F, H, W, pair_capacity): every call
+ * leaves the bin counters zeroed again, so the per-call memset is skipped.  Without the flag any memory may be passed. */
+#define VHAP_RASTER_WS_CLEAN 1
 size_t vhap_raster_workspace_bytes(int B, int F, int H, int W, size_t pair_capacity);
 int vhap_raster_fwd(const float* pos, const int32_t* tri, int B, int V, int F, int H, int W,
                     float* rast, float* rast_db, void* workspace, size_t workspace_bytes,
-                    size_t pair_capacity, vhap_stream_t stream);
+                    size_t pair_capacity, int flags, vhap_stream_t stream);
 
 /* Fused rasterize + interpolate ("RI-fwd", the G-buffer pass): replaces dr.rasterize followed by
  * dr.interpolate(v_normal, rast, tri) (render_nvdiffrast.py:384) and
@@ -64,7 +68,7 @@ int vhap_raster_interp_fwd(const float* pos, const int32_t* tri, const float* vn
                            const float* uv, const int32_t* tri_uv, int B, int V, int VT, int F,
                            int H, int W, float* rast, float* rast_db, float* normal, float* texc,
                            float* texd, void* workspace, size_t workspace_bytes,
-                           size_t pair_capacity, vhap_stream_t stream);
+                           size_t pair_capacity, int flags, vhap_stream_t stream);
 
 /* Rasterize backward: replaces nvdiffrast's RasterizeGradKernel(Db).
  *   d_rast [B,H,W,4] (only .xy is used, like nvdiffrast), d_rast_db [B,H,W,4] or NULL
@@ -148,8 +152,9 @@ int vhap_antialias_bwd(const float* color, const float* rast, const float* pos,
  * background composite with the y-flip of :419) and tracker.py:430-439 / :547-550.
  *   normal_raw, albedo [B,H,W,3]; rast [B,H,W,4]; bg_image [B,3,H,W] in IMAGE space (row 0 = top) or
  *   NULL, in which case bg_color (HOST pointer to 3 floats) is used; lights [9,3]; sh_const [9].
- *   rgba [B,H,W,4] in renderer space.  stats (2 words, may be NULL): [0] = max(diffuse) as an
- *   order-preserving uint, [1] = sum over pixels of the unbiased variance of diffuse across RGB.
+ *   rgba [B,H,W,4] in renderer space.  stats (4 words, may be NULL): [0] = number of entries equal to the
+ *   maximum, [1] = max(diffuse) as an order-preserving uint, [2] = sum over pixels of the unbiased
+ *   variance of diffuse across RGB.
  * Backward: d_albedo / d_normal_raw [B,H,W,3] overwritten (either may be NULL); d_lights [9,3]
  * ACCUMULATED (may be NULL).  d_reg (device scalar, may be NULL) is the upstream gradient of
  * reg = relu(max(diffuse) - 1) + mean(var); it reaches d_lights only, like the reference's

@@ -108,3 +108,31 @@ def test_shade_and_photo_match_host_ops():
     assert _rel(a[4][msk], b[4][msk]) < 2e-3
     assert _rel(a[4][~msk], b[4][~msk]) < 2e-3 or float(b[4][~msk].abs().max()) == 0
     assert _rel(a[5], b[5]) < 2e-3 and _rel(a[6], b[6]) < 2e-3
+
+
+def test_shade_reg_diffuse_ties_distribute_like_torch_max():
+    """Uniform SH lighting (the tracker's initial state) makes EVERY pixel attain max(diffuse): the gradient of
+    relu(max - 1) must be shared among the ties as torch.max() does, not multiplied by their number."""
+    from vhap_amd import fused as FU
+    from vhap_amd.render_hip import HipDiffRenderer, get_SH_shading, safe_normalize
+    B, H, W = 1, 16, 16
+    g = torch.Generator().manual_seed(0)
+    nraw = torch.randn(B, H, W, 3, generator=g).cuda()
+    alb = torch.rand(B, H, W, 3, generator=g).cuda()
+    rast = torch.ones(B, H, W, 4).cuda()
+    gt = torch.rand(B, 3, H, W, generator=g).cuda()
+    r = HipDiffRenderer(lighting_type="SH").cuda()
+    grads = []
+    for fused in (False, True):
+        lights = torch.zeros(1, 9, 3).cuda()
+        lights[0, 0] = 3.5449077 * 1.01                         # uniform, slightly above 1 -> relu active, all pixels tie
+        lights.requires_grad_()
+        if fused:
+            _, reg = FU.shade(nraw, alb, lights, rast, gt.permute(0, 2, 3, 1), r.sh_const, want_reg=True)
+        else:
+            dd = get_SH_shading(safe_normalize(nraw), lights, r.sh_const).permute(0, 3, 1, 2)
+            reg = torch.relu(dd.max() - 1) + dd.var(dim=1).mean()
+        reg.backward()
+        grads.append((float(reg), lights.grad.clone()))
+    assert abs(grads[0][0] - grads[1][0]) < 1e-6
+    assert float((grads[0][1] - grads[1][1]).abs().max()) < 1e-4 * float(grads[0][1].abs().max())

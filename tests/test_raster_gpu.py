@@ -115,4 +115,4 @@ def test_bad_arguments_raise():
         ops.raster_fwd(ctx, pos, tri.long(), (64, 64))
     with pytest.raises(RuntimeError):
         ops.raster_fwd(ctx, pos.cpu(), tri.cpu(), (64, 64))
-    assert _lib.lib().vhap_raster_fwd(0, 0, 1, 1, 1, 8, 8, 0, 0, 0, 0, 0, 0) == -1
+    assert _lib.lib().vhap_raster_fwd(0, 0, 1, 1, 1, 8, 8, 0, 0, 0, 0, 0, 0, 0) == -1

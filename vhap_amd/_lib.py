@@ -22,8 +22,8 @@ SIGNATURES = {
     "vhap_strerror": (ctypes.c_char_p, [c_i]),
     "vhap_debug_set_flags": (None, [c_i]),
     "vhap_raster_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_sz]),
-    "vhap_raster_fwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_sz, c_sz, c_fp]),
-    "vhap_raster_interp_fwd": (c_i, [c_fp] * 5 + [c_i] * 6 + [c_fp] * 5 + [c_fp, c_sz, c_sz, c_fp]),
+    "vhap_raster_fwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_sz, c_sz, c_i, c_fp]),
+    "vhap_raster_interp_fwd": (c_i, [c_fp] * 5 + [c_i] * 6 + [c_fp] * 5 + [c_fp, c_sz, c_sz, c_i, c_fp]),
     "vhap_raster_bwd": (c_i, [c_fp] * 5 + [c_i] * 5 + [c_fp, c_fp]),
     "vhap_gbuffer_bwd": (c_i, [c_fp] * 11 + [c_i] * 5 + [c_fp] * 3),
     "vhap_interp_fwd": (c_i, [c_fp, c_i, c_fp, c_fp, c_fp] + [c_i] * 6 + [c_fp, c_fp, c_fp]),

@@ -263,7 +263,8 @@ extern "C" int vhap_antialias_bwd(const float* color, const float* rast, const f
     hipStream_t st = vhap_stream(stream);
     const long long n = (long long)B * H * W * C;
     if (d_color) {   // pass-through part of the gradient
-        if (hipMemcpyAsync(d_color, d_out, sizeof(float) * n, hipMemcpyDeviceToDevice, st) != hipSuccess) return VHAP_E_HIP;
+        vhap_copy_async(d_color, d_out, sizeof(float) * n, st);
+        VHAP_LAUNCH_CHECK();
     }
     return dispatch_C(C, [&](auto c) {
         aa_bwd_kernel<decltype(c)::value><<<1024, 256, 0, st>>>(color, reinterpret_cast<const float4*>(rast),

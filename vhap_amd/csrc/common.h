@@ -33,3 +33,26 @@ __device__ __forceinline__ float vhap_wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+
+// Zero-fill / copy as ordinary kernel launches.  hipMemsetAsync / hipMemcpyAsync become memset / memcpy NODES under
+// stream capture, and on ROCm 7.2 those nodes were observed to run out of order with the neighbouring kernel nodes when
+// the graph is replayed on the null stream (stale accumulators, tools/debug_graph6.py) -- kernels nodes keep their order.
+// `bytes` must be a multiple of 4 and `p` 4-byte aligned.
+static __global__ __launch_bounds__(256) void vhap_zero_words_kernel(uint32_t* __restrict__ p, size_t nwords) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (size_t)gridDim.x * 256) p[i] = 0u;
+}
+static inline void vhap_zero_async(void* p, size_t bytes, hipStream_t st) {
+    const size_t nwords = bytes / 4;
+    if (nwords == 0) return;
+    const int blocks = (int)((nwords + 255) / 256 < 2048 ? (nwords + 255) / 256 : 2048);
+    vhap_zero_words_kernel<<<blocks, 256, 0, st>>>(reinterpret_cast<uint32_t*>(p), nwords);
+}
+static __global__ __launch_bounds__(256) void vhap_copy_words_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, size_t nwords) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+static inline void vhap_copy_async(void* dst, const void* src, size_t bytes, hipStream_t st) {
+    const size_t nwords = bytes / 4;
+    if (nwords == 0) return;
+    const int blocks = (int)((nwords + 255) / 256 < 4096 ? (nwords + 255) / 256 : 4096);
+    vhap_copy_words_kernel<<<blocks, 256, 0, st>>>(reinterpret_cast<const uint32_t*>(src), reinterpret_cast<uint32_t*>(dst), nwords);
+}

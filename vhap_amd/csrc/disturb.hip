@@ -16,6 +16,7 @@
 namespace {
 
 constexpr int MAXC = 16;  // max clusters (the reference configures 7 + background + "none" = 9)
+constexpr int DB = 1024;   // pixels per counting-sort block (16 waves): keeps the single-workgroup scan short
 
 __device__ __forceinline__ int pixel_cluster(const float4* __restrict__ rast, const int* __restrict__ fid2cid, int nfid, long long p) {
     const int fid = (int)rast[p].w;
@@ -23,10 +24,10 @@ __device__ __forceinline__ int pixel_cluster(const float4* __restrict__ rast, co
 }
 
 // pass 1: block_counts[block][c]
-__global__ __launch_bounds__(256) void disturb_count_kernel(const float4* __restrict__ rast, const int* __restrict__ fid2cid, int nfid,
+__global__ __launch_bounds__(DB) void disturb_count_kernel(const float4* __restrict__ rast, const int* __restrict__ fid2cid, int nfid,
                                                             int ncl, long long n, int* __restrict__ block_counts) {
-    __shared__ int cnt[4][MAXC];
-    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+    __shared__ int cnt[DB / 64][MAXC];
+    const long long p = (long long)blockIdx.x * DB + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = p < n ? pixel_cluster(rast, fid2cid, nfid, p) : -1;
     for (int k = 0; k < ncl; k++) {
@@ -34,7 +35,11 @@ __global__ __launch_bounds__(256) void disturb_count_kernel(const float4* __rest
         if (lane == 0) cnt[wave][k] = m;
     }
     __syncthreads();
-    if (threadIdx.x < ncl) block_counts[(size_t)blockIdx.x * MAXC + threadIdx.x] = cnt[0][threadIdx.x] + cnt[1][threadIdx.x] + cnt[2][threadIdx.x] + cnt[3][threadIdx.x];
+    if (threadIdx.x < ncl) {
+        int tot = 0;
+        for (int w = 0; w < DB / 64; w++) tot += cnt[w][threadIdx.x];
+        block_counts[(size_t)blockIdx.x * MAXC + threadIdx.x] = tot;
+    }
 }
 
 // pass 2 (one workgroup of 1024 = 16 waves): exclusive scan over blocks for all clusters at once; wave-level shuffle
@@ -88,11 +93,11 @@ __global__ __launch_bounds__(1024) void disturb_scan_kernel(int* __restrict__ bl
 }
 
 // pass 3: perm[starts[c] + block_offset[c] + rank in block] = pixel id
-__global__ __launch_bounds__(256) void disturb_scatter_kernel(const float4* __restrict__ rast, const int* __restrict__ fid2cid, int nfid,
+__global__ __launch_bounds__(DB) void disturb_scatter_kernel(const float4* __restrict__ rast, const int* __restrict__ fid2cid, int nfid,
                                                               int ncl, long long n, const int* __restrict__ block_offsets,
                                                               const int* __restrict__ totals, int* __restrict__ perm) {
-    __shared__ int wcnt[4][MAXC];
-    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+    __shared__ int wcnt[DB / 64][MAXC];
+    const long long p = (long long)blockIdx.x * DB + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = p < n ? pixel_cluster(rast, fid2cid, nfid, p) : -1;
     int rank = 0;
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(256) void disturb_bwd_kernel(const float4* __restri
 extern "C" size_t vhap_disturb_workspace_ints(int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return 0;
     const long long n = (long long)B * H * W;
-    const long long nblocks = (n + 255) / 256;
+    const long long nblocks = (n + DB - 1) / DB;
     return (size_t)(2 * MAXC + nblocks * MAXC + n);
 }
 
@@ -159,19 +164,19 @@ extern "C" int vhap_disturb_fwd(const float* rgba, const float* rast, const int3
     if (!rgba || !rast || !fid2cid || !w_fg || !w_bg || !idx || !workspace || !out || !keep) return VHAP_E_NULLPTR;
     if (B <= 0 || H <= 0 || W <= 0 || ncl <= 0 || ncl > MAXC || nfid <= 0 || (long long)B * H * W >= (1ll << 31)) return VHAP_E_BADDIM;
     const long long n = (long long)B * H * W;
-    const int nblocks = vhap_cdiv(n, 256);
+    const int nblocks = vhap_cdiv(n, DB);
     int* totals = workspace;
     int* block_counts = workspace + 2 * MAXC;
     int* perm = block_counts + (size_t)nblocks * MAXC;
     hipStream_t st = vhap_stream(stream);
     const float4* r4 = reinterpret_cast<const float4*>(rast);
-    disturb_count_kernel<<<nblocks, 256, 0, st>>>(r4, fid2cid, nfid, ncl, n, block_counts);
+    disturb_count_kernel<<<nblocks, DB, 0, st>>>(r4, fid2cid, nfid, ncl, n, block_counts);
     VHAP_LAUNCH_CHECK();
     disturb_scan_kernel<<<1, 1024, 0, st>>>(block_counts, nblocks, ncl, totals);
     VHAP_LAUNCH_CHECK();
-    disturb_scatter_kernel<<<nblocks, 256, 0, st>>>(r4, fid2cid, nfid, ncl, n, block_counts, totals, perm);
+    disturb_scatter_kernel<<<nblocks, DB, 0, st>>>(r4, fid2cid, nfid, ncl, n, block_counts, totals, perm);
     VHAP_LAUNCH_CHECK();
-    disturb_apply_kernel<<<nblocks, 256, 0, st>>>(reinterpret_cast<const float4*>(rgba), nullptr, nullptr, B, H, W, r4, fid2cid, nfid, w_fg,
+    disturb_apply_kernel<<<vhap_cdiv(n, 256), 256, 0, st>>>(reinterpret_cast<const float4*>(rgba), nullptr, nullptr, B, H, W, r4, fid2cid, nfid, w_fg,
                                                   w_bg, reinterpret_cast<const long long*>(idx), totals, perm,
                                                   reinterpret_cast<float4*>(out), keep);
     VHAP_LAUNCH_CHECK();

@@ -230,6 +230,10 @@ extern "C" int vhap_raster_bwd(const float* pos, const int32_t* tri, const float
 
 namespace {
 
+// 16 lanes cooperate on one (frame, triangle): lane s visits bbox pixels s, s+16, ...; a 4-step butterfly
+// reduces the 18 accumulators inside the 16-lane row; lanes 0..8 then issue the atomics.
+constexpr int GB_LANES = 16;
+
 __global__ __launch_bounds__(256) void gbuffer_bwd_kernel(const float4* __restrict__ pos, const int* __restrict__ tri,
                                                           const float* __restrict__ vnormal, const float2* __restrict__ uv,
                                                           const int* __restrict__ tri_uv, const float4* __restrict__ rast,
@@ -237,9 +241,10 @@ __global__ __launch_bounds__(256) void gbuffer_bwd_kernel(const float4* __restri
                                                           const float4* __restrict__ d_texd, const float4* __restrict__ d_rast,
                                                           const float4* __restrict__ d_db, int B, int V, int F, int H, int W,
                                                           float* __restrict__ d_pos, float* __restrict__ d_vnormal) {
-    const int g = blockIdx.x * 256 + threadIdx.x;
-    if (g >= B * F) return;
-    const int b = g / F, t = g - b * F;
+    const long long gid = ((long long)blockIdx.x * 256 + threadIdx.x) / GB_LANES;
+    const int sub = threadIdx.x & (GB_LANES - 1);
+    if (gid >= (long long)B * F) return;   // whole 16-lane group exits together
+    const int b = (int)(gid / F), t = (int)(gid - (long long)b * F);
     const int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
     if ((unsigned)i0 >= (unsigned)V || (unsigned)i1 >= (unsigned)V || (unsigned)i2 >= (unsigned)V) return;
     const float4* P = pos + (size_t)b * V;
@@ -249,7 +254,6 @@ __global__ __launch_bounds__(256) void gbuffer_bwd_kernel(const float4* __restri
     if (!tri_bbox(p0, p1, p2, H, W, sx, sy, area, px0, px1, py0, py1)) return;
     const float xs = 2.0f / (float)W, xo = 1.0f / (float)W - 1.0f;
     const float ys = 2.0f / (float)H, yo = 1.0f / (float)H - 1.0f;
-    // per-triangle constants
     const float X0 = p2.y * p1.w - p1.y * p2.w, Y0 = p1.x * p2.w - p2.x * p1.w;
     const float X1 = p0.y * p2.w - p2.y * p0.w, Y1 = p2.x * p0.w - p0.x * p2.w;
     const float X2 = p1.y * p0.w - p0.y * p1.w, Y2 = p0.x * p1.w - p1.x * p0.w;
@@ -266,94 +270,94 @@ __global__ __launch_bounds__(256) void gbuffer_bwd_kernel(const float4* __restri
         e0 = make_float2(u0.x - u2.x, u0.y - u2.y);
         e1 = make_float2(u1.x - u2.x, u1.y - u2.y);
     }
-    float dp[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};   // [vertex][x, y, w]
-    float dn[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    float acc[18];   // [0..8] = d_pos (vertex-major: x, y, w), [9..17] = d_vnormal (vertex-major)
+#pragma unroll
+    for (int k = 0; k < 18; k++) acc[k] = 0.f;
     const float idf = (float)(t + 1);
-    for (int py = py0; py <= py1; py++) {
-        const size_t row = ((size_t)b * H + py) * W;
-        const float fy = ys * (float)py + yo;
-        for (int px = px0; px <= px1; px++) {
-            const size_t pi = row + px;
-            const float4 r = rast[pi];
-            if (r.w != idf) continue;
-            const float b0 = r.x, b1 = r.y, b2 = (1.0f - b0) - b1;
-            float g0 = 0.f, g1 = 0.f;
-            float4 gd = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (d_rast) { const float4 q = d_rast[pi]; g0 = q.x; g1 = q.y; }
-            if (d_db) gd = d_db[pi];
-            if (d_normal) {
-                const float* gn = d_normal + 3 * pi;
+    const int bw = px1 - px0 + 1, npx = bw * (py1 - py0 + 1);
+    for (int k = sub; k < npx; k += GB_LANES) {
+        const int ry = k / bw, px = px0 + (k - ry * bw), py = py0 + ry;
+        const size_t pi = ((size_t)b * H + py) * W + px;
+        const float4 r = rast[pi];
+        if (r.w != idf) continue;
+        const float b0 = r.x, b1 = r.y, b2 = (1.0f - b0) - b1;
+        float g0 = 0.f, g1 = 0.f;
+        float4 gd = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (d_rast) { const float4 q = d_rast[pi]; g0 = q.x; g1 = q.y; }
+        if (d_db) gd = d_db[pi];
+        if (d_normal) {
+            const float* gn = d_normal + 3 * pi;
 #pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    const float v = gn[k];
-                    dn[0][k] += b0 * v; dn[1][k] += b1 * v; dn[2][k] += b2 * v;
-                    g0 += v * nd0[k]; g1 += v * nd1[k];
-                }
+            for (int c = 0; c < 3; c++) {
+                const float v = gn[c];
+                acc[9 + c] += b0 * v; acc[12 + c] += b1 * v; acc[15 + c] += b2 * v;
+                g0 += v * nd0[c]; g1 += v * nd1[c];
             }
-            if (d_texc) {
-                const float2 gt = d_texc[pi];
-                g0 += gt.x * e0.x + gt.y * e0.y;
-                g1 += gt.x * e1.x + gt.y * e1.y;
-            }
-            if (d_texd) {
-                const float4 q = d_texd[pi];   // grads of (du/dX, du/dY, dv/dX, dv/dY) of the texture coordinate
-                gd.x += q.x * e0.x + q.z * e0.y; gd.z += q.x * e1.x + q.z * e1.y;
-                gd.y += q.y * e0.x + q.w * e0.y; gd.w += q.y * e1.x + q.w * e1.y;
-            }
-            // ---- rasterizer backward (same algebra as raster_bwd_kernel) ----
-            const float fx = xs * (float)px + xo;
-            const float p0x = p0.x - fx * p0.w, p0y = p0.y - fy * p0.w;
-            const float p1x = p1.x - fx * p1.w, p1y = p1.y - fy * p1.w;
-            const float p2x = p2.x - fx * p2.w, p2y = p2.y - fy * p2.w;
-            const float a0 = p1x * p2y - p1y * p2x, a1 = p2x * p0y - p2y * p0x, a2 = p0x * p1y - p0y * p1x;
-            const float at = a0 + a1 + a2;
-            if (!(fabsf(at) > 0.0f)) continue;
-            const float iw = 1.0f / at;
-            const float r0 = a0 * iw, r1 = a1 * iw;
-            float G0 = g0 + xs * iw * Tx * gd.x + ys * iw * Ty * gd.y;
-            float G1 = g1 + xs * iw * Tx * gd.z + ys * iw * Ty * gd.w;
-            if (!(r0 >= 0.0f && r0 <= 1.0f)) G0 = 0.0f;
-            if (!(r1 >= 0.0f && r1 <= 1.0f)) G1 = 0.0f;
-            const float giw = xs * (b0 * Tx - X0) * gd.x + ys * (b0 * Ty - Y0) * gd.y + xs * (b1 * Tx - X1) * gd.z +
-                              ys * (b1 * Ty - Y1) * gd.w;
-            const float s = G0 * r0 + G1 * r1;
-            const float gat = -iw * iw * giw;
-            const float ga0 = (G0 - s) * iw + gat, ga1 = (G1 - s) * iw + gat, ga2 = (-s) * iw + gat;
-            const float gp0x = -p2y * ga1 + p1y * ga2, gp0y = p2x * ga1 - p1x * ga2;
-            const float gp1x = p2y * ga0 - p0y * ga2, gp1y = -p2x * ga0 + p0x * ga2;
-            const float gp2x = -p1y * ga0 + p0y * ga1, gp2y = p1x * ga0 - p0x * ga1;
-            dp[0][0] += gp0x; dp[0][1] += gp0y; dp[0][2] += -fx * gp0x - fy * gp0y;
-            dp[1][0] += gp1x; dp[1][1] += gp1y; dp[1][2] += -fx * gp1x - fy * gp1y;
-            dp[2][0] += gp2x; dp[2][1] += gp2y; dp[2][2] += -fx * gp2x - fy * gp2y;
-            const float cx = xs * iw, cy = ys * iw;
-            const float sxg = b0 * gd.x + b1 * gd.z, syg = b0 * gd.y + b1 * gd.w;
-            const float gX0 = cx * (sxg - gd.x), gX1 = cx * (sxg - gd.z), gX2 = cx * sxg;
-            const float gY0 = cy * (syg - gd.y), gY1 = cy * (syg - gd.w), gY2 = cy * syg;
-            dp[2][1] += p1.w * gX0; dp[1][2] += p2.y * gX0; dp[1][1] -= p2.w * gX0; dp[2][2] -= p1.y * gX0;
-            dp[0][1] += p2.w * gX1; dp[2][2] += p0.y * gX1; dp[2][1] -= p0.w * gX1; dp[0][2] -= p2.y * gX1;
-            dp[1][1] += p0.w * gX2; dp[0][2] += p1.y * gX2; dp[0][1] -= p1.w * gX2; dp[1][2] -= p0.y * gX2;
-            dp[1][0] += p2.w * gY0; dp[2][2] += p1.x * gY0; dp[2][0] -= p1.w * gY0; dp[1][2] -= p2.x * gY0;
-            dp[2][0] += p0.w * gY1; dp[0][2] += p2.x * gY1; dp[0][0] -= p2.w * gY1; dp[2][2] -= p0.x * gY1;
-            dp[0][0] += p1.w * gY2; dp[1][2] += p0.x * gY2; dp[1][0] -= p0.w * gY2; dp[0][2] -= p1.x * gY2;
         }
-    }
-    const int vi[3] = {i0, i1, i2};
-    if (d_pos) {
-        float* D = d_pos + (size_t)b * V * 4;
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            if (dp[k][0] != 0.f) atomicAdd(&D[4 * vi[k] + 0], dp[k][0]);
-            if (dp[k][1] != 0.f) atomicAdd(&D[4 * vi[k] + 1], dp[k][1]);
-            if (dp[k][2] != 0.f) atomicAdd(&D[4 * vi[k] + 3], dp[k][2]);
+        if (d_texc) {
+            const float2 gt = d_texc[pi];
+            g0 += gt.x * e0.x + gt.y * e0.y;
+            g1 += gt.x * e1.x + gt.y * e1.y;
         }
+        if (d_texd) {
+            const float4 q = d_texd[pi];   // grads of (du/dX, du/dY, dv/dX, dv/dY) of the texture coordinate
+            gd.x += q.x * e0.x + q.z * e0.y; gd.z += q.x * e1.x + q.z * e1.y;
+            gd.y += q.y * e0.x + q.w * e0.y; gd.w += q.y * e1.x + q.w * e1.y;
+        }
+        // ---- rasterizer backward (same algebra as raster_bwd_kernel) ----
+        const float fx = xs * (float)px + xo, fy = ys * (float)py + yo;
+        const float p0x = p0.x - fx * p0.w, p0y = p0.y - fy * p0.w;
+        const float p1x = p1.x - fx * p1.w, p1y = p1.y - fy * p1.w;
+        const float p2x = p2.x - fx * p2.w, p2y = p2.y - fy * p2.w;
+        const float a0 = p1x * p2y - p1y * p2x, a1 = p2x * p0y - p2y * p0x, a2 = p0x * p1y - p0y * p1x;
+        const float at = a0 + a1 + a2;
+        if (!(fabsf(at) > 0.0f)) continue;
+        const float iw = 1.0f / at;
+        const float r0 = a0 * iw, r1 = a1 * iw;
+        float G0 = g0 + xs * iw * Tx * gd.x + ys * iw * Ty * gd.y;
+        float G1 = g1 + xs * iw * Tx * gd.z + ys * iw * Ty * gd.w;
+        if (!(r0 >= 0.0f && r0 <= 1.0f)) G0 = 0.0f;
+        if (!(r1 >= 0.0f && r1 <= 1.0f)) G1 = 0.0f;
+        const float giw = xs * (b0 * Tx - X0) * gd.x + ys * (b0 * Ty - Y0) * gd.y + xs * (b1 * Tx - X1) * gd.z +
+                          ys * (b1 * Ty - Y1) * gd.w;
+        const float s = G0 * r0 + G1 * r1;
+        const float gat = -iw * iw * giw;
+        const float ga0 = (G0 - s) * iw + gat, ga1 = (G1 - s) * iw + gat, ga2 = (-s) * iw + gat;
+        const float gp0x = -p2y * ga1 + p1y * ga2, gp0y = p2x * ga1 - p1x * ga2;
+        const float gp1x = p2y * ga0 - p0y * ga2, gp1y = -p2x * ga0 + p0x * ga2;
+        const float gp2x = -p1y * ga0 + p0y * ga1, gp2y = p1x * ga0 - p0x * ga1;
+        acc[0] += gp0x; acc[1] += gp0y; acc[2] += -fx * gp0x - fy * gp0y;
+        acc[3] += gp1x; acc[4] += gp1y; acc[5] += -fx * gp1x - fy * gp1y;
+        acc[6] += gp2x; acc[7] += gp2y; acc[8] += -fx * gp2x - fy * gp2y;
+        const float cx = xs * iw, cy = ys * iw;
+        const float sxg = b0 * gd.x + b1 * gd.z, syg = b0 * gd.y + b1 * gd.w;
+        const float gX0 = cx * (sxg - gd.x), gX1 = cx * (sxg - gd.z), gX2 = cx * sxg;
+        const float gY0 = cy * (syg - gd.y), gY1 = cy * (syg - gd.w), gY2 = cy * syg;
+        acc[7] += p1.w * gX0; acc[5] += p2.y * gX0; acc[4] -= p2.w * gX0; acc[8] -= p1.y * gX0;
+        acc[1] += p2.w * gX1; acc[8] += p0.y * gX1; acc[7] -= p0.w * gX1; acc[2] -= p2.y * gX1;
+        acc[4] += p0.w * gX2; acc[2] += p1.y * gX2; acc[1] -= p1.w * gX2; acc[5] -= p0.y * gX2;
+        acc[3] += p2.w * gY0; acc[8] += p1.x * gY0; acc[6] -= p1.w * gY0; acc[5] -= p2.x * gY0;
+        acc[6] += p0.w * gY1; acc[2] += p2.x * gY1; acc[0] -= p2.w * gY1; acc[8] -= p0.x * gY1;
+        acc[0] += p1.w * gY2; acc[5] += p0.x * gY2; acc[3] -= p0.w * gY2; acc[2] -= p1.x * gY2;
     }
-    if (d_vnormal && d_normal) {
-        float* D = d_vnormal + (size_t)b * V * 3;
+    // butterfly over the 16-lane group (every lane ends up with the full sums)
 #pragma unroll
-        for (int k = 0; k < 3; k++)
+    for (int k = 0; k < 18; k++) {
+        float v = acc[k];
 #pragma unroll
-            for (int c = 0; c < 3; c++)
-                if (dn[k][c] != 0.f) atomicAdd(&D[3 * vi[k] + c], dn[k][c]);
+        for (int o = GB_LANES / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, GB_LANES);
+        acc[k] = v;
+    }
+    if (sub < 9) {
+        const int vtx = sub / 3, c = sub - 3 * vtx;
+        const int vi = vtx == 0 ? i0 : (vtx == 1 ? i1 : i2);
+        float vp = 0.f, vn = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            if (k == sub) { vp = acc[k]; vn = acc[9 + k]; }
+        }
+        if (d_pos && vp != 0.f) atomicAdd(&d_pos[((size_t)b * V + vi) * 4 + (c == 2 ? 3 : c)], vp);
+        if (d_vnormal && d_normal && vn != 0.f) atomicAdd(&d_vnormal[((size_t)b * V + vi) * 3 + c], vn);
     }
 }
 
@@ -367,7 +371,7 @@ extern "C" int vhap_gbuffer_bwd(const float* pos, const int32_t* tri, const floa
     if (!pos || !tri || !rast) return VHAP_E_NULLPTR;
     if ((d_normal && !vnormal) || ((d_texc || d_texd) && (!uv || !tri_uv))) return VHAP_E_NULLPTR;
     if (B <= 0 || V <= 0 || F <= 0 || H <= 0 || W <= 0 || (long long)B * F >= (1ll << 31)) return VHAP_E_BADDIM;
-    gbuffer_bwd_kernel<<<vhap_cdiv((long long)B * F, 256), 256, 0, vhap_stream(stream)>>>(
+    gbuffer_bwd_kernel<<<vhap_cdiv((long long)B * F * GB_LANES, 256), 256, 0, vhap_stream(stream)>>>(
         reinterpret_cast<const float4*>(pos), tri, vnormal, reinterpret_cast<const float2*>(uv), tri_uv,
         reinterpret_cast<const float4*>(rast), d_normal, reinterpret_cast<const float2*>(d_texc), reinterpret_cast<const float4*>(d_texd),
         reinterpret_cast<const float4*>(d_rast), reinterpret_cast<const float4*>(d_rast_db), B, V, F, H, W, d_pos, d_vnormal);

@@ -48,18 +48,23 @@ struct ShadeParams {
     int B, H, W;
 };
 
-// stats[0] = ordered-uint max of diffuse (atomicMax), stats[1] = float sum over pixels of var_channels(diffuse)
+// stats (4 words): [0..1] = u64 (ordered-uint max of diffuse << 32 | number of entries equal to it), [2] = float sum over
+// pixels of var_channels(diffuse).  The tie count makes the backward of max() distribute evenly like torch's.
 __global__ __launch_bounds__(256) void shade_fwd_kernel(const ShadeParams P, float4* __restrict__ rgba,
                                                         unsigned* __restrict__ stats) {
     __shared__ float s_l[27], s_c[9];
     __shared__ float red_var[4];
-    __shared__ unsigned red_max[4];
+    __shared__ unsigned long long red_max[4];
     if (threadIdx.x < 27) s_l[threadIdx.x] = P.lights[threadIdx.x];
     if (threadIdx.x < 9) s_c[threadIdx.x] = P.sh_const[threadIdx.x];
     __syncthreads();
     const long long npix = (long long)P.B * P.H * P.W;
     float var = 0.f;
-    unsigned mx = 0u;
+    unsigned long long mx = 0ull;   // (ordered max << 32) | tie count
+    auto merge = [](unsigned long long a, unsigned long long b) {
+        const unsigned ha = (unsigned)(a >> 32), hb = (unsigned)(b >> 32);
+        return ha > hb ? a : (hb > ha ? b : a + (b & 0xffffffffull));
+    };
     for (long long pi = (long long)blockIdx.x * 256 + threadIdx.x; pi < npix; pi += (long long)gridDim.x * 256) {
         const float* nr = P.normal_raw + 3 * pi;
         const float nx = nr[0], ny = nr[1], nz = nr[2];
@@ -73,7 +78,8 @@ __global__ __launch_bounds__(256) void shade_fwd_kernel(const ShadeParams P, flo
         }
         const float mean = (d[0] + d[1] + d[2]) * (1.0f / 3.0f);
         var += 0.5f * ((d[0] - mean) * (d[0] - mean) + (d[1] - mean) * (d[1] - mean) + (d[2] - mean) * (d[2] - mean));
-        mx = max(mx, f2ord(fmaxf(d[0], fmaxf(d[1], d[2]))));
+#pragma unroll
+        for (int c = 0; c < 3; c++) mx = merge(mx, ((unsigned long long)f2ord(d[c]) << 32) | 1ull);
         const bool fg = P.rast[pi].w > 0.0f;
         float4 o;
         if (fg) {
@@ -93,13 +99,24 @@ __global__ __launch_bounds__(256) void shade_fwd_kernel(const ShadeParams P, flo
     if (stats) {
         var = vhap_wave_sum(var);
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o, 64));
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)mx, o, 64), hi = (unsigned)__shfl_xor((int)(unsigned)(mx >> 32), o, 64);
+            mx = merge(mx, ((unsigned long long)hi << 32) | lo);
+        }
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         if (lane == 0) { red_var[wave] = var; red_max[wave] = mx; }
         __syncthreads();
         if (threadIdx.x == 0) {
-            atomicAdd(reinterpret_cast<float*>(stats) + 1, red_var[0] + red_var[1] + red_var[2] + red_var[3]);
-            atomicMax(stats, max(max(red_max[0], red_max[1]), max(red_max[2], red_max[3])));
+            atomicAdd(reinterpret_cast<float*>(stats) + 2, red_var[0] + red_var[1] + red_var[2] + red_var[3]);
+            const unsigned long long m = merge(merge(red_max[0], red_max[1]), merge(red_max[2], red_max[3]));
+            unsigned long long* g = reinterpret_cast<unsigned long long*>(stats);
+            unsigned long long old = *reinterpret_cast<volatile unsigned long long*>(g);
+            while (true) {   // (max, count) monoid: CAS loop, at most one per block
+                const unsigned long long want = merge(old, m);
+                const unsigned long long seen = atomicCAS(g, old, want);
+                if (seen == old) break;
+                old = seen;
+            }
         }
     }
 }
@@ -126,9 +143,10 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(const ShadeParams P, con
     if (d_reg && stats) {
         const float dr = d_reg[0];
         g_var = dr / (float)npix;
-        mx_ord = stats[0];
+        mx_ord = stats[1];                                  // high word of the packed (max, ties)
+        const unsigned ties = stats[0];
         const unsigned u = (mx_ord & 0x80000000u) ? (mx_ord & 0x7fffffffu) : ~mx_ord;
-        g_max = __uint_as_float(u) > 1.0f ? dr : 0.f;
+        g_max = __uint_as_float(u) > 1.0f ? dr / (float)max(ties, 1u) : 0.f;   // evenly among ties, like torch.max()
     }
     for (long long pi = (long long)blockIdx.x * 256 + threadIdx.x; pi < npix; pi += (long long)gridDim.x * 256) {
         const float* nr = P.normal_raw + 3 * pi;
@@ -264,7 +282,7 @@ extern "C" int vhap_shade_fwd(const float* normal_raw, const float* albedo, cons
     ShadeParams P{normal_raw, albedo, reinterpret_cast<const float4*>(rast), bg_image, 0.f, 0.f, 0.f, lights, sh_const, B, H, W};
     if (!bg_image) { P.bg_r = bg_color[0]; P.bg_g = bg_color[1]; P.bg_b = bg_color[2]; }
     hipStream_t st = vhap_stream(stream);
-    if (stats && hipMemsetAsync(stats, 0, 8, st) != hipSuccess) return VHAP_E_HIP;
+    if (stats) { vhap_zero_async(stats, 16, st); VHAP_LAUNCH_CHECK(); }
     const long long npix = (long long)B * H * W;
     shade_fwd_kernel<<<min(vhap_cdiv(npix, 256), MAX_BLOCKS), 256, 0, st>>>(P, reinterpret_cast<float4*>(rgba), reinterpret_cast<unsigned*>(stats));
     VHAP_LAUNCH_CHECK();
@@ -291,7 +309,8 @@ extern "C" int vhap_photo_fwd(const float* pred_rgba, const float* gt_nchw, int 
     if (!pred_rgba || !gt_nchw || !out2) return VHAP_E_NULLPTR;
     if (int e = check_img(B, H, W)) return e;
     hipStream_t st = vhap_stream(stream);
-    if (hipMemsetAsync(out2, 0, 8, st) != hipSuccess) return VHAP_E_HIP;
+    vhap_zero_async(out2, 8, st);
+    VHAP_LAUNCH_CHECK();
     const long long npix = (long long)B * H * W;
     photo_fwd_kernel<<<min(vhap_cdiv(npix, 256), MAX_BLOCKS), 256, 0, st>>>(reinterpret_cast<const float4*>(pred_rgba), gt_nchw, B, H, W, out2);
     VHAP_LAUNCH_CHECK();

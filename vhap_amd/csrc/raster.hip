@@ -91,11 +91,13 @@ __device__ __forceinline__ BlockRange decode_range(unsigned tr, int nby) {
 __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(const float* __restrict__ pos, const int* __restrict__ tri,
                                                                 const int* __restrict__ tri_uv, int V, int F, int H, int W,
                                                                 int nbx, int nby, unsigned* __restrict__ counts,
-                                                                unsigned* __restrict__ trange, TriRecord* __restrict__ records) {
+                                                                unsigned* __restrict__ trange, TriRecord* __restrict__ records,
+                                                                BinHeader* __restrict__ hdr_to_zero) {
     extern __shared__ __attribute__((aligned(16))) unsigned lds_cnt[];
     const int nbin = nbx * nby;
     const bool use_lds = nbin <= LDS_BIN_LIMIT;
     const int b = blockIdx.y, t = blockIdx.x * BIN_THREADS + threadIdx.x;
+    if (hdr_to_zero && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) hdr_to_zero->total = 0u;   // bin_scan (next launch) accumulates
     if (use_lds) {
         for (int i = threadIdx.x; i < nbin; i += BIN_THREADS) lds_cnt[i] = 0u;
         __syncthreads();
@@ -240,7 +242,10 @@ struct RasterParams {
     const float* uv;       // [VT,2]
     const int* tri_uv;     // [F,3]
     int B, V, VT, F, H, W, nbx, nby, nwx;  // nwx = workgroups per block row
+    int row_mul;
     const unsigned* counts;
+    unsigned* counts_w;
+    unsigned* cursors_w;
     const unsigned* offsets;
     const unsigned* list;
     const unsigned* trange;
@@ -260,7 +265,10 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterParams P) {
     const unsigned L = vhap_xcd_remap(blockIdx.x, gridDim.x);
     const int nwg = P.nwx * P.nby;  // workgroups per frame
     const int b = L / nwg, wgi = L - b * nwg;
-    const int wy = wgi / P.nwx, wx = wgi - wy * P.nwx;
+    const int wy_lin = wgi / P.nwx, wx = wgi - wy_lin * P.nwx;
+    // visit block rows in a strided order (row_mul is coprime to nby): rows through the head are compute-heavy, background
+    // rows are pure stores -- interleaving them in dispatch order lets the stores overlap the triangle loops
+    const int wy = (int)(((long long)wy_lin * P.row_mul) % P.nby);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int bx = wx * WG_BLOCKS + wave, by = wy;  // this wave's 8x8 block
     if (bx >= P.nbx) return;                        // whole wave outside the image
@@ -274,6 +282,10 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterParams P) {
     const size_t bin = (size_t)b * P.nbx * P.nby + (size_t)by * P.nbx + bx;
     const unsigned n = (P.debug & 1) ? 0u : (use_list ? P.counts[bin] : (unsigned)P.F);
     const unsigned off = use_list ? P.offsets[bin] : 0u;
+    if (lane == 0) {   // leave the workspace clean for the next call (see VHAP_RASTER_WS_CLEAN)
+        P.counts_w[bin] = 0u;
+        P.cursors_w[bin] = 0u;
+    }
 
     unsigned long long best = ~0ull;  // (ordered z/w test value << 32) | triangle id
 
@@ -463,7 +475,7 @@ int check_dims(int B, int V, int F, int H, int W) {
 }
 
 template <bool INTERP>
-int launch_raster(RasterParams P, void* ws, size_t ws_bytes, size_t cap, hipStream_t st) {
+int launch_raster(RasterParams P, void* ws, size_t ws_bytes, size_t cap, int flags, hipStream_t st) {
     const int B = P.B, F = P.F;
     P.nbx = (P.W + BLK - 1) / BLK;
     P.nby = (P.H + BLK - 1) / BLK;
@@ -481,8 +493,12 @@ int launch_raster(RasterParams P, void* ws, size_t ws_bytes, size_t cap, hipStre
     unsigned* trange = reinterpret_cast<unsigned*>(w + l.trange);
     unsigned* list = reinterpret_cast<unsigned*>(w + l.list);
     TriRecord* records = reinterpret_cast<TriRecord*>(w + l.records);
-    // header, counts and cursors are contiguous: one memset node
-    if (hipMemsetAsync(w + l.hdr, 0, l.offsets - l.hdr, st) != hipSuccess) return VHAP_E_HIP;
+    // header, counts and cursors are contiguous: one zero-fill launch -- skipped when the caller vouches that the workspace was
+    // zero-initialised once and only ever used by completed calls of this function (every call leaves it clean again)
+    if (!(flags & VHAP_RASTER_WS_CLEAN)) {
+        vhap_zero_async(w + l.hdr, l.offsets - l.hdr, st);
+        VHAP_LAUNCH_CHECK();
+    }
     const dim3 gbin(vhap_cdiv(F, BIN_THREADS), B);
     const bool use_lds = nbin <= LDS_BIN_LIMIT;
     const size_t fill_lds = use_lds ? 2 * sizeof(unsigned) * nbin : 0;
@@ -492,13 +508,22 @@ int launch_raster(RasterParams P, void* ws, size_t ws_bytes, size_t cap, hipStre
             return VHAP_E_HIP;
     }
     bin_count_kernel<<<gbin, BIN_THREADS, use_lds ? sizeof(unsigned) * nbin : 0, st>>>(P.pos, P.tri, P.tri_uv, P.V, F, P.H, P.W, P.nbx,
-                                                                                    P.nby, counts, trange, records);
+                                                                                    P.nby, counts, trange, records, hdr);
     VHAP_LAUNCH_CHECK();
     bin_scan_kernel<<<vhap_cdiv((long long)B * nbin, 256), 256, 0, st>>>(counts, offsets, B * nbin, hdr);
     VHAP_LAUNCH_CHECK();
     bin_fill_kernel<<<gbin, BIN_THREADS, fill_lds, st>>>(trange, F, P.nbx, P.nby, offsets, cursors, list, hdr, (unsigned)cap);
     VHAP_LAUNCH_CHECK();
     P.counts = counts;
+    P.counts_w = counts;
+    P.cursors_w = cursors;
+    {   // odd multiplier near 0.38 * nby, made coprime to nby
+        int m = (int)(0.381966f * (float)P.nby) | 1;
+        auto gcd = [](int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; };
+        while (m > 1 && gcd(m, P.nby) != 1) m -= 2;
+        P.row_mul = m < 1 ? 1 : m;
+        if (!(g_debug_flags & 16)) P.row_mul = 1;   // A/B switch (profiling): strided row order off by default
+    }
     P.offsets = offsets;
     P.list = list;
     P.trange = trange;
@@ -523,20 +548,20 @@ extern "C" size_t vhap_raster_workspace_bytes(int B, int F, int H, int W, size_t
 
 extern "C" int vhap_raster_fwd(const float* pos, const int32_t* tri, int B, int V, int F, int H, int W, float* rast,
                                float* rast_db, void* workspace, size_t workspace_bytes, size_t pair_capacity,
-                               vhap_stream_t stream) {
+                               int flags, vhap_stream_t stream) {
     VHAP_ENTER();
     if (!pos || !tri || !rast) return VHAP_E_NULLPTR;
     if (int e = check_dims(B, V, F, H, W)) return e;
     RasterParams P{};
     P.pos = pos; P.tri = tri; P.B = B; P.V = V; P.F = F; P.H = H; P.W = W;
     P.rast = rast; P.rast_db = rast_db;
-    return launch_raster<false>(P, workspace, workspace_bytes, pair_capacity, vhap_stream(stream));
+    return launch_raster<false>(P, workspace, workspace_bytes, pair_capacity, flags, vhap_stream(stream));
 }
 
 extern "C" int vhap_raster_interp_fwd(const float* pos, const int32_t* tri, const float* vnormal, const float* uv,
                                       const int32_t* tri_uv, int B, int V, int VT, int F, int H, int W, float* rast,
                                       float* rast_db, float* normal, float* texc, float* texd, void* workspace,
-                                      size_t workspace_bytes, size_t pair_capacity, vhap_stream_t stream) {
+                                      size_t workspace_bytes, size_t pair_capacity, int flags, vhap_stream_t stream) {
     VHAP_ENTER();
     if (!pos || !tri || !vnormal || !uv || !tri_uv || !rast || !rast_db || !normal || !texc || !texd) return VHAP_E_NULLPTR;
     if (int e = check_dims(B, V, F, H, W)) return e;
@@ -545,5 +570,5 @@ extern "C" int vhap_raster_interp_fwd(const float* pos, const int32_t* tri, cons
     P.pos = pos; P.tri = tri; P.vnormal = vnormal; P.uv = uv; P.tri_uv = tri_uv;
     P.B = B; P.V = V; P.VT = VT; P.F = F; P.H = H; P.W = W;
     P.rast = rast; P.rast_db = rast_db; P.normal = normal; P.texc = texc; P.texd = texd;
-    return launch_raster<true>(P, workspace, workspace_bytes, pair_capacity, vhap_stream(stream));
+    return launch_raster<true>(P, workspace, workspace_bytes, pair_capacity, flags, vhap_stream(stream));
 }

@@ -163,7 +163,7 @@ def vertex_normals(verts, csr):
 
 # ------------------------------------------------------------------------------------------------
 def _decode_ordered_max(stats):
-    u = stats[0:1].view(torch.int32)
+    u = stats[1:2].view(torch.int32)
     return torch.where(u < 0, (u & 0x7FFFFFFF).view(torch.float32), (~u).view(torch.float32))[0]
 
 
@@ -172,14 +172,14 @@ class _Shade(torch.autograd.Function):
     def forward(ctx, normal_raw, albedo, lights, rast, bg_image, bg_color, sh_const, want_reg):
         B, H, W, _ = rast.shape
         rgba = torch.empty(B, H, W, 4, dtype=torch.float32, device=rast.device)
-        stats = torch.empty(2, dtype=torch.float32, device=rast.device) if want_reg else None
+        stats = torch.empty(4, dtype=torch.float32, device=rast.device) if want_reg else None
         col = (ctypes.c_float * 3)(*bg_color) if bg_color is not None else None
         _chk(_lib.lib().vhap_shade_fwd(_p(normal_raw), _p(albedo), _p(rast), _p(bg_image), ctypes.cast(col, ctypes.c_void_p) if col else 0,
                                        _p(lights), _p(sh_const), B, H, W, _p(rgba), _p(stats), _stream()), "vhap_shade_fwd")
         ctx.save_for_backward(normal_raw, albedo, lights, rast, sh_const, stats)
         if want_reg:
             mx = _decode_ordered_max(stats)
-            reg = torch.relu(mx - 1.0) + stats[1] / float(B * H * W)
+            reg = torch.relu(mx - 1.0) + stats[2] / float(B * H * W)
         else:
             reg = torch.zeros((), dtype=torch.float32, device=rast.device)
         return rgba, reg

@@ -13,6 +13,8 @@ Every op is a torch.autograd.Function whose forward/backward enqueue hand-writte
 through ctypes on torch's CURRENT stream.  torch only owns memory, streams and the autograd tape.
 There is no eager/CPU fallback: CPU tensors raise, a missing library raises.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -58,18 +60,42 @@ class RasterizeHipContext:
     """Stands in for dr.RasterizeCudaContext().  Holds only sizing policy (no device state, so it is
     safe to share between threads -- the reference's log_media thread may render concurrently)."""
 
-    def __init__(self, pairs_per_triangle=8, pairs_per_block=8):
+    def __init__(self, pairs_per_triangle=8, pairs_per_block=8, persistent=True):
         self.pairs_per_triangle = pairs_per_triangle
         self.pairs_per_block = pairs_per_block
+        # persistent=True: keep ONE zero-initialised workspace per (device, stream, shape).  The kernels leave it clean, so
+        # the per-call memset is skipped (VHAP_RASTER_WS_CLEAN) and the address is stable under graph capture.  A context is
+        # then tied to in-order use on one stream at a time; use persistent=False (or one context per thread) otherwise.
+        self.persistent = persistent and os.environ.get("VHAP_RASTER_PERSISTENT", "1") != "0"
+        self._ws = {}
 
     def workspace(self, B, F, H, W, device):
+        ws, nbytes, cap = self._workspace(B, F, H, W, device)
+        return ws, nbytes, cap
+
+    def acquire(self, B, F, H, W, device):
+        """-> (workspace tensor, nbytes, capacity, flags)."""
+        if not self.persistent:
+            ws, nbytes, cap = self._workspace(B, F, H, W, device)
+            return ws, nbytes, cap, 0
+        key = (str(device), torch.cuda.current_stream(device).cuda_stream if torch.cuda.is_available() else 0, B, F, H, W)
+        hit = self._ws.get(key)
+        if hit is None:
+            ws, nbytes, cap = self._workspace(B, F, H, W, device, zero=True)
+            if len(self._ws) > 8:
+                self._ws.clear()
+            hit = self._ws[key] = (ws, nbytes, cap)
+        return hit[0], hit[1], hit[2], 1
+
+    def _workspace(self, B, F, H, W, device, zero=False):
         # capacity of the (triangle, 8x8-block) lists; exceeding it is still correct (brute-force path)
         nblk = ((int(H) + 7) // 8) * ((int(W) + 7) // 8)
         cap = int(B) * (int(F) * self.pairs_per_triangle + nblk * self.pairs_per_block)
         nbytes = _lib.lib().vhap_raster_workspace_bytes(B, F, H, W, cap)
         if nbytes == 0:
             raise ValueError(f"rasterize: dimensions out of range (B={B}, F={F}, H={H}, W={W})")
-        return torch.empty(nbytes, dtype=torch.uint8, device=device), nbytes, cap
+        alloc = torch.zeros if zero else torch.empty
+        return alloc(nbytes, dtype=torch.uint8, device=device), nbytes, cap
 
 
 def _check_raster_args(pos, tri, resolution):
@@ -88,10 +114,10 @@ def raster_fwd(ctx, pos, tri, resolution, with_db=True):
     pos, tri = _f32c(pos), _i32c(tri)
     B, V, _ = pos.shape
     F = tri.shape[0]
-    ws, nbytes, cap = ctx.workspace(B, F, H, W, pos.device)
+    ws, nbytes, cap, flags = ctx.acquire(B, F, H, W, pos.device)
     rast = torch.empty(B, H, W, 4, dtype=torch.float32, device=pos.device)
     db = torch.empty_like(rast) if with_db else None
-    rc = _lib.lib().vhap_raster_fwd(_p(pos), _p(tri), B, V, F, H, W, _p(rast), _p(db), _p(ws), nbytes, cap, _stream())
+    rc = _lib.lib().vhap_raster_fwd(_p(pos), _p(tri), B, V, F, H, W, _p(rast), _p(db), _p(ws), nbytes, cap, flags, _stream())
     _lib.check(rc, "vhap_raster_fwd")
     return rast, db
 
@@ -105,7 +131,7 @@ def raster_interp_fwd(ctx, pos, tri, vnormal, uv, tri_uv, resolution):
     F = tri.shape[0]
     if vnormal.shape != (B, V, 3) or uv.dim() != 2 or uv.shape[1] != 2 or tri_uv.shape != tri.shape:
         raise ValueError("raster_interp_fwd: vnormal [B,V,3], uv [VT,2], tri_uv [F,3] expected")
-    ws, nbytes, cap = ctx.workspace(B, F, H, W, pos.device)
+    ws, nbytes, cap, flags = ctx.acquire(B, F, H, W, pos.device)
     dev = pos.device
     rast = torch.empty(B, H, W, 4, dtype=torch.float32, device=dev)
     db = torch.empty_like(rast)
@@ -114,7 +140,7 @@ def raster_interp_fwd(ctx, pos, tri, vnormal, uv, tri_uv, resolution):
     texd = torch.empty_like(rast)
     _hook("raster_interp_fwd", "begin")
     rc = _lib.lib().vhap_raster_interp_fwd(_p(pos), _p(tri), _p(vnormal), _p(uv), _p(tri_uv), B, V, uv.shape[0], F, H, W,
-                                           _p(rast), _p(db), _p(normal), _p(texc), _p(texd), _p(ws), nbytes, cap, _stream())
+                                           _p(rast), _p(db), _p(normal), _p(texc), _p(texd), _p(ws), nbytes, cap, flags, _stream())
     _hook("raster_interp_fwd", "end")
     _lib.check(rc, "vhap_raster_interp_fwd")
     return rast, db, normal, texc, texd

@@ -11,6 +11,7 @@ is a sparse apply, the B-fold texture copy is gone, and frame batches can be sha
 with one all-reduce per Adam step (vhap_amd.dist).  Logging / TensorBoard / landmark detection /
 dataset IO of the reference are out of scope.
 """
+import os
 from collections import defaultdict
 
 import numpy as np
@@ -556,7 +557,9 @@ class GraphedStep:
             # dry pass: populate every lazy cache (region tables, mesh tables, FLAME bases) outside the capture ...
             s = dict(self.sample)
             tracker.fill_cam_params_into_sample(s)
-            tracker.compute_energy(s, stage=stage)
+            E_dry, *_ = tracker.compute_energy(s, stage=stage)
+            torch.autograd.grad(E_dry, self.params, allow_unused=True)   # backward too: BLAS kernels for every GEMM shape get loaded now
+            del E_dry
             # ... and create the Adam state with a zero-gradient step (a no-op on the parameters), then rewind its counter
             for p in self.params:
                 p.grad = torch.zeros_like(p)
@@ -567,6 +570,7 @@ class GraphedStep:
                     st["step"].zero_()
         torch.cuda.current_stream().wait_stream(side)
         self.inv_n = torch.zeros((), device=dev)
+        self.stream = torch.cuda.Stream()
         self.gF, self.gB, self.gA = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         tracker._split = {}
         try:
@@ -576,7 +580,7 @@ class GraphedStep:
                 tracker.fill_cam_params_into_sample(s)
                 E_rest, self.log_dict, *_ = tracker.compute_energy(s, stage=stage)
                 self.S, self.N = tracker._split["S"], tracker._split["N"]
-            pool = self.gF.pool()
+            pool = self.gF.pool() if os.environ.get("VHAP_GRAPH_POOLS") != "separate" else None
             with torch.cuda.graph(self.gB, pool=pool):
                 E = E_rest + tracker.cfg.w.photo * self.S * self.inv_n
                 grads = torch.autograd.grad(E, self.params, allow_unused=True)
@@ -592,6 +596,20 @@ class GraphedStep:
             tracker._split = None
 
     def __call__(self):
+        # Replays go to a stream of our own, never the null stream: on ROCm 7.2 the memset nodes that torch's reductions
+        # record (semaphore clears) were observed out of order with their kernels when a graph is launched on stream 0.
+        cur = torch.cuda.current_stream()
+        if cur.cuda_stream == 0 and os.environ.get("VHAP_GRAPH_NULL_STREAM") != "1":   # (env: debugging only)
+            self.stream.wait_stream(cur)
+            with torch.cuda.stream(self.stream):
+                self._replay()
+            cur.wait_stream(self.stream)
+        else:
+            self._replay()
+        self.tr.global_step += 1
+        return self.E
+
+    def _replay(self):
         tr = self.tr
         self.gF.replay()
         n = self.N
@@ -604,5 +622,4 @@ class GraphedStep:
         if tr.dist is not None:
             tr.dist.average_gradients(self.params)
         self.gA.replay()
-        tr.global_step += 1
-        return self.E
+
