@@ -222,6 +222,92 @@ int vhap_disturb_fwd(const float* rgba, const float* rast, const int32_t* fid2ci
 int vhap_disturb_bwd(const float* d_out, const float* keep, int B, int H, int W, float* d_rgba,
                      vhap_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Per-frame parameter stage (vhap_amd/csrc/frame.hip): replaces the gathers by timestep, lbs.batch_rodrigues
+ * (vhap/model/lbs.py:25-57), batch_rigid_transform (:254-301), the joint regression and pose feature of
+ * lbs.lbs (:148-176) as called from FlameHead.forward (vhap/model/flame.py:571-634), and the parameter
+ * energies compute_pose_smooth_energy / compute_joint_smooth_energy / compute_expr_smooth_energy /
+ * compute_joint_L2_energy / reg_expr / reg_shape (vhap/model/tracker.py:486-500, 616-680).
+ *   timesteps [B] int64 rows of the [N,*] parameter arrays; previous frame = max(t - 1, 0), detached
+ *   JT [J,3] = J_regressor v_template; JS [3J, NS+NE] = J_regressor shapedirs; Jreg [J,V] (only with static_offset)
+ *   weights[12]: VHAP_FW_* (0 disables a term); parents[J]
+ *   coef [Bp,Kp] (rows >= B zero-filled), A [B,J,12], transl [B,3], Jrest [B,J,3] (saved for the backward),
+ *   terms[6] = smooth_pose, reg_joint, smooth_joint, reg_expr, smooth_expr, reg_shape (weighted)
+ * bwd: gradients are ACCUMULATED into the full-size arrays g_* (caller zero-fills; any may be NULL);
+ *   d_coef / d_A / d_transl / d_terms may be NULL (= zero).
+ * ------------------------------------------------------------------------------------------- */
+enum {
+    VHAP_FW_SMOOTH_TRANS = 0, VHAP_FW_SMOOTH_ROT = 1, VHAP_FW_SMOOTH_NECK = 2, VHAP_FW_SMOOTH_JAW = 3,
+    VHAP_FW_SMOOTH_EYES = 4, VHAP_FW_SMOOTH_EXPR = 5, VHAP_FW_REG_NECK = 6, VHAP_FW_REG_JAW = 7,
+    VHAP_FW_REG_EYES = 8, VHAP_FW_REG_EXPR = 9, VHAP_FW_REG_SHAPE = 10
+};
+int vhap_frame_prep_fwd(const int64_t* timesteps, const float* shape, const float* expr,
+                        const float* rotation, const float* translation, const float* neck,
+                        const float* jaw, const float* eyes, const float* JT, const float* JS,
+                        const float* Jreg, const float* static_offset, const int32_t* parents,
+                        const float* weights, int B, int Bp, int N, int NS, int NE, int J, int Kp, int V,
+                        float* coef, float* A, float* transl, float* Jrest, float* terms,
+                        vhap_stream_t stream);
+int vhap_frame_prep_bwd(const int64_t* timesteps, const float* shape, const float* expr,
+                        const float* rotation, const float* translation, const float* neck,
+                        const float* jaw, const float* eyes, const float* JS, const float* Jreg,
+                        const float* static_offset, const int32_t* parents, const float* weights,
+                        const float* Jrest, const float* d_coef, const float* d_A, const float* d_transl,
+                        const float* d_terms, int B, int Bp, int N, int NS, int NE, int J, int Kp, int V,
+                        float* g_shape, float* g_expr, float* g_rotation, float* g_translation,
+                        float* g_neck, float* g_jaw, float* g_eyes, float* g_offset,
+                        vhap_stream_t stream);
+/* mvp [B,4,4] = P(K) [RT; 0 0 0 1] (render_nvdiffrast.py:102-160); K [B,4] = fx, fy, cx, cy (or one row shared
+ * when K_batched == 0), RT [B,3,4] (or one shared); d_K [B,4] overwritten */
+int vhap_camera_fwd(const float* K, const float* RT, int B, int K_batched, int RT_batched, int H, int W,
+                    float near_plane, float far_plane, float* mvp, vhap_stream_t stream);
+int vhap_camera_bwd(const float* RT, const float* d_mvp, int B, int RT_batched, int H, int W, float* d_K,
+                    vhap_stream_t stream);
+/* Landmark energy (lbs.vertices2landmarks, vhap/model/lbs.py:60-98 + compute_lmk_energy, tracker.py:347-389):
+ * mean over B x [l0,l1) of (|du| + |dv|) conf, with conf x boost for landmarks [boost0,boost1).
+ *   lmk_vidx [L,3] int32 vertex ids of each landmark's triangle, lmk_bary [L,3], lmk2d [B,L2,3] = u, v, confidence (pixels)
+ *   lmk3d [B,L,3] optional output; energy: device scalar (overwritten)
+ * bwd: d_verts [B,V,3] ACCUMULATED, d_mvp [B,16] overwritten (may be NULL). */
+int vhap_landmark_fwd(const float* verts, const int32_t* lmk_vidx, const float* lmk_bary, const float* mvp,
+                      const float* lmk2d, int B, int V, int L, int L2, int l0, int l1, int boost0, int boost1,
+                      float boost, int H, int W, float* lmk3d, float* energy, vhap_stream_t stream);
+int vhap_landmark_bwd(const float* verts, const int32_t* lmk_vidx, const float* lmk_bary, const float* mvp,
+                      const float* lmk2d, const float* d_energy, int B, int V, int L, int L2, int l0, int l1,
+                      int boost0, int boost1, float boost, int H, int W, float* d_verts, float* d_mvp,
+                      vhap_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Offset / texture regularisers and Adam (vhap_amd/csrc/reg.hip).
+ * offset_reg: terms[3] = s_lap sum_v w_lap[v] |(L o)_v|^2, s_abs sum_v w_abs[v] |o_v|_1, s_rigid sum_regions sum_xyz var
+ *   (tracker.py:552-600, 682-690; L in CSR: lap_ptr [V+1], lap_col, lap_val; regions in CSR: region_ptr, region_idx;
+ *   w_lap / w_abs [V] or NULL).  bwd: d_offset [V,3] ACCUMULATED.
+ * tex_prep: albedo_hwc [T,T,3] = painted [3,T,T] + extra [3,T,T] (either may be NULL); terms[2] = s_tv * TV(albedo),
+ *   s_res * sum(extra^2 * res_mask) (tracker.py:247-258, 518-541; res_mask [T,T] uint8 or NULL).  bwd: d_extra [3,T,T]
+ *   overwritten (d_albedo_hwc may be NULL).
+ * adam_step: torch.optim.Adam update (tracker.py:159-211) of up to VHAP_ADAM_MAX_TENSORS tensors in one launch; the
+ *   pointer tables are HOST arrays of device pointers; lr_device[lr_index[k]] and step_device[0] live on the device
+ *   (graph replays see their current values); step_device is incremented.
+ * ------------------------------------------------------------------------------------------- */
+#define VHAP_ADAM_MAX_TENSORS 16
+int vhap_offset_reg_fwd(const float* offset, const int32_t* lap_ptr, const int32_t* lap_col,
+                        const float* lap_val, const float* w_lap, const float* w_abs,
+                        const int32_t* region_ptr, const int32_t* region_idx, int V, int n_regions,
+                        float s_lap, float s_abs, float s_rigid, float* terms, vhap_stream_t stream);
+int vhap_offset_reg_bwd(const float* offset, const int32_t* lap_ptr, const int32_t* lap_col,
+                        const float* lap_val, const float* w_lap, const float* w_abs,
+                        const int32_t* region_ptr, const int32_t* region_idx, int V, int n_regions,
+                        float s_lap, float s_abs, float s_rigid, const float* d_terms, float* d_offset,
+                        vhap_stream_t stream);
+int vhap_tex_prep_fwd(const float* painted, const float* extra, const uint8_t* res_mask, int T, float s_tv,
+                      float s_res, float* albedo_hwc, float* terms, vhap_stream_t stream);
+int vhap_tex_prep_bwd(const float* albedo_hwc, const float* extra, const uint8_t* res_mask,
+                      const float* d_albedo_hwc, const float* d_terms, int T, float s_tv, float s_res,
+                      float* d_extra, vhap_stream_t stream);
+int vhap_adam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                   float* const* exp_avg_sq, const int64_t* numel, const int32_t* lr_index,
+                   const float* lr_device, int32_t* step_device, float beta1, float beta2, float eps,
+                   vhap_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,6 +15,7 @@ SO_PATH = os.path.join(_HERE, "lib", "libvhap_hip.so")
 c_fp = ctypes.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 c_i = ctypes.c_int
 c_sz = ctypes.c_size_t
+c_f = ctypes.c_float
 
 # name -> (restype, [argtypes]) ; must list EVERY symbol declared in include/vhap_hip.h
 SIGNATURES = {
@@ -51,6 +52,17 @@ SIGNATURES = {
     "vhap_transform_bwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
     "vhap_vnormal_fwd": (c_i, [c_fp] * 4 + [c_i, c_i, c_fp, c_fp]),
     "vhap_vnormal_bwd": (c_i, [c_fp] * 5 + [c_i, c_i, c_i, c_fp, c_fp, c_fp]),
+    "vhap_frame_prep_fwd": (c_i, [c_fp] * 14 + [c_i] * 8 + [c_fp] * 6),
+    "vhap_frame_prep_bwd": (c_i, [c_fp] * 18 + [c_i] * 8 + [c_fp] * 9),
+    "vhap_camera_fwd": (c_i, [c_fp, c_fp] + [c_i] * 5 + [c_f, c_f, c_fp, c_fp]),
+    "vhap_camera_bwd": (c_i, [c_fp, c_fp] + [c_i] * 4 + [c_fp, c_fp]),
+    "vhap_landmark_fwd": (c_i, [c_fp] * 5 + [c_i] * 8 + [c_f, c_i, c_i] + [c_fp] * 3),
+    "vhap_landmark_bwd": (c_i, [c_fp] * 6 + [c_i] * 8 + [c_f, c_i, c_i] + [c_fp] * 3),
+    "vhap_offset_reg_fwd": (c_i, [c_fp] * 8 + [c_i, c_i, c_f, c_f, c_f, c_fp, c_fp]),
+    "vhap_offset_reg_bwd": (c_i, [c_fp] * 8 + [c_i, c_i, c_f, c_f, c_f, c_fp, c_fp, c_fp]),
+    "vhap_tex_prep_fwd": (c_i, [c_fp] * 3 + [c_i, c_f, c_f] + [c_fp] * 3),
+    "vhap_tex_prep_bwd": (c_i, [c_fp] * 5 + [c_i, c_f, c_f] + [c_fp] * 2),
+    "vhap_adam_step": (c_i, [c_i] + [c_fp] * 8 + [c_f, c_f, c_f, c_fp]),
 }
 
 _lib = None

@@ -1,0 +1,306 @@
+// Regularisers on the vertex offsets and on the texture, and the fused Adam update, for gfx950.
+//
+//   offset_reg : Laplacian smoothness, L1 magnitude and per-region rigidity of the static vertex offsets
+//                (vhap/model/tracker.py:552-600, 682-690).  The reference forms L (v0 + o) - L v0 with two dense
+//                [V,V] batched matmuls per step; L is linear, so this is L o, one CSR gather per vertex.
+//   tex_prep   : albedo = painted base + residual in the channel-last layout the texture sampler wants, fused with the
+//                total-variation and masked-residual energies (tracker.py:247-258, 518-541): one pass over the texture
+//                instead of ~12 full-size elementwise launches.
+//   adam       : one launch for every parameter tensor of the step (torch.optim.Adam semantics, tracker.py:159-211).
+#include "common.h"
+
+namespace {
+
+constexpr int RB = 256;
+
+__device__ __forceinline__ float block_sum256(float v, float* red) {
+    v = vhap_wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+struct OffCfg {
+    int V, nreg, nbv;               // vertices, rigid regions, number of vertex blocks
+    float s_lap, s_abs, s_rigid;    // weight / normaliser of each term
+};
+
+// blocks [0, nbv): Laplacian + magnitude over a slice of vertices; blocks [nbv, nbv + nreg): one rigid region each.
+// d_terms == nullptr: forward (terms accumulated); else backward (d_off accumulated).
+__global__ __launch_bounds__(RB) void offset_reg_kernel(OffCfg c, const float* __restrict__ off, const int* __restrict__ lap_ptr,
+                                                        const int* __restrict__ lap_col, const float* __restrict__ lap_val,
+                                                        const float* __restrict__ w_lap, const float* __restrict__ w_abs,
+                                                        const int* __restrict__ reg_ptr, const int* __restrict__ reg_idx,
+                                                        float* __restrict__ terms, const float* __restrict__ d_terms,
+                                                        float* __restrict__ d_off) {
+    __shared__ float red[4];
+    const bool bwd = d_terms != nullptr;
+    if ((int)blockIdx.x < c.nbv) {
+        const int v = blockIdx.x * RB + threadIdx.x;
+        float e_lap = 0.f, e_abs = 0.f;
+        if (v < c.V) {
+            const int k0 = lap_ptr[v], k1 = lap_ptr[v + 1];
+            float lo[3] = {0.f, 0.f, 0.f};
+            for (int k = k0; k < k1; k++) {
+                const float a = lap_val[k];
+                const float* o = off + 3 * lap_col[k];
+                lo[0] += a * o[0]; lo[1] += a * o[1]; lo[2] += a * o[2];
+            }
+            const float wl = w_lap ? w_lap[v] : 1.0f, wa = w_abs ? w_abs[v] : 1.0f;
+            const float o0 = off[3 * v], o1 = off[3 * v + 1], o2 = off[3 * v + 2];
+            e_lap = (lo[0] * lo[0] + lo[1] * lo[1] + lo[2] * lo[2]) * wl;
+            e_abs = (fabsf(o0) + fabsf(o1) + fabsf(o2)) * wa;
+            if (bwd) {
+                const float gl = 2.0f * c.s_lap * wl * d_terms[0];
+                for (int k = k0; k < k1; k++) {
+                    const float a = lap_val[k] * gl;
+                    float* d = d_off + 3 * lap_col[k];
+                    atomicAdd(&d[0], a * lo[0]); atomicAdd(&d[1], a * lo[1]); atomicAdd(&d[2], a * lo[2]);
+                }
+                const float ga = c.s_abs * wa * d_terms[1];
+                const float sg[3] = {o0 > 0.f ? 1.f : (o0 < 0.f ? -1.f : 0.f), o1 > 0.f ? 1.f : (o1 < 0.f ? -1.f : 0.f),
+                                     o2 > 0.f ? 1.f : (o2 < 0.f ? -1.f : 0.f)};
+                atomicAdd(&d_off[3 * v], ga * sg[0]); atomicAdd(&d_off[3 * v + 1], ga * sg[1]); atomicAdd(&d_off[3 * v + 2], ga * sg[2]);
+            }
+        }
+        if (!bwd) {
+            e_lap = block_sum256(e_lap, red);
+            e_abs = block_sum256(e_abs, red);
+            if (threadIdx.x == 0) { atomicAdd(&terms[0], e_lap * c.s_lap); atomicAdd(&terms[1], e_abs * c.s_abs); }
+        }
+        return;
+    }
+    // rigid region: unbiased variance over the region's vertices, mean over x, y, z
+    const int r = blockIdx.x - c.nbv;
+    const int i0 = reg_ptr[r], i1 = reg_ptr[r + 1], n = i1 - i0;
+    if (n < 2) return;
+    float s[3] = {0.f, 0.f, 0.f};
+    for (int i = i0 + threadIdx.x; i < i1; i += RB) {
+        const float* o = off + 3 * reg_idx[i];
+        s[0] += o[0]; s[1] += o[1]; s[2] += o[2];
+    }
+    float mean[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) mean[k] = block_sum256(s[k], red) / (float)n;
+    const float inv = 1.0f / (float)(n - 1);
+    if (bwd) {
+        const float g = 2.0f * inv * c.s_rigid * d_terms[2];
+        for (int i = i0 + threadIdx.x; i < i1; i += RB) {
+            const int v = reg_idx[i];
+#pragma unroll
+            for (int k = 0; k < 3; k++) atomicAdd(&d_off[3 * v + k], g * (off[3 * v + k] - mean[k]));
+        }
+        return;
+    }
+    float q = 0.f;
+    for (int i = i0 + threadIdx.x; i < i1; i += RB) {
+        const float* o = off + 3 * reg_idx[i];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { const float d = o[k] - mean[k]; q += d * d; }
+    }
+    q = block_sum256(q, red);
+    if (threadIdx.x == 0) atomicAdd(&terms[2], q * inv * c.s_rigid);
+}
+
+// ---- texture ----
+struct TexCfg {
+    int T;
+    float s_tv, s_res;
+};
+
+__device__ __forceinline__ void load_texel(const float* __restrict__ painted, const float* __restrict__ extra, size_t plane, size_t i,
+                                           float* a) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) a[c] = (painted ? painted[c * plane + i] : 0.f) + (extra ? extra[c * plane + i] : 0.f);
+}
+
+// one thread per texel: albedo (channel-last) + TV / residual energies
+__global__ __launch_bounds__(RB) void tex_prep_fwd_kernel(TexCfg c, const float* __restrict__ painted, const float* __restrict__ extra,
+                                                          const unsigned char* __restrict__ res_mask, float* __restrict__ albedo,
+                                                          float* __restrict__ terms) {
+    __shared__ float red[4];
+    const int T = c.T;
+    const size_t plane = (size_t)T * T;
+    float e_tv = 0.f, e_res = 0.f;
+    for (size_t i = (size_t)blockIdx.x * RB + threadIdx.x; i < plane; i += (size_t)gridDim.x * RB) {
+        const int y = (int)(i / T), x = (int)(i - (size_t)y * T);
+        float a[3], ay[3], ax[3];
+        load_texel(painted, extra, plane, i, a);
+        albedo[3 * i] = a[0]; albedo[3 * i + 1] = a[1]; albedo[3 * i + 2] = a[2];
+        if (c.s_tv != 0.f) {
+            if (y + 1 < T) {
+                load_texel(painted, extra, plane, i + T, ay);
+#pragma unroll
+                for (int k = 0; k < 3; k++) { const float d = a[k] - ay[k]; e_tv += d * d; }
+            }
+            if (x + 1 < T) {
+                load_texel(painted, extra, plane, i + 1, ax);
+#pragma unroll
+                for (int k = 0; k < 3; k++) { const float d = a[k] - ax[k]; e_tv += d * d; }
+            }
+        }
+        if (c.s_res != 0.f && extra && res_mask && res_mask[i]) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) { const float r = extra[k * plane + i]; e_res += r * r; }
+        }
+    }
+    e_tv = block_sum256(e_tv, red);
+    e_res = block_sum256(e_res, red);
+    if (threadIdx.x == 0) {
+        if (e_tv != 0.f) atomicAdd(&terms[0], e_tv * c.s_tv);
+        if (e_res != 0.f) atomicAdd(&terms[1], e_res * c.s_res);
+    }
+}
+
+// d_extra[c,y,x] = d_albedo[y,x,c] + TV stencil on the saved albedo + masked residual
+__global__ __launch_bounds__(RB) void tex_prep_bwd_kernel(TexCfg c, const float* __restrict__ albedo, const float* __restrict__ extra,
+                                                          const unsigned char* __restrict__ res_mask, const float* __restrict__ d_albedo,
+                                                          const float* __restrict__ d_terms, float* __restrict__ d_extra) {
+    const int T = c.T;
+    const size_t plane = (size_t)T * T;
+    const float gtv = 2.0f * c.s_tv * d_terms[0], gres = 2.0f * c.s_res * d_terms[1];
+    for (size_t i = (size_t)blockIdx.x * RB + threadIdx.x; i < plane; i += (size_t)gridDim.x * RB) {
+        const int y = (int)(i / T), x = (int)(i - (size_t)y * T);
+        float g[3] = {0.f, 0.f, 0.f};
+        if (d_albedo) { g[0] = d_albedo[3 * i]; g[1] = d_albedo[3 * i + 1]; g[2] = d_albedo[3 * i + 2]; }
+        if (gtv != 0.f) {
+            const float* a = albedo + 3 * i;
+            float acc[3] = {0.f, 0.f, 0.f};
+            if (y + 1 < T) { const float* n = a + 3 * (size_t)T; acc[0] += a[0] - n[0]; acc[1] += a[1] - n[1]; acc[2] += a[2] - n[2]; }
+            if (y > 0) { const float* n = a - 3 * (size_t)T; acc[0] += a[0] - n[0]; acc[1] += a[1] - n[1]; acc[2] += a[2] - n[2]; }
+            if (x + 1 < T) { const float* n = a + 3; acc[0] += a[0] - n[0]; acc[1] += a[1] - n[1]; acc[2] += a[2] - n[2]; }
+            if (x > 0) { const float* n = a - 3; acc[0] += a[0] - n[0]; acc[1] += a[1] - n[1]; acc[2] += a[2] - n[2]; }
+            g[0] += gtv * acc[0]; g[1] += gtv * acc[1]; g[2] += gtv * acc[2];
+        }
+        if (gres != 0.f && res_mask && res_mask[i]) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) g[k] += gres * extra[k * plane + i];
+        }
+        d_extra[i] = g[0]; d_extra[plane + i] = g[1]; d_extra[2 * plane + i] = g[2];
+    }
+}
+
+// ---- Adam ----
+struct AdamTable {
+    float* p[VHAP_ADAM_MAX_TENSORS];
+    const float* g[VHAP_ADAM_MAX_TENSORS];
+    float* m[VHAP_ADAM_MAX_TENSORS];
+    float* v[VHAP_ADAM_MAX_TENSORS];
+    long long n[VHAP_ADAM_MAX_TENSORS];
+    int lr_index[VHAP_ADAM_MAX_TENSORS];
+    int blk_start[VHAP_ADAM_MAX_TENSORS + 1];   // 1-D grid: tensor k owns blocks [blk_start[k], blk_start[k + 1])
+    int n_tensors;
+};
+
+__global__ __launch_bounds__(RB) void adam_kernel(AdamTable t, const float* __restrict__ lr, const int* __restrict__ step, float beta1,
+                                                  float beta2, float eps) {
+    int k = 0;
+    while (k + 1 < t.n_tensors && (int)blockIdx.x >= t.blk_start[k + 1]) k++;
+    const long long n = t.n[k];
+    const long long blk = (int)blockIdx.x - t.blk_start[k], nblk = t.blk_start[k + 1] - t.blk_start[k];
+    const float st = (float)(step[0] + 1);
+    const float bc1 = 1.0f - powf(beta1, st), bc2s = sqrtf(1.0f - powf(beta2, st));
+    const float step_size = lr[t.lr_index[k]] / bc1;
+    float* __restrict__ p = t.p[k];
+    const float* __restrict__ g = t.g[k];
+    float* __restrict__ m = t.m[k];
+    float* __restrict__ v = t.v[k];
+    for (long long i = blk * RB + threadIdx.x; i < n; i += nblk * RB) {
+        const float gi = g[i];
+        const float mi = m[i] + (gi - m[i]) * (1.0f - beta1);          // lerp, like torch
+        const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= step_size * mi / (sqrtf(vi) / bc2s + eps);
+    }
+}
+
+__global__ void adam_bump_kernel(int* step) { step[0] += 1; }
+
+}  // namespace
+
+extern "C" int vhap_offset_reg_fwd(const float* offset, const int32_t* lap_ptr, const int32_t* lap_col, const float* lap_val,
+                                   const float* w_lap, const float* w_abs, const int32_t* region_ptr, const int32_t* region_idx,
+                                   int V, int n_regions, float s_lap, float s_abs, float s_rigid, float* terms, vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!offset || !lap_ptr || !lap_col || !lap_val || !terms) return VHAP_E_NULLPTR;
+    if (n_regions > 0 && (!region_ptr || !region_idx)) return VHAP_E_NULLPTR;
+    if (V <= 0 || n_regions < 0) return VHAP_E_BADDIM;
+    hipStream_t st = vhap_stream(stream);
+    vhap_zero_async(terms, 3 * sizeof(float), st);
+    VHAP_LAUNCH_CHECK();
+    OffCfg c{V, n_regions, vhap_cdiv(V, RB), s_lap, s_abs, s_rigid};
+    offset_reg_kernel<<<c.nbv + n_regions, RB, 0, st>>>(c, offset, lap_ptr, lap_col, lap_val, w_lap, w_abs, region_ptr, region_idx, terms, nullptr,
+                                                      nullptr);
+    VHAP_LAUNCH_CHECK();
+    return VHAP_OK;
+}
+
+extern "C" int vhap_offset_reg_bwd(const float* offset, const int32_t* lap_ptr, const int32_t* lap_col, const float* lap_val,
+                                   const float* w_lap, const float* w_abs, const int32_t* region_ptr, const int32_t* region_idx,
+                                   int V, int n_regions, float s_lap, float s_abs, float s_rigid, const float* d_terms, float* d_offset,
+                                   vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!offset || !lap_ptr || !lap_col || !lap_val || !d_terms || !d_offset) return VHAP_E_NULLPTR;
+    if (n_regions > 0 && (!region_ptr || !region_idx)) return VHAP_E_NULLPTR;
+    if (V <= 0 || n_regions < 0) return VHAP_E_BADDIM;
+    OffCfg c{V, n_regions, vhap_cdiv(V, RB), s_lap, s_abs, s_rigid};
+    offset_reg_kernel<<<c.nbv + n_regions, RB, 0, vhap_stream(stream)>>>(c, offset, lap_ptr, lap_col, lap_val, w_lap, w_abs, region_ptr, region_idx,
+                                                                         nullptr, d_terms, d_offset);
+    VHAP_LAUNCH_CHECK();
+    return VHAP_OK;
+}
+
+extern "C" int vhap_tex_prep_fwd(const float* painted, const float* extra, const uint8_t* res_mask, int T, float s_tv, float s_res,
+                                 float* albedo_hwc, float* terms, vhap_stream_t stream) {
+    VHAP_ENTER();
+    if ((!painted && !extra) || !albedo_hwc || !terms) return VHAP_E_NULLPTR;
+    if (T <= 0) return VHAP_E_BADDIM;
+    hipStream_t st = vhap_stream(stream);
+    vhap_zero_async(terms, 2 * sizeof(float), st);
+    VHAP_LAUNCH_CHECK();
+    TexCfg c{T, s_tv, s_res};
+    const int blocks = (int)(((size_t)T * T + RB - 1) / RB < 8192 ? ((size_t)T * T + RB - 1) / RB : 8192);
+    tex_prep_fwd_kernel<<<blocks, RB, 0, st>>>(c, painted, extra, res_mask, albedo_hwc, terms);
+    VHAP_LAUNCH_CHECK();
+    return VHAP_OK;
+}
+
+extern "C" int vhap_tex_prep_bwd(const float* albedo_hwc, const float* extra, const uint8_t* res_mask, const float* d_albedo_hwc,
+                                 const float* d_terms, int T, float s_tv, float s_res, float* d_extra, vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!albedo_hwc || !extra || !d_terms || !d_extra) return VHAP_E_NULLPTR;
+    if (T <= 0) return VHAP_E_BADDIM;
+    TexCfg c{T, s_tv, s_res};
+    const int blocks = (int)(((size_t)T * T + RB - 1) / RB < 8192 ? ((size_t)T * T + RB - 1) / RB : 8192);
+    tex_prep_bwd_kernel<<<blocks, RB, 0, vhap_stream(stream)>>>(c, albedo_hwc, extra, res_mask, d_albedo_hwc, d_terms, d_extra);
+    VHAP_LAUNCH_CHECK();
+    return VHAP_OK;
+}
+
+extern "C" int vhap_adam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                              float* const* exp_avg_sq, const int64_t* numel, const int32_t* lr_index, const float* lr_device,
+                              int32_t* step_device, float beta1, float beta2, float eps, vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !numel || !lr_index || !lr_device || !step_device) return VHAP_E_NULLPTR;
+    if (n_tensors <= 0 || n_tensors > VHAP_ADAM_MAX_TENSORS) return VHAP_E_BADDIM;
+    AdamTable t;
+    int nblocks = 0;
+    t.n_tensors = n_tensors;
+    for (int k = 0; k < n_tensors; k++) {
+        if (!params[k] || !grads[k] || !exp_avg[k] || !exp_avg_sq[k]) return VHAP_E_NULLPTR;
+        if (numel[k] < 0 || lr_index[k] < 0) return VHAP_E_BADDIM;
+        t.p[k] = params[k]; t.g[k] = grads[k]; t.m[k] = exp_avg[k]; t.v[k] = exp_avg_sq[k]; t.n[k] = numel[k]; t.lr_index[k] = lr_index[k];
+        const long long want = (numel[k] + RB * 4 - 1) / (RB * 4);
+        t.blk_start[k] = nblocks;
+        nblocks += (int)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
+    }
+    t.blk_start[n_tensors] = nblocks;
+    hipStream_t st = vhap_stream(stream);
+    adam_kernel<<<nblocks, RB, 0, st>>>(t, lr_device, step_device, beta1, beta2, eps);
+    VHAP_LAUNCH_CHECK();
+    adam_bump_kernel<<<1, 1, 0, st>>>(step_device);
+    VHAP_LAUNCH_CHECK();
+    return VHAP_OK;
+}

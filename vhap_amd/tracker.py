@@ -20,6 +20,7 @@ import torch.nn.functional as F
 
 from .config import BaseTrackingConfig, PhotometricStageConfig
 from . import fused as FU
+from . import native as NV
 from .flame import FlameHead, FlameTexPainted, FlameUvMask
 from .lbs import batch_rodrigues
 from .render_hip import HipDiffRenderer
@@ -53,6 +54,8 @@ class FlameTracker:
         self.dist = None                                          # set by vhap_amd.dist.attach()
         self.fused_gbuffer = True                                 # one launch for rasterize + both interpolates
         self.fused = True                                         # fused shading / loss kernels (False: reference-shaped torch ops)
+        self.native = True                                        # per-frame stage / landmarks / regularisers as fused HIP kernels too
+        self._nm = None
         self.opt_dict = defaultdict(bool)
         self._split = None
 
@@ -99,8 +102,10 @@ class FlameTracker:
                 groups.append({"params": sel, "lr": g_lr * lr_scale})
         rest = [p for v in params.values() for p in v]
         groups.append({"params": rest})
-        capturable = str(self.device).startswith("cuda")          # step counter on the device: the step can be graph-captured
-        return torch.optim.Adam(groups, lr=lr.base * lr_scale, capturable=capturable)
+        on_gpu = str(self.device).startswith("cuda")
+        if on_gpu and self.fused and self.native:
+            return NV.HipAdam(groups, lr=lr.base * lr_scale)        # one launch for all parameter tensors
+        return torch.optim.Adam(groups, lr=lr.base * lr_scale, capturable=on_gpu)   # device step counter: graph-capturable
 
     # ---- model ----
     def forward_flame(self, timesteps):
@@ -340,6 +345,8 @@ class FlameTracker:
 
     def compute_energy(self, sample, step_i=None, stage=None, disturbance=None):
         """tracker.py:692-750."""
+        if self._native_ok(stage):
+            return self._compute_energy_native(sample, stage, disturbance)
         log_dict = {}
         result_dict = {"gt_rgb": sample["rgb"]}
         timesteps = sample["timestep_index"]
@@ -361,6 +368,160 @@ class FlameTracker:
         if stage is not None:
             log_dict.update(self.compute_regularization_energy(result_dict, verts, verts_cano, lmks, albedos, timesteps, stage))
         E_total = torch.stack([v for v in log_dict.values()]).sum()
+        log_dict["total"] = E_total
+        return E_total, log_dict, verts, faces, lmks, albedos, result_dict
+
+    # ---- native step: the whole energy through fused HIP stages (vhap_amd.native / fused / ops) ----
+    def _native_ok(self, stage):
+        return (self.fused and self.native and stage is not None and str(self.device).startswith("cuda") and
+                not self.cfg.model.use_dynamic_offset and self.render.lighting_type == "SH" and
+                self.render.lighting_space == "world" and len(self.flame._parents) == 5 and not self.cfg.w.blur_iter and
+                self.cfg.model.tex_extra and self.cfg.model.residual_tex)
+
+    def _native_models(self):
+        if self._nm is None:
+            fl = self.flame
+            if fl._fb is None:
+                fl._fb = FU.FlameBasis(fl.shapedirs, fl.posedirs, fl.J_regressor, fl.v_template, fl.lbs_weights)
+            w = self.cfg.w
+            wl = self._vertex_weights("lap", w.reg_offset_lap_relax_coef, w.reg_offset_lap_relax_for) if len(w.reg_offset_lap_relax_for) else None
+            wa = self._vertex_weights("off", w.reg_offset_relax_coef, w.reg_offset_relax_for) if len(w.reg_offset_relax_for) else None
+            regions = [fl.mask.get_vid_by_region([r]) for r in w.reg_offset_rigid_for] if w.reg_offset_rigid is not None else []
+            self._nm = {
+                "frame": NV.FrameModel(fl._fb, fl.J_regressor, fl._parents),
+                "lmk": NV.LandmarkModel(fl.faces, fl.full_lmk_faces_idx, fl.full_lmk_bary_coords),
+                "off": NV.OffsetRegModel(fl.lap_ptr, fl.lap_col, fl.lap_val, wl, wa, regions, self.device),
+                "res_mask": (self._uvmask_res()[0] > 0).to(torch.uint8).contiguous(),
+                "weights": {},
+            }
+            h, wd = self.image_size
+            m = float(max(h, wd))
+            self._nm["K1"] = torch.tensor([[m, m, 0.0, 0.0]], device=self.device)
+            self._nm["K0"] = torch.tensor([[0.0, 0.0, 0.5 * wd, 0.5 * h]], device=self.device)
+        return self._nm
+
+    def _w_tv(self):
+        w_tv = self.cfg.w.reg_tex_tv
+        if w_tv is None:
+            return None
+        w_tv = w_tv * self.cfg.data.scale_factor ** 2
+        if self.cfg.data.n_downsample_rgb is not None:
+            w_tv /= self.cfg.data.n_downsample_rgb ** 2
+        return w_tv
+
+    def _frame_weights(self, stage):
+        nm = self._native_models()
+        if stage not in nm["weights"]:
+            w, o, tracking = self.cfg.w, self.opt_dict, "tracking" in stage
+            kw = {}
+            if o["pose"] and tracking:
+                kw.update(smooth_trans=w.smooth_trans, smooth_rot=w.smooth_rot)
+            if o["joints"]:
+                kw.update(reg_neck=w.reg_neck, reg_jaw=w.reg_jaw, reg_eyes=w.reg_eyes)
+                if tracking:
+                    kw.update(smooth_neck=w.smooth_neck, smooth_jaw=w.smooth_jaw, smooth_eyes=w.smooth_eyes)
+            if o["expr"]:
+                kw.update(reg_expr=w.reg_expr)
+                if tracking:
+                    kw.update(smooth_expr=w.smooth_expr)
+            if o["shape"]:
+                kw.update(reg_shape=w.reg_shape)
+            nm["weights"][stage] = (NV.frame_weights(**kw), dict(o))
+        wts, o_then = nm["weights"][stage]
+        if o_then != dict(self.opt_dict):                          # the stage's optimisable set changed: rebuild
+            del nm["weights"][stage]
+            return self._frame_weights(stage)
+        return wts
+
+    def _compute_energy_native(self, sample, stage, disturbance=None):
+        """Same energies as compute_energy (tracker.py:692-750), every stage a fused HIP kernel."""
+        nm = self._native_models()
+        w, o, cfg = self.cfg.w, self.opt_dict, self.cfg
+        tracking = "tracking" in stage
+        ts = sample["timestep_index"]
+        if not torch.is_tensor(ts):
+            ts = torch.as_tensor(np.asarray(ts), device=self.device)
+        ts = ts.long()
+        B = ts.shape[0]
+        coef, A, transl, pterms = NV.frame_prep(nm["frame"], self._frame_weights(stage), ts, self.shape, self.expr, self.rotation,
+                                                self.translation, self.neck_pose, self.jaw_pose, self.eyes_pose, self.static_offset)
+        verts, verts_cano = FU.flame_skin(self.flame._fb, coef, A, transl, self.static_offset)
+        if self.calibrated:
+            K = sample["intrinsic"].to(self.device)
+            if K.shape[-2:] == (3, 3):
+                K = torch.stack([K[..., 0, 0], K[..., 1, 1], K[..., 0, 2], K[..., 1, 2]], dim=-1)
+            RT = sample["extrinsic"].to(self.device)
+        else:
+            K = self.focal_length * nm["K1"] + nm["K0"]            # [1,4]: f, f, cx, cy (tracker.py:141-157)
+            RT = self.RT[None]
+        mvp = NV.camera(K, RT, B, self.image_size)
+        faces = self.flame.faces
+        log_dict, result_dict = {}, {"gt_rgb": sample["rgb"]}
+        parts = []
+        lmks = None
+        if w.landmark is not None:
+            disable_jaw = not w.always_enable_jawline_landmarks and cfg.pipeline[stage]["disable_jawline_landmarks"]
+            E_lmk, lmks = NV.landmark_energy(nm["lmk"], verts, mvp, sample["lmk2d"].to(self.device), self.image_size, disable_jaw,
+                                             want_lmk3d=not torch.is_grad_enabled())
+            log_dict["lmk"] = w.landmark * E_lmk
+        tex_on = o["texture"]
+        painted = self.flame_tex_painted()[0]
+        if painted.shape[-1] != self.tex_extra.shape[-1]:
+            painted = F.interpolate(painted[None], self.tex_extra.shape[-2:], mode="bilinear")[0]
+        albedo_cl, tterms = NV.tex_prep(painted, self.tex_extra, nm["res_mask"], self._w_tv() if tex_on else None,
+                                        w.reg_tex_res_clusters if tex_on else None)
+        albedos = albedo_cl.permute(0, 3, 1, 2).expand(B, -1, -1, -1)
+        if isinstance(cfg.pipeline[stage], PhotometricStageConfig) and w.photo is not None:
+            verts_clip = FU.transform(verts, mvp)
+            rast_dict = {"rast_out": None, "rast_out_db": None, "verts": verts, "verts_camera": None, "verts_clip": verts_clip,
+                         "image_size": tuple(self.image_size), "require_grad": True}
+            gt_rgb = sample["rgb"].to(verts)
+            bg_color = self.get_background_color(gt_rgb, None, stage)
+            fid, vid = self._regions(stage)
+            want_reg = bool(o["lights"]) and w.reg_diffuse is not None
+            out = self.render.render_rgba(rast_dict, verts, faces, self._verts_uv_flipped, self.flame.textures_idx, None,
+                                          self.lights[None], bg_color, fid, vid, True, disturbance=disturbance, outputs="loss",
+                                          want_reg_diffuse=want_reg, tex_cl=albedo_cl)
+            abs_sum, n_alpha = FU.photo_sum(out["rgba_rs"], gt_rgb)
+            result_dict.update({"rgba_rs": out["rgba_rs"], "reg_diffuse_value": out["reg_diffuse"]})
+            if self._split is not None:                            # graphed step: the normaliser is applied later (GraphedStep)
+                self._split["S"], self._split["N"] = abs_sum, n_alpha
+                log_dict["photo"] = abs_sum * 0.0
+            else:
+                n_mask = n_alpha * 3
+                if self.dist is not None:
+                    n_mask = self.dist.all_reduce_sum(n_mask) / self.dist.world_size
+                log_dict["photo"] = w.photo * (abs_sum / n_mask)
+        # regularisers, in the reference's order (tracker.py:480-605)
+        pt = dict(zip(NV.FRAME_TERMS, pterms.unbind(0)))
+        if o["pose"] and tracking:
+            log_dict["smooth_pose"] = pt["smooth_pose"]
+        if o["joints"]:
+            log_dict["reg_joint"] = pt["reg_joint"]
+            if tracking:
+                log_dict["smooth_joint"] = pt["smooth_joint"]
+        if o["expr"]:
+            log_dict["reg_expr"] = pt["reg_expr"]
+            if tracking:
+                log_dict["smooth_expr"] = pt["smooth_expr"]
+        if o["shape"]:
+            log_dict["reg_shape"] = pt["reg_shape"]
+        if tex_on:
+            if w.reg_tex_tv is not None:
+                log_dict["reg_tex_tv"] = tterms[0]
+            if w.reg_tex_res_clusters is not None:
+                log_dict["reg_tex_res_clusters"] = tterms[1]
+        if o["lights"] and self.lights is not None:
+            if w.reg_light is not None:
+                log_dict["reg_light"] = w.reg_light * ((self.lights - self.lights_uniform) ** 2).mean()
+            if w.reg_diffuse is not None and "reg_diffuse_value" in result_dict:
+                log_dict["reg_diffuse"] = w.reg_diffuse * result_dict["reg_diffuse_value"]
+        if (o["static_offset"] or o["dynamic_offset"]) and self.static_offset is not None:
+            ot = NV.offset_reg(nm["off"], self.static_offset, w.reg_offset_lap, w.reg_offset, w.reg_offset_rigid)
+            for i, k in enumerate(("reg_offset_lap", "reg_offset", "reg_offset_rigid")):
+                if getattr(w, k) is not None:
+                    log_dict[k] = ot[i]
+        E_total = torch.stack(list(log_dict.values())).sum()
         log_dict["total"] = E_total
         return E_total, log_dict, verts, faces, lmks, albedos, result_dict
 
@@ -563,8 +724,11 @@ class GraphedStep:
             # ... and create the Adam state with a zero-gradient step (a no-op on the parameters), then rewind its counter
             for p in self.params:
                 p.grad = torch.zeros_like(p)
-            had_state = len(optimizer.state) > 0
-            if not had_state:
+            if isinstance(optimizer, NV.HipAdam):
+                if optimizer._tab is None:
+                    optimizer._build()
+                optimizer.sync_lr()
+            elif len(optimizer.state) == 0:
                 optimizer.step()
                 for st in optimizer.state.values():
                     st["step"].zero_()
@@ -596,6 +760,8 @@ class GraphedStep:
             tracker._split = None
 
     def __call__(self):
+        if isinstance(self.opt, NV.HipAdam):
+            self.opt.sync_lr()                                     # lr schedulers act on the host copy
         # Replays go to a stream of our own, never the null stream: on ROCm 7.2 the memset nodes that torch's reductions
         # record (semaphore clears) were observed out of order with their kernels when a graph is launched on stream 0.
         cur = torch.cuda.current_stream()
