@@ -80,12 +80,14 @@ int vhap_raster_bwd(const float* pos, const int32_t* tri, const float* rast, con
 /* Triangle-parallel backward of the fused G-buffer pass (vhap_raster_interp_fwd): chains the gradients of
  * normal [B,H,W,3], texc [B,H,W,2], texd [B,H,W,4] (and, optionally, direct gradients of rast / rast_db) into
  * d_pos [B,V,4] and d_vnormal [B,V,3] (both ACCUMULATED, caller zero-fills) with one set of atomics per
- * triangle vertex instead of per pixel.  Any gradient pointer may be NULL (= zero). */
+ * triangle vertex instead of per pixel.  Any gradient pointer may be NULL (= zero).
+ * uv_nograd_faces [F] uint8 or NULL: triangles whose texture coordinates are treated as constants (d_texc ignored;
+ * d_texd still flows) -- the reference's `texc = torch.where(rast_mask, texc.detach(), texc)` (render_nvdiffrast.py:391-396). */
 int vhap_gbuffer_bwd(const float* pos, const int32_t* tri, const float* vnormal, const float* uv,
                      const int32_t* tri_uv, const float* rast, const float* d_normal,
                      const float* d_texc, const float* d_texd, const float* d_rast,
-                     const float* d_rast_db, int B, int V, int F, int H, int W, float* d_pos,
-                     float* d_vnormal, vhap_stream_t stream);
+                     const float* d_rast_db, const uint8_t* uv_nograd_faces, int B, int V, int F, int H,
+                     int W, float* d_pos, float* d_vnormal, vhap_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Interpolate: replaces dr.interpolate(attr, rast, tri, rast_db, diff_attrs)  (:384, :389)
@@ -143,8 +145,8 @@ int vhap_antialias_fwd(const float* color, const float* rast, const float* pos,
                        int F, float* out, int32_t* work, vhap_stream_t stream);
 int vhap_antialias_bwd(const float* color, const float* rast, const float* pos,
                        const int32_t* tri, const int32_t* opp, const float* d_out,
-                       const int32_t* work, int B, int H, int W, int C, int V, int F,
-                       float* d_color, float* d_pos, vhap_stream_t stream);
+                       const int32_t* work, const uint8_t* pos_nograd_verts, int B, int H, int W,
+                       int C, int V, int F, float* d_color, float* d_pos, vhap_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Per-pixel shading / compositing and the photometric sum (vhap_amd/csrc/pixel.hip).
@@ -219,6 +221,12 @@ size_t vhap_disturb_workspace_ints(int B, int H, int W);
 int vhap_disturb_fwd(const float* rgba, const float* rast, const int32_t* fid2cid, int nfid, int ncl,
                      const int32_t* w_fg, const int32_t* w_bg, const int64_t* idx, int B, int H,
                      int W, int32_t* workspace, float* out, float* keep, vhap_stream_t stream);
+/* same, with the random numbers drawn inside the kernel (counter-based hash): Bernoulli(rate_fg / rate_bg) masks and one
+ * 32-bit index draw per pixel.  rng_state [1] uint32 on the device is the stream counter; every call advances it, so replays of a
+ * captured graph draw fresh numbers. */
+int vhap_disturb_fwd_rng(const float* rgba, const float* rast, const int32_t* fid2cid, int nfid, int ncl,
+                         float rate_fg, float rate_bg, uint32_t* rng_state, int B, int H, int W,
+                         int32_t* workspace, float* out, float* keep, vhap_stream_t stream);
 int vhap_disturb_bwd(const float* d_out, const float* keep, int B, int H, int W, float* d_rgba,
                      vhap_stream_t stream);
 

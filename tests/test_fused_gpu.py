@@ -136,3 +136,63 @@ def test_shade_reg_diffuse_ties_distribute_like_torch_max():
         grads.append((float(reg), lights.grad.clone()))
     assert abs(grads[0][0] - grads[1][0]) < 1e-6
     assert float((grads[0][1] - grads[1][1]).abs().max()) < 1e-4 * float(grads[0][1].abs().max())
+
+
+def _disturb_scene(B=3, H=70, W=90, F=40, ncl=6, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    fid = torch.randint(0, F + 1, (B, H, W), generator=g)            # 0 = background
+    fid[:, :10] = 0
+    fid2cid = torch.cat([torch.zeros(1, dtype=torch.long), torch.randint(1, ncl, (F,), generator=g)])
+    rast = torch.zeros(B, H, W, 4)
+    rast[..., 3] = fid.float()
+    rgba = torch.rand(B, H, W, 4, generator=g)
+    return rast.cuda(), rgba.cuda(), fid2cid.cuda(), ncl
+
+
+def test_disturb_kernel_matches_host_ops_bit_exact():
+    """Counting sort + gather (vhap_disturb_fwd) == the boolean-mask formulation of render_nvdiffrast.py:424-460, exactly,
+    with injected random numbers; sizes are not multiples of the block size (ragged last block)."""
+    from vhap_amd.render_hip import HipDiffRenderer
+    rast, rgba, fid2cid, ncl = _disturb_scene()
+    B, H, W, _ = rgba.shape
+    r = HipDiffRenderer(lighting_type="SH", fid2cid=fid2cid[1:]).cuda()
+    r._ncl = ncl
+    rnd = r.make_disturbance((B, H, W), "cuda", generator=torch.Generator("cuda").manual_seed(3))
+    r.fused = True
+    out_hip, _ = r.disturb(rgba.clone().requires_grad_(), None, rast, rnd)
+    r.fused = False
+    x = rgba.clone().requires_grad_()
+    out_ref, _ = r.disturb(x, x, rast, rnd)
+    assert torch.equal(out_hip.detach(), out_ref.detach())
+    # backward: gradient only through the pixels that kept their colour
+    gin = torch.rand_like(rgba)
+    y = rgba.clone().requires_grad_()
+    r.fused = True
+    o, _ = r.disturb(y, None, rast, rnd)
+    o.backward(gin)
+    out_ref.backward(gin)
+    assert torch.equal(y.grad, x.grad)
+
+
+def test_disturb_in_kernel_rng_properties():
+    """vhap_disturb_fwd_rng: replaced pixels take the colour of a pixel of the SAME cluster; the replaced fraction follows the
+    rates; cluster 1 is untouched; two calls draw different numbers."""
+    from vhap_amd import fused as FU
+    rast, rgba, fid2cid, ncl = _disturb_scene(B=4, H=128, W=128, seed=2)
+    state = torch.tensor([12345], dtype=torch.int32, device="cuda")
+    out1 = FU.disturb_rng(rgba, rast, fid2cid.int(), ncl, state, 0.5, 0.25)
+    out2 = FU.disturb_rng(rgba, rast, fid2cid.int(), ncl, state, 0.5, 0.25)
+    assert int(state) == 12347 and not torch.equal(out1, out2)
+    cid = fid2cid[rast[..., 3].long()]
+    changed = (out1 != rgba).any(-1)
+    assert not bool(changed[cid == 1].any())
+    fg, bg = (cid > 1), (cid == 0)
+    assert abs(float(changed[fg].float().mean()) - 0.5) < 0.03 and abs(float(changed[bg].float().mean()) - 0.25) < 0.03
+    # every output colour exists among the input colours of its cluster
+    wts = torch.tensor([1, 1000003, 1000033 ** 2 % (2 ** 40), 7], device="cuda")
+    key = lambda t: ((t * 1e6).round().long() * wts).sum(-1)
+    for c in range(ncl):
+        if c == 1 or not bool((cid == c).any()):
+            continue
+        pool = set(key(rgba[cid == c]).tolist())
+        assert set(key(out1[cid == c]).tolist()) <= pool

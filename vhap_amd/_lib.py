@@ -26,7 +26,7 @@ SIGNATURES = {
     "vhap_raster_fwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_sz, c_sz, c_i, c_fp]),
     "vhap_raster_interp_fwd": (c_i, [c_fp] * 5 + [c_i] * 6 + [c_fp] * 5 + [c_fp, c_sz, c_sz, c_i, c_fp]),
     "vhap_raster_bwd": (c_i, [c_fp] * 5 + [c_i] * 5 + [c_fp, c_fp]),
-    "vhap_gbuffer_bwd": (c_i, [c_fp] * 11 + [c_i] * 5 + [c_fp] * 3),
+    "vhap_gbuffer_bwd": (c_i, [c_fp] * 12 + [c_i] * 5 + [c_fp] * 3),
     "vhap_interp_fwd": (c_i, [c_fp, c_i, c_fp, c_fp, c_fp] + [c_i] * 6 + [c_fp, c_fp, c_fp]),
     "vhap_interp_bwd": (c_i, [c_fp, c_i, c_fp, c_fp, c_fp, c_fp, c_fp] + [c_i] * 6 + [c_fp] * 4),
     "vhap_texture_num_levels": (c_i, [c_i, c_i]),
@@ -37,9 +37,10 @@ SIGNATURES = {
     "vhap_texture_mip_fold": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp]),
     "vhap_antialias_work_ints": (c_sz, [c_i] * 3),
     "vhap_antialias_fwd": (c_i, [c_fp] * 5 + [c_i] * 6 + [c_fp, c_fp, c_fp]),
-    "vhap_antialias_bwd": (c_i, [c_fp] * 7 + [c_i] * 6 + [c_fp, c_fp, c_fp]),
+    "vhap_antialias_bwd": (c_i, [c_fp] * 8 + [c_i] * 6 + [c_fp, c_fp, c_fp]),
     "vhap_disturb_workspace_ints": (c_sz, [c_i] * 3),
     "vhap_disturb_fwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
+    "vhap_disturb_fwd_rng": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_f, c_f, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
     "vhap_disturb_bwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp]),
     "vhap_shade_fwd": (c_i, [c_fp] * 7 + [c_i] * 3 + [c_fp] * 3),
     "vhap_shade_bwd": (c_i, [c_fp] * 8 + [c_i] * 3 + [c_fp] * 4),

@@ -157,8 +157,8 @@ template <int C>
 __global__ __launch_bounds__(256) void aa_bwd_kernel(const float* __restrict__ color, const float4* __restrict__ rast,
                                                      const float4* __restrict__ pos, const int* __restrict__ tri,
                                                      const int* __restrict__ opp, const float* __restrict__ d_out,
-                                                     const int* __restrict__ work, int H, int W, int V, int F,
-                                                     float* __restrict__ d_color, float* __restrict__ d_pos) {
+                                                     const int* __restrict__ work, const unsigned char* __restrict__ pos_nograd, int H,
+                                                     int W, int V, int F, float* __restrict__ d_color, float* __restrict__ d_pos) {
     const int count = work[0];
     const int HW = H * W;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < count; i += gridDim.x * 256) {
@@ -205,12 +205,16 @@ __global__ __launch_bounds__(256) void aa_bwd_kernel(const float* __restrict__ c
         const float4 pa = P[g.va], pb = P[g.vb];
         const float iwa = 1.0f / pa.w, iwb = 1.0f / pb.w;
         float* D = d_pos + (size_t)b * V * 4;
-        atomicAdd(&D[4 * g.va + 0], gxa * xh * iwa);
-        atomicAdd(&D[4 * g.va + 1], gya * yh * iwa);
-        atomicAdd(&D[4 * g.va + 3], -(gxa * pa.x * xh + gya * pa.y * yh) * iwa * iwa);
-        atomicAdd(&D[4 * g.vb + 0], gxb * xh * iwb);
-        atomicAdd(&D[4 * g.vb + 1], gyb * yh * iwb);
-        atomicAdd(&D[4 * g.vb + 3], -(gxb * pb.x * xh + gyb * pb.y * yh) * iwb * iwb);
+        if (!(pos_nograd && pos_nograd[g.va])) {     // (detached vertices: render_nvdiffrast.py:462-464)
+            atomicAdd(&D[4 * g.va + 0], gxa * xh * iwa);
+            atomicAdd(&D[4 * g.va + 1], gya * yh * iwa);
+            atomicAdd(&D[4 * g.va + 3], -(gxa * pa.x * xh + gya * pa.y * yh) * iwa * iwa);
+        }
+        if (!(pos_nograd && pos_nograd[g.vb])) {
+            atomicAdd(&D[4 * g.vb + 0], gxb * xh * iwb);
+            atomicAdd(&D[4 * g.vb + 1], gyb * yh * iwb);
+            atomicAdd(&D[4 * g.vb + 3], -(gxb * pb.x * xh + gyb * pb.y * yh) * iwb * iwb);
+        }
     }
 }
 
@@ -255,8 +259,8 @@ extern "C" int vhap_antialias_fwd(const float* color, const float* rast, const f
 }
 
 extern "C" int vhap_antialias_bwd(const float* color, const float* rast, const float* pos, const int32_t* tri,
-                                   const int32_t* opp, const float* d_out, const int32_t* work, int B, int H, int W, int C,
-                                   int V, int F, float* d_color, float* d_pos, vhap_stream_t stream) {
+                                   const int32_t* opp, const float* d_out, const int32_t* work, const uint8_t* pos_nograd_verts, int B,
+                                   int H, int W, int C, int V, int F, float* d_color, float* d_pos, vhap_stream_t stream) {
     VHAP_ENTER();
     if (!color || !rast || !pos || !tri || !opp || !d_out || !work) return VHAP_E_NULLPTR;
     if (B <= 0 || H <= 0 || W <= 0 || V <= 0 || F <= 0) return VHAP_E_BADDIM;
@@ -268,8 +272,8 @@ extern "C" int vhap_antialias_bwd(const float* color, const float* rast, const f
     }
     return dispatch_C(C, [&](auto c) {
         aa_bwd_kernel<decltype(c)::value><<<1024, 256, 0, st>>>(color, reinterpret_cast<const float4*>(rast),
-                                                              reinterpret_cast<const float4*>(pos), tri, opp, d_out, work, H, W,
-                                                              V, F, d_color, d_pos);
+                                                              reinterpret_cast<const float4*>(pos), tri, opp, d_out, work,
+                                                              pos_nograd_verts, H, W, V, F, d_color, d_pos);
         VHAP_LAUNCH_CHECK();
         return VHAP_OK;
     });

@@ -7,8 +7,8 @@
 // this with a 9-iteration Python loop of boolean-mask indexing (one host sync each) and randint.
 //
 // Here: a deterministic counting sort of the pixel ids by cluster (row-major order inside a cluster, i.e.
-// exactly the order of the reference's boolean-mask gather) in three passes -- per-block cluster
-// histograms (wave ballots), a one-workgroup scan over blocks, and a scatter using wave prefix ranks --
+// exactly the order of the reference's boolean-mask gather) in two passes -- per-block cluster histograms
+// (wave ballots) and a scatter in which every workgroup derives its own prefix from the histograms --
 // followed by one gather pass.  No host sync, no atomics, graph-capturable.  Randomness is supplied by the
 // caller (Bernoulli masks and one 31-bit integer per pixel), so runs can be made reproducible.
 #include "common.h"
@@ -16,101 +16,125 @@
 namespace {
 
 constexpr int MAXC = 16;  // max clusters (the reference configures 7 + background + "none" = 9)
-constexpr int DB = 1024;   // pixels per counting-sort block (16 waves): keeps the single-workgroup scan short
+constexpr int DB = 1024;  // threads per counting-sort workgroup
+constexpr int PPT = 4;    // pixels per thread: a workgroup owns DB * PPT consecutive pixels
+constexpr int DPIX = DB * PPT;
 
 __device__ __forceinline__ int pixel_cluster(const float4* __restrict__ rast, const int* __restrict__ fid2cid, int nfid, long long p) {
     const int fid = (int)rast[p].w;
     return fid2cid[min(max(fid, 0), nfid - 1)];
 }
 
-// pass 1: block_counts[block][c]
+// counter-based random bits (two rounds of the murmur3 finaliser over a Weyl-mixed key): statistically ample for a
+// colour-dither; one stream per (call, pixel, draw)
+__device__ __forceinline__ unsigned mix32(unsigned h) {
+    h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ unsigned rnd32(unsigned seed, unsigned p, unsigned draw) {
+    return mix32(mix32(p * 0x9e3779b9u + seed) ^ (draw * 0x7f4a7c15u + 0x2545f491u));
+}
+
+// pass 1: block_counts[block][c]; also advances the random-stream counter of the call (nobody reads it during this pass)
 __global__ __launch_bounds__(DB) void disturb_count_kernel(const float4* __restrict__ rast, const int* __restrict__ fid2cid, int nfid,
-                                                            int ncl, long long n, int* __restrict__ block_counts) {
+                                                            int ncl, long long n, int* __restrict__ block_counts,
+                                                            unsigned* __restrict__ rng_state) {
     __shared__ int cnt[DB / 64][MAXC];
-    const long long p = (long long)blockIdx.x * DB + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = p < n ? pixel_cluster(rast, fid2cid, nfid, p) : -1;
-    for (int k = 0; k < ncl; k++) {
-        const int m = __popcll(__ballot(c == k));
-        if (lane == 0) cnt[wave][k] = m;
+    if (rng_state && blockIdx.x == 0 && threadIdx.x == 0) rng_state[0] += 1u;
+    int mine[MAXC];
+#pragma unroll
+    for (int k = 0; k < MAXC; k++) mine[k] = 0;
+#pragma unroll
+    for (int it = 0; it < PPT; it++) {
+        const long long p = (long long)blockIdx.x * DPIX + it * DB + threadIdx.x;
+        const int c = p < n ? pixel_cluster(rast, fid2cid, nfid, p) : -1;
+#pragma unroll
+        for (int k = 0; k < MAXC; k++)
+            if (k < ncl) mine[k] += __popcll(__ballot(c == k));     // wave-uniform
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < MAXC; k++) cnt[wave][k] = mine[k];
     }
     __syncthreads();
-    if (threadIdx.x < ncl) {
+    if (threadIdx.x < MAXC) {
         int tot = 0;
         for (int w = 0; w < DB / 64; w++) tot += cnt[w][threadIdx.x];
-        block_counts[(size_t)blockIdx.x * MAXC + threadIdx.x] = tot;
+        block_counts[(size_t)blockIdx.x * MAXC + threadIdx.x] = threadIdx.x < ncl ? tot : 0;
     }
 }
 
-// pass 2 (one workgroup of 1024 = 16 waves): exclusive scan over blocks for all clusters at once; wave-level shuffle
-// scans + one LDS exchange (two barriers in total).  totals[c], totals[MAXC + c] = first slot of cluster c.
-__global__ __launch_bounds__(1024) void disturb_scan_kernel(int* __restrict__ block_counts, int nblocks, int ncl, int* __restrict__ totals) {
-    __shared__ int wtot[16][MAXC];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int per = (nblocks + 1023) / 1024;
-    const int b0 = t * per, b1 = min(b0 + per, nblocks);
-    int s[MAXC], incl[MAXC];
-#pragma unroll
-    for (int c = 0; c < MAXC; c++) s[c] = 0;
-    for (int b = b0; b < b1; b++) {
-#pragma unroll
-        for (int c = 0; c < MAXC; c++)
-            if (c < ncl) s[c] += block_counts[(size_t)b * MAXC + c];
-    }
-#pragma unroll
-    for (int c = 0; c < MAXC; c++) {
-        int v = s[c];
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int u = __shfl_up(v, o, 64);
-            if (lane >= o) v += u;
-        }
-        incl[c] = v;
-        if (lane == 63) wtot[wave][c] = v;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < MAXC; c++) {
-        if (c >= ncl) continue;
-        int run = incl[c] - s[c];
-        for (int w = 0; w < wave; w++) run += wtot[w][c];
-        for (int b = b0; b < b1; b++) {
-            const int v = block_counts[(size_t)b * MAXC + c];
-            block_counts[(size_t)b * MAXC + c] = run;
-            run += v;
-        }
-    }
-    if (t == 0) {
-        int start = 0;
-        for (int c = 0; c < ncl; c++) {
-            int tot = 0;
-            for (int w = 0; w < 16; w++) tot += wtot[w][c];
-            totals[c] = tot;
-            totals[MAXC + c] = start;
-            start += tot;
-        }
-    }
-}
-
-// pass 3: perm[starts[c] + block_offset[c] + rank in block] = pixel id
+// pass 2: every workgroup derives its own exclusive prefix (and the cluster totals) from the per-block histograms -- nblocks * 64 B,
+// L2-resident -- instead of waiting for a single-workgroup scan; then perm[start_c + prefix_c + rank in block] = pixel id.
+// Workgroup 0 publishes totals[c] and totals[MAXC + c] = start_c for the gather pass.
 __global__ __launch_bounds__(DB) void disturb_scatter_kernel(const float4* __restrict__ rast, const int* __restrict__ fid2cid, int nfid,
-                                                              int ncl, long long n, const int* __restrict__ block_offsets,
-                                                              const int* __restrict__ totals, int* __restrict__ perm) {
-    __shared__ int wcnt[DB / 64][MAXC];
-    const long long p = (long long)blockIdx.x * DB + threadIdx.x;
+                                                              int ncl, long long n, int nblocks, const int* __restrict__ block_counts,
+                                                              int* __restrict__ totals, int* __restrict__ perm) {
+    __shared__ int red[2][DB / 64][MAXC];
+    __shared__ int base[MAXC];          // start_c + prefix of this block
+    __shared__ int wcnt[PPT][DB / 64][MAXC];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = p < n ? pixel_cluster(rast, fid2cid, nfid, p) : -1;
-    int rank = 0;
-    for (int k = 0; k < ncl; k++) {
-        const unsigned long long m = __ballot(c == k);
-        if (c == k) rank = __popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) wcnt[wave][k] = __popcll(m);
+    int before[MAXC], total[MAXC];
+#pragma unroll
+    for (int k = 0; k < MAXC; k++) { before[k] = 0; total[k] = 0; }
+    for (int j = threadIdx.x; j < nblocks; j += DB) {
+        const int4* row = reinterpret_cast<const int4*>(block_counts + (size_t)j * MAXC);
+        const bool pre = j < (int)blockIdx.x;
+#pragma unroll
+        for (int q = 0; q < MAXC / 4; q++) {
+            const int4 v = row[q];
+            total[4 * q] += v.x; total[4 * q + 1] += v.y; total[4 * q + 2] += v.z; total[4 * q + 3] += v.w;
+            if (pre) { before[4 * q] += v.x; before[4 * q + 1] += v.y; before[4 * q + 2] += v.z; before[4 * q + 3] += v.w; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < MAXC; k++) {
+        int a = before[k], t = total[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); t += __shfl_xor(t, o, 64); }
+        if (lane == 0) { red[0][wave][k] = a; red[1][wave][k] = t; }
+    }
+    // ranks inside the block, in pixel order: iteration-major, then wave, then lane
+    int c_of[PPT], rank_of[PPT];
+#pragma unroll
+    for (int it = 0; it < PPT; it++) {
+        const long long p = (long long)blockIdx.x * DPIX + it * DB + threadIdx.x;
+        const int c = p < n ? pixel_cluster(rast, fid2cid, nfid, p) : -1;
+        int rank = 0;
+        for (int k = 0; k < ncl; k++) {
+            const unsigned long long m = __ballot(c == k);
+            if (c == k) rank = __popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) wcnt[it][wave][k] = __popcll(m);
+        }
+        c_of[it] = c; rank_of[it] = rank;
     }
     __syncthreads();
-    if (c >= 0) {
-        int off = totals[MAXC + c] + block_offsets[(size_t)blockIdx.x * MAXC + c] + rank;
-        for (int w = 0; w < wave; w++) off += wcnt[w][c];
-        perm[off] = (int)p;
+    if (threadIdx.x < MAXC) {
+        int a = 0;
+        for (int w = 0; w < DB / 64; w++) a += red[0][w][threadIdx.x];
+        // start of cluster k = sum of the totals of the clusters before it
+        int start = 0;
+        for (int k = 0; k < (int)threadIdx.x; k++)
+            for (int w = 0; w < DB / 64; w++) start += red[1][w][k];
+        base[threadIdx.x] = start + a;
+        if (blockIdx.x == 0) {
+            int t = 0;
+            for (int w = 0; w < DB / 64; w++) t += red[1][w][threadIdx.x];
+            totals[threadIdx.x] = t;
+            totals[MAXC + threadIdx.x] = start;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < PPT; it++) {
+        const int c = c_of[it];
+        if (c < 0) continue;
+        int off = base[c] + rank_of[it];
+        for (int i2 = 0; i2 < it; i2++)
+            for (int w = 0; w < DB / 64; w++) off += wcnt[i2][w][c];
+        for (int w = 0; w < wave; w++) off += wcnt[it][w][c];
+        perm[off] = (int)((long long)blockIdx.x * DPIX + it * DB + threadIdx.x);
     }
 }
 
@@ -119,19 +143,30 @@ __global__ __launch_bounds__(256) void disturb_apply_kernel(const float4* __rest
                                                             const float* __restrict__ bg_image, int B, int H, int W,
                                                             const float4* __restrict__ rast, const int* __restrict__ fid2cid, int nfid,
                                                             const int* __restrict__ w_fg, const int* __restrict__ w_bg,
-                                                            const long long* __restrict__ idx, const int* __restrict__ totals,
+                                                            const long long* __restrict__ idx, const unsigned* __restrict__ rng_state,
+                                                            float rate_fg, float rate_bg, const int* __restrict__ totals,
                                                             const int* __restrict__ perm, float4* __restrict__ out,
                                                             float* __restrict__ keep) {
     const long long n = (long long)B * H * W;
     const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
     if (p >= n) return;
     const int c = pixel_cluster(rast, fid2cid, nfid, p);
-    const int w = c == 0 ? w_bg[p] : (c == 1 ? 0 : w_fg[p]);
+    int w;
+    unsigned long long pick;
+    if (rng_state) {     // in-kernel random numbers: Bernoulli(rate) and a 32-bit index draw per pixel
+        const unsigned seed = rng_state[0];
+        const float u = (float)(rnd32(seed, (unsigned)p, 0u) >> 8) * (1.0f / 16777216.0f);
+        w = c == 0 ? (u < rate_bg) : (c == 1 ? 0 : (u < rate_fg));
+        pick = rnd32(seed, (unsigned)p, 1u);
+    } else {
+        w = c == 0 ? w_bg[p] : (c == 1 ? 0 : w_fg[p]);
+        pick = (unsigned long long)idx[p];
+    }
     const int nc = totals[c];
     float4 v = rgba[p];   // after compositing, background pixels of `rgba` already hold the background colour
     float k = 1.0f;
     if (w != 0 && nc > 0) {
-        const int q = perm[totals[MAXC + c] + (int)(idx[p] % (long long)nc)];
+        const int q = perm[totals[MAXC + c] + (int)(pick % (unsigned long long)nc)];
         v = rgba[q];
         k = 0.0f;
     }
@@ -153,34 +188,48 @@ __global__ __launch_bounds__(256) void disturb_bwd_kernel(const float4* __restri
 extern "C" size_t vhap_disturb_workspace_ints(int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return 0;
     const long long n = (long long)B * H * W;
-    const long long nblocks = (n + DB - 1) / DB;
+    const long long nblocks = (n + DPIX - 1) / DPIX;
     return (size_t)(2 * MAXC + nblocks * MAXC + n);
+}
+
+static int disturb_run(const float* rgba, const float* rast, const int32_t* fid2cid, int nfid, int ncl, const int32_t* w_fg,
+                       const int32_t* w_bg, const int64_t* idx, uint32_t* rng_state, float rate_fg, float rate_bg, int B, int H, int W,
+                       int32_t* workspace, float* out, float* keep, vhap_stream_t stream) {
+    if (!rgba || !rast || !fid2cid || !workspace || !out || !keep) return VHAP_E_NULLPTR;
+    if (!rng_state && (!w_fg || !w_bg || !idx)) return VHAP_E_NULLPTR;
+    if (B <= 0 || H <= 0 || W <= 0 || ncl <= 0 || ncl > MAXC || nfid <= 0 || (long long)B * H * W >= (1ll << 31)) return VHAP_E_BADDIM;
+    const long long n = (long long)B * H * W;
+    const int nblocks = vhap_cdiv(n, DPIX);
+    int* totals = workspace;
+    int* block_counts = workspace + 2 * MAXC;
+    int* perm = block_counts + (size_t)nblocks * MAXC;
+    hipStream_t st = vhap_stream(stream);
+    const float4* r4 = reinterpret_cast<const float4*>(rast);
+    disturb_count_kernel<<<nblocks, DB, 0, st>>>(r4, fid2cid, nfid, ncl, n, block_counts, rng_state);
+    VHAP_LAUNCH_CHECK();
+    disturb_scatter_kernel<<<nblocks, DB, 0, st>>>(r4, fid2cid, nfid, ncl, n, nblocks, block_counts, totals, perm);
+    VHAP_LAUNCH_CHECK();
+    disturb_apply_kernel<<<vhap_cdiv(n, 256), 256, 0, st>>>(reinterpret_cast<const float4*>(rgba), nullptr, nullptr, B, H, W, r4, fid2cid, nfid, w_fg,
+                                                  w_bg, reinterpret_cast<const long long*>(idx), rng_state, rate_fg, rate_bg, totals, perm,
+                                                  reinterpret_cast<float4*>(out), keep);
+    VHAP_LAUNCH_CHECK();
+    return VHAP_OK;
 }
 
 extern "C" int vhap_disturb_fwd(const float* rgba, const float* rast, const int32_t* fid2cid, int nfid, int ncl, const int32_t* w_fg,
                                 const int32_t* w_bg, const int64_t* idx, int B, int H, int W, int32_t* workspace, float* out,
                                 float* keep, vhap_stream_t stream) {
     VHAP_ENTER();
-    if (!rgba || !rast || !fid2cid || !w_fg || !w_bg || !idx || !workspace || !out || !keep) return VHAP_E_NULLPTR;
-    if (B <= 0 || H <= 0 || W <= 0 || ncl <= 0 || ncl > MAXC || nfid <= 0 || (long long)B * H * W >= (1ll << 31)) return VHAP_E_BADDIM;
-    const long long n = (long long)B * H * W;
-    const int nblocks = vhap_cdiv(n, DB);
-    int* totals = workspace;
-    int* block_counts = workspace + 2 * MAXC;
-    int* perm = block_counts + (size_t)nblocks * MAXC;
-    hipStream_t st = vhap_stream(stream);
-    const float4* r4 = reinterpret_cast<const float4*>(rast);
-    disturb_count_kernel<<<nblocks, DB, 0, st>>>(r4, fid2cid, nfid, ncl, n, block_counts);
-    VHAP_LAUNCH_CHECK();
-    disturb_scan_kernel<<<1, 1024, 0, st>>>(block_counts, nblocks, ncl, totals);
-    VHAP_LAUNCH_CHECK();
-    disturb_scatter_kernel<<<nblocks, DB, 0, st>>>(r4, fid2cid, nfid, ncl, n, block_counts, totals, perm);
-    VHAP_LAUNCH_CHECK();
-    disturb_apply_kernel<<<vhap_cdiv(n, 256), 256, 0, st>>>(reinterpret_cast<const float4*>(rgba), nullptr, nullptr, B, H, W, r4, fid2cid, nfid, w_fg,
-                                                  w_bg, reinterpret_cast<const long long*>(idx), totals, perm,
-                                                  reinterpret_cast<float4*>(out), keep);
-    VHAP_LAUNCH_CHECK();
-    return VHAP_OK;
+    return disturb_run(rgba, rast, fid2cid, nfid, ncl, w_fg, w_bg, idx, nullptr, 0.f, 0.f, B, H, W, workspace, out, keep, stream);
+}
+
+extern "C" int vhap_disturb_fwd_rng(const float* rgba, const float* rast, const int32_t* fid2cid, int nfid, int ncl, float rate_fg,
+                                    float rate_bg, uint32_t* rng_state, int B, int H, int W, int32_t* workspace, float* out,
+                                    float* keep, vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!rng_state) return VHAP_E_NULLPTR;
+    return disturb_run(rgba, rast, fid2cid, nfid, ncl, nullptr, nullptr, nullptr, rng_state, rate_fg, rate_bg, B, H, W, workspace, out, keep,
+                       stream);
 }
 
 extern "C" int vhap_disturb_bwd(const float* d_out, const float* keep, int B, int H, int W, float* d_rgba, vhap_stream_t stream) {

@@ -165,31 +165,66 @@ __global__ __launch_bounds__(FP_THREADS) void frame_prep_fwd_kernel(FrameCfg cfg
     e_reg = block_sum(e_reg, red);
     e_smooth = block_sum(e_smooth, red);
     e_shape = block_sum(e_shape, red);
-    // rest joints: wave w owns outputs w, w + 4, ...
-    const int lane = tid & 63, wave = tid >> 6;
-    for (int o = wave; o < 3 * cfg.J; o += FP_THREADS / 64) {
-        float acc = 0.f;
-        const float* js = in.JS + (size_t)o * NB;
-        for (int k = lane; k < NB; k += 64) acc += js[k] * beta[k];
+    // rest joints J = JT + JS betas (+ J_regressor offset): every lane takes a strided slice of the reduction axis for ALL 3J
+    // outputs (independent loads, no dependent chain), then 3J block reductions
+    {
+        float part[3 * MAXJ];
+#pragma unroll
+        for (int o = 0; o < 3 * MAXJ; o++) part[o] = 0.f;
+        for (int k = tid; k < NB; k += FP_THREADS) {
+            const float bk = beta[k];
+#pragma unroll
+            for (int o = 0; o < 3 * MAXJ; o++)
+                if (o < 3 * cfg.J) part[o] += in.JS[(size_t)o * NB + k] * bk;
+        }
         if (in.offset) {
-            const int j = o / 3, c = o - 3 * j;
-            const float* jr = in.Jreg + (size_t)j * cfg.V;
-            for (int v = lane; v < cfg.V; v += 64) {
-                const float wv = jr[v];
-                if (wv != 0.f) acc += wv * in.offset[3 * v + c];
+            for (int v = tid; v < cfg.V; v += FP_THREADS) {
+                const float o0 = in.offset[3 * v], o1 = in.offset[3 * v + 1], o2 = in.offset[3 * v + 2];
+#pragma unroll
+                for (int j = 0; j < MAXJ; j++) {
+                    if (j < cfg.J) {
+                        const float wv = in.Jreg[(size_t)j * cfg.V + v];
+                        part[3 * j] += wv * o0; part[3 * j + 1] += wv * o1; part[3 * j + 2] += wv * o2;
+                    }
+                }
             }
         }
-        acc = vhap_wave_sum(acc);
-        if (lane == 0) Jl[o] = in.JT[o] + acc;
+        __shared__ float wred[FP_THREADS / 64][3 * MAXJ];
+        const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+        for (int o = 0; o < 3 * MAXJ; o++) {
+            const float v = vhap_wave_sum(part[o]);
+            if (lane == 0) wred[wave][o] = v;
+        }
+        __syncthreads();
+        if (tid < 3 * cfg.J) {
+            float a = in.JT[tid];
+#pragma unroll
+            for (int w = 0; w < FP_THREADS / 64; w++) a += wred[w][tid];
+            Jl[tid] = a;
+        }
     }
     __syncthreads();
     if (tid < 3 * cfg.J) Jrest[(size_t)b * 3 * cfg.J + tid] = Jl[tid];
     if (tid < 3) transl[3 * b + tid] = in.translation[3 * t + tid];
+    __shared__ float spose[2][3 * MAXJ + 3];   // [current | previous]: 15 pose values + translation
+    if (tid < 2 * 18) {
+        const int which = tid / 18, i = tid - 18 * which;
+        const long long tt = which ? p : t;
+        float v;
+        if (i < 3) v = in.rotation[3 * tt + i];
+        else if (i < 6) v = in.neck[3 * tt + i - 3];
+        else if (i < 9) v = in.jaw[3 * tt + i - 6];
+        else if (i < 15) v = in.eyes[6 * tt + i - 9];
+        else v = in.translation[3 * tt + i - 15];
+        spose[which][i] = v;
+    }
+    __syncthreads();
     if (tid != 0) return;
     // ---- lane 0: rotations, chain, parameter energies ----
     float pose[3 * MAXJ], prev[3 * MAXJ];
-    gather_pose(in, t, pose);
-    gather_pose(in, p, prev);
+#pragma unroll
+    for (int i = 0; i < 15; i++) { pose[i] = spose[0][i]; prev[i] = spose[1][i]; }
     Mat3 GR[MAXJ];
     float Gt[MAXJ][3];
     float reg_R[MAXJ];
@@ -231,7 +266,7 @@ __global__ __launch_bounds__(FP_THREADS) void frame_prep_fwd_kernel(FrameCfg cfg
     float sp_t = 0.f, sp_r = 0.f, sj_n = 0.f, sj_j = 0.f, sj_e = 0.f;
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        const float dt = in.translation[3 * t + c] - in.translation[3 * p + c];
+        const float dt = spose[0][15 + c] - spose[1][15 + c];
         const float dr = pose[c] - prev[c], dn = pose[3 + c] - prev[3 + c], dj = pose[6 + c] - prev[6 + c];
         const float d0 = pose[9 + c] - prev[9 + c], d1 = pose[12 + c] - prev[12 + c];
         sp_t += dt * dt; sp_r += dr * dr; sj_n += dn * dn; sj_j += dj * dj; sj_e += d0 * d0 + d1 * d1;
@@ -275,11 +310,29 @@ __global__ __launch_bounds__(FP_THREADS) void frame_prep_bwd_kernel(FrameCfg cfg
 #pragma unroll
     for (int i = 0; i < 6; i++) dt_[i] = d_terms ? d_terms[i] : 0.f;
     const float* drow = d_coef ? d_coef + (size_t)b * cfg.Kp : nullptr;
+    // stage every small per-frame input in LDS with parallel loads; lane 0 then runs the serial algebra out of LDS
+    __shared__ float spose[2][18], sJ[3 * MAXJ], sdA[12 * MAXJ], sdpf[9 * MAXJ], sdt[3];
+    if (tid < 36) {
+        const int which = tid / 18, i = tid - 18 * which;
+        const long long tt = which ? p : t;
+        float v;
+        if (i < 3) v = in.rotation[3 * tt + i];
+        else if (i < 6) v = in.neck[3 * tt + i - 3];
+        else if (i < 9) v = in.jaw[3 * tt + i - 6];
+        else if (i < 15) v = in.eyes[6 * tt + i - 9];
+        else v = in.translation[3 * tt + i - 15];
+        spose[which][i] = v;
+    }
+    for (int i = tid; i < 3 * cfg.J; i += FP_THREADS) sJ[i] = Jrest[(size_t)b * 3 * cfg.J + i];
+    for (int i = tid; i < 12 * cfg.J; i += FP_THREADS) sdA[i] = d_A ? d_A[(size_t)b * cfg.J * 12 + i] : 0.f;
+    for (int i = tid; i < cfg.P; i += FP_THREADS) sdpf[i] = drow ? drow[NB + i] : 0.f;
+    if (tid < 3) sdt[tid] = d_transl ? d_transl[3 * b + tid] : 0.f;
+    __syncthreads();
     if (tid == 0) {
         float pose[3 * MAXJ], prev[3 * MAXJ], dpose[3 * MAXJ];
-        gather_pose(in, t, pose);
-        gather_pose(in, p, prev);
-        const float* Jl = Jrest + (size_t)b * 3 * cfg.J;
+#pragma unroll
+        for (int i = 0; i < 15; i++) { pose[i] = spose[0][i]; prev[i] = spose[1][i]; }
+        const float* Jl = sJ;
         Mat3 R[MAXJ], GR[MAXJ], dGR[MAXJ];
         float dGt[MAXJ][3], dJ[3 * MAXJ];
         for (int j = 0; j < cfg.J; j++) {
@@ -290,13 +343,13 @@ __global__ __launch_bounds__(FP_THREADS) void frame_prep_bwd_kernel(FrameCfg cfg
         }
         // A_j = [GR_j | Gt_j - GR_j J_j]
         for (int j = 0; j < cfg.J; j++) {
-            const float* da = d_A ? d_A + ((size_t)b * cfg.J + j) * 12 : nullptr;
+            const float* da = sdA + 12 * j;
             float dta[3] = {0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < 3; i++) {
-                if (da) dta[i] = da[4 * i + 3];
+                dta[i] = da[4 * i + 3];
 #pragma unroll
-                for (int c = 0; c < 3; c++) dGR[j].m[3 * i + c] = (da ? da[4 * i + c] : 0.f) - dta[i] * Jl[3 * j + c];
+                for (int c = 0; c < 3; c++) dGR[j].m[3 * i + c] = da[4 * i + c] - dta[i] * Jl[3 * j + c];
                 dGt[j][i] = dta[i];
             }
             float v[3];
@@ -336,7 +389,7 @@ __global__ __launch_bounds__(FP_THREADS) void frame_prep_bwd_kernel(FrameCfg cfg
                 if (cfg.J == 5) wj = (j == 1 ? w[VHAP_FW_REG_NECK] : (j == 2 ? w[VHAP_FW_REG_JAW] : w[VHAP_FW_REG_EYES])) * dn9 * dt_[1];
 #pragma unroll
                 for (int i = 0; i < 9; i++) {
-                    if (drow) dR.m[i] += drow[NB + 9 * (j - 1) + i];
+                    dR.m[i] += sdpf[9 * (j - 1) + i];
                     dR.m[i] += 2.0f * wj * (R[j].m[i] - ((i % 4 == 0) ? 1.0f : 0.0f));
                 }
             }
@@ -371,8 +424,7 @@ __global__ __launch_bounds__(FP_THREADS) void frame_prep_bwd_kernel(FrameCfg cfg
             if (g.jaw) atomicAdd(&g.jaw[3 * t + c], dpose[6 + c]);
             if (g.eyes) { atomicAdd(&g.eyes[6 * t + c], dpose[9 + c]); atomicAdd(&g.eyes[6 * t + 3 + c], dpose[12 + c]); }
             if (g.translation) {
-                const float dtr = (d_transl ? d_transl[3 * b + c] : 0.f) +
-                                  k3 * w[VHAP_FW_SMOOTH_TRANS] * dt_[0] * (in.translation[3 * t + c] - in.translation[3 * p + c]);
+                const float dtr = sdt[c] + k3 * w[VHAP_FW_SMOOTH_TRANS] * dt_[0] * (spose[0][15 + c] - spose[1][15 + c]);
                 atomicAdd(&g.translation[3 * t + c], dtr);
             }
         }

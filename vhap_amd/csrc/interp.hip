@@ -237,10 +237,11 @@ constexpr int GB_LANES = 16;
 __global__ __launch_bounds__(256) void gbuffer_bwd_kernel(const float4* __restrict__ pos, const int* __restrict__ tri,
                                                           const float* __restrict__ vnormal, const float2* __restrict__ uv,
                                                           const int* __restrict__ tri_uv, const float4* __restrict__ rast,
-                                                          const float* __restrict__ d_normal, const float2* __restrict__ d_texc,
-                                                          const float4* __restrict__ d_texd, const float4* __restrict__ d_rast,
-                                                          const float4* __restrict__ d_db, int B, int V, int F, int H, int W,
-                                                          float* __restrict__ d_pos, float* __restrict__ d_vnormal) {
+                                                          const float* __restrict__ d_normal, const float2* d_texc,
+                                                          const float4* d_texd, const float4* __restrict__ d_rast,
+                                                          const float4* __restrict__ d_db, const unsigned char* __restrict__ uv_nograd,
+                                                          int B, int V, int F, int H, int W, float* __restrict__ d_pos,
+                                                          float* __restrict__ d_vnormal) {
     const long long gid = ((long long)blockIdx.x * 256 + threadIdx.x) / GB_LANES;
     const int sub = threadIdx.x & (GB_LANES - 1);
     if (gid >= (long long)B * F) return;   // whole 16-lane group exits together
@@ -265,6 +266,7 @@ __global__ __launch_bounds__(256) void gbuffer_bwd_kernel(const float4* __restri
         for (int k = 0; k < 3; k++) { nd0[k] = N[3 * i0 + k] - N[3 * i2 + k]; nd1[k] = N[3 * i1 + k] - N[3 * i2 + k]; }
     }
     float2 e0 = make_float2(0.f, 0.f), e1 = e0;
+    if (uv && uv_nograd && uv_nograd[t]) d_texc = nullptr;   // texc detached on this face (its screen-space derivatives texd are not)
     if (uv) {
         const float2 u0 = uv[tri_uv[3 * t]], u1 = uv[tri_uv[3 * t + 1]], u2 = uv[tri_uv[3 * t + 2]];
         e0 = make_float2(u0.x - u2.x, u0.y - u2.y);
@@ -365,8 +367,8 @@ __global__ __launch_bounds__(256) void gbuffer_bwd_kernel(const float4* __restri
 
 extern "C" int vhap_gbuffer_bwd(const float* pos, const int32_t* tri, const float* vnormal, const float* uv, const int32_t* tri_uv,
                                 const float* rast, const float* d_normal, const float* d_texc, const float* d_texd,
-                                const float* d_rast, const float* d_rast_db, int B, int V, int F, int H, int W, float* d_pos,
-                                float* d_vnormal, vhap_stream_t stream) {
+                                const float* d_rast, const float* d_rast_db, const uint8_t* uv_nograd_faces, int B, int V, int F, int H,
+                                int W, float* d_pos, float* d_vnormal, vhap_stream_t stream) {
     VHAP_ENTER();
     if (!pos || !tri || !rast) return VHAP_E_NULLPTR;
     if ((d_normal && !vnormal) || ((d_texc || d_texd) && (!uv || !tri_uv))) return VHAP_E_NULLPTR;
@@ -374,7 +376,7 @@ extern "C" int vhap_gbuffer_bwd(const float* pos, const int32_t* tri, const floa
     gbuffer_bwd_kernel<<<vhap_cdiv((long long)B * F * GB_LANES, 256), 256, 0, vhap_stream(stream)>>>(
         reinterpret_cast<const float4*>(pos), tri, vnormal, reinterpret_cast<const float2*>(uv), tri_uv,
         reinterpret_cast<const float4*>(rast), d_normal, reinterpret_cast<const float2*>(d_texc), reinterpret_cast<const float4*>(d_texd),
-        reinterpret_cast<const float4*>(d_rast), reinterpret_cast<const float4*>(d_rast_db), B, V, F, H, W, d_pos, d_vnormal);
+        reinterpret_cast<const float4*>(d_rast), reinterpret_cast<const float4*>(d_rast_db), uv_nograd_faces, B, V, F, H, W, d_pos, d_vnormal);
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;
 }

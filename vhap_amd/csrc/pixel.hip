@@ -58,44 +58,50 @@ __global__ __launch_bounds__(256) void shade_fwd_kernel(const ShadeParams P, flo
     if (threadIdx.x < 27) s_l[threadIdx.x] = P.lights[threadIdx.x];
     if (threadIdx.x < 9) s_c[threadIdx.x] = P.sh_const[threadIdx.x];
     __syncthreads();
-    const long long npix = (long long)P.B * P.H * P.W;
     float var = 0.f;
-    unsigned long long mx = 0ull;   // (ordered max << 32) | tie count
+    float mxv = -INFINITY;          // running max of the diffuse colour channels and the number of entries equal to it
+    unsigned mxn = 0u;
     auto merge = [](unsigned long long a, unsigned long long b) {
         const unsigned ha = (unsigned)(a >> 32), hb = (unsigned)(b >> 32);
         return ha > hb ? a : (hb > ha ? b : a + (b & 0xffffffffull));
     };
-    for (long long pi = (long long)blockIdx.x * 256 + threadIdx.x; pi < npix; pi += (long long)gridDim.x * 256) {
-        const float* nr = P.normal_raw + 3 * pi;
-        const float nx = nr[0], ny = nr[1], nz = nr[2];
-        const float inv = 1.0f / sqrtf(fmaxf(nx * nx + ny * ny + nz * nz, 1e-20f));
-        SH9 b;
-        sh_basis(nx * inv, ny * inv, nz * inv, s_c, b);
-        float d[3] = {0.f, 0.f, 0.f};
+    const int rows = P.B * P.H, HW = P.H * P.W;
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {      // rows: (frame, y) are uniform per workgroup, no per-pixel division
+        const int bI = row / P.H, y = row - bI * P.H;
+        const float* bg_row = P.bg_image ? P.bg_image + (size_t)bI * 3 * HW + (size_t)(P.H - 1 - y) * P.W : nullptr;
+        for (int x = threadIdx.x; x < P.W; x += 256) {
+            const size_t pi = (size_t)row * P.W + x;
+            const float* nr = P.normal_raw + 3 * pi;
+            const float nx = nr[0], ny = nr[1], nz = nr[2];
+            const float inv = 1.0f / sqrtf(fmaxf(nx * nx + ny * ny + nz * nz, 1e-20f));
+            SH9 b;
+            sh_basis(nx * inv, ny * inv, nz * inv, s_c, b);
+            float d[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < 9; k++) {
-            d[0] += b.v[k] * s_l[3 * k]; d[1] += b.v[k] * s_l[3 * k + 1]; d[2] += b.v[k] * s_l[3 * k + 2];
-        }
-        const float mean = (d[0] + d[1] + d[2]) * (1.0f / 3.0f);
-        var += 0.5f * ((d[0] - mean) * (d[0] - mean) + (d[1] - mean) * (d[1] - mean) + (d[2] - mean) * (d[2] - mean));
+            for (int k = 0; k < 9; k++) {
+                d[0] += b.v[k] * s_l[3 * k]; d[1] += b.v[k] * s_l[3 * k + 1]; d[2] += b.v[k] * s_l[3 * k + 2];
+            }
+            const float mean = (d[0] + d[1] + d[2]) * (1.0f / 3.0f);
+            var += 0.5f * ((d[0] - mean) * (d[0] - mean) + (d[1] - mean) * (d[1] - mean) + (d[2] - mean) * (d[2] - mean));
 #pragma unroll
-        for (int c = 0; c < 3; c++) mx = merge(mx, ((unsigned long long)f2ord(d[c]) << 32) | 1ull);
-        const bool fg = P.rast[pi].w > 0.0f;
-        float4 o;
-        if (fg) {
-            const float* al = P.albedo + 3 * pi;
-            o = make_float4(al[0] * d[0], al[1] * d[1], al[2] * d[2], 1.0f);
-        } else if (P.bg_image) {
-            const int HW = P.H * P.W;
-            const int bI = (int)(pi / HW), rem = (int)(pi - (long long)bI * HW);
-            const int y = rem / P.W, x = rem - y * P.W;
-            const float* g = P.bg_image + (size_t)bI * 3 * HW + (size_t)(P.H - 1 - y) * P.W + x;
-            o = make_float4(g[0], g[HW], g[2 * HW], 0.0f);
-        } else {
-            o = make_float4(P.bg_r, P.bg_g, P.bg_b, 0.0f);
+            for (int c = 0; c < 3; c++) {
+                if (d[c] > mxv) { mxv = d[c]; mxn = 1u; }
+                else if (d[c] == mxv) mxn++;
+            }
+            const bool fg = P.rast[pi].w > 0.0f;
+            float4 o;
+            if (fg) {
+                const float* al = P.albedo + 3 * pi;
+                o = make_float4(al[0] * d[0], al[1] * d[1], al[2] * d[2], 1.0f);
+            } else if (bg_row) {
+                o = make_float4(bg_row[x], bg_row[HW + x], bg_row[2 * HW + x], 0.0f);
+            } else {
+                o = make_float4(P.bg_r, P.bg_g, P.bg_b, 0.0f);
+            }
+            rgba[pi] = o;
         }
-        rgba[pi] = o;
     }
+    unsigned long long mx = mxn ? (((unsigned long long)f2ord(mxv) << 32) | mxn) : 0ull;   // (ordered max << 32) | tie count
     if (stats) {
         var = vhap_wave_sum(var);
 #pragma unroll
@@ -148,7 +154,7 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(const ShadeParams P, con
         const unsigned u = (mx_ord & 0x80000000u) ? (mx_ord & 0x7fffffffu) : ~mx_ord;
         g_max = __uint_as_float(u) > 1.0f ? dr / (float)max(ties, 1u) : 0.f;   // evenly among ties, like torch.max()
     }
-    for (long long pi = (long long)blockIdx.x * 256 + threadIdx.x; pi < npix; pi += (long long)gridDim.x * 256) {
+    for (size_t pi = (size_t)blockIdx.x * 256 + threadIdx.x; pi < (size_t)npix; pi += (size_t)gridDim.x * 256) {
         const float* nr = P.normal_raw + 3 * pi;
         const float rx = nr[0], ry = nr[1], rz = nr[2];
         const float l2 = rx * rx + ry * ry + rz * rz;
@@ -226,16 +232,16 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(const ShadeParams P, con
 __global__ __launch_bounds__(256) void photo_fwd_kernel(const float4* __restrict__ pred, const float* __restrict__ gt, int B, int H,
                                                         int W, float* __restrict__ out) {
     __shared__ float rs[4], rn[4];
-    const long long npix = (long long)B * H * W;
     float s = 0.f, n = 0.f;
-    for (long long pi = (long long)blockIdx.x * 256 + threadIdx.x; pi < npix; pi += (long long)gridDim.x * 256) {
-        const int HW = H * W;
-        const int b = (int)(pi / HW), rem = (int)(pi - (long long)b * HW);
-        const int y = rem / W, x = rem - y * W;
-        const float* g = gt + (size_t)b * 3 * HW + (size_t)(H - 1 - y) * W + x;
-        const float4 p = pred[pi];
-        s += fabsf(g[0] - p.x) + fabsf(g[HW] - p.y) + fabsf(g[2 * HW] - p.z);
-        n += p.w > 0.0f ? 1.0f : 0.0f;
+    const int rows = B * H, HW = H * W;
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+        const int b = row / H, y = row - b * H;
+        const float* g = gt + (size_t)b * 3 * HW + (size_t)(H - 1 - y) * W;
+        for (int x = threadIdx.x; x < W; x += 256) {
+            const float4 p = pred[(size_t)row * W + x];
+            s += fabsf(g[x] - p.x) + fabsf(g[HW + x] - p.y) + fabsf(g[2 * HW + x] - p.z);
+            n += p.w > 0.0f ? 1.0f : 0.0f;
+        }
     }
     s = vhap_wave_sum(s);
     n = vhap_wave_sum(n);
@@ -252,13 +258,13 @@ __global__ __launch_bounds__(256) void photo_fwd_kernel(const float4* __restrict
 __global__ __launch_bounds__(256) void photo_bwd_kernel(const float4* __restrict__ pred, const float* __restrict__ gt,
                                                         const float* __restrict__ d_sum, int B, int H, int W,
                                                         float4* __restrict__ d_pred) {
-    const long long npix = (long long)B * H * W;
-    const long long pi = (long long)blockIdx.x * 256 + threadIdx.x;
+    const unsigned npix = (unsigned)B * H * W;      // < 2^31 (check_img)
+    const unsigned pi = blockIdx.x * 256u + threadIdx.x;
     if (pi >= npix) return;
     const float gs = d_sum[0];
-    const int HW = H * W;
-    const int b = (int)(pi / HW), rem = (int)(pi - (long long)b * HW);
-    const int y = rem / W, x = rem - y * W;
+    const unsigned HW = (unsigned)H * W;
+    const unsigned b = pi / HW, rem = pi - b * HW;
+    const unsigned y = rem / (unsigned)W, x = rem - y * (unsigned)W;
     const float* g = gt + (size_t)b * 3 * HW + (size_t)(H - 1 - y) * W + x;
     const float4 p = pred[pi];
     auto sg = [](float e) { return e > 0.f ? 1.0f : (e < 0.f ? -1.0f : 0.0f); };

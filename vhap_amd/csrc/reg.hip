@@ -115,41 +115,63 @@ __device__ __forceinline__ void load_texel(const float* __restrict__ painted, co
     for (int c = 0; c < 3; c++) a[c] = (painted ? painted[c * plane + i] : 0.f) + (extra ? extra[c * plane + i] : 0.f);
 }
 
-// one thread per texel: albedo (channel-last) + TV / residual energies
+// albedo (channel-last) + TV / residual energies.  A workgroup owns a 256-column x TEX_ROWS-row strip; every lane walks down its
+// column keeping the previous row in registers (vertical differences cost one extra halo row per strip), the horizontal
+// neighbour comes from the next lane.
+constexpr int TEX_ROWS = 8;
 __global__ __launch_bounds__(RB) void tex_prep_fwd_kernel(TexCfg c, const float* __restrict__ painted, const float* __restrict__ extra,
                                                           const unsigned char* __restrict__ res_mask, float* __restrict__ albedo,
                                                           float* __restrict__ terms) {
     __shared__ float red[4];
     const int T = c.T;
     const size_t plane = (size_t)T * T;
+    const int x = blockIdx.x * RB + threadIdx.x, y0 = blockIdx.y * TEX_ROWS;
+    const int lane = threadIdx.x & 63;
+    const bool in_x = x < T;
     float e_tv = 0.f, e_res = 0.f;
-    for (size_t i = (size_t)blockIdx.x * RB + threadIdx.x; i < plane; i += (size_t)gridDim.x * RB) {
-        const int y = (int)(i / T), x = (int)(i - (size_t)y * T);
-        float a[3], ay[3], ax[3];
-        load_texel(painted, extra, plane, i, a);
-        albedo[3 * i] = a[0]; albedo[3 * i + 1] = a[1]; albedo[3 * i + 2] = a[2];
-        if (c.s_tv != 0.f) {
-            if (y + 1 < T) {
-                load_texel(painted, extra, plane, i + T, ay);
+    float up[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-                for (int k = 0; k < 3; k++) { const float d = a[k] - ay[k]; e_tv += d * d; }
-            }
-            if (x + 1 < T) {
-                load_texel(painted, extra, plane, i + 1, ax);
+    for (int r = 0; r <= TEX_ROWS; r++) {
+        const int y = y0 + r;
+        if (y >= T) break;
+        const size_t i = (size_t)y * T + x;
+        float a[3] = {0.f, 0.f, 0.f}, ex[3] = {0.f, 0.f, 0.f};
+        if (in_x) {
 #pragma unroll
-                for (int k = 0; k < 3; k++) { const float d = a[k] - ax[k]; e_tv += d * d; }
+            for (int k = 0; k < 3; k++) {
+                ex[k] = extra ? extra[k * plane + i] : 0.f;
+                a[k] = (painted ? painted[k * plane + i] : 0.f) + ex[k];
             }
         }
-        if (c.s_res != 0.f && extra && res_mask && res_mask[i]) {
+        if (r > 0 && in_x) {
 #pragma unroll
-            for (int k = 0; k < 3; k++) { const float r = extra[k * plane + i]; e_res += r * r; }
+            for (int k = 0; k < 3; k++) { const float d = up[k] - a[k]; e_tv += d * d; }
         }
+        if (r < TEX_ROWS) {
+            float rt[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) rt[k] = __shfl_down(a[k], 1, 64);
+            if (lane == 63 && x + 1 < T) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) rt[k] = (painted ? painted[k * plane + i + 1] : 0.f) + (extra ? extra[k * plane + i + 1] : 0.f);
+            }
+            if (in_x) {
+                albedo[3 * i] = a[0]; albedo[3 * i + 1] = a[1]; albedo[3 * i + 2] = a[2];
+                if (x + 1 < T) {
+#pragma unroll
+                    for (int k = 0; k < 3; k++) { const float d = a[k] - rt[k]; e_tv += d * d; }
+                }
+                if (res_mask && extra && res_mask[i]) e_res += ex[0] * ex[0] + ex[1] * ex[1] + ex[2] * ex[2];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) up[k] = a[k];
     }
     e_tv = block_sum256(e_tv, red);
     e_res = block_sum256(e_res, red);
     if (threadIdx.x == 0) {
-        if (e_tv != 0.f) atomicAdd(&terms[0], e_tv * c.s_tv);
-        if (e_res != 0.f) atomicAdd(&terms[1], e_res * c.s_res);
+        if (e_tv != 0.f && c.s_tv != 0.f) atomicAdd(&terms[0], e_tv * c.s_tv);
+        if (e_res != 0.f && c.s_res != 0.f) atomicAdd(&terms[1], e_res * c.s_res);
     }
 }
 
@@ -261,8 +283,7 @@ extern "C" int vhap_tex_prep_fwd(const float* painted, const float* extra, const
     vhap_zero_async(terms, 2 * sizeof(float), st);
     VHAP_LAUNCH_CHECK();
     TexCfg c{T, s_tv, s_res};
-    const int blocks = (int)(((size_t)T * T + RB - 1) / RB < 8192 ? ((size_t)T * T + RB - 1) / RB : 8192);
-    tex_prep_fwd_kernel<<<blocks, RB, 0, st>>>(c, painted, extra, res_mask, albedo_hwc, terms);
+    tex_prep_fwd_kernel<<<dim3(vhap_cdiv(T, RB), vhap_cdiv(T, TEX_ROWS)), RB, 0, st>>>(c, painted, extra, res_mask, albedo_hwc, terms);
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;
 }

@@ -240,14 +240,19 @@ def photo_sum(pred_rgba_renderer_space, gt_nchw):
 # ------------------------------------------------------------------------------------------------
 class _Disturb(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, rgba, rast, fid2cid, ncl, w_fg, w_bg, idx):
+    def forward(ctx, rgba, rast, fid2cid, ncl, w_fg, w_bg, idx, rng=None):
         B, H, W, _ = rgba.shape
         L = _lib.lib()
         ws = torch.empty(L.vhap_disturb_workspace_ints(B, H, W), dtype=torch.int32, device=rgba.device)
         out = torch.empty_like(rgba)
         keep = torch.empty(B, H, W, dtype=torch.float32, device=rgba.device)
-        _chk(L.vhap_disturb_fwd(_p(rgba), _p(rast), _p(fid2cid), fid2cid.numel(), ncl, _p(w_fg), _p(w_bg), _p(idx), B, H, W, _p(ws),
-                                _p(out), _p(keep), _stream()), "vhap_disturb_fwd")
+        if rng is not None:
+            state, rate_fg, rate_bg = rng
+            _chk(L.vhap_disturb_fwd_rng(_p(rgba), _p(rast), _p(fid2cid), fid2cid.numel(), ncl, rate_fg, rate_bg, _p(state), B, H, W,
+                                        _p(ws), _p(out), _p(keep), _stream()), "vhap_disturb_fwd_rng")
+        else:
+            _chk(L.vhap_disturb_fwd(_p(rgba), _p(rast), _p(fid2cid), fid2cid.numel(), ncl, _p(w_fg), _p(w_bg), _p(idx), B, H, W, _p(ws),
+                                    _p(out), _p(keep), _stream()), "vhap_disturb_fwd")
         ctx.save_for_backward(keep)
         return out
 
@@ -257,9 +262,15 @@ class _Disturb(torch.autograd.Function):
         B, H, W = keep.shape
         d = torch.empty(B, H, W, 4, dtype=torch.float32, device=keep.device)
         _chk(_lib.lib().vhap_disturb_bwd(_p(_f32c(d_out)), _p(keep), B, H, W, _p(d), _stream()), "vhap_disturb_bwd")
-        return d, None, None, None, None, None, None
+        return d, None, None, None, None, None, None, None
 
 
 def disturb(rgba, rast, fid2cid_i32, ncl, w_fg, w_bg, idx):
     """Cluster-wise colour disturbance of the composited image; w_fg / w_bg int32 [B,H,W(,1)], idx int64 [B*H*W]."""
     return _Disturb.apply(_f32c(rgba), _f32c(rast), fid2cid_i32, int(ncl), w_fg.contiguous(), w_bg.contiguous(), idx.contiguous())
+
+
+def disturb_rng(rgba, rast, fid2cid_i32, ncl, rng_state, rate_fg, rate_bg):
+    """Same with in-kernel random numbers; `rng_state` uint32 [1] device counter (advanced by every call)."""
+    return _Disturb.apply(_f32c(rgba), _f32c(rast), fid2cid_i32, int(ncl), None, None, None,
+                          (rng_state, float(rate_fg or 0.0), float(rate_bg or 0.0)))

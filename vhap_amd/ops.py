@@ -319,7 +319,7 @@ def opposite_table(tri):
 
 class _Antialias(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, color, rast, pos, tri, opp):
+    def forward(ctx, color, rast, pos, tri, opp, pos_nograd):
         B, H, W, C = color.shape
         V, F = pos.shape[1], tri.shape[0]
         out = torch.empty_like(color)
@@ -327,26 +327,27 @@ class _Antialias(torch.autograd.Function):
         rc = _lib.lib().vhap_antialias_fwd(_p(color), _p(rast), _p(pos), _p(tri), _p(opp), B, H, W, C, V, F, _p(out),
                                            _p(work), _stream())
         _lib.check(rc, "vhap_antialias_fwd")
-        ctx.save_for_backward(color, rast, pos, tri, opp, work)
+        ctx.save_for_backward(color, rast, pos, tri, opp, work, pos_nograd)
         return out
 
     @staticmethod
     def backward(ctx, d_out):
-        color, rast, pos, tri, opp, work = ctx.saved_tensors
+        color, rast, pos, tri, opp, work, pos_nograd = ctx.saved_tensors
         B, H, W, C = color.shape
         V, F = pos.shape[1], tri.shape[0]
-        need_color, _, need_pos, _, _ = ctx.needs_input_grad
+        need_color, _, need_pos = ctx.needs_input_grad[:3]
         d_out = _f32c(d_out)
         d_color = torch.empty_like(color) if need_color else None
         d_pos = torch.zeros_like(pos) if need_pos else None
-        rc = _lib.lib().vhap_antialias_bwd(_p(color), _p(rast), _p(pos), _p(tri), _p(opp), _p(d_out), _p(work), B, H, W, C,
-                                           V, F, _p(d_color), _p(d_pos), _stream())
+        rc = _lib.lib().vhap_antialias_bwd(_p(color), _p(rast), _p(pos), _p(tri), _p(opp), _p(d_out), _p(work), _p(pos_nograd), B, H, W,
+                                           C, V, F, _p(d_color), _p(d_pos), _stream())
         _lib.check(rc, "vhap_antialias_bwd")
-        return d_color, None, d_pos, None, None
+        return d_color, None, d_pos, None, None, None
 
 
-def antialias(color, rast, pos, tri, topology_hash=None, pos_gradient_boost=1.0, opp=None):
-    """dr.antialias(color [B,H,W,C], rast, pos [B,V,4], tri) -> [B,H,W,C]."""
+def antialias(color, rast, pos, tri, topology_hash=None, pos_gradient_boost=1.0, opp=None, pos_nograd_verts=None):
+    """dr.antialias(color [B,H,W,C], rast, pos [B,V,4], tri) -> [B,H,W,C].  `pos_nograd_verts` (MI355X extension): uint8 [V],
+    vertices that receive no silhouette gradient (the reference detaches them in `pos` beforehand)."""
     _chk_cuda(color, rast, pos, tri)
     if pos_gradient_boost != 1.0:
         raise NotImplementedError("pos_gradient_boost != 1 is not used by the reference")
@@ -355,7 +356,7 @@ def antialias(color, rast, pos, tri, topology_hash=None, pos_gradient_boost=1.0,
     color, rast, pos, tri = _f32c(color), _f32c(rast), _f32c(pos), _i32c(tri)
     if opp is None:
         opp = opposite_table(tri)
-    return _Antialias.apply(color, rast, pos, tri, _i32c(opp))
+    return _Antialias.apply(color, rast, pos, tri, _i32c(opp), pos_nograd_verts)
 
 
 class _RasterInterp(torch.autograd.Function):
@@ -363,16 +364,16 @@ class _RasterInterp(torch.autograd.Function):
     the backward chains the two interpolate backwards into the rasterize backward."""
 
     @staticmethod
-    def forward(ctx, glctx, pos, tri, vnormal, uv, tri_uv, resolution):
+    def forward(ctx, glctx, pos, tri, vnormal, uv, tri_uv, resolution, uv_nograd):
         rast, db, normal, texc, texd = raster_interp_fwd(glctx, pos, tri, vnormal, uv, tri_uv, resolution)
         ctx.set_materialize_grads(False)           # unused outputs (rast, rast_db) arrive as None, not as zero images
-        ctx.save_for_backward(pos, tri, vnormal, uv, tri_uv, rast, db)
+        ctx.save_for_backward(pos, tri, vnormal, uv, tri_uv, rast, db, uv_nograd)
         ctx.res = (int(resolution[0]), int(resolution[1]))
         return rast, db, normal, texc, texd
 
     @staticmethod
     def backward(ctx, d_rast, d_db, d_normal, d_texc, d_texd):
-        pos, tri, vnormal, uv, tri_uv, rast, db = ctx.saved_tensors
+        pos, tri, vnormal, uv, tri_uv, rast, db, uv_nograd = ctx.saved_tensors
         H, W = ctx.res
         B, V, _ = pos.shape
         F = tri.shape[0]
@@ -381,13 +382,14 @@ class _RasterInterp(torch.autograd.Function):
         d_pos = torch.zeros_like(pos) if need_pos else None
         d_vn = torch.zeros_like(vnormal) if (need_n and d_normal is not None) else None
         _lib.check(_lib.lib().vhap_gbuffer_bwd(_p(pos), _p(tri), _p(vnormal), _p(uv), _p(tri_uv), _p(rast), _p(c(d_normal)),
-                                               _p(c(d_texc)), _p(c(d_texd)), _p(c(d_rast)), _p(c(d_db)), B, V, F, H, W, _p(d_pos),
-                                               _p(d_vn), _stream()), "vhap_gbuffer_bwd")
-        return None, d_pos, None, d_vn, None, None, None
+                                               _p(c(d_texc)), _p(c(d_texd)), _p(c(d_rast)), _p(c(d_db)), _p(uv_nograd), B, V, F, H, W,
+                                               _p(d_pos), _p(d_vn), _stream()), "vhap_gbuffer_bwd")
+        return None, d_pos, None, d_vn, None, None, None, None
 
 
-def raster_interp(glctx, pos, tri, vnormal, uv, tri_uv, resolution):
-    """Differentiable fused pass -> (rast, rast_db, normal [B,H,W,3], texc [B,H,W,2], texd [B,H,W,4])."""
+def raster_interp(glctx, pos, tri, vnormal, uv, tri_uv, resolution, uv_nograd_faces=None):
+    """Differentiable fused pass -> (rast, rast_db, normal [B,H,W,3], texc [B,H,W,2], texd [B,H,W,4]).
+    `uv_nograd_faces`: uint8 [F], faces whose texture coordinates carry no gradient."""
     _chk_cuda(pos, tri, vnormal, uv, tri_uv)
     _check_raster_args(pos, tri, resolution)
-    return _RasterInterp.apply(glctx, _f32c(pos), _i32c(tri), _f32c(vnormal), _f32c(uv), _i32c(tri_uv), tuple(resolution))
+    return _RasterInterp.apply(glctx, _f32c(pos), _i32c(tri), _f32c(vnormal), _f32c(uv), _i32c(tri_uv), tuple(resolution), uv_nograd_faces)

@@ -56,6 +56,8 @@ class HipDiffRenderer(torch.nn.Module):
         self.glctx = ops.RasterizeHipContext()
         self.fused = True           # fused HIP kernels for transform / normals / shading (False: host-side torch ops)
         self._csr_cache = {}
+        self._mask_cache = {}
+        self._rng_state = None
         self.fragment_cache = None
         if fid2cid is not None:
             self.register_buffer("fid2cid", F.pad(fid2cid, [1, 0], value=0), persistent=False)   # 0 = background
@@ -205,6 +207,16 @@ class HipDiffRenderer(torch.nn.Module):
             return get_SH_shading(normal, lighting_coeff, self.sh_const)
         raise NotImplementedError(f"Unknown lighting type: {self.lighting_type}")
 
+    def _u8_mask(self, indices, n):
+        """Static index list -> cached uint8 membership table [n] (keyed by the index tensor's storage)."""
+        key = (indices.data_ptr(), int(indices.numel()), int(n))
+        m = self._mask_cache.get(key)
+        if m is None:
+            m = torch.zeros(n, dtype=torch.uint8, device=indices.device)
+            m.index_fill_(0, indices.long(), 1)
+            self._mask_cache[key] = m
+        return m
+
     def detach_by_indices(self, x, indices):
         keep = torch.ones(x.shape[1], dtype=torch.bool, device=x.device)
         keep.index_fill_(0, indices, False)
@@ -285,18 +297,23 @@ class HipDiffRenderer(torch.nn.Module):
         out_dict = {}
 
         v_normal = self._vertex_normals_for(verts, verts_camera, faces)
+        in_kernel_masks = False
         if rast_out is None:    # deferred: fused rasterize + interpolate(normal) + interpolate(uv, 'all')
             pos = verts_clip if rast_dict.get("require_grad", True) else verts_clip.detach()
+            # the two "detach by region" masks of the reference become static uint8 tables read by the backward kernels
+            in_kernel_masks = True
+            face_mask = self._u8_mask(align_texture_except_fid, faces.shape[0]) if align_texture_except_fid is not None else None
             rast_out, rast_out_db, normal, texc, texd = ops.raster_interp(self.glctx, pos, tri, v_normal, verts_uv, tri_uv,
-                                                                          rast_dict["image_size"])
+                                                                          rast_dict["image_size"], uv_nograd_faces=face_mask)
             rast_dict["rast_out"], rast_dict["rast_out_db"] = rast_out, rast_out_db
         else:
             normal, _ = ops.interpolate(v_normal, rast_out, tri)
             texc, texd = ops.interpolate(verts_uv[None, ...], rast_out, tri_uv, rast_db=rast_out_db, diff_attrs="all")
-        fg_mask = rast_out[..., 3:4] > 0
+        fast = outputs == "loss" and self.fused and self.lighting_type == "SH"
+        fg_mask = rast_out[..., 3:4] > 0 if not fast else None
         normal_raw = normal
-        normal = safe_normalize(normal) if not (outputs == "loss" and self.fused and self.lighting_type == "SH") else None
-        if align_texture_except_fid is not None:
+        normal = safe_normalize(normal) if not fast else None
+        if align_texture_except_fid is not None and not in_kernel_masks:
             mask = torch.zeros(faces.shape[0] + 1, dtype=torch.bool, device=rast_out.device)
             mask.index_fill_(0, align_texture_except_fid + 1, True)        # (scalar fill: no host->device copy, graph-safe)
             rast_mask = mask[rast_out[..., 3].long()][..., None]
@@ -310,7 +327,6 @@ class HipDiffRenderer(torch.nn.Module):
             tex_cl = tex.permute(0, 2, 3, 1).contiguous()
         albedo = ops.texture(tex_cl, texc, texd, filter_mode="linear-mipmap-linear")
 
-        fast = outputs == "loss" and self.fused and self.lighting_type == "SH"
         if fast:
             rgba, reg_diffuse = FU.shade(normal_raw, albedo, lights, rast_out, background_color, self.sh_const, want_reg_diffuse)
             rgba_bg = None
@@ -321,7 +337,18 @@ class HipDiffRenderer(torch.nn.Module):
             rgba_bg = self._background(background_color, rgba)
             rgba = torch.where(fg_mask, rgba, rgba_bg)
 
-        if enable_disturbance:
+        if enable_disturbance and disturbance is None and not (self.disturb_rate_fg or self.disturb_rate_bg):
+            pass                                   # both rates None / 0: every weight is 0, the image is unchanged
+        elif enable_disturbance and disturbance is None and fast and rgba.is_cuda:
+            if not hasattr(self, "_ncl"):
+                self._ncl = int(self.fid2cid.max().item()) + 1
+            # random numbers drawn inside the kernel (no [B,H,W] random tensors, no generator launches)
+            if self._rng_state is None or self._rng_state.device != rgba.device:
+                self._rng_state = torch.randint(0, 2 ** 31 - 1, (1,), device=rgba.device).to(torch.int32)
+            if not hasattr(self, "_fid2cid_i32") or self._fid2cid_i32.device != rgba.device:
+                self._fid2cid_i32 = self.fid2cid.int().contiguous()
+            rgba = FU.disturb_rng(rgba, rast_out, self._fid2cid_i32, self._ncl, self._rng_state, self.disturb_rate_fg, self.disturb_rate_bg)
+        elif enable_disturbance:
             if disturbance is None:
                 disturbance = self.make_disturbance(rgba.shape[:3], rgba.device)
             if rgba_bg is None and not (self.fused and rgba.is_cuda and not isinstance(disturbance["idx"], (list, tuple))):
@@ -330,9 +357,13 @@ class HipDiffRenderer(torch.nn.Module):
             if cid is not None:
                 out_dict["cid"] = cid.flip(1)
 
+        vert_mask = None
         if align_boundary_except_vid is not None:
-            verts_clip = self.detach_by_indices(verts_clip, align_boundary_except_vid)
-        rgba_aa = ops.antialias(rgba, rast_out, verts_clip, tri, opp=mesh["opp"])
+            if in_kernel_masks:
+                vert_mask = self._u8_mask(align_boundary_except_vid, verts_clip.shape[1])
+            else:
+                verts_clip = self.detach_by_indices(verts_clip, align_boundary_except_vid)
+        rgba_aa = ops.antialias(rgba, rast_out, verts_clip, tri, opp=mesh["opp"], pos_nograd_verts=vert_mask)
         if fast:
             out_dict.update({"rgba_rs": rgba_aa, "reg_diffuse": reg_diffuse})
             return out_dict
