@@ -186,7 +186,7 @@ int vhap_photo_bwd(const float* pred_rgba, const float* gt_nchw, const float* d_
  *   A [B,5,12] relative joint transforms (3x4 row-major); Kb = number of shape+expr rows
  * skin_bwd: d_coef [Bp,Kp] overwritten, d_A [B,5,12] / d_transl [B,3] ACCUMULATED (caller zero-fills),
  *   g_posed / g_shaped [B,V,3] scratch (g_shaped = gradient w.r.t. v_shaped incl. d_vshaped),
- *   partials: vhap_flame_bwd_partial_floats() floats.
+ *   partials: vhap_flame_bwd_partial_floats() floats (0 since ABI 1: may be NULL).
  * ------------------------------------------------------------------------------------------- */
 int vhap_flame_skin_fwd(const float* coef, const float* basis, const float* A,
                         const float* lbs_weights, const float* v_template, const float* offset,

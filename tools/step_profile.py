@@ -1,0 +1,39 @@
+"""Per-step kernel table from a rocprofv3 --kernel-trace CSV of bench.py: one graph-replayed step, kernels in launch order
+grouped by name (count, total us).  usage: python tools/step_profile.py <kernel_trace.csv> [--seq]"""
+import collections
+import csv
+import re
+import sys
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+idx = [i for i, r in enumerate(rows) if "raster_kernel" in r["Kernel_Name"]]
+a = idx[-30]
+first = "frame_prep_fwd" if any("frame_prep_fwd" in r["Kernel_Name"] for r in rows) else "flame_skin_fwd"
+s = max(i for i in range(a) if first in rows[i]["Kernel_Name"])
+e = min(i for i in range(a + 1, len(rows)) if first in rows[i]["Kernel_Name"])
+seq = rows[s - 1:e - 1]
+dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+
+
+def short(n):
+    n = re.sub(r"\(anonymous namespace\)::", "", n)
+    n = re.sub(r"void ", "", n)
+    n = re.sub(r"at::native::", "", n)
+    return n[:90]
+
+
+print("kernels/step %d  wall %.1f us  busy %.1f us" % (len(seq), (int(seq[-1]["End_Timestamp"]) - int(seq[0]["Start_Timestamp"])) / 1e3,
+                                                       sum(dur(r) for r in seq)))
+if "--seq" in sys.argv:
+    for r in seq:
+        print("%8.1f %s" % (dur(r), short(r["Kernel_Name"])))
+else:
+    agg = collections.OrderedDict()
+    for r in seq:
+        k = short(r["Kernel_Name"])
+        agg.setdefault(k, [0, 0.0])
+        agg[k][0] += 1
+        agg[k][1] += dur(r)
+    for k, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print("%8.1f us  x%-3d %s" % (t, n, k))

@@ -15,6 +15,8 @@
         if (vhap_e_ != hipSuccess && vhap_e_ != hipErrorNotReady) return VHAP_E_HIP; \
     } while (0)
 
+extern int vhap_g_debug_flags;   // misc.hip
+
 static inline hipStream_t vhap_stream(vhap_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 static inline int vhap_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

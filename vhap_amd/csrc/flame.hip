@@ -167,59 +167,49 @@ __global__ __launch_bounds__(256) void flame_skin_bwd_kernel(const float* __rest
     }
 }
 
-// d_coef partials: grid (Vp/64, ceil(B/16)), 256 threads = 4 waves; wave w owns n-tiles [7w, 7w+7) of Kp/16 = 28.
-// part [gridDim.x][Bp][Kp]
+// d_coef [Bp,Kp] += G^T-contraction over vertices: d_coef[b][k] = sum_{v,c} g[b][v][c] * basisT[c][v][k] with g = g_shaped for
+// the shape/expression columns (k < Kb) and g_posed for the pose-corrective columns.  A skinny GEMM (M = 16 frames, N = Kp,
+// K = 3V ~ 15k): the work is the 27 MB read of the basis, so the grid is (N tiles) x (S splits of the vertex axis) ~ 700
+// workgroups -- enough loads in flight to stream it -- each wave reducing its slice with 16x16x4 MFMAs, the four waves of a
+// workgroup summed through LDS, and one atomic per output element and workgroup (S-deep chains only).
 __global__ __launch_bounds__(256) void flame_coef_bwd_kernel(const float* __restrict__ g_shaped, const float* __restrict__ g_posed,
                                                              const float* __restrict__ basisT, int B, int V, int Vp, int Kb,
-                                                             int Kp, int ntile_per_wave, float* __restrict__ part) {
+                                                             int Kp, int v_per_wave, float* __restrict__ d_coef) {
+    __shared__ float red[4][64][4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int li = lane & 15, lk = lane >> 4;
-    const int v0 = blockIdx.x * 64, b0 = blockIdx.y * 16;
-    const int Bp = gridDim.y * 16;
-    const int nt0 = wave * ntile_per_wave;
-    const int ntiles = Kp / 16;
-    f32x4 acc[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nt = blockIdx.x, b0 = blockIdx.z * 16;
+    const float* __restrict__ G = (nt * 16 < Kb) ? g_shaped : g_posed;     // tiles never straddle Kb (a multiple of 16)
+    const int vbeg = (blockIdx.y * 4 + wave) * v_per_wave;
+    const int vend = min(vbeg + v_per_wave, V);
     const bool bvalid = b0 + li < B;
     const size_t cs = (size_t)Vp * Kp;
-    for (int ks = 0; ks < 16; ks++) {
-        const int v = v0 + ks * 4 + lk;
-        const bool ok = bvalid && v < V;
-        const size_t go = ((size_t)(b0 + li) * V + v) * 3;
+    const float* gp = G + (size_t)(b0 + li) * V * 3;
+    const float* bp = basisT + (size_t)nt * 16 + li;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int v0 = vbeg; v0 < vend; v0 += 4) {
+        const int v = v0 + lk;
+        const bool ok = v < vend;
+        float a[3], bb[3];
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            const float as = ok ? g_shaped[go + c] : 0.f;
-            const float ap = ok ? g_posed[go + c] : 0.f;
-            const float* bp = basisT + c * cs + (size_t)v * Kp + li;
+            a[c] = (ok && bvalid) ? gp[(size_t)v * 3 + c] : 0.f;
+            bb[c] = ok ? bp[c * cs + (size_t)v * Kp] : 0.f;
+        }
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const int nt = nt0 + i;
-                if (i < ntile_per_wave && nt < ntiles) {
-                    const float a = (nt * 16 < Kb) ? as : ap;   // tiles never straddle Kb (Kb is a multiple of 16)
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bp[nt * 16], acc[i], 0, 0, 0);
-                }
-            }
+        for (int c = 0; c < 3; c++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c], bb[c], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) red[wave][lane][r] = acc[r];
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const float s = (red[0][lane][r] + red[1][lane][r]) + (red[2][lane][r] + red[3][lane][r]);
+            if (s != 0.f) atomicAdd(&d_coef[(size_t)(b0 + lk * 4 + r) * Kp + nt * 16 + li], s);
         }
     }
-    float* out = part + (size_t)blockIdx.x * Bp * Kp;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const int nt = nt0 + i;
-        if (i < ntile_per_wave && nt < ntiles) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) out[(size_t)(b0 + lk * 4 + r) * Kp + nt * 16 + li] = acc[i][r];
-        }
-    }
-}
-
-// sum partials over the leading dimension: out [n] = sum_p part[p][n]
-__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int P, int n, float* __restrict__ out) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    float s = 0.f;
-    for (int p = 0; p < P; p++) s += part[(size_t)p * n + i];
-    out[i] = s;
 }
 
 // clip = [v;1] @ M^T with M [B,4,4] row-major (clip_r = M[r][0..2].v + M[r][3])
@@ -371,8 +361,8 @@ extern "C" int vhap_flame_skin_fwd(const float* coef, const float* basis, const 
 }
 
 extern "C" size_t vhap_flame_bwd_partial_floats(int B, int Vp, int Kp) {
-    if (B <= 0 || Vp <= 0 || Kp <= 0) return 0;
-    return (size_t)(Vp / 64) * (size_t)(((B + 15) / 16) * 16) * Kp;
+    (void)B; (void)Vp; (void)Kp;
+    return 0;   // no scratch needed any more (split-K sums use atomics); kept for ABI stability
 }
 
 extern "C" int vhap_flame_skin_bwd(const float* d_verts, const float* d_vshaped, const float* v_posed, const float* A,
@@ -380,19 +370,23 @@ extern "C" int vhap_flame_skin_bwd(const float* d_verts, const float* d_vshaped,
                                    float* g_posed, float* g_shaped, float* partials, float* d_coef, float* d_A, float* d_transl,
                                    vhap_stream_t stream) {
     VHAP_ENTER();
-    if (!d_verts || !v_posed || !A || !lbs_weights || !basisT || !g_posed || !g_shaped || !partials || !d_coef || !d_A || !d_transl)
+    if (!d_verts || !v_posed || !A || !lbs_weights || !basisT || !g_posed || !g_shaped || !d_coef || !d_A || !d_transl)
         return VHAP_E_NULLPTR;
     if (B <= 0 || V <= 0 || Vp < V || Vp % 64 || Kb % 16 || Kp % 16 || Kp / 16 > 32) return VHAP_E_BADDIM;
     hipStream_t st = vhap_stream(stream);
     flame_skin_bwd_kernel<<<dim3(vhap_cdiv(V, 256), B), 256, 0, st>>>(d_verts, d_vshaped, v_posed, A, lbs_weights, B, V, g_posed, g_shaped,
                                                                       d_A, d_transl);
     VHAP_LAUNCH_CHECK();
-    const int ntiles = Kp / 16, per_wave = (ntiles + 3) / 4;
-    const dim3 grid(Vp / 64, (B + 15) / 16);
-    flame_coef_bwd_kernel<<<grid, 256, 0, st>>>(g_shaped, g_posed, basisT, B, V, Vp, Kb, Kp, per_wave, partials);
+    (void)partials;                                  // (kept in the signature; the split-K sums go through atomics now)
+    const int ntiles = Kp / 16, btiles = (B + 15) / 16;
+    vhap_zero_async(d_coef, sizeof(float) * (size_t)btiles * 16 * Kp, st);
     VHAP_LAUNCH_CHECK();
-    const int n = grid.y * 16 * Kp;
-    reduce_partials_kernel<<<vhap_cdiv(n, 256), 256, 0, st>>>(partials, grid.x, n, d_coef);
+    int S = 768 / (ntiles * btiles);                 // ~768 workgroups in flight
+    S = S < 1 ? 1 : S;
+    int v_per_wave = (V + S * 4 - 1) / (S * 4);
+    v_per_wave = (v_per_wave + 3) / 4 * 4;           // whole 4-vertex MFMA steps
+    S = (V + v_per_wave * 4 - 1) / (v_per_wave * 4);
+    flame_coef_bwd_kernel<<<dim3(ntiles, S, btiles), 256, 0, st>>>(g_shaped, g_posed, basisT, B, V, Vp, Kb, Kp, v_per_wave, d_coef);
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;
 }

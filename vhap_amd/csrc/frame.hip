@@ -104,6 +104,11 @@ __device__ __forceinline__ void rodrigues_bwd(const float* r, const Mat3& dR, fl
     dr[2] += dn[2] * ith + dth * az * ith;
 }
 
+// FLAME's kinematic tree (root, neck, jaw, left eye, right eye).  With the tree known at compile time the joint loops unroll
+// completely and every per-joint matrix stays in registers; a run-time `parents` table forces them into scratch memory
+// (dynamic indexing), which costs ~50 us of serial latency per launch.
+__device__ __forceinline__ constexpr int flame_parent(int j) { return j == 0 ? -1 : (j == 1 ? 0 : 1); }
+
 struct FrameIn {
     const long long* ts;
     const float *shape, *expr, *rotation, *translation, *neck, *jaw, *eyes;
@@ -133,6 +138,7 @@ __device__ __forceinline__ float block_sum(float v, float* red /*[FP_THREADS/64]
 }
 
 // terms: [0] smooth_pose [1] reg_joint [2] smooth_joint [3] reg_expr [4] smooth_expr [5] reg_shape   (weighted)
+template <int JT>   // JT = 5: FLAME tree, fully unrolled; JT = 0: generic tree from cfg.parents
 __global__ __launch_bounds__(FP_THREADS) void frame_prep_fwd_kernel(FrameCfg cfg, FrameIn in, float* __restrict__ coef,
                                                                     float* __restrict__ A, float* __restrict__ transl,
                                                                     float* __restrict__ Jrest, float* __restrict__ terms) {
@@ -228,7 +234,9 @@ __global__ __launch_bounds__(FP_THREADS) void frame_prep_fwd_kernel(FrameCfg cfg
     Mat3 GR[MAXJ];
     float Gt[MAXJ][3];
     float reg_R[MAXJ];
-    for (int j = 0; j < cfg.J; j++) {
+#pragma unroll
+    for (int j = 0; j < (JT ? JT : MAXJ); j++) {
+        if (!JT && j >= cfg.J) break;
         const Mat3 R = rodrigues(pose + 3 * j);
         float fro = 0.f;
 #pragma unroll
@@ -238,7 +246,7 @@ __global__ __launch_bounds__(FP_THREADS) void frame_prep_fwd_kernel(FrameCfg cfg
             fro += d * d;
         }
         reg_R[j] = fro;
-        const int par = cfg.parents[j];
+        const int par = JT ? flame_parent(j) : cfg.parents[j];
         if (j == 0) {
             GR[0] = R;
 #pragma unroll
@@ -296,6 +304,7 @@ struct FrameGrad {
     float *shape, *expr, *rotation, *translation, *neck, *jaw, *eyes, *offset;   // full-size, ACCUMULATED (any may be null)
 };
 
+template <int JT>
 __global__ __launch_bounds__(FP_THREADS) void frame_prep_bwd_kernel(FrameCfg cfg, FrameIn in, const float* __restrict__ Jrest,
                                                                     const float* __restrict__ d_coef, const float* __restrict__ d_A,
                                                                     const float* __restrict__ d_transl,
@@ -335,14 +344,18 @@ __global__ __launch_bounds__(FP_THREADS) void frame_prep_bwd_kernel(FrameCfg cfg
         const float* Jl = sJ;
         Mat3 R[MAXJ], GR[MAXJ], dGR[MAXJ];
         float dGt[MAXJ][3], dJ[3 * MAXJ];
-        for (int j = 0; j < cfg.J; j++) {
+#pragma unroll
+        for (int j = 0; j < (JT ? JT : MAXJ); j++) {
+            if (!JT && j >= cfg.J) break;
             R[j] = rodrigues(pose + 3 * j);
-            GR[j] = j == 0 ? R[0] : mul(GR[cfg.parents[j]], R[j]);
+            GR[j] = j == 0 ? R[0] : mul(GR[JT ? (j ? flame_parent(j) : 0) : cfg.parents[j]], R[j]);
 #pragma unroll
             for (int c = 0; c < 3; c++) { dJ[3 * j + c] = 0.f; dpose[3 * j + c] = 0.f; }
         }
         // A_j = [GR_j | Gt_j - GR_j J_j]
-        for (int j = 0; j < cfg.J; j++) {
+#pragma unroll
+        for (int j = 0; j < (JT ? JT : MAXJ); j++) {
+            if (!JT && j >= cfg.J) break;
             const float* da = sdA + 12 * j;
             float dta[3] = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -358,10 +371,13 @@ __global__ __launch_bounds__(FP_THREADS) void frame_prep_bwd_kernel(FrameCfg cfg
             for (int c = 0; c < 3; c++) dJ[3 * j + c] -= v[c];
         }
         const float dn9 = 1.0f / (9.0f * (float)(2 * cfg.B - 1));
-        for (int j = cfg.J - 1; j >= 0; j--) {
+#pragma unroll
+        for (int jj = 0; jj < (JT ? JT : MAXJ); jj++) {
+            const int j = (JT ? JT : cfg.J) - 1 - jj;
+            if (!JT && j < 0) break;
             Mat3 dR;
             if (j > 0) {
-                const int par = cfg.parents[j];
+                const int par = JT ? flame_parent(j > 0 ? j : 1) : cfg.parents[j];
                 float rel[3], drel[3];
 #pragma unroll
                 for (int c = 0; c < 3; c++) rel[c] = Jl[3 * j + c] - Jl[3 * par + c];
@@ -493,7 +509,9 @@ extern "C" int vhap_frame_prep_fwd(const int64_t* timesteps, const float* shape,
     hipStream_t st = vhap_stream(stream);
     vhap_zero_async(terms, 6 * sizeof(float), st);
     VHAP_LAUNCH_CHECK();
-    frame_prep_fwd_kernel<<<Bp, FP_THREADS, 0, st>>>(cfg, in, coef, A, transl, Jrest, terms);
+    const bool flame_tree = J == 5 && parents[1] == 0 && parents[2] == 1 && parents[3] == 1 && parents[4] == 1;
+    if (flame_tree) frame_prep_fwd_kernel<5><<<Bp, FP_THREADS, 0, st>>>(cfg, in, coef, A, transl, Jrest, terms);
+    else frame_prep_fwd_kernel<0><<<Bp, FP_THREADS, 0, st>>>(cfg, in, coef, A, transl, Jrest, terms);
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;
 }
@@ -512,7 +530,9 @@ extern "C" int vhap_frame_prep_bwd(const int64_t* timesteps, const float* shape,
     if (!make_cfg(cfg, B, Bp, N, NS, NE, J, Kp, V, parents, weights)) return VHAP_E_BADDIM;
     FrameIn in{reinterpret_cast<const long long*>(timesteps), shape, expr, rotation, translation, neck, jaw, eyes, nullptr, JS, Jreg, static_offset};
     FrameGrad g{g_shape, g_expr, g_rotation, g_translation, g_neck, g_jaw, g_eyes, g_offset};
-    frame_prep_bwd_kernel<<<B, FP_THREADS, 0, vhap_stream(stream)>>>(cfg, in, Jrest, d_coef, d_A, d_transl, d_terms, g);
+    const bool flame_tree = J == 5 && parents[1] == 0 && parents[2] == 1 && parents[3] == 1 && parents[4] == 1;
+    if (flame_tree) frame_prep_bwd_kernel<5><<<B, FP_THREADS, 0, vhap_stream(stream)>>>(cfg, in, Jrest, d_coef, d_A, d_transl, d_terms, g);
+    else frame_prep_bwd_kernel<0><<<B, FP_THREADS, 0, vhap_stream(stream)>>>(cfg, in, Jrest, d_coef, d_A, d_transl, d_terms, g);
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;
 }

@@ -15,3 +15,7 @@ extern "C" const char* vhap_strerror(int code) {
         default: return "unknown error";
     }
 }
+
+// Profiling / A-B switches (not part of the stable ABI): 16 = strided row order in the rasteriser, 32 = per-pixel texture backward
+int vhap_g_debug_flags = 0;
+extern "C" void vhap_debug_set_flags(int flags) { vhap_g_debug_flags = flags; }

@@ -14,7 +14,12 @@
 
 namespace {
 
-constexpr int MAX_BLOCKS = 2048;  // grid-stride: one atomic per block and output -> at most 2048 same-address atomics
+// Reducing kernels: PB-thread workgroups, at most MAX_BLOCKS of them.  Every workgroup ends with ONE atomic per output;
+// same-address atomics serialise (~12 ns each, more under CAS retries), and all workgroups finish at about the same time,
+// so the chain length is what is paid: 2048 x 256 threads cost ~150 us of tail, 512 x 1024 threads ~6 us.
+constexpr int PB = 1024;
+constexpr int NW = PB / 64;
+constexpr int MAX_BLOCKS = 512;
 
 struct SH9 {
     float v[9];
@@ -50,11 +55,11 @@ struct ShadeParams {
 
 // stats (4 words): [0..1] = u64 (ordered-uint max of diffuse << 32 | number of entries equal to it), [2] = float sum over
 // pixels of var_channels(diffuse).  The tie count makes the backward of max() distribute evenly like torch's.
-__global__ __launch_bounds__(256) void shade_fwd_kernel(const ShadeParams P, float4* __restrict__ rgba,
+__global__ __launch_bounds__(PB) void shade_fwd_kernel(const ShadeParams P, float4* __restrict__ rgba,
                                                         unsigned* __restrict__ stats) {
     __shared__ float s_l[27], s_c[9];
-    __shared__ float red_var[4];
-    __shared__ unsigned long long red_max[4];
+    __shared__ float red_var[NW];
+    __shared__ unsigned long long red_max[NW];
     if (threadIdx.x < 27) s_l[threadIdx.x] = P.lights[threadIdx.x];
     if (threadIdx.x < 9) s_c[threadIdx.x] = P.sh_const[threadIdx.x];
     __syncthreads();
@@ -65,13 +70,10 @@ __global__ __launch_bounds__(256) void shade_fwd_kernel(const ShadeParams P, flo
         const unsigned ha = (unsigned)(a >> 32), hb = (unsigned)(b >> 32);
         return ha > hb ? a : (hb > ha ? b : a + (b & 0xffffffffull));
     };
-    const int rows = P.B * P.H, HW = P.H * P.W;
-    for (int row = blockIdx.x; row < rows; row += gridDim.x) {      // rows: (frame, y) are uniform per workgroup, no per-pixel division
-        const int bI = row / P.H, y = row - bI * P.H;
-        const float* bg_row = P.bg_image ? P.bg_image + (size_t)bI * 3 * HW + (size_t)(P.H - 1 - y) * P.W : nullptr;
-        for (int x = threadIdx.x; x < P.W; x += 256) {
-            const size_t pi = (size_t)row * P.W + x;
-            const float* nr = P.normal_raw + 3 * pi;
+    const unsigned npix = (unsigned)P.B * P.H * P.W, HW = (unsigned)P.H * P.W;     // < 2^31 (check_img): 32-bit index math only
+    for (unsigned pi = blockIdx.x * PB + threadIdx.x; pi < npix; pi += gridDim.x * PB) {
+        {
+            const float* nr = P.normal_raw + 3 * (size_t)pi;
             const float nx = nr[0], ny = nr[1], nz = nr[2];
             const float inv = 1.0f / sqrtf(fmaxf(nx * nx + ny * ny + nz * nz, 1e-20f));
             SH9 b;
@@ -91,10 +93,13 @@ __global__ __launch_bounds__(256) void shade_fwd_kernel(const ShadeParams P, flo
             const bool fg = P.rast[pi].w > 0.0f;
             float4 o;
             if (fg) {
-                const float* al = P.albedo + 3 * pi;
+                const float* al = P.albedo + 3 * (size_t)pi;
                 o = make_float4(al[0] * d[0], al[1] * d[1], al[2] * d[2], 1.0f);
-            } else if (bg_row) {
-                o = make_float4(bg_row[x], bg_row[HW + x], bg_row[2 * HW + x], 0.0f);
+            } else if (P.bg_image) {
+                const unsigned bI = pi / HW, rem = pi - bI * HW;
+                const unsigned y = rem / (unsigned)P.W, x = rem - y * (unsigned)P.W;
+                const float* g = P.bg_image + (size_t)bI * 3 * HW + (size_t)(P.H - 1 - y) * P.W + x;
+                o = make_float4(g[0], g[HW], g[2 * HW], 0.0f);
             } else {
                 o = make_float4(P.bg_r, P.bg_g, P.bg_b, 0.0f);
             }
@@ -113,8 +118,10 @@ __global__ __launch_bounds__(256) void shade_fwd_kernel(const ShadeParams P, flo
         if (lane == 0) { red_var[wave] = var; red_max[wave] = mx; }
         __syncthreads();
         if (threadIdx.x == 0) {
-            atomicAdd(reinterpret_cast<float*>(stats) + 2, red_var[0] + red_var[1] + red_var[2] + red_var[3]);
-            const unsigned long long m = merge(merge(red_max[0], red_max[1]), merge(red_max[2], red_max[3]));
+            float vs = 0.f;
+            unsigned long long m = 0ull;
+            for (int w = 0; w < NW; w++) { vs += red_var[w]; m = merge(m, red_max[w]); }
+            atomicAdd(reinterpret_cast<float*>(stats) + 2, vs);
             unsigned long long* g = reinterpret_cast<unsigned long long*>(stats);
             unsigned long long old = *reinterpret_cast<volatile unsigned long long*>(g);
             while (true) {   // (max, count) monoid: CAS loop, at most one per block
@@ -131,12 +138,12 @@ __global__ __launch_bounds__(256) void shade_fwd_kernel(const ShadeParams P, flo
 // lights only (the reference computes it on shade(normal.detach())):
 //   g_var = d_reg / npix  (coefficient of d var / d diffuse_c = diffuse_c - mean)
 //   g_max = d_reg if max(diffuse) > 1 else 0, applied where diffuse_c equals the max (stats[0]).
-__global__ __launch_bounds__(256) void shade_bwd_kernel(const ShadeParams P, const float4* __restrict__ d_rgba,
+__global__ __launch_bounds__(PB) void shade_bwd_kernel(const ShadeParams P, const float4* __restrict__ d_rgba,
                                                         const float* __restrict__ d_reg, const unsigned* __restrict__ stats,
                                                         float* __restrict__ d_albedo, float* __restrict__ d_normal_raw,
                                                         float* __restrict__ d_lights) {
     __shared__ float s_l[27], s_c[9];
-    __shared__ float red[4][27];
+    __shared__ float red[NW][27];
     if (threadIdx.x < 27) s_l[threadIdx.x] = P.lights[threadIdx.x];
     if (threadIdx.x < 9) s_c[threadIdx.x] = P.sh_const[threadIdx.x];
     __syncthreads();
@@ -154,7 +161,7 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(const ShadeParams P, con
         const unsigned u = (mx_ord & 0x80000000u) ? (mx_ord & 0x7fffffffu) : ~mx_ord;
         g_max = __uint_as_float(u) > 1.0f ? dr / (float)max(ties, 1u) : 0.f;   // evenly among ties, like torch.max()
     }
-    for (size_t pi = (size_t)blockIdx.x * 256 + threadIdx.x; pi < (size_t)npix; pi += (size_t)gridDim.x * 256) {
+    for (size_t pi = (size_t)blockIdx.x * PB + threadIdx.x; pi < (size_t)npix; pi += (size_t)gridDim.x * PB) {
         const float* nr = P.normal_raw + 3 * pi;
         const float rx = nr[0], ry = nr[1], rz = nr[2];
         const float l2 = rx * rx + ry * ry + rz * rz;
@@ -221,7 +228,8 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(const ShadeParams P, con
         }
         __syncthreads();
         if (threadIdx.x < 27) {
-            const float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+            float s = 0.f;
+            for (int w = 0; w < NW; w++) s += red[w][threadIdx.x];
             if (s != 0.f) atomicAdd(&d_lights[threadIdx.x], s);
         }
     }
@@ -229,19 +237,18 @@ __global__ __launch_bounds__(256) void shade_bwd_kernel(const ShadeParams P, con
 
 // pred rgba [B,H,W,4] (renderer space, row 0 = bottom) vs gt [B,3,H,W] (image space).
 // out[0] += sum |gt - pred_rgb|, out[1] += #(alpha > 0) (as float, exact below 2^24 per block partial)
-__global__ __launch_bounds__(256) void photo_fwd_kernel(const float4* __restrict__ pred, const float* __restrict__ gt, int B, int H,
+__global__ __launch_bounds__(PB) void photo_fwd_kernel(const float4* __restrict__ pred, const float* __restrict__ gt, int B, int H,
                                                         int W, float* __restrict__ out) {
-    __shared__ float rs[4], rn[4];
+    __shared__ float rs[NW], rn[NW];
     float s = 0.f, n = 0.f;
-    const int rows = B * H, HW = H * W;
-    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
-        const int b = row / H, y = row - b * H;
-        const float* g = gt + (size_t)b * 3 * HW + (size_t)(H - 1 - y) * W;
-        for (int x = threadIdx.x; x < W; x += 256) {
-            const float4 p = pred[(size_t)row * W + x];
-            s += fabsf(g[x] - p.x) + fabsf(g[HW + x] - p.y) + fabsf(g[2 * HW + x] - p.z);
-            n += p.w > 0.0f ? 1.0f : 0.0f;
-        }
+    const unsigned npix = (unsigned)B * H * W, HW = (unsigned)H * W;
+    for (unsigned pi = blockIdx.x * PB + threadIdx.x; pi < npix; pi += gridDim.x * PB) {
+        const unsigned b = pi / HW, rem = pi - b * HW;
+        const unsigned y = rem / (unsigned)W, x = rem - y * (unsigned)W;
+        const float* g = gt + (size_t)b * 3 * HW + (size_t)(H - 1 - y) * W + x;
+        const float4 p = pred[pi];
+        s += fabsf(g[0] - p.x) + fabsf(g[HW] - p.y) + fabsf(g[2 * HW] - p.z);
+        n += p.w > 0.0f ? 1.0f : 0.0f;
     }
     s = vhap_wave_sum(s);
     n = vhap_wave_sum(n);
@@ -249,8 +256,10 @@ __global__ __launch_bounds__(256) void photo_fwd_kernel(const float4* __restrict
     if (lane == 0) { rs[wave] = s; rn[wave] = n; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        atomicAdd(&out[0], rs[0] + rs[1] + rs[2] + rs[3]);
-        atomicAdd(&out[1], rn[0] + rn[1] + rn[2] + rn[3]);
+        float a = 0.f, c = 0.f;
+        for (int w = 0; w < NW; w++) { a += rs[w]; c += rn[w]; }
+        atomicAdd(&out[0], a);
+        atomicAdd(&out[1], c);
     }
 }
 
@@ -290,7 +299,7 @@ extern "C" int vhap_shade_fwd(const float* normal_raw, const float* albedo, cons
     hipStream_t st = vhap_stream(stream);
     if (stats) { vhap_zero_async(stats, 16, st); VHAP_LAUNCH_CHECK(); }
     const long long npix = (long long)B * H * W;
-    shade_fwd_kernel<<<min(vhap_cdiv(npix, 256), MAX_BLOCKS), 256, 0, st>>>(P, reinterpret_cast<float4*>(rgba), reinterpret_cast<unsigned*>(stats));
+    shade_fwd_kernel<<<min(vhap_cdiv(npix, PB), MAX_BLOCKS), PB, 0, st>>>(P, reinterpret_cast<float4*>(rgba), reinterpret_cast<unsigned*>(stats));
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;
 }
@@ -303,7 +312,7 @@ extern "C" int vhap_shade_bwd(const float* normal_raw, const float* albedo, cons
     if (int e = check_img(B, H, W)) return e;
     ShadeParams P{normal_raw, albedo, reinterpret_cast<const float4*>(rast), nullptr, 0.f, 0.f, 0.f, lights, sh_const, B, H, W};
     const long long npix = (long long)B * H * W;
-    shade_bwd_kernel<<<min(vhap_cdiv(npix, 256), MAX_BLOCKS), 256, 0, vhap_stream(stream)>>>(
+    shade_bwd_kernel<<<min(vhap_cdiv(npix, PB), MAX_BLOCKS), PB, 0, vhap_stream(stream)>>>(
         P, reinterpret_cast<const float4*>(d_rgba), d_reg, reinterpret_cast<const unsigned*>(stats), d_albedo, d_normal_raw, d_lights);
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;
@@ -318,7 +327,7 @@ extern "C" int vhap_photo_fwd(const float* pred_rgba, const float* gt_nchw, int 
     vhap_zero_async(out2, 8, st);
     VHAP_LAUNCH_CHECK();
     const long long npix = (long long)B * H * W;
-    photo_fwd_kernel<<<min(vhap_cdiv(npix, 256), MAX_BLOCKS), 256, 0, st>>>(reinterpret_cast<const float4*>(pred_rgba), gt_nchw, B, H, W, out2);
+    photo_fwd_kernel<<<min(vhap_cdiv(npix, PB), MAX_BLOCKS), PB, 0, st>>>(reinterpret_cast<const float4*>(pred_rgba), gt_nchw, B, H, W, out2);
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;
 }

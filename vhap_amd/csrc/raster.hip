@@ -446,7 +446,6 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterParams P) {
     }
 }
 
-int g_debug_flags = 0;
 
 struct WsLayout {
     size_t hdr, counts, cursors, offsets, trange, records, list, total;
@@ -522,7 +521,7 @@ int launch_raster(RasterParams P, void* ws, size_t ws_bytes, size_t cap, int fla
         auto gcd = [](int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; };
         while (m > 1 && gcd(m, P.nby) != 1) m -= 2;
         P.row_mul = m < 1 ? 1 : m;
-        if (!(g_debug_flags & 16)) P.row_mul = 1;   // A/B switch (profiling): strided row order off by default
+        if (!(vhap_g_debug_flags & 16)) P.row_mul = 1;   // A/B switch (profiling): strided row order off by default
     }
     P.offsets = offsets;
     P.list = list;
@@ -530,7 +529,7 @@ int launch_raster(RasterParams P, void* ws, size_t ws_bytes, size_t cap, int fla
     P.records = records;
     P.hdr = hdr;
     P.capacity = (unsigned)cap;
-    P.debug = g_debug_flags;
+    P.debug = vhap_g_debug_flags;
     raster_kernel<INTERP><<<B * P.nwx * P.nby, 256, 0, st>>>(P);
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;
@@ -538,7 +537,6 @@ int launch_raster(RasterParams P, void* ws, size_t ws_bytes, size_t cap, int fla
 
 }  // namespace
 
-extern "C" void vhap_debug_set_flags(int flags) { g_debug_flags = flags; }
 
 extern "C" size_t vhap_raster_workspace_bytes(int B, int F, int H, int W, size_t pair_capacity) {
     if (check_dims(B, 1, F, H, W) != VHAP_OK) return 0;

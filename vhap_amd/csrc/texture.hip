@@ -282,6 +282,177 @@ __global__ __launch_bounds__(256) void texture_bwd_kernel(const float* __restric
     if (d_uv_da) d_uv_da[pi] = gda;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Tiled backward: a workgroup owns a 16x16 pixel tile.  Neighbouring pixels hit the same texels (every texel of a level
+// sampled near 1 texel/pixel receives ~4 bilinear taps), and device-scope float atomics to HBM-resident memory are the
+// bottleneck of the per-pixel kernel (24 per covered pixel).  The tile therefore accumulates its taps in an LDS hash
+// table keyed by (level, texel) -- LDS float atomics -- and flushes every touched texel ONCE: ~3x fewer global atomics.
+// Probing is bounded; a tap that finds no slot goes straight to global memory, so the result never depends on the table.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int TT = 16;            // tile edge (pixels)
+constexpr int NSLOT = 2048;       // hash slots per tile
+constexpr unsigned EMPTY_KEY = 0xffffffffu;
+
+template <int C>
+struct TileAcc {
+    unsigned* keys;
+    float* vals;
+    float* d_tex;
+    float* d_mips;
+    const TexDesc* D;
+    int tb;
+    __device__ __forceinline__ void add(int level, int texelC, const float (&v)[C]) const {
+        const unsigned key = ((unsigned)level << 27) | (unsigned)(texelC / C);
+        unsigned slot = (key * 2654435761u) >> 21;          // 11 bits
+#pragma unroll 1
+        for (int probe = 0; probe < 8; probe++) {
+            const unsigned prev = atomicCAS(&keys[slot], EMPTY_KEY, key);
+            if (prev == EMPTY_KEY || prev == key) {
+#pragma unroll
+                for (int k = 0; k < C; k++)
+                    if (v[k] != 0.f) atomicAdd(&vals[slot * C + k], v[k]);
+                return;
+            }
+            slot = (slot + 1) & (NSLOT - 1);
+        }
+        float* G = level_ptr_w(d_tex, d_mips, *D, tb, level);
+#pragma unroll
+        for (int k = 0; k < C; k++)
+            if (v[k] != 0.f) atomicAdd(&G[texelC + k], v[k]);
+    }
+};
+
+template <int C>
+__device__ __forceinline__ void bilinear_bwd_tile(const float* __restrict__ T, const TileAcc<C>* acc, int level, const Taps& t,
+                                                  const float (&g)[C], float wgt, float& gfx, float& gfy, float (&val)[C]) {
+    gfx = 0.f;
+    gfy = 0.f;
+    const float w00 = (1.f - t.fx) * (1.f - t.fy), w10 = t.fx * (1.f - t.fy), w01 = (1.f - t.fx) * t.fy, w11 = t.fx * t.fy;
+    float gk[C];
+#pragma unroll
+    for (int k = 0; k < C; k++) {
+        const float a00 = T[t.i00 + k], a10 = T[t.i10 + k], a01 = T[t.i01 + k], a11 = T[t.i11 + k];
+        const float top = a00 + t.fx * (a10 - a00), bot = a01 + t.fx * (a11 - a01);
+        val[k] = top + t.fy * (bot - top);
+        gk[k] = g[k] * wgt;
+        gfx += gk[k] * ((1.f - t.fy) * (a10 - a00) + t.fy * (a11 - a01));
+        gfy += gk[k] * (bot - top);
+    }
+    if (acc) {
+        float v[C];
+#pragma unroll
+        for (int k = 0; k < C; k++) v[k] = w00 * gk[k];
+        acc->add(level, t.i00, v);
+#pragma unroll
+        for (int k = 0; k < C; k++) v[k] = w10 * gk[k];
+        acc->add(level, t.i10, v);
+#pragma unroll
+        for (int k = 0; k < C; k++) v[k] = w01 * gk[k];
+        acc->add(level, t.i01, v);
+#pragma unroll
+        for (int k = 0; k < C; k++) v[k] = w11 * gk[k];
+        acc->add(level, t.i11, v);
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(TT * TT) void texture_bwd_tiled_kernel(const float* __restrict__ tex, const float* __restrict__ mips,
+                                                                    const TexDesc D, const float2* __restrict__ uv,
+                                                                    const float4* __restrict__ uv_da, const float* __restrict__ d_out,
+                                                                    int H, int W, float* __restrict__ d_tex, float* __restrict__ d_mips,
+                                                                    float2* __restrict__ d_uv, float4* __restrict__ d_uv_da) {
+    __shared__ unsigned keys[NSLOT];
+    __shared__ float vals[NSLOT * C];
+    const int tid = threadIdx.x;
+    const int px = blockIdx.x * TT + (tid & (TT - 1)), py = blockIdx.y * TT + (tid >> 4), b = blockIdx.z;
+    const bool inside = px < W && py < H;
+    const size_t pi = ((size_t)b * H + (inside ? py : 0)) * W + (inside ? px : 0);
+    const int tb = D.TB == 1 ? 0 : b;
+    float g[C];
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < C; k++) {
+        g[k] = inside ? d_out[pi * C + k] : 0.f;
+        any = any || g[k] != 0.f;
+    }
+    const bool tile_any = __syncthreads_or(any ? 1 : 0) != 0;
+    if (!tile_any) {          // background tile: nothing to accumulate
+        if (inside) {
+            if (d_uv) d_uv[pi] = make_float2(0.f, 0.f);
+            if (d_uv_da) d_uv_da[pi] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return;
+    }
+    const bool want_tex = d_tex != nullptr;
+    if (want_tex) {
+        for (int i = tid; i < NSLOT; i += TT * TT) keys[i] = EMPTY_KEY;
+        for (int i = tid; i < NSLOT * C; i += TT * TT) vals[i] = 0.f;
+    }
+    __syncthreads();
+    const TileAcc<C> accv{keys, vals, d_tex, d_mips, &D, tb};
+    const TileAcc<C>* acc = want_tex ? &accv : nullptr;
+    float2 guv = make_float2(0.f, 0.f);
+    float4 gda = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (any) {
+        const float2 c = uv[pi];
+        if (uv_da == nullptr) {
+            const Taps t = make_taps(c.x, c.y, D.W, D.H, C);
+            float gfx, gfy, val[C];
+            bilinear_bwd_tile<C>(level_ptr(tex, mips, D, tb, 0), acc, 0, t, g, 1.0f, gfx, gfy, val);
+            guv.x = gfx * (float)D.W;
+            guv.y = gfy * (float)D.H;
+        } else {
+            const LevelSel s = select_level(uv_da[pi], D.W, D.H, D.L);
+            const int w0 = D.W >> s.l0, h0 = D.H >> s.l0;
+            const Taps t0 = make_taps(c.x, c.y, w0, h0, C);
+            const bool two = s.two && s.f > 0.0f;
+            float gfx0, gfy0, c0[C];
+            bilinear_bwd_tile<C>(level_ptr(tex, mips, D, tb, s.l0), acc, s.l0, t0, g, two ? 1.0f - s.f : 1.0f, gfx0, gfy0, c0);
+            guv.x = gfx0 * (float)w0;
+            guv.y = gfy0 * (float)h0;
+            if (two) {
+                const int w1 = D.W >> (s.l0 + 1), h1 = D.H >> (s.l0 + 1);
+                const Taps t1 = make_taps(c.x, c.y, w1, h1, C);
+                float gfx1, gfy1, c1[C];
+                bilinear_bwd_tile<C>(level_ptr(tex, mips, D, tb, s.l0 + 1), acc, s.l0 + 1, t1, g, s.f, gfx1, gfy1, c1);
+                guv.x += gfx1 * (float)w1;
+                guv.y += gfy1 * (float)h1;
+                if (s.diff && d_uv_da) {
+                    float gf = 0.f;
+#pragma unroll
+                    for (int k = 0; k < C; k++) gf += g[k] * (c1[k] - c0[k]);
+                    const float glam = gf * 0.5f / (s.lambda * 0.69314718056f);
+                    const float q = s.l2n_sqrt > 0.f ? 0.5f / s.l2n_sqrt : 0.f;
+                    const float gl2n = glam * q;
+                    const float gA = 0.5f * glam + gl2n * 0.5f * (s.A - s.B);
+                    const float gB = 0.5f * glam - gl2n * 0.5f * (s.A - s.B);
+                    const float gC = gl2n * 2.0f * s.Cq;
+                    const float gsx = 2.f * s.sx * gA + s.sy * gC, gsy = 2.f * s.sy * gB + s.sx * gC;
+                    const float gtx = 2.f * s.tx * gA + s.ty * gC, gty = 2.f * s.ty * gB + s.tx * gC;
+                    gda = make_float4(gsx * (float)D.W, gsy * (float)D.W, gtx * (float)D.H, gty * (float)D.H);
+                }
+            }
+        }
+    }
+    if (inside) {
+        if (d_uv) d_uv[pi] = guv;
+        if (d_uv_da) d_uv_da[pi] = gda;
+    }
+    if (!want_tex) return;
+    __syncthreads();
+    for (int sidx = tid; sidx < NSLOT; sidx += TT * TT) {
+        const unsigned key = keys[sidx];
+        if (key == EMPTY_KEY) continue;
+        const int level = (int)(key >> 27);
+        float* G = level_ptr_w(d_tex, d_mips, D, tb, level) + (size_t)(key & 0x7ffffffu) * C;
+#pragma unroll
+        for (int k = 0; k < C; k++) {
+            const float v = vals[sidx * C + k];
+            if (v != 0.f) atomicAdd(&G[k], v);
+        }
+    }
+}
+
 template <typename F>
 int dispatch_C(int C, F&& f) {
     switch (C) {
@@ -370,6 +541,16 @@ extern "C" int vhap_texture_bwd(const float* tex, const float* mips, int TB, int
     const TexDesc D = make_desc(TB, Ht, Wt, C);
     if (uv_da && D.L > 0 && (!mips || (d_tex && !d_mips))) return VHAP_E_NULLPTR;
     const long long npix = (long long)B * H * W;
+    const bool tiled = !(vhap_g_debug_flags & 32) && (long long)Ht * Wt < (1ll << 27);      // (flag 32: A/B switch to the per-pixel kernel)
+    if (tiled) {
+        return dispatch_C(C, [&](auto c) {
+            texture_bwd_tiled_kernel<decltype(c)::value><<<dim3(vhap_cdiv(W, TT), vhap_cdiv(H, TT), B), TT * TT, 0, vhap_stream(stream)>>>(
+                tex, mips, D, reinterpret_cast<const float2*>(uv), reinterpret_cast<const float4*>(uv_da), d_out, H, W, d_tex, d_mips,
+                reinterpret_cast<float2*>(d_uv), reinterpret_cast<float4*>(d_uv_da));
+            VHAP_LAUNCH_CHECK();
+            return VHAP_OK;
+        });
+    }
     return dispatch_C(C, [&](auto c) {
         texture_bwd_kernel<decltype(c)::value><<<vhap_cdiv(npix, 256), 256, 0, vhap_stream(stream)>>>(
             tex, mips, D, reinterpret_cast<const float2*>(uv), reinterpret_cast<const float4*>(uv_da), d_out, npix, H * W, d_tex,
