@@ -34,7 +34,7 @@ SIGNATURES = {
     "vhap_texture_mip_build": (c_i, [c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp]),
     "vhap_texture_fwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp]),
     "vhap_texture_bwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_i] + [c_fp] * 5),
-    "vhap_texture_mip_fold": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp]),
+    "vhap_texture_mip_fold": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "vhap_antialias_work_ints": (c_sz, [c_i] * 3),
     "vhap_antialias_fwd": (c_i, [c_fp] * 5 + [c_i] * 6 + [c_fp, c_fp, c_fp]),
     "vhap_antialias_bwd": (c_i, [c_fp] * 8 + [c_i] * 6 + [c_fp, c_fp, c_fp]),
@@ -62,7 +62,7 @@ SIGNATURES = {
     "vhap_offset_reg_fwd": (c_i, [c_fp] * 8 + [c_i, c_i, c_f, c_f, c_f, c_fp, c_fp]),
     "vhap_offset_reg_bwd": (c_i, [c_fp] * 8 + [c_i, c_i, c_f, c_f, c_f, c_fp, c_fp, c_fp]),
     "vhap_tex_prep_fwd": (c_i, [c_fp] * 3 + [c_i, c_f, c_f] + [c_fp] * 3),
-    "vhap_tex_prep_bwd": (c_i, [c_fp] * 5 + [c_i, c_f, c_f] + [c_fp] * 2),
+    "vhap_tex_prep_bwd": (c_i, [c_fp] * 6 + [c_i, c_f, c_f] + [c_fp] * 2),
     "vhap_adam_step": (c_i, [c_i] + [c_fp] * 8 + [c_f, c_f, c_f, c_fp]),
 }
 

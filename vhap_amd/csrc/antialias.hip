@@ -120,36 +120,52 @@ __global__ __launch_bounds__(256) void aa_fwd_kernel(const float* __restrict__ c
                                                      const float4* __restrict__ pos, const int* __restrict__ tri,
                                                      const int* __restrict__ opp, int B, int H, int W, int V, int F,
                                                      float* __restrict__ out, int* __restrict__ work) {
-    const long long pi = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long npix = (long long)B * H * W;
-    if (pi >= npix) return;
-    const int HW = H * W;
-    const int b = (int)(pi / HW);
-    const int rem = (int)(pi - (long long)b * HW);
-    const int py = rem / W, px = rem - py * W;
-    const float4 r0 = rast[pi];
+    const unsigned npix = (unsigned)B * H * W;             // < 2^31 (checked by the entry point): 32-bit index math
+    const unsigned pi = blockIdx.x * 256u + threadIdx.x;
+    const bool live = pi < npix;
+    const unsigned HW = (unsigned)H * W;
+    const unsigned b = live ? pi / HW : 0u;
+    const unsigned rem = pi - b * HW;
+    const int py = (int)(rem / (unsigned)W), px = (int)(rem - (unsigned)py * W);
+    const float4 r0 = live ? rast[pi] : make_float4(0.f, 0.f, 0.f, 0.f);
     const int t0 = (int)r0.w - 1;
     const float4* P = pos + (size_t)b * V;
+    const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int d = 0; d < 2; d++) {
-        if (d == 0 ? px + 1 >= W : py + 1 >= H) continue;
-        const long long pj = pi + (d == 0 ? 1 : W);
-        const float4 r1 = rast[pj];
-        const int t1 = (int)r1.w - 1;
-        if (t0 == t1) continue;
-        if (t0 >= F || t1 >= F) continue;
-        const Geo g = analyse(P, tri, opp, t0, t1, r0.z, r1.z, px, py, d, H, W);
-        if (!g.ok) continue;
-        const float dc = fminf(fmaxf(g.dc_raw, 0.0f), 1.0f);
-        const float alpha = g.ds * (0.5f - dc);
-        const float* c0 = color + (size_t)pi * C;
-        const float* c1 = color + (size_t)pj * C;
-        float* o = out + (size_t)(alpha > 0.0f ? pi : pj) * C;
+        // every lane reaches the ballot below: silhouette pairs are appended to the work list with ONE atomic per wave
+        bool need = false;
+        Geo g;
+        float alpha = 0.f;
+        unsigned pj = pi;
+        if (live && !(d == 0 ? px + 1 >= W : py + 1 >= H)) {
+            pj = pi + (d == 0 ? 1u : (unsigned)W);
+            const float4 r1 = rast[pj];
+            const int t1 = (int)r1.w - 1;
+            if (t0 != t1 && t0 < F && t1 < F) {
+                g = analyse(P, tri, opp, t0, t1, r0.z, r1.z, px, py, d, H, W);
+                if (g.ok) {
+                    const float dc = fminf(fmaxf(g.dc_raw, 0.0f), 1.0f);
+                    alpha = g.ds * (0.5f - dc);
+                    need = true;
+                }
+            }
+        }
+        const unsigned long long m = __ballot(need);
+        if (m == 0ull) continue;
+        int base = 0;
+        if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&work[0], __popcll(m));
+        base = __shfl(base, __ffsll((long long)m) - 1, 64);
+        if (need) {
+            const float* c0 = color + (size_t)pi * C;
+            const float* c1 = color + (size_t)pj * C;
+            float* o = out + (size_t)(alpha > 0.0f ? pi : pj) * C;
 #pragma unroll
-        for (int k = 0; k < C; k++) atomicAdd(&o[k], alpha * (c1[k] - c0[k]));
-        const int slot = atomicAdd(&work[0], 1);
-        int4 item = make_int4((int)pi, d | (g.ds < 0.f ? 2 : 0) | (g.di << 2), __float_as_int(alpha), b);
-        reinterpret_cast<int4*>(work + 4)[slot] = item;
+            for (int k = 0; k < C; k++) atomicAdd(&o[k], alpha * (c1[k] - c0[k]));
+            const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+            const int4 item = make_int4((int)pi, d | (g.ds < 0.f ? 2 : 0) | (g.di << 2), __float_as_int(alpha), (int)b);
+            reinterpret_cast<int4*>(work + 4)[slot] = item;
+        }
     }
 }
 

@@ -363,6 +363,162 @@ __global__ __launch_bounds__(256) void gbuffer_bwd_kernel(const float4* __restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Pixel-parallel variant with LDS aggregation.  A workgroup owns a 16x16 pixel tile of one frame; every covered pixel runs
+// the same chain as above for ITS triangle and adds the 18 vertex contributions into an LDS hash table keyed by vertex id
+// (LDS float atomics: a tile touches only a few dozen vertices).  The table is flushed with one global atomic per touched
+// vertex component, ~20x fewer than a plain per-pixel kernel, and no lane ever walks pixels it does not own -- the
+// triangle-parallel kernel above spends most of its time on bounding-box pixels won by other triangles.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int GT = 16;          // tile edge
+constexpr int GSLOT = 512;      // hash slots (vertices) per tile
+constexpr unsigned GEMPTY = 0xffffffffu;
+
+__global__ __launch_bounds__(GT * GT) void gbuffer_bwd_tiled_kernel(const float4* __restrict__ pos, const int* __restrict__ tri,
+                                                                    const float* __restrict__ vnormal, const float2* __restrict__ uv,
+                                                                    const int* __restrict__ tri_uv, const float4* __restrict__ rast,
+                                                                    const float* __restrict__ d_normal, const float2* __restrict__ d_texc,
+                                                                    const float4* __restrict__ d_texd, const float4* __restrict__ d_rast,
+                                                                    const float4* __restrict__ d_db, const unsigned char* __restrict__ uv_nograd,
+                                                                    int V, int F, int H, int W, float* __restrict__ d_pos,
+                                                                    float* __restrict__ d_vnormal) {
+    __shared__ unsigned keys[GSLOT];
+    __shared__ float vals[GSLOT * 6];     // [0..2] = d_pos x, y, w ; [3..5] = d_vnormal
+    const int tid = threadIdx.x;
+    const int px = blockIdx.x * GT + (tid & (GT - 1)), py = blockIdx.y * GT + (tid >> 4), b = blockIdx.z;
+    const bool inside = px < W && py < H;
+    const size_t pi = ((size_t)b * H + (inside ? py : 0)) * W + (inside ? px : 0);
+    const float4 r = inside ? rast[pi] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int t = (int)r.w - 1;
+    const bool cov = inside && t >= 0 && t < F;
+    if (__syncthreads_or(cov ? 1 : 0) == 0) return;       // background tile
+    for (int i = tid; i < GSLOT; i += GT * GT) keys[i] = GEMPTY;
+    for (int i = tid; i < GSLOT * 6; i += GT * GT) vals[i] = 0.f;
+    __syncthreads();
+    if (cov) {
+        const int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
+        if ((unsigned)i0 < (unsigned)V && (unsigned)i1 < (unsigned)V && (unsigned)i2 < (unsigned)V) {
+            const float4* P = pos + (size_t)b * V;
+            const float4 p0 = P[i0], p1 = P[i1], p2 = P[i2];
+            const float xs = 2.0f / (float)W, xo = 1.0f / (float)W - 1.0f;
+            const float ys = 2.0f / (float)H, yo = 1.0f / (float)H - 1.0f;
+            float acc[18];
+#pragma unroll
+            for (int k = 0; k < 18; k++) acc[k] = 0.f;
+            const float b0 = r.x, b1 = r.y, b2 = (1.0f - b0) - b1;
+            float g0 = 0.f, g1 = 0.f;
+            float4 gd = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (d_rast) { const float4 q = d_rast[pi]; g0 = q.x; g1 = q.y; }
+            if (d_db) gd = d_db[pi];
+            if (d_normal && vnormal) {
+                const float* N = vnormal + (size_t)b * V * 3;
+                const float* gn = d_normal + 3 * pi;
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const float v = gn[c];
+                    const float n2 = N[3 * i2 + c];
+                    acc[9 + c] = b0 * v; acc[12 + c] = b1 * v; acc[15 + c] = b2 * v;
+                    g0 += v * (N[3 * i0 + c] - n2); g1 += v * (N[3 * i1 + c] - n2);
+                }
+            }
+            if (uv && (d_texc || d_texd)) {
+                const float2 u0 = uv[tri_uv[3 * t]], u1 = uv[tri_uv[3 * t + 1]], u2 = uv[tri_uv[3 * t + 2]];
+                const float2 e0 = make_float2(u0.x - u2.x, u0.y - u2.y), e1 = make_float2(u1.x - u2.x, u1.y - u2.y);
+                if (d_texc && !(uv_nograd && uv_nograd[t])) {
+                    const float2 gt = d_texc[pi];
+                    g0 += gt.x * e0.x + gt.y * e0.y;
+                    g1 += gt.x * e1.x + gt.y * e1.y;
+                }
+                if (d_texd) {
+                    const float4 q = d_texd[pi];
+                    gd.x += q.x * e0.x + q.z * e0.y; gd.z += q.x * e1.x + q.z * e1.y;
+                    gd.y += q.y * e0.x + q.w * e0.y; gd.w += q.y * e1.x + q.w * e1.y;
+                }
+            }
+            const float X0 = p2.y * p1.w - p1.y * p2.w, Y0 = p1.x * p2.w - p2.x * p1.w;
+            const float X1 = p0.y * p2.w - p2.y * p0.w, Y1 = p2.x * p0.w - p0.x * p2.w;
+            const float X2 = p1.y * p0.w - p0.y * p1.w, Y2 = p0.x * p1.w - p1.x * p0.w;
+            const float Tx = X0 + X1 + X2, Ty = Y0 + Y1 + Y2;
+            const float fx = xs * (float)px + xo, fy = ys * (float)py + yo;
+            const float p0x = p0.x - fx * p0.w, p0y = p0.y - fy * p0.w;
+            const float p1x = p1.x - fx * p1.w, p1y = p1.y - fy * p1.w;
+            const float p2x = p2.x - fx * p2.w, p2y = p2.y - fy * p2.w;
+            const float a0 = p1x * p2y - p1y * p2x, a1 = p2x * p0y - p2y * p0x, a2 = p0x * p1y - p0y * p1x;
+            const float at = a0 + a1 + a2;
+            if (fabsf(at) > 0.0f) {
+                const float iw = 1.0f / at;
+                const float r0 = a0 * iw, r1 = a1 * iw;
+                float G0 = g0 + xs * iw * Tx * gd.x + ys * iw * Ty * gd.y;
+                float G1 = g1 + xs * iw * Tx * gd.z + ys * iw * Ty * gd.w;
+                if (!(r0 >= 0.0f && r0 <= 1.0f)) G0 = 0.0f;
+                if (!(r1 >= 0.0f && r1 <= 1.0f)) G1 = 0.0f;
+                const float giw = xs * (b0 * Tx - X0) * gd.x + ys * (b0 * Ty - Y0) * gd.y + xs * (b1 * Tx - X1) * gd.z +
+                                  ys * (b1 * Ty - Y1) * gd.w;
+                const float sg = G0 * r0 + G1 * r1;
+                const float gat = -iw * iw * giw;
+                const float ga0 = (G0 - sg) * iw + gat, ga1 = (G1 - sg) * iw + gat, ga2 = (-sg) * iw + gat;
+                const float gp0x = -p2y * ga1 + p1y * ga2, gp0y = p2x * ga1 - p1x * ga2;
+                const float gp1x = p2y * ga0 - p0y * ga2, gp1y = -p2x * ga0 + p0x * ga2;
+                const float gp2x = -p1y * ga0 + p0y * ga1, gp2y = p1x * ga0 - p0x * ga1;
+                acc[0] += gp0x; acc[1] += gp0y; acc[2] += -fx * gp0x - fy * gp0y;
+                acc[3] += gp1x; acc[4] += gp1y; acc[5] += -fx * gp1x - fy * gp1y;
+                acc[6] += gp2x; acc[7] += gp2y; acc[8] += -fx * gp2x - fy * gp2y;
+                const float cx = xs * iw, cy = ys * iw;
+                const float sxg = b0 * gd.x + b1 * gd.z, syg = b0 * gd.y + b1 * gd.w;
+                const float gX0 = cx * (sxg - gd.x), gX1 = cx * (sxg - gd.z), gX2 = cx * sxg;
+                const float gY0 = cy * (syg - gd.y), gY1 = cy * (syg - gd.w), gY2 = cy * syg;
+                acc[7] += p1.w * gX0; acc[5] += p2.y * gX0; acc[4] -= p2.w * gX0; acc[8] -= p1.y * gX0;
+                acc[1] += p2.w * gX1; acc[8] += p0.y * gX1; acc[7] -= p0.w * gX1; acc[2] -= p2.y * gX1;
+                acc[4] += p0.w * gX2; acc[2] += p1.y * gX2; acc[1] -= p1.w * gX2; acc[5] -= p0.y * gX2;
+                acc[3] += p2.w * gY0; acc[8] += p1.x * gY0; acc[6] -= p1.w * gY0; acc[5] -= p2.x * gY0;
+                acc[6] += p0.w * gY1; acc[2] += p2.x * gY1; acc[0] -= p2.w * gY1; acc[8] -= p0.x * gY1;
+                acc[0] += p1.w * gY2; acc[5] += p0.x * gY2; acc[3] -= p0.w * gY2; acc[2] -= p1.x * gY2;
+            }
+            // three vertices -> LDS table (bounded probing; overflow goes straight to global memory)
+#pragma unroll
+            for (int vtx = 0; vtx < 3; vtx++) {
+                const int vi = vtx == 0 ? i0 : (vtx == 1 ? i1 : i2);
+                unsigned slot = ((unsigned)vi * 2654435761u) >> 23;     // 9 bits
+                bool done = false;
+#pragma unroll 1
+                for (int probe = 0; probe < 8 && !done; probe++) {
+                    const unsigned prev = atomicCAS(&keys[slot], GEMPTY, (unsigned)vi);
+                    if (prev == GEMPTY || prev == (unsigned)vi) {
+#pragma unroll
+                        for (int c = 0; c < 3; c++) {
+                            const float vp = acc[3 * vtx + c], vn = acc[9 + 3 * vtx + c];
+                            if (vp != 0.f) atomicAdd(&vals[slot * 6 + c], vp);
+                            if (vn != 0.f) atomicAdd(&vals[slot * 6 + 3 + c], vn);
+                        }
+                        done = true;
+                    } else {
+                        slot = (slot + 1) & (GSLOT - 1);
+                    }
+                }
+                if (!done) {
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        const float vp = acc[3 * vtx + c], vn = acc[9 + 3 * vtx + c];
+                        if (d_pos && vp != 0.f) atomicAdd(&d_pos[((size_t)b * V + vi) * 4 + (c == 2 ? 3 : c)], vp);
+                        if (d_vnormal && vn != 0.f) atomicAdd(&d_vnormal[((size_t)b * V + vi) * 3 + c], vn);
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    for (int sidx = tid; sidx < GSLOT; sidx += GT * GT) {
+        const unsigned vi = keys[sidx];
+        if (vi == GEMPTY) continue;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float vp = vals[sidx * 6 + c], vn = vals[sidx * 6 + 3 + c];
+            if (d_pos && vp != 0.f) atomicAdd(&d_pos[((size_t)b * V + vi) * 4 + (c == 2 ? 3 : c)], vp);
+            if (d_vnormal && vn != 0.f) atomicAdd(&d_vnormal[((size_t)b * V + vi) * 3 + c], vn);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int vhap_gbuffer_bwd(const float* pos, const int32_t* tri, const float* vnormal, const float* uv, const int32_t* tri_uv,
@@ -373,6 +529,14 @@ extern "C" int vhap_gbuffer_bwd(const float* pos, const int32_t* tri, const floa
     if (!pos || !tri || !rast) return VHAP_E_NULLPTR;
     if ((d_normal && !vnormal) || ((d_texc || d_texd) && (!uv || !tri_uv))) return VHAP_E_NULLPTR;
     if (B <= 0 || V <= 0 || F <= 0 || H <= 0 || W <= 0 || (long long)B * F >= (1ll << 31)) return VHAP_E_BADDIM;
+    if (!(vhap_g_debug_flags & 64)) {          // (flag 64: A/B switch to the triangle-parallel kernel)
+        gbuffer_bwd_tiled_kernel<<<dim3(vhap_cdiv(W, GT), vhap_cdiv(H, GT), B), GT * GT, 0, vhap_stream(stream)>>>(
+            reinterpret_cast<const float4*>(pos), tri, vnormal, reinterpret_cast<const float2*>(uv), tri_uv,
+            reinterpret_cast<const float4*>(rast), d_normal, reinterpret_cast<const float2*>(d_texc), reinterpret_cast<const float4*>(d_texd),
+            reinterpret_cast<const float4*>(d_rast), reinterpret_cast<const float4*>(d_rast_db), uv_nograd_faces, V, F, H, W, d_pos, d_vnormal);
+        VHAP_LAUNCH_CHECK();
+        return VHAP_OK;
+    }
     gbuffer_bwd_kernel<<<vhap_cdiv((long long)B * F * GB_LANES, 256), 256, 0, vhap_stream(stream)>>>(
         reinterpret_cast<const float4*>(pos), tri, vnormal, reinterpret_cast<const float2*>(uv), tri_uv,
         reinterpret_cast<const float4*>(rast), d_normal, reinterpret_cast<const float2*>(d_texc), reinterpret_cast<const float4*>(d_texd),

@@ -80,6 +80,45 @@ __global__ __launch_bounds__(256) void mip_fold_kernel(float* __restrict__ fine,
     fine[tb * fine_stride + ((size_t)y * w + x) * C + c] += 0.25f * g;
 }
 
+// The small levels in ONE single-workgroup launch each way (they are pure launch latency otherwise: 7 of the 11 levels of a
+// 2048^2 texture hold <= 64x64 texels).  Levels are processed in sequence with a barrier in between; global memory written by
+// the workgroup is visible to it after __syncthreads + __threadfence_block.
+constexpr int TAIL_MAX = 128;     // levels whose SOURCE is at most TAIL_MAX x TAIL_MAX go to the tail kernel
+__global__ __launch_bounds__(1024) void mip_down_tail_kernel(float* __restrict__ mips, const TexDesc D, int l_first) {
+    for (int tb = 0; tb < D.TB; tb++) {
+        for (int l = l_first; l <= D.L; l++) {
+            const int h = D.H >> l, w = D.W >> l, C = D.C;
+            const float* src = mips + (size_t)tb * D.per_tex + D.off[l - 1];
+            float* dst = mips + (size_t)tb * D.per_tex + D.off[l];
+            const int sw = 2 * w;
+            for (int i = threadIdx.x; i < h * w * C; i += 1024) {
+                const int c = i % C, x = (i / C) % w, y = i / (C * w);
+                const float a00 = src[((size_t)(2 * y) * sw + 2 * x) * C + c], a01 = src[((size_t)(2 * y) * sw + 2 * x + 1) * C + c];
+                const float a10 = src[((size_t)(2 * y + 1) * sw + 2 * x) * C + c], a11 = src[((size_t)(2 * y + 1) * sw + 2 * x + 1) * C + c];
+                dst[i] = ((a00 + a01) + (a10 + a11)) * 0.25f;
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
+    }
+}
+// fold levels L .. l_last+1 into level l_last (coarse -> fine), l_last >= 1
+__global__ __launch_bounds__(1024) void mip_fold_tail_kernel(float* __restrict__ d_mips, const TexDesc D, int l_last) {
+    for (int tb = 0; tb < D.TB; tb++) {
+        for (int l = D.L; l > l_last; l--) {
+            const int h = D.H >> (l - 1), w = D.W >> (l - 1), C = D.C;       // fine extents
+            float* fine = d_mips + (size_t)tb * D.per_tex + D.off[l - 1];
+            const float* coarse = d_mips + (size_t)tb * D.per_tex + D.off[l];
+            for (int i = threadIdx.x; i < h * w * C; i += 1024) {
+                const int c = i % C, x = (i / C) % w, y = i / (C * w);
+                fine[i] += 0.25f * coarse[((size_t)(y >> 1) * (w >> 1) + (x >> 1)) * C + c];
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
+    }
+}
+
 struct Taps {
     int i00, i10, i01, i11;  // texel indices (already multiplied by C)
     float fx, fy;
@@ -486,7 +525,11 @@ extern "C" int vhap_texture_mip_build(const float* tex, int TB, int Ht, int Wt, 
     const TexDesc D = make_desc(TB, Ht, Wt, C);
     if (D.L == 0) return VHAP_OK;
     if (!tex || !mips) return VHAP_E_NULLPTR;
-    for (int l = 1; l <= D.L; l++) {
+    // first level whose source is small enough for the single-workgroup tail (never level 1: its source is `tex`)
+    int l_tail = D.L + 1;
+    for (int l = 2; l <= D.L; l++)
+        if ((Ht >> (l - 1)) <= TAIL_MAX && (Wt >> (l - 1)) <= TAIL_MAX) { l_tail = l; break; }
+    for (int l = 1; l <= D.L && l < l_tail; l++) {
         const int h = Ht >> l, w = Wt >> l;
         const float* src = l == 1 ? tex : mips + D.off[l - 1];
         const long long sstride = l == 1 ? (long long)Ht * Wt * C : D.per_tex;
@@ -494,16 +537,29 @@ extern "C" int vhap_texture_mip_build(const float* tex, int TB, int Ht, int Wt, 
         mip_down_kernel<<<vhap_cdiv(n, 256), 256, 0, vhap_stream(stream)>>>(src, mips + D.off[l], TB, h, w, C, sstride, D.per_tex);
         VHAP_LAUNCH_CHECK();
     }
+    if (l_tail <= D.L) {
+        mip_down_tail_kernel<<<1, 1024, 0, vhap_stream(stream)>>>(mips, D, l_tail);
+        VHAP_LAUNCH_CHECK();
+    }
     return VHAP_OK;
 }
 
-extern "C" int vhap_texture_mip_fold(float* d_tex, float* d_mips, int TB, int Ht, int Wt, int C, vhap_stream_t stream) {
+extern "C" int vhap_texture_mip_fold(float* d_tex, float* d_mips, int TB, int Ht, int Wt, int C, int stop_level, vhap_stream_t stream) {
     VHAP_ENTER();
     if (int e = check_tex(TB, Ht, Wt, C)) return e;
     const TexDesc D = make_desc(TB, Ht, Wt, C);
     if (D.L == 0) return VHAP_OK;
-    if (!d_tex || !d_mips) return VHAP_E_NULLPTR;
-    for (int l = D.L; l >= 1; l--) {   // coarse -> fine
+    if (stop_level < 0 || stop_level > 1) return VHAP_E_BADDIM;
+    if ((!d_tex && stop_level == 0) || !d_mips) return VHAP_E_NULLPTR;
+    // coarse -> fine; the levels whose FINE side is at most TAIL_MAX^2 in one single-workgroup launch
+    int l_tail = D.L + 1;      // levels >= l_tail are folded by the tail kernel (into level l_tail - 1)
+    for (int l = 2; l <= D.L; l++)
+        if ((Ht >> (l - 1)) <= TAIL_MAX && (Wt >> (l - 1)) <= TAIL_MAX) { l_tail = l; break; }
+    if (l_tail <= D.L) {
+        mip_fold_tail_kernel<<<1, 1024, 0, vhap_stream(stream)>>>(d_mips, D, l_tail - 1);
+        VHAP_LAUNCH_CHECK();
+    }
+    for (int l = (l_tail <= D.L ? l_tail - 1 : D.L); l > stop_level; l--) {
         const int h = Ht >> (l - 1), w = Wt >> (l - 1);   // fine extents
         float* fine = l == 1 ? d_tex : d_mips + D.off[l - 1];
         const long long fstride = l == 1 ? (long long)Ht * Wt * C : D.per_tex;

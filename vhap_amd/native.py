@@ -218,6 +218,83 @@ def offset_reg(om, offset, w_lap, w_abs, w_rigid):
 
 
 # ------------------------------------------------------------------------------------------------
+class _TexSample(torch.autograd.Function):
+    """albedo = painted + residual (channel-last) -> mip pyramid -> trilinear sample at (texc, texd), with the TV / residual
+    energies of the texture computed in the same pass over it.  One autograd node, so the backward can keep the texture
+    gradient in its pyramid form until the last kernel: texture_bwd (atomics into the levels) -> fold down to level 1 ->
+    tex_prep_bwd adds level 0 + 0.25 * level 1 + the regulariser gradients and writes d_extra in one pass."""
+
+    @staticmethod
+    def forward(ctx, painted, extra, mask, scales, texc, texd):
+        L = _lib.lib()
+        src = extra if extra is not None else painted
+        T, dev = src.shape[-1], src.device
+        B, H, W, _ = texc.shape
+        albedo = torch.empty(1, T, T, 3, dtype=torch.float32, device=dev)
+        terms = torch.empty(2, dtype=torch.float32, device=dev)
+        _chk(L.vhap_tex_prep_fwd(_p(painted), _p(extra), _p(mask), T, *scales, _p(albedo), _p(terms), _stream()), "vhap_tex_prep_fwd")
+        mips = torch.empty(L.vhap_texture_mip_floats(1, T, T, 3), dtype=torch.float32, device=dev)
+        _chk(L.vhap_texture_mip_build(_p(albedo), 1, T, T, 3, _p(mips), _stream()), "vhap_texture_mip_build")
+        out = torch.empty(B, H, W, 3, dtype=torch.float32, device=dev)
+        _chk(L.vhap_texture_fwd(_p(albedo), _p(mips), 1, T, T, 3, _p(texc), _p(texd), B, H, W, _p(out), _stream()), "vhap_texture_fwd")
+        ctx.scales, ctx.T = scales, T
+        ctx.save_for_backward(albedo, mips, extra, mask, texc, texd)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(albedo)
+        return out, terms, albedo
+
+    @staticmethod
+    def backward(ctx, d_out, d_terms, _d_albedo):
+        albedo, mips, extra, mask, texc, texd = ctx.saved_tensors
+        L = _lib.lib()
+        T = ctx.T
+        B, H, W, _ = texc.shape
+        need_tex = extra is not None and ctx.needs_input_grad[1]
+        need_uv, need_da = ctx.needs_input_grad[4], ctx.needs_input_grad[5]
+        dev = albedo.device
+        d_tex = d_mips = d_extra = d_uv = d_da = None
+        if d_out is not None:
+            if need_tex:
+                # level 0 and levels 1.. in ONE zero-filled buffer
+                buf = torch.zeros(albedo.numel() + mips.numel(), dtype=torch.float32, device=dev)
+                d_tex, d_mips = buf[:albedo.numel()], buf[albedo.numel():]
+            d_uv = torch.empty_like(texc) if need_uv else None
+            d_da = torch.empty_like(texd) if need_da else None
+            _chk(L.vhap_texture_bwd(_p(albedo), _p(mips), 1, T, T, 3, _p(texc), _p(texd), _p(_f32c(d_out)), B, H, W, _p(d_tex), _p(d_mips),
+                                    _p(d_uv), _p(d_da), _stream()), "vhap_texture_bwd")
+            if need_tex and mips.numel() > 0:
+                _chk(L.vhap_texture_mip_fold(_p(d_tex), _p(d_mips), 1, T, T, 3, 1, _stream()), "vhap_texture_mip_fold")
+        if need_tex:
+            if d_terms is None:
+                d_terms = torch.zeros(2, dtype=torch.float32, device=dev)
+            d_extra = torch.empty_like(extra)
+            d_mip1 = d_mips if (d_mips is not None and d_mips.numel() > 0) else None     # level 1 sits at offset 0 of the pyramid
+            _chk(L.vhap_tex_prep_bwd(_p(albedo), _p(extra), _p(mask), _p(d_tex), _p(d_mip1), _p(_f32c(d_terms)), T, *ctx.scales,
+                                     _p(d_extra), _stream()), "vhap_tex_prep_bwd")
+        return None, d_extra, None, None, d_uv, d_da
+
+
+class TexSampler:
+    """Callable handed to HipDiffRenderer.render_rgba(tex_sampler=...): samples painted + residual at the interpolated
+    texture coordinates; afterwards `.terms` = (reg_tex_tv, reg_tex_res_clusters) weighted, `.albedo_cl` = [1,T,T,3]."""
+
+    def __init__(self, painted, extra, res_mask_u8, w_tv, w_res):
+        T = (extra if extra is not None else painted).shape[-1]
+        self.scales = (float(w_tv or 0.0) / (3.0 * T * (T - 1)), float(w_res or 0.0) / (3.0 * T * T))
+        f = lambda t: _f32c(t.reshape(3, T, T)) if t is not None else None
+        self.painted, self.extra, self.mask = f(painted), f(extra), res_mask_u8
+        self.terms = self.albedo_cl = None
+
+    def __call__(self, texc, texd):
+        out, self.terms, self.albedo_cl = _TexSample.apply(self.painted, self.extra, self.mask, self.scales, _f32c(texc), _f32c(texd))
+        return out
+
+    def prep_only(self):
+        """No photometric term in this stage: only the channel-last albedo and the regulariser terms."""
+        self.albedo_cl, self.terms = tex_prep(self.painted, self.extra, self.mask, None, None, scales=self.scales)
+        return self.albedo_cl
+
+
 class _TexPrep(torch.autograd.Function):
     @staticmethod
     def forward(ctx, painted, extra, mask, scales):
@@ -239,16 +316,17 @@ class _TexPrep(torch.autograd.Function):
         if d_terms is None:
             d_terms = torch.zeros(2, dtype=torch.float32, device=albedo.device)
         d_extra = torch.empty_like(extra)
-        _chk(_lib.lib().vhap_tex_prep_bwd(_p(albedo), _p(extra), _p(mask), _p(_f32c(d_albedo) if d_albedo is not None else None),
+        _chk(_lib.lib().vhap_tex_prep_bwd(_p(albedo), _p(extra), _p(mask), _p(_f32c(d_albedo) if d_albedo is not None else None), 0,
                                           _p(_f32c(d_terms)), ctx.T, *ctx.scales, _p(d_extra), _stream()), "vhap_tex_prep_bwd")
         return None, d_extra, None, None
 
 
-def tex_prep(painted, extra, res_mask_u8, w_tv, w_res):
+def tex_prep(painted, extra, res_mask_u8, w_tv, w_res, scales=None):
     """painted [3,T,T] or None, extra [3,T,T] or None -> albedo [1,T,T,3] (channel-last), terms [2] = reg_tex_tv,
     reg_tex_res_clusters (weighted)."""
     T = (extra if extra is not None else painted).shape[-1]
-    scales = (float(w_tv or 0.0) / (3.0 * T * (T - 1)), float(w_res or 0.0) / (3.0 * T * T))
+    if scales is None:
+        scales = (float(w_tv or 0.0) / (3.0 * T * (T - 1)), float(w_res or 0.0) / (3.0 * T * T))
     f = lambda t: _f32c(t.reshape(3, T, T)) if t is not None else None
     return _TexPrep.apply(f(painted), f(extra), res_mask_u8, scales)
 

@@ -274,7 +274,7 @@ class _Texture(torch.autograd.Function):
                                          _p(d_tex), _p(d_mips), _p(d_uv), _p(d_da), _stream())
         _lib.check(rc, "vhap_texture_bwd")
         if d_mips is not None:
-            rc = _lib.lib().vhap_texture_mip_fold(_p(d_tex), _p(d_mips), TB, Ht, Wt, C, _stream())
+            rc = _lib.lib().vhap_texture_mip_fold(_p(d_tex), _p(d_mips), TB, Ht, Wt, C, 0, _stream())
             _lib.check(rc, "vhap_texture_mip_fold")
         return d_tex, d_uv, d_da
 

@@ -286,7 +286,7 @@ class HipDiffRenderer(torch.nn.Module):
     # ---- render (render_nvdiffrast.py:354-484) ----
     def render_rgba(self, rast_dict, verts, faces, verts_uv, faces_uv, tex, lights, background_color=[1., 1., 1.],
                     align_texture_except_fid=None, align_boundary_except_vid=None, enable_disturbance=False,
-                    disturbance=None, outputs="all", want_reg_diffuse=False, tex_cl=None):
+                    disturbance=None, outputs="all", want_reg_diffuse=False, tex_cl=None, tex_sampler=None):
         """`outputs="loss"` (MI355X extension): return only what the photometric energy needs --
         {'rgba_rs': antialiased RGBA in RENDERER space (row 0 = bottom, not flipped), 'reg_diffuse': scalar} -- through
         the fused shading kernel; `outputs="all"` reproduces the reference's dictionary."""
@@ -321,11 +321,14 @@ class HipDiffRenderer(torch.nn.Module):
 
         # [N,3,T,T] -> channel-last.  An expanded (stride-0) batch is ONE texture: sample it shared
         # instead of materialising B copies (the reference does .permute().contiguous(), :398)
-        if tex_cl is None:                       # (`tex_cl`: the caller already holds the channel-last texture [1,T,T,3])
-            if tex.shape[0] > 1 and tex.stride(0) == 0:
-                tex = tex[:1]
-            tex_cl = tex.permute(0, 2, 3, 1).contiguous()
-        albedo = ops.texture(tex_cl, texc, texd, filter_mode="linear-mipmap-linear")
+        if tex_sampler is not None:               # (`tex_sampler(texc, texd)`: the caller owns texture assembly + sampling)
+            albedo = tex_sampler(texc, texd)
+        else:
+            if tex_cl is None:                    # (`tex_cl`: the caller already holds the channel-last texture [1,T,T,3])
+                if tex.shape[0] > 1 and tex.stride(0) == 0:
+                    tex = tex[:1]
+                tex_cl = tex.permute(0, 2, 3, 1).contiguous()
+            albedo = ops.texture(tex_cl, texc, texd, filter_mode="linear-mipmap-linear")
 
         if fast:
             rgba, reg_diffuse = FU.shade(normal_raw, albedo, lights, rast_out, background_color, self.sh_const, want_reg_diffuse)

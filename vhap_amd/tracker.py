@@ -468,10 +468,12 @@ class FlameTracker:
         painted = self.flame_tex_painted()[0]
         if painted.shape[-1] != self.tex_extra.shape[-1]:
             painted = F.interpolate(painted[None], self.tex_extra.shape[-2:], mode="bilinear")[0]
-        albedo_cl, tterms = NV.tex_prep(painted, self.tex_extra, nm["res_mask"], self._w_tv() if tex_on else None,
-                                        w.reg_tex_res_clusters if tex_on else None)
-        albedos = albedo_cl.permute(0, 3, 1, 2).expand(B, -1, -1, -1)
-        if isinstance(cfg.pipeline[stage], PhotometricStageConfig) and w.photo is not None:
+        sampler = NV.TexSampler(painted, self.tex_extra, nm["res_mask"], self._w_tv() if tex_on else None,
+                                w.reg_tex_res_clusters if tex_on else None)
+        photometric = isinstance(cfg.pipeline[stage], PhotometricStageConfig) and w.photo is not None
+        if not photometric:
+            sampler.prep_only()
+        if photometric:
             verts_clip = FU.transform(verts, mvp)
             rast_dict = {"rast_out": None, "rast_out_db": None, "verts": verts, "verts_camera": None, "verts_clip": verts_clip,
                          "image_size": tuple(self.image_size), "require_grad": True}
@@ -481,7 +483,7 @@ class FlameTracker:
             want_reg = bool(o["lights"]) and w.reg_diffuse is not None
             out = self.render.render_rgba(rast_dict, verts, faces, self._verts_uv_flipped, self.flame.textures_idx, None,
                                           self.lights[None], bg_color, fid, vid, True, disturbance=disturbance, outputs="loss",
-                                          want_reg_diffuse=want_reg, tex_cl=albedo_cl)
+                                          want_reg_diffuse=want_reg, tex_sampler=sampler)
             abs_sum, n_alpha = FU.photo_sum(out["rgba_rs"], gt_rgb)
             result_dict.update({"rgba_rs": out["rgba_rs"], "reg_diffuse_value": out["reg_diffuse"]})
             if self._split is not None:                            # graphed step: the normaliser is applied later (GraphedStep)
@@ -492,6 +494,8 @@ class FlameTracker:
                 if self.dist is not None:
                     n_mask = self.dist.all_reduce_sum(n_mask) / self.dist.world_size
                 log_dict["photo"] = w.photo * (abs_sum / n_mask)
+        tterms = sampler.terms
+        albedos = sampler.albedo_cl.permute(0, 3, 1, 2).expand(B, -1, -1, -1)
         # regularisers, in the reference's order (tracker.py:480-605)
         pt = dict(zip(NV.FRAME_TERMS, pterms.unbind(0)))
         if o["pose"] and tracking:
