@@ -140,7 +140,7 @@ int vhap_texture_mip_fold(float* d_tex, float* d_mips, int TB, int Ht, int Wt, i
  *   the pixel pairs it blended there and the backward replays them.
  * Backward: d_color [B,H,W,C] overwritten; d_pos [B,V,4] ACCUMULATED (caller zero-fills).
  * ------------------------------------------------------------------------------------------- */
-size_t vhap_antialias_work_ints(int B, int H, int W);
+size_t vhap_antialias_work_ints(int B, int H, int W, int F);
 int vhap_antialias_fwd(const float* color, const float* rast, const float* pos,
                        const int32_t* tri, const int32_t* opp, int B, int H, int W, int C, int V,
                        int F, float* out, int32_t* work, vhap_stream_t stream);

@@ -35,7 +35,7 @@ SIGNATURES = {
     "vhap_texture_fwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp]),
     "vhap_texture_bwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_i] + [c_fp] * 5),
     "vhap_texture_mip_fold": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
-    "vhap_antialias_work_ints": (c_sz, [c_i] * 3),
+    "vhap_antialias_work_ints": (c_sz, [c_i] * 4),
     "vhap_antialias_fwd": (c_i, [c_fp] * 5 + [c_i] * 6 + [c_fp, c_fp, c_fp]),
     "vhap_antialias_bwd": (c_i, [c_fp] * 8 + [c_i] * 6 + [c_fp, c_fp, c_fp]),
     "vhap_disturb_workspace_ints": (c_sz, [c_i] * 3),

@@ -102,66 +102,150 @@ __device__ __forceinline__ Geo analyse(const float4* __restrict__ P, const int* 
     return g;
 }
 
-// work[0] = item count; items (4 ints each) start at work[4]: {pixel index of p0, d | use1 << 1, alpha bits, 0}
-__global__ __launch_bounds__(256) void aa_copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, long long n4,
-                                                      int* __restrict__ work) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i == 0) work[0] = 0;
-    if (i < n4) dst[i] = src[i];
+// Pre-pass: which triangles of which frame have at least one silhouette edge.  The silhouette test of analyse() is a property
+// of (frame, triangle, edge) -- cross products are translation invariant -- and fewer than 10 % of the triangles of a closed
+// surface have one, while about half of all neighbouring pixel pairs straddle two different triangles (the mesh is ~9
+// pixels per triangle at 512^2): one byte per pair decides whether the full edge analysis (8 vertex gathers) is needed at all.
+__global__ __launch_bounds__(256) void aa_silhouette_kernel(const float4* __restrict__ pos, const int* __restrict__ tri,
+                                                            const int* __restrict__ opp, int B, int V, int F, int H, int W,
+                                                            unsigned char* __restrict__ sil) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * F) return;
+    const int b = i / F, t = i - b * F;
+    const float4* P = pos + (size_t)b * V;
+    const float xh = 0.5f * (float)W, yh = 0.5f * (float)H;
+    float x[3], y[3], ox[3], oy[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int vi = tri[3 * t + k];
+        int oi = opp[3 * t + k];
+        if (oi < 0) oi = vi;
+        const float4 p = P[vi], o = P[oi];
+        x[k] = p.x / p.w * xh; y[k] = p.y / p.w * yh;
+        ox[k] = o.x / o.w * xh; oy[k] = o.y / o.w * yh;
+    }
+    const float bb = (x[1] - x[0]) * (y[2] - y[0]) - (x[2] - x[0]) * (y[1] - y[0]);
+    const float a0 = (x[1] - ox[0]) * (y[2] - oy[0]) - (x[2] - ox[0]) * (y[1] - oy[0]);
+    const float a1 = (x[2] - ox[1]) * (y[0] - oy[1]) - (x[0] - ox[1]) * (y[2] - oy[1]);
+    const float a2 = (x[0] - ox[2]) * (y[1] - oy[2]) - (x[1] - ox[2]) * (y[0] - oy[2]);
+    // conservative: an area within rounding noise of zero counts as "maybe" (the per-pair analysis then decides exactly)
+    const float tol = 1e-4f * (fabsf(bb) + 1e-12f);
+    const bool nb = bb < 0.f;
+    auto maybe = [&](float a) { return fabsf(a) <= tol + 1e-6f * fabsf(a) || ((a < 0.f) == nb); };
+    sil[i] = (unsigned char)((maybe(a0) ? 1 : 0) | (maybe(a1) ? 2 : 0) | (maybe(a2) ? 4 : 0) | (fabsf(bb) <= 1e-12f ? 7 : 0));
 }
-__global__ __launch_bounds__(256) void aa_copy_tail_kernel(const float* __restrict__ src, float* __restrict__ dst, long long start,
-                                                           long long n) {
-    const long long i = start + (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) dst[i] = src[i];
+
+// work[0] = item count, work[1] = candidate count; items (4 ints each) start at work[4]:
+//   {pixel index of p0, d | use1 << 1 | edge << 2, alpha bits, frame}
+// Forward in two passes so that the expensive edge analysis runs on DENSE waves: a candidate pair is rare (a few per cent of
+// the pixels), but a wave pays for the analysis if ANY of its 64 lanes needs it.
+//   detect: stream over the pixels -- out = color, and every neighbouring pair whose front triangle has a silhouette edge is
+//           appended to a compact candidate list (one atomic per wave);
+//   blend:  one lane per candidate: analyse(), blend, append the work item for the backward.
+constexpr int DET_T = 1024, DET_PPT = 4;      // detect: 1024 lanes x 4 pixels per workgroup
+template <int C>
+__global__ __launch_bounds__(DET_T) void aa_detect_kernel(const float* __restrict__ color, const float4* __restrict__ rast,
+                                                          const unsigned char* __restrict__ sil, int B, int H, int W, int F,
+                                                          float* __restrict__ out, int* __restrict__ work, unsigned* __restrict__ cand,
+                                                          int dbg) {
+    // candidates are compacted per workgroup in LDS first: a returning atomic on ONE global counter serialises (~12 ns each),
+    // so it is issued once per 4096 pixels, not once per wave
+    __shared__ unsigned lcand[2 * DET_T * DET_PPT];
+    __shared__ int lcount, gbase;
+    if (threadIdx.x == 0) lcount = 0;
+    __syncthreads();
+    const unsigned npix = (unsigned)B * H * W;             // < 2^30 (checked by the entry point): 32-bit index math
+    const unsigned HW = (unsigned)H * W;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int it = 0; it < DET_PPT; it++) {
+        const unsigned pi = (blockIdx.x * DET_PPT + it) * DET_T + threadIdx.x;
+        const bool live = pi < npix;
+        const unsigned b = live ? pi / HW : 0u;
+        const unsigned rem = pi - b * HW;
+        const int py = (int)(rem / (unsigned)W), px = (int)(rem - (unsigned)py * W);
+        const float4 r0 = live ? rast[pi] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int t0 = (int)r0.w - 1;
+        if (live) {
+            if constexpr (C == 4) {
+                reinterpret_cast<float4*>(out)[pi] = reinterpret_cast<const float4*>(color)[pi];
+            } else {
+#pragma unroll
+                for (int k = 0; k < C; k++) out[(size_t)pi * C + k] = color[(size_t)pi * C + k];
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < 2; d++) {
+            bool c = false;
+            if (live && !(d == 0 ? px + 1 >= W : py + 1 >= H) && !(dbg & 1024)) {
+                const float4 r1 = rast[pi + (d == 0 ? 1u : (unsigned)W)];
+                const int t1 = (int)r1.w - 1;
+                if (t0 != t1 && t0 < F && t1 < F) {
+                    // the triangle analyse() will pick: the nearer one; a background pixel never wins
+                    const int tf = (t0 >= 0 && t1 >= 0) ? (r0.z < r1.z ? t0 : t1) : (t0 >= 0 ? t0 : t1);
+                    c = sil == nullptr || sil[(size_t)b * F + tf] != 0;
+                }
+            }
+            const unsigned long long m = __ballot(c);
+            if (m == 0ull) continue;
+            const int leader = __ffsll((long long)m) - 1;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&lcount, __popcll(m));
+            base = __shfl(base, leader, 64);
+            if (c) lcand[base + __popcll(m & ((1ull << lane) - 1ull))] = (pi << 1) | (unsigned)d;
+        }
+    }
+    __syncthreads();
+    const int n = lcount;
+    if (n == 0) return;
+    if (threadIdx.x == 0) gbase = atomicAdd(&work[1], n);
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += DET_T) cand[gbase + i] = lcand[i];
 }
 
 template <int C>
-__global__ __launch_bounds__(256) void aa_fwd_kernel(const float* __restrict__ color, const float4* __restrict__ rast,
-                                                     const float4* __restrict__ pos, const int* __restrict__ tri,
-                                                     const int* __restrict__ opp, int B, int H, int W, int V, int F,
-                                                     float* __restrict__ out, int* __restrict__ work) {
-    const unsigned npix = (unsigned)B * H * W;             // < 2^31 (checked by the entry point): 32-bit index math
-    const unsigned pi = blockIdx.x * 256u + threadIdx.x;
-    const bool live = pi < npix;
+__global__ __launch_bounds__(256) void aa_blend_kernel(const float* __restrict__ color, const float4* __restrict__ rast,
+                                                       const float4* __restrict__ pos, const int* __restrict__ tri,
+                                                       const int* __restrict__ opp, const unsigned* __restrict__ cand, int H, int W,
+                                                       int V, int F, float* __restrict__ out, int* __restrict__ work, int dbg) {
+    const int count = work[1];
     const unsigned HW = (unsigned)H * W;
-    const unsigned b = live ? pi / HW : 0u;
-    const unsigned rem = pi - b * HW;
-    const int py = (int)(rem / (unsigned)W), px = (int)(rem - (unsigned)py * W);
-    const float4 r0 = live ? rast[pi] : make_float4(0.f, 0.f, 0.f, 0.f);
-    const int t0 = (int)r0.w - 1;
-    const float4* P = pos + (size_t)b * V;
     const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int d = 0; d < 2; d++) {
-        // every lane reaches the ballot below: silhouette pairs are appended to the work list with ONE atomic per wave
+    const int nwave_iter = (count + (int)(gridDim.x * 256) - 1) / (int)(gridDim.x * 256);
+    for (int it = 0; it < nwave_iter; it++) {          // uniform trip count: every lane reaches the ballot
+        const int i = (it * (int)gridDim.x + (int)blockIdx.x) * 256 + (int)threadIdx.x;
         bool need = false;
         Geo g;
         float alpha = 0.f;
-        unsigned pj = pi;
-        if (live && !(d == 0 ? px + 1 >= W : py + 1 >= H)) {
+        unsigned pi = 0, pj = 0, b = 0;
+        int d = 0;
+        if (i < count) {
+            const unsigned e = cand[i];
+            pi = e >> 1; d = (int)(e & 1u);
             pj = pi + (d == 0 ? 1u : (unsigned)W);
-            const float4 r1 = rast[pj];
-            const int t1 = (int)r1.w - 1;
-            if (t0 != t1 && t0 < F && t1 < F) {
-                g = analyse(P, tri, opp, t0, t1, r0.z, r1.z, px, py, d, H, W);
-                if (g.ok) {
-                    const float dc = fminf(fmaxf(g.dc_raw, 0.0f), 1.0f);
-                    alpha = g.ds * (0.5f - dc);
-                    need = true;
-                }
+            b = pi / HW;
+            const unsigned rem = pi - b * HW;
+            const int py = (int)(rem / (unsigned)W), px = (int)(rem - (unsigned)py * W);
+            const float4 r0 = rast[pi], r1 = rast[pj];
+            g = analyse(pos + (size_t)b * V, tri, opp, (int)r0.w - 1, (int)r1.w - 1, r0.z, r1.z, px, py, d, H, W);
+            if (g.ok) {
+                const float dc = fminf(fmaxf(g.dc_raw, 0.0f), 1.0f);
+                alpha = g.ds * (0.5f - dc);
+                need = true;
             }
         }
         const unsigned long long m = __ballot(need);
         if (m == 0ull) continue;
+        const int leader = __ffsll((long long)m) - 1;
         int base = 0;
-        if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&work[0], __popcll(m));
-        base = __shfl(base, __ffsll((long long)m) - 1, 64);
+        if (lane == leader) base = atomicAdd(&work[0], __popcll(m));
+        base = __shfl(base, leader, 64);
         if (need) {
             const float* c0 = color + (size_t)pi * C;
             const float* c1 = color + (size_t)pj * C;
             float* o = out + (size_t)(alpha > 0.0f ? pi : pj) * C;
 #pragma unroll
-            for (int k = 0; k < C; k++) atomicAdd(&o[k], alpha * (c1[k] - c0[k]));
+            for (int k = 0; k < C; k++) if (!(dbg & 512)) atomicAdd(&o[k], alpha * (c1[k] - c0[k]));
             const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
             const int4 item = make_int4((int)pi, d | (g.ds < 0.f ? 2 : 0) | (g.di << 2), __float_as_int(alpha), (int)b);
             reinterpret_cast<int4*>(work + 4)[slot] = item;
@@ -246,9 +330,11 @@ int dispatch_C(int C, Fn&& f) {
 
 }  // namespace
 
-extern "C" size_t vhap_antialias_work_ints(int B, int H, int W) {
-    if (B <= 0 || H <= 0 || W <= 0) return 0;
-    return 4 + 4 * 2 * (size_t)B * H * W;   // worst case: every pixel blends with both neighbours
+extern "C" size_t vhap_antialias_work_ints(int B, int H, int W, int F) {
+    if (B <= 0 || H <= 0 || W <= 0 || F <= 0) return 0;
+    // header + item list (worst case: every pixel blends with both neighbours) + one silhouette byte per (frame, triangle)
+    // + candidate list (two pairs per pixel)
+    return 4 + 4 * 2 * (size_t)B * H * W + ((size_t)B * F + 3) / 4 + 2 * (size_t)B * H * W;
 }
 
 extern "C" int vhap_antialias_fwd(const float* color, const float* rast, const float* pos, const int32_t* tri,
@@ -256,19 +342,23 @@ extern "C" int vhap_antialias_fwd(const float* color, const float* rast, const f
                                   vhap_stream_t stream) {
     VHAP_ENTER();
     if (!color || !rast || !pos || !tri || !opp || !out || !work) return VHAP_E_NULLPTR;
-    if (B <= 0 || H <= 0 || W <= 0 || V <= 0 || F <= 0 || (long long)B * H * W >= (1ll << 31)) return VHAP_E_BADDIM;
-    const long long npix = (long long)B * H * W, n = npix * C, n4 = n / 4;
+    if (B <= 0 || H <= 0 || W <= 0 || V <= 0 || F <= 0 || (long long)B * H * W >= (1ll << 30)) return VHAP_E_BADDIM;
+    const long long npix = (long long)B * H * W;
     hipStream_t st = vhap_stream(stream);
-    aa_copy_kernel<<<vhap_cdiv(n4 > 0 ? n4 : 1, 256), 256, 0, st>>>(reinterpret_cast<const float4*>(color),
-                                                                    reinterpret_cast<float4*>(out), n4, work);
+    unsigned char* sil = reinterpret_cast<unsigned char*>(work + 4 + 4 * 2 * (size_t)npix);
+    unsigned* cand = reinterpret_cast<unsigned*>(work + 4 + 4 * 2 * (size_t)npix + ((size_t)B * F + 3) / 4);
+    vhap_zero_async(work, 16, st);
     VHAP_LAUNCH_CHECK();
-    if (n4 * 4 < n) {
-        aa_copy_tail_kernel<<<1, 256, 0, st>>>(color, out, n4 * 4, n);
-        VHAP_LAUNCH_CHECK();
-    }
+    aa_silhouette_kernel<<<vhap_cdiv((long long)B * F, 256), 256, 0, st>>>(reinterpret_cast<const float4*>(pos), tri, opp, B, V, F, H, W, sil);
+    VHAP_LAUNCH_CHECK();
+    const int dbg = vhap_g_debug_flags;
     return dispatch_C(C, [&](auto c) {
-        aa_fwd_kernel<decltype(c)::value><<<vhap_cdiv(npix, 256), 256, 0, st>>>(
-            color, reinterpret_cast<const float4*>(rast), reinterpret_cast<const float4*>(pos), tri, opp, B, H, W, V, F, out, work);
+        constexpr int CC = decltype(c)::value;
+        aa_detect_kernel<CC><<<vhap_cdiv(npix, DET_T * DET_PPT), DET_T, 0, st>>>(color, reinterpret_cast<const float4*>(rast), (dbg & 2048) ? nullptr : sil, B, H, W,
+                                                                   F, out, work, cand, dbg);
+        VHAP_LAUNCH_CHECK();
+        aa_blend_kernel<CC><<<1024, 256, 0, st>>>(color, reinterpret_cast<const float4*>(rast), reinterpret_cast<const float4*>(pos), tri, opp,
+                                                  cand, H, W, V, F, out, work, dbg);
         VHAP_LAUNCH_CHECK();
         return VHAP_OK;
     });

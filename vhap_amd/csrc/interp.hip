@@ -381,7 +381,7 @@ __global__ __launch_bounds__(GT * GT) void gbuffer_bwd_tiled_kernel(const float4
                                                                     const float4* __restrict__ d_texd, const float4* __restrict__ d_rast,
                                                                     const float4* __restrict__ d_db, const unsigned char* __restrict__ uv_nograd,
                                                                     int V, int F, int H, int W, float* __restrict__ d_pos,
-                                                                    float* __restrict__ d_vnormal) {
+                                                                    float* __restrict__ d_vnormal, int dbg) {
     __shared__ unsigned keys[GSLOT];
     __shared__ float vals[GSLOT * 6];     // [0..2] = d_pos x, y, w ; [3..5] = d_vnormal
     const int tid = threadIdx.x;
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(GT * GT) void gbuffer_bwd_tiled_kernel(const float4
             }
             // three vertices -> LDS table (bounded probing; overflow goes straight to global memory)
 #pragma unroll
-            for (int vtx = 0; vtx < 3; vtx++) {
+            for (int vtx = 0; vtx < ((dbg & 256) ? 0 : 3); vtx++) {
                 const int vi = vtx == 0 ? i0 : (vtx == 1 ? i1 : i2);
                 unsigned slot = ((unsigned)vi * 2654435761u) >> 23;     // 9 bits
                 bool done = false;
@@ -507,6 +507,7 @@ __global__ __launch_bounds__(GT * GT) void gbuffer_bwd_tiled_kernel(const float4
         }
     }
     __syncthreads();
+    if (dbg & 128) return;
     for (int sidx = tid; sidx < GSLOT; sidx += GT * GT) {
         const unsigned vi = keys[sidx];
         if (vi == GEMPTY) continue;
@@ -533,7 +534,7 @@ extern "C" int vhap_gbuffer_bwd(const float* pos, const int32_t* tri, const floa
         gbuffer_bwd_tiled_kernel<<<dim3(vhap_cdiv(W, GT), vhap_cdiv(H, GT), B), GT * GT, 0, vhap_stream(stream)>>>(
             reinterpret_cast<const float4*>(pos), tri, vnormal, reinterpret_cast<const float2*>(uv), tri_uv,
             reinterpret_cast<const float4*>(rast), d_normal, reinterpret_cast<const float2*>(d_texc), reinterpret_cast<const float4*>(d_texd),
-            reinterpret_cast<const float4*>(d_rast), reinterpret_cast<const float4*>(d_rast_db), uv_nograd_faces, V, F, H, W, d_pos, d_vnormal);
+            reinterpret_cast<const float4*>(d_rast), reinterpret_cast<const float4*>(d_rast_db), uv_nograd_faces, V, F, H, W, d_pos, d_vnormal, vhap_g_debug_flags);
         VHAP_LAUNCH_CHECK();
         return VHAP_OK;
     }

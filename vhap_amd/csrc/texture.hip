@@ -399,7 +399,7 @@ __global__ __launch_bounds__(TT * TT) void texture_bwd_tiled_kernel(const float*
                                                                     const TexDesc D, const float2* __restrict__ uv,
                                                                     const float4* __restrict__ uv_da, const float* __restrict__ d_out,
                                                                     int H, int W, float* __restrict__ d_tex, float* __restrict__ d_mips,
-                                                                    float2* __restrict__ d_uv, float4* __restrict__ d_uv_da) {
+                                                                    float2* __restrict__ d_uv, float4* __restrict__ d_uv_da, int dbg) {
     __shared__ unsigned keys[NSLOT];
     __shared__ float vals[NSLOT * C];
     const int tid = threadIdx.x;
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(TT * TT) void texture_bwd_tiled_kernel(const float*
     }
     __syncthreads();
     const TileAcc<C> accv{keys, vals, d_tex, d_mips, &D, tb};
-    const TileAcc<C>* acc = want_tex ? &accv : nullptr;
+    const TileAcc<C>* acc = (want_tex && !(dbg & 256)) ? &accv : nullptr;
     float2 guv = make_float2(0.f, 0.f);
     float4 gda = make_float4(0.f, 0.f, 0.f, 0.f);
     if (any) {
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(TT * TT) void texture_bwd_tiled_kernel(const float*
         if (d_uv) d_uv[pi] = guv;
         if (d_uv_da) d_uv_da[pi] = gda;
     }
-    if (!want_tex) return;
+    if (!want_tex || (dbg & 128)) return;
     __syncthreads();
     for (int sidx = tid; sidx < NSLOT; sidx += TT * TT) {
         const unsigned key = keys[sidx];
@@ -602,7 +602,7 @@ extern "C" int vhap_texture_bwd(const float* tex, const float* mips, int TB, int
         return dispatch_C(C, [&](auto c) {
             texture_bwd_tiled_kernel<decltype(c)::value><<<dim3(vhap_cdiv(W, TT), vhap_cdiv(H, TT), B), TT * TT, 0, vhap_stream(stream)>>>(
                 tex, mips, D, reinterpret_cast<const float2*>(uv), reinterpret_cast<const float4*>(uv_da), d_out, H, W, d_tex, d_mips,
-                reinterpret_cast<float2*>(d_uv), reinterpret_cast<float4*>(d_uv_da));
+                reinterpret_cast<float2*>(d_uv), reinterpret_cast<float4*>(d_uv_da), vhap_g_debug_flags);
             VHAP_LAUNCH_CHECK();
             return VHAP_OK;
         });

@@ -323,7 +323,7 @@ class _Antialias(torch.autograd.Function):
         B, H, W, C = color.shape
         V, F = pos.shape[1], tri.shape[0]
         out = torch.empty_like(color)
-        work = torch.empty(_lib.lib().vhap_antialias_work_ints(B, H, W), dtype=torch.int32, device=color.device)
+        work = torch.empty(_lib.lib().vhap_antialias_work_ints(B, H, W, F), dtype=torch.int32, device=color.device)
         rc = _lib.lib().vhap_antialias_fwd(_p(color), _p(rast), _p(pos), _p(tri), _p(opp), B, H, W, C, V, F, _p(out),
                                            _p(work), _stream())
         _lib.check(rc, "vhap_antialias_fwd")
