@@ -17,7 +17,7 @@ namespace {
 
 constexpr int MAXC = 16;  // max clusters (the reference configures 7 + background + "none" = 9)
 constexpr int DB = 1024;  // threads per counting-sort workgroup
-constexpr int PPT = 4;    // pixels per thread: a workgroup owns DB * PPT consecutive pixels
+constexpr int PPT = 8;    // pixels per thread: a workgroup owns DB * PPT consecutive pixels (8192: 512 workgroups at 16x512^2)
 constexpr int DPIX = DB * PPT;
 
 __device__ __forceinline__ int pixel_cluster(const float4* __restrict__ rast, const int* __restrict__ fid2cid, int nfid, long long p) {

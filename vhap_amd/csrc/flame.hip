@@ -19,92 +19,87 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int NJ = 5;  // FLAME joints
 
-// grid (Vp/64, ceil(B/16)), 64 threads.  coef [Bp,Kp] (rows padded to 16, zero-filled), basis [3][K][Vp],
-// A [B,5,12] (row-major 3x4 per joint), w [V,5], templ [V,3], offset [V,3] or null, transl [B,3]
-__global__ __launch_bounds__(64) void flame_skin_fwd_kernel(const float* __restrict__ coef, const float* __restrict__ basis,
-                                                            const float* __restrict__ A, const float* __restrict__ w,
-                                                            const float* __restrict__ templ, const float* __restrict__ offset,
-                                                            const float* __restrict__ transl, int B, int V, int Vp, int K,
-                                                            int Kb, int Kp, float* __restrict__ verts,
-                                                            float* __restrict__ v_shaped, float* __restrict__ v_posed) {
+// grid (Vp/16, ceil(B/16)), 256 threads = 4 waves.  coef [Bp,Kp] (rows padded to 16, zero-filled), basis [3][K][Vp],
+// A [B,5,12] (row-major 3x4 per joint), w [V,5], templ [V,3], offset [V,3] or null, transl [B,3].
+// A workgroup owns a 16-frame x 16-vertex tile; the K axis (shape+expression rows, then the pose-corrective rows) is split over
+// its four waves and summed through LDS: 324 x 4 waves stream the 27 MB basis instead of 81 single waves walking 109
+// dependent steps each (87 -> ~20 us at V = 5143).
+__global__ __launch_bounds__(256) void flame_skin_fwd_kernel(const float* __restrict__ coef, const float* __restrict__ basis,
+                                                             const float* __restrict__ A, const float* __restrict__ w,
+                                                             const float* __restrict__ templ, const float* __restrict__ offset,
+                                                             const float* __restrict__ transl, int B, int V, int Vp, int K,
+                                                             int Kb, int Kp, float* __restrict__ verts,
+                                                             float* __restrict__ v_shaped, float* __restrict__ v_posed) {
     __shared__ float sA[16 * NJ * 12];
     __shared__ float sT[16 * 3];
-    const int lane = threadIdx.x;
-    const int v0 = blockIdx.x * 64, b0 = blockIdx.y * 16;
-    for (int i = lane; i < 16 * NJ * 12; i += 64) {
+    __shared__ float red[2][4][3][64][4];      // [phase][wave][component][lane][r]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int v0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
+    for (int i = tid; i < 16 * NJ * 12; i += 256) {
         const int f = i / (NJ * 12);
         sA[i] = (b0 + f < B) ? A[(size_t)(b0 + f) * NJ * 12 + (i - f * NJ * 12)] : 0.f;
     }
-    if (lane < 48) sT[lane] = (b0 + lane / 3 < B) ? transl[(size_t)(b0 + lane / 3) * 3 + lane % 3] : 0.f;
-    __syncthreads();
+    if (tid < 48) sT[tid] = (b0 + tid / 3 < B) ? transl[(size_t)(b0 + tid / 3) * 3 + tid % 3] : 0.f;
     const int li = lane & 15, lk = lane >> 4;
     const float* cf = coef + (size_t)(b0 + li) * Kp + lk;
-    f32x4 acc[4][3];
-#pragma unroll
-    for (int t = 0; t < 4; t++)
-#pragma unroll
-        for (int c = 0; c < 3; c++) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
     const size_t cs = (size_t)K * Vp;  // component stride
-    auto run = [&](int k_begin, int k_end) {
-        for (int k = k_begin; k < k_end; k += 4) {
+    auto run = [&](int k_begin, int k_end, int phase) {
+        // this wave's share of [k_begin, k_end), in whole 4-row MFMA steps
+        const int steps = (k_end - k_begin) / 4;
+        const int per = (steps + 3) / 4;
+        const int s0 = min(wave * per, steps), s1 = min(s0 + per, steps);
+        f32x4 acc[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll 4
+        for (int st = s0; st < s1; st++) {
+            const int k = k_begin + 4 * st;
             const float a = cf[k];
             const float* bp = basis + (size_t)(k + lk) * Vp + v0 + li;
 #pragma unroll
-            for (int t = 0; t < 4; t++)
-#pragma unroll
-                for (int c = 0; c < 3; c++)
-                    acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bp[c * cs + 16 * t], acc[t][c], 0, 0, 0);
+            for (int c = 0; c < 3; c++) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bp[c * cs], acc[c], 0, 0, 0);
         }
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) red[phase][wave][c][lane][r] = acc[c][r];
     };
-    run(0, Kb);  // shape + expression (Kb is a multiple of 4)
-    float vs[4][4][3];  // [tile][frame r][component]
+    run(0, Kb, 0);   // shape + expression (Kb is a multiple of 4)
+    run(Kb, K, 1);   // pose correctives
+    __syncthreads();
+    if (wave != 0) return;
+    // epilogue on wave 0: lane (li = vertex, lk) holds frames lk*4 + r
+    const int v = v0 + li;
+    if (v >= V) return;
+    float tx = templ[3 * v], ty = templ[3 * v + 1], tz = templ[3 * v + 2];
+    if (offset) { tx += offset[3 * v]; ty += offset[3 * v + 1]; tz += offset[3 * v + 2]; }
+    float wj[NJ];
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
-        const int v = v0 + 16 * t + li;
-        float tx = 0.f, ty = 0.f, tz = 0.f;
-        if (v < V) {
-            tx = templ[3 * v]; ty = templ[3 * v + 1]; tz = templ[3 * v + 2];
-            if (offset) { tx += offset[3 * v]; ty += offset[3 * v + 1]; tz += offset[3 * v + 2]; }
+    for (int j = 0; j < NJ; j++) wj[j] = w[(size_t)v * NJ + j];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int fl = lk * 4 + r, f = b0 + fl;
+        if (f >= B) continue;
+        float sh[3], po[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            sh[c] = (red[0][0][c][lane][r] + red[0][1][c][lane][r]) + (red[0][2][c][lane][r] + red[0][3][c][lane][r]);
+            po[c] = (red[1][0][c][lane][r] + red[1][1][c][lane][r]) + (red[1][2][c][lane][r] + red[1][3][c][lane][r]);
         }
+        const float sx = tx + sh[0], sy = ty + sh[1], sz = tz + sh[2];
+        const size_t o = ((size_t)f * V + v) * 3;
+        v_shaped[o] = sx; v_shaped[o + 1] = sy; v_shaped[o + 2] = sz;
+        const float px = sx + po[0], py = sy + po[1], pz = sz + po[2];
+        float T[12];
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            vs[t][r][0] = tx + acc[t][0][r]; vs[t][r][1] = ty + acc[t][1][r]; vs[t][r][2] = tz + acc[t][2][r];
-            const int f = b0 + lk * 4 + r;
-            if (v < V && f < B) {
-                float* o = v_shaped + ((size_t)f * V + v) * 3;
-                o[0] = vs[t][r][0]; o[1] = vs[t][r][1]; o[2] = vs[t][r][2];
-            }
+        for (int q = 0; q < 12; q++) {
+            float s_ = 0.f;
+#pragma unroll
+            for (int j = 0; j < NJ; j++) s_ += wj[j] * sA[(fl * NJ + j) * 12 + q];
+            T[q] = s_;
         }
-#pragma unroll
-        for (int c = 0; c < 3; c++) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    run(Kb, K);  // pose correctives
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-        const int v = v0 + 16 * t + li;
-        if (v >= V) continue;
-        float wj[NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; j++) wj[j] = w[(size_t)v * NJ + j];
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int fl = lk * 4 + r, f = b0 + fl;
-            if (f >= B) continue;
-            const float px = vs[t][r][0] + acc[t][0][r], py = vs[t][r][1] + acc[t][1][r], pz = vs[t][r][2] + acc[t][2][r];
-            float T[12];
-#pragma unroll
-            for (int q = 0; q < 12; q++) {
-                float s = 0.f;
-#pragma unroll
-                for (int j = 0; j < NJ; j++) s += wj[j] * sA[(fl * NJ + j) * 12 + q];
-                T[q] = s;
-            }
-            const size_t o = ((size_t)f * V + v) * 3;
-            v_posed[o] = px; v_posed[o + 1] = py; v_posed[o + 2] = pz;
-            verts[o] = T[0] * px + T[1] * py + T[2] * pz + T[3] + sT[fl * 3];
-            verts[o + 1] = T[4] * px + T[5] * py + T[6] * pz + T[7] + sT[fl * 3 + 1];
-            verts[o + 2] = T[8] * px + T[9] * py + T[10] * pz + T[11] + sT[fl * 3 + 2];
-        }
+        v_posed[o] = px; v_posed[o + 1] = py; v_posed[o + 2] = pz;
+        verts[o] = T[0] * px + T[1] * py + T[2] * pz + T[3] + sT[fl * 3];
+        verts[o + 1] = T[4] * px + T[5] * py + T[6] * pz + T[7] + sT[fl * 3 + 1];
+        verts[o + 2] = T[8] * px + T[9] * py + T[10] * pz + T[11] + sT[fl * 3 + 2];
     }
 }
 
@@ -353,7 +348,7 @@ extern "C" int vhap_flame_skin_fwd(const float* coef, const float* basis, const 
     VHAP_ENTER();
     if (!coef || !basis || !A || !lbs_weights || !v_template || !transl || !verts || !v_shaped || !v_posed) return VHAP_E_NULLPTR;
     if (B <= 0 || V <= 0 || Vp < V || Vp % 64 || K <= 0 || K % 4 || Kb % 4 || Kb > K || Kp < K) return VHAP_E_BADDIM;
-    flame_skin_fwd_kernel<<<dim3(Vp / 64, (B + 15) / 16), 64, 0, vhap_stream(stream)>>>(coef, basis, A, lbs_weights, v_template, offset,
+    flame_skin_fwd_kernel<<<dim3(Vp / 16, (B + 15) / 16), 256, 0, vhap_stream(stream)>>>(coef, basis, A, lbs_weights, v_template, offset,
                                                                                         transl, B, V, Vp, K, Kb, Kp, verts, v_shaped,
                                                                                         v_posed);
     VHAP_LAUNCH_CHECK();

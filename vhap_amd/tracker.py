@@ -749,14 +749,16 @@ class GraphedStep:
                 E_rest, self.log_dict, *_ = tracker.compute_energy(s, stage=stage)
                 self.S, self.N = tracker._split["S"], tracker._split["N"]
             pool = self.gF.pool() if os.environ.get("VHAP_GRAPH_POOLS") != "separate" else None
+            for p in self.params:
+                p.grad = None
             with torch.cuda.graph(self.gB, pool=pool):
                 E = E_rest + tracker.cfg.w.photo * self.S * self.inv_n
-                grads = torch.autograd.grad(E, self.params, allow_unused=True)
-                for p, g in zip(self.params, grads):
-                    if g is None:
-                        p.grad.zero_()
-                    else:
-                        p.grad.copy_(g)
+                # .grad is None: autograd hands its gradient tensors over to the parameters (no copy); they live in the graph's
+                # pool at fixed addresses and are rewritten by every replay
+                torch.autograd.backward(E, inputs=self.params)
+                for p in self.params:
+                    if p.grad is None:
+                        p.grad = torch.zeros_like(p)
                 self.E = E.detach()
             with torch.cuda.graph(self.gA, pool=pool):
                 optimizer.step()
