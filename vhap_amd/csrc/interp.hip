@@ -383,7 +383,8 @@ __global__ __launch_bounds__(GT * GT) void gbuffer_bwd_tiled_kernel(const float4
                                                                     int V, int F, int H, int W, float* __restrict__ d_pos,
                                                                     float* __restrict__ d_vnormal, int dbg) {
     __shared__ unsigned keys[GSLOT];
-    __shared__ float vals[GSLOT * 6];     // [0..2] = d_pos x, y, w ; [3..5] = d_vnormal
+    __shared__ unsigned long long vals[GSLOT * 6];     // [0..2] = d_pos x, y, w ; [3..5] = d_vnormal: 64-bit fixed point (see texture.hip)
+    __shared__ unsigned smax[2];
     const int tid = threadIdx.x;
     const int px = blockIdx.x * GT + (tid & (GT - 1)), py = blockIdx.y * GT + (tid >> 4), b = blockIdx.z;
     const bool inside = px < W && py < H;
@@ -393,18 +394,22 @@ __global__ __launch_bounds__(GT * GT) void gbuffer_bwd_tiled_kernel(const float4
     const bool cov = inside && t >= 0 && t < F;
     if (__syncthreads_or(cov ? 1 : 0) == 0) return;       // background tile
     for (int i = tid; i < GSLOT; i += GT * GT) keys[i] = GEMPTY;
-    for (int i = tid; i < GSLOT * 6; i += GT * GT) vals[i] = 0.f;
+    for (int i = tid; i < GSLOT * 6; i += GT * GT) vals[i] = 0ull;
+    if (tid < 2) smax[tid] = 0u;
     __syncthreads();
+    float acc[18];
+#pragma unroll
+    for (int k = 0; k < 18; k++) acc[k] = 0.f;
+    int i0 = 0, i1 = 0, i2 = 0;
+    bool have = false;
     if (cov) {
-        const int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
+        i0 = tri[3 * t]; i1 = tri[3 * t + 1]; i2 = tri[3 * t + 2];
         if ((unsigned)i0 < (unsigned)V && (unsigned)i1 < (unsigned)V && (unsigned)i2 < (unsigned)V) {
+            have = true;
             const float4* P = pos + (size_t)b * V;
             const float4 p0 = P[i0], p1 = P[i1], p2 = P[i2];
             const float xs = 2.0f / (float)W, xo = 1.0f / (float)W - 1.0f;
             const float ys = 2.0f / (float)H, yo = 1.0f / (float)H - 1.0f;
-            float acc[18];
-#pragma unroll
-            for (int k = 0; k < 18; k++) acc[k] = 0.f;
             const float b0 = r.x, b1 = r.y, b2 = (1.0f - b0) - b1;
             float g0 = 0.f, g1 = 0.f;
             float4 gd = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -474,9 +479,28 @@ __global__ __launch_bounds__(GT * GT) void gbuffer_bwd_tiled_kernel(const float4
                 acc[6] += p0.w * gY1; acc[2] += p2.x * gY1; acc[0] -= p2.w * gY1; acc[8] -= p0.x * gY1;
                 acc[0] += p1.w * gY2; acc[5] += p0.x * gY2; acc[3] -= p0.w * gY2; acc[2] -= p1.x * gY2;
             }
+        }
+    }
+    // per-tile power-of-two scales (positions / normals) from the largest contribution
+    {
+        float mp = 0.f, mn = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; k++) { mp = fmaxf(mp, fabsf(acc[k])); mn = fmaxf(mn, fabsf(acc[9 + k])); }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { mp = fmaxf(mp, __shfl_xor(mp, o, 64)); mn = fmaxf(mn, __shfl_xor(mn, o, 64)); }
+        if ((tid & 63) == 0) { atomicMax(&smax[0], __float_as_uint(mp)); atomicMax(&smax[1], __float_as_uint(mn)); }
+    }
+    __syncthreads();
+    int exp_p = 0, exp_n = 0;
+    (void)frexpf(__uint_as_float(smax[0]), &exp_p);
+    (void)frexpf(__uint_as_float(smax[1]), &exp_n);
+    const int shp = min(max(40 - exp_p, -100), 100), shn = min(max(40 - exp_n, -100), 100);
+    const float sc_p = ldexpf(1.0f, shp), sc_n = ldexpf(1.0f, shn), isc_p = ldexpf(1.0f, -shp), isc_n = ldexpf(1.0f, -shn);
+    if (have && !(dbg & 256)) {
+        {
             // three vertices -> LDS table (bounded probing; overflow goes straight to global memory)
 #pragma unroll
-            for (int vtx = 0; vtx < ((dbg & 256) ? 0 : 3); vtx++) {
+            for (int vtx = 0; vtx < 3; vtx++) {
                 const int vi = vtx == 0 ? i0 : (vtx == 1 ? i1 : i2);
                 unsigned slot = ((unsigned)vi * 2654435761u) >> 23;     // 9 bits
                 bool done = false;
@@ -487,8 +511,8 @@ __global__ __launch_bounds__(GT * GT) void gbuffer_bwd_tiled_kernel(const float4
 #pragma unroll
                         for (int c = 0; c < 3; c++) {
                             const float vp = acc[3 * vtx + c], vn = acc[9 + 3 * vtx + c];
-                            if (vp != 0.f) atomicAdd(&vals[slot * 6 + c], vp);
-                            if (vn != 0.f) atomicAdd(&vals[slot * 6 + 3 + c], vn);
+                            if (vp != 0.f) atomicAdd(&vals[slot * 6 + c], (unsigned long long)__float2ll_rn(vp * sc_p));
+                            if (vn != 0.f) atomicAdd(&vals[slot * 6 + 3 + c], (unsigned long long)__float2ll_rn(vn * sc_n));
                         }
                         done = true;
                     } else {
@@ -513,9 +537,9 @@ __global__ __launch_bounds__(GT * GT) void gbuffer_bwd_tiled_kernel(const float4
         if (vi == GEMPTY) continue;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
-            const float vp = vals[sidx * 6 + c], vn = vals[sidx * 6 + 3 + c];
-            if (d_pos && vp != 0.f) atomicAdd(&d_pos[((size_t)b * V + vi) * 4 + (c == 2 ? 3 : c)], vp);
-            if (d_vnormal && vn != 0.f) atomicAdd(&d_vnormal[((size_t)b * V + vi) * 3 + c], vn);
+            const long long qp = (long long)vals[sidx * 6 + c], qn = (long long)vals[sidx * 6 + 3 + c];
+            if (d_pos && qp != 0) atomicAdd(&d_pos[((size_t)b * V + vi) * 4 + (c == 2 ? 3 : c)], (float)qp * isc_p);
+            if (d_vnormal && qn != 0) atomicAdd(&d_vnormal[((size_t)b * V + vi) * 3 + c], (float)qn * isc_n);
         }
     }
 }

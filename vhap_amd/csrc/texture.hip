@@ -122,6 +122,7 @@ __global__ __launch_bounds__(1024) void mip_fold_tail_kernel(float* __restrict__
 struct Taps {
     int i00, i10, i01, i11;  // texel indices (already multiplied by C)
     float fx, fy;
+    int x0, y0, x1, y1;      // texel coordinates after wrapping
 };
 
 __device__ __forceinline__ Taps make_taps(float u, float v, int w, int h, int C) {
@@ -141,6 +142,7 @@ __device__ __forceinline__ Taps make_taps(float u, float v, int w, int h, int C)
     // guard against u == 1.0 after rounding (x0 == w)
     if (x0 >= w) x0 -= w;
     if (y0 >= h) y0 -= h;
+    t.x0 = x0; t.y0 = y0; t.x1 = x1; t.y1 = y1;
     t.i00 = (y0 * w + x0) * C; t.i10 = (y0 * w + x1) * C;
     t.i01 = (y1 * w + x0) * C; t.i11 = (y1 * w + x1) * C;
     return t;
@@ -329,30 +331,35 @@ __global__ __launch_bounds__(256) void texture_bwd_kernel(const float* __restric
 // Probing is bounded; a tap that finds no slot goes straight to global memory, so the result never depends on the table.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int TT = 16;            // tile edge (pixels)
-constexpr int NSLOT = 2048;       // hash slots per tile
+constexpr int NSLOT = 1536;       // hash slots per tile (a 16x16 tile touches ~700-1400 texels over two levels)
 constexpr unsigned EMPTY_KEY = 0xffffffffu;
 
+// LDS accumulators are 64-bit FIXED POINT, not float: on gfx950 ds_add_f32 costs ~200 cycles per wave instruction whatever
+// the conflict pattern, ds_add_u64 ~9 cycles (+2 per extra lane on the same address) -- tools/ubench/lds_atomics.hip.  The
+// scale is a power of two chosen per tile from max|d_out| so that every product w*g keeps 40 fractional bits below the
+// tile maximum (more than the 24 of fp32) and 2048 taps cannot overflow; integer sums are exact and order-independent.
 template <int C>
 struct TileAcc {
     unsigned* keys;
-    float* vals;
+    unsigned long long* vals;
     float* d_tex;
     float* d_mips;
     const TexDesc* D;
     int tb;
+    float scale;
     __device__ __forceinline__ void add(int level, int texelC, const float (&v)[C]) const {
         const unsigned key = ((unsigned)level << 27) | (unsigned)(texelC / C);
-        unsigned slot = (key * 2654435761u) >> 21;          // 11 bits
+        unsigned slot = (unsigned)(((unsigned long long)(key * 2654435761u) * NSLOT) >> 32);
 #pragma unroll 1
-        for (int probe = 0; probe < 8; probe++) {
+        for (int probe = 0; probe < 16; probe++) {
             const unsigned prev = atomicCAS(&keys[slot], EMPTY_KEY, key);
             if (prev == EMPTY_KEY || prev == key) {
 #pragma unroll
                 for (int k = 0; k < C; k++)
-                    if (v[k] != 0.f) atomicAdd(&vals[slot * C + k], v[k]);
+                    if (v[k] != 0.f) atomicAdd(&vals[slot * C + k], (unsigned long long)__float2ll_rn(v[k] * scale));
                 return;
             }
-            slot = (slot + 1) & (NSLOT - 1);
+            slot = slot + 1 == NSLOT ? 0 : slot + 1;
         }
         float* G = level_ptr_w(d_tex, d_mips, *D, tb, level);
 #pragma unroll
@@ -362,7 +369,7 @@ struct TileAcc {
 };
 
 template <int C>
-__device__ __forceinline__ void bilinear_bwd_tile(const float* __restrict__ T, const TileAcc<C>* acc, int level, const Taps& t,
+__device__ __forceinline__ void bilinear_bwd_tile(const float* __restrict__ T, const TileAcc<C>& acc, bool use_acc, int level, const Taps& t,
                                                   const float (&g)[C], float wgt, float& gfx, float& gfy, float (&val)[C]) {
     gfx = 0.f;
     gfy = 0.f;
@@ -377,20 +384,20 @@ __device__ __forceinline__ void bilinear_bwd_tile(const float* __restrict__ T, c
         gfx += gk[k] * ((1.f - t.fy) * (a10 - a00) + t.fy * (a11 - a01));
         gfy += gk[k] * (bot - top);
     }
-    if (acc) {
+    if (use_acc) {
         float v[C];
 #pragma unroll
         for (int k = 0; k < C; k++) v[k] = w00 * gk[k];
-        acc->add(level, t.i00, v);
+        acc.add(level, t.i00, v);
 #pragma unroll
         for (int k = 0; k < C; k++) v[k] = w10 * gk[k];
-        acc->add(level, t.i10, v);
+        acc.add(level, t.i10, v);
 #pragma unroll
         for (int k = 0; k < C; k++) v[k] = w01 * gk[k];
-        acc->add(level, t.i01, v);
+        acc.add(level, t.i01, v);
 #pragma unroll
         for (int k = 0; k < C; k++) v[k] = w11 * gk[k];
-        acc->add(level, t.i11, v);
+        acc.add(level, t.i11, v);
     }
 }
 
@@ -401,7 +408,10 @@ __global__ __launch_bounds__(TT * TT) void texture_bwd_tiled_kernel(const float*
                                                                     int H, int W, float* __restrict__ d_tex, float* __restrict__ d_mips,
                                                                     float2* __restrict__ d_uv, float4* __restrict__ d_uv_da, int dbg) {
     __shared__ unsigned keys[NSLOT];
-    __shared__ float vals[NSLOT * C];
+    __shared__ unsigned long long vals[NSLOT * C];
+    __shared__ unsigned smax;
+    __shared__ int lmin_s, bb[4][4];     // per relative level: xmin, ymin, xmax, ymax of the texels touched by the tile
+    __shared__ unsigned irregular;       // bit r: level lmin + r wraps around / too large -> flushed in slot order; bit 4: deeper levels
     const int tid = threadIdx.x;
     const int px = blockIdx.x * TT + (tid & (TT - 1)), py = blockIdx.y * TT + (tid >> 4), b = blockIdx.z;
     const bool inside = px < W && py < H;
@@ -409,11 +419,15 @@ __global__ __launch_bounds__(TT * TT) void texture_bwd_tiled_kernel(const float*
     const int tb = D.TB == 1 ? 0 : b;
     float g[C];
     bool any = false;
+    float gmax = 0.f;
 #pragma unroll
     for (int k = 0; k < C; k++) {
         g[k] = inside ? d_out[pi * C + k] : 0.f;
         any = any || g[k] != 0.f;
+        gmax = fmaxf(gmax, fabsf(g[k]));
     }
+    if (tid == 0) { smax = 0u; lmin_s = 99; irregular = 0u; }
+    if (tid < 16) bb[tid >> 2][tid & 3] = (tid & 2) ? -1 : 0x7fffffff;
     const bool tile_any = __syncthreads_or(any ? 1 : 0) != 0;
     if (!tile_any) {          // background tile: nothing to accumulate
         if (inside) {
@@ -423,39 +437,59 @@ __global__ __launch_bounds__(TT * TT) void texture_bwd_tiled_kernel(const float*
         return;
     }
     const bool want_tex = d_tex != nullptr;
+    LevelSel s;
+    s.l0 = 0; s.f = 0.f; s.two = false; s.diff = false;
+    if (any && uv_da != nullptr) s = select_level(uv_da[pi], D.W, D.H, D.L);
     if (want_tex) {
+        int l = any ? s.l0 : 99;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) l = min(l, __shfl_xor(l, o, 64));
+        if ((tid & 63) == 0) atomicMin(&lmin_s, l);
         for (int i = tid; i < NSLOT; i += TT * TT) keys[i] = EMPTY_KEY;
-        for (int i = tid; i < NSLOT * C; i += TT * TT) vals[i] = 0.f;
+        for (int i = tid; i < NSLOT * C; i += TT * TT) vals[i] = 0ull;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, o, 64));
+        if ((tid & 63) == 0) atomicMax(&smax, __float_as_uint(gmax));     // non-negative floats order like their bit patterns
     }
     __syncthreads();
-    const TileAcc<C> accv{keys, vals, d_tex, d_mips, &D, tb};
-    const TileAcc<C>* acc = (want_tex && !(dbg & 256)) ? &accv : nullptr;
+    // power-of-two scale: max|g| * scale in [2^39, 2^40)
+    int ex = 0;
+    (void)frexpf(__uint_as_float(smax), &ex);
+    const int sh = min(max(40 - ex, -100), 100);
+    const float scale = ldexpf(1.0f, sh), inv_scale = ldexpf(1.0f, -sh);
+    const TileAcc<C> acc{keys, vals, d_tex, d_mips, &D, tb, scale};
+    const bool use_acc = want_tex && !(dbg & 256);
+    const int lmin = lmin_s;
     float2 guv = make_float2(0.f, 0.f);
     float4 gda = make_float4(0.f, 0.f, 0.f, 0.f);
+    // texel boxes of this lane's (up to two) levels, for the ordered flush
+    int bl[2] = {-1, -1}, bx0[2] = {0, 0}, by0[2] = {0, 0}, bx1[2] = {0, 0}, by1[2] = {0, 0};
     if (any) {
         const float2 c = uv[pi];
         if (uv_da == nullptr) {
             const Taps t = make_taps(c.x, c.y, D.W, D.H, C);
             float gfx, gfy, val[C];
-            bilinear_bwd_tile<C>(level_ptr(tex, mips, D, tb, 0), acc, 0, t, g, 1.0f, gfx, gfy, val);
+            bilinear_bwd_tile<C>(level_ptr(tex, mips, D, tb, 0), acc, use_acc, 0, t, g, 1.0f, gfx, gfy, val);
             guv.x = gfx * (float)D.W;
             guv.y = gfy * (float)D.H;
+            bl[0] = 0; bx0[0] = t.x0; by0[0] = t.y0; bx1[0] = t.x1; by1[0] = t.y1;
         } else {
-            const LevelSel s = select_level(uv_da[pi], D.W, D.H, D.L);
             const int w0 = D.W >> s.l0, h0 = D.H >> s.l0;
             const Taps t0 = make_taps(c.x, c.y, w0, h0, C);
             const bool two = s.two && s.f > 0.0f;
             float gfx0, gfy0, c0[C];
-            bilinear_bwd_tile<C>(level_ptr(tex, mips, D, tb, s.l0), acc, s.l0, t0, g, two ? 1.0f - s.f : 1.0f, gfx0, gfy0, c0);
+            bilinear_bwd_tile<C>(level_ptr(tex, mips, D, tb, s.l0), acc, use_acc, s.l0, t0, g, two ? 1.0f - s.f : 1.0f, gfx0, gfy0, c0);
             guv.x = gfx0 * (float)w0;
             guv.y = gfy0 * (float)h0;
+            bl[0] = s.l0; bx0[0] = t0.x0; by0[0] = t0.y0; bx1[0] = t0.x1; by1[0] = t0.y1;
             if (two) {
                 const int w1 = D.W >> (s.l0 + 1), h1 = D.H >> (s.l0 + 1);
                 const Taps t1 = make_taps(c.x, c.y, w1, h1, C);
                 float gfx1, gfy1, c1[C];
-                bilinear_bwd_tile<C>(level_ptr(tex, mips, D, tb, s.l0 + 1), acc, s.l0 + 1, t1, g, s.f, gfx1, gfy1, c1);
+                bilinear_bwd_tile<C>(level_ptr(tex, mips, D, tb, s.l0 + 1), acc, use_acc, s.l0 + 1, t1, g, s.f, gfx1, gfy1, c1);
                 guv.x += gfx1 * (float)w1;
                 guv.y += gfy1 * (float)h1;
+                bl[1] = s.l0 + 1; bx0[1] = t1.x0; by0[1] = t1.y0; bx1[1] = t1.x1; by1[1] = t1.y1;
                 if (s.diff && d_uv_da) {
                     float gf = 0.f;
 #pragma unroll
@@ -478,16 +512,85 @@ __global__ __launch_bounds__(TT * TT) void texture_bwd_tiled_kernel(const float*
         if (d_uv_da) d_uv_da[pi] = gda;
     }
     if (!want_tex || (dbg & 128)) return;
+    // ---- flush ----
+    // In slot (hash) order the 64 atomics of a wave land on 64 scattered cache lines and the memory system handles them one
+    // transaction each (~70 G/s measured); walking each level's texel BOX in row-major order and looking the texels up in the
+    // table makes consecutive lanes hit consecutive addresses.  Boxes that wrap around the texture edge (seams) or are too large
+    // fall back to slot order.
+    {
+        unsigned irr = 0u;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            int xmin = 0x7fffffff, ymin = 0x7fffffff, xmax = -1, ymax = -1;
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                if (bl[q] >= 0 && bl[q] - lmin == r) {
+                    if (bx1[q] < bx0[q] || by1[q] < by0[q]) irr |= 1u << r;
+                    else { xmin = bx0[q]; ymin = by0[q]; xmax = bx1[q]; ymax = by1[q]; }
+                }
+            }
+            if (__ballot(xmax >= 0) == 0ull) continue;        // wave-uniform: nobody touches this level
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                xmin = min(xmin, __shfl_xor(xmin, o, 64)); ymin = min(ymin, __shfl_xor(ymin, o, 64));
+                xmax = max(xmax, __shfl_xor(xmax, o, 64)); ymax = max(ymax, __shfl_xor(ymax, o, 64));
+            }
+            if ((tid & 63) == 0) {
+                atomicMin(&bb[r][0], xmin); atomicMin(&bb[r][1], ymin); atomicMax(&bb[r][2], xmax); atomicMax(&bb[r][3], ymax);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+            if (bl[q] >= 0 && bl[q] - lmin > 3) irr |= 16u;
+        if (__ballot(irr != 0u) != 0ull) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) irr |= (unsigned)__shfl_xor((int)irr, o, 64);
+            if ((tid & 63) == 0) atomicOr(&irregular, irr);
+        }
+    }
     __syncthreads();
+    unsigned slot_order = irregular;      // levels (relative) that must be flushed in slot order
+#pragma unroll 1
+    for (int r = 0; r < 4; r++) {
+        const int xmin = bb[r][0], ymin = bb[r][1], xmax = bb[r][2], ymax = bb[r][3];
+        if (xmax < 0) continue;
+        const int bw = xmax - xmin + 1, bh = ymax - ymin + 1;
+        if (bw * bh > 6144 || (slot_order & (1u << r))) { slot_order |= 1u << r; continue; }
+        const int level = lmin + r, wl = D.W >> level;
+        float* G = level_ptr_w(d_tex, d_mips, D, tb, level);
+        for (int i = tid; i < bw * bh; i += TT * TT) {
+            const int yy = i / bw, xx = i - yy * bw;
+            const unsigned texel = (unsigned)((ymin + yy) * wl + xmin + xx);
+            const unsigned key = ((unsigned)level << 27) | texel;
+            unsigned slot = (unsigned)(((unsigned long long)(key * 2654435761u) * NSLOT) >> 32);
+            int found = -1;
+#pragma unroll 1
+            for (int probe = 0; probe < 16; probe++) {
+                const unsigned k = keys[slot];
+                if (k == key) { found = (int)slot; break; }
+                if (k == EMPTY_KEY) break;
+                slot = slot + 1 == NSLOT ? 0 : slot + 1;
+            }
+            if (found < 0) continue;
+#pragma unroll
+            for (int k = 0; k < C; k++) {
+                const long long q = (long long)vals[found * C + k];
+                if (q != 0) atomicAdd(&G[(size_t)texel * C + k], (float)q * inv_scale);
+            }
+        }
+    }
+    if (slot_order == 0u) return;
     for (int sidx = tid; sidx < NSLOT; sidx += TT * TT) {
         const unsigned key = keys[sidx];
         if (key == EMPTY_KEY) continue;
         const int level = (int)(key >> 27);
+        const int r = level - lmin;
+        if (!((r >= 0 && r < 4 && (slot_order & (1u << r))) || (r > 3 && (slot_order & 16u)))) continue;
         float* G = level_ptr_w(d_tex, d_mips, D, tb, level) + (size_t)(key & 0x7ffffffu) * C;
 #pragma unroll
         for (int k = 0; k < C; k++) {
-            const float v = vals[sidx * C + k];
-            if (v != 0.f) atomicAdd(&G[k], v);
+            const long long q = (long long)vals[sidx * C + k];
+            if (q != 0) atomicAdd(&G[k], (float)q * inv_scale);
         }
     }
 }
