@@ -19,3 +19,18 @@ extern "C" const char* vhap_strerror(int code) {
 // Profiling / A-B switches (not part of the stable ABI): 16 = strided row order in the rasteriser, 32 = per-pixel texture backward
 int vhap_g_debug_flags = 0;
 extern "C" void vhap_debug_set_flags(int flags) { vhap_g_debug_flags = flags; }
+
+// Calibration helpers for PMC-based traffic measurements (tools/ri_fwd_pmc.py): known byte counts through the library's own
+// streaming kernels.  Not part of the stable ABI (not declared in vhap_hip.h).
+extern "C" int vhap_debug_fill(void* p, size_t bytes, vhap_stream_t stream) {
+    VHAP_ENTER();
+    vhap_zero_async(p, bytes, vhap_stream(stream));
+    VHAP_LAUNCH_CHECK();
+    return VHAP_OK;
+}
+extern "C" int vhap_debug_copy(void* dst, const void* src, size_t bytes, vhap_stream_t stream) {
+    VHAP_ENTER();
+    vhap_copy_async(dst, src, bytes, vhap_stream(stream));
+    VHAP_LAUNCH_CHECK();
+    return VHAP_OK;
+}

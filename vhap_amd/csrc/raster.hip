@@ -195,6 +195,79 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_fill_kernel(const unsigned* _
         }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// One-launch binning ("fragmented lists").  count + scan + fill above are three launches because a bin's list must be
+// contiguous and its length is only known after all triangles were counted.  Here every workgroup (1024 consecutive triangles
+// of one frame) owns a fixed REGION of the pair list and lays out its own contribution to every bin inside it: LDS histogram ->
+// workgroup-wide exclusive scan in LDS -> second pass writes the triangle ids.  A bin's list is then the concatenation of at
+// most nfrag = ceil(F/1024) fragments, described by frag[frame][workgroup][bin] = (offset, count); the raster kernel walks the
+// fragments.  No global counters, nothing to clear between calls, no cross-workgroup dependency.  A workgroup whose pairs do not
+// fit its region publishes OVERFLOW descriptors instead: the raster blocks then scan that workgroup's triangle range directly
+// (bbox test against the setup records) -- a local, bounded fallback.
+// grid = (nfrag, B); dynamic LDS = nbin * 4 bytes.
+// ------------------------------------------------------------------------------------------------------------
+constexpr unsigned FRAG_OVERFLOW = 0x80000000u;
+
+__global__ __launch_bounds__(BIN_THREADS) void bin_build_kernel(const float* __restrict__ pos, const int* __restrict__ tri,
+                                                                const int* __restrict__ tri_uv, int V, int F, int H, int W,
+                                                                int nbx, int nby, unsigned* __restrict__ trange,
+                                                                TriRecord* __restrict__ records, uint2* __restrict__ frag,
+                                                                unsigned* __restrict__ list, unsigned region) {
+    extern __shared__ __attribute__((aligned(16))) unsigned lb[];     // [nbin]: counts, then write cursors
+    __shared__ unsigned wtot[BIN_THREADS / 64];
+    const int nbin = nbx * nby;
+    const int b = blockIdx.y, wg = blockIdx.x, nfrag = gridDim.x;
+    const int t = wg * BIN_THREADS + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < nbin; i += BIN_THREADS) lb[i] = 0u;
+    __syncthreads();
+    unsigned tr = TRANGE_NONE;
+    if (t < F) {
+        TriRecord rec;
+        tr = block_range(pos, tri, tri_uv, b, V, t, H, W, rec);
+        trange[(size_t)b * F + t] = tr;
+        if (tr != TRANGE_NONE) records[(size_t)b * F + t] = rec;
+    }
+    BlockRange r{0, -1, 0, -1};
+    if (tr != TRANGE_NONE) r = decode_range(tr, nby);
+    for (int y = r.by0; y <= r.by1; y++)
+        for (int x = r.bx0; x <= r.bx1; x++) atomicAdd(&lb[y * nbx + x], 1u);
+    __syncthreads();
+    // exclusive scan of lb[] over the workgroup: every lane owns `per` consecutive bins
+    const int per = (nbin + BIN_THREADS - 1) / BIN_THREADS;
+    const int i0 = threadIdx.x * per, i1 = min(i0 + per, nbin);
+    unsigned mine = 0u;
+    for (int i = i0; i < i1; i++) mine += lb[i];
+    unsigned incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned u = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += u;
+    }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    unsigned pre = incl - mine, total = 0u;
+    for (int w = 0; w < BIN_THREADS / 64; w++) {
+        if (w < wave) pre += wtot[w];
+        total += wtot[w];
+    }
+    const bool overflow = total > region;
+    const unsigned base = (unsigned)((size_t)(b * nfrag + wg) * region);
+    const int ntri = min(BIN_THREADS, F - wg * BIN_THREADS);
+    for (int i = i0; i < i1; i++) {
+        const unsigned n = lb[i];
+        uint2 d = make_uint2(0u, 0u);
+        if (n) d = overflow ? make_uint2((unsigned)(wg * BIN_THREADS), FRAG_OVERFLOW | (unsigned)ntri) : make_uint2(base + pre, n);
+        frag[((size_t)b * nfrag + wg) * nbin + i] = d;     // workgroup-major: coalesced here, nfrag scattered 8-byte reads per raster wave
+        lb[i] = pre;          // write cursor of this bin inside the region
+        pre += n;
+    }
+    if (overflow) return;     // uniform
+    __syncthreads();
+    for (int y = r.by0; y <= r.by1; y++)
+        for (int x = r.bx0; x <= r.bx1; x++) list[base + atomicAdd(&lb[y * nbx + x], 1u)] = (unsigned)t;
+}
+
 // ---- winner arithmetic (same op order as shade_frag() in the oracle) ----
 struct Frag {
     float b0, b1, zw, iw;
@@ -252,6 +325,8 @@ struct RasterParams {
     const TriRecord* records;
     const BinHeader* hdr;
     unsigned capacity;
+    const uint2* frag;     // fragmented lists (bin_build_kernel) or null: contiguous lists (bin_count/scan/fill)
+    int nfrag;
     int debug;  // ablation switches for profiling only (vhap_debug_set_flags)
     float* rast;
     float* rast_db;
@@ -278,13 +353,33 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterParams P) {
     const bool in_img = px < P.W && py < P.H;
     const int H = P.H, W = P.W;
 
-    const bool use_list = P.hdr->total <= P.capacity;
+    const bool fragmented = P.frag != nullptr;
+    const bool use_list = fragmented || P.hdr->total <= P.capacity;
     const size_t bin = (size_t)b * P.nbx * P.nby + (size_t)by * P.nbx + bx;
-    const unsigned n = (P.debug & 1) ? 0u : (use_list ? P.counts[bin] : (unsigned)P.F);
-    const unsigned off = use_list ? P.offsets[bin] : 0u;
-    if (lane == 0) {   // leave the workspace clean for the next call (see VHAP_RASTER_WS_CLEAN)
-        P.counts_w[bin] = 0u;
-        P.cursors_w[bin] = 0u;
+    __shared__ int4 sfr[4][64];   // per wave: fragment f = (first work item, count | overflow flag, list offset / first triangle, -)
+    unsigned n, off = 0u;
+    int nfr = 0;                  // non-empty fragments of this bin (the mesh is coherent in triangle order: usually 1-3)
+    if (fragmented) {
+        uint2 d = make_uint2(0u, 0u);
+        if (lane < P.nfrag) d = P.frag[((size_t)b * P.nfrag + lane) * ((size_t)P.nbx * P.nby) + (size_t)by * P.nbx + bx];
+        const unsigned c = d.y & ~FRAG_OVERFLOW;
+        unsigned incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned u = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += u;
+        }
+        const unsigned long long nz = __ballot(c != 0u);
+        nfr = __popcll(nz);
+        if (c != 0u) sfr[wave][__popcll(nz & ((1ull << lane) - 1ull))] = make_int4((int)(incl - c), (int)d.y, (int)d.x, 0);
+        n = (P.debug & 1) ? 0u : (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+    } else {
+        n = (P.debug & 1) ? 0u : (use_list ? P.counts[bin] : (unsigned)P.F);
+        off = use_list ? P.offsets[bin] : 0u;
+        if (lane == 0) {   // leave the workspace clean for the next call (see VHAP_RASTER_WS_CLEAN)
+            P.counts_w[bin] = 0u;
+            P.cursors_w[bin] = 0u;
+        }
     }
 
     unsigned long long best = ~0ull;  // (ordered z/w test value << 32) | triangle id
@@ -307,8 +402,20 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterParams P) {
         int AB0 = 0, AB1 = 0, AB2 = 0, C0 = 0, C1 = 0, C2 = 0;  // AB = A (low 16) | B (high 16)
         float zwc = 0.f, gx = 0.f, gy = 0.f;
         if (k < n && !(P.debug & 8)) {
-            t = use_list ? (int)P.list[off + k] : (int)k;
-            if (use_list || TR[t] != TRANGE_NONE) {  // brute-force mode: skip culled triangles (no record)
+            bool direct = !use_list;     // triangle id taken as is (no list): culled triangles have no record, test the range word
+            if (fragmented) {
+                int4 sel = make_int4(0, 0, 0, 0);
+                for (int f = 0; f < nfr; f++) {              // broadcast LDS reads over the non-empty fragments
+                    const int4 d = sfr[wave][f];
+                    if ((int)k >= d.x) sel = d;
+                }
+                direct = ((unsigned)sel.y & FRAG_OVERFLOW) != 0u;
+                const unsigned idx = (unsigned)sel.z + (k - (unsigned)sel.x);
+                t = direct ? (int)idx : (int)P.list[idx];
+            } else {
+                t = use_list ? (int)P.list[off + k] : (int)k;
+            }
+            if (!direct || (t < P.F && TR[t] != TRANGE_NONE)) {  // direct mode: skip culled triangles (no record)
                 const TriRecord* rp = REC + t;
                 const int4 q0 = rp->q0, q1 = rp->q1;
                 const int qx0 = q1.z & 0xffff, qx1 = q1.z >> 16, qy0 = q1.w & 0xffff, qy1 = q1.w >> 16;
@@ -448,7 +555,7 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterParams P) {
 
 
 struct WsLayout {
-    size_t hdr, counts, cursors, offsets, trange, records, list, total;
+    size_t hdr, counts, cursors, offsets, trange, records, list, frag, total;
 };
 
 WsLayout ws_layout(int B, int F, int nbin, size_t cap) {
@@ -462,6 +569,7 @@ WsLayout ws_layout(int B, int F, int nbin, size_t cap) {
     l.trange = o; o = al(o + sizeof(unsigned) * (size_t)B * F);
     l.records = o; o = al(o + sizeof(TriRecord) * (size_t)B * F);
     l.list = o; o = al(o + sizeof(unsigned) * (cap ? cap : 1));
+    l.frag = o; o = al(o + sizeof(uint2) * (size_t)B * nbin * ((F + BIN_THREADS - 1) / BIN_THREADS));
     l.total = o;
     return l;
 }
@@ -492,27 +600,45 @@ int launch_raster(RasterParams P, void* ws, size_t ws_bytes, size_t cap, int fla
     unsigned* trange = reinterpret_cast<unsigned*>(w + l.trange);
     unsigned* list = reinterpret_cast<unsigned*>(w + l.list);
     TriRecord* records = reinterpret_cast<TriRecord*>(w + l.records);
-    // header, counts and cursors are contiguous: one zero-fill launch -- skipped when the caller vouches that the workspace was
-    // zero-initialised once and only ever used by completed calls of this function (every call leaves it clean again)
-    if (!(flags & VHAP_RASTER_WS_CLEAN)) {
-        vhap_zero_async(w + l.hdr, l.offsets - l.hdr, st);
-        VHAP_LAUNCH_CHECK();
-    }
     const dim3 gbin(vhap_cdiv(F, BIN_THREADS), B);
     const bool use_lds = nbin <= LDS_BIN_LIMIT;
-    const size_t fill_lds = use_lds ? 2 * sizeof(unsigned) * nbin : 0;
-    if (fill_lds > 65536) {  // raise the dynamic-LDS cap (160 KiB per CU on gfx950)
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(bin_fill_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)fill_lds) != hipSuccess)
+    const int nfrag = (int)gbin.x;
+    const size_t region = cap / ((size_t)B * nfrag);       // pair-list entries owned by one (frame, 1024-triangle workgroup)
+    const bool fragmented = use_lds && nfrag <= 64 && region >= 1 && !(vhap_g_debug_flags & 4096);   // (flag 4096: A/B switch)
+    P.frag = nullptr;
+    P.nfrag = nfrag;
+    if (fragmented) {
+        // binning in ONE launch: per-workgroup regions of the pair list, fragment descriptors instead of global counters
+        const size_t lds = sizeof(unsigned) * nbin;
+        if (lds > 65536 &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(bin_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return VHAP_E_HIP;
+        uint2* frag = reinterpret_cast<uint2*>(w + l.frag);
+        bin_build_kernel<<<gbin, BIN_THREADS, lds, st>>>(P.pos, P.tri, P.tri_uv, P.V, F, P.H, P.W, P.nbx, P.nby, trange, records, frag, list,
+                                                        (unsigned)region);
+        VHAP_LAUNCH_CHECK();
+        P.frag = frag;
+    } else {
+        // header, counts and cursors are contiguous: one zero-fill launch -- skipped when the caller vouches that the workspace was
+        // zero-initialised once and only ever used by completed calls of this function (every call leaves it clean again)
+        if (!(flags & VHAP_RASTER_WS_CLEAN)) {
+            vhap_zero_async(w + l.hdr, l.offsets - l.hdr, st);
+            VHAP_LAUNCH_CHECK();
+        }
+        const size_t fill_lds = use_lds ? 2 * sizeof(unsigned) * nbin : 0;
+        if (fill_lds > 65536) {  // raise the dynamic-LDS cap (160 KiB per CU on gfx950)
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(bin_fill_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)fill_lds) != hipSuccess)
+                return VHAP_E_HIP;
+        }
+        bin_count_kernel<<<gbin, BIN_THREADS, use_lds ? sizeof(unsigned) * nbin : 0, st>>>(P.pos, P.tri, P.tri_uv, P.V, F, P.H, P.W, P.nbx,
+                                                                                        P.nby, counts, trange, records, hdr);
+        VHAP_LAUNCH_CHECK();
+        bin_scan_kernel<<<vhap_cdiv((long long)B * nbin, 256), 256, 0, st>>>(counts, offsets, B * nbin, hdr);
+        VHAP_LAUNCH_CHECK();
+        bin_fill_kernel<<<gbin, BIN_THREADS, fill_lds, st>>>(trange, F, P.nbx, P.nby, offsets, cursors, list, hdr, (unsigned)cap);
+        VHAP_LAUNCH_CHECK();
     }
-    bin_count_kernel<<<gbin, BIN_THREADS, use_lds ? sizeof(unsigned) * nbin : 0, st>>>(P.pos, P.tri, P.tri_uv, P.V, F, P.H, P.W, P.nbx,
-                                                                                    P.nby, counts, trange, records, hdr);
-    VHAP_LAUNCH_CHECK();
-    bin_scan_kernel<<<vhap_cdiv((long long)B * nbin, 256), 256, 0, st>>>(counts, offsets, B * nbin, hdr);
-    VHAP_LAUNCH_CHECK();
-    bin_fill_kernel<<<gbin, BIN_THREADS, fill_lds, st>>>(trange, F, P.nbx, P.nby, offsets, cursors, list, hdr, (unsigned)cap);
-    VHAP_LAUNCH_CHECK();
     P.counts = counts;
     P.counts_w = counts;
     P.cursors_w = cursors;
