@@ -136,9 +136,12 @@ int vhap_texture_mip_fold(float* d_tex, float* d_mips, int TB, int Ht, int Wt, i
  *   opp [F,3] int32 = static edge->opposite-vertex table (-1 = boundary edge) built once on the
  *   host from the fixed topology (vhap_amd.topology.build_opposite_table) -- it replaces the
  *   edge hash nvdiffrast rebuilds on every call.
- *   work: caller-owned int32 buffer of vhap_antialias_work_ints(B,H,W) ints; the forward records
- *   the pixel pairs it blended there and the backward replays them.
- * Backward: d_color [B,H,W,C] overwritten; d_pos [B,V,4] ACCUMULATED (caller zero-fills).
+ *   work: caller-owned int32 buffer of vhap_antialias_work_ints(B,H,W,F) ints (contents need not be
+ *   initialised): the forward keeps its silhouette table and candidate list there and records the pixel
+ *   pairs it blended; the backward replays them.
+ * Backward: d_color [B,H,W,C] overwritten; d_pos [B,V,4] ACCUMULATED (caller zero-fills);
+ *   pos_nograd_verts [V] uint8 or NULL: vertices whose position receives no silhouette gradient (the
+ *   reference detaches them beforehand, render_nvdiffrast.py:462-464).
  * ------------------------------------------------------------------------------------------- */
 size_t vhap_antialias_work_ints(int B, int H, int W, int F);
 int vhap_antialias_fwd(const float* color, const float* rast, const float* pos,
