@@ -241,7 +241,8 @@ int vhap_disturb_bwd(const float* d_out, const float* keep, int B, int H, int W,
  * energies compute_pose_smooth_energy / compute_joint_smooth_energy / compute_expr_smooth_energy /
  * compute_joint_L2_energy / reg_expr / reg_shape (vhap/model/tracker.py:486-500, 616-680).
  *   timesteps [B] int64 rows of the [N,*] parameter arrays; previous frame = max(t - 1, 0), detached
- *   JT [J,3] = J_regressor v_template; JS [3J, NS+NE] = J_regressor shapedirs; Jreg [J,V] (only with static_offset)
+ *   JT [J,3] = J_regressor v_template; JS [3J, NS+NE] = J_regressor shapedirs; jreg_idx [M] / jreg_w [M,J]: the M vertices
+ *   with a non-zero J_regressor column and their weights (only used with static_offset)
  *   weights[12]: VHAP_FW_* (0 disables a term); parents[J]
  *   coef [Bp,Kp] (rows >= B zero-filled), A [B,J,12], transl [B,3], Jrest [B,J,3] (saved for the backward),
  *   terms[6] = smooth_pose, reg_joint, smooth_joint, reg_expr, smooth_expr, reg_shape (weighted)
@@ -256,14 +257,16 @@ enum {
 int vhap_frame_prep_fwd(const int64_t* timesteps, const float* shape, const float* expr,
                         const float* rotation, const float* translation, const float* neck,
                         const float* jaw, const float* eyes, const float* JT, const float* JS,
-                        const float* Jreg, const float* static_offset, const int32_t* parents,
+                        const int32_t* jreg_idx, const float* jreg_w, int jreg_n,
+                        const float* static_offset, const int32_t* parents,
                         const float* weights, int B, int Bp, int N, int NS, int NE, int J, int Kp, int V,
                         float* coef, float* A, float* transl, float* Jrest, float* terms,
                         vhap_stream_t stream);
 int vhap_frame_prep_bwd(const int64_t* timesteps, const float* shape, const float* expr,
                         const float* rotation, const float* translation, const float* neck,
-                        const float* jaw, const float* eyes, const float* JS, const float* Jreg,
-                        const float* static_offset, const int32_t* parents, const float* weights,
+                        const float* jaw, const float* eyes, const float* JS, const int32_t* jreg_idx,
+                        const float* jreg_w, int jreg_n, const float* static_offset,
+                        const int32_t* parents, const float* weights,
                         const float* Jrest, const float* d_coef, const float* d_A, const float* d_transl,
                         const float* d_terms, int B, int Bp, int N, int NS, int NE, int J, int Kp, int V,
                         float* g_shape, float* g_expr, float* g_rotation, float* g_translation,

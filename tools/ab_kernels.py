@@ -12,7 +12,7 @@ if "--report" in sys.argv:
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     starts = [i for i, r in enumerate(rows) if "frame_prep_fwd" in r["Kernel_Name"]]
     starts = starts[-len(flags) * STEPS:] + [len(rows)]
-    want = ("texture_bwd", "gbuffer_bwd", "aa_", "bin_", "shade_", "disturb_", "frame_prep", "tex_prep", "raster_kernel", "flame_skin_fwd",
+    want = ("texture_bwd", "gbuffer_bwd", "aa_", "bin_", "shade_", "disturb_", "frame_prep", "tex_prep", "offset_reg", "landmark", "raster_kernel", "flame_skin_fwd",
             "mip_fold_tail", "adam_kernel", "photo_", "texture_fwd", "aa_bwd")
     for fi, f in enumerate(flags):
         agg = collections.defaultdict(list)

@@ -53,8 +53,8 @@ SIGNATURES = {
     "vhap_transform_bwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
     "vhap_vnormal_fwd": (c_i, [c_fp] * 4 + [c_i, c_i, c_fp, c_fp]),
     "vhap_vnormal_bwd": (c_i, [c_fp] * 5 + [c_i, c_i, c_i, c_fp, c_fp, c_fp]),
-    "vhap_frame_prep_fwd": (c_i, [c_fp] * 14 + [c_i] * 8 + [c_fp] * 6),
-    "vhap_frame_prep_bwd": (c_i, [c_fp] * 18 + [c_i] * 8 + [c_fp] * 9),
+    "vhap_frame_prep_fwd": (c_i, [c_fp] * 12 + [c_i] + [c_fp] * 3 + [c_i] * 8 + [c_fp] * 6),
+    "vhap_frame_prep_bwd": (c_i, [c_fp] * 11 + [c_i] + [c_fp] * 8 + [c_i] * 8 + [c_fp] * 9),
     "vhap_camera_fwd": (c_i, [c_fp, c_fp] + [c_i] * 5 + [c_f, c_f, c_fp, c_fp]),
     "vhap_camera_bwd": (c_i, [c_fp, c_fp] + [c_i] * 4 + [c_fp, c_fp]),
     "vhap_landmark_fwd": (c_i, [c_fp] * 5 + [c_i] * 8 + [c_f, c_i, c_i] + [c_fp] * 3),

@@ -112,7 +112,9 @@ __device__ __forceinline__ constexpr int flame_parent(int j) { return j == 0 ? -
 struct FrameIn {
     const long long* ts;
     const float *shape, *expr, *rotation, *translation, *neck, *jaw, *eyes;
-    const float *JT, *JS, *Jreg, *offset;   // [J,3], [3J, NS+NE], [J,V] (may be null with offset), [V,3] or null
+    const float *JT, *JS, *Jw, *offset;     // [J,3], [3J, NS+NE], [M,J] weights of the M vertices with a non-zero J_regressor column, [V,3] or null
+    const int* Jv;                          // [M] their vertex ids
+    int M;
 };
 
 __device__ __forceinline__ void gather_pose(const FrameIn& in, long long t, float* pose /*15*/) {
@@ -183,13 +185,14 @@ __global__ __launch_bounds__(FP_THREADS) void frame_prep_fwd_kernel(FrameCfg cfg
             for (int o = 0; o < 3 * MAXJ; o++)
                 if (o < 3 * cfg.J) part[o] += in.JS[(size_t)o * NB + k] * bk;
         }
-        if (in.offset) {
-            for (int v = tid; v < cfg.V; v += FP_THREADS) {
+        if (in.offset) {        // J_regressor is sparse (a few hundred non-zero columns): compact list instead of a walk over all V
+            for (int m = tid; m < in.M; m += FP_THREADS) {
+                const int v = in.Jv[m];
                 const float o0 = in.offset[3 * v], o1 = in.offset[3 * v + 1], o2 = in.offset[3 * v + 2];
 #pragma unroll
                 for (int j = 0; j < MAXJ; j++) {
                     if (j < cfg.J) {
-                        const float wv = in.Jreg[(size_t)j * cfg.V + v];
+                        const float wv = in.Jw[(size_t)m * cfg.J + j];
                         part[3 * j] += wv * o0; part[3 * j + 1] += wv * o1; part[3 * j + 2] += wv * o2;
                     }
                 }
@@ -226,8 +229,26 @@ __global__ __launch_bounds__(FP_THREADS) void frame_prep_fwd_kernel(FrameCfg cfg
         spose[which][i] = v;
     }
     __syncthreads();
+    // ---- lanes 0..J-1: one joint each (Rodrigues, pose feature, ||R - I||^2) -- the same code once instead of J unrolled
+    // copies on one lane: these kernels run ONE wave per frame through tens of KB of straight-line code, instruction fetch
+    // of cold code was most of their time ----
+    __shared__ float sR[MAXJ][9], sreg[MAXJ];
+    if (tid < cfg.J) {
+        const int j = tid;
+        const Mat3 R = rodrigues(&spose[0][3 * j]);
+        float fro = 0.f;
+#pragma unroll
+        for (int i = 0; i < 9; i++) {
+            const float d = R.m[i] - ((i % 4 == 0) ? 1.0f : 0.0f);
+            if (j > 0) row[NB + 9 * (j - 1) + i] = d;
+            fro += d * d;
+            sR[j][i] = R.m[i];
+        }
+        sreg[j] = fro;
+    }
+    __syncthreads();
     if (tid != 0) return;
-    // ---- lane 0: rotations, chain, parameter energies ----
+    // ---- lane 0: kinematic chain, parameter energies ----
     float pose[3 * MAXJ], prev[3 * MAXJ];
 #pragma unroll
     for (int i = 0; i < 15; i++) { pose[i] = spose[0][i]; prev[i] = spose[1][i]; }
@@ -237,15 +258,10 @@ __global__ __launch_bounds__(FP_THREADS) void frame_prep_fwd_kernel(FrameCfg cfg
 #pragma unroll
     for (int j = 0; j < (JT ? JT : MAXJ); j++) {
         if (!JT && j >= cfg.J) break;
-        const Mat3 R = rodrigues(pose + 3 * j);
-        float fro = 0.f;
+        Mat3 R;
 #pragma unroll
-        for (int i = 0; i < 9; i++) {
-            const float d = R.m[i] - ((i % 4 == 0) ? 1.0f : 0.0f);
-            if (j > 0) row[NB + 9 * (j - 1) + i] = d;
-            fro += d * d;
-        }
-        reg_R[j] = fro;
+        for (int i = 0; i < 9; i++) R.m[i] = sR[j][i];
+        reg_R[j] = sreg[j];
         const int par = JT ? flame_parent(j) : cfg.parents[j];
         if (j == 0) {
             GR[0] = R;
@@ -337,20 +353,27 @@ __global__ __launch_bounds__(FP_THREADS) void frame_prep_bwd_kernel(FrameCfg cfg
     for (int i = tid; i < cfg.P; i += FP_THREADS) sdpf[i] = drow ? drow[NB + i] : 0.f;
     if (tid < 3) sdt[tid] = d_transl ? d_transl[3 * b + tid] : 0.f;
     __syncthreads();
-    if (tid == 0) {
-        float pose[3 * MAXJ], prev[3 * MAXJ], dpose[3 * MAXJ];
+    // lanes 0..J-1: R_j (one Rodrigues per lane, SIMD) -> LDS;  lane 0: chain forward + reverse -> dR_j in LDS;
+    // lanes 0..J-1: reverse of Rodrigues + the direct pose terms + the scatter (see frame_prep_fwd_kernel for why)
+    __shared__ float sR[MAXJ][9], sdR[MAXJ][9];
+    if (tid < cfg.J) {
+        const Mat3 R = rodrigues(&spose[0][3 * tid]);
 #pragma unroll
-        for (int i = 0; i < 15; i++) { pose[i] = spose[0][i]; prev[i] = spose[1][i]; }
+        for (int i = 0; i < 9; i++) sR[tid][i] = R.m[i];
+    }
+    __syncthreads();
+    if (tid == 0) {
         const float* Jl = sJ;
         Mat3 R[MAXJ], GR[MAXJ], dGR[MAXJ];
         float dGt[MAXJ][3], dJ[3 * MAXJ];
 #pragma unroll
         for (int j = 0; j < (JT ? JT : MAXJ); j++) {
             if (!JT && j >= cfg.J) break;
-            R[j] = rodrigues(pose + 3 * j);
+#pragma unroll
+            for (int i = 0; i < 9; i++) R[j].m[i] = sR[j][i];
             GR[j] = j == 0 ? R[0] : mul(GR[JT ? (j ? flame_parent(j) : 0) : cfg.parents[j]], R[j]);
 #pragma unroll
-            for (int c = 0; c < 3; c++) { dJ[3 * j + c] = 0.f; dpose[3 * j + c] = 0.f; }
+            for (int c = 0; c < 3; c++) dJ[3 * j + c] = 0.f;
         }
         // A_j = [GR_j | Gt_j - GR_j J_j]
 #pragma unroll
@@ -370,7 +393,6 @@ __global__ __launch_bounds__(FP_THREADS) void frame_prep_bwd_kernel(FrameCfg cfg
 #pragma unroll
             for (int c = 0; c < 3; c++) dJ[3 * j + c] -= v[c];
         }
-        const float dn9 = 1.0f / (9.0f * (float)(2 * cfg.B - 1));
 #pragma unroll
         for (int jj = 0; jj < (JT ? JT : MAXJ); jj++) {
             const int j = (JT ? JT : cfg.J) - 1 - jj;
@@ -399,52 +421,66 @@ __global__ __launch_bounds__(FP_THREADS) void frame_prep_bwd_kernel(FrameCfg cfg
 #pragma unroll
                 for (int c = 0; c < 3; c++) dJ[c] += dGt[0][c];
             }
-            if (j > 0) {
-                // pose feature (R_j - I) feeds the corrective blendshapes; ||I - R_j||^2 is the joint regulariser
-                float wj = 0.f;
-                if (cfg.J == 5) wj = (j == 1 ? w[VHAP_FW_REG_NECK] : (j == 2 ? w[VHAP_FW_REG_JAW] : w[VHAP_FW_REG_EYES])) * dn9 * dt_[1];
 #pragma unroll
-                for (int i = 0; i < 9; i++) {
-                    dR.m[i] += sdpf[9 * (j - 1) + i];
-                    dR.m[i] += 2.0f * wj * (R[j].m[i] - ((i % 4 == 0) ? 1.0f : 0.0f));
-                }
+            for (int i = 0; i < 9; i++) sdR[j][i] = dR.m[i];
+        }
+        for (int o = 0; o < 3 * cfg.J; o++) dJl[o] = dJ[o];
+    }
+    __syncthreads();
+    if (tid < cfg.J) {
+        const int j = tid;
+        const float* pj = &spose[0][3 * j];
+        const float* qj = &spose[1][3 * j];
+        Mat3 dR;
+#pragma unroll
+        for (int i = 0; i < 9; i++) dR.m[i] = sdR[j][i];
+        if (j > 0) {
+            // pose feature (R_j - I) feeds the corrective blendshapes; ||I - R_j||^2 is the joint regulariser
+            const float dn9 = 1.0f / (9.0f * (float)(2 * cfg.B - 1));
+            float wj = 0.f;
+            if (cfg.J == 5) wj = (j == 1 ? w[VHAP_FW_REG_NECK] : (j == 2 ? w[VHAP_FW_REG_JAW] : w[VHAP_FW_REG_EYES])) * dn9 * dt_[1];
+#pragma unroll
+            for (int i = 0; i < 9; i++) {
+                dR.m[i] += sdpf[9 * (j - 1) + i];
+                dR.m[i] += 2.0f * wj * (sR[j][i] - ((i % 4 == 0) ? 1.0f : 0.0f));
             }
-            rodrigues_bwd(pose + 3 * j, dR, dpose + 3 * j);
         }
-        // direct terms on the pose vectors
+        float dp[3] = {0.f, 0.f, 0.f};
+        rodrigues_bwd(pj, dR, dp);
+        // direct terms on the pose vectors (joint order: root rotation, neck, jaw, left eye, right eye)
         const float k3 = 2.0f * iB * (1.0f / 3.0f);
+        float ws = 0.f;     // smoothness weight x upstream gradient of this joint's pose vector
+        if (j == 0) ws = k3 * w[VHAP_FW_SMOOTH_ROT] * dt_[0];
+        else if (j == 1) ws = k3 * w[VHAP_FW_SMOOTH_NECK] * dt_[2];
+        else if (j == 2) ws = k3 * w[VHAP_FW_SMOOTH_JAW] * dt_[2];
+        else ws = 0.5f * k3 * w[VHAP_FW_SMOOTH_EYES] * dt_[2];
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
-            dpose[c] += k3 * w[VHAP_FW_SMOOTH_ROT] * dt_[0] * (pose[c] - prev[c]);
-            dpose[3 + c] += k3 * w[VHAP_FW_SMOOTH_NECK] * dt_[2] * (pose[3 + c] - prev[3 + c]);
-            dpose[6 + c] += k3 * w[VHAP_FW_SMOOTH_JAW] * dt_[2] * (pose[6 + c] - prev[6 + c]);
-            dpose[9 + c] += 0.5f * k3 * w[VHAP_FW_SMOOTH_EYES] * dt_[2] * (pose[9 + c] - prev[9 + c]);
-            dpose[12 + c] += 0.5f * k3 * w[VHAP_FW_SMOOTH_EYES] * dt_[2] * (pose[12 + c] - prev[12 + c]);
-        }
+        for (int c = 0; c < 3; c++) dp[c] += ws * (pj[c] - qj[c]);
         if (cfg.J == 5) {
             const float wjaw = w[VHAP_FW_REG_JAW] * dt_[1], weye = w[VHAP_FW_REG_EYES] * dt_[1];
-            if (pose[6] < 0.f) dpose[6] -= 10.0f * iB * wjaw;
-            dpose[7] += 3.0f * iB * wjaw * pose[7];      // d/dx of 3 * mean over (B, 2) of x^2
-            dpose[8] += 3.0f * iB * wjaw * pose[8];
+            if (j == 2) {
+                if (pj[0] < 0.f) dp[0] -= 10.0f * iB * wjaw;
+                dp[1] += 3.0f * iB * wjaw * pj[1];      // d/dx of 3 * mean over (B, 2) of x^2
+                dp[2] += 3.0f * iB * wjaw * pj[2];
+            } else if (j >= 3) {
+                const float* other = &spose[0][j == 3 ? 12 : 9];
 #pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const float d = 2.0f * weye * 2.0f * iB * (1.0f / 3.0f) * (pose[9 + c] - pose[12 + c]);
-                dpose[9 + c] += d;
-                dpose[12 + c] -= d;
+                for (int c = 0; c < 3; c++) dp[c] += 2.0f * weye * 2.0f * iB * (1.0f / 3.0f) * (pj[c] - other[c]);
             }
         }
+        float* dst = j == 0 ? g.rotation : (j == 1 ? g.neck : (j == 2 ? g.jaw : g.eyes));
+        if (dst && j < 5) {
+            const size_t o = j < 3 ? (size_t)3 * t : (size_t)6 * t + (j == 4 ? 3 : 0);
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
-            if (g.rotation) atomicAdd(&g.rotation[3 * t + c], dpose[c]);
-            if (g.neck) atomicAdd(&g.neck[3 * t + c], dpose[3 + c]);
-            if (g.jaw) atomicAdd(&g.jaw[3 * t + c], dpose[6 + c]);
-            if (g.eyes) { atomicAdd(&g.eyes[6 * t + c], dpose[9 + c]); atomicAdd(&g.eyes[6 * t + 3 + c], dpose[12 + c]); }
-            if (g.translation) {
+            for (int c = 0; c < 3; c++) atomicAdd(&dst[o + c], dp[c]);
+        }
+        if (j == 0 && g.translation) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
                 const float dtr = sdt[c] + k3 * w[VHAP_FW_SMOOTH_TRANS] * dt_[0] * (spose[0][15 + c] - spose[1][15 + c]);
                 atomicAdd(&g.translation[3 * t + c], dtr);
             }
         }
-        for (int o = 0; o < 3 * cfg.J; o++) dJl[o] = dJ[o];
     }
     __syncthreads();
     // betas: blend-kernel gradient + joint regression + L2 / smoothness
@@ -463,19 +499,14 @@ __global__ __launch_bounds__(FP_THREADS) void frame_prep_bwd_kernel(FrameCfg cfg
         }
     }
     if (g.offset && in.offset) {
-        for (int v = tid; v < cfg.V; v += FP_THREADS) {
+        for (int m = tid; m < in.M; m += FP_THREADS) {
+            const int v = in.Jv[m];
             float a[3] = {0.f, 0.f, 0.f};
-            bool any = false;
             for (int j = 0; j < cfg.J; j++) {
-                const float wv = in.Jreg[(size_t)j * cfg.V + v];
-                if (wv != 0.f) {
-                    any = true;
-                    a[0] += wv * dJl[3 * j]; a[1] += wv * dJl[3 * j + 1]; a[2] += wv * dJl[3 * j + 2];
-                }
+                const float wv = in.Jw[(size_t)m * cfg.J + j];
+                a[0] += wv * dJl[3 * j]; a[1] += wv * dJl[3 * j + 1]; a[2] += wv * dJl[3 * j + 2];
             }
-            if (any) {
-                atomicAdd(&g.offset[3 * v], a[0]); atomicAdd(&g.offset[3 * v + 1], a[1]); atomicAdd(&g.offset[3 * v + 2], a[2]);
-            }
+            atomicAdd(&g.offset[3 * v], a[0]); atomicAdd(&g.offset[3 * v + 1], a[1]); atomicAdd(&g.offset[3 * v + 2], a[2]);
         }
     }
 }
@@ -494,18 +525,18 @@ bool make_cfg(FrameCfg& c, int B, int Bp, int N, int NS, int NE, int J, int Kp, 
 
 extern "C" int vhap_frame_prep_fwd(const int64_t* timesteps, const float* shape, const float* expr, const float* rotation,
                                    const float* translation, const float* neck, const float* jaw, const float* eyes,
-                                   const float* JT, const float* JS, const float* Jreg, const float* static_offset,
-                                   const int32_t* parents, const float* weights, int B, int Bp, int N, int NS, int NE, int J,
-                                   int Kp, int V, float* coef, float* A, float* transl, float* Jrest, float* terms,
+                                   const float* JT, const float* JS, const int32_t* jreg_idx, const float* jreg_w, int jreg_n,
+                                   const float* static_offset, const int32_t* parents, const float* weights, int B, int Bp, int N,
+                                   int NS, int NE, int J, int Kp, int V, float* coef, float* A, float* transl, float* Jrest, float* terms,
                                    vhap_stream_t stream) {
     VHAP_ENTER();
     if (!timesteps || !shape || !expr || !rotation || !translation || !neck || !jaw || !eyes || !JT || !JS || !coef || !A ||
         !transl || !Jrest || !terms)
         return VHAP_E_NULLPTR;
-    if (static_offset && !Jreg) return VHAP_E_NULLPTR;
+    if (static_offset && jreg_n > 0 && (!jreg_idx || !jreg_w)) return VHAP_E_NULLPTR;
     FrameCfg cfg;
     if (!make_cfg(cfg, B, Bp, N, NS, NE, J, Kp, V, parents, weights)) return VHAP_E_BADDIM;
-    FrameIn in{reinterpret_cast<const long long*>(timesteps), shape, expr, rotation, translation, neck, jaw, eyes, JT, JS, Jreg, static_offset};
+    FrameIn in{reinterpret_cast<const long long*>(timesteps), shape, expr, rotation, translation, neck, jaw, eyes, JT, JS, jreg_w, static_offset, jreg_idx, jreg_n};
     hipStream_t st = vhap_stream(stream);
     vhap_zero_async(terms, 6 * sizeof(float), st);
     VHAP_LAUNCH_CHECK();
@@ -518,17 +549,17 @@ extern "C" int vhap_frame_prep_fwd(const int64_t* timesteps, const float* shape,
 
 extern "C" int vhap_frame_prep_bwd(const int64_t* timesteps, const float* shape, const float* expr, const float* rotation,
                                    const float* translation, const float* neck, const float* jaw, const float* eyes,
-                                   const float* JS, const float* Jreg, const float* static_offset, const int32_t* parents,
-                                   const float* weights, const float* Jrest, const float* d_coef, const float* d_A,
+                                   const float* JS, const int32_t* jreg_idx, const float* jreg_w, int jreg_n, const float* static_offset,
+                                   const int32_t* parents, const float* weights, const float* Jrest, const float* d_coef, const float* d_A,
                                    const float* d_transl, const float* d_terms, int B, int Bp, int N, int NS, int NE, int J, int Kp,
                                    int V, float* g_shape, float* g_expr, float* g_rotation, float* g_translation, float* g_neck,
                                    float* g_jaw, float* g_eyes, float* g_offset, vhap_stream_t stream) {
     VHAP_ENTER();
     if (!timesteps || !shape || !expr || !rotation || !translation || !neck || !jaw || !eyes || !JS || !Jrest) return VHAP_E_NULLPTR;
-    if (g_offset && (!Jreg || !static_offset)) return VHAP_E_NULLPTR;
+    if (g_offset && (!static_offset || (jreg_n > 0 && (!jreg_idx || !jreg_w)))) return VHAP_E_NULLPTR;
     FrameCfg cfg;
     if (!make_cfg(cfg, B, Bp, N, NS, NE, J, Kp, V, parents, weights)) return VHAP_E_BADDIM;
-    FrameIn in{reinterpret_cast<const long long*>(timesteps), shape, expr, rotation, translation, neck, jaw, eyes, nullptr, JS, Jreg, static_offset};
+    FrameIn in{reinterpret_cast<const long long*>(timesteps), shape, expr, rotation, translation, neck, jaw, eyes, nullptr, JS, jreg_w, static_offset, jreg_idx, jreg_n};
     FrameGrad g{g_shape, g_expr, g_rotation, g_translation, g_neck, g_jaw, g_eyes, g_offset};
     const bool flame_tree = J == 5 && parents[1] == 0 && parents[2] == 1 && parents[3] == 1 && parents[4] == 1;
     if (flame_tree) frame_prep_bwd_kernel<5><<<B, FP_THREADS, 0, vhap_stream(stream)>>>(cfg, in, Jrest, d_coef, d_A, d_transl, d_terms, g);

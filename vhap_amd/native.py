@@ -41,7 +41,10 @@ class FrameModel:
     def __init__(self, fb, J_regressor, parents):
         self.fb = fb
         self.JT, self.JS = fb.JT.contiguous(), fb.JS.contiguous()
-        self.Jreg = J_regressor.contiguous()
+        nzv = (J_regressor != 0).any(dim=0).nonzero().reshape(-1)             # J_regressor is sparse: compact column list
+        self.jreg_idx = nzv.int().contiguous()
+        self.jreg_w = J_regressor[:, nzv].t().contiguous()                     # [M,J]
+        self.jreg_n = int(nzv.numel())
         self.J = int(J_regressor.shape[0])
         self.parents = (ctypes.c_int32 * self.J)(*[int(p) for p in parents])
         self.V = int(J_regressor.shape[1])
@@ -60,7 +63,7 @@ class _FramePrep(torch.autograd.Function):
         small = torch.empty(B * 3 + B * fm.J * 3 + 6, dtype=torch.float32, device=dev)
         transl, Jrest, terms = small[:B * 3].view(B, 3), small[B * 3:B * 3 + B * fm.J * 3], small[-6:]
         _chk(_lib.lib().vhap_frame_prep_fwd(_p(ts), _p(shape), _p(expr), _p(rotation), _p(translation), _p(neck), _p(jaw), _p(eyes),
-                                            _p(fm.JT), _p(fm.JS), _p(fm.Jreg), _p(offset), fm.parents, weights, B, Bp, N, NS, NE,
+                                            _p(fm.JT), _p(fm.JS), _p(fm.jreg_idx), _p(fm.jreg_w), fm.jreg_n, _p(offset), fm.parents, weights, B, Bp, N, NS, NE,
                                             fm.J, fb.Kp, fm.V, _p(coef), _p(A), _p(transl), _p(Jrest), _p(terms), _stream()),
              "vhap_frame_prep_fwd")
         ctx.fm, ctx.weights, ctx.dims = fm, weights, (B, Bp, N, NS, NE)
@@ -83,7 +86,7 @@ class _FramePrep(torch.autograd.Function):
             o += s
         c = lambda t: _f32c(t) if t is not None else None
         _chk(_lib.lib().vhap_frame_prep_bwd(_p(ts), _p(shape), _p(expr), _p(rotation), _p(translation), _p(neck), _p(jaw), _p(eyes),
-                                            _p(fm.JS), _p(fm.Jreg), _p(offset), fm.parents, ctx.weights, _p(Jrest), _p(c(d_coef)),
+                                            _p(fm.JS), _p(fm.jreg_idx), _p(fm.jreg_w), fm.jreg_n, _p(offset), fm.parents, ctx.weights, _p(Jrest), _p(c(d_coef)),
                                             _p(c(d_A)), _p(c(d_transl)), _p(c(d_terms)), B, Bp, N, NS, NE, fm.J, fb.Kp, fm.V,
                                             *[_p(g) for g in grads], _stream()), "vhap_frame_prep_bwd")
         return (None, None, None, *grads)
