@@ -324,6 +324,37 @@ int vhap_adam_step(int n_tensors, float* const* params, const float* const* grad
                    const float* lr_device, int32_t* step_device, float beta1, float beta2, float eps,
                    vhap_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Step glue (vhap_amd/csrc/step.hip, misc.hip) for an executor that chains the stages itself instead of torch autograd
+ * (vhap_amd/step.py): the assembly of the total energy (tracker.py:692-750), the batch-global photometric normaliser
+ * (tracker.py:430-439), the static-offset gradient summed over frames and the focal-length gradient (tracker.py:141-157).
+ *
+ * vhap_set_call_flags(VHAP_CALL_ACC_PREZEROED): process-wide; while set, the entry points that normally clear their small
+ *   accumulators first (terms / energy / stats / out2 of frame_prep, landmark, tex_prep, offset_reg, shade, photo; d_coef of
+ *   flame_skin_bwd) skip that launch -- the caller hands in accumulators from an arena it cleared with ONE launch.
+ * vhap_energy_finalize: log[VHAP_LOG_COUNT] <- the weighted terms (any input may be NULL = term absent); log[VHAP_LOG_REST] = sum
+ *   of everything but the photometric term.
+ * vhap_energy_total: inv_n = world_size / (3 n_global); log[PHOTO] = w_photo * photo2[0] * inv_n; log[TOTAL]; d_sum[0] = w_photo * inv_n
+ *   (the upstream gradient handed to vhap_photo_bwd).
+ * ------------------------------------------------------------------------------------------- */
+#define VHAP_CALL_ACC_PREZEROED 1
+enum {
+    VHAP_LOG_LMK = 0, VHAP_LOG_PHOTO = 1, VHAP_LOG_SMOOTH_POSE = 2, VHAP_LOG_REG_JOINT = 3, VHAP_LOG_SMOOTH_JOINT = 4,
+    VHAP_LOG_REG_EXPR = 5, VHAP_LOG_SMOOTH_EXPR = 6, VHAP_LOG_REG_SHAPE = 7, VHAP_LOG_TEX_TV = 8, VHAP_LOG_TEX_RES = 9,
+    VHAP_LOG_REG_DIFFUSE = 10, VHAP_LOG_OFF_LAP = 11, VHAP_LOG_OFF_ABS = 12, VHAP_LOG_OFF_RIGID = 13, VHAP_LOG_REST = 14,
+    VHAP_LOG_TOTAL = 15, VHAP_LOG_COUNT = 16
+};
+void vhap_set_call_flags(int flags);
+int vhap_energy_finalize(const float* frame_terms, const float* lmk_energy, const float* tex_terms,
+                         const float* off_terms, const float* shade_stats, float w_landmark,
+                         float w_reg_diffuse, int B, int H, int W, float* log, vhap_stream_t stream);
+int vhap_energy_total(float* log, const float* photo2, const float* n_global, float w_photo, int world_size,
+                      float* d_sum, vhap_stream_t stream);
+/* out_accum[i] += sum_b x[b][i]  (x [B,n]) */
+int vhap_sum_frames(const float* x, int B, int n, float* out_accum, vhap_stream_t stream);
+/* d_focal_accum[0] += scale * sum_b (d_K[b][0] + d_K[b][1])   (K = (f, f, cx, cy), f = focal_length * scale) */
+int vhap_focal_bwd(const float* d_K, int B, float scale, float* d_focal_accum, vhap_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -105,3 +105,35 @@ def test_hip_adam_matches_torch_adam():
         for a, b in zip(p_ref, p_hip):
             assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(a.abs().max())), f"step {it}"
     assert int(o_hip.step_count) == 6
+
+
+def test_native_step_matches_autograd_step(tracker):
+    """NativeStep (hand-chained C calls, arenas, in-place gradient accumulation) == the autograd formulation of the same step:
+    every energy term and every parameter gradient."""
+    from vhap_amd.step import LOG_NAMES, NativeStep
+    tr = tracker
+    stage = "rgb_global_tracking"
+    rates = (tr.render.disturb_rate_fg, tr.render.disturb_rate_bg)
+    tr.render.disturb_rate_fg = tr.render.disturb_rate_bg = None          # in-kernel random numbers differ between two runs
+    try:
+        ts = np.array([1, 2, 3])
+        E0, log0, g0, _ = _run(tr, stage, ts, True, None)
+        assert NativeStep.supported(tr, stage)
+        sample = tr.get_sample(ts, device_index=True)
+        ns = NativeStep(tr, sample, stage)
+        for _ in range(2):                                                 # twice: the arenas must be cleared correctly
+            ns.forward()
+            ns.backward(1)
+        torch.cuda.synchronize()
+        log1 = {k: float(v) for k, v in ns.log_dict().items()}
+        for k, v in log0.items():
+            assert abs(v - log1[k]) <= 1e-4 * max(abs(v), 1e-4), f"term {k}: autograd {v} native step {log1[k]}"
+        for k in NAMES:
+            a, b = g0[k], ns.g[k]
+            assert a is not None
+            rel = float((a - b.reshape(a.shape)).abs().max() / (a.abs().max() + 1e-30))
+            assert rel < 2e-3, f"grad {k}: rel {rel:.3e}"
+    finally:
+        tr.render.disturb_rate_fg, tr.render.disturb_rate_bg = rates
+        for p in tr._train_tensors:
+            p.grad = None

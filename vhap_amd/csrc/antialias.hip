@@ -108,8 +108,9 @@ __device__ __forceinline__ Geo analyse(const float4* __restrict__ P, const int* 
 // pixels per triangle at 512^2): one byte per pair decides whether the full edge analysis (8 vertex gathers) is needed at all.
 __global__ __launch_bounds__(256) void aa_silhouette_kernel(const float4* __restrict__ pos, const int* __restrict__ tri,
                                                             const int* __restrict__ opp, int B, int V, int F, int H, int W,
-                                                            unsigned char* __restrict__ sil) {
+                                                            unsigned char* __restrict__ sil, int* __restrict__ work_header) {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < 4) work_header[i] = 0;          // item / candidate counters of this call (the detect pass comes next in stream order)
     if (i >= B * F) return;
     const int b = i / F, t = i - b * F;
     const float4* P = pos + (size_t)b * V;
@@ -347,9 +348,7 @@ extern "C" int vhap_antialias_fwd(const float* color, const float* rast, const f
     hipStream_t st = vhap_stream(stream);
     unsigned char* sil = reinterpret_cast<unsigned char*>(work + 4 + 4 * 2 * (size_t)npix);
     unsigned* cand = reinterpret_cast<unsigned*>(work + 4 + 4 * 2 * (size_t)npix + ((size_t)B * F + 3) / 4);
-    vhap_zero_async(work, 16, st);
-    VHAP_LAUNCH_CHECK();
-    aa_silhouette_kernel<<<vhap_cdiv((long long)B * F, 256), 256, 0, st>>>(reinterpret_cast<const float4*>(pos), tri, opp, B, V, F, H, W, sil);
+    aa_silhouette_kernel<<<vhap_cdiv((long long)B * F, 256), 256, 0, st>>>(reinterpret_cast<const float4*>(pos), tri, opp, B, V, F, H, W, sil, work);
     VHAP_LAUNCH_CHECK();
     const int dbg = vhap_g_debug_flags;
     return dispatch_C(C, [&](auto c) {

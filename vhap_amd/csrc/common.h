@@ -16,6 +16,17 @@
     } while (0)
 
 extern int vhap_g_debug_flags;   // misc.hip
+extern int vhap_g_call_flags;    // misc.hip: VHAP_CALL_* (vhap_set_call_flags)
+
+// zero a small accumulator unless the caller declared that it hands in pre-zeroed accumulators (step executors keep all of them in
+// one arena cleared by a single launch)
+#define VHAP_ZERO_ACC(ptr, bytes, st)                                   \
+    do {                                                                \
+        if (!(vhap_g_call_flags & VHAP_CALL_ACC_PREZEROED)) {           \
+            vhap_zero_async((ptr), (bytes), (st));                      \
+            VHAP_LAUNCH_CHECK();                                        \
+        }                                                               \
+    } while (0)
 
 static inline hipStream_t vhap_stream(vhap_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 

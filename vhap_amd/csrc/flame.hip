@@ -374,8 +374,7 @@ extern "C" int vhap_flame_skin_bwd(const float* d_verts, const float* d_vshaped,
     VHAP_LAUNCH_CHECK();
     (void)partials;                                  // (kept in the signature; the split-K sums go through atomics now)
     const int ntiles = Kp / 16, btiles = (B + 15) / 16;
-    vhap_zero_async(d_coef, sizeof(float) * (size_t)btiles * 16 * Kp, st);
-    VHAP_LAUNCH_CHECK();
+    VHAP_ZERO_ACC(d_coef, sizeof(float) * (size_t)btiles * 16 * Kp, st);
     int S = 768 / (ntiles * btiles);                 // ~768 workgroups in flight
     S = S < 1 ? 1 : S;
     int v_per_wave = (V + S * 4 - 1) / (S * 4);

@@ -538,8 +538,7 @@ extern "C" int vhap_frame_prep_fwd(const int64_t* timesteps, const float* shape,
     if (!make_cfg(cfg, B, Bp, N, NS, NE, J, Kp, V, parents, weights)) return VHAP_E_BADDIM;
     FrameIn in{reinterpret_cast<const long long*>(timesteps), shape, expr, rotation, translation, neck, jaw, eyes, JT, JS, jreg_w, static_offset, jreg_idx, jreg_n};
     hipStream_t st = vhap_stream(stream);
-    vhap_zero_async(terms, 6 * sizeof(float), st);
-    VHAP_LAUNCH_CHECK();
+    VHAP_ZERO_ACC(terms, 6 * sizeof(float), st);
     const bool flame_tree = J == 5 && parents[1] == 0 && parents[2] == 1 && parents[3] == 1 && parents[4] == 1;
     if (flame_tree) frame_prep_fwd_kernel<5><<<Bp, FP_THREADS, 0, st>>>(cfg, in, coef, A, transl, Jrest, terms);
     else frame_prep_fwd_kernel<0><<<Bp, FP_THREADS, 0, st>>>(cfg, in, coef, A, transl, Jrest, terms);
@@ -727,8 +726,7 @@ extern "C" int vhap_landmark_fwd(const float* verts, const int32_t* lmk_vidx, co
     LmkCfg c;
     if (!make_lmk_cfg(c, B, V, L, L2, l0, l1, boost0, boost1, boost, H, W)) return VHAP_E_BADDIM;
     hipStream_t st = vhap_stream(stream);
-    vhap_zero_async(energy, sizeof(float), st);
-    VHAP_LAUNCH_CHECK();
+    VHAP_ZERO_ACC(energy, sizeof(float), st);
     landmark_kernel<<<B, 128, 0, st>>>(c, verts, lmk_vidx, lmk_bary, mvp, lmk2d, lmk3d, energy, nullptr, nullptr, nullptr);
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;

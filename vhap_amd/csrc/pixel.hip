@@ -297,7 +297,7 @@ extern "C" int vhap_shade_fwd(const float* normal_raw, const float* albedo, cons
     ShadeParams P{normal_raw, albedo, reinterpret_cast<const float4*>(rast), bg_image, 0.f, 0.f, 0.f, lights, sh_const, B, H, W};
     if (!bg_image) { P.bg_r = bg_color[0]; P.bg_g = bg_color[1]; P.bg_b = bg_color[2]; }
     hipStream_t st = vhap_stream(stream);
-    if (stats) { vhap_zero_async(stats, 16, st); VHAP_LAUNCH_CHECK(); }
+    if (stats) VHAP_ZERO_ACC(stats, 16, st);
     const long long npix = (long long)B * H * W;
     shade_fwd_kernel<<<min(vhap_cdiv(npix, PB), MAX_BLOCKS), PB, 0, st>>>(P, reinterpret_cast<float4*>(rgba), reinterpret_cast<unsigned*>(stats));
     VHAP_LAUNCH_CHECK();
@@ -324,8 +324,7 @@ extern "C" int vhap_photo_fwd(const float* pred_rgba, const float* gt_nchw, int 
     if (!pred_rgba || !gt_nchw || !out2) return VHAP_E_NULLPTR;
     if (int e = check_img(B, H, W)) return e;
     hipStream_t st = vhap_stream(stream);
-    vhap_zero_async(out2, 8, st);
-    VHAP_LAUNCH_CHECK();
+    VHAP_ZERO_ACC(out2, 8, st);
     const long long npix = (long long)B * H * W;
     photo_fwd_kernel<<<min(vhap_cdiv(npix, PB), MAX_BLOCKS), PB, 0, st>>>(reinterpret_cast<const float4*>(pred_rgba), gt_nchw, B, H, W, out2);
     VHAP_LAUNCH_CHECK();

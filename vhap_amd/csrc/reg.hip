@@ -255,8 +255,7 @@ extern "C" int vhap_offset_reg_fwd(const float* offset, const int32_t* lap_ptr, 
     if (n_regions > 0 && (!region_ptr || !region_idx)) return VHAP_E_NULLPTR;
     if (V <= 0 || n_regions < 0) return VHAP_E_BADDIM;
     hipStream_t st = vhap_stream(stream);
-    vhap_zero_async(terms, 3 * sizeof(float), st);
-    VHAP_LAUNCH_CHECK();
+    VHAP_ZERO_ACC(terms, 3 * sizeof(float), st);
     OffCfg c{V, n_regions, vhap_cdiv(V, RB), s_lap, s_abs, s_rigid};
     offset_reg_kernel<<<c.nbv + n_regions, RB, 0, st>>>(c, offset, lap_ptr, lap_col, lap_val, w_lap, w_abs, region_ptr, region_idx, terms, nullptr,
                                                       nullptr);
@@ -285,8 +284,7 @@ extern "C" int vhap_tex_prep_fwd(const float* painted, const float* extra, const
     if ((!painted && !extra) || !albedo_hwc || !terms) return VHAP_E_NULLPTR;
     if (T <= 0) return VHAP_E_BADDIM;
     hipStream_t st = vhap_stream(stream);
-    vhap_zero_async(terms, 2 * sizeof(float), st);
-    VHAP_LAUNCH_CHECK();
+    VHAP_ZERO_ACC(terms, 2 * sizeof(float), st);
     TexCfg c{T, s_tv, s_res};
     tex_prep_fwd_kernel<<<dim3(vhap_cdiv(T, RB), vhap_cdiv(T, TEX_ROWS)), RB, 0, st>>>(c, painted, extra, res_mask, albedo_hwc, terms);
     VHAP_LAUNCH_CHECK();

@@ -53,6 +53,15 @@ class FrameShardContext:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
+    def all_reduce_mean_(self, t):
+        """In-place mean over ranks of a contiguous tensor (RCCL averages in the collective; gloo sums, then scales)."""
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            t.mul_(1.0 / self.world_size)
+        return t
+
     def average_gradients(self, params):
         """One flat-bucket all-reduce of every gradient (missing grads count as zero)."""
         params = [p for p in params if p.requires_grad]

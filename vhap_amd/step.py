@@ -1,0 +1,271 @@
+"""NativeStep: one photometric fit step (vhap/model/tracker.py:1418-1462 -> compute_energy :692-750 -> backward) as a
+fixed sequence of ~60 calls into libvhap_hip.so, chained by hand instead of by torch autograd.
+
+The autograd formulation (vhap_amd.tracker.FlameTracker._compute_energy_native) spends a quarter of the captured step in
+glue: ~70 launches of a few microseconds each that zero-fill gradient buffers, add gradient contributions, multiply by scalar
+weights, concatenate and sum the energy terms and copy gradients.  Here every buffer is allocated once, all accumulators live in
+two arenas cleared by ONE launch each, the kernels accumulate straight into the parameters' .grad storage, and the energy is
+assembled by two one-thread kernels (vhap_energy_finalize / vhap_energy_total).  Same kernels, same arithmetic, same results
+(tests/test_native_gpu.py::test_native_step_matches_autograd_step).
+
+Used by vhap_amd.tracker.GraphedStep when NativeStep.supported(); torch only provides memory, streams and the collectives.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import PhotometricStageConfig
+from .ops import _p, _stream
+
+LOG_NAMES = ("lmk", "photo", "smooth_pose", "reg_joint", "smooth_joint", "reg_expr", "smooth_expr", "reg_shape", "reg_tex_tv",
+             "reg_tex_res_clusters", "reg_diffuse", "reg_offset_lap", "reg_offset", "reg_offset_rigid", "rest", "total")
+
+
+def _chk(rc, what):
+    _lib.check(rc, what)
+
+
+class NativeStep:
+    @staticmethod
+    def supported(tracker, stage):
+        cfg = tracker.cfg
+        return (tracker._native_ok(stage) and isinstance(cfg.pipeline[stage], PhotometricStageConfig) and cfg.w.photo is not None and
+                cfg.render.background_train in ("target", "white", "black") and tracker.static_offset is not None and
+                not tracker.calibrated)
+
+    def __init__(self, tracker, sample, stage):
+        tr = self.tr = tracker
+        self.stage = stage
+        cfg, w = tr.cfg, tr.cfg.w
+        dev = tr.device
+        L = self.L = _lib.lib()
+        nm = self.nm = tr._native_models()
+        fl = tr.flame
+        fb = self.fb = fl._fb
+        self.fm, self.lm, self.om = nm["frame"], nm["lmk"], nm["off"]
+        self.weights = tr._frame_weights(stage)
+        ts = sample["timestep_index"]
+        self.ts = (ts if torch.is_tensor(ts) else torch.as_tensor(np.asarray(ts), device=dev)).long().contiguous()
+        self.rgb = sample["rgb"].contiguous()                        # [B,3,H,W] image space (static: new batches are copied in)
+        self.lmk2d = sample["lmk2d"].float().contiguous()
+        B = self.B = int(self.ts.shape[0])
+        H, W = self.H, self.W = tr.image_size
+        V = self.V = fb.V
+        J = self.J = self.fm.J
+        N = self.N = int(tr.expr.shape[0])
+        NS, NE = int(tr.shape.shape[0]), int(tr.expr.shape[1])
+        self.NS, self.NE = NS, NE
+        T = self.T = int(tr.tex_extra.shape[-1])
+        Bp = self.Bp = (B + 15) // 16 * 16
+        o = tr.opt_dict
+        f32 = dict(dtype=torch.float32, device=dev)
+        E = lambda *s: torch.empty(*s, **f32)
+        # ---- static tables ----
+        mesh = tr.render._mesh(fl.faces)
+        self.tri, self.opp, self.csr = mesh["tri"], mesh["opp"].int().contiguous(), mesh["csr"]
+        self.F = int(self.tri.shape[0])
+        self.tri_uv = tr.render._tri32(fl.textures_idx)
+        self.uv = tr._verts_uv_flipped
+        fid, vid = tr._regions(stage)
+        self.face_mask = tr.render._u8_mask(fid, self.F) if fid is not None else None
+        self.vert_mask = tr.render._u8_mask(vid, V) if vid is not None else None
+        self.painted = tr.flame_tex_painted()[0].contiguous()
+        if self.painted.shape[-1] != T:
+            self.painted = torch.nn.functional.interpolate(self.painted[None], (T, T), mode="bilinear")[0].contiguous()
+        tex_on = bool(o["texture"])
+        self.tex_scales = (float((tr._w_tv() if tex_on else None) or 0.0) / (3.0 * T * (T - 1)),
+                           float((w.reg_tex_res_clusters if tex_on else None) or 0.0) / (3.0 * T * T))
+        off_on = bool(o["static_offset"] or o["dynamic_offset"])
+        self.off_scales = (float((w.reg_offset_lap if off_on else None) or 0.0) / V, float((w.reg_offset if off_on else None) or 0.0) / (3 * V),
+                           float((w.reg_offset_rigid if off_on else None) or 0.0) / 3.0)
+        self.w_lmk = float(w.landmark or 0.0)
+        self.want_reg = bool(o["lights"]) and w.reg_diffuse is not None
+        self.w_reg = float(w.reg_diffuse or 0.0) if self.want_reg else 0.0
+        self.w_photo = float(w.photo)
+        disable_jaw = not w.always_enable_jawline_landmarks and cfg.pipeline[stage]["disable_jawline_landmarks"]
+        self.lmk_cfg = (17, 68, 0, 0, 1.0) if disable_jaw else (0, 68, 27, 36, 10.0)
+        bg = cfg.render.background_train
+        self.bg_col = None if bg == "target" else (ctypes.c_float * 3)(*([1.0, 1.0, 1.0] if bg == "white" else [0.0, 0.0, 0.0]))
+        self.rate_fg, self.rate_bg = tr.render.disturb_rate_fg, tr.render.disturb_rate_bg
+        self.disturb_on = bool(self.rate_fg or self.rate_bg)
+        if self.disturb_on:
+            r = tr.render
+            if r._rng_state is None or r._rng_state.device != self.rgb.device:
+                r._rng_state = torch.randint(0, 2 ** 31 - 1, (1,), device=dev).to(torch.int32)
+            if not hasattr(r, "_fid2cid_i32") or r._fid2cid_i32.device != self.rgb.device:
+                r._fid2cid_i32 = r.fid2cid.int().contiguous()
+            self.fid2cid, self.ncl, self.rng = r._fid2cid_i32, r._ncl, r._rng_state
+        self.K1, self.K0 = nm["K1"], nm["K0"]
+        self.focal_scale = float(max(H, W))
+        self.RT = tr.RT[None, :3, :].contiguous()
+        self.sh_const = tr.render.sh_const.contiguous()
+        # ---- forward buffers ----
+        self.coef, self.A, self.transl, self.Jrest = E(Bp, fb.Kp), E(B, J, 12), E(B, 3), E(B, J * 3)
+        self.verts, self.v_shaped, self.v_posed = E(B, V, 3), E(B, V, 3), E(B, V, 3)
+        self.K, self.mvp, self.clip, self.vn = E(1, 4), E(B, 4, 4), E(B, V, 4), E(B, V, 3)
+        self.rast, self.db, self.normal, self.texc, self.texd = E(B, H, W, 4), E(B, H, W, 4), E(B, H, W, 3), E(B, H, W, 2), E(B, H, W, 4)
+        self.albedo_tex = E(1, T, T, 3)
+        self.mips = E(L.vhap_texture_mip_floats(1, T, T, 3))
+        self.albedo_px, self.rgba, self.rgba_aa = E(B, H, W, 3), E(B, H, W, 4), E(B, H, W, 4)
+        if self.disturb_on:
+            self.rgba_d, self.keep = E(B, H, W, 4), E(B, H, W)
+            self.dist_ws = torch.empty(L.vhap_disturb_workspace_ints(B, H, W), dtype=torch.int32, device=dev)
+        self.aa_work = torch.empty(L.vhap_antialias_work_ints(B, H, W, self.F), dtype=torch.int32, device=dev)
+        self.ws, self.ws_bytes, self.ws_cap, _ = tr.render.glctx.acquire(B, self.F, H, W, self.rgb.device)
+        # forward accumulators: frame terms [0:6], landmark [6], texture terms [7:9], offset terms [9:12], shade stats [12:16], photo [16:18]
+        self.accF = torch.zeros(32, **f32)
+        self.log = torch.zeros(16, **f32)
+        self.n_global = self.accF[17:18]                      # replaced by the all-reduced count under frame sharding
+        # ---- backward: one arena for everything that is accumulated into ----
+        params = {"shape": tr.shape, "expr": tr.expr, "rotation": tr.rotation, "translation": tr.translation, "neck_pose": tr.neck_pose,
+                  "jaw_pose": tr.jaw_pose, "eyes_pose": tr.eyes_pose, "lights": tr.lights, "static_offset": tr.static_offset,
+                  "focal_length": tr.focal_length}
+        sizes = {k: p.numel() for k, p in params.items()}
+        extra = {"d_clip": B * V * 4, "d_vn": B * V * 3, "d_A": B * J * 12, "d_t": B * 3, "d_coef": Bp * fb.Kp,
+                 "d_tex": self.albedo_tex.numel() + self.mips.numel()}
+        al = lambda n: (n + 63) // 64 * 64
+        total = sum(al(n) for n in sizes.values()) + sum(al(n) for n in extra.values())
+        self.arena = torch.zeros(total, **f32)
+        off = 0
+        self.g = {}
+        for k, p in params.items():
+            self.g[k] = self.arena[off:off + sizes[k]].view(p.shape)
+            off += al(sizes[k])
+        self.param_grad_flat = self.arena[:off]                      # every parameter gradient but the texture's: one all-reduce
+        for k, n in extra.items():
+            self.g[k] = self.arena[off:off + n]
+            off += al(n)
+        self.g["tex_extra"] = torch.zeros_like(tr.tex_extra)          # overwritten by tex_prep_bwd, never accumulated
+        self.params = dict(params, tex_extra=tr.tex_extra)
+        for k, p in self.params.items():                              # the optimiser and the gradient all-reduce see these
+            p.grad = self.g[k]
+        # scratch that is overwritten
+        self.d_rgba_aa, self.d_color, self.d_rgba = E(B, H, W, 4), E(B, H, W, 4), E(B, H, W, 4)
+        self.d_albedo, self.d_normal, self.d_texc, self.d_texd = E(B, H, W, 3), E(B, H, W, 3), E(B, H, W, 2), E(B, H, W, 4)
+        self.d_verts, self.vn_scratch, self.g_posed, self.g_shaped = E(B, V, 3), E(B, V, 3), E(B, V, 3), E(B, V, 3)
+        self.d_mvp, self.d_K, self.d_sum = E(B, 16), E(B, 4), E(1)
+        self.ones = torch.ones(8, **f32)
+        self.c_lmk = torch.full((1,), self.w_lmk, **f32)
+        self.c_reg = torch.full((1,), self.w_reg, **f32)
+
+    # ------------------------------------------------------------------------------------------------
+    def forward(self):
+        L, tr, fb, fm = self.L, self.tr, self.fb, self.fm
+        B, H, W, V, F, T, J = self.B, self.H, self.W, self.V, self.F, self.T, self.J
+        st = _stream()
+        acc = self.accF
+        acc.zero_()                                                   # ONE launch clears every forward accumulator
+        L.vhap_set_call_flags(1)
+        try:
+            so = tr.static_offset
+            _chk(L.vhap_frame_prep_fwd(_p(self.ts), _p(tr.shape), _p(tr.expr), _p(tr.rotation), _p(tr.translation), _p(tr.neck_pose),
+                                       _p(tr.jaw_pose), _p(tr.eyes_pose), _p(fm.JT), _p(fm.JS), _p(fm.jreg_idx), _p(fm.jreg_w), fm.jreg_n,
+                                       _p(so), fm.parents, self.weights, B, self.Bp, self.N, self.NS, self.NE, J, fb.Kp, V,
+                                       _p(self.coef), _p(self.A), _p(self.transl), _p(self.Jrest), _p(acc), st), "vhap_frame_prep_fwd")
+            _chk(L.vhap_flame_skin_fwd(_p(self.coef), _p(fb.basis), _p(self.A), _p(fb.w), _p(fb.templ), _p(so), _p(self.transl), B, V, fb.Vp,
+                                       fb.K, fb.Kb, fb.Kp, _p(self.verts), _p(self.v_shaped), _p(self.v_posed), st), "vhap_flame_skin_fwd")
+            torch.addcmul(self.K0, tr.focal_length.detach(), self.K1, out=self.K)      # K = (f, f, cx, cy), f = focal * max(h, w)
+            _chk(L.vhap_camera_fwd(_p(self.K), _p(self.RT), B, 0, 0, H, W, 0.1, 10.0, _p(self.mvp), st), "vhap_camera_fwd")
+            if self.w_lmk:
+                l0, l1, b0, b1, boost = self.lmk_cfg
+                _chk(L.vhap_landmark_fwd(_p(self.verts), _p(self.lm.vidx), _p(self.lm.bary), _p(self.mvp), _p(self.lmk2d), B, V, self.lm.L,
+                                         self.lmk2d.shape[1], l0, l1, b0, b1, boost, H, W, 0, _p(acc[6:7]), st), "vhap_landmark_fwd")
+            _chk(L.vhap_transform_fwd(_p(self.verts), _p(self.mvp), B, V, _p(self.clip), st), "vhap_transform_fwd")
+            _chk(L.vhap_vnormal_fwd(_p(self.verts), _p(self.csr.tri), _p(self.csr.ptr), _p(self.csr.idx), B, V, _p(self.vn), st), "vhap_vnormal_fwd")
+            _chk(L.vhap_raster_interp_fwd(_p(self.clip), _p(self.tri), _p(self.vn), _p(self.uv), _p(self.tri_uv), B, V, self.uv.shape[0], F, H, W,
+                                          _p(self.rast), _p(self.db), _p(self.normal), _p(self.texc), _p(self.texd), _p(self.ws), self.ws_bytes,
+                                          self.ws_cap, 1, st), "vhap_raster_interp_fwd")
+            _chk(L.vhap_tex_prep_fwd(_p(self.painted), _p(tr.tex_extra), _p(self.nm["res_mask"]), T, *self.tex_scales, _p(self.albedo_tex),
+                                     _p(acc[7:9]), st), "vhap_tex_prep_fwd")
+            _chk(L.vhap_texture_mip_build(_p(self.albedo_tex), 1, T, T, 3, _p(self.mips), st), "vhap_texture_mip_build")
+            _chk(L.vhap_texture_fwd(_p(self.albedo_tex), _p(self.mips), 1, T, T, 3, _p(self.texc), _p(self.texd), B, H, W, _p(self.albedo_px), st),
+                 "vhap_texture_fwd")
+            _chk(L.vhap_shade_fwd(_p(self.normal), _p(self.albedo_px), _p(self.rast), _p(self.rgb) if self.bg_col is None else 0,
+                                  ctypes.cast(self.bg_col, ctypes.c_void_p) if self.bg_col is not None else 0, _p(tr.lights), _p(self.sh_const),
+                                  B, H, W, _p(self.rgba), _p(acc[12:16]) if self.want_reg else 0, st), "vhap_shade_fwd")
+            color = self.rgba
+            if self.disturb_on:
+                _chk(L.vhap_disturb_fwd_rng(_p(self.rgba), _p(self.rast), _p(self.fid2cid), self.fid2cid.numel(), self.ncl,
+                                            float(self.rate_fg or 0.0), float(self.rate_bg or 0.0), _p(self.rng), B, H, W, _p(self.dist_ws),
+                                            _p(self.rgba_d), _p(self.keep), st), "vhap_disturb_fwd_rng")
+                color = self.rgba_d
+            self.aa_in = color
+            _chk(L.vhap_antialias_fwd(_p(color), _p(self.rast), _p(self.clip), _p(self.tri), _p(self.opp), B, H, W, 4, V, F, _p(self.rgba_aa),
+                                      _p(self.aa_work), st), "vhap_antialias_fwd")
+            _chk(L.vhap_photo_fwd(_p(self.rgba_aa), _p(self.rgb), B, H, W, _p(acc[16:18]), st), "vhap_photo_fwd")
+            om = self.om
+            _chk(L.vhap_offset_reg_fwd(_p(so), _p(om.ptr), _p(om.col), _p(om.val), _p(om.w_lap), _p(om.w_abs), _p(om.rptr), _p(om.ridx), om.V,
+                                       om.nreg, *self.off_scales, _p(acc[9:12]), st), "vhap_offset_reg_fwd")
+            _chk(L.vhap_energy_finalize(_p(acc[0:6]), _p(acc[6:7]) if self.w_lmk else 0, _p(acc[7:9]), _p(acc[9:12]),
+                                        _p(acc[12:16]) if self.want_reg else 0, self.w_lmk, self.w_reg, B, H, W, _p(self.log), st),
+                 "vhap_energy_finalize")
+        finally:
+            L.vhap_set_call_flags(0)
+
+    def backward(self, world_size=1):
+        L, tr, fb, fm, g = self.L, self.tr, self.fb, self.fm, self.g
+        B, H, W, V, F, T, J = self.B, self.H, self.W, self.V, self.F, self.T, self.J
+        st = _stream()
+        self.arena.zero_()                                            # ONE launch clears every gradient accumulator
+        L.vhap_set_call_flags(1)
+        try:
+            acc = self.accF
+            _chk(L.vhap_energy_total(_p(self.log), _p(acc[16:18]), _p(self.n_global), self.w_photo, int(world_size), _p(self.d_sum), st),
+                 "vhap_energy_total")
+            _chk(L.vhap_photo_bwd(_p(self.rgba_aa), _p(self.rgb), _p(self.d_sum), B, H, W, _p(self.d_rgba_aa), st), "vhap_photo_bwd")
+            _chk(L.vhap_antialias_bwd(_p(self.aa_in), _p(self.rast), _p(self.clip), _p(self.tri), _p(self.opp), _p(self.d_rgba_aa), _p(self.aa_work),
+                                      _p(self.vert_mask), B, H, W, 4, V, F, _p(self.d_color), _p(g["d_clip"]), st), "vhap_antialias_bwd")
+            d_rgba = self.d_color
+            if self.disturb_on:
+                _chk(L.vhap_disturb_bwd(_p(self.d_color), _p(self.keep), B, H, W, _p(self.d_rgba), st), "vhap_disturb_bwd")
+                d_rgba = self.d_rgba
+            _chk(L.vhap_shade_bwd(_p(self.normal), _p(self.albedo_px), _p(self.rast), _p(tr.lights), _p(self.sh_const), _p(d_rgba),
+                                  _p(self.c_reg) if self.want_reg else 0, _p(acc[12:16]) if self.want_reg else 0, B, H, W, _p(self.d_albedo),
+                                  _p(self.d_normal), _p(g["lights"]), st), "vhap_shade_bwd")
+            n0 = self.albedo_tex.numel()
+            d_tex, d_mips = g["d_tex"][:n0], g["d_tex"][n0:]
+            _chk(L.vhap_texture_bwd(_p(self.albedo_tex), _p(self.mips), 1, T, T, 3, _p(self.texc), _p(self.texd), _p(self.d_albedo), B, H, W,
+                                    _p(d_tex), _p(d_mips), _p(self.d_texc), _p(self.d_texd), st), "vhap_texture_bwd")
+            has_mips = self.mips.numel() > 0
+            if has_mips:
+                _chk(L.vhap_texture_mip_fold(_p(d_tex), _p(d_mips), 1, T, T, 3, 1, st), "vhap_texture_mip_fold")
+            _chk(L.vhap_tex_prep_bwd(_p(self.albedo_tex), _p(tr.tex_extra), _p(self.nm["res_mask"]), _p(d_tex), _p(d_mips) if has_mips else 0,
+                                     _p(self.ones), T, *self.tex_scales, _p(g["tex_extra"]), st), "vhap_tex_prep_bwd")
+            _chk(L.vhap_gbuffer_bwd(_p(self.clip), _p(self.tri), _p(self.vn), _p(self.uv), _p(self.tri_uv), _p(self.rast), _p(self.d_normal),
+                                    _p(self.d_texc), _p(self.d_texd), 0, 0, _p(self.face_mask), B, V, F, H, W, _p(g["d_clip"]), _p(g["d_vn"]), st),
+                 "vhap_gbuffer_bwd")
+            _chk(L.vhap_vnormal_bwd(_p(self.verts), _p(self.csr.tri), _p(self.csr.ptr), _p(self.csr.idx), _p(g["d_vn"]), B, V, 0,
+                                    _p(self.vn_scratch), _p(self.d_verts), st), "vhap_vnormal_bwd")
+            if self.w_lmk:
+                l0, l1, b0, b1, boost = self.lmk_cfg
+                _chk(L.vhap_landmark_bwd(_p(self.verts), _p(self.lm.vidx), _p(self.lm.bary), _p(self.mvp), _p(self.lmk2d), _p(self.c_lmk), B, V,
+                                         self.lm.L, self.lmk2d.shape[1], l0, l1, b0, b1, boost, H, W, _p(self.d_verts), _p(self.d_mvp), st),
+                     "vhap_landmark_bwd")
+            else:
+                self.d_mvp.zero_()
+            _chk(L.vhap_transform_bwd(_p(self.verts), _p(self.mvp), _p(g["d_clip"]), B, V, 1, _p(self.d_verts), _p(self.d_mvp), st),
+                 "vhap_transform_bwd")
+            _chk(L.vhap_camera_bwd(_p(self.RT), _p(self.d_mvp), B, 0, H, W, _p(self.d_K), st), "vhap_camera_bwd")
+            _chk(L.vhap_focal_bwd(_p(self.d_K), B, self.focal_scale, _p(g["focal_length"]), st), "vhap_focal_bwd")
+            _chk(L.vhap_flame_skin_bwd(_p(self.d_verts), 0, _p(self.v_posed), _p(self.A), _p(fb.w), _p(fb.basisT), B, V, fb.Vp, fb.Kb, fb.Kp,
+                                       _p(self.g_posed), _p(self.g_shaped), 0, _p(g["d_coef"]), _p(g["d_A"]), _p(g["d_t"]), st),
+                 "vhap_flame_skin_bwd")
+            _chk(L.vhap_sum_frames(_p(self.g_shaped), B, V * 3, _p(g["static_offset"]), st), "vhap_sum_frames")
+            om = self.om
+            _chk(L.vhap_offset_reg_bwd(_p(tr.static_offset), _p(om.ptr), _p(om.col), _p(om.val), _p(om.w_lap), _p(om.w_abs), _p(om.rptr),
+                                       _p(om.ridx), om.V, om.nreg, *self.off_scales, _p(self.ones), _p(g["static_offset"]), st),
+                 "vhap_offset_reg_bwd")
+            _chk(L.vhap_frame_prep_bwd(_p(self.ts), _p(tr.shape), _p(tr.expr), _p(tr.rotation), _p(tr.translation), _p(tr.neck_pose),
+                                       _p(tr.jaw_pose), _p(tr.eyes_pose), _p(fm.JS), _p(fm.jreg_idx), _p(fm.jreg_w), fm.jreg_n,
+                                       _p(tr.static_offset), fm.parents, self.weights, _p(self.Jrest), _p(g["d_coef"]), _p(g["d_A"]), _p(g["d_t"]),
+                                       _p(self.ones), B, self.Bp, self.N, self.NS, self.NE, J, fb.Kp, V, _p(g["shape"]), _p(g["expr"]),
+                                       _p(g["rotation"]), _p(g["translation"]), _p(g["neck_pose"]), _p(g["jaw_pose"]), _p(g["eyes_pose"]),
+                                       _p(g["static_offset"]), st), "vhap_frame_prep_bwd")
+        finally:
+            L.vhap_set_call_flags(0)
+
+    def log_dict(self):
+        """Views into the device log vector, keyed like FlameTracker.compute_energy's log_dict (terms the stage does not have read 0)."""
+        return {k: self.log[i] for i, k in enumerate(LOG_NAMES) if k != "rest"}

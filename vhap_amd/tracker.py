@@ -714,6 +714,10 @@ class GraphedStep:
         for k in ("intrinsic", "extrinsic"):
             if k in sample and tracker.calibrated:
                 self.sample[k] = sample[k].clone()
+        from .step import NativeStep
+        self.ns = None
+        use_native_step = os.environ.get("VHAP_NATIVE_STEP", "1") != "0" and NativeStep.supported(tracker, stage) and \
+            isinstance(optimizer, NV.HipAdam)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -736,10 +740,31 @@ class GraphedStep:
                 optimizer.step()
                 for st in optimizer.state.values():
                     st["step"].zero_()
+            if use_native_step:
+                # the whole step as a hand-chained call sequence (vhap_amd/step.py): no autograd glue launches
+                self.ns = NativeStep(tracker, self.sample, stage)
+                self.ns.forward()
+                self.ns.backward(1)
         torch.cuda.current_stream().wait_stream(side)
         self.inv_n = torch.zeros((), device=dev)
         self.stream = torch.cuda.Stream()
         self.gF, self.gB, self.gA = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        if self.ns is not None:
+            ns = self.ns
+            world = tracker.dist.world_size if tracker.dist is not None else 1
+            if world > 1:
+                ns.n_global = torch.ones(1, device=dev)             # receives the all-reduced alpha count before every backward replay
+            with torch.cuda.graph(self.gF):
+                ns.forward()
+            pool = self.gF.pool() if os.environ.get("VHAP_GRAPH_POOLS") != "separate" else None
+            with torch.cuda.graph(self.gB, pool=pool):
+                ns.backward(world)
+            with torch.cuda.graph(self.gA, pool=pool):
+                optimizer.step()
+            self.E = ns.log[15]
+            self.log_dict = ns.log_dict()
+            self.S, self.N = ns.accF[16], ns.accF[17]
+            return
         tracker._split = {}
         try:
             with torch.cuda.graph(self.gF):
@@ -784,6 +809,15 @@ class GraphedStep:
     def _replay(self):
         tr = self.tr
         self.gF.replay()
+        if self.ns is not None:
+            if tr.dist is not None:
+                self.ns.n_global.copy_(tr.dist.all_reduce_sum(self.N.reshape(1)))
+            self.gB.replay()
+            if tr.dist is not None:      # the gradients sit in two contiguous buffers: two collectives, no staging copies
+                tr.dist.all_reduce_mean_(self.ns.param_grad_flat)
+                tr.dist.all_reduce_mean_(self.ns.g["tex_extra"])
+            self.gA.replay()
+            return
         n = self.N
         world = 1
         if tr.dist is not None:
@@ -794,4 +828,3 @@ class GraphedStep:
         if tr.dist is not None:
             tr.dist.average_gradients(self.params)
         self.gA.replay()
-
