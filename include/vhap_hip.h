@@ -164,14 +164,15 @@ int vhap_antialias_bwd(const float* color, const float* rast, const float* pos,
  * Backward: d_albedo / d_normal_raw [B,H,W,3] overwritten (either may be NULL); d_lights [9,3]
  * ACCUMULATED (may be NULL).  d_reg (device scalar, may be NULL) is the upstream gradient of
  * reg = relu(max(diffuse) - 1) + mean(var); it reaches d_lights only, like the reference's
- * shade(normal.detach()).
+ * shade(normal.detach()).  keep [B,H,W] or NULL: the `keep` mask of vhap_disturb_fwd -- d_rgba is multiplied by it on the
+ * fly (= vhap_disturb_bwd folded into this pass).
  * ------------------------------------------------------------------------------------------- */
 int vhap_shade_fwd(const float* normal_raw, const float* albedo, const float* rast,
                    const float* bg_image, const float* bg_color, const float* lights,
                    const float* sh_const, int B, int H, int W, float* rgba, float* stats,
                    vhap_stream_t stream);
 int vhap_shade_bwd(const float* normal_raw, const float* albedo, const float* rast,
-                   const float* lights, const float* sh_const, const float* d_rgba,
+                   const float* lights, const float* sh_const, const float* d_rgba, const float* keep,
                    const float* d_reg, const float* stats, int B, int H, int W, float* d_albedo,
                    float* d_normal_raw, float* d_lights, vhap_stream_t stream);
 /* out2[0] = sum |gt - pred_rgb|, out2[1] = #(pred_alpha > 0); pred [B,H,W,4] renderer space,

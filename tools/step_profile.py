@@ -7,11 +7,9 @@ import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "raster_kernel" in r["Kernel_Name"]]
-a = idx[-30]
 first = "frame_prep_fwd" if any("frame_prep_fwd" in r["Kernel_Name"] for r in rows) else "flame_skin_fwd"
-s = max(i for i in range(a) if first in rows[i]["Kernel_Name"])
-e = min(i for i in range(a + 1, len(rows)) if first in rows[i]["Kernel_Name"])
+starts = [i for i, r in enumerate(rows) if first in r["Kernel_Name"]]
+s, e = starts[-6], starts[-5]              # one step well inside the timed graph replays
 seq = rows[s - 1:e - 1]
 dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
 

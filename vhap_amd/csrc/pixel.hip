@@ -19,6 +19,8 @@ namespace {
 // so the chain length is what is paid: 2048 x 256 threads cost ~150 us of tail, 512 x 1024 threads ~6 us.
 constexpr int PB = 1024;
 constexpr int NW = PB / 64;
+constexpr int PBB = 512;      // shade_bwd: 27 accumulators + the SH algebra need ~150 VGPRs -> 2 waves per SIMD, no scratch
+constexpr int NWB = PBB / 64;
 constexpr int MAX_BLOCKS = 512;
 
 struct SH9 {
@@ -55,7 +57,7 @@ struct ShadeParams {
 
 // stats (4 words): [0..1] = u64 (ordered-uint max of diffuse << 32 | number of entries equal to it), [2] = float sum over
 // pixels of var_channels(diffuse).  The tie count makes the backward of max() distribute evenly like torch's.
-__global__ __launch_bounds__(PB) void shade_fwd_kernel(const ShadeParams P, float4* __restrict__ rgba,
+__global__ __launch_bounds__(PB) __attribute__((amdgpu_waves_per_eu(4, 4))) void shade_fwd_kernel(const ShadeParams P, float4* __restrict__ rgba,
                                                         unsigned* __restrict__ stats) {
     __shared__ float s_l[27], s_c[9];
     __shared__ float red_var[NW];
@@ -138,12 +140,15 @@ __global__ __launch_bounds__(PB) void shade_fwd_kernel(const ShadeParams P, floa
 // lights only (the reference computes it on shade(normal.detach())):
 //   g_var = d_reg / npix  (coefficient of d var / d diffuse_c = diffuse_c - mean)
 //   g_max = d_reg if max(diffuse) > 1 else 0, applied where diffuse_c equals the max (stats[0]).
-__global__ __launch_bounds__(PB) void shade_bwd_kernel(const ShadeParams P, const float4* __restrict__ d_rgba,
-                                                        const float* __restrict__ d_reg, const unsigned* __restrict__ stats,
+// (one 1024-thread workgroup per CU = 4 waves per SIMD: tell the compiler, or it budgets 64 VGPRs and spills the 27 light
+// accumulators to scratch)
+__global__ __launch_bounds__(PBB) __attribute__((amdgpu_waves_per_eu(2, 2))) void shade_bwd_kernel(const ShadeParams P, const float4* __restrict__ d_rgba,
+                                                        const float* __restrict__ keep, const float* __restrict__ d_reg,
+                                                        const unsigned* __restrict__ stats,
                                                         float* __restrict__ d_albedo, float* __restrict__ d_normal_raw,
                                                         float* __restrict__ d_lights) {
     __shared__ float s_l[27], s_c[9];
-    __shared__ float red[NW][27];
+    __shared__ float red[NWB][27];
     if (threadIdx.x < 27) s_l[threadIdx.x] = P.lights[threadIdx.x];
     if (threadIdx.x < 9) s_c[threadIdx.x] = P.sh_const[threadIdx.x];
     __syncthreads();
@@ -161,7 +166,7 @@ __global__ __launch_bounds__(PB) void shade_bwd_kernel(const ShadeParams P, cons
         const unsigned u = (mx_ord & 0x80000000u) ? (mx_ord & 0x7fffffffu) : ~mx_ord;
         g_max = __uint_as_float(u) > 1.0f ? dr / (float)max(ties, 1u) : 0.f;   // evenly among ties, like torch.max()
     }
-    for (size_t pi = (size_t)blockIdx.x * PB + threadIdx.x; pi < (size_t)npix; pi += (size_t)gridDim.x * PB) {
+    for (size_t pi = (size_t)blockIdx.x * PBB + threadIdx.x; pi < (size_t)npix; pi += (size_t)gridDim.x * PBB) {
         const float* nr = P.normal_raw + 3 * pi;
         const float rx = nr[0], ry = nr[1], rz = nr[2];
         const float l2 = rx * rx + ry * ry + rz * rz;
@@ -179,7 +184,8 @@ __global__ __launch_bounds__(PB) void shade_bwd_kernel(const ShadeParams P, cons
         float gd[3] = {0.f, 0.f, 0.f};   // photometric part of d(diffuse): flows to lights AND normal
         float ga[3] = {0.f, 0.f, 0.f};
         if (fg) {
-            const float4 g = d_rgba[pi];
+            float4 g = d_rgba[pi];
+            if (keep) { const float k = keep[pi]; g.x *= k; g.y *= k; g.z *= k; }     // backward of the colour disturbance, folded in
             const float* al = P.albedo + 3 * pi;
             ga[0] = g.x * d[0]; ga[1] = g.y * d[1]; ga[2] = g.z * d[2];
             gd[0] = g.x * al[0]; gd[1] = g.y * al[1]; gd[2] = g.z * al[2];
@@ -229,7 +235,7 @@ __global__ __launch_bounds__(PB) void shade_bwd_kernel(const ShadeParams P, cons
         __syncthreads();
         if (threadIdx.x < 27) {
             float s = 0.f;
-            for (int w = 0; w < NW; w++) s += red[w][threadIdx.x];
+            for (int w = 0; w < NWB; w++) s += red[w][threadIdx.x];
             if (s != 0.f) atomicAdd(&d_lights[threadIdx.x], s);
         }
     }
@@ -305,15 +311,15 @@ extern "C" int vhap_shade_fwd(const float* normal_raw, const float* albedo, cons
 }
 
 extern "C" int vhap_shade_bwd(const float* normal_raw, const float* albedo, const float* rast, const float* lights,
-                              const float* sh_const, const float* d_rgba, const float* d_reg, const float* stats, int B, int H,
-                              int W, float* d_albedo, float* d_normal_raw, float* d_lights, vhap_stream_t stream) {
+                              const float* sh_const, const float* d_rgba, const float* keep, const float* d_reg, const float* stats,
+                              int B, int H, int W, float* d_albedo, float* d_normal_raw, float* d_lights, vhap_stream_t stream) {
     VHAP_ENTER();
     if (!normal_raw || !albedo || !rast || !lights || !sh_const || !d_rgba) return VHAP_E_NULLPTR;
     if (int e = check_img(B, H, W)) return e;
     ShadeParams P{normal_raw, albedo, reinterpret_cast<const float4*>(rast), nullptr, 0.f, 0.f, 0.f, lights, sh_const, B, H, W};
     const long long npix = (long long)B * H * W;
-    shade_bwd_kernel<<<min(vhap_cdiv(npix, PB), MAX_BLOCKS), PB, 0, vhap_stream(stream)>>>(
-        P, reinterpret_cast<const float4*>(d_rgba), d_reg, reinterpret_cast<const unsigned*>(stats), d_albedo, d_normal_raw, d_lights);
+    shade_bwd_kernel<<<min(vhap_cdiv(npix, PBB), MAX_BLOCKS), PBB, 0, vhap_stream(stream)>>>(
+        P, reinterpret_cast<const float4*>(d_rgba), keep, d_reg, reinterpret_cast<const unsigned*>(stats), d_albedo, d_normal_raw, d_lights);
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;
 }

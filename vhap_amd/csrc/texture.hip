@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void mip_fold_kernel(float* __restrict__ fine,
 // The small levels in ONE single-workgroup launch each way (they are pure launch latency otherwise: 7 of the 11 levels of a
 // 2048^2 texture hold <= 64x64 texels).  Levels are processed in sequence with a barrier in between; global memory written by
 // the workgroup is visible to it after __syncthreads + __threadfence_block.
-constexpr int TAIL_MAX = 128;     // levels whose SOURCE is at most TAIL_MAX x TAIL_MAX go to the tail kernel
+constexpr int TAIL_MAX = 64;      // levels whose SOURCE is at most TAIL_MAX x TAIL_MAX go to the tail kernel (one workgroup: keep it short)
 __global__ __launch_bounds__(1024) void mip_down_tail_kernel(float* __restrict__ mips, const TexDesc D, int l_first) {
     for (int tb = 0; tb < D.TB; tb++) {
         for (int l = l_first; l <= D.L; l++) {

@@ -194,7 +194,7 @@ class _Shade(torch.autograd.Function):
         d_l = torch.zeros_like(lights) if need_l else None
         use_reg = stats is not None and d_reg is not None
         d_reg_c = _f32c(d_reg.reshape(1)) if use_reg else None
-        _chk(_lib.lib().vhap_shade_bwd(_p(normal_raw), _p(albedo), _p(rast), _p(lights), _p(sh_const), _p(_f32c(d_rgba)), _p(d_reg_c),
+        _chk(_lib.lib().vhap_shade_bwd(_p(normal_raw), _p(albedo), _p(rast), _p(lights), _p(sh_const), _p(_f32c(d_rgba)), 0, _p(d_reg_c),
                                        _p(stats if use_reg else None), B, H, W, _p(d_a), _p(d_n), _p(d_l), _stream()), "vhap_shade_bwd")
         return d_n, d_a, d_l, None, None, None, None, None
 

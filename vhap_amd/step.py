@@ -217,12 +217,9 @@ class NativeStep:
             _chk(L.vhap_photo_bwd(_p(self.rgba_aa), _p(self.rgb), _p(self.d_sum), B, H, W, _p(self.d_rgba_aa), st), "vhap_photo_bwd")
             _chk(L.vhap_antialias_bwd(_p(self.aa_in), _p(self.rast), _p(self.clip), _p(self.tri), _p(self.opp), _p(self.d_rgba_aa), _p(self.aa_work),
                                       _p(self.vert_mask), B, H, W, 4, V, F, _p(self.d_color), _p(g["d_clip"]), st), "vhap_antialias_bwd")
-            d_rgba = self.d_color
-            if self.disturb_on:
-                _chk(L.vhap_disturb_bwd(_p(self.d_color), _p(self.keep), B, H, W, _p(self.d_rgba), st), "vhap_disturb_bwd")
-                d_rgba = self.d_rgba
-            _chk(L.vhap_shade_bwd(_p(self.normal), _p(self.albedo_px), _p(self.rast), _p(tr.lights), _p(self.sh_const), _p(d_rgba),
-                                  _p(self.c_reg) if self.want_reg else 0, _p(acc[12:16]) if self.want_reg else 0, B, H, W, _p(self.d_albedo),
+            # (the backward of the disturbance -- d_rgba = d_color * keep -- is folded into the shading backward)
+            _chk(L.vhap_shade_bwd(_p(self.normal), _p(self.albedo_px), _p(self.rast), _p(tr.lights), _p(self.sh_const), _p(self.d_color),
+                                  _p(self.keep) if self.disturb_on else 0, _p(self.c_reg) if self.want_reg else 0, _p(acc[12:16]) if self.want_reg else 0, B, H, W, _p(self.d_albedo),
                                   _p(self.d_normal), _p(g["lights"]), st), "vhap_shade_bwd")
             n0 = self.albedo_tex.numel()
             d_tex, d_mips = g["d_tex"][:n0], g["d_tex"][n0:]
