@@ -164,3 +164,50 @@ def test_graphed_step_matches_eager_step(flame_model):
     for _ in range(10):
         E1 = float(st())
     assert E1 < E0
+
+
+def test_graphed_optimize_stage_sequential_tracking(flame_model):
+    """optimize_stage(graphed=True): the captured step is reused across timesteps (same-shaped samples copied into its static buffers,
+    Adam state reset per call) and tracks like the eager loop: energies after the stage agree, both decrease."""
+    from vhap_amd.config import BaseTrackingConfig
+    from vhap_amd.flame import FlameHead
+    from vhap_amd.render_hip import HipDiffRenderer
+    from vhap_amd.synthetic import make_dataset, make_scene_params, make_texture
+    from vhap_amd.tracker import GlobalTracker
+    model, topo = flame_model
+    gt = make_scene_params(N, seed=4, image_size=(H, W))
+    head, rend = FlameHead(model, topo).cuda(), HipDiffRenderer(lighting_type="SH").cuda()
+    data = make_dataset(rend, head, gt, (H, W), "cuda", seed=4, tex=make_texture(4, T))
+    stage = "rgb_sequential_tracking"
+
+    def run(graphed):
+        cfg = BaseTrackingConfig()
+        cfg.model.tex_resolution = T
+        cfg.render.disturb_rate_fg = cfg.render.disturb_rate_bg = None
+        tr = GlobalTracker(cfg, model, topo, make_texture(0, T), data)
+        with torch.no_grad():
+            tr.translation[:, 2] = 0.45
+        out = []
+        for t in range(2):                       # two timesteps through the same (cached) capture
+            sample = tr.get_sample(np.array([t]), device_index=True)
+            s = dict(sample)
+            tr.fill_cam_params_into_sample(s)
+            tr.get_train_parameters(stage)
+            with torch.no_grad():
+                e0 = float(tr.compute_energy(s, stage=stage)[0])
+            tr.optimize_stage(stage, sample=dict(sample), num_steps=12, graphed=graphed)
+            s = dict(sample)
+            tr.fill_cam_params_into_sample(s)
+            with torch.no_grad():
+                e1 = float(tr.compute_energy(s, stage=stage)[0])
+            out.append((e0, e1))
+            tr.initialize_next_timtestep(np.array([t]))
+        if graphed:
+            assert len(tr._graphed) == 1
+        return out
+
+    eager, graphed = run(False), run(True)
+    for (a0, a1), (b0, b1) in zip(eager, graphed):
+        assert abs(a0 - b0) <= 1e-3 * abs(a0)
+        assert a1 < a0 and b1 < b0
+        assert abs(a1 - b1) <= 0.03 * abs(a1), (eager, graphed)

@@ -377,6 +377,16 @@ class HipAdam(torch.optim.Optimizer):
             self._lr_dev.copy_(torch.tensor(lrs, dtype=torch.float32), non_blocking=False)
             self._lr_host = lrs
 
+    def reset_state(self, lr_scale_base=None):
+        """Back to a freshly constructed optimiser: zero moments, step 0 (the reference builds a new Adam per optimize_stage call)."""
+        if self._tab is None:
+            return
+        for p in self._tab["ps"]:
+            st = self.state[p]
+            st["exp_avg"].zero_()
+            st["exp_avg_sq"].zero_()
+        self._step.zero_()
+
     @property
     def step_count(self):
         return self._step

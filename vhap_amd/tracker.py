@@ -542,6 +542,7 @@ class GlobalTracker(FlameTracker):
         self.image_size = tuple(dataset["rgb"].shape[-2:])
         self.n_timesteps = dataset["rgb"].shape[0]
         self.global_step = 0
+        self._graphed = {}
         self.init_params()
 
     def init_params(self):
@@ -623,21 +624,68 @@ class GlobalTracker(FlameTracker):
                 s[k] = self.dataset[k][idx]
         return s
 
-    def optimize_stage(self, stage, sample=None, dataloader=None, lr_scale=1.0, num_steps=None):
-        """tracker.py:1391-1416."""
-        optimizer = self.configure_optimizer(self.get_train_parameters(stage), lr_scale=lr_scale)
+    def optimize_stage(self, stage, sample=None, dataloader=None, lr_scale=1.0, num_steps=None, graphed=None):
+        """tracker.py:1391-1416.  `graphed` (default: on for the fused GPU path): run the stage's identical steps as replays of a
+        captured GraphedStep.  The capture is kept per (stage, batch shape, lr scale) and fed new batches by
+        copying into its static sample buffers -- sequential tracking re-enters here once per timestep with a same-shaped sample --
+        and, like the reference, every call starts from a fresh Adam state."""
+        if graphed is None:
+            graphed = self.fused and self.native and str(self.device).startswith("cuda")
+        if not graphed:
+            optimizer = self.configure_optimizer(self.get_train_parameters(stage), lr_scale=lr_scale)
+            if sample is not None:
+                n = self.cfg.pipeline[stage].num_steps if num_steps is None else num_steps
+                for _ in range(n):
+                    self.optimize_iter(sample, optimizer, stage)
+            else:
+                assert dataloader is not None
+                sched = torch.optim.lr_scheduler.ExponentialLR(optimizer, gamma=0.9)
+                for _ in range(self.cfg.pipeline[stage].num_epochs):
+                    for s in dataloader:
+                        self.optimize_iter(s, optimizer, stage)
+                    sched.step()
+            return optimizer
+
+        def step_for(smp):
+            if not torch.is_tensor(smp["timestep_index"]):
+                smp = dict(smp, timestep_index=torch.as_tensor(np.asarray(smp["timestep_index"]), device=self.device))
+            key = (stage, tuple(smp["rgb"].shape), float(lr_scale))
+            st = self._graphed.get(key)
+            if st is None:
+                opt = self.configure_optimizer(self.get_train_parameters(stage), lr_scale=lr_scale)
+                st = self._graphed[key] = GraphedStep(self, smp, opt, stage, warmup=0)
+                st.fresh = True
+            else:
+                self.get_train_parameters(stage)
+                st.update_sample(smp)
+            return st
+
         if sample is not None:
+            st = step_for(sample)
+            if not getattr(st, "fresh", False):
+                st.opt.reset_state(lr_scale_base=None)
+            st.fresh = False
             n = self.cfg.pipeline[stage].num_steps if num_steps is None else num_steps
             for _ in range(n):
-                self.optimize_iter(sample, optimizer, stage)
-        else:
-            assert dataloader is not None
-            sched = torch.optim.lr_scheduler.ExponentialLR(optimizer, gamma=0.9)
-            for _ in range(self.cfg.pipeline[stage].num_epochs):
-                for s in dataloader:
-                    self.optimize_iter(s, optimizer, stage)
-                sched.step()
-        return optimizer
+                st()
+            return st.opt
+        assert dataloader is not None
+        st, sched = None, None
+        for _ in range(self.cfg.pipeline[stage].num_epochs):
+            for s in dataloader:
+                if st is None:
+                    st = step_for(s)
+                    if not getattr(st, "fresh", False):
+                        st.opt.reset_state(lr_scale_base=None)
+                    st.fresh = False
+                    for grp in st.opt.param_groups:               # a scheduler of a previous call may have decayed them
+                        grp["lr"] = grp["initial_lr"] if "initial_lr" in grp else grp["lr"]
+                    sched = torch.optim.lr_scheduler.ExponentialLR(st.opt, gamma=0.9)
+                else:
+                    st.update_sample(s)
+                st()
+            sched.step()
+        return st.opt
 
     def optimize_iter(self, sample, optimizer, stage, disturbance=None):
         """tracker.py:1418-1462 without the logging branches."""
@@ -789,6 +837,16 @@ class GraphedStep:
                 optimizer.step()
         finally:
             tracker._split = None
+
+    def update_sample(self, sample):
+        """Feed a new batch of the SAME shapes: copied into the static buffers the graphs read."""
+        for k, dst in self.sample.items():
+            src = sample[k]
+            if not torch.is_tensor(src):
+                src = torch.as_tensor(np.asarray(src), device=dst.device)
+            if src.shape != dst.shape:
+                raise ValueError(f"GraphedStep.update_sample: {k} has shape {tuple(src.shape)}, captured {tuple(dst.shape)}")
+            dst.copy_(src.to(dst.dtype))
 
     def __call__(self):
         if isinstance(self.opt, NV.HipAdam):
