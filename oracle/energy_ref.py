@@ -44,11 +44,15 @@ def total_energy(P, model, topo, cfg, sample, stage, tex_painted, uvmask_res, im
     verts, v_cano, lmks = R.flame_forward(
         tm, P["shape"][None].expand(B, -1), P["expr"][ts], P["rotation"][ts], P["neck_pose"][ts], P["jaw_pose"][ts],
         P["eyes_pose"][ts], P["translation"][ts], static_offset=P.get("static_offset"))
-    f = P["focal_length"] * max(H, W)
-    K = torch.stack([f, f, torch.full_like(f, 0.5 * W), torch.full_like(f, 0.5 * H)], dim=1)
-    RT = torch.eye(3, 4, dtype=dtype)
-    RT[2, 3] = -1
-    RT = RT[None].expand(B, -1, -1)
+    if "intrinsic" in sample and "extrinsic" in sample:      # calibrated capture (tracker.py:141-147): per-view K [B,3,3] | [B,4], RT [B,3,4]
+        K = sample["intrinsic"].to(dtype)
+        RT = sample["extrinsic"].to(dtype)
+    else:
+        f = P["focal_length"] * max(H, W)
+        K = torch.stack([f, f, torch.full_like(f, 0.5 * W), torch.full_like(f, 0.5 * H)], dim=1)
+        RT = torch.eye(3, 4, dtype=dtype)
+        RT[2, 3] = -1
+        RT = RT[None].expand(B, -1, -1)
     w = cfg.w
     st = cfg.pipeline[stage] if stage is not None else None
     opt = set(st.optimizable_params) if st is not None else set()

@@ -211,3 +211,67 @@ def test_graphed_optimize_stage_sequential_tracking(flame_model):
         assert abs(a0 - b0) <= 1e-3 * abs(a0)
         assert a1 < a0 and b1 < b0
         assert abs(a1 - b1) <= 0.03 * abs(a1), (eager, graphed)
+
+
+def test_calibrated_multiview_energy_matches_oracle(flame_model):
+    """BASELINE config 4 (NeRSemble): calibrated K [B,3,3] / RT per view, 802x550 (not a multiple of the 8x8 raster block), several
+    views of ONE timestep (duplicate rows in the per-frame gathers -> gradient atomics), w.landmark = 3, reg_tex_tv = 1e5, jawline
+    landmarks disabled -- energy and gradients against the oracle."""
+    from vhap_amd.config import nersemble_config
+    from vhap_amd.synthetic import make_texture, smooth_noise
+    from vhap_amd.tracker import GlobalTracker
+    model, topo = flame_model
+    Hc, Wc, NV_ = 550, 802, 3
+    cfg = nersemble_config()
+    cfg.model.tex_resolution = T
+    rng = np.random.default_rng(3)
+    # cameras on a +-40 degree arc at 1 m looking at the origin
+    Ks, RTs = [], []
+    for a in np.linspace(-0.7, 0.7, NV_):
+        c, s_ = np.cos(a), np.sin(a)
+        R_ = np.array([[c, 0, -s_], [0, 1, 0], [s_, 0, c]], dtype=np.float32)      # world -> camera rotation about y
+        RTs.append(np.concatenate([R_, np.array([[0.0], [0.0], [-1.0]], dtype=np.float32)], axis=1))
+        f = 1.9 * Wc
+        Ks.append(np.array([[f, 0, 0.5 * Wc + 3.0], [0, f * 1.01, 0.5 * Hc - 2.0], [0, 0, 1]], dtype=np.float32))
+    data = {"rgb": torch.from_numpy(smooth_noise(rng, (NV_, 3, Hc, Wc))).cuda(),
+            "lmk2d": torch.cat([torch.rand(NV_, 70, 2) * torch.tensor([Wc, Hc]), torch.rand(NV_, 70, 1)], -1).cuda(),
+            "intrinsic": torch.from_numpy(np.stack(Ks)).cuda(), "extrinsic": torch.from_numpy(np.stack(RTs)).cuda()}
+    tr = GlobalTracker(cfg, model, topo, make_texture(0, T), data)
+    g = torch.Generator().manual_seed(8)
+    with torch.no_grad():
+        for name, s_ in (("shape", 0.3), ("expr", 0.3), ("rotation", 0.05), ("jaw_pose", 0.05), ("tex_extra", 0.03), ("lights", 0.05),
+                         ("static_offset", 1e-3)):
+            p = getattr(tr, name)
+            p.add_((torch.randn(p.shape, generator=g) * s_).cuda())
+        tr.jaw_pose[:, 0] += 0.1
+    stage = "rgb_global_tracking"
+    tr.get_train_parameters(stage)
+    ts = np.array([1, 1, 1])                                   # the same timestep seen by three cameras
+    idx = torch.arange(NV_, device="cuda")
+    sample = {"rgb": data["rgb"], "lmk2d": data["lmk2d"], "intrinsic": data["intrinsic"], "extrinsic": data["extrinsic"],
+              "timestep_index": torch.as_tensor(ts, device="cuda")}
+    for p in tr._train_tensors:
+        p.grad = None
+    tr.render.disturb_rate_fg = tr.render.disturb_rate_bg = None
+    E, log, *_ = tr.compute_energy(sample, stage=stage)
+    E.backward()
+    tm = {k: torch.from_numpy(np.asarray(v)) for k, v in model.items()}
+    for k in ("v_template", "shapedirs", "posedirs", "J_regressor", "lbs_weights", "lmk_bary_coords", "verts_uvs"):
+        tm[k] = tm[k].double()
+    names = ["shape", "expr", "rotation", "neck_pose", "jaw_pose", "eyes_pose", "translation", "tex_extra", "lights", "static_offset"]
+    P = {k: getattr(tr, k).detach().cpu().double().requires_grad_() for k in names}
+    o_sample = {"rgb": sample["rgb"].cpu(), "lmk2d": sample["lmk2d"].cpu(), "timestep_index": ts, "intrinsic": data["intrinsic"].cpu(),
+                "extrinsic": data["extrinsic"].cpu()}
+    Eo, logo, _ = energy_ref.total_energy(P, tm, topo, cfg, o_sample, stage, torch.from_numpy(make_texture(0, T))[None].double(),
+                                          tr._uvmask_res().cpu().double(), (Hc, Wc))
+    Eo.backward()
+    for k in logo:
+        a, b = float(log[k]), float(logo[k])
+        assert abs(a - b) <= 2e-3 * max(abs(b), 1e-3), f"term {k}: {a} vs {b}"
+    for k, po in P.items():
+        if po.grad is None or float(po.grad.abs().max()) == 0:
+            continue
+        a, b = getattr(tr, k).grad.detach().cpu().double().reshape(-1), po.grad.reshape(-1)
+        rel = float((a - b).abs().max() / b.abs().max())
+        cos = float((a @ b) / (a.norm() * b.norm() + 1e-300))
+        assert cos > 0.999 and rel < 3e-2, f"grad {k}: rel {rel:.3e} cos {cos:.6f}"
