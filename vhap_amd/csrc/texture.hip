@@ -368,7 +368,7 @@ struct TileAcc {
     }
 };
 
-template <int C>
+template <int C, bool WANT_UV>
 __device__ __forceinline__ void bilinear_bwd_tile(const float* __restrict__ T, const TileAcc<C>& acc, bool use_acc, int level, const Taps& t,
                                                   const float (&g)[C], float wgt, float& gfx, float& gfy, float (&val)[C]) {
     gfx = 0.f;
@@ -377,12 +377,15 @@ __device__ __forceinline__ void bilinear_bwd_tile(const float* __restrict__ T, c
     float gk[C];
 #pragma unroll
     for (int k = 0; k < C; k++) {
-        const float a00 = T[t.i00 + k], a10 = T[t.i10 + k], a01 = T[t.i01 + k], a11 = T[t.i11 + k];
-        const float top = a00 + t.fx * (a10 - a00), bot = a01 + t.fx * (a11 - a01);
-        val[k] = top + t.fy * (bot - top);
         gk[k] = g[k] * wgt;
-        gfx += gk[k] * ((1.f - t.fy) * (a10 - a00) + t.fy * (a11 - a01));
-        gfy += gk[k] * (bot - top);
+        val[k] = 0.f;
+        if constexpr (WANT_UV) {     // the texel values are only needed for the gradient w.r.t. uv / the level
+            const float a00 = T[t.i00 + k], a10 = T[t.i10 + k], a01 = T[t.i01 + k], a11 = T[t.i11 + k];
+            const float top = a00 + t.fx * (a10 - a00), bot = a01 + t.fx * (a11 - a01);
+            val[k] = top + t.fy * (bot - top);
+            gfx += gk[k] * ((1.f - t.fy) * (a10 - a00) + t.fy * (a11 - a01));
+            gfy += gk[k] * (bot - top);
+        }
     }
     if (use_acc) {
         float v[C];
@@ -401,7 +404,7 @@ __device__ __forceinline__ void bilinear_bwd_tile(const float* __restrict__ T, c
     }
 }
 
-template <int C>
+template <int C, bool WANT_UV>
 __global__ __launch_bounds__(TT * TT) void texture_bwd_tiled_kernel(const float* __restrict__ tex, const float* __restrict__ mips,
                                                                     const TexDesc D, const float2* __restrict__ uv,
                                                                     const float4* __restrict__ uv_da, const float* __restrict__ d_out,
@@ -469,7 +472,7 @@ __global__ __launch_bounds__(TT * TT) void texture_bwd_tiled_kernel(const float*
         if (uv_da == nullptr) {
             const Taps t = make_taps(c.x, c.y, D.W, D.H, C);
             float gfx, gfy, val[C];
-            bilinear_bwd_tile<C>(level_ptr(tex, mips, D, tb, 0), acc, use_acc, 0, t, g, 1.0f, gfx, gfy, val);
+            bilinear_bwd_tile<C, WANT_UV>(level_ptr(tex, mips, D, tb, 0), acc, use_acc, 0, t, g, 1.0f, gfx, gfy, val);
             guv.x = gfx * (float)D.W;
             guv.y = gfy * (float)D.H;
             bl[0] = 0; bx0[0] = t.x0; by0[0] = t.y0; bx1[0] = t.x1; by1[0] = t.y1;
@@ -478,7 +481,7 @@ __global__ __launch_bounds__(TT * TT) void texture_bwd_tiled_kernel(const float*
             const Taps t0 = make_taps(c.x, c.y, w0, h0, C);
             const bool two = s.two && s.f > 0.0f;
             float gfx0, gfy0, c0[C];
-            bilinear_bwd_tile<C>(level_ptr(tex, mips, D, tb, s.l0), acc, use_acc, s.l0, t0, g, two ? 1.0f - s.f : 1.0f, gfx0, gfy0, c0);
+            bilinear_bwd_tile<C, WANT_UV>(level_ptr(tex, mips, D, tb, s.l0), acc, use_acc, s.l0, t0, g, two ? 1.0f - s.f : 1.0f, gfx0, gfy0, c0);
             guv.x = gfx0 * (float)w0;
             guv.y = gfy0 * (float)h0;
             bl[0] = s.l0; bx0[0] = t0.x0; by0[0] = t0.y0; bx1[0] = t0.x1; by1[0] = t0.y1;
@@ -486,7 +489,7 @@ __global__ __launch_bounds__(TT * TT) void texture_bwd_tiled_kernel(const float*
                 const int w1 = D.W >> (s.l0 + 1), h1 = D.H >> (s.l0 + 1);
                 const Taps t1 = make_taps(c.x, c.y, w1, h1, C);
                 float gfx1, gfy1, c1[C];
-                bilinear_bwd_tile<C>(level_ptr(tex, mips, D, tb, s.l0 + 1), acc, use_acc, s.l0 + 1, t1, g, s.f, gfx1, gfy1, c1);
+                bilinear_bwd_tile<C, WANT_UV>(level_ptr(tex, mips, D, tb, s.l0 + 1), acc, use_acc, s.l0 + 1, t1, g, s.f, gfx1, gfy1, c1);
                 guv.x += gfx1 * (float)w1;
                 guv.y += gfy1 * (float)h1;
                 bl[1] = s.l0 + 1; bx0[1] = t1.x0; by0[1] = t1.y0; bx1[1] = t1.x1; by1[1] = t1.y1;
@@ -702,10 +705,18 @@ extern "C" int vhap_texture_bwd(const float* tex, const float* mips, int TB, int
     const long long npix = (long long)B * H * W;
     const bool tiled = !(vhap_g_debug_flags & 32) && (long long)Ht * Wt < (1ll << 27);      // (flag 32: A/B switch to the per-pixel kernel)
     if (tiled) {
+        const bool want_uv = d_uv != nullptr || d_uv_da != nullptr;     // a texture-gradient-only call skips the texel gathers
         return dispatch_C(C, [&](auto c) {
-            texture_bwd_tiled_kernel<decltype(c)::value><<<dim3(vhap_cdiv(W, TT), vhap_cdiv(H, TT), B), TT * TT, 0, vhap_stream(stream)>>>(
-                tex, mips, D, reinterpret_cast<const float2*>(uv), reinterpret_cast<const float4*>(uv_da), d_out, H, W, d_tex, d_mips,
-                reinterpret_cast<float2*>(d_uv), reinterpret_cast<float4*>(d_uv_da), vhap_g_debug_flags);
+            constexpr int CC = decltype(c)::value;
+            const dim3 grid(vhap_cdiv(W, TT), vhap_cdiv(H, TT), B);
+            if (want_uv)
+                texture_bwd_tiled_kernel<CC, true><<<grid, TT * TT, 0, vhap_stream(stream)>>>(
+                    tex, mips, D, reinterpret_cast<const float2*>(uv), reinterpret_cast<const float4*>(uv_da), d_out, H, W, d_tex, d_mips,
+                    reinterpret_cast<float2*>(d_uv), reinterpret_cast<float4*>(d_uv_da), vhap_g_debug_flags);
+            else
+                texture_bwd_tiled_kernel<CC, false><<<grid, TT * TT, 0, vhap_stream(stream)>>>(
+                    tex, mips, D, reinterpret_cast<const float2*>(uv), reinterpret_cast<const float4*>(uv_da), d_out, H, W, d_tex, d_mips,
+                    nullptr, nullptr, vhap_g_debug_flags);
             VHAP_LAUNCH_CHECK();
             return VHAP_OK;
         });

@@ -27,6 +27,14 @@ def _chk(rc, what):
     _lib.check(rc, what)
 
 
+class _Null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 class NativeStep:
     @staticmethod
     def supported(tracker, stage):
@@ -147,10 +155,37 @@ class NativeStep:
         self.d_verts, self.vn_scratch, self.g_posed, self.g_shaped = E(B, V, 3), E(B, V, 3), E(B, V, 3), E(B, V, 3)
         self.d_mvp, self.d_K, self.d_sum = E(B, 16), E(B, 4), E(1)
         self.ones = torch.ones(8, **f32)
+        # two independent chains per pass run on two streams (two branches of the captured graph): the bandwidth / atomics bound texture
+        # work next to the latency-bound geometry chain of small launches
+        import os
+        self.overlap = os.environ.get("VHAP_STEP_OVERLAP", "1") != "0"
+        self.side = torch.cuda.Stream()
         self.c_lmk = torch.full((1,), self.w_lmk, **f32)
         self.c_reg = torch.full((1,), self.w_reg, **f32)
 
     # ------------------------------------------------------------------------------------------------
+    def _fork(self):
+        if self.overlap:
+            self.side.wait_stream(torch.cuda.current_stream())
+
+    def _join(self):
+        if self.overlap:
+            torch.cuda.current_stream().wait_stream(self.side)
+
+    def _branch(self):
+        return torch.cuda.stream(self.side) if self.overlap else _Null()
+
+    def _tex_forward(self):
+        """texture assembly + pyramid + the offset regularisers: independent of the geometry chain until the texture is sampled"""
+        L, tr, T, acc = self.L, self.tr, self.T, self.accF
+        st = _stream()
+        _chk(L.vhap_tex_prep_fwd(_p(self.painted), _p(tr.tex_extra), _p(self.nm["res_mask"]), T, *self.tex_scales, _p(self.albedo_tex),
+                                 _p(acc[7:9]), st), "vhap_tex_prep_fwd")
+        _chk(L.vhap_texture_mip_build(_p(self.albedo_tex), 1, T, T, 3, _p(self.mips), st), "vhap_texture_mip_build")
+        om = self.om
+        _chk(L.vhap_offset_reg_fwd(_p(tr.static_offset), _p(om.ptr), _p(om.col), _p(om.val), _p(om.w_lap), _p(om.w_abs), _p(om.rptr), _p(om.ridx),
+                                   om.V, om.nreg, *self.off_scales, _p(acc[9:12]), st), "vhap_offset_reg_fwd")
+
     def forward(self):
         L, tr, fb, fm = self.L, self.tr, self.fb, self.fm
         B, H, W, V, F, T, J = self.B, self.H, self.W, self.V, self.F, self.T, self.J
@@ -160,6 +195,9 @@ class NativeStep:
         L.vhap_set_call_flags(1)
         try:
             so = tr.static_offset
+            self._fork()
+            with self._branch():
+                self._tex_forward()
             _chk(L.vhap_frame_prep_fwd(_p(self.ts), _p(tr.shape), _p(tr.expr), _p(tr.rotation), _p(tr.translation), _p(tr.neck_pose),
                                        _p(tr.jaw_pose), _p(tr.eyes_pose), _p(fm.JT), _p(fm.JS), _p(fm.jreg_idx), _p(fm.jreg_w), fm.jreg_n,
                                        _p(so), fm.parents, self.weights, B, self.Bp, self.N, self.NS, self.NE, J, fb.Kp, V,
@@ -177,9 +215,7 @@ class NativeStep:
             _chk(L.vhap_raster_interp_fwd(_p(self.clip), _p(self.tri), _p(self.vn), _p(self.uv), _p(self.tri_uv), B, V, self.uv.shape[0], F, H, W,
                                           _p(self.rast), _p(self.db), _p(self.normal), _p(self.texc), _p(self.texd), _p(self.ws), self.ws_bytes,
                                           self.ws_cap, 1, st), "vhap_raster_interp_fwd")
-            _chk(L.vhap_tex_prep_fwd(_p(self.painted), _p(tr.tex_extra), _p(self.nm["res_mask"]), T, *self.tex_scales, _p(self.albedo_tex),
-                                     _p(acc[7:9]), st), "vhap_tex_prep_fwd")
-            _chk(L.vhap_texture_mip_build(_p(self.albedo_tex), 1, T, T, 3, _p(self.mips), st), "vhap_texture_mip_build")
+            self._join()
             _chk(L.vhap_texture_fwd(_p(self.albedo_tex), _p(self.mips), 1, T, T, 3, _p(self.texc), _p(self.texd), B, H, W, _p(self.albedo_px), st),
                  "vhap_texture_fwd")
             _chk(L.vhap_shade_fwd(_p(self.normal), _p(self.albedo_px), _p(self.rast), _p(self.rgb) if self.bg_col is None else 0,
@@ -195,14 +231,25 @@ class NativeStep:
             _chk(L.vhap_antialias_fwd(_p(color), _p(self.rast), _p(self.clip), _p(self.tri), _p(self.opp), B, H, W, 4, V, F, _p(self.rgba_aa),
                                       _p(self.aa_work), st), "vhap_antialias_fwd")
             _chk(L.vhap_photo_fwd(_p(self.rgba_aa), _p(self.rgb), B, H, W, _p(acc[16:18]), st), "vhap_photo_fwd")
-            om = self.om
-            _chk(L.vhap_offset_reg_fwd(_p(so), _p(om.ptr), _p(om.col), _p(om.val), _p(om.w_lap), _p(om.w_abs), _p(om.rptr), _p(om.ridx), om.V,
-                                       om.nreg, *self.off_scales, _p(acc[9:12]), st), "vhap_offset_reg_fwd")
             _chk(L.vhap_energy_finalize(_p(acc[0:6]), _p(acc[6:7]) if self.w_lmk else 0, _p(acc[7:9]), _p(acc[9:12]),
                                         _p(acc[12:16]) if self.want_reg else 0, self.w_lmk, self.w_reg, B, H, W, _p(self.log), st),
                  "vhap_energy_finalize")
         finally:
             L.vhap_set_call_flags(0)
+
+    def _tex_backward(self):
+        L, tr, T, g = self.L, self.tr, self.T, self.g
+        B, H, W = self.B, self.H, self.W
+        st = _stream()
+        n0 = self.albedo_tex.numel()
+        d_tex, d_mips = g["d_tex"][:n0], g["d_tex"][n0:]
+        _chk(L.vhap_texture_bwd(_p(self.albedo_tex), _p(self.mips), 1, T, T, 3, _p(self.texc), _p(self.texd), _p(self.d_albedo), B, H, W,
+                                _p(d_tex), _p(d_mips), 0, 0, st), "vhap_texture_bwd")
+        has_mips = self.mips.numel() > 0
+        if has_mips:
+            _chk(L.vhap_texture_mip_fold(_p(d_tex), _p(d_mips), 1, T, T, 3, 1, st), "vhap_texture_mip_fold")
+        _chk(L.vhap_tex_prep_bwd(_p(self.albedo_tex), _p(tr.tex_extra), _p(self.nm["res_mask"]), _p(d_tex), _p(d_mips) if has_mips else 0,
+                                 _p(self.ones), T, *self.tex_scales, _p(g["tex_extra"]), st), "vhap_tex_prep_bwd")
 
     def backward(self, world_size=1):
         L, tr, fb, fm, g = self.L, self.tr, self.fb, self.fm, self.g
@@ -221,15 +268,12 @@ class NativeStep:
             _chk(L.vhap_shade_bwd(_p(self.normal), _p(self.albedo_px), _p(self.rast), _p(tr.lights), _p(self.sh_const), _p(self.d_color),
                                   _p(self.keep) if self.disturb_on else 0, _p(self.c_reg) if self.want_reg else 0, _p(acc[12:16]) if self.want_reg else 0, B, H, W, _p(self.d_albedo),
                                   _p(self.d_normal), _p(g["lights"]), st), "vhap_shade_bwd")
-            n0 = self.albedo_tex.numel()
-            d_tex, d_mips = g["d_tex"][:n0], g["d_tex"][n0:]
+            # texture gradient (atomics-bound) on the side branch, uv gradient -> geometry chain on this one
+            self._fork()
+            with self._branch():
+                self._tex_backward()
             _chk(L.vhap_texture_bwd(_p(self.albedo_tex), _p(self.mips), 1, T, T, 3, _p(self.texc), _p(self.texd), _p(self.d_albedo), B, H, W,
-                                    _p(d_tex), _p(d_mips), _p(self.d_texc), _p(self.d_texd), st), "vhap_texture_bwd")
-            has_mips = self.mips.numel() > 0
-            if has_mips:
-                _chk(L.vhap_texture_mip_fold(_p(d_tex), _p(d_mips), 1, T, T, 3, 1, st), "vhap_texture_mip_fold")
-            _chk(L.vhap_tex_prep_bwd(_p(self.albedo_tex), _p(tr.tex_extra), _p(self.nm["res_mask"]), _p(d_tex), _p(d_mips) if has_mips else 0,
-                                     _p(self.ones), T, *self.tex_scales, _p(g["tex_extra"]), st), "vhap_tex_prep_bwd")
+                                    0, 0, _p(self.d_texc), _p(self.d_texd), st), "vhap_texture_bwd")
             _chk(L.vhap_gbuffer_bwd(_p(self.clip), _p(self.tri), _p(self.vn), _p(self.uv), _p(self.tri_uv), _p(self.rast), _p(self.d_normal),
                                     _p(self.d_texc), _p(self.d_texd), 0, 0, _p(self.face_mask), B, V, F, H, W, _p(g["d_clip"]), _p(g["d_vn"]), st),
                  "vhap_gbuffer_bwd")
@@ -260,6 +304,7 @@ class NativeStep:
                                        _p(self.ones), B, self.Bp, self.N, self.NS, self.NE, J, fb.Kp, V, _p(g["shape"]), _p(g["expr"]),
                                        _p(g["rotation"]), _p(g["translation"]), _p(g["neck_pose"]), _p(g["jaw_pose"]), _p(g["eyes_pose"]),
                                        _p(g["static_offset"]), st), "vhap_frame_prep_bwd")
+            self._join()
         finally:
             L.vhap_set_call_flags(0)
 
