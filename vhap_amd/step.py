@@ -131,7 +131,7 @@ class NativeStep:
                   "jaw_pose": tr.jaw_pose, "eyes_pose": tr.eyes_pose, "lights": tr.lights, "static_offset": tr.static_offset,
                   "focal_length": tr.focal_length}
         sizes = {k: p.numel() for k, p in params.items()}
-        extra = {"d_clip": B * V * 4, "d_vn": B * V * 3, "d_A": B * J * 12, "d_t": B * 3, "d_coef": Bp * fb.Kp,
+        extra = {"d_clip": B * V * 4, "d_vn": B * V * 3, "d_verts": B * V * 3, "d_A": B * J * 12, "d_t": B * 3, "d_coef": Bp * fb.Kp,
                  "d_tex": self.albedo_tex.numel() + self.mips.numel()}
         al = lambda n: (n + 63) // 64 * 64
         total = sum(al(n) for n in sizes.values()) + sum(al(n) for n in extra.values())
@@ -152,7 +152,7 @@ class NativeStep:
         # scratch that is overwritten
         self.d_rgba_aa, self.d_color, self.d_rgba = E(B, H, W, 4), E(B, H, W, 4), E(B, H, W, 4)
         self.d_albedo, self.d_normal, self.d_texc, self.d_texd = E(B, H, W, 3), E(B, H, W, 3), E(B, H, W, 2), E(B, H, W, 4)
-        self.d_verts, self.vn_scratch, self.g_posed, self.g_shaped = E(B, V, 3), E(B, V, 3), E(B, V, 3), E(B, V, 3)
+        self.vn_scratch, self.g_posed, self.g_shaped = E(B, V, 3), E(B, V, 3), E(B, V, 3)
         self.d_mvp, self.d_K, self.d_sum = E(B, 16), E(B, 4), E(1)
         self.ones = torch.ones(8, **f32)
         # two independent chains per pass run on two streams (two branches of the captured graph): the bandwidth / atomics bound texture
@@ -259,6 +259,24 @@ class NativeStep:
         L.vhap_set_call_flags(1)
         try:
             acc = self.accF
+            # the landmark and offset-regulariser gradients depend on nothing the pixel chain produces: issue them on the side branch
+            # right away (they are pure launch latency), the geometry chain picks their results up through an event
+            om = self.om
+            self._fork()
+            with self._branch():
+                st2 = _stream()
+                if self.w_lmk:
+                    l0, l1, b0, b1, boost = self.lmk_cfg
+                    _chk(L.vhap_landmark_bwd(_p(self.verts), _p(self.lm.vidx), _p(self.lm.bary), _p(self.mvp), _p(self.lmk2d), _p(self.c_lmk), B, V,
+                                             self.lm.L, self.lmk2d.shape[1], l0, l1, b0, b1, boost, H, W, _p(g["d_verts"]), _p(self.d_mvp), st2),
+                         "vhap_landmark_bwd")
+                else:
+                    self.d_mvp.zero_()
+                _chk(L.vhap_offset_reg_bwd(_p(tr.static_offset), _p(om.ptr), _p(om.col), _p(om.val), _p(om.w_lap), _p(om.w_abs), _p(om.rptr),
+                                           _p(om.ridx), om.V, om.nreg, *self.off_scales, _p(self.ones), _p(g["static_offset"]), st2),
+                     "vhap_offset_reg_bwd")
+                early = torch.cuda.Event()
+                early.record()
             _chk(L.vhap_energy_total(_p(self.log), _p(acc[16:18]), _p(self.n_global), self.w_photo, int(world_size), _p(self.d_sum), st),
                  "vhap_energy_total")
             _chk(L.vhap_photo_bwd(_p(self.rgba_aa), _p(self.rgb), _p(self.d_sum), B, H, W, _p(self.d_rgba_aa), st), "vhap_photo_bwd")
@@ -268,36 +286,28 @@ class NativeStep:
             _chk(L.vhap_shade_bwd(_p(self.normal), _p(self.albedo_px), _p(self.rast), _p(tr.lights), _p(self.sh_const), _p(self.d_color),
                                   _p(self.keep) if self.disturb_on else 0, _p(self.c_reg) if self.want_reg else 0, _p(acc[12:16]) if self.want_reg else 0, B, H, W, _p(self.d_albedo),
                                   _p(self.d_normal), _p(g["lights"]), st), "vhap_shade_bwd")
-            # texture gradient (atomics-bound) on the side branch, uv gradient -> geometry chain on this one
+            # uv gradient first (alone it takes a third of the time it needs next to the accumulation kernel), then fork: the texture
+            # gradient accumulation (atomics-bound) + fold + TV backward on the side branch, the geometry chain on this one
+            _chk(L.vhap_texture_bwd(_p(self.albedo_tex), _p(self.mips), 1, T, T, 3, _p(self.texc), _p(self.texd), _p(self.d_albedo), B, H, W,
+                                    0, 0, _p(self.d_texc), _p(self.d_texd), st), "vhap_texture_bwd")
             self._fork()
             with self._branch():
                 self._tex_backward()
-            _chk(L.vhap_texture_bwd(_p(self.albedo_tex), _p(self.mips), 1, T, T, 3, _p(self.texc), _p(self.texd), _p(self.d_albedo), B, H, W,
-                                    0, 0, _p(self.d_texc), _p(self.d_texd), st), "vhap_texture_bwd")
             _chk(L.vhap_gbuffer_bwd(_p(self.clip), _p(self.tri), _p(self.vn), _p(self.uv), _p(self.tri_uv), _p(self.rast), _p(self.d_normal),
                                     _p(self.d_texc), _p(self.d_texd), 0, 0, _p(self.face_mask), B, V, F, H, W, _p(g["d_clip"]), _p(g["d_vn"]), st),
                  "vhap_gbuffer_bwd")
-            _chk(L.vhap_vnormal_bwd(_p(self.verts), _p(self.csr.tri), _p(self.csr.ptr), _p(self.csr.idx), _p(g["d_vn"]), B, V, 0,
-                                    _p(self.vn_scratch), _p(self.d_verts), st), "vhap_vnormal_bwd")
-            if self.w_lmk:
-                l0, l1, b0, b1, boost = self.lmk_cfg
-                _chk(L.vhap_landmark_bwd(_p(self.verts), _p(self.lm.vidx), _p(self.lm.bary), _p(self.mvp), _p(self.lmk2d), _p(self.c_lmk), B, V,
-                                         self.lm.L, self.lmk2d.shape[1], l0, l1, b0, b1, boost, H, W, _p(self.d_verts), _p(self.d_mvp), st),
-                     "vhap_landmark_bwd")
-            else:
-                self.d_mvp.zero_()
-            _chk(L.vhap_transform_bwd(_p(self.verts), _p(self.mvp), _p(g["d_clip"]), B, V, 1, _p(self.d_verts), _p(self.d_mvp), st),
+            if self.overlap:
+                torch.cuda.current_stream().wait_event(early)
+            _chk(L.vhap_vnormal_bwd(_p(self.verts), _p(self.csr.tri), _p(self.csr.ptr), _p(self.csr.idx), _p(g["d_vn"]), B, V, 1,
+                                    _p(self.vn_scratch), _p(g["d_verts"]), st), "vhap_vnormal_bwd")
+            _chk(L.vhap_transform_bwd(_p(self.verts), _p(self.mvp), _p(g["d_clip"]), B, V, 1, _p(g["d_verts"]), _p(self.d_mvp), st),
                  "vhap_transform_bwd")
             _chk(L.vhap_camera_bwd(_p(self.RT), _p(self.d_mvp), B, 0, H, W, _p(self.d_K), st), "vhap_camera_bwd")
             _chk(L.vhap_focal_bwd(_p(self.d_K), B, self.focal_scale, _p(g["focal_length"]), st), "vhap_focal_bwd")
-            _chk(L.vhap_flame_skin_bwd(_p(self.d_verts), 0, _p(self.v_posed), _p(self.A), _p(fb.w), _p(fb.basisT), B, V, fb.Vp, fb.Kb, fb.Kp,
+            _chk(L.vhap_flame_skin_bwd(_p(g["d_verts"]), 0, _p(self.v_posed), _p(self.A), _p(fb.w), _p(fb.basisT), B, V, fb.Vp, fb.Kb, fb.Kp,
                                        _p(self.g_posed), _p(self.g_shaped), 0, _p(g["d_coef"]), _p(g["d_A"]), _p(g["d_t"]), st),
                  "vhap_flame_skin_bwd")
             _chk(L.vhap_sum_frames(_p(self.g_shaped), B, V * 3, _p(g["static_offset"]), st), "vhap_sum_frames")
-            om = self.om
-            _chk(L.vhap_offset_reg_bwd(_p(tr.static_offset), _p(om.ptr), _p(om.col), _p(om.val), _p(om.w_lap), _p(om.w_abs), _p(om.rptr),
-                                       _p(om.ridx), om.V, om.nreg, *self.off_scales, _p(self.ones), _p(g["static_offset"]), st),
-                 "vhap_offset_reg_bwd")
             _chk(L.vhap_frame_prep_bwd(_p(self.ts), _p(tr.shape), _p(tr.expr), _p(tr.rotation), _p(tr.translation), _p(tr.neck_pose),
                                        _p(tr.jaw_pose), _p(tr.eyes_pose), _p(fm.JS), _p(fm.jreg_idx), _p(fm.jreg_w), fm.jreg_n,
                                        _p(tr.static_offset), fm.parents, self.weights, _p(self.Jrest), _p(g["d_coef"]), _p(g["d_A"]), _p(g["d_t"]),
