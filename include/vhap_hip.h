@@ -169,18 +169,19 @@ int vhap_antialias_bwd(const float* color, const float* rast, const float* pos,
  * ------------------------------------------------------------------------------------------- */
 int vhap_shade_fwd(const float* normal_raw, const float* albedo, const float* rast,
                    const float* bg_image, const float* bg_color, const float* lights,
-                   const float* sh_const, int B, int H, int W, float* rgba, float* stats,
-                   vhap_stream_t stream);
+                   const float* sh_const, const int32_t* fid2cid, int nfid, int B, int H, int W,
+                   float* rgba, float* stats, uint8_t* cid, vhap_stream_t stream);
 int vhap_shade_bwd(const float* normal_raw, const float* albedo, const float* rast,
                    const float* lights, const float* sh_const, const float* d_rgba, const float* keep,
                    const float* d_reg, const float* stats, int B, int H, int W, float* d_albedo,
                    float* d_normal_raw, float* d_lights, vhap_stream_t stream);
 /* out2[0] = sum |gt - pred_rgb|, out2[1] = #(pred_alpha > 0); pred [B,H,W,4] renderer space,
- * gt [B,3,H,W] image space.  Backward: d_pred.rgb = -sign(gt - pred) * d_sum[0] (device scalar). */
+ * gt [B,3,H,W] image space.  Backward: d_pred.rgb = -sign(gt - pred) * d_sum[0] (device scalar); d_pred_copy (may be NULL)
+ * receives the same values -- hand it to vhap_antialias_bwd as d_color with VHAP_CALL_AA_PASSTHROUGH_DONE set. */
 int vhap_photo_fwd(const float* pred_rgba, const float* gt_nchw, int B, int H, int W, float* out2,
                    vhap_stream_t stream);
 int vhap_photo_bwd(const float* pred_rgba, const float* gt_nchw, const float* d_sum, int B, int H,
-                   int W, float* d_pred, vhap_stream_t stream);
+                   int W, float* d_pred, float* d_pred_copy, vhap_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * FLAME geometry (vhap_amd/csrc/flame.hip): replaces lbs.blend_shapes (vhap/model/lbs.py:218-239), the
@@ -232,6 +233,11 @@ int vhap_disturb_fwd(const float* rgba, const float* rast, const int32_t* fid2ci
 int vhap_disturb_fwd_rng(const float* rgba, const float* rast, const int32_t* fid2cid, int nfid, int ncl,
                          float rate_fg, float rate_bg, uint32_t* rng_state, int B, int H, int W,
                          int32_t* workspace, float* out, float* keep, vhap_stream_t stream);
+/* same, reading the per-pixel cluster from the one-byte image `cid` [B,H,W] that vhap_shade_fwd writes (fid2cid / cid arguments
+ * there) instead of going through `rast` and the table: 4 MB instead of 67 MB per pass at 16x512^2 */
+int vhap_disturb_fwd_rng_cid(const float* rgba, const uint8_t* cid, int ncl, float rate_fg, float rate_bg,
+                             uint32_t* rng_state, int B, int H, int W, int32_t* workspace, float* out,
+                             float* keep, vhap_stream_t stream);
 int vhap_disturb_bwd(const float* d_out, const float* keep, int B, int H, int W, float* d_rgba,
                      vhap_stream_t stream);
 
@@ -339,6 +345,7 @@ int vhap_adam_step(int n_tensors, float* const* params, const float* const* grad
  *   (the upstream gradient handed to vhap_photo_bwd).
  * ------------------------------------------------------------------------------------------- */
 #define VHAP_CALL_ACC_PREZEROED 1
+#define VHAP_CALL_AA_PASSTHROUGH_DONE 2   /* vhap_antialias_bwd: d_color already holds a copy of d_out (skip the pass-through copy) */
 enum {
     VHAP_LOG_LMK = 0, VHAP_LOG_PHOTO = 1, VHAP_LOG_SMOOTH_POSE = 2, VHAP_LOG_REG_JOINT = 3, VHAP_LOG_SMOOTH_JOINT = 4,
     VHAP_LOG_REG_EXPR = 5, VHAP_LOG_SMOOTH_EXPR = 6, VHAP_LOG_REG_SHAPE = 7, VHAP_LOG_TEX_TV = 8, VHAP_LOG_TEX_RES = 9,

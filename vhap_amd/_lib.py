@@ -41,11 +41,12 @@ SIGNATURES = {
     "vhap_disturb_workspace_ints": (c_sz, [c_i] * 3),
     "vhap_disturb_fwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
     "vhap_disturb_fwd_rng": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_f, c_f, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
+    "vhap_disturb_fwd_rng_cid": (c_i, [c_fp, c_fp, c_i, c_f, c_f, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
     "vhap_disturb_bwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp]),
-    "vhap_shade_fwd": (c_i, [c_fp] * 7 + [c_i] * 3 + [c_fp] * 3),
+    "vhap_shade_fwd": (c_i, [c_fp] * 8 + [c_i] * 4 + [c_fp] * 4),
     "vhap_shade_bwd": (c_i, [c_fp] * 9 + [c_i] * 3 + [c_fp] * 4),
     "vhap_photo_fwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp]),
-    "vhap_photo_bwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp]),
+    "vhap_photo_bwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
     "vhap_flame_skin_fwd": (c_i, [c_fp] * 7 + [c_i] * 6 + [c_fp] * 4),
     "vhap_flame_bwd_partial_floats": (c_sz, [c_i] * 3),
     "vhap_flame_skin_bwd": (c_i, [c_fp] * 6 + [c_i] * 5 + [c_fp] * 7),

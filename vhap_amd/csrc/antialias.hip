@@ -371,7 +371,7 @@ extern "C" int vhap_antialias_bwd(const float* color, const float* rast, const f
     if (B <= 0 || H <= 0 || W <= 0 || V <= 0 || F <= 0) return VHAP_E_BADDIM;
     hipStream_t st = vhap_stream(stream);
     const long long n = (long long)B * H * W * C;
-    if (d_color) {   // pass-through part of the gradient
+    if (d_color && !(vhap_g_call_flags & VHAP_CALL_AA_PASSTHROUGH_DONE)) {   // pass-through part of the gradient
         vhap_copy_async(d_color, d_out, sizeof(float) * n, st);
         VHAP_LAUNCH_CHECK();
     }

@@ -20,9 +20,18 @@ constexpr int DB = 1024;  // threads per counting-sort workgroup
 constexpr int PPT = 8;    // pixels per thread: a workgroup owns DB * PPT consecutive pixels (8192: 512 workgroups at 16x512^2)
 constexpr int DPIX = DB * PPT;
 
-__device__ __forceinline__ int pixel_cluster(const float4* __restrict__ rast, const int* __restrict__ fid2cid, int nfid, long long p) {
-    const int fid = (int)rast[p].w;
-    return fid2cid[min(max(fid, 0), nfid - 1)];
+// cluster of pixel p: from the compact one-byte cluster image when the shading kernel wrote one (4 MB instead of a 67 MB pass over
+// the rasteriser output at 16x512^2), else through the triangle id of rast and the fid -> cluster table
+struct ClusterSrc {
+    const float4* rast;
+    const int* fid2cid;
+    int nfid;
+    const unsigned char* cid;
+};
+__device__ __forceinline__ int pixel_cluster(const ClusterSrc& s, long long p) {
+    if (s.cid) return (int)s.cid[p];
+    const int fid = (int)s.rast[p].w;
+    return s.fid2cid[min(max(fid, 0), s.nfid - 1)];
 }
 
 // counter-based random bits (two rounds of the murmur3 finaliser over a Weyl-mixed key): statistically ample for a
@@ -36,7 +45,7 @@ __device__ __forceinline__ unsigned rnd32(unsigned seed, unsigned p, unsigned dr
 }
 
 // pass 1: block_counts[block][c]; also advances the random-stream counter of the call (nobody reads it during this pass)
-__global__ __launch_bounds__(DB) void disturb_count_kernel(const float4* __restrict__ rast, const int* __restrict__ fid2cid, int nfid,
+__global__ __launch_bounds__(DB) void disturb_count_kernel(const ClusterSrc src,
                                                             int ncl, long long n, int* __restrict__ block_counts,
                                                             unsigned* __restrict__ rng_state) {
     __shared__ int cnt[DB / 64][MAXC];
@@ -48,7 +57,7 @@ __global__ __launch_bounds__(DB) void disturb_count_kernel(const float4* __restr
 #pragma unroll
     for (int it = 0; it < PPT; it++) {
         const long long p = (long long)blockIdx.x * DPIX + it * DB + threadIdx.x;
-        const int c = p < n ? pixel_cluster(rast, fid2cid, nfid, p) : -1;
+        const int c = p < n ? pixel_cluster(src, p) : -1;
 #pragma unroll
         for (int k = 0; k < MAXC; k++)
             if (k < ncl) mine[k] += __popcll(__ballot(c == k));     // wave-uniform
@@ -68,7 +77,7 @@ __global__ __launch_bounds__(DB) void disturb_count_kernel(const float4* __restr
 // pass 2: every workgroup derives its own exclusive prefix (and the cluster totals) from the per-block histograms -- nblocks * 64 B,
 // L2-resident -- instead of waiting for a single-workgroup scan; then perm[start_c + prefix_c + rank in block] = pixel id.
 // Workgroup 0 publishes totals[c] and totals[MAXC + c] = start_c for the gather pass.
-__global__ __launch_bounds__(DB) void disturb_scatter_kernel(const float4* __restrict__ rast, const int* __restrict__ fid2cid, int nfid,
+__global__ __launch_bounds__(DB) void disturb_scatter_kernel(const ClusterSrc src,
                                                               int ncl, long long n, int nblocks, const int* __restrict__ block_counts,
                                                               int* __restrict__ totals, int* __restrict__ perm) {
     __shared__ int red[2][DB / 64][MAXC];
@@ -100,7 +109,7 @@ __global__ __launch_bounds__(DB) void disturb_scatter_kernel(const float4* __res
 #pragma unroll
     for (int it = 0; it < PPT; it++) {
         const long long p = (long long)blockIdx.x * DPIX + it * DB + threadIdx.x;
-        const int c = p < n ? pixel_cluster(rast, fid2cid, nfid, p) : -1;
+        const int c = p < n ? pixel_cluster(src, p) : -1;
         int rank = 0;
         for (int k = 0; k < ncl; k++) {
             const unsigned long long m = __ballot(c == k);
@@ -141,7 +150,7 @@ __global__ __launch_bounds__(DB) void disturb_scatter_kernel(const float4* __res
 // pass 4: out = w ? src[perm[start_c + idx % n_c]] : cur ; keep = 1 - w_eff (gradient mask for the backward)
 __global__ __launch_bounds__(256) void disturb_apply_kernel(const float4* __restrict__ rgba, const float4* __restrict__ rgba_bg_or_null,
                                                             const float* __restrict__ bg_image, int B, int H, int W,
-                                                            const float4* __restrict__ rast, const int* __restrict__ fid2cid, int nfid,
+                                                            const ClusterSrc src,
                                                             const int* __restrict__ w_fg, const int* __restrict__ w_bg,
                                                             const long long* __restrict__ idx, const unsigned* __restrict__ rng_state,
                                                             float rate_fg, float rate_bg, const int* __restrict__ totals,
@@ -150,7 +159,7 @@ __global__ __launch_bounds__(256) void disturb_apply_kernel(const float4* __rest
     const long long n = (long long)B * H * W;
     const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
     if (p >= n) return;
-    const int c = pixel_cluster(rast, fid2cid, nfid, p);
+    const int c = pixel_cluster(src, p);
     int w;
     unsigned long long pick;
     if (rng_state) {     // in-kernel random numbers: Bernoulli(rate) and a 32-bit index draw per pixel
@@ -192,24 +201,25 @@ extern "C" size_t vhap_disturb_workspace_ints(int B, int H, int W) {
     return (size_t)(2 * MAXC + nblocks * MAXC + n);
 }
 
-static int disturb_run(const float* rgba, const float* rast, const int32_t* fid2cid, int nfid, int ncl, const int32_t* w_fg,
+static int disturb_run(const float* rgba, const float* rast, const uint8_t* cid, const int32_t* fid2cid, int nfid, int ncl, const int32_t* w_fg,
                        const int32_t* w_bg, const int64_t* idx, uint32_t* rng_state, float rate_fg, float rate_bg, int B, int H, int W,
                        int32_t* workspace, float* out, float* keep, vhap_stream_t stream) {
-    if (!rgba || !rast || !fid2cid || !workspace || !out || !keep) return VHAP_E_NULLPTR;
+    if (!rgba || !workspace || !out || !keep) return VHAP_E_NULLPTR;
+    if (!cid && (!rast || !fid2cid)) return VHAP_E_NULLPTR;
     if (!rng_state && (!w_fg || !w_bg || !idx)) return VHAP_E_NULLPTR;
-    if (B <= 0 || H <= 0 || W <= 0 || ncl <= 0 || ncl > MAXC || nfid <= 0 || (long long)B * H * W >= (1ll << 31)) return VHAP_E_BADDIM;
+    if (B <= 0 || H <= 0 || W <= 0 || ncl <= 0 || ncl > MAXC || (!cid && nfid <= 0) || (long long)B * H * W >= (1ll << 31)) return VHAP_E_BADDIM;
     const long long n = (long long)B * H * W;
     const int nblocks = vhap_cdiv(n, DPIX);
     int* totals = workspace;
     int* block_counts = workspace + 2 * MAXC;
     int* perm = block_counts + (size_t)nblocks * MAXC;
     hipStream_t st = vhap_stream(stream);
-    const float4* r4 = reinterpret_cast<const float4*>(rast);
-    disturb_count_kernel<<<nblocks, DB, 0, st>>>(r4, fid2cid, nfid, ncl, n, block_counts, rng_state);
+    const ClusterSrc src{reinterpret_cast<const float4*>(rast), fid2cid, nfid, cid};
+    disturb_count_kernel<<<nblocks, DB, 0, st>>>(src, ncl, n, block_counts, rng_state);
     VHAP_LAUNCH_CHECK();
-    disturb_scatter_kernel<<<nblocks, DB, 0, st>>>(r4, fid2cid, nfid, ncl, n, nblocks, block_counts, totals, perm);
+    disturb_scatter_kernel<<<nblocks, DB, 0, st>>>(src, ncl, n, nblocks, block_counts, totals, perm);
     VHAP_LAUNCH_CHECK();
-    disturb_apply_kernel<<<vhap_cdiv(n, 256), 256, 0, st>>>(reinterpret_cast<const float4*>(rgba), nullptr, nullptr, B, H, W, r4, fid2cid, nfid, w_fg,
+    disturb_apply_kernel<<<vhap_cdiv(n, 256), 256, 0, st>>>(reinterpret_cast<const float4*>(rgba), nullptr, nullptr, B, H, W, src, w_fg,
                                                   w_bg, reinterpret_cast<const long long*>(idx), rng_state, rate_fg, rate_bg, totals, perm,
                                                   reinterpret_cast<float4*>(out), keep);
     VHAP_LAUNCH_CHECK();
@@ -220,7 +230,7 @@ extern "C" int vhap_disturb_fwd(const float* rgba, const float* rast, const int3
                                 const int32_t* w_bg, const int64_t* idx, int B, int H, int W, int32_t* workspace, float* out,
                                 float* keep, vhap_stream_t stream) {
     VHAP_ENTER();
-    return disturb_run(rgba, rast, fid2cid, nfid, ncl, w_fg, w_bg, idx, nullptr, 0.f, 0.f, B, H, W, workspace, out, keep, stream);
+    return disturb_run(rgba, rast, nullptr, fid2cid, nfid, ncl, w_fg, w_bg, idx, nullptr, 0.f, 0.f, B, H, W, workspace, out, keep, stream);
 }
 
 extern "C" int vhap_disturb_fwd_rng(const float* rgba, const float* rast, const int32_t* fid2cid, int nfid, int ncl, float rate_fg,
@@ -228,7 +238,15 @@ extern "C" int vhap_disturb_fwd_rng(const float* rgba, const float* rast, const 
                                     float* keep, vhap_stream_t stream) {
     VHAP_ENTER();
     if (!rng_state) return VHAP_E_NULLPTR;
-    return disturb_run(rgba, rast, fid2cid, nfid, ncl, nullptr, nullptr, nullptr, rng_state, rate_fg, rate_bg, B, H, W, workspace, out, keep,
+    return disturb_run(rgba, rast, nullptr, fid2cid, nfid, ncl, nullptr, nullptr, nullptr, rng_state, rate_fg, rate_bg, B, H, W, workspace, out, keep,
+                       stream);
+}
+
+extern "C" int vhap_disturb_fwd_rng_cid(const float* rgba, const uint8_t* cid, int ncl, float rate_fg, float rate_bg, uint32_t* rng_state,
+                                        int B, int H, int W, int32_t* workspace, float* out, float* keep, vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!rng_state || !cid) return VHAP_E_NULLPTR;
+    return disturb_run(rgba, nullptr, cid, nullptr, 0, ncl, nullptr, nullptr, nullptr, rng_state, rate_fg, rate_bg, B, H, W, workspace, out, keep,
                        stream);
 }
 

@@ -53,6 +53,9 @@ struct ShadeParams {
     const float* lights;      // [9,3]
     const float* sh_const;    // [9]
     int B, H, W;
+    const int* fid2cid;       // optional: triangle id + 1 -> colour cluster (0 = background) ...
+    int nfid;
+    unsigned char* cid;       // ... written per pixel for the disturbance pass (it then never touches `rast`)
 };
 
 // stats (4 words): [0..1] = u64 (ordered-uint max of diffuse << 32 | number of entries equal to it), [2] = float sum over
@@ -92,7 +95,9 @@ __global__ __launch_bounds__(PB) __attribute__((amdgpu_waves_per_eu(4, 4))) void
                 if (d[c] > mxv) { mxv = d[c]; mxn = 1u; }
                 else if (d[c] == mxv) mxn++;
             }
-            const bool fg = P.rast[pi].w > 0.0f;
+            const float rw = P.rast[pi].w;
+            const bool fg = rw > 0.0f;
+            if (P.cid) P.cid[pi] = (unsigned char)P.fid2cid[min(max((int)rw, 0), P.nfid - 1)];
             float4 o;
             if (fg) {
                 const float* al = P.albedo + 3 * (size_t)pi;
@@ -272,7 +277,7 @@ __global__ __launch_bounds__(PB) void photo_fwd_kernel(const float4* __restrict_
 // d_pred.rgb = -sign(gt - pred) * d_sum[0]; d_pred.a = 0
 __global__ __launch_bounds__(256) void photo_bwd_kernel(const float4* __restrict__ pred, const float* __restrict__ gt,
                                                         const float* __restrict__ d_sum, int B, int H, int W,
-                                                        float4* __restrict__ d_pred) {
+                                                        float4* __restrict__ d_pred, float4* __restrict__ d_pred2) {
     const unsigned npix = (unsigned)B * H * W;      // < 2^31 (check_img)
     const unsigned pi = blockIdx.x * 256u + threadIdx.x;
     if (pi >= npix) return;
@@ -283,7 +288,9 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(const float4* __restrict
     const float* g = gt + (size_t)b * 3 * HW + (size_t)(H - 1 - y) * W + x;
     const float4 p = pred[pi];
     auto sg = [](float e) { return e > 0.f ? 1.0f : (e < 0.f ? -1.0f : 0.0f); };
-    d_pred[pi] = make_float4(-sg(g[0] - p.x) * gs, -sg(g[HW] - p.y) * gs, -sg(g[2 * HW] - p.z) * gs, 0.0f);
+    const float4 d = make_float4(-sg(g[0] - p.x) * gs, -sg(g[HW] - p.y) * gs, -sg(g[2 * HW] - p.z) * gs, 0.0f);
+    d_pred[pi] = d;
+    if (d_pred2) d_pred2[pi] = d;     // second copy: the pass-through part of the antialias backward, written here instead of copied there
 }
 
 int check_img(int B, int H, int W) {
@@ -294,13 +301,14 @@ int check_img(int B, int H, int W) {
 }  // namespace
 
 extern "C" int vhap_shade_fwd(const float* normal_raw, const float* albedo, const float* rast, const float* bg_image,
-                              const float* bg_color, const float* lights, const float* sh_const, int B, int H, int W,
-                              float* rgba, float* stats, vhap_stream_t stream) {
+                              const float* bg_color, const float* lights, const float* sh_const, const int32_t* fid2cid, int nfid,
+                              int B, int H, int W, float* rgba, float* stats, uint8_t* cid, vhap_stream_t stream) {
     VHAP_ENTER();
     if (!normal_raw || !albedo || !rast || !lights || !sh_const || !rgba) return VHAP_E_NULLPTR;
     if (!bg_image && !bg_color) return VHAP_E_NULLPTR;
+    if (cid && (!fid2cid || nfid <= 0)) return VHAP_E_NULLPTR;
     if (int e = check_img(B, H, W)) return e;
-    ShadeParams P{normal_raw, albedo, reinterpret_cast<const float4*>(rast), bg_image, 0.f, 0.f, 0.f, lights, sh_const, B, H, W};
+    ShadeParams P{normal_raw, albedo, reinterpret_cast<const float4*>(rast), bg_image, 0.f, 0.f, 0.f, lights, sh_const, B, H, W, fid2cid, nfid, cid};
     if (!bg_image) { P.bg_r = bg_color[0]; P.bg_g = bg_color[1]; P.bg_b = bg_color[2]; }
     hipStream_t st = vhap_stream(stream);
     if (stats) VHAP_ZERO_ACC(stats, 16, st);
@@ -316,7 +324,7 @@ extern "C" int vhap_shade_bwd(const float* normal_raw, const float* albedo, cons
     VHAP_ENTER();
     if (!normal_raw || !albedo || !rast || !lights || !sh_const || !d_rgba) return VHAP_E_NULLPTR;
     if (int e = check_img(B, H, W)) return e;
-    ShadeParams P{normal_raw, albedo, reinterpret_cast<const float4*>(rast), nullptr, 0.f, 0.f, 0.f, lights, sh_const, B, H, W};
+    ShadeParams P{normal_raw, albedo, reinterpret_cast<const float4*>(rast), nullptr, 0.f, 0.f, 0.f, lights, sh_const, B, H, W, nullptr, 0, nullptr};
     const long long npix = (long long)B * H * W;
     shade_bwd_kernel<<<min(vhap_cdiv(npix, PBB), MAX_BLOCKS), PBB, 0, vhap_stream(stream)>>>(
         P, reinterpret_cast<const float4*>(d_rgba), keep, d_reg, reinterpret_cast<const unsigned*>(stats), d_albedo, d_normal_raw, d_lights);
@@ -338,13 +346,13 @@ extern "C" int vhap_photo_fwd(const float* pred_rgba, const float* gt_nchw, int 
 }
 
 extern "C" int vhap_photo_bwd(const float* pred_rgba, const float* gt_nchw, const float* d_sum, int B, int H, int W,
-                              float* d_pred, vhap_stream_t stream) {
+                              float* d_pred, float* d_pred_copy, vhap_stream_t stream) {
     VHAP_ENTER();
     if (!pred_rgba || !gt_nchw || !d_sum || !d_pred) return VHAP_E_NULLPTR;
     if (int e = check_img(B, H, W)) return e;
     const long long npix = (long long)B * H * W;
     photo_bwd_kernel<<<vhap_cdiv(npix, 256), 256, 0, vhap_stream(stream)>>>(reinterpret_cast<const float4*>(pred_rgba), gt_nchw,
-                                                                           d_sum, B, H, W, reinterpret_cast<float4*>(d_pred));
+                                                                           d_sum, B, H, W, reinterpret_cast<float4*>(d_pred), reinterpret_cast<float4*>(d_pred_copy));
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;
 }

@@ -175,7 +175,7 @@ class _Shade(torch.autograd.Function):
         stats = torch.empty(4, dtype=torch.float32, device=rast.device) if want_reg else None
         col = (ctypes.c_float * 3)(*bg_color) if bg_color is not None else None
         _chk(_lib.lib().vhap_shade_fwd(_p(normal_raw), _p(albedo), _p(rast), _p(bg_image), ctypes.cast(col, ctypes.c_void_p) if col else 0,
-                                       _p(lights), _p(sh_const), B, H, W, _p(rgba), _p(stats), _stream()), "vhap_shade_fwd")
+                                       _p(lights), _p(sh_const), 0, 0, B, H, W, _p(rgba), _p(stats), 0, _stream()), "vhap_shade_fwd")
         ctx.save_for_backward(normal_raw, albedo, lights, rast, sh_const, stats)
         if want_reg:
             mx = _decode_ordered_max(stats)
@@ -228,7 +228,7 @@ class _PhotoSum(torch.autograd.Function):
         pred, gt = ctx.saved_tensors
         B, H, W, _ = pred.shape
         d_pred = torch.empty_like(pred)
-        _chk(_lib.lib().vhap_photo_bwd(_p(pred), _p(gt), _p(_f32c(d_sum.reshape(1))), B, H, W, _p(d_pred), _stream()), "vhap_photo_bwd")
+        _chk(_lib.lib().vhap_photo_bwd(_p(pred), _p(gt), _p(_f32c(d_sum.reshape(1))), B, H, W, _p(d_pred), 0, _stream()), "vhap_photo_bwd")
         return d_pred, None
 
 

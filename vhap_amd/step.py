@@ -120,6 +120,7 @@ class NativeStep:
         if self.disturb_on:
             self.rgba_d, self.keep = E(B, H, W, 4), E(B, H, W)
             self.dist_ws = torch.empty(L.vhap_disturb_workspace_ints(B, H, W), dtype=torch.int32, device=dev)
+            self.cid = torch.empty(B, H, W, dtype=torch.uint8, device=dev)
         self.aa_work = torch.empty(L.vhap_antialias_work_ints(B, H, W, self.F), dtype=torch.int32, device=dev)
         self.ws, self.ws_bytes, self.ws_cap, _ = tr.render.glctx.acquire(B, self.F, H, W, self.rgb.device)
         # forward accumulators: frame terms [0:6], landmark [6], texture terms [7:9], offset terms [9:12], shade stats [12:16], photo [16:18]
@@ -220,12 +221,14 @@ class NativeStep:
                  "vhap_texture_fwd")
             _chk(L.vhap_shade_fwd(_p(self.normal), _p(self.albedo_px), _p(self.rast), _p(self.rgb) if self.bg_col is None else 0,
                                   ctypes.cast(self.bg_col, ctypes.c_void_p) if self.bg_col is not None else 0, _p(tr.lights), _p(self.sh_const),
-                                  B, H, W, _p(self.rgba), _p(acc[12:16]) if self.want_reg else 0, st), "vhap_shade_fwd")
+                                  _p(self.fid2cid) if self.disturb_on else 0, self.fid2cid.numel() if self.disturb_on else 0,
+                                  B, H, W, _p(self.rgba), _p(acc[12:16]) if self.want_reg else 0, _p(self.cid) if self.disturb_on else 0, st),
+                 "vhap_shade_fwd")
             color = self.rgba
             if self.disturb_on:
-                _chk(L.vhap_disturb_fwd_rng(_p(self.rgba), _p(self.rast), _p(self.fid2cid), self.fid2cid.numel(), self.ncl,
-                                            float(self.rate_fg or 0.0), float(self.rate_bg or 0.0), _p(self.rng), B, H, W, _p(self.dist_ws),
-                                            _p(self.rgba_d), _p(self.keep), st), "vhap_disturb_fwd_rng")
+                _chk(L.vhap_disturb_fwd_rng_cid(_p(self.rgba), _p(self.cid), self.ncl, float(self.rate_fg or 0.0), float(self.rate_bg or 0.0),
+                                                _p(self.rng), B, H, W, _p(self.dist_ws), _p(self.rgba_d), _p(self.keep), st),
+                     "vhap_disturb_fwd_rng_cid")
                 color = self.rgba_d
             self.aa_in = color
             _chk(L.vhap_antialias_fwd(_p(color), _p(self.rast), _p(self.clip), _p(self.tri), _p(self.opp), B, H, W, 4, V, F, _p(self.rgba_aa),
@@ -279,9 +282,11 @@ class NativeStep:
                 early.record()
             _chk(L.vhap_energy_total(_p(self.log), _p(acc[16:18]), _p(self.n_global), self.w_photo, int(world_size), _p(self.d_sum), st),
                  "vhap_energy_total")
-            _chk(L.vhap_photo_bwd(_p(self.rgba_aa), _p(self.rgb), _p(self.d_sum), B, H, W, _p(self.d_rgba_aa), st), "vhap_photo_bwd")
+            _chk(L.vhap_photo_bwd(_p(self.rgba_aa), _p(self.rgb), _p(self.d_sum), B, H, W, _p(self.d_rgba_aa), _p(self.d_color), st), "vhap_photo_bwd")
+            L.vhap_set_call_flags(1 | 2)      # d_color already holds the pass-through copy of d_rgba_aa
             _chk(L.vhap_antialias_bwd(_p(self.aa_in), _p(self.rast), _p(self.clip), _p(self.tri), _p(self.opp), _p(self.d_rgba_aa), _p(self.aa_work),
                                       _p(self.vert_mask), B, H, W, 4, V, F, _p(self.d_color), _p(g["d_clip"]), st), "vhap_antialias_bwd")
+            L.vhap_set_call_flags(1)
             # (the backward of the disturbance -- d_rgba = d_color * keep -- is folded into the shading backward)
             _chk(L.vhap_shade_bwd(_p(self.normal), _p(self.albedo_px), _p(self.rast), _p(tr.lights), _p(self.sh_const), _p(self.d_color),
                                   _p(self.keep) if self.disturb_on else 0, _p(self.c_reg) if self.want_reg else 0, _p(acc[12:16]) if self.want_reg else 0, B, H, W, _p(self.d_albedo),
