@@ -113,8 +113,8 @@ int vhap_interp_bwd(const float* attr, int AB, const float* rast, const int32_t*
  *   holds levels 1..L (level 0 is `tex` itself); build it once per optimiser step.
  *   uv [B,H,W,2]; uv_da [B,H,W,4] (NULL -> plain bilinear on level 0); out [B,H,W,C].
  * Backward: d_tex [TB,Ht,Wt,C] and d_mips are ACCUMULATED with atomics (caller zero-fills
- * both), then vhap_texture_mip_fold() folds d_mips down into d_tex (stop_level = 0) or only down to level 1
- * (stop_level = 1: the caller adds 0.25 * d_level1[y/2][x/2] itself, see vhap_tex_prep_bwd).  d_uv [B,H,W,2] and
+ * both), then vhap_texture_mip_fold() folds d_mips down into d_tex (stop_level = 0) or only down to level `stop_level`
+ * (the caller gathers levels 1..stop_level itself, see vhap_tex_prep_bwd).  d_uv [B,H,W,2] and
  * d_uv_da [B,H,W,4] are overwritten (either may be NULL).
  * ------------------------------------------------------------------------------------------- */
 int vhap_texture_num_levels(int Ht, int Wt);
@@ -305,8 +305,9 @@ int vhap_landmark_bwd(const float* verts, const int32_t* lmk_vidx, const float* 
  *   w_lap / w_abs [V] or NULL).  bwd: d_offset [V,3] ACCUMULATED.
  * tex_prep: albedo_hwc [T,T,3] = painted [3,T,T] + extra [3,T,T] (either may be NULL); terms[2] = s_tv * TV(albedo),
  *   s_res * sum(extra^2 * res_mask) (tracker.py:247-258, 518-541; res_mask [T,T] uint8 or NULL).  bwd: d_extra [3,T,T]
- *   overwritten (d_albedo_hwc may be NULL); d_mip1_hwc [T/2,T/2,3] or NULL: unfolded gradient of mip level 1, added as
- *   0.25 * d_mip1[y/2][x/2] (the last step of vhap_texture_mip_fold fused into this pass).
+ *   overwritten (d_albedo_hwc may be NULL); d_mips_hwc: the gradient pyramid (layout of vhap_texture_mip_build) folded down to
+ *   level n_gather by vhap_texture_mip_fold(stop_level = n_gather); levels 1..n_gather are gathered here as
+ *   4^-l * d_level_l[y >> l][x >> l] (the last steps of the fold fused into this pass; NULL / 0 = none).
  * adam_step: torch.optim.Adam update (tracker.py:159-211) of up to VHAP_ADAM_MAX_TENSORS tensors in one launch; the
  *   pointer tables are HOST arrays of device pointers; lr_device[lr_index[k]] and step_device[0] live on the device
  *   (graph replays see their current values); step_device is incremented.
@@ -324,8 +325,8 @@ int vhap_offset_reg_bwd(const float* offset, const int32_t* lap_ptr, const int32
 int vhap_tex_prep_fwd(const float* painted, const float* extra, const uint8_t* res_mask, int T, float s_tv,
                       float s_res, float* albedo_hwc, float* terms, vhap_stream_t stream);
 int vhap_tex_prep_bwd(const float* albedo_hwc, const float* extra, const uint8_t* res_mask,
-                      const float* d_albedo_hwc, const float* d_mip1_hwc, const float* d_terms, int T,
-                      float s_tv, float s_res, float* d_extra, vhap_stream_t stream);
+                      const float* d_albedo_hwc, const float* d_mips_hwc, int n_gather, const float* d_terms,
+                      int T, float s_tv, float s_res, float* d_extra, vhap_stream_t stream);
 int vhap_adam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                    float* const* exp_avg_sq, const int64_t* numel, const int32_t* lr_index,
                    const float* lr_device, int32_t* step_device, float beta1, float beta2, float eps,

@@ -178,7 +178,7 @@ __global__ __launch_bounds__(RB) void tex_prep_fwd_kernel(TexCfg c, const float*
 // d_extra[c,y,x] = d_albedo[y,x,c] + TV stencil on the saved albedo + masked residual
 __global__ __launch_bounds__(RB) void tex_prep_bwd_kernel(TexCfg c, const float* __restrict__ albedo, const float* __restrict__ extra,
                                                           const unsigned char* __restrict__ res_mask, const float* __restrict__ d_albedo,
-                                                          const float* __restrict__ d_mip1, const float* __restrict__ d_terms,
+                                                          const float* __restrict__ d_mips, int n_gather, const float* __restrict__ d_terms,
                                                           float* __restrict__ d_extra) {
     const int T = c.T;
     const size_t plane = (size_t)T * T;
@@ -187,9 +187,16 @@ __global__ __launch_bounds__(RB) void tex_prep_bwd_kernel(TexCfg c, const float*
         const int y = (int)(i / T), x = (int)(i - (size_t)y * T);
         float g[3] = {0.f, 0.f, 0.f};
         if (d_albedo) { g[0] = d_albedo[3 * i]; g[1] = d_albedo[3 * i + 1]; g[2] = d_albedo[3 * i + 2]; }
-        if (d_mip1) {       // box-filter backward of mip level 1 -> 0
-            const float* m = d_mip1 + 3 * ((size_t)(y >> 1) * (T >> 1) + (x >> 1));
-            g[0] += 0.25f * m[0]; g[1] += 0.25f * m[1]; g[2] += 0.25f * m[2];
+        if (d_mips) {       // box-filter backward of the first n_gather mip levels, gathered: level l contributes 4^-l of its texel
+            size_t off = 0;
+            float sc = 0.25f;
+            for (int l = 1; l <= n_gather; l++) {
+                const int tl = T >> l;
+                const float* m = d_mips + off + 3 * ((size_t)(y >> l) * tl + (x >> l));
+                g[0] += sc * m[0]; g[1] += sc * m[1]; g[2] += sc * m[2];
+                off += (size_t)tl * tl * 3;
+                sc *= 0.25f;
+            }
         }
         if (gtv != 0.f) {
             const float* a = albedo + 3 * i;
@@ -292,14 +299,14 @@ extern "C" int vhap_tex_prep_fwd(const float* painted, const float* extra, const
 }
 
 extern "C" int vhap_tex_prep_bwd(const float* albedo_hwc, const float* extra, const uint8_t* res_mask, const float* d_albedo_hwc,
-                                 const float* d_mip1_hwc, const float* d_terms, int T, float s_tv, float s_res, float* d_extra,
-                                 vhap_stream_t stream) {
+                                 const float* d_mips_hwc, int n_gather, const float* d_terms, int T, float s_tv, float s_res,
+                                 float* d_extra, vhap_stream_t stream) {
     VHAP_ENTER();
     if (!albedo_hwc || !extra || !d_terms || !d_extra) return VHAP_E_NULLPTR;
-    if (T <= 0 || (d_mip1_hwc && (T & 1))) return VHAP_E_BADDIM;
+    if (T <= 0 || n_gather < 0 || (d_mips_hwc && n_gather > 0 && (T & ((1 << n_gather) - 1)))) return VHAP_E_BADDIM;
     TexCfg c{T, s_tv, s_res};
     const int blocks = (int)(((size_t)T * T + RB - 1) / RB < 8192 ? ((size_t)T * T + RB - 1) / RB : 8192);
-    tex_prep_bwd_kernel<<<blocks, RB, 0, vhap_stream(stream)>>>(c, albedo_hwc, extra, res_mask, d_albedo_hwc, d_mip1_hwc, d_terms, d_extra);
+    tex_prep_bwd_kernel<<<blocks, RB, 0, vhap_stream(stream)>>>(c, albedo_hwc, extra, res_mask, d_albedo_hwc, n_gather > 0 ? d_mips_hwc : nullptr, n_gather, d_terms, d_extra);
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;
 }

@@ -655,17 +655,23 @@ extern "C" int vhap_texture_mip_fold(float* d_tex, float* d_mips, int TB, int Ht
     if (int e = check_tex(TB, Ht, Wt, C)) return e;
     const TexDesc D = make_desc(TB, Ht, Wt, C);
     if (D.L == 0) return VHAP_OK;
-    if (stop_level < 0 || stop_level > 1) return VHAP_E_BADDIM;
+    if (stop_level < 0 || stop_level > D.L) return VHAP_E_BADDIM;
     if ((!d_tex && stop_level == 0) || !d_mips) return VHAP_E_NULLPTR;
     // coarse -> fine; the levels whose FINE side is at most TAIL_MAX^2 in one single-workgroup launch
     int l_tail = D.L + 1;      // levels >= l_tail are folded by the tail kernel (into level l_tail - 1)
     for (int l = 2; l <= D.L; l++)
         if ((Ht >> (l - 1)) <= TAIL_MAX && (Wt >> (l - 1)) <= TAIL_MAX) { l_tail = l; break; }
-    if (l_tail <= D.L) {
-        mip_fold_tail_kernel<<<1, 1024, 0, vhap_stream(stream)>>>(d_mips, D, l_tail - 1);
-        VHAP_LAUNCH_CHECK();
+    int l_top = D.L;          // coarsest level not yet folded
+    if (l_tail <= D.L) {      // levels D.L .. l_last+1 in one launch, into level l_last
+        const int l_last = max(l_tail - 1, stop_level);
+        if (D.L > l_last) {
+            if (l_last == 0) return VHAP_E_UNSUPPORTED;       // (cannot happen: l_tail >= 2)
+            mip_fold_tail_kernel<<<1, 1024, 0, vhap_stream(stream)>>>(d_mips, D, l_last);
+            VHAP_LAUNCH_CHECK();
+        }
+        l_top = l_last;
     }
-    for (int l = (l_tail <= D.L ? l_tail - 1 : D.L); l > stop_level; l--) {
+    for (int l = l_top; l > stop_level; l--) {
         const int h = Ht >> (l - 1), w = Wt >> (l - 1);   // fine extents
         float* fine = l == 1 ? d_tex : d_mips + D.off[l - 1];
         const long long fstride = l == 1 ? (long long)Ht * Wt * C : D.per_tex;

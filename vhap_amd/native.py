@@ -221,6 +221,14 @@ def offset_reg(om, offset, w_lap, w_abs, w_rigid):
 
 
 # ------------------------------------------------------------------------------------------------
+def _n_gather(T):
+    """Mip levels whose fold is fused into vhap_tex_prep_bwd (gathered per texel) instead of separate read-modify-write passes."""
+    n = 0
+    while n < 3 and T % (1 << (n + 1)) == 0 and (T >> (n + 1)) >= 2:
+        n += 1
+    return n
+
+
 class _TexSample(torch.autograd.Function):
     """albedo = painted + residual (channel-last) -> mip pyramid -> trilinear sample at (texc, texd), with the TV / residual
     energies of the texture computed in the same pass over it.  One autograd node, so the backward can keep the texture
@@ -266,13 +274,14 @@ class _TexSample(torch.autograd.Function):
             _chk(L.vhap_texture_bwd(_p(albedo), _p(mips), 1, T, T, 3, _p(texc), _p(texd), _p(_f32c(d_out)), B, H, W, _p(d_tex), _p(d_mips),
                                     _p(d_uv), _p(d_da), _stream()), "vhap_texture_bwd")
             if need_tex and mips.numel() > 0:
-                _chk(L.vhap_texture_mip_fold(_p(d_tex), _p(d_mips), 1, T, T, 3, 1, _stream()), "vhap_texture_mip_fold")
+                _chk(L.vhap_texture_mip_fold(_p(d_tex), _p(d_mips), 1, T, T, 3, _n_gather(T), _stream()), "vhap_texture_mip_fold")
         if need_tex:
             if d_terms is None:
                 d_terms = torch.zeros(2, dtype=torch.float32, device=dev)
             d_extra = torch.empty_like(extra)
-            d_mip1 = d_mips if (d_mips is not None and d_mips.numel() > 0) else None     # level 1 sits at offset 0 of the pyramid
-            _chk(L.vhap_tex_prep_bwd(_p(albedo), _p(extra), _p(mask), _p(d_tex), _p(d_mip1), _p(_f32c(d_terms)), T, *ctx.scales,
+            has = d_mips is not None and d_mips.numel() > 0
+            _chk(L.vhap_tex_prep_bwd(_p(albedo), _p(extra), _p(mask), _p(d_tex), _p(d_mips) if has else 0, _n_gather(T) if has else 0,
+                                     _p(_f32c(d_terms)), T, *ctx.scales,
                                      _p(d_extra), _stream()), "vhap_tex_prep_bwd")
         return None, d_extra, None, None, d_uv, d_da
 
@@ -319,7 +328,7 @@ class _TexPrep(torch.autograd.Function):
         if d_terms is None:
             d_terms = torch.zeros(2, dtype=torch.float32, device=albedo.device)
         d_extra = torch.empty_like(extra)
-        _chk(_lib.lib().vhap_tex_prep_bwd(_p(albedo), _p(extra), _p(mask), _p(_f32c(d_albedo) if d_albedo is not None else None), 0,
+        _chk(_lib.lib().vhap_tex_prep_bwd(_p(albedo), _p(extra), _p(mask), _p(_f32c(d_albedo) if d_albedo is not None else None), 0, 0,
                                           _p(_f32c(d_terms)), ctx.T, *ctx.scales, _p(d_extra), _stream()), "vhap_tex_prep_bwd")
         return None, d_extra, None, None
 

@@ -17,6 +17,7 @@ import torch
 
 from . import _lib
 from .config import PhotometricStageConfig
+from .native import _n_gather
 from .ops import _p, _stream
 
 LOG_NAMES = ("lmk", "photo", "smooth_pose", "reg_joint", "smooth_joint", "reg_expr", "smooth_expr", "reg_shape", "reg_tex_tv",
@@ -249,9 +250,10 @@ class NativeStep:
         _chk(L.vhap_texture_bwd(_p(self.albedo_tex), _p(self.mips), 1, T, T, 3, _p(self.texc), _p(self.texd), _p(self.d_albedo), B, H, W,
                                 _p(d_tex), _p(d_mips), 0, 0, st), "vhap_texture_bwd")
         has_mips = self.mips.numel() > 0
+        ng = _n_gather(T) if has_mips else 0
         if has_mips:
-            _chk(L.vhap_texture_mip_fold(_p(d_tex), _p(d_mips), 1, T, T, 3, 1, st), "vhap_texture_mip_fold")
-        _chk(L.vhap_tex_prep_bwd(_p(self.albedo_tex), _p(tr.tex_extra), _p(self.nm["res_mask"]), _p(d_tex), _p(d_mips) if has_mips else 0,
+            _chk(L.vhap_texture_mip_fold(_p(d_tex), _p(d_mips), 1, T, T, 3, ng, st), "vhap_texture_mip_fold")
+        _chk(L.vhap_tex_prep_bwd(_p(self.albedo_tex), _p(tr.tex_extra), _p(self.nm["res_mask"]), _p(d_tex), _p(d_mips) if has_mips else 0, ng,
                                  _p(self.ones), T, *self.tex_scales, _p(g["tex_extra"]), st), "vhap_tex_prep_bwd")
 
     def backward(self, world_size=1):
