@@ -13,7 +13,7 @@ if "--report" in sys.argv:
     starts = [i for i, r in enumerate(rows) if "frame_prep_fwd" in r["Kernel_Name"]]
     starts = starts[-len(flags) * STEPS:] + [len(rows)]
     want = ("texture_bwd", "gbuffer_bwd", "aa_", "bin_", "shade_", "disturb_", "frame_prep", "tex_prep", "offset_reg", "landmark", "raster_kernel", "flame_skin_fwd",
-            "mip_fold_tail", "adam_kernel", "photo_", "texture_fwd", "aa_bwd")
+            "mip_fold_tail", "adam_kernel", "shade_", "photo_", "texture_fwd", "aa_bwd")
     for fi, f in enumerate(flags):
         agg = collections.defaultdict(list)
         for s in range(1, STEPS):          # skip the first step of each phase
