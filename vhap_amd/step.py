@@ -197,15 +197,17 @@ class NativeStep:
         L.vhap_set_call_flags(1)
         try:
             so = tr.static_offset
-            self._fork()
-            with self._branch():
-                self._tex_forward()
             _chk(L.vhap_frame_prep_fwd(_p(self.ts), _p(tr.shape), _p(tr.expr), _p(tr.rotation), _p(tr.translation), _p(tr.neck_pose),
                                        _p(tr.jaw_pose), _p(tr.eyes_pose), _p(fm.JT), _p(fm.JS), _p(fm.jreg_idx), _p(fm.jreg_w), fm.jreg_n,
                                        _p(so), fm.parents, self.weights, B, self.Bp, self.N, self.NS, self.NE, J, fb.Kp, V,
                                        _p(self.coef), _p(self.A), _p(self.transl), _p(self.Jrest), _p(acc), st), "vhap_frame_prep_fwd")
             _chk(L.vhap_flame_skin_fwd(_p(self.coef), _p(fb.basis), _p(self.A), _p(fb.w), _p(fb.templ), _p(so), _p(self.transl), B, V, fb.Vp,
                                        fb.K, fb.Kb, fb.Kp, _p(self.verts), _p(self.v_shaped), _p(self.v_posed), st), "vhap_flame_skin_fwd")
+            # fork here, not at the top: next to the bandwidth-bound texture assembly the two latency-bound kernels above take 3x as long,
+            # and they head the critical path of the forward pass; the texture branch still finishes long before the rasteriser does
+            self._fork()
+            with self._branch():
+                self._tex_forward()
             torch.addcmul(self.K0, tr.focal_length.detach(), self.K1, out=self.K)      # K = (f, f, cx, cy), f = focal * max(h, w)
             _chk(L.vhap_camera_fwd(_p(self.K), _p(self.RT), B, 0, 0, H, W, 0.1, 10.0, _p(self.mvp), st), "vhap_camera_fwd")
             if self.w_lmk:
