@@ -12,12 +12,11 @@ import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
 H = W = 96
-T = 128
 NAMES = ("shape", "expr", "rotation", "neck_pose", "jaw_pose", "eyes_pose", "translation", "tex_extra", "lights", "static_offset",
          "focal_length")
 
 
-def _build(frames):
+def _build(T):
     from vhap_amd.config import BaseTrackingConfig
     from vhap_amd.flame import FlameHead
     from vhap_amd.render_hip import HipDiffRenderer
@@ -49,28 +48,30 @@ def _step(tr, frames):
     assert st.ns is not None, "the sharded step must run through NativeStep"
     E = float(st())
     torch.cuda.synchronize()
-    return E, {k: getattr(tr, k).grad.detach().cpu().clone() for k in NAMES}
+    return E, {k: getattr(tr, k).grad.detach().cpu().clone() for k in NAMES}, bool(st.ns.tex_l0_skip)
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, T, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from vhap_amd import dist as vdist
-    tr = _build(None)
+    tr = _build(T)
     vdist.attach(tr)
-    E, g = _step(tr, [0, 1] if rank == 0 else [2, 3])
-    ret[rank] = (E, g)
+    ret[rank] = _step(tr, [0, 1] if rank == 0 else [2, 3])
     dist.destroy_process_group()
 
 
-def test_two_rank_native_step_matches_single_process():
+@pytest.mark.parametrize("T", [128])
+def test_two_rank_native_step_matches_single_process(T):
+    """Sharded, captured step (forward graph / 'texture' backward graph / asynchronous texture-gradient all-reduce / 'geometry' backward
+    graph underneath it / small-gradient all-reduce / Adam graph) == the single-process step on the whole batch."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ret = mp.Manager().dict()
-    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
-    E1, g1 = _step(_build(None), [0, 1, 2, 3])
+    mp.spawn(_worker, args=(2, port, T, ret), nprocs=2, join=True)
+    E1, g1, _ = _step(_build(T), [0, 1, 2, 3])
     Em = 0.5 * (ret[0][0] + ret[1][0])
     assert abs(Em - E1) <= 2e-4 * abs(E1), (Em, E1)
     for k in NAMES:

@@ -53,14 +53,16 @@ class FrameShardContext:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
-    def all_reduce_mean_(self, t):
-        """In-place mean over ranks of a contiguous tensor (RCCL averages in the collective; gloo sums, then scales)."""
+    def all_reduce_mean_(self, t, async_op=False):
+        """In-place mean over ranks of a contiguous tensor (RCCL averages in the collective; gloo sums, then scales).  With
+        async_op the collective is only enqueued (it still waits for the work already on the current stream) and the returned handle's
+        wait() makes the current stream wait for it -- kernels launched in between overlap with it."""
         if dist.get_backend(self.group) == "nccl":
-            dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group)
-        else:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-            t.mul_(1.0 / self.world_size)
-        return t
+            work = dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op)
+            return work if async_op else None
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        t.mul_(1.0 / self.world_size)
+        return None
 
     def average_gradients(self, params):
         """One flat-bucket all-reduce of every gradient (missing grads count as zero)."""

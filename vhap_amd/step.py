@@ -161,6 +161,8 @@ class NativeStep:
         # work next to the latency-bound geometry chain of small launches
         import os
         self.overlap = os.environ.get("VHAP_STEP_OVERLAP", "1") != "0"
+        self.split_tex = False        # True: stop at the gradient pyramid, the caller runs tex_finish() later (pyramid-level exchange)
+        self.tex_l0_skip = False      # True: tex_finish() ignores the base level of the pyramid
         self.side = torch.cuda.Stream()
         self.c_lmk = torch.full((1,), self.w_lmk, **f32)
         self.c_reg = torch.full((1,), self.w_reg, **f32)
@@ -251,79 +253,128 @@ class NativeStep:
         d_tex, d_mips = g["d_tex"][:n0], g["d_tex"][n0:]
         _chk(L.vhap_texture_bwd(_p(self.albedo_tex), _p(self.mips), 1, T, T, 3, _p(self.texc), _p(self.texd), _p(self.d_albedo), B, H, W,
                                 _p(d_tex), _p(d_mips), 0, 0, st), "vhap_texture_bwd")
+        if not self.split_tex:
+            self.tex_finish()
+
+    def tex_finish(self):
+        """Gradient pyramid -> d(tex_extra): fold + TV / residual gradients + layout change.  Under frame sharding this runs AFTER the
+        pyramid was averaged over the ranks (the regulariser part is identical on every rank, so it is added once, afterwards); with
+        `tex_l0_skip` the level-0 part of the pyramid is not exchanged and therefore not used either."""
+        L, tr, T, g = self.L, self.tr, self.T, self.g
+        st = _stream()
+        n0 = self.albedo_tex.numel()
+        d_tex, d_mips = g["d_tex"][:n0], g["d_tex"][n0:]
         has_mips = self.mips.numel() > 0
         ng = _n_gather(T) if has_mips else 0
         if has_mips:
             _chk(L.vhap_texture_mip_fold(_p(d_tex), _p(d_mips), 1, T, T, 3, ng, st), "vhap_texture_mip_fold")
-        _chk(L.vhap_tex_prep_bwd(_p(self.albedo_tex), _p(tr.tex_extra), _p(self.nm["res_mask"]), _p(d_tex), _p(d_mips) if has_mips else 0, ng,
-                                 _p(self.ones), T, *self.tex_scales, _p(g["tex_extra"]), st), "vhap_tex_prep_bwd")
+        _chk(L.vhap_tex_prep_bwd(_p(self.albedo_tex), _p(tr.tex_extra), _p(self.nm["res_mask"]), 0 if self.tex_l0_skip else _p(d_tex),
+                                 _p(d_mips) if has_mips else 0, ng, _p(self.ones), T, *self.tex_scales, _p(g["tex_extra"]), st),
+             "vhap_tex_prep_bwd")
 
-    def backward(self, world_size=1):
-        L, tr, fb, fm, g = self.L, self.tr, self.fb, self.fm, self.g
-        B, H, W, V, F, T, J = self.B, self.H, self.W, self.V, self.F, self.T, self.J
+    def _bwd_early(self):
+        """landmark and offset-regulariser gradients: they depend on nothing the pixel chain produces (pure launch latency)"""
+        L, tr, g, om = self.L, self.tr, self.g, self.om
+        B, H, W, V = self.B, self.H, self.W, self.V
         st = _stream()
-        self.arena.zero_()                                            # ONE launch clears every gradient accumulator
+        if self.w_lmk:
+            l0, l1, b0, b1, boost = self.lmk_cfg
+            _chk(L.vhap_landmark_bwd(_p(self.verts), _p(self.lm.vidx), _p(self.lm.bary), _p(self.mvp), _p(self.lmk2d), _p(self.c_lmk), B, V,
+                                     self.lm.L, self.lmk2d.shape[1], l0, l1, b0, b1, boost, H, W, _p(g["d_verts"]), _p(self.d_mvp), st),
+                 "vhap_landmark_bwd")
+        else:
+            self.d_mvp.zero_()
+        _chk(L.vhap_offset_reg_bwd(_p(tr.static_offset), _p(om.ptr), _p(om.col), _p(om.val), _p(om.w_lap), _p(om.w_abs), _p(om.rptr),
+                                   _p(om.ridx), om.V, om.nreg, *self.off_scales, _p(self.ones), _p(g["static_offset"]), st),
+             "vhap_offset_reg_bwd")
+
+    def _bwd_pixel(self, world_size):
+        """energy total -> photometric -> antialias -> shading backward -> gradient w.r.t. the texture coordinates"""
+        L, tr, g, acc = self.L, self.tr, self.g, self.accF
+        B, H, W, V, F, T = self.B, self.H, self.W, self.V, self.F, self.T
+        st = _stream()
+        _chk(L.vhap_energy_total(_p(self.log), _p(acc[16:18]), _p(self.n_global), self.w_photo, int(world_size), _p(self.d_sum), st),
+             "vhap_energy_total")
+        _chk(L.vhap_photo_bwd(_p(self.rgba_aa), _p(self.rgb), _p(self.d_sum), B, H, W, _p(self.d_rgba_aa), _p(self.d_color), st), "vhap_photo_bwd")
+        L.vhap_set_call_flags(1 | 2)      # d_color already holds the pass-through copy of d_rgba_aa
+        _chk(L.vhap_antialias_bwd(_p(self.aa_in), _p(self.rast), _p(self.clip), _p(self.tri), _p(self.opp), _p(self.d_rgba_aa), _p(self.aa_work),
+                                  _p(self.vert_mask), B, H, W, 4, V, F, _p(self.d_color), _p(g["d_clip"]), st), "vhap_antialias_bwd")
+        L.vhap_set_call_flags(1)
+        # (the backward of the disturbance -- d_rgba = d_color * keep -- is folded into the shading backward)
+        _chk(L.vhap_shade_bwd(_p(self.normal), _p(self.albedo_px), _p(self.rast), _p(tr.lights), _p(self.sh_const), _p(self.d_color),
+                              _p(self.keep) if self.disturb_on else 0, _p(self.c_reg) if self.want_reg else 0,
+                              _p(acc[12:16]) if self.want_reg else 0, B, H, W, _p(self.d_albedo), _p(self.d_normal), _p(g["lights"]), st),
+             "vhap_shade_bwd")
+        _chk(L.vhap_texture_bwd(_p(self.albedo_tex), _p(self.mips), 1, T, T, 3, _p(self.texc), _p(self.texd), _p(self.d_albedo), B, H, W,
+                                0, 0, _p(self.d_texc), _p(self.d_texd), st), "vhap_texture_bwd")
+
+    def _bwd_geometry(self, early=None):
+        """G-buffer backward -> vertex normals -> clip transform -> camera -> skinning -> per-frame parameters"""
+        L, tr, fb, fm, g = self.L, self.tr, self.fb, self.fm, self.g
+        B, H, W, V, F, J = self.B, self.H, self.W, self.V, self.F, self.J
+        st = _stream()
+        _chk(L.vhap_gbuffer_bwd(_p(self.clip), _p(self.tri), _p(self.vn), _p(self.uv), _p(self.tri_uv), _p(self.rast), _p(self.d_normal),
+                                _p(self.d_texc), _p(self.d_texd), 0, 0, _p(self.face_mask), B, V, F, H, W, _p(g["d_clip"]), _p(g["d_vn"]), st),
+             "vhap_gbuffer_bwd")
+        if early is not None:
+            torch.cuda.current_stream().wait_event(early)
+        _chk(L.vhap_vnormal_bwd(_p(self.verts), _p(self.csr.tri), _p(self.csr.ptr), _p(self.csr.idx), _p(g["d_vn"]), B, V, 1,
+                                _p(self.vn_scratch), _p(g["d_verts"]), st), "vhap_vnormal_bwd")
+        _chk(L.vhap_transform_bwd(_p(self.verts), _p(self.mvp), _p(g["d_clip"]), B, V, 1, _p(g["d_verts"]), _p(self.d_mvp), st),
+             "vhap_transform_bwd")
+        _chk(L.vhap_camera_bwd(_p(self.RT), _p(self.d_mvp), B, 0, H, W, _p(self.d_K), st), "vhap_camera_bwd")
+        _chk(L.vhap_focal_bwd(_p(self.d_K), B, self.focal_scale, _p(g["focal_length"]), st), "vhap_focal_bwd")
+        _chk(L.vhap_flame_skin_bwd(_p(g["d_verts"]), 0, _p(self.v_posed), _p(self.A), _p(fb.w), _p(fb.basisT), B, V, fb.Vp, fb.Kb, fb.Kp,
+                                   _p(self.g_posed), _p(self.g_shaped), 0, _p(g["d_coef"]), _p(g["d_A"]), _p(g["d_t"]), st),
+             "vhap_flame_skin_bwd")
+        _chk(L.vhap_sum_frames(_p(self.g_shaped), B, V * 3, _p(g["static_offset"]), st), "vhap_sum_frames")
+        _chk(L.vhap_frame_prep_bwd(_p(self.ts), _p(tr.shape), _p(tr.expr), _p(tr.rotation), _p(tr.translation), _p(tr.neck_pose),
+                                   _p(tr.jaw_pose), _p(tr.eyes_pose), _p(fm.JS), _p(fm.jreg_idx), _p(fm.jreg_w), fm.jreg_n,
+                                   _p(tr.static_offset), fm.parents, self.weights, _p(self.Jrest), _p(g["d_coef"]), _p(g["d_A"]), _p(g["d_t"]),
+                                   _p(self.ones), B, self.Bp, self.N, self.NS, self.NE, J, fb.Kp, V, _p(g["shape"]), _p(g["expr"]),
+                                   _p(g["rotation"]), _p(g["translation"]), _p(g["neck_pose"]), _p(g["jaw_pose"]), _p(g["eyes_pose"]),
+                                   _p(g["static_offset"]), st), "vhap_frame_prep_bwd")
+
+    def backward(self, world_size=1, part="all"):
+        """part = 'all': the whole backward as one two-branch DAG (one GPU).  Under frame sharding the backward is captured in two
+        graphs so that the big collective can start early: 'texture' (pixel chain + the complete texture gradient, serial) -- the
+        caller launches the asynchronous all-reduce of the texture gradient -- then 'geometry' (everything else), which hides it."""
+        L = self.L
         L.vhap_set_call_flags(1)
         try:
-            acc = self.accF
-            # the landmark and offset-regulariser gradients depend on nothing the pixel chain produces: issue them on the side branch
-            # right away (they are pure launch latency), the geometry chain picks their results up through an event
-            om = self.om
-            self._fork()
-            with self._branch():
-                st2 = _stream()
-                if self.w_lmk:
-                    l0, l1, b0, b1, boost = self.lmk_cfg
-                    _chk(L.vhap_landmark_bwd(_p(self.verts), _p(self.lm.vidx), _p(self.lm.bary), _p(self.mvp), _p(self.lmk2d), _p(self.c_lmk), B, V,
-                                             self.lm.L, self.lmk2d.shape[1], l0, l1, b0, b1, boost, H, W, _p(g["d_verts"]), _p(self.d_mvp), st2),
-                         "vhap_landmark_bwd")
-                else:
-                    self.d_mvp.zero_()
-                _chk(L.vhap_offset_reg_bwd(_p(tr.static_offset), _p(om.ptr), _p(om.col), _p(om.val), _p(om.w_lap), _p(om.w_abs), _p(om.rptr),
-                                           _p(om.ridx), om.V, om.nreg, *self.off_scales, _p(self.ones), _p(g["static_offset"]), st2),
-                     "vhap_offset_reg_bwd")
-                early = torch.cuda.Event()
-                early.record()
-            _chk(L.vhap_energy_total(_p(self.log), _p(acc[16:18]), _p(self.n_global), self.w_photo, int(world_size), _p(self.d_sum), st),
-                 "vhap_energy_total")
-            _chk(L.vhap_photo_bwd(_p(self.rgba_aa), _p(self.rgb), _p(self.d_sum), B, H, W, _p(self.d_rgba_aa), _p(self.d_color), st), "vhap_photo_bwd")
-            L.vhap_set_call_flags(1 | 2)      # d_color already holds the pass-through copy of d_rgba_aa
-            _chk(L.vhap_antialias_bwd(_p(self.aa_in), _p(self.rast), _p(self.clip), _p(self.tri), _p(self.opp), _p(self.d_rgba_aa), _p(self.aa_work),
-                                      _p(self.vert_mask), B, H, W, 4, V, F, _p(self.d_color), _p(g["d_clip"]), st), "vhap_antialias_bwd")
-            L.vhap_set_call_flags(1)
-            # (the backward of the disturbance -- d_rgba = d_color * keep -- is folded into the shading backward)
-            _chk(L.vhap_shade_bwd(_p(self.normal), _p(self.albedo_px), _p(self.rast), _p(tr.lights), _p(self.sh_const), _p(self.d_color),
-                                  _p(self.keep) if self.disturb_on else 0, _p(self.c_reg) if self.want_reg else 0, _p(acc[12:16]) if self.want_reg else 0, B, H, W, _p(self.d_albedo),
-                                  _p(self.d_normal), _p(g["lights"]), st), "vhap_shade_bwd")
-            # uv gradient first (alone it takes a third of the time it needs next to the accumulation kernel), then fork: the texture
-            # gradient accumulation (atomics-bound) + fold + TV backward on the side branch, the geometry chain on this one
-            _chk(L.vhap_texture_bwd(_p(self.albedo_tex), _p(self.mips), 1, T, T, 3, _p(self.texc), _p(self.texd), _p(self.d_albedo), B, H, W,
-                                    0, 0, _p(self.d_texc), _p(self.d_texd), st), "vhap_texture_bwd")
-            self._fork()
-            with self._branch():
+            if part in ("all", "texture"):
+                self.arena.zero_()                                    # ONE launch clears every gradient accumulator
+            if part == "all":
+                early = None
+                self._fork()
+                with self._branch():
+                    self._bwd_early()
+                    if self.overlap:
+                        early = torch.cuda.Event()
+                        early.record()
+                self._bwd_pixel(world_size)
+                # uv gradient first (alone it takes a third of the time it needs next to the accumulation kernel), then fork: the texture
+                # gradient accumulation (atomics-bound) + fold + TV backward on the side branch, the geometry chain on this one
+                self._fork()
+                with self._branch():
+                    self._tex_backward()
+                self._bwd_geometry(early)
+                self._join()
+            elif part == "texture":
+                self._bwd_pixel(world_size)
                 self._tex_backward()
-            _chk(L.vhap_gbuffer_bwd(_p(self.clip), _p(self.tri), _p(self.vn), _p(self.uv), _p(self.tri_uv), _p(self.rast), _p(self.d_normal),
-                                    _p(self.d_texc), _p(self.d_texd), 0, 0, _p(self.face_mask), B, V, F, H, W, _p(g["d_clip"]), _p(g["d_vn"]), st),
-                 "vhap_gbuffer_bwd")
-            if self.overlap:
-                torch.cuda.current_stream().wait_event(early)
-            _chk(L.vhap_vnormal_bwd(_p(self.verts), _p(self.csr.tri), _p(self.csr.ptr), _p(self.csr.idx), _p(g["d_vn"]), B, V, 1,
-                                    _p(self.vn_scratch), _p(g["d_verts"]), st), "vhap_vnormal_bwd")
-            _chk(L.vhap_transform_bwd(_p(self.verts), _p(self.mvp), _p(g["d_clip"]), B, V, 1, _p(g["d_verts"]), _p(self.d_mvp), st),
-                 "vhap_transform_bwd")
-            _chk(L.vhap_camera_bwd(_p(self.RT), _p(self.d_mvp), B, 0, H, W, _p(self.d_K), st), "vhap_camera_bwd")
-            _chk(L.vhap_focal_bwd(_p(self.d_K), B, self.focal_scale, _p(g["focal_length"]), st), "vhap_focal_bwd")
-            _chk(L.vhap_flame_skin_bwd(_p(g["d_verts"]), 0, _p(self.v_posed), _p(self.A), _p(fb.w), _p(fb.basisT), B, V, fb.Vp, fb.Kb, fb.Kp,
-                                       _p(self.g_posed), _p(self.g_shaped), 0, _p(g["d_coef"]), _p(g["d_A"]), _p(g["d_t"]), st),
-                 "vhap_flame_skin_bwd")
-            _chk(L.vhap_sum_frames(_p(self.g_shaped), B, V * 3, _p(g["static_offset"]), st), "vhap_sum_frames")
-            _chk(L.vhap_frame_prep_bwd(_p(self.ts), _p(tr.shape), _p(tr.expr), _p(tr.rotation), _p(tr.translation), _p(tr.neck_pose),
-                                       _p(tr.jaw_pose), _p(tr.eyes_pose), _p(fm.JS), _p(fm.jreg_idx), _p(fm.jreg_w), fm.jreg_n,
-                                       _p(tr.static_offset), fm.parents, self.weights, _p(self.Jrest), _p(g["d_coef"]), _p(g["d_A"]), _p(g["d_t"]),
-                                       _p(self.ones), B, self.Bp, self.N, self.NS, self.NE, J, fb.Kp, V, _p(g["shape"]), _p(g["expr"]),
-                                       _p(g["rotation"]), _p(g["translation"]), _p(g["neck_pose"]), _p(g["jaw_pose"]), _p(g["eyes_pose"]),
-                                       _p(g["static_offset"]), st), "vhap_frame_prep_bwd")
-            self._join()
+            elif part == "geometry":
+                early = None
+                self._fork()
+                with self._branch():
+                    self._bwd_early()
+                    if self.overlap:
+                        early = torch.cuda.Event()
+                        early.record()
+                self._bwd_geometry(early)
+                self._join()
+            else:
+                raise ValueError(part)
         finally:
             L.vhap_set_call_flags(0)
 
