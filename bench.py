@@ -26,6 +26,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+UNROLL = 5                 # steps per graph replay on one GPU
 B_PER_GPU = 16
 H = W = 512
 TEX = 2048
@@ -144,7 +145,9 @@ def main():
     step = None
     if not args.eager:
         from vhap_amd.tracker import GraphedStep
-        step = GraphedStep(tr, sample, optimizer, STAGE)          # same work per step, ~3 graph launches instead of ~1300 kernels
+        # same work per step; on one GPU a replay carries UNROLL consecutive steps (one graph launch gap per UNROLL steps)
+        unroll = UNROLL if (world == 1 and args.steps % UNROLL == 0 and args.warmup % UNROLL == 0) else 1
+        step = GraphedStep(tr, sample, optimizer, STAGE, unroll=unroll)
 
     ev = []                                                      # HIP event pairs around the RI-fwd launches
     recording = {"on": False}
@@ -162,12 +165,13 @@ def main():
         torch.cuda.synchronize()
 
     run = step if step is not None else (lambda: tr.optimize_iter(dict(sample), optimizer, STAGE))
-    for _ in range(args.warmup):
+    per_call = step.unroll if step is not None else 1
+    for _ in range(args.warmup // per_call):
         run()
     barrier()
     recording["on"] = True
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(args.steps // per_call):
         run()
     barrier()
     dt = time.perf_counter() - t0

@@ -751,7 +751,7 @@ class GraphedStep:
     Everything the graphs touch is static: the sample tensors, the parameters, their .grad and the Adam state.
     A new batch is fed by copying into `self.sample` (same shapes) -- exactly the sequential-tracking pattern."""
 
-    def __init__(self, tracker, sample, optimizer, stage, warmup=2):
+    def __init__(self, tracker, sample, optimizer, stage, warmup=2, unroll=1):
         assert tracker.fused, "graph capture needs the fused (sync-free) path"
         self.tr, self.opt, self.stage = tracker, optimizer, stage
         dev = tracker.device
@@ -765,6 +765,7 @@ class GraphedStep:
         from .step import NativeStep
         self.ns = None
         self.single = False
+        self.unroll = 1
         use_native_step = os.environ.get("VHAP_NATIVE_STEP", "1") != "0" and NativeStep.supported(tracker, stage) and \
             isinstance(optimizer, NV.HipAdam)
         side = torch.cuda.Stream()
@@ -806,10 +807,13 @@ class GraphedStep:
             self.single = world == 1 and os.environ.get("VHAP_SINGLE_GRAPH", "1") != "0"
             if self.single:
                 # nothing happens between the passes on one GPU: ONE graph launch per step instead of three (~15 us of launch gap each)
+                # `unroll` > 1: that many consecutive steps per graph launch (the launch gap, ~25 us, is paid once per replay)
+                self.unroll = max(1, int(unroll))
                 with torch.cuda.graph(self.gF):
-                    ns.forward()
-                    ns.backward(1)
-                    optimizer.step()
+                    for _ in range(self.unroll):
+                        ns.forward()
+                        ns.backward(1)
+                        optimizer.step()
             else:
                 # Frame sharding.  The big collective is the texture gradient (50 MB at T = 2048).  The backward is captured in two graphs:
                 # 'texture' makes that gradient final first, its asynchronous all-reduce is launched, and 'geometry' (G-buffer backward,
@@ -876,7 +880,7 @@ class GraphedStep:
             cur.wait_stream(self.stream)
         else:
             self._replay()
-        self.tr.global_step += 1
+        self.tr.global_step += self.unroll
         return self.E
 
     def _replay(self):
