@@ -364,6 +364,19 @@ int vhap_sum_frames(const float* x, int B, int n, float* out_accum, vhap_stream_
 /* d_focal_accum[0] += scale * sum_b (d_K[b][0] + d_K[b][1])   (K = (f, f, cx, cy), f = focal_length * scale) */
 int vhap_focal_bwd(const float* d_K, int B, float scale, float* d_focal_accum, vhap_stream_t stream);
 
+/* ---- frame ingest --------------------------------------------------------------------------------------
+ * Replaces, per batch and on the device, the reference's per-image host transforms video_dataset.py:253-259 (apply_transforms):
+ * :302-323 apply_background_color (fp64 compositing over 'white' / 'black', truncating uint8 cast) and :261-268 apply_to_tensor
+ * (HWC uint8 -> CHW fp32 / 255), bit for bit.  The sequence stays resident as uint8:
+ *   rgb_u8   [N,H,W,3] uint8      alpha_u8 [N,H,W] uint8 or NULL (required when bg_mode != VHAP_BG_NONE or alpha_out != NULL)
+ *   index    [B] int64 frame numbers (negative counts from the end) or NULL (= 0..B-1)
+ *   rgb_out  [B,3,H,W] fp32       alpha_out [B,1,H,W] fp32 or NULL
+ *   bad_index: optional device int, OR-ed with 1 when an index is out of range (that frame is written as zeros).
+ * Other background colours are VHAP_E_BADDIM (the reference raises NotImplementedError). */
+enum { VHAP_BG_NONE = 0, VHAP_BG_WHITE = 1, VHAP_BG_BLACK = 2 };
+int vhap_frame_ingest(const unsigned char* rgb_u8, const unsigned char* alpha_u8, const long long* index, int N, int B, int H, int W,
+                      int bg_mode, float* rgb_out, float* alpha_out, int* bad_index, vhap_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

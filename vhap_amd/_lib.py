@@ -70,6 +70,7 @@ SIGNATURES = {
     "vhap_sum_frames": (c_i, [c_fp, c_i, c_i, c_fp, c_fp]),
     "vhap_focal_bwd": (c_i, [c_fp, c_i, c_f, c_fp, c_fp]),
     "vhap_adam_step": (c_i, [c_i] + [c_fp] * 8 + [c_f, c_f, c_f, c_fp]),
+    "vhap_frame_ingest": (c_i, [c_fp, c_fp, c_fp] + [c_i] * 5 + [c_fp] * 4),
 }
 
 _lib = None

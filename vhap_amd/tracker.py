@@ -539,8 +539,12 @@ class GlobalTracker(FlameTracker):
         super().__init__(cfg, flame_model, topo, base_texture)
         self.calibrated = cfg.data.calibrated
         self.dataset = dataset
-        self.image_size = tuple(dataset["rgb"].shape[-2:])
-        self.n_timesteps = dataset["rgb"].shape[0]
+        self.frames = dataset.get("frames")                      # optional ingest.FrameStore: the sequence resident as uint8 (8(f) rank 1)
+        if self.frames is not None:
+            self.image_size, self.n_timesteps = self.frames.image_size, len(self.frames)
+        else:
+            self.image_size = tuple(dataset["rgb"].shape[-2:])
+            self.n_timesteps = dataset["rgb"].shape[0]
         self.global_step = 0
         self._graphed = {}
         self.init_params()
@@ -617,8 +621,14 @@ class GlobalTracker(FlameTracker):
         """`device_index=True` keeps `timestep_index` as a device LongTensor (needed for graph capture: a numpy
         index would be re-uploaded on every step)."""
         ts = np.asarray(timesteps)
-        idx = torch.as_tensor(ts, device=self.dataset["rgb"].device)
-        s = {"rgb": self.dataset["rgb"][idx], "lmk2d": self.dataset["lmk2d"][idx], "timestep_index": idx if device_index else ts}
+        idx = torch.as_tensor(ts, device=self.dataset["lmk2d"].device)
+        if self.frames is not None:                               # gather + composite + convert in one launch (vhap_frame_ingest)
+            rgb, alpha = self.frames.batch(idx)
+        else:
+            rgb, alpha = self.dataset["rgb"][idx], None
+        s = {"rgb": rgb, "lmk2d": self.dataset["lmk2d"][idx], "timestep_index": idx if device_index else ts}
+        if alpha is not None:
+            s["alpha_map"] = alpha
         for k in ("intrinsic", "extrinsic"):
             if k in self.dataset:
                 s[k] = self.dataset[k][idx]
@@ -856,6 +866,22 @@ class GraphedStep:
                 optimizer.step()
         finally:
             tracker._split = None
+
+    def update_timesteps(self, timesteps):
+        """Feed the batch of these timesteps from the tracker's dataset; with a uint8 FrameStore the frames are converted straight
+        into the static rgb buffer (no intermediate fp32 batch)."""
+        tr = self.tr
+        idx = torch.as_tensor(np.asarray(timesteps), device=self.sample["timestep_index"].device)
+        if tr.frames is None:
+            return self.update_sample(tr.get_sample(timesteps, device_index=True))
+        if idx.shape != self.sample["timestep_index"].shape:
+            raise ValueError("GraphedStep.update_timesteps: batch size differs from the captured one")
+        tr.frames.batch(idx, out=self.sample["rgb"])
+        self.sample["lmk2d"].copy_(tr.dataset["lmk2d"][idx])
+        self.sample["timestep_index"].copy_(idx)
+        for k in ("intrinsic", "extrinsic"):
+            if k in self.sample:
+                self.sample[k].copy_(tr.dataset[k][idx])
 
     def update_sample(self, sample):
         """Feed a new batch of the SAME shapes: copied into the static buffers the graphs read."""
