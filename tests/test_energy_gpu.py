@@ -117,6 +117,33 @@ def test_short_fit_reduces_energy_and_exports_npz(setup, tmp_path):
     assert rep["expr"].shape == (N, 100) and rep["tex_extra"].shape == (3, T, T) and rep["lights"].shape == (9, 3)
 
 
+def test_evaluate_and_param_roundtrip(setup, tmp_path):
+    """evaluate() (tracker.py:1079-1117; batched here) == the per-timestep evaluation-mode energies (stage None, pinned on the oracle by
+    test_compute_energy_matches_oracle[None]); load_from_tracked_flame_params (tracker.py:79-130) restores what save_result wrote."""
+    tr = setup["tr"]
+    rep = tr.evaluate(batch_size=2, path=tmp_path / "tracked_flame_params_0.npz")
+    assert rep["photo"].shape == (N,) and np.isfinite(rep["photo"]).all()
+    for t in range(N):
+        s = tr.get_sample(np.array([t]))
+        tr.fill_cam_params_into_sample(s)
+        with torch.no_grad():
+            _, log, *_ = tr.compute_energy(s, stage=None)
+        assert abs(float(log["photo"]) - rep["photo"][t]) <= 1e-5 * abs(float(log["photo"]))
+        assert abs(float(log["lmk"]) - rep["lmk"][t]) <= 1e-5 * abs(float(log["lmk"]))
+    assert abs(rep["mean_photo"] - rep["photo"].mean()) < 1e-7
+    names = ("rotation", "translation", "neck_pose", "jaw_pose", "eyes_pose", "shape", "expr", "focal_length", "tex_extra", "lights",
+             "static_offset")
+    saved = {k: getattr(tr, k).detach().clone() for k in names}
+    with torch.no_grad():
+        for k in names:
+            getattr(tr, k).add_(0.123)
+    tr.load_from_tracked_flame_params(tmp_path / "tracked_flame_params_0.npz")
+    for k in names:
+        assert torch.equal(getattr(tr, k), saved[k]), k
+    rep2 = tr.evaluate(batch_size=3)
+    np.testing.assert_allclose(rep2["photo"], rep["photo"], rtol=1e-5)
+
+
 def test_graphed_step_matches_eager_step(flame_model):
     """The captured hipGraph step == the eager optimize_iter: same energy, same gradients (to fp32-atomics noise), and the
     parameters move; replaying keeps lowering the energy."""

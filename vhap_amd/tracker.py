@@ -746,6 +746,72 @@ class GlobalTracker(FlameTracker):
             np.savez(path, **out)
         return out
 
+    def load_from_tracked_flame_params(self, fp):
+        """tracker.py:79-130: counterpart of save_result (path, NpzFile or dict).  Per-frame arrays load their first
+        min(len) rows, like the reference's load_param_list; optional entries that are missing are left untouched."""
+        report = np.load(fp) if isinstance(fp, (str, os.PathLike)) else fp
+        dev = self.device
+
+        @torch.no_grad()
+        def load_param(param, arr):
+            param.copy_(torch.as_tensor(np.asarray(arr)).to(dev).reshape(param.shape))
+
+        @torch.no_grad()
+        def load_param_list(param, arr):
+            n = min(len(param), len(arr))
+            param[:n].copy_(torch.as_tensor(np.asarray(arr[:n])).to(dev))
+
+        for k in ("rotation", "translation", "neck_pose", "jaw_pose", "eyes_pose", "expr"):
+            load_param_list(getattr(self, k), report[k])
+        load_param(self.shape, report["shape"])
+        if self.lights is not None:
+            load_param(self.lights, report["lights"])
+        if not self.calibrated:
+            load_param(self.focal_length, report["focal_length"])
+        if self.cfg.model.tex_extra and "tex_extra" in report:
+            load_param(self.tex_extra, report["tex_extra"])
+        if self.cfg.model.use_static_offset and "static_offset" in report:
+            load_param(self.static_offset, report["static_offset"])
+        if self.cfg.model.use_dynamic_offset and "dynamic_offset" in report:
+            load_param_list(self.dynamic_offset, report["dynamic_offset"])
+        self.clear_cache()
+
+    @torch.no_grad()
+    def evaluate(self, batch_size=16, path=None):
+        """tracker.py:1079-1117: save the parameters, then render every timestep in evaluation mode
+        (stage None: `background_eval`, no disturbance, no region alignment, no regularisers) and report the photometric and
+        landmark energies per timestep and their means.  The reference evaluates one timestep per call; here `batch_size`
+        timesteps go through the kernels at once and the per-timestep normalisation sum|err| / (3 #(alpha > 0)) is done on
+        per-frame partial sums, which is the same number.  Media / TensorBoard logging is out of scope."""
+        if path is not None:
+            self.save_result(path)
+        w = self.cfg.w
+        photo = torch.zeros(self.n_timesteps, device=self.device)
+        lmk = torch.zeros(self.n_timesteps, device=self.device)
+        faces = self.flame.faces
+        for t0 in range(0, self.n_timesteps, batch_size):
+            ts = np.arange(t0, min(t0 + batch_size, self.n_timesteps))
+            sample = self.get_sample(ts, device_index=True)
+            self.clear_cache()
+            self.fill_cam_params_into_sample(sample)
+            verts, _, lmks, albedos = self.forward_flame(sample["timestep_index"])
+            if w.landmark is not None:
+                rd = self.compute_lmk_energy(sample, lmks, False)[1]
+                conf = sample["lmk2d"][:, :68, 2].to(verts).clone()
+                conf[:, 27:36] *= 10
+                lmk[t0:t0 + len(ts)] = w.landmark * ((rd["gt_lmk2d"][:, :68] - rd["pred_lmk2d"][:, :68]).abs().sum(2) * conf).mean(1)
+            if w.photo is not None:
+                gt_rgb = sample["rgb"].to(verts)
+                rast_dict = self.rasterize_flame(sample, verts, faces, train_mode=True)
+                lights = self.lights[None] if self.lights is not None else None
+                out = self.render_rgba(rast_dict, verts, faces, albedos, lights, self.get_background_color(gt_rgb, None, None))
+                rgba = out["rgba"]
+                abs_sum = (gt_rgb - rgba[:, :3]).abs().sum(dim=(1, 2, 3))
+                n_mask = (rgba[:, 3:] > 0).sum(dim=(1, 2, 3)) * 3
+                photo[t0:t0 + len(ts)] = w.photo * abs_sum / n_mask
+        photo, lmk = photo.cpu().numpy(), lmk.cpu().numpy()
+        return {"photo": photo, "lmk": lmk, "mean_photo": float(photo.mean()), "mean_lmk": float(lmk.mean())}
+
 
 class GraphedStep:
     """One optimiser step captured in hipGraphs (the 50-500 identical steps of a
