@@ -10,7 +10,7 @@ import torch  # noqa: F401  -- MUST precede the CDLL below: torch ships its own 
                # would put a second HIP runtime in the process and torch.cuda would report no device
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "lib", "libvhap_hip.so")
+SO_PATH = os.environ.get("VHAP_HIP_LIB") or os.path.join(_HERE, "lib", "libvhap_hip.so")   # (env: A/B of two builds)
 
 c_fp = ctypes.c_void_p   # device pointers travel as integers (tensor.data_ptr())
 c_i = ctypes.c_int

@@ -207,6 +207,7 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_fill_kernel(const unsigned* _
 // grid = (nfrag, B); dynamic LDS = nbin * 4 bytes.
 // ------------------------------------------------------------------------------------------------------------
 constexpr unsigned FRAG_OVERFLOW = 0x80000000u;
+constexpr int MAX_FRAG = 32;   // fragments per bin the raster kernel stages per wave (meshes up to 32768 triangles; beyond: count/scan/fill)
 
 __global__ __launch_bounds__(BIN_THREADS) void bin_build_kernel(const float* __restrict__ pos, const int* __restrict__ tri,
                                                                 const int* __restrict__ tri_uv, int V, int F, int H, int W,
@@ -328,6 +329,7 @@ struct RasterParams {
     const uint2* frag;     // fragmented lists (bin_build_kernel) or null: contiguous lists (bin_count/scan/fill)
     int nfrag;
     int debug;  // ablation switches for profiling only (vhap_debug_set_flags)
+    float xs, xo, ys, yo;  // pixel centre -> NDC: fx = xs * px + xo (2/W, 1/W - 1; correctly rounded divisions done once on the host)
     float* rast;
     float* rast_db;
     float* normal;
@@ -356,23 +358,26 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterParams P) {
     const bool fragmented = P.frag != nullptr;
     const bool use_list = fragmented || P.hdr->total <= P.capacity;
     const size_t bin = (size_t)b * P.nbx * P.nby + (size_t)by * P.nbx + bx;
-    __shared__ int4 sfr[4][64];   // per wave: fragment f = (first work item, count | overflow flag, list offset / first triangle, -)
+    __shared__ int4 sfr[4][MAX_FRAG];   // per wave: fragment f = (first work item, count | overflow flag, list offset / first triangle, -)
     unsigned n, off = 0u;
     int nfr = 0;                  // non-empty fragments of this bin (the mesh is coherent in triangle order: usually 1-3)
     if (fragmented) {
         uint2 d = make_uint2(0u, 0u);
         if (lane < P.nfrag) d = P.frag[((size_t)b * P.nfrag + lane) * ((size_t)P.nbx * P.nby) + (size_t)by * P.nbx + bx];
         const unsigned c = d.y & ~FRAG_OVERFLOW;
-        unsigned incl = c;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned u = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += u;
+        // walk the non-empty fragments (usually 1-3; none for a background block) with scalar code: a wave-wide prefix scan here
+        // would put six dependent cross-lane steps on the critical path of EVERY wave, background ones included
+        unsigned long long nz = __ballot(c != 0u);
+        unsigned run = 0u;
+        while (nz) {
+            const int l = __builtin_ctzll(nz);
+            nz &= nz - 1;
+            const unsigned dy = (unsigned)rli((int)d.y, l);
+            if (lane == 0) sfr[wave][nfr] = make_int4((int)run, (int)dy, rli((int)d.x, l), 0);
+            run += dy & ~FRAG_OVERFLOW;
+            nfr++;
         }
-        const unsigned long long nz = __ballot(c != 0u);
-        nfr = __popcll(nz);
-        if (c != 0u) sfr[wave][__popcll(nz & ((1ull << lane) - 1ull))] = make_int4((int)(incl - c), (int)d.y, (int)d.x, 0);
-        n = (P.debug & 1) ? 0u : (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+        n = (P.debug & 1) ? 0u : run;
     } else {
         n = (P.debug & 1) ? 0u : (use_list ? P.counts[bin] : (unsigned)P.F);
         off = use_list ? P.offsets[bin] : 0u;
@@ -391,7 +396,7 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterParams P) {
     const TriRecord* REC = P.records + (size_t)b * P.F;
     const unsigned* TR = P.trange + (size_t)b * P.F;
 
-    __shared__ int4 sd[4][3][64];  // per-wave broadcast staging of the current chunk (3 KiB per wave)
+    __shared__ int4 sd[4][4][64];  // per-wave broadcast staging of the current chunk (4 KiB per wave)
     typedef short short2_t __attribute__((ext_vector_type(2)));
     const short2_t dxy = __builtin_bit_cast(short2_t, dx16 | (dy16 << 16));
 
@@ -401,6 +406,8 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterParams P) {
         int t = 0;
         int AB0 = 0, AB1 = 0, AB2 = 0, C0 = 0, C1 = 0, C2 = 0;  // AB = A (low 16) | B (high 16)
         float zwc = 0.f, gx = 0.f, gy = 0.f;
+        int4 vidx = make_int4(0, 0, 0, 0);                     // (i2, uv0, uv1, uv2) of the winner's lookup (i0, i1 ride in sd[2])
+        int vi0 = 0, vi1 = 0;
         if (k < n && !(P.debug & 8)) {
             bool direct = !use_list;     // triangle id taken as is (no list): culled triangles have no record, test the range word
             if (fragmented) {
@@ -416,13 +423,19 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterParams P) {
                 t = use_list ? (int)P.list[off + k] : (int)k;
             }
             if (!direct || (t < P.F && TR[t] != TRANGE_NONE)) {  // direct mode: skip culled triangles (no record)
+                // the whole 80-byte record in one batch of loads: a wave's life is a chain of dependent global loads (descriptor ->
+                // list -> record -> winner's vertices), each a full memory latency while the chip is saturated with stores, so the
+                // bbox test must not gate a second round trip; the vertex / uv indices ride along for the same reason (below)
                 const TriRecord* rp = REC + t;
                 const int4 q0 = rp->q0, q1 = rp->q1;
+                const float4 q2 = rp->q2;
+                const int4 q3 = rp->q3, q4 = rp->q4;
+                vi0 = q3.z; vi1 = q3.w;
+                vidx = make_int4(q4.x, q4.y, q4.z, q4.w);
+                asm volatile("" ::"v"(q0.x), "v"(q1.x), "v"(q2.x), "v"(q3.x));   // keeps the compiler from sinking these loads below the bbox test
                 const int qx0 = q1.z & 0xffff, qx1 = q1.z >> 16, qy0 = q1.w & 0xffff, qy1 = q1.w >> 16;
                 hit = !(qx1 < bx0 || qx0 > bx1 || qy1 < by0 || qy0 > by1);
                 if (hit) {
-                    const float4 q2 = rp->q2;
-                    const int4 q3 = rp->q3;
                     const int sx0 = q0.x, sy0 = q0.y, sx1 = q0.z, sy1 = q0.w, sx2 = q1.x, sy2 = q1.y;
                     // edge i is opposite vertex i: a = v[(i+1)%3], b = v[(i+2)%3];  E = A*x + B*y + C,
                     // inside iff E > 0 or (E == 0 and top-left).  Fold the tie rule and a -1 into the
@@ -462,12 +475,18 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterParams P) {
         // so no barrier is needed.
         sd[wave][0][lane] = make_int4(AB0, AB1, AB2, C0);
         sd[wave][1][lane] = make_int4(C1, C2, __float_as_int(zwc), __float_as_int(gx));
-        sd[wave][2][lane] = make_int4(__float_as_int(gy), t, 0, 0);
+        sd[wave][2][lane] = make_int4(__float_as_int(gy), (t << 6) | lane, vi0, vi1);   // key word: triangle id, then its slot in this chunk
+        sd[wave][3][lane] = vidx;
+        // Coverage loop, software-pipelined: the broadcast reads of the NEXT triangle are issued before the arithmetic of the current
+        // one, so the DS latency (~100 cycles, paid per triangle otherwise) overlaps the ~17 VALU instructions of the test.
+        // (software-pipelining this loop -- next triangle's DS reads before the current arithmetic -- was measured 3 % SLOWER: the
+        // kernel is sensitive to VALU issue slots, the DS latency is already hidden by the other waves)
         unsigned long long mask = __ballot(hit && small);
         while (mask) {
             const int j = __builtin_ctzll(mask);
             mask &= mask - 1;
-            const int4 x = sd[wave][0][j], y = sd[wave][1][j], z = sd[wave][2][j];
+            const int4 x = sd[wave][0][j], y = sd[wave][1][j];
+            const int2 z = *reinterpret_cast<const int2*>(&sd[wave][2][j]);
             const int e0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, x.x), dxy, x.w, false);
             const int e1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, x.y), dxy, y.x, false);
             const int e2 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, x.z), dxy, y.y, false);
@@ -491,7 +510,7 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterParams P) {
             const long long E2 = (long long)A2 * (pcx - sx0) + (long long)B2 * (pcy - sy0) + ((A2 > 0 || (A2 == 0 && B2 > 0)) ? 0 : -1);
             const float zt = __fmaf_rn(rl(gx, j), fdx, __fmaf_rn(rl(gy, j), fdy, rl(zwc, j)));
             const bool inside = ((E0 | E1 | E2) >= 0) && (zt >= -1.0f && zt <= 1.0f);
-            const unsigned long long key = ((unsigned long long)f2ord(zt) << 32) | (unsigned)tj;
+            const unsigned long long key = ((unsigned long long)f2ord(zt) << 32) | (unsigned)((tj << 6) | j);
             if (inside && key < best) best = key;
         }
     }
@@ -502,14 +521,22 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterParams P) {
     float4 o_rast = make_float4(0.f, 0.f, 0.f, 0.f), o_db = o_rast, o_td = o_rast;
     float n0 = 0.f, n1 = 0.f, n2 = 0.f, tu = 0.f, tv = 0.f;
     if (best != ~0ull) {
-        const int t = (int)(unsigned)best;
-        const TriRecord* rp = REC + t;
-        const int4 q3 = rp->q3, q4 = rp->q4;
-        const int i0 = q3.z, i1 = q3.w, i2 = q4.x;
+        const int t = (int)((unsigned)best >> 6), slot = (int)((unsigned)best & 63u);
+        int i0, i1, i2;
+        int4 q4;
+        if (n <= 64u) {          // single chunk (the common case): the winner's indices are still staged in LDS -- one round trip less
+            const int4 a = sd[wave][2][slot];
+            q4 = sd[wave][3][slot];
+            i0 = a.z; i1 = a.w; i2 = q4.x;
+        } else {
+            const TriRecord* rp = REC + t;
+            const int4 q3 = rp->q3;
+            q4 = rp->q4;
+            i0 = q3.z; i1 = q3.w; i2 = q4.x;
+        }
         const float4* PV = reinterpret_cast<const float4*>(P.pos) + (size_t)b * P.V;
         const float4 p0 = PV[i0], p1 = PV[i1], p2 = PV[i2];
-        const float xs = __fdiv_rn(2.0f, (float)W), xo = __fdiv_rn(1.0f, (float)W) - 1.0f;
-        const float ys = __fdiv_rn(2.0f, (float)H), yo = __fdiv_rn(1.0f, (float)H) - 1.0f;
+        const float xs = P.xs, xo = P.xo, ys = P.ys, yo = P.yo;
         const float fx = __fmaf_rn(xs, (float)px, xo), fy = __fmaf_rn(ys, (float)py, yo);
         const Frag fr = shade_frag(p0, p1, p2, fx, fy);
         o_rast = make_float4(fr.b0, fr.b1, fr.zw, (float)(t + 1));
@@ -587,6 +614,10 @@ int launch_raster(RasterParams P, void* ws, size_t ws_bytes, size_t cap, int fla
     P.nbx = (P.W + BLK - 1) / BLK;
     P.nby = (P.H + BLK - 1) / BLK;
     P.nwx = (P.nbx + WG_BLOCKS - 1) / WG_BLOCKS;
+    P.xs = 2.0f / (float)P.W;
+    P.xo = 1.0f / (float)P.W - 1.0f;
+    P.ys = 2.0f / (float)P.H;
+    P.yo = 1.0f / (float)P.H - 1.0f;
     const int nbin = P.nbx * P.nby;
     if ((long long)B * nbin >= (1ll << 31) || cap > 0xfffffff0u) return VHAP_E_BADDIM;
     const WsLayout l = ws_layout(B, F, nbin, cap);
@@ -604,7 +635,7 @@ int launch_raster(RasterParams P, void* ws, size_t ws_bytes, size_t cap, int fla
     const bool use_lds = nbin <= LDS_BIN_LIMIT;
     const int nfrag = (int)gbin.x;
     const size_t region = cap / ((size_t)B * nfrag);       // pair-list entries owned by one (frame, 1024-triangle workgroup)
-    const bool fragmented = use_lds && nfrag <= 64 && region >= 1 && !(vhap_g_debug_flags & 4096);   // (flag 4096: A/B switch)
+    const bool fragmented = use_lds && nfrag <= MAX_FRAG && region >= 1 && !(vhap_g_debug_flags & 4096);   // (flag 4096: A/B switch)
     P.frag = nullptr;
     P.nfrag = nfrag;
     if (fragmented) {
