@@ -130,6 +130,16 @@ int vhap_texture_bwd(const float* tex, const float* mips, int TB, int Ht, int Wt
                      vhap_stream_t stream);
 int vhap_texture_mip_fold(float* d_tex, float* d_mips, int TB, int Ht, int Wt, int C, int stop_level,
                           vhap_stream_t stream);
+/* The d_tex / d_mips part of vhap_texture_bwd for ONE SHARED texture (TB == 1; the reference's expanded batch of copies,
+ * tracker.py:234) through uv-space binning: the covered pixels (d_out != 0) of all frames are counting-sorted by the uv tile
+ * they sample, one workgroup per tile accumulates them in LDS and every touched texel is flushed once -- an order of
+ * magnitude fewer global atomics than the screen-tiled kernel when B frames sample the same texture.  Same result up to fp32
+ * summation order (ACCUMULATES into d_tex / d_mips like vhap_texture_bwd).  Textures larger than 2048 texels per side return
+ * VHAP_E_UNSUPPORTED (use vhap_texture_bwd).  `work`: vhap_texture_grad_binned_work_bytes(B,H,W) bytes, no state across calls. */
+size_t vhap_texture_grad_binned_work_bytes(int B, int H, int W);
+int vhap_texture_grad_binned(int Ht, int Wt, int C, const float* uv, const float* uv_da, const float* d_out,
+                             int B, int H, int W, float* d_tex, float* d_mips, void* work, size_t work_bytes,
+                             vhap_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Antialias: replaces dr.antialias(color, rast, pos, tri)  (:465).

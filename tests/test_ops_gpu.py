@@ -203,3 +203,53 @@ def test_fused_raster_interp_backward_matches_separate_ops(scene):
     for a, b in zip(res[1][:3], res[0][:3]):
         assert torch.equal(a, b)
     assert _rel(res[1][3], res[0][3]) < 2e-3 and _rel(res[1][4], res[0][4]) < 2e-3
+
+
+@pytest.mark.parametrize("Ht,Wt,C,B,H,W", [(64, 64, 3, 3, 48, 40), (256, 128, 1, 2, 33, 47), (32, 32, 4, 1, 16, 16), (2048, 2048, 3, 4, 96, 96)])
+def test_texture_grad_binned_matches_tiled_and_oracle(Ht, Wt, C, B, H, W):
+    """vhap_texture_grad_binned (uv-space binning, one shared texture) == the d_tex part of vhap_texture_bwd == the oracle, for every
+    mip level, wrap-around taps, uncovered pixels (d_out == 0) and a frame batch that samples the same texels."""
+    from vhap_amd import _lib
+    from vhap_amd.native import texture_grad_binned
+    from vhap_amd.ops import _p, _stream
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(Ht + W)
+    uv = torch.rand(B, H, W, 2, generator=g, dtype=torch.float64) * 1.4 - 0.2
+    uv[0, 0, :3] = torch.tensor([[0.0, 0.0], [1.0, 1.0], [-1e-9, 0.999999]], dtype=torch.float64)      # seams / u - floor(u) == 1 in fp32
+    scale = torch.exp(torch.rand(B, H, W, 1, generator=g, dtype=torch.float64) * 7 - 8)
+    da = torch.randn(B, H, W, 4, generator=g, dtype=torch.float64) * scale
+    d_out = torch.randn(B, H, W, C, generator=g, dtype=torch.float64) * 1e-3
+    d_out[torch.rand(B, H, W, generator=g) < 0.4] = 0                                        # background pixels
+    if B > 1:
+        uv[1], da[1] = uv[0], da[0]                                                             # two frames on the same texels
+    uv_g, da_g, do_g = (x.float().cuda().contiguous() for x in (uv, da, d_out))
+    tex = torch.zeros(1, Ht, Wt, C, device="cuda")
+    nm = L.vhap_texture_mip_floats(1, Ht, Wt, C)
+    mips = torch.zeros(nm, device="cuda")
+
+    def run(binned):
+        d_tex, d_mips = torch.zeros(Ht * Wt * C, device="cuda"), torch.zeros(max(nm, 1), device="cuda")
+        if binned:
+            assert L.vhap_texture_grad_binned(Ht, Wt, C, _p(uv_g), _p(da_g), _p(do_g), B, H, W, _p(d_tex), _p(d_mips),
+                                              _p(work), work.numel(), _stream()) == 0
+        else:
+            assert L.vhap_texture_bwd(_p(tex), _p(mips), 1, Ht, Wt, C, _p(uv_g), _p(da_g), _p(do_g), B, H, W, _p(d_tex), _p(d_mips), 0, 0,
+                                      _stream()) == 0
+        lv = [d_tex.clone(), d_mips.clone()]
+        if nm:
+            assert L.vhap_texture_mip_fold(_p(d_tex), _p(d_mips), 1, Ht, Wt, C, 0, _stream()) == 0
+        return lv, d_tex.view(Ht, Wt, C)
+
+    work = torch.empty(L.vhap_texture_grad_binned_work_bytes(B, H, W), dtype=torch.uint8, device="cuda")
+    (l_b, f_b), (l_t, f_t) = run(True), run(False)
+    for a, b in zip(l_b, l_t):                                                                   # level by level, before the fold
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()) + 1e-12
+    l_b2, f_b2 = run(True)                                                                       # workspace reuse, determinism
+    assert float((f_b2 - f_b).abs().max()) <= 1e-6 * float(f_b.abs().max())
+    t_o = torch.zeros(1, Ht, Wt, C, dtype=torch.float64, requires_grad=True)
+    (R.texture(t_o, uv, da) * d_out).sum().backward()
+    assert _rel(f_b, t_o.grad[0]) < 1e-3
+    if Ht == Wt:                                                                                 # the cached-workspace wrapper
+        d_tex, d_mips = torch.zeros(Ht * Wt * C, device="cuda"), torch.zeros(max(nm, 1), device="cuda")
+        assert texture_grad_binned(Ht, C, uv_g, da_g, do_g, d_tex, d_mips)
+        assert torch.allclose(d_tex, l_b[0], rtol=1e-5, atol=1e-12)

@@ -1,5 +1,6 @@
 """Per-step kernel table from a rocprofv3 --kernel-trace CSV of bench.py: one graph-replayed step, kernels in launch order
-grouped by name (count, total us).  usage: python tools/step_profile.py <kernel_trace.csv> [--seq]"""
+grouped by name (count, total us).  usage: python tools/step_profile.py <kernel_trace.csv> [--seq | --timeline]
+(--timeline: start offset, duration, HW queue and name of every kernel of the step -- shows what overlaps with what)"""
 import collections
 import csv
 import re
@@ -23,7 +24,13 @@ def short(n):
 
 print("kernels/step %d  wall %.1f us  busy %.1f us" % (len(seq), (int(seq[-1]["End_Timestamp"]) - int(seq[0]["Start_Timestamp"])) / 1e3,
                                                        sum(dur(r) for r in seq)))
-if "--seq" in sys.argv:
+if "--timeline" in sys.argv:
+    t0 = int(seq[0]["Start_Timestamp"])
+    qs = {}
+    for r in seq:
+        q = qs.setdefault(r.get("Queue_Id", "0"), len(qs))
+        print("%8.1f %8.1f  q%d %s" % ((int(r["Start_Timestamp"]) - t0) / 1e3, dur(r), q, short(r["Kernel_Name"])[:64]))
+elif "--seq" in sys.argv:
     for r in seq:
         print("%8.1f %s" % (dur(r), short(r["Kernel_Name"])))
 else:

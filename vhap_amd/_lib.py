@@ -35,6 +35,8 @@ SIGNATURES = {
     "vhap_texture_fwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp]),
     "vhap_texture_bwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_i] + [c_fp] * 5),
     "vhap_texture_mip_fold": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    "vhap_texture_grad_binned_work_bytes": (c_sz, [c_i, c_i, c_i]),
+    "vhap_texture_grad_binned": (c_i, [c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_sz, c_fp]),
     "vhap_antialias_work_ints": (c_sz, [c_i] * 4),
     "vhap_antialias_fwd": (c_i, [c_fp] * 5 + [c_i] * 6 + [c_fp, c_fp, c_fp]),
     "vhap_antialias_bwd": (c_i, [c_fp] * 8 + [c_i] * 6 + [c_fp, c_fp, c_fp]),

@@ -598,6 +598,241 @@ __global__ __launch_bounds__(TT * TT) void texture_bwd_tiled_kernel(const float*
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Texture gradient through UV-SPACE binning (shared texture, TB == 1).
+//
+// The screen-tiled kernel above dedups taps only inside one 16x16 pixel tile of one frame; every frame of the batch and
+// every neighbouring tile flushes the same texels again, so a 16-frame batch still issues ~20 M device-scope float atomics
+// (the backward critical path of the fit step).  Here the covered pixels of ALL frames are first counting-sorted by the
+// tile of the uv square they sample (NT x NT tiles); one workgroup per uv tile then accumulates all of its pixels' taps into
+// a DENSE LDS image of the tile -- every mip level of the tile plus a one-texel halo, 64-bit fixed point as above -- and
+// flushes each touched texel once.  Global atomics drop to (touched texels + halos) x C, their addresses are row-contiguous,
+// and the result is independent of the pixel order (integer sums), i.e. deterministic up to the <= 4 halo contributions.
+//   texbin_count   : per-tile pixel count and max|g|            (LDS histogram per 4096 pixels, then global atomics)
+//   texbin_scan    : exclusive scan of the counts               (one workgroup)
+//   texbin_scatter : pixel indices into their tile's list       (LDS ranks, one global cursor bump per workgroup and tile)
+//   texgrad_tile   : accumulate + flush                         (one workgroup per non-empty tile)
+// A pixel with uf = u - floor(u) belongs to tile tx = min(NT-1, int(uf * NT)); at level l (width w) its taps x0 = floor(uf*w - 0.5),
+// x0 + 1 lie in [lo, hi + 1] with lo = floor(fl(tx/NT * w) - 0.5), hi = floor(fl((tx+1)/NT * w) - 0.5) -- fp32 rounding is
+// monotone and tx/NT is exact, so the bounds hold for the rounded products too; a tap outside them (never observed) goes
+// straight to global memory, so memory safety does not depend on the argument.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int TG_PPT = 16;          // pixels per lane in the count / scatter passes (4096 pixels per workgroup)
+constexpr int TG_MAX_NT = 64;       // at most 64 x 64 tiles: the per-workgroup histograms are 2 x 16 KiB of LDS
+struct TileGeo {
+    int NT, cells;                                  // tiles per axis; LDS cells per tile over all levels
+    int nx[MAX_LEVELS + 1], ny[MAX_LEVELS + 1], off[MAX_LEVELS + 1];
+};
+
+TileGeo make_tile_geo(const TexDesc& D) {
+    TileGeo G;
+    int nt = 8;
+    const int m = D.W > D.H ? D.W : D.H;
+    while (nt < TG_MAX_NT && m / nt > 32) nt *= 2;
+    G.NT = nt;
+    int o = 0;
+    for (int l = 0; l <= D.L; l++) {
+        G.nx[l] = (D.W >> l) / nt + 3;
+        G.ny[l] = (D.H >> l) / nt + 3;
+        G.off[l] = o;
+        o += G.nx[l] * G.ny[l];
+    }
+    for (int l = D.L + 1; l <= MAX_LEVELS; l++) { G.nx[l] = G.ny[l] = 0; G.off[l] = o; }
+    G.cells = o;
+    return G;
+}
+
+__device__ __forceinline__ int tile_of(float2 c, int NT) {
+    const float uf = c.x - floorf(c.x), vf = c.y - floorf(c.y);
+    const int tx = min(NT - 1, (int)(uf * (float)NT)), ty = min(NT - 1, (int)(vf * (float)NT));
+    return ty * NT + tx;
+}
+__device__ __forceinline__ int tile_lo(int t, int NT, int w) { return (int)floorf(((float)t / (float)NT) * (float)w - 0.5f); }
+
+template <int C, bool SCATTER>
+__global__ __launch_bounds__(256) void texbin_pass_kernel(const float2* __restrict__ uv, const float* __restrict__ d_out, long long npix,
+                                                          int NT, unsigned* __restrict__ counts, unsigned* __restrict__ tilemax,
+                                                          const unsigned* __restrict__ offsets, unsigned* __restrict__ cursors,
+                                                          unsigned* __restrict__ list) {
+    extern __shared__ unsigned tg_sh[];          // [NT*NT] counts / ranks, [NT*NT] max|g| bits (count pass) or list bases (scatter pass)
+    const int nt2 = NT * NT, tid = threadIdx.x;
+    unsigned* shc = tg_sh;
+    unsigned* shb = tg_sh + nt2;
+    for (int i = tid; i < 2 * nt2; i += 256) tg_sh[i] = 0u;
+    __syncthreads();
+    int tile[TG_PPT];
+    const long long p0 = (long long)blockIdx.x * (256 * TG_PPT) + tid;
+#pragma unroll
+    for (int k = 0; k < TG_PPT; k++) {
+        const long long p = p0 + (long long)k * 256;
+        tile[k] = -1;
+        if (p < npix) {
+            float gmax = 0.f;
+#pragma unroll
+            for (int c = 0; c < C; c++) gmax = fmaxf(gmax, fabsf(d_out[p * C + c]));
+            if (gmax != 0.f) {
+                tile[k] = tile_of(uv[p], NT);
+                atomicAdd(&shc[tile[k]], 1u);
+                if (!SCATTER) atomicMax(&shb[tile[k]], __float_as_uint(gmax));      // non-negative floats order like their bit patterns
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < nt2; i += 256) {
+        const unsigned c = shc[i];
+        if (c == 0u) continue;
+        if (SCATTER) {
+            shb[i] = offsets[i] + atomicAdd(&cursors[i], c);
+            shc[i] = 0u;
+        } else {
+            atomicAdd(&counts[i], c);
+            atomicMax(&tilemax[i], shb[i]);
+        }
+    }
+    if (!SCATTER) return;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < TG_PPT; k++)
+        if (tile[k] >= 0) list[shb[tile[k]] + atomicAdd(&shc[tile[k]], 1u)] = (unsigned)(p0 + (long long)k * 256);
+}
+
+// exclusive scan of counts[0..n) -> offsets[0..n], n <= 4096; clears the scatter cursors
+__global__ __launch_bounds__(1024) void texbin_scan_kernel(const unsigned* __restrict__ counts, int n, unsigned* __restrict__ offsets,
+                                                           unsigned* __restrict__ cursors) {
+    __shared__ unsigned wtot[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (n + 1023) / 1024, i0 = tid * per, i1 = min(i0 + per, n);
+    unsigned mine = 0u;
+    for (int i = i0; i < i1; i++) mine += counts[i];
+    unsigned incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned u = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += u;
+    }
+    if (lane == 63) wtot[wave] = incl;
+    __syncthreads();
+    unsigned pre = incl - mine;
+    for (int w = 0; w < wave; w++) pre += wtot[w];
+    for (int i = i0; i < i1; i++) {
+        offsets[i] = pre;
+        cursors[i] = 0u;
+        pre += counts[i];
+    }
+    if (tid == 1023) offsets[n] = pre;
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void texgrad_tile_kernel(const TexDesc D, const TileGeo G, const float2* __restrict__ uv,
+                                                           const float4* __restrict__ uv_da, const float* __restrict__ d_out,
+                                                           const unsigned* __restrict__ offsets, const unsigned* __restrict__ list,
+                                                           const unsigned* __restrict__ tilemax, float* __restrict__ d_tex,
+                                                           float* __restrict__ d_mips) {
+    extern __shared__ unsigned long long tg_vals[];      // [G.cells * C]
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const unsigned beg = offsets[t], end = offsets[t + 1];
+    if (beg == end) return;
+    for (int i = tid; i < G.cells * C; i += 256) tg_vals[i] = 0ull;
+    int ex = 0;
+    (void)frexpf(__uint_as_float(tilemax[t]), &ex);
+    const int sh = min(max(40 - ex, -100), 100);
+    const float scale = ldexpf(1.0f, sh), inv_scale = ldexpf(1.0f, -sh);
+    const int tx = t % G.NT, ty = t / G.NT;
+    __syncthreads();
+
+    auto tap_level = [&](int l, float2 c, const float (&g)[C], float wgt) {
+        const int w = D.W >> l, h = D.H >> l;
+        const float u = c.x - floorf(c.x), v = c.y - floorf(c.y);
+        const float x = u * (float)w - 0.5f, y = v * (float)h - 0.5f;
+        const float x0f = floorf(x), y0f = floorf(y);
+        const float fx = x - x0f, fy = y - y0f;
+        const int x0 = (int)x0f, y0 = (int)y0f;
+        const int lx = x0 - tile_lo(tx, G.NT, w), ly = y0 - tile_lo(ty, G.NT, h);
+        const float w00 = (1.f - fx) * (1.f - fy), w10 = fx * (1.f - fy), w01 = (1.f - fx) * fy, w11 = fx * fy;
+        const float wq[4] = {w00, w10, w01, w11};
+        const bool local = lx >= 0 && ly >= 0 && lx + 1 < G.nx[l] && ly + 1 < G.ny[l];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int dx = q & 1, dy = q >> 1;
+            if (local) {
+                unsigned long long* cell = tg_vals + (size_t)(G.off[l] + (ly + dy) * G.nx[l] + lx + dx) * C;
+#pragma unroll
+                for (int k = 0; k < C; k++) {
+                    const float val = wq[q] * (g[k] * wgt);
+                    if (val != 0.f) atomicAdd(&cell[k], (unsigned long long)__float2ll_rn(val * scale));
+                }
+            } else {
+                int gx = x0 + dx, gy = y0 + dy;
+                gx = gx < 0 ? gx + w : (gx >= w ? gx - w : gx);
+                gy = gy < 0 ? gy + h : (gy >= h ? gy - h : gy);
+                if (gx >= w) gx -= w;
+                if (gy >= h) gy -= h;
+                float* Gp = level_ptr_w(d_tex, d_mips, D, 0, l) + ((size_t)gy * w + gx) * C;
+#pragma unroll
+                for (int k = 0; k < C; k++) {
+                    const float val = wq[q] * (g[k] * wgt);
+                    if (val != 0.f) atomicAdd(&Gp[k], val);
+                }
+            }
+        }
+    };
+
+    for (unsigned i = beg + tid; i < end; i += 256) {
+        const size_t p = list[i];
+        float g[C];
+#pragma unroll
+        for (int k = 0; k < C; k++) g[k] = d_out[p * C + k];
+        const float2 c = uv[p];
+        if (uv_da == nullptr) {
+            tap_level(0, c, g, 1.0f);
+        } else {
+            const LevelSel s = select_level(uv_da[p], D.W, D.H, D.L);
+            const bool two = s.two && s.f > 0.0f;
+            tap_level(s.l0, c, g, two ? 1.0f - s.f : 1.0f);
+            if (two) tap_level(s.l0 + 1, c, g, s.f);
+        }
+    }
+    __syncthreads();
+    // flush: level by level, rows of the tile image are contiguous texel runs in memory
+    for (int l = 0; l <= D.L; l++) {
+        const int w = D.W >> l, h = D.H >> l, nx = G.nx[l], n = nx * G.ny[l];
+        const int lox = tile_lo(tx, G.NT, w), loy = tile_lo(ty, G.NT, h);
+        float* Gl = level_ptr_w(d_tex, d_mips, D, 0, l);
+        for (int i = tid; i < n; i += 256) {
+            const unsigned long long* cell = tg_vals + (size_t)(G.off[l] + i) * C;
+            bool nz = false;
+#pragma unroll
+            for (int k = 0; k < C; k++) nz = nz || cell[k] != 0ull;
+            if (!nz) continue;
+            const int cy = i / nx, cx = i - cy * nx;
+            int gx = (lox + cx) % w, gy = (loy + cy) % h;
+            if (gx < 0) gx += w;
+            if (gy < 0) gy += h;
+            float* Gp = Gl + ((size_t)gy * w + gx) * C;
+#pragma unroll
+            for (int k = 0; k < C; k++) {
+                const long long q = (long long)cell[k];
+                if (q != 0) atomicAdd(&Gp[k], (float)q * inv_scale);
+            }
+        }
+    }
+}
+
+struct TexBinWs {
+    size_t counts, tilemax, cursors, offsets, list, total;
+};
+TexBinWs texbin_layout(long long npix) {
+    TexBinWs l;
+    const size_t n = (size_t)TG_MAX_NT * TG_MAX_NT;
+    l.counts = 0;
+    l.tilemax = l.counts + n * 4;
+    l.cursors = l.tilemax + n * 4;
+    l.offsets = l.cursors + n * 4;
+    l.list = l.offsets + (n + 64) * 4;
+    l.total = l.list + (size_t)npix * 4;
+    return l;
+}
+
 template <typename F>
 int dispatch_C(int C, F&& f) {
     switch (C) {
@@ -733,5 +968,55 @@ extern "C" int vhap_texture_bwd(const float* tex, const float* mips, int TB, int
             d_mips, reinterpret_cast<float2*>(d_uv), reinterpret_cast<float4*>(d_uv_da));
         VHAP_LAUNCH_CHECK();
         return VHAP_OK;
+    });
+}
+
+extern "C" size_t vhap_texture_grad_binned_work_bytes(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return texbin_layout((long long)B * H * W).total;
+}
+
+extern "C" int vhap_texture_grad_binned(int Ht, int Wt, int C, const float* uv, const float* uv_da, const float* d_out, int B, int H, int W,
+                                        float* d_tex, float* d_mips, void* work, size_t work_bytes, vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!uv || !d_out || !d_tex || !work) return VHAP_E_NULLPTR;
+    if (int e = check_tex(1, Ht, Wt, C)) return e;
+    if (B <= 0 || H <= 0 || W <= 0) return VHAP_E_BADDIM;
+    const long long npix = (long long)B * H * W;
+    if (npix >= (1ll << 32)) return VHAP_E_BADDIM;
+    const TexDesc D = make_desc(1, Ht, Wt, C);
+    if (uv_da && D.L > 0 && !d_mips) return VHAP_E_NULLPTR;
+    const TileGeo G = make_tile_geo(D);
+    const size_t lds = (size_t)G.cells * C * sizeof(unsigned long long);
+    if ((Wt > Ht ? Wt : Ht) / G.NT > 32 || lds > 64 * 1024) return VHAP_E_UNSUPPORTED;       // larger textures: vhap_texture_bwd
+    const TexBinWs l = texbin_layout(npix);
+    if (work_bytes < l.total) return VHAP_E_WORKSPACE;
+    char* w = static_cast<char*>(work);
+    unsigned* counts = reinterpret_cast<unsigned*>(w + l.counts);
+    unsigned* tilemax = reinterpret_cast<unsigned*>(w + l.tilemax);
+    unsigned* cursors = reinterpret_cast<unsigned*>(w + l.cursors);
+    unsigned* offsets = reinterpret_cast<unsigned*>(w + l.offsets);
+    unsigned* list = reinterpret_cast<unsigned*>(w + l.list);
+    const int nt2 = G.NT * G.NT;
+    hipStream_t st = vhap_stream(stream);
+    vhap_zero_async(w + l.counts, (size_t)2 * TG_MAX_NT * TG_MAX_NT * 4, st);      // counts + tilemax
+    VHAP_LAUNCH_CHECK();
+    const int nwg = vhap_cdiv(npix, 256 * TG_PPT);
+    const size_t hist = (size_t)2 * nt2 * sizeof(unsigned);
+    return dispatch_C(C, [&](auto c) {
+        constexpr int CC = decltype(c)::value;
+        const float2* uv2 = reinterpret_cast<const float2*>(uv);
+        texbin_pass_kernel<CC, false><<<nwg, 256, hist, st>>>(uv2, d_out, npix, G.NT, counts, tilemax, nullptr, nullptr, nullptr);
+        VHAP_LAUNCH_CHECK();
+        texbin_scan_kernel<<<1, 1024, 0, st>>>(counts, nt2, offsets, cursors);
+        VHAP_LAUNCH_CHECK();
+        texbin_pass_kernel<CC, true><<<nwg, 256, hist, st>>>(uv2, d_out, npix, G.NT, nullptr, nullptr, offsets, cursors, list);
+        VHAP_LAUNCH_CHECK();
+        if (lds > 48 * 1024 &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(texgrad_tile_kernel<CC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return (int)VHAP_E_HIP;
+        texgrad_tile_kernel<CC><<<nt2, 256, lds, st>>>(D, G, uv2, reinterpret_cast<const float4*>(uv_da), d_out, offsets, list, tilemax, d_tex, d_mips);
+        VHAP_LAUNCH_CHECK();
+        return (int)VHAP_OK;
     });
 }

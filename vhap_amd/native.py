@@ -11,6 +11,7 @@ Together they replace the several hundred tiny eager launches per step that the 
     HipAdam          torch.optim.Adam (tracker.py:159-211)
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -229,6 +230,31 @@ def _n_gather(T):
     return n
 
 
+_TEXBIN_WORK = {}
+
+
+def texture_grad_binned(T, C, texc, texd, d_out, d_tex, d_mips, work=None):
+    """d_tex / d_mips += texture gradient of a SHARED T x T x C texture sampled at (texc, texd) by all frames, through uv-space binning
+    (vhap_texture_grad_binned).  Returns False when the library declines (texture too large): the caller then uses vhap_texture_bwd."""
+    L = _lib.lib()
+    B, H, W, _ = texc.shape
+    if work is None:
+        key = (B, H, W, texc.device)
+        work = _TEXBIN_WORK.get(key)
+        if work is None:
+            work = _TEXBIN_WORK[key] = torch.empty(L.vhap_texture_grad_binned_work_bytes(B, H, W), dtype=torch.uint8, device=texc.device)
+    rc = L.vhap_texture_grad_binned(T, T, C, _p(texc), _p(texd), _p(d_out), B, H, W, _p(d_tex), _p(d_mips) if d_mips is not None and d_mips.numel() else 0,
+                                    _p(work), work.numel(), _stream())
+    if rc == -5:        # VHAP_E_UNSUPPORTED
+        return False
+    _chk(rc, "vhap_texture_grad_binned")
+    return True
+
+
+def use_binned_texgrad():
+    return os.environ.get("VHAP_TEXGRAD", "binned") != "tiled"      # (env: A/B against the screen-tiled kernel)
+
+
 class _TexSample(torch.autograd.Function):
     """albedo = painted + residual (channel-last) -> mip pyramid -> trilinear sample at (texc, texd), with the TV / residual
     energies of the texture computed in the same pass over it.  One autograd node, so the backward can keep the texture
@@ -271,8 +297,12 @@ class _TexSample(torch.autograd.Function):
                 d_tex, d_mips = buf[:albedo.numel()], buf[albedo.numel():]
             d_uv = torch.empty_like(texc) if need_uv else None
             d_da = torch.empty_like(texd) if need_da else None
-            _chk(L.vhap_texture_bwd(_p(albedo), _p(mips), 1, T, T, 3, _p(texc), _p(texd), _p(_f32c(d_out)), B, H, W, _p(d_tex), _p(d_mips),
-                                    _p(d_uv), _p(d_da), _stream()), "vhap_texture_bwd")
+            d_out = _f32c(d_out)
+            binned = need_tex and use_binned_texgrad() and texture_grad_binned(T, 3, texc, texd, d_out, d_tex, d_mips)
+            if not binned or need_uv or need_da:
+                _chk(L.vhap_texture_bwd(_p(albedo), _p(mips), 1, T, T, 3, _p(texc), _p(texd), _p(d_out), B, H, W,
+                                        _p(None if binned else d_tex), _p(None if binned else d_mips), _p(d_uv), _p(d_da), _stream()),
+                     "vhap_texture_bwd")
             if need_tex and mips.numel() > 0:
                 _chk(L.vhap_texture_mip_fold(_p(d_tex), _p(d_mips), 1, T, T, 3, _n_gather(T), _stream()), "vhap_texture_mip_fold")
         if need_tex:

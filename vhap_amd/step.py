@@ -16,6 +16,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from . import native as NV
 from .config import PhotometricStageConfig
 from .native import _n_gather
 from .ops import _p, _stream
@@ -154,6 +155,7 @@ class NativeStep:
         # scratch that is overwritten
         self.d_rgba_aa, self.d_color, self.d_rgba = E(B, H, W, 4), E(B, H, W, 4), E(B, H, W, 4)
         self.d_albedo, self.d_normal, self.d_texc, self.d_texd = E(B, H, W, 3), E(B, H, W, 3), E(B, H, W, 2), E(B, H, W, 4)
+        self.texbin_work = torch.empty(self.L.vhap_texture_grad_binned_work_bytes(B, H, W), dtype=torch.uint8, device=dev)
         self.vn_scratch, self.g_posed, self.g_shaped = E(B, V, 3), E(B, V, 3), E(B, V, 3)
         self.d_mvp, self.d_K, self.d_sum = E(B, 16), E(B, 4), E(1)
         self.ones = torch.ones(8, **f32)
@@ -251,8 +253,9 @@ class NativeStep:
         st = _stream()
         n0 = self.albedo_tex.numel()
         d_tex, d_mips = g["d_tex"][:n0], g["d_tex"][n0:]
-        _chk(L.vhap_texture_bwd(_p(self.albedo_tex), _p(self.mips), 1, T, T, 3, _p(self.texc), _p(self.texd), _p(self.d_albedo), B, H, W,
-                                _p(d_tex), _p(d_mips), 0, 0, st), "vhap_texture_bwd")
+        if not (NV.use_binned_texgrad() and NV.texture_grad_binned(T, 3, self.texc, self.texd, self.d_albedo, d_tex, d_mips, self.texbin_work)):
+            _chk(L.vhap_texture_bwd(_p(self.albedo_tex), _p(self.mips), 1, T, T, 3, _p(self.texc), _p(self.texd), _p(self.d_albedo), B, H, W,
+                                    _p(d_tex), _p(d_mips), 0, 0, st), "vhap_texture_bwd")
         if not self.split_tex:
             self.tex_finish()
 
@@ -289,7 +292,7 @@ class NativeStep:
              "vhap_offset_reg_bwd")
 
     def _bwd_pixel(self, world_size):
-        """energy total -> photometric -> antialias -> shading backward -> gradient w.r.t. the texture coordinates"""
+        """energy total -> photometric -> antialias -> shading backward (-> d_albedo, d_normal per pixel)"""
         L, tr, g, acc = self.L, self.tr, self.g, self.accF
         B, H, W, V, F, T = self.B, self.H, self.W, self.V, self.F, self.T
         st = _stream()
@@ -305,8 +308,12 @@ class NativeStep:
                               _p(self.keep) if self.disturb_on else 0, _p(self.c_reg) if self.want_reg else 0,
                               _p(acc[12:16]) if self.want_reg else 0, B, H, W, _p(self.d_albedo), _p(self.d_normal), _p(g["lights"]), st),
              "vhap_shade_bwd")
+
+    def _bwd_uv(self):
+        """gradient w.r.t. the texture coordinates and their screen-space derivatives (input of the G-buffer backward)"""
+        L, B, H, W, T = self.L, self.B, self.H, self.W, self.T
         _chk(L.vhap_texture_bwd(_p(self.albedo_tex), _p(self.mips), 1, T, T, 3, _p(self.texc), _p(self.texd), _p(self.d_albedo), B, H, W,
-                                0, 0, _p(self.d_texc), _p(self.d_texd), st), "vhap_texture_bwd")
+                                0, 0, _p(self.d_texc), _p(self.d_texd), _stream()), "vhap_texture_bwd")
 
     def _bwd_geometry(self, early=None):
         """G-buffer backward -> vertex normals -> clip transform -> camera -> skinning -> per-frame parameters"""
@@ -353,11 +360,12 @@ class NativeStep:
                         early = torch.cuda.Event()
                         early.record()
                 self._bwd_pixel(world_size)
-                # uv gradient first (alone it takes a third of the time it needs next to the accumulation kernel), then fork: the texture
-                # gradient accumulation (atomics-bound) + fold + TV backward on the side branch, the geometry chain on this one
+                # fork as soon as d_albedo exists: the texture gradient (uv-binned accumulation + fold + TV backward) on the side branch,
+                # the uv gradient and the geometry chain on this one
                 self._fork()
                 with self._branch():
                     self._tex_backward()
+                self._bwd_uv()
                 self._bwd_geometry(early)
                 self._join()
             elif part == "texture":
@@ -371,6 +379,7 @@ class NativeStep:
                     if self.overlap:
                         early = torch.cuda.Event()
                         early.record()
+                self._bwd_uv()
                 self._bwd_geometry(early)
                 self._join()
             else:
