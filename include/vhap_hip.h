@@ -357,6 +357,7 @@ int vhap_adam_step(int n_tensors, float* const* params, const float* const* grad
  * ------------------------------------------------------------------------------------------- */
 #define VHAP_CALL_ACC_PREZEROED 1
 #define VHAP_CALL_AA_PASSTHROUGH_DONE 2   /* vhap_antialias_bwd: d_color already holds a copy of d_out (skip the pass-through copy) */
+#define VHAP_CALL_ADAM_KEEP_STEP 4        /* vhap_adam_step: do not advance the step counter (a further call of the same step follows) */
 enum {
     VHAP_LOG_LMK = 0, VHAP_LOG_PHOTO = 1, VHAP_LOG_SMOOTH_POSE = 2, VHAP_LOG_REG_JOINT = 3, VHAP_LOG_SMOOTH_JOINT = 4,
     VHAP_LOG_REG_EXPR = 5, VHAP_LOG_SMOOTH_EXPR = 6, VHAP_LOG_REG_SHAPE = 7, VHAP_LOG_TEX_TV = 8, VHAP_LOG_TEX_RES = 9,
@@ -364,6 +365,7 @@ enum {
     VHAP_LOG_TOTAL = 15, VHAP_LOG_COUNT = 16
 };
 void vhap_set_call_flags(int flags);
+int vhap_get_call_flags(void);
 int vhap_energy_finalize(const float* frame_terms, const float* lmk_energy, const float* tex_terms,
                          const float* off_terms, const float* shade_stats, float w_landmark,
                          float w_reg_diffuse, int B, int H, int W, float* log, vhap_stream_t stream);

@@ -67,6 +67,7 @@ SIGNATURES = {
     "vhap_tex_prep_fwd": (c_i, [c_fp] * 3 + [c_i, c_f, c_f] + [c_fp] * 3),
     "vhap_tex_prep_bwd": (c_i, [c_fp] * 5 + [c_i, c_fp, c_i, c_f, c_f] + [c_fp] * 2),
     "vhap_set_call_flags": (None, [c_i]),
+    "vhap_get_call_flags": (c_i, []),
     "vhap_energy_finalize": (c_i, [c_fp] * 5 + [c_f, c_f, c_i, c_i, c_i, c_fp, c_fp]),
     "vhap_energy_total": (c_i, [c_fp, c_fp, c_fp, c_f, c_i, c_fp, c_fp]),
     "vhap_sum_frames": (c_i, [c_fp, c_i, c_i, c_fp, c_fp]),

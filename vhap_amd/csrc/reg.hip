@@ -332,7 +332,9 @@ extern "C" int vhap_adam_step(int n_tensors, float* const* params, const float* 
     hipStream_t st = vhap_stream(stream);
     adam_kernel<<<nblocks, RB, 0, st>>>(t, lr_device, step_device, beta1, beta2, eps);
     VHAP_LAUNCH_CHECK();
-    adam_bump_kernel<<<1, 1, 0, st>>>(step_device);
-    VHAP_LAUNCH_CHECK();
+    if (!(vhap_g_call_flags & VHAP_CALL_ADAM_KEEP_STEP)) {
+        adam_bump_kernel<<<1, 1, 0, st>>>(step_device);
+        VHAP_LAUNCH_CHECK();
+    }
     return VHAP_OK;
 }

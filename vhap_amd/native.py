@@ -431,13 +431,16 @@ class HipAdam(torch.optim.Optimizer):
         return self._step
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, only=None, skip=None, advance=True):
+        """`only` / `skip` (tensors): update a subset -- a step may be issued in pieces, e.g. the texture as soon as its gradient is
+        complete, on a side stream; every piece but the last passes advance=False so that all of them see the same step count."""
         if self._tab is None:
             self._build()
         t = self._tab
         if not torch.cuda.is_current_stream_capturing():
             self.sync_lr()
-        sel = [i for i, p in enumerate(t["ps"]) if p.grad is not None]      # like torch: parameters without .grad are skipped
+        pick_p = lambda p: (only is None or any(p is q for q in only)) and (skip is None or not any(p is q for q in skip))
+        sel = [i for i, p in enumerate(t["ps"]) if p.grad is not None and pick_p(p)]      # like torch: parameters without .grad are skipped
         if not sel:
             return
         for i in sel:
@@ -449,7 +452,15 @@ class HipAdam(torch.optim.Optimizer):
         pick = lambda arr, ty: (ty * n)(*[arr[i] for i in sel])
         G = P(*[t["ps"][i].grad.data_ptr() for i in sel])
         g0 = self.param_groups[0]
-        _chk(_lib.lib().vhap_adam_step(n, pick(t["p"], ctypes.c_void_p), G, pick(t["m"], ctypes.c_void_p), pick(t["v"], ctypes.c_void_p),
-                                       pick(t["numel"], ctypes.c_int64), pick(t["lr_index"], ctypes.c_int32), _p(self._lr_dev),
-                                       _p(self._step), float(g0["betas"][0]), float(g0["betas"][1]), float(g0["eps"]), _stream()),
-             "vhap_adam_step")
+        L = _lib.lib()
+        saved = L.vhap_get_call_flags()
+        if not advance:
+            L.vhap_set_call_flags(saved | 4)                           # VHAP_CALL_ADAM_KEEP_STEP
+        try:
+            _chk(L.vhap_adam_step(n, pick(t["p"], ctypes.c_void_p), G, pick(t["m"], ctypes.c_void_p), pick(t["v"], ctypes.c_void_p),
+                                  pick(t["numel"], ctypes.c_int64), pick(t["lr_index"], ctypes.c_int32), _p(self._lr_dev),
+                                  _p(self._step), float(g0["betas"][0]), float(g0["betas"][1]), float(g0["eps"]), _stream()),
+                 "vhap_adam_step")
+        finally:
+            if not advance:
+                L.vhap_set_call_flags(saved)

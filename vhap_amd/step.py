@@ -201,6 +201,9 @@ class NativeStep:
         L.vhap_set_call_flags(1)
         try:
             so = tr.static_offset
+            # the camera first: two tiny launches that would take 3-5x as long next to the texture branch below
+            torch.addcmul(self.K0, tr.focal_length.detach(), self.K1, out=self.K)      # K = (f, f, cx, cy), f = focal * max(h, w)
+            _chk(L.vhap_camera_fwd(_p(self.K), _p(self.RT), B, 0, 0, H, W, 0.1, 10.0, _p(self.mvp), st), "vhap_camera_fwd")
             _chk(L.vhap_frame_prep_fwd(_p(self.ts), _p(tr.shape), _p(tr.expr), _p(tr.rotation), _p(tr.translation), _p(tr.neck_pose),
                                        _p(tr.jaw_pose), _p(tr.eyes_pose), _p(fm.JT), _p(fm.JS), _p(fm.jreg_idx), _p(fm.jreg_w), fm.jreg_n,
                                        _p(so), fm.parents, self.weights, B, self.Bp, self.N, self.NS, self.NE, J, fb.Kp, V,
@@ -212,12 +215,12 @@ class NativeStep:
             self._fork()
             with self._branch():
                 self._tex_forward()
-            torch.addcmul(self.K0, tr.focal_length.detach(), self.K1, out=self.K)      # K = (f, f, cx, cy), f = focal * max(h, w)
-            _chk(L.vhap_camera_fwd(_p(self.K), _p(self.RT), B, 0, 0, H, W, 0.1, 10.0, _p(self.mvp), st), "vhap_camera_fwd")
-            if self.w_lmk:
-                l0, l1, b0, b1, boost = self.lmk_cfg
-                _chk(L.vhap_landmark_fwd(_p(self.verts), _p(self.lm.vidx), _p(self.lm.bary), _p(self.mvp), _p(self.lmk2d), B, V, self.lm.L,
-                                         self.lmk2d.shape[1], l0, l1, b0, b1, boost, H, W, 0, _p(acc[6:7]), st), "vhap_landmark_fwd")
+                if self.w_lmk:                                        # needs only verts + mvp: off the rasteriser's critical path
+                    l0, l1, b0, b1, boost = self.lmk_cfg
+                    _chk(L.vhap_landmark_fwd(_p(self.verts), _p(self.lm.vidx), _p(self.lm.bary), _p(self.mvp), _p(self.lmk2d), B, V, self.lm.L,
+                                             self.lmk2d.shape[1], l0, l1, b0, b1, boost, H, W, 0, _p(acc[6:7]), _stream()), "vhap_landmark_fwd")
+                self.arena.zero_()                                    # ONE launch clears every gradient accumulator of the backward
+                self._arena_clean = True
             _chk(L.vhap_transform_fwd(_p(self.verts), _p(self.mvp), B, V, _p(self.clip), st), "vhap_transform_fwd")
             _chk(L.vhap_vnormal_fwd(_p(self.verts), _p(self.csr.tri), _p(self.csr.ptr), _p(self.csr.idx), B, V, _p(self.vn), st), "vhap_vnormal_fwd")
             _chk(L.vhap_raster_interp_fwd(_p(self.clip), _p(self.tri), _p(self.vn), _p(self.uv), _p(self.tri_uv), B, V, self.uv.shape[0], F, H, W,
@@ -342,15 +345,18 @@ class NativeStep:
                                    _p(g["rotation"]), _p(g["translation"]), _p(g["neck_pose"]), _p(g["jaw_pose"]), _p(g["eyes_pose"]),
                                    _p(g["static_offset"]), st), "vhap_frame_prep_bwd")
 
-    def backward(self, world_size=1, part="all"):
+    def backward(self, world_size=1, part="all", optimizer=None):
         """part = 'all': the whole backward as one two-branch DAG (one GPU).  Under frame sharding the backward is captured in two
-        graphs so that the big collective can start early: 'texture' (pixel chain + the complete texture gradient, serial) -- the
+        graphs so that the big collective can start early (`optimizer`, one GPU only: a HipAdam whose texture update is issued on the
+        side branch -- the caller then steps the remaining parameters with optimizer.step(skip=(tex_extra,))): 'texture' (pixel chain + the complete texture gradient, serial) -- the
         caller launches the asynchronous all-reduce of the texture gradient -- then 'geometry' (everything else), which hides it."""
         L = self.L
         L.vhap_set_call_flags(1)
         try:
             if part in ("all", "texture"):
-                self.arena.zero_()                                    # ONE launch clears every gradient accumulator
+                if not getattr(self, "_arena_clean", False):          # (normally done on the forward's side branch already)
+                    self.arena.zero_()
+                self._arena_clean = False
             if part == "all":
                 early = None
                 self._fork()
@@ -365,6 +371,8 @@ class NativeStep:
                 self._fork()
                 with self._branch():
                     self._tex_backward()
+                    if optimizer is not None:                         # the texture's Adam update as soon as its gradient is complete
+                        optimizer.step(only=(self.tr.tex_extra,), advance=False)
                 self._bwd_uv()
                 self._bwd_geometry(early)
                 self._join()

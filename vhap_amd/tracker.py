@@ -885,11 +885,20 @@ class GraphedStep:
                 # nothing happens between the passes on one GPU: ONE graph launch per step instead of three (~15 us of launch gap each)
                 # `unroll` > 1: that many consecutive steps per graph launch (the launch gap, ~25 us, is paid once per replay)
                 self.unroll = max(1, int(unroll))
+                # the texture's Adam update (7 x 50 MB of traffic at T = 2048) goes on the backward's side branch, right behind its
+                # gradient, instead of on the tail of the step
+                tex = tracker.tex_extra
+                split = tex is not None and any(p is tex for p in self.params) and len(self.params) > 1 and \
+                    os.environ.get("VHAP_SPLIT_ADAM", "1") != "0"
                 with torch.cuda.graph(self.gF):
                     for _ in range(self.unroll):
                         ns.forward()
-                        ns.backward(1)
-                        optimizer.step()
+                        if split:
+                            ns.backward(1, optimizer=optimizer)
+                            optimizer.step(skip=(tex,))
+                        else:
+                            ns.backward(1)
+                            optimizer.step()
             else:
                 # Frame sharding.  The big collective is the texture gradient (50 MB at T = 2048).  The backward is captured in two graphs:
                 # 'texture' makes that gradient final first, its asynchronous all-reduce is launched, and 'geometry' (G-buffer backward,
