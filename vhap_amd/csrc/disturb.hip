@@ -8,7 +8,8 @@
 //
 // Here: a deterministic counting sort of the pixel ids by cluster (row-major order inside a cluster, i.e.
 // exactly the order of the reference's boolean-mask gather) in two passes -- per-block cluster histograms
-// (wave ballots) and a scatter in which every workgroup derives its own prefix from the histograms --
+// (wave ballots over the cluster values present in a wave) and a scatter in which every workgroup derives its own prefix from the
+// histograms and an LDS prefix table over its (iteration, wave) counters --
 // followed by one gather pass.  No host sync, no atomics, graph-capturable.  Randomness is supplied by the
 // caller (Bernoulli masks and one 31-bit integer per pixel), so runs can be made reproducible.
 #include "common.h"
@@ -51,20 +52,20 @@ __global__ __launch_bounds__(DB) void disturb_count_kernel(const ClusterSrc src,
     __shared__ int cnt[DB / 64][MAXC];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (rng_state && blockIdx.x == 0 && threadIdx.x == 0) rng_state[0] += 1u;
-    int mine[MAXC];
-#pragma unroll
-    for (int k = 0; k < MAXC; k++) mine[k] = 0;
+    if (lane < MAXC) cnt[wave][lane] = 0;
+    // a wave holds 64 consecutive pixels (one or two clusters, rarely more): loop over the cluster values present, not over all clusters
 #pragma unroll
     for (int it = 0; it < PPT; it++) {
         const long long p = (long long)blockIdx.x * DPIX + it * DB + threadIdx.x;
-        const int c = p < n ? pixel_cluster(src, p) : -1;
-#pragma unroll
-        for (int k = 0; k < MAXC; k++)
-            if (k < ncl) mine[k] += __popcll(__ballot(c == k));     // wave-uniform
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int k = 0; k < MAXC; k++) cnt[wave][k] = mine[k];
+        int c = p < n ? pixel_cluster(src, p) : -1;
+        if (c >= ncl) c = -1;                       // (ids outside the configured clusters are left alone)
+        unsigned long long todo = __ballot(c >= 0);
+        while (todo) {
+            const int k = __builtin_amdgcn_readlane(c, __builtin_ctzll(todo));
+            const unsigned long long m = __ballot(c == k);
+            if (lane == 0) cnt[wave][k] += __popcll(m);
+            todo &= ~m;
+        }
     }
     __syncthreads();
     if (threadIdx.x < MAXC) {
@@ -104,17 +105,24 @@ __global__ __launch_bounds__(DB) void disturb_scatter_kernel(const ClusterSrc sr
         for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); t += __shfl_xor(t, o, 64); }
         if (lane == 0) { red[0][wave][k] = a; red[1][wave][k] = t; }
     }
-    // ranks inside the block, in pixel order: iteration-major, then wave, then lane
+    // ranks inside the block, in pixel order: iteration-major, then wave, then lane.  A wave holds 64 consecutive pixels -- one or
+    // two clusters, rarely more -- so it loops over the cluster values PRESENT (readfirstlane + ballot) instead of over all clusters.
+    for (int i = threadIdx.x; i < PPT * (DB / 64) * MAXC; i += DB) (&wcnt[0][0][0])[i] = 0;
+    __syncthreads();
     int c_of[PPT], rank_of[PPT];
 #pragma unroll
     for (int it = 0; it < PPT; it++) {
         const long long p = (long long)blockIdx.x * DPIX + it * DB + threadIdx.x;
-        const int c = p < n ? pixel_cluster(src, p) : -1;
+        int c = p < n ? pixel_cluster(src, p) : -1;
+        if (c >= ncl) c = -1;                       // (ids outside the configured clusters are left alone)
         int rank = 0;
-        for (int k = 0; k < ncl; k++) {
+        unsigned long long todo = __ballot(c >= 0);
+        while (todo) {
+            const int k = __builtin_amdgcn_readlane(c, __builtin_ctzll(todo));
             const unsigned long long m = __ballot(c == k);
             if (c == k) rank = __popcll(m & ((1ull << lane) - 1ull));
             if (lane == 0) wcnt[it][wave][k] = __popcll(m);
+            todo &= ~m;
         }
         c_of[it] = c; rank_of[it] = rank;
     }
@@ -134,16 +142,29 @@ __global__ __launch_bounds__(DB) void disturb_scatter_kernel(const ClusterSrc sr
             totals[MAXC + threadIdx.x] = start;
         }
     }
+    // exclusive prefix of wcnt over (iteration, wave) per cluster, in place: wave w scans cluster w (two entries per lane), so that a
+    // pixel needs ONE LDS read for its offset instead of walking up to PPT * 16 counters
+    {
+        constexpr int NE = PPT * (DB / 64);       // 128 entries per cluster
+        static_assert(NE == 128 && DB / 64 == MAXC, "one wave per cluster, two entries per lane");
+        int* col = &wcnt[0][0][0] + wave;         // entry e of cluster `wave` lives at col[e * MAXC]
+        const int a0 = col[(2 * lane) * MAXC], a1 = col[(2 * lane + 1) * MAXC];
+        int incl = a0 + a1;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += u;
+        }
+        const int excl = incl - (a0 + a1);
+        col[(2 * lane) * MAXC] = excl;
+        col[(2 * lane + 1) * MAXC] = excl + a0;
+    }
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < PPT; it++) {
         const int c = c_of[it];
         if (c < 0) continue;
-        int off = base[c] + rank_of[it];
-        for (int i2 = 0; i2 < it; i2++)
-            for (int w = 0; w < DB / 64; w++) off += wcnt[i2][w][c];
-        for (int w = 0; w < wave; w++) off += wcnt[it][w][c];
-        perm[off] = (int)((long long)blockIdx.x * DPIX + it * DB + threadIdx.x);
+        perm[base[c] + wcnt[it][wave][c] + rank_of[it]] = (int)((long long)blockIdx.x * DPIX + it * DB + threadIdx.x);
     }
 }
 
@@ -159,7 +180,8 @@ __global__ __launch_bounds__(256) void disturb_apply_kernel(const float4* __rest
     const long long n = (long long)B * H * W;
     const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
     if (p >= n) return;
-    const int c = pixel_cluster(src, p);
+    int c = pixel_cluster(src, p);
+    if (c >= MAXC) c = 1;                           // (treated like 'face in no cluster': never disturbed)
     int w;
     unsigned long long pick;
     if (rng_state) {     // in-kernel random numbers: Bernoulli(rate) and a 32-bit index draw per pixel
@@ -175,7 +197,10 @@ __global__ __launch_bounds__(256) void disturb_apply_kernel(const float4* __rest
     float4 v = rgba[p];   // after compositing, background pixels of `rgba` already hold the background colour
     float k = 1.0f;
     if (w != 0 && nc > 0) {
-        const int q = perm[totals[MAXC + c] + (int)(pick % (unsigned long long)nc)];
+        // injected indices: idx % n like the reference's randint-then-index (a 64-bit division per disturbed pixel -- parity path only);
+        // in-kernel draws: floor(r * n / 2^32), the same distribution without a division
+        const int j = rng_state ? (int)((pick * (unsigned long long)nc) >> 32) : (int)(pick % (unsigned long long)nc);
+        const int q = perm[totals[MAXC + c] + j];
         v = rgba[q];
         k = 0.0f;
     }

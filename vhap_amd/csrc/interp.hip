@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void gbuffer_bwd_kernel(const float4* __restri
 // triangle-parallel kernel above spends most of its time on bounding-box pixels won by other triangles.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int GT = 16;          // tile edge
-constexpr int GSLOT = 512;      // hash slots (vertices) per tile
+constexpr int GSLOT = 256;      // hash slots (vertices) per tile: a tile touches a few dozen; 512 slots (28 KB of LDS) cost 20 % in occupancy
 constexpr unsigned GEMPTY = 0xffffffffu;
 
 __global__ __launch_bounds__(GT * GT) void gbuffer_bwd_tiled_kernel(const float4* __restrict__ pos, const int* __restrict__ tri,
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(GT * GT) void gbuffer_bwd_tiled_kernel(const float4
 #pragma unroll
             for (int vtx = 0; vtx < 3; vtx++) {
                 const int vi = vtx == 0 ? i0 : (vtx == 1 ? i1 : i2);
-                unsigned slot = ((unsigned)vi * 2654435761u) >> 23;     // 9 bits
+                unsigned slot = ((unsigned)vi * 2654435761u) >> 24;     // 8 bits
                 bool done = false;
 #pragma unroll 1
                 for (int probe = 0; probe < 8 && !done; probe++) {
