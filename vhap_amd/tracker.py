@@ -874,6 +874,9 @@ class GraphedStep:
         torch.cuda.current_stream().wait_stream(side)
         self.inv_n = torch.zeros((), device=dev)
         self.stream = torch.cuda.Stream()
+        # with a process group alive, its helper threads (RCCL watchdog, heartbeat) issue runtime calls of their own: keep those from
+        # invalidating a capture in progress on this thread
+        cap = dict(capture_error_mode="thread_local") if tracker.dist is not None else {}
         self.gF, self.gB, self.gA = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         if self.ns is not None:
             ns = self.ns
@@ -890,7 +893,7 @@ class GraphedStep:
                 tex = tracker.tex_extra
                 split = tex is not None and any(p is tex for p in self.params) and len(self.params) > 1 and \
                     os.environ.get("VHAP_SPLIT_ADAM", "1") != "0"
-                with torch.cuda.graph(self.gF):
+                with torch.cuda.graph(self.gF, **cap):
                     for _ in range(self.unroll):
                         ns.forward()
                         if split:
@@ -903,15 +906,15 @@ class GraphedStep:
                 # Frame sharding.  The big collective is the texture gradient (50 MB at T = 2048).  The backward is captured in two graphs:
                 # 'texture' makes that gradient final first, its asynchronous all-reduce is launched, and 'geometry' (G-buffer backward,
                 # normals, skinning, per-frame parameters: ~0.35 ms) runs underneath it; the small gradients follow in a second collective.
-                with torch.cuda.graph(self.gF):
+                with torch.cuda.graph(self.gF, **cap):
                     ns.forward()
                 pool = self.gF.pool() if os.environ.get("VHAP_GRAPH_POOLS") != "separate" else None
-                with torch.cuda.graph(self.gB, pool=pool):
+                with torch.cuda.graph(self.gB, pool=pool, **cap):
                     ns.backward(world, part="texture")
                 self.gB2 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.gB2, pool=pool):
+                with torch.cuda.graph(self.gB2, pool=pool, **cap):
                     ns.backward(world, part="geometry")
-                with torch.cuda.graph(self.gA, pool=pool):
+                with torch.cuda.graph(self.gA, pool=pool, **cap):
                     optimizer.step()
             self.E = ns.log[15]
             self.log_dict = ns.log_dict()
@@ -919,7 +922,7 @@ class GraphedStep:
             return
         tracker._split = {}
         try:
-            with torch.cuda.graph(self.gF):
+            with torch.cuda.graph(self.gF, **cap):
                 s = dict(self.sample)
                 tracker.clear_cache()
                 tracker.fill_cam_params_into_sample(s)
@@ -928,7 +931,7 @@ class GraphedStep:
             pool = self.gF.pool() if os.environ.get("VHAP_GRAPH_POOLS") != "separate" else None
             for p in self.params:
                 p.grad = None
-            with torch.cuda.graph(self.gB, pool=pool):
+            with torch.cuda.graph(self.gB, pool=pool, **cap):
                 E = E_rest + tracker.cfg.w.photo * self.S * self.inv_n
                 # .grad is None: autograd hands its gradient tensors over to the parameters (no copy); they live in the graph's
                 # pool at fixed addresses and are rewritten by every replay
@@ -937,7 +940,7 @@ class GraphedStep:
                     if p.grad is None:
                         p.grad = torch.zeros_like(p)
                 self.E = E.detach()
-            with torch.cuda.graph(self.gA, pool=pool):
+            with torch.cuda.graph(self.gA, pool=pool, **cap):
                 optimizer.step()
         finally:
             tracker._split = None
