@@ -447,12 +447,6 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterParams P) {
                     const int tl0 = (A0 > 0 || (A0 == 0 && B0 > 0)) ? 1 : 0;
                     const int tl1 = (A1 > 0 || (A1 == 0 && B1 > 0)) ? 1 : 0;
                     const int tl2 = (A2 > 0 || (A2 == 0 && B2 > 0)) ? 1 : 0;
-                    const long long E0 = (long long)A0 * (cx - sx1) + (long long)B0 * (cy - sy1);
-                    const long long E1 = (long long)A1 * (cx - sx2) + (long long)B1 * (cy - sy2);
-                    const long long E2 = (long long)A2 * (cx - sx0) + (long long)B2 * (cy - sy0);
-                    C0 = sat30(E0 + tl0 - 1);
-                    C1 = sat30(E1 + tl1 - 1);
-                    C2 = sat30(E2 + tl2 - 1);
                     // edges shorter than 2048 px: A, B fit int16 -> one v_dot2c_i32_i16 per edge and pixel
                     const int amax = max(max(abs(A0), abs(B0)), max(max(abs(A1), abs(B1)), max(abs(A2), abs(B2))));
                     small = amax < 32768;
@@ -462,7 +456,31 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterParams P) {
                     // z/w test plane anchored at the block origin (depth_plane() in the oracle)
                     const double d1 = (double)q2.y - (double)q2.x, d2 = (double)q2.z - (double)q2.x;
                     const double inv = __hiloint2double(q3.y, q3.x);
-                    zwc = (float)((double)q2.x + ((double)E1 * d1 + (double)E2 * d2) * inv);
+                    double e1d, e2d;
+                    if (amax < 16384) {
+                        // edges shorter than 1024 px (practically all): the block overlaps the triangle's bounding box, so the block
+                        // origin is within amax + 136 sub-pixels of every vertex and each edge function fits 31 bits -- 24-bit
+                        // multiplies (full rate; 64-bit mads are quarter rate), no saturation, one int->double conversion.  Same
+                        // integers as the 64-bit path below, hence the same bits.
+                        const int e0 = __mul24(A0, cx - sx1) + __mul24(B0, cy - sy1);
+                        const int e1 = __mul24(A1, cx - sx2) + __mul24(B1, cy - sy2);
+                        const int e2 = __mul24(A2, cx - sx0) + __mul24(B2, cy - sy0);
+                        C0 = e0 + tl0 - 1;
+                        C1 = e1 + tl1 - 1;
+                        C2 = e2 + tl2 - 1;
+                        e1d = (double)e1;
+                        e2d = (double)e2;
+                    } else {
+                        const long long E0 = (long long)A0 * (cx - sx1) + (long long)B0 * (cy - sy1);
+                        const long long E1 = (long long)A1 * (cx - sx2) + (long long)B1 * (cy - sy2);
+                        const long long E2 = (long long)A2 * (cx - sx0) + (long long)B2 * (cy - sy0);
+                        C0 = sat30(E0 + tl0 - 1);
+                        C1 = sat30(E1 + tl1 - 1);
+                        C2 = sat30(E2 + tl2 - 1);
+                        e1d = (double)E1;
+                        e2d = (double)E2;
+                    }
+                    zwc = (float)((double)q2.x + (e1d * d1 + e2d * d2) * inv);
                     gx = (float)((((double)A1 * d1 + (double)A2 * d2) * 16.0) * inv);
                     gy = (float)((((double)B1 * d1 + (double)B2 * d2) * 16.0) * inv);
                 }
