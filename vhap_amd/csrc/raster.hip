@@ -294,9 +294,9 @@ __device__ __forceinline__ Frag shade_frag(const float4 p0, const float4 p1, con
     return r;
 }
 
-__device__ __forceinline__ unsigned f2ord(float f) {
+__device__ __forceinline__ unsigned f2ord(float f) {   // order-preserving float -> unsigned: negative ? ~u : u | sign  (branch-free: 3 VALU)
     const unsigned u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return u ^ ((unsigned)((int)u >> 31) | 0x80000000u);
 }
 
 __device__ __forceinline__ int sat30(long long e) {
@@ -509,9 +509,10 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterParams P) {
             const int e1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, x.y), dxy, y.x, false);
             const int e2 = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, x.z), dxy, y.y, false);
             const float zt = __fmaf_rn(__int_as_float(y.w), fdx, __fmaf_rn(__int_as_float(z.x), fdy, __int_as_float(y.z)));
-            const bool inside = ((e0 | e1 | e2) >= 0) && (zt >= -1.0f && zt <= 1.0f);
+            const bool inside = ((e0 | e1 | e2) >= 0) & (fabsf(zt) <= 1.0f);
             const unsigned long long key = ((unsigned long long)f2ord(zt) << 32) | (unsigned)z.y;
-            if (inside && key < best) best = key;
+            const bool take = inside & (key < best);
+            best = take ? key : best;
         }
         // rare: triangles with an edge longer than 2048 px -- exact 64-bit edge functions per pixel
         unsigned long long mbig = __ballot(hit && !small);
