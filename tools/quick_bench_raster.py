@@ -1,11 +1,12 @@
-"""Ad-hoc timing of the RI-fwd pass (used during development; bench.py is the contract)."""
+"""Ad-hoc timing of the RI-fwd pass (used during development; bench.py is the contract).  The input scene comes from the test-suite's
+scene builder (tests/scenes.py); everything timed is the HIP path."""
 import sys, time
 import numpy as np, torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vhap_amd import ops
 from vhap_amd.synthetic import make_flame_model
 from tests.scenes import head_scene
-from oracle import torch_ref as R
+from vhap_amd.render_hip import HipDiffRenderer
 
 B, H, W = (int(x) for x in (sys.argv[1:4] if len(sys.argv) > 3 else (16, 512, 512)))
 model, topo = make_flame_model(0)
@@ -14,7 +15,7 @@ c = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
 pos = sc["clip"].float().cuda()
 tri, tri_uv = c(topo.faces.astype(np.int32)), c(topo.faces_uv.astype(np.int32))
 uv = c(topo.verts_uvs.astype(np.float32))
-vn = R.compute_v_normals(sc["verts"], torch.from_numpy(topo.faces.astype(np.int64))).float().cuda()
+vn = HipDiffRenderer(lighting_type="SH").cuda().compute_v_normals(sc["verts"].float().cuda(), torch.from_numpy(topo.faces.astype(np.int64)).cuda()).contiguous()
 ctx = ops.RasterizeHipContext()
 from vhap_amd import _lib
 _lib.lib().vhap_debug_set_flags(int(os.environ.get('VHAP_DEBUG', '0')))
