@@ -1,6 +1,9 @@
 """Oracle-side assembly of the total energy (tracker.py:692-750 and everything it calls) from the
 restatements in torch_ref.py -- TEST INFRASTRUCTURE ONLY.  Used to check the product's
-FlameTracker.compute_energy (value and gradients w.r.t. every parameter) end to end."""
+FlameTracker.compute_energy (value and gradients w.r.t. every parameter) end to end.
+Pinned: the landmark energy and every regulariser / smoothness term against the reference's own FlameTracker methods
+(tests/golden/energy_golden.npz, tests/test_energy_golden.py); the photometric term goes through the raster ops, whose parity is
+"unpinned" (DESIGN.md section 1)."""
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -30,6 +33,53 @@ def joint_l2(neck, jaw, eyes, w):
             diff = diff + ((eyes[:, :3] - eyes[:, 3:]) ** 2).mean()
         e = e + diff * w[f"reg_{name}"]
     return e
+
+
+def regularization_energy(P, ts, w, stage, opt, tex_painted, uvmask_res, v_cano, diffuse_nchw, topo, dtype=torch.float64):
+    """tracker.py:480-690 (compute_regularization_energy and its helpers): every regulariser / smoothness term of a stage as a dict.
+    `opt`: names of the parameter groups being optimised (the reference's opt_dict); `diffuse_nchw`: the shaded
+    `diffuse_detach_normal` image [B,3,H,W] (only read when 'lights' is optimised).  Pinned on the reference's own methods by
+    tests/golden/energy_golden.npz (tools/make_golden_energy.py)."""
+    prev = np.clip(ts - 1, 0, P["expr"].shape[0] - 1)
+    log = {}
+    tracking = "tracking" in stage
+    if "pose" in opt and tracking:
+        log["smooth_pose"] = ((P["translation"][ts] - P["translation"][prev].detach()) ** 2).mean() * w.smooth_trans + \
+            ((P["rotation"][ts] - P["rotation"][prev].detach()) ** 2).mean() * w.smooth_rot
+    if "joints" in opt:
+        log["reg_joint"] = joint_l2(P["neck_pose"][ts], P["jaw_pose"][ts], P["eyes_pose"][ts], w)
+        if tracking:
+            log["smooth_joint"] = sum(((P[k][ts] - P[k][prev].detach()) ** 2).mean() * c for k, c in
+                                      (("neck_pose", w.smooth_neck), ("jaw_pose", w.smooth_jaw), ("eyes_pose", w.smooth_eyes)))
+    if "expr" in opt:
+        log["reg_expr"] = w.reg_expr * (P["expr"][ts] ** 2).mean()
+        if tracking:
+            log["smooth_expr"] = ((P["expr"][ts] - P["expr"][prev].detach()) ** 2).mean() * w.smooth_expr
+    if "shape" in opt:
+        log["reg_shape"] = w.reg_shape * (P["shape"] ** 2).mean()
+    if "texture" in opt:
+        log["reg_tex_tv"] = w.reg_tex_tv * R.tex_tv_energy((tex_painted + P["tex_extra"][None])[0])
+        log["reg_tex_res_clusters"] = w.reg_tex_res_clusters * (P["tex_extra"] ** 2 * uvmask_res).mean()
+    if "lights" in opt:
+        d = diffuse_nchw
+        log["reg_diffuse"] = w.reg_diffuse * (F.relu(d.max() - 1) + d.var(dim=1).mean())
+    if ("static_offset" in opt or "dynamic_offset" in opt) and P.get("static_offset") is not None:
+        off = P["static_offset"]
+        V = off.shape[1]
+        L = _laplacian(V, topo).to(dtype)
+        v0 = (v_cano - off).detach()
+        wl = torch.ones(1, V, 1, dtype=dtype)
+        wl[:, torch.from_numpy(topo.get_vid_by_region(list(w.reg_offset_lap_relax_for)))] *= w.reg_offset_lap_relax_coef
+        log["reg_offset_lap"] = w.reg_offset_lap * R.laplacian_energy(L, v0, v0 + off, wl)
+        wo = torch.ones(1, V, 1, dtype=dtype)
+        wo[:, torch.from_numpy(topo.get_vid_by_region(list(w.reg_offset_relax_for)))] *= w.reg_offset_relax_coef
+        log["reg_offset"] = w.reg_offset * (off.abs() * wo).mean()
+        rigid = 0
+        for region in w.reg_offset_rigid_for:
+            vids = torch.from_numpy(topo.get_vid_by_region([region]))
+            rigid = rigid + off[:, vids, :].var(dim=-2).mean()
+        log["reg_offset_rigid"] = w.reg_offset_rigid * rigid
+    return log
 
 
 def total_energy(P, model, topo, cfg, sample, stage, tex_painted, uvmask_res, image_size, dtype=torch.float64,
@@ -82,42 +132,7 @@ def total_energy(P, model, topo, cfg, sample, stage, tex_painted, uvmask_res, im
         extras.update(out)
         extras["tid"] = tid
     if stage is not None:
-        tracking = "tracking" in stage
-        if "pose" in opt and tracking:
-            log["smooth_pose"] = ((P["translation"][ts] - P["translation"][prev].detach()) ** 2).mean() * w.smooth_trans + \
-                ((P["rotation"][ts] - P["rotation"][prev].detach()) ** 2).mean() * w.smooth_rot
-        if "joints" in opt:
-            log["reg_joint"] = joint_l2(P["neck_pose"][ts], P["jaw_pose"][ts], P["eyes_pose"][ts], w)
-            if tracking:
-                log["smooth_joint"] = sum(((P[k][ts] - P[k][prev].detach()) ** 2).mean() * c for k, c in
-                                          (("neck_pose", w.smooth_neck), ("jaw_pose", w.smooth_jaw), ("eyes_pose", w.smooth_eyes)))
-        if "expr" in opt:
-            log["reg_expr"] = w.reg_expr * (P["expr"][ts] ** 2).mean()
-            if tracking:
-                log["smooth_expr"] = ((P["expr"][ts] - P["expr"][prev].detach()) ** 2).mean() * w.smooth_expr
-        if "shape" in opt:
-            log["reg_shape"] = w.reg_shape * (P["shape"] ** 2).mean()
-        if "texture" in opt:
-            log["reg_tex_tv"] = w.reg_tex_tv * R.tex_tv_energy((tex_painted + P["tex_extra"][None])[0])
-            log["reg_tex_res_clusters"] = w.reg_tex_res_clusters * (P["tex_extra"] ** 2 * uvmask_res).mean()
-        if "lights" in opt:
-            d = extras["diffuse_detach_normal"].permute(0, 3, 1, 2)
-            log["reg_diffuse"] = w.reg_diffuse * (F.relu(d.max() - 1) + d.var(dim=1).mean())
-        if ("static_offset" in opt or "dynamic_offset" in opt) and P.get("static_offset") is not None:
-            off = P["static_offset"]
-            V = off.shape[1]
-            L = _laplacian(V, topo).to(dtype)
-            v0 = (v_cano - off).detach()
-            wl = torch.ones(1, V, 1, dtype=dtype)
-            wl[:, torch.from_numpy(topo.get_vid_by_region(list(w.reg_offset_lap_relax_for)))] *= w.reg_offset_lap_relax_coef
-            log["reg_offset_lap"] = w.reg_offset_lap * R.laplacian_energy(L, v0, v0 + off, wl)
-            wo = torch.ones(1, V, 1, dtype=dtype)
-            wo[:, torch.from_numpy(topo.get_vid_by_region(list(w.reg_offset_relax_for)))] *= w.reg_offset_relax_coef
-            log["reg_offset"] = w.reg_offset * (off.abs() * wo).mean()
-            rigid = 0
-            for region in w.reg_offset_rigid_for:
-                vids = torch.from_numpy(topo.get_vid_by_region([region]))
-                rigid = rigid + off[:, vids, :].var(dim=-2).mean()
-            log["reg_offset_rigid"] = w.reg_offset_rigid * rigid
+        d = extras["diffuse_detach_normal"].permute(0, 3, 1, 2) if "lights" in opt else None
+        log.update(regularization_energy(P, ts, w, stage, opt, tex_painted, uvmask_res, v_cano, d, topo, dtype))
     E = torch.stack(list(log.values())).sum()
     return E, log, extras

@@ -1,0 +1,150 @@
+"""Energy terms pinned on the REFERENCE's own code (CPU).  tests/golden/energy_golden.npz holds what
+FlameTracker.compute_lmk_energy / compute_regularization_energy (+ helpers), NVDiffRenderer.world_to_clip / world_to_ndc /
+compute_v_normals / compute_face_normals and BaseTrackingConfig() of /root/reference return on a small seeded state
+(tools/make_golden_energy.py).  Checked here: (1) the oracle restatement (fp64: 1e-9; fp32 reference helpers: 1e-5), (2) the product's
+host formulation -- vhap_amd.tracker.FlameTracker on a CPU device, fp32: 2e-4 -- which is what the HIP kernels are compared with on the
+GPU (tests/test_native_gpu.py), (3) every default of vhap_amd.config that the reference also has."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import energy_ref
+from oracle import torch_ref as R
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "energy_golden.npz"), allow_pickle=True)
+OPT = {"pose", "joints", "expr", "shape", "texture", "lights", "static_offset"}
+STAGES = ("rgb_init_offset", "rgb_global_tracking")
+
+
+def _ref(prefix):
+    return {k[len(prefix):]: float(G[k]) for k in G.files if k.startswith(prefix)}
+
+
+def _state(dtype):
+    P = {k[2:]: torch.from_numpy(G[k]).to(dtype) for k in G.files if k.startswith("P/")}
+    H, W = (int(x) for x in G["image_size"])
+    return P, np.asarray(G["ts"]), (H, W)
+
+
+def _camera(P, B, H, W, dtype):
+    f = P["focal_length"] * max(H, W)
+    K = torch.stack([f, f, torch.full_like(f, 0.5 * W), torch.full_like(f, 0.5 * H)], dim=1)
+    RT = torch.eye(3, 4, dtype=dtype)
+    RT[2, 3] = -1
+    return K, RT[None].expand(B, -1, -1).contiguous()
+
+
+def test_oracle_energies_match_reference(flame_model):
+    from vhap_amd.config import BaseTrackingConfig
+    model, topo = flame_model
+    dt = torch.float64
+    P, ts, (H, W) = _state(dt)
+    tm = {k: torch.from_numpy(np.asarray(v)) for k, v in model.items()}
+    for k in ("v_template", "shapedirs", "posedirs", "J_regressor", "lbs_weights", "lmk_bary_coords", "verts_uvs"):
+        tm[k] = tm[k].to(dt)
+    B = len(ts)
+    verts, v_cano, lmks = R.flame_forward(tm, P["shape"][None].expand(B, -1), P["expr"][ts], P["rotation"][ts], P["neck_pose"][ts],
+                                          P["jaw_pose"][ts], P["eyes_pose"][ts], P["translation"][ts], static_offset=P["static_offset"])
+    K, RT = _camera(P, B, H, W, dt)
+    # camera chain and normals (the reference computes these in fp32)
+    assert float((R.world_to_clip(verts, RT, K, (H, W)) - torch.from_numpy(G["clip_ref"])).abs().max()) < 2e-5
+    assert float((R.world_to_ndc(lmks, RT, K, (H, W), flip_y=True) - torch.from_numpy(G["ndc_ref"])).abs().max()) < 2e-5
+    faces = tm["faces"].long()
+    vflat = verts.clone()
+    vflat[0, torch.from_numpy(G["collapse"])] = 0            # a collapsed two-ring: zero normals -> the (0, 0, 1) fallback of the reference
+    vn = R.compute_v_normals(vflat, faces)
+    ref_vn = torch.from_numpy(G["vn_ref"])
+    fallback = (ref_vn == torch.tensor([0.0, 0.0, 1.0], dtype=dt)).all(-1)
+    assert int(fallback.sum()) >= 5 and torch.equal(vn[fallback], ref_vn[fallback])
+    # (vertices touching the collapsed patch sum near-cancelling sliver normals: ill-conditioned in fp32, excluded)
+    fnp = faces.numpy()
+    near = np.unique(fnp[np.isin(fnp, G["collapse"]).any(1)])
+    keep = torch.ones(vn.shape[1], dtype=torch.bool)
+    keep[torch.from_numpy(near)] = False
+    assert float((vn - ref_vn)[:, keep].abs().max()) < 5e-4
+    # landmark energy: the four (disable_jawline, always_enable) combinations of tracker.py:371-381
+    lmk2d = torch.from_numpy(G["lmk2d"])
+    out = _ref("out/")
+    for dis in (False, True):
+        for always in (True, False):
+            use_jaw = not (not always and dis)
+            e = float(R.landmark_energy(lmks, lmk2d, RT, K, (H, W), use_jawline=use_jaw))
+            want = out[f"lmk_{'nojaw' if dis else 'jaw'}_always{int(always)}"]
+            assert abs(e - want) <= 2e-5 * abs(want), (dis, always, e, want)
+    # every regulariser / smoothness term, both stage kinds
+    w = BaseTrackingConfig().w
+    for stage in STAGES:
+        log = energy_ref.regularization_energy(P, ts, w, stage, OPT, torch.from_numpy(G["tex_painted"]), torch.from_numpy(G["uvmask"]), v_cano,
+                                               torch.from_numpy(G["diffuse"]), topo, dt)
+        ref = _ref(f"out/reg/{stage}/")
+        assert set(log) == set(ref), (stage, sorted(log), sorted(ref))
+        for k, want in ref.items():
+            assert abs(float(log[k].detach()) - want) <= 1e-9 * abs(want) + 1e-15, (stage, k, float(log[k].detach()), want)
+    assert abs(float(energy_ref.joint_l2(P["neck_pose"][ts], P["jaw_pose"][ts], P["eyes_pose"][ts], w)) - out["joint_l2"]) < 1e-12
+
+
+def test_product_host_energies_match_reference(flame_model):
+    """The product's torch formulation of the same terms (FlameTracker on a CPU device, fp32) against the reference's numbers."""
+    from vhap_amd.config import BaseTrackingConfig
+    from vhap_amd.synthetic import make_texture
+    from vhap_amd.tracker import GlobalTracker
+    model, topo = flame_model
+    P, ts, (H, W) = _state(torch.float32)
+    N, Tt = P["expr"].shape[0], P["tex_extra"].shape[-1]
+    cfg = BaseTrackingConfig()
+    cfg.device = "cpu"
+    cfg.model.tex_resolution = Tt
+    tr = GlobalTracker(cfg, model, topo, make_texture(0, Tt), {"rgb": torch.zeros(N, 3, H, W), "lmk2d": torch.zeros(N, 70, 3)})
+    with torch.no_grad():
+        for k, v in P.items():
+            getattr(tr, k).copy_(v.reshape(getattr(tr, k).shape))
+    tr.opt_dict.update({k: True for k in OPT})
+    mask = torch.from_numpy(G["uvmask"]).float()
+    tr._uvmask_res = lambda: mask
+    assert torch.allclose(tr.flame_tex_painted(), torch.from_numpy(G["tex_painted"]).float(), atol=1e-6)
+    verts, v_cano, lmks, _ = tr.forward_flame(ts)
+    for stage in STAGES:
+        log = tr.compute_regularization_energy({"diffuse_detach_normal": torch.from_numpy(G["diffuse"]).float()}, verts, v_cano, lmks, None, ts,
+                                               stage)
+        ref = _ref(f"out/reg/{stage}/")
+        assert set(log) == set(ref), (stage, sorted(log), sorted(ref))
+        for k, want in ref.items():
+            assert abs(float(log[k].detach()) - want) <= 2e-4 * abs(want) + 1e-9, (stage, k, float(log[k].detach()), want)
+    sample = {"rgb": torch.zeros(len(ts), 3, H, W), "lmk2d": torch.from_numpy(G["lmk2d"]).float()}
+    tr.fill_cam_params_into_sample(sample)
+    out = _ref("out/")
+    for dis in (False, True):
+        for always in (True, False):
+            cfg.w.always_enable_jawline_landmarks = always
+            e = float(tr.compute_lmk_energy(sample, lmks, dis)[0])
+            want = out[f"lmk_{'nojaw' if dis else 'jaw'}_always{int(always)}"]
+            assert abs(e - want) <= 2e-4 * abs(want), (dis, always, e, want)
+
+
+def test_config_defaults_match_reference():
+    """Every default the product's config shares with the reference's BaseTrackingConfig() has the same value; the loss weights, the
+    learning rates and the stage lists must all be present."""
+    from vhap_amd.config import BaseTrackingConfig
+    cfg = BaseTrackingConfig()
+    missing, seen = [], 0
+    for key, val in zip(G["cfg_keys"], G["cfg_vals"]):
+        obj, ok = cfg, True
+        for part in key.split("."):
+            if not hasattr(obj, part):
+                ok = False
+                break
+            obj = getattr(obj, part)
+        if not ok:
+            missing.append(key)
+            continue
+        seen += 1
+        norm = lambda v: repr(tuple(v)) if isinstance(v, (list, tuple)) else repr(v)
+        if key == "render.backend":                         # the one intended difference: the drop-in switch itself
+            assert (obj, eval(val)) == ("hip", "nvdiffrast")
+            continue
+        assert norm(obj) == norm(eval(val, {"__builtins__": {}}, {})), (key, obj, val)
+    must = [k for k in missing if k.startswith(("w.", "lr.", "pipeline.", "render.")) or (k.startswith("model.") and k != "model.flame_params_path")]
+    assert not must, must
+    assert seen > 80, (seen, missing)

@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Golden vectors for the ENERGY terms of the hot path, produced by the REFERENCE's own code (runs only in the build container).
+
+Imported unmodified from /root/reference (third-party imports that are absent here -- tyro, tensorboard, torchvision, matplotlib,
+nvdiffrast -- are stubbed: none of them is touched by the functions called):
+  vhap/config/base.py   -> BaseTrackingConfig(): every default weight / stage list (pins vhap_amd.config field by field)
+  vhap/model/tracker.py -> FlameTracker.compute_lmk_energy (:347-389), compute_regularization_energy (:480-605) with its helpers
+                           compute_pose_smooth_energy / compute_joint_smooth_energy / compute_expr_smooth_energy /
+                           compute_joint_L2_energy / compute_laplacian_smoothing_loss / scale_vertex_weights_by_region (:607-690)
+  vhap/util/render_nvdiffrast.py -> NVDiffRenderer.world_to_clip / world_to_ndc / compute_v_normals / compute_face_normals
+The tracker methods are called on a FlameTracker created WITHOUT __init__ (it would need FLAME assets and a CUDA context) whose
+attributes are filled from the synthetic FLAME-topology model of this repo; what they compute from those attributes is the
+reference's arithmetic.  Inputs that come from parts of the reference which cannot run here are taken from the oracle restatement and
+stored alongside: canonical vertices (FLAME assets), the shaded `diffuse_detach_normal` image (nvdiffrast) and the uniform Laplacian
+(pytorch3d) -- so these vectors pin the energy formulas, not those three inputs.
+Output: tests/golden/energy_golden.npz (inputs + reference outputs, float64).
+"""
+import dataclasses
+import importlib.util
+import os
+import sys
+import types
+from collections import defaultdict
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+OUT = os.path.join(ROOT, "tests", "golden", "energy_golden.npz")
+sys.path.insert(0, ROOT)
+
+
+def load(path, name):
+    spec = importlib.util.spec_from_file_location(name, path)
+    m = importlib.util.module_from_spec(spec)
+    sys.modules[name] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+def stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def load_reference():
+    class _Any:
+        def __init__(self, *a, **k): pass
+        def __getattr__(self, k): return _Any()
+        def __call__(self, *a, **k): return _Any()
+    stub("tyro", cli=lambda *a, **k: None, to_yaml=lambda *a, **k: "", conf=_Any(), extras=_Any())
+    stub("nvdiffrast"); stub("nvdiffrast.torch")
+    stub("torchvision"); stub("torchvision.transforms"); stub("torchvision.transforms.functional")
+    stub("matplotlib", cm=_Any()); stub("matplotlib.cm")
+    stub("torch.utils.tensorboard", SummaryWriter=_Any)
+    for pkg, sub in (("vhap", ""), ("vhap.util", "/util"), ("vhap.config", "/config"), ("vhap.model", "/model")):
+        stub(pkg).__path__ = [f"{REF}/vhap{sub}"]            # real sub-modules load on demand; the stubs below take precedence
+    stub("vhap.util.log", get_logger=lambda name: _Any())
+    stub("vhap.util.visualization", plot_landmarks_2d=None)
+    stub("vhap.model.flame", FlameHead=_Any, FlameTexPCA=_Any, FlameTexPainted=_Any, FlameUvMask=_Any)
+    base = load(f"{REF}/vhap/config/base.py", "vhap.config.base")
+    load(f"{REF}/vhap/model/lbs.py", "vhap.model.lbs")
+    load(f"{REF}/vhap/util/mesh.py", "vhap.util.mesh")
+    sys.path.insert(0, REF)
+    rn = load(f"{REF}/vhap/util/render_nvdiffrast.py", "vhap.util.render_nvdiffrast")
+    tracker = load(f"{REF}/vhap/model/tracker.py", "ref_tracker")
+    return base, rn, tracker
+
+
+def config_to_dict(cfg, prefix=""):
+    out = {}
+    for f in dataclasses.fields(cfg):
+        v = getattr(cfg, f.name)
+        if dataclasses.is_dataclass(v):
+            out.update(config_to_dict(v, prefix + f.name + "."))
+        else:
+            out[prefix + f.name] = v
+    return out
+
+
+def main():
+    base, rn, T = load_reference()
+    from oracle import energy_ref, torch_ref as R
+    from vhap_amd.synthetic import make_flame_model, make_scene_params, make_texture, monocular_camera
+    dt = torch.float64
+    torch.manual_seed(0)
+    torch.Tensor.cuda = lambda self, *a, **k: self          # the reference moves helper tensors with .cuda(); there is no GPU here
+
+    # ---- 1. configuration defaults ------------------------------------------------------------------------------------------
+    import typing
+    from pathlib import Path
+
+    def default_instance(cls):           # the reference builds its config through tyro; here: defaults, sub-configs recursively
+        hints = typing.get_type_hints(cls)
+        kw = {}
+        for f in dataclasses.fields(cls):
+            if f.default is not dataclasses.MISSING or f.default_factory is not dataclasses.MISSING:
+                continue
+            t = hints[f.name]
+            kw[f.name] = default_instance(t) if dataclasses.is_dataclass(t) else (Path(".") if t is Path else "x")
+        return cls(**kw)
+    rcfg = default_instance(base.BaseTrackingConfig)
+    cfg_items = {k: v for k, v in config_to_dict(rcfg).items()
+                 if isinstance(v, (int, float, bool, str, type(None), list, tuple)) and not k.startswith(("data.root", "exp.", "data.sequence"))}
+
+    # ---- 2. a small state on the synthetic FLAME-topology model ----------------------------------------------------------------
+    model, topo = make_flame_model(0)
+    tm = {k: torch.from_numpy(np.asarray(v)) for k, v in model.items()}
+    for k in ("v_template", "shapedirs", "posedirs", "J_regressor", "lbs_weights", "lmk_bary_coords", "verts_uvs"):
+        tm[k] = tm[k].to(dt)
+    N, H, W, Tt = 4, 96, 80, 32
+    g = torch.Generator().manual_seed(3)
+    rnd = lambda *s, sc=1.0: torch.randn(*s, generator=g, dtype=dt) * sc
+    V = tm["v_template"].shape[0]
+    P = dict(shape=rnd(300, sc=0.3), expr=rnd(N, 100, sc=0.3), rotation=rnd(N, 3, sc=0.1), neck_pose=rnd(N, 3, sc=0.05),
+             jaw_pose=rnd(N, 3, sc=0.1), eyes_pose=rnd(N, 6, sc=0.1), translation=rnd(N, 3, sc=0.02), tex_extra=rnd(3, Tt, Tt, sc=0.05),
+             lights=rnd(9, 3, sc=0.1), static_offset=rnd(1, V, 3, sc=1e-3), focal_length=torch.tensor([2.3], dtype=dt))
+    P["translation"][:, 2] += 0.4
+    ts = np.array([1, 3, 0])                                   # includes timestep 0 (its 'previous' frame clamps to itself)
+    B = len(ts)
+    tex_painted = torch.from_numpy(make_texture(0, Tt)).to(dt)[None]
+    uvmask = (torch.rand(Tt, Tt, generator=g) < 0.3).to(dt)
+    lmk2d = torch.cat([torch.rand(B, 70, 2, generator=g, dtype=dt) * torch.tensor([W, H], dtype=dt), (torch.rand(B, 70, 1, generator=g) < 0.9).to(dt)], -1)
+    diffuse = torch.rand(B, 3, H, W, generator=g, dtype=dt) * 1.3      # stands in for result_dict['diffuse_detach_normal'] (nvdiffrast)
+    verts, v_cano, lmks = R.flame_forward(tm, P["shape"][None].expand(B, -1), P["expr"][ts], P["rotation"][ts], P["neck_pose"][ts],
+                                          P["jaw_pose"][ts], P["eyes_pose"][ts], P["translation"][ts], static_offset=P["static_offset"])
+    f = P["focal_length"] * max(H, W)
+    K = torch.stack([f, f, torch.full_like(f, 0.5 * W), torch.full_like(f, 0.5 * H)], dim=1)
+    RT = torch.eye(3, 4, dtype=dt); RT[2, 3] = -1
+    RT = RT[None].expand(B, -1, -1).contiguous()
+    Lap = energy_ref._laplacian(V, topo).to(dt)
+
+    # ---- 3. the reference's renderer helpers -------------------------------------------------------------------------------------
+    rend = rn.NVDiffRenderer.__new__(rn.NVDiffRenderer)
+    # (the reference builds its projection matrices in fp32: these helpers and the landmark energy run in fp32)
+    clip_ref = rend.world_to_clip(verts.float(), RT.float(), K.float(), (H, W)).double()
+    ndc_ref = rend.world_to_ndc(lmks.float(), RT.float(), K.float(), (H, W), flip_y=True).double()
+    real_tensor = torch.tensor
+    rn.torch = types.SimpleNamespace(**{k: getattr(torch, k) for k in dir(torch) if not k.startswith("__")})
+    rn.torch.tensor = lambda *a, **k: real_tensor(*a, **{kk: vv for kk, vv in k.items() if kk != "device"})     # the reference hard-codes device='cuda'
+    faces = tm["faces"].long()
+    # collapse a vertex and its two-ring to one point: the vertex and its one-ring then have only degenerate faces -> the (0,0,1) fallback
+    fnp = tm["faces"].numpy()
+    ring = {100}
+    for _ in range(2):
+        ring |= set(fnp[np.isin(fnp, list(ring)).any(1)].ravel().tolist())
+    collapse = np.array(sorted(ring))
+    vflat = verts.clone(); vflat[0, collapse] = 0
+    vn_ref = rend.compute_v_normals(vflat.float(), faces).double()
+    fn_ref = rend.compute_face_normals(verts.float(), faces).double()
+    rn.torch = torch
+
+    # ---- 4. the reference's tracker energies on a tracker object without __init__ ----------------------------------------------------
+    tr = object.__new__(T.FlameTracker)
+    tr.cfg, tr.device = rcfg, "cpu"
+    tr.render = rend
+    tr.opt_dict = defaultdict(bool, {k: True for k in ("pose", "joints", "expr", "shape", "texture", "lights", "static_offset")})
+    tr.n_timesteps = N
+    for k in ("shape", "expr", "rotation", "neck_pose", "jaw_pose", "eyes_pose", "translation", "tex_extra", "lights", "static_offset"):
+        setattr(tr, k, P[k])
+    tr.dynamic_offset = None
+    tr.lights_uniform = torch.zeros(9, 3, dtype=dt)
+    tr.get_albedo = lambda: tex_painted + P["tex_extra"][None]
+    vid = lambda regions: torch.from_numpy(topo.get_vid_by_region(list(regions))).long()
+    tr.flame = types.SimpleNamespace(mask=types.SimpleNamespace(get_vid_by_region=vid), laplacian_matrix=Lap,
+                                     laplacian_matrix_negate_diag=Lap - 2 * torch.diag(torch.diag(Lap)))
+    tr.flame_uvmask = types.SimpleNamespace(get_uvmask_by_region=lambda regions: uvmask)
+    sample = {"rgb": torch.zeros(B, 3, H, W, dtype=dt), "lmk2d": lmk2d, "intrinsic": K, "extrinsic": RT}
+    out = {}
+    for tag, dis in (("jaw", False), ("nojaw", True)):
+        for always in (True, False):
+            rcfg.w.always_enable_jawline_landmarks = always
+            e, rd = tr.compute_lmk_energy({k: v.float() for k, v in sample.items()}, lmks.float(), disable_jawline_landmarks=dis)
+            out[f"lmk_{tag}_always{int(always)}"] = e
+    rcfg.w.always_enable_jawline_landmarks = True
+    for stage in ("rgb_init_offset", "rgb_global_tracking"):
+        log = tr.compute_regularization_energy({"diffuse_detach_normal": diffuse}, verts, v_cano, lmks, None, ts, stage)
+        for k, v in log.items():
+            out[f"reg/{stage}/{k}"] = v
+    out["joint_l2"] = tr.compute_joint_L2_energy(ts)
+
+    save = {f"P/{k}": v.numpy() for k, v in P.items()}
+    save.update(ts=ts, tex_painted=tex_painted.numpy(), uvmask=uvmask.numpy(), lmk2d=lmk2d.numpy(), diffuse=diffuse.numpy(),
+                image_size=np.array([H, W]), collapse=collapse,
+                clip_ref=clip_ref.numpy(), ndc_ref=ndc_ref.numpy(), vn_ref=vn_ref.numpy(), fn_ref=fn_ref.numpy())
+    save.update({f"out/{k}": np.asarray(float(v)) for k, v in out.items()})
+    save["cfg_keys"] = np.array(sorted(cfg_items), dtype=object)
+    save["cfg_vals"] = np.array([repr(cfg_items[k]) for k in sorted(cfg_items)], dtype=object)
+    np.savez_compressed(OUT, **save)
+    print("wrote", os.path.abspath(OUT), os.path.getsize(OUT), "bytes;", len(out), "energy values;", len(cfg_items), "config defaults")
+    for k, v in out.items():
+        print(f"  {k:45s} {float(v):.10g}")
+
+
+if __name__ == "__main__":
+    main()
