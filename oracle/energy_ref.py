@@ -2,8 +2,9 @@
 restatements in torch_ref.py -- TEST INFRASTRUCTURE ONLY.  Used to check the product's
 FlameTracker.compute_energy (value and gradients w.r.t. every parameter) end to end.
 Pinned: the landmark energy and every regulariser / smoothness term against the reference's own FlameTracker methods
-(tests/golden/energy_golden.npz, tests/test_energy_golden.py); the photometric term goes through the raster ops, whose parity is
-"unpinned" (DESIGN.md section 1)."""
+(tests/golden/energy_golden.npz, tests/test_energy_golden.py); the photometric term is pinned AROUND the four raster ops (the
+reference's compute_photometric_energy / render_rgba chain run with the oracle's ops inside); the ops' internals are "parity unpinned"
+(DESIGN.md section 1)."""
 import numpy as np
 import torch
 import torch.nn.functional as F

@@ -148,3 +148,57 @@ def test_config_defaults_match_reference():
     must = [k for k in missing if k.startswith(("w.", "lr.", "pipeline.", "render.")) or (k.startswith("model.") and k != "model.flame_params_path")]
     assert not must, must
     assert seen > 80, (seen, missing)
+
+
+def test_oracle_photometric_energy_matches_reference_around_the_raster_ops(flame_model):
+    """The reference's compute_photometric_energy -> render_rgba chain, run in the build container with only the four nvdiffrast ops
+    replaced by the oracle's restatements, against the oracle's own render_rgba + photometric_energy on the same visibility: pins the
+    camera chain, normals, region detach, SH shading, compositing and flips, the colour disturbance (the reference's random draws are
+    replayed through the oracle's injected-randomness interface), boundary detach and the loss normalisation -- values and gradients.
+    The reference runs this in fp32, the oracle here in fp64: 2e-5 on values, 2e-3 of the max-norm on gradients."""
+    from vhap_amd.config import BaseTrackingConfig
+    model, topo = flame_model
+    dt = torch.float64
+    tm = {k: torch.from_numpy(np.asarray(v)) for k, v in model.items()}
+    for k in ("v_template", "verts_uvs"):
+        tm[k] = tm[k].to(dt)
+    faces, faces_uv = tm["faces"].long(), tm["faces_uv"].long()
+    pin = {k[len("photo_in/"):]: torch.from_numpy(G[k]) for k in G.files if k.startswith("photo_in/")}
+    pout = {k[len("photo_out/"):]: G[k] for k in G.files if k.startswith("photo_out/")}
+    B, _, H, W = pin["rgb"].shape
+    tid = torch.from_numpy(pout["tid"].astype(np.int64))
+    uv = tm["verts_uvs"].clone()
+    uv[:, 1] = 1 - uv[:, 1]
+    opp = torch.from_numpy(topo.opp.astype(np.int64))
+    cfg = BaseTrackingConfig()
+    fid2cid = torch.from_numpy(topo.fid2cid.astype(np.int64))
+    for tag, stage in (("eval", None), ("rgb_global_tracking", "rgb_global_tracking")):
+        verts = pin["verts"].to(dt).requires_grad_()
+        tex_extra = pin["tex_extra"].to(dt).requires_grad_()
+        lights = pin["lights"].to(dt).requires_grad_()
+        K, RT = pin["K"].to(dt), pin["RT"].to(dt)
+        clip = R.camera_to_clip(R.world_to_camera(verts, RT), K, (H, W))
+        rast, db = R.rast_from_ids(clip, faces, tid, (H, W))
+        tex = (pin["tex_painted"].to(dt)[None] + tex_extra[None]).permute(0, 2, 3, 1)
+        tmask = amask = disturb = None
+        if stage is not None:
+            st = cfg.pipeline[stage]
+            tmask = torch.zeros(faces.shape[0] + 1, dtype=torch.bool)
+            tmask[torch.from_numpy(topo.get_fid_by_region(list(st.align_texture_except))) + 1] = True
+            amask = torch.from_numpy(topo.get_vid_by_region(list(st.align_boundary_except)))
+            disturb = dict(w_fg=torch.from_numpy(pout["disturb/w_fg"]), w_bg=torch.from_numpy(pout["disturb/w_bg"]), fid2cid=fid2cid,
+                           idx=[torch.from_numpy(r.astype(np.int64)) for r in pout["disturb/idx"]])
+        gt = pin["rgb"].to(dt)
+        out = R.render_rgba(rast, db, verts, clip, faces, uv, faces_uv, tex, lights[None], gt.permute(0, 2, 3, 1), opp, R.sh_const(dt),
+                            tex_detach_mask=tmask, aa_detach_vid=amask, disturb=disturb)
+        E = R.photometric_energy(gt, out["rgba"])
+        E.backward()
+        want = float(pout[f"{tag}/E"])
+        assert abs(float(E) - want) <= 2e-5 * abs(want), (tag, float(E), want)
+        assert float((out["rgba"].permute(0, 3, 1, 2).detach() - torch.from_numpy(pout[f"{tag}/rgba"])).abs().max()) < 2e-5
+        ddn = out["diffuse_detach_normal"].permute(0, 3, 1, 2).detach()
+        assert float((ddn - torch.from_numpy(pout[f"{tag}/diffuse_detach_normal"])).abs().max()) < 2e-5
+        for name, g in (("d_verts", verts.grad), ("d_tex_extra", tex_extra.grad), ("d_lights", lights.grad)):
+            ref = torch.from_numpy(pout[f"{tag}/{name}"]).to(dt)
+            err = float((g - ref).abs().max() / ref.abs().max())
+            assert err < 2e-3, (tag, name, err)

@@ -182,7 +182,90 @@ def main():
             out[f"reg/{stage}/{k}"] = v
     out["joint_l2"] = tr.compute_joint_L2_energy(ts)
 
+    # ---- 5. the photometric energy: compute_photometric_energy (:391-478) -> FlameTracker.render_rgba (:305-335) -> NVDiffRenderer.rasterize /
+    #         render_rgba (render_nvdiffrast.py:216-245, 354-484), with ONLY the four nvdiffrast ops replaced by the oracle's restatements.
+    #         Pins everything around the ops: camera chain, normals, region detach, SH shading, compositing / flips, the colour disturbance
+    #         (random draws replayed below), boundary detach, the loss normalisation -- values and gradients.
+    import oracle
+    dr = sys.modules["nvdiffrast.torch"]
+    B2, H2, W2, T2 = 2, 64, 56, 32
+    faces_l, faces_uv_l = tm["faces"].long(), tm["faces_uv"].long()
+    opp = torch.from_numpy(topo.opp.astype(np.int64))
+    stash = {}
+
+    def dr_rasterize(glctx, clip, tri, size):
+        rast_np, _ = oracle.rasterize(clip.detach().float().numpy(), tri.numpy().astype(np.int32), tuple(size))
+        stash["tid"] = torch.from_numpy(rast_np[..., 3].astype(np.int64) - 1)
+        return R.rast_from_ids(clip, tri.long(), stash["tid"], tuple(size))
+    dr.rasterize = dr_rasterize
+    dr.interpolate = lambda attr, rast, tri, rast_db=None, diff_attrs=None: R.interpolate(attr, rast, tri.long(), rast_db, diff_attrs)
+    dr.texture = lambda tex, uv, uv_da=None, filter_mode="linear", max_mip_level=None: R.texture(tex, uv, uv_da, filter_mode)
+    dr.antialias = lambda color, rast, pos, tri: R.antialias(color, rast, pos, tri.long(), opp)
+    dr.RasterizeCudaContext = lambda: None
+    rn.torch = types.SimpleNamespace(**{k: getattr(torch, k) for k in dir(torch) if not k.startswith("__")})
+    rn.torch.tensor = lambda *a, **k: real_tensor(*a, **{kk: vv for kk, vv in k.items() if kk != "device"})
+    rend2 = rn.NVDiffRenderer(use_opengl=False, lighting_type="SH", lighting_space="world", disturb_rate_fg=0.5, disturb_rate_bg=0.5,
+                              fid2cid=torch.from_numpy(topo.fid2cid[1:].astype(np.int64)))
+    f32 = torch.float32
+    sp = make_scene_params(B2, 5, (H2, W2))
+    q = lambda k: torch.from_numpy(sp[k]).to(dt)
+    v2, _, _ = R.flame_forward(tm, q("shape")[None].expand(B2, -1), q("expr"), q("rotation"), q("neck_pose"), q("jaw_pose"), q("eyes_pose"),
+                               q("translation"))
+    K2n, RT2n = monocular_camera(B2, (H2, W2))
+    photo_in = dict(verts=v2.to(f32).numpy(), K=K2n[:1].astype(np.float32),      # [1,4] like fill_cam_params_into_sample (tracker.py:150-156)
+                     RT=RT2n.astype(np.float32),
+                    tex_painted=make_texture(1, T2).astype(np.float32), tex_extra=(rnd(3, T2, T2, sc=0.05)).to(f32).numpy(),
+                    lights=(rnd(9, 3, sc=0.1) + torch.tensor([[3.5, 3.5, 3.5]] + [[0.0] * 3] * 8, dtype=dt)).to(f32).numpy(),
+                    rgb=torch.rand(B2, 3, H2, W2, generator=g).to(f32).numpy())
+    tr2 = object.__new__(T.FlameTracker)
+    tr2.cfg, tr2.device, tr2.render, tr2.image_size = rcfg, "cpu", rend2, (H2, W2)
+    fid = lambda regions: torch.from_numpy(topo.get_fid_by_region(list(regions))).long()
+    tr2.flame = types.SimpleNamespace(mask=types.SimpleNamespace(get_vid_by_region=vid, get_fid_by_region=fid), textures_idx=faces_uv_l,
+                                      verts_uvs=tm["verts_uvs"].to(f32))
+    photo_out = {}
+    for stage, seed in ((None, None), ("rgb_global_tracking", 1234)):
+        verts_l = torch.from_numpy(photo_in["verts"]).requires_grad_()
+        tex_l = torch.from_numpy(photo_in["tex_extra"]).requires_grad_()
+        lights_l = torch.from_numpy(photo_in["lights"]).requires_grad_()
+        tr2.lights = lights_l
+        albedos = (torch.from_numpy(photo_in["tex_painted"])[None] + tex_l[None]).expand(B2, -1, -1, -1)
+        sample2 = {"rgb": torch.from_numpy(photo_in["rgb"]), "intrinsic": torch.from_numpy(photo_in["K"]), "extrinsic": torch.from_numpy(photo_in["RT"])}
+        rend2.clear_cache()
+        rast_dict = tr2.rasterize_flame(sample2, verts_l, faces_l, train_mode=True)
+        if seed is not None:
+            torch.manual_seed(seed)
+        E, rd = tr2.compute_photometric_energy(sample2, verts_l, faces_l, albedos, rast_dict, None, stage)
+        E.backward()
+        tag = "eval" if stage is None else stage
+        photo_out[f"{tag}/E"] = E.detach().double().numpy()
+        photo_out[f"{tag}/rgba"] = rd["rgba"].detach().numpy()
+        photo_out[f"{tag}/d_verts"] = verts_l.grad.numpy()
+        photo_out[f"{tag}/d_tex_extra"] = tex_l.grad.numpy()
+        photo_out[f"{tag}/d_lights"] = lights_l.grad.numpy()
+        photo_out[f"{tag}/diffuse_detach_normal"] = rd["diffuse_detach_normal"].detach().numpy()
+        if seed is not None:
+            # replay the reference's draws (render_nvdiffrast.py:428-457) for the oracle's injected-randomness interface
+            torch.manual_seed(seed)
+            like = torch.zeros(B2, H2, W2, 1, dtype=f32)
+            w_fg = (torch.rand_like(like) < 0.5).int()
+            w_bg = (torch.rand_like(like) < 0.5).int()
+            cid = rend2.fid2cid[(stash["tid"] + 1)]
+            ncl = int(rend2.fid2cid.max()) + 1
+            idx = np.zeros((ncl, B2 * H2 * W2), np.int32)
+            for i in range(ncl):
+                n_i = int((cid == i).sum())
+                if i != 1 and n_i > 0:
+                    idx[i] = torch.randint(0, n_i, (B2 * H2 * W2,)).numpy()
+            photo_out["disturb/w_fg"], photo_out["disturb/w_bg"], photo_out["disturb/idx"] = w_fg.numpy(), w_bg.numpy(), idx
+        photo_out["tid"] = stash["tid"].numpy().astype(np.int32)
+    rn.torch = torch
+    for k, v in photo_out.items():
+        if k.endswith("/E"):
+            print(f"  photo {k:40s} {float(v):.10g}")
+
     save = {f"P/{k}": v.numpy() for k, v in P.items()}
+    save.update({f"photo_in/{k}": v for k, v in photo_in.items()})
+    save.update({f"photo_out/{k}": v for k, v in photo_out.items()})
     save.update(ts=ts, tex_painted=tex_painted.numpy(), uvmask=uvmask.numpy(), lmk2d=lmk2d.numpy(), diffuse=diffuse.numpy(),
                 image_size=np.array([H, W]), collapse=collapse,
                 clip_ref=clip_ref.numpy(), ndc_ref=ndc_ref.numpy(), vn_ref=vn_ref.numpy(), fn_ref=fn_ref.numpy())
