@@ -118,7 +118,7 @@ def test_product_host_energies_match_reference(flame_model):
     for dis in (False, True):
         for always in (True, False):
             cfg.w.always_enable_jawline_landmarks = always
-            e = float(tr.compute_lmk_energy(sample, lmks, dis)[0])
+            e = float(tr.compute_lmk_energy(sample, lmks, dis)[0].detach())
             want = out[f"lmk_{'nojaw' if dis else 'jaw'}_always{int(always)}"]
             assert abs(e - want) <= 2e-4 * abs(want), (dis, always, e, want)
 
@@ -202,3 +202,43 @@ def test_oracle_photometric_energy_matches_reference_around_the_raster_ops(flame
             ref = torch.from_numpy(pout[f"{tag}/{name}"]).to(dt)
             err = float((g - ref).abs().max() / ref.abs().max())
             assert err < 2e-3, (tag, name, err)
+
+
+def test_flame_forward_and_region_tables_match_reference(flame_model):
+    """FlameHead.forward (flame.py:571-646, with static AND dynamic offsets) and the FlameMask derivations (flame.py:940-1033: vertex regions
+    -> face regions, fid2cid with later clusters overwriting earlier ones, region look-ups of the stage configs), computed by the
+    reference's own methods on the synthetic model / regions, against the oracle (fp64) and the product (FlameHead fp32, Topology)."""
+    from vhap_amd.config import BaseTrackingConfig
+    from vhap_amd.flame import FlameHead
+    model, topo = flame_model
+    dt = torch.float64
+    P, ts, _ = _state(dt)
+    tm = {k: torch.from_numpy(np.asarray(v)) for k, v in model.items()}
+    for k in ("v_template", "shapedirs", "posedirs", "J_regressor", "lbs_weights", "lmk_bary_coords", "verts_uvs"):
+        tm[k] = tm[k].to(dt)
+    B = len(ts)
+    dyn = torch.from_numpy(G["flame/dynamic_offset"]).to(dt)
+    pick = torch.from_numpy(G["flame/pick"])
+    args = (P["shape"][None].expand(B, -1), P["expr"][ts], P["rotation"][ts], P["neck_pose"][ts], P["jaw_pose"][ts], P["eyes_pose"][ts],
+            P["translation"][ts])
+    verts, cano, lmks = R.flame_forward(tm, *args, static_offset=P["static_offset"], dynamic_offset=dyn)
+    for got, key in ((verts[:, pick], "verts"), (cano[:, pick], "verts_cano"), (lmks, "lmks")):
+        assert float((got - torch.from_numpy(G[f"flame/{key}"])).abs().max()) < 1e-12, key
+    head = FlameHead(model, topo)                                # the product's module, fp32, CPU
+    v32, c32, l32 = head(*[a.float() for a in args], return_verts_cano=True, static_offset=P["static_offset"].float(), dynamic_offset=dyn.float())
+    for got, key in ((v32[:, pick], "verts"), (c32[:, pick], "verts_cano"), (l32, "lmks")):
+        assert float((got.double() - torch.from_numpy(G[f"flame/{key}"])).abs().max()) < 5e-6, key
+    # region tables
+    names = list(G["mask/f_names"])
+    assert sorted(topo.f_regions) == sorted(names)
+    for k in names:
+        assert np.array_equal(np.sort(topo.f_regions[k]), np.sort(G[f"mask/f/{k}"])), k
+    # the reference's table has F + 1 entries indexed by the UNSHIFTED face id (the last one is never addressed); NVDiffRenderer.__init__ pads a
+    # leading 0 for "no face" (render_nvdiffrast.py:78) -- the product stores that padded form
+    F_ = topo.num_faces
+    assert G["mask/fid2cid"].shape[0] == F_ + 1 and np.array_equal(topo.fid2cid[1:], G["mask/fid2cid"][:F_]) and topo.fid2cid[0] == 0
+    cfg = BaseTrackingConfig()
+    for stage in ("rgb_init_texture", "rgb_init_all", "rgb_global_tracking"):
+        st = cfg.pipeline[stage]
+        assert np.array_equal(topo.get_fid_by_region(list(st.align_texture_except)), G[f"mask/fid/{stage}"]), stage
+        assert np.array_equal(topo.get_vid_by_region(list(st.align_boundary_except)), G[f"mask/vid/{stage}"]), stage

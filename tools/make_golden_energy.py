@@ -7,7 +7,10 @@ nvdiffrast -- are stubbed: none of them is touched by the functions called):
   vhap/model/tracker.py -> FlameTracker.compute_lmk_energy (:347-389), compute_regularization_energy (:480-605) with its helpers
                            compute_pose_smooth_energy / compute_joint_smooth_energy / compute_expr_smooth_energy /
                            compute_joint_L2_energy / compute_laplacian_smoothing_loss / scale_vertex_weights_by_region (:607-690)
-  vhap/util/render_nvdiffrast.py -> NVDiffRenderer.world_to_clip / world_to_ndc / compute_v_normals / compute_face_normals
+  vhap/util/render_nvdiffrast.py -> NVDiffRenderer.world_to_clip / world_to_ndc / compute_v_normals / compute_face_normals; rasterize /
+                           render_rgba with the four nvdiffrast ops replaced by the oracle's (section 5 below)
+  vhap/model/flame.py   -> FlameHead.forward (:571-646) and FlameMask.construct_vid_table / process_face_mask / process_face_clusters /
+                           get_vid_by_region / get_fid_by_region (:940-1033), on objects created without __init__
 The tracker methods are called on a FlameTracker created WITHOUT __init__ (it would need FLAME assets and a CUDA context) whose
 attributes are filled from the synthetic FLAME-topology model of this repo; what they compute from those attributes is the
 reference's arithmetic.  Inputs that come from parts of the reference which cannot run here are taken from the oracle restatement and
@@ -60,14 +63,15 @@ def load_reference():
         stub(pkg).__path__ = [f"{REF}/vhap{sub}"]            # real sub-modules load on demand; the stubs below take precedence
     stub("vhap.util.log", get_logger=lambda name: _Any())
     stub("vhap.util.visualization", plot_landmarks_2d=None)
-    stub("vhap.model.flame", FlameHead=_Any, FlameTexPCA=_Any, FlameTexPainted=_Any, FlameUvMask=_Any)
+    stub("pytorch3d"); stub("pytorch3d.io", load_obj=None); stub("pytorch3d.structures"); stub("pytorch3d.structures.meshes", Meshes=_Any)
     base = load(f"{REF}/vhap/config/base.py", "vhap.config.base")
     load(f"{REF}/vhap/model/lbs.py", "vhap.model.lbs")
     load(f"{REF}/vhap/util/mesh.py", "vhap.util.mesh")
+    flame = load(f"{REF}/vhap/model/flame.py", "vhap.model.flame")
     sys.path.insert(0, REF)
     rn = load(f"{REF}/vhap/util/render_nvdiffrast.py", "vhap.util.render_nvdiffrast")
     tracker = load(f"{REF}/vhap/model/tracker.py", "ref_tracker")
-    return base, rn, tracker
+    return base, rn, tracker, flame
 
 
 def config_to_dict(cfg, prefix=""):
@@ -82,7 +86,7 @@ def config_to_dict(cfg, prefix=""):
 
 
 def main():
-    base, rn, T = load_reference()
+    base, rn, T, FL = load_reference()
     from oracle import energy_ref, torch_ref as R
     from vhap_amd.synthetic import make_flame_model, make_scene_params, make_texture, monocular_camera
     dt = torch.float64
@@ -263,7 +267,46 @@ def main():
         if k.endswith("/E"):
             print(f"  photo {k:40s} {float(v):.10g}")
 
+    # ---- 6. FlameHead.forward (flame.py:571-646) on an object without __init__ carrying the synthetic model's buffers ---------------------
+    fh = object.__new__(FL.FlameHead)
+    torch.nn.Module.__init__(fh)
+    fh.dtype = dt
+    for k in ("v_template", "shapedirs", "posedirs", "J_regressor", "lbs_weights"):
+        fh.register_buffer(k, tm[k])
+    fh.register_buffer("parents", tm["parents"].long())
+    fh.register_buffer("faces", tm["faces"].long())
+    fh.register_buffer("full_lmk_faces_idx", tm["lmk_faces_idx"].long()[None])
+    fh.register_buffer("full_lmk_bary_coords", tm["lmk_bary_coords"][None])
+    dyn = rnd(B, V, 3, sc=5e-4).float().double()               # (stored as fp32)
+    fv, fcano, flm = FL.FlameHead.forward(fh, P["shape"][None].expand(B, -1), P["expr"][ts], P["rotation"][ts], P["neck_pose"][ts], P["jaw_pose"][ts],
+                                           P["eyes_pose"][ts], P["translation"][ts], return_verts_cano=True,
+                                           static_offset=P["static_offset"], dynamic_offset=dyn)
+    pick = np.sort(np.random.default_rng(0).choice(V, 600, replace=False))     # a vertex subset keeps the fixture small
+    flame_out = dict(dynamic_offset=dyn.float().numpy(), pick=pick, verts=fv[:, pick].numpy(), verts_cano=fcano[:, pick].numpy(), lmks=flm.numpy())
+
+    # ---- 7. FlameMask (flame.py:940-1040): vertex regions -> face regions, fid2cid, region look-ups, on the synthetic topology's regions -----
+    fm = object.__new__(FL.FlameMask)
+    torch.nn.Module.__init__(fm)
+    fm.num_verts, fm.num_faces = topo.num_verts, topo.num_faces
+    fm.v = FL.BufferContainer()
+    for name, vids in topo.v_regions.items():
+        fm.v.register_buffer(name, torch.from_numpy(np.asarray(vids)).long())
+    fm.construct_vid_table()
+    fm.process_face_mask(torch.from_numpy(topo.faces.astype(np.int64)))
+    fm.process_face_clusters(list(topo.tex_clusters))
+    mask_out = {"fid2cid": fm.fid2cid.numpy()}
+    names = sorted(k for k, _ in fm.f)
+    mask_out["f_names"] = np.array(names, dtype=object)
+    for k in names:
+        mask_out[f"f/{k}"] = fm.f.get_buffer(k).numpy()
+    for stage_name in ("rgb_init_texture", "rgb_init_all", "rgb_global_tracking"):
+        st = rcfg.pipeline[stage_name]
+        mask_out[f"fid/{stage_name}"] = fm.get_fid_by_region(list(st.align_texture_except)).numpy()
+        mask_out[f"vid/{stage_name}"] = fm.get_vid_by_region(list(st.align_boundary_except)).numpy()
+
     save = {f"P/{k}": v.numpy() for k, v in P.items()}
+    save.update({f"flame/{k}": v for k, v in flame_out.items()})
+    save.update({f"mask/{k}": v for k, v in mask_out.items()})
     save.update({f"photo_in/{k}": v for k, v in photo_in.items()})
     save.update({f"photo_out/{k}": v for k, v in photo_out.items()})
     save.update(ts=ts, tex_painted=tex_painted.numpy(), uvmask=uvmask.numpy(), lmk2d=lmk2d.numpy(), diffuse=diffuse.numpy(),
