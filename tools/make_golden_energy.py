@@ -304,7 +304,34 @@ def main():
         mask_out[f"fid/{stage_name}"] = fm.get_fid_by_region(list(st.align_texture_except)).numpy()
         mask_out[f"vid/{stage_name}"] = fm.get_vid_by_region(list(st.align_boundary_except)).numpy()
 
+    # ---- 8. host logic of GlobalTracker: which tensors a stage trains (get_train_parameters :1465-1513), the Adam parameter groups and
+    #         learning rates (configure_optimizer :159-211), seeding the next timesteps (initialize_next_timtestep :1515-1529) -------------
+    import json
+    tr3 = object.__new__(T.GlobalTracker)
+    tr3.cfg, tr3.calibrated, tr3.n_timesteps = rcfg, False, 9
+    pnames = ("focal_length", "shape", "tex_pca", "tex_extra", "static_offset", "lights", "translation", "rotation", "eyes_pose", "neck_pose",
+              "jaw_pose", "expr", "dynamic_offset")
+    for i, k in enumerate(pnames):
+        setattr(tr3, k, torch.full((9, 3), float(i), requires_grad=True))
+    name_of = lambda t: next(k for k in pnames if getattr(tr3, k) is t)
+    host = {}
+    for stage_name in rcfg.pipeline.__dict__:
+        params = tr3.get_train_parameters(stage_name)
+        opt = tr3.configure_optimizer(params, lr_scale=0.5)
+        host[stage_name] = {"params": {k: [name_of(t) for t in v] for k, v in params.items() if len(v)},
+                            "groups": [[sorted(name_of(t) for t in gr["params"]), gr["lr"]] for gr in opt.param_groups],
+                            "opt_dict": sorted(k for k, v in tr3.opt_dict.items() if v)}
+    g3 = torch.Generator().manual_seed(9)
+    for k in ("translation", "rotation", "neck_pose", "jaw_pose", "eyes_pose", "expr", "dynamic_offset"):
+        setattr(tr3, k, torch.randn(9, 4, generator=g3, dtype=dt))
+    before = {k: getattr(tr3, k).clone().numpy() for k in ("translation", "rotation", "neck_pose", "jaw_pose", "eyes_pose", "expr")}
+    tr3.initialize_next_timtestep(torch.tensor([2, 3, 4]))
+    after = {k: getattr(tr3, k).numpy() for k in before}
+
     save = {f"P/{k}": v.numpy() for k, v in P.items()}
+    save["host/json"] = np.array(json.dumps(host))
+    save.update({f"host/before/{k}": v for k, v in before.items()})
+    save.update({f"host/after/{k}": v for k, v in after.items()})
     save.update({f"flame/{k}": v for k, v in flame_out.items()})
     save.update({f"mask/{k}": v for k, v in mask_out.items()})
     save.update({f"photo_in/{k}": v for k, v in photo_in.items()})
