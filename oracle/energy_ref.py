@@ -84,8 +84,9 @@ def regularization_energy(P, ts, w, stage, opt, tex_painted, uvmask_res, v_cano,
 
 
 def total_energy(P, model, topo, cfg, sample, stage, tex_painted, uvmask_res, image_size, dtype=torch.float64,
-                 disturb=None):
+                 disturb=None, tid=None):
     """P: dict of parameter tensors (leaf, requires_grad) named like the GlobalTracker attributes.
+    `tid`: optional [B,H,W] triangle ids (-1 = none) to use instead of rasterising (golden-vector comparisons fix the visibility).
     Returns (E_total, log_dict, extras)."""
     H, W = image_size
     ts = np.asarray(sample["timestep_index"])
@@ -115,8 +116,9 @@ def total_energy(P, model, topo, cfg, sample, stage, tex_painted, uvmask_res, im
     if stage is None or isinstance(st, PhotometricStageConfig):
         faces = tm["faces"]
         clip = R.camera_to_clip(R.world_to_camera(verts, RT), K, image_size)
-        rast_np, _ = oracle.rasterize(clip.detach().float().numpy(), topo.faces.astype(np.int32), image_size)
-        tid = torch.from_numpy(rast_np[..., 3].astype(np.int64) - 1)
+        if tid is None:
+            rast_np, _ = oracle.rasterize(clip.detach().float().numpy(), topo.faces.astype(np.int32), image_size)
+            tid = torch.from_numpy(rast_np[..., 3].astype(np.int64) - 1)
         rast, db = R.rast_from_ids(clip, faces, tid, image_size)
         tex = (tex_painted + P["tex_extra"][None]).permute(0, 2, 3, 1)
         uv = tm["verts_uvs"].clone()

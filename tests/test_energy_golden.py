@@ -49,13 +49,13 @@ def test_oracle_energies_match_reference(flame_model):
                                           P["jaw_pose"][ts], P["eyes_pose"][ts], P["translation"][ts], static_offset=P["static_offset"])
     K, RT = _camera(P, B, H, W, dt)
     # camera chain and normals (the reference computes these in fp32)
-    assert float((R.world_to_clip(verts, RT, K, (H, W)) - torch.from_numpy(G["clip_ref"])).abs().max()) < 2e-5
+    assert float((R.world_to_clip(verts, RT, K, (H, W)) - torch.from_numpy(G["clip_ref"]).double()).abs().max()) < 2e-5
     assert float((R.world_to_ndc(lmks, RT, K, (H, W), flip_y=True) - torch.from_numpy(G["ndc_ref"])).abs().max()) < 2e-5
     faces = tm["faces"].long()
     vflat = verts.clone()
     vflat[0, torch.from_numpy(G["collapse"])] = 0            # a collapsed two-ring: zero normals -> the (0, 0, 1) fallback of the reference
     vn = R.compute_v_normals(vflat, faces)
-    ref_vn = torch.from_numpy(G["vn_ref"])
+    ref_vn = torch.from_numpy(G["vn_ref"]).double()
     fallback = (ref_vn == torch.tensor([0.0, 0.0, 1.0], dtype=dt)).all(-1)
     assert int(fallback.sum()) >= 5 and torch.equal(vn[fallback], ref_vn[fallback])
     # (vertices touching the collapsed patch sum near-cancelling sliver normals: ill-conditioned in fp32, excluded)
@@ -64,6 +64,8 @@ def test_oracle_energies_match_reference(flame_model):
     keep = torch.ones(vn.shape[1], dtype=torch.bool)
     keep[torch.from_numpy(near)] = False
     assert float((vn - ref_vn)[:, keep].abs().max()) < 5e-4
+    fn = R.safe_normalize(torch.cross(verts[:, faces[:, 1]] - verts[:, faces[:, 0]], verts[:, faces[:, 2]] - verts[:, faces[:, 0]], dim=-1))
+    assert float((fn[:, :500] - torch.from_numpy(G["fn_ref"]).double()).abs().max()) < 5e-4       # compute_face_normals (:318-330)
     # landmark energy: the four (disable_jawline, always_enable) combinations of tracker.py:371-381
     lmk2d = torch.from_numpy(G["lmk2d"])
     out = _ref("out/")
@@ -76,8 +78,8 @@ def test_oracle_energies_match_reference(flame_model):
     # every regulariser / smoothness term, both stage kinds
     w = BaseTrackingConfig().w
     for stage in STAGES:
-        log = energy_ref.regularization_energy(P, ts, w, stage, OPT, torch.from_numpy(G["tex_painted"]), torch.from_numpy(G["uvmask"]), v_cano,
-                                               torch.from_numpy(G["diffuse"]), topo, dt)
+        log = energy_ref.regularization_energy(P, ts, w, stage, OPT, torch.from_numpy(G["tex_painted"]), torch.from_numpy(G["uvmask"]).to(dt), v_cano,
+                                               torch.from_numpy(G["diffuse"]).to(dt), topo, dt)
         ref = _ref(f"out/reg/{stage}/")
         assert set(log) == set(ref), (stage, sorted(log), sorted(ref))
         for k, want in ref.items():
@@ -283,3 +285,47 @@ def test_tracker_host_logic_matches_reference(flame_model):
         p = getattr(tr, k)
         w = min(4, p.shape[1])
         assert torch.equal(p[:, :w], torch.from_numpy(G[f"host/after/{k}"]).float()[:, :w]), k
+
+
+@pytest.mark.parametrize("stage", [None, "lmk_init_all", "rgb_init_offset", "rgb_global_tracking"])
+def test_oracle_total_energy_and_gradients_match_reference_compute_energy(flame_model, stage):
+    """The reference's GlobalTracker.compute_energy (:692-750: forward_flame, camera, landmark + photometric + regularisation terms, their
+    assembly per stage kind) and its backward -- run in the build container on a tracker object without __init__, fp32, with only the four
+    nvdiffrast ops replaced by the oracle's and the colour-disturbance draws replayed -- against the oracle's total_energy (fp64) on the
+    same visibility: every term of the log to 1e-4, the gradient w.r.t. EVERY parameter to 1 % of its max-norm."""
+    from vhap_amd.config import BaseTrackingConfig
+    model, topo = flame_model
+    dt = torch.float64
+    tag = "eval" if stage is None else stage
+    P, ts, (H, W) = _state(torch.float32)
+    P = {k: v.to(dt).requires_grad_() for k, v in P.items()}
+    tm = {k: torch.from_numpy(np.asarray(v)) for k, v in model.items()}
+    for k in ("v_template", "shapedirs", "posedirs", "J_regressor", "lbs_weights", "lmk_bary_coords", "verts_uvs"):
+        tm[k] = tm[k].float().to(dt)                                       # (the reference run used the fp32 model)
+    full = {k[len(f"full/{tag}/"):]: G[k] for k in G.files if k.startswith(f"full/{tag}/")}
+    sample = {"rgb": torch.from_numpy(G["full/rgb"]).to(dt), "lmk2d": torch.from_numpy(G["lmk2d"]).float().to(dt), "timestep_index": ts}
+    cfg = BaseTrackingConfig()
+    disturb = tid = None
+    if "tid" in full:
+        tid = torch.from_numpy(full["tid"].astype(np.int64))
+        assert 0.05 < float(full["coverage"]) < 0.9
+    if "idx" in full:
+        disturb = dict(w_fg=torch.from_numpy(full["w_fg"].astype(np.int32)), w_bg=torch.from_numpy(full["w_bg"].astype(np.int32)),
+                       fid2cid=torch.from_numpy(topo.fid2cid.astype(np.int64)), idx=[torch.from_numpy(r.astype(np.int64)) for r in full["idx"]])
+    E, log, _ = energy_ref.total_energy(P, tm, topo, cfg, sample, stage, torch.from_numpy(G["tex_painted"]).float().to(dt),
+                                        torch.from_numpy(G["uvmask"]).float().to(dt), (H, W), dt, disturb=disturb, tid=tid)
+    E.backward()
+    ref_log = {k[len("log/"):]: float(v) for k, v in full.items() if k.startswith("log/")}
+    assert set(log) | {"total"} == set(ref_log), (sorted(log), sorted(ref_log))
+    for k, want in ref_log.items():
+        got = float(E.detach()) if k == "total" else float(log[k].detach())
+        assert abs(got - want) <= 1e-4 * abs(want) + 1e-7, (tag, k, got, want)
+    for k, p in P.items():
+        ref = torch.from_numpy(full[f"grad/{k}"]).to(dt).reshape(p.shape)
+        g = torch.zeros_like(p) if p.grad is None else p.grad
+        scale = float(ref.abs().max())
+        if scale == 0.0:
+            assert float(g.abs().max()) == 0.0, (tag, k)                   # not part of this stage's energy
+            continue
+        err = float((g - ref).abs().max()) / scale
+        assert err < 1e-2, (tag, k, err)

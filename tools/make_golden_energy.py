@@ -128,7 +128,7 @@ def main():
     tex_painted = torch.from_numpy(make_texture(0, Tt)).to(dt)[None]
     uvmask = (torch.rand(Tt, Tt, generator=g) < 0.3).to(dt)
     lmk2d = torch.cat([torch.rand(B, 70, 2, generator=g, dtype=dt) * torch.tensor([W, H], dtype=dt), (torch.rand(B, 70, 1, generator=g) < 0.9).to(dt)], -1)
-    diffuse = torch.rand(B, 3, H, W, generator=g, dtype=dt) * 1.3      # stands in for result_dict['diffuse_detach_normal'] (nvdiffrast)
+    diffuse = (torch.rand(B, 3, H, W, generator=g, dtype=dt) * 1.3).float().double()      # stands in for result_dict['diffuse_detach_normal'] (nvdiffrast); stored as fp32
     verts, v_cano, lmks = R.flame_forward(tm, P["shape"][None].expand(B, -1), P["expr"][ts], P["rotation"][ts], P["neck_pose"][ts],
                                           P["jaw_pose"][ts], P["eyes_pose"][ts], P["translation"][ts], static_offset=P["static_offset"])
     f = P["focal_length"] * max(H, W)
@@ -255,7 +255,7 @@ def main():
             w_bg = (torch.rand_like(like) < 0.5).int()
             cid = rend2.fid2cid[(stash["tid"] + 1)]
             ncl = int(rend2.fid2cid.max()) + 1
-            idx = np.zeros((ncl, B2 * H2 * W2), np.int32)
+            idx = np.zeros((ncl, B2 * H2 * W2), np.uint16)
             for i in range(ncl):
                 n_i = int((cid == i).sum())
                 if i != 1 and n_i > 0:
@@ -328,7 +328,76 @@ def main():
     tr3.initialize_next_timtestep(torch.tensor([2, 3, 4]))
     after = {k: getattr(tr3, k).numpy() for k in before}
 
+    # ---- 9. the WHOLE energy: GlobalTracker.compute_energy (:692-750) = forward_flame (:213-235) + fill_cam_params_into_sample (:141-157) +
+    #         landmark + photometric + regularisation terms, and its backward, for four stage kinds; fp32 like the reference; the nvdiffrast
+    #         ops inside are the oracle's, the colour-disturbance draws are replayed as in section 5 -------------------------------------------
+    rn.torch = types.SimpleNamespace(**{k: getattr(torch, k) for k in dir(torch) if not k.startswith("__")})
+    rn.torch.tensor = lambda *a, **k: real_tensor(*a, **{kk: vv for kk, vv in k.items() if kk != "device"})
+    H9, W9 = H, W
+    fh32 = object.__new__(FL.FlameHead)
+    torch.nn.Module.__init__(fh32)
+    fh32.dtype = f32
+    for k in ("v_template", "shapedirs", "posedirs", "J_regressor", "lbs_weights"):
+        fh32.register_buffer(k, tm[k].to(f32))
+    fh32.register_buffer("parents", tm["parents"].long())
+    fh32.register_buffer("faces", faces_l)
+    fh32.register_buffer("full_lmk_faces_idx", tm["lmk_faces_idx"].long()[None])
+    fh32.register_buffer("full_lmk_bary_coords", tm["lmk_bary_coords"].to(f32)[None])
+    fh32.mask = types.SimpleNamespace(get_vid_by_region=vid, get_fid_by_region=fid)
+    fh32.textures_idx, fh32.verts_uvs = faces_uv_l, tm["verts_uvs"].to(f32)
+    fh32.laplacian_matrix = Lap.to(f32)
+    fh32.laplacian_matrix_negate_diag = (Lap - 2 * torch.diag(torch.diag(Lap))).to(f32)
+    rgb9 = torch.rand(B, 3, H9, W9, generator=g).to(f32)
+    full_out = {"rgb": rgb9.numpy()}
+    leafs = ("shape", "expr", "rotation", "neck_pose", "jaw_pose", "eyes_pose", "translation", "tex_extra", "lights", "static_offset", "focal_length")
+    for stage, seed in ((None, None), ("lmk_init_all", None), ("rgb_init_offset", 77), ("rgb_global_tracking", 78)):
+        tr9 = object.__new__(T.GlobalTracker)
+        tr9.cfg, tr9.device, tr9.render, tr9.image_size, tr9.calibrated, tr9.n_timesteps = rcfg, "cpu", rend2, (H9, W9), False, N
+        tr9.flame = fh32
+        for k in leafs:
+            setattr(tr9, k, P[k].to(f32).clone().requires_grad_())
+        tr9.dynamic_offset, tr9.tex_pca = None, None
+        tr9.RT = torch.eye(3, 4); tr9.RT[2, 3] = -1
+        tr9.lights_uniform = torch.zeros(9, 3)
+        tr9.flame_tex_painted = lambda: tex_painted.to(f32)
+        tr9.flame_uvmask = types.SimpleNamespace(get_uvmask_by_region=lambda regions: uvmask.to(f32))
+        tr9.opt_dict = defaultdict(bool)
+        if stage is not None:
+            tr9.get_train_parameters(stage)
+        sample9 = {"rgb": rgb9, "lmk2d": lmk2d.to(f32), "timestep_index": ts}
+        rend2.clear_cache()
+        tr9.fill_cam_params_into_sample(sample9)
+        if seed is not None:
+            torch.manual_seed(seed)
+        E9, log9, *_ = tr9.compute_energy(sample9, stage=stage)
+        E9.backward()
+        tag = "eval" if stage is None else stage
+        for k, v in log9.items():
+            full_out[f"{tag}/log/{k}"] = np.asarray(float(v))
+        for k in leafs:
+            gk = getattr(tr9, k).grad
+            full_out[f"{tag}/grad/{k}"] = (torch.zeros_like(getattr(tr9, k)) if gk is None else gk).numpy()
+        if "tid" in stash and (stage is None or stage.startswith("rgb")):
+            full_out[f"{tag}/tid"] = stash["tid"].numpy().astype(np.int16)
+            full_out[f"{tag}/coverage"] = np.asarray(float((stash["tid"] >= 0).float().mean()))
+        if seed is not None:
+            torch.manual_seed(seed)
+            like = torch.zeros(B, H9, W9, 1, dtype=f32)
+            w_fg = (torch.rand_like(like) < 0.5).int()
+            w_bg = (torch.rand_like(like) < 0.5).int()
+            cid = rend2.fid2cid[(stash["tid"] + 1)]
+            ncl = int(rend2.fid2cid.max()) + 1
+            idx = np.zeros((ncl, B * H9 * W9), np.uint16)
+            for i in range(ncl):
+                n_i = int((cid == i).sum())
+                if i != 1 and n_i > 0:
+                    idx[i] = torch.randint(0, n_i, (B * H9 * W9,)).numpy()
+            full_out[f"{tag}/w_fg"], full_out[f"{tag}/w_bg"], full_out[f"{tag}/idx"] = w_fg.numpy().astype(np.uint8), w_bg.numpy().astype(np.uint8), idx
+        print(f"  full {tag:22s} total {float(E9):.8g}  terms {sorted(log9)}")
+    rn.torch = torch
+
     save = {f"P/{k}": v.numpy() for k, v in P.items()}
+    save.update({f"full/{k}": v for k, v in full_out.items()})
     save["host/json"] = np.array(json.dumps(host))
     save.update({f"host/before/{k}": v for k, v in before.items()})
     save.update({f"host/after/{k}": v for k, v in after.items()})
@@ -336,9 +405,10 @@ def main():
     save.update({f"mask/{k}": v for k, v in mask_out.items()})
     save.update({f"photo_in/{k}": v for k, v in photo_in.items()})
     save.update({f"photo_out/{k}": v for k, v in photo_out.items()})
-    save.update(ts=ts, tex_painted=tex_painted.numpy(), uvmask=uvmask.numpy(), lmk2d=lmk2d.numpy(), diffuse=diffuse.numpy(),
+    save.update(ts=ts, tex_painted=tex_painted.numpy(), uvmask=uvmask.numpy().astype(np.uint8), lmk2d=lmk2d.numpy(), diffuse=diffuse.float().numpy(),
                 image_size=np.array([H, W]), collapse=collapse,
-                clip_ref=clip_ref.numpy(), ndc_ref=ndc_ref.numpy(), vn_ref=vn_ref.numpy(), fn_ref=fn_ref.numpy())
+                clip_ref=clip_ref.float().numpy(), ndc_ref=ndc_ref.numpy(), vn_ref=vn_ref.float().numpy(),
+                fn_ref=fn_ref[:, :500].float().numpy())          # (fp32 results of the reference; face normals: the first 500 faces)
     save.update({f"out/{k}": np.asarray(float(v)) for k, v in out.items()})
     save["cfg_keys"] = np.array(sorted(cfg_items), dtype=object)
     save["cfg_vals"] = np.array([repr(cfg_items[k]) for k in sorted(cfg_items)], dtype=object)
