@@ -3,7 +3,9 @@ FlameTracker.compute_lmk_energy / compute_regularization_energy (+ helpers), NVD
 compute_v_normals / compute_face_normals and BaseTrackingConfig() of /root/reference return on a small seeded state
 (tools/make_golden_energy.py).  Checked here: (1) the oracle restatement (fp64: 1e-9; fp32 reference helpers: 1e-5), (2) the product's
 host formulation -- vhap_amd.tracker.FlameTracker on a CPU device, fp32: 2e-4 -- which is what the HIP kernels are compared with on the
-GPU (tests/test_native_gpu.py), (3) every default of vhap_amd.config that the reference also has."""
+GPU (tests/test_native_gpu.py), (3) every default of vhap_amd.config that the reference also has; further down: the photometric chain
+and the whole GlobalTracker.compute_energy + backward of the reference (the four nvdiffrast ops inside replaced by the oracle's), the FLAME
+forward, the region tables and the tracker's host logic."""
 import os
 
 import numpy as np
