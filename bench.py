@@ -147,7 +147,18 @@ def main():
         from vhap_amd.tracker import GraphedStep
         # same work per step; on one GPU a replay carries UNROLL consecutive steps (one graph launch gap per UNROLL steps)
         unroll = UNROLL if (world == 1 and args.steps % UNROLL == 0 and args.warmup % UNROLL == 0) else 1
-        step = GraphedStep(tr, sample, optimizer, STAGE, unroll=unroll)
+        ok, why = 1, ""
+        try:
+            step = GraphedStep(tr, sample, optimizer, STAGE, unroll=unroll)
+        except Exception as e:                                   # a failed capture must not sink the run: same work, eager launches
+            ok, why, step = 0, f"{type(e).__name__}: {e}", None
+        if world > 1:                                            # all ranks take the same path
+            flag = torch.tensor([ok], dtype=torch.int32, device=device)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+            if int(flag) == 0:
+                step = None
+        if step is None and rank == 0:
+            print(f"[bench] captured step unavailable ({why or 'another rank failed'}); running the eager step", file=sys.stderr, flush=True)
 
     ev = []                                                      # HIP event pairs around the RI-fwd launches
     recording = {"on": False}
@@ -237,7 +248,7 @@ def main():
                                    "(photometric + landmark + TV + all regularisers, colour disturbance on), "
                                    "FLAME topology V=5143 F=10144, texture 2048x2048, fwd+bwd+Adam",
                        "global_batch": B_PER_GPU * world, "parallelism": f"dp{world} (frame-sharded; per step one scalar all-reduce + two gradient all-reduces over RCCL)",
-                       "coverage": cov},
+                       "coverage": cov, "captured_step": step is not None},
             "roofline": {"bound": "hbm", "achieved": alg / ri_s / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": alg / ri_s / HBM_PEAK, "traffic": pmc_traffic(),
                          "kernel": "fused rasterize+interpolate forward (vhap_raster_interp_fwd = bin_build_kernel + "
