@@ -331,3 +331,28 @@ def test_oracle_total_energy_and_gradients_match_reference_compute_energy(flame_
             continue
         err = float((g - ref).abs().max()) / scale
         assert err < 1e-2, (tag, k, err)
+
+
+def test_saved_npz_schema_matches_reference_save_result(flame_model, tmp_path):
+    """The on-disk contract with the downstream consumers (export_as_nerf_dataset.py / GaussianAvatars): keys, shapes and dtypes of the
+    reference's save_result (:1152-1218) output, produced by the reference's own method, against the product's save_result."""
+    import json
+    from vhap_amd.config import BaseTrackingConfig
+    from vhap_amd.synthetic import make_texture
+    from vhap_amd.tracker import GlobalTracker
+    model, topo = flame_model
+    schema = json.loads(str(G["schema/json"]))
+    N, (T_,) = schema["expr"][0][0], set(schema["tex_extra"][0][1:])
+    H, W = (int(x) for x in G["image_size"])
+    cfg = BaseTrackingConfig()
+    cfg.device = "cpu"
+    cfg.model.tex_resolution = T_
+    tr = GlobalTracker(cfg, model, topo, make_texture(0, T_), {"rgb": torch.zeros(N, 3, H, W), "lmk2d": torch.zeros(N, 70, 3)})
+    tr.save_result(tmp_path / "tracked_flame_params.npz")
+    rep = np.load(tmp_path / "tracked_flame_params.npz")
+    assert set(rep.files) == set(schema), (sorted(rep.files), sorted(schema))
+    for k, (shape, dtype) in schema.items():
+        assert list(rep[k].shape) == shape, (k, rep[k].shape, shape)
+        if k == "timestep_id":                                   # the reference stores the dataset's frame names; the product has no dataset IO: indices
+            continue
+        assert str(rep[k].dtype) == dtype, (k, rep[k].dtype, dtype)

@@ -399,7 +399,24 @@ def main():
         print(f"  full {tag:22s} total {float(E9):.8g}  terms {sorted(log9)}")
     rn.torch = torch
 
+    # ---- 10. the on-disk contract: save_result (:1152-1218) -> tracked_flame_params.npz keys / shapes / dtypes ---------------------------
+    import tempfile
+    from pathlib import Path as _Path
+    tr10 = object.__new__(T.GlobalTracker)
+    tr10.cfg, tr10.calibrated, tr10.image_size = rcfg, False, (H, W)
+    for k in leafs:
+        setattr(tr10, k, P[k].to(f32))
+    tr10.dynamic_offset, tr10.tex_pca = None, torch.zeros(5)
+    tr10.dataset = types.SimpleNamespace(timestep_ids=[f"{i:05d}" for i in range(N)])
+    tr10.timestep = N
+    with tempfile.TemporaryDirectory() as d_:
+        tr10.out_dir = _Path(d_)
+        tr10.save_result(epoch=3)
+        rep = np.load(_Path(d_) / "tracked_flame_params_3.npz")
+        schema = {k: [list(rep[k].shape), str(rep[k].dtype)] for k in rep.files}
+
     save = {f"P/{k}": v.numpy() for k, v in P.items()}
+    save["schema/json"] = np.array(json.dumps(schema))
     save.update({f"full/{k}": v for k, v in full_out.items()})
     save["host/json"] = np.array(json.dumps(host))
     save.update({f"host/before/{k}": v for k, v in before.items()})
