@@ -173,3 +173,38 @@ def test_oracle_backward_matches_finite_differences():
     tid = torch.from_numpy(r_np[..., 3].astype(np.int64) - 1)
     f = lambda p: torch.cat([x[..., :3] if i == 0 else x for i, x in enumerate(R.rast_from_ids(p, tri, tid, (6, 6)))], -1)
     assert torch.autograd.gradcheck(f, (pos,), eps=1e-7, atol=1e-5)
+
+
+def test_texture_oracle_against_independent_torch_implementations():
+    """The texture restatement against implementations it shares no code with: the mip chain == repeated 2x2 average pooling, plain bilinear
+    sampling == torch's grid_sample (align_corners=False: texel centres at half-integers) away from the wrap seam, and the trilinear blend ==
+    the explicit lerp of two grid_sample look-ups at the level the Jacobian selects."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(4)
+    T, C, B, H, W = 64, 3, 2, 9, 11
+    tex = torch.rand(1, T, T, C, generator=g, dtype=torch.float64)
+    mips = R.build_mips(tex)
+    cur = tex.permute(0, 3, 1, 2)
+    for l, m in enumerate(mips[1:], 1):
+        cur = F.avg_pool2d(cur, 2)
+        assert torch.allclose(m.permute(0, 3, 1, 2), cur, atol=1e-14), l
+    uv = torch.rand(B, H, W, 2, generator=g, dtype=torch.float64) * 0.8 + 0.1
+
+    def gs(level_img, uv_):                                       # [1,T,T,C] sampled at uv in [0,1]^2
+        out = F.grid_sample(level_img.permute(0, 3, 1, 2).expand(B, -1, -1, -1), uv_ * 2 - 1, mode="bilinear", padding_mode="border",
+                            align_corners=False)
+        return out.permute(0, 2, 3, 1)
+    assert torch.allclose(R.texture(tex, uv, None, filter_mode="linear"), gs(tex, uv), atol=1e-12)
+    # an isotropic footprint of s texels per pixel selects level log2(s): blend levels floor and floor + 1
+    for s in (1.0, 2.0, 3.0, 5.5):
+        da = torch.zeros(B, H, W, 4, dtype=torch.float64)
+        da[..., 0] = s / T                                       # du/dx
+        da[..., 3] = s / T                                       # dv/dy
+        level = np.log2(s)
+        l0 = int(np.floor(level))
+        f = level - l0
+        want = gs(mips[l0], uv) * (1 - f) + gs(mips[l0 + 1], uv) * f if f > 0 else gs(mips[l0], uv)
+        # (coarse levels: keep clear of the border where grid_sample clamps and the oracle wraps)
+        inner = ((uv > 0.2) & (uv < 0.8)).all(-1)
+        got = R.texture(tex, uv, da, filter_mode="linear-mipmap-linear")
+        assert torch.allclose(got[inner], want[inner], atol=1e-10), s
