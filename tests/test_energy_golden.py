@@ -15,7 +15,7 @@ import torch
 from oracle import energy_ref
 from oracle import torch_ref as R
 
-G = np.load(os.path.join(os.path.dirname(__file__), "golden", "energy_golden.npz"), allow_pickle=True)
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "energy_golden.npz"))
 OPT = {"pose", "joints", "expr", "shape", "texture", "lights", "static_offset"}
 STAGES = ("rgb_init_offset", "rgb_global_tracking")
 
@@ -133,7 +133,7 @@ def test_config_defaults_match_reference():
     from vhap_amd.config import BaseTrackingConfig
     cfg = BaseTrackingConfig()
     missing, seen = [], 0
-    for key, val in zip(G["cfg_keys"], G["cfg_vals"]):
+    for key, val in zip((str(x) for x in G["cfg_keys"]), (str(x) for x in G["cfg_vals"])):
         obj, ok = cfg, True
         for part in key.split("."):
             if not hasattr(obj, part):
@@ -233,7 +233,7 @@ def test_flame_forward_and_region_tables_match_reference(flame_model):
     for got, key in ((v32[:, pick], "verts"), (c32[:, pick], "verts_cano"), (l32, "lmks")):
         assert float((got.double() - torch.from_numpy(G[f"flame/{key}"])).abs().max()) < 5e-6, key
     # region tables
-    names = list(G["mask/f_names"])
+    names = [str(x) for x in G["mask/f_names"]]
     assert sorted(topo.f_regions) == sorted(names)
     for k in names:
         assert np.array_equal(np.sort(topo.f_regions[k]), np.sort(G[f"mask/f/{k}"])), k

@@ -299,7 +299,7 @@ def main():
     fm.process_face_clusters(list(topo.tex_clusters))
     mask_out = {"fid2cid": fm.fid2cid.numpy()}
     names = sorted(k for k, _ in fm.f)
-    mask_out["f_names"] = np.array(names, dtype=object)
+    mask_out["f_names"] = np.array(names)
     for k in names:
         mask_out[f"f/{k}"] = fm.f.get_buffer(k).numpy()
     for stage_name in ("rgb_init_texture", "rgb_init_all", "rgb_global_tracking"):
@@ -430,8 +430,8 @@ def main():
                 clip_ref=clip_ref.float().numpy(), ndc_ref=ndc_ref.numpy(), vn_ref=vn_ref.float().numpy(),
                 fn_ref=fn_ref[:, :500].float().numpy())          # (fp32 results of the reference; face normals: the first 500 faces)
     save.update({f"out/{k}": np.asarray(float(v)) for k, v in out.items()})
-    save["cfg_keys"] = np.array(sorted(cfg_items), dtype=object)
-    save["cfg_vals"] = np.array([repr(cfg_items[k]) for k in sorted(cfg_items)], dtype=object)
+    save["cfg_keys"] = np.array(sorted(cfg_items))
+    save["cfg_vals"] = np.array([repr(cfg_items[k]) for k in sorted(cfg_items)])
     np.savez_compressed(OUT, **save)
     print("wrote", os.path.abspath(OUT), os.path.getsize(OUT), "bytes;", len(out), "energy values;", len(cfg_items), "config defaults")
     for k, v in out.items():
