@@ -51,8 +51,8 @@ def _step(tr, frames):
     return E, {k: getattr(tr, k).grad.detach().cpu().clone() for k in NAMES}, bool(st.ns.tex_l0_skip)
 
 
-def _worker(rank, world, port, T, ret):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+def _worker(rank, world, port, T, ret, schedule):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), VHAP_SHARD_SCHEDULE=schedule)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from vhap_amd import dist as vdist
     tr = _build(T)
@@ -61,16 +61,17 @@ def _worker(rank, world, port, T, ret):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("T", [128])
-def test_two_rank_native_step_matches_single_process(T):
-    """Sharded, captured step (forward graph / 'texture' backward graph / asynchronous texture-gradient all-reduce / 'geometry' backward
-    graph underneath it / small-gradient all-reduce / Adam graph) == the single-process step on the whole batch."""
+@pytest.mark.parametrize("T,schedule", [(128, "parallel"), (128, "serial")])
+def test_two_rank_native_step_matches_single_process(T, schedule):
+    """Sharded, captured step == the single-process step on the whole batch, for both schedules: 'parallel' (forward graph / pixel-chain
+    graph / texture-gradient graph + its all-reduce on a second stream next to the geometry graph / small-gradient all-reduce / Adam graph)
+    and 'serial' (texture graph / asynchronous all-reduce / geometry graph underneath it)."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ret = mp.Manager().dict()
-    mp.spawn(_worker, args=(2, port, T, ret), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, T, ret, schedule), nprocs=2, join=True)
     E1, g1, _ = _step(_build(T), [0, 1, 2, 3])
     Em = 0.5 * (ret[0][0] + ret[1][0])
     assert abs(Em - E1) <= 2e-4 * abs(E1), (Em, E1)

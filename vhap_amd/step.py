@@ -349,11 +349,12 @@ class NativeStep:
         """part = 'all': the whole backward as one two-branch DAG (one GPU).  Under frame sharding the backward is captured in two
         graphs so that the big collective can start early (`optimizer`, one GPU only: a HipAdam whose texture update is issued on the
         side branch -- the caller then steps the remaining parameters with optimizer.step(skip=(tex_extra,))): 'texture' (pixel chain + the complete texture gradient, serial) -- the
-        caller launches the asynchronous all-reduce of the texture gradient -- then 'geometry' (everything else), which hides it."""
+        caller launches the asynchronous all-reduce of the texture gradient -- then 'geometry' (everything else), which hides it; or
+        'pixel' then 'tex' and 'geometry' side by side on two streams (GraphedStep's default under sharding)."""
         L = self.L
         L.vhap_set_call_flags(1)
         try:
-            if part in ("all", "texture"):
+            if part in ("all", "texture", "pixel"):
                 if not getattr(self, "_arena_clean", False):          # (normally done on the forward's side branch already)
                     self.arena.zero_()
                 self._arena_clean = False
@@ -378,6 +379,10 @@ class NativeStep:
                 self._join()
             elif part == "texture":
                 self._bwd_pixel(world_size)
+                self._tex_backward()
+            elif part == "pixel":                                     # 'texture' in two pieces: the caller runs 'tex' next to 'geometry'
+                self._bwd_pixel(world_size)
+            elif part == "tex":
                 self._tex_backward()
             elif part == "geometry":
                 early = None

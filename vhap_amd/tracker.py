@@ -909,9 +909,20 @@ class GraphedStep:
                 with torch.cuda.graph(self.gF, **cap):
                     ns.forward()
                 pool = self.gF.pool() if os.environ.get("VHAP_GRAPH_POOLS") != "separate" else None
-                with torch.cuda.graph(self.gB, pool=pool, **cap):
-                    ns.backward(world, part="texture")
+                # 'parallel' (default): pixel chain, then the texture part (own stream, followed by its all-reduce) NEXT TO the geometry part --
+                # the same two-branch overlap as on one GPU; 'serial': texture part, collective launched, geometry part underneath it
+                self.par = os.environ.get("VHAP_SHARD_SCHEDULE", "parallel") != "serial"
                 self.gB2 = torch.cuda.CUDAGraph()
+                if self.par:
+                    with torch.cuda.graph(self.gB, pool=pool, **cap):
+                        ns.backward(world, part="pixel")
+                    self.gBt = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self.gBt, **cap):               # replayed concurrently with gB2: a pool of its own
+                        ns.backward(world, part="tex")
+                    self.tex_stream = torch.cuda.Stream()
+                else:
+                    with torch.cuda.graph(self.gB, pool=pool, **cap):
+                        ns.backward(world, part="texture")
                 with torch.cuda.graph(self.gB2, pool=pool, **cap):
                     ns.backward(world, part="geometry")
                 with torch.cuda.graph(self.gA, pool=pool, **cap):
@@ -997,11 +1008,23 @@ class GraphedStep:
                 self.ns.n_global.copy_(tr.dist.all_reduce_sum(self.N.reshape(1)))
             self.gB.replay()
             # the gradients sit in contiguous buffers: collectives straight on them (ReduceOp.AVG), no staging copies
-            work = tr.dist.all_reduce_mean_(self.ns.g["tex_extra"], async_op=True)
-            self.gB2.replay()                                          # runs under the texture collective
-            tr.dist.all_reduce_mean_(self.ns.param_grad_flat)
-            if work is not None:
-                work.wait()
+            if getattr(self, "par", False):
+                cur = torch.cuda.current_stream()
+                self.tex_stream.wait_stream(cur)
+                with torch.cuda.stream(self.tex_stream):
+                    self.gBt.replay()                                      # texture gradient, next to ...
+                    work = tr.dist.all_reduce_mean_(self.ns.g["tex_extra"], async_op=True)
+                self.gB2.replay()                                          # ... the geometry chain; the collective runs under its tail
+                tr.dist.all_reduce_mean_(self.ns.param_grad_flat)
+                if work is not None:
+                    work.wait()
+                cur.wait_stream(self.tex_stream)
+            else:
+                work = tr.dist.all_reduce_mean_(self.ns.g["tex_extra"], async_op=True)
+                self.gB2.replay()                                          # runs under the texture collective
+                tr.dist.all_reduce_mean_(self.ns.param_grad_flat)
+                if work is not None:
+                    work.wait()
             self.gA.replay()
             return
         n = self.N
