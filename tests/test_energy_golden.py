@@ -294,7 +294,8 @@ def test_oracle_total_energy_and_gradients_match_reference_compute_energy(flame_
     """The reference's GlobalTracker.compute_energy (:692-750: forward_flame, camera, landmark + photometric + regularisation terms, their
     assembly per stage kind) and its backward -- run in the build container on a tracker object without __init__, fp32, with only the four
     nvdiffrast ops replaced by the oracle's and the colour-disturbance draws replayed -- against the oracle's total_energy (fp64) on the
-    same visibility: every term of the log to 1e-4, the gradient w.r.t. EVERY parameter to 1 % of its max-norm."""
+    same visibility: every term of the log to 5e-6 relative, the gradient w.r.t. EVERY parameter to 2e-4 of its max-norm (measured spread of
+    the fp32 reference against the fp64 oracle: 1.4e-7 and 1.3e-5)."""
     from vhap_amd.config import BaseTrackingConfig
     model, topo = flame_model
     dt = torch.float64
@@ -321,7 +322,7 @@ def test_oracle_total_energy_and_gradients_match_reference_compute_energy(flame_
     assert set(log) | {"total"} == set(ref_log), (sorted(log), sorted(ref_log))
     for k, want in ref_log.items():
         got = float(E.detach()) if k == "total" else float(log[k].detach())
-        assert abs(got - want) <= 1e-4 * abs(want) + 1e-7, (tag, k, got, want)
+        assert abs(got - want) <= 5e-6 * abs(want) + 1e-9, (tag, k, got, want)
     for k, p in P.items():
         ref = torch.from_numpy(full[f"grad/{k}"]).to(dt).reshape(p.shape)
         g = torch.zeros_like(p) if p.grad is None else p.grad
@@ -330,7 +331,7 @@ def test_oracle_total_energy_and_gradients_match_reference_compute_energy(flame_
             assert float(g.abs().max()) == 0.0, (tag, k)                   # not part of this stage's energy
             continue
         err = float((g - ref).abs().max()) / scale
-        assert err < 1e-2, (tag, k, err)
+        assert err < 2e-4, (tag, k, err)
 
 
 def test_saved_npz_schema_matches_reference_save_result(flame_model, tmp_path):
