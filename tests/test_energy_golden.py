@@ -127,6 +127,30 @@ def test_product_host_energies_match_reference(flame_model):
             assert abs(e - want) <= 2e-4 * abs(want), (dis, always, e, want)
 
 
+def test_nersemble_config_matches_reference():
+    """vhap/config/nersemble.py (the calibrated multi-view configuration of BASELINE config 4): every default the product's
+    nersemble_config() shares with NersembleTrackingConfig() has the same value."""
+    from vhap_amd.config import nersemble_config
+    cfg = nersemble_config()
+    seen = 0
+    for key, val in zip((str(x) for x in G["ners_keys"]), (str(x) for x in G["ners_vals"])):
+        obj, ok = cfg, True
+        for part in key.split("."):
+            if not hasattr(obj, part):
+                ok = False
+                break
+            obj = getattr(obj, part)
+        if not ok:
+            assert not key.startswith(("w.", "lr.", "pipeline.", "render.")), key
+            continue
+        if key == "render.backend":
+            continue
+        seen += 1
+        norm = lambda v: repr(tuple(v)) if isinstance(v, (list, tuple)) else repr(v)
+        assert norm(obj) == norm(eval(val, {"__builtins__": {}}, {})), (key, obj, val)
+    assert seen > 80
+
+
 def test_config_defaults_match_reference():
     """Every default the product's config shares with the reference's BaseTrackingConfig() has the same value; the loss weights, the
     learning rates and the stage lists must all be present."""

@@ -113,6 +113,11 @@ def main():
     cfg_items = {k: v for k, v in config_to_dict(rcfg).items()
                  if isinstance(v, (int, float, bool, str, type(None), list, tuple)) and not k.startswith(("data.root", "exp.", "data.sequence"))}
 
+    ners = load(f"{REF}/vhap/config/nersemble.py", "vhap.config.nersemble")
+    ncfg = default_instance(ners.NersembleTrackingConfig)
+    ners_items = {k: v for k, v in config_to_dict(ncfg).items()
+                  if isinstance(v, (int, float, bool, str, type(None), list, tuple)) and not k.startswith(("data.root", "exp.", "data.sequence"))}
+
     # ---- 2. a small state on the synthetic FLAME-topology model ----------------------------------------------------------------
     model, topo = make_flame_model(0)
     tm = {k: torch.from_numpy(np.asarray(v)) for k, v in model.items()}
@@ -430,6 +435,8 @@ def main():
                 clip_ref=clip_ref.float().numpy(), ndc_ref=ndc_ref.numpy(), vn_ref=vn_ref.float().numpy(),
                 fn_ref=fn_ref[:, :500].float().numpy())          # (fp32 results of the reference; face normals: the first 500 faces)
     save.update({f"out/{k}": np.asarray(float(v)) for k, v in out.items()})
+    save["ners_keys"] = np.array(sorted(ners_items))
+    save["ners_vals"] = np.array([repr(ners_items[k]) for k in sorted(ners_items)])
     save["cfg_keys"] = np.array(sorted(cfg_items))
     save["cfg_vals"] = np.array([repr(cfg_items[k]) for k in sorted(cfg_items)])
     np.savez_compressed(OUT, **save)
