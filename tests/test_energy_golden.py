@@ -381,3 +381,55 @@ def test_saved_npz_schema_matches_reference_save_result(flame_model, tmp_path):
         if k == "timestep_id":                                   # the reference stores the dataset's frame names; the product has no dataset IO: indices
             continue
         assert str(rep[k].dtype) == dtype, (k, rep[k].dtype, dtype)
+
+
+def test_stage_scheduler_matches_reference(flame_model):
+    """GlobalTracker.optimize (:1343-1389) and optimize_stage (:1391-1416) of the reference with the per-step work stubbed out: the sequence of
+    stages, the timesteps of every batch, the seeding of the next timesteps, the evaluation points, the learning-rate scale of the global
+    stage, the number of steps per stage and the per-step learning rates of every Adam group (ExponentialLR 0.9 per epoch) -- against the
+    product's scheduler driven through the same stubs."""
+    import json
+    from vhap_amd.config import BaseTrackingConfig
+    from vhap_amd.synthetic import make_texture
+    from vhap_amd.tracker import GlobalTracker
+    model, topo = flame_model
+    ref = json.loads(str(G["sched/json"]))
+    cfg = BaseTrackingConfig()
+    cfg.device = "cpu"
+    cfg.model.tex_resolution = 16
+
+    def tracker(n):
+        return GlobalTracker(cfg, model, topo, make_texture(0, 16), {"rgb": torch.zeros(n, 3, 8, 8), "lmk2d": torch.zeros(n, 70, 3)})
+
+    tr = tracker(20)
+    trace = []
+
+    def rec_stage(stage, sample=None, dataloader=None, lr_scale=1.0, **kw):
+        if sample is not None:
+            trace.append(["stage", stage, [int(t) for t in sample["timestep_index"]], float(lr_scale)])
+        else:
+            trace.append(["stage", stage, {"shuffle": bool(dataloader.shuffle), "batch_size": dataloader.bs, "batches": len(dataloader)},
+                          float(lr_scale)])
+            seen = sorted(int(t) for b in dataloader for t in b["timestep_index"])
+            assert seen == list(range(20))                                   # one pass = every frame once
+    tr.optimize_stage = rec_stage
+    tr.initialize_next_timtestep = lambda ts: trace.append(["init_next", [int(t) for t in ts]])
+    tr.evaluate = lambda **kw: trace.append(["evaluate", 0])
+    tr.optimize()
+    assert trace == ref["trace"], (trace, ref["trace"])
+
+    for stage, kw in (("lmk_init_rigid", dict(sample={"timestep_index": np.arange(3)})),
+                      ("rgb_global_tracking", dict(dataloader=[{"timestep_index": np.arange(2)}, {"timestep_index": np.arange(2, 3)}],
+                                                   lr_scale=0.1, evaluate_every=10))):
+        tr = tracker(9)
+        calls = []
+        tr.optimize_iter = lambda sample, optimizer, stage, calls=calls: calls.append([g["lr"] for g in optimizer.param_groups])
+        tr.evaluate = lambda calls=calls, **kw: calls.append(["evaluate", None])
+        tr.optimize_stage(stage, graphed=False, **kw)
+        want = ref["stage_calls"][stage]
+        assert len(calls) == len(want), (stage, len(calls), len(want))
+        for got, w in zip(calls, want):
+            if w[0] == "evaluate":
+                assert got[0] == "evaluate"
+            else:
+                assert len(got) == len(w) and all(abs(a - b) <= 1e-12 * abs(b) for a, b in zip(got, w)), (stage, got, w)

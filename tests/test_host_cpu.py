@@ -111,3 +111,42 @@ def test_config_mirrors_reference_defaults():
     assert "hair" in c2.pipeline.rgb_init_all.align_boundary_except            # base.py:341-347
     n = nersemble_config()
     assert n.w.landmark == 3.0 and n.data.calibrated and "texture" not in n.pipeline.rgb_sequential_tracking.optimizable_params
+
+
+def test_landmark_only_pipeline_runs_end_to_end_on_cpu(flame_model):
+    """GlobalTracker.optimize() with cfg.exp.photometric = False (tracker.py:1343-1389, landmark stages only -- the reference's own
+    CPU-runnable configuration, BASELINE config 1): the whole stage scheduler executes on a CPU device and the landmark energy drops."""
+    import numpy as np
+    from vhap_amd.config import BaseTrackingConfig
+    from vhap_amd.synthetic import make_scene_params, make_texture, monocular_camera
+    from vhap_amd.tracker import GlobalTracker
+    model, topo = flame_model
+    cfg = BaseTrackingConfig()
+    cfg.device = "cpu"
+    cfg.exp.photometric = False
+    cfg.model.tex_resolution = 16
+    cfg.batch_size = 2
+    for st in cfg.pipeline.__dict__.values():
+        if hasattr(st, "num_steps"):
+            st.num_steps = 6
+        if hasattr(st, "num_epochs"):
+            st.num_epochs = 2
+    N, H, W = 4, 64, 64
+    gt = make_scene_params(N, seed=2, image_size=(H, W))
+    g = lambda k: torch.from_numpy(gt[k]).float()
+    tr = GlobalTracker(cfg, model, topo, make_texture(0, 16), {"rgb": torch.zeros(N, 3, H, W), "lmk2d": torch.zeros(N, 70, 3)})
+    with torch.no_grad():                                             # landmark targets: the ground-truth parameters through the product's own model
+        _, lmks = tr.flame(g("shape")[None].expand(N, -1), g("expr"), g("rotation"), g("neck_pose"), g("jaw_pose"), g("eyes_pose"), g("translation"))
+        K, RT = monocular_camera(N, (H, W), float(gt["focal_length"][0]))
+        ndc = tr.render.world_to_ndc(lmks, torch.from_numpy(RT).float(), torch.from_numpy(K).float(), (H, W), flip_y=True)
+        tr.dataset["lmk2d"] = torch.stack([(ndc[..., 0] * 0.5 + 0.5) * W, (ndc[..., 1] * 0.5 + 0.5) * H, torch.ones(N, lmks.shape[1])], dim=-1)
+
+    def lmk_energy():
+        s = tr.get_sample(np.arange(N))
+        tr.fill_cam_params_into_sample(s)
+        with torch.no_grad():
+            return float(tr.compute_energy(s, stage="lmk_global_tracking")[1]["lmk"])
+    before = lmk_energy()
+    report = tr.optimize(evaluate=False)
+    after = lmk_energy()
+    assert report is None and tr.global_step == 6 * 2 + 6 * 2 + 2 * 2 and after < 0.7 * before, (before, after, tr.global_step)

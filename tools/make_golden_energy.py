@@ -88,6 +88,20 @@ def config_to_dict(cfg, prefix=""):
     return out
 
 
+class _IndexDataset(torch.utils.data.Dataset):
+    """stands in for the reference's VideoDataset in the stage-scheduler trace: item i = {"timestep_index": i}"""
+    batchify_all_views = False
+
+    def __init__(self, n):
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        return {"timestep_index": i}
+
+
 def main():
     base, rn, T, FL = load_reference()
     from oracle import energy_ref, torch_ref as R
@@ -420,7 +434,39 @@ def main():
         rep = np.load(_Path(d_) / "tracked_flame_params_3.npz")
         schema = {k: [list(rep[k].shape), str(rep[k].dtype)] for k in rep.files}
 
+    # ---- 11. the stage scheduler: GlobalTracker.optimize (:1343-1389) call trace, and optimize_stage's (:1391-1416) step count / learning-rate
+    #          schedule, with the per-step work stubbed out --------------------------------------------------------------------------------------
+    trace = []
+    tr11 = object.__new__(T.GlobalTracker)
+    tr11.cfg, tr11.n_timesteps, tr11.logger = rcfg, 20, types.SimpleNamespace(info=lambda *a, **k: None)
+    tr11.dataset = _IndexDataset(20)
+
+    def rec_stage(stage, sample=None, dataloader=None, lr_scale=1.0):
+        if sample is not None:
+            trace.append(["stage", stage, [int(t) for t in sample["timestep_index"]], float(lr_scale)])
+        else:
+            trace.append(["stage", stage, {"shuffle": isinstance(dataloader.sampler, torch.utils.data.RandomSampler),
+                                           "batch_size": dataloader.batch_size, "batches": len(dataloader)}, float(lr_scale)])
+    tr11.optimize_stage = rec_stage
+    tr11.initialize_next_timtestep = lambda ts: trace.append(["init_next", [int(t) for t in ts]])
+    tr11.evaluate = lambda make_visualization=True, epoch=0: trace.append(["evaluate", int(epoch)])
+    tr11.optimize()
+    sched = {}
+    for stage_name, kw in (("lmk_init_rigid", dict(sample={"timestep_index": torch.arange(3)})),
+                           ("rgb_global_tracking", dict(dataloader=[{"timestep_index": torch.arange(2)}, {"timestep_index": torch.arange(2, 3)}],
+                                                        lr_scale=0.1))):
+        tr12 = object.__new__(T.GlobalTracker)
+        tr12.cfg, tr12.calibrated, tr12.n_timesteps, tr12.logger = rcfg, False, 9, types.SimpleNamespace(info=lambda *a, **k: None)
+        for i, k in enumerate(pnames):
+            setattr(tr12, k, torch.full((9, 3), float(i), requires_grad=True))
+        calls = []
+        tr12.optimize_iter = lambda sample, optimizer, stage, calls=calls: calls.append([gr["lr"] for gr in optimizer.param_groups])
+        tr12.evaluate = lambda make_visualization=True, epoch=0, calls=calls: calls.append(["evaluate", int(epoch)])
+        tr12.optimize_stage(stage_name, **kw)
+        sched[stage_name] = calls
+
     save = {f"P/{k}": v.numpy() for k, v in P.items()}
+    save["sched/json"] = np.array(json.dumps({"trace": trace, "stage_calls": sched}))
     save["schema/json"] = np.array(json.dumps(schema))
     save.update({f"full/{k}": v for k, v in full_out.items()})
     save["host/json"] = np.array(json.dumps(host))

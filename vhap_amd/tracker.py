@@ -634,11 +634,39 @@ class GlobalTracker(FlameTracker):
                 s[k] = self.dataset[k][idx]
         return s
 
-    def optimize_stage(self, stage, sample=None, dataloader=None, lr_scale=1.0, num_steps=None, graphed=None):
+    def optimize(self, batch_size=None, evaluate=True):
+        """tracker.py:1343-1389, the stage scheduler: sequential tracking over the frames in order -- the first batch also runs the
+        initialisation stages -- each batch seeding the next timesteps, an evaluation pass, then global tracking over shuffled
+        batches at a tenth of the learning rates.  The frames come from the in-memory dataset / the resident uint8 store instead of a
+        DataLoader; logging and media output are out of scope.  Returns the evaluation report (or None)."""
+        self.global_step = 0
+        bs = int(batch_size or self.cfg.batch_size or self.n_timesteps)
+        on_gpu = str(self.device).startswith("cuda")
+        for t0 in range(0, self.n_timesteps, bs):
+            ts = np.arange(t0, min(t0 + bs, self.n_timesteps))
+            sample = self.get_sample(ts, device_index=on_gpu)
+            if t0 == 0:
+                self.optimize_stage("lmk_init_rigid", sample)
+                self.optimize_stage("lmk_init_all", sample)
+                if self.cfg.exp.photometric:
+                    self.optimize_stage("rgb_init_texture", sample)
+                    self.optimize_stage("rgb_init_all", sample)
+                    if self.cfg.model.use_static_offset:
+                        self.optimize_stage("rgb_init_offset", sample)
+            self.optimize_stage("rgb_sequential_tracking" if self.cfg.exp.photometric else "lmk_sequential_tracking", sample)
+            self.initialize_next_timtestep(ts)
+        report = self.evaluate(batch_size=bs) if evaluate else None
+        loader = ShuffledBatches(self, bs, device_index=on_gpu)
+        self.optimize_stage("rgb_global_tracking" if self.cfg.exp.photometric else "lmk_global_tracking", dataloader=loader, lr_scale=0.1,
+                            evaluate_every=10 if evaluate else None)
+        return report
+
+    def optimize_stage(self, stage, sample=None, dataloader=None, lr_scale=1.0, num_steps=None, graphed=None, evaluate_every=None):
         """tracker.py:1391-1416.  `graphed` (default: on for the fused GPU path): run the stage's identical steps as replays of a
         captured GraphedStep.  The capture is kept per (stage, batch shape, lr scale) and fed new batches by
         copying into its static sample buffers -- sequential tracking re-enters here once per timestep with a same-shaped sample --
-        and, like the reference, every call starts from a fresh Adam state."""
+        and, like the reference, every call starts from a fresh Adam state.  `evaluate_every`: run evaluate() after every that many
+        epochs of a dataloader stage (the reference does so every 10, tracker.py:1414-1415; off by default)."""
         if graphed is None:
             graphed = self.fused and self.native and str(self.device).startswith("cuda")
         if not graphed:
@@ -650,19 +678,26 @@ class GlobalTracker(FlameTracker):
             else:
                 assert dataloader is not None
                 sched = torch.optim.lr_scheduler.ExponentialLR(optimizer, gamma=0.9)
-                for _ in range(self.cfg.pipeline[stage].num_epochs):
+                for epoch_i in range(self.cfg.pipeline[stage].num_epochs):
                     for s in dataloader:
                         self.optimize_iter(s, optimizer, stage)
                     sched.step()
+                    if evaluate_every and (epoch_i + 1) % evaluate_every == 0:
+                        self.evaluate()
             return optimizer
 
-        def step_for(smp):
+        def step_for(smp, opt=None):
+            """the captured step for this batch shape; `opt`: share this optimiser (a ragged last batch of the same stage call)"""
             if not torch.is_tensor(smp["timestep_index"]):
                 smp = dict(smp, timestep_index=torch.as_tensor(np.asarray(smp["timestep_index"]), device=self.device))
             key = (stage, tuple(smp["rgb"].shape), float(lr_scale))
             st = self._graphed.get(key)
+            if st is not None and opt is not None and st.opt is not opt:
+                st = None                                             # captured against another optimiser: capture again
             if st is None:
-                opt = self.configure_optimizer(self.get_train_parameters(stage), lr_scale=lr_scale)
+                params = self.get_train_parameters(stage)
+                if opt is None:
+                    opt = self.configure_optimizer(params, lr_scale=lr_scale)
                 st = self._graphed[key] = GraphedStep(self, smp, opt, stage, warmup=0)
                 st.fresh = True
             else:
@@ -680,22 +715,23 @@ class GlobalTracker(FlameTracker):
                 st()
             return st.opt
         assert dataloader is not None
-        st, sched = None, None
-        for _ in range(self.cfg.pipeline[stage].num_epochs):
+        opt, sched = None, None
+        for epoch_i in range(self.cfg.pipeline[stage].num_epochs):
             for s in dataloader:
-                if st is None:
-                    st = step_for(s)
+                st = step_for(s, opt)                              # one optimiser (one Adam state) for every batch shape of this call
+                if opt is None:
+                    opt = st.opt
                     if not getattr(st, "fresh", False):
-                        st.opt.reset_state(lr_scale_base=None)
-                    st.fresh = False
-                    for grp in st.opt.param_groups:               # a scheduler of a previous call may have decayed them
+                        opt.reset_state(lr_scale_base=None)
+                    for grp in opt.param_groups:                  # a scheduler of a previous call may have decayed them
                         grp["lr"] = grp["initial_lr"] if "initial_lr" in grp else grp["lr"]
-                    sched = torch.optim.lr_scheduler.ExponentialLR(st.opt, gamma=0.9)
-                else:
-                    st.update_sample(s)
+                    sched = torch.optim.lr_scheduler.ExponentialLR(opt, gamma=0.9)
+                st.fresh = False
                 st()
             sched.step()
-        return st.opt
+            if evaluate_every and (epoch_i + 1) % evaluate_every == 0:
+                self.evaluate()
+        return opt
 
     def optimize_iter(self, sample, optimizer, stage, disturbance=None):
         """tracker.py:1418-1462 without the logging branches."""
@@ -811,6 +847,24 @@ class GlobalTracker(FlameTracker):
                 photo[t0:t0 + len(ts)] = w.photo * abs_sum / n_mask
         photo, lmk = photo.cpu().numpy(), lmk.cpu().numpy()
         return {"photo": photo, "lmk": lmk, "mean_photo": float(photo.mean()), "mean_lmk": float(lmk.mean())}
+
+
+class ShuffledBatches:
+    """What DataLoader(dataset, batch_size, shuffle=True) is to the reference's global tracking (tracker.py:1376-1385): every pass over
+    it yields the frames once, in a fresh random order, in batches (the last one may be smaller)."""
+
+    shuffle = True
+
+    def __init__(self, tracker, batch_size, device_index=False, generator=None):
+        self.tr, self.bs, self.device_index, self.gen = tracker, int(batch_size), device_index, generator
+
+    def __len__(self):
+        return (self.tr.n_timesteps + self.bs - 1) // self.bs
+
+    def __iter__(self):
+        perm = torch.randperm(self.tr.n_timesteps, generator=self.gen).numpy()
+        for i in range(0, len(perm), self.bs):
+            yield self.tr.get_sample(perm[i:i + self.bs], device_index=self.device_index)
 
 
 class GraphedStep:
