@@ -118,6 +118,12 @@ def test_product_host_energies_match_reference(flame_model):
             assert abs(float(log[k].detach()) - want) <= 2e-4 * abs(want) + 1e-9, (stage, k, float(log[k].detach()), want)
     sample = {"rgb": torch.zeros(len(ts), 3, H, W), "lmk2d": torch.from_numpy(G["lmk2d"]).float()}
     tr.fill_cam_params_into_sample(sample)
+    # the renderer's camera helpers (host-side torch code of HipDiffRenderer) against the reference's world_to_clip / world_to_ndc
+    with torch.no_grad():
+        clip = tr.render.world_to_clip(verts, sample["extrinsic"], sample["intrinsic"], (H, W))
+        ndc = tr.render.world_to_ndc(lmks, sample["extrinsic"], sample["intrinsic"], (H, W), flip_y=True)
+    assert float((clip.double() - torch.from_numpy(G["clip_ref"]).double()).abs().max()) < 2e-5
+    assert float((ndc.double() - torch.from_numpy(G["ndc_ref"])).abs().max()) < 2e-5
     out = _ref("out/")
     for dis in (False, True):
         for always in (True, False):
