@@ -439,3 +439,17 @@ def test_stage_scheduler_matches_reference(flame_model):
                 assert got[0] == "evaluate"
             else:
                 assert len(got) == len(w) and all(abs(a - b) <= 1e-12 * abs(b) for a, b in zip(got, w)), (stage, got, w)
+
+
+def test_op_shim_accepts_the_reference_call_sites():
+    """How the reference's renderer actually calls nvdiffrast (names, positional counts, keyword names -- recorded while its render_rgba /
+    rasterize ran in the build container) binds to vhap_amd.ops, so that `sys.modules['nvdiffrast.torch'] = vhap_amd.ops` serves
+    render_nvdiffrast.py unmodified."""
+    import inspect
+    import json
+    from vhap_amd import ops
+    calls = json.loads(str(G["dr_calls/json"]))
+    assert {c[0] for c in calls} == {"RasterizeCudaContext", "rasterize", "interpolate", "texture", "antialias"}
+    for name, npos, kws in calls:
+        fn = getattr(ops, name)
+        inspect.signature(fn).bind(*([None] * npos), **{k: None for k in kws})           # raises TypeError if the call would not bind

@@ -223,11 +223,18 @@ def main():
         rast_np, _ = oracle.rasterize(clip.detach().float().numpy(), tri.numpy().astype(np.int32), tuple(size))
         stash["tid"] = torch.from_numpy(rast_np[..., 3].astype(np.int64) - 1)
         return R.rast_from_ids(clip, tri.long(), stash["tid"], tuple(size))
-    dr.rasterize = dr_rasterize
-    dr.interpolate = lambda attr, rast, tri, rast_db=None, diff_attrs=None: R.interpolate(attr, rast, tri.long(), rast_db, diff_attrs)
-    dr.texture = lambda tex, uv, uv_da=None, filter_mode="linear", max_mip_level=None: R.texture(tex, uv, uv_da, filter_mode)
-    dr.antialias = lambda color, rast, pos, tri: R.antialias(color, rast, pos, tri.long(), opp)
-    dr.RasterizeCudaContext = lambda: None
+    dr_calls = set()                                                  # how the reference calls into nvdiffrast: (name, #positional, keyword names)
+
+    def traced(name, fn):
+        def w(*a, **k):
+            dr_calls.add((name, len(a), tuple(sorted(k))))
+            return fn(*a, **k)
+        return w
+    dr.rasterize = traced("rasterize", dr_rasterize)
+    dr.interpolate = traced("interpolate", lambda attr, rast, tri, rast_db=None, diff_attrs=None: R.interpolate(attr, rast, tri.long(), rast_db, diff_attrs))
+    dr.texture = traced("texture", lambda tex, uv, uv_da=None, filter_mode="linear", max_mip_level=None: R.texture(tex, uv, uv_da, filter_mode))
+    dr.antialias = traced("antialias", lambda color, rast, pos, tri: R.antialias(color, rast, pos, tri.long(), opp))
+    dr.RasterizeCudaContext = traced("RasterizeCudaContext", lambda: None)
     rn.torch = types.SimpleNamespace(**{k: getattr(torch, k) for k in dir(torch) if not k.startswith("__")})
     rn.torch.tensor = lambda *a, **k: real_tensor(*a, **{kk: vv for kk, vv in k.items() if kk != "device"})
     rend2 = rn.NVDiffRenderer(use_opengl=False, lighting_type="SH", lighting_space="world", disturb_rate_fg=0.5, disturb_rate_bg=0.5,
@@ -467,6 +474,7 @@ def main():
 
     save = {f"P/{k}": v.numpy() for k, v in P.items()}
     save["sched/json"] = np.array(json.dumps({"trace": trace, "stage_calls": sched}))
+    save["dr_calls/json"] = np.array(json.dumps(sorted([n, k, list(kw)] for n, k, kw in dr_calls)))
     save["schema/json"] = np.array(json.dumps(schema))
     save.update({f"full/{k}": v for k, v in full_out.items()})
     save["host/json"] = np.array(json.dumps(host))

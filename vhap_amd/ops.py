@@ -98,6 +98,12 @@ class RasterizeHipContext:
         return alloc(nbytes, dtype=torch.uint8, device=device), nbytes, cap
 
 
+
+# nvdiffrast's constructor names, so that `sys.modules['nvdiffrast.torch'] = vhap_amd.ops` serves the reference's
+# render_nvdiffrast.py unmodified (render_nvdiffrast.py:74: dr.RasterizeGLContext() if use_opengl else dr.RasterizeCudaContext())
+RasterizeCudaContext = RasterizeHipContext
+RasterizeGLContext = RasterizeHipContext
+
 def _check_raster_args(pos, tri, resolution):
     if pos.dim() != 3 or pos.shape[-1] != 4:
         raise ValueError("pos must have shape [B, V, 4] (instanced mode)")
