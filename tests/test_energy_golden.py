@@ -453,3 +453,16 @@ def test_op_shim_accepts_the_reference_call_sites():
     for name, npos, kws in calls:
         fn = getattr(ops, name)
         inspect.signature(fn).bind(*([None] * npos), **{k: None for k in kws})           # raises TypeError if the call would not bind
+
+
+def test_renderer_surface_accepts_the_reference_tracker_calls():
+    """Boundary b1: the positional / keyword shape of every call the reference's FlameTracker makes into its renderer (recorded while its
+    compute_energy ran in the build container) binds to HipDiffRenderer's methods."""
+    import inspect
+    import json
+    from vhap_amd.render_hip import HipDiffRenderer
+    calls = json.loads(str(G["rend_calls/json"]))
+    assert {c[0] for c in calls} >= {"rasterize", "render_rgba", "world_to_ndc", "clear_cache"}
+    for name, npos, kws in calls:
+        fn = getattr(HipDiffRenderer, name)
+        inspect.signature(fn).bind(*([None] * (npos + 1)), **{k: None for k in kws})     # (+1: self)

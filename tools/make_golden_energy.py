@@ -376,6 +376,14 @@ def main():
     fh32.textures_idx, fh32.verts_uvs = faces_uv_l, tm["verts_uvs"].to(f32)
     fh32.laplacian_matrix = Lap.to(f32)
     fh32.laplacian_matrix_negate_diag = (Lap - 2 * torch.diag(torch.diag(Lap))).to(f32)
+    rend_calls = set()                                                # how the reference TRACKER calls its renderer (boundary b1)
+    for mname in ("rasterize", "render_rgba", "world_to_ndc", "clear_cache"):
+        def wrap(fn, mname=mname):
+            def w(*a, **k):
+                rend_calls.add((mname, len(a), tuple(sorted(k))))
+                return fn(*a, **k)
+            return w
+        setattr(rend2, mname, wrap(getattr(rend2, mname)))
     rgb9 = torch.rand(B, 3, H9, W9, generator=g).to(f32)
     full_out = {"rgb": rgb9.numpy()}
     leafs = ("shape", "expr", "rotation", "neck_pose", "jaw_pose", "eyes_pose", "translation", "tex_extra", "lights", "static_offset", "focal_length")
@@ -474,6 +482,7 @@ def main():
 
     save = {f"P/{k}": v.numpy() for k, v in P.items()}
     save["sched/json"] = np.array(json.dumps({"trace": trace, "stage_calls": sched}))
+    save["rend_calls/json"] = np.array(json.dumps(sorted([n, k, list(kw)] for n, k, kw in rend_calls)))
     save["dr_calls/json"] = np.array(json.dumps(sorted([n, k, list(kw)] for n, k, kw in dr_calls)))
     save["schema/json"] = np.array(json.dumps(schema))
     save.update({f"full/{k}": v for k, v in full_out.items()})
