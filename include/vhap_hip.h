@@ -2,7 +2,9 @@
  * vhap_hip.h -- C ABI of libvhap_hip.so, the MI355X (gfx950) implementation of the
  * photometric FLAME-fitting hot path of ShenhanQian/VHAP.
  *
- * Every entry point is stateless and re-entrant: the caller owns all buffers (device pointers,
+ * Every entry point is stateless and re-entrant -- the library has NO mutable global state (ABI 2: the per-call behaviour
+ * switches that ABI 1 kept in a process-wide variable are the `call_flags` argument of the entry points that honour them):
+ * the caller owns all buffers (device pointers,
  * row-major, contiguous, fp32 / int32), passes an explicit workspace where one is needed, and
  * the HIP stream to enqueue on (as void*, i.e. a hipStream_t; NULL = default stream).  Calls
  * return immediately after enqueueing.  Return value: VHAP_OK (0) or a negative VHAP_E_* code;
@@ -24,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VHAP_ABI_VERSION 1
+#define VHAP_ABI_VERSION 2
 
 #define VHAP_OK 0
 #define VHAP_E_NULLPTR (-1)   /* a required pointer is NULL */
@@ -37,9 +39,15 @@ typedef void* vhap_stream_t;
 
 int vhap_abi_version(void);
 const char* vhap_strerror(int code);
-/* Profiling-only ablation switches (bit 0: rasterizer skips triangle work, bit 1: skips stores).
- * Never set in production; 0 restores normal behaviour. */
-void vhap_debug_set_flags(int flags);
+/* call_flags (an argument of the entry points that honour them; 0 = the plain behaviour):
+ *   VHAP_CALL_ACC_PREZEROED       the small accumulators this call adds into (terms / energy / stats / out2 of frame_prep, landmark,
+ *                                 tex_prep, offset_reg, shade, photo; d_coef of flame_skin_bwd) were zero-filled by the caller --
+ *                                 a step executor keeps all of them in one arena cleared by ONE launch; the call skips its own clear
+ *   VHAP_CALL_AA_PASSTHROUGH_DONE vhap_antialias_bwd: d_color already holds a copy of d_out (skip the pass-through copy)
+ *   VHAP_CALL_ADAM_KEEP_STEP      vhap_adam_step: do not advance the step counter (a further call of the same step follows) */
+#define VHAP_CALL_ACC_PREZEROED 1
+#define VHAP_CALL_AA_PASSTHROUGH_DONE 2
+#define VHAP_CALL_ADAM_KEEP_STEP 4
 
 /* ---------------------------------------------------------------------------------------------
  * Rasterize: replaces dr.rasterize(glctx, pos, tri, resolution)  (render_nvdiffrast.py:254,257)
@@ -160,7 +168,7 @@ int vhap_antialias_fwd(const float* color, const float* rast, const float* pos,
 int vhap_antialias_bwd(const float* color, const float* rast, const float* pos,
                        const int32_t* tri, const int32_t* opp, const float* d_out,
                        const int32_t* work, const uint8_t* pos_nograd_verts, int B, int H, int W,
-                       int C, int V, int F, float* d_color, float* d_pos, vhap_stream_t stream);
+                       int C, int V, int F, float* d_color, float* d_pos, int call_flags, vhap_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Per-pixel shading / compositing and the photometric sum (vhap_amd/csrc/pixel.hip).
@@ -180,7 +188,7 @@ int vhap_antialias_bwd(const float* color, const float* rast, const float* pos,
 int vhap_shade_fwd(const float* normal_raw, const float* albedo, const float* rast,
                    const float* bg_image, const float* bg_color, const float* lights,
                    const float* sh_const, const int32_t* fid2cid, int nfid, int B, int H, int W,
-                   float* rgba, float* stats, uint8_t* cid, vhap_stream_t stream);
+                   float* rgba, float* stats, uint8_t* cid, int call_flags, vhap_stream_t stream);
 int vhap_shade_bwd(const float* normal_raw, const float* albedo, const float* rast,
                    const float* lights, const float* sh_const, const float* d_rgba, const float* keep,
                    const float* d_reg, const float* stats, int B, int H, int W, float* d_albedo,
@@ -189,7 +197,7 @@ int vhap_shade_bwd(const float* normal_raw, const float* albedo, const float* ra
  * gt [B,3,H,W] image space.  Backward: d_pred.rgb = -sign(gt - pred) * d_sum[0] (device scalar); d_pred_copy (may be NULL)
  * receives the same values -- hand it to vhap_antialias_bwd as d_color with VHAP_CALL_AA_PASSTHROUGH_DONE set. */
 int vhap_photo_fwd(const float* pred_rgba, const float* gt_nchw, int B, int H, int W, float* out2,
-                   vhap_stream_t stream);
+                   int call_flags, vhap_stream_t stream);
 int vhap_photo_bwd(const float* pred_rgba, const float* gt_nchw, const float* d_sum, int B, int H,
                    int W, float* d_pred, float* d_pred_copy, vhap_stream_t stream);
 
@@ -212,7 +220,8 @@ size_t vhap_flame_bwd_partial_floats(int B, int Vp, int Kp);
 int vhap_flame_skin_bwd(const float* d_verts, const float* d_vshaped, const float* v_posed,
                         const float* A, const float* lbs_weights, const float* basisT, int B, int V,
                         int Vp, int Kb, int Kp, float* g_posed, float* g_shaped, float* partials,
-                        float* d_coef, float* d_A, float* d_transl, vhap_stream_t stream);
+                        float* d_coef, float* d_A, float* d_transl, int call_flags,
+                        vhap_stream_t stream);
 /* clip [B,V,4] = [verts;1] @ M^T, M [B,4,4]; backward: d_verts (= or += when accumulate), d_M ACCUMULATED */
 int vhap_transform_fwd(const float* verts, const float* M, int B, int V, float* clip,
                        vhap_stream_t stream);
@@ -278,7 +287,7 @@ int vhap_frame_prep_fwd(const int64_t* timesteps, const float* shape, const floa
                         const float* static_offset, const int32_t* parents,
                         const float* weights, int B, int Bp, int N, int NS, int NE, int J, int Kp, int V,
                         float* coef, float* A, float* transl, float* Jrest, float* terms,
-                        vhap_stream_t stream);
+                        int call_flags, vhap_stream_t stream);
 int vhap_frame_prep_bwd(const int64_t* timesteps, const float* shape, const float* expr,
                         const float* rotation, const float* translation, const float* neck,
                         const float* jaw, const float* eyes, const float* JS, const int32_t* jreg_idx,
@@ -302,7 +311,8 @@ int vhap_camera_bwd(const float* RT, const float* d_mvp, int B, int RT_batched, 
  * bwd: d_verts [B,V,3] ACCUMULATED, d_mvp [B,16] overwritten (may be NULL). */
 int vhap_landmark_fwd(const float* verts, const int32_t* lmk_vidx, const float* lmk_bary, const float* mvp,
                       const float* lmk2d, int B, int V, int L, int L2, int l0, int l1, int boost0, int boost1,
-                      float boost, int H, int W, float* lmk3d, float* energy, vhap_stream_t stream);
+                      float boost, int H, int W, float* lmk3d, float* energy, int call_flags,
+                      vhap_stream_t stream);
 int vhap_landmark_bwd(const float* verts, const int32_t* lmk_vidx, const float* lmk_bary, const float* mvp,
                       const float* lmk2d, const float* d_energy, int B, int V, int L, int L2, int l0, int l1,
                       int boost0, int boost1, float boost, int H, int W, float* d_verts, float* d_mvp,
@@ -326,46 +336,39 @@ int vhap_landmark_bwd(const float* verts, const int32_t* lmk_vidx, const float* 
 int vhap_offset_reg_fwd(const float* offset, const int32_t* lap_ptr, const int32_t* lap_col,
                         const float* lap_val, const float* w_lap, const float* w_abs,
                         const int32_t* region_ptr, const int32_t* region_idx, int V, int n_regions,
-                        float s_lap, float s_abs, float s_rigid, float* terms, vhap_stream_t stream);
+                        float s_lap, float s_abs, float s_rigid, float* terms, int call_flags,
+                        vhap_stream_t stream);
 int vhap_offset_reg_bwd(const float* offset, const int32_t* lap_ptr, const int32_t* lap_col,
                         const float* lap_val, const float* w_lap, const float* w_abs,
                         const int32_t* region_ptr, const int32_t* region_idx, int V, int n_regions,
                         float s_lap, float s_abs, float s_rigid, const float* d_terms, float* d_offset,
                         vhap_stream_t stream);
 int vhap_tex_prep_fwd(const float* painted, const float* extra, const uint8_t* res_mask, int T, float s_tv,
-                      float s_res, float* albedo_hwc, float* terms, vhap_stream_t stream);
+                      float s_res, float* albedo_hwc, float* terms, int call_flags, vhap_stream_t stream);
 int vhap_tex_prep_bwd(const float* albedo_hwc, const float* extra, const uint8_t* res_mask,
                       const float* d_albedo_hwc, const float* d_mips_hwc, int n_gather, const float* d_terms,
                       int T, float s_tv, float s_res, float* d_extra, vhap_stream_t stream);
 int vhap_adam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                    float* const* exp_avg_sq, const int64_t* numel, const int32_t* lr_index,
                    const float* lr_device, int32_t* step_device, float beta1, float beta2, float eps,
-                   vhap_stream_t stream);
+                   int call_flags, vhap_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Step glue (vhap_amd/csrc/step.hip, misc.hip) for an executor that chains the stages itself instead of torch autograd
  * (vhap_amd/step.py): the assembly of the total energy (tracker.py:692-750), the batch-global photometric normaliser
  * (tracker.py:430-439), the static-offset gradient summed over frames and the focal-length gradient (tracker.py:141-157).
  *
- * vhap_set_call_flags(VHAP_CALL_ACC_PREZEROED): process-wide; while set, the entry points that normally clear their small
- *   accumulators first (terms / energy / stats / out2 of frame_prep, landmark, tex_prep, offset_reg, shade, photo; d_coef of
- *   flame_skin_bwd) skip that launch -- the caller hands in accumulators from an arena it cleared with ONE launch.
  * vhap_energy_finalize: log[VHAP_LOG_COUNT] <- the weighted terms (any input may be NULL = term absent); log[VHAP_LOG_REST] = sum
  *   of everything but the photometric term.
  * vhap_energy_total: inv_n = world_size / (3 n_global); log[PHOTO] = w_photo * photo2[0] * inv_n; log[TOTAL]; d_sum[0] = w_photo * inv_n
  *   (the upstream gradient handed to vhap_photo_bwd).
  * ------------------------------------------------------------------------------------------- */
-#define VHAP_CALL_ACC_PREZEROED 1
-#define VHAP_CALL_AA_PASSTHROUGH_DONE 2   /* vhap_antialias_bwd: d_color already holds a copy of d_out (skip the pass-through copy) */
-#define VHAP_CALL_ADAM_KEEP_STEP 4        /* vhap_adam_step: do not advance the step counter (a further call of the same step follows) */
 enum {
     VHAP_LOG_LMK = 0, VHAP_LOG_PHOTO = 1, VHAP_LOG_SMOOTH_POSE = 2, VHAP_LOG_REG_JOINT = 3, VHAP_LOG_SMOOTH_JOINT = 4,
     VHAP_LOG_REG_EXPR = 5, VHAP_LOG_SMOOTH_EXPR = 6, VHAP_LOG_REG_SHAPE = 7, VHAP_LOG_TEX_TV = 8, VHAP_LOG_TEX_RES = 9,
     VHAP_LOG_REG_DIFFUSE = 10, VHAP_LOG_OFF_LAP = 11, VHAP_LOG_OFF_ABS = 12, VHAP_LOG_OFF_RIGID = 13, VHAP_LOG_REST = 14,
     VHAP_LOG_TOTAL = 15, VHAP_LOG_COUNT = 16
 };
-void vhap_set_call_flags(int flags);
-int vhap_get_call_flags(void);
 int vhap_energy_finalize(const float* frame_terms, const float* lmk_energy, const float* tex_terms,
                          const float* off_terms, const float* shade_stats, float w_landmark,
                          float w_reg_diffuse, int B, int H, int W, float* log, vhap_stream_t stream);

@@ -33,8 +33,8 @@ tr, own, model, topo, gt = bench.build_tracker(0, 1, "cuda:0")
 opt = tr.configure_optimizer(tr.get_train_parameters(bench.STAGE), lr_scale=0.0)
 sample = tr.get_sample(own, device_index=True)
 for f in flags:
-    _lib.lib().vhap_debug_set_flags(f)
+    _lib.debug_set_flags(f)
     for _ in range(STEPS):
         tr.optimize_iter(dict(sample), opt, bench.STAGE)
     torch.cuda.synchronize()
-_lib.lib().vhap_debug_set_flags(0)
+_lib.debug_set_flags(0)

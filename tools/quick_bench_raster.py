@@ -18,7 +18,7 @@ uv = c(topo.verts_uvs.astype(np.float32))
 vn = HipDiffRenderer(lighting_type="SH").cuda().compute_v_normals(sc["verts"].float().cuda(), torch.from_numpy(topo.faces.astype(np.int64)).cuda()).contiguous()
 ctx = ops.RasterizeHipContext()
 from vhap_amd import _lib
-_lib.lib().vhap_debug_set_flags(int(os.environ.get('VHAP_DEBUG', '0')))
+_lib.debug_set_flags(int(os.environ.get('VHAP_DEBUG', '0')))
 for fused in (False, True):
     f = (lambda: ops.raster_interp_fwd(ctx, pos, tri, vn, uv, tri_uv, (H, W))) if fused else (lambda: ops.raster_fwd(ctx, pos, tri, (H, W)))
     for _ in range(5): f()

@@ -21,7 +21,6 @@ c_f = ctypes.c_float
 SIGNATURES = {
     "vhap_abi_version": (c_i, []),
     "vhap_strerror": (ctypes.c_char_p, [c_i]),
-    "vhap_debug_set_flags": (None, [c_i]),
     "vhap_raster_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_sz]),
     "vhap_raster_fwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_sz, c_sz, c_i, c_fp]),
     "vhap_raster_interp_fwd": (c_i, [c_fp] * 5 + [c_i] * 6 + [c_fp] * 5 + [c_fp, c_sz, c_sz, c_i, c_fp]),
@@ -39,42 +38,44 @@ SIGNATURES = {
     "vhap_texture_grad_binned": (c_i, [c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_sz, c_fp]),
     "vhap_antialias_work_ints": (c_sz, [c_i] * 4),
     "vhap_antialias_fwd": (c_i, [c_fp] * 5 + [c_i] * 6 + [c_fp, c_fp, c_fp]),
-    "vhap_antialias_bwd": (c_i, [c_fp] * 8 + [c_i] * 6 + [c_fp, c_fp, c_fp]),
+    "vhap_antialias_bwd": (c_i, [c_fp] * 8 + [c_i] * 6 + [c_fp, c_fp, c_i, c_fp]),
     "vhap_disturb_workspace_ints": (c_sz, [c_i] * 3),
     "vhap_disturb_fwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
     "vhap_disturb_fwd_rng": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_f, c_f, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
     "vhap_disturb_fwd_rng_cid": (c_i, [c_fp, c_fp, c_i, c_f, c_f, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
     "vhap_disturb_bwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp]),
-    "vhap_shade_fwd": (c_i, [c_fp] * 8 + [c_i] * 4 + [c_fp] * 4),
+    "vhap_shade_fwd": (c_i, [c_fp] * 8 + [c_i] * 4 + [c_fp] * 3 + [c_i, c_fp]),
     "vhap_shade_bwd": (c_i, [c_fp] * 9 + [c_i] * 3 + [c_fp] * 4),
-    "vhap_photo_fwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp]),
+    "vhap_photo_fwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp, c_i, c_fp]),
     "vhap_photo_bwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
     "vhap_flame_skin_fwd": (c_i, [c_fp] * 7 + [c_i] * 6 + [c_fp] * 4),
     "vhap_flame_bwd_partial_floats": (c_sz, [c_i] * 3),
-    "vhap_flame_skin_bwd": (c_i, [c_fp] * 6 + [c_i] * 5 + [c_fp] * 7),
+    "vhap_flame_skin_bwd": (c_i, [c_fp] * 6 + [c_i] * 5 + [c_fp] * 6 + [c_i, c_fp]),
     "vhap_transform_fwd": (c_i, [c_fp, c_fp, c_i, c_i, c_fp, c_fp]),
     "vhap_transform_bwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
     "vhap_vnormal_fwd": (c_i, [c_fp] * 4 + [c_i, c_i, c_fp, c_fp]),
     "vhap_vnormal_bwd": (c_i, [c_fp] * 5 + [c_i, c_i, c_i, c_fp, c_fp, c_fp]),
-    "vhap_frame_prep_fwd": (c_i, [c_fp] * 12 + [c_i] + [c_fp] * 3 + [c_i] * 8 + [c_fp] * 6),
+    "vhap_frame_prep_fwd": (c_i, [c_fp] * 12 + [c_i] + [c_fp] * 3 + [c_i] * 8 + [c_fp] * 5 + [c_i, c_fp]),
     "vhap_frame_prep_bwd": (c_i, [c_fp] * 11 + [c_i] + [c_fp] * 8 + [c_i] * 8 + [c_fp] * 9),
     "vhap_camera_fwd": (c_i, [c_fp, c_fp] + [c_i] * 5 + [c_f, c_f, c_fp, c_fp]),
     "vhap_camera_bwd": (c_i, [c_fp, c_fp] + [c_i] * 4 + [c_fp, c_fp]),
-    "vhap_landmark_fwd": (c_i, [c_fp] * 5 + [c_i] * 8 + [c_f, c_i, c_i] + [c_fp] * 3),
+    "vhap_landmark_fwd": (c_i, [c_fp] * 5 + [c_i] * 8 + [c_f, c_i, c_i] + [c_fp] * 2 + [c_i, c_fp]),
     "vhap_landmark_bwd": (c_i, [c_fp] * 6 + [c_i] * 8 + [c_f, c_i, c_i] + [c_fp] * 3),
-    "vhap_offset_reg_fwd": (c_i, [c_fp] * 8 + [c_i, c_i, c_f, c_f, c_f, c_fp, c_fp]),
+    "vhap_offset_reg_fwd": (c_i, [c_fp] * 8 + [c_i, c_i, c_f, c_f, c_f, c_fp, c_i, c_fp]),
     "vhap_offset_reg_bwd": (c_i, [c_fp] * 8 + [c_i, c_i, c_f, c_f, c_f, c_fp, c_fp, c_fp]),
-    "vhap_tex_prep_fwd": (c_i, [c_fp] * 3 + [c_i, c_f, c_f] + [c_fp] * 3),
+    "vhap_tex_prep_fwd": (c_i, [c_fp] * 3 + [c_i, c_f, c_f] + [c_fp] * 2 + [c_i, c_fp]),
     "vhap_tex_prep_bwd": (c_i, [c_fp] * 5 + [c_i, c_fp, c_i, c_f, c_f] + [c_fp] * 2),
-    "vhap_set_call_flags": (None, [c_i]),
-    "vhap_get_call_flags": (c_i, []),
     "vhap_energy_finalize": (c_i, [c_fp] * 5 + [c_f, c_f, c_i, c_i, c_i, c_fp, c_fp]),
     "vhap_energy_total": (c_i, [c_fp, c_fp, c_fp, c_f, c_i, c_fp, c_fp]),
     "vhap_sum_frames": (c_i, [c_fp, c_i, c_i, c_fp, c_fp]),
     "vhap_focal_bwd": (c_i, [c_fp, c_i, c_f, c_fp, c_fp]),
-    "vhap_adam_step": (c_i, [c_i] + [c_fp] * 8 + [c_f, c_f, c_f, c_fp]),
+    "vhap_adam_step": (c_i, [c_i] + [c_fp] * 8 + [c_f, c_f, c_f, c_i, c_fp]),
     "vhap_frame_ingest": (c_i, [c_fp, c_fp, c_fp] + [c_i] * 5 + [c_fp] * 4),
 }
+
+ABI_VERSION = 2
+# call_flags of include/vhap_hip.h (per-call arguments since ABI 2; the library keeps no mutable state)
+CALL_ACC_PREZEROED, CALL_AA_PASSTHROUGH_DONE, CALL_ADAM_KEEP_STEP = 1, 2, 4
 
 _lib = None
 
@@ -95,10 +96,17 @@ def lib():
             fn = getattr(L, name)          # AttributeError if the .so lacks a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if L.vhap_abi_version() != 1:
+        if L.vhap_abi_version() != ABI_VERSION:
             raise VhapHipError("libvhap_hip.so ABI version mismatch")
         _lib = L
     return _lib
+
+
+def debug_set_flags(flags):
+    """Profiling-only A/B switches of the CALLING THREAD (thread-local in the library; not part of the stable ABI)."""
+    fn = lib().vhap_debug_set_flags
+    fn.restype, fn.argtypes = None, [c_i]
+    fn(int(flags))
 
 
 def check(code, what=""):

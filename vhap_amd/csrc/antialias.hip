@@ -365,13 +365,13 @@ extern "C" int vhap_antialias_fwd(const float* color, const float* rast, const f
 
 extern "C" int vhap_antialias_bwd(const float* color, const float* rast, const float* pos, const int32_t* tri,
                                    const int32_t* opp, const float* d_out, const int32_t* work, const uint8_t* pos_nograd_verts, int B,
-                                   int H, int W, int C, int V, int F, float* d_color, float* d_pos, vhap_stream_t stream) {
+                                   int H, int W, int C, int V, int F, float* d_color, float* d_pos, int call_flags, vhap_stream_t stream) {
     VHAP_ENTER();
     if (!color || !rast || !pos || !tri || !opp || !d_out || !work) return VHAP_E_NULLPTR;
     if (B <= 0 || H <= 0 || W <= 0 || V <= 0 || F <= 0) return VHAP_E_BADDIM;
     hipStream_t st = vhap_stream(stream);
     const long long n = (long long)B * H * W * C;
-    if (d_color && !(vhap_g_call_flags & VHAP_CALL_AA_PASSTHROUGH_DONE)) {   // pass-through part of the gradient
+    if (d_color && !(call_flags & VHAP_CALL_AA_PASSTHROUGH_DONE)) {   // pass-through part of the gradient
         vhap_copy_async(d_color, d_out, sizeof(float) * n, st);
         VHAP_LAUNCH_CHECK();
     }

@@ -15,14 +15,15 @@
         if (vhap_e_ != hipSuccess && vhap_e_ != hipErrorNotReady) return VHAP_E_HIP; \
     } while (0)
 
-extern int vhap_g_debug_flags;   // misc.hip
-extern int vhap_g_call_flags;    // misc.hip: VHAP_CALL_* (vhap_set_call_flags)
+// Profiling-only A/B switches: thread-local (a profiling script sets them on its own thread; nothing in the product path does),
+// so entry points stay re-entrant.  misc.hip
+extern thread_local int vhap_g_debug_flags;
 
-// zero a small accumulator unless the caller declared that it hands in pre-zeroed accumulators (step executors keep all of them in
-// one arena cleared by a single launch)
+// zero a small accumulator unless the caller declared -- in the `call_flags` argument of THIS call -- that it hands in pre-zeroed
+// accumulators (step executors keep all of them in one arena cleared by a single launch)
 #define VHAP_ZERO_ACC(ptr, bytes, st)                                   \
     do {                                                                \
-        if (!(vhap_g_call_flags & VHAP_CALL_ACC_PREZEROED)) {           \
+        if (!(call_flags & VHAP_CALL_ACC_PREZEROED)) {                  \
             vhap_zero_async((ptr), (bytes), (st));                      \
             VHAP_LAUNCH_CHECK();                                        \
         }                                                               \

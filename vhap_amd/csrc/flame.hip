@@ -363,7 +363,7 @@ extern "C" size_t vhap_flame_bwd_partial_floats(int B, int Vp, int Kp) {
 extern "C" int vhap_flame_skin_bwd(const float* d_verts, const float* d_vshaped, const float* v_posed, const float* A,
                                    const float* lbs_weights, const float* basisT, int B, int V, int Vp, int Kb, int Kp,
                                    float* g_posed, float* g_shaped, float* partials, float* d_coef, float* d_A, float* d_transl,
-                                   vhap_stream_t stream) {
+                                   int call_flags, vhap_stream_t stream) {
     VHAP_ENTER();
     if (!d_verts || !v_posed || !A || !lbs_weights || !basisT || !g_posed || !g_shaped || !d_coef || !d_A || !d_transl)
         return VHAP_E_NULLPTR;

@@ -528,7 +528,7 @@ extern "C" int vhap_frame_prep_fwd(const int64_t* timesteps, const float* shape,
                                    const float* JT, const float* JS, const int32_t* jreg_idx, const float* jreg_w, int jreg_n,
                                    const float* static_offset, const int32_t* parents, const float* weights, int B, int Bp, int N,
                                    int NS, int NE, int J, int Kp, int V, float* coef, float* A, float* transl, float* Jrest, float* terms,
-                                   vhap_stream_t stream) {
+                                   int call_flags, vhap_stream_t stream) {
     VHAP_ENTER();
     if (!timesteps || !shape || !expr || !rotation || !translation || !neck || !jaw || !eyes || !JT || !JS || !coef || !A ||
         !transl || !Jrest || !terms)
@@ -720,7 +720,7 @@ static bool make_lmk_cfg(LmkCfg& c, int B, int V, int L, int L2, int l0, int l1,
 
 extern "C" int vhap_landmark_fwd(const float* verts, const int32_t* lmk_vidx, const float* lmk_bary, const float* mvp,
                                  const float* lmk2d, int B, int V, int L, int L2, int l0, int l1, int boost0, int boost1, float boost,
-                                 int H, int W, float* lmk3d, float* energy, vhap_stream_t stream) {
+                                 int H, int W, float* lmk3d, float* energy, int call_flags, vhap_stream_t stream) {
     VHAP_ENTER();
     if (!verts || !lmk_vidx || !lmk_bary || !mvp || !lmk2d || !energy) return VHAP_E_NULLPTR;
     LmkCfg c;

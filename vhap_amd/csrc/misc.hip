@@ -17,10 +17,8 @@ extern "C" const char* vhap_strerror(int code) {
 }
 
 // Profiling / A-B switches (not part of the stable ABI): 16 = strided row order in the rasteriser, 32 = per-pixel texture backward
-int vhap_g_debug_flags = 0;
-int vhap_g_call_flags = 0;
-extern "C" void vhap_set_call_flags(int flags) { vhap_g_call_flags = flags; }
-extern "C" int vhap_get_call_flags(void) { return vhap_g_call_flags; }
+// thread-local: the calling (profiling) thread only; not part of the stable ABI (not declared in vhap_hip.h)
+thread_local int vhap_g_debug_flags = 0;
 extern "C" void vhap_debug_set_flags(int flags) { vhap_g_debug_flags = flags; }
 
 // Calibration helpers for PMC-based traffic measurements (tools/ri_fwd_pmc.py): known byte counts through the library's own

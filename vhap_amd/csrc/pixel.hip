@@ -329,7 +329,7 @@ int check_img(int B, int H, int W) {
 
 extern "C" int vhap_shade_fwd(const float* normal_raw, const float* albedo, const float* rast, const float* bg_image,
                               const float* bg_color, const float* lights, const float* sh_const, const int32_t* fid2cid, int nfid,
-                              int B, int H, int W, float* rgba, float* stats, uint8_t* cid, vhap_stream_t stream) {
+                              int B, int H, int W, float* rgba, float* stats, uint8_t* cid, int call_flags, vhap_stream_t stream) {
     VHAP_ENTER();
     if (!normal_raw || !albedo || !rast || !lights || !sh_const || !rgba) return VHAP_E_NULLPTR;
     if (!bg_image && !bg_color) return VHAP_E_NULLPTR;
@@ -360,7 +360,7 @@ extern "C" int vhap_shade_bwd(const float* normal_raw, const float* albedo, cons
 }
 
 extern "C" int vhap_photo_fwd(const float* pred_rgba, const float* gt_nchw, int B, int H, int W, float* out2,
-                              vhap_stream_t stream) {
+                              int call_flags, vhap_stream_t stream) {
     VHAP_ENTER();
     if (!pred_rgba || !gt_nchw || !out2) return VHAP_E_NULLPTR;
     if (int e = check_img(B, H, W)) return e;

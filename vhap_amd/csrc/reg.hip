@@ -256,7 +256,8 @@ __global__ void adam_bump_kernel(int* step) { step[0] += 1; }
 
 extern "C" int vhap_offset_reg_fwd(const float* offset, const int32_t* lap_ptr, const int32_t* lap_col, const float* lap_val,
                                    const float* w_lap, const float* w_abs, const int32_t* region_ptr, const int32_t* region_idx,
-                                   int V, int n_regions, float s_lap, float s_abs, float s_rigid, float* terms, vhap_stream_t stream) {
+                                   int V, int n_regions, float s_lap, float s_abs, float s_rigid, float* terms, int call_flags,
+                                   vhap_stream_t stream) {
     VHAP_ENTER();
     if (!offset || !lap_ptr || !lap_col || !lap_val || !terms) return VHAP_E_NULLPTR;
     if (n_regions > 0 && (!region_ptr || !region_idx)) return VHAP_E_NULLPTR;
@@ -286,7 +287,7 @@ extern "C" int vhap_offset_reg_bwd(const float* offset, const int32_t* lap_ptr, 
 }
 
 extern "C" int vhap_tex_prep_fwd(const float* painted, const float* extra, const uint8_t* res_mask, int T, float s_tv, float s_res,
-                                 float* albedo_hwc, float* terms, vhap_stream_t stream) {
+                                 float* albedo_hwc, float* terms, int call_flags, vhap_stream_t stream) {
     VHAP_ENTER();
     if ((!painted && !extra) || !albedo_hwc || !terms) return VHAP_E_NULLPTR;
     if (T <= 0) return VHAP_E_BADDIM;
@@ -313,7 +314,7 @@ extern "C" int vhap_tex_prep_bwd(const float* albedo_hwc, const float* extra, co
 
 extern "C" int vhap_adam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                               float* const* exp_avg_sq, const int64_t* numel, const int32_t* lr_index, const float* lr_device,
-                              int32_t* step_device, float beta1, float beta2, float eps, vhap_stream_t stream) {
+                              int32_t* step_device, float beta1, float beta2, float eps, int call_flags, vhap_stream_t stream) {
     VHAP_ENTER();
     if (!params || !grads || !exp_avg || !exp_avg_sq || !numel || !lr_index || !lr_device || !step_device) return VHAP_E_NULLPTR;
     if (n_tensors <= 0 || n_tensors > VHAP_ADAM_MAX_TENSORS) return VHAP_E_BADDIM;
@@ -332,7 +333,7 @@ extern "C" int vhap_adam_step(int n_tensors, float* const* params, const float* 
     hipStream_t st = vhap_stream(stream);
     adam_kernel<<<nblocks, RB, 0, st>>>(t, lr_device, step_device, beta1, beta2, eps);
     VHAP_LAUNCH_CHECK();
-    if (!(vhap_g_call_flags & VHAP_CALL_ADAM_KEEP_STEP)) {
+    if (!(call_flags & VHAP_CALL_ADAM_KEEP_STEP)) {
         adam_bump_kernel<<<1, 1, 0, st>>>(step_device);
         VHAP_LAUNCH_CHECK();
     }

@@ -79,7 +79,7 @@ class _FlameSkin(torch.autograd.Function):
         d_A = torch.zeros_like(A)
         d_t = torch.zeros(B, 3, dtype=torch.float32, device=dev)
         _chk(_lib.lib().vhap_flame_skin_bwd(_p(d_verts), _p(d_vs), _p(v_posed), _p(A), _p(fb.w), _p(fb.basisT), B, V, fb.Vp, fb.Kb,
-                                            fb.Kp, _p(g_posed), _p(g_shaped), _p(partial), _p(d_coef), _p(d_A), _p(d_t), _stream()),
+                                            fb.Kp, _p(g_posed), _p(g_shaped), _p(partial), _p(d_coef), _p(d_A), _p(d_t), 0, _stream()),
              "vhap_flame_skin_bwd")
         d_off = g_shaped.sum(dim=0, keepdim=True) if ctx.has_offset else None
         return None, d_coef, d_A, d_t, d_off
@@ -175,7 +175,7 @@ class _Shade(torch.autograd.Function):
         stats = torch.empty(4, dtype=torch.float32, device=rast.device) if want_reg else None
         col = (ctypes.c_float * 3)(*bg_color) if bg_color is not None else None
         _chk(_lib.lib().vhap_shade_fwd(_p(normal_raw), _p(albedo), _p(rast), _p(bg_image), ctypes.cast(col, ctypes.c_void_p) if col else 0,
-                                       _p(lights), _p(sh_const), 0, 0, B, H, W, _p(rgba), _p(stats), 0, _stream()), "vhap_shade_fwd")
+                                       _p(lights), _p(sh_const), 0, 0, B, H, W, _p(rgba), _p(stats), 0, 0, _stream()), "vhap_shade_fwd")
         ctx.save_for_backward(normal_raw, albedo, lights, rast, sh_const, stats)
         if want_reg:
             mx = _decode_ordered_max(stats)
@@ -217,7 +217,7 @@ class _PhotoSum(torch.autograd.Function):
     def forward(ctx, pred, gt):
         B, H, W, _ = pred.shape
         out = torch.empty(2, dtype=torch.float32, device=pred.device)
-        _chk(_lib.lib().vhap_photo_fwd(_p(pred), _p(gt), B, H, W, _p(out), _stream()), "vhap_photo_fwd")
+        _chk(_lib.lib().vhap_photo_fwd(_p(pred), _p(gt), B, H, W, _p(out), 0, _stream()), "vhap_photo_fwd")
         ctx.save_for_backward(pred, gt)
         n = out[1].detach()
         ctx.mark_non_differentiable(n)

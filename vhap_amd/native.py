@@ -65,7 +65,7 @@ class _FramePrep(torch.autograd.Function):
         transl, Jrest, terms = small[:B * 3].view(B, 3), small[B * 3:B * 3 + B * fm.J * 3], small[-6:]
         _chk(_lib.lib().vhap_frame_prep_fwd(_p(ts), _p(shape), _p(expr), _p(rotation), _p(translation), _p(neck), _p(jaw), _p(eyes),
                                             _p(fm.JT), _p(fm.JS), _p(fm.jreg_idx), _p(fm.jreg_w), fm.jreg_n, _p(offset), fm.parents, weights, B, Bp, N, NS, NE,
-                                            fm.J, fb.Kp, fm.V, _p(coef), _p(A), _p(transl), _p(Jrest), _p(terms), _stream()),
+                                            fm.J, fb.Kp, fm.V, _p(coef), _p(A), _p(transl), _p(Jrest), _p(terms), 0, _stream()),
              "vhap_frame_prep_fwd")
         ctx.fm, ctx.weights, ctx.dims = fm, weights, (B, Bp, N, NS, NE)
         ctx.save_for_backward(ts, shape, expr, rotation, translation, neck, jaw, eyes, offset, Jrest)
@@ -146,7 +146,7 @@ class _Landmark(torch.autograd.Function):
         e = torch.empty((), dtype=torch.float32, device=verts.device)
         lmk3d = torch.empty(B, lm.L, 3, dtype=torch.float32, device=verts.device) if want_lmk3d else None
         _chk(_lib.lib().vhap_landmark_fwd(_p(verts), _p(lm.vidx), _p(lm.bary), _p(mvp), _p(lmk2d), B, V, lm.L, lmk2d.shape[1], l0, l1,
-                                          b0, b1, boost, H, W, _p(lmk3d), _p(e), _stream()), "vhap_landmark_fwd")
+                                          b0, b1, boost, H, W, _p(lmk3d), _p(e), 0, _stream()), "vhap_landmark_fwd")
         ctx.lm, ctx.cfg = lm, cfg
         ctx.save_for_backward(verts, mvp, lmk2d)
         if lmk3d is None:
@@ -199,7 +199,7 @@ class _OffsetReg(torch.autograd.Function):
     def forward(ctx, om, off, scales):
         terms = torch.empty(3, dtype=torch.float32, device=off.device)
         _chk(_lib.lib().vhap_offset_reg_fwd(_p(off), _p(om.ptr), _p(om.col), _p(om.val), _p(om.w_lap), _p(om.w_abs), _p(om.rptr), _p(om.ridx),
-                                            om.V, om.nreg, *scales, _p(terms), _stream()), "vhap_offset_reg_fwd")
+                                            om.V, om.nreg, *scales, _p(terms), 0, _stream()), "vhap_offset_reg_fwd")
         ctx.om, ctx.scales = om, scales
         ctx.save_for_backward(off)
         return terms
@@ -269,7 +269,7 @@ class _TexSample(torch.autograd.Function):
         B, H, W, _ = texc.shape
         albedo = torch.empty(1, T, T, 3, dtype=torch.float32, device=dev)
         terms = torch.empty(2, dtype=torch.float32, device=dev)
-        _chk(L.vhap_tex_prep_fwd(_p(painted), _p(extra), _p(mask), T, *scales, _p(albedo), _p(terms), _stream()), "vhap_tex_prep_fwd")
+        _chk(L.vhap_tex_prep_fwd(_p(painted), _p(extra), _p(mask), T, *scales, _p(albedo), _p(terms), 0, _stream()), "vhap_tex_prep_fwd")
         mips = torch.empty(L.vhap_texture_mip_floats(1, T, T, 3), dtype=torch.float32, device=dev)
         _chk(L.vhap_texture_mip_build(_p(albedo), 1, T, T, 3, _p(mips), _stream()), "vhap_texture_mip_build")
         out = torch.empty(B, H, W, 3, dtype=torch.float32, device=dev)
@@ -344,7 +344,7 @@ class _TexPrep(torch.autograd.Function):
         dev = (extra if extra is not None else painted).device
         albedo = torch.empty(1, T, T, 3, dtype=torch.float32, device=dev)
         terms = torch.empty(2, dtype=torch.float32, device=dev)
-        _chk(_lib.lib().vhap_tex_prep_fwd(_p(painted), _p(extra), _p(mask), T, *scales, _p(albedo), _p(terms), _stream()), "vhap_tex_prep_fwd")
+        _chk(_lib.lib().vhap_tex_prep_fwd(_p(painted), _p(extra), _p(mask), T, *scales, _p(albedo), _p(terms), 0, _stream()), "vhap_tex_prep_fwd")
         ctx.scales, ctx.T = scales, T
         ctx.save_for_backward(albedo, extra, mask)
         ctx.set_materialize_grads(False)
@@ -453,14 +453,7 @@ class HipAdam(torch.optim.Optimizer):
         G = P(*[t["ps"][i].grad.data_ptr() for i in sel])
         g0 = self.param_groups[0]
         L = _lib.lib()
-        saved = L.vhap_get_call_flags()
-        if not advance:
-            L.vhap_set_call_flags(saved | 4)                           # VHAP_CALL_ADAM_KEEP_STEP
-        try:
-            _chk(L.vhap_adam_step(n, pick(t["p"], ctypes.c_void_p), G, pick(t["m"], ctypes.c_void_p), pick(t["v"], ctypes.c_void_p),
-                                  pick(t["numel"], ctypes.c_int64), pick(t["lr_index"], ctypes.c_int32), _p(self._lr_dev),
-                                  _p(self._step), float(g0["betas"][0]), float(g0["betas"][1]), float(g0["eps"]), _stream()),
-                 "vhap_adam_step")
-        finally:
-            if not advance:
-                L.vhap_set_call_flags(saved)
+        _chk(L.vhap_adam_step(n, pick(t["p"], ctypes.c_void_p), G, pick(t["m"], ctypes.c_void_p), pick(t["v"], ctypes.c_void_p),
+                              pick(t["numel"], ctypes.c_int64), pick(t["lr_index"], ctypes.c_int32), _p(self._lr_dev),
+                              _p(self._step), float(g0["betas"][0]), float(g0["betas"][1]), float(g0["eps"]),
+                              0 if advance else _lib.CALL_ADAM_KEEP_STEP, _stream()), "vhap_adam_step")

@@ -346,7 +346,7 @@ class _Antialias(torch.autograd.Function):
         d_color = torch.empty_like(color) if need_color else None
         d_pos = torch.zeros_like(pos) if need_pos else None
         rc = _lib.lib().vhap_antialias_bwd(_p(color), _p(rast), _p(pos), _p(tri), _p(opp), _p(d_out), _p(work), _p(pos_nograd), B, H, W,
-                                           C, V, F, _p(d_color), _p(d_pos), _stream())
+                                           C, V, F, _p(d_color), _p(d_pos), 0, _stream())
         _lib.check(rc, "vhap_antialias_bwd")
         return d_color, None, d_pos, None, None, None
 

@@ -21,6 +21,8 @@ from .config import PhotometricStageConfig
 from .native import _n_gather
 from .ops import _p, _stream
 
+PRE = _lib.CALL_ACC_PREZEROED        # per-call flag (ABI 2): this call's small accumulators were cleared by the arena clear
+
 LOG_NAMES = ("lmk", "photo", "smooth_pose", "reg_joint", "smooth_joint", "reg_expr", "smooth_expr", "reg_shape", "reg_tex_tv",
              "reg_tex_res_clusters", "reg_diffuse", "reg_offset_lap", "reg_offset", "reg_offset_rigid", "rest", "total")
 
@@ -186,11 +188,11 @@ class NativeStep:
         L, tr, T, acc = self.L, self.tr, self.T, self.accF
         st = _stream()
         _chk(L.vhap_tex_prep_fwd(_p(self.painted), _p(tr.tex_extra), _p(self.nm["res_mask"]), T, *self.tex_scales, _p(self.albedo_tex),
-                                 _p(acc[7:9]), st), "vhap_tex_prep_fwd")
+                                 _p(acc[7:9]), PRE, st), "vhap_tex_prep_fwd")
         _chk(L.vhap_texture_mip_build(_p(self.albedo_tex), 1, T, T, 3, _p(self.mips), st), "vhap_texture_mip_build")
         om = self.om
         _chk(L.vhap_offset_reg_fwd(_p(tr.static_offset), _p(om.ptr), _p(om.col), _p(om.val), _p(om.w_lap), _p(om.w_abs), _p(om.rptr), _p(om.ridx),
-                                   om.V, om.nreg, *self.off_scales, _p(acc[9:12]), st), "vhap_offset_reg_fwd")
+                                   om.V, om.nreg, *self.off_scales, _p(acc[9:12]), PRE, st), "vhap_offset_reg_fwd")
 
     def forward(self):
         L, tr, fb, fm = self.L, self.tr, self.fb, self.fm
@@ -198,8 +200,7 @@ class NativeStep:
         st = _stream()
         acc = self.accF
         acc.zero_()                                                   # ONE launch clears every forward accumulator
-        L.vhap_set_call_flags(1)
-        try:
+        if True:           # every accumulator below comes from the arena just cleared: the calls get VHAP_CALL_ACC_PREZEROED
             so = tr.static_offset
             # the camera first: two tiny launches that would take 3-5x as long next to the texture branch below
             torch.addcmul(self.K0, tr.focal_length.detach(), self.K1, out=self.K)      # K = (f, f, cx, cy), f = focal * max(h, w)
@@ -207,7 +208,7 @@ class NativeStep:
             _chk(L.vhap_frame_prep_fwd(_p(self.ts), _p(tr.shape), _p(tr.expr), _p(tr.rotation), _p(tr.translation), _p(tr.neck_pose),
                                        _p(tr.jaw_pose), _p(tr.eyes_pose), _p(fm.JT), _p(fm.JS), _p(fm.jreg_idx), _p(fm.jreg_w), fm.jreg_n,
                                        _p(so), fm.parents, self.weights, B, self.Bp, self.N, self.NS, self.NE, J, fb.Kp, V,
-                                       _p(self.coef), _p(self.A), _p(self.transl), _p(self.Jrest), _p(acc), st), "vhap_frame_prep_fwd")
+                                       _p(self.coef), _p(self.A), _p(self.transl), _p(self.Jrest), _p(acc), PRE, st), "vhap_frame_prep_fwd")
             _chk(L.vhap_flame_skin_fwd(_p(self.coef), _p(fb.basis), _p(self.A), _p(fb.w), _p(fb.templ), _p(so), _p(self.transl), B, V, fb.Vp,
                                        fb.K, fb.Kb, fb.Kp, _p(self.verts), _p(self.v_shaped), _p(self.v_posed), st), "vhap_flame_skin_fwd")
             # fork here, not at the top: next to the bandwidth-bound texture assembly the two latency-bound kernels above take 3x as long,
@@ -218,7 +219,7 @@ class NativeStep:
                 if self.w_lmk:                                        # needs only verts + mvp: off the rasteriser's critical path
                     l0, l1, b0, b1, boost = self.lmk_cfg
                     _chk(L.vhap_landmark_fwd(_p(self.verts), _p(self.lm.vidx), _p(self.lm.bary), _p(self.mvp), _p(self.lmk2d), B, V, self.lm.L,
-                                             self.lmk2d.shape[1], l0, l1, b0, b1, boost, H, W, 0, _p(acc[6:7]), _stream()), "vhap_landmark_fwd")
+                                             self.lmk2d.shape[1], l0, l1, b0, b1, boost, H, W, 0, _p(acc[6:7]), PRE, _stream()), "vhap_landmark_fwd")
                 self.arena.zero_()                                    # ONE launch clears every gradient accumulator of the backward
                 self._arena_clean = True
             _chk(L.vhap_transform_fwd(_p(self.verts), _p(self.mvp), B, V, _p(self.clip), st), "vhap_transform_fwd")
@@ -232,7 +233,7 @@ class NativeStep:
             _chk(L.vhap_shade_fwd(_p(self.normal), _p(self.albedo_px), _p(self.rast), _p(self.rgb) if self.bg_col is None else 0,
                                   ctypes.cast(self.bg_col, ctypes.c_void_p) if self.bg_col is not None else 0, _p(tr.lights), _p(self.sh_const),
                                   _p(self.fid2cid) if self.disturb_on else 0, self.fid2cid.numel() if self.disturb_on else 0,
-                                  B, H, W, _p(self.rgba), _p(acc[12:16]) if self.want_reg else 0, _p(self.cid) if self.disturb_on else 0, st),
+                                  B, H, W, _p(self.rgba), _p(acc[12:16]) if self.want_reg else 0, _p(self.cid) if self.disturb_on else 0, PRE, st),
                  "vhap_shade_fwd")
             color = self.rgba
             if self.disturb_on:
@@ -243,12 +244,10 @@ class NativeStep:
             self.aa_in = color
             _chk(L.vhap_antialias_fwd(_p(color), _p(self.rast), _p(self.clip), _p(self.tri), _p(self.opp), B, H, W, 4, V, F, _p(self.rgba_aa),
                                       _p(self.aa_work), st), "vhap_antialias_fwd")
-            _chk(L.vhap_photo_fwd(_p(self.rgba_aa), _p(self.rgb), B, H, W, _p(acc[16:18]), st), "vhap_photo_fwd")
+            _chk(L.vhap_photo_fwd(_p(self.rgba_aa), _p(self.rgb), B, H, W, _p(acc[16:18]), PRE, st), "vhap_photo_fwd")
             _chk(L.vhap_energy_finalize(_p(acc[0:6]), _p(acc[6:7]) if self.w_lmk else 0, _p(acc[7:9]), _p(acc[9:12]),
                                         _p(acc[12:16]) if self.want_reg else 0, self.w_lmk, self.w_reg, B, H, W, _p(self.log), st),
                  "vhap_energy_finalize")
-        finally:
-            L.vhap_set_call_flags(0)
 
     def _tex_backward(self):
         L, tr, T, g = self.L, self.tr, self.T, self.g
@@ -302,10 +301,9 @@ class NativeStep:
         _chk(L.vhap_energy_total(_p(self.log), _p(acc[16:18]), _p(self.n_global), self.w_photo, int(world_size), _p(self.d_sum), st),
              "vhap_energy_total")
         _chk(L.vhap_photo_bwd(_p(self.rgba_aa), _p(self.rgb), _p(self.d_sum), B, H, W, _p(self.d_rgba_aa), _p(self.d_color), st), "vhap_photo_bwd")
-        L.vhap_set_call_flags(1 | 2)      # d_color already holds the pass-through copy of d_rgba_aa
         _chk(L.vhap_antialias_bwd(_p(self.aa_in), _p(self.rast), _p(self.clip), _p(self.tri), _p(self.opp), _p(self.d_rgba_aa), _p(self.aa_work),
-                                  _p(self.vert_mask), B, H, W, 4, V, F, _p(self.d_color), _p(g["d_clip"]), st), "vhap_antialias_bwd")
-        L.vhap_set_call_flags(1)
+                                  _p(self.vert_mask), B, H, W, 4, V, F, _p(self.d_color), _p(g["d_clip"]),
+                                  _lib.CALL_AA_PASSTHROUGH_DONE, st), "vhap_antialias_bwd")   # d_color already holds the pass-through copy of d_rgba_aa
         # (the backward of the disturbance -- d_rgba = d_color * keep -- is folded into the shading backward)
         _chk(L.vhap_shade_bwd(_p(self.normal), _p(self.albedo_px), _p(self.rast), _p(tr.lights), _p(self.sh_const), _p(self.d_color),
                               _p(self.keep) if self.disturb_on else 0, _p(self.c_reg) if self.want_reg else 0,
@@ -335,7 +333,7 @@ class NativeStep:
         _chk(L.vhap_camera_bwd(_p(self.RT), _p(self.d_mvp), B, 0, H, W, _p(self.d_K), st), "vhap_camera_bwd")
         _chk(L.vhap_focal_bwd(_p(self.d_K), B, self.focal_scale, _p(g["focal_length"]), st), "vhap_focal_bwd")
         _chk(L.vhap_flame_skin_bwd(_p(g["d_verts"]), 0, _p(self.v_posed), _p(self.A), _p(fb.w), _p(fb.basisT), B, V, fb.Vp, fb.Kb, fb.Kp,
-                                   _p(self.g_posed), _p(self.g_shaped), 0, _p(g["d_coef"]), _p(g["d_A"]), _p(g["d_t"]), st),
+                                   _p(self.g_posed), _p(self.g_shaped), 0, _p(g["d_coef"]), _p(g["d_A"]), _p(g["d_t"]), PRE, st),
              "vhap_flame_skin_bwd")
         _chk(L.vhap_sum_frames(_p(self.g_shaped), B, V * 3, _p(g["static_offset"]), st), "vhap_sum_frames")
         _chk(L.vhap_frame_prep_bwd(_p(self.ts), _p(tr.shape), _p(tr.expr), _p(tr.rotation), _p(tr.translation), _p(tr.neck_pose),
@@ -351,9 +349,7 @@ class NativeStep:
         side branch -- the caller then steps the remaining parameters with optimizer.step(skip=(tex_extra,))): 'texture' (pixel chain + the complete texture gradient, serial) -- the
         caller launches the asynchronous all-reduce of the texture gradient -- then 'geometry' (everything else), which hides it; or
         'pixel' then 'tex' and 'geometry' side by side on two streams (GraphedStep's default under sharding)."""
-        L = self.L
-        L.vhap_set_call_flags(1)
-        try:
+        if True:
             if part in ("all", "texture", "pixel"):
                 if not getattr(self, "_arena_clean", False):          # (normally done on the forward's side branch already)
                     self.arena.zero_()
@@ -397,8 +393,6 @@ class NativeStep:
                 self._join()
             else:
                 raise ValueError(part)
-        finally:
-            L.vhap_set_call_flags(0)
 
     def log_dict(self):
         """Views into the device log vector, keyed like FlameTracker.compute_energy's log_dict (terms the stage does not have read 0)."""
