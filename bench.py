@@ -1,18 +1,23 @@
 #!/usr/bin/env python3
 """bench.py -- photometric FLAME-fit throughput on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 20 --warmup 5 [--config {2,3,4}] [--scaling {weak,strong}]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one `optimize_iter` of stage rgb_global_tracking (tracker.py:1418-1462): FLAME forward,
-landmark + photometric + all regularisation energies, backward to every parameter, one Adam step --
-on a 16-frame 512x512 synthetic monocular batch per GPU (BASELINE configs[1]), frames resident in
-HBM.  N > 1: every rank fits its own 16 frames of one subject (weak scaling, global batch 16*N) and
-the shared-parameter gradients are averaged with ONE RCCL all-reduce per step (vhap_amd.dist).
-Prints ONE JSON line on rank 0.  `roofline` times the fused rasterize+interpolate pass (the five
-launches behind vhap_raster_interp_fwd) with HIP events inside the timed steps; `cpu_baseline` times
-the CPU oracle restatement of the same step on a bounded sample (rank 0, N = 1 only).
+One "step" = one `optimize_iter` of stage rgb_global_tracking (tracker.py:1418-1462): FLAME forward, landmark + photometric + all
+regularisation energies, backward to every parameter, one Adam step, frames resident in HBM, ONE step per graph launch (the stage gets a
+new shuffled batch every step in the reference, tracker.py:1376-1385).  Workloads (BASELINE.json configs):
+    2 (default, the configuration `metric` is quoted on): monocular 512x512, 16 frames per batch
+    3: monocular 1024x1024, 8 frames per batch, static offset
+    4: NeRSemble-like, 16 calibrated views of one timestep, 802x550
+N > 1, --scaling weak (default): every rank fits its own batch of the same size (global batch x N); --scaling strong: the batch (frames or
+views) is split B/N per rank.  The shared-parameter gradients are averaged over RCCL each step (vhap_amd.dist).
+Prints ONE JSON line on rank 0.  `roofline`: the fused rasterize+interpolate pass (bin_build + raster kernel behind
+vhap_raster_interp_fwd), algorithmic bytes / duration, with the duration measured three ways -- `frac` = inside the step (HIP event-record
+nodes in an instrumented capture of the same step, or HIP events around the pass in eagerly issued native steps if the runtime refuses
+event nodes), `frac_isolated` = a hipGraph of 20 back-to-back passes.  `cpu_baseline`: the CPU oracle restatement of the SAME step (one
+whole batch: forward + backward + Adam, colour disturbance on) on the host cores, rank 0, N = 1 only.
 """
 import argparse
 import json
@@ -26,99 +31,227 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-UNROLL = 5                 # steps per graph replay on one GPU
-B_PER_GPU = 16
-H = W = 512
 TEX = 2048
 STAGE = "rgb_global_tracking"
 HBM_PEAK = 8.0e12                       # B/s, MI355X_MICROARCH.md
-RI_ALG_BYTES_PER_FRAME = 429364 + 68 * H * W
+CONFIGS = {
+    2: dict(B=16, H=512, W=512, kind="monocular", name="monocular 512x512, 16 frames per batch"),
+    3: dict(B=8, H=1024, W=1024, kind="monocular", name="monocular 1024x1024, 8 frames per batch, static offset"),
+    4: dict(B=16, H=802, W=550, kind="multiview", name="NeRSemble-like: 16 calibrated views of one timestep, 802x550"),
+}
 
 
-def build_tracker(rank, world, device):
-    from vhap_amd.config import BaseTrackingConfig
+def ri_alg_bytes_per_frame(H, W):
+    return 429364 + 68 * H * W           # geometry reads + 68 B/px of G-buffer writes
+
+
+def build_tracker(C, rank, world, device, scaling):
+    from vhap_amd.config import BaseTrackingConfig, nersemble_config
     from vhap_amd.flame import FlameHead
     from vhap_amd.render_hip import HipDiffRenderer
-    from vhap_amd.synthetic import make_dataset, make_flame_model, make_scene_params, make_texture
+    from vhap_amd.synthetic import make_dataset, make_flame_model, make_multiview_dataset, make_scene_params, make_texture
     from vhap_amd.tracker import GlobalTracker
+    H, W, B = C["H"], C["W"], C["B"]
     model, topo = make_flame_model(seed=0)
-    cfg = BaseTrackingConfig()
-    cfg.device = device
-    n_total = B_PER_GPU * world
-    gt = make_scene_params(n_total, seed=0, image_size=(H, W))
-    own = np.arange(rank * B_PER_GPU, (rank + 1) * B_PER_GPU)
-    gt_own = {k: (v[own] if (isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == n_total) else v) for k, v in gt.items()}
     head = FlameHead(model, topo).to(device)
     rend = HipDiffRenderer(lighting_type="SH").to(device)
     tex_gt = make_texture(1, TEX)
-    d_own = make_dataset(rend, head, gt_own, (H, W), device, seed=rank, tex=tex_gt)
-    data = {"rgb": torch.zeros(n_total, 3, H, W, device=device), "lmk2d": torch.zeros(n_total, d_own["lmk2d"].shape[1], 3, device=device)}
-    data["rgb"][own] = d_own["rgb"]
-    data["lmk2d"][own] = d_own["lmk2d"]
-    del head, rend, d_own
-    tr = GlobalTracker(cfg, model, topo, make_texture(0, TEX), data)
     g = torch.Generator().manual_seed(123)                     # mid-fit state: ground truth + noise (same on all ranks)
+    if C["kind"] == "multiview":
+        cfg = nersemble_config()
+        cfg.device = device
+        gt = make_scene_params(1, seed=0, image_size=(H, W))
+        data = make_multiview_dataset(rend, head, gt, (H, W), device, n_views=B, seed=0, tex=tex_gt)
+        n_local = B // world if scaling == "strong" else B
+        if scaling == "strong":                                 # the views of the timestep split over the ranks
+            own = np.arange(rank * n_local, (rank + 1) * n_local)
+            data = {k: v[torch.as_tensor(own, device=v.device)] for k, v in data.items()}
+        # (weak: every rank sees all 16 views of its own copy of the timestep -- the per-GPU work of the single-GPU run)
+        tr = GlobalTracker(cfg, model, topo, make_texture(0, TEX), data)
+        own = np.arange(1)                                      # timesteps of this rank's batch
+        with torch.no_grad():
+            for name, s in (("shape", 0.05), ("expr", 0.05), ("neck_pose", 0.005), ("jaw_pose", 0.01), ("eyes_pose", 0.01)):
+                p = getattr(tr, name)
+                src = np.asarray(gt[name])
+                p.copy_(torch.from_numpy(src).to(device).reshape(p.shape) + (torch.randn(p.shape, generator=g) * s).to(device))
+            tr.rotation.add_((torch.randn(tr.rotation.shape, generator=g) * 0.01).to(device))
+            tr.translation.add_((torch.randn(tr.translation.shape, generator=g) * 0.002).to(device))
+    else:
+        cfg = BaseTrackingConfig()
+        cfg.device = device
+        n_local = B // world if scaling == "strong" else B
+        n_total = n_local * world
+        gt = make_scene_params(n_total, seed=0, image_size=(H, W))
+        own = np.arange(rank * n_local, (rank + 1) * n_local)
+        gt_own = {k: (v[own] if (isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == n_total) else v) for k, v in gt.items()}
+        d_own = make_dataset(rend, head, gt_own, (H, W), device, seed=rank, tex=tex_gt)
+        data = {"rgb": torch.zeros(n_total, 3, H, W, device=device), "lmk2d": torch.zeros(n_total, d_own["lmk2d"].shape[1], 3, device=device)}
+        data["rgb"][own] = d_own["rgb"]
+        data["lmk2d"][own] = d_own["lmk2d"]
+        del d_own
+        tr = GlobalTracker(cfg, model, topo, make_texture(0, TEX), data)
+        with torch.no_grad():
+            for name, s in (("shape", 0.05), ("expr", 0.05), ("rotation", 0.01), ("neck_pose", 0.005), ("jaw_pose", 0.01),
+                            ("eyes_pose", 0.01), ("translation", 0.002)):
+                p = getattr(tr, name)
+                p.copy_(torch.from_numpy(np.asarray(gt[name])).to(device) + (torch.randn(p.shape, generator=g) * s).to(device))
     with torch.no_grad():
-        for name, s in (("shape", 0.05), ("expr", 0.05), ("rotation", 0.01), ("neck_pose", 0.005), ("jaw_pose", 0.01),
-                        ("eyes_pose", 0.01), ("translation", 0.002)):
-            p = getattr(tr, name)
-            src = gt["shape"] if name == "shape" else gt[name]
-            p.copy_(torch.from_numpy(np.asarray(src)).to(device) + (torch.randn(p.shape, generator=g) * s).to(device))
         tr.lights.copy_(torch.from_numpy(gt["lights"]).to(device))
         tr.tex_extra.add_((torch.randn(tr.tex_extra.shape, generator=g) * 0.01).to(device))
         tr.static_offset.add_((torch.randn(tr.static_offset.shape, generator=g) * 1e-4).to(device))
-    return tr, own, model, topo, gt
+    del head, rend
+    return tr, own, n_local, model, topo, gt
 
 
 def pmc_traffic():
     """HBM bytes per launch of the RI-fwd pass from the memory-side PMC counters (FETCH_SIZE / WRITE_SIZE, two separate rocprofv3
-    passes, scaled by in-run calibration kernels: tools/ri_fwd_pmc.py -> profiles/r01_ri_fwd_pmc.json).  Counters cannot be read
-    from inside this process, so the committed measurement of the same launch sequence is reported; None if absent."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_ri_fwd_pmc.json")
+    --pmc passes, scaled by in-run calibration kernels: tools/ri_fwd_pmc.py -> profiles/rNN_ri_fwd_pmc.json).  Counters cannot be read
+    from inside this process: the newest committed measurement of the same launch sequence (config 2) is reported, with its file name in
+    roofline.traffic_source; None if absent."""
+    pdir = os.path.join(ROOT, "profiles")
     try:
-        with open(path) as f:
-            return json.load(f).get("traffic_bytes_per_launch")
-    except (OSError, ValueError):
-        return None
+        names = sorted(n for n in os.listdir(pdir) if n.endswith("_ri_fwd_pmc.json"))
+        with open(os.path.join(pdir, names[-1])) as f:
+            return json.load(f).get("traffic_bytes_per_launch"), "profiles/" + names[-1]
+    except (OSError, ValueError, IndexError):
+        return None, None
 
 
-def cpu_baseline(model, topo, gt, budget_s=25.0):
-    """Time the CPU oracle (torch restatement + C rasteriser) on the same workload shape, bounded sample."""
-    from oracle import energy_ref
-    from vhap_amd.config import BaseTrackingConfig
-    from vhap_amd.synthetic import make_texture, smooth_noise
-    nb = 1                                                      # frames in the sample batch
+def cpu_baseline(C, tr, sample, model, topo, budget_s=30.0):
+    """The CPU oracle restatement (torch-CPU fp32 + C rasteriser) of the SAME step: ONE whole batch of the quoted configuration --
+    forward with the colour disturbance on, backward to every parameter, torch.optim.Adam -- repeated while the budget lasts."""
+    from oracle import energy_ref, fit_ref
+    H, W = C["H"], C["W"]
     cores = min(os.cpu_count() or 1, 16)                       # more threads only add contention for this op mix
     torch.set_num_threads(cores)
     os.environ["OMP_NUM_THREADS"] = str(cores)
     dt = torch.float32
-    cfg = BaseTrackingConfig()
+    cfg = tr.cfg
     tm = {k: torch.from_numpy(np.asarray(v)) for k, v in model.items()}
-    rng = np.random.default_rng(0)
-    P = {}
-    for k in ("expr", "rotation", "neck_pose", "jaw_pose", "eyes_pose", "translation"):
-        P[k] = torch.from_numpy(np.asarray(gt[k])[:nb]).clone().to(dt).requires_grad_()
-    for k in ("shape", "lights", "focal_length"):
-        P[k] = torch.from_numpy(np.asarray(gt[k])).clone().to(dt).requires_grad_()
-    P["tex_extra"] = (torch.randn(3, TEX, TEX) * 0.01).requires_grad_()
-    P["static_offset"] = (torch.randn(1, topo.num_verts, 3) * 1e-4).requires_grad_()
-    sample = {"rgb": torch.from_numpy(smooth_noise(rng, (nb, 3, H, W))), "lmk2d": torch.cat([torch.rand(nb, 70, 2) * W, torch.ones(nb, 70, 1)], -1),
-              "timestep_index": np.arange(nb)}
-    base_tex = torch.from_numpy(make_texture(0, TEX))[None]
-    uvm = torch.from_numpy(topo.get_uvmask_by_region(list(cfg.w.reg_tex_res_for)))[None].float()
-    n_frames, t0 = 0, time.time()
+    names = ["shape", "expr", "rotation", "neck_pose", "jaw_pose", "eyes_pose", "translation", "tex_extra", "lights", "static_offset"]
+    if not tr.calibrated:
+        names.append("focal_length")
+    P = {k: getattr(tr, k).detach().cpu().to(dt).clone().requires_grad_() for k in names}
+    o_sample = {"rgb": sample["rgb"].cpu(), "lmk2d": sample["lmk2d"].cpu(), "timestep_index": sample["timestep_index"].cpu().numpy()}
+    for k in ("intrinsic", "extrinsic"):
+        if k in sample:
+            o_sample[k] = sample[k].cpu()
+    nb = o_sample["rgb"].shape[0]
+    base_tex = torch.from_numpy(np.asarray(tr.flame_tex_painted().detach().cpu()))
+    uvm = tr._uvmask_res().cpu().float()
+    opt = fit_ref.configure_optimizer(P, cfg, STAGE, lr_scale=0.1, calibrated=tr.calibrated)
+    ncl = int(topo.fid2cid.max()) + 1
+    gen = torch.Generator().manual_seed(0)
+    n_steps, t0 = 0, time.time()
     while True:
-        for p in P.values():
-            p.grad = None
-        E, _, _ = energy_ref.total_energy(P, tm, topo, cfg, sample, STAGE, base_tex, uvm, (H, W), dtype=dt)
+        disturb = dict(w_fg=(torch.rand(nb, H, W, 1, generator=gen) < (cfg.render.disturb_rate_fg or 0)).int(),
+                       w_bg=(torch.rand(nb, H, W, 1, generator=gen) < (cfg.render.disturb_rate_bg or 0)).int(),
+                       idx=[torch.randint(0, 2 ** 31 - 1, (nb * H * W,), generator=gen)] * ncl,
+                       fid2cid=torch.from_numpy(topo.fid2cid.astype(np.int64)))
+        E, _, _ = energy_ref.total_energy(P, tm, topo, cfg, o_sample, STAGE, base_tex, uvm, (H, W), dtype=dt, disturb=disturb)
+        opt.zero_grad()
         E.backward()
-        n_frames += nb
+        opt.step()
+        n_steps += 1
         if time.time() - t0 > budget_s * 0.5:
             break
     dtm = time.time() - t0
-    return {"value": n_frames / dtm, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{n_frames} frames ({nb}-frame batches, 512x512, T=2048) of the CPU oracle restatement "
-                      f"(torch-CPU fp32 + C rasteriser), forward+backward, no Adam, disturbance off, in {dtm:.1f} s"}
+    return {"value": n_steps * nb / dtm, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{n_steps} whole step(s) of the quoted configuration ({nb}-frame batch, {H}x{W}, T={TEX}, stage {STAGE}: forward "
+                      f"with colour disturbance + backward + Adam, TV / mip pyramid cost included) of the CPU oracle restatement "
+                      f"(torch-CPU fp32 + C rasteriser, {cores} threads) in {dtm:.1f} s"}
+
+
+def time_ri_in_step(tr, sample, optimizer, n=8):
+    """Duration of the RI-fwd pass INSIDE the step.  1st choice: an instrumented capture of the same step with event-record nodes
+    (torch.cuda.Event(external=True)) around the pass, replayed n times.  Fallback: the native step issued eagerly, HIP events on the
+    launch stream around the pass (same kernels, same two-stream structure, launches back to back inside one C call)."""
+    from vhap_amd import ops
+    from vhap_amd.step import NativeStep
+    from vhap_amd.tracker import GraphedStep
+    rec = {"mode": None, "ev": []}
+
+    def hook(name, phase):
+        if rec["mode"] is None or name != "raster_interp_fwd":
+            return
+        if rec["mode"] == "graph" and not torch.cuda.is_current_stream_capturing():
+            return                                               # (event-record nodes exist only under capture; the dry passes are skipped)
+        e = torch.cuda.Event(enable_timing=True, external=True) if rec["mode"] == "graph" else torch.cuda.Event(enable_timing=True)
+        e.record()                                               # torch's current stream == the launch stream
+        rec["ev"].append(e)
+    ops.PROFILE_HOOK = hook
+    try:
+        try:
+            rec["mode"], rec["ev"] = "graph", []
+            st = GraphedStep(tr, sample, optimizer, STAGE)       # the capture records the two event nodes
+            rec["mode"] = None
+            ev = rec["ev"][-2:]
+            if len(ev) != 2 or st.ns is None:
+                raise RuntimeError("no event nodes captured")
+            ms = []
+            for _ in range(n):
+                st()
+                torch.cuda.synchronize()
+                ms.append(ev[0].elapsed_time(ev[1]))
+            if not all(np.isfinite(ms)) or min(ms) <= 0:
+                raise RuntimeError(f"implausible event-node timings {ms}")
+            return float(np.median(ms)) * 1e-3, "HIP event-record nodes around the pass inside an instrumented capture of the step (median of %d replays)" % n
+        except Exception as e:                                   # noqa: BLE001 -- any runtime refusal: fall back, say so
+            why = f"{type(e).__name__}: {e}"[:120]
+        rec["mode"], rec["ev"] = "eager", []
+        ns = NativeStep(tr, sample, STAGE)
+        stream = torch.cuda.Stream()
+        stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(stream):
+            for i in range(n + 2):
+                if i == 2:
+                    rec["ev"] = []
+                ns.forward()
+                ns.backward(1)
+                optimizer.step()
+        torch.cuda.synchronize()
+        ev = rec["ev"]
+        ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(0, len(ev) - 1, 2)]
+        return float(np.median(ms)) * 1e-3, f"HIP events around the pass in {n} eagerly issued native steps (event nodes unavailable: {why})"
+    finally:
+        ops.PROFILE_HOOK = None
+
+
+def time_ri_isolated(tr, sample, C, stream):
+    from vhap_amd import ops
+    H, W = C["H"], C["W"]
+    with torch.no_grad():
+        s = dict(sample)
+        tr.fill_cam_params_into_sample(s)
+        verts, *_ = tr.forward_flame(s["timestep_index"])
+        rd = tr.render.rasterize(verts, tr.flame.faces, s["extrinsic"], s["intrinsic"], (H, W), defer=True)
+        vn = tr.render.compute_v_normals(verts, tr.flame.faces)
+        tri, tri_uv = tr.render._tri32(tr.flame.faces), tr.render._tri32(tr.flame.textures_idx)
+        pos = rd["verts_clip"].contiguous()
+        stream.wait_stream(torch.cuda.current_stream())
+        NREP = 20
+        with torch.cuda.stream(stream):
+            for _ in range(3):                                  # warm-up (workspace for this stream, code objects)
+                ops.raster_interp_fwd(tr.render.glctx, pos, tri, vn, tr._verts_uv_flipped, tri_uv, (H, W))
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream):
+            for _ in range(NREP):
+                ops.raster_interp_fwd(tr.render.glctx, pos, tri, vn, tr._verts_uv_flipped, tri_uv, (H, W))
+        ms = []
+        with torch.cuda.stream(stream):
+            g.replay()
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                g.replay()
+                e1.record()
+                e1.synchronize()
+                ms.append(e0.elapsed_time(e1) / NREP)
+        torch.cuda.current_stream().wait_stream(stream)
+        r = tr.render.rasterize(verts, tr.flame.faces, s["extrinsic"], s["intrinsic"], (H, W))
+        cov = float((r["rast_out"][..., 3] > 0).float().mean())
+    return float(np.mean(ms)) * 1e-3, cov
 
 
 def main():
@@ -126,49 +259,46 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json config number (default 2)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo for single-GPU tests of the multi-rank path)")
+    ap.add_argument("--unroll", type=int, default=1, help="steps per graph launch on one GPU (1 = what the stage really does)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="run optimize_iter eagerly instead of replaying the captured hipGraphs")
     args = ap.parse_args()
+    C = CONFIGS[args.config]
 
     from vhap_amd import dist as vdist
-    from vhap_amd import ops
-    rank, world, local = vdist.init_from_env()
+    rank, world, local = vdist.init_from_env(args.backend)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.scaling == "strong" and C["B"] % world:
+        raise SystemExit(f"--scaling strong: {C['B']} frames do not split over {world} ranks")
+    local = local % max(torch.cuda.device_count(), 1)            # (gloo on one GPU: every rank on the only device)
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
-    tr, own, model, topo, gt = build_tracker(rank, world, device)
+    tr, own, n_local, model, topo, gt = build_tracker(C, rank, world, device, args.scaling)
     if world > 1:
         vdist.attach(tr)
     optimizer = tr.configure_optimizer(tr.get_train_parameters(STAGE), lr_scale=0.1)
     sample = tr.get_sample(own, device_index=True)
+    assert sample["rgb"].shape[0] == n_local
     step = None
     if not args.eager:
         from vhap_amd.tracker import GraphedStep
-        # same work per step; on one GPU a replay carries UNROLL consecutive steps (one graph launch gap per UNROLL steps)
-        unroll = UNROLL if (world == 1 and args.steps % UNROLL == 0 and args.warmup % UNROLL == 0) else 1
+        unroll = args.unroll if (world == 1 and args.steps % args.unroll == 0 and args.warmup % args.unroll == 0) else 1
         ok, why = 1, ""
         try:
             step = GraphedStep(tr, sample, optimizer, STAGE, unroll=unroll)
         except Exception as e:                                   # a failed capture must not sink the run: same work, eager launches
             ok, why, step = 0, f"{type(e).__name__}: {e}", None
         if world > 1:                                            # all ranks take the same path
-            flag = torch.tensor([ok], dtype=torch.int32, device=device)
+            flag = torch.tensor([ok], dtype=torch.int32, device=device if torch.distributed.get_backend() == "nccl" else "cpu")
             torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
             if int(flag) == 0:
                 step = None
         if step is None and rank == 0:
             print(f"[bench] captured step unavailable ({why or 'another rank failed'}); running the eager step", file=sys.stderr, flush=True)
-
-    ev = []                                                      # HIP event pairs around the RI-fwd launches
-    recording = {"on": False}
-
-    def hook(name, phase):
-        if recording["on"] and name == "raster_interp_fwd":
-            e = torch.cuda.Event(enable_timing=True)
-            e.record()                                           # torch's current stream == the launch stream
-            ev.append(e)
-    ops.PROFILE_HOOK = hook
 
     def barrier():
         if world > 1:
@@ -180,89 +310,55 @@ def main():
     for _ in range(args.warmup // per_call):
         run()
     barrier()
-    recording["on"] = True
     t0 = time.perf_counter()
     for _ in range(args.steps // per_call):
         run()
     barrier()
     dt = time.perf_counter() - t0
-    recording["on"] = False
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device=device if torch.distributed.get_backend() == "nccl" else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
-    ri_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(0, len(ev) - 1, 2)]
-    ri_where = "HIP events around every launch inside the timed steps"
-    if not ri_ms:
-        # graph replay bypasses the Python hook: time the SAME launch sequence (same geometry, same buffers' shapes) with
-        # HIP events on the same stream right after the timed region
-        ri_where = ("HIP events around a hipGraph of 20 launches of the pass on the step's geometry, replayed 5x on the step's "
-                    "stream right after the timed graph replays (the product runs the pass inside a hipGraph too)")
-        with torch.no_grad():
-            s = dict(sample)
-            tr.fill_cam_params_into_sample(s)
-            verts, *_ = tr.forward_flame(s["timestep_index"])
-            rd = tr.render.rasterize(verts, tr.flame.faces, s["extrinsic"], s["intrinsic"], (H, W), defer=True)
-            vn = tr.render.compute_v_normals(verts, tr.flame.faces)
-            tri, tri_uv = tr.render._tri32(tr.flame.faces), tr.render._tri32(tr.flame.textures_idx)
-            pos = rd["verts_clip"].contiguous()
-            stream = step.stream if step is not None else torch.cuda.Stream()
-            stream.wait_stream(torch.cuda.current_stream())
-            NREP = 20
-            with torch.cuda.stream(stream):
-                for _ in range(3):                                  # warm-up (workspace for this stream, code objects)
-                    ops.raster_interp_fwd(tr.render.glctx, pos, tri, vn, tr._verts_uv_flipped, tri_uv, (H, W))
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, stream=stream):
-                for _ in range(NREP):
-                    ops.raster_interp_fwd(tr.render.glctx, pos, tri, vn, tr._verts_uv_flipped, tri_uv, (H, W))
-            ri_ms = []
-            with torch.cuda.stream(stream):
-                g.replay()
-                for _ in range(5):
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    g.replay()
-                    e1.record()
-                    e1.synchronize()
-                    ri_ms.append(e0.elapsed_time(e1) / NREP)
-            torch.cuda.current_stream().wait_stream(stream)
-    ri_s = float(np.mean(ri_ms)) * 1e-3 if ri_ms else float("nan")
-    cov = None
     if rank == 0:
-        with torch.no_grad():
-            s = dict(sample)
-            tr.fill_cam_params_into_sample(s)
-            verts, *_ = tr.forward_flame(s["timestep_index"])
-            rd = tr.render.rasterize(verts, tr.flame.faces, s["extrinsic"], s["intrinsic"], (H, W))
-            cov = float((rd["rast_out"][..., 3] > 0).float().mean())
-    if rank == 0:
-        alg = RI_ALG_BYTES_PER_FRAME * B_PER_GPU
+        H, W = C["H"], C["W"]
+        alg = ri_alg_bytes_per_frame(H, W) * n_local
+        ri_iso, cov = time_ri_isolated(tr, sample, C, step.stream if step is not None else torch.cuda.Stream())
+        if world == 1:
+            ri_step, ri_where = time_ri_in_step(tr, sample, optimizer)
+        else:
+            ri_step, ri_where = ri_iso, "isolated figure (in-step instrumentation runs on one GPU only)"
+        traffic, traffic_src = pmc_traffic() if args.config == 2 and n_local == 16 else (None, None)
         out = {
-            "metric": "frames/sec photometric-fit (512x512, batch=16)", "value": B_PER_GPU * world * args.steps / dt,
+            "metric": "frames/sec photometric-fit (512x512, batch=16)" if args.config == 2 else f"frames/sec photometric-fit ({H}x{W}, batch={C['B']})",
+            "value": n_local * world * args.steps / dt,
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "monocular 512x512, 16 frames per GPU, stage rgb_global_tracking "
-                                   "(photometric + landmark + TV + all regularisers, colour disturbance on), "
-                                   "FLAME topology V=5143 F=10144, texture 2048x2048, fwd+bwd+Adam",
-                       "global_batch": B_PER_GPU * world, "parallelism": f"dp{world} (frame-sharded; per step one scalar all-reduce + two gradient all-reduces over RCCL)",
-                       "coverage": cov, "captured_step": step is not None},
-            "roofline": {"bound": "hbm", "achieved": alg / ri_s / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": alg / ri_s / HBM_PEAK, "traffic": pmc_traffic(),
-                         "kernel": "fused rasterize+interpolate forward (vhap_raster_interp_fwd = bin_build_kernel + "
-                                   "raster_kernel<true>, the whole pass is timed); " + ri_where,
-                         "alg_bytes_per_launch": alg, "us_per_launch": ri_s * 1e6},
+            "config": {"workload": f"BASELINE config {args.config}: {C['name']}; stage rgb_global_tracking (photometric + landmark + TV + all "
+                                   "regularisers, colour disturbance on), FLAME topology V=5143 F=10144, texture 2048x2048, fwd+bwd+Adam, "
+                                   "one step per graph launch",
+                       "global_batch": n_local * world, "frames_per_gpu": n_local,
+                       "parallelism": f"dp{world} {args.scaling} (frame-sharded; per step one scalar all-reduce + two gradient all-reduces over "
+                                      f"{'RCCL' if world > 1 and torch.distributed.get_backend() == 'nccl' else 'the process group'})",
+                       "coverage": cov, "captured_step": step is not None, "unroll": per_call},
+            "roofline": {"bound": "hbm", "achieved": alg / ri_step / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": alg / ri_step / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
+                         "frac_in_step": alg / ri_step / HBM_PEAK, "frac_isolated": alg / ri_iso / HBM_PEAK,
+                         "us_per_launch": ri_step * 1e6, "us_per_launch_isolated": ri_iso * 1e6,
+                         "kernel": "fused rasterize+interpolate forward (vhap_raster_interp_fwd = bin_build_kernel + raster_kernel<true>, "
+                                   "the whole pass is timed); frac / us_per_launch: " + ri_where + "; frac_isolated: a hipGraph of 20 "
+                                   "back-to-back passes on the step's geometry, replayed 5x",
+                         "alg_bytes_per_launch": alg},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(model, topo, gt)
+                out["cpu_baseline"] = cpu_baseline(C, tr, sample, model, topo)
             except Exception as e:                               # the baseline must never sink the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {type(e).__name__}: {e}"}
         print(json.dumps(out), flush=True)
     if world > 1:
+        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
 

@@ -66,3 +66,81 @@ def test_two_rank_sharded_step_matches_single_process():
         assert torch.allclose(gp, per_frame.grad, atol=1e-6)
         assert abs(Er - float(E)) < 1e-5
     assert torch.equal(ret[0][0], ret[1][0])                       # replicas see bit-identical gradients
+
+
+def _lmk_tracker(n_frames=4):
+    """The product's own tracker on a CPU device with landmark targets from ground-truth parameters (landmark-only pipeline)."""
+    from vhap_amd.config import BaseTrackingConfig
+    from vhap_amd.synthetic import make_flame_model, make_scene_params, make_texture, monocular_camera
+    from vhap_amd.tracker import GlobalTracker
+    model, topo = make_flame_model(0)
+    cfg = BaseTrackingConfig()
+    cfg.device = "cpu"
+    cfg.exp.photometric = False
+    cfg.model.tex_resolution = 16
+    H = W = 64
+    gt = make_scene_params(n_frames, seed=2, image_size=(H, W))
+    g = lambda k: torch.from_numpy(gt[k]).float()
+    tr = GlobalTracker(cfg, model, topo, make_texture(0, 16), {"rgb": torch.zeros(n_frames, 3, H, W), "lmk2d": torch.zeros(n_frames, 70, 3)})
+    with torch.no_grad():
+        _, lmks = tr.flame(g("shape")[None].expand(n_frames, -1), g("expr"), g("rotation"), g("neck_pose"), g("jaw_pose"), g("eyes_pose"),
+                           g("translation"))
+        K, RT = monocular_camera(n_frames, (H, W), float(gt["focal_length"][0]))
+        ndc = tr.render.world_to_ndc(lmks, torch.from_numpy(RT).float(), torch.from_numpy(K).float(), (H, W), flip_y=True)
+        tr.dataset["lmk2d"] = torch.stack([(ndc[..., 0] * 0.5 + 0.5) * W, (ndc[..., 1] * 0.5 + 0.5) * H, torch.ones(n_frames, lmks.shape[1])], dim=-1)
+    return tr
+
+
+_LMK_NAMES = ("shape", "expr", "rotation", "translation", "neck_pose", "jaw_pose", "eyes_pose", "focal_length")
+
+
+def _lmk_fit(tr, sample, steps=4):
+    stage = "lmk_init_all"
+    opt = tr.configure_optimizer(tr.get_train_parameters(stage))
+    logs = [float(tr.optimize_iter(dict(sample), opt, stage)["total"]) for _ in range(steps)]
+    return logs, {k: getattr(tr, k).detach().clone() for k in _LMK_NAMES}
+
+
+def _worker_tracker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vhap_amd import dist as vdist
+    from vhap_amd.tracker import ShuffledBatches
+    tr = _lmk_tracker()
+    ctx = vdist.attach(tr)
+    sample = ctx.shard_sample(tr.get_sample(np.arange(4)))
+    assert list(sample["timestep_index"]) == ([0, 1] if rank == 0 else [2, 3])
+    logs, params = _lmk_fit(tr, sample)
+    Es = torch.tensor(logs)
+    dist.all_reduce(Es)
+    # the shuffled global-tracking batches: every rank draws the same permutation and takes its own slice of each batch
+    torch.manual_seed(100 + rank)                                  # different local RNG states on purpose
+    order = [list(np.asarray(b["timestep_index"])) for b in ShuffledBatches(tr, 2)]
+    ret[rank] = ((Es / world).tolist(), params, order)
+    dist.destroy_process_group()
+
+
+def test_two_rank_tracker_landmark_fit_matches_single_process():
+    """The TRACKER's own energy under frame sharding (not a stand-in): FlameTracker.compute_energy of a landmark stage on each rank's
+    slice, FrameShardContext.average_gradients, Adam -- four optimiser steps reproduce the single-process fit on the whole batch
+    (energies as the mean over ranks, every trained parameter to fp32 round-off), replicas stay bit-identical, and ShuffledBatches
+    yields complementary slices of the SAME permutation on both ranks."""
+    world = 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ret = mp.Manager().dict()
+    mp.spawn(_worker_tracker, args=(world, port, ret), nprocs=world, join=True)
+    tr = _lmk_tracker()
+    logs, params = _lmk_fit(tr, tr.get_sample(np.arange(4)))
+    for a, b in zip(ret[0][0], logs):
+        assert abs(a - b) <= 1e-5 * abs(b), (ret[0][0], logs)
+    for k in _LMK_NAMES:
+        assert torch.equal(ret[0][1][k], ret[1][1][k]), f"replicas disagree on {k}"
+        d = float((ret[0][1][k] - params[k]).abs().max())
+        assert d <= 2e-5 * max(1.0, float(params[k].abs().max())), (k, d)
+        assert float(params[k].abs().max()) > 0
+    o0, o1 = ret[0][2], ret[1][2]
+    assert len(o0) == len(o1) == 2 and all(len(a) == 1 and len(b) == 1 for a, b in zip(o0, o1))
+    assert sorted(t for b in o0 + o1 for t in b) == [0, 1, 2, 3]

@@ -39,16 +39,51 @@ def _build(T):
     return tr
 
 
-def _step(tr, frames):
+def _build_calibrated(T, n_views=4):
+    """NeRSemble-style: n_views calibrated cameras looking at ONE timestep (BASELINE config 4 in miniature)."""
+    from vhap_amd.config import nersemble_config
+    from vhap_amd.synthetic import make_flame_model, make_texture, smooth_noise
+    from vhap_amd.tracker import GlobalTracker
+    model, topo = make_flame_model(0)
+    cfg = nersemble_config()
+    cfg.model.tex_resolution = T
+    cfg.render.disturb_rate_fg = cfg.render.disturb_rate_bg = None
+    rng = np.random.default_rng(3)
+    Hc, Wc = 80, 112
+    Ks, RTs = [], []
+    for a in np.linspace(-0.6, 0.6, n_views):
+        c, s_ = np.cos(a), np.sin(a)
+        R_ = np.array([[c, 0, -s_], [0, 1, 0], [s_, 0, c]], dtype=np.float32)
+        RTs.append(np.concatenate([R_, np.array([[0.0], [0.0], [-1.0]], dtype=np.float32)], axis=1))
+        f = 1.9 * Wc
+        Ks.append(np.array([[f, 0, 0.5 * Wc + 1.0], [0, f * 1.01, 0.5 * Hc - 1.0], [0, 0, 1]], dtype=np.float32))
+    data = {"rgb": torch.from_numpy(smooth_noise(rng, (n_views, 3, Hc, Wc))).cuda(),
+            "lmk2d": torch.cat([torch.rand(n_views, 70, 2, generator=torch.Generator().manual_seed(2)) * torch.tensor([Wc, Hc]),
+                                torch.ones(n_views, 70, 1)], -1).cuda(),
+            "intrinsic": torch.from_numpy(np.stack(Ks)).cuda(), "extrinsic": torch.from_numpy(np.stack(RTs)).cuda(),
+            "timestep_index": torch.zeros(n_views, dtype=torch.long)}
+    tr = GlobalTracker(cfg, model, topo, make_texture(0, T), data)
+    assert tr.n_timesteps == 1
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for name, s in (("shape", 0.2), ("expr", 0.2), ("rotation", 0.05), ("jaw_pose", 0.05), ("tex_extra", 0.03), ("static_offset", 1e-3)):
+            p = getattr(tr, name)
+            p.add_((torch.randn(p.shape, generator=g) * s).cuda())
+    return tr
+
+
+def _step(tr, frames, stage="rgb_global_tracking", shard=None):
     from vhap_amd.tracker import GraphedStep
-    stage = "rgb_global_tracking"
     opt = tr.configure_optimizer(tr.get_train_parameters(stage), lr_scale=0.0)
     sample = tr.get_sample(np.asarray(frames), device_index=True)
+    if shard is not None:                                          # this rank's slice of the views of the timestep
+        sample = {k: (v[shard] if torch.is_tensor(v) else v) for k, v in sample.items()}
     st = GraphedStep(tr, sample, opt, stage, warmup=0)
     assert st.ns is not None, "the sharded step must run through NativeStep"
     E = float(st())
     torch.cuda.synchronize()
-    return E, {k: getattr(tr, k).grad.detach().cpu().clone() for k in NAMES}, bool(st.ns.tex_l0_skip)
+    return E, {k: getattr(tr, k).grad.detach().cpu().clone() for k in NAMES if hasattr(tr, k) and getattr(tr, k).grad is not None}, \
+        bool(st.ns.tex_l0_skip)
 
 
 def _worker(rank, world, port, T, ret, schedule):
@@ -80,3 +115,39 @@ def test_two_rank_native_step_matches_single_process(T, schedule):
         assert torch.equal(b0, b1), f"replicas disagree on {k}"
         rel = float((a - b0).abs().max() / (a.abs().max() + 1e-30))
         assert rel < 2e-3, f"grad {k}: rel {rel:.3e}"
+
+
+def _worker_cal(rank, world, port, T, ret, stage):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vhap_amd import dist as vdist
+    tr = _build_calibrated(T)
+    vdist.attach(tr)
+    ret[rank] = _step(tr, [0], stage=stage, shard=slice(2 * rank, 2 * rank + 2))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("stage", ["rgb_global_tracking", "lmk_init_all"])
+def test_two_rank_calibrated_multiview_step_matches_single_process(stage):
+    """BASELINE config 4 in miniature: the views of ONE timestep split over two ranks (2 + 2).  Every view writes into the same row of the
+    per-frame parameters, so the rows' gradients are sums over views on each rank and averages over ranks -- the sharded captured
+    NativeStep (calibrated K / RT per view, no focal length) must reproduce the single-process step on all four views, for a
+    photometric and for a landmark-only stage."""
+    T = 128
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ret = mp.Manager().dict()
+    mp.spawn(_worker_cal, args=(2, port, T, ret, stage), nprocs=2, join=True)
+    E1, g1, _ = _step(_build_calibrated(T), [0], stage=stage)
+    Em = 0.5 * (ret[0][0] + ret[1][0])
+    assert abs(Em - E1) <= 2e-4 * abs(E1), (Em, E1)
+    assert "focal_length" not in g1
+    for k, a in g1.items():
+        b0, b1 = ret[0][1][k], ret[1][1][k]
+        assert torch.equal(b0, b1), f"replicas disagree on {k}"
+        if float(a.abs().max()) == 0:
+            continue
+        rel = float((a - b0).abs().max() / (a.abs().max() + 1e-30))
+        assert rel < 2e-3, f"{stage}: grad {k}: rel {rel:.3e}"

@@ -319,6 +319,30 @@ def test_tracker_host_logic_matches_reference(flame_model):
         assert torch.equal(p[:, :w], torch.from_numpy(G[f"host/after/{k}"]).float()[:, :w]), k
 
 
+def test_oracle_fit_groups_match_reference_golden(flame_model):
+    """oracle/fit_ref.py (the oracle-side optimiser set-up used by the K-step parity test): the tensors a stage trains and the Adam groups /
+    learning rates, against what the reference's own get_train_parameters / configure_optimizer produced (host/json of the golden)."""
+    import json
+    from oracle import fit_ref
+    from vhap_amd.config import BaseTrackingConfig
+    ref = json.loads(str(G["host/json"]))
+    cfg = BaseTrackingConfig()
+    names = ("focal_length", "shape", "tex_extra", "static_offset", "lights", "translation", "rotation", "eyes_pose", "neck_pose", "jaw_pose",
+             "expr")
+    P = {k: torch.zeros(3, dtype=torch.float64, requires_grad=True) for k in names}
+    name_of = lambda t: next(k for k in names if P[k] is t)
+    for stage, want in ref.items():
+        params = fit_ref.train_parameters(P, cfg, stage)
+        assert {k: [name_of(t) for t in v] for k, v in params.items()} == want["params"], stage
+        groups = fit_ref.optimizer_groups(params, cfg, lr_scale=0.5)
+        got = [[sorted(name_of(t) for t in g["params"]), g["lr"]] for g in groups]
+        assert len(got) == len(want["groups"]), stage
+        for (gn, glr), (wn, wlr) in zip(got, want["groups"]):
+            assert gn == wn and abs(glr - wlr) <= 1e-12, (stage, gn, glr, wn, wlr)
+        opt = fit_ref.configure_optimizer(P, cfg, stage, lr_scale=0.5)
+        assert [g["lr"] for g in opt.param_groups] == [g["lr"] for g in groups]
+
+
 @pytest.mark.parametrize("stage", [None, "lmk_init_all", "rgb_init_offset", "rgb_global_tracking"])
 def test_oracle_total_energy_and_gradients_match_reference_compute_energy(flame_model, stage):
     """The reference's GlobalTracker.compute_energy (:692-750: forward_flame, camera, landmark + photometric + regularisation terms, their

@@ -150,3 +150,52 @@ def test_landmark_only_pipeline_runs_end_to_end_on_cpu(flame_model):
     report = tr.optimize(evaluate=False)
     after = lmk_energy()
     assert report is None and tr.global_step == 6 * 2 + 6 * 2 + 2 * 2 and after < 0.7 * before, (before, after, tr.global_step)
+
+
+def test_multiview_dataset_is_grouped_by_timestep_on_cpu(flame_model):
+    """NeRSemble-style capture (nersemble_dataset.py, batchify_all_views): V views x T timesteps.  n_timesteps counts TIMESTEPS (the
+    reference's len(dataset)), the per-frame parameters have one row per timestep, a sample holds every view of the requested timesteps
+    with their real timestep_index, evaluate() reports per timestep, and the landmark-only pipeline runs (views used to be
+    treated as timesteps of their own)."""
+    from vhap_amd.config import nersemble_config
+    from vhap_amd.synthetic import make_texture
+    from vhap_amd.tracker import GlobalTracker, ShuffledBatches
+    model, topo = flame_model
+    cfg = nersemble_config()
+    cfg.device = "cpu"
+    cfg.exp.photometric = False
+    cfg.model.tex_resolution = 16
+    for st in cfg.pipeline.__dict__.values():
+        if hasattr(st, "num_steps"):
+            st.num_steps = 3
+        if hasattr(st, "num_epochs"):
+            st.num_epochs = 1
+    NT, NVW, H, W = 3, 4, 40, 56
+    ft = np.repeat(np.arange(NT), NVW)[np.random.default_rng(0).permutation(NT * NVW)]        # frames in arbitrary order
+    Nf = NT * NVW
+    K = torch.tensor([[80.0, 0, W / 2], [0, 80.0, H / 2], [0, 0, 1]]).expand(Nf, 3, 3).clone()
+    RT = torch.eye(3, 4).expand(Nf, 3, 4).clone()
+    RT[:, 2, 3] = -1.0
+    RT[:, 0, 3] = torch.linspace(-0.1, 0.1, Nf)
+    g = torch.Generator().manual_seed(0)
+    data = {"rgb": torch.zeros(Nf, 3, H, W), "lmk2d": torch.cat([torch.rand(Nf, 70, 2, generator=g) * torch.tensor([W, H]), torch.ones(Nf, 70, 1)], -1),
+            "intrinsic": K, "extrinsic": RT, "timestep_index": torch.from_numpy(ft), "camera_index": torch.arange(Nf) % NVW}
+    tr = GlobalTracker(cfg, model, topo, make_texture(0, 16), data)
+    assert tr.n_timesteps == NT and tr.n_frames == Nf
+    assert tr.expr.shape == (NT, 100) and tr.rotation.shape == (NT, 3)
+    s = tr.get_sample(np.array([2, 0]))
+    assert len(s["timestep_index"]) == 2 * NVW and list(s["timestep_index"]) == [2] * NVW + [0] * NVW
+    assert s["rgb"].shape[0] == 2 * NVW and s["intrinsic"].shape == (2 * NVW, 3, 3)
+    got = sorted(int(i) for i in np.concatenate([tr._frames_of[2], tr._frames_of[0]]))
+    assert got == sorted(int(i) for i in np.nonzero((ft == 2) | (ft == 0))[0])
+    batches = list(ShuffledBatches(tr, 1))
+    assert len(batches) == NT and all(len(set(np.asarray(b["timestep_index"]).tolist())) == 1 and len(b["timestep_index"]) == NVW for b in batches)
+    tr.optimize(evaluate=False)                                      # default batch: one timestep with all its views
+    assert tr.global_step == 2 * 3 + NT * 3 + NT                     # 2 init stages on the first timestep, tracking per timestep, 1 epoch
+    out = tr.save_result()
+    assert out["expr"].shape == (NT, 100) and list(out["timestep_id"]) == list(range(NT))
+    cfg.w.photo = None
+    rep = tr.evaluate(batch_size=2)
+    assert rep["lmk"].shape == (NT,) and np.isfinite(rep["lmk"]).all()
+    with pytest.raises(ValueError):
+        GlobalTracker(cfg, model, topo, make_texture(0, 16), dict(data, timestep_index=torch.from_numpy(ft + 1)))   # timestep 0 has no frame

@@ -137,3 +137,139 @@ def test_native_step_matches_autograd_step(tracker):
         tr.render.disturb_rate_fg, tr.render.disturb_rate_bg = rates
         for p in tr._train_tensors:
             p.grad = None
+
+
+@pytest.mark.parametrize("stage,ts", [("lmk_init_rigid", [0, 1, 2, 3]), ("lmk_init_all", [0, 2]), ("lmk_sequential_tracking", [2]),
+                                      ("rgb_sequential_tracking", [1]), ("rgb_init_texture", [0, 1])])
+def test_native_step_covers_every_stage_kind(tracker, stage, ts):
+    """NativeStep for the landmark-only stages (no pixel chain) and the other photometric stage kinds == the autograd formulation; the
+    reference runs 2 x 500 landmark steps before any photometric one (config/base.py stage table, tracker.py:1352-1357)."""
+    from vhap_amd.step import NativeStep
+    tr = tracker
+    rates = (tr.render.disturb_rate_fg, tr.render.disturb_rate_bg)
+    tr.render.disturb_rate_fg = tr.render.disturb_rate_bg = None
+    try:
+        ts = np.array(ts)
+        E0, log0, g0, _ = _run(tr, stage, ts, True, None)
+        assert NativeStep.supported(tr, stage)
+        ns = NativeStep(tr, tr.get_sample(ts, device_index=True), stage)
+        for _ in range(2):
+            ns.forward()
+            ns.backward(1)
+        torch.cuda.synchronize()
+        log1 = {k: float(v) for k, v in ns.log_dict().items()}
+        for k, v in log0.items():
+            assert abs(v - log1[k]) <= 1e-4 * max(abs(v), 1e-4), f"{stage}: term {k}: autograd {v} native step {log1[k]}"
+        trained = {id(p) for v in tr.get_train_parameters(stage).values() for p in v}
+        for k in NAMES:
+            if id(getattr(tr, k)) not in trained:
+                continue
+            a, b = g0[k], ns.g[k]
+            assert a is not None, k
+            rel = float((a - b.reshape(a.shape)).abs().max() / (a.abs().max() + 1e-30))
+            assert rel < 2e-3, f"{stage}: grad {k}: rel {rel:.3e}"
+    finally:
+        tr.render.disturb_rate_fg, tr.render.disturb_rate_bg = rates
+        for p in tr._train_tensors:
+            p.grad = None
+
+
+def test_optimize_runs_every_stage_through_captured_native_steps(flame_model):
+    """GlobalTracker.optimize() with the default graphed=True on the GPU (tracker.py:1343-1389): landmark stages, photometric stages,
+    sequential tracking and global tracking all replay captured NativeSteps (the landmark stages used to hit a KeyError
+    inside the capture); energies drop and the export is finite."""
+    from vhap_amd.config import BaseTrackingConfig
+    from vhap_amd.flame import FlameHead
+    from vhap_amd.render_hip import HipDiffRenderer
+    from vhap_amd.synthetic import make_dataset, make_scene_params, make_texture
+    from vhap_amd.tracker import GlobalTracker
+    model, topo = flame_model
+    Nf, Hh, Ww, Tt = 4, 96, 96, 128
+    cfg = BaseTrackingConfig()
+    cfg.model.tex_resolution = Tt
+    cfg.batch_size = 2
+    for st in cfg.pipeline.__dict__.values():
+        if hasattr(st, "num_steps"):
+            st.num_steps = 8
+        if hasattr(st, "num_epochs"):
+            st.num_epochs = 2
+    gt = make_scene_params(Nf, seed=5, image_size=(Hh, Ww))
+    head, rend = FlameHead(model, topo).cuda(), HipDiffRenderer(lighting_type="SH").cuda()
+    data = make_dataset(rend, head, gt, (Hh, Ww), "cuda", seed=5, tex=make_texture(5, Tt))
+    tr = GlobalTracker(cfg, model, topo, make_texture(0, Tt), data)
+    with torch.no_grad():
+        tr.translation[:, 2] = 0.40
+    rep0 = tr.evaluate(batch_size=2)
+    report = tr.optimize(batch_size=2, evaluate=True)
+    rep1 = tr.evaluate(batch_size=2)
+    stages = {k[0] for k in tr._graphed}
+    assert {"lmk_init_rigid", "lmk_init_all", "rgb_init_texture", "rgb_init_all", "rgb_init_offset", "rgb_sequential_tracking",
+            "rgb_global_tracking"} <= stages, stages
+    assert all(st.ns is not None for st in tr._graphed.values()), "every stage must replay the native call sequence"
+    assert report is not None and rep1["mean_lmk"] < rep0["mean_lmk"] and rep1["mean_photo"] < rep0["mean_photo"], (rep0, rep1)
+    out = tr.save_result()
+    assert all(np.isfinite(np.asarray(v, np.float64)).all() for v in out.values())
+    assert tr.global_step == 5 * 8 + 2 * 8 + 2 * 2 * 2        # 5 init stages + 2 sequential batches + 2 epochs x 2 batches
+
+
+def test_c_abi_is_reentrant_across_threads(tracker):
+    """ABI 2 keeps no mutable state: a second thread calling ops (the reference's log_media thread renders while the fit runs,
+    tracker.py:817-826) while this thread issues NativeStep passes -- whose calls carry VHAP_CALL_ACC_PREZEROED /
+    VHAP_CALL_AA_PASSTHROUGH_DONE as per-call arguments -- must see the plain behaviour: its antialias backward still writes the
+    pass-through gradient, its shading still clears its own accumulators."""
+    import threading
+    from vhap_amd import ops
+    from vhap_amd.step import NativeStep
+    tr = tracker
+    stage = "rgb_global_tracking"
+    tr.get_train_parameters(stage)
+    rates = (tr.render.disturb_rate_fg, tr.render.disturb_rate_bg)
+    tr.render.disturb_rate_fg = tr.render.disturb_rate_bg = None
+    try:
+        ns = NativeStep(tr, tr.get_sample(np.array([0, 1]), device_index=True), stage)
+        ns.forward()
+        ns.backward(1)
+        torch.cuda.synchronize()
+        g_ref = {k: ns.g[k].detach().clone() for k in ("expr", "lights", "static_offset")}
+        e_ref = float(ns.log[15])
+        rast, pos, tri = ns.rast.clone(), ns.clip.clone(), ns.tri
+        color = torch.rand(2, H, W, 4, device="cuda")
+        w = torch.randn(2, H, W, 4, device="cuda")
+
+        def aa_grad(stream):
+            with torch.cuda.stream(stream):
+                c = color.clone().requires_grad_()
+                (ops.antialias(c, rast, pos, tri, opp=ns.opp) * w).sum().backward()
+                stream.synchronize()
+                return c.grad.clone()
+        want = aa_grad(torch.cuda.Stream())
+        assert float((want - w).abs().max()) < 10.0 and float(want.abs().max()) > 0     # pass-through part present
+        errs, stop = [], threading.Event()
+
+        def worker():
+            s = torch.cuda.Stream()
+            try:
+                while not stop.is_set():
+                    got = aa_grad(s)
+                    if not torch.equal(got, want):
+                        errs.append(float((got - want).abs().max()))
+            except Exception as e:          # noqa: BLE001
+                errs.append(repr(e))
+        th = threading.Thread(target=worker)
+        th.start()
+        try:
+            for _ in range(30):
+                ns.forward()
+                ns.backward(1)
+            torch.cuda.synchronize()
+        finally:
+            stop.set()
+            th.join()
+        assert not errs, errs[:3]
+        assert abs(float(ns.log[15]) - e_ref) <= 1e-5 * abs(e_ref)
+        for k, v in g_ref.items():
+            assert float((ns.g[k] - v).abs().max()) <= 2e-3 * float(v.abs().max()), k
+    finally:
+        tr.render.disturb_rate_fg, tr.render.disturb_rate_bg = rates
+        for p in tr._train_tensors:
+            p.grad = None

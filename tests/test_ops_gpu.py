@@ -159,6 +159,84 @@ def test_antialias_forward_backward(scene):
     assert float((gp - go).norm() / go.norm()) < 5e-2
 
 
+def test_antialias_backward_with_detached_vertices(scene):
+    """vhap_antialias_bwd(pos_nograd_verts) == the reference's detach_by_indices before dr.antialias (render_nvdiffrast.py:349-352,
+    463-464) as restated by the oracle: the masked vertices get exactly zero silhouette gradient, the others the oracle's."""
+    from vhap_amd import ops
+    B, H, W = scene["B"], scene["H"], scene["W"]
+    topo = scene["topo"]
+    g = torch.Generator().manual_seed(13)
+    color = torch.rand(B, H, W, 4, generator=g, dtype=torch.float64)
+    w = torch.randn(B, H, W, 4, generator=g, dtype=torch.float64)
+    opp = torch.from_numpy(topo.opp.astype(np.int64))
+    vid = torch.from_numpy(topo.get_vid_by_region(["hair", "boundary", "ears"]))       # a real stage's kind of exclusion list
+    V = scene["pos"].shape[1]
+    assert 50 < vid.numel() < V - 50
+    pos_o = scene["pos"].clone().requires_grad_()
+    vc = pos_o.clone()
+    vc[:, vid] = pos_o[:, vid].detach()
+    rast_o, _ = R.rast_from_ids(pos_o.detach(), scene["tri"], scene["tid"], (H, W))
+    (R.antialias(color, rast_o, vc, scene["tri"], opp) * w).sum().backward()
+    go = pos_o.grad
+    assert float(go[:, vid].abs().max()) == 0 and float(go.abs().max()) > 0
+    # the mask must matter: without it those vertices do receive gradient
+    pos_u = scene["pos"].clone().requires_grad_()
+    (R.antialias(color, rast_o, pos_u, scene["tri"], opp) * w).sum().backward()
+    assert float(pos_u.grad[:, vid].abs().max()) > 0
+
+    mask = torch.zeros(V, dtype=torch.uint8)
+    mask[vid] = 1
+    pos_g = scene["pos"].float().cuda().requires_grad_()
+    out = ops.antialias(color.float().cuda(), rast_o.float().cuda(), pos_g, scene["tri"].int().cuda(), opp=opp.int().cuda(),
+                        pos_nograd_verts=mask.cuda())
+    (out * w.float().cuda()).sum().backward()
+    gp = pos_g.grad.double().cpu()
+    assert float(gp[:, vid].abs().max()) == 0
+    assert float((gp - go).norm() / go.norm()) < 5e-2
+
+
+def test_gbuffer_backward_with_uv_detached_faces(scene):
+    """vhap_gbuffer_bwd(uv_nograd_faces) == the reference's `texc = torch.where(mask[fid], texc.detach(), texc)`
+    (render_nvdiffrast.py:390-396) as restated by the oracle: on masked faces d_texc is dropped while d_texd and d_normal still flow."""
+    from vhap_amd import ops
+    B, H, W = scene["B"], scene["H"], scene["W"]
+    topo = scene["topo"]
+    g = torch.Generator().manual_seed(14)
+    V = scene["pos"].shape[1]
+    F = scene["tri"].shape[0]
+    fid = torch.from_numpy(topo.get_fid_by_region(["hair", "boundary", "neck"]))
+    assert 100 < fid.numel() < F - 100
+    vn = torch.nn.functional.normalize(torch.randn(B, V, 3, generator=g, dtype=torch.float64), dim=-1)
+    uv = torch.from_numpy(topo.verts_uvs.astype(np.float64))
+    tri_uv = torch.from_numpy(topo.faces_uv.astype(np.int64))
+    wn, wc, wd = (torch.randn(B, H, W, k, generator=g, dtype=torch.float64) for k in (3, 2, 4))
+    wd = wd * 0.01
+
+    def oracle_grads(masked):
+        pos_o, vn_o = scene["pos"].clone().requires_grad_(), vn.clone().requires_grad_()
+        rast_o, db_o = R.rast_from_ids(pos_o, scene["tri"], scene["tid"], (H, W))
+        normal, _ = R.interpolate(vn_o, rast_o, scene["tri"])
+        texc, texd = R.interpolate(uv[None], rast_o, tri_uv, db_o, "all")
+        if masked:
+            m = torch.zeros(F + 1, dtype=torch.bool)
+            m[fid + 1] = True
+            texc = torch.where(m[rast_o[..., 3].detach().long()][..., None], texc.detach(), texc)
+        ((normal * wn).sum() + (texc * wc).sum() + (texd * wd).sum()).backward()
+        return pos_o.grad, vn_o.grad
+
+    gp_o, gn_o = oracle_grads(True)
+    gp_u, _ = oracle_grads(False)
+    assert float((gp_o - gp_u).abs().max()) > 1e-3 * float(gp_u.abs().max())            # the mask changes the answer
+    mask = torch.zeros(F, dtype=torch.uint8)
+    mask[fid] = 1
+    pos_g, vn_g = scene["pos"].float().cuda().requires_grad_(), vn.float().cuda().requires_grad_()
+    rast, db, normal, texc, texd = ops.raster_interp(ops.RasterizeHipContext(), pos_g, scene["tri"].int().cuda(), vn_g, uv.float().cuda(),
+                                                     tri_uv.int().cuda(), (H, W), uv_nograd_faces=mask.cuda())
+    ((normal * wn.float().cuda()).sum() + (texc * wc.float().cuda()).sum() + (texd * wd.float().cuda()).sum()).backward()
+    assert _rel(vn_g.grad, gn_o) < 2e-3
+    assert _rel(pos_g.grad, gp_o) < 1e-2
+
+
 def test_antialias_vertical_edge_known_answer():
     """A vertical silhouette at x = k + 0.25 px blends the two pixels with weights 0.25 / 0.75."""
     from vhap_amd import ops

@@ -53,6 +53,13 @@ class FrameShardContext:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
+    def broadcast_int(self, value, src=0):
+        """The same Python int on every rank (rank `src`'s)."""
+        dev = "cuda" if dist.get_backend(self.group) == "nccl" else "cpu"
+        t = torch.tensor([int(value)], dtype=torch.int64, device=dev)
+        dist.broadcast(t, src=src, group=self.group)
+        return int(t.item())
+
     def all_reduce_mean_(self, t, async_op=False):
         """In-place mean over ranks of a contiguous tensor (RCCL averages in the collective; gloo sums, then scales).  With
         async_op the collective is only enqueued (it still waits for the work already on the current stream) and the returned handle's

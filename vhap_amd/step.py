@@ -19,7 +19,7 @@ from . import _lib
 from . import native as NV
 from .config import PhotometricStageConfig
 from .native import _n_gather
-from .ops import _p, _stream
+from .ops import _hook, _p, _stream
 
 PRE = _lib.CALL_ACC_PREZEROED        # per-call flag (ABI 2): this call's small accumulators were cleared by the arena clear
 
@@ -42,10 +42,11 @@ class _Null:
 class NativeStep:
     @staticmethod
     def supported(tracker, stage):
+        """Every stage kind of the pipeline: photometric stages (monocular: focal length trained; calibrated multi-view: per-view K / RT from
+        the sample, tracker.py:141-157) and the landmark-only stages (lmk_init_*, lmk_*_tracking: no pixel chain at all)."""
         cfg = tracker.cfg
-        return (tracker._native_ok(stage) and isinstance(cfg.pipeline[stage], PhotometricStageConfig) and cfg.w.photo is not None and
-                cfg.render.background_train in ("target", "white", "black") and tracker.static_offset is not None and
-                not tracker.calibrated)
+        photometric = isinstance(cfg.pipeline[stage], PhotometricStageConfig) and cfg.w.photo is not None
+        return tracker._native_ok(stage) and (not photometric or cfg.render.background_train in ("target", "white", "black"))
 
     def __init__(self, tracker, sample, stage):
         tr = self.tr = tracker
@@ -61,6 +62,11 @@ class NativeStep:
         ts = sample["timestep_index"]
         self.ts = (ts if torch.is_tensor(ts) else torch.as_tensor(np.asarray(ts), device=dev)).long().contiguous()
         self.rgb = sample["rgb"].contiguous()                        # [B,3,H,W] image space (static: new batches are copied in)
+        self.photometric = isinstance(cfg.pipeline[stage], PhotometricStageConfig) and w.photo is not None
+        self.calibrated = bool(tr.calibrated)
+        self.has_offset = tr.static_offset is not None
+        if self.calibrated:                                          # static sample tensors: read by every forward (new batches are copied in)
+            self.K_in, self.RT_in = sample["intrinsic"], sample["extrinsic"]
         self.lmk2d = sample["lmk2d"].float().contiguous()
         B = self.B = int(self.ts.shape[0])
         H, W = self.H, self.W = tr.image_size
@@ -80,7 +86,7 @@ class NativeStep:
         self.F = int(self.tri.shape[0])
         self.tri_uv = tr.render._tri32(fl.textures_idx)
         self.uv = tr._verts_uv_flipped
-        fid, vid = tr._regions(stage)
+        fid, vid = tr._regions(stage) if self.photometric else (None, None)
         self.face_mask = tr.render._u8_mask(fid, self.F) if fid is not None else None
         self.vert_mask = tr.render._u8_mask(vid, V) if vid is not None else None
         self.painted = tr.flame_tex_painted()[0].contiguous()
@@ -95,13 +101,13 @@ class NativeStep:
         self.w_lmk = float(w.landmark or 0.0)
         self.want_reg = bool(o["lights"]) and w.reg_diffuse is not None
         self.w_reg = float(w.reg_diffuse or 0.0) if self.want_reg else 0.0
-        self.w_photo = float(w.photo)
+        self.w_photo = float(w.photo or 0.0)
         disable_jaw = not w.always_enable_jawline_landmarks and cfg.pipeline[stage]["disable_jawline_landmarks"]
         self.lmk_cfg = (17, 68, 0, 0, 1.0) if disable_jaw else (0, 68, 27, 36, 10.0)
         bg = cfg.render.background_train
         self.bg_col = None if bg == "target" else (ctypes.c_float * 3)(*([1.0, 1.0, 1.0] if bg == "white" else [0.0, 0.0, 0.0]))
         self.rate_fg, self.rate_bg = tr.render.disturb_rate_fg, tr.render.disturb_rate_bg
-        self.disturb_on = bool(self.rate_fg or self.rate_bg)
+        self.disturb_on = bool(self.rate_fg or self.rate_bg) and self.photometric
         if self.disturb_on:
             r = tr.render
             if r._rng_state is None or r._rng_state.device != self.rgb.device:
@@ -111,33 +117,43 @@ class NativeStep:
             self.fid2cid, self.ncl, self.rng = r._fid2cid_i32, r._ncl, r._rng_state
         self.K1, self.K0 = nm["K1"], nm["K0"]
         self.focal_scale = float(max(H, W))
-        self.RT = tr.RT[None, :3, :].contiguous()
+        self.RT = E(B, 3, 4) if self.calibrated else tr.RT[None, :3, :].contiguous()
         self.sh_const = tr.render.sh_const.contiguous()
         # ---- forward buffers ----
         self.coef, self.A, self.transl, self.Jrest = E(Bp, fb.Kp), E(B, J, 12), E(B, 3), E(B, J * 3)
         self.verts, self.v_shaped, self.v_posed = E(B, V, 3), E(B, V, 3), E(B, V, 3)
-        self.K, self.mvp, self.clip, self.vn = E(1, 4), E(B, 4, 4), E(B, V, 4), E(B, V, 3)
-        self.rast, self.db, self.normal, self.texc, self.texd = E(B, H, W, 4), E(B, H, W, 4), E(B, H, W, 3), E(B, H, W, 2), E(B, H, W, 4)
-        self.albedo_tex = E(1, T, T, 3)
-        self.mips = E(L.vhap_texture_mip_floats(1, T, T, 3))
-        self.albedo_px, self.rgba, self.rgba_aa = E(B, H, W, 3), E(B, H, W, 4), E(B, H, W, 4)
-        if self.disturb_on:
-            self.rgba_d, self.keep = E(B, H, W, 4), E(B, H, W)
-            self.dist_ws = torch.empty(L.vhap_disturb_workspace_ints(B, H, W), dtype=torch.int32, device=dev)
-            self.cid = torch.empty(B, H, W, dtype=torch.uint8, device=dev)
-        self.aa_work = torch.empty(L.vhap_antialias_work_ints(B, H, W, self.F), dtype=torch.int32, device=dev)
-        self.ws, self.ws_bytes, self.ws_cap, _ = tr.render.glctx.acquire(B, self.F, H, W, self.rgb.device)
+        self.K, self.mvp = E(B if self.calibrated else 1, 4), E(B, 4, 4)
+        self.tex_fwd_on = self.photometric or tex_on                  # the texture is assembled only when something reads it
+        if self.tex_fwd_on:
+            self.albedo_tex = E(1, T, T, 3)
+            self.mips = E(L.vhap_texture_mip_floats(1, T, T, 3))
+        else:
+            self.albedo_tex, self.mips = E(0), E(0)
+        if self.photometric:
+            self.clip, self.vn = E(B, V, 4), E(B, V, 3)
+            self.rast, self.db, self.normal, self.texc, self.texd = E(B, H, W, 4), E(B, H, W, 4), E(B, H, W, 3), E(B, H, W, 2), E(B, H, W, 4)
+            self.albedo_px, self.rgba, self.rgba_aa = E(B, H, W, 3), E(B, H, W, 4), E(B, H, W, 4)
+            if self.disturb_on:
+                self.rgba_d, self.keep = E(B, H, W, 4), E(B, H, W)
+                self.dist_ws = torch.empty(L.vhap_disturb_workspace_ints(B, H, W), dtype=torch.int32, device=dev)
+                self.cid = torch.empty(B, H, W, dtype=torch.uint8, device=dev)
+            self.aa_work = torch.empty(L.vhap_antialias_work_ints(B, H, W, self.F), dtype=torch.int32, device=dev)
+            self.ws, self.ws_bytes, self.ws_cap, _ = tr.render.glctx.acquire(B, self.F, H, W, self.rgb.device)
         # forward accumulators: frame terms [0:6], landmark [6], texture terms [7:9], offset terms [9:12], shade stats [12:16], photo [16:18]
         self.accF = torch.zeros(32, **f32)
         self.log = torch.zeros(16, **f32)
         self.n_global = self.accF[17:18]                      # replaced by the all-reduced count under frame sharding
         # ---- backward: one arena for everything that is accumulated into ----
         params = {"shape": tr.shape, "expr": tr.expr, "rotation": tr.rotation, "translation": tr.translation, "neck_pose": tr.neck_pose,
-                  "jaw_pose": tr.jaw_pose, "eyes_pose": tr.eyes_pose, "lights": tr.lights, "static_offset": tr.static_offset,
-                  "focal_length": tr.focal_length}
+                  "jaw_pose": tr.jaw_pose, "eyes_pose": tr.eyes_pose, "lights": tr.lights}
+        if self.has_offset:
+            params["static_offset"] = tr.static_offset
+        if not self.calibrated:
+            params["focal_length"] = tr.focal_length
         sizes = {k: p.numel() for k, p in params.items()}
-        extra = {"d_clip": B * V * 4, "d_vn": B * V * 3, "d_verts": B * V * 3, "d_A": B * J * 12, "d_t": B * 3, "d_coef": Bp * fb.Kp,
-                 "d_tex": self.albedo_tex.numel() + self.mips.numel()}
+        extra = {"d_verts": B * V * 3, "d_A": B * J * 12, "d_t": B * 3, "d_coef": Bp * fb.Kp}
+        if self.photometric:
+            extra.update({"d_clip": B * V * 4, "d_vn": B * V * 3, "d_tex": self.albedo_tex.numel() + self.mips.numel()})
         al = lambda n: (n + 63) // 64 * 64
         total = sum(al(n) for n in sizes.values()) + sum(al(n) for n in extra.values())
         self.arena = torch.zeros(total, **f32)
@@ -150,15 +166,20 @@ class NativeStep:
         for k, n in extra.items():
             self.g[k] = self.arena[off:off + n]
             off += al(n)
-        self.g["tex_extra"] = torch.zeros_like(tr.tex_extra)          # overwritten by tex_prep_bwd, never accumulated
-        self.params = dict(params, tex_extra=tr.tex_extra)
+        self.params = dict(params)
+        self.tex_bwd_on = tex_on and (self.photometric or any(self.tex_scales))
+        if self.tex_bwd_on:
+            self.g["tex_extra"] = torch.zeros_like(tr.tex_extra)      # overwritten by tex_prep_bwd, never accumulated
+            self.params["tex_extra"] = tr.tex_extra
         for k, p in self.params.items():                              # the optimiser and the gradient all-reduce see these
             p.grad = self.g[k]
         # scratch that is overwritten
-        self.d_rgba_aa, self.d_color, self.d_rgba = E(B, H, W, 4), E(B, H, W, 4), E(B, H, W, 4)
-        self.d_albedo, self.d_normal, self.d_texc, self.d_texd = E(B, H, W, 3), E(B, H, W, 3), E(B, H, W, 2), E(B, H, W, 4)
-        self.texbin_work = torch.empty(self.L.vhap_texture_grad_binned_work_bytes(B, H, W), dtype=torch.uint8, device=dev)
-        self.vn_scratch, self.g_posed, self.g_shaped = E(B, V, 3), E(B, V, 3), E(B, V, 3)
+        if self.photometric:
+            self.d_rgba_aa, self.d_color, self.d_rgba = E(B, H, W, 4), E(B, H, W, 4), E(B, H, W, 4)
+            self.d_albedo, self.d_normal, self.d_texc, self.d_texd = E(B, H, W, 3), E(B, H, W, 3), E(B, H, W, 2), E(B, H, W, 4)
+            self.texbin_work = torch.empty(self.L.vhap_texture_grad_binned_work_bytes(B, H, W), dtype=torch.uint8, device=dev)
+            self.vn_scratch = E(B, V, 3)
+        self.g_posed, self.g_shaped = E(B, V, 3), E(B, V, 3)
         self.d_mvp, self.d_K, self.d_sum = E(B, 16), E(B, 4), E(1)
         self.ones = torch.ones(8, **f32)
         # two independent chains per pass run on two streams (two branches of the captured graph): the bandwidth / atomics bound texture
@@ -187,72 +208,108 @@ class NativeStep:
         """texture assembly + pyramid + the offset regularisers: independent of the geometry chain until the texture is sampled"""
         L, tr, T, acc = self.L, self.tr, self.T, self.accF
         st = _stream()
-        _chk(L.vhap_tex_prep_fwd(_p(self.painted), _p(tr.tex_extra), _p(self.nm["res_mask"]), T, *self.tex_scales, _p(self.albedo_tex),
-                                 _p(acc[7:9]), PRE, st), "vhap_tex_prep_fwd")
-        _chk(L.vhap_texture_mip_build(_p(self.albedo_tex), 1, T, T, 3, _p(self.mips), st), "vhap_texture_mip_build")
-        om = self.om
-        _chk(L.vhap_offset_reg_fwd(_p(tr.static_offset), _p(om.ptr), _p(om.col), _p(om.val), _p(om.w_lap), _p(om.w_abs), _p(om.rptr), _p(om.ridx),
-                                   om.V, om.nreg, *self.off_scales, _p(acc[9:12]), PRE, st), "vhap_offset_reg_fwd")
+        if self.tex_fwd_on:
+            _chk(L.vhap_tex_prep_fwd(_p(self.painted), _p(tr.tex_extra), _p(self.nm["res_mask"]), T, *self.tex_scales, _p(self.albedo_tex),
+                                     _p(acc[7:9]), PRE, st), "vhap_tex_prep_fwd")
+            if self.photometric:
+                _chk(L.vhap_texture_mip_build(_p(self.albedo_tex), 1, T, T, 3, _p(self.mips), st), "vhap_texture_mip_build")
+        if self.has_offset and any(self.off_scales):
+            om = self.om
+            _chk(L.vhap_offset_reg_fwd(_p(tr.static_offset), _p(om.ptr), _p(om.col), _p(om.val), _p(om.w_lap), _p(om.w_abs), _p(om.rptr),
+                                       _p(om.ridx), om.V, om.nreg, *self.off_scales, _p(acc[9:12]), PRE, st), "vhap_offset_reg_fwd")
+
+    def _camera_forward(self):
+        L, tr, B, H, W = self.L, self.tr, self.B, self.H, self.W
+        if self.calibrated:
+            # per-view intrinsics / extrinsics of the sample (tracker.py:141-147): K [B,3,3] or [B,4] -> (fx, fy, cx, cy); RT [B,3|4,4]
+            K = self.K_in
+            if K.shape[-2:] == (3, 3):
+                torch.stack([K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2]], dim=-1, out=self.K)
+            else:
+                self.K.copy_(K)
+            self.RT.copy_(self.RT_in[:, :3, :])
+            kb = rb = 1
+        else:
+            torch.addcmul(self.K0, tr.focal_length.detach(), self.K1, out=self.K)      # K = (f, f, cx, cy), f = focal * max(h, w)
+            kb = rb = 0
+        _chk(L.vhap_camera_fwd(_p(self.K), _p(self.RT), B, kb, rb, H, W, 0.1, 10.0, _p(self.mvp), _stream()), "vhap_camera_fwd")
+
+    def _landmark_forward(self):
+        L, B, H, W, V = self.L, self.B, self.H, self.W, self.V
+        l0, l1, b0, b1, boost = self.lmk_cfg
+        _chk(L.vhap_landmark_fwd(_p(self.verts), _p(self.lm.vidx), _p(self.lm.bary), _p(self.mvp), _p(self.lmk2d), B, V, self.lm.L,
+                                 self.lmk2d.shape[1], l0, l1, b0, b1, boost, H, W, 0, _p(self.accF[6:7]), PRE, _stream()), "vhap_landmark_fwd")
 
     def forward(self):
+        """Every accumulator below comes from the arena cleared by the first launch: the calls get VHAP_CALL_ACC_PREZEROED."""
         L, tr, fb, fm = self.L, self.tr, self.fb, self.fm
         B, H, W, V, F, T, J = self.B, self.H, self.W, self.V, self.F, self.T, self.J
         st = _stream()
         acc = self.accF
         acc.zero_()                                                   # ONE launch clears every forward accumulator
-        if True:           # every accumulator below comes from the arena just cleared: the calls get VHAP_CALL_ACC_PREZEROED
-            so = tr.static_offset
-            # the camera first: two tiny launches that would take 3-5x as long next to the texture branch below
-            torch.addcmul(self.K0, tr.focal_length.detach(), self.K1, out=self.K)      # K = (f, f, cx, cy), f = focal * max(h, w)
-            _chk(L.vhap_camera_fwd(_p(self.K), _p(self.RT), B, 0, 0, H, W, 0.1, 10.0, _p(self.mvp), st), "vhap_camera_fwd")
-            _chk(L.vhap_frame_prep_fwd(_p(self.ts), _p(tr.shape), _p(tr.expr), _p(tr.rotation), _p(tr.translation), _p(tr.neck_pose),
-                                       _p(tr.jaw_pose), _p(tr.eyes_pose), _p(fm.JT), _p(fm.JS), _p(fm.jreg_idx), _p(fm.jreg_w), fm.jreg_n,
-                                       _p(so), fm.parents, self.weights, B, self.Bp, self.N, self.NS, self.NE, J, fb.Kp, V,
-                                       _p(self.coef), _p(self.A), _p(self.transl), _p(self.Jrest), _p(acc), PRE, st), "vhap_frame_prep_fwd")
-            _chk(L.vhap_flame_skin_fwd(_p(self.coef), _p(fb.basis), _p(self.A), _p(fb.w), _p(fb.templ), _p(so), _p(self.transl), B, V, fb.Vp,
-                                       fb.K, fb.Kb, fb.Kp, _p(self.verts), _p(self.v_shaped), _p(self.v_posed), st), "vhap_flame_skin_fwd")
-            # fork here, not at the top: next to the bandwidth-bound texture assembly the two latency-bound kernels above take 3x as long,
-            # and they head the critical path of the forward pass; the texture branch still finishes long before the rasteriser does
-            self._fork()
-            with self._branch():
-                self._tex_forward()
-                if self.w_lmk:                                        # needs only verts + mvp: off the rasteriser's critical path
-                    l0, l1, b0, b1, boost = self.lmk_cfg
-                    _chk(L.vhap_landmark_fwd(_p(self.verts), _p(self.lm.vidx), _p(self.lm.bary), _p(self.mvp), _p(self.lmk2d), B, V, self.lm.L,
-                                             self.lmk2d.shape[1], l0, l1, b0, b1, boost, H, W, 0, _p(acc[6:7]), PRE, _stream()), "vhap_landmark_fwd")
-                self.arena.zero_()                                    # ONE launch clears every gradient accumulator of the backward
-                self._arena_clean = True
-            _chk(L.vhap_transform_fwd(_p(self.verts), _p(self.mvp), B, V, _p(self.clip), st), "vhap_transform_fwd")
-            _chk(L.vhap_vnormal_fwd(_p(self.verts), _p(self.csr.tri), _p(self.csr.ptr), _p(self.csr.idx), B, V, _p(self.vn), st), "vhap_vnormal_fwd")
-            _chk(L.vhap_raster_interp_fwd(_p(self.clip), _p(self.tri), _p(self.vn), _p(self.uv), _p(self.tri_uv), B, V, self.uv.shape[0], F, H, W,
-                                          _p(self.rast), _p(self.db), _p(self.normal), _p(self.texc), _p(self.texd), _p(self.ws), self.ws_bytes,
-                                          self.ws_cap, 1, st), "vhap_raster_interp_fwd")
-            self._join()
-            _chk(L.vhap_texture_fwd(_p(self.albedo_tex), _p(self.mips), 1, T, T, 3, _p(self.texc), _p(self.texd), B, H, W, _p(self.albedo_px), st),
-                 "vhap_texture_fwd")
-            _chk(L.vhap_shade_fwd(_p(self.normal), _p(self.albedo_px), _p(self.rast), _p(self.rgb) if self.bg_col is None else 0,
-                                  ctypes.cast(self.bg_col, ctypes.c_void_p) if self.bg_col is not None else 0, _p(tr.lights), _p(self.sh_const),
-                                  _p(self.fid2cid) if self.disturb_on else 0, self.fid2cid.numel() if self.disturb_on else 0,
-                                  B, H, W, _p(self.rgba), _p(acc[12:16]) if self.want_reg else 0, _p(self.cid) if self.disturb_on else 0, PRE, st),
-                 "vhap_shade_fwd")
-            color = self.rgba
-            if self.disturb_on:
-                _chk(L.vhap_disturb_fwd_rng_cid(_p(self.rgba), _p(self.cid), self.ncl, float(self.rate_fg or 0.0), float(self.rate_bg or 0.0),
-                                                _p(self.rng), B, H, W, _p(self.dist_ws), _p(self.rgba_d), _p(self.keep), st),
-                     "vhap_disturb_fwd_rng_cid")
-                color = self.rgba_d
-            self.aa_in = color
-            _chk(L.vhap_antialias_fwd(_p(color), _p(self.rast), _p(self.clip), _p(self.tri), _p(self.opp), B, H, W, 4, V, F, _p(self.rgba_aa),
-                                      _p(self.aa_work), st), "vhap_antialias_fwd")
-            _chk(L.vhap_photo_fwd(_p(self.rgba_aa), _p(self.rgb), B, H, W, _p(acc[16:18]), PRE, st), "vhap_photo_fwd")
-            _chk(L.vhap_energy_finalize(_p(acc[0:6]), _p(acc[6:7]) if self.w_lmk else 0, _p(acc[7:9]), _p(acc[9:12]),
-                                        _p(acc[12:16]) if self.want_reg else 0, self.w_lmk, self.w_reg, B, H, W, _p(self.log), st),
-                 "vhap_energy_finalize")
+        so = tr.static_offset
+        # the camera first: two tiny launches that would take 3-5x as long next to the texture branch below
+        self._camera_forward()
+        _chk(L.vhap_frame_prep_fwd(_p(self.ts), _p(tr.shape), _p(tr.expr), _p(tr.rotation), _p(tr.translation), _p(tr.neck_pose),
+                                   _p(tr.jaw_pose), _p(tr.eyes_pose), _p(fm.JT), _p(fm.JS), _p(fm.jreg_idx), _p(fm.jreg_w), fm.jreg_n,
+                                   _p(so), fm.parents, self.weights, B, self.Bp, self.N, self.NS, self.NE, J, fb.Kp, V,
+                                   _p(self.coef), _p(self.A), _p(self.transl), _p(self.Jrest), _p(acc), PRE, st), "vhap_frame_prep_fwd")
+        _chk(L.vhap_flame_skin_fwd(_p(self.coef), _p(fb.basis), _p(self.A), _p(fb.w), _p(fb.templ), _p(so), _p(self.transl), B, V, fb.Vp,
+                                   fb.K, fb.Kb, fb.Kp, _p(self.verts), _p(self.v_shaped), _p(self.v_posed), st), "vhap_flame_skin_fwd")
+        if not self.photometric:
+            # landmark-only stage (lmk_init_*, lmk_*_tracking): no pixel chain, a handful of latency-bound launches
+            self._tex_forward()
+            if self.w_lmk:
+                self._landmark_forward()
+            self.arena.zero_()
+            self._arena_clean = True
+            _chk(L.vhap_energy_finalize(_p(acc[0:6]), _p(acc[6:7]) if self.w_lmk else 0, _p(acc[7:9]), _p(acc[9:12]), 0, self.w_lmk, 0.0,
+                                        B, H, W, _p(self.log), st), "vhap_energy_finalize")
+            return
+        # fork here, not at the top: next to the bandwidth-bound texture assembly the two latency-bound kernels above take 3x as long,
+        # and they head the critical path of the forward pass; the texture branch still finishes long before the rasteriser does
+        self._fork()
+        with self._branch():
+            self._tex_forward()
+            if self.w_lmk:                                        # needs only verts + mvp: off the rasteriser's critical path
+                self._landmark_forward()
+            self.arena.zero_()                                    # ONE launch clears every gradient accumulator of the backward
+            self._arena_clean = True
+        _chk(L.vhap_transform_fwd(_p(self.verts), _p(self.mvp), B, V, _p(self.clip), st), "vhap_transform_fwd")
+        _chk(L.vhap_vnormal_fwd(_p(self.verts), _p(self.csr.tri), _p(self.csr.ptr), _p(self.csr.idx), B, V, _p(self.vn), st), "vhap_vnormal_fwd")
+        _hook("raster_interp_fwd", "begin")                       # (bench.py: HIP events / event-record graph nodes around the RI-fwd pass)
+        _chk(L.vhap_raster_interp_fwd(_p(self.clip), _p(self.tri), _p(self.vn), _p(self.uv), _p(self.tri_uv), B, V, self.uv.shape[0], F, H, W,
+                                      _p(self.rast), _p(self.db), _p(self.normal), _p(self.texc), _p(self.texd), _p(self.ws), self.ws_bytes,
+                                      self.ws_cap, 1, st), "vhap_raster_interp_fwd")
+        _hook("raster_interp_fwd", "end")
+        self._join()
+        _chk(L.vhap_texture_fwd(_p(self.albedo_tex), _p(self.mips), 1, T, T, 3, _p(self.texc), _p(self.texd), B, H, W, _p(self.albedo_px), st),
+             "vhap_texture_fwd")
+        _chk(L.vhap_shade_fwd(_p(self.normal), _p(self.albedo_px), _p(self.rast), _p(self.rgb) if self.bg_col is None else 0,
+                              ctypes.cast(self.bg_col, ctypes.c_void_p) if self.bg_col is not None else 0, _p(tr.lights), _p(self.sh_const),
+                              _p(self.fid2cid) if self.disturb_on else 0, self.fid2cid.numel() if self.disturb_on else 0,
+                              B, H, W, _p(self.rgba), _p(acc[12:16]) if self.want_reg else 0, _p(self.cid) if self.disturb_on else 0, PRE, st),
+             "vhap_shade_fwd")
+        color = self.rgba
+        if self.disturb_on:
+            _chk(L.vhap_disturb_fwd_rng_cid(_p(self.rgba), _p(self.cid), self.ncl, float(self.rate_fg or 0.0), float(self.rate_bg or 0.0),
+                                            _p(self.rng), B, H, W, _p(self.dist_ws), _p(self.rgba_d), _p(self.keep), st),
+                 "vhap_disturb_fwd_rng_cid")
+            color = self.rgba_d
+        self.aa_in = color
+        _chk(L.vhap_antialias_fwd(_p(color), _p(self.rast), _p(self.clip), _p(self.tri), _p(self.opp), B, H, W, 4, V, F, _p(self.rgba_aa),
+                                  _p(self.aa_work), st), "vhap_antialias_fwd")
+        _chk(L.vhap_photo_fwd(_p(self.rgba_aa), _p(self.rgb), B, H, W, _p(acc[16:18]), PRE, st), "vhap_photo_fwd")
+        _chk(L.vhap_energy_finalize(_p(acc[0:6]), _p(acc[6:7]) if self.w_lmk else 0, _p(acc[7:9]), _p(acc[9:12]),
+                                    _p(acc[12:16]) if self.want_reg else 0, self.w_lmk, self.w_reg, B, H, W, _p(self.log), st),
+             "vhap_energy_finalize")
 
     def _tex_backward(self):
         L, tr, T, g = self.L, self.tr, self.T, self.g
         B, H, W = self.B, self.H, self.W
         st = _stream()
+        if not self.tex_bwd_on:
+            return
         n0 = self.albedo_tex.numel()
         d_tex, d_mips = g["d_tex"][:n0], g["d_tex"][n0:]
         if not (NV.use_binned_texgrad() and NV.texture_grad_binned(T, 3, self.texc, self.texd, self.d_albedo, d_tex, d_mips, self.texbin_work)):
@@ -267,6 +324,10 @@ class NativeStep:
         `tex_l0_skip` the level-0 part of the pyramid is not exchanged and therefore not used either."""
         L, tr, T, g = self.L, self.tr, self.T, self.g
         st = _stream()
+        if not self.photometric:                                      # only the TV / residual gradients (a landmark stage that trains the texture)
+            _chk(L.vhap_tex_prep_bwd(_p(self.albedo_tex), _p(tr.tex_extra), _p(self.nm["res_mask"]), 0, 0, 0, _p(self.ones), T, *self.tex_scales,
+                                     _p(g["tex_extra"]), st), "vhap_tex_prep_bwd")
+            return
         n0 = self.albedo_tex.numel()
         d_tex, d_mips = g["d_tex"][:n0], g["d_tex"][n0:]
         has_mips = self.mips.numel() > 0
@@ -289,9 +350,10 @@ class NativeStep:
                  "vhap_landmark_bwd")
         else:
             self.d_mvp.zero_()
-        _chk(L.vhap_offset_reg_bwd(_p(tr.static_offset), _p(om.ptr), _p(om.col), _p(om.val), _p(om.w_lap), _p(om.w_abs), _p(om.rptr),
-                                   _p(om.ridx), om.V, om.nreg, *self.off_scales, _p(self.ones), _p(g["static_offset"]), st),
-             "vhap_offset_reg_bwd")
+        if self.has_offset and any(self.off_scales):
+            _chk(L.vhap_offset_reg_bwd(_p(tr.static_offset), _p(om.ptr), _p(om.col), _p(om.val), _p(om.w_lap), _p(om.w_abs), _p(om.rptr),
+                                       _p(om.ridx), om.V, om.nreg, *self.off_scales, _p(self.ones), _p(g["static_offset"]), st),
+                 "vhap_offset_reg_bwd")
 
     def _bwd_pixel(self, world_size):
         """energy total -> photometric -> antialias -> shading backward (-> d_albedo, d_normal per pixel)"""
@@ -316,10 +378,30 @@ class NativeStep:
         _chk(L.vhap_texture_bwd(_p(self.albedo_tex), _p(self.mips), 1, T, T, 3, _p(self.texc), _p(self.texd), _p(self.d_albedo), B, H, W,
                                 0, 0, _p(self.d_texc), _p(self.d_texd), _stream()), "vhap_texture_bwd")
 
+    def _bwd_params(self):
+        """d_verts, d_mvp -> camera -> skinning -> per-frame parameters (the tail shared by photometric and landmark-only stages)"""
+        L, tr, fb, fm, g = self.L, self.tr, self.fb, self.fm, self.g
+        B, H, W, V, J = self.B, self.H, self.W, self.V, self.J
+        st = _stream()
+        if not self.calibrated:                                       # the focal length is a parameter only without calibration (tracker.py:148-157)
+            _chk(L.vhap_camera_bwd(_p(self.RT), _p(self.d_mvp), B, 0, H, W, _p(self.d_K), st), "vhap_camera_bwd")
+            _chk(L.vhap_focal_bwd(_p(self.d_K), B, self.focal_scale, _p(g["focal_length"]), st), "vhap_focal_bwd")
+        _chk(L.vhap_flame_skin_bwd(_p(g["d_verts"]), 0, _p(self.v_posed), _p(self.A), _p(fb.w), _p(fb.basisT), B, V, fb.Vp, fb.Kb, fb.Kp,
+                                   _p(self.g_posed), _p(self.g_shaped), 0, _p(g["d_coef"]), _p(g["d_A"]), _p(g["d_t"]), PRE, st),
+             "vhap_flame_skin_bwd")
+        if self.has_offset:
+            _chk(L.vhap_sum_frames(_p(self.g_shaped), B, V * 3, _p(g["static_offset"]), st), "vhap_sum_frames")
+        _chk(L.vhap_frame_prep_bwd(_p(self.ts), _p(tr.shape), _p(tr.expr), _p(tr.rotation), _p(tr.translation), _p(tr.neck_pose),
+                                   _p(tr.jaw_pose), _p(tr.eyes_pose), _p(fm.JS), _p(fm.jreg_idx), _p(fm.jreg_w), fm.jreg_n,
+                                   _p(tr.static_offset), fm.parents, self.weights, _p(self.Jrest), _p(g["d_coef"]), _p(g["d_A"]), _p(g["d_t"]),
+                                   _p(self.ones), B, self.Bp, self.N, self.NS, self.NE, J, fb.Kp, V, _p(g["shape"]), _p(g["expr"]),
+                                   _p(g["rotation"]), _p(g["translation"]), _p(g["neck_pose"]), _p(g["jaw_pose"]), _p(g["eyes_pose"]),
+                                   _p(g["static_offset"]) if self.has_offset else 0, st), "vhap_frame_prep_bwd")
+
     def _bwd_geometry(self, early=None):
         """G-buffer backward -> vertex normals -> clip transform -> camera -> skinning -> per-frame parameters"""
-        L, tr, fb, fm, g = self.L, self.tr, self.fb, self.fm, self.g
-        B, H, W, V, F, J = self.B, self.H, self.W, self.V, self.F, self.J
+        L, g = self.L, self.g
+        B, H, W, V, F = self.B, self.H, self.W, self.V, self.F
         st = _stream()
         _chk(L.vhap_gbuffer_bwd(_p(self.clip), _p(self.tri), _p(self.vn), _p(self.uv), _p(self.tri_uv), _p(self.rast), _p(self.d_normal),
                                 _p(self.d_texc), _p(self.d_texd), 0, 0, _p(self.face_mask), B, V, F, H, W, _p(g["d_clip"]), _p(g["d_vn"]), st),
@@ -330,18 +412,7 @@ class NativeStep:
                                 _p(self.vn_scratch), _p(g["d_verts"]), st), "vhap_vnormal_bwd")
         _chk(L.vhap_transform_bwd(_p(self.verts), _p(self.mvp), _p(g["d_clip"]), B, V, 1, _p(g["d_verts"]), _p(self.d_mvp), st),
              "vhap_transform_bwd")
-        _chk(L.vhap_camera_bwd(_p(self.RT), _p(self.d_mvp), B, 0, H, W, _p(self.d_K), st), "vhap_camera_bwd")
-        _chk(L.vhap_focal_bwd(_p(self.d_K), B, self.focal_scale, _p(g["focal_length"]), st), "vhap_focal_bwd")
-        _chk(L.vhap_flame_skin_bwd(_p(g["d_verts"]), 0, _p(self.v_posed), _p(self.A), _p(fb.w), _p(fb.basisT), B, V, fb.Vp, fb.Kb, fb.Kp,
-                                   _p(self.g_posed), _p(self.g_shaped), 0, _p(g["d_coef"]), _p(g["d_A"]), _p(g["d_t"]), PRE, st),
-             "vhap_flame_skin_bwd")
-        _chk(L.vhap_sum_frames(_p(self.g_shaped), B, V * 3, _p(g["static_offset"]), st), "vhap_sum_frames")
-        _chk(L.vhap_frame_prep_bwd(_p(self.ts), _p(tr.shape), _p(tr.expr), _p(tr.rotation), _p(tr.translation), _p(tr.neck_pose),
-                                   _p(tr.jaw_pose), _p(tr.eyes_pose), _p(fm.JS), _p(fm.jreg_idx), _p(fm.jreg_w), fm.jreg_n,
-                                   _p(tr.static_offset), fm.parents, self.weights, _p(self.Jrest), _p(g["d_coef"]), _p(g["d_A"]), _p(g["d_t"]),
-                                   _p(self.ones), B, self.Bp, self.N, self.NS, self.NE, J, fb.Kp, V, _p(g["shape"]), _p(g["expr"]),
-                                   _p(g["rotation"]), _p(g["translation"]), _p(g["neck_pose"]), _p(g["jaw_pose"]), _p(g["eyes_pose"]),
-                                   _p(g["static_offset"]), st), "vhap_frame_prep_bwd")
+        self._bwd_params()
 
     def backward(self, world_size=1, part="all", optimizer=None):
         """part = 'all': the whole backward as one two-branch DAG (one GPU).  Under frame sharding the backward is captured in two
@@ -349,50 +420,60 @@ class NativeStep:
         side branch -- the caller then steps the remaining parameters with optimizer.step(skip=(tex_extra,))): 'texture' (pixel chain + the complete texture gradient, serial) -- the
         caller launches the asynchronous all-reduce of the texture gradient -- then 'geometry' (everything else), which hides it; or
         'pixel' then 'tex' and 'geometry' side by side on two streams (GraphedStep's default under sharding)."""
-        if True:
+        if part in ("all", "texture", "pixel"):
+            if not getattr(self, "_arena_clean", False):              # (normally done on the forward's side branch already)
+                self.arena.zero_()
+            self._arena_clean = False
+        if not self.photometric:
+            # landmark-only stage: E = landmark + regularisers; one short serial chain (any `part` but the first of a sharded split is empty)
             if part in ("all", "texture", "pixel"):
-                if not getattr(self, "_arena_clean", False):          # (normally done on the forward's side branch already)
-                    self.arena.zero_()
-                self._arena_clean = False
-            if part == "all":
-                early = None
-                self._fork()
-                with self._branch():
-                    self._bwd_early()
-                    if self.overlap:
-                        early = torch.cuda.Event()
-                        early.record()
-                self._bwd_pixel(world_size)
-                # fork as soon as d_albedo exists: the texture gradient (uv-binned accumulation + fold + TV backward) on the side branch,
-                # the uv gradient and the geometry chain on this one
-                self._fork()
-                with self._branch():
-                    self._tex_backward()
-                    if optimizer is not None:                         # the texture's Adam update as soon as its gradient is complete
+                _chk(self.L.vhap_energy_total(_p(self.log), 0, 0, 0.0, int(world_size), 0, _stream()), "vhap_energy_total")
+                self._bwd_early()
+                if self.tex_bwd_on:
+                    self.tex_finish()
+                    if optimizer is not None:
                         optimizer.step(only=(self.tr.tex_extra,), advance=False)
-                self._bwd_uv()
-                self._bwd_geometry(early)
-                self._join()
-            elif part == "texture":
-                self._bwd_pixel(world_size)
+                self._bwd_params()
+            return
+        if part == "all":
+            early = None
+            self._fork()
+            with self._branch():
+                self._bwd_early()
+                if self.overlap:
+                    early = torch.cuda.Event()
+                    early.record()
+            self._bwd_pixel(world_size)
+            # fork as soon as d_albedo exists: the texture gradient (uv-binned accumulation + fold + TV backward) on the side branch,
+            # the uv gradient and the geometry chain on this one
+            self._fork()
+            with self._branch():
                 self._tex_backward()
-            elif part == "pixel":                                     # 'texture' in two pieces: the caller runs 'tex' next to 'geometry'
-                self._bwd_pixel(world_size)
-            elif part == "tex":
-                self._tex_backward()
-            elif part == "geometry":
-                early = None
-                self._fork()
-                with self._branch():
-                    self._bwd_early()
-                    if self.overlap:
-                        early = torch.cuda.Event()
-                        early.record()
-                self._bwd_uv()
-                self._bwd_geometry(early)
-                self._join()
-            else:
-                raise ValueError(part)
+                if optimizer is not None and self.tex_bwd_on:     # the texture's Adam update as soon as its gradient is complete
+                    optimizer.step(only=(self.tr.tex_extra,), advance=False)
+            self._bwd_uv()
+            self._bwd_geometry(early)
+            self._join()
+        elif part == "texture":
+            self._bwd_pixel(world_size)
+            self._tex_backward()
+        elif part == "pixel":                                     # 'texture' in two pieces: the caller runs 'tex' next to 'geometry'
+            self._bwd_pixel(world_size)
+        elif part == "tex":
+            self._tex_backward()
+        elif part == "geometry":
+            early = None
+            self._fork()
+            with self._branch():
+                self._bwd_early()
+                if self.overlap:
+                    early = torch.cuda.Event()
+                    early.record()
+            self._bwd_uv()
+            self._bwd_geometry(early)
+            self._join()
+        else:
+            raise ValueError(part)
 
     def log_dict(self):
         """Views into the device log vector, keyed like FlameTracker.compute_energy's log_dict (terms the stage does not have read 0)."""

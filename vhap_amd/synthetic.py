@@ -206,3 +206,47 @@ def make_dataset(tracker_like_render, flame_head, gt, image_size, device, seed=0
         v = (ndc[..., 1] * 0.5 + 0.5) * H + torch.from_numpy(rng.standard_normal((N, lmks.shape[1])).astype(np.float32)).to(device) * lmk_noise_px
         lmk2d = torch.stack([u, v, torch.ones_like(u)], dim=-1)
     return {"rgb": rgb, "lmk2d": lmk2d}
+
+
+def arc_cameras(n_views, image_size, arc_deg=60.0, radius=1.0, focal_px=None):
+    """Calibrated cameras of a NeRSemble-like rig: `n_views` cameras on a +-arc_deg arc of `radius` metres around
+    the origin, looking at it.  Returns K [n,3,3] (pixels) and RT [n,3,4] (world -> camera, OpenGL: camera looks down -z)."""
+    H, W = image_size
+    # default focal length: the 0.31 m tall template head fills 60 % of the long image side at `radius`
+    f = float(focal_px) if focal_px is not None else 0.6 * max(H, W) / 0.31 * radius
+    Ks, RTs = [], []
+    for a in np.linspace(-np.deg2rad(arc_deg), np.deg2rad(arc_deg), n_views):
+        c, s = np.cos(a), np.sin(a)
+        R = np.array([[c, 0, -s], [0, 1, 0], [s, 0, c]], np.float32)               # rotation about the vertical axis
+        RTs.append(np.concatenate([R, np.array([[0.0], [0.0], [-radius]], np.float32)], axis=1))
+        Ks.append(np.array([[f, 0, 0.5 * W], [0, f, 0.5 * H], [0, 0, 1]], np.float32))
+    return np.stack(Ks), np.stack(RTs)
+
+
+def make_multiview_dataset(render, flame_head, gt, image_size, device, n_views=16, seed=0, lmk_noise_px=1.0, tex=None, timestep=0):
+    """All `n_views` calibrated views of ONE timestep of `gt`, rendered with the product renderer (BASELINE config 4).  Returns the dataset
+    dict GlobalTracker expects for a multi-view capture: rgb [n,3,H,W], lmk2d [n,70,3], intrinsic [n,3,3], extrinsic [n,3,4],
+    timestep_index [n] (all 0), camera_index [n]."""
+    import torch
+    H, W = image_size
+    rng = np.random.default_rng(seed + 4000)
+    g = lambda k: torch.from_numpy(gt[k]).to(device)
+    t = slice(timestep, timestep + 1)
+    K, RT = arc_cameras(n_views, image_size)
+    with torch.no_grad():
+        verts, lmks = flame_head(g("shape")[None], g("expr")[t], g("rotation")[t] * 0, g("neck_pose")[t], g("jaw_pose")[t], g("eyes_pose")[t],
+                                 g("translation")[t] * 0)
+        verts, lmks = verts.expand(n_views, -1, -1).contiguous(), lmks.expand(n_views, -1, -1).contiguous()
+        Kt, RTt = torch.from_numpy(K).to(device), torch.from_numpy(RT).to(device)
+        bg = torch.from_numpy(smooth_noise(rng, (n_views, 3, H, W), octaves=4)).to(device).permute(0, 2, 3, 1).contiguous()
+        rast = render.rasterize(verts, flame_head.faces, RTt, Kt, image_size)
+        uv = flame_head.verts_uvs.clone()
+        uv[:, 1] = 1 - uv[:, 1]
+        tex_t = torch.from_numpy(tex if tex is not None else make_texture(seed, 512)).to(device)[None]
+        out = render.render_rgba(rast, verts, flame_head.faces, uv, flame_head.textures_idx, tex_t, g("lights")[None], bg)
+        rgb = out["rgba"][..., :3].permute(0, 3, 1, 2).clamp(0, 1).contiguous()
+        ndc = render.world_to_ndc(lmks, RTt, Kt, image_size, flip_y=True)
+        noise = lambda: torch.from_numpy(rng.standard_normal((n_views, lmks.shape[1])).astype(np.float32)).to(device) * lmk_noise_px
+        lmk2d = torch.stack([(ndc[..., 0] * 0.5 + 0.5) * W + noise(), (ndc[..., 1] * 0.5 + 0.5) * H + noise(), torch.ones_like(ndc[..., 0])], dim=-1)
+    return {"rgb": rgb, "lmk2d": lmk2d, "intrinsic": Kt, "extrinsic": RTt,
+            "timestep_index": torch.zeros(n_views, dtype=torch.long), "camera_index": torch.arange(n_views)}

@@ -533,7 +533,12 @@ class FlameTracker:
 class GlobalTracker(FlameTracker):
     """tracker.py:1221-1529 on an in-memory dataset (list/tensor of frames).  `dataset` must provide
     `rgb` [N,3,H,W] float in [0,1], `lmk2d` [N,68+,3] (pixel u, v, confidence) and, if calibrated,
-    `intrinsic` / `extrinsic`."""
+    `intrinsic` / `extrinsic`.
+
+    Multi-view captures (NeRSemble, nersemble_dataset.py with batchify_all_views: ONE dataset item = all views of a timestep, so the
+    reference's n_timesteps = len(dataset) counts timesteps, not images): the dataset additionally carries `timestep_index` [N] -- the
+    timestep each of the N frames (images) belongs to, 0..n_timesteps-1 -- and optionally `camera_index` [N].  All views of a timestep
+    share that timestep's row of the per-frame parameters; samples, shuffled batches and evaluate() are formed by TIMESTEP."""
 
     def __init__(self, cfg, flame_model, topo, base_texture, dataset):
         super().__init__(cfg, flame_model, topo, base_texture)
@@ -541,10 +546,25 @@ class GlobalTracker(FlameTracker):
         self.dataset = dataset
         self.frames = dataset.get("frames")                      # optional ingest.FrameStore: the sequence resident as uint8 (8(f) rank 1)
         if self.frames is not None:
-            self.image_size, self.n_timesteps = self.frames.image_size, len(self.frames)
+            self.image_size, self.n_frames = self.frames.image_size, len(self.frames)
         else:
             self.image_size = tuple(dataset["rgb"].shape[-2:])
-            self.n_timesteps = dataset["rgb"].shape[0]
+            self.n_frames = dataset["rgb"].shape[0]
+        if "timestep_index" in dataset:                               # multi-view: frames (images) grouped by timestep
+            ft = np.asarray(dataset["timestep_index"].cpu() if torch.is_tensor(dataset["timestep_index"]) else dataset["timestep_index"]).astype(np.int64)
+            if ft.shape != (self.n_frames,) or ft.min() < 0:
+                raise ValueError("dataset['timestep_index'] must hold one non-negative timestep per frame")
+            self.frame_timestep = ft
+            self.n_timesteps = int(ft.max()) + 1
+            order = np.argsort(ft, kind="stable")
+            starts = np.searchsorted(ft[order], np.arange(self.n_timesteps + 1))
+            self._frames_of = [order[starts[t]:starts[t + 1]] for t in range(self.n_timesteps)]
+            if any(len(f) == 0 for f in self._frames_of):
+                raise ValueError("dataset['timestep_index']: every timestep 0..max needs at least one frame")
+        else:
+            self.frame_timestep = np.arange(self.n_frames)
+            self.n_timesteps = self.n_frames
+            self._frames_of = None
         self.global_step = 0
         self._graphed = {}
         self.init_params()
@@ -621,12 +641,18 @@ class GlobalTracker(FlameTracker):
         """`device_index=True` keeps `timestep_index` as a device LongTensor (needed for graph capture: a numpy
         index would be re-uploaded on every step)."""
         ts = np.asarray(timesteps)
-        idx = torch.as_tensor(ts, device=self.dataset["lmk2d"].device)
+        if self._frames_of is not None:                           # every view of the requested timesteps; each frame carries ITS timestep
+            fidx = np.concatenate([self._frames_of[int(t)] for t in ts.reshape(-1)])
+            ts = self.frame_timestep[fidx]
+        else:
+            fidx = ts
+        idx = torch.as_tensor(fidx, device=self.dataset["lmk2d"].device)
+        ts_dev = torch.as_tensor(ts, device=idx.device)
         if self.frames is not None:                               # gather + composite + convert in one launch (vhap_frame_ingest)
             rgb, alpha = self.frames.batch(idx)
         else:
             rgb, alpha = self.dataset["rgb"][idx], None
-        s = {"rgb": rgb, "lmk2d": self.dataset["lmk2d"][idx], "timestep_index": idx if device_index else ts}
+        s = {"rgb": rgb, "lmk2d": self.dataset["lmk2d"][idx], "timestep_index": ts_dev if device_index else ts}
         if alpha is not None:
             s["alpha_map"] = alpha
         for k in ("intrinsic", "extrinsic"):
@@ -640,11 +666,14 @@ class GlobalTracker(FlameTracker):
         batches at a tenth of the learning rates.  The frames come from the in-memory dataset / the resident uint8 store instead of a
         DataLoader; logging and media output are out of scope.  Returns the evaluation report (or None)."""
         self.global_step = 0
-        bs = int(batch_size or self.cfg.batch_size or self.n_timesteps)
+        # multi-view: one timestep (all its views) per batch, like the reference's DataLoader(batch_size=None) over a batchify_all_views dataset
+        bs = int(batch_size or (1 if self._frames_of is not None else self.cfg.batch_size) or self.n_timesteps)
         on_gpu = str(self.device).startswith("cuda")
         for t0 in range(0, self.n_timesteps, bs):
             ts = np.arange(t0, min(t0 + bs, self.n_timesteps))
             sample = self.get_sample(ts, device_index=on_gpu)
+            if self.dist is not None:                                 # frame sharding: this rank's contiguous slice of the batch
+                sample = self.dist.shard_sample(sample)
             if t0 == 0:
                 self.optimize_stage("lmk_init_rigid", sample)
                 self.optimize_stage("lmk_init_all", sample)
@@ -708,7 +737,7 @@ class GlobalTracker(FlameTracker):
         if sample is not None:
             st = step_for(sample)
             if not getattr(st, "fresh", False):
-                st.opt.reset_state(lr_scale_base=None)
+                _reset_optimizer(st.opt)
             st.fresh = False
             n = self.cfg.pipeline[stage].num_steps if num_steps is None else num_steps
             for _ in range(n):
@@ -722,7 +751,7 @@ class GlobalTracker(FlameTracker):
                 if opt is None:
                     opt = st.opt
                     if not getattr(st, "fresh", False):
-                        opt.reset_state(lr_scale_base=None)
+                        _reset_optimizer(opt)
                     for grp in opt.param_groups:                  # a scheduler of a previous call may have decayed them
                         grp["lr"] = grp["initial_lr"] if "initial_lr" in grp else grp["lr"]
                     sched = torch.optim.lr_scheduler.ExponentialLR(opt, gamma=0.9)
@@ -822,8 +851,9 @@ class GlobalTracker(FlameTracker):
         if path is not None:
             self.save_result(path)
         w = self.cfg.w
-        photo = torch.zeros(self.n_timesteps, device=self.device)
-        lmk = torch.zeros(self.n_timesteps, device=self.device)
+        # per-timestep sums over all views of the timestep (the reference evaluates one dataset item = one timestep with all its views)
+        photo_s, photo_n = torch.zeros(self.n_timesteps, device=self.device), torch.zeros(self.n_timesteps, device=self.device)
+        lmk_s, lmk_n = torch.zeros(self.n_timesteps, device=self.device), torch.zeros(self.n_timesteps, device=self.device)
         faces = self.flame.faces
         for t0 in range(0, self.n_timesteps, batch_size):
             ts = np.arange(t0, min(t0 + batch_size, self.n_timesteps))
@@ -835,7 +865,9 @@ class GlobalTracker(FlameTracker):
                 rd = self.compute_lmk_energy(sample, lmks, False)[1]
                 conf = sample["lmk2d"][:, :68, 2].to(verts).clone()
                 conf[:, 27:36] *= 10
-                lmk[t0:t0 + len(ts)] = w.landmark * ((rd["gt_lmk2d"][:, :68] - rd["pred_lmk2d"][:, :68]).abs().sum(2) * conf).mean(1)
+                tsi = sample["timestep_index"].long()
+                lmk_s.index_add_(0, tsi, w.landmark * ((rd["gt_lmk2d"][:, :68] - rd["pred_lmk2d"][:, :68]).abs().sum(2) * conf).mean(1))
+                lmk_n.index_add_(0, tsi, torch.ones_like(tsi, dtype=lmk_n.dtype))
             if w.photo is not None:
                 gt_rgb = sample["rgb"].to(verts)
                 rast_dict = self.rasterize_flame(sample, verts, faces, train_mode=True)
@@ -844,9 +876,23 @@ class GlobalTracker(FlameTracker):
                 rgba = out["rgba"]
                 abs_sum = (gt_rgb - rgba[:, :3]).abs().sum(dim=(1, 2, 3))
                 n_mask = (rgba[:, 3:] > 0).sum(dim=(1, 2, 3)) * 3
-                photo[t0:t0 + len(ts)] = w.photo * abs_sum / n_mask
-        photo, lmk = photo.cpu().numpy(), lmk.cpu().numpy()
+                tsi = sample["timestep_index"].long()
+                photo_s.index_add_(0, tsi, w.photo * abs_sum)
+                photo_n.index_add_(0, tsi, n_mask.to(photo_n.dtype))
+        photo = (photo_s / photo_n.clamp_min(1)).cpu().numpy() if w.photo is not None else photo_s.cpu().numpy()
+        lmk = (lmk_s / lmk_n.clamp_min(1)).cpu().numpy()
         return {"photo": photo, "lmk": lmk, "mean_photo": float(photo.mean()), "mean_lmk": float(lmk.mean())}
+
+
+def _reset_optimizer(opt):
+    """Back to a freshly constructed Adam (the reference builds a new optimiser per optimize_stage call, tracker.py:1399)."""
+    if isinstance(opt, NV.HipAdam):
+        opt.reset_state()
+        return
+    for st in opt.state.values():                                  # torch.optim.Adam(capturable=True): state tensors live on the device
+        for k in ("exp_avg", "exp_avg_sq", "step"):
+            if k in st and torch.is_tensor(st[k]):
+                st[k].zero_()
 
 
 class ShuffledBatches:
@@ -862,9 +908,15 @@ class ShuffledBatches:
         return (self.tr.n_timesteps + self.bs - 1) // self.bs
 
     def __iter__(self):
-        perm = torch.randperm(self.tr.n_timesteps, generator=self.gen).numpy()
+        tr = self.tr
+        if tr.dist is not None and self.gen is None:
+            # frame sharding: every rank must draw the SAME permutation (each then takes its slice of every batch); a generator seeded
+            # with a value broadcast from rank 0, advanced in lock step afterwards
+            self.gen = torch.Generator().manual_seed(tr.dist.broadcast_int(int(torch.randint(0, 2 ** 31 - 1, (1,)))))
+        perm = torch.randperm(tr.n_timesteps, generator=self.gen).numpy()
         for i in range(0, len(perm), self.bs):
-            yield self.tr.get_sample(perm[i:i + self.bs], device_index=self.device_index)
+            s = tr.get_sample(perm[i:i + self.bs], device_index=self.device_index)
+            yield tr.dist.shard_sample(s) if tr.dist is not None else s
 
 
 class GraphedStep:
@@ -945,7 +997,7 @@ class GraphedStep:
                 # the texture's Adam update (7 x 50 MB of traffic at T = 2048) goes on the backward's side branch, right behind its
                 # gradient, instead of on the tail of the step
                 tex = tracker.tex_extra
-                split = tex is not None and any(p is tex for p in self.params) and len(self.params) > 1 and \
+                split = tex is not None and any(p is tex for p in self.params) and len(self.params) > 1 and ns.tex_bwd_on and \
                     os.environ.get("VHAP_SPLIT_ADAM", "1") != "0"
                 with torch.cuda.graph(self.gF, **cap):
                     for _ in range(self.unroll):
@@ -956,6 +1008,16 @@ class GraphedStep:
                         else:
                             ns.backward(1)
                             optimizer.step()
+            elif not ns.photometric:
+                # Frame sharding of a landmark-only stage: forward, backward, ONE all-reduce of the (small) gradient arena, Adam
+                self.lmk_only = True
+                with torch.cuda.graph(self.gF, **cap):
+                    ns.forward()
+                pool = self.gF.pool() if os.environ.get("VHAP_GRAPH_POOLS") != "separate" else None
+                with torch.cuda.graph(self.gB, pool=pool, **cap):
+                    ns.backward(world)
+                with torch.cuda.graph(self.gA, pool=pool, **cap):
+                    optimizer.step()
             else:
                 # Frame sharding.  The big collective is the texture gradient (50 MB at T = 2048).  The backward is captured in two graphs:
                 # 'texture' makes that gradient final first, its asynchronous all-reduce is launched, and 'geometry' (G-buffer backward,
@@ -992,12 +1054,12 @@ class GraphedStep:
                 tracker.clear_cache()
                 tracker.fill_cam_params_into_sample(s)
                 E_rest, self.log_dict, *_ = tracker.compute_energy(s, stage=stage)
-                self.S, self.N = tracker._split["S"], tracker._split["N"]
+                self.S, self.N = tracker._split.get("S"), tracker._split.get("N")     # None: the stage has no photometric term
             pool = self.gF.pool() if os.environ.get("VHAP_GRAPH_POOLS") != "separate" else None
             for p in self.params:
                 p.grad = None
             with torch.cuda.graph(self.gB, pool=pool, **cap):
-                E = E_rest + tracker.cfg.w.photo * self.S * self.inv_n
+                E = E_rest + tracker.cfg.w.photo * self.S * self.inv_n if self.S is not None else E_rest
                 # .grad is None: autograd hands its gradient tensors over to the parameters (no copy); they live in the graph's
                 # pool at fixed addresses and are rewritten by every replay
                 torch.autograd.backward(E, inputs=self.params)
@@ -1058,6 +1120,13 @@ class GraphedStep:
         if self.ns is not None:
             if self.single:
                 return
+            if getattr(self, "lmk_only", False):
+                self.gB.replay()
+                tr.dist.all_reduce_mean_(self.ns.param_grad_flat)
+                if self.ns.tex_bwd_on:
+                    tr.dist.all_reduce_mean_(self.ns.g["tex_extra"])
+                self.gA.replay()
+                return
             if tr.dist is not None:
                 self.ns.n_global.copy_(tr.dist.all_reduce_sum(self.N.reshape(1)))
             self.gB.replay()
@@ -1067,26 +1136,27 @@ class GraphedStep:
                 self.tex_stream.wait_stream(cur)
                 with torch.cuda.stream(self.tex_stream):
                     self.gBt.replay()                                      # texture gradient, next to ...
-                    work = tr.dist.all_reduce_mean_(self.ns.g["tex_extra"], async_op=True)
+                    work = tr.dist.all_reduce_mean_(self.ns.g["tex_extra"], async_op=True) if self.ns.tex_bwd_on else None
                 self.gB2.replay()                                          # ... the geometry chain; the collective runs under its tail
                 tr.dist.all_reduce_mean_(self.ns.param_grad_flat)
                 if work is not None:
                     work.wait()
                 cur.wait_stream(self.tex_stream)
             else:
-                work = tr.dist.all_reduce_mean_(self.ns.g["tex_extra"], async_op=True)
+                work = tr.dist.all_reduce_mean_(self.ns.g["tex_extra"], async_op=True) if self.ns.tex_bwd_on else None
                 self.gB2.replay()                                          # runs under the texture collective
                 tr.dist.all_reduce_mean_(self.ns.param_grad_flat)
                 if work is not None:
                     work.wait()
             self.gA.replay()
             return
-        n = self.N
-        world = 1
-        if tr.dist is not None:
-            world = tr.dist.world_size
-            n = tr.dist.all_reduce_sum(n)
-        self.inv_n.copy_(world / (3.0 * n))
+        if self.N is not None:
+            n = self.N
+            world = 1
+            if tr.dist is not None:
+                world = tr.dist.world_size
+                n = tr.dist.all_reduce_sum(n)
+            self.inv_n.copy_(world / (3.0 * n))
         self.gB.replay()
         if tr.dist is not None:
             tr.dist.average_gradients(self.params)
