@@ -151,3 +151,26 @@ def test_two_rank_calibrated_multiview_step_matches_single_process(stage):
             continue
         rel = float((a - b0).abs().max() / (a.abs().max() + 1e-30))
         assert rel < 2e-3, f"{stage}: grad {k}: rel {rel:.3e}"
+
+
+def test_bench_multi_rank_path_runs_under_torchrun_with_gloo():
+    """bench.py's own N > 1 code path (torchrun env, rank-0 JSON line, max-over-ranks timing, the sharded captured step with its
+    collectives) had never executed anywhere: two ranks on this one GPU over gloo, strong scaling (8 + 8 frames)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--backend", "gloo",
+           "--scaling", "strong", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["global_batch"] == 16 and out["config"]["frames_per_gpu"] == 8
+    assert out["config"]["captured_step"] is True and out["value"] > 0 and np.isfinite(out["roofline"]["frac"])

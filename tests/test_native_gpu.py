@@ -209,7 +209,7 @@ def test_optimize_runs_every_stage_through_captured_native_steps(flame_model):
     assert report is not None and rep1["mean_lmk"] < rep0["mean_lmk"] and rep1["mean_photo"] < rep0["mean_photo"], (rep0, rep1)
     out = tr.save_result()
     assert all(np.isfinite(np.asarray(v, np.float64)).all() for v in out.values())
-    assert tr.global_step == 5 * 8 + 2 * 8 + 2 * 2 * 2        # 5 init stages + 2 sequential batches + 2 epochs x 2 batches
+    assert tr.global_step == 5 * 8 + 2 * 8 + 2 * 2            # 5 init stages + 2 sequential batches + 2 epochs x 2 batches
 
 
 def test_c_abi_is_reentrant_across_threads(tracker):
@@ -251,8 +251,9 @@ def test_c_abi_is_reentrant_across_threads(tracker):
             try:
                 while not stop.is_set():
                     got = aa_grad(s)
-                    if not torch.equal(got, want):
-                        errs.append(float((got - want).abs().max()))
+                    d = float((got - want).abs().max())      # (float atomics: the last bit depends on the order; a lost pass-through is O(1))
+                    if not d <= 1e-5:
+                        errs.append(d)
             except Exception as e:          # noqa: BLE001
                 errs.append(repr(e))
         th = threading.Thread(target=worker)

@@ -81,7 +81,7 @@ def test_brute_force_fallback_when_bins_overflow(flame_model):
     _assert_raster_equal((rast.cpu().numpy(), db.cpu().numpy()), ref, "fallback")
 
 
-@pytest.mark.parametrize("B,H,W", [(16, 512, 512), (8, 1024, 1024), (16, 550, 802)])
+@pytest.mark.parametrize("B,H,W", [(16, 512, 512), (8, 1024, 1024), (16, 802, 550)])
 def test_baseline_sizes_match_oracle_bit_exact(flame_model, B, H, W):
     """BASELINE configs 2, 3 and 4 at their FULL batch shapes (the code that only behaves differently at size: each XCD owning whole
     frames needs B >= 8, the per-frame pair-list regions, the fragment walk over thousands of bins): plain rasteriser AND the fused
