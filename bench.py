@@ -163,58 +163,36 @@ def cpu_baseline(C, tr, sample, model, topo, budget_s=30.0):
 
 
 def time_ri_in_step(tr, sample, optimizer, n=8):
-    """Duration of the RI-fwd pass INSIDE the step.  1st choice: an instrumented capture of the same step with event-record nodes
-    (torch.cuda.Event(external=True)) around the pass, replayed n times.  Fallback: the native step issued eagerly, HIP events on the
-    launch stream around the pass (same kernels, same two-stream structure, launches back to back inside one C call)."""
+    """Duration of the RI-fwd pass INSIDE the step: the native step (the call sequence the captured graph replays, same kernels, same
+    two-stream structure) issued eagerly on a side stream with HIP events on the launch stream right before and after the pass (its two
+    launches go out back to back inside one C call; the stream is busy, so the first event completes when the preceding kernel does).
+    Event-record NODES inside the captured graph would be the direct measurement, but ROCm 7.2 refuses to read them
+    (hipErrorCapturedEvent from hipEventElapsedTime); the rocprofv3 kernel trace of the captured step (profiles/) is the cross-check."""
     from vhap_amd import ops
     from vhap_amd.step import NativeStep
-    from vhap_amd.tracker import GraphedStep
-    rec = {"mode": None, "ev": []}
+    ev = []
 
     def hook(name, phase):
-        if rec["mode"] is None or name != "raster_interp_fwd":
-            return
-        if rec["mode"] == "graph" and not torch.cuda.is_current_stream_capturing():
-            return                                               # (event-record nodes exist only under capture; the dry passes are skipped)
-        e = torch.cuda.Event(enable_timing=True, external=True) if rec["mode"] == "graph" else torch.cuda.Event(enable_timing=True)
-        e.record()                                               # torch's current stream == the launch stream
-        rec["ev"].append(e)
-    ops.PROFILE_HOOK = hook
+        if name == "raster_interp_fwd":
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()                                           # torch's current stream == the launch stream
+            ev.append(e)
+    ns = NativeStep(tr, sample, STAGE)
+    stream = torch.cuda.Stream()
+    stream.wait_stream(torch.cuda.current_stream())
     try:
-        try:
-            rec["mode"], rec["ev"] = "graph", []
-            st = GraphedStep(tr, sample, optimizer, STAGE)       # the capture records the two event nodes
-            rec["mode"] = None
-            ev = rec["ev"][-2:]
-            if len(ev) != 2 or st.ns is None:
-                raise RuntimeError("no event nodes captured")
-            ms = []
-            for _ in range(n):
-                st()
-                torch.cuda.synchronize()
-                ms.append(ev[0].elapsed_time(ev[1]))
-            if not all(np.isfinite(ms)) or min(ms) <= 0:
-                raise RuntimeError(f"implausible event-node timings {ms}")
-            return float(np.median(ms)) * 1e-3, "HIP event-record nodes around the pass inside an instrumented capture of the step (median of %d replays)" % n
-        except Exception as e:                                   # noqa: BLE001 -- any runtime refusal: fall back, say so
-            why = f"{type(e).__name__}: {e}"[:120]
-        rec["mode"], rec["ev"] = "eager", []
-        ns = NativeStep(tr, sample, STAGE)
-        stream = torch.cuda.Stream()
-        stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(stream):
             for i in range(n + 2):
-                if i == 2:
-                    rec["ev"] = []
+                if i == 2:                                       # two warm-up steps un-instrumented
+                    ops.PROFILE_HOOK = hook
                 ns.forward()
                 ns.backward(1)
                 optimizer.step()
         torch.cuda.synchronize()
-        ev = rec["ev"]
-        ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(0, len(ev) - 1, 2)]
-        return float(np.median(ms)) * 1e-3, f"HIP events around the pass in {n} eagerly issued native steps (event nodes unavailable: {why})"
     finally:
         ops.PROFILE_HOOK = None
+    ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(0, len(ev) - 1, 2)]
+    return float(np.median(ms)) * 1e-3, f"HIP events around the pass in {n} eagerly issued native steps (median)"
 
 
 def time_ri_isolated(tr, sample, C, stream):

@@ -62,6 +62,12 @@ const char* vhap_strerror(int code);
  * by COMPLETED calls of vhap_raster_fwd / vhap_raster_interp_fwd with the same (B, F, H, W, pair_capacity): every call
  * leaves the bin counters zeroed again, so the per-call memset is skipped.  Without the flag any memory may be passed. */
 #define VHAP_RASTER_WS_CLEAN 1
+/* Split calls (so that work the raster kernel depends on but the binning does not -- vertex normals, the texture pyramid -- can run next
+ * to the binning on another stream): VHAP_RASTER_BIN_ONLY runs only the triangle set-up + binning into `workspace`;
+ * VHAP_RASTER_PREBINNED skips it and rasterises from the bins a BIN_ONLY call with the same (pos, tri, B, F, H, W, pair_capacity) left
+ * there.  Only with the one-launch binning (F <= 32768, H*W/64 <= 16384 bins): otherwise VHAP_E_UNSUPPORTED. */
+#define VHAP_RASTER_BIN_ONLY 2
+#define VHAP_RASTER_PREBINNED 4
 size_t vhap_raster_workspace_bytes(int B, int F, int H, int W, size_t pair_capacity);
 int vhap_raster_fwd(const float* pos, const int32_t* tri, int B, int V, int F, int H, int W,
                     float* rast, float* rast_db, void* workspace, size_t workspace_bytes,
@@ -84,6 +90,41 @@ int vhap_raster_interp_fwd(const float* pos, const int32_t* tri, const float* vn
 int vhap_raster_bwd(const float* pos, const int32_t* tri, const float* rast, const float* d_rast,
                     const float* d_rast_db, int B, int V, int F, int H, int W, float* d_pos,
                     vhap_stream_t stream);
+
+/* DEFERRED SHADING: the G-buffer pass fused with everything up to the composited colour -- replaces dr.rasterize (:254), both
+ * dr.interpolate calls (:384, :389), dr.texture (:399), safe_normalize (:386), the SH shading, rgb = albedo * diffuse, alpha = coverage
+ * and the background composite with its y-flip (:402-421) in ONE launch.  The interpolated normal / uv / uv derivatives and the sampled
+ * albedo never leave registers: per pixel the kernel writes rast (16 B), rgba (16 B) and optionally the colour-cluster byte (for the
+ * disturbance pass) instead of the 97 B the separate passes write and the 88 B they read back; the backward re-computes them
+ * (vhap_deferred_shade_bwd).
+ *   tex [Ht,Wt,3] ONE texture shared by all frames (tracker.py:234 replicates it B x) + mips (vhap_texture_mip_build)
+ *   lights [9,3], sh_const [9]; bg_image [B,3,H,W] image space (row 0 = top) or NULL -> bg_color (HOST pointer to 3 floats)
+ *   fid2cid [nfid] (index = triangle id + 1) / cid [B,H,W] uint8: optional
+ *   rast [B,H,W,4] as vhap_raster_fwd; rgba [B,H,W,4] renderer space (row 0 = bottom): shaded colour, alpha = coverage
+ *   stats (4 words, may be NULL): as vhap_shade_fwd, OVERWRITTEN (a tiny second launch reduces per-wave partials kept in `workspace`)
+ * With VHAP_RASTER_BIN_ONLY only pos / tri / uv / tri_uv / the dimensions / workspace are used. */
+int vhap_raster_shade_fwd(const float* pos, const int32_t* tri, const float* vnormal, const float* uv,
+                          const int32_t* tri_uv, const float* tex, const float* mips, int Ht, int Wt,
+                          const float* lights, const float* sh_const, const float* bg_image,
+                          const float* bg_color, const int32_t* fid2cid, int nfid, int B, int V, int VT,
+                          int F, int H, int W, float* rast, float* rgba, uint8_t* cid, float* stats,
+                          void* workspace, size_t workspace_bytes, size_t pair_capacity, int flags,
+                          vhap_stream_t stream);
+/* Backward of the shading part of vhap_raster_shade_fwd (everything between the interpolated attributes and rgba): per covered pixel the
+ * normal / uv / uv derivatives are re-computed from (rast, geometry) with the forward's arithmetic, the texture is re-sampled, and the
+ * upstream gradient d_rgba [B,H,W,4] (x keep [B,H,W] if given = the colour-disturbance backward) is chained through rgb = albedo * diffuse
+ * and the SH shading.  Outputs, all [B,H,W,*] and OVERWRITTEN (zeros on background pixels):
+ *   texc [..,2], texd [..,4], d_albedo [..,3]  -> the texture-gradient accumulation (vhap_texture_grad_binned / vhap_texture_bwd)
+ *   d_normal [..,3], d_texc [..,2], d_texd [..,4] -> vhap_gbuffer_bwd
+ *   d_lights [9,3] ACCUMULATED (photometric part + the diffuse regulariser: d_reg device scalar and stats as in vhap_shade_bwd, may be NULL)
+ * Replaces vhap_shade_bwd + the d_uv / d_uv_da part of vhap_texture_bwd (and the re-reading of five G-buffer images). */
+int vhap_deferred_shade_bwd(const float* pos, const int32_t* tri, const float* vnormal, const float* uv,
+                            const int32_t* tri_uv, const float* tex, const float* mips, int Ht, int Wt,
+                            const float* lights, const float* sh_const, const float* rast,
+                            const float* d_rgba, const float* keep, const float* d_reg, const float* stats,
+                            int B, int V, int VT, int F, int H, int W, float* texc, float* texd,
+                            float* d_albedo, float* d_normal, float* d_texc, float* d_texd,
+                            float* d_lights, vhap_stream_t stream);
 
 /* Triangle-parallel backward of the fused G-buffer pass (vhap_raster_interp_fwd): chains the gradients of
  * normal [B,H,W,3], texc [B,H,W,2], texd [B,H,W,4] (and, optionally, direct gradients of rast / rast_db) into
@@ -216,6 +257,12 @@ int vhap_flame_skin_fwd(const float* coef, const float* basis, const float* A,
                         const float* lbs_weights, const float* v_template, const float* offset,
                         const float* transl, int B, int V, int Vp, int K, int Kb, int Kp,
                         float* verts, float* v_shaped, float* v_posed, vhap_stream_t stream);
+/* same, fused with vhap_transform_fwd: also writes clip [B,V,4] = [verts;1] @ mvp^T (mvp [B,4,4]) -- bit-identical to the two calls */
+int vhap_flame_skin_clip_fwd(const float* coef, const float* basis, const float* A,
+                             const float* lbs_weights, const float* v_template, const float* offset,
+                             const float* transl, const float* mvp, int B, int V, int Vp, int K, int Kb,
+                             int Kp, float* verts, float* v_shaped, float* v_posed, float* clip,
+                             vhap_stream_t stream);
 size_t vhap_flame_bwd_partial_floats(int B, int Vp, int Kp);
 int vhap_flame_skin_bwd(const float* d_verts, const float* d_vshaped, const float* v_posed,
                         const float* A, const float* lbs_weights, const float* basisT, int B, int V,

@@ -1,0 +1,146 @@
+"""Deferred shading (vhap_raster_shade_fwd / vhap_deferred_shade_bwd) against the separate passes it replaces
+(vhap_raster_interp_fwd -> vhap_texture_fwd -> vhap_shade_fwd, and vhap_shade_bwd + the uv part of vhap_texture_bwd), on the buffers of a
+real fit step.  The separate passes are the ones pinned on the oracle (test_raster_gpu / test_ops_gpu / test_fused_gpu); the captured
+step itself is checked against the oracle in test_fit_parity_gpu.  The rasteriser outputs must be bit-identical; the re-computed
+interpolants (uv, uv derivatives) must be bit-identical to what the G-buffer pass wrote; colours and gradients agree to fp32 round-off
+(the shading arithmetic is the same code, but the compiler may contract it differently in different kernels): 2e-6 absolute on colours,
+1e-5 of the max-norm on gradients."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _tracker(flame_model, B, H, W, T, seed, disturb):
+    from vhap_amd.config import BaseTrackingConfig
+    from vhap_amd.flame import FlameHead
+    from vhap_amd.render_hip import HipDiffRenderer
+    from vhap_amd.synthetic import make_dataset, make_scene_params, make_texture
+    from vhap_amd.tracker import GlobalTracker
+    model, topo = flame_model
+    cfg = BaseTrackingConfig()
+    cfg.model.tex_resolution = T
+    if not disturb:
+        cfg.render.disturb_rate_fg = cfg.render.disturb_rate_bg = None
+    gt = make_scene_params(B, seed=seed, image_size=(H, W))
+    head, rend = FlameHead(model, topo).cuda(), HipDiffRenderer(lighting_type="SH").cuda()
+    data = make_dataset(rend, head, gt, (H, W), "cuda", seed=seed, tex=make_texture(seed, T))
+    tr = GlobalTracker(cfg, model, topo, make_texture(0, T), data)
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, s in (("shape", 0.2), ("expr", 0.2), ("rotation", 0.05), ("jaw_pose", 0.05), ("tex_extra", 0.03), ("lights", 0.05),
+                        ("static_offset", 5e-4)):
+            p = getattr(tr, name)
+            p.add_((torch.randn(p.shape, generator=g) * s).cuda())
+        tr.translation[:, 2] += 0.45
+        tr.lights[0] += 0.6                       # pushes max(diffuse) above 1: the relu branch of the diffuse regulariser is active
+    return tr
+
+
+@pytest.mark.parametrize("B,H,W,T,bg", [(3, 96, 120, 128, "target"), (2, 250, 203, 512, "white"), (9, 256, 256, 2048, "target")])
+def test_deferred_kernels_match_the_separate_passes(flame_model, monkeypatch, B, H, W, T, bg):
+    from vhap_amd import _lib
+    from vhap_amd.ops import _p, _stream
+    from vhap_amd.step import NativeStep
+    monkeypatch.setenv("VHAP_DEFERRED", "0")                 # the reference: the separate passes
+    tr = _tracker(flame_model, B, H, W, T, seed=31, disturb=True)
+    tr.cfg.render.background_train = bg
+    stage = "rgb_global_tracking"
+    tr.get_train_parameters(stage)
+    ns = NativeStep(tr, tr.get_sample(np.arange(B), device_index=True), stage)
+    assert not ns.deferred and ns.disturb_on and ns.want_reg
+    ns.forward()
+    ns.backward(1)
+    torch.cuda.synchronize()
+    L = _lib.lib()
+    V, F = ns.V, ns.F
+    dev = "cuda"
+    E = lambda *s: torch.empty(*s, dtype=torch.float32, device=dev)
+    rast, rgba, stats = E(B, H, W, 4), E(B, H, W, 4), torch.zeros(4, device=dev)
+    cid = torch.empty(B, H, W, dtype=torch.uint8, device=dev)
+    bgc = ns.bg_col
+
+    def shade_fwd(flags, rast, rgba, cid, stats):
+        return L.vhap_raster_shade_fwd(_p(ns.clip), _p(ns.tri), _p(ns.vn), _p(ns.uv), _p(ns.tri_uv), _p(ns.albedo_tex), _p(ns.mips), T, T,
+                                       _p(tr.lights), _p(ns.sh_const), _p(ns.rgb) if bgc is None else 0,
+                                       ctypes.cast(bgc, ctypes.c_void_p) if bgc is not None else 0, _p(ns.fid2cid), ns.fid2cid.numel(),
+                                       B, V, ns.uv.shape[0], F, H, W, _p(rast), _p(rgba), _p(cid), _p(stats), _p(ns.ws), ns.ws_bytes,
+                                       ns.ws_cap, flags, _stream())
+    assert shade_fwd(1, rast, rgba, cid, stats) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(rast.view(torch.int32), ns.rast.view(torch.int32)), "rasteriser output differs"
+    assert torch.equal(cid, ns.cid)
+    cov = rast[..., 3] > 0
+    assert 0.05 < float(cov.float().mean()) < 0.95
+    assert torch.equal(rgba[..., 3], ns.rgba[..., 3])
+    assert torch.equal(rgba[~cov], ns.rgba[~cov]), "background composite differs"
+    assert float((rgba - ns.rgba).abs().max()) <= 2e-6
+    s_new, s_old = stats.view(torch.int32).cpu().numpy(), ns.accF[12:16].view(torch.int32).cpu().numpy()
+    dec = lambda u: np.array([(u & 0x7fffffff) if (u & 0x80000000) else (~u & 0xffffffff)], np.uint32).view(np.float32)[0]
+    mx_new, mx_old = dec(int(s_new[1]) & 0xffffffff), dec(int(s_old[1]) & 0xffffffff)
+    assert mx_old > 1.0 and abs(mx_new - mx_old) <= 2e-6 * mx_old
+    assert abs(float(stats[2]) - float(ns.accF[14])) <= 1e-5 * abs(float(ns.accF[14]))
+    if mx_new == mx_old:
+        assert int(s_new[0]) == int(s_old[0])
+    # split call: binning only, then rasterisation from the bins -- bit-identical to the single call
+    r2, c2, i2, st2 = E(B, H, W, 4), E(B, H, W, 4), torch.empty_like(cid), torch.zeros(4, device=dev)
+    assert ns.bin_split
+    assert shade_fwd(1 | 2, r2, c2, i2, st2) == 0
+    assert shade_fwd(1 | 4, r2, c2, i2, st2) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(r2.view(torch.int32), rast.view(torch.int32)) and torch.equal(c2.view(torch.int32), rgba.view(torch.int32))
+    assert torch.equal(i2, cid) and torch.equal(st2.view(torch.int32), stats.view(torch.int32))
+
+    # ---- backward
+    texc, texd, d_alb, d_n, d_tc, d_td = E(B, H, W, 2), E(B, H, W, 4), E(B, H, W, 3), E(B, H, W, 3), E(B, H, W, 2), E(B, H, W, 4)
+    for t in (texc, texd, d_n, d_tc, d_td):
+        t.zero_()                                              # (background pixels of these are not written)
+    d_lights = torch.zeros(9, 3, device=dev)
+    # d_lights of the separate passes alone: re-run vhap_shade_bwd into a fresh accumulator
+    ref_lights = torch.zeros(9, 3, device=dev)
+    d_alb_ref, d_n_ref = E(B, H, W, 3), E(B, H, W, 3)
+    assert L.vhap_shade_bwd(_p(ns.normal), _p(ns.albedo_px), _p(ns.rast), _p(tr.lights), _p(ns.sh_const), _p(ns.d_color), _p(ns.keep),
+                            _p(ns.c_reg), _p(ns.accF[12:16]), B, H, W, _p(d_alb_ref), _p(d_n_ref), _p(ref_lights), _stream()) == 0
+    assert L.vhap_deferred_shade_bwd(_p(ns.clip), _p(ns.tri), _p(ns.vn), _p(ns.uv), _p(ns.tri_uv), _p(ns.albedo_tex), _p(ns.mips), T, T,
+                                     _p(tr.lights), _p(ns.sh_const), _p(ns.rast), _p(ns.d_color), _p(ns.keep), _p(ns.c_reg),
+                                     _p(ns.accF[12:16]), B, V, ns.uv.shape[0], F, H, W, _p(texc), _p(texd), _p(d_alb), _p(d_n), _p(d_tc),
+                                     _p(d_td), _p(d_lights), _stream()) == 0
+    torch.cuda.synchronize()
+    m = cov[..., None]
+    assert torch.equal((texc * m).view(torch.int32), (ns.texc * m).view(torch.int32)), "re-computed uv differs from the G-buffer's"
+    assert torch.equal((texd * m).view(torch.int32), (ns.texd * m).view(torch.int32)), "re-computed uv derivatives differ"
+    rel = lambda a, b: float((a - b).abs().max() / (b.abs().max() + 1e-30))
+    assert torch.equal(d_alb[~cov], torch.zeros_like(d_alb[~cov]))
+    assert rel(d_alb, d_alb_ref) <= 1e-5 and rel(d_alb, ns.d_albedo) <= 1e-5
+    assert rel(d_n * m, d_n_ref * m) <= 1e-5
+    assert rel(d_tc * m, ns.d_texc * m) <= 1e-5 and rel(d_td * m, ns.d_texd * m) <= 1e-5
+    assert float(ns.d_texd.abs().max()) > 0 and float(ns.d_texc.abs().max()) > 0
+    assert rel(d_lights, ref_lights) <= 2e-5, (d_lights, ref_lights)
+
+
+def test_deferred_step_matches_separate_pass_step(flame_model, monkeypatch):
+    """The whole NativeStep with and without deferred shading: same energy terms, same gradients."""
+    from vhap_amd.step import NativeStep
+    B, H, W, T = 4, 160, 128, 256
+    stage = "rgb_global_tracking"
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("VHAP_DEFERRED", mode)
+        tr = _tracker(flame_model, B, H, W, T, seed=7, disturb=False)
+        tr.get_train_parameters(stage)
+        ns = NativeStep(tr, tr.get_sample(np.arange(B), device_index=True), stage)
+        assert ns.deferred == (mode == "1")
+        for _ in range(2):
+            ns.forward()
+            ns.backward(1)
+        torch.cuda.synchronize()
+        out[mode] = ({k: float(v) for k, v in ns.log_dict().items()}, {k: v.detach().clone() for k, v in ns.g.items() if k in ns.params})
+    (l0, g0), (l1, g1) = out["0"], out["1"]
+    for k, v in l0.items():
+        assert abs(v - l1[k]) <= 2e-6 * max(abs(v), 1e-4), (k, v, l1[k])
+    for k, a in g0.items():
+        b = g1[k]
+        assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max()) + 1e-12, k

@@ -10,7 +10,8 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 first = "frame_prep_fwd" if any("frame_prep_fwd" in r["Kernel_Name"] for r in rows) else "flame_skin_fwd"
 starts = [i for i, r in enumerate(rows) if first in r["Kernel_Name"]]
-s, e = starts[-6], starts[-5]              # one step well inside the timed graph replays
+k = int(sys.argv[sys.argv.index("--step") + 1]) if "--step" in sys.argv else len(starts) // 2
+s, e = starts[k], starts[k + 1]            # one step well inside the timed graph replays (bench.py issues a few eager steps at the end)
 seq = rows[s - 1:e - 1]
 dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
 

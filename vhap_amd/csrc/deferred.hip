@@ -1,0 +1,182 @@
+// Backward of the deferred-shading part of vhap_raster_shade_fwd (raster.hip, mode 2) for gfx950.
+//
+// The forward keeps the interpolated normal / uv / uv derivatives and the sampled albedo in registers and writes only rast + rgba.
+// This kernel RE-COMPUTES them per covered pixel from (triangle id, clip positions, vertex normals, uv table) with the forward's own
+// arithmetic (frag_common.h, tex_sample.h, shade_common.h: same bits), chains the upstream colour gradient through
+//      rgb = albedo * diffuse,  diffuse = SH(normalize(n)) . lights,  albedo = texture(uv, uv_da)
+// (render_nvdiffrast.py:386-421, 399) and emits what the two remaining consumers need: (uv, uv_da, d_albedo) for the texture-gradient
+// accumulation and (d_normal, d_uv, d_uv_da) for the G-buffer backward; d_lights is reduced per workgroup.  One pass instead of
+// vhap_shade_bwd + vhap_texture_bwd(uv part), and none of normal / texc / texd / albedo / rast_db is ever read back from HBM.
+#include "common.h"
+#include "frag_common.h"
+#include "shade_common.h"
+#include "tex_sample.h"
+
+namespace {
+
+constexpr int DB_T = 256;
+constexpr int DB_NW = DB_T / 64;
+constexpr int DB_MAX_BLOCKS = 2048;
+
+struct DeferredParams {
+    const float4* pos;       // [B,V,4]
+    const int* tri;          // [F,3]
+    const float* vnormal;    // [B,V,3]
+    const float2* uv;        // [VT,2]
+    const int* tri_uv;       // [F,3]
+    const float* tex;
+    const float* mips;
+    TexDesc D;
+    const float* lights;
+    const float* sh_const;
+    const float4* rast;
+    const float4* d_rgba;
+    const float* keep;
+    const float* d_reg;
+    const unsigned* stats;
+    int B, V, F, H, W;
+    float xs, xo, ys, yo;
+    float2* texc;
+    float4* texd;
+    float* d_albedo;
+    float* d_normal;
+    float2* d_texc;
+    float4* d_texd;
+    float* d_lights;
+};
+
+__global__ __launch_bounds__(DB_T) void deferred_shade_bwd_kernel(const DeferredParams P) {
+    __shared__ float s_l[27], s_c[9];
+    __shared__ float red[DB_NW][27];
+    if (threadIdx.x < 27) s_l[threadIdx.x] = P.lights[threadIdx.x];
+    if (threadIdx.x < 9) s_c[threadIdx.x] = P.sh_const[threadIdx.x];
+    __syncthreads();
+    const unsigned HW = (unsigned)P.H * P.W, npix = (unsigned)P.B * HW;
+    float gl[27];
+#pragma unroll
+    for (int i = 0; i < 27; i++) gl[i] = 0.f;
+    // regulariser part of d(diffuse) (lights only, on shade(normal.detach()): tracker.py:547-550), see shade_bwd_kernel
+    float g_var = 0.f, g_max = 0.f;
+    unsigned mx_ord = 0u;
+    if (P.d_reg && P.stats) {
+        const float dr = P.d_reg[0];
+        g_var = dr / (float)npix;
+        mx_ord = P.stats[1];
+        const unsigned ties = P.stats[0];
+        const unsigned u = (mx_ord & 0x80000000u) ? (mx_ord & 0x7fffffffu) : ~mx_ord;
+        g_max = __uint_as_float(u) > 1.0f ? dr / (float)max(ties, 1u) : 0.f;
+    }
+    const bool reg_on = g_var != 0.f || g_max != 0.f;
+    auto reg_grad = [&](const float (&d)[3], float (&gr)[3]) {
+        const float mean = (d[0] + d[1] + d[2]) * (1.0f / 3.0f);
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            gr[c] = g_var * (d[c] - mean);
+            if (g_max != 0.f && sh_f2ord(d[c]) == mx_ord) gr[c] += g_max;
+        }
+    };
+    unsigned n_bg = 0u;                      // background pixels of this thread: their (constant) regulariser term is added once at the end
+    for (unsigned pi = blockIdx.x * DB_T + threadIdx.x; pi < npix; pi += gridDim.x * DB_T) {
+        const float4 r = P.rast[pi];
+        const int t = (int)r.w - 1;
+        if (t < 0 || t >= P.F) {             // background: nothing flows (its colour is the detached target / a constant)
+            n_bg++;
+            float* da = P.d_albedo + 3 * (size_t)pi;
+            da[0] = 0.f; da[1] = 0.f; da[2] = 0.f;
+            continue;
+        }
+        const unsigned b = pi / HW, rem = pi - b * HW;
+        const unsigned py = rem / (unsigned)P.W, px = rem - py * (unsigned)P.W;
+        const int i0 = P.tri[3 * t], i1 = P.tri[3 * t + 1], i2 = P.tri[3 * t + 2];
+        const int j0 = P.tri_uv[3 * t], j1 = P.tri_uv[3 * t + 1], j2 = P.tri_uv[3 * t + 2];
+        float4 g = P.d_rgba[pi];
+        if (P.keep) { const float k = P.keep[pi]; g.x *= k; g.y *= k; g.z *= k; }     // backward of the colour disturbance, folded in
+        const float4* PV = P.pos + (size_t)b * P.V;
+        const float4 p0 = PV[i0], p1 = PV[i1], p2 = PV[i2];
+        const float fx = __fmaf_rn(P.xs, (float)px, P.xo), fy = __fmaf_rn(P.ys, (float)py, P.yo);
+        const Frag fr = shade_frag(p0, p1, p2, fx, fy);
+        const float4 o_db = frag_db(p0, p1, p2, fr, P.xs, P.ys);
+        const FragAttr at = frag_attr(P.vnormal + (size_t)b * P.V * 3, P.uv, i0, i1, i2, j0, j1, j2, fr, o_db);
+        SH9 bsh;
+        float x, y, z, inv, d[3];
+        sh_diffuse(at.n0, at.n1, at.n2, s_c, s_l, bsh, x, y, z, inv, d);
+        const float ga[3] = {g.x * d[0], g.y * d[1], g.z * d[2]};                     // d L / d albedo
+        float2 guv;
+        float4 gda;
+        float alb[3];
+        tex_sample_bwd_uv<3>(P.tex, P.mips, P.D, 0, make_float2(at.tu, at.tv), at.td, ga, nullptr, nullptr, guv, gda, true, alb);
+        const float gd[3] = {g.x * alb[0], g.y * alb[1], g.z * alb[2]};               // photometric part of d L / d diffuse
+        float gr[3] = {0.f, 0.f, 0.f};
+        if (reg_on) reg_grad(d, gr);
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            gl[3 * k] += bsh.v[k] * (gd[0] + gr[0]); gl[3 * k + 1] += bsh.v[k] * (gd[1] + gr[1]); gl[3 * k + 2] += bsh.v[k] * (gd[2] + gr[2]);
+        }
+        float gnx, gny, gnz;
+        const float l2 = at.n0 * at.n0 + at.n1 * at.n1 + at.n2 * at.n2;
+        sh_normal_bwd(x, y, z, inv, !(l2 > 1e-20f), s_c, s_l, gd, gnx, gny, gnz);
+        P.texc[pi] = make_float2(at.tu, at.tv);
+        P.texd[pi] = at.td;
+        float* da = P.d_albedo + 3 * (size_t)pi;
+        da[0] = ga[0]; da[1] = ga[1]; da[2] = ga[2];
+        float* dn = P.d_normal + 3 * (size_t)pi;
+        dn[0] = gnx; dn[1] = gny; dn[2] = gnz;
+        P.d_texc[pi] = guv;
+        P.d_texd[pi] = gda;
+    }
+    if (!P.d_lights) return;
+    if (reg_on && n_bg) {
+        // background pixels: normal 0 -> the same basis / diffuse colour for all of them
+        SH9 bsh;
+        float x, y, z, inv, d[3], gr[3];
+        sh_diffuse(0.f, 0.f, 0.f, s_c, s_l, bsh, x, y, z, inv, d);
+        reg_grad(d, gr);
+        const float nb = (float)n_bg;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            gl[3 * k] += nb * (bsh.v[k] * gr[0]); gl[3 * k + 1] += nb * (bsh.v[k] * gr[1]); gl[3 * k + 2] += nb * (bsh.v[k] * gr[2]);
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 27; i++) {
+        const float s = vhap_wave_sum(gl[i]);
+        if (lane == 0) red[wave][i] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 27) {
+        float s = 0.f;
+        for (int w = 0; w < DB_NW; w++) s += red[w][threadIdx.x];
+        if (s != 0.f) atomicAdd(&P.d_lights[threadIdx.x], s);
+    }
+}
+
+}  // namespace
+
+extern "C" int vhap_deferred_shade_bwd(const float* pos, const int32_t* tri, const float* vnormal, const float* uv, const int32_t* tri_uv,
+                                       const float* tex, const float* mips, int Ht, int Wt, const float* lights, const float* sh_const,
+                                       const float* rast, const float* d_rgba, const float* keep, const float* d_reg, const float* stats,
+                                       int B, int V, int VT, int F, int H, int W, float* texc, float* texd, float* d_albedo,
+                                       float* d_normal, float* d_texc, float* d_texd, float* d_lights, vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!pos || !tri || !vnormal || !uv || !tri_uv || !tex || !lights || !sh_const || !rast || !d_rgba || !texc || !texd || !d_albedo ||
+        !d_normal || !d_texc || !d_texd)
+        return VHAP_E_NULLPTR;
+    if (B <= 0 || V <= 0 || VT <= 0 || F <= 0 || H <= 0 || W <= 0 || Ht <= 0 || Wt <= 0 || (long long)B * H * W >= (1ll << 31))
+        return VHAP_E_BADDIM;
+    DeferredParams P{};
+    P.pos = reinterpret_cast<const float4*>(pos); P.tri = tri; P.vnormal = vnormal; P.uv = reinterpret_cast<const float2*>(uv);
+    P.tri_uv = tri_uv; P.tex = tex; P.mips = mips; P.D = make_desc(1, Ht, Wt, 3);
+    if (P.D.L > 0 && !mips) return VHAP_E_NULLPTR;
+    P.lights = lights; P.sh_const = sh_const; P.rast = reinterpret_cast<const float4*>(rast);
+    P.d_rgba = reinterpret_cast<const float4*>(d_rgba); P.keep = keep; P.d_reg = d_reg; P.stats = reinterpret_cast<const unsigned*>(stats);
+    P.B = B; P.V = V; P.F = F; P.H = H; P.W = W;
+    P.xs = 2.0f / (float)W; P.xo = 1.0f / (float)W - 1.0f; P.ys = 2.0f / (float)H; P.yo = 1.0f / (float)H - 1.0f;
+    P.texc = reinterpret_cast<float2*>(texc); P.texd = reinterpret_cast<float4*>(texd); P.d_albedo = d_albedo; P.d_normal = d_normal;
+    P.d_texc = reinterpret_cast<float2*>(d_texc); P.d_texd = reinterpret_cast<float4*>(d_texd); P.d_lights = d_lights;
+    const long long npix = (long long)B * H * W;
+    const int blocks = (int)((npix + DB_T - 1) / DB_T < DB_MAX_BLOCKS ? (npix + DB_T - 1) / DB_T : DB_MAX_BLOCKS);
+    deferred_shade_bwd_kernel<<<blocks, DB_T, 0, vhap_stream(stream)>>>(P);
+    VHAP_LAUNCH_CHECK();
+    return VHAP_OK;
+}

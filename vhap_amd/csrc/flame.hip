@@ -29,9 +29,11 @@ __global__ __launch_bounds__(256) void flame_skin_fwd_kernel(const float* __rest
                                                              const float* __restrict__ templ, const float* __restrict__ offset,
                                                              const float* __restrict__ transl, int B, int V, int Vp, int K,
                                                              int Kb, int Kp, float* __restrict__ verts,
-                                                             float* __restrict__ v_shaped, float* __restrict__ v_posed) {
+                                                             float* __restrict__ v_shaped, float* __restrict__ v_posed,
+                                                             const float* __restrict__ mvp, float4* __restrict__ clip) {
     __shared__ float sA[16 * NJ * 12];
     __shared__ float sT[16 * 3];
+    __shared__ float sM[16 * 16];              // per-frame world -> clip matrices (fused vhap_transform_fwd), when clip != null
     __shared__ float red[2][4][3][64][4];      // [phase][wave][component][lane][r]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int v0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
@@ -40,6 +42,7 @@ __global__ __launch_bounds__(256) void flame_skin_fwd_kernel(const float* __rest
         sA[i] = (b0 + f < B) ? A[(size_t)(b0 + f) * NJ * 12 + (i - f * NJ * 12)] : 0.f;
     }
     if (tid < 48) sT[tid] = (b0 + tid / 3 < B) ? transl[(size_t)(b0 + tid / 3) * 3 + tid % 3] : 0.f;
+    if (clip) sM[tid] = (b0 + tid / 16 < B) ? mvp[(size_t)(b0 + tid / 16) * 16 + tid % 16] : 0.f;
     const int li = lane & 15, lk = lane >> 4;
     const float* cf = coef + (size_t)(b0 + li) * Kp + lk;
     const size_t cs = (size_t)K * Vp;  // component stride
@@ -97,9 +100,15 @@ __global__ __launch_bounds__(256) void flame_skin_fwd_kernel(const float* __rest
             T[q] = s_;
         }
         v_posed[o] = px; v_posed[o + 1] = py; v_posed[o + 2] = pz;
-        verts[o] = T[0] * px + T[1] * py + T[2] * pz + T[3] + sT[fl * 3];
-        verts[o + 1] = T[4] * px + T[5] * py + T[6] * pz + T[7] + sT[fl * 3 + 1];
-        verts[o + 2] = T[8] * px + T[9] * py + T[10] * pz + T[11] + sT[fl * 3 + 2];
+        const float wx = T[0] * px + T[1] * py + T[2] * pz + T[3] + sT[fl * 3];
+        const float wy = T[4] * px + T[5] * py + T[6] * pz + T[7] + sT[fl * 3 + 1];
+        const float wz = T[8] * px + T[9] * py + T[10] * pz + T[11] + sT[fl * 3 + 2];
+        verts[o] = wx; verts[o + 1] = wy; verts[o + 2] = wz;
+        if (clip) {                            // same expression as transform_fwd_kernel: identical bits
+            const float* M = sM + fl * 16;
+            clip[(size_t)f * V + v] = make_float4(M[0] * wx + M[1] * wy + M[2] * wz + M[3], M[4] * wx + M[5] * wy + M[6] * wz + M[7],
+                                                  M[8] * wx + M[9] * wy + M[10] * wz + M[11], M[12] * wx + M[13] * wy + M[14] * wz + M[15]);
+        }
     }
 }
 
@@ -350,7 +359,22 @@ extern "C" int vhap_flame_skin_fwd(const float* coef, const float* basis, const 
     if (B <= 0 || V <= 0 || Vp < V || Vp % 64 || K <= 0 || K % 4 || Kb % 4 || Kb > K || Kp < K) return VHAP_E_BADDIM;
     flame_skin_fwd_kernel<<<dim3(Vp / 16, (B + 15) / 16), 256, 0, vhap_stream(stream)>>>(coef, basis, A, lbs_weights, v_template, offset,
                                                                                         transl, B, V, Vp, K, Kb, Kp, verts, v_shaped,
-                                                                                        v_posed);
+                                                                                        v_posed, nullptr, nullptr);
+    VHAP_LAUNCH_CHECK();
+    return VHAP_OK;
+}
+
+extern "C" int vhap_flame_skin_clip_fwd(const float* coef, const float* basis, const float* A, const float* lbs_weights,
+                                        const float* v_template, const float* offset, const float* transl, const float* mvp, int B,
+                                        int V, int Vp, int K, int Kb, int Kp, float* verts, float* v_shaped, float* v_posed,
+                                        float* clip, vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!coef || !basis || !A || !lbs_weights || !v_template || !transl || !verts || !v_shaped || !v_posed || !mvp || !clip)
+        return VHAP_E_NULLPTR;
+    if (B <= 0 || V <= 0 || Vp < V || Vp % 64 || K <= 0 || K % 4 || Kb % 4 || Kb > K || Kp < K) return VHAP_E_BADDIM;
+    flame_skin_fwd_kernel<<<dim3(Vp / 16, (B + 15) / 16), 256, 0, vhap_stream(stream)>>>(coef, basis, A, lbs_weights, v_template, offset,
+                                                                                        transl, B, V, Vp, K, Kb, Kp, verts, v_shaped,
+                                                                                        v_posed, mvp, reinterpret_cast<float4*>(clip));
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;
 }

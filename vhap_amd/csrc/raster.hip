@@ -4,20 +4,25 @@
 // 384, 389).  Conventions are specified in DESIGN.md section 3 and restated independently in
 // oracle/raster_oracle.c, against which this file is checked bit-for-bit (triangle ids, z/w, u, v).
 //
-// Structure (one frame batch = memset + 3 small launches + 1 big one):
-//   bin_count  : 1 thread / (frame, triangle): snap to 1/16 px, cull, pixel bbox -> range of 8x8
-//                pixel BLOCKS; histogram in LDS, one global atomic per touched block per workgroup
-//   bin_scan   : per-256-block exclusive scan + one atomic per workgroup -> list offsets
-//   bin_fill   : same LDS aggregation, writes (tri id, 3 vertex indices) into the block lists
-//   raster     : 1 workgroup = 4 waves = 32x8 pixels, each WAVE owns one 8x8 block and its list.
-//                Per 64-triangle chunk every lane sets up ONE triangle (exact integer edge
-//                functions and the z/w test plane, both relative to the block origin), v_readlane
-//                broadcasts each triangle through SGPRs and every lane (= pixel) evaluates coverage
-//                (3 integer mads) and the depth plane (2 FMAs) and keeps the smallest (depth, id)
-//                key in registers.  No LDS, no barriers, no atomics in the resolve; the winner is
-//                independent of list order.  The lane then shades its pixel once (u, v, z/w,
-//                derivatives, normal, uv, uv derivatives) and writes the G-buffer.
+// Structure (one frame batch = 2 launches):
+//   bin_build  : 1 thread / (frame, triangle): snap to 1/16 px, cull, pixel bbox -> range of 8x8 pixel BLOCKS, 80-byte setup
+//                record; every 1024-triangle workgroup lays its (triangle, block) pairs out in its own region of the pair list
+//                (LDS histogram -> workgroup scan -> scatter) and publishes fragment descriptors -- no global counters.
+//                (bin_count / bin_scan / bin_fill: the three-launch variant with contiguous lists, for meshes > 32768 triangles.)
+//   raster     : 1 workgroup = 4 waves = 32x8 pixels, each WAVE owns one 8x8 block and walks its fragments.  Per 64-triangle
+//                chunk every lane sets up ONE triangle (exact integer edge functions and the z/w test plane, relative to the
+//                block origin) and publishes it in LDS; every lane (= pixel) then reads triangle j with broadcast ds_read_b128,
+//                evaluates coverage (3 v_dot2) and the depth plane (2 FMAs) and keeps the smallest (depth, id) key in
+//                registers.  No barriers, no atomics; the winner is independent of list order.  The lane then shades its pixel
+//                once.  Three modes of the same kernel: 0 = rasterize only (rast, rast_db); 1 = + both interpolations (normal, uv,
+//                uv derivatives: the G-buffer of the nvdiffrast-shaped ops); 2 = DEFERRED SHADING: the interpolated attributes stay
+//                in registers, the texture is sampled (trilinear mip-mapped), the SH diffuse shading and the background composite are
+//                applied and only rast (16 B) + rgba (16 B) + the colour-cluster byte leave the kernel -- 33 B/px instead of the
+//                68 + 12 + 17 the three separate passes write (and 88 they re-read).
 #include "raster_common.h"
+#include "frag_common.h"
+#include "shade_common.h"
+#include "tex_sample.h"
 
 #pragma clang fp contract(off)  // bit-exact op order vs the oracle: only explicit fma() fuses
 
@@ -269,31 +274,7 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_build_kernel(const float* __r
         for (int x = r.bx0; x <= r.bx1; x++) list[base + atomicAdd(&lb[y * nbx + x], 1u)] = (unsigned)t;
 }
 
-// ---- winner arithmetic (same op order as shade_frag() in the oracle) ----
-struct Frag {
-    float b0, b1, zw, iw;
-};
-
-__device__ __forceinline__ Frag shade_frag(const float4 p0, const float4 p1, const float4 p2, float fx, float fy) {
-    Frag r;
-    const float p0x = __fmaf_rn(-fx, p0.w, p0.x), p0y = __fmaf_rn(-fy, p0.w, p0.y);
-    const float p1x = __fmaf_rn(-fx, p1.w, p1.x), p1y = __fmaf_rn(-fy, p1.w, p1.y);
-    const float p2x = __fmaf_rn(-fx, p2.w, p2.x), p2y = __fmaf_rn(-fy, p2.w, p2.y);
-    const float a0 = __fmaf_rn(p1x, p2y, -(p1y * p2x));
-    const float a1 = __fmaf_rn(p2x, p0y, -(p2y * p0x));
-    const float a2 = __fmaf_rn(p0x, p1y, -(p0y * p1x));
-    const float at = (a0 + a1) + a2;
-    const float iw = (fabsf(at) > 0.0f) ? __fdiv_rn(1.0f, at) : 0.0f;
-    const float z = __fmaf_rn(p0.z, a0, __fmaf_rn(p1.z, a1, p2.z * a2));
-    const float w = __fmaf_rn(p0.w, a0, __fmaf_rn(p1.w, a1, p2.w * a2));
-    const float zw = __fdiv_rn(z, w);
-    r.b0 = fminf(fmaxf(a0 * iw, 0.0f), 1.0f);
-    r.b1 = fminf(fmaxf(a1 * iw, 0.0f), 1.0f);
-    r.zw = fminf(fmaxf(zw, -1.0f), 1.0f);
-    r.iw = iw;
-    return r;
-}
-
+// ---- winner arithmetic: frag_common.h (same op order as shade_frag() in the oracle) ----
 __device__ __forceinline__ unsigned f2ord(float f) {   // order-preserving float -> unsigned: negative ? ~u : u | sign  (branch-free: 3 VALU)
     const unsigned u = __float_as_uint(f);
     return u ^ ((unsigned)((int)u >> 31) | 0x80000000u);
@@ -335,10 +316,24 @@ struct RasterParams {
     float* normal;
     float* texc;
     float* texd;
+    // deferred shading (mode 2)
+    const float* tex;         // [Ht,Wt,3] ONE texture shared by the batch
+    const float* mips;        // its pyramid (vhap_texture_mip_build)
+    TexDesc D;
+    const float* lights;      // [9,3]
+    const float* sh_const;    // [9]
+    const float* bg_image;    // [B,3,H,W] image space (row 0 = top) or null -> (bg_r, bg_g, bg_b)
+    float bg_r, bg_g, bg_b;
+    const int* fid2cid;       // [nfid] triangle id + 1 -> colour cluster, or null
+    int nfid;
+    float* rgba;              // [B,H,W,4] shaded + composited colour
+    unsigned char* cid;       // [B,H,W] or null
+    uint4* stats_part;        // per-wave partials of the diffuse-regulariser statistics ((max << 32 | ties) lo, hi, var sum, -) or null
 };
 
-template <bool INTERP>
+template <int MODE>
 __global__ __launch_bounds__(256) void raster_kernel(const RasterParams P) {
+    constexpr bool INTERP = MODE >= 1;
     const unsigned L = vhap_xcd_remap(blockIdx.x, gridDim.x);
     const int nwg = P.nwx * P.nby;  // workgroups per frame
     const int b = L / nwg, wgi = L - b * nwg;
@@ -348,7 +343,12 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterParams P) {
     const int wy = (int)(((long long)wy_lin * P.row_mul) % P.nby);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int bx = wx * WG_BLOCKS + wave, by = wy;  // this wave's 8x8 block
-    if (bx >= P.nbx) return;                        // whole wave outside the image
+    if (bx >= P.nbx) {                              // whole wave outside the image
+        if constexpr (MODE == 2) {
+            if (P.stats_part && lane == 0) P.stats_part[(size_t)blockIdx.x * 4 + wave] = make_uint4(0u, 0u, 0u, 0u);
+        }
+        return;
+    }
     const int bx0 = bx * BLK, by0 = by * BLK;
     const int dxp = lane & 7, dyp = lane >> 3;
     const int px = bx0 + dxp, py = by0 + dyp;
@@ -535,11 +535,16 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterParams P) {
     }
 
     if ((P.debug & 2) && best != 12345ull) return;  // ablation: no stores
-    if (!in_img) return;
-    const size_t pidx = ((size_t)b * H + py) * W + px;
-    float4 o_rast = make_float4(0.f, 0.f, 0.f, 0.f), o_db = o_rast, o_td = o_rast;
-    float n0 = 0.f, n1 = 0.f, n2 = 0.f, tu = 0.f, tv = 0.f;
-    if (best != ~0ull) {
+    if constexpr (MODE != 2) {
+        if (!in_img) return;
+    }
+    const size_t pidx = in_img ? ((size_t)b * H + py) * W + px : 0;
+    float4 o_rast = make_float4(0.f, 0.f, 0.f, 0.f), o_db = o_rast;
+    FragAttr at;
+    at.n0 = at.n1 = at.n2 = at.tu = at.tv = 0.f;
+    at.td = o_rast;
+    const bool cov = in_img && best != ~0ull;
+    if (cov) {
         const int t = (int)((unsigned)best >> 6), slot = (int)((unsigned)best & 63u);
         int i0, i1, i2;
         int4 q4;
@@ -555,56 +560,107 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterParams P) {
         }
         const float4* PV = reinterpret_cast<const float4*>(P.pos) + (size_t)b * P.V;
         const float4 p0 = PV[i0], p1 = PV[i1], p2 = PV[i2];
-        const float xs = P.xs, xo = P.xo, ys = P.ys, yo = P.yo;
-        const float fx = __fmaf_rn(xs, (float)px, xo), fy = __fmaf_rn(ys, (float)py, yo);
+        const float fx = __fmaf_rn(P.xs, (float)px, P.xo), fy = __fmaf_rn(P.ys, (float)py, P.yo);
         const Frag fr = shade_frag(p0, p1, p2, fx, fy);
         o_rast = make_float4(fr.b0, fr.b1, fr.zw, (float)(t + 1));
-        const float dfxdx = xs * fr.iw, dfydy = ys * fr.iw;
-        const float da0dx = __fmaf_rn(p2.y, p1.w, -(p1.y * p2.w));
-        const float da0dy = __fmaf_rn(p1.x, p2.w, -(p2.x * p1.w));
-        const float da1dx = __fmaf_rn(p0.y, p2.w, -(p2.y * p0.w));
-        const float da1dy = __fmaf_rn(p2.x, p0.w, -(p0.x * p2.w));
-        const float da2dx = __fmaf_rn(p1.y, p0.w, -(p0.y * p1.w));
-        const float da2dy = __fmaf_rn(p0.x, p1.w, -(p1.x * p0.w));
-        const float datdx = (da0dx + da1dx) + da2dx;
-        const float datdy = (da0dy + da1dy) + da2dy;
-        o_db.x = dfxdx * __fmaf_rn(fr.b0, datdx, -da0dx);
-        o_db.y = dfydy * __fmaf_rn(fr.b0, datdy, -da0dy);
-        o_db.z = dfxdx * __fmaf_rn(fr.b1, datdx, -da1dx);
-        o_db.w = dfydy * __fmaf_rn(fr.b1, datdy, -da1dy);
-        if constexpr (INTERP) {
-            const float b2 = (1.0f - fr.b0) - fr.b1;
-            const float* N = P.vnormal + (size_t)b * P.V * 3;
-            n0 = __fmaf_rn(fr.b0, N[3 * i0 + 0], __fmaf_rn(fr.b1, N[3 * i1 + 0], b2 * N[3 * i2 + 0]));
-            n1 = __fmaf_rn(fr.b0, N[3 * i0 + 1], __fmaf_rn(fr.b1, N[3 * i1 + 1], b2 * N[3 * i2 + 1]));
-            n2 = __fmaf_rn(fr.b0, N[3 * i0 + 2], __fmaf_rn(fr.b1, N[3 * i1 + 2], b2 * N[3 * i2 + 2]));
-            const float2* UV = reinterpret_cast<const float2*>(P.uv);
-            const float2 u0 = UV[q4.y], u1 = UV[q4.z], u2 = UV[q4.w];
-            tu = __fmaf_rn(fr.b0, u0.x, __fmaf_rn(fr.b1, u1.x, b2 * u2.x));
-            tv = __fmaf_rn(fr.b0, u0.y, __fmaf_rn(fr.b1, u1.y, b2 * u2.y));
-            const float eu0 = u0.x - u2.x, eu1 = u1.x - u2.x, ev0 = u0.y - u2.y, ev1 = u1.y - u2.y;
-            o_td.x = __fmaf_rn(o_db.x, eu0, o_db.z * eu1);
-            o_td.y = __fmaf_rn(o_db.y, eu0, o_db.w * eu1);
-            o_td.z = __fmaf_rn(o_db.x, ev0, o_db.z * ev1);
-            o_td.w = __fmaf_rn(o_db.y, ev0, o_db.w * ev1);
+        o_db = frag_db(p0, p1, p2, fr, P.xs, P.ys);
+        if constexpr (INTERP)
+            at = frag_attr(P.vnormal + (size_t)b * P.V * 3, reinterpret_cast<const float2*>(P.uv), i0, i1, i2, q4.y, q4.z, q4.w, fr, o_db);
+    }
+    if constexpr (MODE == 2) {
+        // ---- deferred shading: texture sample, SH diffuse, composite over the background (render_nvdiffrast.py:386-421) ----
+        float var = 0.f;
+        unsigned long long mx = 0ull;
+        if (in_img) {
+            SH9 bsh;
+            float nx, ny, nz, inv, d[3];
+            sh_diffuse(at.n0, at.n1, at.n2, P.sh_const, P.lights, bsh, nx, ny, nz, inv, d);   // background: normal 0 -> the constant bands
+            float4 o_rgba;
+            if (cov) {
+                float alb[3];
+                tex_sample<3>(P.tex, P.mips, P.D, 0, make_float2(at.tu, at.tv), at.td, alb);
+                o_rgba = make_float4(alb[0] * d[0], alb[1] * d[1], alb[2] * d[2], 1.0f);
+            } else if (P.bg_image) {
+                const size_t HW = (size_t)H * W;
+                const float* g = P.bg_image + (size_t)b * 3 * HW + (size_t)(H - 1 - py) * W + px;
+                o_rgba = make_float4(g[0], g[HW], g[2 * HW], 0.0f);
+            } else {
+                o_rgba = make_float4(P.bg_r, P.bg_g, P.bg_b, 0.0f);
+            }
+            reinterpret_cast<float4*>(P.rast)[pidx] = o_rast;
+            reinterpret_cast<float4*>(P.rgba)[pidx] = o_rgba;
+            if (P.cid) P.cid[pidx] = (unsigned char)P.fid2cid[min(max((int)o_rast.w, 0), P.nfid - 1)];
+            if (P.stats_part) {
+                const float mean = (d[0] + d[1] + d[2]) * (1.0f / 3.0f);
+                var = 0.5f * ((d[0] - mean) * (d[0] - mean) + (d[1] - mean) * (d[1] - mean) + (d[2] - mean) * (d[2] - mean));
+                float mxv = d[0];
+                unsigned mxn = 1u;
+#pragma unroll
+                for (int c = 1; c < 3; c++) {
+                    if (d[c] > mxv) { mxv = d[c]; mxn = 1u; }
+                    else if (d[c] == mxv) mxn++;
+                }
+                mx = ((unsigned long long)sh_f2ord(mxv) << 32) | mxn;
+            }
         }
+        if (P.stats_part) {         // statistics of the diffuse regulariser (tracker.py:547-550): one partial per wave, no atomics
+            var = vhap_wave_sum(var);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)mx, o, 64), hi = (unsigned)__shfl_xor((int)(unsigned)(mx >> 32), o, 64);
+                mx = sh_merge_max(mx, ((unsigned long long)hi << 32) | lo);
+            }
+            if (lane == 0) P.stats_part[(size_t)blockIdx.x * 4 + wave] = make_uint4((unsigned)mx, (unsigned)(mx >> 32), __float_as_uint(var), 0u);
+        }
+        return;
     }
     reinterpret_cast<float4*>(P.rast)[pidx] = o_rast;
     if (P.rast_db) reinterpret_cast<float4*>(P.rast_db)[pidx] = o_db;
-    if constexpr (INTERP) {
+    if constexpr (MODE == 1) {
         float* no = P.normal + 3 * pidx;
-        no[0] = n0; no[1] = n1; no[2] = n2;
-        reinterpret_cast<float2*>(P.texc)[pidx] = make_float2(tu, tv);
-        reinterpret_cast<float4*>(P.texd)[pidx] = o_td;
+        no[0] = at.n0; no[1] = at.n1; no[2] = at.n2;
+        reinterpret_cast<float2*>(P.texc)[pidx] = make_float2(at.tu, at.tv);
+        reinterpret_cast<float4*>(P.texd)[pidx] = at.td;
+    }
+}
+
+// final reduction of the per-wave shading statistics -> stats[4] in the layout of vhap_shade_fwd: (ties, ordered max, var sum, -)
+__global__ __launch_bounds__(1024) void shade_stats_reduce_kernel(const uint4* __restrict__ part, int n, unsigned* __restrict__ stats) {
+    __shared__ float rv[16];
+    __shared__ unsigned long long rm[16];
+    float var = 0.f;
+    unsigned long long mx = 0ull;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const uint4 p = part[i];
+        var += __uint_as_float(p.z);
+        mx = sh_merge_max(mx, ((unsigned long long)p.y << 32) | p.x);
+    }
+    var = vhap_wave_sum(var);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)mx, o, 64), hi = (unsigned)__shfl_xor((int)(unsigned)(mx >> 32), o, 64);
+        mx = sh_merge_max(mx, ((unsigned long long)hi << 32) | lo);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { rv[wave] = var; rm[wave] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float v = 0.f;
+        unsigned long long m = 0ull;
+        for (int w = 0; w < 16; w++) { v += rv[w]; m = sh_merge_max(m, rm[w]); }
+        stats[0] = (unsigned)m;
+        stats[1] = (unsigned)(m >> 32);
+        stats[2] = __float_as_uint(v);
+        stats[3] = 0u;
     }
 }
 
 
 struct WsLayout {
-    size_t hdr, counts, cursors, offsets, trange, records, list, frag, total;
+    size_t hdr, counts, cursors, offsets, trange, records, list, frag, stats, total;
 };
 
-WsLayout ws_layout(int B, int F, int nbin, size_t cap) {
+WsLayout ws_layout(int B, int F, int nbin, size_t cap, size_t npart) {
     WsLayout l;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t o = 0;
@@ -616,6 +672,7 @@ WsLayout ws_layout(int B, int F, int nbin, size_t cap) {
     l.records = o; o = al(o + sizeof(TriRecord) * (size_t)B * F);
     l.list = o; o = al(o + sizeof(unsigned) * (cap ? cap : 1));
     l.frag = o; o = al(o + sizeof(uint2) * (size_t)B * nbin * ((F + BIN_THREADS - 1) / BIN_THREADS));
+    l.stats = o; o = al(o + sizeof(uint4) * npart);                 // per-wave shading-statistics partials (mode 2): 4 per raster workgroup
     l.total = o;
     return l;
 }
@@ -627,8 +684,8 @@ int check_dims(int B, int V, int F, int H, int W) {
     return VHAP_OK;
 }
 
-template <bool INTERP>
-int launch_raster(RasterParams P, void* ws, size_t ws_bytes, size_t cap, int flags, hipStream_t st) {
+template <int MODE>
+int launch_raster(RasterParams P, void* ws, size_t ws_bytes, size_t cap, int flags, hipStream_t st, float* stats_out = nullptr) {
     const int B = P.B, F = P.F;
     P.nbx = (P.W + BLK - 1) / BLK;
     P.nby = (P.H + BLK - 1) / BLK;
@@ -639,7 +696,7 @@ int launch_raster(RasterParams P, void* ws, size_t ws_bytes, size_t cap, int fla
     P.yo = 1.0f / (float)P.H - 1.0f;
     const int nbin = P.nbx * P.nby;
     if ((long long)B * nbin >= (1ll << 31) || cap > 0xfffffff0u) return VHAP_E_BADDIM;
-    const WsLayout l = ws_layout(B, F, nbin, cap);
+    const WsLayout l = ws_layout(B, F, nbin, cap, (size_t)B * P.nwx * P.nby * 4);
     if (!ws) return VHAP_E_NULLPTR;
     if (ws_bytes < l.total) return VHAP_E_WORKSPACE;
     char* w = static_cast<char*>(ws);
@@ -657,7 +714,11 @@ int launch_raster(RasterParams P, void* ws, size_t ws_bytes, size_t cap, int fla
     const bool fragmented = use_lds && nfrag <= MAX_FRAG && region >= 1 && !(vhap_g_debug_flags & 4096);   // (flag 4096: A/B switch)
     P.frag = nullptr;
     P.nfrag = nfrag;
-    if (fragmented) {
+    const bool prebinned = (flags & VHAP_RASTER_PREBINNED) != 0;
+    if ((flags & (VHAP_RASTER_BIN_ONLY | VHAP_RASTER_PREBINNED)) && !fragmented) return VHAP_E_UNSUPPORTED;   // split calls: one-launch binning only
+    if (fragmented && prebinned) {
+        P.frag = reinterpret_cast<uint2*>(w + l.frag);
+    } else if (fragmented) {
         // binning in ONE launch: per-workgroup regions of the pair list, fragment descriptors instead of global counters
         const size_t lds = sizeof(unsigned) * nbin;
         if (lds > 65536 &&
@@ -689,6 +750,7 @@ int launch_raster(RasterParams P, void* ws, size_t ws_bytes, size_t cap, int fla
         bin_fill_kernel<<<gbin, BIN_THREADS, fill_lds, st>>>(trange, F, P.nbx, P.nby, offsets, cursors, list, hdr, (unsigned)cap);
         VHAP_LAUNCH_CHECK();
     }
+    if (flags & VHAP_RASTER_BIN_ONLY) return VHAP_OK;
     P.counts = counts;
     P.counts_w = counts;
     P.cursors_w = cursors;
@@ -706,8 +768,14 @@ int launch_raster(RasterParams P, void* ws, size_t ws_bytes, size_t cap, int fla
     P.hdr = hdr;
     P.capacity = (unsigned)cap;
     P.debug = vhap_g_debug_flags;
-    raster_kernel<INTERP><<<B * P.nwx * P.nby, 256, 0, st>>>(P);
+    const int nwg = B * P.nwx * P.nby;
+    if (MODE == 2 && stats_out) P.stats_part = reinterpret_cast<uint4*>(w + l.stats);
+    raster_kernel<MODE><<<nwg, 256, 0, st>>>(P);
     VHAP_LAUNCH_CHECK();
+    if (MODE == 2 && stats_out) {
+        shade_stats_reduce_kernel<<<1, 1024, 0, st>>>(P.stats_part, nwg * 4, reinterpret_cast<unsigned*>(stats_out));
+        VHAP_LAUNCH_CHECK();
+    }
     return VHAP_OK;
 }
 
@@ -716,8 +784,8 @@ int launch_raster(RasterParams P, void* ws, size_t ws_bytes, size_t cap, int fla
 
 extern "C" size_t vhap_raster_workspace_bytes(int B, int F, int H, int W, size_t pair_capacity) {
     if (check_dims(B, 1, F, H, W) != VHAP_OK) return 0;
-    const int nbin = ((W + BLK - 1) / BLK) * ((H + BLK - 1) / BLK);
-    return ws_layout(B, F, nbin, pair_capacity).total;
+    const int nbx = (W + BLK - 1) / BLK, nby = (H + BLK - 1) / BLK;
+    return ws_layout(B, F, nbx * nby, pair_capacity, (size_t)B * ((nbx + WG_BLOCKS - 1) / WG_BLOCKS) * nby * 4).total;
 }
 
 extern "C" int vhap_raster_fwd(const float* pos, const int32_t* tri, int B, int V, int F, int H, int W, float* rast,
@@ -729,7 +797,7 @@ extern "C" int vhap_raster_fwd(const float* pos, const int32_t* tri, int B, int 
     RasterParams P{};
     P.pos = pos; P.tri = tri; P.B = B; P.V = V; P.F = F; P.H = H; P.W = W;
     P.rast = rast; P.rast_db = rast_db;
-    return launch_raster<false>(P, workspace, workspace_bytes, pair_capacity, flags, vhap_stream(stream));
+    return launch_raster<0>(P, workspace, workspace_bytes, pair_capacity, flags, vhap_stream(stream));
 }
 
 extern "C" int vhap_raster_interp_fwd(const float* pos, const int32_t* tri, const float* vnormal, const float* uv,
@@ -744,5 +812,28 @@ extern "C" int vhap_raster_interp_fwd(const float* pos, const int32_t* tri, cons
     P.pos = pos; P.tri = tri; P.vnormal = vnormal; P.uv = uv; P.tri_uv = tri_uv;
     P.B = B; P.V = V; P.VT = VT; P.F = F; P.H = H; P.W = W;
     P.rast = rast; P.rast_db = rast_db; P.normal = normal; P.texc = texc; P.texd = texd;
-    return launch_raster<true>(P, workspace, workspace_bytes, pair_capacity, flags, vhap_stream(stream));
+    return launch_raster<1>(P, workspace, workspace_bytes, pair_capacity, flags, vhap_stream(stream));
+}
+
+extern "C" int vhap_raster_shade_fwd(const float* pos, const int32_t* tri, const float* vnormal, const float* uv, const int32_t* tri_uv,
+                                     const float* tex, const float* mips, int Ht, int Wt, const float* lights, const float* sh_const,
+                                     const float* bg_image, const float* bg_color, const int32_t* fid2cid, int nfid, int B, int V,
+                                     int VT, int F, int H, int W, float* rast, float* rgba, uint8_t* cid, float* stats,
+                                     void* workspace, size_t workspace_bytes, size_t pair_capacity, int flags, vhap_stream_t stream) {
+    VHAP_ENTER();
+    const bool bin_only = (flags & VHAP_RASTER_BIN_ONLY) != 0;
+    if (!pos || !tri || !uv || !tri_uv) return VHAP_E_NULLPTR;
+    if (!bin_only && (!vnormal || !tex || !lights || !sh_const || !rast || !rgba || (!bg_image && !bg_color))) return VHAP_E_NULLPTR;
+    if (cid && (!fid2cid || nfid <= 0)) return VHAP_E_NULLPTR;
+    if (int e = check_dims(B, V, F, H, W)) return e;
+    if (VT <= 0 || Ht <= 0 || Wt <= 0) return VHAP_E_BADDIM;
+    RasterParams P{};
+    P.pos = pos; P.tri = tri; P.vnormal = vnormal; P.uv = uv; P.tri_uv = tri_uv;
+    P.B = B; P.V = V; P.VT = VT; P.F = F; P.H = H; P.W = W;
+    P.rast = rast; P.rgba = rgba; P.cid = cid; P.fid2cid = fid2cid; P.nfid = nfid;
+    P.tex = tex; P.mips = mips; P.D = make_desc(1, Ht, Wt, 3);
+    if (P.D.L > 0 && !mips && !bin_only) return VHAP_E_NULLPTR;
+    P.lights = lights; P.sh_const = sh_const; P.bg_image = bg_image;
+    if (!bg_image && bg_color) { P.bg_r = bg_color[0]; P.bg_g = bg_color[1]; P.bg_b = bg_color[2]; }
+    return launch_raster<2>(P, workspace, workspace_bytes, pair_capacity, flags, vhap_stream(stream), stats);
 }

@@ -11,6 +11,7 @@ assembled by two one-thread kernels (vhap_energy_finalize / vhap_energy_total). 
 Used by vhap_amd.tracker.GraphedStep when NativeStep.supported(); torch only provides memory, streams and the collectives.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -129,16 +130,23 @@ class NativeStep:
             self.mips = E(L.vhap_texture_mip_floats(1, T, T, 3))
         else:
             self.albedo_tex, self.mips = E(0), E(0)
+        # deferred shading (default): the rasteriser samples the texture and shades in registers; normal / rast_db / albedo images do not exist
+        self.deferred = self.photometric and os.environ.get("VHAP_DEFERRED", "1") != "0"
         if self.photometric:
             self.clip, self.vn = E(B, V, 4), E(B, V, 3)
-            self.rast, self.db, self.normal, self.texc, self.texd = E(B, H, W, 4), E(B, H, W, 4), E(B, H, W, 3), E(B, H, W, 2), E(B, H, W, 4)
-            self.albedo_px, self.rgba, self.rgba_aa = E(B, H, W, 3), E(B, H, W, 4), E(B, H, W, 4)
+            self.rast, self.texc, self.texd = E(B, H, W, 4), E(B, H, W, 2), E(B, H, W, 4)
+            if not self.deferred:
+                self.db, self.normal, self.albedo_px = E(B, H, W, 4), E(B, H, W, 3), E(B, H, W, 3)
+            self.rgba, self.rgba_aa = E(B, H, W, 4), E(B, H, W, 4)
             if self.disturb_on:
                 self.rgba_d, self.keep = E(B, H, W, 4), E(B, H, W)
                 self.dist_ws = torch.empty(L.vhap_disturb_workspace_ints(B, H, W), dtype=torch.int32, device=dev)
                 self.cid = torch.empty(B, H, W, dtype=torch.uint8, device=dev)
             self.aa_work = torch.empty(L.vhap_antialias_work_ints(B, H, W, self.F), dtype=torch.int32, device=dev)
             self.ws, self.ws_bytes, self.ws_cap, _ = tr.render.glctx.acquire(B, self.F, H, W, self.rgb.device)
+            # one-launch binning available (raster.hip: LDS_BIN_LIMIT bins, MAX_FRAG x 1024 triangles): binning and rasterisation can be split
+            nfrag = (self.F + 1023) // 1024
+            self.bin_split = ((W + 7) // 8) * ((H + 7) // 8) <= 16384 and nfrag <= 32 and self.ws_cap // (B * nfrag) >= 1
         # forward accumulators: frame terms [0:6], landmark [6], texture terms [7:9], offset terms [9:12], shade stats [12:16], photo [16:18]
         self.accF = torch.zeros(32, **f32)
         self.log = torch.zeros(16, **f32)
@@ -184,11 +192,11 @@ class NativeStep:
         self.ones = torch.ones(8, **f32)
         # two independent chains per pass run on two streams (two branches of the captured graph): the bandwidth / atomics bound texture
         # work next to the latency-bound geometry chain of small launches
-        import os
         self.overlap = os.environ.get("VHAP_STEP_OVERLAP", "1") != "0"
         self.split_tex = False        # True: stop at the gradient pyramid, the caller runs tex_finish() later (pyramid-level exchange)
         self.tex_l0_skip = False      # True: tex_finish() ignores the base level of the pyramid
         self.side = torch.cuda.Stream()
+        self.side2 = torch.cuda.Stream()
         self.c_lmk = torch.full((1,), self.w_lmk, **f32)
         self.c_reg = torch.full((1,), self.w_reg, **f32)
 
@@ -254,8 +262,13 @@ class NativeStep:
                                    _p(tr.jaw_pose), _p(tr.eyes_pose), _p(fm.JT), _p(fm.JS), _p(fm.jreg_idx), _p(fm.jreg_w), fm.jreg_n,
                                    _p(so), fm.parents, self.weights, B, self.Bp, self.N, self.NS, self.NE, J, fb.Kp, V,
                                    _p(self.coef), _p(self.A), _p(self.transl), _p(self.Jrest), _p(acc), PRE, st), "vhap_frame_prep_fwd")
-        _chk(L.vhap_flame_skin_fwd(_p(self.coef), _p(fb.basis), _p(self.A), _p(fb.w), _p(fb.templ), _p(so), _p(self.transl), B, V, fb.Vp,
-                                   fb.K, fb.Kb, fb.Kp, _p(self.verts), _p(self.v_shaped), _p(self.v_posed), st), "vhap_flame_skin_fwd")
+        if self.photometric:                                      # skinning fused with the world -> clip transform (one launch, same bits)
+            _chk(L.vhap_flame_skin_clip_fwd(_p(self.coef), _p(fb.basis), _p(self.A), _p(fb.w), _p(fb.templ), _p(so), _p(self.transl), _p(self.mvp),
+                                            B, V, fb.Vp, fb.K, fb.Kb, fb.Kp, _p(self.verts), _p(self.v_shaped), _p(self.v_posed), _p(self.clip), st),
+                 "vhap_flame_skin_clip_fwd")
+        else:
+            _chk(L.vhap_flame_skin_fwd(_p(self.coef), _p(fb.basis), _p(self.A), _p(fb.w), _p(fb.templ), _p(so), _p(self.transl), B, V, fb.Vp,
+                                       fb.K, fb.Kb, fb.Kp, _p(self.verts), _p(self.v_shaped), _p(self.v_posed), st), "vhap_flame_skin_fwd")
         if not self.photometric:
             # landmark-only stage (lmk_init_*, lmk_*_tracking): no pixel chain, a handful of latency-bound launches
             self._tex_forward()
@@ -269,13 +282,18 @@ class NativeStep:
         # fork here, not at the top: next to the bandwidth-bound texture assembly the two latency-bound kernels above take 3x as long,
         # and they head the critical path of the forward pass; the texture branch still finishes long before the rasteriser does
         self._fork()
+        tex_ready = None
         with self._branch():
             self._tex_forward()
+            if self.overlap and self.deferred:                    # the deferred rasteriser samples the texture: it waits for THIS point only
+                tex_ready = torch.cuda.Event()
+                tex_ready.record()
             if self.w_lmk:                                        # needs only verts + mvp: off the rasteriser's critical path
                 self._landmark_forward()
             self.arena.zero_()                                    # ONE launch clears every gradient accumulator of the backward
             self._arena_clean = True
-        _chk(L.vhap_transform_fwd(_p(self.verts), _p(self.mvp), B, V, _p(self.clip), st), "vhap_transform_fwd")
+        if self.deferred:
+            return self._forward_deferred(tex_ready)
         _chk(L.vhap_vnormal_fwd(_p(self.verts), _p(self.csr.tri), _p(self.csr.ptr), _p(self.csr.idx), B, V, _p(self.vn), st), "vhap_vnormal_fwd")
         _hook("raster_interp_fwd", "begin")                       # (bench.py: HIP events / event-record graph nodes around the RI-fwd pass)
         _chk(L.vhap_raster_interp_fwd(_p(self.clip), _p(self.tri), _p(self.vn), _p(self.uv), _p(self.tri_uv), B, V, self.uv.shape[0], F, H, W,
@@ -300,6 +318,54 @@ class NativeStep:
         _chk(L.vhap_antialias_fwd(_p(color), _p(self.rast), _p(self.clip), _p(self.tri), _p(self.opp), B, H, W, 4, V, F, _p(self.rgba_aa),
                                   _p(self.aa_work), st), "vhap_antialias_fwd")
         _chk(L.vhap_photo_fwd(_p(self.rgba_aa), _p(self.rgb), B, H, W, _p(acc[16:18]), PRE, st), "vhap_photo_fwd")
+        _chk(L.vhap_energy_finalize(_p(acc[0:6]), _p(acc[6:7]) if self.w_lmk else 0, _p(acc[7:9]), _p(acc[9:12]),
+                                    _p(acc[12:16]) if self.want_reg else 0, self.w_lmk, self.w_reg, B, H, W, _p(self.log), st),
+             "vhap_energy_finalize")
+
+    def _forward_deferred(self, tex_ready):
+        """binning || vertex normals -> rasterise + interpolate + texture + shade + composite in ONE kernel -> disturbance -> antialias ->
+        photometric sum"""
+        L, tr = self.L, self.tr
+        B, H, W, V, F, T = self.B, self.H, self.W, self.V, self.F, self.T
+        st = _stream()
+        acc = self.accF
+        cur = torch.cuda.current_stream()
+
+        def raster(flags):
+            return L.vhap_raster_shade_fwd(_p(self.clip), _p(self.tri), _p(self.vn), _p(self.uv), _p(self.tri_uv), _p(self.albedo_tex),
+                                           _p(self.mips), T, T, _p(tr.lights), _p(self.sh_const), _p(self.rgb) if self.bg_col is None else 0,
+                                           ctypes.cast(self.bg_col, ctypes.c_void_p) if self.bg_col is not None else 0,
+                                           _p(self.fid2cid) if self.disturb_on else 0, self.fid2cid.numel() if self.disturb_on else 0,
+                                           B, V, self.uv.shape[0], F, H, W, _p(self.rast), _p(self.rgba), _p(self.cid) if self.disturb_on else 0,
+                                           _p(acc[12:16]) if self.want_reg else 0, _p(self.ws), self.ws_bytes, self.ws_cap, flags, st)
+        _hook("raster_interp_fwd", "begin")
+        split = self.overlap and self.bin_split
+        if split:                                                 # vertex normals next to the binning (the raster kernel needs both)
+            self.side2.wait_stream(cur)
+            with torch.cuda.stream(self.side2):
+                _chk(L.vhap_vnormal_fwd(_p(self.verts), _p(self.csr.tri), _p(self.csr.ptr), _p(self.csr.idx), B, V, _p(self.vn), _stream()),
+                     "vhap_vnormal_fwd")
+            _chk(raster(1 | 2), "vhap_raster_shade_fwd")          # VHAP_RASTER_WS_CLEAN | VHAP_RASTER_BIN_ONLY
+            cur.wait_stream(self.side2)
+        else:
+            _chk(L.vhap_vnormal_fwd(_p(self.verts), _p(self.csr.tri), _p(self.csr.ptr), _p(self.csr.idx), B, V, _p(self.vn), st), "vhap_vnormal_fwd")
+        if tex_ready is not None:
+            cur.wait_event(tex_ready)
+        else:
+            self._join()
+        _chk(raster((1 | 4) if split else 1), "vhap_raster_shade_fwd")   # ... | VHAP_RASTER_PREBINNED
+        _hook("raster_interp_fwd", "end")
+        color = self.rgba
+        if self.disturb_on:
+            _chk(L.vhap_disturb_fwd_rng_cid(_p(self.rgba), _p(self.cid), self.ncl, float(self.rate_fg or 0.0), float(self.rate_bg or 0.0),
+                                            _p(self.rng), B, H, W, _p(self.dist_ws), _p(self.rgba_d), _p(self.keep), st),
+                 "vhap_disturb_fwd_rng_cid")
+            color = self.rgba_d
+        self.aa_in = color
+        _chk(L.vhap_antialias_fwd(_p(color), _p(self.rast), _p(self.clip), _p(self.tri), _p(self.opp), B, H, W, 4, V, F, _p(self.rgba_aa),
+                                  _p(self.aa_work), st), "vhap_antialias_fwd")
+        _chk(L.vhap_photo_fwd(_p(self.rgba_aa), _p(self.rgb), B, H, W, _p(acc[16:18]), PRE, st), "vhap_photo_fwd")
+        self._join()
         _chk(L.vhap_energy_finalize(_p(acc[0:6]), _p(acc[6:7]) if self.w_lmk else 0, _p(acc[7:9]), _p(acc[9:12]),
                                     _p(acc[12:16]) if self.want_reg else 0, self.w_lmk, self.w_reg, B, H, W, _p(self.log), st),
              "vhap_energy_finalize")
@@ -367,6 +433,15 @@ class NativeStep:
                                   _p(self.vert_mask), B, H, W, 4, V, F, _p(self.d_color), _p(g["d_clip"]),
                                   _lib.CALL_AA_PASSTHROUGH_DONE, st), "vhap_antialias_bwd")   # d_color already holds the pass-through copy of d_rgba_aa
         # (the backward of the disturbance -- d_rgba = d_color * keep -- is folded into the shading backward)
+        if self.deferred:
+            # shading + texture-coordinate backward in one pass, from re-computed attributes (nothing of the forward's G-buffer is re-read)
+            _chk(L.vhap_deferred_shade_bwd(_p(self.clip), _p(self.tri), _p(self.vn), _p(self.uv), _p(self.tri_uv), _p(self.albedo_tex), _p(self.mips),
+                                           T, T, _p(tr.lights), _p(self.sh_const), _p(self.rast), _p(self.d_color),
+                                           _p(self.keep) if self.disturb_on else 0, _p(self.c_reg) if self.want_reg else 0,
+                                           _p(acc[12:16]) if self.want_reg else 0, B, V, self.uv.shape[0], F, H, W, _p(self.texc), _p(self.texd),
+                                           _p(self.d_albedo), _p(self.d_normal), _p(self.d_texc), _p(self.d_texd), _p(g["lights"]), st),
+                 "vhap_deferred_shade_bwd")
+            return
         _chk(L.vhap_shade_bwd(_p(self.normal), _p(self.albedo_px), _p(self.rast), _p(tr.lights), _p(self.sh_const), _p(self.d_color),
                               _p(self.keep) if self.disturb_on else 0, _p(self.c_reg) if self.want_reg else 0,
                               _p(acc[12:16]) if self.want_reg else 0, B, H, W, _p(self.d_albedo), _p(self.d_normal), _p(g["lights"]), st),
@@ -375,6 +450,8 @@ class NativeStep:
     def _bwd_uv(self):
         """gradient w.r.t. the texture coordinates and their screen-space derivatives (input of the G-buffer backward)"""
         L, B, H, W, T = self.L, self.B, self.H, self.W, self.T
+        if self.deferred:
+            return                                                # produced by vhap_deferred_shade_bwd already
         _chk(L.vhap_texture_bwd(_p(self.albedo_tex), _p(self.mips), 1, T, T, 3, _p(self.texc), _p(self.texd), _p(self.d_albedo), B, H, W,
                                 0, 0, _p(self.d_texc), _p(self.d_texd), _stream()), "vhap_texture_bwd")
 
