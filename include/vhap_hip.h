@@ -112,19 +112,26 @@ int vhap_raster_shade_fwd(const float* pos, const int32_t* tri, const float* vno
                           vhap_stream_t stream);
 /* Backward of the shading part of vhap_raster_shade_fwd (everything between the interpolated attributes and rgba): per covered pixel the
  * normal / uv / uv derivatives are re-computed from (rast, geometry) with the forward's arithmetic, the texture is re-sampled, and the
- * upstream gradient d_rgba [B,H,W,4] (x keep [B,H,W] if given = the colour-disturbance backward) is chained through rgb = albedo * diffuse
- * and the SH shading.  Outputs, all [B,H,W,*] and OVERWRITTEN (zeros on background pixels):
+ * upstream gradient is chained through rgb = albedo * diffuse and the SH shading.  The upstream gradient is either the image
+ * d_rgba [B,H,W,4], or (d_rgba == NULL) the photometric gradient computed on the fly, -sign(gt - pred) * d_sum[0] (tracker.py:430-439;
+ * pred_rgba [B,H,W,4] renderer space, gt_nchw [B,3,H,W] image space, d_sum device scalar: what vhap_photo_bwd would have written);
+ * in both cases x keep [B,H,W] if given (= the colour-disturbance backward).
+ * Outputs, all [B,H,W,*] and OVERWRITTEN (d_albedo: zeros on background pixels; the others are written on covered pixels only):
  *   texc [..,2], texd [..,4], d_albedo [..,3]  -> the texture-gradient accumulation (vhap_texture_grad_binned / vhap_texture_bwd)
  *   d_normal [..,3], d_texc [..,2], d_texd [..,4] -> vhap_gbuffer_bwd
- *   d_lights [9,3] ACCUMULATED (photometric part + the diffuse regulariser: d_reg device scalar and stats as in vhap_shade_bwd, may be NULL)
- * Replaces vhap_shade_bwd + the d_uv / d_uv_da part of vhap_texture_bwd (and the re-reading of five G-buffer images). */
+ *   d_lights [9,3] ACCUMULATED (photometric part + the diffuse regulariser: d_reg device scalar and stats as in vhap_shade_bwd, may be NULL);
+ *   work: vhap_deferred_shade_bwd_work_floats(B,H,W) floats (per-workgroup partial sums of d_lights; required when d_lights != NULL)
+ * Replaces vhap_photo_bwd (optionally) + vhap_shade_bwd + the d_uv / d_uv_da part of vhap_texture_bwd (and the re-reading of five
+ * G-buffer images). */
+size_t vhap_deferred_shade_bwd_work_floats(int B, int H, int W);
 int vhap_deferred_shade_bwd(const float* pos, const int32_t* tri, const float* vnormal, const float* uv,
                             const int32_t* tri_uv, const float* tex, const float* mips, int Ht, int Wt,
                             const float* lights, const float* sh_const, const float* rast,
-                            const float* d_rgba, const float* keep, const float* d_reg, const float* stats,
+                            const float* d_rgba, const float* pred_rgba, const float* gt_nchw,
+                            const float* d_sum, const float* keep, const float* d_reg, const float* stats,
                             int B, int V, int VT, int F, int H, int W, float* texc, float* texd,
                             float* d_albedo, float* d_normal, float* d_texc, float* d_texd,
-                            float* d_lights, vhap_stream_t stream);
+                            float* d_lights, float* work, size_t work_floats, vhap_stream_t stream);
 
 /* Triangle-parallel backward of the fused G-buffer pass (vhap_raster_interp_fwd): chains the gradients of
  * normal [B,H,W,3], texc [B,H,W,2], texd [B,H,W,4] (and, optionally, direct gradients of rast / rast_db) into

@@ -187,6 +187,8 @@ class NativeStep:
             self.d_albedo, self.d_normal, self.d_texc, self.d_texd = E(B, H, W, 3), E(B, H, W, 3), E(B, H, W, 2), E(B, H, W, 4)
             self.texbin_work = torch.empty(self.L.vhap_texture_grad_binned_work_bytes(B, H, W), dtype=torch.uint8, device=dev)
             self.vn_scratch = E(B, V, 3)
+            if self.deferred:
+                self.def_work = E(self.L.vhap_deferred_shade_bwd_work_floats(B, H, W))
         self.g_posed, self.g_shaped = E(B, V, 3), E(B, V, 3)
         self.d_mvp, self.d_K, self.d_sum = E(B, 16), E(B, 4), E(1)
         self.ones = torch.ones(8, **f32)
@@ -256,6 +258,16 @@ class NativeStep:
         acc = self.accF
         acc.zero_()                                                   # ONE launch clears every forward accumulator
         so = tr.static_offset
+        tex_ready = None
+        early_tex = self.photometric and self.deferred and self.overlap
+        if early_tex:
+            # deferred shading: the rasteriser itself samples the texture, so the texture assembly + pyramid (~100 us, bandwidth-bound) heads
+            # the critical path together with the geometry chain: start it at once on the side branch
+            self._fork()
+            with self._branch():
+                self._tex_forward()
+                tex_ready = torch.cuda.Event()
+                tex_ready.record()
         # the camera first: two tiny launches that would take 3-5x as long next to the texture branch below
         self._camera_forward()
         _chk(L.vhap_frame_prep_fwd(_p(self.ts), _p(tr.shape), _p(tr.expr), _p(tr.rotation), _p(tr.translation), _p(tr.neck_pose),
@@ -282,12 +294,9 @@ class NativeStep:
         # fork here, not at the top: next to the bandwidth-bound texture assembly the two latency-bound kernels above take 3x as long,
         # and they head the critical path of the forward pass; the texture branch still finishes long before the rasteriser does
         self._fork()
-        tex_ready = None
         with self._branch():
-            self._tex_forward()
-            if self.overlap and self.deferred:                    # the deferred rasteriser samples the texture: it waits for THIS point only
-                tex_ready = torch.cuda.Event()
-                tex_ready.record()
+            if not early_tex:
+                self._tex_forward()
             if self.w_lmk:                                        # needs only verts + mvp: off the rasteriser's critical path
                 self._landmark_forward()
             self.arena.zero_()                                    # ONE launch clears every gradient accumulator of the backward
@@ -436,10 +445,11 @@ class NativeStep:
         if self.deferred:
             # shading + texture-coordinate backward in one pass, from re-computed attributes (nothing of the forward's G-buffer is re-read)
             _chk(L.vhap_deferred_shade_bwd(_p(self.clip), _p(self.tri), _p(self.vn), _p(self.uv), _p(self.tri_uv), _p(self.albedo_tex), _p(self.mips),
-                                           T, T, _p(tr.lights), _p(self.sh_const), _p(self.rast), _p(self.d_color),
+                                           T, T, _p(tr.lights), _p(self.sh_const), _p(self.rast), _p(self.d_color), 0, 0, 0,
                                            _p(self.keep) if self.disturb_on else 0, _p(self.c_reg) if self.want_reg else 0,
                                            _p(acc[12:16]) if self.want_reg else 0, B, V, self.uv.shape[0], F, H, W, _p(self.texc), _p(self.texd),
-                                           _p(self.d_albedo), _p(self.d_normal), _p(self.d_texc), _p(self.d_texd), _p(g["lights"]), st),
+                                           _p(self.d_albedo), _p(self.d_normal), _p(self.d_texc), _p(self.d_texd), _p(g["lights"]),
+                                           _p(self.def_work), self.def_work.numel(), st),
                  "vhap_deferred_shade_bwd")
             return
         _chk(L.vhap_shade_bwd(_p(self.normal), _p(self.albedo_px), _p(self.rast), _p(tr.lights), _p(self.sh_const), _p(self.d_color),
