@@ -48,6 +48,7 @@ const char* vhap_strerror(int code);
 #define VHAP_CALL_ACC_PREZEROED 1
 #define VHAP_CALL_AA_PASSTHROUGH_DONE 2
 #define VHAP_CALL_ADAM_KEEP_STEP 4
+#define VHAP_CALL_TEXBIN_COUNTED 8      /* (internal to vhap_texture_grad_binned_counted) */
 
 /* ---------------------------------------------------------------------------------------------
  * Rasterize: replaces dr.rasterize(glctx, pos, tri, resolution)  (render_nvdiffrast.py:254,257)
@@ -120,7 +121,10 @@ int vhap_raster_shade_fwd(const float* pos, const int32_t* tri, const float* vno
  *   texc [..,2], texd [..,4], d_albedo [..,3]  -> the texture-gradient accumulation (vhap_texture_grad_binned / vhap_texture_bwd)
  *   d_normal [..,3], d_texc [..,2], d_texd [..,4] -> vhap_gbuffer_bwd
  *   d_lights [9,3] ACCUMULATED (photometric part + the diffuse regulariser: d_reg device scalar and stats as in vhap_shade_bwd, may be NULL);
- *   work: vhap_deferred_shade_bwd_work_floats(B,H,W) floats (per-workgroup partial sums of d_lights; required when d_lights != NULL)
+ *   work: vhap_deferred_shade_bwd_work_floats(B,H,W) floats, ZERO on entry (partial sums of d_lights are accumulated there, the
+ *         call leaves them in it; required when d_lights != NULL)
+ *   texbin_work (may be NULL): the workspace of vhap_texture_grad_binned with its first 2 x 64 x 64 x 4 bytes ZERO on entry -- the uv-tile
+ *         histogram (the count pass of the binning) is filled in here, from registers; follow with vhap_texture_grad_binned_counted()
  * Replaces vhap_photo_bwd (optionally) + vhap_shade_bwd + the d_uv / d_uv_da part of vhap_texture_bwd (and the re-reading of five
  * G-buffer images). */
 size_t vhap_deferred_shade_bwd_work_floats(int B, int H, int W);
@@ -131,7 +135,8 @@ int vhap_deferred_shade_bwd(const float* pos, const int32_t* tri, const float* v
                             const float* d_sum, const float* keep, const float* d_reg, const float* stats,
                             int B, int V, int VT, int F, int H, int W, float* texc, float* texd,
                             float* d_albedo, float* d_normal, float* d_texc, float* d_texd,
-                            float* d_lights, float* work, size_t work_floats, vhap_stream_t stream);
+                            float* d_lights, float* work, size_t work_floats, void* texbin_work,
+                            vhap_stream_t stream);
 
 /* Triangle-parallel backward of the fused G-buffer pass (vhap_raster_interp_fwd): chains the gradients of
  * normal [B,H,W,3], texc [B,H,W,2], texd [B,H,W,4] (and, optionally, direct gradients of rast / rast_db) into
@@ -196,6 +201,10 @@ size_t vhap_texture_grad_binned_work_bytes(int B, int H, int W);
 int vhap_texture_grad_binned(int Ht, int Wt, int C, const float* uv, const float* uv_da, const float* d_out,
                              int B, int H, int W, float* d_tex, float* d_mips, void* work, size_t work_bytes,
                              vhap_stream_t stream);
+/* same, for a `work` whose tile histogram was already filled in by vhap_deferred_shade_bwd(texbin_work = work): skips the count pass */
+int vhap_texture_grad_binned_counted(int Ht, int Wt, int C, const float* uv, const float* uv_da,
+                                     const float* d_out, int B, int H, int W, float* d_tex, float* d_mips,
+                                     void* work, size_t work_bytes, vhap_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Antialias: replaces dr.antialias(color, rast, pos, tri)  (:465).

@@ -48,6 +48,23 @@ __device__ __forceinline__ float vhap_wave_sum(float v) {
     return v;
 }
 
+// Wave-wide sum on the VALU: two quad permutes + two row mirrors (DPP modifiers, full rate) sum each row of 16 lanes, four
+// v_readlane + three adds combine the rows; the result is wave-uniform.  __shfl_xor (ds_bpermute) goes through the LDS crossbar --
+// one per CU, ~10x the cost when a kernel reduces dozens of values per wave (deferred.hip: 27 per wave).
+template <int CTRL>
+__device__ __forceinline__ float vhap_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float vhap_wave_sum_dpp(float v) {
+    v += vhap_dpp<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += vhap_dpp<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += vhap_dpp<0x141>(v);     // row_half_mirror: quads 0 <-> 1, 2 <-> 3
+    v += vhap_dpp<0x140>(v);     // row_mirror: halves of the row
+    const int i = __float_as_int(v);
+    return (__int_as_float(__builtin_amdgcn_readlane(i, 0)) + __int_as_float(__builtin_amdgcn_readlane(i, 16))) +
+           (__int_as_float(__builtin_amdgcn_readlane(i, 32)) + __int_as_float(__builtin_amdgcn_readlane(i, 48)));
+}
+
 // Zero-fill / copy as ordinary kernel launches.  hipMemsetAsync / hipMemcpyAsync become memset / memcpy NODES under
 // stream capture, and on ROCm 7.2 those nodes were observed to run out of order with the neighbouring kernel nodes when
 // the graph is replayed on the null stream (stale accumulators, tools/debug_graph6.py) -- kernels nodes keep their order.

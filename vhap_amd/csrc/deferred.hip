@@ -16,6 +16,7 @@ namespace {
 
 constexpr int DB_T = 256;
 constexpr int DB_NW = DB_T / 64;
+constexpr int DB_SLOTS = 64;      // partial-sum rows of the lights gradient: workgroup w adds into row w % 64 (chains of ~256 atomics per address)
 
 struct DeferredParams {
     const float4* pos;       // [B,V,4]
@@ -44,12 +45,16 @@ struct DeferredParams {
     float* d_normal;
     float2* d_texc;
     float4* d_texd;
-    float* part;             // [gridDim.x][27] per-workgroup partial sums of d_lights
+    float* part;             // [DB_SLOTS][27] partial sums of d_lights (zero on entry)
+    unsigned* tb_counts;     // optional: the uv-tile histogram of vhap_texture_grad_binned (counts / max|g| bits per tile, zero on entry)
+    unsigned* tb_max;
+    int NT;
 };
 
 // One thread = one pixel, no loop: nothing is carried between pixels, so the register budget is set by the gather chain of ONE pixel
 // (rast -> triangle -> vertices / normals / uvs -> texture taps) and several waves per SIMD overlap those round trips.  The [9,3] lights
-// gradient is reduced per wave and per workgroup into `part`; a second tiny launch sums the partials (no same-address atomic chains).
+// gradient is reduced per wave (DPP, on the VALU) and per workgroup, added into one of DB_SLOTS rows of `part` (short atomic chains), and a
+// second tiny launch sums the rows into d_lights.
 __global__ __launch_bounds__(DB_T) void deferred_shade_bwd_kernel(const DeferredParams P) {
     __shared__ float s_l[27], s_c[9];
     __shared__ float red[DB_NW][27];
@@ -92,6 +97,8 @@ __global__ __launch_bounds__(DB_T) void deferred_shade_bwd_kernel(const Deferred
         da[0] = 0.f; da[1] = 0.f; da[2] = 0.f;
     }
     const unsigned long long covm = __ballot(cov);
+    int tb_tile = -1;
+    float tb_g = 0.f;
     if (covm) {
         if (cov) {
             const unsigned b = pi / HW, rem = pi - b * HW;
@@ -123,6 +130,8 @@ __global__ __launch_bounds__(DB_T) void deferred_shade_bwd_kernel(const Deferred
             const float ga[3] = {g.x * d[0], g.y * d[1], g.z * d[2]};                     // d L / d albedo
             float* da = P.d_albedo + 3 * (size_t)pi;
             da[0] = ga[0]; da[1] = ga[1]; da[2] = ga[2];
+            tb_g = fmaxf(fabsf(ga[0]), fmaxf(fabsf(ga[1]), fabsf(ga[2])));
+            if (tb_g != 0.f) tb_tile = tile_of(make_float2(at.tu, at.tv), P.NT);      // same criterion and tile as texbin_pass_kernel
             float2 guv;
             float4 gda;
             float alb[3];
@@ -143,7 +152,25 @@ __global__ __launch_bounds__(DB_T) void deferred_shade_bwd_kernel(const Deferred
             }
         }
 #pragma unroll
-        for (int i = 0; i < 27; i++) gl[i] = vhap_wave_sum(gl[i]);
+        for (int i = 0; i < 27; i++) gl[i] = vhap_wave_sum_dpp(gl[i]);
+        if (P.tb_counts) {
+            // count pass of the uv-space binning, fused: a wave covers 64 consecutive pixels of a row, which sample one or two uv tiles --
+            // one pair of atomics per (wave, tile) instead of a separate pass over uv / d_albedo
+            unsigned long long todo = __ballot(tb_tile >= 0);
+            while (todo) {
+                const int leader = __builtin_ctzll(todo);
+                const int tl = __builtin_amdgcn_readlane(tb_tile, leader);
+                const unsigned long long same = __ballot(tb_tile == tl);
+                float m = tb_tile == tl ? tb_g : 0.f;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+                if (lane == leader) {
+                    atomicAdd(&P.tb_counts[tl], (unsigned)__popcll(same));
+                    atomicMax(&P.tb_max[tl], __float_as_uint(m));
+                }
+                todo &= ~same;
+            }
+        }
     }
     if (!P.part) return;
     if (reg_on) {
@@ -169,27 +196,21 @@ __global__ __launch_bounds__(DB_T) void deferred_shade_bwd_kernel(const Deferred
     if (threadIdx.x < 27) {
         float s = 0.f;
         for (int w = 0; w < DB_NW; w++) s += red[w][threadIdx.x];
-        P.part[(size_t)blockIdx.x * 27 + threadIdx.x] = s;
+        if (s != 0.f) atomicAdd(&P.part[(size_t)(blockIdx.x % DB_SLOTS) * 27 + threadIdx.x], s);
     }
 }
 
-// d_lights[i] += sum over workgroups of part[w][i]: one workgroup per entry (27), 256 threads striding over the partials
-__global__ __launch_bounds__(256) void deferred_lights_reduce_kernel(const float* __restrict__ part, int nblk, float* __restrict__ d_lights) {
-    __shared__ float red[4];
-    const int i = blockIdx.x;
-    float s = 0.f;
-    for (int w = threadIdx.x; w < nblk; w += 256) s += part[(size_t)w * 27 + i];
-    s = vhap_wave_sum(s);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) d_lights[i] += (red[0] + red[1]) + (red[2] + red[3]);
+// d_lights[i] += sum over the DB_SLOTS rows of part: one wave per entry
+__global__ __launch_bounds__(64) void deferred_lights_reduce_kernel(const float* __restrict__ part, float* __restrict__ d_lights) {
+    const float s = vhap_wave_sum_dpp(part[(size_t)threadIdx.x * 27 + blockIdx.x]);
+    if (threadIdx.x == 0) d_lights[blockIdx.x] += s;
 }
 
 }  // namespace
 
 extern "C" size_t vhap_deferred_shade_bwd_work_floats(int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return 0;
-    return (size_t)(((long long)B * H * W + DB_T - 1) / DB_T) * 27;
+    return (size_t)DB_SLOTS * 27;
 }
 
 extern "C" int vhap_deferred_shade_bwd(const float* pos, const int32_t* tri, const float* vnormal, const float* uv, const int32_t* tri_uv,
@@ -198,7 +219,7 @@ extern "C" int vhap_deferred_shade_bwd(const float* pos, const int32_t* tri, con
                                        const float* d_sum, const float* keep, const float* d_reg, const float* stats,
                                        int B, int V, int VT, int F, int H, int W, float* texc, float* texd, float* d_albedo,
                                        float* d_normal, float* d_texc, float* d_texd, float* d_lights, float* work, size_t work_floats,
-                                       vhap_stream_t stream) {
+                                       void* texbin_work, vhap_stream_t stream) {
     VHAP_ENTER();
     if (!pos || !tri || !vnormal || !uv || !tri_uv || !tex || !lights || !sh_const || !rast || !texc || !texd || !d_albedo ||
         !d_normal || !d_texc || !d_texd)
@@ -219,13 +240,19 @@ extern "C" int vhap_deferred_shade_bwd(const float* pos, const int32_t* tri, con
     P.texc = reinterpret_cast<float2*>(texc); P.texd = reinterpret_cast<float4*>(texd); P.d_albedo = d_albedo; P.d_normal = d_normal;
     P.d_texc = reinterpret_cast<float2*>(d_texc); P.d_texd = reinterpret_cast<float4*>(d_texd);
     P.part = d_lights ? work : nullptr;
+    if (texbin_work) {                          // layout of vhap_texture_grad_binned's workspace: counts, then max|g| bits
+        const TexBinWs l = texbin_layout(1);
+        P.tb_counts = reinterpret_cast<unsigned*>(static_cast<char*>(texbin_work) + l.counts);
+        P.tb_max = reinterpret_cast<unsigned*>(static_cast<char*>(texbin_work) + l.tilemax);
+        P.NT = texbin_nt(Ht, Wt);
+    }
     const long long npix = (long long)B * H * W;
     const int blocks = (int)((npix + DB_T - 1) / DB_T);
     hipStream_t st = vhap_stream(stream);
     deferred_shade_bwd_kernel<<<blocks, DB_T, 0, st>>>(P);
     VHAP_LAUNCH_CHECK();
     if (d_lights) {
-        deferred_lights_reduce_kernel<<<27, 256, 0, st>>>(work, blocks, d_lights);
+        deferred_lights_reduce_kernel<<<27, DB_SLOTS, 0, st>>>(work, d_lights);
         VHAP_LAUNCH_CHECK();
     }
     return VHAP_OK;

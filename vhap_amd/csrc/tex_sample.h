@@ -125,6 +125,36 @@ __device__ __forceinline__ void bilinear_bwd(const float* __restrict__ T, float*
 }
 
 
+// ---- uv-space binning of the texture gradient (texture.hip: vhap_texture_grad_binned): shared with deferred.hip, which fills the tile
+// histogram while it computes d_albedo ----
+constexpr int TG_MAX_NT = 64;       // at most 64 x 64 tiles: the per-workgroup histograms are 2 x 16 KiB of LDS
+inline int texbin_nt(int Ht, int Wt) {
+    int nt = 8;
+    const int m = Wt > Ht ? Wt : Ht;
+    while (nt < TG_MAX_NT && m / nt > 32) nt *= 2;
+    return nt;
+}
+__device__ __forceinline__ int tile_of(float2 c, int NT) {
+    const float uf = c.x - floorf(c.x), vf = c.y - floorf(c.y);
+    const int tx = min(NT - 1, (int)(uf * (float)NT)), ty = min(NT - 1, (int)(vf * (float)NT));
+    return ty * NT + tx;
+}
+struct TexBinWs {
+    size_t counts, tilemax, cursors, offsets, list, total;
+};
+TexBinWs texbin_layout(long long npix) {
+    TexBinWs l;
+    const size_t n = (size_t)TG_MAX_NT * TG_MAX_NT;
+    l.counts = 0;
+    l.tilemax = l.counts + n * 4;
+    l.cursors = l.tilemax + n * 4;
+    l.offsets = l.cursors + n * 4;
+    l.list = l.offsets + (n + 64) * 4;
+    l.total = l.list + (size_t)npix * 4;
+    return l;
+}
+
+
 // value of ONE trilinear sample (the body of texture_fwd_kernel): res[C]
 template <int C>
 __device__ __forceinline__ void tex_sample(const float* __restrict__ tex, const float* __restrict__ mips, const TexDesc& D, int tb,

@@ -451,7 +451,6 @@ __global__ __launch_bounds__(TT * TT) void texture_bwd_tiled_kernel(const float*
 // straight to global memory, so memory safety does not depend on the argument.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int TG_PPT = 16;          // pixels per lane in the count / scatter passes (4096 pixels per workgroup)
-constexpr int TG_MAX_NT = 64;       // at most 64 x 64 tiles: the per-workgroup histograms are 2 x 16 KiB of LDS
 struct TileGeo {
     int NT, cells;                                  // tiles per axis; LDS cells per tile over all levels
     int nx[MAX_LEVELS + 1], ny[MAX_LEVELS + 1], off[MAX_LEVELS + 1];
@@ -459,9 +458,7 @@ struct TileGeo {
 
 TileGeo make_tile_geo(const TexDesc& D) {
     TileGeo G;
-    int nt = 8;
-    const int m = D.W > D.H ? D.W : D.H;
-    while (nt < TG_MAX_NT && m / nt > 32) nt *= 2;
+    const int nt = texbin_nt(D.H, D.W);
     G.NT = nt;
     int o = 0;
     for (int l = 0; l <= D.L; l++) {
@@ -475,11 +472,6 @@ TileGeo make_tile_geo(const TexDesc& D) {
     return G;
 }
 
-__device__ __forceinline__ int tile_of(float2 c, int NT) {
-    const float uf = c.x - floorf(c.x), vf = c.y - floorf(c.y);
-    const int tx = min(NT - 1, (int)(uf * (float)NT)), ty = min(NT - 1, (int)(vf * (float)NT));
-    return ty * NT + tx;
-}
 __device__ __forceinline__ int tile_lo(int t, int NT, int w) { return (int)floorf(((float)t / (float)NT) * (float)w - 0.5f); }
 
 template <int C, bool SCATTER>
@@ -651,21 +643,6 @@ __global__ __launch_bounds__(256) void texgrad_tile_kernel(const TexDesc D, cons
     }
 }
 
-struct TexBinWs {
-    size_t counts, tilemax, cursors, offsets, list, total;
-};
-TexBinWs texbin_layout(long long npix) {
-    TexBinWs l;
-    const size_t n = (size_t)TG_MAX_NT * TG_MAX_NT;
-    l.counts = 0;
-    l.tilemax = l.counts + n * 4;
-    l.cursors = l.tilemax + n * 4;
-    l.offsets = l.cursors + n * 4;
-    l.list = l.offsets + (n + 64) * 4;
-    l.total = l.list + (size_t)npix * 4;
-    return l;
-}
-
 template <typename F>
 int dispatch_C(int C, F&& f) {
     switch (C) {
@@ -810,8 +787,8 @@ extern "C" size_t vhap_texture_grad_binned_work_bytes(int B, int H, int W) {
     return texbin_layout((long long)B * H * W).total;
 }
 
-extern "C" int vhap_texture_grad_binned(int Ht, int Wt, int C, const float* uv, const float* uv_da, const float* d_out, int B, int H, int W,
-                                        float* d_tex, float* d_mips, void* work, size_t work_bytes, vhap_stream_t stream) {
+static int texture_grad_binned_impl(int Ht, int Wt, int C, const float* uv, const float* uv_da, const float* d_out, int B, int H, int W,
+                                    float* d_tex, float* d_mips, void* work, size_t work_bytes, int call_flags, vhap_stream_t stream) {
     VHAP_ENTER();
     if (!uv || !d_out || !d_tex || !work) return VHAP_E_NULLPTR;
     if (int e = check_tex(1, Ht, Wt, C)) return e;
@@ -833,15 +810,20 @@ extern "C" int vhap_texture_grad_binned(int Ht, int Wt, int C, const float* uv, 
     unsigned* list = reinterpret_cast<unsigned*>(w + l.list);
     const int nt2 = G.NT * G.NT;
     hipStream_t st = vhap_stream(stream);
-    vhap_zero_async(w + l.counts, (size_t)2 * TG_MAX_NT * TG_MAX_NT * 4, st);      // counts + tilemax
-    VHAP_LAUNCH_CHECK();
+    const bool counted = (call_flags & VHAP_CALL_TEXBIN_COUNTED) != 0;     // counts / tilemax already filled in by vhap_deferred_shade_bwd
+    if (!counted) {
+        vhap_zero_async(w + l.counts, (size_t)2 * TG_MAX_NT * TG_MAX_NT * 4, st);      // counts + tilemax
+        VHAP_LAUNCH_CHECK();
+    }
     const int nwg = vhap_cdiv(npix, 256 * TG_PPT);
     const size_t hist = (size_t)2 * nt2 * sizeof(unsigned);
     return dispatch_C(C, [&](auto c) {
         constexpr int CC = decltype(c)::value;
         const float2* uv2 = reinterpret_cast<const float2*>(uv);
-        texbin_pass_kernel<CC, false><<<nwg, 256, hist, st>>>(uv2, d_out, npix, G.NT, counts, tilemax, nullptr, nullptr, nullptr);
-        VHAP_LAUNCH_CHECK();
+        if (!counted) {
+            texbin_pass_kernel<CC, false><<<nwg, 256, hist, st>>>(uv2, d_out, npix, G.NT, counts, tilemax, nullptr, nullptr, nullptr);
+            VHAP_LAUNCH_CHECK();
+        }
         texbin_scan_kernel<<<1, 1024, 0, st>>>(counts, nt2, offsets, cursors);
         VHAP_LAUNCH_CHECK();
         texbin_pass_kernel<CC, true><<<nwg, 256, hist, st>>>(uv2, d_out, npix, G.NT, nullptr, nullptr, offsets, cursors, list);
@@ -853,4 +835,14 @@ extern "C" int vhap_texture_grad_binned(int Ht, int Wt, int C, const float* uv, 
         VHAP_LAUNCH_CHECK();
         return (int)VHAP_OK;
     });
+}
+
+extern "C" int vhap_texture_grad_binned(int Ht, int Wt, int C, const float* uv, const float* uv_da, const float* d_out, int B, int H, int W,
+                                        float* d_tex, float* d_mips, void* work, size_t work_bytes, vhap_stream_t stream) {
+    return texture_grad_binned_impl(Ht, Wt, C, uv, uv_da, d_out, B, H, W, d_tex, d_mips, work, work_bytes, 0, stream);
+}
+
+extern "C" int vhap_texture_grad_binned_counted(int Ht, int Wt, int C, const float* uv, const float* uv_da, const float* d_out, int B, int H,
+                                                int W, float* d_tex, float* d_mips, void* work, size_t work_bytes, vhap_stream_t stream) {
+    return texture_grad_binned_impl(Ht, Wt, C, uv, uv_da, d_out, B, H, W, d_tex, d_mips, work, work_bytes, VHAP_CALL_TEXBIN_COUNTED, stream);
 }

@@ -132,6 +132,7 @@ class NativeStep:
             self.albedo_tex, self.mips = E(0), E(0)
         # deferred shading (default): the rasteriser samples the texture and shades in registers; normal / rast_db / albedo images do not exist
         self.deferred = self.photometric and os.environ.get("VHAP_DEFERRED", "1") != "0"
+        self.tb_fused = False
         if self.photometric:
             self.clip, self.vn = E(B, V, 4), E(B, V, 3)
             self.rast, self.texc, self.texd = E(B, H, W, 4), E(B, H, W, 2), E(B, H, W, 4)
@@ -162,6 +163,8 @@ class NativeStep:
         extra = {"d_verts": B * V * 3, "d_A": B * J * 12, "d_t": B * 3, "d_coef": Bp * fb.Kp}
         if self.photometric:
             extra.update({"d_clip": B * V * 4, "d_vn": B * V * 3, "d_tex": self.albedo_tex.numel() + self.mips.numel()})
+            if self.deferred:
+                extra["def_work"] = int(L.vhap_deferred_shade_bwd_work_floats(B, H, W))    # zero on entry: lives in the arena
         al = lambda n: (n + 63) // 64 * 64
         total = sum(al(n) for n in sizes.values()) + sum(al(n) for n in extra.values())
         self.arena = torch.zeros(total, **f32)
@@ -185,10 +188,13 @@ class NativeStep:
         if self.photometric:
             self.d_rgba_aa, self.d_color, self.d_rgba = E(B, H, W, 4), E(B, H, W, 4), E(B, H, W, 4)
             self.d_albedo, self.d_normal, self.d_texc, self.d_texd = E(B, H, W, 3), E(B, H, W, 3), E(B, H, W, 2), E(B, H, W, 4)
-            self.texbin_work = torch.empty(self.L.vhap_texture_grad_binned_work_bytes(B, H, W), dtype=torch.uint8, device=dev)
+            self.texbin_work = torch.zeros(self.L.vhap_texture_grad_binned_work_bytes(B, H, W), dtype=torch.uint8, device=dev)
+            # the uv-tile histogram (count pass of the binned texture gradient) is filled in by the deferred backward itself
+            self.tb_fused = self.deferred and self.tex_bwd_on and NV.use_binned_texgrad() and T <= 2048
+            self.tb_head = self.texbin_work[:2 * 64 * 64 * 4]
             self.vn_scratch = E(B, V, 3)
             if self.deferred:
-                self.def_work = E(self.L.vhap_deferred_shade_bwd_work_floats(B, H, W))
+                self.def_work = self.g["def_work"]
         self.g_posed, self.g_shaped = E(B, V, 3), E(B, V, 3)
         self.d_mvp, self.d_K, self.d_sum = E(B, 16), E(B, 4), E(1)
         self.ones = torch.ones(8, **f32)
@@ -301,6 +307,8 @@ class NativeStep:
                 self._landmark_forward()
             self.arena.zero_()                                    # ONE launch clears every gradient accumulator of the backward
             self._arena_clean = True
+            if self.tb_fused:
+                self.tb_head.zero_()                              # tile histogram of the texture-gradient binning (filled by the backward)
         if self.deferred:
             return self._forward_deferred(tex_ready)
         _chk(L.vhap_vnormal_fwd(_p(self.verts), _p(self.csr.tri), _p(self.csr.ptr), _p(self.csr.idx), B, V, _p(self.vn), st), "vhap_vnormal_fwd")
@@ -387,7 +395,10 @@ class NativeStep:
             return
         n0 = self.albedo_tex.numel()
         d_tex, d_mips = g["d_tex"][:n0], g["d_tex"][n0:]
-        if not (NV.use_binned_texgrad() and NV.texture_grad_binned(T, 3, self.texc, self.texd, self.d_albedo, d_tex, d_mips, self.texbin_work)):
+        if self.tb_fused:
+            _chk(L.vhap_texture_grad_binned_counted(T, T, 3, _p(self.texc), _p(self.texd), _p(self.d_albedo), B, H, W, _p(d_tex), _p(d_mips),
+                                                    _p(self.texbin_work), self.texbin_work.numel(), st), "vhap_texture_grad_binned_counted")
+        elif not (NV.use_binned_texgrad() and NV.texture_grad_binned(T, 3, self.texc, self.texd, self.d_albedo, d_tex, d_mips, self.texbin_work)):
             _chk(L.vhap_texture_bwd(_p(self.albedo_tex), _p(self.mips), 1, T, T, 3, _p(self.texc), _p(self.texd), _p(self.d_albedo), B, H, W,
                                     _p(d_tex), _p(d_mips), 0, 0, st), "vhap_texture_bwd")
         if not self.split_tex:
@@ -449,7 +460,7 @@ class NativeStep:
                                            _p(self.keep) if self.disturb_on else 0, _p(self.c_reg) if self.want_reg else 0,
                                            _p(acc[12:16]) if self.want_reg else 0, B, V, self.uv.shape[0], F, H, W, _p(self.texc), _p(self.texd),
                                            _p(self.d_albedo), _p(self.d_normal), _p(self.d_texc), _p(self.d_texd), _p(g["lights"]),
-                                           _p(self.def_work), self.def_work.numel(), st),
+                                           _p(self.def_work), self.def_work.numel(), _p(self.texbin_work) if self.tb_fused else 0, st),
                  "vhap_deferred_shade_bwd")
             return
         _chk(L.vhap_shade_bwd(_p(self.normal), _p(self.albedo_px), _p(self.rast), _p(tr.lights), _p(self.sh_const), _p(self.d_color),
@@ -510,6 +521,8 @@ class NativeStep:
         if part in ("all", "texture", "pixel"):
             if not getattr(self, "_arena_clean", False):              # (normally done on the forward's side branch already)
                 self.arena.zero_()
+                if self.tb_fused:
+                    self.tb_head.zero_()
             self._arena_clean = False
         if not self.photometric:
             # landmark-only stage: E = landmark + regularisers; one short serial chain (any `part` but the first of a sharded split is empty)
