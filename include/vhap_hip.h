@@ -138,6 +138,20 @@ int vhap_deferred_shade_bwd(const float* pos, const int32_t* tri, const float* v
                             float* d_lights, float* work, size_t work_floats, void* texbin_work,
                             vhap_stream_t stream);
 
+/* vhap_deferred_shade_bwd FUSED with vhap_gbuffer_bwd: the gradients w.r.t. the interpolated normal / uv / uv derivatives never leave
+ * registers -- they go straight through the barycentric chain into d_pos [B,V,4] and d_vnormal [B,V,3] (both ACCUMULATED, per-tile LDS
+ * vertex tables as in vhap_gbuffer_bwd); uv_nograd_faces as there.  Same arguments otherwise; still writes texc / texd / d_albedo for
+ * the texture-gradient accumulation. */
+int vhap_deferred_gbuffer_bwd(const float* pos, const int32_t* tri, const float* vnormal, const float* uv,
+                              const int32_t* tri_uv, const float* tex, const float* mips, int Ht, int Wt,
+                              const float* lights, const float* sh_const, const float* rast,
+                              const float* d_rgba, const float* pred_rgba, const float* gt_nchw,
+                              const float* d_sum, const float* keep, const float* d_reg, const float* stats,
+                              const uint8_t* uv_nograd_faces, int B, int V, int VT, int F, int H, int W,
+                              float* texc, float* texd, float* d_albedo, float* d_pos, float* d_vnormal,
+                              float* d_lights, float* work, size_t work_floats, void* texbin_work,
+                              vhap_stream_t stream);
+
 /* Triangle-parallel backward of the fused G-buffer pass (vhap_raster_interp_fwd): chains the gradients of
  * normal [B,H,W,3], texc [B,H,W,2], texd [B,H,W,4] (and, optionally, direct gradients of rast / rast_db) into
  * d_pos [B,V,4] and d_vnormal [B,V,3] (both ACCUMULATED, caller zero-fills) with one set of atomics per

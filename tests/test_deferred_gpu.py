@@ -128,20 +128,23 @@ def test_deferred_step_matches_separate_pass_step(flame_model, monkeypatch):
     B, H, W, T = 4, 160, 128, 256
     stage = "rgb_global_tracking"
     out = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("VHAP_DEFERRED", mode)
+    for mode in ("0", "1", "2"):                # separate passes; deferred shading with the stand-alone backward; ... fused with the G-buffer backward
+        monkeypatch.setenv("VHAP_DEFERRED", "0" if mode == "0" else "1")
+        monkeypatch.setenv("VHAP_FUSED_BWD", "1" if mode == "2" else "0")
         tr = _tracker(flame_model, B, H, W, T, seed=7, disturb=False)
         tr.get_train_parameters(stage)
         ns = NativeStep(tr, tr.get_sample(np.arange(B), device_index=True), stage)
-        assert ns.deferred == (mode == "1")
+        assert ns.deferred == (mode != "0") and ns.fused_bwd == (mode == "2")
         for _ in range(2):
             ns.forward()
             ns.backward(1)
         torch.cuda.synchronize()
         out[mode] = ({k: float(v) for k, v in ns.log_dict().items()}, {k: v.detach().clone() for k, v in ns.g.items() if k in ns.params})
-    (l0, g0), (l1, g1) = out["0"], out["1"]
-    for k, v in l0.items():
-        assert abs(v - l1[k]) <= 2e-6 * max(abs(v), 1e-4), (k, v, l1[k])
-    for k, a in g0.items():
-        b = g1[k]
-        assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max()) + 1e-12, k
+    l0, g0 = out["0"]
+    for mode in ("1", "2"):
+        l1, g1 = out[mode]
+        for k, v in l0.items():
+            assert abs(v - l1[k]) <= 2e-6 * max(abs(v), 1e-4), (mode, k, v, l1[k])
+        for k, a in g0.items():
+            b = g1[k]
+            assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max()) + 1e-12, (mode, k)

@@ -52,8 +52,21 @@ __device__ __forceinline__ float vhap_wave_sum(float v) {
 // v_readlane + three adds combine the rows; the result is wave-uniform.  __shfl_xor (ds_bpermute) goes through the LDS crossbar --
 // one per CU, ~10x the cost when a kernel reduces dozens of values per wave (deferred.hip: 27 per wave).
 template <int CTRL>
-__device__ __forceinline__ float vhap_dpp(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+__device__ __forceinline__ float vhap_dpp(float v) {     // (every lane has a valid source for these controls: `old` = v costs no v_mov)
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+// N values at once, step by step: the N adds of a step are independent, so the DPP read-after-write hazard slots are filled with
+// useful work instead of s_nop.  Afterwards EVERY lane holds the sum over its row of 16 lanes.
+template <int N>
+__device__ __forceinline__ void vhap_row_sums_dpp(float (&v)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] += vhap_dpp<0xB1>(v[i]);      // quad_perm [1,0,3,2]
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] += vhap_dpp<0x4E>(v[i]);      // quad_perm [2,3,0,1]
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] += vhap_dpp<0x141>(v[i]);     // row_half_mirror
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] += vhap_dpp<0x140>(v[i]);     // row_mirror
 }
 __device__ __forceinline__ float vhap_wave_sum_dpp(float v) {
     v += vhap_dpp<0xB1>(v);      // quad_perm [1,0,3,2]

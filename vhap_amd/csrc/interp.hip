@@ -6,6 +6,7 @@
 // hardware fp32 atomics (global_atomic_add_f32, -munsafe-fp-atomics) -- float order is therefore
 // not deterministic, tests compare within 1e-4 relative.
 #include "common.h"
+#include "gbuffer_tile.h"
 
 namespace {
 
@@ -364,16 +365,9 @@ __global__ __launch_bounds__(256) void gbuffer_bwd_kernel(const float4* __restri
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Pixel-parallel variant with LDS aggregation.  A workgroup owns a 16x16 pixel tile of one frame; every covered pixel runs
-// the same chain as above for ITS triangle and adds the 18 vertex contributions into an LDS hash table keyed by vertex id
-// (LDS float atomics: a tile touches only a few dozen vertices).  The table is flushed with one global atomic per touched
-// vertex component, ~20x fewer than a plain per-pixel kernel, and no lane ever walks pixels it does not own -- the
-// triangle-parallel kernel above spends most of its time on bounding-box pixels won by other triangles.
+// Pixel-parallel variant with LDS aggregation (gbuffer_tile.h).  A workgroup owns a 16x16 pixel tile of one frame; no lane ever walks
+// pixels it does not own -- the triangle-parallel kernel above spends most of its time on bounding-box pixels won by other triangles.
 // ------------------------------------------------------------------------------------------------------------
-constexpr int GT = 16;          // tile edge
-constexpr int GSLOT = 256;      // hash slots (vertices) per tile: a tile touches a few dozen; 512 slots (28 KB of LDS) cost 20 % in occupancy
-constexpr unsigned GEMPTY = 0xffffffffu;
-
 __global__ __launch_bounds__(GT * GT) void gbuffer_bwd_tiled_kernel(const float4* __restrict__ pos, const int* __restrict__ tri,
                                                                     const float* __restrict__ vnormal, const float2* __restrict__ uv,
                                                                     const int* __restrict__ tri_uv, const float4* __restrict__ rast,
@@ -382,9 +376,7 @@ __global__ __launch_bounds__(GT * GT) void gbuffer_bwd_tiled_kernel(const float4
                                                                     const float4* __restrict__ d_db, const unsigned char* __restrict__ uv_nograd,
                                                                     int V, int F, int H, int W, float* __restrict__ d_pos,
                                                                     float* __restrict__ d_vnormal, int dbg) {
-    __shared__ unsigned keys[GSLOT];
-    __shared__ unsigned long long vals[GSLOT * 6];     // [0..2] = d_pos x, y, w ; [3..5] = d_vnormal: 64-bit fixed point (see texture.hip)
-    __shared__ unsigned smax[2];
+    __shared__ GbTile S;
     const int tid = threadIdx.x;
     const int px = blockIdx.x * GT + (tid & (GT - 1)), py = blockIdx.y * GT + (tid >> 4), b = blockIdx.z;
     const bool inside = px < W && py < H;
@@ -393,9 +385,7 @@ __global__ __launch_bounds__(GT * GT) void gbuffer_bwd_tiled_kernel(const float4
     const int t = (int)r.w - 1;
     const bool cov = inside && t >= 0 && t < F;
     if (__syncthreads_or(cov ? 1 : 0) == 0) return;       // background tile
-    for (int i = tid; i < GSLOT; i += GT * GT) keys[i] = GEMPTY;
-    for (int i = tid; i < GSLOT * 6; i += GT * GT) vals[i] = 0ull;
-    if (tid < 2) smax[tid] = 0u;
+    gb_tile_init(S);
     __syncthreads();
     float acc[18];
 #pragma unroll
@@ -408,8 +398,6 @@ __global__ __launch_bounds__(GT * GT) void gbuffer_bwd_tiled_kernel(const float4
             have = true;
             const float4* P = pos + (size_t)b * V;
             const float4 p0 = P[i0], p1 = P[i1], p2 = P[i2];
-            const float xs = 2.0f / (float)W, xo = 1.0f / (float)W - 1.0f;
-            const float ys = 2.0f / (float)H, yo = 1.0f / (float)H - 1.0f;
             const float b0 = r.x, b1 = r.y, b2 = (1.0f - b0) - b1;
             float g0 = 0.f, g1 = 0.f;
             float4 gd = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -440,108 +428,10 @@ __global__ __launch_bounds__(GT * GT) void gbuffer_bwd_tiled_kernel(const float4
                     gd.y += q.y * e0.x + q.w * e0.y; gd.w += q.y * e1.x + q.w * e1.y;
                 }
             }
-            const float X0 = p2.y * p1.w - p1.y * p2.w, Y0 = p1.x * p2.w - p2.x * p1.w;
-            const float X1 = p0.y * p2.w - p2.y * p0.w, Y1 = p2.x * p0.w - p0.x * p2.w;
-            const float X2 = p1.y * p0.w - p0.y * p1.w, Y2 = p0.x * p1.w - p1.x * p0.w;
-            const float Tx = X0 + X1 + X2, Ty = Y0 + Y1 + Y2;
-            const float fx = xs * (float)px + xo, fy = ys * (float)py + yo;
-            const float p0x = p0.x - fx * p0.w, p0y = p0.y - fy * p0.w;
-            const float p1x = p1.x - fx * p1.w, p1y = p1.y - fy * p1.w;
-            const float p2x = p2.x - fx * p2.w, p2y = p2.y - fy * p2.w;
-            const float a0 = p1x * p2y - p1y * p2x, a1 = p2x * p0y - p2y * p0x, a2 = p0x * p1y - p0y * p1x;
-            const float at = a0 + a1 + a2;
-            if (fabsf(at) > 0.0f) {
-                const float iw = 1.0f / at;
-                const float r0 = a0 * iw, r1 = a1 * iw;
-                float G0 = g0 + xs * iw * Tx * gd.x + ys * iw * Ty * gd.y;
-                float G1 = g1 + xs * iw * Tx * gd.z + ys * iw * Ty * gd.w;
-                if (!(r0 >= 0.0f && r0 <= 1.0f)) G0 = 0.0f;
-                if (!(r1 >= 0.0f && r1 <= 1.0f)) G1 = 0.0f;
-                const float giw = xs * (b0 * Tx - X0) * gd.x + ys * (b0 * Ty - Y0) * gd.y + xs * (b1 * Tx - X1) * gd.z +
-                                  ys * (b1 * Ty - Y1) * gd.w;
-                const float sg = G0 * r0 + G1 * r1;
-                const float gat = -iw * iw * giw;
-                const float ga0 = (G0 - sg) * iw + gat, ga1 = (G1 - sg) * iw + gat, ga2 = (-sg) * iw + gat;
-                const float gp0x = -p2y * ga1 + p1y * ga2, gp0y = p2x * ga1 - p1x * ga2;
-                const float gp1x = p2y * ga0 - p0y * ga2, gp1y = -p2x * ga0 + p0x * ga2;
-                const float gp2x = -p1y * ga0 + p0y * ga1, gp2y = p1x * ga0 - p0x * ga1;
-                acc[0] += gp0x; acc[1] += gp0y; acc[2] += -fx * gp0x - fy * gp0y;
-                acc[3] += gp1x; acc[4] += gp1y; acc[5] += -fx * gp1x - fy * gp1y;
-                acc[6] += gp2x; acc[7] += gp2y; acc[8] += -fx * gp2x - fy * gp2y;
-                const float cx = xs * iw, cy = ys * iw;
-                const float sxg = b0 * gd.x + b1 * gd.z, syg = b0 * gd.y + b1 * gd.w;
-                const float gX0 = cx * (sxg - gd.x), gX1 = cx * (sxg - gd.z), gX2 = cx * sxg;
-                const float gY0 = cy * (syg - gd.y), gY1 = cy * (syg - gd.w), gY2 = cy * syg;
-                acc[7] += p1.w * gX0; acc[5] += p2.y * gX0; acc[4] -= p2.w * gX0; acc[8] -= p1.y * gX0;
-                acc[1] += p2.w * gX1; acc[8] += p0.y * gX1; acc[7] -= p0.w * gX1; acc[2] -= p2.y * gX1;
-                acc[4] += p0.w * gX2; acc[2] += p1.y * gX2; acc[1] -= p1.w * gX2; acc[5] -= p0.y * gX2;
-                acc[3] += p2.w * gY0; acc[8] += p1.x * gY0; acc[6] -= p1.w * gY0; acc[5] -= p2.x * gY0;
-                acc[6] += p0.w * gY1; acc[2] += p2.x * gY1; acc[0] -= p2.w * gY1; acc[8] -= p0.x * gY1;
-                acc[0] += p1.w * gY2; acc[5] += p0.x * gY2; acc[3] -= p0.w * gY2; acc[2] -= p1.x * gY2;
-            }
+            gb_chain(p0, p1, p2, b0, b1, px, py, H, W, g0, g1, gd, acc);
         }
     }
-    // per-tile power-of-two scales (positions / normals) from the largest contribution
-    {
-        float mp = 0.f, mn = 0.f;
-#pragma unroll
-        for (int k = 0; k < 9; k++) { mp = fmaxf(mp, fabsf(acc[k])); mn = fmaxf(mn, fabsf(acc[9 + k])); }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { mp = fmaxf(mp, __shfl_xor(mp, o, 64)); mn = fmaxf(mn, __shfl_xor(mn, o, 64)); }
-        if ((tid & 63) == 0) { atomicMax(&smax[0], __float_as_uint(mp)); atomicMax(&smax[1], __float_as_uint(mn)); }
-    }
-    __syncthreads();
-    int exp_p = 0, exp_n = 0;
-    (void)frexpf(__uint_as_float(smax[0]), &exp_p);
-    (void)frexpf(__uint_as_float(smax[1]), &exp_n);
-    const int shp = min(max(40 - exp_p, -100), 100), shn = min(max(40 - exp_n, -100), 100);
-    const float sc_p = ldexpf(1.0f, shp), sc_n = ldexpf(1.0f, shn), isc_p = ldexpf(1.0f, -shp), isc_n = ldexpf(1.0f, -shn);
-    if (have && !(dbg & 256)) {
-        {
-            // three vertices -> LDS table (bounded probing; overflow goes straight to global memory)
-#pragma unroll
-            for (int vtx = 0; vtx < 3; vtx++) {
-                const int vi = vtx == 0 ? i0 : (vtx == 1 ? i1 : i2);
-                unsigned slot = ((unsigned)vi * 2654435761u) >> 24;     // 8 bits
-                bool done = false;
-#pragma unroll 1
-                for (int probe = 0; probe < 8 && !done; probe++) {
-                    const unsigned prev = atomicCAS(&keys[slot], GEMPTY, (unsigned)vi);
-                    if (prev == GEMPTY || prev == (unsigned)vi) {
-#pragma unroll
-                        for (int c = 0; c < 3; c++) {
-                            const float vp = acc[3 * vtx + c], vn = acc[9 + 3 * vtx + c];
-                            if (vp != 0.f) atomicAdd(&vals[slot * 6 + c], (unsigned long long)__float2ll_rn(vp * sc_p));
-                            if (vn != 0.f) atomicAdd(&vals[slot * 6 + 3 + c], (unsigned long long)__float2ll_rn(vn * sc_n));
-                        }
-                        done = true;
-                    } else {
-                        slot = (slot + 1) & (GSLOT - 1);
-                    }
-                }
-                if (!done) {
-#pragma unroll
-                    for (int c = 0; c < 3; c++) {
-                        const float vp = acc[3 * vtx + c], vn = acc[9 + 3 * vtx + c];
-                        if (d_pos && vp != 0.f) atomicAdd(&d_pos[((size_t)b * V + vi) * 4 + (c == 2 ? 3 : c)], vp);
-                        if (d_vnormal && vn != 0.f) atomicAdd(&d_vnormal[((size_t)b * V + vi) * 3 + c], vn);
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-    if (dbg & 128) return;
-    for (int sidx = tid; sidx < GSLOT; sidx += GT * GT) {
-        const unsigned vi = keys[sidx];
-        if (vi == GEMPTY) continue;
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const long long qp = (long long)vals[sidx * 6 + c], qn = (long long)vals[sidx * 6 + 3 + c];
-            if (d_pos && qp != 0) atomicAdd(&d_pos[((size_t)b * V + vi) * 4 + (c == 2 ? 3 : c)], (float)qp * isc_p);
-            if (d_vnormal && qn != 0) atomicAdd(&d_vnormal[((size_t)b * V + vi) * 3 + c], (float)qn * isc_n);
-        }
-    }
+    gb_tile_commit(S, acc, have, i0, i1, i2, b, V, d_pos, d_vnormal, dbg);
 }
 
 }  // namespace

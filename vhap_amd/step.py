@@ -133,6 +133,10 @@ class NativeStep:
         # deferred shading (default): the rasteriser samples the texture and shades in registers; normal / rast_db / albedo images do not exist
         self.deferred = self.photometric and os.environ.get("VHAP_DEFERRED", "1") != "0"
         self.tb_fused = False
+        # shading backward fused with the G-buffer backward (one gather chain per covered pixel, d_normal / d_uv / d_uv_da stay in registers)
+        # (measured on MI355X, tools/kbench.py: 265 us fused vs 129 + 125 us separately -- both kernels are bound by VALU issue, not by the
+        # gather latency a fusion would share -- so it is off by default)
+        self.fused_bwd = self.deferred and os.environ.get("VHAP_FUSED_BWD", "0") == "1"
         if self.photometric:
             self.clip, self.vn = E(B, V, 4), E(B, V, 3)
             self.rast, self.texc, self.texd = E(B, H, W, 4), E(B, H, W, 2), E(B, H, W, 4)
@@ -187,10 +191,13 @@ class NativeStep:
         # scratch that is overwritten
         if self.photometric:
             self.d_rgba_aa, self.d_color, self.d_rgba = E(B, H, W, 4), E(B, H, W, 4), E(B, H, W, 4)
-            self.d_albedo, self.d_normal, self.d_texc, self.d_texd = E(B, H, W, 3), E(B, H, W, 3), E(B, H, W, 2), E(B, H, W, 4)
+            self.d_albedo = E(B, H, W, 3)
+            if not self.fused_bwd:
+                self.d_normal, self.d_texc, self.d_texd = E(B, H, W, 3), E(B, H, W, 2), E(B, H, W, 4)
             self.texbin_work = torch.zeros(self.L.vhap_texture_grad_binned_work_bytes(B, H, W), dtype=torch.uint8, device=dev)
             # the uv-tile histogram (count pass of the binned texture gradient) is filled in by the deferred backward itself
-            self.tb_fused = self.deferred and self.tex_bwd_on and NV.use_binned_texgrad() and T <= 2048
+            self.tb_fused = self.deferred and self.tex_bwd_on and NV.use_binned_texgrad() and T <= 2048 and \
+                os.environ.get("VHAP_TB_FUSED", "0") == "1"       # (measured: +50 us on the pixel kernel for 25 us saved -- off)
             self.tb_head = self.texbin_work[:2 * 64 * 64 * 4]
             self.vn_scratch = E(B, V, 3)
             if self.deferred:
@@ -453,6 +460,15 @@ class NativeStep:
                                   _p(self.vert_mask), B, H, W, 4, V, F, _p(self.d_color), _p(g["d_clip"]),
                                   _lib.CALL_AA_PASSTHROUGH_DONE, st), "vhap_antialias_bwd")   # d_color already holds the pass-through copy of d_rgba_aa
         # (the backward of the disturbance -- d_rgba = d_color * keep -- is folded into the shading backward)
+        if self.fused_bwd:
+            _chk(L.vhap_deferred_gbuffer_bwd(_p(self.clip), _p(self.tri), _p(self.vn), _p(self.uv), _p(self.tri_uv), _p(self.albedo_tex), _p(self.mips),
+                                             T, T, _p(tr.lights), _p(self.sh_const), _p(self.rast), _p(self.d_color), 0, 0, 0,
+                                             _p(self.keep) if self.disturb_on else 0, _p(self.c_reg) if self.want_reg else 0,
+                                             _p(acc[12:16]) if self.want_reg else 0, _p(self.face_mask), B, V, self.uv.shape[0], F, H, W,
+                                             _p(self.texc), _p(self.texd), _p(self.d_albedo), _p(g["d_clip"]), _p(g["d_vn"]), _p(g["lights"]),
+                                             _p(self.def_work), self.def_work.numel(), _p(self.texbin_work) if self.tb_fused else 0, st),
+                 "vhap_deferred_gbuffer_bwd")
+            return
         if self.deferred:
             # shading + texture-coordinate backward in one pass, from re-computed attributes (nothing of the forward's G-buffer is re-read)
             _chk(L.vhap_deferred_shade_bwd(_p(self.clip), _p(self.tri), _p(self.vn), _p(self.uv), _p(self.tri_uv), _p(self.albedo_tex), _p(self.mips),
@@ -472,7 +488,7 @@ class NativeStep:
         """gradient w.r.t. the texture coordinates and their screen-space derivatives (input of the G-buffer backward)"""
         L, B, H, W, T = self.L, self.B, self.H, self.W, self.T
         if self.deferred:
-            return                                                # produced by vhap_deferred_shade_bwd already
+            return                                                # produced by vhap_deferred_shade_bwd already (or never materialised: fused_bwd)
         _chk(L.vhap_texture_bwd(_p(self.albedo_tex), _p(self.mips), 1, T, T, 3, _p(self.texc), _p(self.texd), _p(self.d_albedo), B, H, W,
                                 0, 0, _p(self.d_texc), _p(self.d_texd), _stream()), "vhap_texture_bwd")
 
@@ -501,9 +517,10 @@ class NativeStep:
         L, g = self.L, self.g
         B, H, W, V, F = self.B, self.H, self.W, self.V, self.F
         st = _stream()
-        _chk(L.vhap_gbuffer_bwd(_p(self.clip), _p(self.tri), _p(self.vn), _p(self.uv), _p(self.tri_uv), _p(self.rast), _p(self.d_normal),
-                                _p(self.d_texc), _p(self.d_texd), 0, 0, _p(self.face_mask), B, V, F, H, W, _p(g["d_clip"]), _p(g["d_vn"]), st),
-             "vhap_gbuffer_bwd")
+        if not self.fused_bwd:
+            _chk(L.vhap_gbuffer_bwd(_p(self.clip), _p(self.tri), _p(self.vn), _p(self.uv), _p(self.tri_uv), _p(self.rast), _p(self.d_normal),
+                                    _p(self.d_texc), _p(self.d_texd), 0, 0, _p(self.face_mask), B, V, F, H, W, _p(g["d_clip"]), _p(g["d_vn"]), st),
+                 "vhap_gbuffer_bwd")
         if early is not None:
             torch.cuda.current_stream().wait_event(early)
         _chk(L.vhap_vnormal_bwd(_p(self.verts), _p(self.csr.tri), _p(self.csr.ptr), _p(self.csr.idx), _p(g["d_vn"]), B, V, 1,
