@@ -115,7 +115,8 @@ int vhap_raster_shade_fwd(const float* pos, const int32_t* tri, const float* vno
  * normal / uv / uv derivatives are re-computed from (rast, geometry) with the forward's arithmetic, the texture is re-sampled, and the
  * upstream gradient is chained through rgb = albedo * diffuse and the SH shading.  The upstream gradient is either the image
  * d_rgba [B,H,W,4], or (d_rgba == NULL) the photometric gradient computed on the fly, -sign(gt - pred) * d_sum[0] (tracker.py:430-439;
- * pred_rgba [B,H,W,4] renderer space, gt_nchw [B,3,H,W] image space, d_sum device scalar: what vhap_photo_bwd would have written);
+ * pred_rgba [B,H,W,4] renderer space, gt_nchw [B,3,H,W] image space, d_sum device scalar: what vhap_photo_bwd would have written) plus
+ * d_delta [B,H,W,4] if given (the sparse colour part of vhap_antialias_photo_bwd);
  * in both cases x keep [B,H,W] if given (= the colour-disturbance backward).
  * Outputs, all [B,H,W,*] and OVERWRITTEN (d_albedo: zeros on background pixels; the others are written on covered pixels only):
  *   texc [..,2], texd [..,4], d_albedo [..,3]  -> the texture-gradient accumulation (vhap_texture_grad_binned / vhap_texture_bwd)
@@ -132,8 +133,8 @@ int vhap_deferred_shade_bwd(const float* pos, const int32_t* tri, const float* v
                             const int32_t* tri_uv, const float* tex, const float* mips, int Ht, int Wt,
                             const float* lights, const float* sh_const, const float* rast,
                             const float* d_rgba, const float* pred_rgba, const float* gt_nchw,
-                            const float* d_sum, const float* keep, const float* d_reg, const float* stats,
-                            int B, int V, int VT, int F, int H, int W, float* texc, float* texd,
+                            const float* d_sum, const float* d_delta, const float* keep, const float* d_reg,
+                            const float* stats, int B, int V, int VT, int F, int H, int W, float* texc, float* texd,
                             float* d_albedo, float* d_normal, float* d_texc, float* d_texd,
                             float* d_lights, float* work, size_t work_floats, void* texbin_work,
                             vhap_stream_t stream);
@@ -146,8 +147,8 @@ int vhap_deferred_gbuffer_bwd(const float* pos, const int32_t* tri, const float*
                               const int32_t* tri_uv, const float* tex, const float* mips, int Ht, int Wt,
                               const float* lights, const float* sh_const, const float* rast,
                               const float* d_rgba, const float* pred_rgba, const float* gt_nchw,
-                              const float* d_sum, const float* keep, const float* d_reg, const float* stats,
-                              const uint8_t* uv_nograd_faces, int B, int V, int VT, int F, int H, int W,
+                              const float* d_sum, const float* d_delta, const float* keep, const float* d_reg,
+                              const float* stats, const uint8_t* uv_nograd_faces, int B, int V, int VT, int F, int H, int W,
                               float* texc, float* texd, float* d_albedo, float* d_pos, float* d_vnormal,
                               float* d_lights, float* work, size_t work_floats, void* texbin_work,
                               vhap_stream_t stream);
@@ -240,6 +241,25 @@ int vhap_antialias_bwd(const float* color, const float* rast, const float* pos,
                        const int32_t* tri, const int32_t* opp, const float* d_out,
                        const int32_t* work, const uint8_t* pos_nograd_verts, int B, int H, int W,
                        int C, int V, int F, float* d_color, float* d_pos, int call_flags, vhap_stream_t stream);
+
+/* In-place variant for the photometric step (C = 4): `color` [B,H,W,4] is antialiased IN PLACE (no copy of the image: the deltas
+ * alpha (c1 - c0) are computed for all pairs first, from the original colours, then added); the pair records in `work`
+ * (vhap_antialias_inplace_work_ints ints, sized for the worst case, only the used part is touched) keep the original colours.
+ * vhap_antialias_photo_bwd: the backward for the photometric loss sum|gt - out| with upstream d_sum (tracker.py:430-439) -- the loss
+ * gradient -sign(gt - out) d_sum is evaluated on the fly at the pixels of the pair list (pred_rgba = the antialiased image, gt_nchw
+ * [B,3,H,W] image space), position gradients go to d_pos [B,V,4] (ACCUMULATED, pos_nograd_verts as above), and the colour part of the
+ * antialias backward BESIDES the pass-through is ADDED into d_delta [B,H,W,4], an image the caller keeps at zero: hand it to
+ * vhap_deferred_shade_bwd (d_delta) and restore the zeros afterwards with vhap_antialias_clear_delta (it visits the pair list only).
+ * Replaces vhap_photo_bwd + vhap_antialias_bwd and their three dense gradient images. */
+size_t vhap_antialias_inplace_work_ints(int B, int H, int W, int F);
+int vhap_antialias_inplace_fwd(float* color, const float* rast, const float* pos, const int32_t* tri,
+                               const int32_t* opp, int B, int H, int W, int V, int F, int32_t* work,
+                               vhap_stream_t stream);
+int vhap_antialias_photo_bwd(const float* pred_rgba, const float* gt_nchw, const float* d_sum,
+                             const float* rast, const float* pos, const int32_t* tri, const int32_t* opp,
+                             const int32_t* work, const uint8_t* pos_nograd_verts, int B, int H, int W, int V,
+                             int F, float* d_delta, float* d_pos, vhap_stream_t stream);
+int vhap_antialias_clear_delta(const int32_t* work, int B, int H, int W, float* d_delta, vhap_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Per-pixel shading / compositing and the photometric sum (vhap_amd/csrc/pixel.hip).

@@ -106,7 +106,7 @@ def test_deferred_kernels_match_the_separate_passes(flame_model, monkeypatch, B,
     assert L.vhap_shade_bwd(_p(ns.normal), _p(ns.albedo_px), _p(ns.rast), _p(tr.lights), _p(ns.sh_const), _p(ns.d_color), _p(ns.keep),
                             _p(ns.c_reg), _p(ns.accF[12:16]), B, H, W, _p(d_alb_ref), _p(d_n_ref), _p(ref_lights), _stream()) == 0
     assert L.vhap_deferred_shade_bwd(_p(ns.clip), _p(ns.tri), _p(ns.vn), _p(ns.uv), _p(ns.tri_uv), _p(ns.albedo_tex), _p(ns.mips), T, T,
-                                     _p(tr.lights), _p(ns.sh_const), _p(ns.rast), _p(ns.d_color), 0, 0, 0, _p(ns.keep), _p(ns.c_reg),
+                                     _p(tr.lights), _p(ns.sh_const), _p(ns.rast), _p(ns.d_color), 0, 0, 0, 0, _p(ns.keep), _p(ns.c_reg),
                                      _p(ns.accF[12:16]), B, V, ns.uv.shape[0], F, H, W, _p(texc), _p(texd), _p(d_alb), _p(d_n), _p(d_tc),
                                      _p(d_td), _p(d_lights), _p(work), work.numel(), 0, _stream()) == 0
     torch.cuda.synchronize()
@@ -128,20 +128,23 @@ def test_deferred_step_matches_separate_pass_step(flame_model, monkeypatch):
     B, H, W, T = 4, 160, 128, 256
     stage = "rgb_global_tracking"
     out = {}
-    for mode in ("0", "1", "2"):                # separate passes; deferred shading with the stand-alone backward; ... fused with the G-buffer backward
+    # separate passes; deferred shading with the stand-alone backward; ... fused with the G-buffer backward; ... with in-place antialiasing
+    # and the photometric gradient on the fly (the default)
+    for mode in ("0", "1", "2", "3"):
         monkeypatch.setenv("VHAP_DEFERRED", "0" if mode == "0" else "1")
         monkeypatch.setenv("VHAP_FUSED_BWD", "1" if mode == "2" else "0")
+        monkeypatch.setenv("VHAP_AA_INPLACE", "1" if mode == "3" else "0")
         tr = _tracker(flame_model, B, H, W, T, seed=7, disturb=False)
         tr.get_train_parameters(stage)
         ns = NativeStep(tr, tr.get_sample(np.arange(B), device_index=True), stage)
-        assert ns.deferred == (mode != "0") and ns.fused_bwd == (mode == "2")
+        assert ns.deferred == (mode != "0") and ns.fused_bwd == (mode == "2") and ns.aa_inplace == (mode == "3")
         for _ in range(2):
             ns.forward()
             ns.backward(1)
         torch.cuda.synchronize()
         out[mode] = ({k: float(v) for k, v in ns.log_dict().items()}, {k: v.detach().clone() for k, v in ns.g.items() if k in ns.params})
     l0, g0 = out["0"]
-    for mode in ("1", "2"):
+    for mode in ("1", "2", "3"):
         l1, g1 = out[mode]
         for k, v in l0.items():
             assert abs(v - l1[k]) <= 2e-6 * max(abs(v), 1e-4), (mode, k, v, l1[k])

@@ -53,7 +53,7 @@ def raster(flags):
 
 def deferred_bwd(tb):
     return L.vhap_deferred_shade_bwd(_p(ns.clip), _p(ns.tri), _p(ns.vn), _p(ns.uv), _p(ns.tri_uv), _p(ns.albedo_tex), _p(ns.mips), T, T,
-                                     _p(tr.lights), _p(ns.sh_const), _p(ns.rast), _p(ns.d_color), 0, 0, 0, _p(ns.keep) if ns.disturb_on else 0,
+                                     _p(tr.lights), _p(ns.sh_const), _p(ns.rast), *ns._upstream(), _p(ns.keep) if ns.disturb_on else 0,
                                      _p(ns.c_reg) if ns.want_reg else 0, _p(acc[12:16]) if ns.want_reg else 0, B, V, ns.uv.shape[0], F, H, W,
                                      _p(ns.texc), _p(ns.texd), _p(ns.d_albedo), _p(ns.d_normal), _p(ns.d_texc), _p(ns.d_texd), _p(g["lights"]),
                                      _p(ns.def_work), ns.def_work.numel(), _p(ns.texbin_work) if tb else 0, st())
@@ -61,7 +61,7 @@ def deferred_bwd(tb):
 
 def fused_bwd():
     return L.vhap_deferred_gbuffer_bwd(_p(ns.clip), _p(ns.tri), _p(ns.vn), _p(ns.uv), _p(ns.tri_uv), _p(ns.albedo_tex), _p(ns.mips), T, T,
-                                       _p(tr.lights), _p(ns.sh_const), _p(ns.rast), _p(ns.d_color), 0, 0, 0, _p(ns.keep) if ns.disturb_on else 0,
+                                       _p(tr.lights), _p(ns.sh_const), _p(ns.rast), *ns._upstream(), _p(ns.keep) if ns.disturb_on else 0,
                                        _p(ns.c_reg) if ns.want_reg else 0, _p(acc[12:16]) if ns.want_reg else 0, _p(ns.face_mask), B, V,
                                        ns.uv.shape[0], F, H, W, _p(ns.texc), _p(ns.texd), _p(ns.d_albedo), _p(g["d_clip"]), _p(g["d_vn"]),
                                        _p(g["lights"]), _p(ns.def_work), ns.def_work.numel(), 0, st())
@@ -76,12 +76,12 @@ calls = {
     "raster_shade whole": lambda: raster(1),
     "disturb": (lambda: L.vhap_disturb_fwd_rng_cid(_p(ns.rgba), _p(ns.cid), ns.ncl, float(ns.rate_fg or 0.0), float(ns.rate_bg or 0.0), _p(ns.rng), B, H, W,
                                                    _p(ns.dist_ws), _p(ns.rgba_d), _p(ns.keep), st())) if ns.disturb_on else None,
-    "antialias_fwd": lambda: L.vhap_antialias_fwd(_p(ns.aa_in), _p(ns.rast), _p(ns.clip), _p(ns.tri), _p(ns.opp), B, H, W, 4, V, F, _p(ns.rgba_aa),
-                                                  _p(ns.aa_work), st()),
+    "antialias_inplace_fwd": lambda: L.vhap_antialias_inplace_fwd(_p(ns.aa_in), _p(ns.rast), _p(ns.clip), _p(ns.tri), _p(ns.opp), B, H, W, V, F,
+                                                                  _p(ns.aa_work), st()),
     "photo_fwd": lambda: L.vhap_photo_fwd(_p(ns.rgba_aa), _p(ns.rgb), B, H, W, _p(acc[16:18]), PRE, st()),
-    "photo_bwd": lambda: L.vhap_photo_bwd(_p(ns.rgba_aa), _p(ns.rgb), _p(ns.d_sum), B, H, W, _p(ns.d_rgba_aa), _p(ns.d_color), st()),
-    "antialias_bwd": lambda: L.vhap_antialias_bwd(_p(ns.aa_in), _p(ns.rast), _p(ns.clip), _p(ns.tri), _p(ns.opp), _p(ns.d_rgba_aa), _p(ns.aa_work),
-                                                  _p(ns.vert_mask), B, H, W, 4, V, F, _p(ns.d_color), _p(g["d_clip"]), 2, st()),
+    "antialias_photo_bwd + clear": lambda: (L.vhap_antialias_photo_bwd(_p(ns.rgba_aa), _p(ns.rgb), _p(ns.d_sum), _p(ns.rast), _p(ns.clip), _p(ns.tri),
+                                                                     _p(ns.opp), _p(ns.aa_work), _p(ns.vert_mask), B, H, W, V, F, _p(ns.d_delta),
+                                                                     _p(g["d_clip"]), st()), ns._clear_delta()),
     "deferred_shade_bwd": lambda: deferred_bwd(False),
     "deferred_shade_bwd + tile histogram": lambda: deferred_bwd(True),
     "deferred_gbuffer_bwd (fused)": fused_bwd,

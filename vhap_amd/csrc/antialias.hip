@@ -167,7 +167,7 @@ __global__ __launch_bounds__(DET_T) void aa_detect_kernel(const float* __restric
         const int py = (int)(rem / (unsigned)W), px = (int)(rem - (unsigned)py * W);
         const float4 r0 = live ? rast[pi] : make_float4(0.f, 0.f, 0.f, 0.f);
         const int t0 = (int)r0.w - 1;
-        if (live) {
+        if (live && out) {
             if constexpr (C == 4) {
                 reinterpret_cast<float4*>(out)[pi] = reinterpret_cast<const float4*>(color)[pi];
             } else {
@@ -319,6 +319,155 @@ __global__ __launch_bounds__(256) void aa_bwd_kernel(const float* __restrict__ c
     }
 }
 
+// ---- in-place variant for the photometric step (C = 4): the image is never copied.  Blending `out[q] += alpha (c1 - c0)` reads the
+// ORIGINAL colours of both pixels of every pair, so it runs in two tiny passes over the pair list: `blend2` analyses the candidates and
+// records (pair, alpha, c0, c1); `apply` adds the deltas into the image itself.  The backward takes the original colours from the record.
+// item (12 ints): {pixel index of p0, d | use1 << 1 | edge << 2, alpha bits, frame, c0[4], c1[4]}
+constexpr int ITEM2 = 12;
+__global__ __launch_bounds__(256) void aa_blend2_kernel(const float4* __restrict__ color, const float4* __restrict__ rast,
+                                                        const float4* __restrict__ pos, const int* __restrict__ tri,
+                                                        const int* __restrict__ opp, const unsigned* __restrict__ cand, int H, int W,
+                                                        int V, int F, int* __restrict__ work) {
+    const int count = work[1];
+    const unsigned HW = (unsigned)H * W;
+    const int lane = threadIdx.x & 63;
+    const int nwave_iter = (count + (int)(gridDim.x * 256) - 1) / (int)(gridDim.x * 256);
+    for (int it = 0; it < nwave_iter; it++) {          // uniform trip count: every lane reaches the ballot
+        const int i = (it * (int)gridDim.x + (int)blockIdx.x) * 256 + (int)threadIdx.x;
+        bool need = false;
+        Geo g;
+        float alpha = 0.f;
+        unsigned pi = 0, pj = 0, b = 0;
+        int d = 0;
+        if (i < count) {
+            const unsigned e = cand[i];
+            pi = e >> 1; d = (int)(e & 1u);
+            pj = pi + (d == 0 ? 1u : (unsigned)W);
+            b = pi / HW;
+            const unsigned rem = pi - b * HW;
+            const int py = (int)(rem / (unsigned)W), px = (int)(rem - (unsigned)py * W);
+            const float4 r0 = rast[pi], r1 = rast[pj];
+            g = analyse(pos + (size_t)b * V, tri, opp, (int)r0.w - 1, (int)r1.w - 1, r0.z, r1.z, px, py, d, H, W);
+            if (g.ok) {
+                const float dc = fminf(fmaxf(g.dc_raw, 0.0f), 1.0f);
+                alpha = g.ds * (0.5f - dc);
+                need = true;
+            }
+        }
+        const unsigned long long m = __ballot(need);
+        if (m == 0ull) continue;
+        const int leader = __ffsll((long long)m) - 1;
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&work[0], __popcll(m));
+        base = __shfl(base, leader, 64);
+        if (need) {
+            const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+            int4* item = reinterpret_cast<int4*>(work + 4) + (size_t)slot * (ITEM2 / 4);
+            item[0] = make_int4((int)pi, d | (g.ds < 0.f ? 2 : 0) | (g.di << 2), __float_as_int(alpha), (int)b);
+            reinterpret_cast<float4*>(item)[1] = color[pi];
+            reinterpret_cast<float4*>(item)[2] = color[pj];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void aa_apply_kernel(const int* __restrict__ work, int W, float* __restrict__ color) {
+    const int count = work[0];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < count; i += gridDim.x * 256) {
+        const int4* item = reinterpret_cast<const int4*>(work + 4) + (size_t)i * (ITEM2 / 4);
+        const int4 h = item[0];
+        const float4 c0 = reinterpret_cast<const float4*>(item)[1], c1 = reinterpret_cast<const float4*>(item)[2];
+        const float alpha = __int_as_float(h.z);
+        const size_t pi = (unsigned)h.x, pj = pi + ((h.y & 1) == 0 ? 1 : W);
+        float* o = color + 4 * (alpha > 0.0f ? pi : pj);
+        atomicAdd(&o[0], alpha * (c1.x - c0.x));
+        atomicAdd(&o[1], alpha * (c1.y - c0.y));
+        atomicAdd(&o[2], alpha * (c1.z - c0.z));
+        atomicAdd(&o[3], alpha * (c1.w - c0.w));
+    }
+}
+
+// Backward for the photometric loss: d L / d out[q] = -sign(gt - out[q]) * d_sum on rgb, 0 on alpha (tracker.py:430-439), computed on
+// the fly for the (few) pixels of the pair list -- no dense gradient image exists.  The colour part of the antialias backward (what flows
+// to c0 / c1 BESIDES the pass-through) is ADDED into the dense image d_delta, which is zero everywhere else (aa_clear_delta restores that).
+__global__ __launch_bounds__(256) void aa_photo_bwd_kernel(const float4* __restrict__ pred, const float* __restrict__ gt,
+                                                           const float* __restrict__ d_sum, const float4* __restrict__ rast,
+                                                           const float4* __restrict__ pos, const int* __restrict__ tri,
+                                                           const int* __restrict__ opp, const int* __restrict__ work,
+                                                           const unsigned char* __restrict__ pos_nograd, int H, int W, int V, int F,
+                                                           float* __restrict__ d_delta, float* __restrict__ d_pos) {
+    const int count = work[0];
+    const int HW = H * W;
+    const float gs = d_sum[0];
+    auto sg = [](float e) { return e > 0.f ? 1.0f : (e < 0.f ? -1.0f : 0.0f); };
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < count; i += gridDim.x * 256) {
+        const int4* item = reinterpret_cast<const int4*>(work + 4) + (size_t)i * (ITEM2 / 4);
+        const int4 h = item[0];
+        const float4 c0 = reinterpret_cast<const float4*>(item)[1], c1 = reinterpret_cast<const float4*>(item)[2];
+        const long long pi = (unsigned)h.x;
+        const int d = h.y & 1;
+        const float alpha = __int_as_float(h.z);
+        const int b = h.w;
+        const long long pj = pi + (d == 0 ? 1 : W);
+        const long long q = alpha > 0.0f ? pi : pj;
+        const int remq = (int)(q - (long long)b * HW);
+        const int qy = remq / W, qx = remq - qy * W;
+        const float* g = gt + (size_t)b * 3 * HW + (size_t)(H - 1 - qy) * W + qx;
+        const float4 p = pred[q];
+        const float go[3] = {-sg(g[0] - p.x) * gs, -sg(g[HW] - p.y) * gs, -sg(g[2 * HW] - p.z) * gs};
+        const float dd = go[0] * (c1.x - c0.x) + go[1] * (c1.y - c0.y) + go[2] * (c1.z - c0.z);
+        if (d_delta) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                atomicAdd(&d_delta[(size_t)pj * 4 + k], alpha * go[k]);
+                atomicAdd(&d_delta[(size_t)pi * 4 + k], -alpha * go[k]);
+            }
+        }
+        if (!d_pos || dd == 0.f) continue;
+        const int rem = (int)(pi - (long long)b * HW);
+        const int py = rem / W, px = rem - py * W;
+        const float4 r0 = rast[pi], r1 = rast[pj];
+        const float4* P = pos + (size_t)b * V;
+        const Geo ge = analyse(P, tri, opp, (int)r0.w - 1, (int)r1.w - 1, r0.z, r1.z, px, py, d, H, W);
+        if (!ge.ok) continue;                                    // cannot happen: same inputs as the forward
+        if (!(ge.dc_raw >= 0.0f && ge.dc_raw <= 1.0f)) continue;  // clamp() passes no gradient outside [0,1]
+        const float dx = ge.xb - ge.xa, dy = ge.yb - ge.ya;
+        const float idy = 1.0f / dy;
+        const float gq = -dd;
+        float gxa = gq * (1.0f + ge.ya * idy);
+        float gxb = gq * (-ge.ya * idy);
+        float gya = gq * (-dx * ge.yb * idy * idy);
+        float gyb = gq * (ge.ya * dx * idy * idy);
+        if (d == 1) {   // undo the XY flip
+            float tmp = gxa; gxa = gya; gya = tmp;
+            tmp = gxb; gxb = gyb; gyb = tmp;
+        }
+        const float xh = 0.5f * (float)W, yh = 0.5f * (float)H;
+        const float4 pa = P[ge.va], pb = P[ge.vb];
+        const float iwa = 1.0f / pa.w, iwb = 1.0f / pb.w;
+        float* D = d_pos + (size_t)b * V * 4;
+        if (!(pos_nograd && pos_nograd[ge.va])) {     // (detached vertices: render_nvdiffrast.py:462-464)
+            atomicAdd(&D[4 * ge.va + 0], gxa * xh * iwa);
+            atomicAdd(&D[4 * ge.va + 1], gya * yh * iwa);
+            atomicAdd(&D[4 * ge.va + 3], -(gxa * pa.x * xh + gya * pa.y * yh) * iwa * iwa);
+        }
+        if (!(pos_nograd && pos_nograd[ge.vb])) {
+            atomicAdd(&D[4 * ge.vb + 0], gxb * xh * iwb);
+            atomicAdd(&D[4 * ge.vb + 1], gyb * yh * iwb);
+            atomicAdd(&D[4 * ge.vb + 3], -(gxb * pb.x * xh + gyb * pb.y * yh) * iwb * iwb);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void aa_clear_delta_kernel(const int* __restrict__ work, int W, float4* __restrict__ d_delta) {
+    const int count = work[0];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < count; i += gridDim.x * 256) {
+        const int4 h = reinterpret_cast<const int4*>(work + 4)[(size_t)i * (ITEM2 / 4)];
+        const size_t pi = (unsigned)h.x, pj = pi + ((h.y & 1) == 0 ? 1 : W);
+        d_delta[pi] = make_float4(0.f, 0.f, 0.f, 0.f);
+        d_delta[pj] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
 template <typename Fn>
 int dispatch_C(int C, Fn&& f) {
     switch (C) {
@@ -382,4 +531,56 @@ extern "C" int vhap_antialias_bwd(const float* color, const float* rast, const f
         VHAP_LAUNCH_CHECK();
         return VHAP_OK;
     });
+}
+
+// ---- in-place variant (photometric step) ----
+extern "C" size_t vhap_antialias_inplace_work_ints(int B, int H, int W, int F) {
+    if (B <= 0 || H <= 0 || W <= 0 || F <= 0) return 0;
+    // header + item list (worst case: every pixel blends with both neighbours; 12 ints per item) + one silhouette byte per
+    // (frame, triangle) + candidate list (two pairs per pixel).  Only the part that is used is ever touched.
+    return 4 + (size_t)ITEM2 * 2 * (size_t)B * H * W + ((size_t)B * F + 3) / 4 + 2 * (size_t)B * H * W;
+}
+
+extern "C" int vhap_antialias_inplace_fwd(float* color, const float* rast, const float* pos, const int32_t* tri, const int32_t* opp, int B,
+                                          int H, int W, int V, int F, int32_t* work, vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!color || !rast || !pos || !tri || !opp || !work) return VHAP_E_NULLPTR;
+    if (B <= 0 || H <= 0 || W <= 0 || V <= 0 || F <= 0 || (long long)B * H * W >= (1ll << 30)) return VHAP_E_BADDIM;
+    const long long npix = (long long)B * H * W;
+    hipStream_t st = vhap_stream(stream);
+    unsigned char* sil = reinterpret_cast<unsigned char*>(work + 4 + (size_t)ITEM2 * 2 * (size_t)npix);
+    unsigned* cand = reinterpret_cast<unsigned*>(work + 4 + (size_t)ITEM2 * 2 * (size_t)npix + ((size_t)B * F + 3) / 4);
+    aa_silhouette_kernel<<<vhap_cdiv((long long)B * F, 256), 256, 0, st>>>(reinterpret_cast<const float4*>(pos), tri, opp, B, V, F, H, W, sil, work);
+    VHAP_LAUNCH_CHECK();
+    aa_detect_kernel<4><<<vhap_cdiv(npix, DET_T * DET_PPT), DET_T, 0, st>>>(nullptr, reinterpret_cast<const float4*>(rast), sil, B, H, W, F, nullptr,
+                                                                          work, cand, 0);
+    VHAP_LAUNCH_CHECK();
+    aa_blend2_kernel<<<1024, 256, 0, st>>>(reinterpret_cast<const float4*>(color), reinterpret_cast<const float4*>(rast),
+                                          reinterpret_cast<const float4*>(pos), tri, opp, cand, H, W, V, F, work);
+    VHAP_LAUNCH_CHECK();
+    aa_apply_kernel<<<256, 256, 0, st>>>(work, W, color);
+    VHAP_LAUNCH_CHECK();
+    return VHAP_OK;
+}
+
+extern "C" int vhap_antialias_photo_bwd(const float* pred_rgba, const float* gt_nchw, const float* d_sum, const float* rast, const float* pos,
+                                        const int32_t* tri, const int32_t* opp, const int32_t* work, const uint8_t* pos_nograd_verts, int B,
+                                        int H, int W, int V, int F, float* d_delta, float* d_pos, vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!pred_rgba || !gt_nchw || !d_sum || !rast || !pos || !tri || !opp || !work) return VHAP_E_NULLPTR;
+    if (B <= 0 || H <= 0 || W <= 0 || V <= 0 || F <= 0) return VHAP_E_BADDIM;
+    aa_photo_bwd_kernel<<<256, 256, 0, vhap_stream(stream)>>>(reinterpret_cast<const float4*>(pred_rgba), gt_nchw, d_sum,
+                                                               reinterpret_cast<const float4*>(rast), reinterpret_cast<const float4*>(pos), tri,
+                                                               opp, work, pos_nograd_verts, H, W, V, F, d_delta, d_pos);
+    VHAP_LAUNCH_CHECK();
+    return VHAP_OK;
+}
+
+extern "C" int vhap_antialias_clear_delta(const int32_t* work, int B, int H, int W, float* d_delta, vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!work || !d_delta) return VHAP_E_NULLPTR;
+    if (B <= 0 || H <= 0 || W <= 0) return VHAP_E_BADDIM;
+    aa_clear_delta_kernel<<<256, 256, 0, vhap_stream(stream)>>>(work, W, reinterpret_cast<float4*>(d_delta));
+    VHAP_LAUNCH_CHECK();
+    return VHAP_OK;
 }

@@ -163,7 +163,7 @@ static __global__ __launch_bounds__(64) void vhap_deferred_lights_reduce_kernel(
 static int vhap_fill_deferred_params(DeferredParams& P, const float* pos, const int32_t* tri, const float* vnormal, const float* uv,
                               const int32_t* tri_uv, const float* tex, const float* mips, int Ht, int Wt, const float* lights,
                               const float* sh_const, const float* rast, const float* d_rgba, const float* pred_rgba, const float* gt_nchw,
-                              const float* d_sum, const float* keep, const float* d_reg, const float* stats, int B, int V, int VT, int F, int H,
+                              const float* d_sum, const float* d_delta, const float* keep, const float* d_reg, const float* stats, int B, int V, int VT, int F, int H,
                               int W, float* texc, float* texd, float* d_albedo, float* d_lights, float* work, size_t work_floats,
                               void* texbin_work) {
     if (!pos || !tri || !vnormal || !uv || !tri_uv || !tex || !lights || !sh_const || !rast || !texc || !texd || !d_albedo) return VHAP_E_NULLPTR;
@@ -176,6 +176,7 @@ static int vhap_fill_deferred_params(DeferredParams& P, const float* pos, const 
     if (P.D.L > 0 && !mips) return VHAP_E_NULLPTR;
     P.lights = lights; P.sh_const = sh_const; P.rast = reinterpret_cast<const float4*>(rast);
     P.d_rgba = reinterpret_cast<const float4*>(d_rgba); P.pred = reinterpret_cast<const float4*>(pred_rgba); P.gt = gt_nchw; P.d_sum = d_sum;
+    P.d_delta = reinterpret_cast<const float4*>(d_delta);
     P.keep = keep; P.d_reg = d_reg; P.stats = reinterpret_cast<const unsigned*>(stats);
     P.B = B; P.V = V; P.F = F; P.H = H; P.W = W;
     P.xs = 2.0f / (float)W; P.xo = 1.0f / (float)W - 1.0f; P.ys = 2.0f / (float)H; P.yo = 1.0f / (float)H - 1.0f;
@@ -198,7 +199,7 @@ extern "C" size_t vhap_deferred_shade_bwd_work_floats(int B, int H, int W) {
 extern "C" int vhap_deferred_shade_bwd(const float* pos, const int32_t* tri, const float* vnormal, const float* uv, const int32_t* tri_uv,
                                        const float* tex, const float* mips, int Ht, int Wt, const float* lights, const float* sh_const,
                                        const float* rast, const float* d_rgba, const float* pred_rgba, const float* gt_nchw,
-                                       const float* d_sum, const float* keep, const float* d_reg, const float* stats,
+                                       const float* d_sum, const float* d_delta, const float* keep, const float* d_reg, const float* stats,
                                        int B, int V, int VT, int F, int H, int W, float* texc, float* texd, float* d_albedo,
                                        float* d_normal, float* d_texc, float* d_texd, float* d_lights, float* work, size_t work_floats,
                                        void* texbin_work, vhap_stream_t stream) {
@@ -206,7 +207,7 @@ extern "C" int vhap_deferred_shade_bwd(const float* pos, const int32_t* tri, con
     if (!d_normal || !d_texc || !d_texd) return VHAP_E_NULLPTR;
     DeferredParams P{};
     if (int e = vhap_fill_deferred_params(P, pos, tri, vnormal, uv, tri_uv, tex, mips, Ht, Wt, lights, sh_const, rast, d_rgba, pred_rgba, gt_nchw,
-                                          d_sum, keep, d_reg, stats, B, V, VT, F, H, W, texc, texd, d_albedo, d_lights, work, work_floats,
+                                          d_sum, d_delta, keep, d_reg, stats, B, V, VT, F, H, W, texc, texd, d_albedo, d_lights, work, work_floats,
                                           texbin_work))
         return e;
     P.d_normal = d_normal; P.d_texc = reinterpret_cast<float2*>(d_texc); P.d_texd = reinterpret_cast<float4*>(d_texd);
@@ -226,7 +227,7 @@ extern "C" int vhap_deferred_shade_bwd(const float* pos, const int32_t* tri, con
 extern "C" int vhap_deferred_gbuffer_bwd(const float* pos, const int32_t* tri, const float* vnormal, const float* uv, const int32_t* tri_uv,
                                          const float* tex, const float* mips, int Ht, int Wt, const float* lights, const float* sh_const,
                                          const float* rast, const float* d_rgba, const float* pred_rgba, const float* gt_nchw,
-                                         const float* d_sum, const float* keep, const float* d_reg, const float* stats,
+                                         const float* d_sum, const float* d_delta, const float* keep, const float* d_reg, const float* stats,
                                          const uint8_t* uv_nograd_faces, int B, int V, int VT, int F, int H, int W, float* texc, float* texd,
                                          float* d_albedo, float* d_pos, float* d_vnormal, float* d_lights, float* work, size_t work_floats,
                                          void* texbin_work, vhap_stream_t stream) {
@@ -234,7 +235,7 @@ extern "C" int vhap_deferred_gbuffer_bwd(const float* pos, const int32_t* tri, c
     if (!d_pos || !d_vnormal) return VHAP_E_NULLPTR;
     DeferredParams P{};
     if (int e = vhap_fill_deferred_params(P, pos, tri, vnormal, uv, tri_uv, tex, mips, Ht, Wt, lights, sh_const, rast, d_rgba, pred_rgba, gt_nchw,
-                                          d_sum, keep, d_reg, stats, B, V, VT, F, H, W, texc, texd, d_albedo, d_lights, work, work_floats,
+                                          d_sum, d_delta, keep, d_reg, stats, B, V, VT, F, H, W, texc, texd, d_albedo, d_lights, work, work_floats,
                                           texbin_work))
         return e;
     if (B > 65535) return VHAP_E_BADDIM;

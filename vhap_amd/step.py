@@ -137,17 +137,22 @@ class NativeStep:
         # (measured on MI355X, tools/kbench.py: 265 us fused vs 129 + 125 us separately -- both kernels are bound by VALU issue, not by the
         # gather latency a fusion would share -- so it is off by default)
         self.fused_bwd = self.deferred and os.environ.get("VHAP_FUSED_BWD", "0") == "1"
+        # antialiasing in place + photometric gradient on the fly: no copy of the image, no dense gradient images (d_rgba_aa / d_color)
+        self.aa_inplace = self.deferred and os.environ.get("VHAP_AA_INPLACE", "1") != "0"
         if self.photometric:
             self.clip, self.vn = E(B, V, 4), E(B, V, 3)
             self.rast, self.texc, self.texd = E(B, H, W, 4), E(B, H, W, 2), E(B, H, W, 4)
             if not self.deferred:
                 self.db, self.normal, self.albedo_px = E(B, H, W, 4), E(B, H, W, 3), E(B, H, W, 3)
-            self.rgba, self.rgba_aa = E(B, H, W, 4), E(B, H, W, 4)
+            self.rgba = E(B, H, W, 4)
+            if not self.aa_inplace:
+                self.rgba_aa = E(B, H, W, 4)
             if self.disturb_on:
                 self.rgba_d, self.keep = E(B, H, W, 4), E(B, H, W)
                 self.dist_ws = torch.empty(L.vhap_disturb_workspace_ints(B, H, W), dtype=torch.int32, device=dev)
                 self.cid = torch.empty(B, H, W, dtype=torch.uint8, device=dev)
-            self.aa_work = torch.empty(L.vhap_antialias_work_ints(B, H, W, self.F), dtype=torch.int32, device=dev)
+            self.aa_work = torch.empty((L.vhap_antialias_inplace_work_ints if self.aa_inplace else L.vhap_antialias_work_ints)(B, H, W, self.F),
+                                       dtype=torch.int32, device=dev)
             self.ws, self.ws_bytes, self.ws_cap, _ = tr.render.glctx.acquire(B, self.F, H, W, self.rgb.device)
             # one-launch binning available (raster.hip: LDS_BIN_LIMIT bins, MAX_FRAG x 1024 triangles): binning and rasterisation can be split
             nfrag = (self.F + 1023) // 1024
@@ -190,7 +195,10 @@ class NativeStep:
             p.grad = self.g[k]
         # scratch that is overwritten
         if self.photometric:
-            self.d_rgba_aa, self.d_color, self.d_rgba = E(B, H, W, 4), E(B, H, W, 4), E(B, H, W, 4)
+            if self.aa_inplace:
+                self.d_delta = torch.zeros(B, H, W, 4, **f32)       # zero except, transiently, at the pixels of the antialias pair list
+            else:
+                self.d_rgba_aa, self.d_color = E(B, H, W, 4), E(B, H, W, 4)
             self.d_albedo = E(B, H, W, 3)
             if not self.fused_bwd:
                 self.d_normal, self.d_texc, self.d_texd = E(B, H, W, 3), E(B, H, W, 2), E(B, H, W, 4)
@@ -386,8 +394,13 @@ class NativeStep:
                  "vhap_disturb_fwd_rng_cid")
             color = self.rgba_d
         self.aa_in = color
-        _chk(L.vhap_antialias_fwd(_p(color), _p(self.rast), _p(self.clip), _p(self.tri), _p(self.opp), B, H, W, 4, V, F, _p(self.rgba_aa),
-                                  _p(self.aa_work), st), "vhap_antialias_fwd")
+        if self.aa_inplace:
+            _chk(L.vhap_antialias_inplace_fwd(_p(color), _p(self.rast), _p(self.clip), _p(self.tri), _p(self.opp), B, H, W, V, F,
+                                              _p(self.aa_work), st), "vhap_antialias_inplace_fwd")
+            self.rgba_aa = color                                   # the prediction: the same buffer, antialiased
+        else:
+            _chk(L.vhap_antialias_fwd(_p(color), _p(self.rast), _p(self.clip), _p(self.tri), _p(self.opp), B, H, W, 4, V, F, _p(self.rgba_aa),
+                                      _p(self.aa_work), st), "vhap_antialias_fwd")
         _chk(L.vhap_photo_fwd(_p(self.rgba_aa), _p(self.rgb), B, H, W, _p(acc[16:18]), PRE, st), "vhap_photo_fwd")
         self._join()
         _chk(L.vhap_energy_finalize(_p(acc[0:6]), _p(acc[6:7]) if self.w_lmk else 0, _p(acc[7:9]), _p(acc[9:12]),
@@ -455,34 +468,53 @@ class NativeStep:
         st = _stream()
         _chk(L.vhap_energy_total(_p(self.log), _p(acc[16:18]), _p(self.n_global), self.w_photo, int(world_size), _p(self.d_sum), st),
              "vhap_energy_total")
-        _chk(L.vhap_photo_bwd(_p(self.rgba_aa), _p(self.rgb), _p(self.d_sum), B, H, W, _p(self.d_rgba_aa), _p(self.d_color), st), "vhap_photo_bwd")
-        _chk(L.vhap_antialias_bwd(_p(self.aa_in), _p(self.rast), _p(self.clip), _p(self.tri), _p(self.opp), _p(self.d_rgba_aa), _p(self.aa_work),
-                                  _p(self.vert_mask), B, H, W, 4, V, F, _p(self.d_color), _p(g["d_clip"]),
-                                  _lib.CALL_AA_PASSTHROUGH_DONE, st), "vhap_antialias_bwd")   # d_color already holds the pass-through copy of d_rgba_aa
+        if self.aa_inplace:
+            # no dense gradient images: the loss gradient is evaluated on the fly (here at the pixels of the antialias pair list, in the
+            # shading backward everywhere); the sparse colour part of the antialias backward travels in d_delta
+            _chk(L.vhap_antialias_photo_bwd(_p(self.rgba_aa), _p(self.rgb), _p(self.d_sum), _p(self.rast), _p(self.clip), _p(self.tri), _p(self.opp),
+                                            _p(self.aa_work), _p(self.vert_mask), B, H, W, V, F, _p(self.d_delta), _p(g["d_clip"]), st),
+                 "vhap_antialias_photo_bwd")
+        else:
+            _chk(L.vhap_photo_bwd(_p(self.rgba_aa), _p(self.rgb), _p(self.d_sum), B, H, W, _p(self.d_rgba_aa), _p(self.d_color), st), "vhap_photo_bwd")
+            _chk(L.vhap_antialias_bwd(_p(self.aa_in), _p(self.rast), _p(self.clip), _p(self.tri), _p(self.opp), _p(self.d_rgba_aa), _p(self.aa_work),
+                                      _p(self.vert_mask), B, H, W, 4, V, F, _p(self.d_color), _p(g["d_clip"]),
+                                      _lib.CALL_AA_PASSTHROUGH_DONE, st), "vhap_antialias_bwd")   # d_color already holds the pass-through copy of d_rgba_aa
         # (the backward of the disturbance -- d_rgba = d_color * keep -- is folded into the shading backward)
         if self.fused_bwd:
             _chk(L.vhap_deferred_gbuffer_bwd(_p(self.clip), _p(self.tri), _p(self.vn), _p(self.uv), _p(self.tri_uv), _p(self.albedo_tex), _p(self.mips),
-                                             T, T, _p(tr.lights), _p(self.sh_const), _p(self.rast), _p(self.d_color), 0, 0, 0,
+                                             T, T, _p(tr.lights), _p(self.sh_const), _p(self.rast), *self._upstream(),
                                              _p(self.keep) if self.disturb_on else 0, _p(self.c_reg) if self.want_reg else 0,
                                              _p(acc[12:16]) if self.want_reg else 0, _p(self.face_mask), B, V, self.uv.shape[0], F, H, W,
                                              _p(self.texc), _p(self.texd), _p(self.d_albedo), _p(g["d_clip"]), _p(g["d_vn"]), _p(g["lights"]),
                                              _p(self.def_work), self.def_work.numel(), _p(self.texbin_work) if self.tb_fused else 0, st),
                  "vhap_deferred_gbuffer_bwd")
+            self._clear_delta()
             return
         if self.deferred:
             # shading + texture-coordinate backward in one pass, from re-computed attributes (nothing of the forward's G-buffer is re-read)
             _chk(L.vhap_deferred_shade_bwd(_p(self.clip), _p(self.tri), _p(self.vn), _p(self.uv), _p(self.tri_uv), _p(self.albedo_tex), _p(self.mips),
-                                           T, T, _p(tr.lights), _p(self.sh_const), _p(self.rast), _p(self.d_color), 0, 0, 0,
+                                           T, T, _p(tr.lights), _p(self.sh_const), _p(self.rast), *self._upstream(),
                                            _p(self.keep) if self.disturb_on else 0, _p(self.c_reg) if self.want_reg else 0,
                                            _p(acc[12:16]) if self.want_reg else 0, B, V, self.uv.shape[0], F, H, W, _p(self.texc), _p(self.texd),
                                            _p(self.d_albedo), _p(self.d_normal), _p(self.d_texc), _p(self.d_texd), _p(g["lights"]),
                                            _p(self.def_work), self.def_work.numel(), _p(self.texbin_work) if self.tb_fused else 0, st),
                  "vhap_deferred_shade_bwd")
+            self._clear_delta()
             return
         _chk(L.vhap_shade_bwd(_p(self.normal), _p(self.albedo_px), _p(self.rast), _p(tr.lights), _p(self.sh_const), _p(self.d_color),
                               _p(self.keep) if self.disturb_on else 0, _p(self.c_reg) if self.want_reg else 0,
                               _p(acc[12:16]) if self.want_reg else 0, B, H, W, _p(self.d_albedo), _p(self.d_normal), _p(g["lights"]), st),
              "vhap_shade_bwd")
+
+    def _upstream(self):
+        """(d_rgba | pred, gt, d_sum, d_delta) arguments of the deferred backward: a dense gradient image, or the on-the-fly form"""
+        if self.aa_inplace:
+            return 0, _p(self.rgba_aa), _p(self.rgb), _p(self.d_sum), _p(self.d_delta)
+        return _p(self.d_color), 0, 0, 0, 0
+
+    def _clear_delta(self):
+        if self.aa_inplace:
+            _chk(self.L.vhap_antialias_clear_delta(_p(self.aa_work), self.B, self.H, self.W, _p(self.d_delta), _stream()), "vhap_antialias_clear_delta")
 
     def _bwd_uv(self):
         """gradient w.r.t. the texture coordinates and their screen-space derivatives (input of the G-buffer backward)"""
