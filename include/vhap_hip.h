@@ -129,6 +129,9 @@ int vhap_raster_shade_fwd(const float* pos, const int32_t* tri, const float* vno
  * Replaces vhap_photo_bwd (optionally) + vhap_shade_bwd + the d_uv / d_uv_da part of vhap_texture_bwd (and the re-reading of five
  * G-buffer images). */
 size_t vhap_deferred_shade_bwd_work_floats(int B, int H, int W);
+/* d_lights == NULL with a work table: only the partial sums are accumulated into `work`; finish later (off the critical path) with this */
+int vhap_deferred_lights_reduce(const float* work, const float* lights, const float* sh_const, const float* d_reg,
+                                const float* stats, int B, int H, int W, float* d_lights, vhap_stream_t stream);
 int vhap_deferred_shade_bwd(const float* pos, const int32_t* tri, const float* vnormal, const float* uv,
                             const int32_t* tri_uv, const float* tex, const float* mips, int Ht, int Wt,
                             const float* lights, const float* sh_const, const float* rast,
@@ -401,6 +404,10 @@ int vhap_camera_fwd(const float* K, const float* RT, int B, int K_batched, int R
                     float near_plane, float far_plane, float* mvp, vhap_stream_t stream);
 int vhap_camera_bwd(const float* RT, const float* d_mvp, int B, int RT_batched, int H, int W, float* d_K,
                     vhap_stream_t stream);
+/* the uncalibrated camera (tracker.py:148-157): K = (f, f, cx, cy) with f = focal_length[0] * focal_scale (device scalar x max(H, W)) */
+int vhap_camera_focal_fwd(const float* focal_length, float focal_scale, float cx, float cy, const float* RT, int B,
+                          int RT_batched, int H, int W, float near_plane, float far_plane, float* mvp,
+                          vhap_stream_t stream);
 /* Landmark energy (lbs.vertices2landmarks, vhap/model/lbs.py:60-98 + compute_lmk_energy, tracker.py:347-389):
  * mean over B x [l0,l1) of (|du| + |dv|) conf, with conf x boost for landmarks [boost0,boost1).
  *   lmk_vidx [L,3] int32 vertex ids of each landmark's triangle, lmk_bary [L,3], lmk2d [B,L2,3] = u, v, confidence (pixels)
@@ -445,6 +452,14 @@ int vhap_tex_prep_fwd(const float* painted, const float* extra, const uint8_t* r
 int vhap_tex_prep_bwd(const float* albedo_hwc, const float* extra, const uint8_t* res_mask,
                       const float* d_albedo_hwc, const float* d_mips_hwc, int n_gather, const float* d_terms,
                       int T, float s_tv, float s_res, float* d_extra, vhap_stream_t stream);
+/* vhap_tex_prep_bwd fused with the torch.optim.Adam update of `extra` (one tensor of a vhap_adam_step call issued in pieces: it reads the
+ * step counter but does not advance it -- VHAP_CALL_ADAM_KEEP_STEP semantics; lr_device points at THIS tensor's learning rate): the
+ * gradient d_extra is still written, but never read back, and the separate update pass over the texture disappears. */
+int vhap_tex_prep_bwd_adam(const float* albedo_hwc, float* extra, const uint8_t* res_mask,
+                           const float* d_albedo_hwc, const float* d_mips_hwc, int n_gather, const float* d_terms,
+                           int T, float s_tv, float s_res, float* d_extra, float* exp_avg, float* exp_avg_sq,
+                           const float* lr_device, const int32_t* step_device, float beta1, float beta2, float eps,
+                           vhap_stream_t stream);
 int vhap_adam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                    float* const* exp_avg_sq, const int64_t* numel, const int32_t* lr_index,
                    const float* lr_device, int32_t* step_device, float beta1, float beta2, float eps,

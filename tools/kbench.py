@@ -55,7 +55,7 @@ def deferred_bwd(tb):
     return L.vhap_deferred_shade_bwd(_p(ns.clip), _p(ns.tri), _p(ns.vn), _p(ns.uv), _p(ns.tri_uv), _p(ns.albedo_tex), _p(ns.mips), T, T,
                                      _p(tr.lights), _p(ns.sh_const), _p(ns.rast), *ns._upstream(), _p(ns.keep) if ns.disturb_on else 0,
                                      _p(ns.c_reg) if ns.want_reg else 0, _p(acc[12:16]) if ns.want_reg else 0, B, V, ns.uv.shape[0], F, H, W,
-                                     _p(ns.texc), _p(ns.texd), _p(ns.d_albedo), _p(ns.d_normal), _p(ns.d_texc), _p(ns.d_texd), _p(g["lights"]),
+                                     _p(ns.texc), _p(ns.texd), _p(ns.d_albedo), _p(ns.d_normal), _p(ns.d_texc), _p(ns.d_texd), 0,
                                      _p(ns.def_work), ns.def_work.numel(), _p(ns.texbin_work) if tb else 0, st())
 
 
@@ -64,7 +64,7 @@ def fused_bwd():
                                        _p(tr.lights), _p(ns.sh_const), _p(ns.rast), *ns._upstream(), _p(ns.keep) if ns.disturb_on else 0,
                                        _p(ns.c_reg) if ns.want_reg else 0, _p(acc[12:16]) if ns.want_reg else 0, _p(ns.face_mask), B, V,
                                        ns.uv.shape[0], F, H, W, _p(ns.texc), _p(ns.texd), _p(ns.d_albedo), _p(g["d_clip"]), _p(g["d_vn"]),
-                                       _p(g["lights"]), _p(ns.def_work), ns.def_work.numel(), 0, st())
+                                       0, _p(ns.def_work), ns.def_work.numel(), 0, st())
 
 
 calls = {

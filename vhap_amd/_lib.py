@@ -26,6 +26,7 @@ SIGNATURES = {
     "vhap_raster_interp_fwd": (c_i, [c_fp] * 5 + [c_i] * 6 + [c_fp] * 5 + [c_fp, c_sz, c_sz, c_i, c_fp]),
     "vhap_raster_shade_fwd": (c_i, [c_fp] * 7 + [c_i, c_i] + [c_fp] * 5 + [c_i] * 7 + [c_fp] * 4 + [c_fp, c_sz, c_sz, c_i, c_fp]),
     "vhap_deferred_shade_bwd_work_floats": (c_sz, [c_i] * 3),
+    "vhap_deferred_lights_reduce": (c_i, [c_fp] * 5 + [c_i] * 3 + [c_fp, c_fp]),
     "vhap_deferred_shade_bwd": (c_i, [c_fp] * 7 + [c_i, c_i] + [c_fp] * 11 + [c_i] * 6 + [c_fp] * 8 + [c_sz, c_fp, c_fp]),
     "vhap_deferred_gbuffer_bwd": (c_i, [c_fp] * 7 + [c_i, c_i] + [c_fp] * 12 + [c_i] * 6 + [c_fp] * 7 + [c_sz, c_fp, c_fp]),
     "vhap_raster_bwd": (c_i, [c_fp] * 5 + [c_i] * 5 + [c_fp, c_fp]),
@@ -68,6 +69,7 @@ SIGNATURES = {
     "vhap_frame_prep_fwd": (c_i, [c_fp] * 12 + [c_i] + [c_fp] * 3 + [c_i] * 8 + [c_fp] * 5 + [c_i, c_fp]),
     "vhap_frame_prep_bwd": (c_i, [c_fp] * 11 + [c_i] + [c_fp] * 8 + [c_i] * 8 + [c_fp] * 9),
     "vhap_camera_fwd": (c_i, [c_fp, c_fp] + [c_i] * 5 + [c_f, c_f, c_fp, c_fp]),
+    "vhap_camera_focal_fwd": (c_i, [c_fp, c_f, c_f, c_f, c_fp] + [c_i] * 4 + [c_f, c_f, c_fp, c_fp]),
     "vhap_camera_bwd": (c_i, [c_fp, c_fp] + [c_i] * 4 + [c_fp, c_fp]),
     "vhap_landmark_fwd": (c_i, [c_fp] * 5 + [c_i] * 8 + [c_f, c_i, c_i] + [c_fp] * 2 + [c_i, c_fp]),
     "vhap_landmark_bwd": (c_i, [c_fp] * 6 + [c_i] * 8 + [c_f, c_i, c_i] + [c_fp] * 3),
@@ -75,6 +77,7 @@ SIGNATURES = {
     "vhap_offset_reg_bwd": (c_i, [c_fp] * 8 + [c_i, c_i, c_f, c_f, c_f, c_fp, c_fp, c_fp]),
     "vhap_tex_prep_fwd": (c_i, [c_fp] * 3 + [c_i, c_f, c_f] + [c_fp] * 2 + [c_i, c_fp]),
     "vhap_tex_prep_bwd": (c_i, [c_fp] * 5 + [c_i, c_fp, c_i, c_f, c_f] + [c_fp] * 2),
+    "vhap_tex_prep_bwd_adam": (c_i, [c_fp] * 5 + [c_i, c_fp, c_i, c_f, c_f] + [c_fp] * 5 + [c_f, c_f, c_f, c_fp]),
     "vhap_energy_finalize": (c_i, [c_fp] * 5 + [c_f, c_f, c_i, c_i, c_i, c_fp, c_fp]),
     "vhap_energy_total": (c_i, [c_fp, c_fp, c_fp, c_f, c_i, c_fp, c_fp]),
     "vhap_sum_frames": (c_i, [c_fp, c_i, c_i, c_fp, c_fp]),

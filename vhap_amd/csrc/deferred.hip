@@ -170,7 +170,7 @@ static int vhap_fill_deferred_params(DeferredParams& P, const float* pos, const 
     if (!d_rgba && (!pred_rgba || !gt_nchw || !d_sum)) return VHAP_E_NULLPTR;
     if (B <= 0 || V <= 0 || VT <= 0 || F <= 0 || H <= 0 || W <= 0 || Ht <= 0 || Wt <= 0 || (long long)B * H * W >= (1ll << 31))
         return VHAP_E_BADDIM;
-    if (d_lights && (!work || work_floats < (size_t)DB_SLOTS * DB_ROW)) return VHAP_E_WORKSPACE;
+    if ((d_lights || work) && (!work || work_floats < (size_t)DB_SLOTS * DB_ROW)) return VHAP_E_WORKSPACE;
     P.pos = reinterpret_cast<const float4*>(pos); P.tri = tri; P.vnormal = vnormal; P.uv = reinterpret_cast<const float2*>(uv);
     P.tri_uv = tri_uv; P.tex = tex; P.mips = mips; P.D = make_desc(1, Ht, Wt, 3);
     if (P.D.L > 0 && !mips) return VHAP_E_NULLPTR;
@@ -181,7 +181,7 @@ static int vhap_fill_deferred_params(DeferredParams& P, const float* pos, const 
     P.B = B; P.V = V; P.F = F; P.H = H; P.W = W;
     P.xs = 2.0f / (float)W; P.xo = 1.0f / (float)W - 1.0f; P.ys = 2.0f / (float)H; P.yo = 1.0f / (float)H - 1.0f;
     P.texc = reinterpret_cast<float2*>(texc); P.texd = reinterpret_cast<float4*>(texd); P.d_albedo = d_albedo;
-    P.part = d_lights ? work : nullptr;
+    P.part = work;                              // (d_lights == NULL with a work table: partial sums only, vhap_deferred_lights_reduce later)
     if (texbin_work) {                          // layout of vhap_texture_grad_binned's workspace: counts, then max|g| bits
         const TexBinWs l = texbin_layout(1);
         P.tb_counts = reinterpret_cast<unsigned*>(static_cast<char*>(texbin_work) + l.counts);
@@ -247,5 +247,16 @@ extern "C" int vhap_deferred_gbuffer_bwd(const float* pos, const int32_t* tri, c
                                                                     (unsigned)((long long)B * H * W), d_lights);
         VHAP_LAUNCH_CHECK();
     }
+    return VHAP_OK;
+}
+
+extern "C" int vhap_deferred_lights_reduce(const float* work, const float* lights, const float* sh_const, const float* d_reg, const float* stats,
+                                           int B, int H, int W, float* d_lights, vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!work || !lights || !sh_const || !d_lights) return VHAP_E_NULLPTR;
+    if (B <= 0 || H <= 0 || W <= 0) return VHAP_E_BADDIM;
+    vhap_deferred_lights_reduce_kernel<<<27, DB_SLOTS, 0, vhap_stream(stream)>>>(work, lights, sh_const, d_reg, reinterpret_cast<const unsigned*>(stats),
+                                                                                 (unsigned)((long long)B * H * W), d_lights);
+    VHAP_LAUNCH_CHECK();
     return VHAP_OK;
 }

@@ -575,13 +575,21 @@ extern "C" int vhap_frame_prep_bwd(const int64_t* timesteps, const float* shape,
 // ------------------------------------------------------------------------------------------------------------
 namespace {
 
+// focal != null: the uncalibrated camera of tracker.py:148-157 -- K = (f, f, cx, cy) with f = focal[0] * fscale, built here instead of
+// by separate elementwise launches
 __global__ __launch_bounds__(64) void camera_fwd_kernel(const float* __restrict__ K, const float* __restrict__ RT, int B, int kstride,
                                                         int rtstride, float h, float w, float near, float far,
-                                                        float* __restrict__ mvp) {
+                                                        float* __restrict__ mvp, const float* __restrict__ focal, float fscale, float cx,
+                                                        float cy) {
     const int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= B * 4) return;
     const int b = i >> 2, c = i & 3;
+    float kf[4];
     const float* k = K + (size_t)b * kstride;
+    if (focal) {
+        kf[0] = kf[1] = focal[0] * fscale; kf[2] = cx; kf[3] = cy;
+        k = kf;
+    }
     const float* rt = RT + (size_t)b * rtstride;
     const float mv0 = rt[c], mv1 = rt[4 + c], mv2 = rt[8 + c], mv3 = c == 3 ? 1.0f : 0.0f;
     float* m = mvp + (size_t)b * 16;
@@ -698,7 +706,18 @@ extern "C" int vhap_camera_fwd(const float* K, const float* RT, int B, int K_bat
     if (!K || !RT || !mvp) return VHAP_E_NULLPTR;
     if (B <= 0 || H <= 0 || W <= 0 || !(far_plane > near_plane)) return VHAP_E_BADDIM;
     camera_fwd_kernel<<<vhap_cdiv(B * 4, 64), 64, 0, vhap_stream(stream)>>>(K, RT, B, K_batched ? 4 : 0, RT_batched ? 12 : 0, (float)H, (float)W,
-                                                                            near_plane, far_plane, mvp);
+                                                                            near_plane, far_plane, mvp, nullptr, 0.f, 0.f, 0.f);
+    VHAP_LAUNCH_CHECK();
+    return VHAP_OK;
+}
+
+extern "C" int vhap_camera_focal_fwd(const float* focal_length, float focal_scale, float cx, float cy, const float* RT, int B, int RT_batched,
+                                     int H, int W, float near_plane, float far_plane, float* mvp, vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!focal_length || !RT || !mvp) return VHAP_E_NULLPTR;
+    if (B <= 0 || H <= 0 || W <= 0 || !(far_plane > near_plane)) return VHAP_E_BADDIM;
+    camera_fwd_kernel<<<vhap_cdiv(B * 4, 64), 64, 0, vhap_stream(stream)>>>(nullptr, RT, B, 0, RT_batched ? 12 : 0, (float)H, (float)W, near_plane,
+                                                                            far_plane, mvp, focal_length, focal_scale, cx, cy);
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;
 }

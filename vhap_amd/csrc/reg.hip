@@ -176,13 +176,31 @@ __global__ __launch_bounds__(RB) void tex_prep_fwd_kernel(TexCfg c, const float*
 }
 
 // d_extra[c,y,x] = d_albedo[y,x,c] + TV stencil on the saved albedo + masked residual
+// ADAM: the torch.optim.Adam update of `extra` (adam_kernel's arithmetic) applied to the freshly computed gradient in the same pass --
+// the gradient is still written (it is the parameter's .grad), but never read back, and the separate 350 MB update pass disappears
+struct TexAdam {
+    float* p;
+    float* m;
+    float* v;
+    const float* lr;
+    const int* step;
+    float beta1, beta2, eps;
+};
+template <bool ADAM>
 __global__ __launch_bounds__(RB) void tex_prep_bwd_kernel(TexCfg c, const float* __restrict__ albedo, const float* __restrict__ extra,
                                                           const unsigned char* __restrict__ res_mask, const float* __restrict__ d_albedo,
                                                           const float* __restrict__ d_mips, int n_gather, const float* __restrict__ d_terms,
-                                                          float* __restrict__ d_extra) {
+                                                          float* __restrict__ d_extra, const TexAdam A) {
     const int T = c.T;
     const size_t plane = (size_t)T * T;
     const float gtv = 2.0f * c.s_tv * d_terms[0], gres = 2.0f * c.s_res * d_terms[1];
+    float bc2s = 1.f, step_size = 0.f;
+    if constexpr (ADAM) {
+        const float st = (float)(A.step[0] + 1);
+        const float bc1 = 1.0f - powf(A.beta1, st);
+        bc2s = sqrtf(1.0f - powf(A.beta2, st));
+        step_size = A.lr[0] / bc1;
+    }
     for (size_t i = (size_t)blockIdx.x * RB + threadIdx.x; i < plane; i += (size_t)gridDim.x * RB) {
         const int y = (int)(i / T), x = (int)(i - (size_t)y * T);
         float g[3] = {0.f, 0.f, 0.f};
@@ -212,6 +230,18 @@ __global__ __launch_bounds__(RB) void tex_prep_bwd_kernel(TexCfg c, const float*
             for (int k = 0; k < 3; k++) g[k] += gres * extra[k * plane + i];
         }
         d_extra[i] = g[0]; d_extra[plane + i] = g[1]; d_extra[2 * plane + i] = g[2];
+        if constexpr (ADAM) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const size_t j = k * plane + i;
+                const float gi = g[k];
+                const float mi = A.m[j] + (gi - A.m[j]) * (1.0f - A.beta1);          // lerp, like torch
+                const float vi = A.beta2 * A.v[j] + (1.0f - A.beta2) * gi * gi;
+                A.m[j] = mi;
+                A.v[j] = vi;
+                A.p[j] -= step_size * mi / (sqrtf(vi) / bc2s + A.eps);
+            }
+        }
     }
 }
 
@@ -307,7 +337,24 @@ extern "C" int vhap_tex_prep_bwd(const float* albedo_hwc, const float* extra, co
     if (T <= 0 || n_gather < 0 || (d_mips_hwc && n_gather > 0 && (T & ((1 << n_gather) - 1)))) return VHAP_E_BADDIM;
     TexCfg c{T, s_tv, s_res};
     const int blocks = (int)(((size_t)T * T + RB - 1) / RB < 8192 ? ((size_t)T * T + RB - 1) / RB : 8192);
-    tex_prep_bwd_kernel<<<blocks, RB, 0, vhap_stream(stream)>>>(c, albedo_hwc, extra, res_mask, d_albedo_hwc, n_gather > 0 ? d_mips_hwc : nullptr, n_gather, d_terms, d_extra);
+    tex_prep_bwd_kernel<false><<<blocks, RB, 0, vhap_stream(stream)>>>(c, albedo_hwc, extra, res_mask, d_albedo_hwc, n_gather > 0 ? d_mips_hwc : nullptr,
+                                                                       n_gather, d_terms, d_extra, TexAdam{});
+    VHAP_LAUNCH_CHECK();
+    return VHAP_OK;
+}
+
+extern "C" int vhap_tex_prep_bwd_adam(const float* albedo_hwc, float* extra, const uint8_t* res_mask, const float* d_albedo_hwc,
+                                      const float* d_mips_hwc, int n_gather, const float* d_terms, int T, float s_tv, float s_res,
+                                      float* d_extra, float* exp_avg, float* exp_avg_sq, const float* lr_device, const int32_t* step_device,
+                                      float beta1, float beta2, float eps, vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!albedo_hwc || !extra || !d_terms || !d_extra || !exp_avg || !exp_avg_sq || !lr_device || !step_device) return VHAP_E_NULLPTR;
+    if (T <= 0 || n_gather < 0 || (d_mips_hwc && n_gather > 0 && (T & ((1 << n_gather) - 1)))) return VHAP_E_BADDIM;
+    TexCfg c{T, s_tv, s_res};
+    const int blocks = (int)(((size_t)T * T + RB - 1) / RB < 8192 ? ((size_t)T * T + RB - 1) / RB : 8192);
+    tex_prep_bwd_kernel<true><<<blocks, RB, 0, vhap_stream(stream)>>>(c, albedo_hwc, extra, res_mask, d_albedo_hwc, n_gather > 0 ? d_mips_hwc : nullptr,
+                                                                      n_gather, d_terms, d_extra,
+                                                                      TexAdam{extra, exp_avg, exp_avg_sq, lr_device, step_device, beta1, beta2, eps});
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;
 }

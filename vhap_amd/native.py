@@ -225,7 +225,7 @@ def offset_reg(om, offset, w_lap, w_abs, w_rigid):
 def _n_gather(T):
     """Mip levels whose fold is fused into vhap_tex_prep_bwd (gathered per texel) instead of separate read-modify-write passes."""
     n = 0
-    while n < 3 and T % (1 << (n + 1)) == 0 and (T >> (n + 1)) >= 2:
+    while n < 5 and T % (1 << (n + 1)) == 0 and (T >> (n + 1)) >= 2:
         n += 1
     return n
 
@@ -425,6 +425,18 @@ class HipAdam(torch.optim.Optimizer):
             st["exp_avg"].zero_()
             st["exp_avg_sq"].zero_()
         self._step.zero_()
+
+    def fused_update_args(self, p):
+        """(exp_avg, exp_avg_sq, lr pointer, step pointer, beta1, beta2, eps) of parameter `p` for a kernel that applies the Adam update itself
+        (vhap_tex_prep_bwd_adam); the caller must still run step(skip=(p,)) to advance the counter.  None if `p` is not ours."""
+        if self._tab is None:
+            self._build()
+        for gi, g in enumerate(self.param_groups):
+            if any(q is p for q in g["params"]):
+                st = self.state[p]
+                return (st["exp_avg"], st["exp_avg_sq"], self._lr_dev[gi:gi + 1], self._step, float(g["betas"][0]), float(g["betas"][1]),
+                        float(g["eps"]))
+        return None
 
     @property
     def step_count(self):

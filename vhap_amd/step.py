@@ -260,9 +260,10 @@ class NativeStep:
                 self.K.copy_(K)
             self.RT.copy_(self.RT_in[:, :3, :])
             kb = rb = 1
-        else:
-            torch.addcmul(self.K0, tr.focal_length.detach(), self.K1, out=self.K)      # K = (f, f, cx, cy), f = focal * max(h, w)
-            kb = rb = 0
+        else:                                                     # K = (f, f, cx, cy), f = focal * max(h, w): built inside the kernel
+            _chk(L.vhap_camera_focal_fwd(_p(tr.focal_length), self.focal_scale, 0.5 * W, 0.5 * H, _p(self.RT), B, 0, H, W, 0.1, 10.0, _p(self.mvp),
+                                         _stream()), "vhap_camera_focal_fwd")
+            return
         _chk(L.vhap_camera_fwd(_p(self.K), _p(self.RT), B, kb, rb, H, W, 0.1, 10.0, _p(self.mvp), _stream()), "vhap_camera_fwd")
 
     def _landmark_forward(self):
@@ -407,12 +408,13 @@ class NativeStep:
                                     _p(acc[12:16]) if self.want_reg else 0, self.w_lmk, self.w_reg, B, H, W, _p(self.log), st),
              "vhap_energy_finalize")
 
-    def _tex_backward(self):
+    def _tex_backward(self, optimizer=None):
+        """-> True when the texture's Adam update was applied inside (fused into the last kernel of the chain)"""
         L, tr, T, g = self.L, self.tr, self.T, self.g
         B, H, W = self.B, self.H, self.W
         st = _stream()
         if not self.tex_bwd_on:
-            return
+            return False
         n0 = self.albedo_tex.numel()
         d_tex, d_mips = g["d_tex"][:n0], g["d_tex"][n0:]
         if self.tb_fused:
@@ -422,9 +424,10 @@ class NativeStep:
             _chk(L.vhap_texture_bwd(_p(self.albedo_tex), _p(self.mips), 1, T, T, 3, _p(self.texc), _p(self.texd), _p(self.d_albedo), B, H, W,
                                     _p(d_tex), _p(d_mips), 0, 0, st), "vhap_texture_bwd")
         if not self.split_tex:
-            self.tex_finish()
+            return self.tex_finish(optimizer)
+        return False
 
-    def tex_finish(self):
+    def tex_finish(self, optimizer=None):
         """Gradient pyramid -> d(tex_extra): fold + TV / residual gradients + layout change.  Under frame sharding this runs AFTER the
         pyramid was averaged over the ranks (the regulariser part is identical on every rank, so it is added once, afterwards); with
         `tex_l0_skip` the level-0 part of the pyramid is not exchanged and therefore not used either."""
@@ -433,16 +436,25 @@ class NativeStep:
         if not self.photometric:                                      # only the TV / residual gradients (a landmark stage that trains the texture)
             _chk(L.vhap_tex_prep_bwd(_p(self.albedo_tex), _p(tr.tex_extra), _p(self.nm["res_mask"]), 0, 0, 0, _p(self.ones), T, *self.tex_scales,
                                      _p(g["tex_extra"]), st), "vhap_tex_prep_bwd")
-            return
+            return False
         n0 = self.albedo_tex.numel()
         d_tex, d_mips = g["d_tex"][:n0], g["d_tex"][n0:]
         has_mips = self.mips.numel() > 0
         ng = _n_gather(T) if has_mips else 0
         if has_mips:
             _chk(L.vhap_texture_mip_fold(_p(d_tex), _p(d_mips), 1, T, T, 3, ng, st), "vhap_texture_mip_fold")
+        fu = optimizer.fused_update_args(tr.tex_extra) if (optimizer is not None and hasattr(optimizer, "fused_update_args") and
+                                                            os.environ.get("VHAP_TEX_ADAM_FUSED", "1") != "0") else None
+        if fu is not None:                                          # gradient assembly + Adam update of the texture in ONE pass over it
+            m, v, lr, step, b1, b2, eps = fu
+            _chk(L.vhap_tex_prep_bwd_adam(_p(self.albedo_tex), _p(tr.tex_extra), _p(self.nm["res_mask"]), 0 if self.tex_l0_skip else _p(d_tex),
+                                          _p(d_mips) if has_mips else 0, ng, _p(self.ones), T, *self.tex_scales, _p(g["tex_extra"]), _p(m), _p(v),
+                                          _p(lr), _p(step), b1, b2, eps, st), "vhap_tex_prep_bwd_adam")
+            return True
         _chk(L.vhap_tex_prep_bwd(_p(self.albedo_tex), _p(tr.tex_extra), _p(self.nm["res_mask"]), 0 if self.tex_l0_skip else _p(d_tex),
                                  _p(d_mips) if has_mips else 0, ng, _p(self.ones), T, *self.tex_scales, _p(g["tex_extra"]), st),
              "vhap_tex_prep_bwd")
+        return False
 
     def _bwd_early(self):
         """landmark and offset-regulariser gradients: they depend on nothing the pixel chain produces (pure launch latency)"""
@@ -485,10 +497,9 @@ class NativeStep:
                                              T, T, _p(tr.lights), _p(self.sh_const), _p(self.rast), *self._upstream(),
                                              _p(self.keep) if self.disturb_on else 0, _p(self.c_reg) if self.want_reg else 0,
                                              _p(acc[12:16]) if self.want_reg else 0, _p(self.face_mask), B, V, self.uv.shape[0], F, H, W,
-                                             _p(self.texc), _p(self.texd), _p(self.d_albedo), _p(g["d_clip"]), _p(g["d_vn"]), _p(g["lights"]),
+                                             _p(self.texc), _p(self.texd), _p(self.d_albedo), _p(g["d_clip"]), _p(g["d_vn"]), 0,
                                              _p(self.def_work), self.def_work.numel(), _p(self.texbin_work) if self.tb_fused else 0, st),
                  "vhap_deferred_gbuffer_bwd")
-            self._clear_delta()
             return
         if self.deferred:
             # shading + texture-coordinate backward in one pass, from re-computed attributes (nothing of the forward's G-buffer is re-read)
@@ -496,10 +507,9 @@ class NativeStep:
                                            T, T, _p(tr.lights), _p(self.sh_const), _p(self.rast), *self._upstream(),
                                            _p(self.keep) if self.disturb_on else 0, _p(self.c_reg) if self.want_reg else 0,
                                            _p(acc[12:16]) if self.want_reg else 0, B, V, self.uv.shape[0], F, H, W, _p(self.texc), _p(self.texd),
-                                           _p(self.d_albedo), _p(self.d_normal), _p(self.d_texc), _p(self.d_texd), _p(g["lights"]),
+                                           _p(self.d_albedo), _p(self.d_normal), _p(self.d_texc), _p(self.d_texd), 0,
                                            _p(self.def_work), self.def_work.numel(), _p(self.texbin_work) if self.tb_fused else 0, st),
                  "vhap_deferred_shade_bwd")
-            self._clear_delta()
             return
         _chk(L.vhap_shade_bwd(_p(self.normal), _p(self.albedo_px), _p(self.rast), _p(tr.lights), _p(self.sh_const), _p(self.d_color),
                               _p(self.keep) if self.disturb_on else 0, _p(self.c_reg) if self.want_reg else 0,
@@ -511,6 +521,17 @@ class NativeStep:
         if self.aa_inplace:
             return 0, _p(self.rgba_aa), _p(self.rgb), _p(self.d_sum), _p(self.d_delta)
         return _p(self.d_color), 0, 0, 0, 0
+
+    def _bwd_pixel_finish(self):
+        """the tail of the deferred shading backward that nothing downstream waits for: lights-gradient partials -> d_lights, and d_delta back
+        to all-zero (issued AFTER the texture branch was forked, so that neither delays it)"""
+        if not self.deferred:
+            return
+        L, tr, acc = self.L, self.tr, self.accF
+        _chk(L.vhap_deferred_lights_reduce(_p(self.def_work), _p(tr.lights), _p(self.sh_const), _p(self.c_reg) if self.want_reg else 0,
+                                           _p(acc[12:16]) if self.want_reg else 0, self.B, self.H, self.W, _p(self.g["lights"]), _stream()),
+             "vhap_deferred_lights_reduce")
+        self._clear_delta()
 
     def _clear_delta(self):
         if self.aa_inplace:
@@ -597,17 +618,20 @@ class NativeStep:
             # the uv gradient and the geometry chain on this one
             self._fork()
             with self._branch():
-                self._tex_backward()
-                if optimizer is not None and self.tex_bwd_on:     # the texture's Adam update as soon as its gradient is complete
+                done = self._tex_backward(optimizer)                  # (with an optimiser: its Adam update fused into the last kernel)
+                if optimizer is not None and self.tex_bwd_on and not done:
                     optimizer.step(only=(self.tr.tex_extra,), advance=False)
+            self._bwd_pixel_finish()
             self._bwd_uv()
             self._bwd_geometry(early)
             self._join()
         elif part == "texture":
             self._bwd_pixel(world_size)
+            self._bwd_pixel_finish()
             self._tex_backward()
         elif part == "pixel":                                     # 'texture' in two pieces: the caller runs 'tex' next to 'geometry'
             self._bwd_pixel(world_size)
+            self._bwd_pixel_finish()
         elif part == "tex":
             self._tex_backward()
         elif part == "geometry":
