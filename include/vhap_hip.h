@@ -69,6 +69,12 @@ const char* vhap_strerror(int code);
  * there.  Only with the one-launch binning (F <= 32768, H*W/64 <= 16384 bins): otherwise VHAP_E_UNSUPPORTED. */
 #define VHAP_RASTER_BIN_ONLY 2
 #define VHAP_RASTER_PREBINNED 4
+/* VHAP_RASTER_PROFILE (measurement only): the binning and raster kernels stamp the wall clock of their first wave's start and last wave's
+ * end into `workspace` at vhap_raster_profile_offset(): 2 x 256 pairs of uint64 (100 MHz ticks; pairs [0,256) = binning kernel, [256,512)
+ * = raster kernel; duration = max(ends) - min(starts)) -- the only way to time a kernel INSIDE a captured graph replay (HIP refuses to read
+ * event-record nodes, a profiler is not always there).  Costs two tiny launches and one atomic per wave. */
+#define VHAP_RASTER_PROFILE 8
+size_t vhap_raster_profile_offset(int B, int F, int H, int W, size_t pair_capacity);
 size_t vhap_raster_workspace_bytes(int B, int F, int H, int W, size_t pair_capacity);
 int vhap_raster_fwd(const float* pos, const int32_t* tri, int B, int V, int F, int H, int W,
                     float* rast, float* rast_db, void* workspace, size_t workspace_bytes,

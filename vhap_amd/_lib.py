@@ -22,6 +22,7 @@ SIGNATURES = {
     "vhap_abi_version": (c_i, []),
     "vhap_strerror": (ctypes.c_char_p, [c_i]),
     "vhap_raster_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_sz]),
+    "vhap_raster_profile_offset": (c_sz, [c_i, c_i, c_i, c_i, c_sz]),
     "vhap_raster_fwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_sz, c_sz, c_i, c_fp]),
     "vhap_raster_interp_fwd": (c_i, [c_fp] * 5 + [c_i] * 6 + [c_fp] * 5 + [c_fp, c_sz, c_sz, c_i, c_fp]),
     "vhap_raster_shade_fwd": (c_i, [c_fp] * 7 + [c_i, c_i] + [c_fp] * 5 + [c_i] * 7 + [c_fp] * 4 + [c_fp, c_sz, c_sz, c_i, c_fp]),

@@ -211,6 +211,21 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_fill_kernel(const unsigned* _
 // (bbox test against the setup records) -- a local, bounded fallback.
 // grid = (nfrag, B); dynamic LDS = nbin * 4 bytes.
 // ------------------------------------------------------------------------------------------------------------
+// In-kernel wall-clock stamps (VHAP_RASTER_PROFILE): first start / last end of a kernel's waves, for timing the pass INSIDE a captured
+// graph, where neither HIP events nor a profiler can look.  wall_clock64() = the constant 100 MHz counter.  Hashed over PROF_SLOTS (min, max)
+// pairs so that the atomics do not queue up on one address.
+constexpr int PROF_SLOTS = 256;
+__device__ __forceinline__ void prof_begin(unsigned long long* prof) {
+    if (prof && threadIdx.x == 0) atomicMin(&prof[2 * (blockIdx.x % PROF_SLOTS)], (unsigned long long)wall_clock64());
+}
+__device__ __forceinline__ void prof_end(unsigned long long* prof) {
+    if (prof && (threadIdx.x & 63) == 0) atomicMax(&prof[2 * (blockIdx.x % PROF_SLOTS) + 1], (unsigned long long)wall_clock64());
+}
+__global__ __launch_bounds__(256) void prof_init_kernel(unsigned long long* prof, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) prof[i] = (i & 1) ? 0ull : ~0ull;
+}
+
 constexpr unsigned FRAG_OVERFLOW = 0x80000000u;
 constexpr int MAX_FRAG = 32;   // fragments per bin the raster kernel stages per wave (meshes up to 32768 triangles; beyond: count/scan/fill)
 
@@ -218,8 +233,9 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_build_kernel(const float* __r
                                                                 const int* __restrict__ tri_uv, int V, int F, int H, int W,
                                                                 int nbx, int nby, unsigned* __restrict__ trange,
                                                                 TriRecord* __restrict__ records, uint2* __restrict__ frag,
-                                                                unsigned* __restrict__ list, unsigned region) {
+                                                                unsigned* __restrict__ list, unsigned region, unsigned long long* prof) {
     extern __shared__ __attribute__((aligned(16))) unsigned lb[];     // [nbin]: counts, then write cursors
+    prof_begin(prof);
     __shared__ unsigned wtot[BIN_THREADS / 64];
     const int nbin = nbx * nby;
     const int b = blockIdx.y, wg = blockIdx.x, nfrag = gridDim.x;
@@ -268,10 +284,11 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_build_kernel(const float* __r
         lb[i] = pre;          // write cursor of this bin inside the region
         pre += n;
     }
-    if (overflow) return;     // uniform
+    if (overflow) { prof_end(prof); return; }     // uniform
     __syncthreads();
     for (int y = r.by0; y <= r.by1; y++)
         for (int x = r.bx0; x <= r.bx1; x++) list[base + atomicAdd(&lb[y * nbx + x], 1u)] = (unsigned)t;
+    prof_end(prof);
 }
 
 // ---- winner arithmetic: frag_common.h (same op order as shade_frag() in the oracle) ----
@@ -329,11 +346,13 @@ struct RasterParams {
     float* rgba;              // [B,H,W,4] shaded + composited colour
     unsigned char* cid;       // [B,H,W] or null
     uint4* stats_part;        // per-wave partials of the diffuse-regulariser statistics ((max << 32 | ties) lo, hi, var sum, -) or null
+    unsigned long long* prof; // VHAP_RASTER_PROFILE: (first start, last end) stamps of this kernel, PROF_SLOTS pairs; or null
 };
 
 template <int MODE>
 __global__ __launch_bounds__(256) void raster_kernel(const RasterParams P) {
     constexpr bool INTERP = MODE >= 1;
+    prof_begin(P.prof);
     const unsigned L = vhap_xcd_remap(blockIdx.x, gridDim.x);
     const int nwg = P.nwx * P.nby;  // workgroups per frame
     const int b = L / nwg, wgi = L - b * nwg;
@@ -347,6 +366,7 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterParams P) {
         if constexpr (MODE == 2) {
             if (P.stats_part && lane == 0) P.stats_part[(size_t)blockIdx.x * 4 + wave] = make_uint4(0u, 0u, 0u, 0u);
         }
+        prof_end(P.prof);
         return;
     }
     const int bx0 = bx * BLK, by0 = by * BLK;
@@ -536,6 +556,7 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterParams P) {
 
     if ((P.debug & 2) && best != 12345ull) return;  // ablation: no stores
     if constexpr (MODE != 2) {
+        if (__ballot(in_img) == 0ull) prof_end(P.prof);
         if (!in_img) return;
     }
     const size_t pidx = in_img ? ((size_t)b * H + py) * W + px : 0;
@@ -612,6 +633,7 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterParams P) {
             }
             if (lane == 0) P.stats_part[(size_t)blockIdx.x * 4 + wave] = make_uint4((unsigned)mx, (unsigned)(mx >> 32), __float_as_uint(var), 0u);
         }
+        prof_end(P.prof);
         return;
     }
     reinterpret_cast<float4*>(P.rast)[pidx] = o_rast;
@@ -622,6 +644,7 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterParams P) {
         reinterpret_cast<float2*>(P.texc)[pidx] = make_float2(at.tu, at.tv);
         reinterpret_cast<float4*>(P.texd)[pidx] = at.td;
     }
+    if (P.prof && lane == __builtin_ctzll(__ballot(true))) atomicMax(&P.prof[2 * (blockIdx.x % PROF_SLOTS) + 1], (unsigned long long)wall_clock64());
 }
 
 // final reduction of the per-wave shading statistics -> stats[4] in the layout of vhap_shade_fwd: (ties, ordered max, var sum, -).
@@ -689,7 +712,7 @@ __global__ __launch_bounds__(1024) void shade_stats_reduce_kernel(const uint4* _
 
 
 struct WsLayout {
-    size_t hdr, counts, cursors, offsets, trange, records, list, frag, stats, stats2, total;
+    size_t hdr, counts, cursors, offsets, trange, records, list, frag, stats, stats2, prof, total;
 };
 
 WsLayout ws_layout(int B, int F, int nbin, size_t cap, size_t npart) {
@@ -706,6 +729,7 @@ WsLayout ws_layout(int B, int F, int nbin, size_t cap, size_t npart) {
     l.frag = o; o = al(o + sizeof(uint2) * (size_t)B * nbin * ((F + BIN_THREADS - 1) / BIN_THREADS));
     l.stats = o; o = al(o + sizeof(uint4) * npart);                 // per-wave shading-statistics partials (mode 2): 4 per raster workgroup
     l.stats2 = o; o = al(o + sizeof(uint4) * (STATS_BLOCKS + 1));    // second-level partials + the completion counter
+    l.prof = o; o = al(o + sizeof(unsigned long long) * 2 * PROF_SLOTS * 2);      // VHAP_RASTER_PROFILE stamps: binning, then raster kernel
     l.total = o;
     return l;
 }
@@ -758,8 +782,14 @@ int launch_raster(RasterParams P, void* ws, size_t ws_bytes, size_t cap, int fla
             hipFuncSetAttribute(reinterpret_cast<const void*>(bin_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return VHAP_E_HIP;
         uint2* frag = reinterpret_cast<uint2*>(w + l.frag);
+        unsigned long long* prof_bin = nullptr;
+        if (flags & VHAP_RASTER_PROFILE) {
+            prof_bin = reinterpret_cast<unsigned long long*>(w + l.prof);
+            prof_init_kernel<<<vhap_cdiv(2 * PROF_SLOTS, 256), 256, 0, st>>>(prof_bin, 2 * PROF_SLOTS);
+            VHAP_LAUNCH_CHECK();
+        }
         bin_build_kernel<<<gbin, BIN_THREADS, lds, st>>>(P.pos, P.tri, P.tri_uv, P.V, F, P.H, P.W, P.nbx, P.nby, trange, records, frag, list,
-                                                        (unsigned)region);
+                                                        (unsigned)region, prof_bin);
         VHAP_LAUNCH_CHECK();
         P.frag = frag;
     } else {
@@ -803,6 +833,11 @@ int launch_raster(RasterParams P, void* ws, size_t ws_bytes, size_t cap, int fla
     P.debug = vhap_g_debug_flags;
     const int nwg = B * P.nwx * P.nby;
     if (MODE == 2 && stats_out) P.stats_part = reinterpret_cast<uint4*>(w + l.stats);
+    if (flags & VHAP_RASTER_PROFILE) {
+        P.prof = reinterpret_cast<unsigned long long*>(w + l.prof) + 2 * PROF_SLOTS;
+        prof_init_kernel<<<vhap_cdiv(2 * PROF_SLOTS, 256), 256, 0, st>>>(P.prof, 2 * PROF_SLOTS);
+        VHAP_LAUNCH_CHECK();
+    }
     raster_kernel<MODE><<<nwg, 256, 0, st>>>(P);
     VHAP_LAUNCH_CHECK();
     if (MODE == 2 && stats_out) {
@@ -875,4 +910,12 @@ extern "C" int vhap_raster_shade_fwd(const float* pos, const int32_t* tri, const
     P.lights = lights; P.sh_const = sh_const; P.bg_image = bg_image;
     if (!bg_image && bg_color) { P.bg_r = bg_color[0]; P.bg_g = bg_color[1]; P.bg_b = bg_color[2]; }
     return launch_raster<2>(P, workspace, workspace_bytes, pair_capacity, flags, vhap_stream(stream), stats);
+}
+
+// VHAP_RASTER_PROFILE: byte offset inside `workspace` of the stamps -- 2 x 256 pairs of uint64 (first start, last end; 100 MHz ticks):
+// pairs [0,256) belong to the binning kernel, [256,512) to the raster kernel; reduce with min over the starts / max over the ends.
+extern "C" size_t vhap_raster_profile_offset(int B, int F, int H, int W, size_t pair_capacity) {
+    if (check_dims(B, 1, F, H, W) != VHAP_OK) return 0;
+    const int nbx = (W + BLK - 1) / BLK, nby = (H + BLK - 1) / BLK;
+    return ws_layout(B, F, nbx * nby, pair_capacity, (size_t)B * ((nbx + WG_BLOCKS - 1) / WG_BLOCKS) * nby * 4).prof;
 }

@@ -133,6 +133,7 @@ class NativeStep:
         # deferred shading (default): the rasteriser samples the texture and shades in registers; normal / rast_db / albedo images do not exist
         self.deferred = self.photometric and os.environ.get("VHAP_DEFERRED", "1") != "0"
         self.tb_fused = False
+        self.raster_profile = os.environ.get("VHAP_RASTER_PROFILE", "0") == "1"
         # shading backward fused with the G-buffer backward (one gather chain per covered pixel, d_normal / d_uv / d_uv_da stay in registers)
         # (measured on MI355X, tools/kbench.py: 265 us fused vs 129 + 125 us separately -- both kernels are bound by VALU issue, not by the
         # gather latency a fusion would share -- so it is off by default)
@@ -328,10 +329,10 @@ class NativeStep:
         if self.deferred:
             return self._forward_deferred(tex_ready)
         _chk(L.vhap_vnormal_fwd(_p(self.verts), _p(self.csr.tri), _p(self.csr.ptr), _p(self.csr.idx), B, V, _p(self.vn), st), "vhap_vnormal_fwd")
-        _hook("raster_interp_fwd", "begin")                       # (bench.py: HIP events / event-record graph nodes around the RI-fwd pass)
+        _hook("raster_interp_fwd", "begin")                       # (bench.py: HIP events around the RI-fwd pass of eagerly issued steps)
         _chk(L.vhap_raster_interp_fwd(_p(self.clip), _p(self.tri), _p(self.vn), _p(self.uv), _p(self.tri_uv), B, V, self.uv.shape[0], F, H, W,
                                       _p(self.rast), _p(self.db), _p(self.normal), _p(self.texc), _p(self.texd), _p(self.ws), self.ws_bytes,
-                                      self.ws_cap, 1, st), "vhap_raster_interp_fwd")
+                                      self.ws_cap, 1 | (8 if self.raster_profile else 0), st), "vhap_raster_interp_fwd")
         _hook("raster_interp_fwd", "end")
         self._join()
         _chk(L.vhap_texture_fwd(_p(self.albedo_tex), _p(self.mips), 1, T, T, 3, _p(self.texc), _p(self.texd), B, H, W, _p(self.albedo_px), st),
@@ -372,13 +373,14 @@ class NativeStep:
                                            B, V, self.uv.shape[0], F, H, W, _p(self.rast), _p(self.rgba), _p(self.cid) if self.disturb_on else 0,
                                            _p(acc[12:16]) if self.want_reg else 0, _p(self.ws), self.ws_bytes, self.ws_cap, flags, st)
         _hook("raster_interp_fwd", "begin")
+        prof = 8 if self.raster_profile else 0                    # VHAP_RASTER_PROFILE (bench.py: in-graph timing of the pass)
         split = self.overlap and self.bin_split
         if split:                                                 # vertex normals next to the binning (the raster kernel needs both)
             self.side2.wait_stream(cur)
             with torch.cuda.stream(self.side2):
                 _chk(L.vhap_vnormal_fwd(_p(self.verts), _p(self.csr.tri), _p(self.csr.ptr), _p(self.csr.idx), B, V, _p(self.vn), _stream()),
                      "vhap_vnormal_fwd")
-            _chk(raster(1 | 2), "vhap_raster_shade_fwd")          # VHAP_RASTER_WS_CLEAN | VHAP_RASTER_BIN_ONLY
+            _chk(raster(1 | 2 | prof), "vhap_raster_shade_fwd")   # VHAP_RASTER_WS_CLEAN | VHAP_RASTER_BIN_ONLY
             cur.wait_stream(self.side2)
         else:
             _chk(L.vhap_vnormal_fwd(_p(self.verts), _p(self.csr.tri), _p(self.csr.ptr), _p(self.csr.idx), B, V, _p(self.vn), st), "vhap_vnormal_fwd")
@@ -386,7 +388,7 @@ class NativeStep:
             cur.wait_event(tex_ready)
         else:
             self._join()
-        _chk(raster((1 | 4) if split else 1), "vhap_raster_shade_fwd")   # ... | VHAP_RASTER_PREBINNED
+        _chk(raster(((1 | 4) if split else 1) | prof), "vhap_raster_shade_fwd")   # ... | VHAP_RASTER_PREBINNED
         _hook("raster_interp_fwd", "end")
         color = self.rgba
         if self.disturb_on:
@@ -407,6 +409,18 @@ class NativeStep:
         _chk(L.vhap_energy_finalize(_p(acc[0:6]), _p(acc[6:7]) if self.w_lmk else 0, _p(acc[7:9]), _p(acc[9:12]),
                                     _p(acc[12:16]) if self.want_reg else 0, self.w_lmk, self.w_reg, B, H, W, _p(self.log), st),
              "vhap_energy_finalize")
+
+    def raster_profile_us(self):
+        """(binning us, raster kernel us) of the LAST forward, from the in-kernel wall-clock stamps (needs raster_profile; synchronises)"""
+        off = self.L.vhap_raster_profile_offset(self.B, self.F, self.H, self.W, self.ws_cap)
+        torch.cuda.synchronize()
+        st = self.ws[off:off + 2 * 256 * 2 * 8].view(torch.int64).view(2, 256, 2).cpu().numpy().astype(np.uint64)
+        out = []
+        for k in range(2):
+            starts, ends = st[k, :, 0], st[k, :, 1]
+            live = ends > 0
+            out.append(float(ends[live].max() - starts[live].min()) * 0.01 if live.any() else float("nan"))      # 100 MHz ticks -> us
+        return tuple(out)
 
     def _tex_backward(self, optimizer=None):
         """-> True when the texture's Adam update was applied inside (fused into the last kernel of the chain)"""
@@ -444,7 +458,7 @@ class NativeStep:
         if has_mips:
             _chk(L.vhap_texture_mip_fold(_p(d_tex), _p(d_mips), 1, T, T, 3, ng, st), "vhap_texture_mip_fold")
         fu = optimizer.fused_update_args(tr.tex_extra) if (optimizer is not None and hasattr(optimizer, "fused_update_args") and
-                                                            os.environ.get("VHAP_TEX_ADAM_FUSED", "1") != "0") else None
+                                                            os.environ.get("VHAP_TEX_ADAM_FUSED", "0") == "1") else None    # (measured: 137 us fused vs 50 + 59 us -- off)
         if fu is not None:                                          # gradient assembly + Adam update of the texture in ONE pass over it
             m, v, lr, step, b1, b2, eps = fu
             _chk(L.vhap_tex_prep_bwd_adam(_p(self.albedo_tex), _p(tr.tex_extra), _p(self.nm["res_mask"]), 0 if self.tex_l0_skip else _p(d_tex),
