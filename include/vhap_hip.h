@@ -206,6 +206,11 @@ int vhap_texture_num_levels(int Ht, int Wt);
 size_t vhap_texture_mip_floats(int TB, int Ht, int Wt, int C);
 int vhap_texture_mip_build(const float* tex, int TB, int Ht, int Wt, int C, float* mips,
                            vhap_stream_t stream);
+/* levels first_level .. L of the pyramid from level first_level - 1, which is already in place (first_level = 1: the same as
+ * vhap_texture_mip_build; 2: after vhap_tex_prep_mip1_fwd, which writes level 1 while it assembles the texture).  Four levels per
+ * launch where the extents allow.  Bit-identical to vhap_texture_mip_build. */
+int vhap_texture_mip_build_from(const float* tex, int TB, int Ht, int Wt, int C, float* mips, int first_level,
+                                vhap_stream_t stream);
 int vhap_texture_fwd(const float* tex, const float* mips, int TB, int Ht, int Wt, int C,
                      const float* uv, const float* uv_da, int B, int H, int W, float* out,
                      vhap_stream_t stream);
@@ -339,6 +344,13 @@ int vhap_vnormal_fwd(const float* verts, const int32_t* tri, const int32_t* vc_p
 int vhap_vnormal_bwd(const float* verts, const int32_t* tri, const int32_t* vc_ptr,
                      const int32_t* vc_idx, const float* d_vn, int B, int V, int accumulate,
                      float* scratch, float* d_verts, vhap_stream_t stream);
+/* same pair with the normalisation saved by the forward (inv_len [B,V] = 1 / |raw normal|, 0 where the constant fallback normal was taken):
+ * the backward's first pass then needs no second gather over the incident faces */
+int vhap_vnormal_fwd_saved(const float* verts, const int32_t* tri, const int32_t* vc_ptr,
+                           const int32_t* vc_idx, int B, int V, float* vn, float* inv_len, vhap_stream_t stream);
+int vhap_vnormal_bwd_saved(const float* verts, const int32_t* tri, const int32_t* vc_ptr,
+                           const int32_t* vc_idx, const float* vn, const float* inv_len, const float* d_vn,
+                           int B, int V, int accumulate, float* scratch, float* d_verts, vhap_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Colour disturbance (vhap_amd/csrc/disturb.hip): replaces render_nvdiffrast.py:424-460.
@@ -455,6 +467,11 @@ int vhap_offset_reg_bwd(const float* offset, const int32_t* lap_ptr, const int32
                         vhap_stream_t stream);
 int vhap_tex_prep_fwd(const float* painted, const float* extra, const uint8_t* res_mask, int T, float s_tv,
                       float s_res, float* albedo_hwc, float* terms, int call_flags, vhap_stream_t stream);
+/* vhap_tex_prep_fwd that also writes level 1 of the pyramid (mips_hwc: the buffer of vhap_texture_mip_build, whose first (T/2)^2 x 3
+ * floats are level 1); T must be even.  Follow with vhap_texture_mip_build_from(first_level = 2). */
+int vhap_tex_prep_mip1_fwd(const float* painted, const float* extra, const uint8_t* res_mask, int T, float s_tv,
+                           float s_res, float* albedo_hwc, float* mips_hwc, float* terms, int call_flags,
+                           vhap_stream_t stream);
 int vhap_tex_prep_bwd(const float* albedo_hwc, const float* extra, const uint8_t* res_mask,
                       const float* d_albedo_hwc, const float* d_mips_hwc, int n_gather, const float* d_terms,
                       int T, float s_tv, float s_res, float* d_extra, vhap_stream_t stream);

@@ -151,3 +151,28 @@ def test_deferred_step_matches_separate_pass_step(flame_model, monkeypatch):
         for k, a in g0.items():
             b = g1[k]
             assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max()) + 1e-12, (mode, k)
+
+
+@pytest.mark.parametrize("T", [2048, 256, 128, 96])
+def test_fused_pyramid_build_is_bit_identical(T):
+    """vhap_tex_prep_mip1_fwd (level 1 written while the texture is assembled) + vhap_texture_mip_build_from (four levels per launch) ==
+    vhap_tex_prep_fwd + vhap_texture_mip_build, bit for bit: albedo, every pyramid level, the TV / residual terms."""
+    from vhap_amd import _lib
+    from vhap_amd.ops import _p, _stream
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(T)
+    painted = torch.rand(3, T, T, generator=g).cuda()
+    extra = (torch.randn(3, T, T, generator=g) * 0.05).cuda()
+    mask = (torch.rand(T, T, generator=g) < 0.2).to(torch.uint8).cuda()
+    n = L.vhap_texture_mip_floats(1, T, T, 3)
+    a0, a1 = torch.empty(1, T, T, 3, device="cuda"), torch.empty(1, T, T, 3, device="cuda")
+    m0, m1 = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    t0, t1 = torch.zeros(2, device="cuda"), torch.zeros(2, device="cuda")
+    assert L.vhap_tex_prep_fwd(_p(painted), _p(extra), _p(mask), T, 1e-3, 2e-3, _p(a0), _p(t0), 0, _stream()) == 0
+    assert L.vhap_texture_mip_build(_p(a0), 1, T, T, 3, _p(m0), _stream()) == 0
+    assert L.vhap_tex_prep_mip1_fwd(_p(painted), _p(extra), _p(mask), T, 1e-3, 2e-3, _p(a1), _p(m1), _p(t1), 0, _stream()) == 0
+    assert L.vhap_texture_mip_build_from(_p(a1), 1, T, T, 3, _p(m1), 2, _stream()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(a0, a1)
+    assert torch.equal(m0.view(torch.int32), m1.view(torch.int32)), int((m0 != m1).sum())
+    assert torch.allclose(t0, t1, rtol=1e-5, atol=0) and float(t0[0]) > 0 and float(t0[1]) > 0

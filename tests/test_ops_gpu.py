@@ -331,3 +331,32 @@ def test_texture_grad_binned_matches_tiled_and_oracle(Ht, Wt, C, B, H, W):
         d_tex, d_mips = torch.zeros(Ht * Wt * C, device="cuda"), torch.zeros(max(nm, 1), device="cuda")
         assert texture_grad_binned(Ht, C, uv_g, da_g, do_g, d_tex, d_mips)
         assert torch.allclose(d_tex, l_b[0], rtol=1e-5, atol=1e-12)
+
+
+def test_texture_expanded_batch_is_sampled_as_one_copy():
+    """dr.texture(tex.expand(B, ...)) -- how the reference passes its single texture (tracker.py:234, render_nvdiffrast.py:398) -- must not
+    materialise B copies: same values and the same (summed) gradient as B explicit copies, without the B-fold allocation."""
+    from vhap_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, H, W, T = 3, 24, 20, 64
+    base = torch.rand(1, T, T, 3, generator=g).cuda()
+    uv = torch.rand(B, H, W, 2, generator=g).cuda()
+    da = (torch.randn(B, H, W, 4, generator=g) * 0.02).cuda()
+    w = torch.randn(B, H, W, 3, generator=g).cuda()
+    t1 = base.clone().requires_grad_()
+    torch.cuda.reset_peak_memory_stats()
+    m0 = torch.cuda.memory_allocated()
+    out1 = ops.texture(t1.expand(B, -1, -1, -1), uv, da)
+    (out1 * w).sum().backward()
+    peak = torch.cuda.max_memory_allocated() - m0
+    t2 = base.clone().requires_grad_()
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    m1 = torch.cuda.memory_allocated()
+    out2 = ops.texture(t2.expand(B, -1, -1, -1).contiguous(), uv, da)
+    (out2 * w).sum().backward()
+    peak_copies = torch.cuda.max_memory_allocated() - m1
+    assert torch.equal(out1, out2)
+    assert float((t1.grad - t2.grad).abs().max()) <= 1e-5 * float(t2.grad.abs().max())
+    assert peak <= peak_copies - 2 * (B - 1) * base.numel() * 4, (peak, peak_copies)      # no B-fold texture (+ gradient) copies
+

@@ -70,7 +70,7 @@ def fused_bwd():
 calls = {
     "tex_forward (tex_prep + mips + offset_reg)": lambda: ns._tex_forward(),
     "frame_prep+skin (geometry head)": None,
-    "vnormal_fwd": lambda: L.vhap_vnormal_fwd(_p(ns.verts), _p(ns.csr.tri), _p(ns.csr.ptr), _p(ns.csr.idx), B, V, _p(ns.vn), st()),
+    "vnormal_fwd": lambda: L.vhap_vnormal_fwd_saved(_p(ns.verts), _p(ns.csr.tri), _p(ns.csr.ptr), _p(ns.csr.idx), B, V, _p(ns.vn), _p(ns.vn_inv), st()),
     "raster_shade bin_only": lambda: raster(1 | 2),
     "raster_shade prebinned (+stats reduce)": lambda: raster(1 | 4),
     "raster_shade whole": lambda: raster(1),
@@ -97,7 +97,7 @@ calls = {
 
 
 def geometry_tail():
-    L.vhap_vnormal_bwd(_p(ns.verts), _p(ns.csr.tri), _p(ns.csr.ptr), _p(ns.csr.idx), _p(g["d_vn"]), B, V, 1, _p(ns.vn_scratch), _p(g["d_verts"]), st())
+    L.vhap_vnormal_bwd_saved(_p(ns.verts), _p(ns.csr.tri), _p(ns.csr.ptr), _p(ns.csr.idx), _p(ns.vn), _p(ns.vn_inv), _p(g["d_vn"]), B, V, 1, _p(ns.vn_scratch), _p(g["d_verts"]), st())
     L.vhap_transform_bwd(_p(ns.verts), _p(ns.mvp), _p(g["d_clip"]), B, V, 1, _p(g["d_verts"]), _p(ns.d_mvp), st())
     ns._bwd_params()
 

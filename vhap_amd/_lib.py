@@ -67,6 +67,8 @@ SIGNATURES = {
     "vhap_transform_bwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
     "vhap_vnormal_fwd": (c_i, [c_fp] * 4 + [c_i, c_i, c_fp, c_fp]),
     "vhap_vnormal_bwd": (c_i, [c_fp] * 5 + [c_i, c_i, c_i, c_fp, c_fp, c_fp]),
+    "vhap_vnormal_fwd_saved": (c_i, [c_fp] * 4 + [c_i, c_i, c_fp, c_fp, c_fp]),
+    "vhap_vnormal_bwd_saved": (c_i, [c_fp] * 7 + [c_i, c_i, c_i, c_fp, c_fp, c_fp]),
     "vhap_frame_prep_fwd": (c_i, [c_fp] * 12 + [c_i] + [c_fp] * 3 + [c_i] * 8 + [c_fp] * 5 + [c_i, c_fp]),
     "vhap_frame_prep_bwd": (c_i, [c_fp] * 11 + [c_i] + [c_fp] * 8 + [c_i] * 8 + [c_fp] * 9),
     "vhap_camera_fwd": (c_i, [c_fp, c_fp] + [c_i] * 5 + [c_f, c_f, c_fp, c_fp]),
@@ -77,6 +79,8 @@ SIGNATURES = {
     "vhap_offset_reg_fwd": (c_i, [c_fp] * 8 + [c_i, c_i, c_f, c_f, c_f, c_fp, c_i, c_fp]),
     "vhap_offset_reg_bwd": (c_i, [c_fp] * 8 + [c_i, c_i, c_f, c_f, c_f, c_fp, c_fp, c_fp]),
     "vhap_tex_prep_fwd": (c_i, [c_fp] * 3 + [c_i, c_f, c_f] + [c_fp] * 2 + [c_i, c_fp]),
+    "vhap_tex_prep_mip1_fwd": (c_i, [c_fp] * 3 + [c_i, c_f, c_f] + [c_fp] * 3 + [c_i, c_fp]),
+    "vhap_texture_mip_build_from": (c_i, [c_fp, c_i, c_i, c_i, c_i, c_fp, c_i, c_fp]),
     "vhap_tex_prep_bwd": (c_i, [c_fp] * 5 + [c_i, c_fp, c_i, c_f, c_f] + [c_fp] * 2),
     "vhap_tex_prep_bwd_adam": (c_i, [c_fp] * 5 + [c_i, c_fp, c_i, c_f, c_f] + [c_fp] * 5 + [c_f, c_f, c_f, c_fp]),
     "vhap_energy_finalize": (c_i, [c_fp] * 5 + [c_f, c_f, c_i, c_i, c_i, c_fp, c_fp]),

@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void transform_bwd_kernel(const float* __restr
 // n_raw[v] = sum over incident faces of (v1-v0) x (v2-v0); fallback (0,0,1) if |n|^2 <= 1e-20; normalise.
 __global__ __launch_bounds__(256) void vnormal_fwd_kernel(const float* __restrict__ verts, const int* __restrict__ tri,
                                                           const int* __restrict__ vc_ptr, const int* __restrict__ vc_idx, int V,
-                                                          float* __restrict__ vn) {
+                                                          float* __restrict__ vn, float* __restrict__ inv_len) {
     const int b = blockIdx.y, v = blockIdx.x * 256 + threadIdx.x;
     if (v >= V) return;
     const float* P = verts + (size_t)b * V * 3;
@@ -286,10 +286,24 @@ __global__ __launch_bounds__(256) void vnormal_fwd_kernel(const float* __restric
         nx += ay * bz - az * by; ny += az * bx - ax * bz; nz += ax * by - ay * bx;
     }
     float l2 = nx * nx + ny * ny + nz * nz;
-    if (!(l2 > 1e-20f)) { nx = 0.f; ny = 0.f; nz = 1.f; l2 = 1.f; }
+    const bool fallback = !(l2 > 1e-20f);
+    if (fallback) { nx = 0.f; ny = 0.f; nz = 1.f; l2 = 1.f; }
     const float inv = 1.0f / sqrtf(fmaxf(l2, 1e-20f));
     float* o = vn + ((size_t)b * V + v) * 3;
     o[0] = nx * inv; o[1] = ny * inv; o[2] = nz * inv;
+    if (inv_len) inv_len[(size_t)b * V + v] = fallback ? 0.f : inv;    // saved for the backward: 1 / |raw normal| (0: constant fallback normal)
+}
+
+// pass 1 of the backward from what the forward saved (unit normal + 1 / |raw normal|): no second gather over the incident faces
+__global__ __launch_bounds__(256) void vnormal_bwd1_saved_kernel(const float* __restrict__ vn, const float* __restrict__ inv_len,
+                                                                 const float* __restrict__ d_vn, int n, float* __restrict__ d_nraw) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float inv = inv_len[i];
+    const float ux = vn[3 * i], uy = vn[3 * i + 1], uz = vn[3 * i + 2];
+    const float dx = d_vn[3 * i], dy = d_vn[3 * i + 1], dz = d_vn[3 * i + 2];
+    const float dot = ux * dx + uy * dy + uz * dz;
+    d_nraw[3 * i] = (dx - ux * dot) * inv; d_nraw[3 * i + 1] = (dy - uy * dot) * inv; d_nraw[3 * i + 2] = (dz - uz * dot) * inv;
 }
 
 // pass 1: d_vn -> d_nraw (through the normalisation; zero where the fallback was taken)
@@ -434,7 +448,31 @@ extern "C" int vhap_vnormal_fwd(const float* verts, const int32_t* tri, const in
     VHAP_ENTER();
     if (!verts || !tri || !vc_ptr || !vc_idx || !vn) return VHAP_E_NULLPTR;
     if (B <= 0 || V <= 0 || B > 65535) return VHAP_E_BADDIM;
-    vnormal_fwd_kernel<<<dim3(vhap_cdiv(V, 256), B), 256, 0, vhap_stream(stream)>>>(verts, tri, vc_ptr, vc_idx, V, vn);
+    vnormal_fwd_kernel<<<dim3(vhap_cdiv(V, 256), B), 256, 0, vhap_stream(stream)>>>(verts, tri, vc_ptr, vc_idx, V, vn, nullptr);
+    VHAP_LAUNCH_CHECK();
+    return VHAP_OK;
+}
+
+extern "C" int vhap_vnormal_fwd_saved(const float* verts, const int32_t* tri, const int32_t* vc_ptr, const int32_t* vc_idx, int B, int V,
+                                      float* vn, float* inv_len, vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!verts || !tri || !vc_ptr || !vc_idx || !vn || !inv_len) return VHAP_E_NULLPTR;
+    if (B <= 0 || V <= 0 || B > 65535) return VHAP_E_BADDIM;
+    vnormal_fwd_kernel<<<dim3(vhap_cdiv(V, 256), B), 256, 0, vhap_stream(stream)>>>(verts, tri, vc_ptr, vc_idx, V, vn, inv_len);
+    VHAP_LAUNCH_CHECK();
+    return VHAP_OK;
+}
+
+extern "C" int vhap_vnormal_bwd_saved(const float* verts, const int32_t* tri, const int32_t* vc_ptr, const int32_t* vc_idx, const float* vn,
+                                      const float* inv_len, const float* d_vn, int B, int V, int accumulate, float* scratch,
+                                      float* d_verts, vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!verts || !tri || !vc_ptr || !vc_idx || !vn || !inv_len || !d_vn || !scratch || !d_verts) return VHAP_E_NULLPTR;
+    if (B <= 0 || V <= 0 || B > 65535) return VHAP_E_BADDIM;
+    hipStream_t st = vhap_stream(stream);
+    vnormal_bwd1_saved_kernel<<<vhap_cdiv((long long)B * V, 256), 256, 0, st>>>(vn, inv_len, d_vn, B * V, scratch);
+    VHAP_LAUNCH_CHECK();
+    vnormal_bwd2_kernel<<<dim3(vhap_cdiv(V, 256), B), 256, 0, st>>>(verts, tri, vc_ptr, vc_idx, scratch, V, accumulate, d_verts);
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;
 }

@@ -121,7 +121,7 @@ __device__ __forceinline__ void load_texel(const float* __restrict__ painted, co
 constexpr int TEX_ROWS = 8;
 __global__ __launch_bounds__(RB) void tex_prep_fwd_kernel(TexCfg c, const float* __restrict__ painted, const float* __restrict__ extra,
                                                           const unsigned char* __restrict__ res_mask, float* __restrict__ albedo,
-                                                          float* __restrict__ terms) {
+                                                          float* __restrict__ terms, float* __restrict__ mip1) {
     __shared__ float red[4];
     const int T = c.T;
     const size_t plane = (size_t)T * T;
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(RB) void tex_prep_fwd_kernel(TexCfg c, const float*
     const int lane = threadIdx.x & 63;
     const bool in_x = x < T;
     float e_tv = 0.f, e_res = 0.f;
-    float up[3] = {0.f, 0.f, 0.f};
+    float up[3] = {0.f, 0.f, 0.f}, uprt[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int r = 0; r <= TEX_ROWS; r++) {
         const int y = y0 + r;
@@ -162,7 +162,16 @@ __global__ __launch_bounds__(RB) void tex_prep_fwd_kernel(TexCfg c, const float*
                     for (int k = 0; k < 3; k++) { const float d = a[k] - rt[k]; e_tv += d * d; }
                 }
                 if (res_mask && extra && res_mask[i]) e_res += ex[0] * ex[0] + ex[1] * ex[1] + ex[2] * ex[2];
+                // first level of the pyramid, fused (T even; strips start on even rows): the 2x2 box ((a00 + a01) + (a10 + a11)) / 4 of
+                // vhap_texture_mip_build, same op order -> same bits, without re-reading the 50 MB the kernel has just written
+                if (mip1 && (r & 1) && !(x & 1) && x + 1 < T) {
+                    float* m = mip1 + 3 * ((size_t)(y >> 1) * (T >> 1) + (x >> 1));
+#pragma unroll
+                    for (int k = 0; k < 3; k++) m[k] = ((up[k] + uprt[k]) + (a[k] + rt[k])) * 0.25f;
+                }
             }
+#pragma unroll
+            for (int k = 0; k < 3; k++) uprt[k] = rt[k];
         }
 #pragma unroll
         for (int k = 0; k < 3; k++) up[k] = a[k];
@@ -324,7 +333,20 @@ extern "C" int vhap_tex_prep_fwd(const float* painted, const float* extra, const
     hipStream_t st = vhap_stream(stream);
     VHAP_ZERO_ACC(terms, 2 * sizeof(float), st);
     TexCfg c{T, s_tv, s_res};
-    tex_prep_fwd_kernel<<<dim3(vhap_cdiv(T, RB), vhap_cdiv(T, TEX_ROWS)), RB, 0, st>>>(c, painted, extra, res_mask, albedo_hwc, terms);
+    tex_prep_fwd_kernel<<<dim3(vhap_cdiv(T, RB), vhap_cdiv(T, TEX_ROWS)), RB, 0, st>>>(c, painted, extra, res_mask, albedo_hwc, terms, nullptr);
+    VHAP_LAUNCH_CHECK();
+    return VHAP_OK;
+}
+
+extern "C" int vhap_tex_prep_mip1_fwd(const float* painted, const float* extra, const uint8_t* res_mask, int T, float s_tv, float s_res,
+                                      float* albedo_hwc, float* mips_hwc, float* terms, int call_flags, vhap_stream_t stream) {
+    VHAP_ENTER();
+    if ((!painted && !extra) || !albedo_hwc || !terms || !mips_hwc) return VHAP_E_NULLPTR;
+    if (T <= 0 || (T & 1)) return VHAP_E_BADDIM;
+    hipStream_t st = vhap_stream(stream);
+    VHAP_ZERO_ACC(terms, 2 * sizeof(float), st);
+    TexCfg c{T, s_tv, s_res};
+    tex_prep_fwd_kernel<<<dim3(vhap_cdiv(T, RB), vhap_cdiv(T, TEX_ROWS)), RB, 0, st>>>(c, painted, extra, res_mask, albedo_hwc, terms, mips_hwc);
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;
 }

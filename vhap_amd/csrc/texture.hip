@@ -54,6 +54,41 @@ __global__ __launch_bounds__(256) void mip_fold_kernel(float* __restrict__ fine,
     fine[tb * fine_stride + ((size_t)y * w + x) * C + c] += 0.25f * g;
 }
 
+// Four levels in one launch: a workgroup loads a 32x32 tile of level l (12 KB of LDS at C = 3) and writes the 16x16 / 8x8 / 4x4 / 2x2
+// tiles of levels l+1 .. l+4, each computed from the STORED values of the level above with mip_down_kernel's expression (same bits).
+// Extents of level l must be multiples of 32.
+template <int C>
+__global__ __launch_bounds__(256) void mip_down4_kernel(const float* __restrict__ src, float* __restrict__ mips, const TexDesc D, int l) {
+    __shared__ float a[32 * 32 * C], b[16 * 16 * C];
+    const int w = D.W >> l, tx = blockIdx.x, ty = blockIdx.y, tb = blockIdx.z;
+    const float* S = src + (size_t)tb * (l == 0 ? (size_t)D.H * D.W * C : (size_t)D.per_tex);
+    for (int i = threadIdx.x; i < 32 * 32 * C; i += 256) {
+        const int c = i % C, x = (i / C) % 32, y = i / (C * 32);
+        a[i] = S[((size_t)(ty * 32 + y) * w + tx * 32 + x) * C + c];
+    }
+    __syncthreads();
+    float* cur = a;
+    float* nxt = b;
+    int n = 32;
+#pragma unroll
+    for (int s = 1; s <= 4; s++) {
+        const int m = n >> 1;
+        float* dst = mips + (size_t)tb * D.per_tex + D.off[l + s];
+        const int wl = D.W >> (l + s);
+        for (int i = threadIdx.x; i < m * m * C; i += 256) {
+            const int c = i % C, x = (i / C) % m, y = i / (C * m);
+            const float a00 = cur[((2 * y) * n + 2 * x) * C + c], a01 = cur[((2 * y) * n + 2 * x + 1) * C + c];
+            const float a10 = cur[((2 * y + 1) * n + 2 * x) * C + c], a11 = cur[((2 * y + 1) * n + 2 * x + 1) * C + c];
+            const float v = ((a00 + a01) + (a10 + a11)) * 0.25f;
+            nxt[i] = v;
+            dst[((size_t)(ty * m + y) * wl + tx * m + x) * C + c] = v;
+        }
+        __syncthreads();
+        float* t = cur; cur = nxt; nxt = t;
+        n = m;
+    }
+}
+
 // The small levels in ONE single-workgroup launch each way (they are pure launch latency otherwise: 7 of the 11 levels of a
 // 2048^2 texture hold <= 64x64 texels).  Levels are processed in sequence with a barrier in between; global memory written by
 // the workgroup is visible to it after __syncthreads + __threadfence_block.
@@ -690,6 +725,44 @@ extern "C" int vhap_texture_mip_build(const float* tex, int TB, int Ht, int Wt, 
     }
     if (l_tail <= D.L) {
         mip_down_tail_kernel<<<1, 1024, 0, vhap_stream(stream)>>>(mips, D, l_tail);
+        VHAP_LAUNCH_CHECK();
+    }
+    return VHAP_OK;
+}
+
+// levels first_level .. L from level first_level - 1 (which the caller has already: vhap_tex_prep_mip1_fwd writes level 1 itself)
+extern "C" int vhap_texture_mip_build_from(const float* tex, int TB, int Ht, int Wt, int C, float* mips, int first_level,
+                                           vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (int e = check_tex(TB, Ht, Wt, C)) return e;
+    const TexDesc D = make_desc(TB, Ht, Wt, C);
+    if (D.L == 0 || first_level > D.L) return VHAP_OK;
+    if (!mips || (first_level <= 1 && !tex)) return VHAP_E_NULLPTR;
+    if (first_level < 1) return VHAP_E_BADDIM;
+    hipStream_t st = vhap_stream(stream);
+    int l_tail = D.L + 1;
+    for (int l = 2; l <= D.L; l++)
+        if ((Ht >> (l - 1)) <= TAIL_MAX && (Wt >> (l - 1)) <= TAIL_MAX) { l_tail = l; break; }
+    int l = first_level;
+    while (l <= D.L && l < l_tail) {
+        const int hs = Ht >> (l - 1), ws = Wt >> (l - 1);           // source extents (level l - 1)
+        const float* src = l == 1 ? tex : mips + D.off[l - 1];
+        if (C == 3 && l + 3 <= D.L && hs % 32 == 0 && ws % 32 == 0) {
+            // four levels at once (the tail kernel takes over where the sources get small)
+            mip_down4_kernel<3><<<dim3(ws / 32, hs / 32, TB), 256, 0, st>>>(src, mips, D, l - 1);
+            VHAP_LAUNCH_CHECK();
+            l += 4;
+            continue;
+        }
+        const int h = Ht >> l, w = Wt >> l;
+        const long long sstride = l == 1 ? (long long)Ht * Wt * C : D.per_tex;
+        const long long n = (long long)TB * h * w * C;
+        mip_down_kernel<<<vhap_cdiv(n, 256), 256, 0, st>>>(src, mips + D.off[l], TB, h, w, C, sstride, D.per_tex);
+        VHAP_LAUNCH_CHECK();
+        l++;
+    }
+    if (l <= D.L) {
+        mip_down_tail_kernel<<<1, 1024, 0, st>>>(mips, D, l);
         VHAP_LAUNCH_CHECK();
     }
     return VHAP_OK;

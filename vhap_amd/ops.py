@@ -299,6 +299,10 @@ def texture(tex, uv, uv_da=None, mip_level_bias=None, mip=None, filter_mode="aut
         raise ValueError("tex must have shape [1|B, Ht, Wt, C<=4]")
     if tex.shape[0] not in (1, uv.shape[0]):
         raise ValueError("tex batch dimension must be 1 or match uv")
+    if tex.shape[0] > 1 and tex.stride(0) == 0:
+        # the reference hands over ONE texture expanded to the batch (tracker.py:234 `.expand(B, ...)`): sample the single copy (TB = 1)
+        # instead of materialising B of them (805 MB at B = 16, T = 2048); autograd sums the gradient over the expansion as before
+        tex = tex[:1]
     tex, uv = _f32c(tex), _f32c(uv)
     da = None
     if filter_mode == "linear-mipmap-linear":

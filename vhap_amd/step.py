@@ -141,7 +141,7 @@ class NativeStep:
         # antialiasing in place + photometric gradient on the fly: no copy of the image, no dense gradient images (d_rgba_aa / d_color)
         self.aa_inplace = self.deferred and os.environ.get("VHAP_AA_INPLACE", "1") != "0"
         if self.photometric:
-            self.clip, self.vn = E(B, V, 4), E(B, V, 3)
+            self.clip, self.vn, self.vn_inv = E(B, V, 4), E(B, V, 3), E(B, V)
             self.rast, self.texc, self.texd = E(B, H, W, 4), E(B, H, W, 2), E(B, H, W, 4)
             if not self.deferred:
                 self.db, self.normal, self.albedo_px = E(B, H, W, 4), E(B, H, W, 3), E(B, H, W, 3)
@@ -240,7 +240,12 @@ class NativeStep:
         """texture assembly + pyramid + the offset regularisers: independent of the geometry chain until the texture is sampled"""
         L, tr, T, acc = self.L, self.tr, self.T, self.accF
         st = _stream()
-        if self.tex_fwd_on:
+        if self.tex_fwd_on and self.photometric and T % 2 == 0 and self.mips.numel() > 0:
+            # texture assembly + TV / residual energies + level 1 of the pyramid in one pass; the rest of the pyramid four levels per launch
+            _chk(L.vhap_tex_prep_mip1_fwd(_p(self.painted), _p(tr.tex_extra), _p(self.nm["res_mask"]), T, *self.tex_scales, _p(self.albedo_tex),
+                                          _p(self.mips), _p(acc[7:9]), PRE, st), "vhap_tex_prep_mip1_fwd")
+            _chk(L.vhap_texture_mip_build_from(_p(self.albedo_tex), 1, T, T, 3, _p(self.mips), 2, st), "vhap_texture_mip_build_from")
+        elif self.tex_fwd_on:
             _chk(L.vhap_tex_prep_fwd(_p(self.painted), _p(tr.tex_extra), _p(self.nm["res_mask"]), T, *self.tex_scales, _p(self.albedo_tex),
                                      _p(acc[7:9]), PRE, st), "vhap_tex_prep_fwd")
             if self.photometric:
@@ -328,7 +333,7 @@ class NativeStep:
                 self.tb_head.zero_()                              # tile histogram of the texture-gradient binning (filled by the backward)
         if self.deferred:
             return self._forward_deferred(tex_ready)
-        _chk(L.vhap_vnormal_fwd(_p(self.verts), _p(self.csr.tri), _p(self.csr.ptr), _p(self.csr.idx), B, V, _p(self.vn), st), "vhap_vnormal_fwd")
+        _chk(L.vhap_vnormal_fwd_saved(_p(self.verts), _p(self.csr.tri), _p(self.csr.ptr), _p(self.csr.idx), B, V, _p(self.vn), _p(self.vn_inv), st), "vhap_vnormal_fwd")
         _hook("raster_interp_fwd", "begin")                       # (bench.py: HIP events around the RI-fwd pass of eagerly issued steps)
         _chk(L.vhap_raster_interp_fwd(_p(self.clip), _p(self.tri), _p(self.vn), _p(self.uv), _p(self.tri_uv), B, V, self.uv.shape[0], F, H, W,
                                       _p(self.rast), _p(self.db), _p(self.normal), _p(self.texc), _p(self.texd), _p(self.ws), self.ws_bytes,
@@ -378,12 +383,12 @@ class NativeStep:
         if split:                                                 # vertex normals next to the binning (the raster kernel needs both)
             self.side2.wait_stream(cur)
             with torch.cuda.stream(self.side2):
-                _chk(L.vhap_vnormal_fwd(_p(self.verts), _p(self.csr.tri), _p(self.csr.ptr), _p(self.csr.idx), B, V, _p(self.vn), _stream()),
+                _chk(L.vhap_vnormal_fwd_saved(_p(self.verts), _p(self.csr.tri), _p(self.csr.ptr), _p(self.csr.idx), B, V, _p(self.vn), _p(self.vn_inv), _stream()),
                      "vhap_vnormal_fwd")
             _chk(raster(1 | 2 | prof), "vhap_raster_shade_fwd")   # VHAP_RASTER_WS_CLEAN | VHAP_RASTER_BIN_ONLY
             cur.wait_stream(self.side2)
         else:
-            _chk(L.vhap_vnormal_fwd(_p(self.verts), _p(self.csr.tri), _p(self.csr.ptr), _p(self.csr.idx), B, V, _p(self.vn), st), "vhap_vnormal_fwd")
+            _chk(L.vhap_vnormal_fwd_saved(_p(self.verts), _p(self.csr.tri), _p(self.csr.ptr), _p(self.csr.idx), B, V, _p(self.vn), _p(self.vn_inv), st), "vhap_vnormal_fwd")
         if tex_ready is not None:
             cur.wait_event(tex_ready)
         else:
@@ -590,8 +595,8 @@ class NativeStep:
                  "vhap_gbuffer_bwd")
         if early is not None:
             torch.cuda.current_stream().wait_event(early)
-        _chk(L.vhap_vnormal_bwd(_p(self.verts), _p(self.csr.tri), _p(self.csr.ptr), _p(self.csr.idx), _p(g["d_vn"]), B, V, 1,
-                                _p(self.vn_scratch), _p(g["d_verts"]), st), "vhap_vnormal_bwd")
+        _chk(L.vhap_vnormal_bwd_saved(_p(self.verts), _p(self.csr.tri), _p(self.csr.ptr), _p(self.csr.idx), _p(self.vn), _p(self.vn_inv),
+                                      _p(g["d_vn"]), B, V, 1, _p(self.vn_scratch), _p(g["d_verts"]), st), "vhap_vnormal_bwd_saved")
         _chk(L.vhap_transform_bwd(_p(self.verts), _p(self.mvp), _p(g["d_clip"]), B, V, 1, _p(g["d_verts"]), _p(self.d_mvp), st),
              "vhap_transform_bwd")
         self._bwd_params()
