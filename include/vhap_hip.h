@@ -132,6 +132,8 @@ int vhap_raster_shade_fwd(const float* pos, const int32_t* tri, const float* vno
  *         call leaves them in it; required when d_lights != NULL)
  *   texbin_work (may be NULL): the workspace of vhap_texture_grad_binned with its first 2 x 64 x 64 x 4 bytes ZERO on entry -- the uv-tile
  *         histogram (the count pass of the binning) is filled in here, from registers; follow with vhap_texture_grad_binned_counted()
+ *   tile_ids [B,H,W] uint16 (may be NULL): the uv tile (of vhap_texture_grad_binned) each pixel's texture gradient falls into, 0xFFFF = none --
+ *         follow with vhap_texture_grad_binned_ids(), whose sorting passes then read 2 B per pixel instead of uv + d_albedo
  * Replaces vhap_photo_bwd (optionally) + vhap_shade_bwd + the d_uv / d_uv_da part of vhap_texture_bwd (and the re-reading of five
  * G-buffer images). */
 size_t vhap_deferred_shade_bwd_work_floats(int B, int H, int W);
@@ -146,7 +148,7 @@ int vhap_deferred_shade_bwd(const float* pos, const int32_t* tri, const float* v
                             const float* stats, int B, int V, int VT, int F, int H, int W, float* texc, float* texd,
                             float* d_albedo, float* d_normal, float* d_texc, float* d_texd,
                             float* d_lights, float* work, size_t work_floats, void* texbin_work,
-                            vhap_stream_t stream);
+                            uint16_t* tile_ids, vhap_stream_t stream);
 
 /* vhap_deferred_shade_bwd FUSED with vhap_gbuffer_bwd: the gradients w.r.t. the interpolated normal / uv / uv derivatives never leave
  * registers -- they go straight through the barycentric chain into d_pos [B,V,4] and d_vnormal [B,V,3] (both ACCUMULATED, per-tile LDS
@@ -160,7 +162,7 @@ int vhap_deferred_gbuffer_bwd(const float* pos, const int32_t* tri, const float*
                               const float* stats, const uint8_t* uv_nograd_faces, int B, int V, int VT, int F, int H, int W,
                               float* texc, float* texd, float* d_albedo, float* d_pos, float* d_vnormal,
                               float* d_lights, float* work, size_t work_floats, void* texbin_work,
-                              vhap_stream_t stream);
+                              uint16_t* tile_ids, vhap_stream_t stream);
 
 /* Triangle-parallel backward of the fused G-buffer pass (vhap_raster_interp_fwd): chains the gradients of
  * normal [B,H,W,3], texc [B,H,W,2], texd [B,H,W,4] (and, optionally, direct gradients of rast / rast_db) into
@@ -230,6 +232,10 @@ size_t vhap_texture_grad_binned_work_bytes(int B, int H, int W);
 int vhap_texture_grad_binned(int Ht, int Wt, int C, const float* uv, const float* uv_da, const float* d_out,
                              int B, int H, int W, float* d_tex, float* d_mips, void* work, size_t work_bytes,
                              vhap_stream_t stream);
+/* same, with the uv tile of every pixel supplied by the producer of d_out (vhap_deferred_shade_bwd: tile_ids [B,H,W] uint16, 0xFFFF = none) */
+int vhap_texture_grad_binned_ids(int Ht, int Wt, int C, const float* uv, const float* uv_da, const float* d_out,
+                                 const uint16_t* tile_ids, int B, int H, int W, float* d_tex, float* d_mips,
+                                 void* work, size_t work_bytes, vhap_stream_t stream);
 /* same, for a `work` whose tile histogram was already filled in by vhap_deferred_shade_bwd(texbin_work = work): skips the count pass */
 int vhap_texture_grad_binned_counted(int Ht, int Wt, int C, const float* uv, const float* uv_da,
                                      const float* d_out, int B, int H, int W, float* d_tex, float* d_mips,

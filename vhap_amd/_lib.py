@@ -28,8 +28,8 @@ SIGNATURES = {
     "vhap_raster_shade_fwd": (c_i, [c_fp] * 7 + [c_i, c_i] + [c_fp] * 5 + [c_i] * 7 + [c_fp] * 4 + [c_fp, c_sz, c_sz, c_i, c_fp]),
     "vhap_deferred_shade_bwd_work_floats": (c_sz, [c_i] * 3),
     "vhap_deferred_lights_reduce": (c_i, [c_fp] * 5 + [c_i] * 3 + [c_fp, c_fp]),
-    "vhap_deferred_shade_bwd": (c_i, [c_fp] * 7 + [c_i, c_i] + [c_fp] * 11 + [c_i] * 6 + [c_fp] * 8 + [c_sz, c_fp, c_fp]),
-    "vhap_deferred_gbuffer_bwd": (c_i, [c_fp] * 7 + [c_i, c_i] + [c_fp] * 12 + [c_i] * 6 + [c_fp] * 7 + [c_sz, c_fp, c_fp]),
+    "vhap_deferred_shade_bwd": (c_i, [c_fp] * 7 + [c_i, c_i] + [c_fp] * 11 + [c_i] * 6 + [c_fp] * 8 + [c_sz, c_fp, c_fp, c_fp]),
+    "vhap_deferred_gbuffer_bwd": (c_i, [c_fp] * 7 + [c_i, c_i] + [c_fp] * 12 + [c_i] * 6 + [c_fp] * 7 + [c_sz, c_fp, c_fp, c_fp]),
     "vhap_raster_bwd": (c_i, [c_fp] * 5 + [c_i] * 5 + [c_fp, c_fp]),
     "vhap_gbuffer_bwd": (c_i, [c_fp] * 12 + [c_i] * 5 + [c_fp] * 3),
     "vhap_interp_fwd": (c_i, [c_fp, c_i, c_fp, c_fp, c_fp] + [c_i] * 6 + [c_fp, c_fp, c_fp]),
@@ -42,6 +42,7 @@ SIGNATURES = {
     "vhap_texture_mip_fold": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
     "vhap_texture_grad_binned_work_bytes": (c_sz, [c_i, c_i, c_i]),
     "vhap_texture_grad_binned": (c_i, [c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_sz, c_fp]),
+    "vhap_texture_grad_binned_ids": (c_i, [c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_sz, c_fp]),
     "vhap_texture_grad_binned_counted": (c_i, [c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_sz, c_fp]),
     "vhap_antialias_work_ints": (c_sz, [c_i] * 4),
     "vhap_antialias_fwd": (c_i, [c_fp] * 5 + [c_i] * 6 + [c_fp, c_fp, c_fp]),

@@ -43,6 +43,7 @@ __global__ __launch_bounds__(DB_T) void deferred_shade_bwd_kernel(const Deferred
     if (valid && !cov) {                     // background: nothing flows (its colour is the detached target / a constant)
         float* da = P.d_albedo + 3 * (size_t)pi;
         da[0] = 0.f; da[1] = 0.f; da[2] = 0.f;
+        if (P.tile_ids) P.tile_ids[pi] = (unsigned short)0xFFFF;
     }
     const bool any = __ballot(cov) != 0ull;
     if (any) {
@@ -83,6 +84,7 @@ __global__ __launch_bounds__(GT * GT) void deferred_gbuffer_bwd_kernel(const Def
     if (inside && !cov) {                    // background: nothing flows (its colour is the detached target / a constant)
         float* da = P.d_albedo + 3 * (size_t)pi;
         da[0] = 0.f; da[1] = 0.f; da[2] = 0.f;
+        if (P.tile_ids) P.tile_ids[pi] = (unsigned short)0xFFFF;
     }
     const unsigned npix = (unsigned)P.B * (unsigned)H * (unsigned)W;
     const DiffuseReg R = diffuse_reg(P.d_reg, P.stats, npix);
@@ -165,7 +167,7 @@ static int vhap_fill_deferred_params(DeferredParams& P, const float* pos, const 
                               const float* sh_const, const float* rast, const float* d_rgba, const float* pred_rgba, const float* gt_nchw,
                               const float* d_sum, const float* d_delta, const float* keep, const float* d_reg, const float* stats, int B, int V, int VT, int F, int H,
                               int W, float* texc, float* texd, float* d_albedo, float* d_lights, float* work, size_t work_floats,
-                              void* texbin_work) {
+                              void* texbin_work, uint16_t* tile_ids) {
     if (!pos || !tri || !vnormal || !uv || !tri_uv || !tex || !lights || !sh_const || !rast || !texc || !texd || !d_albedo) return VHAP_E_NULLPTR;
     if (!d_rgba && (!pred_rgba || !gt_nchw || !d_sum)) return VHAP_E_NULLPTR;
     if (B <= 0 || V <= 0 || VT <= 0 || F <= 0 || H <= 0 || W <= 0 || Ht <= 0 || Wt <= 0 || (long long)B * H * W >= (1ll << 31))
@@ -182,6 +184,8 @@ static int vhap_fill_deferred_params(DeferredParams& P, const float* pos, const 
     P.xs = 2.0f / (float)W; P.xo = 1.0f / (float)W - 1.0f; P.ys = 2.0f / (float)H; P.yo = 1.0f / (float)H - 1.0f;
     P.texc = reinterpret_cast<float2*>(texc); P.texd = reinterpret_cast<float4*>(texd); P.d_albedo = d_albedo;
     P.part = work;                              // (d_lights == NULL with a work table: partial sums only, vhap_deferred_lights_reduce later)
+    P.tile_ids = tile_ids;
+    P.NT = texbin_nt(Ht, Wt);
     if (texbin_work) {                          // layout of vhap_texture_grad_binned's workspace: counts, then max|g| bits
         const TexBinWs l = texbin_layout(1);
         P.tb_counts = reinterpret_cast<unsigned*>(static_cast<char*>(texbin_work) + l.counts);
@@ -202,13 +206,13 @@ extern "C" int vhap_deferred_shade_bwd(const float* pos, const int32_t* tri, con
                                        const float* d_sum, const float* d_delta, const float* keep, const float* d_reg, const float* stats,
                                        int B, int V, int VT, int F, int H, int W, float* texc, float* texd, float* d_albedo,
                                        float* d_normal, float* d_texc, float* d_texd, float* d_lights, float* work, size_t work_floats,
-                                       void* texbin_work, vhap_stream_t stream) {
+                                       void* texbin_work, uint16_t* tile_ids, vhap_stream_t stream) {
     VHAP_ENTER();
     if (!d_normal || !d_texc || !d_texd) return VHAP_E_NULLPTR;
     DeferredParams P{};
     if (int e = vhap_fill_deferred_params(P, pos, tri, vnormal, uv, tri_uv, tex, mips, Ht, Wt, lights, sh_const, rast, d_rgba, pred_rgba, gt_nchw,
                                           d_sum, d_delta, keep, d_reg, stats, B, V, VT, F, H, W, texc, texd, d_albedo, d_lights, work, work_floats,
-                                          texbin_work))
+                                          texbin_work, tile_ids))
         return e;
     P.d_normal = d_normal; P.d_texc = reinterpret_cast<float2*>(d_texc); P.d_texd = reinterpret_cast<float4*>(d_texd);
     const long long npix = (long long)B * H * W;
@@ -230,13 +234,13 @@ extern "C" int vhap_deferred_gbuffer_bwd(const float* pos, const int32_t* tri, c
                                          const float* d_sum, const float* d_delta, const float* keep, const float* d_reg, const float* stats,
                                          const uint8_t* uv_nograd_faces, int B, int V, int VT, int F, int H, int W, float* texc, float* texd,
                                          float* d_albedo, float* d_pos, float* d_vnormal, float* d_lights, float* work, size_t work_floats,
-                                         void* texbin_work, vhap_stream_t stream) {
+                                         void* texbin_work, uint16_t* tile_ids, vhap_stream_t stream) {
     VHAP_ENTER();
     if (!d_pos || !d_vnormal) return VHAP_E_NULLPTR;
     DeferredParams P{};
     if (int e = vhap_fill_deferred_params(P, pos, tri, vnormal, uv, tri_uv, tex, mips, Ht, Wt, lights, sh_const, rast, d_rgba, pred_rgba, gt_nchw,
                                           d_sum, d_delta, keep, d_reg, stats, B, V, VT, F, H, W, texc, texd, d_albedo, d_lights, work, work_floats,
-                                          texbin_work))
+                                          texbin_work, tile_ids))
         return e;
     if (B > 65535) return VHAP_E_BADDIM;
     hipStream_t st = vhap_stream(stream);

@@ -44,6 +44,7 @@ struct DeferredParams {
     unsigned* tb_counts;     // optional: the uv-tile histogram of vhap_texture_grad_binned (counts / max|g| bits per tile, zero on entry)
     unsigned* tb_max;
     int NT;
+    unsigned short* tile_ids; // optional [B,H,W]: uv tile of every pixel for vhap_texture_grad_binned_ids (0xFFFF = no gradient)
 };
 
 // regulariser part of d(diffuse) (lights only, on shade(normal.detach()): tracker.py:547-550), see shade_bwd_kernel
@@ -118,7 +119,8 @@ __device__ __forceinline__ DeferredGrad deferred_pixel(const DeferredParams& P, 
     float* da = P.d_albedo + 3 * (size_t)pi;
     da[0] = ga[0]; da[1] = ga[1]; da[2] = ga[2];
     tb_g = fmaxf(fabsf(ga[0]), fmaxf(fabsf(ga[1]), fabsf(ga[2])));
-    tb_tile = (P.tb_counts && tb_g != 0.f) ? tile_of(make_float2(at.tu, at.tv), P.NT) : -1;   // same criterion and tile as texbin_pass_kernel
+    tb_tile = ((P.tb_counts || P.tile_ids) && tb_g != 0.f) ? tile_of(make_float2(at.tu, at.tv), P.NT) : -1;   // criterion / tile of texbin_pass_kernel
+    if (P.tile_ids) P.tile_ids[pi] = (unsigned short)(tb_tile < 0 ? 0xFFFF : tb_tile);
     float alb[3];
     tex_sample_bwd_uv<3>(P.tex, P.mips, P.D, 0, make_float2(at.tu, at.tv), at.td, ga, nullptr, nullptr, o.guv, o.gda, true, alb);
     const float gd[3] = {g.x * alb[0], g.y * alb[1], g.z * alb[2]};               // photometric part of d L / d diffuse

@@ -509,11 +509,14 @@ TileGeo make_tile_geo(const TexDesc& D) {
 
 __device__ __forceinline__ int tile_lo(int t, int NT, int w) { return (int)floorf(((float)t / (float)NT) * (float)w - 0.5f); }
 
+// tile_ids (optional): the uv tile of every pixel as 16 bits (0xFFFF = no gradient), written by the producer of d_out
+// (vhap_deferred_shade_bwd): the passes then read 2 B/px (+ d_out of the covered third in the count pass, for the per-tile scale) instead
+// of uv + d_out = 20 B/px each.
 template <int C, bool SCATTER>
 __global__ __launch_bounds__(256) void texbin_pass_kernel(const float2* __restrict__ uv, const float* __restrict__ d_out, long long npix,
                                                           int NT, unsigned* __restrict__ counts, unsigned* __restrict__ tilemax,
                                                           const unsigned* __restrict__ offsets, unsigned* __restrict__ cursors,
-                                                          unsigned* __restrict__ list) {
+                                                          unsigned* __restrict__ list, const unsigned short* __restrict__ tile_ids) {
     extern __shared__ unsigned tg_sh[];          // [NT*NT] counts / ranks, [NT*NT] max|g| bits (count pass) or list bases (scatter pass)
     const int nt2 = NT * NT, tid = threadIdx.x;
     unsigned* shc = tg_sh;
@@ -526,7 +529,19 @@ __global__ __launch_bounds__(256) void texbin_pass_kernel(const float2* __restri
     for (int k = 0; k < TG_PPT; k++) {
         const long long p = p0 + (long long)k * 256;
         tile[k] = -1;
-        if (p < npix) {
+        if (p < npix && tile_ids) {
+            const int tl = (int)tile_ids[p];
+            if (tl != 0xFFFF) {
+                tile[k] = tl;
+                atomicAdd(&shc[tl], 1u);
+                if (!SCATTER) {
+                    float gmax = 0.f;
+#pragma unroll
+                    for (int c = 0; c < C; c++) gmax = fmaxf(gmax, fabsf(d_out[p * C + c]));
+                    atomicMax(&shb[tl], __float_as_uint(gmax));
+                }
+            }
+        } else if (p < npix) {
             float gmax = 0.f;
 #pragma unroll
             for (int c = 0; c < C; c++) gmax = fmaxf(gmax, fabsf(d_out[p * C + c]));
@@ -861,7 +876,8 @@ extern "C" size_t vhap_texture_grad_binned_work_bytes(int B, int H, int W) {
 }
 
 static int texture_grad_binned_impl(int Ht, int Wt, int C, const float* uv, const float* uv_da, const float* d_out, int B, int H, int W,
-                                    float* d_tex, float* d_mips, void* work, size_t work_bytes, int call_flags, vhap_stream_t stream) {
+                                    float* d_tex, float* d_mips, void* work, size_t work_bytes, int call_flags, vhap_stream_t stream,
+                                    const unsigned short* tile_ids = nullptr) {
     VHAP_ENTER();
     if (!uv || !d_out || !d_tex || !work) return VHAP_E_NULLPTR;
     if (int e = check_tex(1, Ht, Wt, C)) return e;
@@ -894,12 +910,12 @@ static int texture_grad_binned_impl(int Ht, int Wt, int C, const float* uv, cons
         constexpr int CC = decltype(c)::value;
         const float2* uv2 = reinterpret_cast<const float2*>(uv);
         if (!counted) {
-            texbin_pass_kernel<CC, false><<<nwg, 256, hist, st>>>(uv2, d_out, npix, G.NT, counts, tilemax, nullptr, nullptr, nullptr);
+            texbin_pass_kernel<CC, false><<<nwg, 256, hist, st>>>(uv2, d_out, npix, G.NT, counts, tilemax, nullptr, nullptr, nullptr, tile_ids);
             VHAP_LAUNCH_CHECK();
         }
         texbin_scan_kernel<<<1, 1024, 0, st>>>(counts, nt2, offsets, cursors);
         VHAP_LAUNCH_CHECK();
-        texbin_pass_kernel<CC, true><<<nwg, 256, hist, st>>>(uv2, d_out, npix, G.NT, nullptr, nullptr, offsets, cursors, list);
+        texbin_pass_kernel<CC, true><<<nwg, 256, hist, st>>>(uv2, d_out, npix, G.NT, nullptr, nullptr, offsets, cursors, list, tile_ids);
         VHAP_LAUNCH_CHECK();
         if (lds > 48 * 1024 &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(texgrad_tile_kernel<CC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -918,4 +934,13 @@ extern "C" int vhap_texture_grad_binned(int Ht, int Wt, int C, const float* uv, 
 extern "C" int vhap_texture_grad_binned_counted(int Ht, int Wt, int C, const float* uv, const float* uv_da, const float* d_out, int B, int H,
                                                 int W, float* d_tex, float* d_mips, void* work, size_t work_bytes, vhap_stream_t stream) {
     return texture_grad_binned_impl(Ht, Wt, C, uv, uv_da, d_out, B, H, W, d_tex, d_mips, work, work_bytes, VHAP_CALL_TEXBIN_COUNTED, stream);
+}
+
+// same, with the uv tile of every pixel supplied by the producer of d_out (tile_ids [B,H,W] uint16, 0xFFFF = no gradient;
+// vhap_deferred_shade_bwd writes them): the two sorting passes read 2 B per pixel instead of 20
+extern "C" int vhap_texture_grad_binned_ids(int Ht, int Wt, int C, const float* uv, const float* uv_da, const float* d_out,
+                                            const uint16_t* tile_ids, int B, int H, int W, float* d_tex, float* d_mips, void* work,
+                                            size_t work_bytes, vhap_stream_t stream) {
+    if (!tile_ids) return VHAP_E_NULLPTR;
+    return texture_grad_binned_impl(Ht, Wt, C, uv, uv_da, d_out, B, H, W, d_tex, d_mips, work, work_bytes, 0, stream, tile_ids);
 }

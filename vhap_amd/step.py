@@ -132,7 +132,7 @@ class NativeStep:
             self.albedo_tex, self.mips = E(0), E(0)
         # deferred shading (default): the rasteriser samples the texture and shades in registers; normal / rast_db / albedo images do not exist
         self.deferred = self.photometric and os.environ.get("VHAP_DEFERRED", "1") != "0"
-        self.tb_fused = False
+        self.tb_fused = self.tb_ids = False
         self.raster_profile = os.environ.get("VHAP_RASTER_PROFILE", "0") == "1"
         # shading backward fused with the G-buffer backward (one gather chain per covered pixel, d_normal / d_uv / d_uv_da stay in registers)
         # (measured on MI355X, tools/kbench.py: 265 us fused vs 129 + 125 us separately -- both kernels are bound by VALU issue, not by the
@@ -208,6 +208,11 @@ class NativeStep:
             self.tb_fused = self.deferred and self.tex_bwd_on and NV.use_binned_texgrad() and T <= 2048 and \
                 os.environ.get("VHAP_TB_FUSED", "0") == "1"       # (measured: +50 us on the pixel kernel for 25 us saved -- off)
             self.tb_head = self.texbin_work[:2 * 64 * 64 * 4]
+            # ... and the uv tile of every pixel is handed to the sorting passes as 2 B/px instead of uv + d_albedo (20 B/px, twice)
+            self.tb_ids = self.deferred and self.tex_bwd_on and NV.use_binned_texgrad() and T <= 2048 and not self.tb_fused and \
+                os.environ.get("VHAP_TB_IDS", "1") != "0"
+            if self.tb_ids:
+                self.tile_ids = torch.empty(B, H, W, dtype=torch.int16, device=dev)
             self.vn_scratch = E(B, V, 3)
             if self.deferred:
                 self.def_work = self.g["def_work"]
@@ -288,20 +293,20 @@ class NativeStep:
         so = tr.static_offset
         tex_ready = None
         early_tex = self.photometric and self.deferred and self.overlap
-        if early_tex:
-            # deferred shading: the rasteriser itself samples the texture, so the texture assembly + pyramid (~100 us, bandwidth-bound) heads
-            # the critical path together with the geometry chain: start it at once on the side branch
-            self._fork()
-            with self._branch():
-                self._tex_forward()
-                tex_ready = torch.cuda.Event()
-                tex_ready.record()
-        # the camera first: two tiny launches that would take 3-5x as long next to the texture branch below
+        # the camera and the per-frame stage first: tiny latency-bound launches that take 3-5x as long next to the texture branch below
         self._camera_forward()
         _chk(L.vhap_frame_prep_fwd(_p(self.ts), _p(tr.shape), _p(tr.expr), _p(tr.rotation), _p(tr.translation), _p(tr.neck_pose),
                                    _p(tr.jaw_pose), _p(tr.eyes_pose), _p(fm.JT), _p(fm.JS), _p(fm.jreg_idx), _p(fm.jreg_w), fm.jreg_n,
                                    _p(so), fm.parents, self.weights, B, self.Bp, self.N, self.NS, self.NE, J, fb.Kp, V,
                                    _p(self.coef), _p(self.A), _p(self.transl), _p(self.Jrest), _p(acc), PRE, st), "vhap_frame_prep_fwd")
+        if early_tex:
+            # deferred shading: the rasteriser itself samples the texture, so the texture assembly + pyramid (~75 us, bandwidth-bound) must be
+            # ready when the geometry chain (skinning -> normals / binning) is: start it here on the side branch
+            self._fork()
+            with self._branch():
+                self._tex_forward()
+                tex_ready = torch.cuda.Event()
+                tex_ready.record()
         if self.photometric:                                      # skinning fused with the world -> clip transform (one launch, same bits)
             _chk(L.vhap_flame_skin_clip_fwd(_p(self.coef), _p(fb.basis), _p(self.A), _p(fb.w), _p(fb.templ), _p(so), _p(self.transl), _p(self.mvp),
                                             B, V, fb.Vp, fb.K, fb.Kb, fb.Kp, _p(self.verts), _p(self.v_shaped), _p(self.v_posed), _p(self.clip), st),
@@ -439,6 +444,9 @@ class NativeStep:
         if self.tb_fused:
             _chk(L.vhap_texture_grad_binned_counted(T, T, 3, _p(self.texc), _p(self.texd), _p(self.d_albedo), B, H, W, _p(d_tex), _p(d_mips),
                                                     _p(self.texbin_work), self.texbin_work.numel(), st), "vhap_texture_grad_binned_counted")
+        elif self.tb_ids:
+            _chk(L.vhap_texture_grad_binned_ids(T, T, 3, _p(self.texc), _p(self.texd), _p(self.d_albedo), _p(self.tile_ids), B, H, W, _p(d_tex),
+                                                _p(d_mips), _p(self.texbin_work), self.texbin_work.numel(), st), "vhap_texture_grad_binned_ids")
         elif not (NV.use_binned_texgrad() and NV.texture_grad_binned(T, 3, self.texc, self.texd, self.d_albedo, d_tex, d_mips, self.texbin_work)):
             _chk(L.vhap_texture_bwd(_p(self.albedo_tex), _p(self.mips), 1, T, T, 3, _p(self.texc), _p(self.texd), _p(self.d_albedo), B, H, W,
                                     _p(d_tex), _p(d_mips), 0, 0, st), "vhap_texture_bwd")
@@ -517,7 +525,8 @@ class NativeStep:
                                              _p(self.keep) if self.disturb_on else 0, _p(self.c_reg) if self.want_reg else 0,
                                              _p(acc[12:16]) if self.want_reg else 0, _p(self.face_mask), B, V, self.uv.shape[0], F, H, W,
                                              _p(self.texc), _p(self.texd), _p(self.d_albedo), _p(g["d_clip"]), _p(g["d_vn"]), 0,
-                                             _p(self.def_work), self.def_work.numel(), _p(self.texbin_work) if self.tb_fused else 0, st),
+                                             _p(self.def_work), self.def_work.numel(), _p(self.texbin_work) if self.tb_fused else 0,
+                                           _p(self.tile_ids) if self.tb_ids else 0, st),
                  "vhap_deferred_gbuffer_bwd")
             return
         if self.deferred:
@@ -527,7 +536,8 @@ class NativeStep:
                                            _p(self.keep) if self.disturb_on else 0, _p(self.c_reg) if self.want_reg else 0,
                                            _p(acc[12:16]) if self.want_reg else 0, B, V, self.uv.shape[0], F, H, W, _p(self.texc), _p(self.texd),
                                            _p(self.d_albedo), _p(self.d_normal), _p(self.d_texc), _p(self.d_texd), 0,
-                                           _p(self.def_work), self.def_work.numel(), _p(self.texbin_work) if self.tb_fused else 0, st),
+                                           _p(self.def_work), self.def_work.numel(), _p(self.texbin_work) if self.tb_fused else 0,
+                                           _p(self.tile_ids) if self.tb_ids else 0, st),
                  "vhap_deferred_shade_bwd")
             return
         _chk(L.vhap_shade_bwd(_p(self.normal), _p(self.albedo_px), _p(self.rast), _p(tr.lights), _p(self.sh_const), _p(self.d_color),
