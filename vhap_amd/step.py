@@ -293,20 +293,21 @@ class NativeStep:
         so = tr.static_offset
         tex_ready = None
         early_tex = self.photometric and self.deferred and self.overlap
-        # the camera and the per-frame stage first: tiny latency-bound launches that take 3-5x as long next to the texture branch below
-        self._camera_forward()
-        _chk(L.vhap_frame_prep_fwd(_p(self.ts), _p(tr.shape), _p(tr.expr), _p(tr.rotation), _p(tr.translation), _p(tr.neck_pose),
-                                   _p(tr.jaw_pose), _p(tr.eyes_pose), _p(fm.JT), _p(fm.JS), _p(fm.jreg_idx), _p(fm.jreg_w), fm.jreg_n,
-                                   _p(so), fm.parents, self.weights, B, self.Bp, self.N, self.NS, self.NE, J, fb.Kp, V,
-                                   _p(self.coef), _p(self.A), _p(self.transl), _p(self.Jrest), _p(acc), PRE, st), "vhap_frame_prep_fwd")
         if early_tex:
-            # deferred shading: the rasteriser itself samples the texture, so the texture assembly + pyramid (~75 us, bandwidth-bound) must be
-            # ready when the geometry chain (skinning -> normals / binning) is: start it here on the side branch
+            # deferred shading: the rasteriser itself samples the texture, so the texture assembly + pyramid (~75 us, bandwidth-bound) heads the
+            # critical path together with the geometry chain: start it at once on the side branch.  (Measured alternatives: forked after the
+            # per-frame stage, the skinning kernel -- 27 MB of basis -- runs 70 us instead of 26 next to the texture assembly and the
+            # rasteriser starts 25 us later; forked after the skinning, the rasteriser waits for the pyramid.)
             self._fork()
             with self._branch():
                 self._tex_forward()
                 tex_ready = torch.cuda.Event()
                 tex_ready.record()
+        self._camera_forward()
+        _chk(L.vhap_frame_prep_fwd(_p(self.ts), _p(tr.shape), _p(tr.expr), _p(tr.rotation), _p(tr.translation), _p(tr.neck_pose),
+                                   _p(tr.jaw_pose), _p(tr.eyes_pose), _p(fm.JT), _p(fm.JS), _p(fm.jreg_idx), _p(fm.jreg_w), fm.jreg_n,
+                                   _p(so), fm.parents, self.weights, B, self.Bp, self.N, self.NS, self.NE, J, fb.Kp, V,
+                                   _p(self.coef), _p(self.A), _p(self.transl), _p(self.Jrest), _p(acc), PRE, st), "vhap_frame_prep_fwd")
         if self.photometric:                                      # skinning fused with the world -> clip transform (one launch, same bits)
             _chk(L.vhap_flame_skin_clip_fwd(_p(self.coef), _p(fb.basis), _p(self.A), _p(fb.w), _p(fb.templ), _p(so), _p(self.transl), _p(self.mvp),
                                             B, V, fb.Vp, fb.K, fb.Kb, fb.Kp, _p(self.verts), _p(self.v_shaped), _p(self.v_posed), _p(self.clip), st),
