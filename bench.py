@@ -284,12 +284,16 @@ def main():
 
     run = step if step is not None else (lambda: tr.optimize_iter(dict(sample), optimizer, STAGE))
     per_call = step.unroll if step is not None else 1
-    for _ in range(args.warmup // per_call):
-        run()
+    import contextlib
+    loop_ctx = step.replay_stream if step is not None else contextlib.nullcontext       # (as GlobalTracker.optimize_stage replays its steps)
+    with loop_ctx():
+        for _ in range(args.warmup // per_call):
+            run()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps // per_call):
-        run()
+    with loop_ctx():
+        for _ in range(args.steps // per_call):
+            run()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:

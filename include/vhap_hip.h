@@ -339,6 +339,17 @@ int vhap_flame_skin_bwd(const float* d_verts, const float* d_vshaped, const floa
                         int Vp, int Kb, int Kp, float* g_posed, float* g_shaped, float* partials,
                         float* d_coef, float* d_A, float* d_transl, int call_flags,
                         vhap_stream_t stream);
+/* The vertex stage of the backward in one call (three launches instead of seven): vhap_vnormal_bwd_saved + vhap_transform_bwd +
+ * vhap_flame_skin_bwd + vhap_sum_frames.  The gradient w.r.t. the world-space vertices is assembled in registers from d_verts_in [B,V,3]
+ * (may be NULL: e.g. the landmark part), the vertex-normal backward of d_vn and M^T d_clip, and chained through the skinning backward
+ * without being written back.  d_A / d_transl / d_mvp [B,16] (may be NULL) / d_offset [V,3] (may be NULL: sum over frames of g_shaped)
+ * are ACCUMULATED; g_posed / g_shaped / d_coef as vhap_flame_skin_bwd (VHAP_CALL_ACC_PREZEROED applies to d_coef); scratch [B,V,3]. */
+int vhap_verts_bwd_fused(const float* verts, const int32_t* tri, const int32_t* vc_ptr, const int32_t* vc_idx,
+                         const float* vn, const float* inv_len, const float* d_vn, const float* mvp,
+                         const float* d_clip, const float* d_verts_in, const float* v_posed, const float* A,
+                         const float* lbs_weights, const float* basisT, int B, int V, int Vp, int Kb, int Kp,
+                         float* scratch, float* g_posed, float* g_shaped, float* d_coef, float* d_A,
+                         float* d_transl, float* d_mvp, float* d_offset, int call_flags, vhap_stream_t stream);
 /* clip [B,V,4] = [verts;1] @ M^T, M [B,4,4]; backward: d_verts (= or += when accumulate), d_M ACCUMULATED */
 int vhap_transform_fwd(const float* verts, const float* M, int B, int V, float* clip,
                        vhap_stream_t stream);

@@ -134,6 +134,7 @@ def test_deferred_step_matches_separate_pass_step(flame_model, monkeypatch):
         monkeypatch.setenv("VHAP_DEFERRED", "0" if mode == "0" else "1")
         monkeypatch.setenv("VHAP_FUSED_BWD", "1" if mode == "2" else "0")
         monkeypatch.setenv("VHAP_AA_INPLACE", "1" if mode == "3" else "0")
+        monkeypatch.setenv("VHAP_VERTS_BWD_FUSED", "0" if mode == "0" else "1")      # (the fused vertex-stage backward vs its four separate launches)
         tr = _tracker(flame_model, B, H, W, T, seed=7, disturb=False)
         tr.get_train_parameters(stage)
         ns = NativeStep(tr, tr.get_sample(np.arange(B), device_index=True), stage)

@@ -64,6 +64,7 @@ SIGNATURES = {
     "vhap_flame_skin_clip_fwd": (c_i, [c_fp] * 8 + [c_i] * 6 + [c_fp] * 5),
     "vhap_flame_bwd_partial_floats": (c_sz, [c_i] * 3),
     "vhap_flame_skin_bwd": (c_i, [c_fp] * 6 + [c_i] * 5 + [c_fp] * 6 + [c_i, c_fp]),
+    "vhap_verts_bwd_fused": (c_i, [c_fp] * 14 + [c_i] * 5 + [c_fp] * 8 + [c_i, c_fp]),
     "vhap_transform_fwd": (c_i, [c_fp, c_fp, c_i, c_i, c_fp, c_fp]),
     "vhap_transform_bwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
     "vhap_vnormal_fwd": (c_i, [c_fp] * 4 + [c_i, c_i, c_fp, c_fp]),

@@ -363,6 +363,107 @@ __global__ __launch_bounds__(256) void vnormal_bwd2_kernel(const float* __restri
     else { d_verts[o] = sx; d_verts[o + 1] = sy; d_verts[o + 2] = sz; }
 }
 
+// ---- the vertex stage of the backward in ONE launch: gradient w.r.t. the world-space vertices assembled in registers from its three
+// sources -- what already sits in d_verts (landmarks), the second pass of the vertex-normal backward (CSR gather over incident faces)
+// and the clip transform's backward M^T d_clip -- and chained at once through the skinning backward (g_posed, g_shaped, d_A, d_transl)
+// and the per-vertex sum over frames for the shared static offset.  Replaces vnormal_bwd2 + transform_bwd + flame_skin_bwd + sum_frames
+// (four dependent latency-bound launches over 82 k vertices) and never writes d_verts back.  The 16 + 63 per-frame sums (d_M, d_A,
+// d_transl) are reduced per row of 16 lanes with DPP adds and finished through LDS.  grid (ceil(V/256), B).
+constexpr int VB_NRED = 16 + NJ * 12 + 3;
+__global__ __launch_bounds__(256) void verts_bwd_fused_kernel(const float* __restrict__ verts, const int* __restrict__ tri,
+                                                              const int* __restrict__ vc_ptr, const int* __restrict__ vc_idx,
+                                                              const float* __restrict__ d_nraw, const float* __restrict__ M,
+                                                              const float4* __restrict__ d_clip, const float* __restrict__ d_verts_in,
+                                                              const float* __restrict__ v_posed, const float* __restrict__ A,
+                                                              const float* __restrict__ w, int V, float* __restrict__ g_posed,
+                                                              float* __restrict__ g_shaped, float* __restrict__ d_A,
+                                                              float* __restrict__ d_transl, float* __restrict__ d_M,
+                                                              float* __restrict__ d_offset) {
+    __shared__ float sA[NJ * 12], sM[16];
+    __shared__ float red[16][VB_NRED];
+    const int b = blockIdx.y, v = blockIdx.x * 256 + threadIdx.x;
+    if (threadIdx.x < NJ * 12) sA[threadIdx.x] = A[(size_t)b * NJ * 12 + threadIdx.x];
+    if (threadIdx.x >= 64 && threadIdx.x < 80) sM[threadIdx.x - 64] = M[(size_t)b * 16 + threadIdx.x - 64];
+    __syncthreads();
+    float acc[VB_NRED];
+#pragma unroll
+    for (int i = 0; i < VB_NRED; i++) acc[i] = 0.f;
+    if (v < V) {
+        const float* P = verts + (size_t)b * V * 3;
+        const float* G = d_nraw + (size_t)b * V * 3;
+        const size_t o = ((size_t)b * V + v) * 3;
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+        if (d_verts_in) { gx = d_verts_in[o]; gy = d_verts_in[o + 1]; gz = d_verts_in[o + 2]; }
+        // vertex-normal backward, pass 2 (see vnormal_bwd2_kernel)
+        for (int k = vc_ptr[v]; k < vc_ptr[v + 1]; k++) {
+            const int c = vc_idx[k], t = c / 3, i = c - 3 * t;
+            const int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
+            const float hx = G[3 * i0] + G[3 * i1] + G[3 * i2], hy = G[3 * i0 + 1] + G[3 * i1 + 1] + G[3 * i2 + 1],
+                        hz = G[3 * i0 + 2] + G[3 * i1 + 2] + G[3 * i2 + 2];
+            const float ax = P[3 * i1] - P[3 * i0], ay = P[3 * i1 + 1] - P[3 * i0 + 1], az = P[3 * i1 + 2] - P[3 * i0 + 2];
+            const float bx = P[3 * i2] - P[3 * i0], by = P[3 * i2 + 1] - P[3 * i0 + 1], bz = P[3 * i2 + 2] - P[3 * i0 + 2];
+            const float d1x = by * hz - bz * hy, d1y = bz * hx - bx * hz, d1z = bx * hy - by * hx;   // e2 x g
+            const float d2x = hy * az - hz * ay, d2y = hz * ax - hx * az, d2z = hx * ay - hy * ax;   // g x e1
+            if (i == 0) { gx -= d1x + d2x; gy -= d1y + d2y; gz -= d1z + d2z; }
+            else if (i == 1) { gx += d1x; gy += d1y; gz += d1z; }
+            else { gx += d2x; gy += d2y; gz += d2z; }
+        }
+        // clip transform backward (see transform_bwd_kernel)
+        const float4 gc = d_clip[(size_t)b * V + v];
+        gx += sM[0] * gc.x + sM[4] * gc.y + sM[8] * gc.z + sM[12] * gc.w;
+        gy += sM[1] * gc.x + sM[5] * gc.y + sM[9] * gc.z + sM[13] * gc.w;
+        gz += sM[2] * gc.x + sM[6] * gc.y + sM[10] * gc.z + sM[14] * gc.w;
+        {
+            const float x = P[3 * v], y = P[3 * v + 1], z = P[3 * v + 2];
+            const float gg[4] = {gc.x, gc.y, gc.z, gc.w};
+#pragma unroll
+            for (int r = 0; r < 4; r++) { acc[4 * r] = gg[r] * x; acc[4 * r + 1] = gg[r] * y; acc[4 * r + 2] = gg[r] * z; acc[4 * r + 3] = gg[r]; }
+        }
+        // skinning backward (see flame_skin_bwd_kernel)
+        const float px = v_posed[o], py = v_posed[o + 1], pz = v_posed[o + 2];
+        float wj[NJ], T[12];
+#pragma unroll
+        for (int j = 0; j < NJ; j++) wj[j] = w[(size_t)v * NJ + j];
+#pragma unroll
+        for (int q = 0; q < 12; q++) {
+            float s_ = 0.f;
+#pragma unroll
+            for (int j = 0; j < NJ; j++) s_ += wj[j] * sA[j * 12 + q];
+            T[q] = s_;
+        }
+        const float hx = T[0] * gx + T[4] * gy + T[8] * gz;
+        const float hy = T[1] * gx + T[5] * gy + T[9] * gz;
+        const float hz = T[2] * gx + T[6] * gy + T[10] * gz;
+        g_posed[o] = hx; g_posed[o + 1] = hy; g_posed[o + 2] = hz;
+        g_shaped[o] = hx; g_shaped[o + 1] = hy; g_shaped[o + 2] = hz;
+        if (d_offset) {                          // shared static offset: sum over the frames (16-way atomics per component)
+            atomicAdd(&d_offset[3 * v], hx); atomicAdd(&d_offset[3 * v + 1], hy); atomicAdd(&d_offset[3 * v + 2], hz);
+        }
+        const float dT[12] = {gx * px, gx * py, gx * pz, gx, gy * px, gy * py, gy * pz, gy, gz * px, gz * py, gz * pz, gz};
+#pragma unroll
+        for (int j = 0; j < NJ; j++)
+#pragma unroll
+            for (int q = 0; q < 12; q++) acc[16 + j * 12 + q] = wj[j] * dT[q];
+        acc[16 + NJ * 12] = gx; acc[16 + NJ * 12 + 1] = gy; acc[16 + NJ * 12 + 2] = gz;
+    }
+    vhap_row_sums_dpp<VB_NRED>(acc);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if ((lane & 15) == 0) {
+#pragma unroll
+        for (int i = 0; i < VB_NRED; i++) red[wave * 4 + (lane >> 4)][i] = acc[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < VB_NRED) {
+        float s_ = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) s_ += red[r][threadIdx.x];
+        const int i = threadIdx.x;
+        if (i < 16) { if (d_M) atomicAdd(&d_M[(size_t)b * 16 + i], s_); }
+        else if (i < 16 + NJ * 12) atomicAdd(&d_A[(size_t)b * NJ * 12 + i - 16], s_);
+        else atomicAdd(&d_transl[(size_t)b * 3 + i - 16 - NJ * 12], s_);
+    }
+}
+
 }  // namespace
 
 extern "C" int vhap_flame_skin_fwd(const float* coef, const float* basis, const float* A, const float* lbs_weights,
@@ -411,6 +512,35 @@ extern "C" int vhap_flame_skin_bwd(const float* d_verts, const float* d_vshaped,
                                                                       d_A, d_transl);
     VHAP_LAUNCH_CHECK();
     (void)partials;                                  // (kept in the signature; the split-K sums go through atomics now)
+    const int ntiles = Kp / 16, btiles = (B + 15) / 16;
+    VHAP_ZERO_ACC(d_coef, sizeof(float) * (size_t)btiles * 16 * Kp, st);
+    int S = 768 / (ntiles * btiles);                 // ~768 workgroups in flight
+    S = S < 1 ? 1 : S;
+    int v_per_wave = (V + S * 4 - 1) / (S * 4);
+    v_per_wave = (v_per_wave + 3) / 4 * 4;           // whole 4-vertex MFMA steps
+    S = (V + v_per_wave * 4 - 1) / (v_per_wave * 4);
+    flame_coef_bwd_kernel<<<dim3(ntiles, S, btiles), 256, 0, st>>>(g_shaped, g_posed, basisT, B, V, Vp, Kb, Kp, v_per_wave, d_coef);
+    VHAP_LAUNCH_CHECK();
+    return VHAP_OK;
+}
+
+extern "C" int vhap_verts_bwd_fused(const float* verts, const int32_t* tri, const int32_t* vc_ptr, const int32_t* vc_idx, const float* vn,
+                                    const float* inv_len, const float* d_vn, const float* mvp, const float* d_clip, const float* d_verts_in,
+                                    const float* v_posed, const float* A, const float* lbs_weights, const float* basisT, int B, int V, int Vp,
+                                    int Kb, int Kp, float* scratch, float* g_posed, float* g_shaped, float* d_coef, float* d_A,
+                                    float* d_transl, float* d_mvp, float* d_offset, int call_flags, vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!verts || !tri || !vc_ptr || !vc_idx || !vn || !inv_len || !d_vn || !mvp || !d_clip || !v_posed || !A || !lbs_weights || !basisT ||
+        !scratch || !g_posed || !g_shaped || !d_coef || !d_A || !d_transl)
+        return VHAP_E_NULLPTR;
+    if (B <= 0 || V <= 0 || B > 65535 || Vp < V || Vp % 64 || Kb % 16 || Kp % 16 || Kp / 16 > 32) return VHAP_E_BADDIM;
+    hipStream_t st = vhap_stream(stream);
+    vnormal_bwd1_saved_kernel<<<vhap_cdiv((long long)B * V, 256), 256, 0, st>>>(vn, inv_len, d_vn, B * V, scratch);
+    VHAP_LAUNCH_CHECK();
+    verts_bwd_fused_kernel<<<dim3(vhap_cdiv(V, 256), B), 256, 0, st>>>(verts, tri, vc_ptr, vc_idx, scratch, mvp, reinterpret_cast<const float4*>(d_clip),
+                                                                       d_verts_in, v_posed, A, lbs_weights, V, g_posed, g_shaped, d_A, d_transl,
+                                                                       d_mvp, d_offset);
+    VHAP_LAUNCH_CHECK();
     const int ntiles = Kp / 16, btiles = (B + 15) / 16;
     VHAP_ZERO_ACC(d_coef, sizeof(float) * (size_t)btiles * 16 * Kp, st);
     int S = 768 / (ntiles * btiles);                 // ~768 workgroups in flight

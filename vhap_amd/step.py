@@ -606,11 +606,30 @@ class NativeStep:
                  "vhap_gbuffer_bwd")
         if early is not None:
             torch.cuda.current_stream().wait_event(early)
-        _chk(L.vhap_vnormal_bwd_saved(_p(self.verts), _p(self.csr.tri), _p(self.csr.ptr), _p(self.csr.idx), _p(self.vn), _p(self.vn_inv),
-                                      _p(g["d_vn"]), B, V, 1, _p(self.vn_scratch), _p(g["d_verts"]), st), "vhap_vnormal_bwd_saved")
-        _chk(L.vhap_transform_bwd(_p(self.verts), _p(self.mvp), _p(g["d_clip"]), B, V, 1, _p(g["d_verts"]), _p(self.d_mvp), st),
-             "vhap_transform_bwd")
-        self._bwd_params()
+        if os.environ.get("VHAP_VERTS_BWD_FUSED", "1") == "0":
+            _chk(L.vhap_vnormal_bwd_saved(_p(self.verts), _p(self.csr.tri), _p(self.csr.ptr), _p(self.csr.idx), _p(self.vn), _p(self.vn_inv),
+                                          _p(g["d_vn"]), B, V, 1, _p(self.vn_scratch), _p(g["d_verts"]), st), "vhap_vnormal_bwd_saved")
+            _chk(L.vhap_transform_bwd(_p(self.verts), _p(self.mvp), _p(g["d_clip"]), B, V, 1, _p(g["d_verts"]), _p(self.d_mvp), st),
+                 "vhap_transform_bwd")
+            self._bwd_params()
+            return
+        # vertex-normal / clip-transform / skinning backward + offset sum in one kernel (+ the split-K coefficient GEMM), then the tiny
+        # camera chain and the per-frame parameters
+        tr, fb, fm = self.tr, self.fb, self.fm
+        J = self.J
+        _chk(L.vhap_verts_bwd_fused(_p(self.verts), _p(self.csr.tri), _p(self.csr.ptr), _p(self.csr.idx), _p(self.vn), _p(self.vn_inv), _p(g["d_vn"]),
+                                    _p(self.mvp), _p(g["d_clip"]), _p(g["d_verts"]), _p(self.v_posed), _p(self.A), _p(fb.w), _p(fb.basisT), B, V,
+                                    fb.Vp, fb.Kb, fb.Kp, _p(self.vn_scratch), _p(self.g_posed), _p(self.g_shaped), _p(g["d_coef"]), _p(g["d_A"]),
+                                    _p(g["d_t"]), _p(self.d_mvp), _p(g["static_offset"]) if self.has_offset else 0, PRE, st), "vhap_verts_bwd_fused")
+        if not self.calibrated:
+            _chk(L.vhap_camera_bwd(_p(self.RT), _p(self.d_mvp), B, 0, H, W, _p(self.d_K), st), "vhap_camera_bwd")
+            _chk(L.vhap_focal_bwd(_p(self.d_K), B, self.focal_scale, _p(g["focal_length"]), st), "vhap_focal_bwd")
+        _chk(L.vhap_frame_prep_bwd(_p(self.ts), _p(tr.shape), _p(tr.expr), _p(tr.rotation), _p(tr.translation), _p(tr.neck_pose),
+                                   _p(tr.jaw_pose), _p(tr.eyes_pose), _p(fm.JS), _p(fm.jreg_idx), _p(fm.jreg_w), fm.jreg_n,
+                                   _p(tr.static_offset), fm.parents, self.weights, _p(self.Jrest), _p(g["d_coef"]), _p(g["d_A"]), _p(g["d_t"]),
+                                   _p(self.ones), B, self.Bp, self.N, self.NS, self.NE, J, fb.Kp, V, _p(g["shape"]), _p(g["expr"]),
+                                   _p(g["rotation"]), _p(g["translation"]), _p(g["neck_pose"]), _p(g["jaw_pose"]), _p(g["eyes_pose"]),
+                                   _p(g["static_offset"]) if self.has_offset else 0, st), "vhap_frame_prep_bwd")
 
     def backward(self, world_size=1, part="all", optimizer=None):
         """part = 'all': the whole backward as one two-branch DAG (one GPU).  Under frame sharding the backward is captured in two

@@ -740,8 +740,9 @@ class GlobalTracker(FlameTracker):
                 _reset_optimizer(st.opt)
             st.fresh = False
             n = self.cfg.pipeline[stage].num_steps if num_steps is None else num_steps
-            for _ in range(n):
-                st()
+            with st.replay_stream():                                  # back-to-back replays on the step's own stream: no stream hop per step
+                for _ in range(n):
+                    st()
             return st.opt
         assert dataloader is not None
         opt, sched = None, None
@@ -756,7 +757,8 @@ class GlobalTracker(FlameTracker):
                         grp["lr"] = grp["initial_lr"] if "initial_lr" in grp else grp["lr"]
                     sched = torch.optim.lr_scheduler.ExponentialLR(opt, gamma=0.9)
                 st.fresh = False
-                st()
+                with st.replay_stream():
+                    st()
             sched.step()
             if evaluate_every and (epoch_i + 1) % evaluate_every == 0:
                 self.evaluate()
@@ -1113,6 +1115,26 @@ class GraphedStep:
             self._replay()
         self.tr.global_step += self.unroll
         return self.E
+
+    def replay_stream(self):
+        """Context for a loop of replays: makes the step's private stream current (after it has caught up with the caller's stream), so that
+        consecutive replays are enqueued back to back instead of hopping null stream -> private stream -> null stream every step (two
+        cross-stream event waits, ~10-15 us of GPU idle per step); on exit the caller's stream waits for the step's."""
+        step = self
+
+        class _Ctx:
+            def __enter__(self):
+                self.cur = torch.cuda.current_stream()
+                step.stream.wait_stream(self.cur)
+                self.ctx = torch.cuda.stream(step.stream)
+                self.ctx.__enter__()
+                return step
+
+            def __exit__(self, *a):
+                self.ctx.__exit__(*a)
+                self.cur.wait_stream(step.stream)
+                return False
+        return _Ctx()
 
     def _replay(self):
         tr = self.tr
