@@ -109,13 +109,15 @@ int vhap_raster_bwd(const float* pos, const int32_t* tri, const float* rast, con
  *   fid2cid [nfid] (index = triangle id + 1) / cid [B,H,W] uint8: optional
  *   rast [B,H,W,4] as vhap_raster_fwd; rgba [B,H,W,4] renderer space (row 0 = bottom): shaded colour, alpha = coverage
  *   stats (4 words, may be NULL): as vhap_shade_fwd, OVERWRITTEN (a tiny second launch reduces per-wave partials kept in `workspace`)
+ *   tile_ids [B,H,W] uint16 (may be NULL): the uv tile of vhap_texture_grad_binned each covered pixel samples, 0xFFFF on the background --
+ *   lets the texture-gradient sort run during the forward pass (vhap_texbin_sort_ids), off the backward's critical path
  * With VHAP_RASTER_BIN_ONLY only pos / tri / uv / tri_uv / the dimensions / workspace are used. */
 int vhap_raster_shade_fwd(const float* pos, const int32_t* tri, const float* vnormal, const float* uv,
                           const int32_t* tri_uv, const float* tex, const float* mips, int Ht, int Wt,
                           const float* lights, const float* sh_const, const float* bg_image,
                           const float* bg_color, const int32_t* fid2cid, int nfid, int B, int V, int VT,
                           int F, int H, int W, float* rast, float* rgba, uint8_t* cid, float* stats,
-                          void* workspace, size_t workspace_bytes, size_t pair_capacity, int flags,
+                          uint16_t* tile_ids, void* workspace, size_t workspace_bytes, size_t pair_capacity, int flags,
                           vhap_stream_t stream);
 /* Backward of the shading part of vhap_raster_shade_fwd (everything between the interpolated attributes and rgba): per covered pixel the
  * normal / uv / uv derivatives are re-computed from (rast, geometry) with the forward's arithmetic, the texture is re-sampled, and the
@@ -236,6 +238,14 @@ int vhap_texture_grad_binned(int Ht, int Wt, int C, const float* uv, const float
 int vhap_texture_grad_binned_ids(int Ht, int Wt, int C, const float* uv, const float* uv_da, const float* d_out,
                                  const uint16_t* tile_ids, int B, int H, int W, float* d_tex, float* d_mips,
                                  void* work, size_t work_bytes, vhap_stream_t stream);
+/* The sort and the accumulation as two calls: vhap_texbin_sort_ids counting-sorts the pixels by their uv tile (tile_ids from
+ * vhap_raster_shade_fwd) into `work` without looking at any gradient -- it can run during the forward pass -- and
+ * vhap_texture_grad_binned_sorted then only accumulates d_out through the sorted lists (one launch). */
+int vhap_texbin_sort_ids(const uint16_t* tile_ids, int Ht, int Wt, int B, int H, int W, void* work, size_t work_bytes,
+                         vhap_stream_t stream);
+int vhap_texture_grad_binned_sorted(int Ht, int Wt, int C, const float* uv, const float* uv_da, const float* d_out,
+                                    int B, int H, int W, float* d_tex, float* d_mips, const void* work,
+                                    size_t work_bytes, vhap_stream_t stream);
 /* same, for a `work` whose tile histogram was already filled in by vhap_deferred_shade_bwd(texbin_work = work): skips the count pass */
 int vhap_texture_grad_binned_counted(int Ht, int Wt, int C, const float* uv, const float* uv_da,
                                      const float* d_out, int B, int H, int W, float* d_tex, float* d_mips,

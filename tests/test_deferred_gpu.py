@@ -67,7 +67,7 @@ def test_deferred_kernels_match_the_separate_passes(flame_model, monkeypatch, B,
         return L.vhap_raster_shade_fwd(_p(ns.clip), _p(ns.tri), _p(ns.vn), _p(ns.uv), _p(ns.tri_uv), _p(ns.albedo_tex), _p(ns.mips), T, T,
                                        _p(tr.lights), _p(ns.sh_const), _p(ns.rgb) if bgc is None else 0,
                                        ctypes.cast(bgc, ctypes.c_void_p) if bgc is not None else 0, _p(ns.fid2cid), ns.fid2cid.numel(),
-                                       B, V, ns.uv.shape[0], F, H, W, _p(rast), _p(rgba), _p(cid), _p(stats), _p(ns.ws), ns.ws_bytes,
+                                       B, V, ns.uv.shape[0], F, H, W, _p(rast), _p(rgba), _p(cid), _p(stats), 0, _p(ns.ws), ns.ws_bytes,
                                        ns.ws_cap, flags, _stream())
     assert shade_fwd(1, rast, rgba, cid, stats) == 0
     torch.cuda.synchronize()

@@ -47,7 +47,7 @@ def raster(flags):
                                    _p(tr.lights), _p(ns.sh_const), _p(ns.rgb) if ns.bg_col is None else 0,
                                    ctypes.cast(ns.bg_col, ctypes.c_void_p) if ns.bg_col is not None else 0,
                                    _p(ns.fid2cid) if ns.disturb_on else 0, ns.fid2cid.numel() if ns.disturb_on else 0, B, V, ns.uv.shape[0], F, H, W,
-                                   _p(ns.rast), _p(ns.rgba), _p(ns.cid) if ns.disturb_on else 0, _p(acc[12:16]) if ns.want_reg else 0, _p(ns.ws),
+                                   _p(ns.rast), _p(ns.rgba), _p(ns.cid) if ns.disturb_on else 0, _p(acc[12:16]) if ns.want_reg else 0, 0, _p(ns.ws),
                                    ns.ws_bytes, ns.ws_cap, flags, st())
 
 

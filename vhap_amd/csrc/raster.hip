@@ -346,6 +346,8 @@ struct RasterParams {
     float* rgba;              // [B,H,W,4] shaded + composited colour
     unsigned char* cid;       // [B,H,W] or null
     uint4* stats_part;        // per-wave partials of the diffuse-regulariser statistics ((max << 32 | ties) lo, hi, var sum, -) or null
+    unsigned short* tile_ids; // [B,H,W] or null: uv tile of the texture-gradient binning (texbin) each pixel samples, 0xFFFF = background
+    int NT;
     unsigned long long* prof; // VHAP_RASTER_PROFILE: (first start, last end) stamps of this kernel, PROF_SLOTS pairs; or null
 };
 
@@ -611,6 +613,7 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterParams P) {
             reinterpret_cast<float4*>(P.rast)[pidx] = o_rast;
             reinterpret_cast<float4*>(P.rgba)[pidx] = o_rgba;
             if (P.cid) P.cid[pidx] = (unsigned char)P.fid2cid[min(max((int)o_rast.w, 0), P.nfid - 1)];
+            if (P.tile_ids) P.tile_ids[pidx] = (unsigned short)(cov ? tile_of(make_float2(at.tu, at.tv), P.NT) : 0xFFFF);
             if (P.stats_part) {
                 const float mean = (d[0] + d[1] + d[2]) * (1.0f / 3.0f);
                 var = 0.5f * ((d[0] - mean) * (d[0] - mean) + (d[1] - mean) * (d[1] - mean) + (d[2] - mean) * (d[2] - mean));
@@ -892,7 +895,7 @@ extern "C" int vhap_raster_interp_fwd(const float* pos, const int32_t* tri, cons
 extern "C" int vhap_raster_shade_fwd(const float* pos, const int32_t* tri, const float* vnormal, const float* uv, const int32_t* tri_uv,
                                      const float* tex, const float* mips, int Ht, int Wt, const float* lights, const float* sh_const,
                                      const float* bg_image, const float* bg_color, const int32_t* fid2cid, int nfid, int B, int V,
-                                     int VT, int F, int H, int W, float* rast, float* rgba, uint8_t* cid, float* stats,
+                                     int VT, int F, int H, int W, float* rast, float* rgba, uint8_t* cid, float* stats, uint16_t* tile_ids,
                                      void* workspace, size_t workspace_bytes, size_t pair_capacity, int flags, vhap_stream_t stream) {
     VHAP_ENTER();
     const bool bin_only = (flags & VHAP_RASTER_BIN_ONLY) != 0;
@@ -905,6 +908,7 @@ extern "C" int vhap_raster_shade_fwd(const float* pos, const int32_t* tri, const
     P.pos = pos; P.tri = tri; P.vnormal = vnormal; P.uv = uv; P.tri_uv = tri_uv;
     P.B = B; P.V = V; P.VT = VT; P.F = F; P.H = H; P.W = W;
     P.rast = rast; P.rgba = rgba; P.cid = cid; P.fid2cid = fid2cid; P.nfid = nfid;
+    P.tile_ids = tile_ids; P.NT = texbin_nt(Ht, Wt);
     P.tex = tex; P.mips = mips; P.D = make_desc(1, Ht, Wt, 3);
     if (P.D.L > 0 && !mips && !bin_only) return VHAP_E_NULLPTR;
     P.lights = lights; P.sh_const = sh_const; P.bg_image = bg_image;

@@ -534,7 +534,7 @@ __global__ __launch_bounds__(256) void texbin_pass_kernel(const float2* __restri
             if (tl != 0xFFFF) {
                 tile[k] = tl;
                 atomicAdd(&shc[tl], 1u);
-                if (!SCATTER) {
+                if (!SCATTER && d_out) {
                     float gmax = 0.f;
 #pragma unroll
                     for (int c = 0; c < C; c++) gmax = fmaxf(gmax, fabsf(d_out[p * C + c]));
@@ -561,7 +561,7 @@ __global__ __launch_bounds__(256) void texbin_pass_kernel(const float2* __restri
             shc[i] = 0u;
         } else {
             atomicAdd(&counts[i], c);
-            atomicMax(&tilemax[i], shb[i]);
+            if (tilemax) atomicMax(&tilemax[i], shb[i]);
         }
     }
     if (!SCATTER) return;
@@ -608,8 +608,28 @@ __global__ __launch_bounds__(256) void texgrad_tile_kernel(const TexDesc D, cons
     const unsigned beg = offsets[t], end = offsets[t + 1];
     if (beg == end) return;
     for (int i = tid; i < G.cells * C; i += 256) tg_vals[i] = 0ull;
+    __shared__ unsigned s_tmax;
+    unsigned tmax_bits;
+    if (tilemax) {
+        tmax_bits = tilemax[t];
+    } else {            // the list was sorted before the gradient existed (tile ids from the forward): find the tile's max |g| here
+        if (tid == 0) s_tmax = 0u;
+        __syncthreads();
+        float m = 0.f;
+        for (unsigned i = beg + tid; i < end; i += 256) {
+            const size_t p = list[i];
+#pragma unroll
+            for (int k = 0; k < C; k++) m = fmaxf(m, fabsf(d_out[p * C + k]));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if ((tid & 63) == 0) atomicMax(&s_tmax, __float_as_uint(m));
+        __syncthreads();
+        tmax_bits = s_tmax;
+        if (tmax_bits == 0u) return;         // nothing to add (uniform)
+    }
     int ex = 0;
-    (void)frexpf(__uint_as_float(tilemax[t]), &ex);
+    (void)frexpf(__uint_as_float(tmax_bits), &ex);
     const int sh = min(max(40 - ex, -100), 100);
     const float scale = ldexpf(1.0f, sh), inv_scale = ldexpf(1.0f, -sh);
     const int tx = t % G.NT, ty = t / G.NT;
@@ -943,4 +963,72 @@ extern "C" int vhap_texture_grad_binned_ids(int Ht, int Wt, int C, const float* 
                                             size_t work_bytes, vhap_stream_t stream) {
     if (!tile_ids) return VHAP_E_NULLPTR;
     return texture_grad_binned_impl(Ht, Wt, C, uv, uv_da, d_out, B, H, W, d_tex, d_mips, work, work_bytes, 0, stream, tile_ids);
+}
+
+// The sort and the accumulation as two calls, for a caller that knows every pixel's uv tile BEFORE the gradient exists (the deferred-shading
+// forward writes tile_ids): vhap_texbin_sort_ids counting-sorts the pixels by tile into `work` (three small launches, no dependence on
+// d_out -- it can run next to the rest of the forward pass), vhap_texture_grad_binned_sorted then only accumulates (one launch on the
+// backward's critical path instead of four); pixels of the lists whose gradient turns out to be zero add nothing.
+extern "C" int vhap_texbin_sort_ids(const uint16_t* tile_ids, int Ht, int Wt, int B, int H, int W, void* work, size_t work_bytes,
+                                    vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!tile_ids || !work) return VHAP_E_NULLPTR;
+    if (int e = check_tex(1, Ht, Wt, 3)) return e;
+    if (B <= 0 || H <= 0 || W <= 0) return VHAP_E_BADDIM;
+    const long long npix = (long long)B * H * W;
+    if (npix >= (1ll << 32)) return VHAP_E_BADDIM;
+    const TexDesc D = make_desc(1, Ht, Wt, 3);
+    const TileGeo G = make_tile_geo(D);
+    if ((Wt > Ht ? Wt : Ht) / G.NT > 32) return VHAP_E_UNSUPPORTED;
+    const TexBinWs l = texbin_layout(npix);
+    if (work_bytes < l.total) return VHAP_E_WORKSPACE;
+    char* w = static_cast<char*>(work);
+    unsigned* counts = reinterpret_cast<unsigned*>(w + l.counts);
+    unsigned* cursors = reinterpret_cast<unsigned*>(w + l.cursors);
+    unsigned* offsets = reinterpret_cast<unsigned*>(w + l.offsets);
+    unsigned* list = reinterpret_cast<unsigned*>(w + l.list);
+    const int nt2 = G.NT * G.NT;
+    hipStream_t st = vhap_stream(stream);
+    vhap_zero_async(w + l.counts, (size_t)TG_MAX_NT * TG_MAX_NT * 4, st);
+    VHAP_LAUNCH_CHECK();
+    const int nwg = vhap_cdiv(npix, 256 * TG_PPT);
+    const size_t hist = (size_t)2 * nt2 * sizeof(unsigned);
+    texbin_pass_kernel<3, false><<<nwg, 256, hist, st>>>(nullptr, nullptr, npix, G.NT, counts, nullptr, nullptr, nullptr, nullptr, tile_ids);
+    VHAP_LAUNCH_CHECK();
+    texbin_scan_kernel<<<1, 1024, 0, st>>>(counts, nt2, offsets, cursors);
+    VHAP_LAUNCH_CHECK();
+    texbin_pass_kernel<3, true><<<nwg, 256, hist, st>>>(nullptr, nullptr, npix, G.NT, nullptr, nullptr, offsets, cursors, list, tile_ids);
+    VHAP_LAUNCH_CHECK();
+    return VHAP_OK;
+}
+
+extern "C" int vhap_texture_grad_binned_sorted(int Ht, int Wt, int C, const float* uv, const float* uv_da, const float* d_out, int B, int H,
+                                               int W, float* d_tex, float* d_mips, const void* work, size_t work_bytes,
+                                               vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!uv || !d_out || !d_tex || !work) return VHAP_E_NULLPTR;
+    if (int e = check_tex(1, Ht, Wt, C)) return e;
+    if (B <= 0 || H <= 0 || W <= 0) return VHAP_E_BADDIM;
+    const long long npix = (long long)B * H * W;
+    const TexDesc D = make_desc(1, Ht, Wt, C);
+    if (uv_da && D.L > 0 && !d_mips) return VHAP_E_NULLPTR;
+    const TileGeo G = make_tile_geo(D);
+    const size_t lds = (size_t)G.cells * C * sizeof(unsigned long long);
+    if ((Wt > Ht ? Wt : Ht) / G.NT > 32 || lds > 64 * 1024) return VHAP_E_UNSUPPORTED;
+    const TexBinWs l = texbin_layout(npix);
+    if (work_bytes < l.total) return VHAP_E_WORKSPACE;
+    const char* w = static_cast<const char*>(work);
+    const unsigned* offsets = reinterpret_cast<const unsigned*>(w + l.offsets);
+    const unsigned* list = reinterpret_cast<const unsigned*>(w + l.list);
+    hipStream_t st = vhap_stream(stream);
+    return dispatch_C(C, [&](auto c) {
+        constexpr int CC = decltype(c)::value;
+        if (lds > 48 * 1024 &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(texgrad_tile_kernel<CC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return (int)VHAP_E_HIP;
+        texgrad_tile_kernel<CC><<<G.NT * G.NT, 256, lds, st>>>(D, G, reinterpret_cast<const float2*>(uv), reinterpret_cast<const float4*>(uv_da), d_out,
+                                                               offsets, list, nullptr, d_tex, d_mips);
+        VHAP_LAUNCH_CHECK();
+        return (int)VHAP_OK;
+    });
 }

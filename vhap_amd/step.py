@@ -382,7 +382,8 @@ class NativeStep:
                                            ctypes.cast(self.bg_col, ctypes.c_void_p) if self.bg_col is not None else 0,
                                            _p(self.fid2cid) if self.disturb_on else 0, self.fid2cid.numel() if self.disturb_on else 0,
                                            B, V, self.uv.shape[0], F, H, W, _p(self.rast), _p(self.rgba), _p(self.cid) if self.disturb_on else 0,
-                                           _p(acc[12:16]) if self.want_reg else 0, _p(self.ws), self.ws_bytes, self.ws_cap, flags, st)
+                                           _p(acc[12:16]) if self.want_reg else 0, _p(self.tile_ids) if self.tb_ids else 0, _p(self.ws),
+                                           self.ws_bytes, self.ws_cap, flags, st)
         _hook("raster_interp_fwd", "begin")
         prof = 8 if self.raster_profile else 0                    # VHAP_RASTER_PROFILE (bench.py: in-graph timing of the pass)
         split = self.overlap and self.bin_split
@@ -401,6 +402,13 @@ class NativeStep:
             self._join()
         _chk(raster(((1 | 4) if split else 1) | prof), "vhap_raster_shade_fwd")   # ... | VHAP_RASTER_PREBINNED
         _hook("raster_interp_fwd", "end")
+        if self.tb_ids:
+            # the counting sort of the pixels by uv tile (for the texture gradient) needs only the tile ids the rasteriser has just written:
+            # on the side branch NOW, next to the rest of the forward pass, instead of on the backward's critical path
+            self._fork()
+            with self._branch():
+                _chk(L.vhap_texbin_sort_ids(_p(self.tile_ids), T, T, B, H, W, _p(self.texbin_work), self.texbin_work.numel(), _stream()),
+                     "vhap_texbin_sort_ids")
         color = self.rgba
         if self.disturb_on:
             _chk(L.vhap_disturb_fwd_rng_cid(_p(self.rgba), _p(self.cid), self.ncl, float(self.rate_fg or 0.0), float(self.rate_bg or 0.0),
@@ -445,9 +453,9 @@ class NativeStep:
         if self.tb_fused:
             _chk(L.vhap_texture_grad_binned_counted(T, T, 3, _p(self.texc), _p(self.texd), _p(self.d_albedo), B, H, W, _p(d_tex), _p(d_mips),
                                                     _p(self.texbin_work), self.texbin_work.numel(), st), "vhap_texture_grad_binned_counted")
-        elif self.tb_ids:
-            _chk(L.vhap_texture_grad_binned_ids(T, T, 3, _p(self.texc), _p(self.texd), _p(self.d_albedo), _p(self.tile_ids), B, H, W, _p(d_tex),
-                                                _p(d_mips), _p(self.texbin_work), self.texbin_work.numel(), st), "vhap_texture_grad_binned_ids")
+        elif self.tb_ids:                                          # (sorted during the forward pass: only the accumulation is left)
+            _chk(L.vhap_texture_grad_binned_sorted(T, T, 3, _p(self.texc), _p(self.texd), _p(self.d_albedo), B, H, W, _p(d_tex), _p(d_mips),
+                                                   _p(self.texbin_work), self.texbin_work.numel(), st), "vhap_texture_grad_binned_sorted")
         elif not (NV.use_binned_texgrad() and NV.texture_grad_binned(T, 3, self.texc, self.texd, self.d_albedo, d_tex, d_mips, self.texbin_work)):
             _chk(L.vhap_texture_bwd(_p(self.albedo_tex), _p(self.mips), 1, T, T, 3, _p(self.texc), _p(self.texd), _p(self.d_albedo), B, H, W,
                                     _p(d_tex), _p(d_mips), 0, 0, st), "vhap_texture_bwd")
@@ -527,7 +535,7 @@ class NativeStep:
                                              _p(acc[12:16]) if self.want_reg else 0, _p(self.face_mask), B, V, self.uv.shape[0], F, H, W,
                                              _p(self.texc), _p(self.texd), _p(self.d_albedo), _p(g["d_clip"]), _p(g["d_vn"]), 0,
                                              _p(self.def_work), self.def_work.numel(), _p(self.texbin_work) if self.tb_fused else 0,
-                                           _p(self.tile_ids) if self.tb_ids else 0, st),
+                                           0, st),
                  "vhap_deferred_gbuffer_bwd")
             return
         if self.deferred:
@@ -538,7 +546,7 @@ class NativeStep:
                                            _p(acc[12:16]) if self.want_reg else 0, B, V, self.uv.shape[0], F, H, W, _p(self.texc), _p(self.texd),
                                            _p(self.d_albedo), _p(self.d_normal), _p(self.d_texc), _p(self.d_texd), 0,
                                            _p(self.def_work), self.def_work.numel(), _p(self.texbin_work) if self.tb_fused else 0,
-                                           _p(self.tile_ids) if self.tb_ids else 0, st),
+                                           0, st),
                  "vhap_deferred_shade_bwd")
             return
         _chk(L.vhap_shade_bwd(_p(self.normal), _p(self.albedo_px), _p(self.rast), _p(tr.lights), _p(self.sh_const), _p(self.d_color),
