@@ -240,12 +240,15 @@ int vhap_texture_grad_binned_ids(int Ht, int Wt, int C, const float* uv, const f
                                  void* work, size_t work_bytes, vhap_stream_t stream);
 /* The sort and the accumulation as two calls: vhap_texbin_sort_ids counting-sorts the pixels by their uv tile (tile_ids from
  * vhap_raster_shade_fwd) into `work` without looking at any gradient -- it can run during the forward pass -- and
- * vhap_texture_grad_binned_sorted then only accumulates d_out through the sorted lists (one launch). */
-int vhap_texbin_sort_ids(const uint16_t* tile_ids, int Ht, int Wt, int B, int H, int W, void* work, size_t work_bytes,
-                         vhap_stream_t stream);
+ * vhap_texture_grad_binned_sorted then only accumulates d_out through the sorted lists (one launch).
+ *   keep [B,H,W] (may be NULL): pixels with keep == 0 (their colour was replaced by the disturbance) are left out of the lists
+ *   gmax_bound (device scalar, may be NULL): an upper bound of |d_out| -- the fixed-point scale of the accumulation is then taken from it
+ *   (one scale for all tiles); without it every tile first scans its list for its own maximum. */
+int vhap_texbin_sort_ids(const uint16_t* tile_ids, const float* keep, int Ht, int Wt, int B, int H, int W, void* work,
+                         size_t work_bytes, vhap_stream_t stream);
 int vhap_texture_grad_binned_sorted(int Ht, int Wt, int C, const float* uv, const float* uv_da, const float* d_out,
                                     int B, int H, int W, float* d_tex, float* d_mips, const void* work,
-                                    size_t work_bytes, vhap_stream_t stream);
+                                    size_t work_bytes, const float* gmax_bound, vhap_stream_t stream);
 /* same, for a `work` whose tile histogram was already filled in by vhap_deferred_shade_bwd(texbin_work = work): skips the count pass */
 int vhap_texture_grad_binned_counted(int Ht, int Wt, int C, const float* uv, const float* uv_da,
                                      const float* d_out, int B, int H, int W, float* d_tex, float* d_mips,
@@ -536,6 +539,11 @@ int vhap_energy_finalize(const float* frame_terms, const float* lmk_energy, cons
                          float w_reg_diffuse, int B, int H, int W, float* log, vhap_stream_t stream);
 int vhap_energy_total(float* log, const float* photo2, const float* n_global, float w_photo, int world_size,
                       float* d_sum, vhap_stream_t stream);
+/* same; additionally gmax_bound[0] = 2 |d_sum| max(1, max(diffuse)) (shade_stats of vhap_shade_fwd / vhap_raster_shade_fwd, may be NULL
+ * -> 8 |d_sum|): an upper bound of the per-pixel albedo gradient |d_rgb * diffuse| including the antialiasing's colour part, for
+ * vhap_texture_grad_binned_sorted */
+int vhap_energy_total_bound(float* log, const float* photo2, const float* n_global, float w_photo, int world_size,
+                            float* d_sum, const float* shade_stats, float* gmax_bound, vhap_stream_t stream);
 /* out_accum[i] += sum_b x[b][i]  (x [B,n]) */
 int vhap_sum_frames(const float* x, int B, int n, float* out_accum, vhap_stream_t stream);
 /* d_focal_accum[0] += scale * sum_b (d_K[b][0] + d_K[b][1])   (K = (f, f, cx, cy), f = focal_length * scale) */

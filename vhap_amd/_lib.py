@@ -26,8 +26,9 @@ SIGNATURES = {
     "vhap_raster_fwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_sz, c_sz, c_i, c_fp]),
     "vhap_raster_interp_fwd": (c_i, [c_fp] * 5 + [c_i] * 6 + [c_fp] * 5 + [c_fp, c_sz, c_sz, c_i, c_fp]),
     "vhap_raster_shade_fwd": (c_i, [c_fp] * 7 + [c_i, c_i] + [c_fp] * 5 + [c_i] * 7 + [c_fp] * 5 + [c_fp, c_sz, c_sz, c_i, c_fp]),
-    "vhap_texbin_sort_ids": (c_i, [c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_sz, c_fp]),
-    "vhap_texture_grad_binned_sorted": (c_i, [c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_sz, c_fp]),
+    "vhap_texbin_sort_ids": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_sz, c_fp]),
+    "vhap_texture_grad_binned_sorted": (c_i, [c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_sz, c_fp, c_fp]),
+    "vhap_energy_total_bound": (c_i, [c_fp, c_fp, c_fp, c_f, c_i, c_fp, c_fp, c_fp, c_fp]),
     "vhap_deferred_shade_bwd_work_floats": (c_sz, [c_i] * 3),
     "vhap_deferred_lights_reduce": (c_i, [c_fp] * 5 + [c_i] * 3 + [c_fp, c_fp]),
     "vhap_deferred_shade_bwd": (c_i, [c_fp] * 7 + [c_i, c_i] + [c_fp] * 11 + [c_i] * 6 + [c_fp] * 8 + [c_sz, c_fp, c_fp, c_fp]),

@@ -35,7 +35,8 @@ __global__ void energy_finalize_kernel(const float* __restrict__ frame_terms, co
 
 // photo2 = (sum |gt - pred|, #(alpha > 0)) ; n_global = the alpha count summed over ranks (== photo2[1] on one GPU)
 __global__ void energy_total_kernel(float* __restrict__ log, const float* __restrict__ photo2, const float* __restrict__ n_global,
-                                    float w_photo, float world, float* __restrict__ d_sum) {
+                                    float w_photo, float world, float* __restrict__ d_sum, const unsigned* __restrict__ shade_stats,
+                                    float* __restrict__ gmax_bound) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     float photo = 0.f, g = 0.f;
     if (photo2) {
@@ -46,6 +47,11 @@ __global__ void energy_total_kernel(float* __restrict__ log, const float* __rest
     log[VHAP_LOG_PHOTO] = photo;
     log[VHAP_LOG_TOTAL] = log[VHAP_LOG_REST] + photo;
     if (d_sum) d_sum[0] = g;
+    if (gmax_bound) {
+        // |d albedo| = |d rgb| diffuse <= (|g| + antialias colour part <= |g|) max(diffuse); without the statistic: a generous constant
+        const float dmax = shade_stats ? fmaxf(decode_ordered(shade_stats[1]), 1.0f) : 4.0f;
+        gmax_bound[0] = 4.0f * fabsf(g) * dmax;      // (|d rgb| <= |g| + four antialias pairs x 0.5 |g|; 2^23 of fixed-point headroom on top)
+    }
 }
 
 __global__ __launch_bounds__(256) void sum_frames_kernel(const float* __restrict__ x, int B, int n, float* __restrict__ out) {
@@ -81,7 +87,17 @@ extern "C" int vhap_energy_total(float* log, const float* photo2, const float* n
                                  vhap_stream_t stream) {
     VHAP_ENTER();
     if (!log || (photo2 && !n_global)) return VHAP_E_NULLPTR;
-    energy_total_kernel<<<1, 64, 0, vhap_stream(stream)>>>(log, photo2, n_global, w_photo, (float)world_size, d_sum);
+    energy_total_kernel<<<1, 64, 0, vhap_stream(stream)>>>(log, photo2, n_global, w_photo, (float)world_size, d_sum, nullptr, nullptr);
+    VHAP_LAUNCH_CHECK();
+    return VHAP_OK;
+}
+
+extern "C" int vhap_energy_total_bound(float* log, const float* photo2, const float* n_global, float w_photo, int world_size, float* d_sum,
+                                       const float* shade_stats, float* gmax_bound, vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!log || (photo2 && !n_global) || !gmax_bound) return VHAP_E_NULLPTR;
+    energy_total_kernel<<<1, 64, 0, vhap_stream(stream)>>>(log, photo2, n_global, w_photo, (float)world_size, d_sum,
+                                                           reinterpret_cast<const unsigned*>(shade_stats), gmax_bound);
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;
 }

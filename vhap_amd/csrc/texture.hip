@@ -516,7 +516,8 @@ template <int C, bool SCATTER>
 __global__ __launch_bounds__(256) void texbin_pass_kernel(const float2* __restrict__ uv, const float* __restrict__ d_out, long long npix,
                                                           int NT, unsigned* __restrict__ counts, unsigned* __restrict__ tilemax,
                                                           const unsigned* __restrict__ offsets, unsigned* __restrict__ cursors,
-                                                          unsigned* __restrict__ list, const unsigned short* __restrict__ tile_ids) {
+                                                          unsigned* __restrict__ list, const unsigned short* __restrict__ tile_ids,
+                                                          const float* __restrict__ keep) {
     extern __shared__ unsigned tg_sh[];          // [NT*NT] counts / ranks, [NT*NT] max|g| bits (count pass) or list bases (scatter pass)
     const int nt2 = NT * NT, tid = threadIdx.x;
     unsigned* shc = tg_sh;
@@ -531,7 +532,7 @@ __global__ __launch_bounds__(256) void texbin_pass_kernel(const float2* __restri
         tile[k] = -1;
         if (p < npix && tile_ids) {
             const int tl = (int)tile_ids[p];
-            if (tl != 0xFFFF) {
+            if (tl != 0xFFFF && !(keep && keep[p] == 0.f)) {       // (keep == 0: the pixel's colour was replaced, no gradient reaches its texels)
                 tile[k] = tl;
                 atomicAdd(&shc[tl], 1u);
                 if (!SCATTER && d_out) {
@@ -602,7 +603,7 @@ __global__ __launch_bounds__(256) void texgrad_tile_kernel(const TexDesc D, cons
                                                            const float4* __restrict__ uv_da, const float* __restrict__ d_out,
                                                            const unsigned* __restrict__ offsets, const unsigned* __restrict__ list,
                                                            const unsigned* __restrict__ tilemax, float* __restrict__ d_tex,
-                                                           float* __restrict__ d_mips) {
+                                                           float* __restrict__ d_mips, const float* __restrict__ gmax_bound) {
     extern __shared__ unsigned long long tg_vals[];      // [G.cells * C]
     const int t = blockIdx.x, tid = threadIdx.x;
     const unsigned beg = offsets[t], end = offsets[t + 1];
@@ -612,6 +613,9 @@ __global__ __launch_bounds__(256) void texgrad_tile_kernel(const TexDesc D, cons
     unsigned tmax_bits;
     if (tilemax) {
         tmax_bits = tilemax[t];
+    } else if (gmax_bound) {         // an upper bound of |d_out| supplied by the caller: one scale for all tiles, no extra pass over the list
+        tmax_bits = __float_as_uint(fabsf(gmax_bound[0]));
+        if (tmax_bits == 0u) return;
     } else {            // the list was sorted before the gradient existed (tile ids from the forward): find the tile's max |g| here
         if (tid == 0) s_tmax = 0u;
         __syncthreads();
@@ -930,17 +934,18 @@ static int texture_grad_binned_impl(int Ht, int Wt, int C, const float* uv, cons
         constexpr int CC = decltype(c)::value;
         const float2* uv2 = reinterpret_cast<const float2*>(uv);
         if (!counted) {
-            texbin_pass_kernel<CC, false><<<nwg, 256, hist, st>>>(uv2, d_out, npix, G.NT, counts, tilemax, nullptr, nullptr, nullptr, tile_ids);
+            texbin_pass_kernel<CC, false><<<nwg, 256, hist, st>>>(uv2, d_out, npix, G.NT, counts, tilemax, nullptr, nullptr, nullptr, tile_ids, nullptr);
             VHAP_LAUNCH_CHECK();
         }
         texbin_scan_kernel<<<1, 1024, 0, st>>>(counts, nt2, offsets, cursors);
         VHAP_LAUNCH_CHECK();
-        texbin_pass_kernel<CC, true><<<nwg, 256, hist, st>>>(uv2, d_out, npix, G.NT, nullptr, nullptr, offsets, cursors, list, tile_ids);
+        texbin_pass_kernel<CC, true><<<nwg, 256, hist, st>>>(uv2, d_out, npix, G.NT, nullptr, nullptr, offsets, cursors, list, tile_ids, nullptr);
         VHAP_LAUNCH_CHECK();
         if (lds > 48 * 1024 &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(texgrad_tile_kernel<CC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return (int)VHAP_E_HIP;
-        texgrad_tile_kernel<CC><<<nt2, 256, lds, st>>>(D, G, uv2, reinterpret_cast<const float4*>(uv_da), d_out, offsets, list, tilemax, d_tex, d_mips);
+        texgrad_tile_kernel<CC><<<nt2, 256, lds, st>>>(D, G, uv2, reinterpret_cast<const float4*>(uv_da), d_out, offsets, list, tilemax, d_tex, d_mips,
+                                                       nullptr);
         VHAP_LAUNCH_CHECK();
         return (int)VHAP_OK;
     });
@@ -969,8 +974,8 @@ extern "C" int vhap_texture_grad_binned_ids(int Ht, int Wt, int C, const float* 
 // forward writes tile_ids): vhap_texbin_sort_ids counting-sorts the pixels by tile into `work` (three small launches, no dependence on
 // d_out -- it can run next to the rest of the forward pass), vhap_texture_grad_binned_sorted then only accumulates (one launch on the
 // backward's critical path instead of four); pixels of the lists whose gradient turns out to be zero add nothing.
-extern "C" int vhap_texbin_sort_ids(const uint16_t* tile_ids, int Ht, int Wt, int B, int H, int W, void* work, size_t work_bytes,
-                                    vhap_stream_t stream) {
+extern "C" int vhap_texbin_sort_ids(const uint16_t* tile_ids, const float* keep, int Ht, int Wt, int B, int H, int W, void* work,
+                                    size_t work_bytes, vhap_stream_t stream) {
     VHAP_ENTER();
     if (!tile_ids || !work) return VHAP_E_NULLPTR;
     if (int e = check_tex(1, Ht, Wt, 3)) return e;
@@ -993,18 +998,18 @@ extern "C" int vhap_texbin_sort_ids(const uint16_t* tile_ids, int Ht, int Wt, in
     VHAP_LAUNCH_CHECK();
     const int nwg = vhap_cdiv(npix, 256 * TG_PPT);
     const size_t hist = (size_t)2 * nt2 * sizeof(unsigned);
-    texbin_pass_kernel<3, false><<<nwg, 256, hist, st>>>(nullptr, nullptr, npix, G.NT, counts, nullptr, nullptr, nullptr, nullptr, tile_ids);
+    texbin_pass_kernel<3, false><<<nwg, 256, hist, st>>>(nullptr, nullptr, npix, G.NT, counts, nullptr, nullptr, nullptr, nullptr, tile_ids, keep);
     VHAP_LAUNCH_CHECK();
     texbin_scan_kernel<<<1, 1024, 0, st>>>(counts, nt2, offsets, cursors);
     VHAP_LAUNCH_CHECK();
-    texbin_pass_kernel<3, true><<<nwg, 256, hist, st>>>(nullptr, nullptr, npix, G.NT, nullptr, nullptr, offsets, cursors, list, tile_ids);
+    texbin_pass_kernel<3, true><<<nwg, 256, hist, st>>>(nullptr, nullptr, npix, G.NT, nullptr, nullptr, offsets, cursors, list, tile_ids, keep);
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;
 }
 
 extern "C" int vhap_texture_grad_binned_sorted(int Ht, int Wt, int C, const float* uv, const float* uv_da, const float* d_out, int B, int H,
                                                int W, float* d_tex, float* d_mips, const void* work, size_t work_bytes,
-                                               vhap_stream_t stream) {
+                                               const float* gmax_bound, vhap_stream_t stream) {
     VHAP_ENTER();
     if (!uv || !d_out || !d_tex || !work) return VHAP_E_NULLPTR;
     if (int e = check_tex(1, Ht, Wt, C)) return e;
@@ -1027,7 +1032,7 @@ extern "C" int vhap_texture_grad_binned_sorted(int Ht, int Wt, int C, const floa
             hipFuncSetAttribute(reinterpret_cast<const void*>(texgrad_tile_kernel<CC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return (int)VHAP_E_HIP;
         texgrad_tile_kernel<CC><<<G.NT * G.NT, 256, lds, st>>>(D, G, reinterpret_cast<const float2*>(uv), reinterpret_cast<const float4*>(uv_da), d_out,
-                                                               offsets, list, nullptr, d_tex, d_mips);
+                                                               offsets, list, nullptr, d_tex, d_mips, gmax_bound);
         VHAP_LAUNCH_CHECK();
         return (int)VHAP_OK;
     });

@@ -217,7 +217,7 @@ class NativeStep:
             if self.deferred:
                 self.def_work = self.g["def_work"]
         self.g_posed, self.g_shaped = E(B, V, 3), E(B, V, 3)
-        self.d_mvp, self.d_K, self.d_sum = E(B, 16), E(B, 4), E(1)
+        self.d_mvp, self.d_K, self.d_sum, self.gmax_bound = E(B, 16), E(B, 4), E(1), E(1)
         self.ones = torch.ones(8, **f32)
         # two independent chains per pass run on two streams (two branches of the captured graph): the bandwidth / atomics bound texture
         # work next to the latency-bound geometry chain of small launches
@@ -402,19 +402,21 @@ class NativeStep:
             self._join()
         _chk(raster(((1 | 4) if split else 1) | prof), "vhap_raster_shade_fwd")   # ... | VHAP_RASTER_PREBINNED
         _hook("raster_interp_fwd", "end")
-        if self.tb_ids:
-            # the counting sort of the pixels by uv tile (for the texture gradient) needs only the tile ids the rasteriser has just written:
-            # on the side branch NOW, next to the rest of the forward pass, instead of on the backward's critical path
-            self._fork()
-            with self._branch():
-                _chk(L.vhap_texbin_sort_ids(_p(self.tile_ids), T, T, B, H, W, _p(self.texbin_work), self.texbin_work.numel(), _stream()),
-                     "vhap_texbin_sort_ids")
+
         color = self.rgba
         if self.disturb_on:
             _chk(L.vhap_disturb_fwd_rng_cid(_p(self.rgba), _p(self.cid), self.ncl, float(self.rate_fg or 0.0), float(self.rate_bg or 0.0),
                                             _p(self.rng), B, H, W, _p(self.dist_ws), _p(self.rgba_d), _p(self.keep), st),
                  "vhap_disturb_fwd_rng_cid")
             color = self.rgba_d
+        if self.tb_ids:
+            # the counting sort of the pixels by uv tile (for the texture gradient) needs only the tile ids the rasteriser wrote and the
+            # disturbance's keep mask (replaced pixels pass no gradient): on the side branch NOW, next to the rest of the forward pass,
+            # instead of on the backward's critical path
+            self._fork()
+            with self._branch():
+                _chk(L.vhap_texbin_sort_ids(_p(self.tile_ids), _p(self.keep) if self.disturb_on else 0, T, T, B, H, W, _p(self.texbin_work),
+                                            self.texbin_work.numel(), _stream()), "vhap_texbin_sort_ids")
         self.aa_in = color
         if self.aa_inplace:
             _chk(L.vhap_antialias_inplace_fwd(_p(color), _p(self.rast), _p(self.clip), _p(self.tri), _p(self.opp), B, H, W, V, F,
@@ -455,7 +457,8 @@ class NativeStep:
                                                     _p(self.texbin_work), self.texbin_work.numel(), st), "vhap_texture_grad_binned_counted")
         elif self.tb_ids:                                          # (sorted during the forward pass: only the accumulation is left)
             _chk(L.vhap_texture_grad_binned_sorted(T, T, 3, _p(self.texc), _p(self.texd), _p(self.d_albedo), B, H, W, _p(d_tex), _p(d_mips),
-                                                   _p(self.texbin_work), self.texbin_work.numel(), st), "vhap_texture_grad_binned_sorted")
+                                                   _p(self.texbin_work), self.texbin_work.numel(), _p(self.gmax_bound), st),
+                 "vhap_texture_grad_binned_sorted")
         elif not (NV.use_binned_texgrad() and NV.texture_grad_binned(T, 3, self.texc, self.texd, self.d_albedo, d_tex, d_mips, self.texbin_work)):
             _chk(L.vhap_texture_bwd(_p(self.albedo_tex), _p(self.mips), 1, T, T, 3, _p(self.texc), _p(self.texd), _p(self.d_albedo), B, H, W,
                                     _p(d_tex), _p(d_mips), 0, 0, st), "vhap_texture_bwd")
@@ -514,8 +517,8 @@ class NativeStep:
         L, tr, g, acc = self.L, self.tr, self.g, self.accF
         B, H, W, V, F, T = self.B, self.H, self.W, self.V, self.F, self.T
         st = _stream()
-        _chk(L.vhap_energy_total(_p(self.log), _p(acc[16:18]), _p(self.n_global), self.w_photo, int(world_size), _p(self.d_sum), st),
-             "vhap_energy_total")
+        _chk(L.vhap_energy_total_bound(_p(self.log), _p(acc[16:18]), _p(self.n_global), self.w_photo, int(world_size), _p(self.d_sum),
+                                       _p(acc[12:16]) if self.want_reg else 0, _p(self.gmax_bound), st), "vhap_energy_total_bound")
         if self.aa_inplace:
             # no dense gradient images: the loss gradient is evaluated on the fly (here at the pixels of the antialias pair list, in the
             # shading backward everywhere); the sparse colour part of the antialias backward travels in d_delta
