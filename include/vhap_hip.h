@@ -44,10 +44,13 @@ const char* vhap_strerror(int code);
  *                                 tex_prep, offset_reg, shade, photo; d_coef of flame_skin_bwd) were zero-filled by the caller --
  *                                 a step executor keeps all of them in one arena cleared by ONE launch; the call skips its own clear
  *   VHAP_CALL_AA_PASSTHROUGH_DONE vhap_antialias_bwd: d_color already holds a copy of d_out (skip the pass-through copy)
- *   VHAP_CALL_ADAM_KEEP_STEP      vhap_adam_step: do not advance the step counter (a further call of the same step follows) */
+ *   VHAP_CALL_ADAM_KEEP_STEP      vhap_adam_step: do not advance the step counter (a further call of the same step follows)
+ *   VHAP_CALL_ADAM_STEP_ADVANCED  vhap_adam_step: the counter was advanced for this step already (vhap_adam_advance at its head): use it as
+ *                                 it is and leave it alone -- the pieces of one step may then run in any order on any streams */
 #define VHAP_CALL_ACC_PREZEROED 1
 #define VHAP_CALL_AA_PASSTHROUGH_DONE 2
 #define VHAP_CALL_ADAM_KEEP_STEP 4
+#define VHAP_CALL_ADAM_STEP_ADVANCED 16
 #define VHAP_CALL_TEXBIN_COUNTED 8      /* (internal to vhap_texture_grad_binned_counted) */
 
 /* ---------------------------------------------------------------------------------------------
@@ -74,6 +77,9 @@ const char* vhap_strerror(int code);
  * = raster kernel; duration = max(ends) - min(starts)) -- the only way to time a kernel INSIDE a captured graph replay (HIP refuses to read
  * event-record nodes, a profiler is not always there).  Costs two tiny launches and one atomic per wave. */
 #define VHAP_RASTER_PROFILE 8
+/* VHAP_RASTER_STATS_LATER (vhap_raster_shade_fwd): leave the reduction of the per-wave shading statistics to a later
+ * vhap_raster_shade_stats call on the same workspace (nothing on the pixel chain reads them before the energy is assembled). */
+#define VHAP_RASTER_STATS_LATER 16
 size_t vhap_raster_profile_offset(int B, int F, int H, int W, size_t pair_capacity);
 size_t vhap_raster_workspace_bytes(int B, int F, int H, int W, size_t pair_capacity);
 int vhap_raster_fwd(const float* pos, const int32_t* tri, int B, int V, int F, int H, int W,
@@ -119,6 +125,15 @@ int vhap_raster_shade_fwd(const float* pos, const int32_t* tri, const float* vno
                           int F, int H, int W, float* rast, float* rgba, uint8_t* cid, float* stats,
                           uint16_t* tile_ids, void* workspace, size_t workspace_bytes, size_t pair_capacity, int flags,
                           vhap_stream_t stream);
+/* The VHAP_RASTER_BIN_ONLY call of vhap_raster_shade_fwd with the vertex normals of vhap_vnormal_fwd_saved (compute_v_normals,
+ * render_nvdiffrast.py:216-232; verts [B,V,3] world space, vertex->corner CSR, vn [B,V,3], inv_len [B,V] or NULL) computed by extra
+ * workgroups of the same launch -- the raster pass needs both, neither needs the other.  VHAP_E_UNSUPPORTED as BIN_ONLY. */
+int vhap_raster_bin_vnormal(const float* pos, const int32_t* tri, const int32_t* tri_uv, int B, int V, int F, int H, int W,
+                            void* workspace, size_t workspace_bytes, size_t pair_capacity, int flags, const float* verts,
+                            const int32_t* vc_ptr, const int32_t* vc_idx, float* vn, float* inv_len, vhap_stream_t stream);
+/* The statistics reduction a vhap_raster_shade_fwd(..., VHAP_RASTER_STATS_LATER) call left out: same sizes, workspace and flags. */
+int vhap_raster_shade_stats(int B, int F, int H, int W, void* workspace, size_t workspace_bytes, size_t pair_capacity, int flags,
+                            float* stats, vhap_stream_t stream);
 /* Backward of the shading part of vhap_raster_shade_fwd (everything between the interpolated attributes and rgba): per covered pixel the
  * normal / uv / uv derivatives are re-computed from (rast, geometry) with the forward's arithmetic, the texture is re-sampled, and the
  * upstream gradient is chained through rgb = albedo * diffuse and the SH shading.  The upstream gradient is either the image
@@ -324,6 +339,15 @@ int vhap_photo_fwd(const float* pred_rgba, const float* gt_nchw, int B, int H, i
                    int call_flags, vhap_stream_t stream);
 int vhap_photo_bwd(const float* pred_rgba, const float* gt_nchw, const float* d_sum, int B, int H,
                    int W, float* d_pred, float* d_pred_copy, vhap_stream_t stream);
+/* vhap_photo_fwd + vhap_energy_finalize + vhap_energy_total_bound (world size 1) in ONE launch: the workgroup that finishes last assembles
+ * log[VHAP_LOG_COUNT], d_sum and gmax_bound (either may be NULL) from the stage accumulators (any of frame_terms .. shade_stats may be
+ * NULL = term absent), so that no single-thread launch sits between the forward and the backward pass.  out3 = (sum, count, ticket): three
+ * words, zero on entry (cleared here unless VHAP_CALL_ACC_PREZEROED), the ticket word is left at zero. */
+int vhap_photo_fwd_total(const float* pred_rgba, const float* gt_nchw, int B, int H, int W, float* out3,
+                         const float* frame_terms, const float* lmk_energy, const float* tex_terms,
+                         const float* off_terms, const float* shade_stats, float w_landmark, float w_reg_diffuse,
+                         float w_photo, float* log, float* d_sum, float* gmax_bound, int call_flags,
+                         vhap_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * FLAME geometry (vhap_amd/csrc/flame.hip): replaces lbs.blend_shapes (vhap/model/lbs.py:218-239), the
@@ -517,6 +541,9 @@ int vhap_adam_step(int n_tensors, float* const* params, const float* const* grad
                    float* const* exp_avg_sq, const int64_t* numel, const int32_t* lr_index,
                    const float* lr_device, int32_t* step_device, float beta1, float beta2, float eps,
                    int call_flags, vhap_stream_t stream);
+/* step_device[0] += 1 (one tiny launch): advance the counter at the HEAD of a step, then issue the step's vhap_adam_step calls with
+ * VHAP_CALL_ADAM_STEP_ADVANCED. */
+int vhap_adam_advance(int32_t* step_device, vhap_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Step glue (vhap_amd/csrc/step.hip, misc.hip) for an executor that chains the stages itself instead of torch autograd

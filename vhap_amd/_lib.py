@@ -93,12 +93,16 @@ SIGNATURES = {
     "vhap_sum_frames": (c_i, [c_fp, c_i, c_i, c_fp, c_fp]),
     "vhap_focal_bwd": (c_i, [c_fp, c_i, c_f, c_fp, c_fp]),
     "vhap_adam_step": (c_i, [c_i] + [c_fp] * 8 + [c_f, c_f, c_f, c_i, c_fp]),
+    "vhap_adam_advance": (c_i, [c_fp, c_fp]),
+    "vhap_raster_bin_vnormal": (c_i, [c_fp, c_fp, c_fp] + [c_i] * 5 + [c_fp, c_sz, c_sz, c_i] + [c_fp] * 6),
+    "vhap_raster_shade_stats": (c_i, [c_i] * 4 + [c_fp, c_sz, c_sz, c_i, c_fp, c_fp]),
+    "vhap_photo_fwd_total": (c_i, [c_fp, c_fp, c_i, c_i, c_i] + [c_fp] * 6 + [c_f] * 3 + [c_fp] * 3 + [c_i, c_fp]),
     "vhap_frame_ingest": (c_i, [c_fp, c_fp, c_fp] + [c_i] * 5 + [c_fp] * 4),
 }
 
 ABI_VERSION = 2
 # call_flags of include/vhap_hip.h (per-call arguments since ABI 2; the library keeps no mutable state)
-CALL_ACC_PREZEROED, CALL_AA_PASSTHROUGH_DONE, CALL_ADAM_KEEP_STEP = 1, 2, 4
+CALL_ACC_PREZEROED, CALL_AA_PASSTHROUGH_DONE, CALL_ADAM_KEEP_STEP, CALL_ADAM_STEP_ADVANCED = 1, 2, 4, 16
 
 _lib = None
 

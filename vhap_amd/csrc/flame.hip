@@ -12,6 +12,7 @@
 // run and consecutive tiles are contiguous.  Everything else is one thread per (frame, vertex).
 // The tiny per-frame algebra (Rodrigues, joint regression, kinematic chain) stays on the host side.
 #include "common.h"
+#include "vnormal_common.h"
 
 namespace {
 
@@ -276,22 +277,7 @@ __global__ __launch_bounds__(256) void vnormal_fwd_kernel(const float* __restric
                                                           float* __restrict__ vn, float* __restrict__ inv_len) {
     const int b = blockIdx.y, v = blockIdx.x * 256 + threadIdx.x;
     if (v >= V) return;
-    const float* P = verts + (size_t)b * V * 3;
-    float nx = 0.f, ny = 0.f, nz = 0.f;
-    for (int k = vc_ptr[v]; k < vc_ptr[v + 1]; k++) {
-        const int t = vc_idx[k] / 3;
-        const int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
-        const float ax = P[3 * i1] - P[3 * i0], ay = P[3 * i1 + 1] - P[3 * i0 + 1], az = P[3 * i1 + 2] - P[3 * i0 + 2];
-        const float bx = P[3 * i2] - P[3 * i0], by = P[3 * i2 + 1] - P[3 * i0 + 1], bz = P[3 * i2 + 2] - P[3 * i0 + 2];
-        nx += ay * bz - az * by; ny += az * bx - ax * bz; nz += ax * by - ay * bx;
-    }
-    float l2 = nx * nx + ny * ny + nz * nz;
-    const bool fallback = !(l2 > 1e-20f);
-    if (fallback) { nx = 0.f; ny = 0.f; nz = 1.f; l2 = 1.f; }
-    const float inv = 1.0f / sqrtf(fmaxf(l2, 1e-20f));
-    float* o = vn + ((size_t)b * V + v) * 3;
-    o[0] = nx * inv; o[1] = ny * inv; o[2] = nz * inv;
-    if (inv_len) inv_len[(size_t)b * V + v] = fallback ? 0.f : inv;    // saved for the backward: 1 / |raw normal| (0: constant fallback normal)
+    vhap_vnormal_vertex(verts + (size_t)b * V * 3, tri, vc_ptr, vc_idx, v, vn + ((size_t)b * V + v) * 3, inv_len ? inv_len + (size_t)b * V + v : nullptr);
 }
 
 // pass 1 of the backward from what the forward saved (unit normal + 1 / |raw normal|): no second gather over the incident faces

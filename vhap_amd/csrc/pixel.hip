@@ -11,6 +11,7 @@
 // One thread per pixel, 16-byte accesses where the layout allows, block reduction + one atomic per
 // block for the scalar / [9,3] outputs.
 #include "common.h"
+#include "energy_common.h"
 
 namespace {
 
@@ -275,8 +276,17 @@ __global__ __launch_bounds__(PBB) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 // pred rgba [B,H,W,4] (renderer space, row 0 = bottom) vs gt [B,3,H,W] (image space).
 // out[0] += sum |gt - pred_rgb|, out[1] += #(alpha > 0) (as float, exact below 2^24 per block partial)
+// TOTAL: the workgroup that finishes last (ticket counter in out[2], left at zero again) assembles the step energy from the stage accumulators
+// and derives the upstream gradient of the photometric term -- what vhap_energy_finalize + vhap_energy_total do as two launches.
+struct PhotoTotal {
+    const float *frame_terms, *lmk, *tex_terms, *off_terms;
+    const unsigned* shade_stats;
+    float w_lmk, w_reg_diffuse, w_photo;
+    float *log, *d_sum, *gmax_bound;
+};
+template <bool TOTAL>
 __global__ __launch_bounds__(PB) void photo_fwd_kernel(const float4* __restrict__ pred, const float* __restrict__ gt, int B, int H,
-                                                        int W, float* __restrict__ out) {
+                                                        int W, float* __restrict__ out, const PhotoTotal E) {
     __shared__ float rs[NW], rn[NW];
     float s = 0.f, n = 0.f;
     const unsigned npix = (unsigned)B * H * W, HW = (unsigned)H * W;
@@ -293,11 +303,28 @@ __global__ __launch_bounds__(PB) void photo_fwd_kernel(const float4* __restrict_
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) { rs[wave] = s; rn[wave] = n; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        float a = 0.f, c = 0.f;
-        for (int w = 0; w < NW; w++) { a += rs[w]; c += rn[w]; }
-        atomicAdd(&out[0], a);
-        atomicAdd(&out[1], c);
+    if (wave == 0) {
+        int last = 0;
+        if (lane == 0) {
+            float a = 0.f, c = 0.f;
+            for (int w = 0; w < NW; w++) { a += rs[w]; c += rn[w]; }
+            atomicAdd(&out[0], a);
+            atomicAdd(&out[1], c);
+            if constexpr (TOTAL) {
+                __threadfence();
+                last = atomicAdd(reinterpret_cast<unsigned*>(out + 2), 1u) == gridDim.x - 1;
+            }
+        }
+        if constexpr (TOTAL) {
+            if (__shfl(last, 0, 64)) {                 // the workgroup that finished last: its first wave assembles the energy
+                __threadfence();
+                const float sum = __hip_atomic_load(&out[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float cnt = __hip_atomic_load(&out[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                vhap_energy::finalize_total_wave(E.frame_terms, E.lmk, E.tex_terms, E.off_terms, E.shade_stats, E.w_lmk, E.w_reg_diffuse,
+                                                 (float)npix, sum, cnt, E.w_photo, 1.0f, E.log, E.d_sum, E.gmax_bound);
+                if (lane == 0) reinterpret_cast<unsigned*>(out + 2)[0] = 0u;
+            }
+        }
     }
 }
 
@@ -367,7 +394,25 @@ extern "C" int vhap_photo_fwd(const float* pred_rgba, const float* gt_nchw, int 
     hipStream_t st = vhap_stream(stream);
     VHAP_ZERO_ACC(out2, 8, st);
     const long long npix = (long long)B * H * W;
-    photo_fwd_kernel<<<min(vhap_cdiv(npix, PB), MAX_BLOCKS), PB, 0, st>>>(reinterpret_cast<const float4*>(pred_rgba), gt_nchw, B, H, W, out2);
+    photo_fwd_kernel<false><<<min(vhap_cdiv(npix, PB), MAX_BLOCKS), PB, 0, st>>>(reinterpret_cast<const float4*>(pred_rgba), gt_nchw, B, H, W, out2,
+                                                                                   PhotoTotal{});
+    VHAP_LAUNCH_CHECK();
+    return VHAP_OK;
+}
+
+extern "C" int vhap_photo_fwd_total(const float* pred_rgba, const float* gt_nchw, int B, int H, int W, float* out3, const float* frame_terms,
+                                    const float* lmk_energy, const float* tex_terms, const float* off_terms, const float* shade_stats,
+                                    float w_landmark, float w_reg_diffuse, float w_photo, float* log, float* d_sum, float* gmax_bound,
+                                    int call_flags, vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!pred_rgba || !gt_nchw || !out3 || !log) return VHAP_E_NULLPTR;
+    if (int e = check_img(B, H, W)) return e;
+    hipStream_t st = vhap_stream(stream);
+    VHAP_ZERO_ACC(out3, 12, st);
+    const long long npix = (long long)B * H * W;
+    const PhotoTotal E{frame_terms, lmk_energy, tex_terms, off_terms, reinterpret_cast<const unsigned*>(shade_stats), w_landmark, w_reg_diffuse,
+                       w_photo, log, d_sum, gmax_bound};
+    photo_fwd_kernel<true><<<min(vhap_cdiv(npix, PB), MAX_BLOCKS), PB, 0, st>>>(reinterpret_cast<const float4*>(pred_rgba), gt_nchw, B, H, W, out3, E);
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;
 }

@@ -23,6 +23,7 @@
 #include "frag_common.h"
 #include "shade_common.h"
 #include "tex_sample.h"
+#include "vnormal_common.h"
 
 #pragma clang fp contract(off)  // bit-exact op order vs the oracle: only explicit fma() fuses
 
@@ -229,16 +230,33 @@ __global__ __launch_bounds__(256) void prof_init_kernel(unsigned long long* prof
 constexpr unsigned FRAG_OVERFLOW = 0x80000000u;
 constexpr int MAX_FRAG = 32;   // fragments per bin the raster kernel stages per wave (meshes up to 32768 triangles; beyond: count/scan/fill)
 
+struct VnJob {                 // vertex normals computed by extra workgroups of the binning launch (verts == nullptr: none)
+    const float* verts;        // [B,V,3] world-space vertices
+    const int *vc_ptr, *vc_idx;
+    float *vn, *inv_len;       // [B,V,3], [B,V] (may be null)
+};
+
 __global__ __launch_bounds__(BIN_THREADS) void bin_build_kernel(const float* __restrict__ pos, const int* __restrict__ tri,
                                                                 const int* __restrict__ tri_uv, int V, int F, int H, int W,
                                                                 int nbx, int nby, unsigned* __restrict__ trange,
                                                                 TriRecord* __restrict__ records, uint2* __restrict__ frag,
-                                                                unsigned* __restrict__ list, unsigned region, unsigned long long* prof) {
+                                                                unsigned* __restrict__ list, unsigned region, unsigned long long* prof,
+                                                                int nfrag, const VnJob vj) {
     extern __shared__ __attribute__((aligned(16))) unsigned lb[];     // [nbin]: counts, then write cursors
     prof_begin(prof);
+    if ((int)blockIdx.x >= nfrag) {
+        // vhap_raster_bin_vnormal: the workgroups behind the binning ones compute the frame's vertex normals (independent work the raster
+        // kernel needs too -- one launch instead of two on two queues with a hand-over each)
+        const int v = ((int)blockIdx.x - nfrag) * BIN_THREADS + (int)threadIdx.x, b = blockIdx.y;
+        if (v < V)
+            vhap_vnormal_vertex(vj.verts + (size_t)b * V * 3, tri, vj.vc_ptr, vj.vc_idx, v, vj.vn + ((size_t)b * V + v) * 3,
+                                vj.inv_len ? vj.inv_len + (size_t)b * V + v : nullptr);
+        prof_end(prof);
+        return;
+    }
     __shared__ unsigned wtot[BIN_THREADS / 64];
     const int nbin = nbx * nby;
-    const int b = blockIdx.y, wg = blockIdx.x, nfrag = gridDim.x;
+    const int b = blockIdx.y, wg = blockIdx.x;
     const int t = wg * BIN_THREADS + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < nbin; i += BIN_THREADS) lb[i] = 0u;
@@ -745,7 +763,8 @@ int check_dims(int B, int V, int F, int H, int W) {
 }
 
 template <int MODE>
-int launch_raster(RasterParams P, void* ws, size_t ws_bytes, size_t cap, int flags, hipStream_t st, float* stats_out = nullptr) {
+int launch_raster(RasterParams P, void* ws, size_t ws_bytes, size_t cap, int flags, hipStream_t st, float* stats_out = nullptr,
+                  const VnJob vj = VnJob{}) {
     const int B = P.B, F = P.F;
     P.nbx = (P.W + BLK - 1) / BLK;
     P.nby = (P.H + BLK - 1) / BLK;
@@ -775,7 +794,7 @@ int launch_raster(RasterParams P, void* ws, size_t ws_bytes, size_t cap, int fla
     P.frag = nullptr;
     P.nfrag = nfrag;
     const bool prebinned = (flags & VHAP_RASTER_PREBINNED) != 0;
-    if ((flags & (VHAP_RASTER_BIN_ONLY | VHAP_RASTER_PREBINNED)) && !fragmented) return VHAP_E_UNSUPPORTED;   // split calls: one-launch binning only
+    if (((flags & (VHAP_RASTER_BIN_ONLY | VHAP_RASTER_PREBINNED)) || vj.verts) && !fragmented) return VHAP_E_UNSUPPORTED;   // split calls: one-launch binning only
     if (fragmented && prebinned) {
         P.frag = reinterpret_cast<uint2*>(w + l.frag);
     } else if (fragmented) {
@@ -791,8 +810,9 @@ int launch_raster(RasterParams P, void* ws, size_t ws_bytes, size_t cap, int fla
             prof_init_kernel<<<vhap_cdiv(2 * PROF_SLOTS, 256), 256, 0, st>>>(prof_bin, 2 * PROF_SLOTS);
             VHAP_LAUNCH_CHECK();
         }
-        bin_build_kernel<<<gbin, BIN_THREADS, lds, st>>>(P.pos, P.tri, P.tri_uv, P.V, F, P.H, P.W, P.nbx, P.nby, trange, records, frag, list,
-                                                        (unsigned)region, prof_bin);
+        const dim3 gbv(gbin.x + (vj.verts ? vhap_cdiv(P.V, BIN_THREADS) : 0), B);
+        bin_build_kernel<<<gbv, BIN_THREADS, lds, st>>>(P.pos, P.tri, P.tri_uv, P.V, F, P.H, P.W, P.nbx, P.nby, trange, records, frag, list,
+                                                       (unsigned)region, prof_bin, nfrag, vj);
         VHAP_LAUNCH_CHECK();
         P.frag = frag;
     } else {
@@ -843,7 +863,7 @@ int launch_raster(RasterParams P, void* ws, size_t ws_bytes, size_t cap, int fla
     }
     raster_kernel<MODE><<<nwg, 256, 0, st>>>(P);
     VHAP_LAUNCH_CHECK();
-    if (MODE == 2 && stats_out) {
+    if (MODE == 2 && stats_out && !(flags & VHAP_RASTER_STATS_LATER)) {
         uint4* part2 = reinterpret_cast<uint4*>(w + l.stats2);
         unsigned* counter = reinterpret_cast<unsigned*>(part2 + STATS_BLOCKS);
         if (!(flags & VHAP_RASTER_WS_CLEAN)) {      // (a zero-initialised workspace keeps the counter at 0 between calls)
@@ -914,6 +934,46 @@ extern "C" int vhap_raster_shade_fwd(const float* pos, const int32_t* tri, const
     P.lights = lights; P.sh_const = sh_const; P.bg_image = bg_image;
     if (!bg_image && bg_color) { P.bg_r = bg_color[0]; P.bg_g = bg_color[1]; P.bg_b = bg_color[2]; }
     return launch_raster<2>(P, workspace, workspace_bytes, pair_capacity, flags, vhap_stream(stream), stats);
+}
+
+// The BIN_ONLY call of vhap_raster_shade_fwd with the frames' vertex normals (vhap_vnormal_fwd_saved) computed by extra workgroups of the
+// same launch: the raster pass needs both, neither needs the other.
+extern "C" int vhap_raster_bin_vnormal(const float* pos, const int32_t* tri, const int32_t* tri_uv, int B, int V, int F, int H, int W,
+                                       void* workspace, size_t workspace_bytes, size_t pair_capacity, int flags, const float* verts,
+                                       const int32_t* vc_ptr, const int32_t* vc_idx, float* vn, float* inv_len, vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!pos || !tri || !tri_uv || !verts || !vc_ptr || !vc_idx || !vn) return VHAP_E_NULLPTR;
+    if (int e = check_dims(B, V, F, H, W)) return e;
+    RasterParams P{};
+    P.pos = pos; P.tri = tri; P.tri_uv = tri_uv;
+    P.B = B; P.V = V; P.F = F; P.H = H; P.W = W;
+    return launch_raster<2>(P, workspace, workspace_bytes, pair_capacity, (flags & ~VHAP_RASTER_PREBINNED) | VHAP_RASTER_BIN_ONLY,
+                            vhap_stream(stream), nullptr, VnJob{verts, vc_ptr, vc_idx, vn, inv_len});
+}
+
+// The statistics reduction a vhap_raster_shade_fwd(..., VHAP_RASTER_STATS_LATER) call left out (same workspace, same sizes): nothing on the
+// pixel chain reads `stats` before the energy assembly, so a step executor issues it beside the chain instead of inside it.
+extern "C" int vhap_raster_shade_stats(int B, int F, int H, int W, void* workspace, size_t workspace_bytes, size_t pair_capacity, int flags,
+                                       float* stats, vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!workspace || !stats) return VHAP_E_NULLPTR;
+    if (int e = check_dims(B, 1, F, H, W)) return e;
+    const int nbx = (W + BLK - 1) / BLK, nby = (H + BLK - 1) / BLK, nwx = (nbx + WG_BLOCKS - 1) / WG_BLOCKS;
+    const int nwg = B * nwx * nby;
+    const WsLayout l = ws_layout(B, F, nbx * nby, pair_capacity, (size_t)nwg * 4);
+    if (workspace_bytes < l.total) return VHAP_E_WORKSPACE;
+    char* w = static_cast<char*>(workspace);
+    hipStream_t st = vhap_stream(stream);
+    uint4* part2 = reinterpret_cast<uint4*>(w + l.stats2);
+    unsigned* counter = reinterpret_cast<unsigned*>(part2 + STATS_BLOCKS);
+    if (!(flags & VHAP_RASTER_WS_CLEAN)) {
+        vhap_zero_async(counter, sizeof(uint4), st);
+        VHAP_LAUNCH_CHECK();
+    }
+    shade_stats_reduce_kernel<<<STATS_BLOCKS, 1024, 0, st>>>(reinterpret_cast<const uint4*>(w + l.stats), nwg * 4, part2, counter,
+                                                            reinterpret_cast<unsigned*>(stats));
+    VHAP_LAUNCH_CHECK();
+    return VHAP_OK;
 }
 
 // VHAP_RASTER_PROFILE: byte offset inside `workspace` of the stamps -- 2 x 256 pairs of uint64 (first start, last end; 100 MHz ticks):

@@ -266,13 +266,13 @@ struct AdamTable {
     int n_tensors;
 };
 
-__global__ __launch_bounds__(RB) void adam_kernel(AdamTable t, const float* __restrict__ lr, const int* __restrict__ step, float beta1,
-                                                  float beta2, float eps) {
+__global__ __launch_bounds__(RB) void adam_kernel(AdamTable t, const float* __restrict__ lr, const int* __restrict__ step, int step_add,
+                                                  float beta1, float beta2, float eps) {
     int k = 0;
     while (k + 1 < t.n_tensors && (int)blockIdx.x >= t.blk_start[k + 1]) k++;
     const long long n = t.n[k];
     const long long blk = (int)blockIdx.x - t.blk_start[k], nblk = t.blk_start[k + 1] - t.blk_start[k];
-    const float st = (float)(step[0] + 1);
+    const float st = (float)(step[0] + step_add);
     const float bc1 = 1.0f - powf(beta1, st), bc2s = sqrtf(1.0f - powf(beta2, st));
     const float step_size = lr[t.lr_index[k]] / bc1;
     float* __restrict__ p = t.p[k];
@@ -400,11 +400,20 @@ extern "C" int vhap_adam_step(int n_tensors, float* const* params, const float* 
     }
     t.blk_start[n_tensors] = nblocks;
     hipStream_t st = vhap_stream(stream);
-    adam_kernel<<<nblocks, RB, 0, st>>>(t, lr_device, step_device, beta1, beta2, eps);
+    const bool advanced = (call_flags & VHAP_CALL_ADAM_STEP_ADVANCED) != 0;      // the counter already names THIS step (vhap_adam_advance)
+    adam_kernel<<<nblocks, RB, 0, st>>>(t, lr_device, step_device, advanced ? 0 : 1, beta1, beta2, eps);
     VHAP_LAUNCH_CHECK();
-    if (!(call_flags & VHAP_CALL_ADAM_KEEP_STEP)) {
+    if (!advanced && !(call_flags & VHAP_CALL_ADAM_KEEP_STEP)) {
         adam_bump_kernel<<<1, 1, 0, st>>>(step_device);
         VHAP_LAUNCH_CHECK();
     }
+    return VHAP_OK;
+}
+
+extern "C" int vhap_adam_advance(int32_t* step_device, vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!step_device) return VHAP_E_NULLPTR;
+    adam_bump_kernel<<<1, 1, 0, vhap_stream(stream)>>>(step_device);
+    VHAP_LAUNCH_CHECK();
     return VHAP_OK;
 }

@@ -4,54 +4,22 @@
 // for the shared static offset, and the focal-length gradient (tracker.py:141-157).  Each is one tiny launch instead of
 // 5-15 elementwise / reduction launches of the autograd formulation.
 #include "common.h"
+#include "energy_common.h"
 
 namespace {
 
-__device__ __forceinline__ float decode_ordered(unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
-
-// log layout (VHAP_LOG_*): see vhap_hip.h
 __global__ void energy_finalize_kernel(const float* __restrict__ frame_terms, const float* __restrict__ lmk, const float* __restrict__ tex_terms,
                                        const float* __restrict__ off_terms, const unsigned* __restrict__ shade_stats, float w_lmk,
                                        float w_reg_diffuse, float npix, float* __restrict__ log) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    float v[VHAP_LOG_COUNT];
-    for (int i = 0; i < VHAP_LOG_COUNT; i++) v[i] = 0.f;
-    if (lmk) v[VHAP_LOG_LMK] = w_lmk * lmk[0];
-    if (frame_terms)
-        for (int i = 0; i < 6; i++) v[VHAP_LOG_SMOOTH_POSE + i] = frame_terms[i];
-    if (tex_terms) { v[VHAP_LOG_TEX_TV] = tex_terms[0]; v[VHAP_LOG_TEX_RES] = tex_terms[1]; }
-    if (shade_stats) {
-        const float mx = decode_ordered(shade_stats[1]);
-        v[VHAP_LOG_REG_DIFFUSE] = w_reg_diffuse * (fmaxf(mx - 1.0f, 0.0f) + __uint_as_float(shade_stats[2]) / npix);
-    }
-    if (off_terms)
-        for (int i = 0; i < 3; i++) v[VHAP_LOG_OFF_LAP + i] = off_terms[i];
-    float rest = 0.f;
-    for (int i = 0; i < VHAP_LOG_REST; i++)
-        if (i != VHAP_LOG_PHOTO) rest += v[i];
-    v[VHAP_LOG_REST] = rest;
-    for (int i = 0; i < VHAP_LOG_COUNT; i++) log[i] = v[i];
+    vhap_energy::finalize(frame_terms, lmk, tex_terms, off_terms, shade_stats, w_lmk, w_reg_diffuse, npix, log);
 }
 
-// photo2 = (sum |gt - pred|, #(alpha > 0)) ; n_global = the alpha count summed over ranks (== photo2[1] on one GPU)
 __global__ void energy_total_kernel(float* __restrict__ log, const float* __restrict__ photo2, const float* __restrict__ n_global,
                                     float w_photo, float world, float* __restrict__ d_sum, const unsigned* __restrict__ shade_stats,
                                     float* __restrict__ gmax_bound) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    float photo = 0.f, g = 0.f;
-    if (photo2) {
-        const float inv_n = world / (3.0f * n_global[0]);
-        g = w_photo * inv_n;
-        photo = g * photo2[0];
-    }
-    log[VHAP_LOG_PHOTO] = photo;
-    log[VHAP_LOG_TOTAL] = log[VHAP_LOG_REST] + photo;
-    if (d_sum) d_sum[0] = g;
-    if (gmax_bound) {
-        // |d albedo| = |d rgb| diffuse <= (|g| + antialias colour part <= |g|) max(diffuse); without the statistic: a generous constant
-        const float dmax = shade_stats ? fmaxf(decode_ordered(shade_stats[1]), 1.0f) : 4.0f;
-        gmax_bound[0] = 4.0f * fabsf(g) * dmax;      // (|d rgb| <= |g| + four antialias pairs x 0.5 |g|; 2^23 of fixed-point headroom on top)
-    }
+    vhap_energy::total(log, photo2 != nullptr, photo2 ? photo2[0] : 0.f, photo2 ? n_global[0] : 1.f, w_photo, world, d_sum, shade_stats, gmax_bound);
 }
 
 __global__ __launch_bounds__(256) void sum_frames_kernel(const float* __restrict__ x, int B, int n, float* __restrict__ out) {

@@ -443,9 +443,18 @@ class HipAdam(torch.optim.Optimizer):
         return self._step
 
     @torch.no_grad()
-    def step(self, closure=None, only=None, skip=None, advance=True):
+    def advance(self):
+        """Advance the step counter NOW (one tiny launch, e.g. at the head of a captured step, off the critical path); the pieces of this
+        step are then issued as step(..., advanced=True) in any order, on any streams, with no counter launch behind them."""
+        if self._tab is None:
+            self._build()
+        _chk(_lib.lib().vhap_adam_advance(_p(self._step), _stream()), "vhap_adam_advance")
+
+    @torch.no_grad()
+    def step(self, closure=None, only=None, skip=None, advance=True, advanced=False):
         """`only` / `skip` (tensors): update a subset -- a step may be issued in pieces, e.g. the texture as soon as its gradient is
-        complete, on a side stream; every piece but the last passes advance=False so that all of them see the same step count."""
+        complete, on a side stream; every piece but the last passes advance=False so that all of them see the same step count
+        (or all pass advanced=True after advance())."""
         if self._tab is None:
             self._build()
         t = self._tab
@@ -468,4 +477,5 @@ class HipAdam(torch.optim.Optimizer):
         _chk(L.vhap_adam_step(n, pick(t["p"], ctypes.c_void_p), G, pick(t["m"], ctypes.c_void_p), pick(t["v"], ctypes.c_void_p),
                               pick(t["numel"], ctypes.c_int64), pick(t["lr_index"], ctypes.c_int32), _p(self._lr_dev),
                               _p(self._step), float(g0["betas"][0]), float(g0["betas"][1]), float(g0["eps"]),
-                              0 if advance else _lib.CALL_ADAM_KEEP_STEP, _stream()), "vhap_adam_step")
+                              _lib.CALL_ADAM_STEP_ADVANCED if advanced else (0 if advance else _lib.CALL_ADAM_KEEP_STEP), _stream()),
+             "vhap_adam_step")

@@ -133,6 +133,10 @@ class NativeStep:
         # deferred shading (default): the rasteriser samples the texture and shades in registers; normal / rast_db / albedo images do not exist
         self.deferred = self.photometric and os.environ.get("VHAP_DEFERRED", "1") != "0"
         self.tb_fused = self.tb_ids = False
+        # one GPU: energy assembly + upstream gradient in the epilogue of the photometric sum (under sharding the pixel count is all-reduced
+        # between the passes, so the two glue launches stay)
+        self.energy_fused = self.deferred and (tracker.dist is None or tracker.dist.world_size == 1) and \
+            os.environ.get("VHAP_ENERGY_FUSED", "1") != "0"
         self.raster_profile = os.environ.get("VHAP_RASTER_PROFILE", "0") == "1"
         # shading backward fused with the G-buffer backward (one gather chain per covered pixel, d_normal / d_uv / d_uv_da stay in registers)
         # (measured on MI355X, tools/kbench.py: 265 us fused vs 129 + 125 us separately -- both kernels are bound by VALU issue, not by the
@@ -222,10 +226,17 @@ class NativeStep:
         # two independent chains per pass run on two streams (two branches of the captured graph): the bandwidth / atomics bound texture
         # work next to the latency-bound geometry chain of small launches
         self.overlap = os.environ.get("VHAP_STEP_OVERLAP", "1") != "0"
+        self.step_optimizer = None    # a HipAdam whose WHOLE update is issued inside forward()/backward() (GraphedStep, one GPU): counter advanced
+                                      # at the head of the step, texture update behind its gradient, the rest before the final join
         self.split_tex = False        # True: stop at the gradient pyramid, the caller runs tex_finish() later (pyramid-level exchange)
         self.tex_l0_skip = False      # True: tex_finish() ignores the base level of the pyramid
         self.side = torch.cuda.Stream()
         self.side2 = torch.cuda.Stream()
+        self.main_first = os.environ.get("VHAP_FORK_ORDER", "1") != "0"
+        self._pending = []
+        # VHAP_PRIO=1: the backward's texture chain (the step's critical path) on a high-priority stream -- its workgroups are dispatched ahead
+        # of the geometry chain's where the two share the chip
+        self.side_b = torch.cuda.Stream(priority=-1) if os.environ.get("VHAP_PRIO", "0") != "0" else self.side
         self.c_lmk = torch.full((1,), self.w_lmk, **f32)
         self.c_reg = torch.full((1,), self.w_reg, **f32)
 
@@ -235,11 +246,35 @@ class NativeStep:
             self.side.wait_stream(torch.cuda.current_stream())
 
     def _join(self):
+        self._flush()
         if self.overlap:
             torch.cuda.current_stream().wait_stream(self.side)
 
     def _branch(self):
         return torch.cuda.stream(self.side) if self.overlap else _Null()
+
+    def _side(self, fn, stream=None):
+        """Run fn() on the side branch, forked at the CURRENT point of this stream.  With `main_first` the fork is only marked (an event) and
+        fn is issued by the next _flush(), i.e. AFTER the main chain's next kernel was captured: the graph executor keeps a node's
+        first-captured successor on the node's own queue and hands the others over to different queues (~10 us each)."""
+        stream = self.side if stream is None else stream
+        if not self.overlap:
+            return fn()
+        if not self.main_first:
+            stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(stream):
+                fn()
+            return
+        ev = torch.cuda.Event()
+        ev.record()
+        self._pending.append((ev, stream, fn))
+
+    def _flush(self):
+        for ev, stream, fn in self._pending:
+            stream.wait_event(ev)
+            with torch.cuda.stream(stream):
+                fn()
+        self._pending = []
 
     def _tex_forward(self):
         """texture assembly + pyramid + the offset regularisers: independent of the geometry chain until the texture is sampled"""
@@ -291,23 +326,31 @@ class NativeStep:
         acc = self.accF
         acc.zero_()                                                   # ONE launch clears every forward accumulator
         so = tr.static_offset
-        tex_ready = None
+        self._tex_ready = None
         early_tex = self.photometric and self.deferred and self.overlap
         if early_tex:
             # deferred shading: the rasteriser itself samples the texture, so the texture assembly + pyramid (~75 us, bandwidth-bound) heads the
             # critical path together with the geometry chain: start it at once on the side branch.  (Measured alternatives: forked after the
             # per-frame stage, the skinning kernel -- 27 MB of basis -- runs 70 us instead of 26 next to the texture assembly and the
             # rasteriser starts 25 us later; forked after the skinning, the rasteriser waits for the pyramid.)
-            self._fork()
-            with self._branch():
+            def tex_branch():
                 self._tex_forward()
-                tex_ready = torch.cuda.Event()
-                tex_ready.record()
-        self._camera_forward()
+                self._tex_ready = torch.cuda.Event()
+                self._tex_ready.record()
+            self._side(tex_branch)
+        # the camera (one tiny workgroup per frame) does not depend on the per-frame stage: side by side instead of 5-28 us ahead of it
+        cam_par = self.overlap and os.environ.get("VHAP_CAM_PAR", "1") != "0"
+        if cam_par:
+            self._side(self._camera_forward, self.side2)
+        else:
+            self._camera_forward()
         _chk(L.vhap_frame_prep_fwd(_p(self.ts), _p(tr.shape), _p(tr.expr), _p(tr.rotation), _p(tr.translation), _p(tr.neck_pose),
                                    _p(tr.jaw_pose), _p(tr.eyes_pose), _p(fm.JT), _p(fm.JS), _p(fm.jreg_idx), _p(fm.jreg_w), fm.jreg_n,
                                    _p(so), fm.parents, self.weights, B, self.Bp, self.N, self.NS, self.NE, J, fb.Kp, V,
                                    _p(self.coef), _p(self.A), _p(self.transl), _p(self.Jrest), _p(acc), PRE, st), "vhap_frame_prep_fwd")
+        self._flush()
+        if cam_par:
+            torch.cuda.current_stream().wait_stream(self.side2)
         if self.photometric:                                      # skinning fused with the world -> clip transform (one launch, same bits)
             _chk(L.vhap_flame_skin_clip_fwd(_p(self.coef), _p(fb.basis), _p(self.A), _p(fb.w), _p(fb.templ), _p(so), _p(self.transl), _p(self.mvp),
                                             B, V, fb.Vp, fb.K, fb.Kb, fb.Kp, _p(self.verts), _p(self.v_shaped), _p(self.v_posed), _p(self.clip), st),
@@ -327,19 +370,22 @@ class NativeStep:
             return
         # fork here, not at the top: next to the bandwidth-bound texture assembly the two latency-bound kernels above take 3x as long,
         # and they head the critical path of the forward pass; the texture branch still finishes long before the rasteriser does
-        self._fork()
-        with self._branch():
+        def side_work():
             if not early_tex:
                 self._tex_forward()
             if self.w_lmk:                                        # needs only verts + mvp: off the rasteriser's critical path
                 self._landmark_forward()
             self.arena.zero_()                                    # ONE launch clears every gradient accumulator of the backward
             self._arena_clean = True
+            if self.step_optimizer is not None:
+                self.step_optimizer.advance()
             if self.tb_fused:
                 self.tb_head.zero_()                              # tile histogram of the texture-gradient binning (filled by the backward)
+        self._side(side_work)
         if self.deferred:
-            return self._forward_deferred(tex_ready)
+            return self._forward_deferred()
         _chk(L.vhap_vnormal_fwd_saved(_p(self.verts), _p(self.csr.tri), _p(self.csr.ptr), _p(self.csr.idx), B, V, _p(self.vn), _p(self.vn_inv), st), "vhap_vnormal_fwd")
+        self._flush()
         _hook("raster_interp_fwd", "begin")                       # (bench.py: HIP events around the RI-fwd pass of eagerly issued steps)
         _chk(L.vhap_raster_interp_fwd(_p(self.clip), _p(self.tri), _p(self.vn), _p(self.uv), _p(self.tri_uv), B, V, self.uv.shape[0], F, H, W,
                                       _p(self.rast), _p(self.db), _p(self.normal), _p(self.texc), _p(self.texd), _p(self.ws), self.ws_bytes,
@@ -367,7 +413,7 @@ class NativeStep:
                                     _p(acc[12:16]) if self.want_reg else 0, self.w_lmk, self.w_reg, B, H, W, _p(self.log), st),
              "vhap_energy_finalize")
 
-    def _forward_deferred(self, tex_ready):
+    def _forward_deferred(self):
         """binning || vertex normals -> rasterise + interpolate + texture + shade + composite in ONE kernel -> disturbance -> antialias ->
         photometric sum"""
         L, tr = self.L, self.tr
@@ -387,21 +433,37 @@ class NativeStep:
         _hook("raster_interp_fwd", "begin")
         prof = 8 if self.raster_profile else 0                    # VHAP_RASTER_PROFILE (bench.py: in-graph timing of the pass)
         split = self.overlap and self.bin_split
-        if split:                                                 # vertex normals next to the binning (the raster kernel needs both)
+        # the reduction of the shading statistics (only the energy assembly reads them) beside the pixel chain instead of inside it
+        stats_later = 16 if (self.overlap and self.want_reg and os.environ.get("VHAP_STATS_LATER", "1") != "0") else 0
+        bin_vn = self.bin_split and os.environ.get("VHAP_BIN_VN", "1") != "0"
+        if bin_vn:
+            # binning + vertex normals in ONE launch (independent work, both inputs of the raster kernel): no fork / join -- a hand-over
+            # between queues costs ~10 us each way on this critical path
+            _chk(L.vhap_raster_bin_vnormal(_p(self.clip), _p(self.tri), _p(self.tri_uv), B, V, F, H, W, _p(self.ws), self.ws_bytes, self.ws_cap,
+                                           1 | prof, _p(self.verts), _p(self.csr.ptr), _p(self.csr.idx), _p(self.vn), _p(self.vn_inv), st),
+                 "vhap_raster_bin_vnormal")
+            split = True
+            self._flush()
+        elif split:                                               # vertex normals next to the binning (the raster kernel needs both)
             self.side2.wait_stream(cur)
             with torch.cuda.stream(self.side2):
                 _chk(L.vhap_vnormal_fwd_saved(_p(self.verts), _p(self.csr.tri), _p(self.csr.ptr), _p(self.csr.idx), B, V, _p(self.vn), _p(self.vn_inv), _stream()),
                      "vhap_vnormal_fwd")
             _chk(raster(1 | 2 | prof), "vhap_raster_shade_fwd")   # VHAP_RASTER_WS_CLEAN | VHAP_RASTER_BIN_ONLY
+            self._flush()
             cur.wait_stream(self.side2)
         else:
             _chk(L.vhap_vnormal_fwd_saved(_p(self.verts), _p(self.csr.tri), _p(self.csr.ptr), _p(self.csr.idx), B, V, _p(self.vn), _p(self.vn_inv), st), "vhap_vnormal_fwd")
-        if tex_ready is not None:
-            cur.wait_event(tex_ready)
+            self._flush()
+        if self._tex_ready is not None:
+            cur.wait_event(self._tex_ready)
         else:
             self._join()
-        _chk(raster(((1 | 4) if split else 1) | prof), "vhap_raster_shade_fwd")   # ... | VHAP_RASTER_PREBINNED
+        _chk(raster(((1 | 4) if split else 1) | prof | stats_later), "vhap_raster_shade_fwd")   # ... | VHAP_RASTER_PREBINNED
         _hook("raster_interp_fwd", "end")
+        if stats_later:
+            self._side(lambda: _chk(L.vhap_raster_shade_stats(B, F, H, W, _p(self.ws), self.ws_bytes, self.ws_cap, 1, _p(acc[12:16]), _stream()),
+                                    "vhap_raster_shade_stats"))
 
         color = self.rgba
         if self.disturb_on:
@@ -409,14 +471,13 @@ class NativeStep:
                                             _p(self.rng), B, H, W, _p(self.dist_ws), _p(self.rgba_d), _p(self.keep), st),
                  "vhap_disturb_fwd_rng_cid")
             color = self.rgba_d
+        self._flush()
         if self.tb_ids:
             # the counting sort of the pixels by uv tile (for the texture gradient) needs only the tile ids the rasteriser wrote and the
             # disturbance's keep mask (replaced pixels pass no gradient): on the side branch NOW, next to the rest of the forward pass,
             # instead of on the backward's critical path
-            self._fork()
-            with self._branch():
-                _chk(L.vhap_texbin_sort_ids(_p(self.tile_ids), _p(self.keep) if self.disturb_on else 0, T, T, B, H, W, _p(self.texbin_work),
-                                            self.texbin_work.numel(), _stream()), "vhap_texbin_sort_ids")
+            self._side(lambda: _chk(L.vhap_texbin_sort_ids(_p(self.tile_ids), _p(self.keep) if self.disturb_on else 0, T, T, B, H, W,
+                                                           _p(self.texbin_work), self.texbin_work.numel(), _stream()), "vhap_texbin_sort_ids"))
         self.aa_in = color
         if self.aa_inplace:
             _chk(L.vhap_antialias_inplace_fwd(_p(color), _p(self.rast), _p(self.clip), _p(self.tri), _p(self.opp), B, H, W, V, F,
@@ -425,6 +486,15 @@ class NativeStep:
         else:
             _chk(L.vhap_antialias_fwd(_p(color), _p(self.rast), _p(self.clip), _p(self.tri), _p(self.opp), B, H, W, 4, V, F, _p(self.rgba_aa),
                                       _p(self.aa_work), st), "vhap_antialias_fwd")
+        self._flush()
+        if self.energy_fused:
+            # one GPU: the photometric sum's last workgroup assembles the energy and the upstream gradient (no single-thread launches -- and
+            # no cross-queue hand-overs -- between the forward and the backward pass)
+            self._join()
+            _chk(L.vhap_photo_fwd_total(_p(self.rgba_aa), _p(self.rgb), B, H, W, _p(acc[16:19]), _p(acc[0:6]), _p(acc[6:7]) if self.w_lmk else 0,
+                                        _p(acc[7:9]), _p(acc[9:12]), _p(acc[12:16]) if self.want_reg else 0, self.w_lmk, self.w_reg, self.w_photo,
+                                        _p(self.log), _p(self.d_sum), _p(self.gmax_bound), PRE, st), "vhap_photo_fwd_total")
+            return
         _chk(L.vhap_photo_fwd(_p(self.rgba_aa), _p(self.rgb), B, H, W, _p(acc[16:18]), PRE, st), "vhap_photo_fwd")
         self._join()
         _chk(L.vhap_energy_finalize(_p(acc[0:6]), _p(acc[6:7]) if self.w_lmk else 0, _p(acc[7:9]), _p(acc[9:12]),
@@ -512,13 +582,16 @@ class NativeStep:
                                        _p(om.ridx), om.V, om.nreg, *self.off_scales, _p(self.ones), _p(g["static_offset"]), st),
                  "vhap_offset_reg_bwd")
 
-    def _bwd_pixel(self, world_size):
+    def _bwd_pixel(self, world_size, after_first=None):
         """energy total -> photometric -> antialias -> shading backward (-> d_albedo, d_normal per pixel)"""
         L, tr, g, acc = self.L, self.tr, self.g, self.accF
         B, H, W, V, F, T = self.B, self.H, self.W, self.V, self.F, self.T
         st = _stream()
-        _chk(L.vhap_energy_total_bound(_p(self.log), _p(acc[16:18]), _p(self.n_global), self.w_photo, int(world_size), _p(self.d_sum),
-                                       _p(acc[12:16]) if self.want_reg else 0, _p(self.gmax_bound), st), "vhap_energy_total_bound")
+        if self.energy_fused:
+            assert int(world_size) == 1                             # (done by the forward's photometric sum)
+        else:
+            _chk(L.vhap_energy_total_bound(_p(self.log), _p(acc[16:18]), _p(self.n_global), self.w_photo, int(world_size), _p(self.d_sum),
+                                           _p(acc[12:16]) if self.want_reg else 0, _p(self.gmax_bound), st), "vhap_energy_total_bound")
         if self.aa_inplace:
             # no dense gradient images: the loss gradient is evaluated on the fly (here at the pixels of the antialias pair list, in the
             # shading backward everywhere); the sparse colour part of the antialias backward travels in d_delta
@@ -530,6 +603,8 @@ class NativeStep:
             _chk(L.vhap_antialias_bwd(_p(self.aa_in), _p(self.rast), _p(self.clip), _p(self.tri), _p(self.opp), _p(self.d_rgba_aa), _p(self.aa_work),
                                       _p(self.vert_mask), B, H, W, 4, V, F, _p(self.d_color), _p(g["d_clip"]),
                                       _lib.CALL_AA_PASSTHROUGH_DONE, st), "vhap_antialias_bwd")   # d_color already holds the pass-through copy of d_rgba_aa
+        if after_first is not None:
+            after_first()
         # (the backward of the disturbance -- d_rgba = d_color * keep -- is folded into the shading backward)
         if self.fused_bwd:
             _chk(L.vhap_deferred_gbuffer_bwd(_p(self.clip), _p(self.tri), _p(self.vn), _p(self.uv), _p(self.tri_uv), _p(self.albedo_tex), _p(self.mips),
@@ -606,7 +681,7 @@ class NativeStep:
                                    _p(g["rotation"]), _p(g["translation"]), _p(g["neck_pose"]), _p(g["jaw_pose"]), _p(g["eyes_pose"]),
                                    _p(g["static_offset"]) if self.has_offset else 0, st), "vhap_frame_prep_bwd")
 
-    def _bwd_geometry(self, early=None):
+    def _bwd_geometry(self, early=None, after_first=None):
         """G-buffer backward -> vertex normals -> clip transform -> camera -> skinning -> per-frame parameters"""
         L, g = self.L, self.g
         B, H, W, V, F = self.B, self.H, self.W, self.V, self.F
@@ -615,6 +690,10 @@ class NativeStep:
             _chk(L.vhap_gbuffer_bwd(_p(self.clip), _p(self.tri), _p(self.vn), _p(self.uv), _p(self.tri_uv), _p(self.rast), _p(self.d_normal),
                                     _p(self.d_texc), _p(self.d_texd), 0, 0, _p(self.face_mask), B, V, F, H, W, _p(g["d_clip"]), _p(g["d_vn"]), st),
                  "vhap_gbuffer_bwd")
+        if after_first is not None:
+            after_first()
+        if early is True:                                             # (the event of backward(part="all")'s early branch, issued by now)
+            early = self._early_ev
         if early is not None:
             torch.cuda.current_stream().wait_event(early)
         if os.environ.get("VHAP_VERTS_BWD_FUSED", "1") == "0":
@@ -648,6 +727,15 @@ class NativeStep:
         side branch -- the caller then steps the remaining parameters with optimizer.step(skip=(tex_extra,))): 'texture' (pixel chain + the complete texture gradient, serial) -- the
         caller launches the asynchronous all-reduce of the texture gradient -- then 'geometry' (everything else), which hides it; or
         'pixel' then 'tex' and 'geometry' side by side on two streams (GraphedStep's default under sharding)."""
+        if self.side_b is not self.side:
+            fwd_side, self.side = self.side, self.side_b
+            try:
+                return self._backward(world_size, part, optimizer)
+            finally:
+                self.side = fwd_side
+        return self._backward(world_size, part, optimizer)
+
+    def _backward(self, world_size, part, optimizer):
         if part in ("all", "texture", "pixel"):
             if not getattr(self, "_arena_clean", False):              # (normally done on the forward's side branch already)
                 self.arena.zero_()
@@ -666,24 +754,29 @@ class NativeStep:
                 self._bwd_params()
             return
         if part == "all":
-            early = None
-            self._fork()
-            with self._branch():
+            self._early_ev = None
+
+            def early_branch():
                 self._bwd_early()
                 if self.overlap:
-                    early = torch.cuda.Event()
-                    early.record()
-            self._bwd_pixel(world_size)
+                    self._early_ev = torch.cuda.Event()
+                    self._early_ev.record()
+            self._side(early_branch)
+            self._bwd_pixel(world_size, after_first=self._flush)
             # fork as soon as d_albedo exists: the texture gradient (uv-binned accumulation + fold + TV backward) on the side branch,
             # the uv gradient and the geometry chain on this one
-            self._fork()
-            with self._branch():
+            def tex_chain():
                 done = self._tex_backward(optimizer)                  # (with an optimiser: its Adam update fused into the last kernel)
                 if optimizer is not None and self.tex_bwd_on and not done:
-                    optimizer.step(only=(self.tr.tex_extra,), advance=False)
-            self._bwd_pixel_finish()
+                    optimizer.step(only=(self.tr.tex_extra,), advance=False, advanced=self.step_optimizer is not None)
+            self._side(tex_chain)
+            self._side(self._bwd_pixel_finish, self.side2)            # (nothing downstream reads these two: beside the geometry chain, not ahead of it)
             self._bwd_uv()
-            self._bwd_geometry(early)
+            self._bwd_geometry(True, after_first=self._flush)
+            if self.overlap:
+                torch.cuda.current_stream().wait_stream(self.side2)
+            if self.step_optimizer is not None:                       # every other parameter: next to the tail of the texture branch
+                self.step_optimizer.step(skip=(self.tr.tex_extra,), advanced=True)
             self._join()
         elif part == "texture":
             self._bwd_pixel(world_size)

@@ -985,6 +985,8 @@ class GraphedStep:
         # with a process group alive, its helper threads (RCCL watchdog, heartbeat) issue runtime calls of their own: keep those from
         # invalidating a capture in progress on this thread
         cap = dict(capture_error_mode="thread_local") if tracker.dist is not None else {}
+        if os.environ.get("VHAP_PRIO", "0") == "2":                 # (experiment: the main chain of the captured step on a high-priority stream)
+            cap["stream"] = torch.cuda.Stream(priority=-1)
         self.gF, self.gB, self.gA = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         if self.ns is not None:
             ns = self.ns
@@ -1001,10 +1003,16 @@ class GraphedStep:
                 tex = tracker.tex_extra
                 split = tex is not None and any(p is tex for p in self.params) and len(self.params) > 1 and ns.tex_bwd_on and \
                     os.environ.get("VHAP_SPLIT_ADAM", "1") != "0"
+                # ... and the step counter is advanced at the head of the step (side branch), so that no piece of the update has to be last
+                early = split and ns.photometric and ns.overlap and hasattr(optimizer, "advance") and \
+                    os.environ.get("VHAP_ADAM_EARLY", "1") != "0" and os.environ.get("VHAP_TEX_ADAM_FUSED", "0") != "1"
+                ns.step_optimizer = optimizer if early else None
                 with torch.cuda.graph(self.gF, **cap):
                     for _ in range(self.unroll):
                         ns.forward()
-                        if split:
+                        if early:
+                            ns.backward(1, optimizer=optimizer)
+                        elif split:
                             ns.backward(1, optimizer=optimizer)
                             optimizer.step(skip=(tex,))
                         else:
