@@ -342,11 +342,13 @@ int vhap_photo_bwd(const float* pred_rgba, const float* gt_nchw, const float* d_
 /* vhap_photo_fwd + vhap_energy_finalize + vhap_energy_total_bound (world size 1) in ONE launch: the workgroup that finishes last assembles
  * log[VHAP_LOG_COUNT], d_sum and gmax_bound (either may be NULL) from the stage accumulators (any of frame_terms .. shade_stats may be
  * NULL = term absent), so that no single-thread launch sits between the forward and the backward pass.  out3 = (sum, count, ticket): three
- * words, zero on entry (cleared here unless VHAP_CALL_ACC_PREZEROED), the ticket word is left at zero. */
+ * words, zero on entry (cleared here unless VHAP_CALL_ACC_PREZEROED), the ticket word is left at zero; work: VHAP_PHOTO_WORK_FLOATS floats
+ * of scratch (per-workgroup partial sums: the totals are summed in a fixed order, i.e. bit-reproducible). */
+#define VHAP_PHOTO_WORK_FLOATS 1024
 int vhap_photo_fwd_total(const float* pred_rgba, const float* gt_nchw, int B, int H, int W, float* out3,
                          const float* frame_terms, const float* lmk_energy, const float* tex_terms,
                          const float* off_terms, const float* shade_stats, float w_landmark, float w_reg_diffuse,
-                         float w_photo, float* log, float* d_sum, float* gmax_bound, int call_flags,
+                         float w_photo, float* log, float* d_sum, float* gmax_bound, float* work, int call_flags,
                          vhap_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------

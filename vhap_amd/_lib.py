@@ -96,7 +96,7 @@ SIGNATURES = {
     "vhap_adam_advance": (c_i, [c_fp, c_fp]),
     "vhap_raster_bin_vnormal": (c_i, [c_fp, c_fp, c_fp] + [c_i] * 5 + [c_fp, c_sz, c_sz, c_i] + [c_fp] * 6),
     "vhap_raster_shade_stats": (c_i, [c_i] * 4 + [c_fp, c_sz, c_sz, c_i, c_fp, c_fp]),
-    "vhap_photo_fwd_total": (c_i, [c_fp, c_fp, c_i, c_i, c_i] + [c_fp] * 6 + [c_f] * 3 + [c_fp] * 3 + [c_i, c_fp]),
+    "vhap_photo_fwd_total": (c_i, [c_fp, c_fp, c_i, c_i, c_i] + [c_fp] * 6 + [c_f] * 3 + [c_fp] * 4 + [c_i, c_fp]),
     "vhap_frame_ingest": (c_i, [c_fp, c_fp, c_fp] + [c_i] * 5 + [c_fp] * 4),
 }
 

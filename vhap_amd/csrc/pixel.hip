@@ -283,6 +283,7 @@ struct PhotoTotal {
     const unsigned* shade_stats;
     float w_lmk, w_reg_diffuse, w_photo;
     float *log, *d_sum, *gmax_bound;
+    float* part;       // [2 x gridDim.x] per-workgroup partial sums
 };
 template <bool TOTAL>
 __global__ __launch_bounds__(PB) void photo_fwd_kernel(const float4* __restrict__ pred, const float* __restrict__ gt, int B, int H,
@@ -308,21 +309,31 @@ __global__ __launch_bounds__(PB) void photo_fwd_kernel(const float4* __restrict_
         if (lane == 0) {
             float a = 0.f, c = 0.f;
             for (int w = 0; w < NW; w++) { a += rs[w]; c += rn[w]; }
-            atomicAdd(&out[0], a);
-            atomicAdd(&out[1], c);
             if constexpr (TOTAL) {
+                // per-workgroup partials + a ticket instead of two contended float atomics per workgroup: the sums come out in a fixed
+                // order (bit-reproducible energy) and the kernel's tail is one round of 64-lane loads instead of ~1500 serialised atomics
+                E.part[2 * blockIdx.x] = a;
+                E.part[2 * blockIdx.x + 1] = c;
                 __threadfence();
                 last = atomicAdd(reinterpret_cast<unsigned*>(out + 2), 1u) == gridDim.x - 1;
+            } else {
+                atomicAdd(&out[0], a);
+                atomicAdd(&out[1], c);
             }
         }
         if constexpr (TOTAL) {
             if (__shfl(last, 0, 64)) {                 // the workgroup that finished last: its first wave assembles the energy
                 __threadfence();
-                const float sum = __hip_atomic_load(&out[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const float cnt = __hip_atomic_load(&out[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                float sum = 0.f, cnt = 0.f;
+                for (unsigned i = lane; i < gridDim.x; i += 64) {
+                    sum += __hip_atomic_load(&E.part[2 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    cnt += __hip_atomic_load(&E.part[2 * i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                sum = vhap_wave_sum(sum);
+                cnt = vhap_wave_sum(cnt);
+                if (lane == 0) { out[0] = sum; out[1] = cnt; reinterpret_cast<unsigned*>(out + 2)[0] = 0u; }
                 vhap_energy::finalize_total_wave(E.frame_terms, E.lmk, E.tex_terms, E.off_terms, E.shade_stats, E.w_lmk, E.w_reg_diffuse,
                                                  (float)npix, sum, cnt, E.w_photo, 1.0f, E.log, E.d_sum, E.gmax_bound);
-                if (lane == 0) reinterpret_cast<unsigned*>(out + 2)[0] = 0u;
             }
         }
     }
@@ -403,15 +414,15 @@ extern "C" int vhap_photo_fwd(const float* pred_rgba, const float* gt_nchw, int 
 extern "C" int vhap_photo_fwd_total(const float* pred_rgba, const float* gt_nchw, int B, int H, int W, float* out3, const float* frame_terms,
                                     const float* lmk_energy, const float* tex_terms, const float* off_terms, const float* shade_stats,
                                     float w_landmark, float w_reg_diffuse, float w_photo, float* log, float* d_sum, float* gmax_bound,
-                                    int call_flags, vhap_stream_t stream) {
+                                    float* work, int call_flags, vhap_stream_t stream) {
     VHAP_ENTER();
-    if (!pred_rgba || !gt_nchw || !out3 || !log) return VHAP_E_NULLPTR;
+    if (!pred_rgba || !gt_nchw || !out3 || !log || !work) return VHAP_E_NULLPTR;
     if (int e = check_img(B, H, W)) return e;
     hipStream_t st = vhap_stream(stream);
     VHAP_ZERO_ACC(out3, 12, st);
     const long long npix = (long long)B * H * W;
     const PhotoTotal E{frame_terms, lmk_energy, tex_terms, off_terms, reinterpret_cast<const unsigned*>(shade_stats), w_landmark, w_reg_diffuse,
-                       w_photo, log, d_sum, gmax_bound};
+                       w_photo, log, d_sum, gmax_bound, work};
     photo_fwd_kernel<true><<<min(vhap_cdiv(npix, PB), MAX_BLOCKS), PB, 0, st>>>(reinterpret_cast<const float4*>(pred_rgba), gt_nchw, B, H, W, out3, E);
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;

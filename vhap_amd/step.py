@@ -223,9 +223,14 @@ class NativeStep:
         self.g_posed, self.g_shaped = E(B, V, 3), E(B, V, 3)
         self.d_mvp, self.d_K, self.d_sum, self.gmax_bound = E(B, 16), E(B, 4), E(1), E(1)
         self.ones = torch.ones(8, **f32)
+        self.photo_work = torch.zeros(1024, **f32)               # VHAP_PHOTO_WORK_FLOATS
         # two independent chains per pass run on two streams (two branches of the captured graph): the bandwidth / atomics bound texture
         # work next to the latency-bound geometry chain of small launches
         self.overlap = os.environ.get("VHAP_STEP_OVERLAP", "1") != "0"
+        self.one_graph = False        # GraphedStep, one GPU: forward + backward + Adam are ONE captured graph -- the forward accumulators are then cleared
+                                      # at the END of the step (off the critical path; the step's first kernels become roots of the graph) and the
+                                      # texture-gradient sort is not joined before the backward needs it
+        self._acc_clean = False
         self.step_optimizer = None    # a HipAdam whose WHOLE update is issued inside forward()/backward() (GraphedStep, one GPU): counter advanced
                                       # at the head of the step, texture update behind its gradient, the rest before the final join
         self.split_tex = False        # True: stop at the gradient pyramid, the caller runs tex_finish() later (pyramid-level exchange)
@@ -324,7 +329,9 @@ class NativeStep:
         B, H, W, V, F, T, J = self.B, self.H, self.W, self.V, self.F, self.T, self.J
         st = _stream()
         acc = self.accF
-        acc.zero_()                                                   # ONE launch clears every forward accumulator
+        if not self._acc_clean:
+            acc.zero_()                                               # ONE launch clears every forward accumulator
+        self._acc_clean = False
         so = tr.static_offset
         self._tex_ready = None
         early_tex = self.photometric and self.deferred and self.overlap
@@ -476,8 +483,17 @@ class NativeStep:
             # the counting sort of the pixels by uv tile (for the texture gradient) needs only the tile ids the rasteriser wrote and the
             # disturbance's keep mask (replaced pixels pass no gradient): on the side branch NOW, next to the rest of the forward pass,
             # instead of on the backward's critical path
-            self._side(lambda: _chk(L.vhap_texbin_sort_ids(_p(self.tile_ids), _p(self.keep) if self.disturb_on else 0, T, T, B, H, W,
-                                                           _p(self.texbin_work), self.texbin_work.numel(), _stream()), "vhap_texbin_sort_ids"))
+            self._sort_fork = None
+
+            def sort_branch():
+                if self.one_graph and self.side_b is self.side:
+                    # everything the energy assembly needs from this branch is in front of this point; the sort itself is only needed by the
+                    # backward's texture chain, which runs on this very stream: the forward does not wait for it
+                    self._sort_fork = torch.cuda.Event()
+                    self._sort_fork.record()
+                _chk(L.vhap_texbin_sort_ids(_p(self.tile_ids), _p(self.keep) if self.disturb_on else 0, T, T, B, H, W,
+                                            _p(self.texbin_work), self.texbin_work.numel(), _stream()), "vhap_texbin_sort_ids")
+            self._side(sort_branch)
         self.aa_in = color
         if self.aa_inplace:
             _chk(L.vhap_antialias_inplace_fwd(_p(color), _p(self.rast), _p(self.clip), _p(self.tri), _p(self.opp), B, H, W, V, F,
@@ -490,10 +506,13 @@ class NativeStep:
         if self.energy_fused:
             # one GPU: the photometric sum's last workgroup assembles the energy and the upstream gradient (no single-thread launches -- and
             # no cross-queue hand-overs -- between the forward and the backward pass)
-            self._join()
+            if self.tb_ids and getattr(self, "_sort_fork", None) is not None:
+                torch.cuda.current_stream().wait_event(self._sort_fork)
+            else:
+                self._join()
             _chk(L.vhap_photo_fwd_total(_p(self.rgba_aa), _p(self.rgb), B, H, W, _p(acc[16:19]), _p(acc[0:6]), _p(acc[6:7]) if self.w_lmk else 0,
                                         _p(acc[7:9]), _p(acc[9:12]), _p(acc[12:16]) if self.want_reg else 0, self.w_lmk, self.w_reg, self.w_photo,
-                                        _p(self.log), _p(self.d_sum), _p(self.gmax_bound), PRE, st), "vhap_photo_fwd_total")
+                                        _p(self.log), _p(self.d_sum), _p(self.gmax_bound), _p(self.photo_work), PRE, st), "vhap_photo_fwd_total")
             return
         _chk(L.vhap_photo_fwd(_p(self.rgba_aa), _p(self.rgb), B, H, W, _p(acc[16:18]), PRE, st), "vhap_photo_fwd")
         self._join()
@@ -777,6 +796,9 @@ class NativeStep:
                 torch.cuda.current_stream().wait_stream(self.side2)
             if self.step_optimizer is not None:                       # every other parameter: next to the tail of the texture branch
                 self.step_optimizer.step(skip=(self.tr.tex_extra,), advanced=True)
+            if self.one_graph:                                        # the next step's forward accumulators (this chain has slack here)
+                self.accF.zero_()
+                self._acc_clean = True
             self._join()
         elif part == "texture":
             self._bwd_pixel(world_size)

@@ -1007,6 +1007,10 @@ class GraphedStep:
                 early = split and ns.photometric and ns.overlap and hasattr(optimizer, "advance") and \
                     os.environ.get("VHAP_ADAM_EARLY", "1") != "0" and os.environ.get("VHAP_TEX_ADAM_FUSED", "0") != "1"
                 ns.step_optimizer = optimizer if early else None
+                if ns.photometric and os.environ.get("VHAP_ONE_GRAPH", "1") != "0":
+                    ns.one_graph = True
+                    ns.accF.zero_()
+                    ns._acc_clean = True
                 with torch.cuda.graph(self.gF, **cap):
                     for _ in range(self.unroll):
                         ns.forward()
