@@ -243,6 +243,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="run optimize_iter eagerly instead of replaying the captured hipGraphs")
     args = ap.parse_args()
+    if os.environ.get("VHAP_DEBUG"):                            # profiling-only A/B switches of the library (tools/ab_env.sh)
+        from vhap_amd import _lib as _vl
+        _vl.debug_set_flags(int(os.environ["VHAP_DEBUG"]))
     C = CONFIGS[args.config]
 
     from vhap_amd import dist as vdist

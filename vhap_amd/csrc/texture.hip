@@ -573,9 +573,25 @@ __global__ __launch_bounds__(256) void texbin_pass_kernel(const float2* __restri
 }
 
 // exclusive scan of counts[0..n) -> offsets[0..n], n <= 4096; clears the scatter cursors
+// `order` (optional, [n]): the tiles sorted by the power of two of their pixel count, fullest first -- the accumulation kernel takes its
+// tiles in this order, so that the long ones start first instead of setting the tail (empty tiles come last)
 __global__ __launch_bounds__(1024) void texbin_scan_kernel(const unsigned* __restrict__ counts, int n, unsigned* __restrict__ offsets,
-                                                           unsigned* __restrict__ cursors) {
+                                                           unsigned* __restrict__ cursors, unsigned* __restrict__ order) {
     __shared__ unsigned wtot[16];
+    __shared__ unsigned bh[33], bo[33];
+    if (order) {
+        if (threadIdx.x < 33) bh[threadIdx.x] = 0u;
+        __syncthreads();
+        const int per_ = (n + 1023) / 1024, j0 = threadIdx.x * per_, j1 = min(j0 + per_, n);
+        for (int i = j0; i < j1; i++) atomicAdd(&bh[counts[i] ? 32 - __clz((int)counts[i]) : 0], 1u);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned pos = 0u;
+            for (int b = 32; b >= 0; b--) { bo[b] = pos; pos += bh[b]; }
+        }
+        __syncthreads();
+        for (int i = j0; i < j1; i++) order[atomicAdd(&bo[counts[i] ? 32 - __clz((int)counts[i]) : 0], 1u)] = (unsigned)i;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int per = (n + 1023) / 1024, i0 = tid * per, i1 = min(i0 + per, n);
     unsigned mine = 0u;
@@ -603,9 +619,10 @@ __global__ __launch_bounds__(256) void texgrad_tile_kernel(const TexDesc D, cons
                                                            const float4* __restrict__ uv_da, const float* __restrict__ d_out,
                                                            const unsigned* __restrict__ offsets, const unsigned* __restrict__ list,
                                                            const unsigned* __restrict__ tilemax, float* __restrict__ d_tex,
-                                                           float* __restrict__ d_mips, const float* __restrict__ gmax_bound) {
+                                                           float* __restrict__ d_mips, const float* __restrict__ gmax_bound,
+                                                           const unsigned* __restrict__ order) {
     extern __shared__ unsigned long long tg_vals[];      // [G.cells * C]
-    const int t = blockIdx.x, tid = threadIdx.x;
+    const int t = order ? (int)order[blockIdx.x] : (int)blockIdx.x, tid = threadIdx.x;
     const unsigned beg = offsets[t], end = offsets[t + 1];
     if (beg == end) return;
     for (int i = tid; i < G.cells * C; i += 256) tg_vals[i] = 0ull;
@@ -676,19 +693,40 @@ __global__ __launch_bounds__(256) void texgrad_tile_kernel(const TexDesc D, cons
         }
     };
 
-    for (unsigned i = beg + tid; i < end; i += 256) {
-        const size_t p = list[i];
-        float g[C];
+    // TG_UNR pixels per lane and round: the list entries first, then all their attributes, then the accumulation -- a pixel is a chain of
+    // two dependent global loads (~2 us each under load) and the fullest tiles hold 8 pixels per lane; un-batched, those tiles set the
+    // kernel's duration
+    constexpr int TG_UNR = 4;
+    for (unsigned i0 = beg + tid; i0 < end; i0 += 256 * TG_UNR) {
+        size_t p[TG_UNR];
+        bool ok[TG_UNR];
 #pragma unroll
-        for (int k = 0; k < C; k++) g[k] = d_out[p * C + k];
-        const float2 c = uv[p];
-        if (uv_da == nullptr) {
-            tap_level(0, c, g, 1.0f);
-        } else {
-            const LevelSel s = select_level(uv_da[p], D.W, D.H, D.L);
-            const bool two = s.two && s.f > 0.0f;
-            tap_level(s.l0, c, g, two ? 1.0f - s.f : 1.0f);
-            if (two) tap_level(s.l0 + 1, c, g, s.f);
+        for (int u = 0; u < TG_UNR; u++) {
+            ok[u] = i0 + 256u * u < end;
+            p[u] = ok[u] ? (size_t)list[i0 + 256u * u] : (size_t)0;
+        }
+        float g[TG_UNR][C];
+        float2 c[TG_UNR];
+        float4 da[TG_UNR];
+#pragma unroll
+        for (int u = 0; u < TG_UNR; u++) {
+            if (!ok[u]) continue;
+#pragma unroll
+            for (int k = 0; k < C; k++) g[u][k] = d_out[p[u] * C + k];
+            c[u] = uv[p[u]];
+            if (uv_da) da[u] = uv_da[p[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < TG_UNR; u++) {
+            if (!ok[u]) continue;
+            if (uv_da == nullptr) {
+                tap_level(0, c[u], g[u], 1.0f);
+            } else {
+                const LevelSel s = select_level(da[u], D.W, D.H, D.L);
+                const bool two = s.two && s.f > 0.0f;
+                tap_level(s.l0, c[u], g[u], two ? 1.0f - s.f : 1.0f);
+                if (two) tap_level(s.l0 + 1, c[u], g[u], s.f);
+            }
         }
     }
     __syncthreads();
@@ -937,7 +975,7 @@ static int texture_grad_binned_impl(int Ht, int Wt, int C, const float* uv, cons
             texbin_pass_kernel<CC, false><<<nwg, 256, hist, st>>>(uv2, d_out, npix, G.NT, counts, tilemax, nullptr, nullptr, nullptr, tile_ids, nullptr);
             VHAP_LAUNCH_CHECK();
         }
-        texbin_scan_kernel<<<1, 1024, 0, st>>>(counts, nt2, offsets, cursors);
+        texbin_scan_kernel<<<1, 1024, 0, st>>>(counts, nt2, offsets, cursors, nullptr);
         VHAP_LAUNCH_CHECK();
         texbin_pass_kernel<CC, true><<<nwg, 256, hist, st>>>(uv2, d_out, npix, G.NT, nullptr, nullptr, offsets, cursors, list, tile_ids, nullptr);
         VHAP_LAUNCH_CHECK();
@@ -945,7 +983,7 @@ static int texture_grad_binned_impl(int Ht, int Wt, int C, const float* uv, cons
             hipFuncSetAttribute(reinterpret_cast<const void*>(texgrad_tile_kernel<CC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return (int)VHAP_E_HIP;
         texgrad_tile_kernel<CC><<<nt2, 256, lds, st>>>(D, G, uv2, reinterpret_cast<const float4*>(uv_da), d_out, offsets, list, tilemax, d_tex, d_mips,
-                                                       nullptr);
+                                                       nullptr, nullptr);
         VHAP_LAUNCH_CHECK();
         return (int)VHAP_OK;
     });
@@ -1000,7 +1038,7 @@ extern "C" int vhap_texbin_sort_ids(const uint16_t* tile_ids, const float* keep,
     const size_t hist = (size_t)2 * nt2 * sizeof(unsigned);
     texbin_pass_kernel<3, false><<<nwg, 256, hist, st>>>(nullptr, nullptr, npix, G.NT, counts, nullptr, nullptr, nullptr, nullptr, tile_ids, keep);
     VHAP_LAUNCH_CHECK();
-    texbin_scan_kernel<<<1, 1024, 0, st>>>(counts, nt2, offsets, cursors);
+    texbin_scan_kernel<<<1, 1024, 0, st>>>(counts, nt2, offsets, cursors, reinterpret_cast<unsigned*>(w + l.tilemax));     // (tilemax slot: the tile order)
     VHAP_LAUNCH_CHECK();
     texbin_pass_kernel<3, true><<<nwg, 256, hist, st>>>(nullptr, nullptr, npix, G.NT, nullptr, nullptr, offsets, cursors, list, tile_ids, keep);
     VHAP_LAUNCH_CHECK();
@@ -1032,7 +1070,8 @@ extern "C" int vhap_texture_grad_binned_sorted(int Ht, int Wt, int C, const floa
             hipFuncSetAttribute(reinterpret_cast<const void*>(texgrad_tile_kernel<CC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return (int)VHAP_E_HIP;
         texgrad_tile_kernel<CC><<<G.NT * G.NT, 256, lds, st>>>(D, G, reinterpret_cast<const float2*>(uv), reinterpret_cast<const float4*>(uv_da), d_out,
-                                                               offsets, list, nullptr, d_tex, d_mips, gmax_bound);
+                                                               offsets, list, nullptr, d_tex, d_mips, gmax_bound,
+                                                               (vhap_g_debug_flags & 8192) ? nullptr : reinterpret_cast<const unsigned*>(w + l.tilemax));
         VHAP_LAUNCH_CHECK();
         return (int)VHAP_OK;
     });
