@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VHAP_ABI_VERSION 2
+#define VHAP_ABI_VERSION 3
 
 #define VHAP_OK 0
 #define VHAP_E_NULLPTR (-1)   /* a required pointer is NULL */
@@ -39,6 +39,13 @@ typedef void* vhap_stream_t;
 
 int vhap_abi_version(void);
 const char* vhap_strerror(int code);
+/* Streams owned by the caller of this library (hipStreamCreateWithPriority, non-blocking; priority 0 = normal, or, high_priority != 0,
+ * the greatest priority the device offers).  The entry points below take any stream; these two exist so that a host which gets its streams from a POOL -- torch
+ * hands out 32 streams per device round-robin, so the 33rd torch.cuda.Stream() IS the first one again -- can hold streams that alias
+ * nothing else in the process.  The step executor forks work onto side streams inside a stream capture and launches the resulting graph
+ * on a stream of its own: an alias between those roles serialises the branches at best and crashed hipGraphLaunch (ROCm 7) at worst. */
+int vhap_stream_create(vhap_stream_t* stream, int high_priority);
+int vhap_stream_destroy(vhap_stream_t stream);
 /* call_flags (an argument of the entry points that honour them; 0 = the plain behaviour):
  *   VHAP_CALL_ACC_PREZEROED       the small accumulators this call adds into (terms / energy / stats / out2 of frame_prep, landmark,
  *                                 tex_prep, offset_reg, shade, photo; d_coef of flame_skin_bwd) were zero-filled by the caller --

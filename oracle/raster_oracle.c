@@ -21,8 +21,20 @@
  *   - output row 0 is the BOTTOM row (y-up NDC), pixel (px,py) centre at NDC
  *       fx = fma(2/W, px, 1/W - 1),  fy = fma(2/H, py, 1/H - 1)
  *   - vertices are snapped to a 1/16-pixel grid: sx = rint(fma(x/w, 8W, 8W)) (ties-to-even),
- *     pixel centre px sits at 16*px+8; a triangle is dropped when any w <= 0 or any snapped
- *     coordinate magnitude >= 2^20 (guard band; near-plane crossing triangles are NOT clipped)
+ *     pixel centre px sits at 16*px+8; a piece is dropped when any w <= 0 or any snapped
+ *     coordinate magnitude >= 2^20 (guard band)
+ *   - NEAR-PLANE CLIPPING (nvdiffrast's rasteriser clips in homogeneous clip space): a vertex is
+ *     in front of the near plane iff d = z + w >= 0 (one float add).  A triangle with no vertex
+ *     behind is drawn as is; with all three behind it is dropped; otherwise it is cut by the plane
+ *     z = -w into ONE or TWO pieces (clip_near() below) that are snapped, culled, covered and
+ *     depth-tested like triangles of their own but carry the id of the triangle they came from.
+ *     The cut point on an edge is always computed from the vertex in front (a) towards the vertex
+ *     behind (b): t = da / (da - db), c = fma(t, b - a, a) for x, y, w and z = -w -- so the two
+ *     triangles sharing a mesh edge get the SAME cut point and the mesh stays watertight.  One
+ *     vertex in front (a; b, c follow it in the triangle's winding): piece (a, ab, ac).  Two in
+ *     front (a, b; o behind, winding o -> a -> b): pieces (a, b, bo) and (a, bo, ao).
+ *     The OUTPUT barycentrics / z/w / differentials of a winning pixel are those of the ORIGINAL
+ *     triangle (the homogeneous formulas of shade_frag() hold on both sides of w = 0)
  *   - coverage uses exact integer edge functions on the snapped coordinates; a pixel on an edge
  *     (E == 0) is inside iff A > 0 || (A == 0 && B > 0) for E = A*x + B*y + C
  *   - back-face culling: snapped signed area <= 0 is culled (CCW = front in y-up NDC)
@@ -111,6 +123,94 @@ static inline zplane_t depth_plane(const float* p0, const float* p1, const float
     return r;
 }
 
+/* Near-plane clipping of one triangle (see the header).  q receives 0, 1 or 2 pieces of three
+ * xyzw vertices each; returns the number of pieces.  A triangle entirely in front is returned
+ * unchanged (same bits as without clipping). */
+static inline void cut_edge(const float* a, float da, const float* b, float db, float* c) {
+    float t = da / (da - db);          /* a in front (da >= 0), b behind (db < 0): 0 <= t < 1 */
+    c[0] = fmaf(t, b[0] - a[0], a[0]);
+    c[1] = fmaf(t, b[1] - a[1], a[1]);
+    c[3] = fmaf(t, b[3] - a[3], a[3]);
+    c[2] = -c[3];                      /* on the plane z = -w exactly: z/w == -1 */
+}
+
+static int clip_near(const float* p0, const float* p1, const float* p2, float q[2][3][4]) {
+    const float* p[3] = {p0, p1, p2};
+    float d[3];
+    int behind = 0, nb = 0;
+    for (int i = 0; i < 3; i++) {
+        d[i] = p[i][2] + p[i][3];
+        if (d[i] < 0.0f) { behind |= 1 << i; nb++; }
+    }
+    if (nb == 0) {
+        for (int i = 0; i < 3; i++) memcpy(q[0][i], p[i], 16);
+        return 1;
+    }
+    if (nb == 3) return 0;
+    if (nb == 2) {                     /* one vertex in front: a, then b, c in winding order */
+        int k = (behind == 6) ? 0 : (behind == 5) ? 1 : 2;
+        const float *a = p[k], *b = p[(k + 1) % 3], *c = p[(k + 2) % 3];
+        memcpy(q[0][0], a, 16);
+        cut_edge(a, d[k], b, d[(k + 1) % 3], q[0][1]);
+        cut_edge(a, d[k], c, d[(k + 2) % 3], q[0][2]);
+        return 1;
+    }
+    {                                  /* one vertex behind: o, then a, b in winding order */
+        int k = (behind == 1) ? 0 : (behind == 2) ? 1 : 2;
+        const float *o = p[k], *a = p[(k + 1) % 3], *b = p[(k + 2) % 3];
+        float bo[4], ao[4];
+        cut_edge(b, d[(k + 2) % 3], o, d[k], bo);
+        cut_edge(a, d[(k + 1) % 3], o, d[k], ao);
+        memcpy(q[0][0], a, 16); memcpy(q[0][1], b, 16); memcpy(q[0][2], bo, 16);
+        memcpy(q[1][0], a, 16); memcpy(q[1][1], bo, 16); memcpy(q[1][2], ao, 16);
+        return 2;
+    }
+}
+
+/* coverage + depth test of one piece (a whole triangle or a piece of a clipped one) carrying triangle id t */
+static void raster_piece(const float* p0, const float* p1, const float* p2, int t, int H, int W, uint64_t* vis) {
+    snapped_t s;
+    if (!snap_tri(p0, p1, p2, H, W, &s)) return;
+    int64_t area = (int64_t)(s.x[1] - s.x[0]) * (s.y[2] - s.y[0]) - (int64_t)(s.x[2] - s.x[0]) * (s.y[1] - s.y[0]);
+    if (area <= 0) return; /* back-facing or degenerate */
+    int minx = s.x[0], maxx = s.x[0], miny = s.y[0], maxy = s.y[0];
+    for (int i = 1; i < 3; i++) {
+        if (s.x[i] < minx) minx = s.x[i]; if (s.x[i] > maxx) maxx = s.x[i];
+        if (s.y[i] < miny) miny = s.y[i]; if (s.y[i] > maxy) maxy = s.y[i];
+    }
+    /* pixel centres at 16*p+8 inside [min,max]: p >= (min-8)/16 (ceil), p <= (max-8)/16 (floor) */
+    int px0 = (minx - 8 + 15) >> 4, px1 = (maxx - 8) >> 4;
+    int py0 = (miny - 8 + 15) >> 4, py1 = (maxy - 8) >> 4;
+    if (px0 < 0) px0 = 0; if (py0 < 0) py0 = 0;
+    if (px1 > W - 1) px1 = W - 1; if (py1 > H - 1) py1 = H - 1;
+    if (px0 > px1 || py0 > py1) return;
+    int64_t A[3], Bc[3], C[3];
+    for (int i = 0; i < 3; i++) {
+        int a = (i + 1) % 3, bb = (i + 2) % 3;
+        A[i] = (int64_t)s.y[a] - s.y[bb];
+        Bc[i] = (int64_t)s.x[bb] - s.x[a];
+        C[i] = -Bc[i] * s.y[a] - A[i] * s.x[a];
+    }
+    for (int py = py0; py <= py1; py++) {
+        for (int px = px0; px <= px1; px++) {
+            int64_t cx = 16 * (int64_t)px + 8, cy = 16 * (int64_t)py + 8;
+            int inside = 1;
+            for (int i = 0; i < 3 && inside; i++) {
+                int64_t E = A[i] * cx + Bc[i] * cy + C[i];
+                if (E < 0) inside = 0;
+                else if (E == 0 && !(A[i] > 0 || (A[i] == 0 && Bc[i] > 0))) inside = 0;
+            }
+            if (!inside) continue;
+            zplane_t zp = depth_plane(p0, p1, p2, &s, area, px & ~7, py & ~7);
+            float zt = fmaf(zp.gx, (float)(px & 7), fmaf(zp.gy, (float)(py & 7), zp.zwc));
+            if (!(zt >= -1.0f && zt <= 1.0f)) continue;
+            uint64_t key = ((uint64_t)f2ord(zt) << 32) | (uint32_t)t;
+            uint64_t* dst = &vis[(size_t)py * W + px];
+            if (key < *dst) *dst = key;
+        }
+    }
+}
+
 /* pos [B,V,4] f32, tri [F,3] i32 -> rast [B,H,W,4], rast_db [B,H,W,4] (may be NULL) */
 int oracle_rasterize(const float* pos, const int32_t* tri, int B, int V, int F, int H, int W,
                      float* rast, float* rast_db) {
@@ -127,47 +227,9 @@ int oracle_rasterize(const float* pos, const int32_t* tri, int B, int V, int F, 
         for (int t = 0; t < F; t++) {
             int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
             if ((unsigned)i0 >= (unsigned)V || (unsigned)i1 >= (unsigned)V || (unsigned)i2 >= (unsigned)V) continue;
-            const float *p0 = P + 4 * i0, *p1 = P + 4 * i1, *p2 = P + 4 * i2;
-            snapped_t s;
-            if (!snap_tri(p0, p1, p2, H, W, &s)) continue;
-            int64_t area = (int64_t)(s.x[1] - s.x[0]) * (s.y[2] - s.y[0]) - (int64_t)(s.x[2] - s.x[0]) * (s.y[1] - s.y[0]);
-            if (area <= 0) continue; /* back-facing or degenerate */
-            int minx = s.x[0], maxx = s.x[0], miny = s.y[0], maxy = s.y[0];
-            for (int i = 1; i < 3; i++) {
-                if (s.x[i] < minx) minx = s.x[i]; if (s.x[i] > maxx) maxx = s.x[i];
-                if (s.y[i] < miny) miny = s.y[i]; if (s.y[i] > maxy) maxy = s.y[i];
-            }
-            /* pixel centres at 16*p+8 inside [min,max]: p >= (min-8)/16 (ceil), p <= (max-8)/16 (floor) */
-            int px0 = (minx - 8 + 15) >> 4, px1 = (maxx - 8) >> 4;
-            int py0 = (miny - 8 + 15) >> 4, py1 = (maxy - 8) >> 4;
-            if (px0 < 0) px0 = 0; if (py0 < 0) py0 = 0;
-            if (px1 > W - 1) px1 = W - 1; if (py1 > H - 1) py1 = H - 1;
-            if (px0 > px1 || py0 > py1) continue;
-            int64_t A[3], Bc[3], C[3];
-            for (int i = 0; i < 3; i++) {
-                int a = (i + 1) % 3, bb = (i + 2) % 3;
-                A[i] = (int64_t)s.y[a] - s.y[bb];
-                Bc[i] = (int64_t)s.x[bb] - s.x[a];
-                C[i] = -Bc[i] * s.y[a] - A[i] * s.x[a];
-            }
-            for (int py = py0; py <= py1; py++) {
-                for (int px = px0; px <= px1; px++) {
-                    int64_t cx = 16 * (int64_t)px + 8, cy = 16 * (int64_t)py + 8;
-                    int inside = 1;
-                    for (int i = 0; i < 3 && inside; i++) {
-                        int64_t E = A[i] * cx + Bc[i] * cy + C[i];
-                        if (E < 0) inside = 0;
-                        else if (E == 0 && !(A[i] > 0 || (A[i] == 0 && Bc[i] > 0))) inside = 0;
-                    }
-                    if (!inside) continue;
-                    zplane_t zp = depth_plane(p0, p1, p2, &s, area, px & ~7, py & ~7);
-                    float zt = fmaf(zp.gx, (float)(px & 7), fmaf(zp.gy, (float)(py & 7), zp.zwc));
-                    if (!(zt >= -1.0f && zt <= 1.0f)) continue;
-                    uint64_t key = ((uint64_t)f2ord(zt) << 32) | (uint32_t)t;
-                    uint64_t* dst = &vis[(size_t)py * W + px];
-                    if (key < *dst) *dst = key;
-                }
-            }
+            float q[2][3][4];
+            int np = clip_near(P + 4 * i0, P + 4 * i1, P + 4 * i2, q);
+            for (int k = 0; k < np; k++) raster_piece(q[k][0], q[k][1], q[k][2], t, H, W, vis);
         }
         /* shading pass */
         for (int py = 0; py < H; py++) {

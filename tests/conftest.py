@@ -31,3 +31,16 @@ def pytest_collection_modifyitems(config, items):
 def flame_model():
     from vhap_amd.synthetic import make_flame_model
     return make_flame_model(seed=0)
+
+
+@pytest.fixture(autouse=True)
+def _release_gpu_objects_between_tests(request):
+    """Captured steps (hipGraphs + their private memory pools + streams) sit in reference cycles with their trackers; left to the cycle
+    collector's own schedule they pile up across the GPU tests of one process.  Collect them after every GPU test."""
+    yield
+    if "gpu" in request.keywords and os.environ.get("VHAP_TEST_GC", "1") != "0":
+        import gc
+        import torch
+        torch.cuda.synchronize()
+        gc.collect()
+        torch.cuda.empty_cache()

@@ -235,6 +235,7 @@ def test_c_abi_is_reentrant_across_threads(tracker):
         rast, pos, tri = ns.rast.clone(), ns.clip.clone(), ns.tri
         color = torch.rand(2, H, W, 4, device="cuda")
         w = torch.randn(2, H, W, 4, device="cuda")
+        torch.cuda.synchronize()                   # the inputs above are read on other (non-blocking) streams below
 
         def aa_grad(stream):
             with torch.cuda.stream(stream):

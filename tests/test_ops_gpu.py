@@ -55,6 +55,35 @@ def test_rasterize_backward(scene):
     assert _rel(pos_g.grad, pos_o.grad) < 1e-2
 
 
+def test_rasterize_backward_through_near_plane_clipped_triangles():
+    """Gradient of (u, v, du/dX ...) w.r.t. clip-space positions for pixels won by PIECES of triangles cut by the near plane (some with a
+    vertex behind the camera): the backward uses the original triangle's vertices -- against autograd through the fp64 restatement on the
+    C oracle's visibility."""
+    from tests.scenes import near_plane_scene
+    from vhap_amd import ops
+    B, H, W = 2, 256, 208
+    pos_np, tri_np, _ = near_plane_scene(B)
+    rast_np, _ = oracle.rasterize(pos_np, tri_np, (H, W))
+    tid = torch.from_numpy(rast_np[..., 3].astype(np.int64) - 1)
+    tri = torch.from_numpy(tri_np).long()
+    behind = torch.from_numpy((pos_np[..., 2] + pos_np[..., 3]) < 0)                       # [B,V]
+    nb = torch.stack([behind[b][tri].sum(-1) for b in range(B)])                             # [B,F]
+    won_by_cut = torch.stack([(nb[b] > 0)[tid[b].clamp(min=0)] & (tid[b] >= 0) for b in range(B)])
+    assert int(won_by_cut.sum()) > 20000
+    g = torch.Generator().manual_seed(0)
+    w_r = torch.randn(B, H, W, 2, generator=g, dtype=torch.float64) * won_by_cut[..., None]     # only the cut triangles' pixels contribute
+    w_d = torch.randn(B, H, W, 4, generator=g, dtype=torch.float64) * 0.01 * won_by_cut[..., None]
+    pos_o = torch.from_numpy(pos_np).double().requires_grad_()
+    rast_o, db_o = R.rast_from_ids(pos_o, tri, tid, (H, W))
+    ((rast_o[..., :2] * w_r).sum() + (db_o * w_d).sum()).backward()
+    pos_g = torch.from_numpy(pos_np).cuda().requires_grad_()
+    rast, db = ops.rasterize(ops.RasterizeHipContext(), pos_g, tri.int().cuda(), (H, W))
+    assert np.array_equal(rast[..., 3].detach().cpu().numpy(), rast_np[..., 3])
+    ((rast[..., :2] * w_r.float().cuda()).sum() + (db * w_d.float().cuda()).sum()).backward()
+    assert float(pos_o.grad.abs().max()) > 0
+    assert _rel(pos_g.grad, pos_o.grad) < 1e-2
+
+
 def test_interpolate_forward_backward(scene):
     from vhap_amd import ops
     B, H, W = scene["B"], scene["H"], scene["W"]

@@ -146,6 +146,80 @@ def test_raster_shared_edge_random_meshes_have_no_double_coverage():
         assert ((cover > 0) == (rast[0, :, :, 3] > 0)).all()
 
 
+def _clip_from_camera(pc, focal=1.5, near=0.1, far=10.0):
+    """OpenGL projection of camera-space points (camera looks down -z; render_nvdiffrast.py:102-139 with c at the image centre)."""
+    pc = np.asarray(pc, np.float64)
+    A, Bz = -(far + near) / (far - near), -2 * far * near / (far - near)
+    return np.stack([2 * focal * pc[:, 0], 2 * focal * pc[:, 1], A * pc[:, 2] + Bz, -pc[:, 2]], 1)
+
+
+def test_raster_near_plane_clipping_floor_known_answer():
+    """A floor that runs from in front of the camera to BEHIND it (vertices with w < 0): coverage, barycentrics and depth against the
+    ray / plane intersection.  Before clipping existed the whole floor was dropped (any w <= 0)."""
+    H = W = 96
+    focal, near = 1.5, 0.1
+    y0 = -0.2
+    cam = np.array([[-5, y0, -5], [5, y0, -5], [5, y0, 1], [-5, y0, 1]], np.float64)     # z = +1: one metre behind the camera
+    pos = _clip_from_camera(cam, focal, near)
+    tri = [[0, 2, 1], [0, 3, 2]]              # winding: front-facing seen from above
+    rast, db = _tri(pos, tri, (H, W))
+    ids = rast[0, :, :, 3]
+    ys, xs = np.mgrid[0:H, 0:W]
+    fx, fy = (2 * xs + 1) / W - 1, (2 * ys + 1) / H - 1
+    with np.errstate(divide="ignore", invalid="ignore"):
+        s = y0 * 2 * focal / fy                # distance along -z at which the pixel's ray meets the floor
+        xh = s * fx / (2 * focal)
+    hit = (fy < 0) & (s >= near) & (s <= 5) & (np.abs(xh) <= 5)
+    margin = (fy < 0) & (s >= near * 0.9) & (s <= 5.3) & (np.abs(xh) <= 5.3)
+    assert (ids[hit & (s > near * 1.1) & (s < 4.7) & (np.abs(xh) < 4.7)] > 0).all()      # covered where the floor is visible
+    assert (ids[~margin] == 0).all()                                                        # and nowhere else (nothing mirrored from w < 0)
+    assert (ids > 0).sum() > 1000 and set(np.unique(ids)) == {0.0, 1.0, 2.0}
+    # barycentrics are those of the ORIGINAL triangles: interpolating the camera-space vertices gives the ray / floor intersection
+    b0, b1 = rast[0, :, :, 0].astype(np.float64), rast[0, :, :, 1].astype(np.float64)
+    T = np.asarray(tri)[np.maximum(ids.astype(int) - 1, 0)]
+    P = b0[..., None] * cam[T[..., 0]] + b1[..., None] * cam[T[..., 1]] + (1 - b0 - b1)[..., None] * cam[T[..., 2]]
+    m = (ids > 0) & hit & (s > 2 * near)
+    assert np.abs(P[m][:, 2] + s[m]).max() < 2e-3 * 5 and np.abs(P[m][:, 0] - xh[m]).max() < 2e-3 * 5
+    A, Bz = -(10 + near) / (10 - near), -2 * 10 * near / (10 - near)
+    assert np.abs(rast[0, :, :, 2][m] - (A * -s[m] + Bz) / s[m]).max() < 1e-4
+    # a floor entirely behind the camera draws nothing; one entirely in front is untouched by the clipper
+    behind = _clip_from_camera(cam + [0, 0, 6.5], focal, near)
+    assert (_tri(behind, tri, (H, W))[0][..., 3] == 0).all()
+
+
+def test_raster_near_plane_clipping_is_watertight():
+    """Cut points are computed from the vertex in front towards the vertex behind, so two triangles sharing an edge share the cut point:
+    a tilted random mesh through the near plane has no hole and no double hit along the shared edges or inside the two-piece triangles."""
+    rng = np.random.default_rng(1)
+    H, W = 64, 56
+    for trial in range(4):
+        n = 7
+        gx, gz = np.meshgrid(np.linspace(-0.6, 0.6, n), np.linspace(-1.2, 0.3, n))       # z up to +0.3: behind the camera
+        gx = gx + rng.normal(0, 0.02, gx.shape)
+        gz = gz + rng.normal(0, 0.03, gz.shape)
+        cam = np.stack([gx, -0.15 + 0.1 * gx + rng.normal(0, 0.003, gx.shape), gz], -1).reshape(-1, 3)
+        pos = _clip_from_camera(cam)
+        tri = []
+        for j in range(n - 1):
+            for i in range(n - 1):
+                a = j * n + i
+                tri += [[a, a + n + 1, a + 1], [a, a + n, a + n + 1]]
+        rast, _ = _tri(pos, tri, (H, W))
+        full = rast[0, :, :, 3] > 0
+        assert full.sum() > 200
+        cover = np.zeros((H, W), int)
+        for t in tri:
+            r1, _ = _tri(pos, [t], (H, W))
+            cover += (r1[0, :, :, 3] > 0)
+        assert cover.max() == 1
+        assert ((cover > 0) == full).all()
+        # no hole strictly inside the covered region: every covered row is one contiguous run (the mesh is convex in screen space per row)
+        for y in range(H):
+            xs = np.nonzero(full[y])[0]
+            if len(xs):
+                assert len(xs) == xs[-1] - xs[0] + 1
+
+
 def test_texture_known_answers_oracle():
     tex = torch.full((1, 16, 16, 3), 0.37, dtype=torch.float64)
     uv = torch.rand(1, 4, 4, 2, dtype=torch.float64)

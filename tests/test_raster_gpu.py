@@ -5,7 +5,7 @@ import torch
 
 import oracle
 from oracle import torch_ref as R
-from tests.scenes import head_scene
+from tests.scenes import head_scene, near_plane_scene
 
 pytestmark = pytest.mark.gpu
 
@@ -79,6 +79,61 @@ def test_brute_force_fallback_when_bins_overflow(flame_model):
     ctx = ops.RasterizeHipContext(pairs_per_triangle=0, pairs_per_block=0)        # capacity 0 -> every tile brute-forces
     rast, db = ops.raster_fwd(ctx, torch.from_numpy(pos).cuda(), torch.from_numpy(tri).cuda(), (H, W))
     _assert_raster_equal((rast.cpu().numpy(), db.cpu().numpy()), ref, "fallback")
+
+
+def _crossing_stats(pos, tri, ids):
+    """(# triangles crossing the near plane that WON pixels, # of those with a vertex behind the camera, # pixels they won), frame 0"""
+    behind = ((pos[0, :, 2] + pos[0, :, 3]) < 0)[tri]
+    nb = behind.sum(-1)
+    won = np.unique(ids[0][ids[0] > 0]).astype(int) - 1
+    cw = np.intersect1d(won, np.nonzero((nb > 0) & (nb < 3))[0])
+    return len(cw), int((pos[0][tri[cw]][..., 3] < 0).any(-1).sum()), int(np.isin(ids[0].astype(int) - 1, cw).sum())
+
+
+@pytest.mark.parametrize("path", ["fragmented", "overflow", "lists", "brute"])
+def test_near_plane_clipping_matches_oracle_bit_exact(path):
+    """Triangles crossing the near plane are cut into one or two pieces that carry the triangle's id (nvdiffrast clips in homogeneous clip
+    space; round 1 dropped them).  Every binning path of the rasteriser -- one-launch fragmented lists, workgroups whose pairs overflow
+    their region (direct scan of their record slots), the three-launch contiguous lists and the brute-force fallback -- against the C oracle
+    on a scene whose cut runs across the screen (tests/scenes.py: near_plane_scene)."""
+    from vhap_amd import _lib, ops
+    B, H, W = 3, 256, 208
+    pos, tri, _ = near_plane_scene(B)
+    ref = oracle.rasterize(pos, tri, (H, W))
+    n_cross, n_wneg, n_px = _crossing_stats(pos, tri, ref[0][..., 3])
+    assert n_cross >= 30 and n_wneg >= 3 and n_px > 10000, (n_cross, n_wneg, n_px)
+    kw = dict(fragmented={}, overflow=dict(pairs_per_triangle=1, pairs_per_block=0), lists={}, brute=dict(pairs_per_triangle=0, pairs_per_block=0))[path]
+    ctx = ops.RasterizeHipContext(**kw)
+    if path == "lists":
+        _lib.debug_set_flags(4096)                                            # A/B switch: bin_count / bin_scan / bin_fill instead of bin_build
+    try:
+        rast, db = ops.raster_fwd(ctx, torch.from_numpy(pos).cuda(), torch.from_numpy(tri).cuda(), (H, W))
+        torch.cuda.synchronize()
+    finally:
+        _lib.debug_set_flags(0)
+    _assert_raster_equal((rast.cpu().numpy(), db.cpu().numpy()), ref, f"near-plane clipping ({path})")
+
+
+def test_near_plane_clipping_fused_gbuffer_matches_oracle():
+    """The fused G-buffer pass on the same scene: normals / uv / uv derivatives of a pixel won by a PIECE are interpolated with the
+    barycentrics of the original triangle (homogeneous formulas, valid on both sides of w = 0)."""
+    from vhap_amd import ops
+    B, H, W = 2, 256, 208
+    pos, tri, _ = near_plane_scene(B, seed=1)
+    V = pos.shape[1]
+    rng = np.random.default_rng(5)
+    uv = rng.random((V + 7, 2)).astype(np.float32)
+    tri_uv = ((tri.astype(np.int64) * 7 + 3) % (V + 7)).astype(np.int32)
+    vn = rng.standard_normal((B, V, 3)).astype(np.float32)
+    r_rast, r_db = oracle.rasterize(pos, tri, (H, W))
+    r_n, _ = oracle.interpolate(vn, r_rast, tri)
+    r_tc, r_td = oracle.interpolate(uv[None], r_rast, tri_uv, r_db)
+    ctx = ops.RasterizeHipContext()
+    out = ops.raster_interp_fwd(ctx, torch.from_numpy(pos).cuda(), torch.from_numpy(tri).cuda(), torch.from_numpy(vn).cuda(),
+                                torch.from_numpy(uv).cuda(), torch.from_numpy(tri_uv).cuda(), (H, W))
+    rast, db, normal, texc, texd = [o.cpu().numpy() for o in out]
+    _assert_raster_equal((rast, db), (r_rast, r_db), "fused near-plane")
+    assert np.array_equal(normal, r_n) and np.array_equal(texc, r_tc) and np.array_equal(texd, r_td)
 
 
 @pytest.mark.parametrize("B,H,W", [(16, 512, 512), (8, 1024, 1024), (16, 802, 550)])

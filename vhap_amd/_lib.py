@@ -21,6 +21,8 @@ c_f = ctypes.c_float
 SIGNATURES = {
     "vhap_abi_version": (c_i, []),
     "vhap_strerror": (ctypes.c_char_p, [c_i]),
+    "vhap_stream_create": (c_i, [ctypes.POINTER(ctypes.c_void_p), c_i]),
+    "vhap_stream_destroy": (c_i, [c_fp]),
     "vhap_raster_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_sz]),
     "vhap_raster_profile_offset": (c_sz, [c_i, c_i, c_i, c_i, c_sz]),
     "vhap_raster_fwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_sz, c_sz, c_i, c_fp]),
@@ -100,7 +102,7 @@ SIGNATURES = {
     "vhap_frame_ingest": (c_i, [c_fp, c_fp, c_fp] + [c_i] * 5 + [c_fp] * 4),
 }
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 # call_flags of include/vhap_hip.h (per-call arguments since ABI 2; the library keeps no mutable state)
 CALL_ACC_PREZEROED, CALL_AA_PASSTHROUGH_DONE, CALL_ADAM_KEEP_STEP, CALL_ADAM_STEP_ADVANCED = 1, 2, 4, 16
 
@@ -140,3 +142,36 @@ def check(code, what=""):
     if code != 0:
         msg = lib().vhap_strerror(code).decode()
         raise VhapHipError(f"{what}: {msg} ({code})")
+
+
+# ---- streams of our own ----------------------------------------------------------------------------------------------------------
+# torch.cuda.Stream() does not create a stream: it hands out the next of 32 pooled streams per device and priority, round-robin, so the
+# 33rd Stream object of a process IS the first one again.  The step executor (vhap_amd/step.py, tracker.GraphedStep) forks work onto
+# side streams inside a stream capture and launches the captured graph on yet another stream; a process that had created enough streams
+# before (a test suite, a long-running tracker) got a launch stream that aliased one of the captured side streams, and hipGraphLaunch of
+# ROCm 7 dereferenced a null pointer setting up the graph's parallel branches.  The library therefore owns its streams
+# (vhap_stream_create), one per (thread, device, role), created on first use and kept for the life of the process.
+import threading
+
+_streams = threading.local()
+
+
+def private_stream(role, device=None, high_priority=False):
+    """The calling thread's stream for `role` ('launch', 'side', 'side2', 'warm', 'tex', ...) on `device`: a torch.cuda.ExternalStream
+    over a HIP stream this library created -- never a member of torch's stream pool, so it aliases no other stream of the process."""
+    if os.environ.get("VHAP_POOL_STREAMS") == "1":                 # (debugging: the old behaviour, streams from torch's pool)
+        return torch.cuda.Stream(device=device, priority=-1 if high_priority else 0)
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    table = getattr(_streams, "table", None)
+    if table is None:
+        table = _streams.table = {}
+    key = (dev.index, role, bool(high_priority))
+    st = table.get(key)
+    if st is None:
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(dev):
+            check(lib().vhap_stream_create(ctypes.byref(handle), 1 if high_priority else 0), "vhap_stream_create")
+        st = table[key] = torch.cuda.ExternalStream(handle.value, device=dev)
+    return st

@@ -251,9 +251,8 @@ __global__ __launch_bounds__(256) void gbuffer_bwd_kernel(const float4* __restri
     if ((unsigned)i0 >= (unsigned)V || (unsigned)i1 >= (unsigned)V || (unsigned)i2 >= (unsigned)V) return;
     const float4* P = pos + (size_t)b * V;
     const float4 p0 = P[i0], p1 = P[i1], p2 = P[i2];
-    int sx[3], sy[3], px0, px1, py0, py1;
-    long long area;
-    if (!tri_bbox(p0, p1, p2, H, W, sx, sy, area, px0, px1, py0, py1)) return;
+    int px0, px1, py0, py1;
+    if (!tri_cover_bbox(p0, p1, p2, H, W, px0, px1, py0, py1)) return;     // (union of the pieces of a triangle cut by the near plane)
     const float xs = 2.0f / (float)W, xo = 1.0f / (float)W - 1.0f;
     const float ys = 2.0f / (float)H, yo = 1.0f / (float)H - 1.0f;
     const float X0 = p2.y * p1.w - p1.y * p2.w, Y0 = p1.x * p2.w - p2.x * p1.w;

@@ -16,6 +16,23 @@ extern "C" const char* vhap_strerror(int code) {
     }
 }
 
+extern "C" int vhap_stream_create(vhap_stream_t* stream, int high_priority) {
+    VHAP_ENTER();
+    if (!stream) return VHAP_E_NULLPTR;
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return VHAP_E_HIP;
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, high_priority ? greatest : 0) != hipSuccess) return VHAP_E_HIP;   // 0 = normal (not `least`)
+    *stream = static_cast<vhap_stream_t>(st);
+    return VHAP_OK;
+}
+
+extern "C" int vhap_stream_destroy(vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!stream) return VHAP_E_NULLPTR;
+    return hipStreamDestroy(static_cast<hipStream_t>(stream)) == hipSuccess ? VHAP_OK : VHAP_E_HIP;
+}
+
 // Profiling / A-B switches (not part of the stable ABI): 16 = strided row order in the rasteriser, 32 = per-pixel texture backward
 // thread-local: the calling (profiling) thread only; not part of the stable ABI (not declared in vhap_hip.h)
 thread_local int vhap_g_debug_flags = 0;

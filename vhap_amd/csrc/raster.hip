@@ -35,7 +35,7 @@ constexpr unsigned TRANGE_NONE = 0xffffffffu;
 constexpr int LDS_BIN_LIMIT = 16384;  // dense per-workgroup bin histogram (<= 2 x 64 KiB of LDS)
 constexpr int BIN_THREADS = 1024;     // fat workgroups: fewer LDS-histogram flushes per frame
 
-// Per-(frame, triangle) setup record written once by bin_count (80 B, five 16-byte quads): everything
+// Per-(frame, piece) setup record written once by the binning kernel (80 B, five 16-byte quads): everything
 // the raster kernel needs that does not depend on the 8x8 block -- snapped vertices, pixel bbox, the
 // per-vertex z/w, 1/area (double) and the vertex / uv-vertex indices.  All the divisions of the setup
 // happen once per triangle here instead of once per (triangle, block, wave) in the raster kernel.
@@ -53,30 +53,67 @@ struct BinHeader {
     unsigned pad[15];
 };
 
-// Block range of one (frame, triangle): bx0 | bx1<<9 | by0<<18 | span<<27 with span = by1-by0, 31 =
-// "up to the last block row" (conservative; the raster kernel re-tests the bbox).  H,W <= 4096 -> < 512.
-// Also fills the triangle's setup record.
-__device__ __forceinline__ unsigned block_range(const float* __restrict__ pos, const int* __restrict__ tri,
-                                                const int* __restrict__ tri_uv, int b, int V, int t, int H, int W,
-                                                TriRecord& rec) {
-    const int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
-    if ((unsigned)i0 >= (unsigned)V || (unsigned)i1 >= (unsigned)V || (unsigned)i2 >= (unsigned)V) return TRANGE_NONE;
-    const float4* P = reinterpret_cast<const float4*>(pos) + (size_t)b * V;
-    const float4 p0 = P[i0], p1 = P[i1], p2 = P[i2];
+// Block range of one piece (a whole triangle, or a piece of a triangle cut by the near plane): bx0 | bx1<<9 | by0<<18 | span<<27 with
+// span = by1-by0, 31 = "up to the last block row" (conservative; the raster kernel re-tests the bbox).  H,W <= 4096 -> < 512.
+// Also fills the piece's setup record (geometry of the piece, vertex / uv indices of the triangle it belongs to).
+__device__ __forceinline__ unsigned piece_range(const float4 p0, const float4 p1, const float4 p2, int H, int W, int i0, int i1, int i2,
+                                                int j0, int j1, int j2, TriRecord& rec) {
+    rec.q3.z = i0; rec.q3.w = i1;
+    rec.q4 = make_int4(i2, j0, j1, j2);
     int sx[3], sy[3], px0, px1, py0, py1;
     long long area;
-    if (!tri_bbox(p0, p1, p2, H, W, sx, sy, area, px0, px1, py0, py1)) return TRANGE_NONE;
+    if (!tri_bbox(p0, p1, p2, H, W, sx, sy, area, px0, px1, py0, py1)) {
+        rec.q0 = rec.q1 = make_int4(0, 0, 0, 0);
+        rec.q2 = make_float4(0.f, 0.f, 0.f, 0.f);
+        rec.q3.x = rec.q3.y = 0;
+        return TRANGE_NONE;
+    }
     const double inv = 1.0 / (double)area;
     rec.q0 = make_int4(sx[0], sy[0], sx[1], sy[1]);
     rec.q1 = make_int4(sx[2], sy[2], px0 | (px1 << 16), py0 | (py1 << 16));
     rec.q2 = make_float4(__fdiv_rn(p0.z, p0.w), __fdiv_rn(p1.z, p1.w), __fdiv_rn(p2.z, p2.w), 0.0f);
-    rec.q3 = make_int4(__double2loint(inv), __double2hiint(inv), i0, i1);
-    int j0 = 0, j1 = 0, j2 = 0;
-    if (tri_uv) { j0 = tri_uv[3 * t]; j1 = tri_uv[3 * t + 1]; j2 = tri_uv[3 * t + 2]; }
-    rec.q4 = make_int4(i2, j0, j1, j2);
+    rec.q3.x = __double2loint(inv); rec.q3.y = __double2hiint(inv);
     const int bx0 = px0 / BLK, bx1 = px1 / BLK, by0 = py0 / BLK, by1 = py1 / BLK;
     const int span = by1 - by0;
     return (unsigned)bx0 | ((unsigned)bx1 << 9) | ((unsigned)by0 << 18) | ((unsigned)(span > 30 ? 31 : span) << 27);
+}
+
+// Setup of one (frame, triangle): RECORD SLOTS t and F + t of the frame hold its (up to) two pieces -- slot t the triangle itself or
+// the first piece of a triangle cut by the near plane (raster_common.h), slot F + t the second piece (one vertex behind the plane: the
+// visible part is a quad).  Writes both range words and the records of the drawable pieces; returns the two range words.  The second
+// slot is TRANGE_NONE for every triangle that does not cross the plane (the whole head, always): one extra 4-byte store per triangle.
+struct TriRanges {
+    unsigned r0, r1;
+};
+__device__ __forceinline__ TriRanges triangle_setup(const float* __restrict__ pos, const int* __restrict__ tri,
+                                                    const int* __restrict__ tri_uv, int b, int V, int F, int t, int H, int W,
+                                                    unsigned* __restrict__ trange_b, TriRecord* __restrict__ records_b) {
+    TriRanges R{TRANGE_NONE, TRANGE_NONE};
+    const int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
+    if ((unsigned)i0 < (unsigned)V && (unsigned)i1 < (unsigned)V && (unsigned)i2 < (unsigned)V) {
+        const float4* P = reinterpret_cast<const float4*>(pos) + (size_t)b * V;
+        const float4 p0 = P[i0], p1 = P[i1], p2 = P[i2];
+        int j0 = 0, j1 = 0, j2 = 0;
+        if (tri_uv) { j0 = tri_uv[3 * t]; j1 = tri_uv[3 * t + 1]; j2 = tri_uv[3 * t + 2]; }
+        const int behind = vhap_behind_mask(p0, p1, p2);
+        TriRecord rec;
+        if (behind == 0) {
+            R.r0 = piece_range(p0, p1, p2, H, W, i0, i1, i2, j0, j1, j2, rec);
+            if (R.r0 != TRANGE_NONE) records_b[t] = rec;
+        } else if (behind != 7) {      // crosses the near plane (never the case for a tracked head: cold path)
+            float4 a0, a1, a2, b0, b1, b2;
+            const int np = vhap_clip_near(p0, p1, p2, behind, a0, a1, a2, b0, b1, b2);
+            R.r0 = piece_range(a0, a1, a2, H, W, i0, i1, i2, j0, j1, j2, rec);
+            records_b[t] = rec;        // always: the winner's indices are read from slot t whichever piece won
+            if (np == 2) {
+                R.r1 = piece_range(b0, b1, b2, H, W, i0, i1, i2, j0, j1, j2, rec);
+                if (R.r1 != TRANGE_NONE) records_b[F + t] = rec;
+            }
+        }
+    }
+    trange_b[t] = R.r0;
+    trange_b[F + t] = R.r1;
+    return R;
 }
 
 struct BlockRange {
@@ -109,14 +146,12 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_count_kernel(const float* __r
         __syncthreads();
     }
     unsigned* c = counts + (size_t)b * nbin;
-    unsigned tr = TRANGE_NONE;
-    if (t < F) {
-        TriRecord rec;
-        tr = block_range(pos, tri, tri_uv, b, V, t, H, W, rec);
-        trange[(size_t)b * F + t] = tr;
-        if (tr != TRANGE_NONE) records[(size_t)b * F + t] = rec;
-    }
-    if (tr != TRANGE_NONE) {
+    TriRanges R{TRANGE_NONE, TRANGE_NONE};
+    if (t < F) R = triangle_setup(pos, tri, tri_uv, b, V, F, t, H, W, trange + (size_t)b * 2 * F, records + (size_t)b * 2 * F);
+#pragma unroll
+    for (int piece = 0; piece < 2; piece++) {
+        const unsigned tr = piece ? R.r1 : R.r0;
+        if (tr == TRANGE_NONE) continue;
         const BlockRange r = decode_range(tr, nby);
         for (int y = r.by0; y <= r.by1; y++)
             for (int x = r.bx0; x <= r.bx1; x++) {
@@ -170,14 +205,21 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_fill_kernel(const unsigned* _
     unsigned* lbase = lds_fill + nbin;
     const int b = blockIdx.y, t = blockIdx.x * BIN_THREADS + threadIdx.x;
     const size_t tb = (size_t)b * nbin;
-    const unsigned tr = t < F ? trange[(size_t)b * F + t] : TRANGE_NONE;
-    BlockRange r{0, -1, 0, -1};
+    const unsigned tr = t < F ? trange[(size_t)b * 2 * F + t] : TRANGE_NONE;
+    const unsigned tr1 = t < F ? trange[(size_t)b * 2 * F + F + t] : TRANGE_NONE;     // second piece of a near-clipped triangle: slot F + t
+    BlockRange r{0, -1, 0, -1}, r1{0, -1, 0, -1};
     if (tr != TRANGE_NONE) r = decode_range(tr, nby);
+    if (tr1 != TRANGE_NONE) r1 = decode_range(tr1, nby);
     if (!use_lds) {
         for (int y = r.by0; y <= r.by1; y++)
             for (int x = r.bx0; x <= r.bx1; x++) {
                 const size_t bi = tb + y * nbx + x;
                 list[offsets[bi] + atomicAdd(&cursors[bi], 1u)] = (unsigned)t;
+            }
+        for (int y = r1.by0; y <= r1.by1; y++)
+            for (int x = r1.bx0; x <= r1.bx1; x++) {
+                const size_t bi = tb + y * nbx + x;
+                list[offsets[bi] + atomicAdd(&cursors[bi], 1u)] = (unsigned)(F + t);
             }
         return;
     }
@@ -185,6 +227,8 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_fill_kernel(const unsigned* _
     __syncthreads();
     for (int y = r.by0; y <= r.by1; y++)
         for (int x = r.bx0; x <= r.bx1; x++) atomicAdd(&lcnt[y * nbx + x], 1u);
+    for (int y = r1.by0; y <= r1.by1; y++)
+        for (int x = r1.bx0; x <= r1.bx1; x++) atomicAdd(&lcnt[y * nbx + x], 1u);
     __syncthreads();
     for (int i = threadIdx.x; i < nbin; i += BIN_THREADS) {
         const unsigned n = lcnt[i];
@@ -198,6 +242,11 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_fill_kernel(const unsigned* _
         for (int x = r.bx0; x <= r.bx1; x++) {
             const int bi = y * nbx + x;
             list[lbase[bi] + atomicAdd(&lcnt[bi], 1u)] = (unsigned)t;
+        }
+    for (int y = r1.by0; y <= r1.by1; y++)
+        for (int x = r1.bx0; x <= r1.bx1; x++) {
+            const int bi = y * nbx + x;
+            list[lbase[bi] + atomicAdd(&lcnt[bi], 1u)] = (unsigned)(F + t);
         }
 }
 
@@ -261,17 +310,15 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_build_kernel(const float* __r
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < nbin; i += BIN_THREADS) lb[i] = 0u;
     __syncthreads();
-    unsigned tr = TRANGE_NONE;
-    if (t < F) {
-        TriRecord rec;
-        tr = block_range(pos, tri, tri_uv, b, V, t, H, W, rec);
-        trange[(size_t)b * F + t] = tr;
-        if (tr != TRANGE_NONE) records[(size_t)b * F + t] = rec;
-    }
-    BlockRange r{0, -1, 0, -1};
-    if (tr != TRANGE_NONE) r = decode_range(tr, nby);
+    TriRanges R{TRANGE_NONE, TRANGE_NONE};
+    if (t < F) R = triangle_setup(pos, tri, tri_uv, b, V, F, t, H, W, trange + (size_t)b * 2 * F, records + (size_t)b * 2 * F);
+    BlockRange r{0, -1, 0, -1}, r1{0, -1, 0, -1};
+    if (R.r0 != TRANGE_NONE) r = decode_range(R.r0, nby);
+    if (R.r1 != TRANGE_NONE) r1 = decode_range(R.r1, nby);     // second piece of a triangle cut by the near plane (cold)
     for (int y = r.by0; y <= r.by1; y++)
         for (int x = r.bx0; x <= r.bx1; x++) atomicAdd(&lb[y * nbx + x], 1u);
+    for (int y = r1.by0; y <= r1.by1; y++)
+        for (int x = r1.bx0; x <= r1.bx1; x++) atomicAdd(&lb[y * nbx + x], 1u);
     __syncthreads();
     // exclusive scan of lb[] over the workgroup: every lane owns `per` consecutive bins
     const int per = (nbin + BIN_THREADS - 1) / BIN_THREADS;
@@ -297,7 +344,9 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_build_kernel(const float* __r
     for (int i = i0; i < i1; i++) {
         const unsigned n = lb[i];
         uint2 d = make_uint2(0u, 0u);
-        if (n) d = overflow ? make_uint2((unsigned)(wg * BIN_THREADS), FRAG_OVERFLOW | (unsigned)ntri) : make_uint2(base + pre, n);
+        // overflow: the raster blocks scan this workgroup's 2 * ntri record slots (ntri first pieces at wg * 1024 + j, then the ntri second
+        // pieces at F + wg * 1024 + j) directly
+        if (n) d = overflow ? make_uint2((unsigned)(wg * BIN_THREADS), FRAG_OVERFLOW | (unsigned)(2 * ntri)) : make_uint2(base + pre, n);
         frag[((size_t)b * nfrag + wg) * nbin + i] = d;     // workgroup-major: coalesced here, nfrag scattered 8-byte reads per raster wave
         lb[i] = pre;          // write cursor of this bin inside the region
         pre += n;
@@ -306,6 +355,8 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_build_kernel(const float* __r
     __syncthreads();
     for (int y = r.by0; y <= r.by1; y++)
         for (int x = r.bx0; x <= r.bx1; x++) list[base + atomicAdd(&lb[y * nbx + x], 1u)] = (unsigned)t;
+    for (int y = r1.by0; y <= r1.by1; y++)
+        for (int x = r1.bx0; x <= r1.bx1; x++) list[base + atomicAdd(&lb[y * nbx + x], 1u)] = (unsigned)(F + t);
     prof_end(prof);
 }
 
@@ -419,7 +470,7 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterParams P) {
         }
         n = (P.debug & 1) ? 0u : run;
     } else {
-        n = (P.debug & 1) ? 0u : (use_list ? P.counts[bin] : (unsigned)P.F);
+        n = (P.debug & 1) ? 0u : (use_list ? P.counts[bin] : 2u * (unsigned)P.F);   // brute force: every record slot (two per triangle)
         off = use_list ? P.offsets[bin] : 0u;
         if (lane == 0) {   // leave the workspace clean for the next call (see VHAP_RASTER_WS_CLEAN)
             P.counts_w[bin] = 0u;
@@ -433,8 +484,8 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterParams P) {
     const int cx = 16 * bx0 + 8, cy = 16 * by0 + 8;  // sub-pixel position of the block-origin pixel centre
     const int dx16 = dxp * 16, dy16 = dyp * 16;
     const float fdx = (float)dxp, fdy = (float)dyp;
-    const TriRecord* REC = P.records + (size_t)b * P.F;
-    const unsigned* TR = P.trange + (size_t)b * P.F;
+    const TriRecord* REC = P.records + (size_t)b * 2 * P.F;     // record slots t and F + t: the (up to) two pieces of triangle t
+    const unsigned* TR = P.trange + (size_t)b * 2 * P.F;
 
     __shared__ int4 sd[4][4][64];  // per-wave broadcast staging of the current chunk (4 KiB per wave)
     typedef short short2_t __attribute__((ext_vector_type(2)));
@@ -457,12 +508,17 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterParams P) {
                     if ((int)k >= d.x) sel = d;
                 }
                 direct = ((unsigned)sel.y & FRAG_OVERFLOW) != 0u;
-                const unsigned idx = (unsigned)sel.z + (k - (unsigned)sel.x);
-                t = direct ? (int)idx : (int)P.list[idx];
+                const unsigned loc = k - (unsigned)sel.x;
+                if (direct) {                 // overflowed workgroup: its ntri first-piece slots, then its ntri second-piece slots
+                    const unsigned ntri = ((unsigned)sel.y & ~FRAG_OVERFLOW) >> 1;
+                    t = (int)(loc < ntri ? (unsigned)sel.z + loc : (unsigned)P.F + (unsigned)sel.z + (loc - ntri));
+                } else {
+                    t = (int)P.list[(unsigned)sel.z + loc];
+                }
             } else {
                 t = use_list ? (int)P.list[off + k] : (int)k;
             }
-            if (!direct || (t < P.F && TR[t] != TRANGE_NONE)) {  // direct mode: skip culled triangles (no record)
+            if (!direct || TR[t] != TRANGE_NONE) {  // direct mode (t < 2F by construction): skip culled triangles / absent pieces (no record)
                 // the whole 80-byte record in one batch of loads: a wave's life is a chain of dependent global loads (descriptor ->
                 // list -> record -> winner's vertices), each a full memory latency while the chip is saturated with stores, so the
                 // bbox test must not gate a second round trip; the vertex / uv indices ride along for the same reason (below)
@@ -533,7 +589,8 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterParams P) {
         // so no barrier is needed.
         sd[wave][0][lane] = make_int4(AB0, AB1, AB2, C0);
         sd[wave][1][lane] = make_int4(C1, C2, __float_as_int(zwc), __float_as_int(gx));
-        sd[wave][2][lane] = make_int4(__float_as_int(gy), (t << 6) | lane, vi0, vi1);   // key word: triangle id, then its slot in this chunk
+        const int tid = t >= P.F ? t - P.F : t;          // a record slot's triangle id (slot F + t: second piece of a near-clipped triangle t)
+        sd[wave][2][lane] = make_int4(__float_as_int(gy), (tid << 6) | lane, vi0, vi1);   // key word: triangle id, then its slot in this chunk
         sd[wave][3][lane] = vidx;
         // Coverage loop, software-pipelined: the broadcast reads of the NEXT triangle are issued before the arithmetic of the current
         // one, so the DS latency (~100 cycles, paid per triangle otherwise) overlaps the ~17 VALU instructions of the test.
@@ -569,7 +626,7 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterParams P) {
             const long long E2 = (long long)A2 * (pcx - sx0) + (long long)B2 * (pcy - sy0) + ((A2 > 0 || (A2 == 0 && B2 > 0)) ? 0 : -1);
             const float zt = __fmaf_rn(rl(gx, j), fdx, __fmaf_rn(rl(gy, j), fdy, rl(zwc, j)));
             const bool inside = ((E0 | E1 | E2) >= 0) && (zt >= -1.0f && zt <= 1.0f);
-            const unsigned long long key = ((unsigned long long)f2ord(zt) << 32) | (unsigned)((tj << 6) | j);
+            const unsigned long long key = ((unsigned long long)f2ord(zt) << 32) | (unsigned)(((tj >= P.F ? tj - P.F : tj) << 6) | j);
             if (inside && key < best) best = key;
         }
     }
@@ -744,8 +801,8 @@ WsLayout ws_layout(int B, int F, int nbin, size_t cap, size_t npart) {
     l.counts = o; o = al(o + sizeof(unsigned) * (size_t)B * nbin);
     l.cursors = o; o = al(o + sizeof(unsigned) * (size_t)B * nbin);
     l.offsets = o; o = al(o + sizeof(unsigned) * (size_t)B * nbin);
-    l.trange = o; o = al(o + sizeof(unsigned) * (size_t)B * F);
-    l.records = o; o = al(o + sizeof(TriRecord) * (size_t)B * F);
+    l.trange = o; o = al(o + sizeof(unsigned) * (size_t)B * F * 2);      // two slots per triangle (near-plane clipping)
+    l.records = o; o = al(o + sizeof(TriRecord) * (size_t)B * F * 2);
     l.list = o; o = al(o + sizeof(unsigned) * (cap ? cap : 1));
     l.frag = o; o = al(o + sizeof(uint2) * (size_t)B * nbin * ((F + BIN_THREADS - 1) / BIN_THREADS));
     l.stats = o; o = al(o + sizeof(uint4) * npart);                 // per-wave shading-statistics partials (mode 2): 4 per raster workgroup
@@ -758,7 +815,7 @@ WsLayout ws_layout(int B, int F, int nbin, size_t cap, size_t npart) {
 int check_dims(int B, int V, int F, int H, int W) {
     if (B <= 0 || V <= 0 || F <= 0 || H <= 0 || W <= 0) return VHAP_E_BADDIM;
     if (H > 4096 || W > 4096 || F >= (1 << 24)) return VHAP_E_BADDIM;
-    if ((long long)B * F >= (1ll << 31) || B > 65535) return VHAP_E_BADDIM;
+    if ((long long)B * F >= (1ll << 30) || B > 65535) return VHAP_E_BADDIM;
     return VHAP_OK;
 }
 

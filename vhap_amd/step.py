@@ -235,13 +235,14 @@ class NativeStep:
                                       # at the head of the step, texture update behind its gradient, the rest before the final join
         self.split_tex = False        # True: stop at the gradient pyramid, the caller runs tex_finish() later (pyramid-level exchange)
         self.tex_l0_skip = False      # True: tex_finish() ignores the base level of the pyramid
-        self.side = torch.cuda.Stream()
-        self.side2 = torch.cuda.Stream()
+        # streams of the library's own (never torch's pool: see _lib.private_stream), shared by every step of this thread
+        self.side = _lib.private_stream("side", dev)
+        self.side2 = _lib.private_stream("side2", dev)
         self.main_first = os.environ.get("VHAP_FORK_ORDER", "1") != "0"
         self._pending = []
         # VHAP_PRIO=1: the backward's texture chain (the step's critical path) on a high-priority stream -- its workgroups are dispatched ahead
         # of the geometry chain's where the two share the chip
-        self.side_b = torch.cuda.Stream(priority=-1) if os.environ.get("VHAP_PRIO", "0") != "0" else self.side
+        self.side_b = _lib.private_stream("side_b", dev, high_priority=True) if os.environ.get("VHAP_PRIO", "0") != "0" else self.side
         self.c_lmk = torch.full((1,), self.w_lmk, **f32)
         self.c_reg = torch.full((1,), self.w_reg, **f32)
 

@@ -19,6 +19,7 @@ import torch
 import torch.nn.functional as F
 
 from .config import BaseTrackingConfig, PhotometricStageConfig
+from . import _lib
 from . import fused as FU
 from . import native as NV
 from .flame import FlameHead, FlameTexPainted, FlameUvMask
@@ -952,7 +953,7 @@ class GraphedStep:
         self.unroll = 1
         use_native_step = os.environ.get("VHAP_NATIVE_STEP", "1") != "0" and NativeStep.supported(tracker, stage) and \
             isinstance(optimizer, NV.HipAdam)
-        side = torch.cuda.Stream()
+        side = _lib.private_stream("warm", dev)                   # (library-owned streams, never torch's pool: _lib.private_stream)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):                                # optional real steps before the capture
@@ -981,12 +982,17 @@ class GraphedStep:
                 self.ns.backward(1)
         torch.cuda.current_stream().wait_stream(side)
         self.inv_n = torch.zeros((), device=dev)
-        self.stream = torch.cuda.Stream()
+        # The LAUNCH stream is a high-priority stream of the library's own.  hipGraphLaunch (ROCm 7) lays a graph's parallel branches out over
+        # internal normal-priority streams and skips those that share the launch stream's hardware queue -- without a bounds check: when one
+        # did (which depends on every stream the process created before: tools/dbg/graph_stream_collision.py), it ran off the end of the
+        # list and dereferenced garbage.  Hardware queues are pooled per priority, so a high-priority launch stream can never share one.
+        self._launch_hi = os.environ.get("VHAP_LAUNCH_PRIO", "high") != "normal"          # (env: debugging / A-B only)
+        self.stream = _lib.private_stream("launch", dev, high_priority=self._launch_hi)
         # with a process group alive, its helper threads (RCCL watchdog, heartbeat) issue runtime calls of their own: keep those from
         # invalidating a capture in progress on this thread
         cap = dict(capture_error_mode="thread_local") if tracker.dist is not None else {}
         if os.environ.get("VHAP_PRIO", "0") == "2":                 # (experiment: the main chain of the captured step on a high-priority stream)
-            cap["stream"] = torch.cuda.Stream(priority=-1)
+            cap["stream"] = _lib.private_stream("capture_hi", dev, high_priority=True)
         self.gF, self.gB, self.gA = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         if self.ns is not None:
             ns = self.ns
@@ -1049,7 +1055,7 @@ class GraphedStep:
                     self.gBt = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(self.gBt, **cap):               # replayed concurrently with gB2: a pool of its own
                         ns.backward(world, part="tex")
-                    self.tex_stream = torch.cuda.Stream()
+                    self.tex_stream = _lib.private_stream("tex", dev, high_priority=self._launch_hi)    # (launches gBt)
                 else:
                     with torch.cuda.graph(self.gB, pool=pool, **cap):
                         ns.backward(world, part="texture")
@@ -1117,8 +1123,9 @@ class GraphedStep:
             self.opt.sync_lr()                                     # lr schedulers act on the host copy
         # Replays go to a stream of our own, never the null stream: on ROCm 7.2 the memset nodes that torch's reductions
         # record (semaphore clears) were observed out of order with their kernels when a graph is launched on stream 0.
+        # ... and never any stream but the step's own launch stream (see __init__: the runtime's graph launch is only safe there).
         cur = torch.cuda.current_stream()
-        if cur.cuda_stream == 0 and os.environ.get("VHAP_GRAPH_NULL_STREAM") != "1":   # (env: debugging only)
+        if cur.cuda_stream != self.stream.cuda_stream and os.environ.get("VHAP_GRAPH_NULL_STREAM") != "1":   # (env: debugging only)
             self.stream.wait_stream(cur)
             with torch.cuda.stream(self.stream):
                 self._replay()
