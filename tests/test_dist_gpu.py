@@ -167,7 +167,8 @@ def test_bench_multi_rank_path_runs_under_torchrun_with_gloo():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--backend", "gloo",
            "--scaling", "strong", "--no-cpu-baseline"]
-    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=900)
+    env = {k: v for k, v in os.environ.items() if k != "VHAP_LAUNCH_PRIO"}      # fresh processes, the shipped default (tests/conftest.py)
+    r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
