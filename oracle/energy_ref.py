@@ -22,6 +22,20 @@ def _laplacian(V, topo):
     return _LAP[V]
 
 
+def vertex_weights(V, topo, scale_factor, region, blur_iter, L, dtype):
+    """scale_vertex_weights_by_region, tracker.py:607-614: ones, the region's vertices scaled, then `blur_iter` rounds of
+    weights <- M weights / 2 with M = L - 2 diag(L) (flame.py:199-201: the uniform Laplacian with its diagonal negated, i.e. the mean of a
+    vertex's own weight and the mean weight of its neighbours)."""
+    wv = torch.ones(1, V, 1, dtype=dtype)
+    wv[:, torch.from_numpy(topo.get_vid_by_region(list(region)))] *= scale_factor
+    if blur_iter:
+        Ld = L.to(dtype)
+        M = Ld - 2 * torch.diag(torch.diag(Ld))
+        for _ in range(int(blur_iter)):
+            wv = (M @ wv[0])[None] / 2
+    return wv
+
+
 def joint_l2(neck, jaw, eyes, w):
     """tracker.py:650-680."""
     e = 0
@@ -69,11 +83,9 @@ def regularization_energy(P, ts, w, stage, opt, tex_painted, uvmask_res, v_cano,
         V = off.shape[1]
         L = _laplacian(V, topo).to(dtype)
         v0 = (v_cano - off).detach()
-        wl = torch.ones(1, V, 1, dtype=dtype)
-        wl[:, torch.from_numpy(topo.get_vid_by_region(list(w.reg_offset_lap_relax_for)))] *= w.reg_offset_lap_relax_coef
+        wl = vertex_weights(V, topo, w.reg_offset_lap_relax_coef, w.reg_offset_lap_relax_for, w.blur_iter, L, dtype)
         log["reg_offset_lap"] = w.reg_offset_lap * R.laplacian_energy(L, v0, v0 + off, wl)
-        wo = torch.ones(1, V, 1, dtype=dtype)
-        wo[:, torch.from_numpy(topo.get_vid_by_region(list(w.reg_offset_relax_for)))] *= w.reg_offset_relax_coef
+        wo = vertex_weights(V, topo, w.reg_offset_relax_coef, w.reg_offset_relax_for, w.blur_iter, L, dtype)
         log["reg_offset"] = w.reg_offset * (off.abs() * wo).mean()
         rigid = 0
         for region in w.reg_offset_rigid_for:

@@ -490,3 +490,40 @@ def test_renderer_surface_accepts_the_reference_tracker_calls():
     for name, npos, kws in calls:
         fn = getattr(HipDiffRenderer, name)
         inspect.signature(fn).bind(*([None] * (npos + 1)), **{k: None for k in kws})     # (+1: self)
+
+
+def test_blur_iter_vertex_weights_match_reference(flame_model):
+    """`w.blur_iter > 0` (base.py:181): the reference's own scale_vertex_weights_by_region (tracker.py:607-614; golden from
+    tools/make_golden_blur.py) against the oracle's vertex_weights and the product's host-side table -- which is all the native kernels
+    ever see of it -- and the two relaxed offset regularisers computed with them.  (The reference's blur only accepts a batch of one.)"""
+    from oracle import energy_ref
+    from vhap_amd.config import BaseTrackingConfig
+    from vhap_amd.synthetic import make_texture
+    from vhap_amd.tracker import GlobalTracker
+    model, topo = flame_model
+    GB = np.load(os.path.join(os.path.dirname(__file__), "golden", "blur_golden.npz"))
+    V = GB["v_cano"].shape[1]
+    cfg = BaseTrackingConfig()
+    cfg.device = "cpu"
+    cfg.model.tex_resolution = 32
+    tr = GlobalTracker(cfg, model, topo, make_texture(0, 32), {"rgb": torch.zeros(3, 3, 16, 16), "lmk2d": torch.zeros(3, 70, 3)})
+    L = energy_ref._laplacian(V, topo)
+    w = cfg.w
+    off = torch.from_numpy(GB["static_offset"])
+    v_cano = torch.from_numpy(GB["v_cano"])
+    for it in (1, 3):
+        w.blur_iter = it
+        for tag, coef, region in (("lap", w.reg_offset_lap_relax_coef, w.reg_offset_lap_relax_for), ("off", w.reg_offset_relax_coef, w.reg_offset_relax_for)):
+            want = torch.from_numpy(GB[f"w_{tag}_{it}"])
+            got_o = energy_ref.vertex_weights(V, topo, coef, region, it, L, torch.float64)
+            got_p = tr._vertex_weights(tag, coef, region)
+            assert float((got_o - want).abs().max()) < 1e-12, (tag, it)
+            assert float((got_p.double() - want).abs().max()) < 1e-6, (tag, it)
+            assert float((want - 1).abs().max()) > 0.05 and float(want.min()) < 1 - 1e-3          # blurred, not the 0/1 table
+        wl = energy_ref.vertex_weights(V, topo, w.reg_offset_lap_relax_coef, w.reg_offset_lap_relax_for, it, L, torch.float64)
+        wo = energy_ref.vertex_weights(V, topo, w.reg_offset_relax_coef, w.reg_offset_relax_for, it, L, torch.float64)
+        v0 = v_cano - off
+        e_lap = w.reg_offset_lap * R.laplacian_energy(L.double(), v0, v0 + off, wl)
+        e_off = w.reg_offset * (off.abs() * wo).mean()
+        assert abs(float(e_lap) - float(GB[f"reg_offset_lap_{it}"])) <= 1e-9 * abs(float(GB[f"reg_offset_lap_{it}"]))
+        assert abs(float(e_off) - float(GB[f"reg_offset_{it}"])) <= 1e-9 * abs(float(GB[f"reg_offset_{it}"]))

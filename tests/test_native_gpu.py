@@ -83,6 +83,30 @@ def test_native_energy_matches_host_formulation(tracker, stage, ts):
         assert rel < 2e-3, f"{stage}: grad {k}: rel {rel:.3e}"
 
 
+def test_native_offset_regularisers_with_blurred_relax_weights(tracker):
+    """`w.blur_iter > 0`: the relax tables become smooth per-vertex floats (host side, pinned on the reference in
+    tests/test_energy_golden.py); the native offset-regulariser kernels must weight with them exactly like the host formulation."""
+    tr = tracker
+    stage, ts = "rgb_init_offset", np.array([3, 1])
+    keep = tr.cfg.w.blur_iter
+    tr.cfg.w.blur_iter = 2
+    tr._nm = None                       # rebuild the native tables with the blurred weights
+    try:
+        assert tr._native_ok(stage)
+        wl = tr._vertex_weights("lap", tr.cfg.w.reg_offset_lap_relax_coef, tr.cfg.w.reg_offset_lap_relax_for)
+        assert float((wl - wl.round()).abs().max()) > 0.05              # genuinely blurred
+        E0, log0, g0, _ = _run(tr, stage, ts, False, None)
+        E1, log1, g1, _ = _run(tr, stage, ts, True, None)
+    finally:
+        tr.native = True
+        tr.cfg.w.blur_iter = keep
+        tr._nm = None
+    for k in ("reg_offset_lap", "reg_offset", "reg_offset_rigid"):
+        assert abs(log0[k] - log1[k]) <= 1e-4 * max(abs(log0[k]), 1e-6), (k, log0[k], log1[k])
+    a, b = g0["static_offset"], g1["static_offset"]
+    assert float((a - b).abs().max()) <= 2e-3 * float(a.abs().max())
+
+
 def test_hip_adam_matches_torch_adam():
     from vhap_amd.native import HipAdam
     g = torch.Generator().manual_seed(0)

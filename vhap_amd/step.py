@@ -237,7 +237,7 @@ class NativeStep:
         self.tex_l0_skip = False      # True: tex_finish() ignores the base level of the pyramid
         # streams of the library's own (never torch's pool: see _lib.private_stream), shared by every step of this thread
         self.side = _lib.private_stream("side", dev)
-        self.side2 = _lib.private_stream("side2", dev)
+        self.side2 = _lib.private_stream("side2", dev) if os.environ.get("VHAP_SIDE2", "1") != "0" else self.side   # (env: A/B, two branches only)
         self.main_first = os.environ.get("VHAP_FORK_ORDER", "1") != "0"
         self._pending = []
         # VHAP_PRIO=1: the backward's texture chain (the step's critical path) on a high-priority stream -- its workgroups are dispatched ahead

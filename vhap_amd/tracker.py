@@ -290,13 +290,20 @@ class FlameTracker:
         return self._uvmask_res_cache
 
     def _vertex_weights(self, key, scale_factor, region):
-        """tracker.py:607-614 with blur_iter = 0 (the default): per-vertex weights [1,V,1], cached."""
-        ck = ("vw", key)
+        """scale_vertex_weights_by_region (tracker.py:607-614): per-vertex weights [1,V,1] -- ones, the region scaled, then `blur_iter` rounds
+        of w <- M w / 2 with M = L - 2 diag(L) (flame.py:199-201) applied through the CSR Laplacian (M w = L w - 2 d * w).  A static table:
+        built once per (stage table, blur_iter) on the host side and cached; the native kernels only ever read it."""
+        ck = ("vw", key, int(self.cfg.w.blur_iter))
         if ck not in self._region_cache:
             wv = torch.ones(1, self.flame.v_template.shape[0], 1, device=self.device)
             wv[:, self.flame.mask.get_vid_by_region(list(region))] *= scale_factor
             if self.cfg.w.blur_iter:
-                raise NotImplementedError("blur_iter > 0 is not implemented (default is 0)")
+                fl = self.flame
+                diag = torch.zeros(wv.shape[1], device=self.device, dtype=wv.dtype)
+                on_diag = fl.lap_row == fl.lap_col
+                diag.index_add_(0, fl.lap_row[on_diag], fl.lap_val[on_diag].to(wv.dtype))
+                for _ in range(int(self.cfg.w.blur_iter)):
+                    wv = (fl.laplacian_apply(wv) - 2 * diag[None, :, None] * wv) / 2
             self._region_cache[ck] = wv
         return self._region_cache[ck]
 
@@ -376,7 +383,7 @@ class FlameTracker:
     def _native_ok(self, stage):
         return (self.fused and self.native and stage is not None and str(self.device).startswith("cuda") and
                 not self.cfg.model.use_dynamic_offset and self.render.lighting_type == "SH" and
-                self.render.lighting_space == "world" and len(self.flame._parents) == 5 and not self.cfg.w.blur_iter and
+                self.render.lighting_space == "world" and len(self.flame._parents) == 5 and
                 self.cfg.model.tex_extra and self.cfg.model.residual_tex)
 
     def _native_models(self):
