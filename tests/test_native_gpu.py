@@ -95,8 +95,9 @@ def test_native_offset_regularisers_with_blurred_relax_weights(tracker):
         assert tr._native_ok(stage)
         wl = tr._vertex_weights("lap", tr.cfg.w.reg_offset_lap_relax_coef, tr.cfg.w.reg_offset_lap_relax_for)
         assert float((wl - wl.round()).abs().max()) > 0.05              # genuinely blurred
-        E0, log0, g0, _ = _run(tr, stage, ts, False, None)
-        E1, log1, g1, _ = _run(tr, stage, ts, True, None)
+        dist = tr.render.make_disturbance((len(ts), H, W), "cuda", generator=torch.Generator("cuda").manual_seed(4))
+        E0, log0, g0, _ = _run(tr, stage, ts, False, dist)
+        E1, log1, g1, _ = _run(tr, stage, ts, True, dist)
     finally:
         tr.native = True
         tr.cfg.w.blur_iter = keep
