@@ -5,8 +5,9 @@
 // oracle/raster_oracle.c, against which this file is checked bit-for-bit (triangle ids, z/w, u, v).
 //
 // Structure (one frame batch = 2 launches):
-//   bin_build  : 1 thread / (frame, triangle): snap to 1/16 px, cull, pixel bbox -> range of 8x8 pixel BLOCKS, 80-byte setup
-//                record; every 1024-triangle workgroup lays its (triangle, block) pairs out in its own region of the pair list
+//   bin_build  : 1 thread / (frame, triangle): near-plane clipping if the triangle crosses z = -w (one or two PIECES, raster_common.h;
+//                record slots t and F + t), snap to 1/16 px, cull, pixel bbox -> range of 8x8 pixel BLOCKS, 80-byte setup
+//                record; every 1024-triangle workgroup lays its (piece, block) pairs out in its own region of the pair list
 //                (LDS histogram -> workgroup scan -> scatter) and publishes fragment descriptors -- no global counters.
 //                (bin_count / bin_scan / bin_fill: the three-launch variant with contiguous lists, for meshes > 32768 triangles.)
 //   raster     : 1 workgroup = 4 waves = 32x8 pixels, each WAVE owns one 8x8 block and walks its fragments.  Per 64-triangle
