@@ -310,6 +310,14 @@ size_t vhap_antialias_inplace_work_ints(int B, int H, int W, int F);
 int vhap_antialias_inplace_fwd(float* color, const float* rast, const float* pos, const int32_t* tri,
                                const int32_t* opp, int B, int H, int W, int V, int F, int32_t* work,
                                vhap_stream_t stream);
+/* The same pass as two calls, detect + blend == vhap_antialias_inplace_fwd: `detect` (silhouette flags and pixel-pair discovery) reads
+ * only rast and the geometry, NOT the colours, so it can be issued right behind the rasteriser, beside whatever still produces the
+ * colours (render_nvdiffrast.py:424-460 runs between the two); `blend` (edge analysis, in-place update) needs the final colours. */
+int vhap_antialias_inplace_detect(const float* rast, const float* pos, const int32_t* tri, const int32_t* opp, int B,
+                                  int H, int W, int V, int F, int32_t* work, vhap_stream_t stream);
+int vhap_antialias_inplace_blend(float* color, const float* rast, const float* pos, const int32_t* tri,
+                                 const int32_t* opp, int B, int H, int W, int V, int F, int32_t* work,
+                                 vhap_stream_t stream);
 int vhap_antialias_photo_bwd(const float* pred_rgba, const float* gt_nchw, const float* d_sum,
                              const float* rast, const float* pos, const int32_t* tri, const int32_t* opp,
                              const int32_t* work, const uint8_t* pos_nograd_verts, int B, int H, int W, int V,

@@ -563,6 +563,42 @@ extern "C" int vhap_antialias_inplace_fwd(float* color, const float* rast, const
     return VHAP_OK;
 }
 
+// The same pass in two calls: `detect` (silhouette flags + pixel-pair discovery) reads only the rasteriser's output and the geometry --
+// NOT the colours -- so a step executor issues it right behind the rasteriser, beside whatever still produces the colours (the colour
+// disturbance), and `blend` (edge analysis + in-place colour update) once the colours are final.  detect + blend == vhap_antialias_inplace_fwd.
+extern "C" int vhap_antialias_inplace_detect(const float* rast, const float* pos, const int32_t* tri, const int32_t* opp, int B, int H, int W,
+                                             int V, int F, int32_t* work, vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!rast || !pos || !tri || !opp || !work) return VHAP_E_NULLPTR;
+    if (B <= 0 || H <= 0 || W <= 0 || V <= 0 || F <= 0 || (long long)B * H * W >= (1ll << 30)) return VHAP_E_BADDIM;
+    const long long npix = (long long)B * H * W;
+    hipStream_t st = vhap_stream(stream);
+    unsigned char* sil = reinterpret_cast<unsigned char*>(work + 4 + (size_t)ITEM2 * 2 * (size_t)npix);
+    unsigned* cand = reinterpret_cast<unsigned*>(work + 4 + (size_t)ITEM2 * 2 * (size_t)npix + ((size_t)B * F + 3) / 4);
+    aa_silhouette_kernel<<<vhap_cdiv((long long)B * F, 256), 256, 0, st>>>(reinterpret_cast<const float4*>(pos), tri, opp, B, V, F, H, W, sil, work);
+    VHAP_LAUNCH_CHECK();
+    aa_detect_kernel<4><<<vhap_cdiv(npix, DET_T * DET_PPT), DET_T, 0, st>>>(nullptr, reinterpret_cast<const float4*>(rast), sil, B, H, W, F, nullptr,
+                                                                          work, cand, 0);
+    VHAP_LAUNCH_CHECK();
+    return VHAP_OK;
+}
+
+extern "C" int vhap_antialias_inplace_blend(float* color, const float* rast, const float* pos, const int32_t* tri, const int32_t* opp, int B,
+                                            int H, int W, int V, int F, int32_t* work, vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!color || !rast || !pos || !tri || !opp || !work) return VHAP_E_NULLPTR;
+    if (B <= 0 || H <= 0 || W <= 0 || V <= 0 || F <= 0 || (long long)B * H * W >= (1ll << 30)) return VHAP_E_BADDIM;
+    const long long npix = (long long)B * H * W;
+    hipStream_t st = vhap_stream(stream);
+    unsigned* cand = reinterpret_cast<unsigned*>(work + 4 + (size_t)ITEM2 * 2 * (size_t)npix + ((size_t)B * F + 3) / 4);
+    aa_blend2_kernel<<<1024, 256, 0, st>>>(reinterpret_cast<const float4*>(color), reinterpret_cast<const float4*>(rast),
+                                          reinterpret_cast<const float4*>(pos), tri, opp, cand, H, W, V, F, work);
+    VHAP_LAUNCH_CHECK();
+    aa_apply_kernel<<<256, 256, 0, st>>>(work, W, color);
+    VHAP_LAUNCH_CHECK();
+    return VHAP_OK;
+}
+
 extern "C" int vhap_antialias_photo_bwd(const float* pred_rgba, const float* gt_nchw, const float* d_sum, const float* rast, const float* pos,
                                         const int32_t* tri, const int32_t* opp, const int32_t* work, const uint8_t* pos_nograd_verts, int B,
                                         int H, int W, int V, int F, float* d_delta, float* d_pos, vhap_stream_t stream) {

@@ -473,6 +473,16 @@ class NativeStep:
             self._side(lambda: _chk(L.vhap_raster_shade_stats(B, F, H, W, _p(self.ws), self.ws_bytes, self.ws_cap, 1, _p(acc[12:16]), _stream()),
                                     "vhap_raster_shade_stats"))
 
+        # the antialiasing's pair discovery needs the rasteriser's output only, not the colours: beside the colour disturbance (143 us of
+        # the main chain) instead of behind it -- 60 us less on the critical path
+        self._aa_det = None
+        if self.aa_inplace and self.overlap and os.environ.get("VHAP_AA_EARLY", "1") != "0":
+            def detect_branch():
+                _chk(L.vhap_antialias_inplace_detect(_p(self.rast), _p(self.clip), _p(self.tri), _p(self.opp), B, H, W, V, F, _p(self.aa_work),
+                                                     _stream()), "vhap_antialias_inplace_detect")
+                self._aa_det = torch.cuda.Event()
+                self._aa_det.record()
+            self._side(detect_branch, self.side2 if os.environ.get("VHAP_AA_EARLY", "1") == "2" else None)   # (on the texture branch's queue: idle here)
         color = self.rgba
         if self.disturb_on:
             _chk(L.vhap_disturb_fwd_rng_cid(_p(self.rgba), _p(self.cid), self.ncl, float(self.rate_fg or 0.0), float(self.rate_bg or 0.0),
@@ -497,8 +507,15 @@ class NativeStep:
             self._side(sort_branch)
         self.aa_in = color
         if self.aa_inplace:
-            _chk(L.vhap_antialias_inplace_fwd(_p(color), _p(self.rast), _p(self.clip), _p(self.tri), _p(self.opp), B, H, W, V, F,
-                                              _p(self.aa_work), st), "vhap_antialias_inplace_fwd")
+            if self._aa_det is not None or self._pending:
+                self._flush()                                      # (the detect branch, had no _flush() come since)
+            if self._aa_det is not None:
+                torch.cuda.current_stream().wait_event(self._aa_det)
+                _chk(L.vhap_antialias_inplace_blend(_p(color), _p(self.rast), _p(self.clip), _p(self.tri), _p(self.opp), B, H, W, V, F,
+                                                    _p(self.aa_work), st), "vhap_antialias_inplace_blend")
+            else:
+                _chk(L.vhap_antialias_inplace_fwd(_p(color), _p(self.rast), _p(self.clip), _p(self.tri), _p(self.opp), B, H, W, V, F,
+                                                  _p(self.aa_work), st), "vhap_antialias_inplace_fwd")
             self.rgba_aa = color                                   # the prediction: the same buffer, antialiased
         else:
             _chk(L.vhap_antialias_fwd(_p(color), _p(self.rast), _p(self.clip), _p(self.tri), _p(self.opp), B, H, W, 4, V, F, _p(self.rgba_aa),
