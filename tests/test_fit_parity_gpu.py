@@ -23,6 +23,15 @@ Stated tolerances (fp32 product vs fp64 oracle):
   g / (|g| + eps) turns a gradient whose sign is inside that noise into a full-size step of either sign, so element-wise agreement of
   noise-level entries is not a meaningful target): every exported array to 1e-3 in relative L2 (static_offset at the full learning rates:
   1e-2), energies along the trajectory to 5e-3 (measured <= 2.2e-5).
+  the noise floor of the trajectory: the sums behind every gradient are float atomics in arbitrary order, so two RUNS of the HIP path
+  differ in the last bits of a gradient -- and through Adam's g / (|g| + eps) a component whose gradient is inside that noise takes a
+  full +-lr step of either sign.  Seen once on `lights` (27 entries, several SH bands with near-zero gradients) at the full learning
+  rates: update L2 3.4e-2 / max-norm 1.0e-3 instead of the usual 4e-5 / 1.5e-6, i.e. exactly the distance at which the oracle's own
+  fp32 run lands from its fp64 run (3.9e-2 / 1.0e-3, SPREAD below).  A bound tighter than what two correct fp32 evaluations of the same
+  trajectory differ by cannot be held: every per-array bound is therefore the tight one stated above OR twice the measured fp32-vs-fp64
+  spread of the oracle's own trajectory for that array and stage, whichever is larger.  Systematic errors stay visible: the energies
+  along the trajectory are held to 2e-4 (a wrong gradient moves them at once), and the step-0 gradients themselves are compared tightly in
+  the test above and in tests/test_energy_gpu.py.
 The measured values are written to gpurun_out/fit_parity_*.txt for the record."""
 import os
 
@@ -36,6 +45,19 @@ pytestmark = pytest.mark.gpu
 
 NAMES = ("shape", "expr", "rotation", "neck_pose", "jaw_pose", "eyes_pose", "translation", "tex_extra", "lights", "static_offset",
          "focal_length")
+
+# fp32-vs-fp64 spread of the ORACLE'S OWN 10-step trajectory (tools/fit_fp32_spread.py -> profiles/r02_fit_fp32_spread.txt):
+# array -> (max-norm rel, L2 rel, update L2 rel)
+SPREAD = {
+    "rgb_init_offset": {"shape": (3.32e-3, 1.67e-3, 1.82e-2), "expr": (2.63e-2, 1.39e-2, 2.23e-2), "rotation": (2.55e-3, 2.47e-3, 1.14e-2),
+                        "neck_pose": (1.23e-2, 8.16e-3, 1.24e-2), "jaw_pose": (6.37e-3, 5.36e-3, 1.59e-2), "eyes_pose": (3.01e-2, 2.28e-2, 4.30e-2),
+                        "translation": (3.98e-4, 2.55e-4, 1.48e-2), "tex_extra": (1.56e-2, 1.95e-3, 8.11e-4), "lights": (9.95e-4, 1.10e-3, 3.85e-2),
+                        "static_offset": (1.44e-1, 7.23e-2, 3.56e-2), "focal_length": (4.72e-6, 4.72e-6, 1.57e-4)},
+    "rgb_global_tracking": {"shape": (5.42e-4, 2.21e-4, 1.52e-2), "expr": (8.56e-3, 3.52e-3, 2.30e-2), "rotation": (1.55e-4, 9.95e-5, 1.72e-3),
+                            "neck_pose": (2.79e-3, 1.73e-3, 7.17e-3), "jaw_pose": (2.84e-4, 2.13e-4, 3.50e-3), "eyes_pose": (8.95e-4, 5.76e-4, 5.24e-3),
+                            "translation": (1.61e-4, 1.05e-4, 3.33e-2), "tex_extra": (1.80e-3, 6.66e-5, 3.72e-4), "lights": (2.01e-4, 2.40e-4, 6.28e-2),
+                            "static_offset": (3.43e-2, 4.80e-3, 7.70e-3), "focal_length": (2.02e-6, 2.02e-6, 6.09e-4)},
+}
 
 
 def _record(name, lines):
@@ -242,13 +264,14 @@ def test_ten_steps_export_matches_oracle_fit(small, stage, lr_scale, same_visibi
             assert np.array_equal(a, start[k].astype(np.float64)), f"{k} must not move in {stage}"
             continue
         assert float(np.abs(a - start[k]).max()) > 0, f"{k} did not move"
+        sp = SPREAD[stage].get(k, (0.0, 0.0, 0.0))           # the noise floor of two correct fp32 trajectories (module docstring)
         if same_visibility:
             full_lr = lr_scale >= 1.0
-            mx_b = {"static_offset": 1e-1 if full_lr else 5e-3, "tex_extra": 2e-2 if full_lr else 1e-3}.get(k, 1e-3)
-            l2_b = 1e-2 if (full_lr and k == "static_offset") else 1e-3
-            if mx > mx_b or l2 > l2_b or dl2 > 2e-2:
+            mx_b = max({"static_offset": 1e-1 if full_lr else 5e-3, "tex_extra": 2e-2 if full_lr else 1e-3}.get(k, 1e-3), 2 * sp[0])
+            l2_b = max(1e-2 if (full_lr and k == "static_offset") else 1e-3, 2 * sp[1])
+            if mx > mx_b or l2 > l2_b or dl2 > max(2e-2, 2 * sp[2]):
                 fails.append(f"{k}: max-norm rel {mx:.2e}, L2 rel {l2:.2e}, update L2 rel {dl2:.2e}")
-        elif l2 > (1e-2 if (lr_scale >= 1.0 and k == "static_offset") else 1e-3):
+        elif l2 > max(1e-2 if (lr_scale >= 1.0 and k == "static_offset") else 1e-3, 2 * sp[1]):
             fails.append(f"{k}: L2 rel {l2:.2e}")
     _record(f"fit_parity_{stage}_{'same' if same_visibility else 'indep'}_visibility.txt", lines + fails)
     assert not fails, fails
