@@ -931,17 +931,21 @@ class ShuffledBatches:
 
 class GraphedStep:
     """One optimiser step captured in hipGraphs (the 50-500 identical steps of a
-    stage are launch-bound in eager mode -- ~1300 launches per step).  Three graphs with the two frame-sharding
-    collectives in between, so that RCCL calls stay ordinary eager calls:
+    stage are launch-bound in eager mode -- ~1300 launches per step).
 
-        F : forward -> every energy term, photometric numerator S and alpha count N     (autograd tape built once)
-            [all-reduce N over ranks]  inv_n = world / (3 N_global)
-        B : E = terms + w_photo * S * inv_n ; backward into static .grad buffers
-            [all-reduce (average) of the flat gradient bucket]
-        A : Adam
+    One GPU: the whole step (vhap_amd/step.py::NativeStep: forward, backward, Adam -- ~45 C-ABI calls on up to three branches) is ONE
+    graph.  Frame sharding: the collectives stay ordinary eager calls between the graphs --
 
+        F  : forward -> every energy term, photometric numerator S and alpha count N
+             [all-reduce N over ranks]
+        B  : backward, pixel chain            Bt : texture gradient (own stream) + its asynchronous all-reduce (50 MB)
+        B2 : backward, geometry chain (beside Bt)      [all-reduce (average) of the flat bucket of every other gradient]
+        A  : Adam
+
+    (the autograd formulation of a stage the NativeStep does not cover -- use_dynamic_offset -- is captured as F / B / A the same way).
     Everything the graphs touch is static: the sample tensors, the parameters, their .grad and the Adam state.
-    A new batch is fed by copying into `self.sample` (same shapes) -- exactly the sequential-tracking pattern."""
+    A new batch is fed by copying into `self.sample` (same shapes) -- exactly the sequential-tracking pattern.
+    Replays always go to the step's own launch stream (see __init__ on why)."""
 
     def __init__(self, tracker, sample, optimizer, stage, warmup=2, unroll=1):
         assert tracker.fused, "graph capture needs the fused (sync-free) path"
