@@ -144,3 +144,78 @@ def test_two_rank_tracker_landmark_fit_matches_single_process():
     o0, o1 = ret[0][2], ret[1][2]
     assert len(o0) == len(o1) == 2 and all(len(a) == 1 and len(b) == 1 for a, b in zip(o0, o1))
     assert sorted(t for b in o0 + o1 for t in b) == [0, 1, 2, 3]
+
+
+def _lmk_multiview_tracker(n_views=4):
+    """BASELINE config 4 in small: calibrated views of ONE timestep (NeRSemble-style: nersemble.py:22-42), landmark-only, CPU device.  The
+    landmark targets are the projections of ground-truth landmarks through each view's camera."""
+    from vhap_amd.config import nersemble_config
+    from vhap_amd.synthetic import arc_cameras, make_flame_model, make_scene_params, make_texture
+    from vhap_amd.tracker import GlobalTracker
+    model, topo = make_flame_model(0)
+    cfg = nersemble_config()
+    cfg.device = "cpu"
+    cfg.exp.photometric = False
+    cfg.model.tex_resolution = 16
+    H, W = 64, 48
+    gt = make_scene_params(1, seed=4, image_size=(H, W))
+    g = lambda k: torch.from_numpy(gt[k]).float()
+    K, RT = arc_cameras(n_views, (H, W))
+    K, RT = torch.from_numpy(K).float(), torch.from_numpy(RT).float()
+    data = {"rgb": torch.zeros(n_views, 3, H, W), "lmk2d": torch.zeros(n_views, 70, 3), "intrinsic": K, "extrinsic": RT,
+            "timestep_index": torch.zeros(n_views, dtype=torch.long), "camera_index": torch.arange(n_views)}
+    tr = GlobalTracker(cfg, model, topo, make_texture(0, 16), data)
+    with torch.no_grad():
+        _, lmks = tr.flame(g("shape")[None], g("expr"), g("rotation") * 0, g("neck_pose"), g("jaw_pose"), g("eyes_pose"), g("translation") * 0)
+        ndc = tr.render.world_to_ndc(lmks.expand(n_views, -1, -1), RT, K, (H, W), flip_y=True)
+        tr.dataset["lmk2d"] = torch.stack([(ndc[..., 0] * 0.5 + 0.5) * W, (ndc[..., 1] * 0.5 + 0.5) * H, torch.ones(n_views, lmks.shape[1])], dim=-1)
+    return tr
+
+
+_MV_NAMES = ("shape", "expr", "rotation", "translation", "neck_pose", "jaw_pose", "eyes_pose")
+
+
+def _mv_fit(tr, sample, steps=4):
+    stage = "lmk_init_all"
+    opt = tr.configure_optimizer(tr.get_train_parameters(stage))
+    logs = [float(tr.optimize_iter(dict(sample), opt, stage)["total"]) for _ in range(steps)]
+    return logs, {k: getattr(tr, k).detach().clone() for k in _MV_NAMES}
+
+
+def _worker_multiview(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vhap_amd import dist as vdist
+    tr = _lmk_multiview_tracker()
+    ctx = vdist.attach(tr)
+    sample = ctx.shard_sample(tr.get_sample(np.array([0])))
+    assert len(sample["timestep_index"]) == 2 and list(np.asarray(sample["timestep_index"])) == [0, 0]      # two views of the one timestep
+    assert sample["intrinsic"].shape == (2, 3, 3)
+    logs, params = _mv_fit(tr, sample)
+    Es = torch.tensor(logs)
+    dist.all_reduce(Es)
+    ret[rank] = ((Es / world).tolist(), params)
+    dist.destroy_process_group()
+
+
+def test_two_rank_multiview_views_of_one_timestep_split_over_ranks():
+    """BASELINE config 4's sharding (B/G split): the VIEWS of one timestep go to different ranks, so both ranks produce gradients
+    for the SAME per-timestep parameter row -- the averaged gradient must equal the single-process one (the row's gradient is the mean over
+    all views either way), and the replicas must stay bit-identical."""
+    world = 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ret = mp.Manager().dict()
+    mp.spawn(_worker_multiview, args=(world, port, ret), nprocs=world, join=True)
+    tr = _lmk_multiview_tracker()
+    assert tr.n_timesteps == 1 and tr.calibrated
+    logs, params = _mv_fit(tr, tr.get_sample(np.array([0])))
+    assert logs[-1] < logs[0]
+    for a, b in zip(ret[0][0], logs):
+        assert abs(a - b) <= 1e-4 * abs(b), (ret[0][0], logs)         # (fp32: the two runs sum the same terms in a different order)
+    for k in _MV_NAMES:
+        assert torch.equal(ret[0][1][k], ret[1][1][k]), f"replicas disagree on {k}"
+        d = float((ret[0][1][k] - params[k]).abs().max())
+        assert d <= 5e-5 * max(1.0, float(params[k].abs().max())), (k, d)     # measured <= 1.1e-5 (fp32 summation order + Adam)
