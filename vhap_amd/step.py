@@ -798,7 +798,13 @@ class NativeStep:
                 if self.overlap:
                     self._early_ev = torch.cuda.Event()
                     self._early_ev.record()
-            self._side(early_branch)
+            # UNMEASURED experiment (VHAP_BWD_EARLY_MAIN=1, off): the texture tail of the backward (texture-gradient accumulation -> fold -> TV
+            # backward -> Adam, 330 us) is 60 us longer than the geometry tail beside it, and its first kernel takes 179 us next to the
+            # G-buffer backward against 110 us alone: the two latency-bound launches of the early branch go IN FRONT of the G-buffer backward
+            # on this chain, so that the accumulation starts with the chip to itself and the geometry tail gives up its slack.
+            early_main = os.environ.get("VHAP_BWD_EARLY_MAIN", "0") == "1"
+            if not early_main:
+                self._side(early_branch)
             self._bwd_pixel(world_size, after_first=self._flush)
             # fork as soon as d_albedo exists: the texture gradient (uv-binned accumulation + fold + TV backward) on the side branch,
             # the uv gradient and the geometry chain on this one
@@ -808,8 +814,11 @@ class NativeStep:
                     optimizer.step(only=(self.tr.tex_extra,), advance=False, advanced=self.step_optimizer is not None)
             self._side(tex_chain)
             self._side(self._bwd_pixel_finish, self.side2)            # (nothing downstream reads these two: beside the geometry chain, not ahead of it)
+            if early_main:
+                self._bwd_early()
+                self._flush()
             self._bwd_uv()
-            self._bwd_geometry(True, after_first=self._flush)
+            self._bwd_geometry(None if early_main else True, after_first=self._flush)
             if self.overlap:
                 torch.cuda.current_stream().wait_stream(self.side2)
             if self.step_optimizer is not None:                       # every other parameter: next to the tail of the texture branch
