@@ -1,12 +1,20 @@
 """Per-step kernel table from a rocprofv3 --kernel-trace CSV of bench.py: one graph-replayed step, kernels in launch order
-grouped by name (count, total us).  usage: python tools/step_profile.py <kernel_trace.csv> [--seq | --timeline]
+grouped by name (count, total us).  usage: python tools/step_profile.py <kernel_trace.csv | results.db> [--seq | --timeline]
+(rocprofv3 --kernel-trace writes a rocpd .db unless --output-format csv is given; both are read)
 (--timeline: start offset, duration, HW queue and name of every kernel of the step -- shows what overlaps with what)"""
 import collections
 import csv
 import re
 import sys
 
-rows = list(csv.DictReader(open(sys.argv[1])))
+if sys.argv[1].endswith(".db"):
+    # rocprofv3's default output (ROCm 7.2) is a rocpd SQLite database, not CSV: read its `kernels` view
+    import sqlite3
+    con = sqlite3.connect(sys.argv[1])
+    rows = [{"Kernel_Name": n, "Start_Timestamp": str(s), "End_Timestamp": str(e), "Queue_Id": str(q)}
+            for n, s, e, q in con.execute("select name, start, end, queue_id from kernels")]
+else:
+    rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 first = "frame_prep_fwd" if any("frame_prep_fwd" in r["Kernel_Name"] for r in rows) else "flame_skin_fwd"
 starts = [i for i, r in enumerate(rows) if first in r["Kernel_Name"]]
