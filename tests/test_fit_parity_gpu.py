@@ -13,7 +13,7 @@ Stated tolerances (fp32 product vs fp64 oracle):
       array to 1e-3 in relative L2 AND in max-norm -- except static_offset's max-norm, 5e-3: its entries are ~1e-3 in size
       and move by lr = 5e-5 per step, and Adam's g / (|g| + eps) makes the step of an entry whose gradient sits inside the fp32-atomics
       noise a full +-lr step of either sign (measured 1.8e-3 max-norm, 1.3e-4 L2) -- and the parameter UPDATE (export - start) to 2e-2 in
-      L2 (measured <= 2e-4); the energies along the trajectory to 2e-4 (measured <= 1e-6).  At the FULL learning rates (rgb_init_offset,
+      L2 (measured <= 2e-4); the energies along the trajectory to 5e-4 (measured <= 1e-6, once 7.4e-5: see the noise floor below).  At the FULL learning rates (rgb_init_offset,
       lr_scale 1: static_offset moves by more than its own size in 10 steps) the same effect is 10x larger on the two element-wise
       arrays -- static_offset: L2 1e-2 / max-norm 1e-1 (measured 4.6e-3 / 5.2e-2), tex_extra: max-norm 2e-2 (measured 6.9e-3); everything
       else stays below 1e-4.  For scale: the ORACLE ITSELF evaluated in fp32 instead of fp64 lands 7e-2 (L2) away from its fp64 run on
@@ -30,7 +30,7 @@ Stated tolerances (fp32 product vs fp64 oracle):
   fp32 run lands from its fp64 run (3.9e-2 / 1.0e-3, SPREAD below).  A bound tighter than what two correct fp32 evaluations of the same
   trajectory differ by cannot be held: every per-array bound is therefore the tight one stated above OR twice the measured fp32-vs-fp64
   spread of the oracle's own trajectory for that array and stage, whichever is larger.  Systematic errors stay visible: the energies
-  along the trajectory are held to 2e-4 (a wrong gradient moves them at once), and the step-0 gradients themselves are compared tightly in
+  along the trajectory are held to 5e-4 (a wrong gradient moves them at once), and the step-0 gradients themselves are compared tightly in
   the test above and in tests/test_energy_gpu.py.
 The measured values are written to gpurun_out/fit_parity_*.txt for the record."""
 import os
@@ -242,7 +242,7 @@ def test_ten_steps_export_matches_oracle_fit(small, stage, lr_scale, same_visibi
     assert set(hip) == set(ora), (sorted(hip), sorted(ora))              # same npz schema (tracker.py:1158-1218)
     lines = [f"stage {stage} lr_scale {lr_scale} K {K} same_visibility {same_visibility}"]
     fails = []
-    e_bound = 2e-4 if same_visibility else 5e-3
+    e_bound = 5e-4 if same_visibility else 5e-3          # (usually <= 1e-6; 7.4e-5 in the run in which one lights component took the other sign)
     for i, (a, b) in enumerate(zip(E_hip, E_ora)):
         e = abs(a - b) / abs(b)
         lines.append(f"step {i}: E hip {a:.6f} oracle {b:.6f} rel {e:.2e}")
