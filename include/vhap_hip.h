@@ -2,7 +2,7 @@
  * vhap_hip.h -- C ABI of libvhap_hip.so, the MI355X (gfx950) implementation of the
  * photometric FLAME-fitting hot path of ShenhanQian/VHAP.
  *
- * Every entry point is stateless and re-entrant -- the library has NO mutable global state (ABI 2: the per-call behaviour
+ * Every entry point is stateless and re-entrant -- the library has NO mutable global state (since ABI 2 the per-call behaviour
  * switches that ABI 1 kept in a process-wide variable are the `call_flags` argument of the entry points that honour them):
  * the caller owns all buffers (device pointers,
  * row-major, contiguous, fp32 / int32), passes an explicit workspace where one is needed, and
@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VHAP_ABI_VERSION 3
+#define VHAP_ABI_VERSION 4
 
 #define VHAP_OK 0
 #define VHAP_E_NULLPTR (-1)   /* a required pointer is NULL */
@@ -429,7 +429,9 @@ int vhap_vnormal_bwd_saved(const float* verts, const int32_t* tri, const int32_t
  *   fid2cid [nfid] int32 (index = triangle id + 1, 0 = background), ncl clusters (<= 16),
  *   w_fg / w_bg [B,H,W] int32 Bernoulli masks, idx [B*H*W] int64 non-negative random integers.
  *   out [B,H,W,4]; keep [B,H,W] = 1 where the pixel kept its own colour (backward mask).
- *   workspace: vhap_disturb_workspace_ints() int32.
+ *   workspace: vhap_disturb_workspace_ints() int32, 16-byte aligned (per-block histograms + the per-cluster colour POOLS: the
+ *   colours of every cluster's pixels, batch-wide, in row-major pixel order, 16 B per pixel -- a disturbed pixel gathers one colour
+ *   from its cluster's pool).  out == rgba is allowed (the pools are copies): undisturbed pixels are then not touched at all.
  * ------------------------------------------------------------------------------------------- */
 size_t vhap_disturb_workspace_ints(int B, int H, int W);
 int vhap_disturb_fwd(const float* rgba, const float* rast, const int32_t* fid2cid, int nfid, int ncl,
@@ -446,6 +448,12 @@ int vhap_disturb_fwd_rng(const float* rgba, const float* rast, const int32_t* fi
 int vhap_disturb_fwd_rng_cid(const float* rgba, const uint8_t* cid, int ncl, float rate_fg, float rate_bg,
                              uint32_t* rng_state, int B, int H, int W, int32_t* workspace, float* out,
                              float* keep, vhap_stream_t stream);
+/* the step executor's form: IN PLACE on rgba, clusters from the one-byte image `cid`; random numbers drawn in-kernel (rng_state != NULL,
+ * w_fg / w_bg / idx ignored) or INJECTED (rng_state == NULL: w_fg / w_bg / idx as in vhap_disturb_fwd -- the same kernels, so that a
+ * step replayed with the oracle's random numbers exercises the code that ships) */
+int vhap_disturb_inplace(float* rgba, const uint8_t* cid, int ncl, const int32_t* w_fg, const int32_t* w_bg, const int64_t* idx,
+                         float rate_fg, float rate_bg, uint32_t* rng_state, int B, int H, int W, int32_t* workspace, float* keep,
+                         vhap_stream_t stream);
 int vhap_disturb_bwd(const float* d_out, const float* keep, int B, int H, int W, float* d_rgba,
                      vhap_stream_t stream);
 
@@ -605,6 +613,29 @@ int vhap_focal_bwd(const float* d_K, int B, float scale, float* d_focal_accum, v
 enum { VHAP_BG_NONE = 0, VHAP_BG_WHITE = 1, VHAP_BG_BLACK = 2 };
 int vhap_frame_ingest(const unsigned char* rgb_u8, const unsigned char* alpha_u8, const long long* index, int N, int B, int H, int W,
                       int bg_mode, float* rgb_out, float* alpha_out, int* bad_index, vhap_stream_t stream);
+
+/* ---- Step plans: the library's own executor for a captured step (vhap/model/tracker.py:1391-1416 runs the same
+ * optimize_iter 50-500 times per stage) -------------------------------------------------------------------------------------------
+ * The host records one step under HIP stream capture (hipStreamBeginCapture .. EndCapture -> a hipGraph_t, NOT instantiated) and hands
+ * the graph over: vhap_plan_from_graph walks its kernel / memset / empty nodes and dependency edges, lays them out over at most
+ * `max_streams` streams (1..8; stream 0 is the stream a replay is launched on, the others belong to the plan; a node's first-captured
+ * successor stays on the node's stream, further successors fork onto side streams) and turns cross-stream edges into event record /
+ * wait pairs.  vhap_plan_launch replays the plan with plain kernel launches on those streams -- hipGraphInstantiate / hipGraphLaunch are
+ * never called (their branch layout is not under the caller's control and ROCm 7's faults when the launch stream shares a hardware
+ * queue with two of its internal branch streams).  Any other node type -> VHAP_E_UNSUPPORTED (the caller keeps the graph).
+ * The plan BORROWS the graph's kernel-argument storage: the hipGraph_t must stay alive until vhap_plan_destroy.  A plan is an object of
+ * its creator: one replay at a time per plan (replays on one launch stream are ordered; different plans are independent). */
+typedef struct vhap_plan* vhap_plan_t;
+int vhap_plan_from_graph(void* hip_graph, int max_streams, vhap_plan_t* plan);
+int vhap_plan_destroy(vhap_plan_t plan);
+int vhap_plan_info(vhap_plan_t plan, int* n_nodes, int* n_streams, int* n_events);
+/* text dump, one line per node in launch order ("index stream kernel <- predecessors | waits | records"); returns the bytes needed */
+size_t vhap_plan_describe(vhap_plan_t plan, char* buf, size_t cap);
+int vhap_plan_node_name(vhap_plan_t plan, int node, char* buf, size_t cap);
+int vhap_plan_launch(vhap_plan_t plan, vhap_stream_t stream);
+/* one replay with every node bracketed by timing events; blocks until done.  start_us[k] (relative to the head of the replay) and
+ * dur_us[k] of node k, n >= number of nodes.  For per-kernel numbers inside the step (bench.py's roofline line), not for the step time. */
+int vhap_plan_launch_timed(vhap_plan_t plan, vhap_stream_t stream, float* start_us, float* dur_us, int n);
 
 #ifdef __cplusplus
 }

@@ -10,13 +10,6 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    # ROCm 7's hipGraphLaunch dereferences garbage when the launch stream shares a hardware queue with two of the graph's internal branch
-    # streams (tracker.GraphedStep.__init__, tools/dbg/graph_stream_collision.py) -- which depends on every stream and graph the process
-    # created and destroyed before, and this one process creates ~40 captured steps.  A high-priority launch stream cannot share a queue
-    # with them (queues are pooled per priority) but costs 27 % of the step's throughput (main chain and side branches on queues of
-    # different priority), so the product's default stays 'normal' (what bench.py, smoke() and every fresh process run) and this long-lived
-    # test process asks for 'high'.  Subprocess tests (test_dist_gpu: bench.py under torchrun) strip the variable again.
-    os.environ.setdefault("VHAP_LAUNCH_PRIO", "high")
 
 
 def pytest_collection_modifyitems(config, items):

@@ -62,6 +62,7 @@ SIGNATURES = {
     "vhap_disturb_fwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
     "vhap_disturb_fwd_rng": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_f, c_f, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
     "vhap_disturb_fwd_rng_cid": (c_i, [c_fp, c_fp, c_i, c_f, c_f, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
+    "vhap_disturb_inplace": (c_i, [c_fp, c_fp, c_i, c_fp, c_fp, c_fp, c_f, c_f, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
     "vhap_disturb_bwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp]),
     "vhap_shade_fwd": (c_i, [c_fp] * 8 + [c_i] * 4 + [c_fp] * 3 + [c_i, c_fp]),
     "vhap_shade_bwd": (c_i, [c_fp] * 9 + [c_i] * 3 + [c_fp] * 4),
@@ -102,9 +103,16 @@ SIGNATURES = {
     "vhap_raster_shade_stats": (c_i, [c_i] * 4 + [c_fp, c_sz, c_sz, c_i, c_fp, c_fp]),
     "vhap_photo_fwd_total": (c_i, [c_fp, c_fp, c_i, c_i, c_i] + [c_fp] * 6 + [c_f] * 3 + [c_fp] * 4 + [c_i, c_fp]),
     "vhap_frame_ingest": (c_i, [c_fp, c_fp, c_fp] + [c_i] * 5 + [c_fp] * 4),
+    "vhap_plan_from_graph": (c_i, [c_fp, c_i, ctypes.POINTER(ctypes.c_void_p)]),
+    "vhap_plan_destroy": (c_i, [c_fp]),
+    "vhap_plan_info": (c_i, [c_fp] + [ctypes.POINTER(c_i)] * 3),
+    "vhap_plan_describe": (c_sz, [c_fp, ctypes.c_char_p, c_sz]),
+    "vhap_plan_node_name": (c_i, [c_fp, c_i, ctypes.c_char_p, c_sz]),
+    "vhap_plan_launch": (c_i, [c_fp, c_fp]),
+    "vhap_plan_launch_timed": (c_i, [c_fp, c_fp, ctypes.POINTER(c_f), ctypes.POINTER(c_f), c_i]),
 }
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 # call_flags of include/vhap_hip.h (per-call arguments since ABI 2; the library keeps no mutable state)
 CALL_ACC_PREZEROED, CALL_AA_PASSTHROUGH_DONE, CALL_ADAM_KEEP_STEP, CALL_ADAM_STEP_ADVANCED = 1, 2, 4, 16
 

@@ -6,12 +6,16 @@
 // (background pixels draw from the background image); the drawn colour is detached.  The reference does
 // this with a 9-iteration Python loop of boolean-mask indexing (one host sync each) and randint.
 //
-// Here: a deterministic counting sort of the pixel ids by cluster (row-major order inside a cluster, i.e.
+// Here: a deterministic counting sort of the pixel COLOURS by cluster (row-major order inside a cluster, i.e.
 // exactly the order of the reference's boolean-mask gather) in two passes -- per-block cluster histograms
 // (wave ballots over the cluster values present in a wave) and a scatter in which every workgroup derives its own prefix from the
-// histograms and an LDS prefix table over its (iteration, wave) counters --
-// followed by one gather pass.  No host sync, no atomics, graph-capturable.  Randomness is supplied by the
-// caller (Bernoulli masks and one 31-bit integer per pixel), so runs can be made reproducible.
+// histograms and an LDS prefix table over its (iteration, wave) counters and copies its pixels' colours into the cluster's POOL
+// (16 B per pixel, contiguous runs per workgroup and cluster) -- followed by one gather pass: a disturbed pixel reads ONE random
+// 16-byte colour from its cluster's dense pool.  (Round 2 sorted pixel ids and gathered twice -- id, then colour at that id: two
+// dependent random HBM sectors per disturbed pixel, 558 MB read per 16 x 512^2 step, the largest reader of the step.)  Because the
+// pools are copies, the gather pass may run IN PLACE (vhap_disturb_inplace): undisturbed pixels are neither read nor written.
+// No host sync, no atomics, graph-capturable.  Randomness: drawn in-kernel from a counter-based generator, or supplied by the
+// caller (Bernoulli masks and one 31-bit integer per pixel) so that runs can be replayed by the oracle.
 #include "common.h"
 
 namespace {
@@ -76,11 +80,11 @@ __global__ __launch_bounds__(DB) void disturb_count_kernel(const ClusterSrc src,
 }
 
 // pass 2: every workgroup derives its own exclusive prefix (and the cluster totals) from the per-block histograms -- nblocks * 64 B,
-// L2-resident -- instead of waiting for a single-workgroup scan; then perm[start_c + prefix_c + rank in block] = pixel id.
+// L2-resident -- instead of waiting for a single-workgroup scan; then pool[start_c + prefix_c + rank in block] = colour of the pixel.
 // Workgroup 0 publishes totals[c] and totals[MAXC + c] = start_c for the gather pass.
-__global__ __launch_bounds__(DB) void disturb_scatter_kernel(const ClusterSrc src,
+__global__ __launch_bounds__(DB) void disturb_scatter_kernel(const ClusterSrc src, const float4* __restrict__ rgba,
                                                               int ncl, long long n, int nblocks, const int* __restrict__ block_counts,
-                                                              int* __restrict__ totals, int* __restrict__ perm) {
+                                                              int* __restrict__ totals, float4* __restrict__ pool) {
     __shared__ int red[2][DB / 64][MAXC];
     __shared__ int base[MAXC];          // start_c + prefix of this block
     __shared__ int wcnt[PPT][DB / 64][MAXC];
@@ -110,11 +114,13 @@ __global__ __launch_bounds__(DB) void disturb_scatter_kernel(const ClusterSrc sr
     for (int i = threadIdx.x; i < PPT * (DB / 64) * MAXC; i += DB) (&wcnt[0][0][0])[i] = 0;
     __syncthreads();
     int c_of[PPT], rank_of[PPT];
+    float4 col_of[PPT];                             // the pixels' colours: loaded here, under the ballots, stored once the offsets are known
 #pragma unroll
     for (int it = 0; it < PPT; it++) {
         const long long p = (long long)blockIdx.x * DPIX + it * DB + threadIdx.x;
         int c = p < n ? pixel_cluster(src, p) : -1;
         if (c >= ncl) c = -1;                       // (ids outside the configured clusters are left alone)
+        if (c >= 0) col_of[it] = rgba[p];
         int rank = 0;
         unsigned long long todo = __ballot(c >= 0);
         while (todo) {
@@ -164,18 +170,19 @@ __global__ __launch_bounds__(DB) void disturb_scatter_kernel(const ClusterSrc sr
     for (int it = 0; it < PPT; it++) {
         const int c = c_of[it];
         if (c < 0) continue;
-        perm[base[c] + wcnt[it][wave][c] + rank_of[it]] = (int)((long long)blockIdx.x * DPIX + it * DB + threadIdx.x);
+        pool[base[c] + wcnt[it][wave][c] + rank_of[it]] = col_of[it];
     }
 }
 
-// pass 4: out = w ? src[perm[start_c + idx % n_c]] : cur ; keep = 1 - w_eff (gradient mask for the backward)
-__global__ __launch_bounds__(256) void disturb_apply_kernel(const float4* __restrict__ rgba, const float4* __restrict__ rgba_bg_or_null,
-                                                            const float* __restrict__ bg_image, int B, int H, int W,
+// pass 3: out = w ? pool[start_c + idx % n_c] : cur ; keep = 1 - w_eff (gradient mask for the backward).
+// INPLACE: `out` IS the image the pools were copied from: only disturbed pixels are touched (no read of the pixel's own colour).
+template <bool INPLACE>
+__global__ __launch_bounds__(256) void disturb_apply_kernel(const float4* __restrict__ rgba, int B, int H, int W,
                                                             const ClusterSrc src,
                                                             const int* __restrict__ w_fg, const int* __restrict__ w_bg,
                                                             const long long* __restrict__ idx, const unsigned* __restrict__ rng_state,
                                                             float rate_fg, float rate_bg, const int* __restrict__ totals,
-                                                            const int* __restrict__ perm, float4* __restrict__ out,
+                                                            const float4* __restrict__ pool, float4* __restrict__ out,
                                                             float* __restrict__ keep) {
     const long long n = (long long)B * H * W;
     const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -194,17 +201,16 @@ __global__ __launch_bounds__(256) void disturb_apply_kernel(const float4* __rest
         pick = (unsigned long long)idx[p];
     }
     const int nc = totals[c];
-    float4 v = rgba[p];   // after compositing, background pixels of `rgba` already hold the background colour
     float k = 1.0f;
     if (w != 0 && nc > 0) {
         // injected indices: idx % n like the reference's randint-then-index (a 64-bit division per disturbed pixel -- parity path only);
         // in-kernel draws: floor(r * n / 2^32), the same distribution without a division
         const int j = rng_state ? (int)((pick * (unsigned long long)nc) >> 32) : (int)(pick % (unsigned long long)nc);
-        const int q = perm[totals[MAXC + c] + j];
-        v = rgba[q];
+        out[p] = pool[totals[MAXC + c] + j];
         k = 0.0f;
+    } else if (!INPLACE) {
+        out[p] = rgba[p];   // after compositing, background pixels of `rgba` already hold the background colour
     }
-    out[p] = v;
     keep[p] = k;
 }
 
@@ -223,7 +229,7 @@ extern "C" size_t vhap_disturb_workspace_ints(int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return 0;
     const long long n = (long long)B * H * W;
     const long long nblocks = (n + DPIX - 1) / DPIX;
-    return (size_t)(2 * MAXC + nblocks * MAXC + n);
+    return (size_t)(2 * MAXC + nblocks * MAXC + 4 * n);          // totals + starts, per-block histograms, the colour pools (16 B per pixel)
 }
 
 static int disturb_run(const float* rgba, const float* rast, const uint8_t* cid, const int32_t* fid2cid, int nfid, int ncl, const int32_t* w_fg,
@@ -237,16 +243,22 @@ static int disturb_run(const float* rgba, const float* rast, const uint8_t* cid,
     const int nblocks = vhap_cdiv(n, DPIX);
     int* totals = workspace;
     int* block_counts = workspace + 2 * MAXC;
-    int* perm = block_counts + (size_t)nblocks * MAXC;
+    float4* pool = reinterpret_cast<float4*>(block_counts + (size_t)nblocks * MAXC);   // (32 + 16 nblocks ints: 64-byte multiple)
+    if ((reinterpret_cast<uintptr_t>(workspace) & 15u) || (reinterpret_cast<uintptr_t>(rgba) & 15u) || (reinterpret_cast<uintptr_t>(out) & 15u))
+        return VHAP_E_BADDIM;
     hipStream_t st = vhap_stream(stream);
     const ClusterSrc src{reinterpret_cast<const float4*>(rast), fid2cid, nfid, cid};
+    const float4* in = reinterpret_cast<const float4*>(rgba);
     disturb_count_kernel<<<nblocks, DB, 0, st>>>(src, ncl, n, block_counts, rng_state);
     VHAP_LAUNCH_CHECK();
-    disturb_scatter_kernel<<<nblocks, DB, 0, st>>>(src, ncl, n, nblocks, block_counts, totals, perm);
+    disturb_scatter_kernel<<<nblocks, DB, 0, st>>>(src, in, ncl, n, nblocks, block_counts, totals, pool);
     VHAP_LAUNCH_CHECK();
-    disturb_apply_kernel<<<vhap_cdiv(n, 256), 256, 0, st>>>(reinterpret_cast<const float4*>(rgba), nullptr, nullptr, B, H, W, src, w_fg,
-                                                  w_bg, reinterpret_cast<const long long*>(idx), rng_state, rate_fg, rate_bg, totals, perm,
-                                                  reinterpret_cast<float4*>(out), keep);
+    if (out == rgba)
+        disturb_apply_kernel<true><<<vhap_cdiv(n, 256), 256, 0, st>>>(in, B, H, W, src, w_fg, w_bg, reinterpret_cast<const long long*>(idx),
+                                                                     rng_state, rate_fg, rate_bg, totals, pool, reinterpret_cast<float4*>(out), keep);
+    else
+        disturb_apply_kernel<false><<<vhap_cdiv(n, 256), 256, 0, st>>>(in, B, H, W, src, w_fg, w_bg, reinterpret_cast<const long long*>(idx),
+                                                                      rng_state, rate_fg, rate_bg, totals, pool, reinterpret_cast<float4*>(out), keep);
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;
 }
@@ -273,6 +285,14 @@ extern "C" int vhap_disturb_fwd_rng_cid(const float* rgba, const uint8_t* cid, i
     if (!rng_state || !cid) return VHAP_E_NULLPTR;
     return disturb_run(rgba, nullptr, cid, nullptr, 0, ncl, nullptr, nullptr, nullptr, rng_state, rate_fg, rate_bg, B, H, W, workspace, out, keep,
                        stream);
+}
+
+extern "C" int vhap_disturb_inplace(float* rgba, const uint8_t* cid, int ncl, const int32_t* w_fg, const int32_t* w_bg, const int64_t* idx,
+                                    float rate_fg, float rate_bg, uint32_t* rng_state, int B, int H, int W, int32_t* workspace, float* keep,
+                                    vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!cid) return VHAP_E_NULLPTR;
+    return disturb_run(rgba, nullptr, cid, nullptr, 0, ncl, w_fg, w_bg, idx, rng_state, rate_fg, rate_bg, B, H, W, workspace, rgba, keep, stream);
 }
 
 extern "C" int vhap_disturb_bwd(const float* d_out, const float* keep, int B, int H, int W, float* d_rgba, vhap_stream_t stream) {

@@ -1,0 +1,346 @@
+// Step plans: the library's own executor for a captured step (include/vhap_hip.h, "Step plans").
+//
+// A fit step is ~45 kernel launches on up to three concurrent chains, identical for the 50-500 steps of a stage
+// (vhap/model/tracker.py:1391-1416 calls optimize_iter that often).  The host records the step ONCE under HIP stream capture (the
+// Python orchestration in vhap_amd/step.py stays what it is) -- and instead of instantiating the captured graph and handing it to
+// hipGraphLaunch, this file walks the graph (kernel nodes + dependency edges), lays the nodes out over a fixed set of streams of the
+// plan's own and replays them with plain hipLaunchKernel calls, cross-stream edges as event record / wait pairs:
+//
+//   * the stream layout is OURS and fixed at build time: a node's first-captured successor stays on the node's stream (the main chain
+//     stays on the launch stream), every other successor goes to a side stream -- hipGraphLaunch re-partitions the DAG on every
+//     instantiate and, on ROCm 7, dereferences garbage when the launch stream shares a hardware queue with two of its internal
+//     branch streams (profiles/r02_graph_launch_crash.txt), which is why round 2's test suite ran a different configuration than it shipped;
+//   * one C call per step: the host cost is ~45 hipLaunchKernel + ~25 event operations from one tight native loop;
+//   * any node can be bracketed by timing events (vhap_plan_launch_timed): the in-step duration of a kernel without a profiler and
+//     without in-kernel clock stamps (HIP refuses to read event-record nodes of a hipGraph replay).
+//
+// Only what a captured step contains is supported: kernel, memset (1-D / 2-D) and empty nodes; anything else -> VHAP_E_UNSUPPORTED and the
+// caller keeps the graph.  The plan borrows the graph's kernel-argument storage: the hipGraph_t must outlive the plan.
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+struct PlanNode {
+    int type = 0;                       // 0 kernel, 1 memset, 2 empty
+    hipKernelNodeParams kp{};
+    hipMemsetParams ms{};
+    int stream = 0;                     // 0 = the launch stream, k > 0 = plan stream k - 1
+    std::vector<int> waits;             // events to wait for before the launch
+    int record = -1;                    // event to record behind the launch
+    std::vector<int> deps;              // predecessor nodes (launch order indices)
+    std::string name;
+};
+
+}  // namespace
+
+struct vhap_plan {
+    std::vector<PlanNode> nodes;        // launch order (a topological order of the DAG)
+    std::vector<hipStream_t> streams;   // plan-owned side streams
+    std::vector<hipEvent_t> events;     // cross-stream edges
+    hipEvent_t start = nullptr;         // recorded on the launch stream at the head of a replay: the side streams' roots wait for it
+    std::vector<hipEvent_t> tails;      // one per side stream: the launch stream waits for them at the end of a replay
+    std::vector<hipEvent_t> tev;        // timing events (2 per node + 1), created by the first timed launch
+    int device = 0;
+};
+
+namespace {
+
+const char* node_type_name(hipGraphNodeType t) {
+    switch (t) {
+        case hipGraphNodeTypeKernel: return "kernel";
+        case hipGraphNodeTypeMemcpy: return "memcpy";
+        case hipGraphNodeTypeMemset: return "memset";
+        case hipGraphNodeTypeHost: return "host";
+        case hipGraphNodeTypeGraph: return "child graph";
+        case hipGraphNodeTypeEmpty: return "empty";
+        case hipGraphNodeTypeWaitEvent: return "event wait";
+        case hipGraphNodeTypeEventRecord: return "event record";
+        default: return "other";
+    }
+}
+
+void destroy(vhap_plan* p) {
+    if (!p) return;
+    for (auto e : p->events) if (e) (void)hipEventDestroy(e);
+    for (auto e : p->tails) if (e) (void)hipEventDestroy(e);
+    for (auto e : p->tev) if (e) (void)hipEventDestroy(e);
+    if (p->start) (void)hipEventDestroy(p->start);
+    for (auto s : p->streams) if (s) (void)hipStreamDestroy(s);
+    delete p;
+}
+
+inline hipStream_t stream_of(const vhap_plan* p, int idx, hipStream_t launch) { return idx == 0 ? launch : p->streams[idx - 1]; }
+
+hipError_t launch_node(const PlanNode& n, hipStream_t st) {
+    if (n.type == 0)
+        return hipLaunchKernel(n.kp.func, n.kp.gridDim, n.kp.blockDim, n.kp.kernelParams, n.kp.sharedMemBytes, st);
+    if (n.type == 1) {
+        const hipMemsetParams& m = n.ms;
+        if (m.height <= 1) {
+            if (m.elementSize == 4) return hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(m.dst), (int)m.value, m.width, st);
+            if (m.elementSize == 2) return hipMemsetD16Async(reinterpret_cast<hipDeviceptr_t>(m.dst), (unsigned short)m.value, m.width, st);
+            return hipMemsetAsync(m.dst, (int)(m.value & 0xff), m.width, st);
+        }
+        return hipMemset2DAsync(m.dst, m.pitch, (int)(m.value & 0xff), m.width * m.elementSize, m.height, st);
+    }
+    return hipSuccess;
+}
+
+}  // namespace
+
+extern "C" int vhap_plan_from_graph(void* hip_graph, int max_streams, vhap_plan_t* out) {
+    VHAP_ENTER();
+    if (!hip_graph || !out) return VHAP_E_NULLPTR;
+    if (max_streams < 1 || max_streams > 8) return VHAP_E_BADDIM;
+    *out = nullptr;
+    hipGraph_t g = static_cast<hipGraph_t>(hip_graph);
+    size_t n = 0;
+    if (hipGraphGetNodes(g, nullptr, &n) != hipSuccess) return VHAP_E_HIP;
+    if (n == 0 || n > 4096) return VHAP_E_BADDIM;
+    std::vector<hipGraphNode_t> gn(n);
+    if (hipGraphGetNodes(g, gn.data(), &n) != hipSuccess) return VHAP_E_HIP;
+    auto index_of = [&](hipGraphNode_t x) {
+        for (size_t i = 0; i < n; i++) if (gn[i] == x) return (int)i;
+        return -1;
+    };
+    // ---- nodes and edges, in the graph's own (creation = capture) order ----
+    std::vector<PlanNode> raw(n);
+    for (size_t i = 0; i < n; i++) {
+        hipGraphNodeType t;
+        if (hipGraphNodeGetType(gn[i], &t) != hipSuccess) return VHAP_E_HIP;
+        PlanNode& nd = raw[i];
+        if (t == hipGraphNodeTypeKernel) {
+            nd.type = 0;
+            if (hipGraphKernelNodeGetParams(gn[i], &nd.kp) != hipSuccess) return VHAP_E_HIP;
+            if (!nd.kp.func || (!nd.kp.kernelParams && nd.kp.extra)) return VHAP_E_UNSUPPORTED;   // (module launches with a packed argument buffer)
+            const char* nm = hipKernelNameRefByPtr(nd.kp.func, nullptr);
+            nd.name = nm ? nm : "?";
+        } else if (t == hipGraphNodeTypeMemset) {
+            nd.type = 1;
+            if (hipGraphMemsetNodeGetParams(gn[i], &nd.ms) != hipSuccess) return VHAP_E_HIP;
+            nd.name = "memset";
+        } else if (t == hipGraphNodeTypeEmpty) {
+            nd.type = 2;
+            nd.name = "empty";
+        } else {
+            fprintf(stderr, "vhap_plan_from_graph: node %zu is a %s node (only kernel / memset / empty nodes are supported)\n", i, node_type_name(t));
+            return VHAP_E_UNSUPPORTED;
+        }
+        size_t nd_deps = 0;
+        if (hipGraphNodeGetDependencies(gn[i], nullptr, &nd_deps) != hipSuccess) return VHAP_E_HIP;
+        if (nd_deps) {
+            std::vector<hipGraphNode_t> d(nd_deps);
+            if (hipGraphNodeGetDependencies(gn[i], d.data(), &nd_deps) != hipSuccess) return VHAP_E_HIP;
+            for (size_t k = 0; k < nd_deps; k++) {
+                const int j = index_of(d[k]);
+                if (j < 0) return VHAP_E_HIP;
+                nd.deps.push_back(j);
+            }
+            std::sort(nd.deps.begin(), nd.deps.end());
+        }
+    }
+    (void)hipGetLastError();
+    // ---- launch order: Kahn's algorithm, always the lowest creation index among the ready nodes (the capture order, which IS a
+    //      topological order, comes out unchanged; a runtime that lists nodes differently still gets a valid one) ----
+    std::vector<int> indeg(n, 0), order, pos(n, -1);
+    std::vector<std::vector<int>> succ(n);
+    for (size_t i = 0; i < n; i++)
+        for (int d : raw[i].deps) { succ[d].push_back((int)i); indeg[i]++; }
+    std::vector<char> done(n, 0);
+    for (size_t k = 0; k < n; k++) {
+        int pick = -1;
+        for (size_t i = 0; i < n; i++) if (!done[i] && indeg[i] == 0) { pick = (int)i; break; }
+        if (pick < 0) return VHAP_E_HIP;                                         // a cycle: not a DAG
+        done[pick] = 1;
+        pos[pick] = (int)order.size();
+        order.push_back(pick);
+        for (int s : succ[pick]) indeg[s]--;
+    }
+    vhap_plan* p = new vhap_plan();
+    (void)hipGetDevice(&p->device);
+    p->nodes.resize(n);
+    for (size_t k = 0; k < n; k++) {
+        p->nodes[k] = raw[order[k]];
+        for (int& d : p->nodes[k].deps) d = pos[d];
+        std::sort(p->nodes[k].deps.begin(), p->nodes[k].deps.end());
+    }
+    // ---- ancestors (bit sets): a stream may take a node without a false dependency iff its tail is an ancestor of the node ----
+    const size_t words = (n + 63) / 64;
+    std::vector<uint64_t> anc(n * words, 0);
+    for (size_t k = 0; k < n; k++)
+        for (int d : p->nodes[k].deps) {
+            anc[k * words + d / 64] |= 1ull << (d % 64);
+            for (size_t w = 0; w < words; w++) anc[k * words + w] |= anc[(size_t)d * words + w];
+        }
+    auto is_anc = [&](int a, int k) { return (anc[(size_t)k * words + a / 64] >> (a % 64)) & 1ull; };
+    // ---- stream assignment ----
+    std::vector<int> tail(1, -1);                                                // tail[s] = last node placed on stream s (-1: none yet)
+    for (size_t k = 0; k < n; k++) {
+        PlanNode& nd = p->nodes[k];
+        int s = -1;
+        // 1. continue a chain: a predecessor that is still the tail of its stream (the main stream first, then the lowest stream)
+        for (int d : nd.deps) {
+            const int ds = p->nodes[d].stream;
+            if (tail[ds] == d && (s < 0 || ds < s)) s = ds;
+        }
+        // 2. a stream whose tail is an ancestor (its work is done before this node may start anyway) -- the launch stream only for
+        //    the very first node: side work parked there would sit in front of the main chain's next kernel
+        if (s < 0 && tail[0] < 0) s = 0;
+        if (s < 0)
+            for (size_t c = 1; c < tail.size(); c++)
+                if (tail[c] < 0 || is_anc(tail[c], (int)k)) { s = (int)c; break; }
+        // 3. a new stream, or (at the limit) the side stream whose tail is oldest
+        if (s < 0) {
+            if ((int)tail.size() < max_streams) {
+                tail.push_back(-1);
+                s = (int)tail.size() - 1;
+            } else if (tail.size() == 1) {
+                s = 0;
+            } else {
+                s = 1;
+                for (size_t c = 2; c < tail.size(); c++) if (tail[c] < tail[s]) s = (int)c;
+            }
+        }
+        nd.stream = s;
+        tail[s] = (int)k;
+    }
+    const int ns = (int)tail.size();
+    // ---- cross-stream edges -> events; an edge is dropped when the consumer's stream already waited for a LATER node of the
+    //      producer's stream (streams are in order) ----
+    std::vector<int> waited((size_t)ns * ns, -1);                                // waited[to * ns + from] = latest node of `from` that `to` waits for
+    for (size_t k = 0; k < n; k++) {
+        PlanNode& nd = p->nodes[k];
+        for (int d : nd.deps) {
+            const int from = p->nodes[d].stream, to = nd.stream;
+            if (from == to) continue;
+            if (waited[(size_t)to * ns + from] >= d) continue;
+            waited[(size_t)to * ns + from] = d;
+            if (p->nodes[d].record < 0) {
+                p->nodes[d].record = (int)p->events.size();
+                p->events.push_back(nullptr);
+            }
+            nd.waits.push_back(p->nodes[d].record);
+        }
+    }
+    bool ok = true;
+    for (auto& e : p->events) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&p->start, hipEventDisableTiming) == hipSuccess;
+    p->streams.assign(ns - 1, nullptr);
+    p->tails.assign(ns - 1, nullptr);
+    for (int s = 0; s + 1 < ns && ok; s++) {
+        ok = ok && hipStreamCreateWithFlags(&p->streams[s], hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&p->tails[s], hipEventDisableTiming) == hipSuccess;
+    }
+    if (!ok) { destroy(p); return VHAP_E_HIP; }
+    *out = p;
+    return VHAP_OK;
+}
+
+extern "C" int vhap_plan_destroy(vhap_plan_t plan) {
+    VHAP_ENTER();
+    if (!plan) return VHAP_E_NULLPTR;
+    destroy(plan);
+    return VHAP_OK;
+}
+
+extern "C" int vhap_plan_info(vhap_plan_t plan, int* n_nodes, int* n_streams, int* n_events) {
+    if (!plan) return VHAP_E_NULLPTR;
+    if (n_nodes) *n_nodes = (int)plan->nodes.size();
+    if (n_streams) *n_streams = (int)plan->streams.size() + 1;
+    if (n_events) *n_events = (int)plan->events.size();
+    return VHAP_OK;
+}
+
+// One line per node: "index stream name <- deps | waits | record" (for DESIGN.md / debugging); returns the length needed.
+extern "C" size_t vhap_plan_describe(vhap_plan_t plan, char* buf, size_t cap) {
+    if (!plan) return 0;
+    std::string s;
+    char line[512];
+    for (size_t k = 0; k < plan->nodes.size(); k++) {
+        const PlanNode& nd = plan->nodes[k];
+        std::string nm = nd.name.substr(0, nd.name.find('('));
+        snprintf(line, sizeof line, "%3zu s%d %-48.48s <-", k, nd.stream, nm.c_str());
+        s += line;
+        for (int d : nd.deps) { snprintf(line, sizeof line, " %d", d); s += line; }
+        if (!nd.waits.empty()) { s += " | waits"; for (int e : nd.waits) { snprintf(line, sizeof line, " e%d", e); s += line; } }
+        if (nd.record >= 0) { snprintf(line, sizeof line, " | records e%d", nd.record); s += line; }
+        s += "\n";
+    }
+    if (buf && cap) {
+        const size_t m = std::min(cap - 1, s.size());
+        memcpy(buf, s.data(), m);
+        buf[m] = 0;
+    }
+    return s.size() + 1;
+}
+
+extern "C" int vhap_plan_node_name(vhap_plan_t plan, int node, char* buf, size_t cap) {
+    if (!plan || !buf || !cap) return VHAP_E_NULLPTR;
+    if (node < 0 || node >= (int)plan->nodes.size()) return VHAP_E_BADDIM;
+    const std::string& nm = plan->nodes[node].name;
+    const size_t m = std::min(cap - 1, nm.size());
+    memcpy(buf, nm.data(), m);
+    buf[m] = 0;
+    return VHAP_OK;
+}
+
+static int plan_launch(vhap_plan* p, hipStream_t launch, bool timed) {
+    const size_t n = p->nodes.size();
+#define PLAN_HIP(x) do { if ((x) != hipSuccess) return VHAP_E_HIP; } while (0)
+    if (timed && p->tev.empty()) {
+        p->tev.assign(2 * n + 1, nullptr);
+        for (auto& e : p->tev) PLAN_HIP(hipEventCreate(&e));
+    }
+    if (!p->streams.empty() || timed) {
+        PLAN_HIP(hipEventRecord(timed ? p->tev[2 * n] : p->start, launch));
+        for (auto s : p->streams) PLAN_HIP(hipStreamWaitEvent(s, timed ? p->tev[2 * n] : p->start, 0));
+    }
+    for (size_t k = 0; k < n; k++) {
+        const PlanNode& nd = p->nodes[k];
+        hipStream_t st = stream_of(p, nd.stream, launch);
+        for (int e : nd.waits) PLAN_HIP(hipStreamWaitEvent(st, p->events[e], 0));
+        if (timed) PLAN_HIP(hipEventRecord(p->tev[2 * k], st));
+        PLAN_HIP(launch_node(nd, st));
+        if (timed) PLAN_HIP(hipEventRecord(p->tev[2 * k + 1], st));
+        if (nd.record >= 0) PLAN_HIP(hipEventRecord(p->events[nd.record], st));
+    }
+    for (size_t s = 0; s < p->streams.size(); s++) {
+        PLAN_HIP(hipEventRecord(p->tails[s], p->streams[s]));
+        PLAN_HIP(hipStreamWaitEvent(launch, p->tails[s], 0));
+    }
+#undef PLAN_HIP
+    return VHAP_OK;
+}
+
+extern "C" int vhap_plan_launch(vhap_plan_t plan, vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!plan) return VHAP_E_NULLPTR;
+    return plan_launch(plan, vhap_stream(stream), false);
+}
+
+// One replay with every node bracketed by timing events; BLOCKS until it has finished.  start_us[k] = start of node k relative to the
+// head of the replay, dur_us[k] = its duration (both in microseconds; the brackets cost a few microseconds per node, so the replay as a
+// whole is slower than an untimed one -- use it for per-kernel numbers, not for the step time).
+extern "C" int vhap_plan_launch_timed(vhap_plan_t plan, vhap_stream_t stream, float* start_us, float* dur_us, int n) {
+    VHAP_ENTER();
+    if (!plan || !start_us || !dur_us) return VHAP_E_NULLPTR;
+    if (n < (int)plan->nodes.size()) return VHAP_E_BADDIM;
+    const int rc = plan_launch(plan, vhap_stream(stream), true);
+    if (rc != VHAP_OK) return rc;
+    if (hipStreamSynchronize(vhap_stream(stream)) != hipSuccess) return VHAP_E_HIP;
+    const size_t nn = plan->nodes.size();
+    for (size_t k = 0; k < nn; k++) {
+        float a = 0.f, b = 0.f;
+        if (hipEventElapsedTime(&a, plan->tev[2 * nn], plan->tev[2 * k]) != hipSuccess) return VHAP_E_HIP;
+        if (hipEventElapsedTime(&b, plan->tev[2 * k], plan->tev[2 * k + 1]) != hipSuccess) return VHAP_E_HIP;
+        start_us[k] = a * 1000.f;
+        dur_us[k] = b * 1000.f;
+    }
+    return VHAP_OK;
+}

@@ -153,7 +153,7 @@ class NativeStep:
             if not self.aa_inplace:
                 self.rgba_aa = E(B, H, W, 4)
             if self.disturb_on:
-                self.rgba_d, self.keep = E(B, H, W, 4), E(B, H, W)
+                self.keep = E(B, H, W)                               # (the disturbance itself is in place: pools of copies, csrc/disturb.hip)
                 self.dist_ws = torch.empty(L.vhap_disturb_workspace_ints(B, H, W), dtype=torch.int32, device=dev)
                 self.cid = torch.empty(B, H, W, dtype=torch.uint8, device=dev)
             self.aa_work = torch.empty((L.vhap_antialias_inplace_work_ints if self.aa_inplace else L.vhap_antialias_work_ints)(B, H, W, self.F),
@@ -231,6 +231,7 @@ class NativeStep:
                                       # at the END of the step (off the critical path; the step's first kernels become roots of the graph) and the
                                       # texture-gradient sort is not joined before the backward needs it
         self._acc_clean = False
+        self.injected = None          # dict(w_fg, w_bg, idx): random numbers of the colour disturbance handed in (parity tests) instead of drawn in-kernel
         self.step_optimizer = None    # a HipAdam whose WHOLE update is issued inside forward()/backward() (GraphedStep, one GPU): counter advanced
                                       # at the head of the step, texture update behind its gradient, the rest before the final join
         self.split_tex = False        # True: stop at the gradient pyramid, the caller runs tex_finish() later (pyramid-level exchange)
@@ -409,10 +410,7 @@ class NativeStep:
              "vhap_shade_fwd")
         color = self.rgba
         if self.disturb_on:
-            _chk(L.vhap_disturb_fwd_rng_cid(_p(self.rgba), _p(self.cid), self.ncl, float(self.rate_fg or 0.0), float(self.rate_bg or 0.0),
-                                            _p(self.rng), B, H, W, _p(self.dist_ws), _p(self.rgba_d), _p(self.keep), st),
-                 "vhap_disturb_fwd_rng_cid")
-            color = self.rgba_d
+            self._disturb(st)
         self.aa_in = color
         _chk(L.vhap_antialias_fwd(_p(color), _p(self.rast), _p(self.clip), _p(self.tri), _p(self.opp), B, H, W, 4, V, F, _p(self.rgba_aa),
                                   _p(self.aa_work), st), "vhap_antialias_fwd")
@@ -485,10 +483,7 @@ class NativeStep:
             self._side(detect_branch, self.side2 if os.environ.get("VHAP_AA_EARLY", "1") == "2" else None)   # (on the texture branch's queue: idle here)
         color = self.rgba
         if self.disturb_on:
-            _chk(L.vhap_disturb_fwd_rng_cid(_p(self.rgba), _p(self.cid), self.ncl, float(self.rate_fg or 0.0), float(self.rate_bg or 0.0),
-                                            _p(self.rng), B, H, W, _p(self.dist_ws), _p(self.rgba_d), _p(self.keep), st),
-                 "vhap_disturb_fwd_rng_cid")
-            color = self.rgba_d
+            self._disturb(st)
         self._flush()
         if self.tb_ids:
             # the counting sort of the pixels by uv tile (for the texture gradient) needs only the tile ids the rasteriser wrote and the
@@ -537,6 +532,20 @@ class NativeStep:
         _chk(L.vhap_energy_finalize(_p(acc[0:6]), _p(acc[6:7]) if self.w_lmk else 0, _p(acc[7:9]), _p(acc[9:12]),
                                     _p(acc[12:16]) if self.want_reg else 0, self.w_lmk, self.w_reg, B, H, W, _p(self.log), st),
              "vhap_energy_finalize")
+
+    def _disturb(self, st):
+        """colour disturbance, in place on rgba (render_nvdiffrast.py:424-460); random numbers drawn in-kernel, or -- `self.injected`, a
+        dict(w_fg, w_bg, idx) as HipDiffRenderer.make_disturbance draws it -- handed in, so that the oracle can replay them"""
+        inj = self.injected
+        B, H, W = self.B, self.H, self.W
+        if inj is not None:
+            w_fg, w_bg, idx = inj["w_fg"].int().contiguous(), inj["w_bg"].int().contiguous(), inj["idx"].long().contiguous()
+            assert w_fg.numel() == w_bg.numel() == idx.numel() == B * H * W
+            self._inj_keep = (w_fg, w_bg, idx)                    # (alive until the launch has run)
+        _chk(self.L.vhap_disturb_inplace(_p(self.rgba), _p(self.cid), self.ncl, _p(w_fg) if inj is not None else 0,
+                                         _p(w_bg) if inj is not None else 0, _p(idx) if inj is not None else 0,
+                                         float(self.rate_fg or 0.0), float(self.rate_bg or 0.0), 0 if inj is not None else _p(self.rng),
+                                         B, H, W, _p(self.dist_ws), _p(self.keep), st), "vhap_disturb_inplace")
 
     def raster_profile_us(self):
         """(binning us, raster kernel us) of the LAST forward, from the in-kernel wall-clock stamps (needs raster_profile; synchronises)"""

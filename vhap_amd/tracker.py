@@ -11,6 +11,7 @@ is a sparse apply, the B-fold texture copy is gone, and frame batches can be sha
 with one all-reduce per Adam step (vhap_amd.dist).  Logging / TensorBoard / landmark detection /
 dataset IO of the reference are out of scope.
 """
+import ctypes
 import os
 from collections import defaultdict
 
@@ -929,6 +930,94 @@ class ShuffledBatches:
             yield tr.dist.shard_sample(s) if tr.dist is not None else s
 
 
+class CapturedPlan:
+    """One captured piece of a step: recorded under HIP stream capture into a hipGraph that is KEPT (never instantiated) and replayed by
+    the library's own executor (include/vhap_hip.h "Step plans", csrc/plan.hip): the nodes laid out over streams of the plan's own, plain
+    kernel launches, cross-stream edges as event pairs -- one C call per replay.  hipGraphLaunch is not used: ROCm 7's re-partitions the
+    branches on its internal streams and dereferences garbage when the launch stream shares a hardware queue with two of them
+    (profiles/r02_graph_launch_crash.txt).  A graph holding a node the executor does not know (anything but kernel / memset / empty nodes)
+    falls back to torch's replay of the instantiated graph, with a warning."""
+
+    MAX_STREAMS = 4
+
+    def __init__(self):
+        self.g = torch.cuda.CUDAGraph(keep_graph=True)
+        self.plan = None
+        self.fallback = os.environ.get("VHAP_EXECUTOR", "plan") == "graph"     # (A/B and debugging: the runtime's own graph launch)
+
+    def capture(self, **kw):
+        outer = self
+
+        class _Ctx:
+            def __enter__(self):
+                self.ctx = torch.cuda.graph(outer.g, **kw)
+                return self.ctx.__enter__()
+
+            def __exit__(self, *a):
+                r = self.ctx.__exit__(*a)
+                if a[0] is None:
+                    outer._finish()
+                return r
+        return _Ctx()
+
+    def _finish(self):
+        if self.fallback:
+            self.g.instantiate()
+            return
+        L = _lib.lib()
+        h = ctypes.c_void_p()
+        rc = L.vhap_plan_from_graph(self.g.raw_cuda_graph(), self.MAX_STREAMS, ctypes.byref(h))
+        if rc == -5:                                               # VHAP_E_UNSUPPORTED
+            import warnings
+            warnings.warn("CapturedPlan: the captured step holds a node type the plan executor does not replay; using hipGraphLaunch")
+            self.fallback = True
+            self.g.instantiate()
+            return
+        _lib.check(rc, "vhap_plan_from_graph")
+        self.plan = h
+
+    def pool(self):
+        return self.g.pool()
+
+    def replay(self):
+        if self.plan is None:
+            return self.g.replay()
+        _lib.check(_lib.lib().vhap_plan_launch(self.plan, torch.cuda.current_stream().cuda_stream), "vhap_plan_launch")
+
+    def describe(self):
+        if self.plan is None:
+            return "(hipGraph replay)"
+        L = _lib.lib()
+        n = L.vhap_plan_describe(self.plan, None, 0)
+        buf = ctypes.create_string_buffer(n)
+        L.vhap_plan_describe(self.plan, buf, n)
+        return buf.value.decode()
+
+    def timed(self):
+        """One replay with per-node timing events -> [(kernel name, stream-relative start us, duration us)]; blocks."""
+        if self.plan is None:
+            raise RuntimeError("CapturedPlan.timed() needs the plan executor")
+        L = _lib.lib()
+        n = ctypes.c_int()
+        L.vhap_plan_info(self.plan, ctypes.byref(n), None, None)
+        st, du = (ctypes.c_float * n.value)(), (ctypes.c_float * n.value)()
+        _lib.check(L.vhap_plan_launch_timed(self.plan, torch.cuda.current_stream().cuda_stream, st, du, n.value), "vhap_plan_launch_timed")
+        out = []
+        buf = ctypes.create_string_buffer(512)
+        for k in range(n.value):
+            L.vhap_plan_node_name(self.plan, k, buf, 512)
+            out.append((buf.value.decode(), float(st[k]), float(du[k])))
+        return out
+
+    def __del__(self):
+        try:
+            if self.plan is not None:
+                _lib.lib().vhap_plan_destroy(self.plan)         # before the graph it borrows its kernel arguments from
+                self.plan = None
+        except Exception:
+            pass
+
+
 class GraphedStep:
     """One optimiser step captured in hipGraphs (the 50-500 identical steps of a
     stage are launch-bound in eager mode -- ~1300 launches per step).
@@ -1006,7 +1095,7 @@ class GraphedStep:
         cap = dict(capture_error_mode="thread_local") if tracker.dist is not None else {}
         if os.environ.get("VHAP_PRIO", "0") == "2":                 # (experiment: the main chain of the captured step on a high-priority stream)
             cap["stream"] = _lib.private_stream("capture_hi", dev, high_priority=True)
-        self.gF, self.gB, self.gA = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        self.gF, self.gB, self.gA = CapturedPlan(), CapturedPlan(), CapturedPlan()
         if self.ns is not None:
             ns = self.ns
             world = tracker.dist.world_size if tracker.dist is not None else 1
@@ -1030,7 +1119,7 @@ class GraphedStep:
                     ns.one_graph = True
                     ns.accF.zero_()
                     ns._acc_clean = True
-                with torch.cuda.graph(self.gF, **cap):
+                with self.gF.capture(**cap):
                     for _ in range(self.unroll):
                         ns.forward()
                         if early:
@@ -1044,37 +1133,37 @@ class GraphedStep:
             elif not ns.photometric:
                 # Frame sharding of a landmark-only stage: forward, backward, ONE all-reduce of the (small) gradient arena, Adam
                 self.lmk_only = True
-                with torch.cuda.graph(self.gF, **cap):
+                with self.gF.capture(**cap):
                     ns.forward()
                 pool = self.gF.pool() if os.environ.get("VHAP_GRAPH_POOLS") != "separate" else None
-                with torch.cuda.graph(self.gB, pool=pool, **cap):
+                with self.gB.capture(pool=pool, **cap):
                     ns.backward(world)
-                with torch.cuda.graph(self.gA, pool=pool, **cap):
+                with self.gA.capture(pool=pool, **cap):
                     optimizer.step()
             else:
                 # Frame sharding.  The big collective is the texture gradient (50 MB at T = 2048).  The backward is captured in two graphs:
                 # 'texture' makes that gradient final first, its asynchronous all-reduce is launched, and 'geometry' (G-buffer backward,
                 # normals, skinning, per-frame parameters: ~0.35 ms) runs underneath it; the small gradients follow in a second collective.
-                with torch.cuda.graph(self.gF, **cap):
+                with self.gF.capture(**cap):
                     ns.forward()
                 pool = self.gF.pool() if os.environ.get("VHAP_GRAPH_POOLS") != "separate" else None
                 # 'parallel' (default): pixel chain, then the texture part (own stream, followed by its all-reduce) NEXT TO the geometry part --
                 # the same two-branch overlap as on one GPU; 'serial': texture part, collective launched, geometry part underneath it
                 self.par = os.environ.get("VHAP_SHARD_SCHEDULE", "parallel") != "serial"
-                self.gB2 = torch.cuda.CUDAGraph()
+                self.gB2 = CapturedPlan()
                 if self.par:
-                    with torch.cuda.graph(self.gB, pool=pool, **cap):
+                    with self.gB.capture(pool=pool, **cap):
                         ns.backward(world, part="pixel")
-                    self.gBt = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(self.gBt, **cap):               # replayed concurrently with gB2: a pool of its own
+                    self.gBt = CapturedPlan()
+                    with self.gBt.capture(**cap):               # replayed concurrently with gB2: a pool of its own
                         ns.backward(world, part="tex")
                     self.tex_stream = _lib.private_stream("tex", dev, high_priority=self._launch_hi)    # (launches gBt)
                 else:
-                    with torch.cuda.graph(self.gB, pool=pool, **cap):
+                    with self.gB.capture(pool=pool, **cap):
                         ns.backward(world, part="texture")
-                with torch.cuda.graph(self.gB2, pool=pool, **cap):
+                with self.gB2.capture(pool=pool, **cap):
                     ns.backward(world, part="geometry")
-                with torch.cuda.graph(self.gA, pool=pool, **cap):
+                with self.gA.capture(pool=pool, **cap):
                     optimizer.step()
             self.E = ns.log[15]
             self.log_dict = ns.log_dict()
@@ -1082,7 +1171,7 @@ class GraphedStep:
             return
         tracker._split = {}
         try:
-            with torch.cuda.graph(self.gF, **cap):
+            with self.gF.capture(**cap):
                 s = dict(self.sample)
                 tracker.clear_cache()
                 tracker.fill_cam_params_into_sample(s)
@@ -1091,7 +1180,7 @@ class GraphedStep:
             pool = self.gF.pool() if os.environ.get("VHAP_GRAPH_POOLS") != "separate" else None
             for p in self.params:
                 p.grad = None
-            with torch.cuda.graph(self.gB, pool=pool, **cap):
+            with self.gB.capture(pool=pool, **cap):
                 E = E_rest + tracker.cfg.w.photo * self.S * self.inv_n if self.S is not None else E_rest
                 # .grad is None: autograd hands its gradient tensors over to the parameters (no copy); they live in the graph's
                 # pool at fixed addresses and are rewritten by every replay
@@ -1100,7 +1189,7 @@ class GraphedStep:
                     if p.grad is None:
                         p.grad = torch.zeros_like(p)
                 self.E = E.detach()
-            with torch.cuda.graph(self.gA, pool=pool, **cap):
+            with self.gA.capture(pool=pool, **cap):
                 optimizer.step()
         finally:
             tracker._split = None
