@@ -1,0 +1,181 @@
+"""The step AS SHIPPED against the oracle at the BASELINE sizes (SURVEY 8(c) known-answer item 12 "oracle loss
+vs HIP loss on cfg 1-4, disturbance off and with injected randomness"):
+
+the hand-chained NativeStep with deferred shading, in-place antialiasing, the uv-binned texture gradient and the colour disturbance ON --
+its random numbers INJECTED (NativeStep.injected: the same in-place pool kernels the captured step runs, fed the oracle's draws instead
+of the in-kernel generator) -- every energy term and the gradient w.r.t. every parameter:
+
+    config 2   2 x 512 x 512 monocular, T = 2048, rgb_global_tracking
+    config 3   1 x 1024 x 1024 monocular, T = 2048, static_offset TRAINED (rgb_init_offset)
+    config 4   2 calibrated views of one timestep, 802 x 550, T = 2048, the NeRSemble configuration
+
+and K = 10 optimiser steps at 2 x 512 x 512, T = 2048 against the oracle's fit loop (fp64 + torch.optim.Adam).
+
+Same visibility throughout (the oracle is handed the triangle ids the HIP rasteriser produced: the rasteriser itself is compared bit for
+bit at these sizes in tests/test_raster_gpu.py).  Stated tolerances, fp32 product vs fp64 oracle: energy terms 5e-5 relative, gradients
+5e-4 of their max-norm."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import energy_ref
+from tests.test_fit_parity_gpu import NAMES, _compare_grads, _make, _record
+
+pytestmark = pytest.mark.gpu
+
+T = 2048
+
+
+def _native_vs_oracle(tr, cfg, topo, tm, base_tex, sample, o_sample, stage, image_size, names, lines, tag, seed):
+    """-> list of failures.  NativeStep (as the captured step runs it) with injected disturbance vs energy_ref.total_energy."""
+    from vhap_amd.step import NativeStep
+    H, W = image_size
+    B = sample["rgb"].shape[0]
+    tr.get_train_parameters(stage)
+    uvmask = tr._uvmask_res().cpu().double()
+    cr = cfg.render
+    tr.render.disturb_rate_fg, tr.render.disturb_rate_bg = cr.disturb_rate_fg, cr.disturb_rate_bg
+    dist = tr.render.make_disturbance((B, H, W), "cuda", generator=torch.Generator("cuda").manual_seed(seed))
+    ns = NativeStep(tr, sample, stage)
+    assert ns.deferred and ns.aa_inplace and ns.disturb_on and ns.photometric
+    ns.injected = dist
+    ns.forward()
+    ns.backward(1)
+    torch.cuda.synchronize()
+    keep = ns.keep.clone()
+    assert 0.2 < float(1 - keep.mean()) < 0.8, "the disturbance must have replaced about half of the pixels"
+    tid = (ns.rast[..., 3].long() - 1).cpu()
+    cov = float((tid >= 0).float().mean())
+    assert 0.03 < cov < 0.97, cov
+    log_n = {k: float(v) for k, v in ns.log_dict().items()}
+    g_n = {k: ns.g[k].detach().clone().reshape(getattr(tr, k).shape) for k in names if k in ns.g}
+    P = {k: getattr(tr, k).detach().cpu().double().requires_grad_() for k in names}
+    ncl = int(topo.fid2cid.max()) + 1
+    o_dist = dict(w_fg=dist["w_fg"].cpu(), w_bg=dist["w_bg"].cpu(), idx=[dist["idx"].cpu()] * ncl,
+                  fid2cid=torch.from_numpy(topo.fid2cid.astype(np.int64)))
+    Eo, logo, _ = energy_ref.total_energy(P, tm, topo, cfg, o_sample, stage, base_tex, uvmask, (H, W), disturb=o_dist, tid=tid)
+    Eo.backward()
+    fails = []
+    lines.append(f"{tag}: {B} x {H}x{W}, T = {T}, stage {stage}, coverage {cov:.3f}, disturbed {float(1 - keep.mean()):.3f}")
+    for k, b in logo.items():
+        b = float(b.detach())
+        e = abs(log_n[k] - b) / max(abs(b), 1e-3)
+        lines.append(f"{tag} term {k}: {e:.2e}")
+        if e > 5e-5:
+            fails.append(f"{tag} term {k}: {log_n[k]} vs {b}")
+    e = abs(log_n["total"] - float(Eo.detach())) / abs(float(Eo.detach()))
+    lines.append(f"{tag} total: {e:.2e}")
+    if e > 5e-5:
+        fails.append(f"{tag} total energy: {log_n['total']} vs {float(Eo.detach())}")
+    worst = _compare_grads(P, g_n, lines, tag, 5e-4, 0.999999)
+    if worst > 5e-4:
+        fails.append(f"{tag} gradients: worst rel {worst:.2e}")
+    assert float(P["tex_extra"].grad.abs().max()) > 0
+    tr.render.disturb_rate_fg, tr.render.disturb_rate_bg = cr.disturb_rate_fg, cr.disturb_rate_bg
+    return fails
+
+
+def test_shipped_native_step_with_injected_disturbance_config2_size(flame_model):
+    H = W = 512
+    S = _make(flame_model, H, W, 2, T, seed=17)
+    tr = S["tr"]
+    ts = np.array([0, 1])
+    sample = tr.get_sample(ts, device_index=True)
+    o_sample = {"rgb": sample["rgb"].cpu(), "lmk2d": sample["lmk2d"].cpu(), "timestep_index": ts}
+    lines = []
+    fails = _native_vs_oracle(tr, S["cfg"], S["topo"], S["tm"], S["base_tex"], sample, o_sample, "rgb_global_tracking", (H, W), NAMES, lines,
+                              "cfg2", seed=12)
+    _record("parity_native_injected_cfg2.txt", lines + fails)
+    assert not fails, fails
+
+
+def test_shipped_native_step_config3_size_static_offset_trained(flame_model):
+    """BASELINE config 3: 1024 x 1024 with static_offset trained (stage rgb_init_offset: the offset regularisers, the full learning-rate
+    stage) -- one frame of it (the oracle needs ~20 s per megapixel)."""
+    H = W = 1024
+    S = _make(flame_model, H, W, 1, T, seed=29)
+    tr = S["tr"]
+    ts = np.array([0])
+    sample = tr.get_sample(ts, device_index=True)
+    o_sample = {"rgb": sample["rgb"].cpu(), "lmk2d": sample["lmk2d"].cpu(), "timestep_index": ts}
+    lines = []
+    fails = _native_vs_oracle(tr, S["cfg"], S["topo"], S["tm"], S["base_tex"], sample, o_sample, "rgb_init_offset", (H, W), NAMES, lines,
+                              "cfg3", seed=5)
+    _record("parity_native_injected_cfg3.txt", lines + fails)
+    assert not fails, fails
+
+
+def test_shipped_native_step_config4_size_calibrated_views(flame_model):
+    """BASELINE config 4: calibrated views (K [B,3,3], RT [B,3,4]) of ONE timestep at 802 x 550 under the NeRSemble configuration
+    (w.landmark 3, reg_tex_tv 1e5, jawline landmarks off): two views on the arc of vhap_amd.synthetic.arc_cameras."""
+    from vhap_amd.config import nersemble_config
+    from vhap_amd.flame import FlameHead
+    from vhap_amd.render_hip import HipDiffRenderer
+    from vhap_amd.synthetic import make_multiview_dataset, make_scene_params, make_texture
+    from vhap_amd.tracker import GlobalTracker
+    model, topo = flame_model
+    H, W, NV = 802, 550, 2
+    cfg = nersemble_config()
+    cfg.model.tex_resolution = T
+    gt = make_scene_params(1, seed=3, image_size=(H, W))
+    head, rend = FlameHead(model, topo).cuda(), HipDiffRenderer(lighting_type="SH").cuda()
+    data = make_multiview_dataset(rend, head, gt, (H, W), "cuda", n_views=NV, seed=3, tex=make_texture(3, T))
+    base_tex = make_texture(0, T)
+    tr = GlobalTracker(cfg, model, topo, base_tex, data)
+    assert tr.calibrated
+    g = torch.Generator().manual_seed(8)
+    with torch.no_grad():
+        for name, s_ in (("shape", 0.3), ("expr", 0.3), ("rotation", 0.05), ("neck_pose", 0.03), ("jaw_pose", 0.05), ("eyes_pose", 0.05),
+                         ("translation", 0.005), ("tex_extra", 0.03), ("lights", 0.05), ("static_offset", 1e-3)):
+            p = getattr(tr, name)
+            p.add_((torch.randn(p.shape, generator=g) * s_).cuda())
+        tr.jaw_pose[:, 0] += 0.1
+    tm = {k: torch.from_numpy(np.asarray(v)) for k, v in model.items()}
+    for k in ("v_template", "shapedirs", "posedirs", "J_regressor", "lbs_weights", "lmk_bary_coords", "verts_uvs"):
+        tm[k] = tm[k].double()
+    sample = tr.get_sample(np.array([0]), device_index=True)
+    assert sample["rgb"].shape[0] == NV
+    ts = sample["timestep_index"].cpu().numpy()
+    o_sample = {"rgb": sample["rgb"].cpu(), "lmk2d": sample["lmk2d"].cpu(), "timestep_index": ts, "intrinsic": sample["intrinsic"].cpu(),
+                "extrinsic": sample["extrinsic"].cpu()}
+    names = [n for n in NAMES if n != "focal_length"]
+    lines = []
+    fails = _native_vs_oracle(tr, cfg, topo, tm, torch.from_numpy(base_tex)[None].double(), sample, o_sample, "rgb_global_tracking", (H, W),
+                              names, lines, "cfg4", seed=21)
+    _record("parity_native_injected_cfg4.txt", lines + fails)
+    assert not fails, fails
+
+
+def test_ten_steps_at_baseline_size_match_oracle_fit(flame_model):
+    """K = 10 optimiser steps (tracker.py:1418-1462) at 2 x 512 x 512, T = 2048, the step as captured (disturbance off: its in-kernel
+    draws cannot be replayed; the injected form is covered above), against the oracle's fit loop; every exported array
+    (tracker.py:1152-1218) to SURVEY 8(c)'s 1e-3 in relative L2, energies along the trajectory to 5e-5."""
+    from tests.test_fit_parity_gpu import _trajectory
+    H = W = 512
+    S = _make(flame_model, H, W, 2, T, seed=17)
+    stage, lr_scale, K = "rgb_global_tracking", 0.1, 10
+    start, hip, ora, (E_hip, E_ora) = _trajectory(S, stage, lr_scale, K, H, W, np.array([0, 1]), same_visibility=True)
+    lines = [f"stage {stage} lr_scale {lr_scale} K {K} 2 x {H}x{W} T {T} same visibility"]
+    fails = []
+    for i, (a, b) in enumerate(zip(E_hip, E_ora)):
+        e = abs(a - b) / abs(b)
+        lines.append(f"step {i}: E hip {a:.6f} oracle {b:.6f} rel {e:.2e}")
+        if e > 5e-5:
+            fails.append(f"energy at step {i}: {a} vs {b}")
+    assert E_hip[-1] < E_hip[0] and E_ora[-1] < E_ora[0]
+    for k in sorted(hip):
+        a, b = np.asarray(hip[k], np.float64), np.asarray(ora[k], np.float64)
+        if k in ("timestep_id", "n_processed_frames", "image_size"):
+            assert np.array_equal(a, b), k
+            continue
+        moved = float(np.abs(b - start[k]).max())
+        if moved == 0:
+            continue
+        l2 = float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+        mx = float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-12))
+        dl2 = float(np.linalg.norm(a - b) / max(np.linalg.norm(b - start[k]), 1e-300))
+        lines.append(f"{k}: L2 rel {l2:.2e}  max-norm rel {mx:.2e}  update L2 rel {dl2:.2e}")
+        if l2 > 1e-3:
+            fails.append(f"{k}: L2 rel {l2:.2e}")
+    _record("fit_parity_10_steps_512_T2048.txt", lines + fails)
+    assert not fails, fails

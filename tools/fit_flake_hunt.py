@@ -133,26 +133,43 @@ def main():
             lines.append(f"{n}: median {np.median(d):.2e} max {np.max(d):.2e} (run {1 + int(np.argmax(d))})")
         outliers = [r for r in full if r > 0]
         lines.append(f"runs whose `lights` ended >= 0.2 lr away from run 0 in some component: {outliers if outliers else 'none'}")
+        # an eager NativeStep to re-evaluate the gradient at recorded parameters (same kernels, issued launch by launch on streams + events)
+        ns_chk = NativeStep(tr, sample, stage)
+        lr_l = cfg.lr.light * lr_scale
         for r in ([0] + outliers)[:4]:
-            # where did run r leave run 0?  (run 0 itself: just report its distance to the oracle at every step)
-            lines.append(f"-- run {r}: step-k gradient vs the oracle at the run's own step-k parameters (same visibility)")
+            lines.append(f"-- run {r}: per step, the gradient the run computed (cap) and an eager re-evaluation at the SAME parameters (eag), each vs the "
+                         f"oracle at those parameters and visibility, max-norm relative; cap-vs-eag; pixels whose triangle id differs between the two; "
+                         f"distance of the run's lights to run 0's before the step, in units of lr")
             for k in range(K):
                 params, tid, g = full[r][k]
                 go = oracle_grad(params, tid)
+                with torch.no_grad():
+                    for n in NAMES:
+                        getattr(tr, n).copy_(params[n].cuda())
+                ns_chk.forward()
+                ns_chk.backward(1)
+                torch.cuda.synchronize()
+                ge = {n: ns_chk.g[n].detach().cpu().double() for n in NAMES if n in ns_chk.g}
+                tid_e = (ns_chk.rast[..., 3].long() - 1).cpu()
+                ndiff = int((tid_e != tid).sum())
+                rel = lambda a, b: float((a.reshape(-1) - b.reshape(-1)).abs().max() / max(float(b.abs().max()), 1e-300))
                 row = []
-                for n in ("lights", "shape", "focal_length", "rotation", "translation", "expr", "static_offset", "tex_extra"):
-                    if n not in g:
-                        continue
-                    a, b = g[n].reshape(-1), go[n].reshape(-1)
-                    row.append(f"{n} {float((a - b).abs().max() / max(float(b.abs().max()), 1e-300)):.1e}")
-                lines.append(f"   step {k}: " + "  ".join(row))
-                if r > 0:
-                    # components of lights whose Adam direction differs between this run and run 0 at this step
-                    a, a0, b = g["lights"].reshape(-1), G[0][k]["lights"], go["lights"].reshape(-1)
-                    flip = (torch.sign(a) != torch.sign(a0)).nonzero().reshape(-1).tolist()
-                    for c in flip:
-                        lines.append(f"      lights[{c}]: g(run {r}) {float(a[c]):+.3e}  g(run 0) {float(a0[c]):+.3e}  g(oracle at run {r}) {float(b[c]):+.3e}"
-                                     f"  |g|max {float(b.abs().max()):.3e}  -> |g| / |g|max = {abs(float(b[c])) / float(b.abs().max()):.1e}")
+                for n in ("lights", "shape", "focal_length", "expr", "static_offset", "tex_extra"):
+                    if n in g:
+                        row.append(f"{n} cap {rel(g[n], go[n]):.1e} eag {rel(ge[n], go[n]):.1e} c-e {rel(g[n], ge[n]):.1e}")
+                dl = float((PR[r][k]["lights"] - PR[0][k]["lights"]).abs().max()) / lr_l
+                lines.append(f"   step {k}: " + " | ".join(row) + f" | tid diff {ndiff} px | lights vs run 0: {dl:.2f} lr")
+                if r > 0 and k > 0:
+                    # components of lights that this step moved the other way than run 0 did: their gradient in both runs and in the oracle
+                    mv_r = PR[r][k]["lights"] - PR[r][k - 1]["lights"]
+                    mv_0 = PR[0][k]["lights"] - PR[0][k - 1]["lights"]
+                    for c in ((mv_r - mv_0).abs() > 0.5 * lr_l).nonzero().reshape(-1).tolist():
+                        a, a0 = G[r][k - 1]["lights"], G[0][k - 1]["lights"]
+                        gprev = oracle_grad(full[r][k - 1][0], full[r][k - 1][1])["lights"].reshape(-1)
+                        lines.append(f"      step {k - 1} moved lights[{c}] by {float(mv_r[c]) / lr_l:+.2f} lr (run 0: {float(mv_0[c]) / lr_l:+.2f} lr): "
+                                     f"g(run {r}) {float(a[c]):+.3e}  g(run 0) {float(a0[c]):+.3e}  g(oracle at run {r}) {float(gprev[c]):+.3e}  "
+                                     f"|g|max {float(gprev.abs().max()):.3e}")
+        del ns_chk
         del ns, ns_e, st
     reset()
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)

@@ -74,8 +74,8 @@ calls = {
     "raster_shade bin_only": lambda: raster(1 | 2),
     "raster_shade prebinned (+stats reduce)": lambda: raster(1 | 4),
     "raster_shade whole": lambda: raster(1),
-    "disturb": (lambda: L.vhap_disturb_fwd_rng_cid(_p(ns.rgba), _p(ns.cid), ns.ncl, float(ns.rate_fg or 0.0), float(ns.rate_bg or 0.0), _p(ns.rng), B, H, W,
-                                                   _p(ns.dist_ws), _p(ns.rgba_d), _p(ns.keep), st())) if ns.disturb_on else None,
+    "disturb": (lambda: L.vhap_disturb_inplace(_p(ns.rgba), _p(ns.cid), ns.ncl, 0, 0, 0, float(ns.rate_fg or 0.0), float(ns.rate_bg or 0.0), _p(ns.rng),
+                                               B, H, W, _p(ns.dist_ws), _p(ns.keep), st())) if ns.disturb_on else None,
     "antialias_inplace_fwd": lambda: L.vhap_antialias_inplace_fwd(_p(ns.aa_in), _p(ns.rast), _p(ns.clip), _p(ns.tri), _p(ns.opp), B, H, W, V, F,
                                                                   _p(ns.aa_work), st()),
     "photo_fwd": lambda: L.vhap_photo_fwd(_p(ns.rgba_aa), _p(ns.rgb), B, H, W, _p(acc[16:18]), PRE, st()),

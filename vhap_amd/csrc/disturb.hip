@@ -21,9 +21,10 @@
 namespace {
 
 constexpr int MAXC = 16;  // max clusters (the reference configures 7 + background + "none" = 9)
-constexpr int DB = 1024;  // threads per counting-sort workgroup
-constexpr int PPT = 8;    // pixels per thread: a workgroup owns DB * PPT consecutive pixels (8192: 512 workgroups at 16x512^2)
+constexpr int DB = 256;   // threads per counting-sort workgroup
+constexpr int PPT = 8;    // pixels per thread: a workgroup owns DB * PPT consecutive pixels (2048: 2048 workgroups at 16x512^2, all resident)
 constexpr int DPIX = DB * PPT;
+constexpr int PB = 1024;  // threads of the single prefix workgroup
 
 // cluster of pixel p: from the compact one-byte cluster image when the shading kernel wrote one (4 MB instead of a 67 MB pass over
 // the rasteriser output at 16x512^2), else through the triangle id of rast and the fid -> cluster table
@@ -79,48 +80,72 @@ __global__ __launch_bounds__(DB) void disturb_count_kernel(const ClusterSrc src,
     }
 }
 
-// pass 2: every workgroup derives its own exclusive prefix (and the cluster totals) from the per-block histograms -- nblocks * 64 B,
-// L2-resident -- instead of waiting for a single-workgroup scan; then pool[start_c + prefix_c + rank in block] = colour of the pixel.
-// Workgroup 0 publishes totals[c] and totals[MAXC + c] = start_c for the gather pass.
-__global__ __launch_bounds__(DB) void disturb_scatter_kernel(const ClusterSrc src, const float4* __restrict__ rgba,
-                                                              int ncl, long long n, int nblocks, const int* __restrict__ block_counts,
-                                                              int* __restrict__ totals, float4* __restrict__ pool) {
-    __shared__ int red[2][DB / 64][MAXC];
-    __shared__ int base[MAXC];          // start_c + prefix of this block
-    __shared__ int wcnt[PPT][DB / 64][MAXC];
+// pass 2 (ONE workgroup): block_counts[block][c] -> exclusive prefix over the blocks, per cluster, in place; totals[c] and
+// totals[MAXC + c] = start of cluster c's pool.  Thread t owns cluster t & 15 and the t >> 4-th of 64 segments of consecutive blocks
+// (a wave reads whole 64-byte rows); the segment sums meet in LDS, wave c scans cluster c's 64 segment sums.
+// (Round 2 let every scatter workgroup of 1024 threads derive its own prefix from all rows: no extra launch, but with 106 VGPRs only
+// one such workgroup fits a CU and its phases -- prefix, ranks, copy -- run one after the other with nothing to overlap; fine for
+// 4-byte ids, 128 us once the pass copies 16-byte colours.)
+__global__ __launch_bounds__(PB) void disturb_prefix_kernel(int* __restrict__ block_counts, int nblocks, int* __restrict__ totals) {
+    __shared__ int seg[64][MAXC];
+    __shared__ int tot[MAXC];
+    const int c = threadIdx.x & (MAXC - 1), sg = threadIdx.x >> 4;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int before[MAXC], total[MAXC];
-#pragma unroll
-    for (int k = 0; k < MAXC; k++) { before[k] = 0; total[k] = 0; }
-    for (int j = threadIdx.x; j < nblocks; j += DB) {
-        const int4* row = reinterpret_cast<const int4*>(block_counts + (size_t)j * MAXC);
-        const bool pre = j < (int)blockIdx.x;
-#pragma unroll
-        for (int q = 0; q < MAXC / 4; q++) {
-            const int4 v = row[q];
-            total[4 * q] += v.x; total[4 * q + 1] += v.y; total[4 * q + 2] += v.z; total[4 * q + 3] += v.w;
-            if (pre) { before[4 * q] += v.x; before[4 * q + 1] += v.y; before[4 * q + 2] += v.z; before[4 * q + 3] += v.w; }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < MAXC; k++) {
-        int a = before[k], t = total[k];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); t += __shfl_xor(t, o, 64); }
-        if (lane == 0) { red[0][wave][k] = a; red[1][wave][k] = t; }
-    }
-    // ranks inside the block, in pixel order: iteration-major, then wave, then lane.  A wave holds 64 consecutive pixels -- one or
-    // two clusters, rarely more -- so it loops over the cluster values PRESENT (readfirstlane + ballot) instead of over all clusters.
-    for (int i = threadIdx.x; i < PPT * (DB / 64) * MAXC; i += DB) (&wcnt[0][0][0])[i] = 0;
+    const int per = (nblocks + 63) / 64;
+    const int j0 = min(sg * per, nblocks), j1 = min(j0 + per, nblocks);
+    int sum = 0;
+    for (int j = j0; j < j1; j++) sum += block_counts[(size_t)j * MAXC + c];
+    seg[sg][c] = sum;
     __syncthreads();
-    int c_of[PPT], rank_of[PPT];
-    float4 col_of[PPT];                             // the pixels' colours: loaded here, under the ballots, stored once the offsets are known
+    {   // wave `wave` (16 of them) scans cluster `wave`: lane = segment
+        const int v = seg[lane][wave];
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += u;
+        }
+        __syncthreads();
+        seg[lane][wave] = incl - v;
+        if (lane == 63) tot[wave] = incl;
+    }
+    __syncthreads();
+    if (threadIdx.x < MAXC) {
+        int start = 0;
+        for (int k = 0; k < (int)threadIdx.x; k++) start += tot[k];
+        totals[threadIdx.x] = tot[threadIdx.x];
+        totals[MAXC + threadIdx.x] = start;
+    }
+    int run = seg[sg][c];
+    for (int j = j0; j < j1; j++) {
+        const int v = block_counts[(size_t)j * MAXC + c];
+        block_counts[(size_t)j * MAXC + c] = run;
+        run += v;
+    }
+}
+
+// pass 3: pool[start_c + prefix_c(block) + rank in block] = colour of the pixel.  Ranks inside the block in pixel order: iteration-major,
+// then wave, then lane.  A wave holds 64 consecutive pixels -- one or two clusters, rarely more -- so it loops over the cluster values
+// PRESENT (readlane + ballot) instead of over all clusters.  256-thread workgroups, all resident at once: the latency-bound rank
+// phase of one overlaps the copy phase of another.
+__global__ __launch_bounds__(DB) void disturb_scatter_kernel(const ClusterSrc src, const float4* __restrict__ rgba,
+                                                              int ncl, long long n, const int* __restrict__ block_prefix,
+                                                              const int* __restrict__ totals, float4* __restrict__ pool) {
+    constexpr int NW = DB / 64;                     // waves
+    constexpr int NE = PPT * NW;                    // (iteration, wave) counters per cluster: 32
+    static_assert(NE == 32 && MAXC == 16, "the in-block scan below assumes 32 counters per cluster, two clusters per wave pass");
+    __shared__ int base[MAXC];                      // start_c + prefix of this block
+    __shared__ int wcnt[PPT][NW][MAXC];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < MAXC) base[threadIdx.x] = totals[MAXC + threadIdx.x] + block_prefix[(size_t)blockIdx.x * MAXC + threadIdx.x];
+    for (int i = threadIdx.x; i < PPT * NW * MAXC; i += DB) (&wcnt[0][0][0])[i] = 0;
+    __syncthreads();
+    int key[PPT];                                   // cluster << 8 | rank in the wave's 64 pixels (-1: not sorted)
 #pragma unroll
     for (int it = 0; it < PPT; it++) {
         const long long p = (long long)blockIdx.x * DPIX + it * DB + threadIdx.x;
         int c = p < n ? pixel_cluster(src, p) : -1;
         if (c >= ncl) c = -1;                       // (ids outside the configured clusters are left alone)
-        if (c >= 0) col_of[it] = rgba[p];
         int rank = 0;
         unsigned long long todo = __ballot(c >= 0);
         while (todo) {
@@ -130,51 +155,34 @@ __global__ __launch_bounds__(DB) void disturb_scatter_kernel(const ClusterSrc sr
             if (lane == 0) wcnt[it][wave][k] = __popcll(m);
             todo &= ~m;
         }
-        c_of[it] = c; rank_of[it] = rank;
+        key[it] = c < 0 ? -1 : ((c << 8) | rank);
     }
     __syncthreads();
-    if (threadIdx.x < MAXC) {
-        int a = 0;
-        for (int w = 0; w < DB / 64; w++) a += red[0][w][threadIdx.x];
-        // start of cluster k = sum of the totals of the clusters before it
-        int start = 0;
-        for (int k = 0; k < (int)threadIdx.x; k++)
-            for (int w = 0; w < DB / 64; w++) start += red[1][w][k];
-        base[threadIdx.x] = start + a;
-        if (blockIdx.x == 0) {
-            int t = 0;
-            for (int w = 0; w < DB / 64; w++) t += red[1][w][threadIdx.x];
-            totals[threadIdx.x] = t;
-            totals[MAXC + threadIdx.x] = start;
-        }
-    }
-    // exclusive prefix of wcnt over (iteration, wave) per cluster, in place: wave w scans cluster w (two entries per lane), so that a
-    // pixel needs ONE LDS read for its offset instead of walking up to PPT * 16 counters
-    {
-        constexpr int NE = PPT * (DB / 64);       // 128 entries per cluster
-        static_assert(NE == 128 && DB / 64 == MAXC, "one wave per cluster, two entries per lane");
-        int* col = &wcnt[0][0][0] + wave;         // entry e of cluster `wave` lives at col[e * MAXC]
-        const int a0 = col[(2 * lane) * MAXC], a1 = col[(2 * lane + 1) * MAXC];
-        int incl = a0 + a1;
+    // exclusive prefix of wcnt over (iteration, wave) per cluster, in place: a wave pass scans two clusters (32 counters each), so that
+    // a pixel needs ONE LDS read for its offset
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int u = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += u;
+    for (int r = 0; r < MAXC / (2 * NW); r++) {
+        const int k = (wave * (MAXC / (2 * NW)) + r) * 2 + (lane >> 5), e = lane & 31;
+        int* cell = &wcnt[0][0][0] + e * MAXC + k;
+        const int v = *cell;
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) {
+            const int u = __shfl_up(incl, o, 32);
+            if (e >= o) incl += u;
         }
-        const int excl = incl - (a0 + a1);
-        col[(2 * lane) * MAXC] = excl;
-        col[(2 * lane + 1) * MAXC] = excl + a0;
+        *cell = incl - v;
     }
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < PPT; it++) {
-        const int c = c_of[it];
-        if (c < 0) continue;
-        pool[base[c] + wcnt[it][wave][c] + rank_of[it]] = col_of[it];
+        if (key[it] < 0) continue;
+        const int c = key[it] >> 8, rank = key[it] & 255;
+        pool[base[c] + wcnt[it][wave][c] + rank] = rgba[(long long)blockIdx.x * DPIX + it * DB + threadIdx.x];
     }
 }
 
-// pass 3: out = w ? pool[start_c + idx % n_c] : cur ; keep = 1 - w_eff (gradient mask for the backward).
+// pass 4: out = w ? pool[start_c + idx % n_c] : cur ; keep = 1 - w_eff (gradient mask for the backward).
 // INPLACE: `out` IS the image the pools were copied from: only disturbed pixels are touched (no read of the pixel's own colour).
 template <bool INPLACE>
 __global__ __launch_bounds__(256) void disturb_apply_kernel(const float4* __restrict__ rgba, int B, int H, int W,
@@ -251,7 +259,9 @@ static int disturb_run(const float* rgba, const float* rast, const uint8_t* cid,
     const float4* in = reinterpret_cast<const float4*>(rgba);
     disturb_count_kernel<<<nblocks, DB, 0, st>>>(src, ncl, n, block_counts, rng_state);
     VHAP_LAUNCH_CHECK();
-    disturb_scatter_kernel<<<nblocks, DB, 0, st>>>(src, in, ncl, n, nblocks, block_counts, totals, pool);
+    disturb_prefix_kernel<<<1, PB, 0, st>>>(block_counts, nblocks, totals);
+    VHAP_LAUNCH_CHECK();
+    disturb_scatter_kernel<<<nblocks, DB, 0, st>>>(src, in, ncl, n, block_counts, totals, pool);
     VHAP_LAUNCH_CHECK();
     if (out == rgba)
         disturb_apply_kernel<true><<<vhap_cdiv(n, 256), 256, 0, st>>>(in, B, H, W, src, w_fg, w_bg, reinterpret_cast<const long long*>(idx),
