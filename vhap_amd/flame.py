@@ -72,6 +72,16 @@ class FlameHead(nn.Module):
         self.fused = True          # MFMA blend+skin kernels on a HIP device (False: host-side torch ops only)
         self._fb = None
 
+    @classmethod
+    def from_flame_pickle(cls, flame_model_path, flame_masks_path=None, shape_params=300, expr_params=100, add_teeth=True, **kw):
+        """The head from the licensed FLAME files, like the reference's FlameHead(shape_params, expr_params, flame_model_path, ...,
+        add_teeth=True) (flame.py:70-204; vhap_amd.flame_assets).  `.model` / `.topo` are what GlobalTracker takes."""
+        from .flame_assets import load_flame_model
+        model, topo = load_flame_model(flame_model_path, flame_masks_path, shape_params, expr_params, add_teeth, **kw)
+        head = cls(model, topo, shape_params, expr_params)
+        head.model = model
+        return head
+
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
         self.mask.to(self.v_template.device)

@@ -13,25 +13,6 @@ N_SHAPE, N_EXPR = 300, 100
 PARENTS = np.array([-1, 0, 1, 1, 1], np.int64)          # root, neck, jaw, eye_L, eye_R
 
 
-def _teeth_vertices(v, topo):
-    """Restates the geometric construction of FlameHead.add_teeth (flame.py:206-260)."""
-    up = v[topo.v_regions["lip_outside_ring_upper"]]
-    lo = v[topo.v_regions["lip_outside_ring_lower"]]
-    mean_dist = np.linalg.norm(up - lo, axis=-1).mean()
-    mid = (up + lo) / 2
-    mid[:, 1] = mid[:, 1].mean()
-    mid[:, 2] -= mean_dist * 1.5
-    ey = np.array([[0, mean_dist, 0]], np.float32)
-    ez = np.array([[0, 0, mean_dist]], np.float32)
-    upper_edge = mid + ey * 0.1
-    upper_root = upper_edge + ey * 2
-    lower_edge = mid - ey * 0.1 - ez * 0.4
-    lower_root = lower_edge - ey * 2
-    th = np.array([[0, 0, mean_dist * 1.0]], np.float32)
-    return np.concatenate([upper_root, lower_root, upper_edge, lower_edge,
-                           upper_root - th, upper_edge - th, lower_root - th, lower_edge - th], 0).astype(np.float32)
-
-
 def make_flame_model(seed=0, add_teeth=True, n_shape=N_SHAPE, n_expr=N_EXPR, topo=None):
     """Returns (model dict of numpy arrays, FlameTopology)."""
     rng = np.random.default_rng(seed)
@@ -84,23 +65,12 @@ def make_flame_model(seed=0, add_teeth=True, n_shape=N_SHAPE, n_expr=N_EXPR, top
             lbs_weights[idx] = 0
             lbs_weights[idx, j] = 1
 
-    if topo.has_teeth:                                                # flame.py:302-325
-        vt = _teeth_vertices(v, topo)
-        up, lo = topo.v_regions["lip_outside_ring_upper"], topo.v_regions["lip_outside_ring_lower"]
-        sd_mean = (shapedirs[up, :, :n_shape] + shapedirs[lo, :, :n_shape]) / 2        # [15,3,n_shape]
-        sd_t = np.zeros((120, 3, NB), np.float32)
-        for r in range(8):
-            sd_t[15 * r:15 * (r + 1), :, :n_shape] = sd_mean
-        shapedirs = np.concatenate([shapedirs, sd_t], 0)
-        pd = posedirs.reshape(4, 9, nv0, 3)
-        pd = np.concatenate([pd, np.zeros((4, 9, 120, 3), np.float32)], 2)
-        posedirs = pd.reshape(36, (nv0 + 120) * 3)
-        J_regressor = np.concatenate([J_regressor, np.zeros((5, 120), np.float32)], 1)
-        lw_t = np.zeros((120, 5), np.float32)
-        lw_t[topo.v_regions["teeth_upper"] - nv0, 1] = 1
-        lw_t[topo.v_regions["teeth_lower"] - nv0, 2] = 1
-        lbs_weights = np.concatenate([lbs_weights, lw_t], 0)
-        v = np.concatenate([v, vt], 0)
+    arrays = dict(v_template=v.astype(np.float32), shapedirs=shapedirs, posedirs=posedirs, J_regressor=J_regressor, lbs_weights=lbs_weights)
+    if topo.has_teeth:                                                # flame.py:206-325
+        from .flame_assets import append_teeth
+        arrays = append_teeth(arrays, topo, n_shape)
+    v, shapedirs, posedirs = arrays["v_template"], arrays["shapedirs"], arrays["posedirs"]
+    J_regressor, lbs_weights = arrays["J_regressor"], arrays["lbs_weights"]
 
     model = dict(
         v_template=v.astype(np.float32), shapedirs=shapedirs, posedirs=posedirs,

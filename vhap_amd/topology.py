@@ -77,10 +77,55 @@ def build_uniform_laplacian_csr(tri, V):
     return ptr, cols.astype(np.int32), vals.astype(np.float32)
 
 
-class FlameTopology:
-    """Faces / UVs / landmark embedding / region masks of the FLAME head, optionally with teeth."""
+FLAME_PART_NAMES = ("face", "neck", "scalp", "boundary", "right_eyeball", "left_eyeball", "right_ear", "left_ear", "forehead", "eye_region",
+                    "nose", "lips", "right_eye_region", "left_eye_region")      # the keys of FLAME_masks.pkl (flame.py:759-763)
 
-    def __init__(self, add_teeth=True, tex_clusters=TEX_CLUSTERS):
+
+def regions_from_flame_parts(part_masks, literal_masks, num_verts):
+    """The vertex regions FlameMask builds from FLAME's own part masks (FLAME_masks.pkl) -- flame.py:754-767 process_vertex_mask +
+    :769-938 create_custom_mask: the part masks as they are, the hand-picked index tables (`literal_masks`: the integer literals of
+    flame.py, shipped in the topology asset as vmask_*), and the derived regions -- hair = scalp minus its intersection with
+    face + neck, the unions (ears, eyeballs, irises, left_eye, right_eye, eyelids, lip_inside_ring), sclerae = eyeballs minus irises,
+    skin = everything but eyeballs, hair, lips_tight and boundary.  Unions are CONCATENATIONS like the reference's (an index listed
+    twice counts twice in the face test of FlameTopology._finalize, flame.py:947-955)."""
+    v = {k: np.asarray(m, np.int64).reshape(-1) for k, m in part_masks.items()}
+    for k, m in literal_masks.items():
+        v[k] = np.asarray(m, np.int64).reshape(-1)
+    cat = lambda *names: np.concatenate([v[n] for n in names])
+    face_and_neck = np.unique(cat("face", "neck"))
+    v["hair"] = np.setdiff1d(np.unique(v["scalp"]), face_and_neck)
+    v["ears"] = cat("right_ear", "left_ear")
+    v["eyeballs"] = cat("right_eyeball", "left_eyeball")
+    v["irises"] = cat("right_iris", "left_iris")
+    v["left_eye"] = cat("left_eye_region", "left_eyeball")
+    v["right_eye"] = cat("right_eye_region", "right_eyeball")
+    v["eyelids"] = cat("left_eyelid", "right_eyelid")
+    v["lip_inside_ring"] = np.concatenate([v["lip_inside_ring_upper"], v["lip_inside_ring_lower"], np.array([1594, 2730], np.int64)])
+    v["sclerae"] = np.setdiff1d(np.unique(v["eyeballs"]), np.unique(v["irises"]))
+    v["skin"] = np.setdiff1d(np.arange(num_verts, dtype=np.int64), np.unique(cat("eyeballs", "hair", "lips_tight", "boundary")))
+    return v
+
+
+def load_flame_masks(path):
+    """FLAME_masks.pkl (flame.py:40,757): a pickled dict part name -> vertex indices (latin1: it was written by Python 2)."""
+    import pickle
+    with open(path, "rb") as f:
+        d = pickle.load(f, encoding="latin1")
+    return {str(k): np.asarray(m, np.int64).reshape(-1) for k, m in d.items()}
+
+
+class FlameTopology:
+    """Faces / UVs / landmark embedding / region masks of the FLAME head, optionally with teeth.
+
+    `part_masks` = the dict of FLAME_masks.pkl (load_flame_masks): the vertex regions are then built the reference's way
+    (regions_from_flame_parts).  Without it (the licensed file is not redistributable) they are approximated by sampling the UV-space
+    region masks of asset/flame/uv_masks.npz at the vertex UVs (tools/make_assets.py)."""
+
+    @classmethod
+    def from_flame_masks(cls, masks_path, add_teeth=True, tex_clusters=TEX_CLUSTERS):
+        return cls(add_teeth=add_teeth, tex_clusters=tex_clusters, part_masks=load_flame_masks(masks_path))
+
+    def __init__(self, add_teeth=True, tex_clusters=TEX_CLUSTERS, part_masks=None):
         d = np.load(ASSET, allow_pickle=False)
         self.v_template_obj = d["v_template"].astype(np.float32)          # [5023,3] (un-centred obj verts)
         self.verts_uvs = d["verts_uvs"].astype(np.float32)                # [5118,2]
@@ -90,12 +135,17 @@ class FlameTopology:
         self.lmk_bary_coords = d["lmk_bary_coords"].astype(np.float32)    # [70,3]
         self.num_verts_orig = self.v_template_obj.shape[0]
         self.num_faces_orig = self.faces.shape[0]
-        names = [str(x) for x in d["region_names"]]
-        bits = np.unpackbits(d["v_region"], axis=1)[:, :len(names)].astype(bool)
-        self.v_regions = {n: np.nonzero(bits[:, i])[0] for i, n in enumerate(names)}
-        for k in d.files:                                                 # literal masks of the reference win
-            if k.startswith("vmask_"):
-                self.v_regions[k[6:]] = d[k].astype(np.int64)
+        literal = {k[6:]: d[k].astype(np.int64) for k in d.files if k.startswith("vmask_")}
+        if part_masks is not None:
+            missing = [k for k in FLAME_PART_NAMES if k not in part_masks]
+            if missing:
+                raise ValueError(f"FLAME part masks lack {missing}")
+            self.v_regions = regions_from_flame_parts(part_masks, literal, self.num_verts_orig)
+        else:
+            names = [str(x) for x in d["region_names"]]
+            bits = np.unpackbits(d["v_region"], axis=1)[:, :len(names)].astype(bool)
+            self.v_regions = {n: np.nonzero(bits[:, i])[0] for i, n in enumerate(names)}
+            self.v_regions.update(literal)                                # literal masks of the reference win
         T = int(d["uvmask_size"])
         self.uvmasks = {k: np.unpackbits(d[f"uvmask_{k}"])[: T * T].reshape(T, T).astype(bool)
                         for k in ("sclerae", "teeth")}
@@ -128,12 +178,12 @@ class FlameTopology:
         self.num_verts = self.num_verts_orig + (120 if self.has_teeth else 0)
         self.num_faces = self.faces.shape[0]
         V, F = self.num_verts, self.num_faces
-        # face regions: a face is in a region iff all 3 of its vertices are (flame.py:947-955)
+        # face regions (flame.py:940-955): every corner adds one count per LISTING of its vertex in the region, a face is in the region
+        # at 3 counts -- for a duplicate-free list: iff all 3 of its vertices are; the reference's concatenated unions may list a vertex twice
         self.f_regions = {}
         for name, vid in self.v_regions.items():
-            m = np.zeros(V, bool)
-            m[vid[vid < V]] = True
-            fid = np.nonzero(m[self.faces].all(1))[0]
+            mult = np.bincount(vid[vid < V], minlength=V)
+            fid = np.nonzero(mult[self.faces].sum(1) >= 3)[0]
             if fid.size:
                 self.f_regions[name] = fid
         # fid2cid (flame.py:965-984): 1 = no cluster, cluster k -> k+2, later clusters overwrite;
