@@ -14,10 +14,14 @@ new shuffled batch every step in the reference, tracker.py:1376-1385).  Workload
 N > 1, --scaling weak (default): every rank fits its own batch of the same size (global batch x N); --scaling strong: the batch (frames or
 views) is split B/N per rank.  The shared-parameter gradients are averaged over RCCL each step (vhap_amd.dist).
 Prints ONE JSON line on rank 0.  `roofline`: the fused rasterize+interpolate pass (bin_build + raster kernel behind
-vhap_raster_interp_fwd), algorithmic bytes / duration, with the duration measured three ways -- `frac` = inside the step (HIP event-record
-nodes in an instrumented capture of the same step, or HIP events around the pass in eagerly issued native steps if the runtime refuses
-event nodes), `frac_isolated` = a hipGraph of 20 back-to-back passes.  `cpu_baseline`: the CPU oracle restatement of the SAME step (one
-whole batch: forward + backward + Adam, colour disturbance on) on the host cores, rank 0, N = 1 only.
+vhap_raster_interp_fwd), algorithmic bytes / duration.  Durations are measured live with HIP events: the captured step is replayed by the
+library's plan executor (csrc/plan.hip: plain kernel launches on the plan's own streams), which can bracket any node with a pair of timing
+events on the stream the node runs on (vhap_plan_launch_timed) -- `frac` = inside replays of the step on the separate passes
+(VHAP_DEFERRED=0, whose raster kernel IS the RI-fwd op), `frac_in_step_deferred` = the step as shipped (raster_kernel<2> does three more
+kernels' work), `frac_isolated` = 20 back-to-back passes alone on the chip.  `stage_fps`: the same stage END TO END over a resident
+sequence -- GlobalTracker.optimize_stage over shuffled batches of a uint8 FrameStore (ingest, batch hand-over, learning-rate schedule
+included) -- next to the replay number.  `cpu_baseline`: the CPU oracle restatement of the SAME step (one whole batch: forward +
+backward + Adam, colour disturbance on) on the host cores, rank 0, N = 1 only: median of 3 timed steps after one warm-up.
 """
 import argparse
 import json
@@ -117,9 +121,10 @@ def pmc_traffic():
         return None, None
 
 
-def cpu_baseline(C, tr, sample, model, topo, budget_s=30.0):
+def cpu_baseline(C, tr, sample, model, topo, n_timed=3, budget_s=100.0):
     """The CPU oracle restatement (torch-CPU fp32 + C rasteriser) of the SAME step: ONE whole batch of the quoted configuration --
-    forward with the colour disturbance on, backward to every parameter, torch.optim.Adam -- repeated while the budget lasts."""
+    forward with the colour disturbance on, backward to every parameter, torch.optim.Adam: one warm-up step, then the median of
+    `n_timed` steps (fewer if the budget runs out: a step is ~15 s on 16 cores)."""
     from oracle import energy_ref, fit_ref
     H, W = C["H"], C["W"]
     cores = min(os.cpu_count() or 1, 16)                       # more threads only add contention for this op mix
@@ -142,8 +147,10 @@ def cpu_baseline(C, tr, sample, model, topo, budget_s=30.0):
     opt = fit_ref.configure_optimizer(P, cfg, STAGE, lr_scale=0.1, calibrated=tr.calibrated)
     ncl = int(topo.fid2cid.max()) + 1
     gen = torch.Generator().manual_seed(0)
-    n_steps, t0 = 0, time.time()
-    while True:
+    times = []
+    t_start = time.time()
+    for k in range(1 + n_timed):                                 # one warm-up step (page faults, thread pools, torch's kernel selection), then the timed ones
+        t0 = time.time()
         disturb = dict(w_fg=(torch.rand(nb, H, W, 1, generator=gen) < (cfg.render.disturb_rate_fg or 0)).int(),
                        w_bg=(torch.rand(nb, H, W, 1, generator=gen) < (cfg.render.disturb_rate_bg or 0)).int(),
                        idx=[torch.randint(0, 2 ** 31 - 1, (nb * H * W,), generator=gen)] * ncl,
@@ -152,46 +159,84 @@ def cpu_baseline(C, tr, sample, model, topo, budget_s=30.0):
         opt.zero_grad()
         E.backward()
         opt.step()
-        n_steps += 1
-        if time.time() - t0 > budget_s * 0.5:
+        if k > 0:
+            times.append(time.time() - t0)
+        if time.time() - t_start > budget_s and times:
             break
-    dtm = time.time() - t0
-    return {"value": n_steps * nb / dtm, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{n_steps} whole step(s) of the quoted configuration ({nb}-frame batch, {H}x{W}, T={TEX}, stage {STAGE}: forward "
-                      f"with colour disturbance + backward + Adam, TV / mip pyramid cost included) of the CPU oracle restatement "
-                      f"(torch-CPU fp32 + C rasteriser, {cores} threads) in {dtm:.1f} s"}
+    med = float(np.median(times))
+    return {"value": nb / med, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"median of {len(times)} timed whole steps after 1 warm-up ({', '.join(f'{t:.1f}' for t in times)} s) of the quoted "
+                      f"configuration ({nb}-frame batch, {H}x{W}, T={TEX}, stage {STAGE}: forward with colour disturbance + backward + Adam, "
+                      f"TV / mip pyramid cost included) of the CPU oracle restatement (torch-CPU fp32 + C rasteriser, {cores} threads)"}
 
 
-def time_ri_in_step(tr, sample, optimizer, deferred, n=12):
-    """Duration of the G-buffer pass INSIDE replays of the captured step, from wall-clock stamps the binning and raster kernels write
-    themselves (VHAP_RASTER_PROFILE: first wave start / last wave end of each kernel, 100 MHz counter) -- HIP refuses to read event-record
-    nodes of a captured graph (hipErrorCapturedEvent) and a profiler is not attached here; the rocprofv3 kernel trace of the same replays
-    (profiles/) is the cross-check.  Returns (binning s, raster kernel s), medians over n replays of an instrumented capture.
-    deferred=True: the step as shipped (raster kernel mode 2: rasterise + interpolate + texture + shade + composite);
+def time_ri_in_step(tr, sample, optimizer, deferred, n=9):
+    """Duration of the G-buffer pass INSIDE replays of the captured step: HIP events the plan executor records around the binning and
+    the raster node, on the stream each runs on (vhap_plan_launch_timed).  Returns (binning s, raster kernel s), medians over n timed
+    replays.  deferred=True: the step as shipped (raster kernel mode 2: rasterise + interpolate + texture + shade + composite);
     deferred=False: the step on the separate passes (VHAP_DEFERRED=0), whose raster kernel is exactly the RI-fwd op (mode 1)."""
     from vhap_amd.tracker import GraphedStep
-    keep = {k: os.environ.get(k) for k in ("VHAP_RASTER_PROFILE", "VHAP_DEFERRED")}
-    os.environ["VHAP_RASTER_PROFILE"] = "1"
+    keep = os.environ.get("VHAP_DEFERRED")
     os.environ["VHAP_DEFERRED"] = "1" if deferred else "0"
     try:
         st = GraphedStep(tr, sample, optimizer, STAGE)
-        assert st.ns is not None and st.ns.raster_profile and st.ns.deferred == deferred
-        for _ in range(3):
-            st()
-        bins, rasts = [], []
-        for _ in range(n):
-            st()
-            b_us, r_us = st.ns.raster_profile_us()
-            bins.append(b_us)
-            rasts.append(r_us)
+        assert st.ns is not None and st.ns.deferred == deferred and st.gF.plan is not None
+        with st.replay_stream():
+            for _ in range(3):
+                st()
+            bins, rasts = [], []
+            for _ in range(n):
+                rec = st.gF.timed()
+                st.tr.global_step += 1
+                b = [d for nm, _, d in rec if "bin_build" in nm]
+                r = [d for nm, _, d in rec if "raster_kernel" in nm]
+                assert len(b) == 1 and len(r) == 1, [nm for nm, _, _ in rec]
+                bins.append(b[0])
+                rasts.append(r[0])
         del st
         return float(np.median(bins)) * 1e-6, float(np.median(rasts)) * 1e-6
     finally:
-        for k, v in keep.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+        if keep is None:
+            os.environ.pop("VHAP_DEFERRED", None)
+        else:
+            os.environ["VHAP_DEFERRED"] = keep
+
+
+def stage_fps(C, tr_ref, model, topo, gt, n_frames=64, epochs=3):
+    """The stage END TO END (tracker.py:1376-1416): GlobalTracker.optimize_stage('rgb_global_tracking') over shuffled batches of a
+    sequence resident in HBM as uint8 (ingest.FrameStore) -- a new batch every step (vhap_frame_ingest into the captured step's static
+    buffers + the landmark / index copies), the ExponentialLR schedule, the host loop -- not replays of one resident batch.  The
+    sequence is the bench batch repeated (its content does not matter to the step's cost).  Returns (frames/s, steps timed)."""
+    from vhap_amd.ingest import FrameStore
+    from vhap_amd.tracker import GlobalTracker, ShuffledBatches
+    B = C["B"]
+    reps = (n_frames + B - 1) // B
+    rgb = tr_ref.dataset["rgb"][:B]
+    u8 = (rgb.permute(0, 2, 3, 1).clamp(0, 1) * 255).round().to(torch.uint8).repeat(reps, 1, 1, 1)[:n_frames].contiguous()
+    data = {"frames": FrameStore(u8, device=tr_ref.device), "lmk2d": tr_ref.dataset["lmk2d"][:B].repeat(reps, 1, 1)[:n_frames].contiguous()}
+    cfg = tr_ref.cfg
+    tr = GlobalTracker(cfg, model, topo, tr_ref.flame_tex_painted()[0].cpu().numpy(), data)
+    with torch.no_grad():
+        for name in ("shape", "lights", "tex_extra", "static_offset", "focal_length"):
+            getattr(tr, name).copy_(getattr(tr_ref, name))
+        for name in ("expr", "rotation", "neck_pose", "jaw_pose", "eyes_pose", "translation"):
+            p, q = getattr(tr, name), getattr(tr_ref, name)[:B]
+            p.copy_(q.repeat(reps, *([1] * (q.dim() - 1)))[:n_frames])
+    loader = ShuffledBatches(tr, B, device_index=True, generator=torch.Generator().manual_seed(0))
+    keep = cfg.pipeline[STAGE].num_epochs
+    try:
+        cfg.pipeline[STAGE].num_epochs = 1                       # capture + warm-up pass
+        tr.optimize_stage(STAGE, dataloader=loader, lr_scale=0.1)
+        torch.cuda.synchronize()
+        cfg.pipeline[STAGE].num_epochs = epochs
+        t0 = time.perf_counter()
+        tr.optimize_stage(STAGE, dataloader=loader, lr_scale=0.1)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    finally:
+        cfg.pipeline[STAGE].num_epochs = keep
+    steps = epochs * len(loader)
+    return n_frames * epochs / dt, steps
 
 
 def time_ri_isolated(tr, sample, C, stream):
@@ -211,8 +256,9 @@ def time_ri_isolated(tr, sample, C, stream):
             for _ in range(3):                                  # warm-up (workspace for this stream, code objects)
                 ops.raster_interp_fwd(tr.render.glctx, pos, tri, vn, tr._verts_uv_flipped, tri_uv, (H, W))
         torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=stream):
+        from vhap_amd.tracker import CapturedPlan
+        g = CapturedPlan()
+        with g.capture(stream=stream):
             for _ in range(NREP):
                 ops.raster_interp_fwd(tr.render.glctx, pos, tri, vn, tr._verts_uv_flipped, tri_uv, (H, W))
         ms = []
@@ -241,6 +287,7 @@ def main():
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo for single-GPU tests of the multi-rank path)")
     ap.add_argument("--unroll", type=int, default=1, help="steps per graph launch on one GPU (1 = what the stage really does)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stage", action="store_true", help="skip the end-to-end stage measurement (stage_fps)")
     ap.add_argument("--eager", action="store_true", help="run optimize_iter eagerly instead of replaying the captured hipGraphs")
     args = ap.parse_args()
     if os.environ.get("VHAP_DEBUG"):                            # profiling-only A/B switches of the library (tools/ab_env.sh)
@@ -258,8 +305,14 @@ def main():
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
     tr, own, n_local, model, topo, gt = build_tracker(C, rank, world, device, args.scaling)
+    n_ranks_seen = 1
     if world > 1:
         vdist.attach(tr)
+        # every rank contributes a one: the sum is the number of ranks the collective library really connected (the driver checks it
+        # against --gpus)
+        ones = torch.ones(1, device=device if torch.distributed.get_backend() == "nccl" else "cpu")
+        torch.distributed.all_reduce(ones)
+        n_ranks_seen = int(ones.item())
     optimizer = tr.configure_optimizer(tr.get_train_parameters(STAGE), lr_scale=0.1)
     sample = tr.get_sample(own, device_index=True)
     assert sample["rgb"].shape[0] == n_local
@@ -316,15 +369,25 @@ def main():
                 print(f"[bench] in-step instrumentation failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
         ri_step = sum(sep) if sep else ri_iso
         traffic, traffic_src = pmc_traffic() if args.config == 2 and n_local == 16 else (None, None)
+        stage = None
+        if world == 1 and not args.no_stage and C["kind"] == "monocular":
+            try:
+                stage = stage_fps(C, tr, model, topo, gt)
+            except Exception as e:                               # noqa: BLE001 -- must never sink the throughput number
+                print(f"[bench] stage_fps failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
         out = {
             "metric": "frames/sec photometric-fit (512x512, batch=16)" if args.config == 2 else f"frames/sec photometric-fit ({H}x{W}, batch={C['B']})",
             "value": n_local * world * args.steps / dt,
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic", "timed_region_s": dt, "n_ranks_seen": n_ranks_seen,
+            "stage_fps": ({"value": stage[0], "unit": "frames/s", "steps": stage[1],
+                           "what": "GlobalTracker.optimize_stage('rgb_global_tracking') end to end over shuffled batches of a 64-frame sequence "
+                                   "resident as uint8 (vhap_frame_ingest into the captured step's buffers, landmark / index hand-over, "
+                                   "ExponentialLR, host loop): a NEW batch every step, like tracker.py:1376-1385"} if stage else None),
             "config": {"workload": f"BASELINE config {args.config}: {C['name']}; stage rgb_global_tracking (photometric + landmark + TV + all "
                                    "regularisers, colour disturbance on), FLAME topology V=5143 F=10144, texture 2048x2048, fwd+bwd+Adam, "
-                                   "one step per graph launch",
+                                   "one step per replay of the captured plan",
                        "global_batch": n_local * world, "frames_per_gpu": n_local,
                        "parallelism": f"dp{world} {args.scaling} (frame-sharded; per step one scalar all-reduce + two gradient all-reduces over "
                                       f"{'RCCL' if world > 1 and torch.distributed.get_backend() == 'nccl' else 'the process group'})",
@@ -339,12 +402,14 @@ def main():
                          "us_in_step_deferred": {"bin_build": fused[0] * 1e6, "raster_kernel<2>": fused[1] * 1e6} if fused else None,
                          "kernel": "RI-fwd = rasterize + both interpolations (vhap_raster_interp_fwd: bin_build_kernel + raster_kernel<1>), "
                                    "292 MB of algorithmic traffic per 16 x 512^2 batch (SURVEY 8(d)).  frac / us_per_launch / frac_in_step: that pass "
-                                   "INSIDE replays of the captured step on the separate passes (VHAP_DEFERRED=0), timed by wall-clock stamps the two "
-                                   "kernels write themselves (sum of the two kernel durations = what a rocprofv3 kernel trace of the replays shows).  "
-                                   "frac_in_step_deferred: the step AS SHIPPED replaces the pass by bin_build + raster_kernel<2>, which also samples the "
-                                   "texture, shades and composites (3 more kernels of the reference pipeline) and writes 33 instead of 68 B/px -- "
-                                   "reported against the same fixed 292 MB.  frac_isolated: a hipGraph of 20 back-to-back RI-fwd passes on the "
-                                   "step's geometry, replayed 5x, HIP events.",
+                                   "INSIDE replays of the captured step on the separate passes (VHAP_DEFERRED=0): HIP events recorded by the plan "
+                                   "executor around the two kernel nodes, on the stream they run on (median of 9 replays; sum of the two kernel "
+                                   "durations = what a rocprofv3 kernel trace of the replays shows).  frac_in_step_deferred: the step AS SHIPPED "
+                                   "replaces the pass by bin_build + raster_kernel<2>, which also samples the texture, shades and composites (3 more "
+                                   "kernels of the reference pipeline) and writes 33 instead of 68 B/px -- reported against the same fixed 292 MB.  "
+                                   "frac_isolated: 20 back-to-back RI-fwd passes on the step's geometry, replayed 5x, HIP events around the 20.  "
+                                   "traffic: PMC bytes of the newest committed measurement of the same launch sequence (a file under profiles/, "
+                                   "not observed by this run).",
                          "alg_bytes_per_launch": alg},
         }
         if world == 1 and not args.no_cpu_baseline:

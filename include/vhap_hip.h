@@ -555,13 +555,16 @@ int vhap_tex_prep_bwd(const float* albedo_hwc, const float* extra, const uint8_t
                       const float* d_albedo_hwc, const float* d_mips_hwc, int n_gather, const float* d_terms,
                       int T, float s_tv, float s_res, float* d_extra, vhap_stream_t stream);
 /* vhap_tex_prep_bwd fused with the torch.optim.Adam update of `extra` (one tensor of a vhap_adam_step call issued in pieces: it reads the
- * step counter but does not advance it -- VHAP_CALL_ADAM_KEEP_STEP semantics; lr_device points at THIS tensor's learning rate): the
- * gradient d_extra is still written, but never read back, and the separate update pass over the texture disappears. */
+ * step counter but does not advance it -- VHAP_CALL_ADAM_KEEP_STEP semantics, or, with VHAP_CALL_ADAM_STEP_ADVANCED in call_flags, the
+ * counter was advanced for this step already; lr_device points at THIS tensor's learning rate): the gradient d_extra is still written,
+ * but never read back, and the separate update pass over the texture disappears.  With n_gather = every level of the pyramid
+ * (vhap_texture_num_levels) the fold cascade (vhap_texture_mip_fold) disappears as well: ONE pass over the texture turns the gradient
+ * pyramid the sampling backward accumulated into the updated parameter. */
 int vhap_tex_prep_bwd_adam(const float* albedo_hwc, float* extra, const uint8_t* res_mask,
                            const float* d_albedo_hwc, const float* d_mips_hwc, int n_gather, const float* d_terms,
                            int T, float s_tv, float s_res, float* d_extra, float* exp_avg, float* exp_avg_sq,
                            const float* lr_device, const int32_t* step_device, float beta1, float beta2, float eps,
-                           vhap_stream_t stream);
+                           int call_flags, vhap_stream_t stream);
 int vhap_adam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                    float* const* exp_avg_sq, const int64_t* numel, const int32_t* lr_index,
                    const float* lr_device, int32_t* step_device, float beta1, float beta2, float eps,

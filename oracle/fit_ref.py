@@ -86,6 +86,8 @@ def optimize_iter(P, optimizer, model, topo, cfg, sample, stage, tex_painted, uv
     optimizer.step()
     out = {k: float(v.detach()) for k, v in log.items()}
     out["total"] = float(E.detach())
+    if "diffuse_detach_normal" in extras:             # reg_diffuse = w (relu(max - 1) + ...) has a kink at max = 1: tests keep away from it
+        out["diffuse_max"] = float(extras["diffuse_detach_normal"].detach().max())
     return out
 
 

@@ -39,9 +39,16 @@ def _worker(rank, world, port, ret):
     ctx.average_gradients([shared, per_frame])
     Es = torch.tensor([float(E)])
     dist.all_reduce(Es)
-    ret[rank] = (shared.grad.clone(), per_frame.grad.clone(), float(Es) / world)
-    with pytest.raises(ValueError):
-        ctx.shard_sample({"rgb": torch.rand(7, 3), "timestep_index": np.arange(7)})
+    out = [shared.grad.clone(), per_frame.grad.clone(), float(Es) / world]
+    # a ragged batch (7 frames over 2 ranks) is not split: every rank fits the whole of it, and the averaged result is the single-process one
+    shared.grad = per_frame.grad = None
+    rag = {"rgb": sample["rgb"][:7], "timestep_index": np.arange(7)}
+    local = ctx.shard_sample(rag)
+    assert len(local["timestep_index"]) == 7
+    E = _energy((shared, per_frame), local, normaliser=ctx.all_reduce_sum, world=world)
+    E.backward()
+    ctx.average_gradients([shared, per_frame])
+    ret[rank] = tuple(out) + (shared.grad.clone(), per_frame.grad.clone(), float(E))
     dist.destroy_process_group()
 
 
@@ -60,11 +67,16 @@ def test_two_rank_sharded_step_matches_single_process():
     sample = {"rgb": torch.rand(8, 3, generator=g), "timestep_index": np.arange(8)}
     E = _energy((shared, per_frame), sample)
     E.backward()
+    g_shared, g_frame = shared.grad.clone(), per_frame.grad.clone()
+    shared.grad = per_frame.grad = None
+    E7 = _energy((shared, per_frame), {"rgb": sample["rgb"][:7], "timestep_index": np.arange(7)})
+    E7.backward()
     for r in range(world):
-        gs, gp, Er = ret[r]
-        assert torch.allclose(gs, shared.grad, atol=1e-6)
-        assert torch.allclose(gp, per_frame.grad, atol=1e-6)
+        gs, gp, Er, gs7, gp7, Er7 = ret[r]
+        assert torch.allclose(gs, g_shared, atol=1e-6)
+        assert torch.allclose(gp, g_frame, atol=1e-6)
         assert abs(Er - float(E)) < 1e-5
+        assert torch.allclose(gs7, shared.grad, atol=1e-6) and torch.allclose(gp7, per_frame.grad, atol=1e-6) and abs(Er7 - float(E7)) < 1e-5
     assert torch.equal(ret[0][0], ret[1][0])                       # replicas see bit-identical gradients
 
 

@@ -83,11 +83,11 @@ def _step(tr, frames, stage="rgb_global_tracking", shard=None):
     E = float(st())
     torch.cuda.synchronize()
     return E, {k: getattr(tr, k).grad.detach().cpu().clone() for k in NAMES if hasattr(tr, k) and getattr(tr, k).grad is not None}, \
-        bool(st.ns.tex_l0_skip)
+        st.gF.describe()
 
 
-def _worker(rank, world, port, T, ret, schedule):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), VHAP_SHARD_SCHEDULE=schedule)
+def _worker(rank, world, port, T, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from vhap_amd import dist as vdist
     tr = _build(T)
@@ -96,17 +96,16 @@ def _worker(rank, world, port, T, ret, schedule):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("T,schedule", [(128, "parallel"), (128, "serial")])
-def test_two_rank_native_step_matches_single_process(T, schedule):
-    """Sharded, captured step == the single-process step on the whole batch, for both schedules: 'parallel' (forward graph / pixel-chain
-    graph / texture-gradient graph + its all-reduce on a second stream next to the geometry graph / small-gradient all-reduce / Adam graph)
-    and 'serial' (texture graph / asynchronous all-reduce / geometry graph underneath it)."""
+@pytest.mark.parametrize("T", [128])
+def test_two_rank_native_step_matches_single_process(T):
+    """Sharded, captured step == the single-process step on the whole batch: forward plan / all-reduce of the pixel count / pixel + texture
+    plan / asynchronous all-reduce of the texture gradient / geometry plan underneath it / small-gradient all-reduce / Adam plan."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ret = mp.Manager().dict()
-    mp.spawn(_worker, args=(2, port, T, ret, schedule), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, T, ret), nprocs=2, join=True)
     E1, g1, _ = _step(_build(T), [0, 1, 2, 3])
     Em = 0.5 * (ret[0][0] + ret[1][0])
     assert abs(Em - E1) <= 2e-4 * abs(E1), (Em, E1)
@@ -167,7 +166,7 @@ def test_bench_multi_rank_path_runs_under_torchrun_with_gloo():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--backend", "gloo",
            "--scaling", "strong", "--no-cpu-baseline"]
-    env = {k: v for k, v in os.environ.items() if k != "VHAP_LAUNCH_PRIO"}      # fresh processes, the shipped default (tests/conftest.py)
+    env = dict(os.environ)
     r = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

@@ -13,7 +13,7 @@ Stated tolerances (fp32 product vs fp64 oracle):
       array to 1e-3 in relative L2 AND in max-norm -- except static_offset's max-norm, 5e-3: its entries are ~1e-3 in size
       and move by lr = 5e-5 per step, and Adam's g / (|g| + eps) makes the step of an entry whose gradient sits inside the fp32-atomics
       noise a full +-lr step of either sign (measured 1.8e-3 max-norm, 1.3e-4 L2) -- and the parameter UPDATE (export - start) to 2e-2 in
-      L2 (measured <= 2e-4); the energies along the trajectory to 5e-4 (measured <= 1e-6, once 7.4e-5: see the noise floor below).  At the FULL learning rates (rgb_init_offset,
+      L2 (measured <= 2e-4); the energies along the trajectory to 5e-4 (measured <= 1e-6).  At the FULL learning rates (rgb_init_offset,
       lr_scale 1: static_offset moves by more than its own size in 10 steps) the same effect is 10x larger on the two element-wise
       arrays -- static_offset: L2 1e-2 / max-norm 1e-1 (measured 4.6e-3 / 5.2e-2), tex_extra: max-norm 2e-2 (measured 6.9e-3); everything
       else stays below 1e-4.  For scale: the ORACLE ITSELF evaluated in fp32 instead of fp64 lands 7e-2 (L2) away from its fp64 run on
@@ -23,15 +23,17 @@ Stated tolerances (fp32 product vs fp64 oracle):
   g / (|g| + eps) turns a gradient whose sign is inside that noise into a full-size step of either sign, so element-wise agreement of
   noise-level entries is not a meaningful target): every exported array to 1e-3 in relative L2 (static_offset at the full learning rates:
   1e-2), energies along the trajectory to 5e-3 (measured <= 2.2e-5).
-  the noise floor of the trajectory: the sums behind every gradient are float atomics in arbitrary order, so two RUNS of the HIP path
-  differ in the last bits of a gradient -- and through Adam's g / (|g| + eps) a component whose gradient is inside that noise takes a
-  full +-lr step of either sign.  Seen once on `lights` (27 entries, several SH bands with near-zero gradients) at the full learning
-  rates: update L2 3.4e-2 / max-norm 1.0e-3 instead of the usual 4e-5 / 1.5e-6, i.e. exactly the distance at which the oracle's own
-  fp32 run lands from its fp64 run (3.9e-2 / 1.0e-3, SPREAD below).  A bound tighter than what two correct fp32 evaluations of the same
-  trajectory differ by cannot be held: every per-array bound is therefore the tight one stated above OR twice the measured fp32-vs-fp64
-  spread of the oracle's own trajectory for that array and stage, whichever is larger.  Systematic errors stay visible: the energies
-  along the trajectory are held to 5e-4 (a wrong gradient moves them at once), and the step-0 gradients themselves are compared tightly in
-  the test above and in tests/test_energy_gpu.py.
+  the kinks of the energy: round 2 saw one run in five of the full-learning-rate trajectory end with `lights` 3.4e-2 (update L2) from the
+  oracle instead of 4e-5, and widened every bound to twice the oracle's own fp32-vs-fp64 spread.  Round 3 hunted it down
+  (tools/fit_flake_hunt.py, profiles/r03_fit_flake_hunt_*.txt: 60 runs x 2 executors, per-step gradients against the oracle at each
+  run's OWN parameters, eager re-evaluation of every suspicious step): no race -- the captured and the eagerly issued step give the same
+  gradient at the same parameters to 1e-7 -- but a KINK: reg_diffuse = w (relu(max(diffuse) - 1) + ...) (tracker.py:547-550) pulls the
+  brightest pixel's diffuse value down to exactly 1, where the gradient w.r.t. `lights` jumps by w d(diffuse)/d(lights) -- 97 % of its
+  max-norm in that run; with the synthetic scene's uniform light (diffuse == 1 everywhere at the start) the fit sits on the kink after
+  six steps, and summation-order noise in the last bit of max(diffuse) decides the side.  The reference has the same kink (and fp32
+  torch the same noise).  These trajectory tests therefore start from lights scaled by 1.25 (the relu stays active, its gradient path is
+  exercised, max(diffuse) stays > 1.15 for the 10 steps: asserted) -- and hold every array to the tight bounds above with no escape
+  hatch; what happens ON the kink is in the committed record.
 The measured values are written to gpurun_out/fit_parity_*.txt for the record."""
 import os
 
@@ -46,20 +48,6 @@ pytestmark = pytest.mark.gpu
 NAMES = ("shape", "expr", "rotation", "neck_pose", "jaw_pose", "eyes_pose", "translation", "tex_extra", "lights", "static_offset",
          "focal_length")
 
-# fp32-vs-fp64 spread of the ORACLE'S OWN 10-step trajectory (tools/fit_fp32_spread.py -> profiles/r02_fit_fp32_spread.txt):
-# array -> (max-norm rel, L2 rel, update L2 rel)
-SPREAD = {
-    "rgb_init_offset": {"shape": (3.32e-3, 1.67e-3, 1.82e-2), "expr": (2.63e-2, 1.39e-2, 2.23e-2), "rotation": (2.55e-3, 2.47e-3, 1.14e-2),
-                        "neck_pose": (1.23e-2, 8.16e-3, 1.24e-2), "jaw_pose": (6.37e-3, 5.36e-3, 1.59e-2), "eyes_pose": (3.01e-2, 2.28e-2, 4.30e-2),
-                        "translation": (3.98e-4, 2.55e-4, 1.48e-2), "tex_extra": (1.56e-2, 1.95e-3, 8.11e-4), "lights": (9.95e-4, 1.10e-3, 3.85e-2),
-                        "static_offset": (1.44e-1, 7.23e-2, 3.56e-2), "focal_length": (4.72e-6, 4.72e-6, 1.57e-4)},
-    "rgb_global_tracking": {"shape": (5.42e-4, 2.21e-4, 1.52e-2), "expr": (8.56e-3, 3.52e-3, 2.30e-2), "rotation": (1.55e-4, 9.95e-5, 1.72e-3),
-                            "neck_pose": (2.79e-3, 1.73e-3, 7.17e-3), "jaw_pose": (2.84e-4, 2.13e-4, 3.50e-3), "eyes_pose": (8.95e-4, 5.76e-4, 5.24e-3),
-                            "translation": (1.61e-4, 1.05e-4, 3.33e-2), "tex_extra": (1.80e-3, 6.66e-5, 3.72e-4), "lights": (2.01e-4, 2.40e-4, 6.28e-2),
-                            "static_offset": (3.43e-2, 4.80e-3, 7.70e-3), "focal_length": (2.02e-6, 2.02e-6, 6.09e-4)},
-}
-
-
 def _record(name, lines):
     try:
         os.makedirs("gpurun_out", exist_ok=True)
@@ -69,7 +57,7 @@ def _record(name, lines):
         pass
 
 
-def _make(flame_model, H, W, N, T, seed):
+def _make(flame_model, H, W, N, T, seed, lights_scale=1.0):
     from vhap_amd.config import BaseTrackingConfig
     from vhap_amd.flame import FlameHead
     from vhap_amd.render_hip import HipDiffRenderer
@@ -92,6 +80,7 @@ def _make(flame_model, H, W, N, T, seed):
             p.add_((torch.randn(p.shape, generator=g) * s).cuda())
         tr.translation[:, 2] += 0.45
         tr.jaw_pose[:, 0] += 0.1
+        tr.lights.mul_(lights_scale)
     tm = {k: torch.from_numpy(np.asarray(v)) for k, v in model.items()}
     for k in ("v_template", "shapedirs", "posedirs", "J_regressor", "lbs_weights", "lmk_bary_coords", "verts_uvs"):
         tm[k] = tm[k].double()
@@ -102,7 +91,7 @@ def _oracle_params(tr):
     return {k: getattr(tr, k).detach().cpu().double().requires_grad_() for k in NAMES}
 
 
-def _compare_grads(P, grads, lines, tag, rel_bound, cos_bound):
+def _compare_grads(P, grads, lines, tag, rel_bound, cos_bound, fails=None):
     worst = 0.0
     for k, po in P.items():
         gp = grads.get(k)
@@ -113,6 +102,8 @@ def _compare_grads(P, grads, lines, tag, rel_bound, cos_bound):
         cos = float((a @ b) / (a.norm() * b.norm() + 1e-300))
         worst = max(worst, rel)
         lines.append(f"{tag} grad {k}: rel {rel:.2e} cos {cos:.7f}")
+        if fails is not None and cos < cos_bound:
+            fails.append(f"{tag} grad {k}: cosine {cos:.7f}")
     return worst
 
 
@@ -202,7 +193,7 @@ def _trajectory(S, stage, lr_scale, K, H, W, ts, same_visibility):
     opt = tr.configure_optimizer(tr.get_train_parameters(stage), lr_scale=lr_scale)
     opt_o = fit_ref.configure_optimizer(P, cfg, stage, lr_scale=lr_scale)
     assert [g["lr"] for g in opt.param_groups] == [g["lr"] for g in opt_o.param_groups]
-    E_hip, E_ora = [], []
+    E_hip, E_ora, dmax = [], [], []
     if same_visibility:
         # the same call sequence as the captured step, issued eagerly so that each step's triangle ids can be handed to the oracle
         ns = NativeStep(tr, sample, stage)
@@ -212,25 +203,29 @@ def _trajectory(S, stage, lr_scale, K, H, W, ts, same_visibility):
             tid = (ns.rast[..., 3].long() - 1).cpu()
             E_hip.append(float(ns.log[15]))
             opt.step()
-            E_ora.append(fit_ref.optimize_iter(P, opt_o, tm, topo, cfg, o_sample, stage, S["base_tex"], uvmask, (H, W), tid=tid)["total"])
+            o = fit_ref.optimize_iter(P, opt_o, tm, topo, cfg, o_sample, stage, S["base_tex"], uvmask, (H, W), tid=tid)
+            E_ora.append(o["total"])
+            dmax.append(o.get("diffuse_max"))
     else:
         st = GraphedStep(tr, sample, opt, stage, warmup=0)
         assert st.ns is not None, "the captured step must be the native call sequence"
         for _ in range(K):
             E_hip.append(float(st()))
-            E_ora.append(fit_ref.optimize_iter(P, opt_o, tm, topo, cfg, o_sample, stage, S["base_tex"], uvmask, (H, W))["total"])
+            o = fit_ref.optimize_iter(P, opt_o, tm, topo, cfg, o_sample, stage, S["base_tex"], uvmask, (H, W))
+            E_ora.append(o["total"])
+            dmax.append(o.get("diffuse_max"))
     torch.cuda.synchronize()
     exp_hip = tr.save_result()
     exp_ora = fit_ref.export(P, (H, W))
     with torch.no_grad():                                     # restore: the fixture is shared
         for k in NAMES:
             getattr(tr, k).copy_(start[k])
-    return {k: v.cpu().numpy() for k, v in start.items()}, exp_hip, exp_ora, (E_hip, E_ora)
+    return {k: v.cpu().numpy() for k, v in start.items()}, exp_hip, exp_ora, (E_hip, E_ora, dmax)
 
 
 @pytest.fixture(scope="module")
 def small(flame_model):
-    return _make(flame_model, 128, 128, 3, 256, seed=23)
+    return _make(flame_model, 128, 128, 3, 256, seed=23, lights_scale=1.25)
 
 
 @pytest.mark.parametrize("stage,lr_scale", [("rgb_global_tracking", 0.1), ("rgb_init_offset", 1.0)])
@@ -238,11 +233,13 @@ def small(flame_model):
 def test_ten_steps_export_matches_oracle_fit(small, stage, lr_scale, same_visibility):
     K, H, W = 10, 128, 128
     ts = np.array([0, 1, 2]) if stage == "rgb_global_tracking" else np.array([1, 2])
-    start, hip, ora, (E_hip, E_ora) = _trajectory(small, stage, lr_scale, K, H, W, ts, same_visibility)
+    start, hip, ora, (E_hip, E_ora, dmax) = _trajectory(small, stage, lr_scale, K, H, W, ts, same_visibility)
     assert set(hip) == set(ora), (sorted(hip), sorted(ora))              # same npz schema (tracker.py:1158-1218)
-    lines = [f"stage {stage} lr_scale {lr_scale} K {K} same_visibility {same_visibility}"]
+    lines = [f"stage {stage} lr_scale {lr_scale} K {K} same_visibility {same_visibility}; oracle max(diffuse) per step: "
+             + " ".join(f"{d:.3f}" for d in dmax)]
+    assert min(dmax) > 1.15, f"the trajectory must stay off the kink of reg_diffuse at max(diffuse) = 1: {dmax}"
     fails = []
-    e_bound = 5e-4 if same_visibility else 5e-3          # (usually <= 1e-6; 7.4e-5 in the run in which one lights component took the other sign)
+    e_bound = 5e-4 if same_visibility else 5e-3          # (measured <= 1e-6 / 2.2e-5)
     for i, (a, b) in enumerate(zip(E_hip, E_ora)):
         e = abs(a - b) / abs(b)
         lines.append(f"step {i}: E hip {a:.6f} oracle {b:.6f} rel {e:.2e}")
@@ -264,14 +261,13 @@ def test_ten_steps_export_matches_oracle_fit(small, stage, lr_scale, same_visibi
             assert np.array_equal(a, start[k].astype(np.float64)), f"{k} must not move in {stage}"
             continue
         assert float(np.abs(a - start[k]).max()) > 0, f"{k} did not move"
-        sp = SPREAD[stage].get(k, (0.0, 0.0, 0.0))           # the noise floor of two correct fp32 trajectories (module docstring)
         if same_visibility:
             full_lr = lr_scale >= 1.0
-            mx_b = max({"static_offset": 1e-1 if full_lr else 5e-3, "tex_extra": 2e-2 if full_lr else 1e-3}.get(k, 1e-3), 2 * sp[0])
-            l2_b = max(1e-2 if (full_lr and k == "static_offset") else 1e-3, 2 * sp[1])
-            if mx > mx_b or l2 > l2_b or dl2 > max(2e-2, 2 * sp[2]):
+            mx_b = {"static_offset": 1e-1 if full_lr else 5e-3, "tex_extra": 2e-2 if full_lr else 1e-3}.get(k, 1e-3)
+            l2_b = 1e-2 if (full_lr and k == "static_offset") else 1e-3
+            if mx > mx_b or l2 > l2_b or dl2 > 2e-2:
                 fails.append(f"{k}: max-norm rel {mx:.2e}, L2 rel {l2:.2e}, update L2 rel {dl2:.2e}")
-        elif l2 > max(1e-2 if (lr_scale >= 1.0 and k == "static_offset") else 1e-3, 2 * sp[1]):
+        elif l2 > (1e-2 if (lr_scale >= 1.0 and k == "static_offset") else 1e-3):
             fails.append(f"{k}: L2 rel {l2:.2e}")
     _record(f"fit_parity_{stage}_{'same' if same_visibility else 'indep'}_visibility.txt", lines + fails)
     assert not fails, fails

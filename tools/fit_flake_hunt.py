@@ -32,13 +32,14 @@ SMALL = ("lights", "shape", "focal_length", "rotation", "translation", "neck_pos
 def main():
     runs = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     K = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+    lights_scale = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0      # 1.0: the scene sits on the kink of reg_diffuse; 1.25: off it
     from oracle import energy_ref
     from tests.test_fit_parity_gpu import NAMES, _make
     from vhap_amd.step import NativeStep
     from vhap_amd.synthetic import make_flame_model
     from vhap_amd.tracker import GraphedStep
     H = W = 128
-    S = _make(make_flame_model(seed=0), H, W, 3, 256, seed=23)
+    S = _make(make_flame_model(seed=0), H, W, 3, 256, seed=23, lights_scale=lights_scale)
     tr, cfg, topo, tm = S["tr"], S["cfg"], S["topo"], S["tm"]
     stage, lr_scale = "rgb_init_offset", 1.0
     ts = np.array([1, 2])
@@ -48,7 +49,7 @@ def main():
     o_sample = {"rgb": sample["rgb"].cpu(), "lmk2d": sample["lmk2d"].cpu(), "timestep_index": ts}
     uvmask = tr._uvmask_res().cpu().double()
     opt = tr.configure_optimizer(tr.get_train_parameters(stage), lr_scale=lr_scale)
-    lines = [f"{runs} runs x {K} steps, stage {stage}, lr_scale {lr_scale}, {len(ts)} x {H}x{W}, T = 256, disturbance off"]
+    lines = [f"{runs} runs x {K} steps, stage {stage}, lr_scale {lr_scale}, {len(ts)} x {H}x{W}, T = 256, disturbance off, lights x {lights_scale}"]
 
     def reset():
         with torch.no_grad():
@@ -61,9 +62,11 @@ def main():
 
     def oracle_grad(params, tid):
         P = {k: params[k].cpu().double().requires_grad_() for k in NAMES}
-        E, _, _ = energy_ref.total_energy(P, tm, topo, cfg, o_sample, stage, S["base_tex"], uvmask, (H, W), tid=tid)
+        E, _, ex = energy_ref.total_energy(P, tm, topo, cfg, o_sample, stage, S["base_tex"], uvmask, (H, W), tid=tid)
         E.backward()
-        return {k: (P[k].grad if P[k].grad is not None else torch.zeros_like(P[k])) for k in NAMES}
+        out = {k: (P[k].grad if P[k].grad is not None else torch.zeros_like(P[k])) for k in NAMES}
+        out["_dmax"] = float(ex["diffuse_detach_normal"].detach().max())       # reg_diffuse's relu(max(diffuse) - 1) has its kink at 1
+        return out
 
     for mode in ("eager", "captured"):
         reset()
@@ -158,7 +161,8 @@ def main():
                     if n in g:
                         row.append(f"{n} cap {rel(g[n], go[n]):.1e} eag {rel(ge[n], go[n]):.1e} c-e {rel(g[n], ge[n]):.1e}")
                 dl = float((PR[r][k]["lights"] - PR[0][k]["lights"]).abs().max()) / lr_l
-                lines.append(f"   step {k}: " + " | ".join(row) + f" | tid diff {ndiff} px | lights vs run 0: {dl:.2f} lr")
+                lines.append(f"   step {k}: " + " | ".join(row) + f" | tid diff {ndiff} px | lights vs run 0: {dl:.2f} lr | oracle max(diffuse) - 1 = "
+                             f"{go['_dmax'] - 1.0:+.2e}")
                 if r > 0 and k > 0:
                     # components of lights that this step moved the other way than run 0 did: their gradient in both runs and in the oracle
                     mv_r = PR[r][k]["lights"] - PR[r][k - 1]["lights"]
@@ -173,7 +177,7 @@ def main():
         del ns, ns_e, st
     reset()
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "fit_flake_hunt.txt"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", f"fit_flake_hunt_lights_x{lights_scale:g}.txt"), "w") as f:
         f.write("\n".join(lines) + "\n")
     print("\n".join(lines))
 

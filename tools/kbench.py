@@ -47,7 +47,7 @@ def raster(flags):
                                    _p(tr.lights), _p(ns.sh_const), _p(ns.rgb) if ns.bg_col is None else 0,
                                    ctypes.cast(ns.bg_col, ctypes.c_void_p) if ns.bg_col is not None else 0,
                                    _p(ns.fid2cid) if ns.disturb_on else 0, ns.fid2cid.numel() if ns.disturb_on else 0, B, V, ns.uv.shape[0], F, H, W,
-                                   _p(ns.rast), _p(ns.rgba), _p(ns.cid) if ns.disturb_on else 0, _p(acc[12:16]) if ns.want_reg else 0, 0, _p(ns.ws),
+                                   _p(ns.rast), _p(ns.rgba), _p(ns.cid) if ns.disturb_on else 0, _p(acc[12:16]), 0, _p(ns.ws),
                                    ns.ws_bytes, ns.ws_cap, flags, st())
 
 
@@ -57,14 +57,6 @@ def deferred_bwd(tb):
                                      _p(ns.c_reg) if ns.want_reg else 0, _p(acc[12:16]) if ns.want_reg else 0, B, V, ns.uv.shape[0], F, H, W,
                                      _p(ns.texc), _p(ns.texd), _p(ns.d_albedo), _p(ns.d_normal), _p(ns.d_texc), _p(ns.d_texd), 0,
                                      _p(ns.def_work), ns.def_work.numel(), _p(ns.texbin_work) if tb else 0, 0, st())
-
-
-def fused_bwd():
-    return L.vhap_deferred_gbuffer_bwd(_p(ns.clip), _p(ns.tri), _p(ns.vn), _p(ns.uv), _p(ns.tri_uv), _p(ns.albedo_tex), _p(ns.mips), T, T,
-                                       _p(tr.lights), _p(ns.sh_const), _p(ns.rast), *ns._upstream(), _p(ns.keep) if ns.disturb_on else 0,
-                                       _p(ns.c_reg) if ns.want_reg else 0, _p(acc[12:16]) if ns.want_reg else 0, _p(ns.face_mask), B, V,
-                                       ns.uv.shape[0], F, H, W, _p(ns.texc), _p(ns.texd), _p(ns.d_albedo), _p(g["d_clip"]), _p(g["d_vn"]),
-                                       0, _p(ns.def_work), ns.def_work.numel(), 0, 0, st())
 
 
 calls = {
@@ -83,13 +75,18 @@ calls = {
                                                                      _p(ns.opp), _p(ns.aa_work), _p(ns.vert_mask), B, H, W, V, F, _p(ns.d_delta),
                                                                      _p(g["d_clip"]), st()), ns._clear_delta()),
     "deferred_shade_bwd": lambda: deferred_bwd(False),
-    "deferred_shade_bwd + tile histogram": lambda: deferred_bwd(True),
-    "deferred_gbuffer_bwd (fused)": fused_bwd,
     "gbuffer_bwd": lambda: L.vhap_gbuffer_bwd(_p(ns.clip), _p(ns.tri), _p(ns.vn), _p(ns.uv), _p(ns.tri_uv), _p(ns.rast), _p(ns.d_normal), _p(ns.d_texc),
                                               _p(ns.d_texd), 0, 0, _p(ns.face_mask), B, V, F, H, W, _p(g["d_clip"]), _p(g["d_vn"]), st()),
     "texture_grad_binned (count+scan+scatter+tile)": lambda: L.vhap_texture_grad_binned(T, T, 3, _p(ns.texc), _p(ns.texd), _p(ns.d_albedo), B, H, W, _p(d_tex),
                                                                                       _p(d_mips), _p(ns.texbin_work), ns.texbin_work.numel(), st()),
-    "tex_finish (fold + tex_prep_bwd)": lambda: ns.tex_finish(),
+    "tex_finish (pyramid gather + TV / residual gradients)": lambda: ns.tex_finish(),
+    "tex_finish + Adam (the fused pass of the captured step)": lambda: ns.tex_finish(opt),
+    "texbin_sort_ids (count + scan + scatter)": (lambda: L.vhap_texbin_sort_ids(_p(ns.tile_ids), _p(ns.keep) if ns.disturb_on else 0, T, T, B, H, W,
+                                                                                _p(ns.texbin_work), ns.texbin_work.numel(), st())) if ns.tb_ids else None,
+    "texture_grad_binned_sorted (texgrad_tile)": (lambda: L.vhap_texture_grad_binned_sorted(T, T, 3, _p(ns.texc), _p(ns.texd), _p(ns.d_albedo), B, H, W,
+                                                                                           _p(d_tex), _p(d_mips), _p(ns.texbin_work),
+                                                                                           ns.texbin_work.numel(), _p(ns.gmax_bound), st())) if ns.tb_ids else None,
+    "verts_bwd_fused .. frame_prep_bwd (geometry tail as shipped)": lambda: ns._bwd_vertex_stage(),
     "adam (texture only)": lambda: opt.step(only=(tr.tex_extra,), advance=False),
     "adam (all but texture)": lambda: opt.step(skip=(tr.tex_extra,), advance=False),
     "geometry tail (vnormal_bwd .. frame_prep_bwd)": None,

@@ -92,7 +92,7 @@ SIGNATURES = {
     "vhap_tex_prep_mip1_fwd": (c_i, [c_fp] * 3 + [c_i, c_f, c_f] + [c_fp] * 3 + [c_i, c_fp]),
     "vhap_texture_mip_build_from": (c_i, [c_fp, c_i, c_i, c_i, c_i, c_fp, c_i, c_fp]),
     "vhap_tex_prep_bwd": (c_i, [c_fp] * 5 + [c_i, c_fp, c_i, c_f, c_f] + [c_fp] * 2),
-    "vhap_tex_prep_bwd_adam": (c_i, [c_fp] * 5 + [c_i, c_fp, c_i, c_f, c_f] + [c_fp] * 5 + [c_f, c_f, c_f, c_fp]),
+    "vhap_tex_prep_bwd_adam": (c_i, [c_fp] * 5 + [c_i, c_fp, c_i, c_f, c_f] + [c_fp] * 5 + [c_f, c_f, c_f, c_i, c_fp]),
     "vhap_energy_finalize": (c_i, [c_fp] * 5 + [c_f, c_f, c_i, c_i, c_i, c_fp, c_fp]),
     "vhap_energy_total": (c_i, [c_fp, c_fp, c_fp, c_f, c_i, c_fp, c_fp]),
     "vhap_sum_frames": (c_i, [c_fp, c_i, c_i, c_fp, c_fp]),
@@ -169,8 +169,6 @@ _streams = threading.local()
 def private_stream(role, device=None, high_priority=False):
     """The calling thread's stream for `role` ('launch', 'side', 'side2', 'warm', 'tex', ...) on `device`: a torch.cuda.ExternalStream
     over a HIP stream this library created -- never a member of torch's stream pool, so it aliases no other stream of the process."""
-    if os.environ.get("VHAP_POOL_STREAMS") == "1":                 # (debugging: the old behaviour, streams from torch's pool)
-        return torch.cuda.Stream(device=device, priority=-1 if high_priority else 0)
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     if dev.index is None:
         dev = torch.device("cuda", torch.cuda.current_device())

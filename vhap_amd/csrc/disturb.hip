@@ -80,48 +80,37 @@ __global__ __launch_bounds__(DB) void disturb_count_kernel(const ClusterSrc src,
     }
 }
 
-// pass 2 (ONE workgroup): block_counts[block][c] -> exclusive prefix over the blocks, per cluster, in place; totals[c] and
-// totals[MAXC + c] = start of cluster c's pool.  Thread t owns cluster t & 15 and the t >> 4-th of 64 segments of consecutive blocks
-// (a wave reads whole 64-byte rows); the segment sums meet in LDS, wave c scans cluster c's 64 segment sums.
+// pass 2 (one workgroup PER CLUSTER): block_counts[block][c] -> exclusive prefix over the blocks, in place; totals[c].  1024 rows per
+// round (one per thread: wave scan + the 16 wave totals through LDS), a carry between rounds.  The consumers derive the start of a
+// cluster's pool (the sum of the totals of the clusters before it) themselves, so the clusters' workgroups are independent.
 // (Round 2 let every scatter workgroup of 1024 threads derive its own prefix from all rows: no extra launch, but with 106 VGPRs only
 // one such workgroup fits a CU and its phases -- prefix, ranks, copy -- run one after the other with nothing to overlap; fine for
-// 4-byte ids, 128 us once the pass copies 16-byte colours.)
+// 4-byte ids, 128 us once the pass copies 16-byte colours.  A single-workgroup scan over all 16 clusters took 19 us.)
 __global__ __launch_bounds__(PB) void disturb_prefix_kernel(int* __restrict__ block_counts, int nblocks, int* __restrict__ totals) {
-    __shared__ int seg[64][MAXC];
-    __shared__ int tot[MAXC];
-    const int c = threadIdx.x & (MAXC - 1), sg = threadIdx.x >> 4;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int per = (nblocks + 63) / 64;
-    const int j0 = min(sg * per, nblocks), j1 = min(j0 + per, nblocks);
-    int sum = 0;
-    for (int j = j0; j < j1; j++) sum += block_counts[(size_t)j * MAXC + c];
-    seg[sg][c] = sum;
+    __shared__ int wtot[PB / 64];
+    __shared__ int carry_s;
+    const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
-    {   // wave `wave` (16 of them) scans cluster `wave`: lane = segment
-        const int v = seg[lane][wave];
+    for (int j0 = 0; j0 < nblocks; j0 += PB) {
+        const int j = j0 + threadIdx.x;
+        const int v = j < nblocks ? block_counts[(size_t)j * MAXC + c] : 0;
         int incl = v;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const int u = __shfl_up(incl, o, 64);
             if (lane >= o) incl += u;
         }
+        if (lane == 63) wtot[wave] = incl;
         __syncthreads();
-        seg[lane][wave] = incl - v;
-        if (lane == 63) tot[wave] = incl;
+        int pre = carry_s;
+        for (int w = 0; w < wave; w++) pre += wtot[w];
+        if (j < nblocks) block_counts[(size_t)j * MAXC + c] = pre + incl - v;
+        __syncthreads();
+        if (threadIdx.x == PB - 1) carry_s = pre + incl;
+        __syncthreads();
     }
-    __syncthreads();
-    if (threadIdx.x < MAXC) {
-        int start = 0;
-        for (int k = 0; k < (int)threadIdx.x; k++) start += tot[k];
-        totals[threadIdx.x] = tot[threadIdx.x];
-        totals[MAXC + threadIdx.x] = start;
-    }
-    int run = seg[sg][c];
-    for (int j = j0; j < j1; j++) {
-        const int v = block_counts[(size_t)j * MAXC + c];
-        block_counts[(size_t)j * MAXC + c] = run;
-        run += v;
-    }
+    if (threadIdx.x == 0) totals[c] = carry_s;
 }
 
 // pass 3: pool[start_c + prefix_c(block) + rank in block] = colour of the pixel.  Ranks inside the block in pixel order: iteration-major,
@@ -137,7 +126,11 @@ __global__ __launch_bounds__(DB) void disturb_scatter_kernel(const ClusterSrc sr
     __shared__ int base[MAXC];                      // start_c + prefix of this block
     __shared__ int wcnt[PPT][NW][MAXC];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x < MAXC) base[threadIdx.x] = totals[MAXC + threadIdx.x] + block_prefix[(size_t)blockIdx.x * MAXC + threadIdx.x];
+    if (threadIdx.x < MAXC) {
+        int start = 0;                               // start of the cluster's pool = the totals of the clusters before it
+        for (int k = 0; k < (int)threadIdx.x; k++) start += totals[k];
+        base[threadIdx.x] = start + block_prefix[(size_t)blockIdx.x * MAXC + threadIdx.x];
+    }
     for (int i = threadIdx.x; i < PPT * NW * MAXC; i += DB) (&wcnt[0][0][0])[i] = 0;
     __syncthreads();
     int key[PPT];                                   // cluster << 8 | rank in the wave's 64 pixels (-1: not sorted)
@@ -192,6 +185,14 @@ __global__ __launch_bounds__(256) void disturb_apply_kernel(const float4* __rest
                                                             float rate_fg, float rate_bg, const int* __restrict__ totals,
                                                             const float4* __restrict__ pool, float4* __restrict__ out,
                                                             float* __restrict__ keep) {
+    __shared__ int s_tot[MAXC], s_start[MAXC];
+    if (threadIdx.x < MAXC) {
+        int start = 0;
+        for (int k = 0; k < (int)threadIdx.x; k++) start += totals[k];
+        s_start[threadIdx.x] = start;
+        s_tot[threadIdx.x] = totals[threadIdx.x];
+    }
+    __syncthreads();
     const long long n = (long long)B * H * W;
     const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
     if (p >= n) return;
@@ -208,13 +209,13 @@ __global__ __launch_bounds__(256) void disturb_apply_kernel(const float4* __rest
         w = c == 0 ? w_bg[p] : (c == 1 ? 0 : w_fg[p]);
         pick = (unsigned long long)idx[p];
     }
-    const int nc = totals[c];
+    const int nc = s_tot[c];
     float k = 1.0f;
     if (w != 0 && nc > 0) {
         // injected indices: idx % n like the reference's randint-then-index (a 64-bit division per disturbed pixel -- parity path only);
         // in-kernel draws: floor(r * n / 2^32), the same distribution without a division
         const int j = rng_state ? (int)((pick * (unsigned long long)nc) >> 32) : (int)(pick % (unsigned long long)nc);
-        out[p] = pool[totals[MAXC + c] + j];
+        out[p] = pool[s_start[c] + j];
         k = 0.0f;
     } else if (!INPLACE) {
         out[p] = rgba[p];   // after compositing, background pixels of `rgba` already hold the background colour
@@ -259,7 +260,7 @@ static int disturb_run(const float* rgba, const float* rast, const uint8_t* cid,
     const float4* in = reinterpret_cast<const float4*>(rgba);
     disturb_count_kernel<<<nblocks, DB, 0, st>>>(src, ncl, n, block_counts, rng_state);
     VHAP_LAUNCH_CHECK();
-    disturb_prefix_kernel<<<1, PB, 0, st>>>(block_counts, nblocks, totals);
+    disturb_prefix_kernel<<<MAXC, PB, 0, st>>>(block_counts, nblocks, totals);
     VHAP_LAUNCH_CHECK();
     disturb_scatter_kernel<<<nblocks, DB, 0, st>>>(src, in, ncl, n, block_counts, totals, pool);
     VHAP_LAUNCH_CHECK();

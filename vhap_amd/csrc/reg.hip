@@ -195,62 +195,109 @@ struct TexAdam {
     const int* step;
     float beta1, beta2, eps;
 };
+// A workgroup owns a 256-column x TEXB_ROWS-row strip like the forward: every lane walks down its column with a three-row window of the
+// saved albedo in registers (one load per texel + two halo rows per strip), the horizontal neighbours come from the adjacent lanes
+// (one halo load per wave side).  The mip part of the texture gradient is GATHERED: level l contributes 4^-l of its texel
+// d_mips[l][y >> l][x >> l] -- with n_gather = every level this replaces the whole fold cascade (vhap_texture_mip_fold).
+// (Round 2's version was one texel per thread on a 1-D grid: a 64-bit division per texel, five scattered taps of the albedo, 2.7 TB/s
+// against the 5.9 TB/s of the Adam pass behind it -- 25 + 63 + 60 us on the tail of the step for fold + this + Adam.)
+constexpr int TEXB_ROWS = 16;
 template <bool ADAM>
 __global__ __launch_bounds__(RB) void tex_prep_bwd_kernel(TexCfg c, const float* __restrict__ albedo, const float* __restrict__ extra,
                                                           const unsigned char* __restrict__ res_mask, const float* __restrict__ d_albedo,
                                                           const float* __restrict__ d_mips, int n_gather, const float* __restrict__ d_terms,
-                                                          float* __restrict__ d_extra, const TexAdam A) {
+                                                          float* __restrict__ d_extra, const TexAdam A, int step_add) {
     const int T = c.T;
     const size_t plane = (size_t)T * T;
     const float gtv = 2.0f * c.s_tv * d_terms[0], gres = 2.0f * c.s_res * d_terms[1];
     float bc2s = 1.f, step_size = 0.f;
     if constexpr (ADAM) {
-        const float st = (float)(A.step[0] + 1);
+        const float st = (float)(A.step[0] + step_add);
         const float bc1 = 1.0f - powf(A.beta1, st);
         bc2s = sqrtf(1.0f - powf(A.beta2, st));
         step_size = A.lr[0] / bc1;
     }
-    for (size_t i = (size_t)blockIdx.x * RB + threadIdx.x; i < plane; i += (size_t)gridDim.x * RB) {
-        const int y = (int)(i / T), x = (int)(i - (size_t)y * T);
+    const int x = blockIdx.x * RB + threadIdx.x, y0 = blockIdx.y * TEXB_ROWS;
+    const int lane = threadIdx.x & 63;
+    const bool in_x = x < T;
+    const bool tv = gtv != 0.f;
+    auto load_row = [&](int y, int xx, float* a) {
+        if (xx >= 0 && xx < T && y >= 0 && y < T) {
+            const float* q = albedo + 3 * ((size_t)y * T + xx);
+            a[0] = q[0]; a[1] = q[1]; a[2] = q[2];
+        } else {
+            a[0] = a[1] = a[2] = 0.f;
+        }
+    };
+    float up[3] = {0.f, 0.f, 0.f}, cur[3] = {0.f, 0.f, 0.f}, dn[3] = {0.f, 0.f, 0.f};
+    if (tv) { load_row(y0 - 1, x, up); load_row(y0, x, cur); }
+#pragma unroll 4
+    for (int r = 0; r < TEXB_ROWS; r++) {
+        const int y = y0 + r;
+        if (y >= T) break;
+        const size_t i = (size_t)y * T + x;
+        if (tv) load_row(y + 1, x, dn);
         float g[3] = {0.f, 0.f, 0.f};
-        if (d_albedo) { g[0] = d_albedo[3 * i]; g[1] = d_albedo[3 * i + 1]; g[2] = d_albedo[3 * i + 2]; }
-        if (d_mips) {       // box-filter backward of the first n_gather mip levels, gathered: level l contributes 4^-l of its texel
-            size_t off = 0;
-            float sc = 0.25f;
-            for (int l = 1; l <= n_gather; l++) {
-                const int tl = T >> l;
-                const float* m = d_mips + off + 3 * ((size_t)(y >> l) * tl + (x >> l));
-                g[0] += sc * m[0]; g[1] += sc * m[1]; g[2] += sc * m[2];
-                off += (size_t)tl * tl * 3;
-                sc *= 0.25f;
+        if (in_x) {
+            if (d_albedo) { g[0] = d_albedo[3 * i]; g[1] = d_albedo[3 * i + 1]; g[2] = d_albedo[3 * i + 2]; }
+            if (d_mips) {
+                size_t off = 0;
+                float sc = 0.25f;
+                for (int l = 1; l <= n_gather; l++) {
+                    const int tl = T >> l;
+                    const float* m = d_mips + off + 3 * ((size_t)(y >> l) * tl + (x >> l));
+                    g[0] += sc * m[0]; g[1] += sc * m[1]; g[2] += sc * m[2];
+                    off += (size_t)tl * tl * 3;
+                    sc *= 0.25f;
+                }
             }
         }
-        if (gtv != 0.f) {
-            const float* a = albedo + 3 * i;
-            float acc[3] = {0.f, 0.f, 0.f};
-            if (y + 1 < T) { const float* n = a + 3 * (size_t)T; acc[0] += a[0] - n[0]; acc[1] += a[1] - n[1]; acc[2] += a[2] - n[2]; }
-            if (y > 0) { const float* n = a - 3 * (size_t)T; acc[0] += a[0] - n[0]; acc[1] += a[1] - n[1]; acc[2] += a[2] - n[2]; }
-            if (x + 1 < T) { const float* n = a + 3; acc[0] += a[0] - n[0]; acc[1] += a[1] - n[1]; acc[2] += a[2] - n[2]; }
-            if (x > 0) { const float* n = a - 3; acc[0] += a[0] - n[0]; acc[1] += a[1] - n[1]; acc[2] += a[2] - n[2]; }
-            g[0] += gtv * acc[0]; g[1] += gtv * acc[1]; g[2] += gtv * acc[2];
-        }
-        if (gres != 0.f && res_mask && res_mask[i]) {
+        if (tv) {
+            float lf[3], rt[3];
 #pragma unroll
-            for (int k = 0; k < 3; k++) g[k] += gres * extra[k * plane + i];
-        }
-        d_extra[i] = g[0]; d_extra[plane + i] = g[1]; d_extra[2 * plane + i] = g[2];
-        if constexpr (ADAM) {
+            for (int k = 0; k < 3; k++) { lf[k] = __shfl_up(cur[k], 1, 64); rt[k] = __shfl_down(cur[k], 1, 64); }
+            if (lane == 0) load_row(y, x - 1, lf);
+            if (lane == 63) load_row(y, x + 1, rt);
+            if (in_x) {
+                float acc[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const size_t j = k * plane + i;
-                const float gi = g[k];
-                const float mi = A.m[j] + (gi - A.m[j]) * (1.0f - A.beta1);          // lerp, like torch
-                const float vi = A.beta2 * A.v[j] + (1.0f - A.beta2) * gi * gi;
-                A.m[j] = mi;
-                A.v[j] = vi;
-                A.p[j] -= step_size * mi / (sqrtf(vi) / bc2s + A.eps);
+                for (int k = 0; k < 3; k++) {
+                    if (y + 1 < T) acc[k] += cur[k] - dn[k];
+                    if (y > 0) acc[k] += cur[k] - up[k];
+                    if (x + 1 < T) acc[k] += cur[k] - rt[k];
+                    if (x > 0) acc[k] += cur[k] - lf[k];
+                    g[k] += gtv * acc[k];
+                }
             }
         }
+        if (in_x) {
+            float ex[3] = {0.f, 0.f, 0.f};
+            const bool res = gres != 0.f && res_mask && res_mask[i];
+            if (res || ADAM) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) ex[k] = extra[k * plane + i];
+            }
+            if (res) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) g[k] += gres * ex[k];
+            }
+            d_extra[i] = g[0]; d_extra[plane + i] = g[1]; d_extra[2 * plane + i] = g[2];
+            if constexpr (ADAM) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const size_t j = k * plane + i;
+                    const float gi = g[k];
+                    const float m0 = A.m[j];
+                    const float mi = m0 + (gi - m0) * (1.0f - A.beta1);              // lerp, like torch
+                    const float vi = A.beta2 * A.v[j] + (1.0f - A.beta2) * gi * gi;
+                    A.m[j] = mi;
+                    A.v[j] = vi;
+                    A.p[j] = ex[k] - step_size * mi / (sqrtf(vi) / bc2s + A.eps);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) { up[k] = cur[k]; cur[k] = dn[k]; }
     }
 }
 
@@ -358,9 +405,8 @@ extern "C" int vhap_tex_prep_bwd(const float* albedo_hwc, const float* extra, co
     if (!albedo_hwc || !extra || !d_terms || !d_extra) return VHAP_E_NULLPTR;
     if (T <= 0 || n_gather < 0 || (d_mips_hwc && n_gather > 0 && (T & ((1 << n_gather) - 1)))) return VHAP_E_BADDIM;
     TexCfg c{T, s_tv, s_res};
-    const int blocks = (int)(((size_t)T * T + RB - 1) / RB < 8192 ? ((size_t)T * T + RB - 1) / RB : 8192);
-    tex_prep_bwd_kernel<false><<<blocks, RB, 0, vhap_stream(stream)>>>(c, albedo_hwc, extra, res_mask, d_albedo_hwc, n_gather > 0 ? d_mips_hwc : nullptr,
-                                                                       n_gather, d_terms, d_extra, TexAdam{});
+    tex_prep_bwd_kernel<false><<<dim3(vhap_cdiv(T, RB), vhap_cdiv(T, TEXB_ROWS)), RB, 0, vhap_stream(stream)>>>(
+        c, albedo_hwc, extra, res_mask, d_albedo_hwc, n_gather > 0 ? d_mips_hwc : nullptr, n_gather, d_terms, d_extra, TexAdam{}, 0);
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;
 }
@@ -368,15 +414,14 @@ extern "C" int vhap_tex_prep_bwd(const float* albedo_hwc, const float* extra, co
 extern "C" int vhap_tex_prep_bwd_adam(const float* albedo_hwc, float* extra, const uint8_t* res_mask, const float* d_albedo_hwc,
                                       const float* d_mips_hwc, int n_gather, const float* d_terms, int T, float s_tv, float s_res,
                                       float* d_extra, float* exp_avg, float* exp_avg_sq, const float* lr_device, const int32_t* step_device,
-                                      float beta1, float beta2, float eps, vhap_stream_t stream) {
+                                      float beta1, float beta2, float eps, int call_flags, vhap_stream_t stream) {
     VHAP_ENTER();
     if (!albedo_hwc || !extra || !d_terms || !d_extra || !exp_avg || !exp_avg_sq || !lr_device || !step_device) return VHAP_E_NULLPTR;
     if (T <= 0 || n_gather < 0 || (d_mips_hwc && n_gather > 0 && (T & ((1 << n_gather) - 1)))) return VHAP_E_BADDIM;
     TexCfg c{T, s_tv, s_res};
-    const int blocks = (int)(((size_t)T * T + RB - 1) / RB < 8192 ? ((size_t)T * T + RB - 1) / RB : 8192);
-    tex_prep_bwd_kernel<true><<<blocks, RB, 0, vhap_stream(stream)>>>(c, albedo_hwc, extra, res_mask, d_albedo_hwc, n_gather > 0 ? d_mips_hwc : nullptr,
-                                                                      n_gather, d_terms, d_extra,
-                                                                      TexAdam{extra, exp_avg, exp_avg_sq, lr_device, step_device, beta1, beta2, eps});
+    tex_prep_bwd_kernel<true><<<dim3(vhap_cdiv(T, RB), vhap_cdiv(T, TEXB_ROWS)), RB, 0, vhap_stream(stream)>>>(
+        c, albedo_hwc, extra, res_mask, d_albedo_hwc, n_gather > 0 ? d_mips_hwc : nullptr, n_gather, d_terms, d_extra,
+        TexAdam{extra, exp_avg, exp_avg_sq, lr_device, step_device, beta1, beta2, eps}, (call_flags & VHAP_CALL_ADAM_STEP_ADVANCED) ? 0 : 1);
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;
 }

@@ -35,9 +35,14 @@ class FrameShardContext:
         return slice(start, start + base + (1 if self.rank < rem else 0))
 
     def shard_sample(self, sample):
+        """This rank's contiguous slice of a batch.  A RAGGED batch (the last one of a sequence or of a shuffled pass: its size is not a
+        multiple of the number of ranks) is not split at all: every rank fits the whole of it.  The per-rank energy is built so that its
+        mean over ranks is the single-process energy for EQUAL shards (local means, the photometric sum normalised by the pixel count of
+        all ranks times the number of ranks) -- which replicas of the same batch satisfy trivially, unequal shards do not; the price is
+        redundant work on that one batch, the averaged gradient (and hence every replica) stays exact."""
         n = len(sample["timestep_index"])
         if n % self.world_size:
-            raise ValueError(f"batch of {n} frames does not split evenly over {self.world_size} ranks")
+            return dict(sample)
         sl = self.shard_slice(n)
         out = {}
         for k, v in sample.items():

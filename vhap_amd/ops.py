@@ -66,7 +66,7 @@ class RasterizeHipContext:
         # persistent=True: keep ONE zero-initialised workspace per (device, stream, shape).  The kernels leave it clean, so
         # the per-call memset is skipped (VHAP_RASTER_WS_CLEAN) and the address is stable under graph capture.  A context is
         # then tied to in-order use on one stream at a time; use persistent=False (or one context per thread) otherwise.
-        self.persistent = persistent and os.environ.get("VHAP_RASTER_PERSISTENT", "1") != "0"
+        self.persistent = persistent
         self._ws = {}
 
     def workspace(self, B, F, H, W, device):

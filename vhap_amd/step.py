@@ -130,20 +130,17 @@ class NativeStep:
             self.mips = E(L.vhap_texture_mip_floats(1, T, T, 3))
         else:
             self.albedo_tex, self.mips = E(0), E(0)
-        # deferred shading (default): the rasteriser samples the texture and shades in registers; normal / rast_db / albedo images do not exist
+        # deferred shading (default): the rasteriser samples the texture and shades in registers; normal / rast_db / albedo images do not exist.
+        # VHAP_DEFERRED=0: the separate passes (G-buffer, texture, shading, out-of-place antialiasing, dense gradient images) -- the
+        # formulation the deferred kernels are tested against (tests/test_deferred_gpu.py) and whose raster kernel IS the RI-fwd op that
+        # bench.py's roofline line is defined on
         self.deferred = self.photometric and os.environ.get("VHAP_DEFERRED", "1") != "0"
-        self.tb_fused = self.tb_ids = False
+        self.tb_ids = False
         # one GPU: energy assembly + upstream gradient in the epilogue of the photometric sum (under sharding the pixel count is all-reduced
         # between the passes, so the two glue launches stay)
-        self.energy_fused = self.deferred and (tracker.dist is None or tracker.dist.world_size == 1) and \
-            os.environ.get("VHAP_ENERGY_FUSED", "1") != "0"
-        self.raster_profile = os.environ.get("VHAP_RASTER_PROFILE", "0") == "1"
-        # shading backward fused with the G-buffer backward (one gather chain per covered pixel, d_normal / d_uv / d_uv_da stay in registers)
-        # (measured on MI355X, tools/kbench.py: 265 us fused vs 129 + 125 us separately -- both kernels are bound by VALU issue, not by the
-        # gather latency a fusion would share -- so it is off by default)
-        self.fused_bwd = self.deferred and os.environ.get("VHAP_FUSED_BWD", "0") == "1"
+        self.energy_fused = self.deferred and (tracker.dist is None or tracker.dist.world_size == 1)
         # antialiasing in place + photometric gradient on the fly: no copy of the image, no dense gradient images (d_rgba_aa / d_color)
-        self.aa_inplace = self.deferred and os.environ.get("VHAP_AA_INPLACE", "1") != "0"
+        self.aa_inplace = self.deferred
         if self.photometric:
             self.clip, self.vn, self.vn_inv = E(B, V, 4), E(B, V, 3), E(B, V)
             self.rast, self.texc, self.texd = E(B, H, W, 4), E(B, H, W, 2), E(B, H, W, 4)
@@ -205,16 +202,11 @@ class NativeStep:
             else:
                 self.d_rgba_aa, self.d_color = E(B, H, W, 4), E(B, H, W, 4)
             self.d_albedo = E(B, H, W, 3)
-            if not self.fused_bwd:
-                self.d_normal, self.d_texc, self.d_texd = E(B, H, W, 3), E(B, H, W, 2), E(B, H, W, 4)
+            self.d_normal, self.d_texc, self.d_texd = E(B, H, W, 3), E(B, H, W, 2), E(B, H, W, 4)
             self.texbin_work = torch.zeros(self.L.vhap_texture_grad_binned_work_bytes(B, H, W), dtype=torch.uint8, device=dev)
-            # the uv-tile histogram (count pass of the binned texture gradient) is filled in by the deferred backward itself
-            self.tb_fused = self.deferred and self.tex_bwd_on and NV.use_binned_texgrad() and T <= 2048 and \
-                os.environ.get("VHAP_TB_FUSED", "0") == "1"       # (measured: +50 us on the pixel kernel for 25 us saved -- off)
-            self.tb_head = self.texbin_work[:2 * 64 * 64 * 4]
-            # ... and the uv tile of every pixel is handed to the sorting passes as 2 B/px instead of uv + d_albedo (20 B/px, twice)
-            self.tb_ids = self.deferred and self.tex_bwd_on and NV.use_binned_texgrad() and T <= 2048 and not self.tb_fused and \
-                os.environ.get("VHAP_TB_IDS", "1") != "0"
+            # the uv tile of every pixel is handed to the sorting passes of the texture gradient as 2 B/px (written by the rasteriser)
+            # instead of uv + d_albedo (20 B/px, twice)
+            self.tb_ids = self.deferred and self.tex_bwd_on and T <= 2048
             if self.tb_ids:
                 self.tile_ids = torch.empty(B, H, W, dtype=torch.int16, device=dev)
             self.vn_scratch = E(B, V, 3)
@@ -226,7 +218,7 @@ class NativeStep:
         self.photo_work = torch.zeros(1024, **f32)               # VHAP_PHOTO_WORK_FLOATS
         # two independent chains per pass run on two streams (two branches of the captured graph): the bandwidth / atomics bound texture
         # work next to the latency-bound geometry chain of small launches
-        self.overlap = os.environ.get("VHAP_STEP_OVERLAP", "1") != "0"
+        self.overlap = os.environ.get("VHAP_STEP_OVERLAP", "1") != "0"      # (0: one chain -- what tools/step_pmc.py attributes counters on)
         self.one_graph = False        # GraphedStep, one GPU: forward + backward + Adam are ONE captured graph -- the forward accumulators are then cleared
                                       # at the END of the step (off the critical path; the step's first kernels become roots of the graph) and the
                                       # texture-gradient sort is not joined before the backward needs it
@@ -234,16 +226,11 @@ class NativeStep:
         self.injected = None          # dict(w_fg, w_bg, idx): random numbers of the colour disturbance handed in (parity tests) instead of drawn in-kernel
         self.step_optimizer = None    # a HipAdam whose WHOLE update is issued inside forward()/backward() (GraphedStep, one GPU): counter advanced
                                       # at the head of the step, texture update behind its gradient, the rest before the final join
-        self.split_tex = False        # True: stop at the gradient pyramid, the caller runs tex_finish() later (pyramid-level exchange)
-        self.tex_l0_skip = False      # True: tex_finish() ignores the base level of the pyramid
+        self.split_tex = False        # True: stop at the gradient pyramid, the caller runs tex_finish() later (pyramid-level exchange under sharding)
         # streams of the library's own (never torch's pool: see _lib.private_stream), shared by every step of this thread
         self.side = _lib.private_stream("side", dev)
-        self.side2 = _lib.private_stream("side2", dev) if os.environ.get("VHAP_SIDE2", "1") != "0" else self.side   # (env: A/B, two branches only)
-        self.main_first = os.environ.get("VHAP_FORK_ORDER", "1") != "0"
+        self.side2 = _lib.private_stream("side2", dev)
         self._pending = []
-        # VHAP_PRIO=1: the backward's texture chain (the step's critical path) on a high-priority stream -- its workgroups are dispatched ahead
-        # of the geometry chain's where the two share the chip
-        self.side_b = _lib.private_stream("side_b", dev, high_priority=True) if os.environ.get("VHAP_PRIO", "0") != "0" else self.side
         self.c_lmk = torch.full((1,), self.w_lmk, **f32)
         self.c_reg = torch.full((1,), self.w_reg, **f32)
 
@@ -261,17 +248,12 @@ class NativeStep:
         return torch.cuda.stream(self.side) if self.overlap else _Null()
 
     def _side(self, fn, stream=None):
-        """Run fn() on the side branch, forked at the CURRENT point of this stream.  With `main_first` the fork is only marked (an event) and
-        fn is issued by the next _flush(), i.e. AFTER the main chain's next kernel was captured: the graph executor keeps a node's
-        first-captured successor on the node's own queue and hands the others over to different queues (~10 us each)."""
+        """Run fn() on the side branch, forked at the CURRENT point of this stream.  The fork is only marked (an event); fn is issued by the
+        next _flush(), i.e. AFTER the main chain's next kernel was captured: the plan executor (csrc/plan.hip) keeps a node's
+        first-captured successor on the node's own stream and forks the others onto side streams (a hand-over costs ~10 us)."""
         stream = self.side if stream is None else stream
         if not self.overlap:
             return fn()
-        if not self.main_first:
-            stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(stream):
-                fn()
-            return
         ev = torch.cuda.Event()
         ev.record()
         self._pending.append((ev, stream, fn))
@@ -305,19 +287,24 @@ class NativeStep:
     def _camera_forward(self):
         L, tr, B, H, W = self.L, self.tr, self.B, self.H, self.W
         if self.calibrated:
-            # per-view intrinsics / extrinsics of the sample (tracker.py:141-147): K [B,3,3] or [B,4] -> (fx, fy, cx, cy); RT [B,3|4,4]
-            K = self.K_in
+            # per-view intrinsics / extrinsics of the sample (tracker.py:141-147): K [B,3,3] or [B,4] -> (fx, fy, cx, cy); RT [B,3|4,4].
+            # The sample tensors are static (new batches are copied INTO them): whatever already has the kernel's layout is read in place
+            # -- a same-layout copy_ would be a memcpy node in the captured step, which the plan executor does not replay
+            K, RT = self.K_in, self.RT_in
             if K.shape[-2:] == (3, 3):
                 torch.stack([K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2]], dim=-1, out=self.K)
+                K = self.K
+            elif not (K.is_contiguous() and K.dtype == torch.float32):
+                K = self.K.copy_(K)
+            if RT.shape[-2] == 3 and RT.is_contiguous() and RT.dtype == torch.float32:
+                self.RT = RT
             else:
-                self.K.copy_(K)
-            self.RT.copy_(self.RT_in[:, :3, :])
-            kb = rb = 1
-        else:                                                     # K = (f, f, cx, cy), f = focal * max(h, w): built inside the kernel
-            _chk(L.vhap_camera_focal_fwd(_p(tr.focal_length), self.focal_scale, 0.5 * W, 0.5 * H, _p(self.RT), B, 0, H, W, 0.1, 10.0, _p(self.mvp),
-                                         _stream()), "vhap_camera_focal_fwd")
+                self.RT.copy_(RT[:, :3, :])                       # (a strided copy: a kernel)
+            _chk(L.vhap_camera_fwd(_p(K), _p(self.RT), B, 1, 1, H, W, 0.1, 10.0, _p(self.mvp), _stream()), "vhap_camera_fwd")
             return
-        _chk(L.vhap_camera_fwd(_p(self.K), _p(self.RT), B, kb, rb, H, W, 0.1, 10.0, _p(self.mvp), _stream()), "vhap_camera_fwd")
+        # monocular: K = (f, f, cx, cy), f = focal * max(h, w): built inside the kernel
+        _chk(L.vhap_camera_focal_fwd(_p(tr.focal_length), self.focal_scale, 0.5 * W, 0.5 * H, _p(self.RT), B, 0, H, W, 0.1, 10.0, _p(self.mvp),
+                                     _stream()), "vhap_camera_focal_fwd")
 
     def _landmark_forward(self):
         L, B, H, W, V = self.L, self.B, self.H, self.W, self.V
@@ -348,17 +335,13 @@ class NativeStep:
                 self._tex_ready.record()
             self._side(tex_branch)
         # the camera (one tiny workgroup per frame) does not depend on the per-frame stage: side by side instead of 5-28 us ahead of it
-        cam_par = self.overlap and os.environ.get("VHAP_CAM_PAR", "1") != "0"
-        if cam_par:
-            self._side(self._camera_forward, self.side2)
-        else:
-            self._camera_forward()
+        self._side(self._camera_forward, self.side2)
         _chk(L.vhap_frame_prep_fwd(_p(self.ts), _p(tr.shape), _p(tr.expr), _p(tr.rotation), _p(tr.translation), _p(tr.neck_pose),
                                    _p(tr.jaw_pose), _p(tr.eyes_pose), _p(fm.JT), _p(fm.JS), _p(fm.jreg_idx), _p(fm.jreg_w), fm.jreg_n,
                                    _p(so), fm.parents, self.weights, B, self.Bp, self.N, self.NS, self.NE, J, fb.Kp, V,
                                    _p(self.coef), _p(self.A), _p(self.transl), _p(self.Jrest), _p(acc), PRE, st), "vhap_frame_prep_fwd")
         self._flush()
-        if cam_par:
+        if self.overlap:
             torch.cuda.current_stream().wait_stream(self.side2)
         if self.photometric:                                      # skinning fused with the world -> clip transform (one launch, same bits)
             _chk(L.vhap_flame_skin_clip_fwd(_p(self.coef), _p(fb.basis), _p(self.A), _p(fb.w), _p(fb.templ), _p(so), _p(self.transl), _p(self.mvp),
@@ -388,8 +371,6 @@ class NativeStep:
             self._arena_clean = True
             if self.step_optimizer is not None:
                 self.step_optimizer.advance()
-            if self.tb_fused:
-                self.tb_head.zero_()                              # tile histogram of the texture-gradient binning (filled by the backward)
         self._side(side_work)
         if self.deferred:
             return self._forward_deferred()
@@ -398,7 +379,7 @@ class NativeStep:
         _hook("raster_interp_fwd", "begin")                       # (bench.py: HIP events around the RI-fwd pass of eagerly issued steps)
         _chk(L.vhap_raster_interp_fwd(_p(self.clip), _p(self.tri), _p(self.vn), _p(self.uv), _p(self.tri_uv), B, V, self.uv.shape[0], F, H, W,
                                       _p(self.rast), _p(self.db), _p(self.normal), _p(self.texc), _p(self.texd), _p(self.ws), self.ws_bytes,
-                                      self.ws_cap, 1 | (8 if self.raster_profile else 0), st), "vhap_raster_interp_fwd")
+                                      self.ws_cap, 1, st), "vhap_raster_interp_fwd")
         _hook("raster_interp_fwd", "end")
         self._join()
         _chk(L.vhap_texture_fwd(_p(self.albedo_tex), _p(self.mips), 1, T, T, 3, _p(self.texc), _p(self.texd), B, H, W, _p(self.albedo_px), st),
@@ -406,7 +387,7 @@ class NativeStep:
         _chk(L.vhap_shade_fwd(_p(self.normal), _p(self.albedo_px), _p(self.rast), _p(self.rgb) if self.bg_col is None else 0,
                               ctypes.cast(self.bg_col, ctypes.c_void_p) if self.bg_col is not None else 0, _p(tr.lights), _p(self.sh_const),
                               _p(self.fid2cid) if self.disturb_on else 0, self.fid2cid.numel() if self.disturb_on else 0,
-                              B, H, W, _p(self.rgba), _p(acc[12:16]) if self.want_reg else 0, _p(self.cid) if self.disturb_on else 0, PRE, st),
+                              B, H, W, _p(self.rgba), _p(acc[12:16]), _p(self.cid) if self.disturb_on else 0, PRE, st),
              "vhap_shade_fwd")
         color = self.rgba
         if self.disturb_on:
@@ -434,38 +415,27 @@ class NativeStep:
                                            ctypes.cast(self.bg_col, ctypes.c_void_p) if self.bg_col is not None else 0,
                                            _p(self.fid2cid) if self.disturb_on else 0, self.fid2cid.numel() if self.disturb_on else 0,
                                            B, V, self.uv.shape[0], F, H, W, _p(self.rast), _p(self.rgba), _p(self.cid) if self.disturb_on else 0,
-                                           _p(acc[12:16]) if self.want_reg else 0, _p(self.tile_ids) if self.tb_ids else 0, _p(self.ws),
+                                           _p(acc[12:16]), _p(self.tile_ids) if self.tb_ids else 0, _p(self.ws),
                                            self.ws_bytes, self.ws_cap, flags, st)
         _hook("raster_interp_fwd", "begin")
-        prof = 8 if self.raster_profile else 0                    # VHAP_RASTER_PROFILE (bench.py: in-graph timing of the pass)
-        split = self.overlap and self.bin_split
-        # the reduction of the shading statistics (only the energy assembly reads them) beside the pixel chain instead of inside it
-        stats_later = 16 if (self.overlap and self.want_reg and os.environ.get("VHAP_STATS_LATER", "1") != "0") else 0
-        bin_vn = self.bin_split and os.environ.get("VHAP_BIN_VN", "1") != "0"
-        if bin_vn:
+        # the shading statistics (diffuse maximum / variance) are ALWAYS collected: reg_diffuse reads them when the lights are trained, and the
+        # fixed-point scale of the texture-gradient accumulation is derived from the measured diffuse maximum whatever the stage trains.
+        # Their reduction (only the energy assembly reads it) runs beside the pixel chain instead of inside it
+        stats_later = 16 if self.overlap else 0
+        if self.bin_split:
             # binning + vertex normals in ONE launch (independent work, both inputs of the raster kernel): no fork / join -- a hand-over
-            # between queues costs ~10 us each way on this critical path
+            # between streams costs ~10 us each way on this critical path
             _chk(L.vhap_raster_bin_vnormal(_p(self.clip), _p(self.tri), _p(self.tri_uv), B, V, F, H, W, _p(self.ws), self.ws_bytes, self.ws_cap,
-                                           1 | prof, _p(self.verts), _p(self.csr.ptr), _p(self.csr.idx), _p(self.vn), _p(self.vn_inv), st),
+                                           1, _p(self.verts), _p(self.csr.ptr), _p(self.csr.idx), _p(self.vn), _p(self.vn_inv), st),
                  "vhap_raster_bin_vnormal")
-            split = True
-            self._flush()
-        elif split:                                               # vertex normals next to the binning (the raster kernel needs both)
-            self.side2.wait_stream(cur)
-            with torch.cuda.stream(self.side2):
-                _chk(L.vhap_vnormal_fwd_saved(_p(self.verts), _p(self.csr.tri), _p(self.csr.ptr), _p(self.csr.idx), B, V, _p(self.vn), _p(self.vn_inv), _stream()),
-                     "vhap_vnormal_fwd")
-            _chk(raster(1 | 2 | prof), "vhap_raster_shade_fwd")   # VHAP_RASTER_WS_CLEAN | VHAP_RASTER_BIN_ONLY
-            self._flush()
-            cur.wait_stream(self.side2)
-        else:
+        else:                                                     # (meshes / frames too large for the one-launch binning: binning inside the raster call)
             _chk(L.vhap_vnormal_fwd_saved(_p(self.verts), _p(self.csr.tri), _p(self.csr.ptr), _p(self.csr.idx), B, V, _p(self.vn), _p(self.vn_inv), st), "vhap_vnormal_fwd")
-            self._flush()
+        self._flush()
         if self._tex_ready is not None:
             cur.wait_event(self._tex_ready)
         else:
             self._join()
-        _chk(raster(((1 | 4) if split else 1) | prof | stats_later), "vhap_raster_shade_fwd")   # ... | VHAP_RASTER_PREBINNED
+        _chk(raster(((1 | 4) if self.bin_split else 1) | stats_later), "vhap_raster_shade_fwd")   # VHAP_RASTER_WS_CLEAN (| VHAP_RASTER_PREBINNED)
         _hook("raster_interp_fwd", "end")
         if stats_later:
             self._side(lambda: _chk(L.vhap_raster_shade_stats(B, F, H, W, _p(self.ws), self.ws_bytes, self.ws_cap, 1, _p(acc[12:16]), _stream()),
@@ -474,13 +444,13 @@ class NativeStep:
         # the antialiasing's pair discovery needs the rasteriser's output only, not the colours: beside the colour disturbance (143 us of
         # the main chain) instead of behind it -- 60 us less on the critical path
         self._aa_det = None
-        if self.aa_inplace and self.overlap and os.environ.get("VHAP_AA_EARLY", "1") != "0":
+        if self.aa_inplace and self.overlap:
             def detect_branch():
                 _chk(L.vhap_antialias_inplace_detect(_p(self.rast), _p(self.clip), _p(self.tri), _p(self.opp), B, H, W, V, F, _p(self.aa_work),
                                                      _stream()), "vhap_antialias_inplace_detect")
                 self._aa_det = torch.cuda.Event()
                 self._aa_det.record()
-            self._side(detect_branch, self.side2 if os.environ.get("VHAP_AA_EARLY", "1") == "2" else None)   # (on the texture branch's queue: idle here)
+            self._side(detect_branch)                             # (on the texture branch's stream: idle here)
         color = self.rgba
         if self.disturb_on:
             self._disturb(st)
@@ -492,7 +462,7 @@ class NativeStep:
             self._sort_fork = None
 
             def sort_branch():
-                if self.one_graph and self.side_b is self.side:
+                if self.one_graph:
                     # everything the energy assembly needs from this branch is in front of this point; the sort itself is only needed by the
                     # backward's texture chain, which runs on this very stream: the forward does not wait for it
                     self._sort_fork = torch.cuda.Event()
@@ -524,7 +494,7 @@ class NativeStep:
             else:
                 self._join()
             _chk(L.vhap_photo_fwd_total(_p(self.rgba_aa), _p(self.rgb), B, H, W, _p(acc[16:19]), _p(acc[0:6]), _p(acc[6:7]) if self.w_lmk else 0,
-                                        _p(acc[7:9]), _p(acc[9:12]), _p(acc[12:16]) if self.want_reg else 0, self.w_lmk, self.w_reg, self.w_photo,
+                                        _p(acc[7:9]), _p(acc[9:12]), _p(acc[12:16]), self.w_lmk, self.w_reg, self.w_photo,
                                         _p(self.log), _p(self.d_sum), _p(self.gmax_bound), _p(self.photo_work), PRE, st), "vhap_photo_fwd_total")
             return
         _chk(L.vhap_photo_fwd(_p(self.rgba_aa), _p(self.rgb), B, H, W, _p(acc[16:18]), PRE, st), "vhap_photo_fwd")
@@ -547,35 +517,21 @@ class NativeStep:
                                          float(self.rate_fg or 0.0), float(self.rate_bg or 0.0), 0 if inj is not None else _p(self.rng),
                                          B, H, W, _p(self.dist_ws), _p(self.keep), st), "vhap_disturb_inplace")
 
-    def raster_profile_us(self):
-        """(binning us, raster kernel us) of the LAST forward, from the in-kernel wall-clock stamps (needs raster_profile; synchronises)"""
-        off = self.L.vhap_raster_profile_offset(self.B, self.F, self.H, self.W, self.ws_cap)
-        torch.cuda.synchronize()
-        st = self.ws[off:off + 2 * 256 * 2 * 8].view(torch.int64).view(2, 256, 2).cpu().numpy().astype(np.uint64)
-        out = []
-        for k in range(2):
-            starts, ends = st[k, :, 0], st[k, :, 1]
-            live = ends > 0
-            out.append(float(ends[live].max() - starts[live].min()) * 0.01 if live.any() else float("nan"))      # 100 MHz ticks -> us
-        return tuple(out)
-
     def _tex_backward(self, optimizer=None):
-        """-> True when the texture's Adam update was applied inside (fused into the last kernel of the chain)"""
-        L, tr, T, g = self.L, self.tr, self.T, self.g
+        """texel part of the texture-sampling backward (-> the gradient pyramid d_tex / d_mips), then -- unless `split_tex` -- tex_finish().
+        -> True when the texture's Adam update was applied inside (fused into the last kernel of the chain)"""
+        L, T, g = self.L, self.T, self.g
         B, H, W = self.B, self.H, self.W
         st = _stream()
         if not self.tex_bwd_on:
             return False
         n0 = self.albedo_tex.numel()
         d_tex, d_mips = g["d_tex"][:n0], g["d_tex"][n0:]
-        if self.tb_fused:
-            _chk(L.vhap_texture_grad_binned_counted(T, T, 3, _p(self.texc), _p(self.texd), _p(self.d_albedo), B, H, W, _p(d_tex), _p(d_mips),
-                                                    _p(self.texbin_work), self.texbin_work.numel(), st), "vhap_texture_grad_binned_counted")
-        elif self.tb_ids:                                          # (sorted during the forward pass: only the accumulation is left)
+        if self.tb_ids:                                            # (sorted during the forward pass: only the accumulation is left)
             _chk(L.vhap_texture_grad_binned_sorted(T, T, 3, _p(self.texc), _p(self.texd), _p(self.d_albedo), B, H, W, _p(d_tex), _p(d_mips),
                                                    _p(self.texbin_work), self.texbin_work.numel(), _p(self.gmax_bound), st),
                  "vhap_texture_grad_binned_sorted")
-        elif not (NV.use_binned_texgrad() and NV.texture_grad_binned(T, 3, self.texc, self.texd, self.d_albedo, d_tex, d_mips, self.texbin_work)):
+        elif not NV.texture_grad_binned(T, 3, self.texc, self.texd, self.d_albedo, d_tex, d_mips, self.texbin_work):
             _chk(L.vhap_texture_bwd(_p(self.albedo_tex), _p(self.mips), 1, T, T, 3, _p(self.texc), _p(self.texd), _p(self.d_albedo), B, H, W,
                                     _p(d_tex), _p(d_mips), 0, 0, st), "vhap_texture_bwd")
         if not self.split_tex:
@@ -583,9 +539,11 @@ class NativeStep:
         return False
 
     def tex_finish(self, optimizer=None):
-        """Gradient pyramid -> d(tex_extra): fold + TV / residual gradients + layout change.  Under frame sharding this runs AFTER the
-        pyramid was averaged over the ranks (the regulariser part is identical on every rank, so it is added once, afterwards); with
-        `tex_l0_skip` the level-0 part of the pyramid is not exchanged and therefore not used either."""
+        """Gradient pyramid -> d(tex_extra) in ONE pass over the texture: every mip level gathered per texel (no fold cascade), TV / residual
+        gradients, layout change and -- with `optimizer`, a HipAdam holding tex_extra -- the Adam update itself (the gradient is still
+        written: it is the parameter's .grad; the update reads the step counter advanced at the head of the step).  Under frame sharding
+        this runs AFTER the pyramid was averaged over the ranks (the regulariser part is identical on every rank, so it is added once,
+        afterwards).  -> True when the update was applied."""
         L, tr, T, g = self.L, self.tr, self.T, self.g
         st = _stream()
         if not self.photometric:                                      # only the TV / residual gradients (a landmark stage that trains the texture)
@@ -596,17 +554,17 @@ class NativeStep:
         d_tex, d_mips = g["d_tex"][:n0], g["d_tex"][n0:]
         has_mips = self.mips.numel() > 0
         ng = _n_gather(T) if has_mips else 0
-        if has_mips:
+        if has_mips and ng < L.vhap_texture_num_levels(T, T):      # (texture sizes whose coarse levels cannot be gathered: fold them first)
             _chk(L.vhap_texture_mip_fold(_p(d_tex), _p(d_mips), 1, T, T, 3, ng, st), "vhap_texture_mip_fold")
-        fu = optimizer.fused_update_args(tr.tex_extra) if (optimizer is not None and hasattr(optimizer, "fused_update_args") and
-                                                            os.environ.get("VHAP_TEX_ADAM_FUSED", "0") == "1") else None    # (measured: 137 us fused vs 50 + 59 us -- off)
-        if fu is not None:                                          # gradient assembly + Adam update of the texture in ONE pass over it
+        fu = optimizer.fused_update_args(tr.tex_extra) if (optimizer is not None and hasattr(optimizer, "fused_update_args")) else None
+        if fu is not None:
             m, v, lr, step, b1, b2, eps = fu
-            _chk(L.vhap_tex_prep_bwd_adam(_p(self.albedo_tex), _p(tr.tex_extra), _p(self.nm["res_mask"]), 0 if self.tex_l0_skip else _p(d_tex),
+            flags = _lib.CALL_ADAM_STEP_ADVANCED if self.step_optimizer is not None else 0
+            _chk(L.vhap_tex_prep_bwd_adam(_p(self.albedo_tex), _p(tr.tex_extra), _p(self.nm["res_mask"]), _p(d_tex),
                                           _p(d_mips) if has_mips else 0, ng, _p(self.ones), T, *self.tex_scales, _p(g["tex_extra"]), _p(m), _p(v),
-                                          _p(lr), _p(step), b1, b2, eps, st), "vhap_tex_prep_bwd_adam")
+                                          _p(lr), _p(step), b1, b2, eps, flags, st), "vhap_tex_prep_bwd_adam")
             return True
-        _chk(L.vhap_tex_prep_bwd(_p(self.albedo_tex), _p(tr.tex_extra), _p(self.nm["res_mask"]), 0 if self.tex_l0_skip else _p(d_tex),
+        _chk(L.vhap_tex_prep_bwd(_p(self.albedo_tex), _p(tr.tex_extra), _p(self.nm["res_mask"]), _p(d_tex),
                                  _p(d_mips) if has_mips else 0, ng, _p(self.ones), T, *self.tex_scales, _p(g["tex_extra"]), st),
              "vhap_tex_prep_bwd")
         return False
@@ -637,7 +595,7 @@ class NativeStep:
             assert int(world_size) == 1                             # (done by the forward's photometric sum)
         else:
             _chk(L.vhap_energy_total_bound(_p(self.log), _p(acc[16:18]), _p(self.n_global), self.w_photo, int(world_size), _p(self.d_sum),
-                                           _p(acc[12:16]) if self.want_reg else 0, _p(self.gmax_bound), st), "vhap_energy_total_bound")
+                                           _p(acc[12:16]), _p(self.gmax_bound), st), "vhap_energy_total_bound")
         if self.aa_inplace:
             # no dense gradient images: the loss gradient is evaluated on the fly (here at the pixels of the antialias pair list, in the
             # shading backward everywhere); the sparse colour part of the antialias backward travels in d_delta
@@ -652,16 +610,6 @@ class NativeStep:
         if after_first is not None:
             after_first()
         # (the backward of the disturbance -- d_rgba = d_color * keep -- is folded into the shading backward)
-        if self.fused_bwd:
-            _chk(L.vhap_deferred_gbuffer_bwd(_p(self.clip), _p(self.tri), _p(self.vn), _p(self.uv), _p(self.tri_uv), _p(self.albedo_tex), _p(self.mips),
-                                             T, T, _p(tr.lights), _p(self.sh_const), _p(self.rast), *self._upstream(),
-                                             _p(self.keep) if self.disturb_on else 0, _p(self.c_reg) if self.want_reg else 0,
-                                             _p(acc[12:16]) if self.want_reg else 0, _p(self.face_mask), B, V, self.uv.shape[0], F, H, W,
-                                             _p(self.texc), _p(self.texd), _p(self.d_albedo), _p(g["d_clip"]), _p(g["d_vn"]), 0,
-                                             _p(self.def_work), self.def_work.numel(), _p(self.texbin_work) if self.tb_fused else 0,
-                                           0, st),
-                 "vhap_deferred_gbuffer_bwd")
-            return
         if self.deferred:
             # shading + texture-coordinate backward in one pass, from re-computed attributes (nothing of the forward's G-buffer is re-read)
             _chk(L.vhap_deferred_shade_bwd(_p(self.clip), _p(self.tri), _p(self.vn), _p(self.uv), _p(self.tri_uv), _p(self.albedo_tex), _p(self.mips),
@@ -669,8 +617,7 @@ class NativeStep:
                                            _p(self.keep) if self.disturb_on else 0, _p(self.c_reg) if self.want_reg else 0,
                                            _p(acc[12:16]) if self.want_reg else 0, B, V, self.uv.shape[0], F, H, W, _p(self.texc), _p(self.texd),
                                            _p(self.d_albedo), _p(self.d_normal), _p(self.d_texc), _p(self.d_texd), 0,
-                                           _p(self.def_work), self.def_work.numel(), _p(self.texbin_work) if self.tb_fused else 0,
-                                           0, st),
+                                           _p(self.def_work), self.def_work.numel(), 0, 0, st),
                  "vhap_deferred_shade_bwd")
             return
         _chk(L.vhap_shade_bwd(_p(self.normal), _p(self.albedo_px), _p(self.rast), _p(tr.lights), _p(self.sh_const), _p(self.d_color),
@@ -703,7 +650,7 @@ class NativeStep:
         """gradient w.r.t. the texture coordinates and their screen-space derivatives (input of the G-buffer backward)"""
         L, B, H, W, T = self.L, self.B, self.H, self.W, self.T
         if self.deferred:
-            return                                                # produced by vhap_deferred_shade_bwd already (or never materialised: fused_bwd)
+            return                                                # produced by vhap_deferred_shade_bwd already
         _chk(L.vhap_texture_bwd(_p(self.albedo_tex), _p(self.mips), 1, T, T, 3, _p(self.texc), _p(self.texd), _p(self.d_albedo), B, H, W,
                                 0, 0, _p(self.d_texc), _p(self.d_texd), _stream()), "vhap_texture_bwd")
 
@@ -732,27 +679,23 @@ class NativeStep:
         L, g = self.L, self.g
         B, H, W, V, F = self.B, self.H, self.W, self.V, self.F
         st = _stream()
-        if not self.fused_bwd:
-            _chk(L.vhap_gbuffer_bwd(_p(self.clip), _p(self.tri), _p(self.vn), _p(self.uv), _p(self.tri_uv), _p(self.rast), _p(self.d_normal),
-                                    _p(self.d_texc), _p(self.d_texd), 0, 0, _p(self.face_mask), B, V, F, H, W, _p(g["d_clip"]), _p(g["d_vn"]), st),
-                 "vhap_gbuffer_bwd")
+        _chk(L.vhap_gbuffer_bwd(_p(self.clip), _p(self.tri), _p(self.vn), _p(self.uv), _p(self.tri_uv), _p(self.rast), _p(self.d_normal),
+                                _p(self.d_texc), _p(self.d_texd), 0, 0, _p(self.face_mask), B, V, F, H, W, _p(g["d_clip"]), _p(g["d_vn"]), st),
+             "vhap_gbuffer_bwd")
         if after_first is not None:
             after_first()
         if early is True:                                             # (the event of backward(part="all")'s early branch, issued by now)
             early = self._early_ev
         if early is not None:
             torch.cuda.current_stream().wait_event(early)
-        if os.environ.get("VHAP_VERTS_BWD_FUSED", "1") == "0":
-            _chk(L.vhap_vnormal_bwd_saved(_p(self.verts), _p(self.csr.tri), _p(self.csr.ptr), _p(self.csr.idx), _p(self.vn), _p(self.vn_inv),
-                                          _p(g["d_vn"]), B, V, 1, _p(self.vn_scratch), _p(g["d_verts"]), st), "vhap_vnormal_bwd_saved")
-            _chk(L.vhap_transform_bwd(_p(self.verts), _p(self.mvp), _p(g["d_clip"]), B, V, 1, _p(g["d_verts"]), _p(self.d_mvp), st),
-                 "vhap_transform_bwd")
-            self._bwd_params()
-            return
-        # vertex-normal / clip-transform / skinning backward + offset sum in one kernel (+ the split-K coefficient GEMM), then the tiny
-        # camera chain and the per-frame parameters
-        tr, fb, fm = self.tr, self.fb, self.fm
-        J = self.J
+        self._bwd_vertex_stage()
+
+    def _bwd_vertex_stage(self):
+        """vertex-normal / clip-transform / skinning backward + offset sum in one kernel (+ the split-K coefficient GEMM), then the tiny
+        camera chain and the per-frame parameters"""
+        L, g, tr, fb, fm = self.L, self.g, self.tr, self.fb, self.fm
+        B, H, W, V, J = self.B, self.H, self.W, self.V, self.J
+        st = _stream()
         _chk(L.vhap_verts_bwd_fused(_p(self.verts), _p(self.csr.tri), _p(self.csr.ptr), _p(self.csr.idx), _p(self.vn), _p(self.vn_inv), _p(g["d_vn"]),
                                     _p(self.mvp), _p(g["d_clip"]), _p(g["d_verts"]), _p(self.v_posed), _p(self.A), _p(fb.w), _p(fb.basisT), B, V,
                                     fb.Vp, fb.Kb, fb.Kp, _p(self.vn_scratch), _p(self.g_posed), _p(self.g_shaped), _p(g["d_coef"]), _p(g["d_A"]),
@@ -768,29 +711,19 @@ class NativeStep:
                                    _p(g["static_offset"]) if self.has_offset else 0, st), "vhap_frame_prep_bwd")
 
     def backward(self, world_size=1, part="all", optimizer=None):
-        """part = 'all': the whole backward as one two-branch DAG (one GPU).  Under frame sharding the backward is captured in two
-        graphs so that the big collective can start early (`optimizer`, one GPU only: a HipAdam whose texture update is issued on the
-        side branch -- the caller then steps the remaining parameters with optimizer.step(skip=(tex_extra,))): 'texture' (pixel chain + the complete texture gradient, serial) -- the
-        caller launches the asynchronous all-reduce of the texture gradient -- then 'geometry' (everything else), which hides it; or
-        'pixel' then 'tex' and 'geometry' side by side on two streams (GraphedStep's default under sharding)."""
-        if self.side_b is not self.side:
-            fwd_side, self.side = self.side, self.side_b
-            try:
-                return self._backward(world_size, part, optimizer)
-            finally:
-                self.side = fwd_side
-        return self._backward(world_size, part, optimizer)
-
-    def _backward(self, world_size, part, optimizer):
-        if part in ("all", "texture", "pixel"):
+        """part = 'all': the whole backward as one DAG of up to three branches (one GPU).  `optimizer`: a HipAdam whose texture update is
+        fused into the last kernel of the texture chain; with `step_optimizer` set as well (GraphedStep) the rest of its update is issued
+        here too, next to the tail of the texture chain.
+        Under frame sharding the backward is captured in two pieces so that the big collective can start early: 'pixel_tex' (energy,
+        pixel chain, the complete texture gradient -> g['tex_extra']) -- the caller launches the asynchronous all-reduce of that
+        gradient -- then 'geometry' (everything else), which runs underneath it."""
+        if part in ("all", "pixel_tex"):
             if not getattr(self, "_arena_clean", False):              # (normally done on the forward's side branch already)
                 self.arena.zero_()
-                if self.tb_fused:
-                    self.tb_head.zero_()
             self._arena_clean = False
         if not self.photometric:
-            # landmark-only stage: E = landmark + regularisers; one short serial chain (any `part` but the first of a sharded split is empty)
-            if part in ("all", "texture", "pixel"):
+            # landmark-only stage: E = landmark + regularisers; one short serial chain ('geometry' of a sharded split is empty)
+            if part in ("all", "pixel_tex"):
                 _chk(self.L.vhap_energy_total(_p(self.log), 0, 0, 0.0, int(world_size), 0, _stream()), "vhap_energy_total")
                 self._bwd_early()
                 if self.tex_bwd_on:
@@ -807,27 +740,18 @@ class NativeStep:
                 if self.overlap:
                     self._early_ev = torch.cuda.Event()
                     self._early_ev.record()
-            # UNMEASURED experiment (VHAP_BWD_EARLY_MAIN=1, off): the texture tail of the backward (texture-gradient accumulation -> fold -> TV
-            # backward -> Adam, 330 us) is 60 us longer than the geometry tail beside it, and its first kernel takes 179 us next to the
-            # G-buffer backward against 110 us alone: the two latency-bound launches of the early branch go IN FRONT of the G-buffer backward
-            # on this chain, so that the accumulation starts with the chip to itself and the geometry tail gives up its slack.
-            early_main = os.environ.get("VHAP_BWD_EARLY_MAIN", "0") == "1"
-            if not early_main:
-                self._side(early_branch)
+            self._side(early_branch)
             self._bwd_pixel(world_size, after_first=self._flush)
-            # fork as soon as d_albedo exists: the texture gradient (uv-binned accumulation + fold + TV backward) on the side branch,
-            # the uv gradient and the geometry chain on this one
+            # fork as soon as d_albedo exists: the texture gradient (uv-binned accumulation, then ONE pass that gathers the pyramid, adds the
+            # regulariser gradients and applies the Adam update) on the side branch, the geometry chain on this one
             def tex_chain():
-                done = self._tex_backward(optimizer)                  # (with an optimiser: its Adam update fused into the last kernel)
+                done = self._tex_backward(optimizer)
                 if optimizer is not None and self.tex_bwd_on and not done:
                     optimizer.step(only=(self.tr.tex_extra,), advance=False, advanced=self.step_optimizer is not None)
             self._side(tex_chain)
             self._side(self._bwd_pixel_finish, self.side2)            # (nothing downstream reads these two: beside the geometry chain, not ahead of it)
-            if early_main:
-                self._bwd_early()
-                self._flush()
             self._bwd_uv()
-            self._bwd_geometry(None if early_main else True, after_first=self._flush)
+            self._bwd_geometry(True, after_first=self._flush)
             if self.overlap:
                 torch.cuda.current_stream().wait_stream(self.side2)
             if self.step_optimizer is not None:                       # every other parameter: next to the tail of the texture branch
@@ -836,15 +760,13 @@ class NativeStep:
                 self.accF.zero_()
                 self._acc_clean = True
             self._join()
-        elif part == "texture":
+        elif part == "pixel_tex":
             self._bwd_pixel(world_size)
-            self._bwd_pixel_finish()
+            self._side(self._bwd_pixel_finish, self.side2)
             self._tex_backward()
-        elif part == "pixel":                                     # 'texture' in two pieces: the caller runs 'tex' next to 'geometry'
-            self._bwd_pixel(world_size)
-            self._bwd_pixel_finish()
-        elif part == "tex":
-            self._tex_backward()
+            self._flush()
+            if self.overlap:
+                torch.cuda.current_stream().wait_stream(self.side2)
         elif part == "geometry":
             early = None
             self._fork()

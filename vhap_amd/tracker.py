@@ -755,9 +755,23 @@ class GlobalTracker(FlameTracker):
             return st.opt
         assert dataloader is not None
         opt, sched = None, None
+        # frames resident as uint8 (FrameStore): the captured step is fed by timestep -- vhap_frame_ingest writes straight into its static
+        # buffers -- instead of through a materialised fp32 batch and a 50 MB copy per step
+        direct = isinstance(dataloader, ShuffledBatches) and self.frames is not None and self.dist is None
+        H, W = self.image_size
         for epoch_i in range(self.cfg.pipeline[stage].num_epochs):
-            for s in dataloader:
-                st = step_for(s, opt)                              # one optimiser (one Adam state) for every batch shape of this call
+            for s in (dataloader.index_batches() if direct else dataloader):
+                if direct:
+                    ts = s
+                    n = len(ts) if self._frames_of is None else sum(len(self._frames_of[int(t)]) for t in ts)
+                    st = self._graphed.get((stage, (n, 3, H, W), float(lr_scale)))
+                    if st is None or (opt is not None and st.opt is not opt):
+                        st = step_for(self.get_sample(ts, device_index=True), opt)
+                    else:
+                        self.get_train_parameters(stage)
+                        st.update_timesteps(ts)
+                else:
+                    st = step_for(s, opt)                          # one optimiser (one Adam state) for every batch shape of this call
                 if opt is None:
                     opt = st.opt
                     if not getattr(st, "fresh", False):
@@ -918,7 +932,9 @@ class ShuffledBatches:
     def __len__(self):
         return (self.tr.n_timesteps + self.bs - 1) // self.bs
 
-    def __iter__(self):
+    def index_batches(self):
+        """the timesteps of every batch of one pass (the sampling half of __iter__: a captured step whose frames live in a uint8
+        FrameStore is fed by GraphedStep.update_timesteps, without materialising the fp32 batch in between)"""
         tr = self.tr
         if tr.dist is not None and self.gen is None:
             # frame sharding: every rank must draw the SAME permutation (each then takes its slice of every batch); a generator seeded
@@ -926,7 +942,12 @@ class ShuffledBatches:
             self.gen = torch.Generator().manual_seed(tr.dist.broadcast_int(int(torch.randint(0, 2 ** 31 - 1, (1,)))))
         perm = torch.randperm(tr.n_timesteps, generator=self.gen).numpy()
         for i in range(0, len(perm), self.bs):
-            s = tr.get_sample(perm[i:i + self.bs], device_index=self.device_index)
+            yield perm[i:i + self.bs]
+
+    def __iter__(self):
+        tr = self.tr
+        for ts in self.index_batches():
+            s = tr.get_sample(ts, device_index=self.device_index)
             yield tr.dist.shard_sample(s) if tr.dist is not None else s
 
 
@@ -1019,22 +1040,22 @@ class CapturedPlan:
 
 
 class GraphedStep:
-    """One optimiser step captured in hipGraphs (the 50-500 identical steps of a
-    stage are launch-bound in eager mode -- ~1300 launches per step).
+    """One optimiser step recorded once under HIP stream capture and replayed by the library's plan executor (CapturedPlan; SURVEY section
+    8(f) rank 3: the 50-500 identical steps of a stage are launch-bound in eager mode -- ~1300 launches per step).
 
-    One GPU: the whole step (vhap_amd/step.py::NativeStep: forward, backward, Adam -- ~45 C-ABI calls on up to three branches) is ONE
-    graph.  Frame sharding: the collectives stay ordinary eager calls between the graphs --
+    One GPU: the whole step (vhap_amd/step.py::NativeStep: forward, backward, Adam -- ~45 C-ABI calls on up to three chains) is ONE
+    plan.  Frame sharding: the collectives stay ordinary eager calls between the plans --
 
         F  : forward -> every energy term, photometric numerator S and alpha count N
              [all-reduce N over ranks]
-        B  : backward, pixel chain            Bt : texture gradient (own stream) + its asynchronous all-reduce (50 MB)
-        B2 : backward, geometry chain (beside Bt)      [all-reduce (average) of the flat bucket of every other gradient]
+        B  : backward: pixel chain + the complete texture gradient      [asynchronous all-reduce of the texture gradient (50 MB)]
+        B2 : backward: geometry chain, underneath that collective       [all-reduce (average) of the flat bucket of every other gradient]
         A  : Adam
 
-    (the autograd formulation of a stage the NativeStep does not cover -- use_dynamic_offset -- is captured as F / B / A the same way).
-    Everything the graphs touch is static: the sample tensors, the parameters, their .grad and the Adam state.
+    (the autograd formulation of a stage the NativeStep does not cover is captured as F / B / A the same way).
+    Everything the plans touch is static: the sample tensors, the parameters, their .grad and the Adam state.
     A new batch is fed by copying into `self.sample` (same shapes) -- exactly the sequential-tracking pattern.
-    Replays always go to the step's own launch stream (see __init__ on why)."""
+    Replays always go to the step's own launch stream."""
 
     def __init__(self, tracker, sample, optimizer, stage, warmup=2, unroll=1):
         assert tracker.fused, "graph capture needs the fused (sync-free) path"
@@ -1082,51 +1103,37 @@ class GraphedStep:
                 self.ns.backward(1)
         torch.cuda.current_stream().wait_stream(side)
         self.inv_n = torch.zeros((), device=dev)
-        # The LAUNCH stream is a stream of the library's own (never torch's pool).  hipGraphLaunch (ROCm 7) lays a graph's parallel branches
-        # out over internal normal-priority streams (one spare) and skips those that share the launch stream's hardware queue -- without a
-        # bounds check: when more than the spare did (which depends on every stream and graph the process created and destroyed before; seen
-        # after ~35 captured steps in one process, never in a fresh one), it ran off the end of the list and dereferenced garbage.  Hardware
-        # queues are pooled per priority, so VHAP_LAUNCH_PRIO=high (a high-priority launch stream) rules the collision out -- at 27 % of the
-        # step's throughput (measured: 1.35 vs 1.06 ms at 16 x 512^2), which is why it is not the default.
-        self._launch_hi = os.environ.get("VHAP_LAUNCH_PRIO", "normal") == "high"
-        self.stream = _lib.private_stream("launch", dev, high_priority=self._launch_hi)
+        # Replays go to a stream of the library's own (never torch's pool, never the null stream): the plan executor forks the captured
+        # step's side chains from it and joins them back into it
+        self.stream = _lib.private_stream("launch", dev)
         # with a process group alive, its helper threads (RCCL watchdog, heartbeat) issue runtime calls of their own: keep those from
         # invalidating a capture in progress on this thread
         cap = dict(capture_error_mode="thread_local") if tracker.dist is not None else {}
-        if os.environ.get("VHAP_PRIO", "0") == "2":                 # (experiment: the main chain of the captured step on a high-priority stream)
-            cap["stream"] = _lib.private_stream("capture_hi", dev, high_priority=True)
         self.gF, self.gB, self.gA = CapturedPlan(), CapturedPlan(), CapturedPlan()
         if self.ns is not None:
             ns = self.ns
             world = tracker.dist.world_size if tracker.dist is not None else 1
             if world > 1:
                 ns.n_global = torch.ones(1, device=dev)             # receives the all-reduced alpha count before every backward replay
-            self.single = world == 1 and os.environ.get("VHAP_SINGLE_GRAPH", "1") != "0"
+            self.single = world == 1
             if self.single:
-                # nothing happens between the passes on one GPU: ONE graph launch per step instead of three (~15 us of launch gap each)
-                # `unroll` > 1: that many consecutive steps per graph launch (the launch gap, ~25 us, is paid once per replay)
+                # nothing happens between the passes on one GPU: ONE plan per step.  `unroll` > 1: that many consecutive steps per replay
                 self.unroll = max(1, int(unroll))
-                # the texture's Adam update (7 x 50 MB of traffic at T = 2048) goes on the backward's side branch, right behind its
-                # gradient, instead of on the tail of the step
+                # the texture's Adam update (7 x 50 MB of traffic at T = 2048) is fused into the last kernel of the backward's texture chain;
+                # the step counter is advanced at the head of the step (side branch), so that no piece of the update has to be last
                 tex = tracker.tex_extra
                 split = tex is not None and any(p is tex for p in self.params) and len(self.params) > 1 and ns.tex_bwd_on and \
-                    os.environ.get("VHAP_SPLIT_ADAM", "1") != "0"
-                # ... and the step counter is advanced at the head of the step (side branch), so that no piece of the update has to be last
-                early = split and ns.photometric and ns.overlap and hasattr(optimizer, "advance") and \
-                    os.environ.get("VHAP_ADAM_EARLY", "1") != "0" and os.environ.get("VHAP_TEX_ADAM_FUSED", "0") != "1"
-                ns.step_optimizer = optimizer if early else None
-                if ns.photometric and os.environ.get("VHAP_ONE_GRAPH", "1") != "0":
+                    ns.photometric and ns.overlap and hasattr(optimizer, "advance")
+                ns.step_optimizer = optimizer if split else None
+                if ns.photometric:
                     ns.one_graph = True
                     ns.accF.zero_()
                     ns._acc_clean = True
                 with self.gF.capture(**cap):
                     for _ in range(self.unroll):
                         ns.forward()
-                        if early:
+                        if split:
                             ns.backward(1, optimizer=optimizer)
-                        elif split:
-                            ns.backward(1, optimizer=optimizer)
-                            optimizer.step(skip=(tex,))
                         else:
                             ns.backward(1)
                             optimizer.step()
@@ -1135,39 +1142,29 @@ class GraphedStep:
                 self.lmk_only = True
                 with self.gF.capture(**cap):
                     ns.forward()
-                pool = self.gF.pool() if os.environ.get("VHAP_GRAPH_POOLS") != "separate" else None
-                with self.gB.capture(pool=pool, **cap):
+                with self.gB.capture(pool=self.gF.pool(), **cap):
                     ns.backward(world)
-                with self.gA.capture(pool=pool, **cap):
+                with self.gA.capture(pool=self.gF.pool(), **cap):
                     optimizer.step()
             else:
-                # Frame sharding.  The big collective is the texture gradient (50 MB at T = 2048).  The backward is captured in two graphs:
-                # 'texture' makes that gradient final first, its asynchronous all-reduce is launched, and 'geometry' (G-buffer backward,
-                # normals, skinning, per-frame parameters: ~0.35 ms) runs underneath it; the small gradients follow in a second collective.
+                # Frame sharding.  The big collective is the texture gradient (50 MB at T = 2048).  The backward is captured in two plans:
+                # 'pixel_tex' makes that gradient final first, its asynchronous all-reduce is launched, and 'geometry' (G-buffer backward,
+                # normals, skinning, per-frame parameters: ~0.3 ms) runs underneath it; the small gradients follow in a second collective.
                 with self.gF.capture(**cap):
                     ns.forward()
-                pool = self.gF.pool() if os.environ.get("VHAP_GRAPH_POOLS") != "separate" else None
-                # 'parallel' (default): pixel chain, then the texture part (own stream, followed by its all-reduce) NEXT TO the geometry part --
-                # the same two-branch overlap as on one GPU; 'serial': texture part, collective launched, geometry part underneath it
-                self.par = os.environ.get("VHAP_SHARD_SCHEDULE", "parallel") != "serial"
+                pool = self.gF.pool()
                 self.gB2 = CapturedPlan()
-                if self.par:
-                    with self.gB.capture(pool=pool, **cap):
-                        ns.backward(world, part="pixel")
-                    self.gBt = CapturedPlan()
-                    with self.gBt.capture(**cap):               # replayed concurrently with gB2: a pool of its own
-                        ns.backward(world, part="tex")
-                    self.tex_stream = _lib.private_stream("tex", dev, high_priority=self._launch_hi)    # (launches gBt)
-                else:
-                    with self.gB.capture(pool=pool, **cap):
-                        ns.backward(world, part="texture")
+                with self.gB.capture(pool=pool, **cap):
+                    ns.backward(world, part="pixel_tex")
                 with self.gB2.capture(pool=pool, **cap):
                     ns.backward(world, part="geometry")
                 with self.gA.capture(pool=pool, **cap):
                     optimizer.step()
             self.E = ns.log[15]
             self.log_dict = ns.log_dict()
-            self.S, self.N = ns.accF[16], ns.accF[17]
+            # (one GPU: the forward accumulators are cleared at the END of the captured step -- the photometric sum / count of the last step
+            # are in the log vector, not here)
+            self.S, self.N = (None, None) if self.single else (ns.accF[16], ns.accF[17])
             return
         tracker._split = {}
         try:
@@ -1177,7 +1174,7 @@ class GraphedStep:
                 tracker.fill_cam_params_into_sample(s)
                 E_rest, self.log_dict, *_ = tracker.compute_energy(s, stage=stage)
                 self.S, self.N = tracker._split.get("S"), tracker._split.get("N")     # None: the stage has no photometric term
-            pool = self.gF.pool() if os.environ.get("VHAP_GRAPH_POOLS") != "separate" else None
+            pool = self.gF.pool()
             for p in self.params:
                 p.grad = None
             with self.gB.capture(pool=pool, **cap):
@@ -1196,16 +1193,24 @@ class GraphedStep:
 
     def update_timesteps(self, timesteps):
         """Feed the batch of these timesteps from the tracker's dataset; with a uint8 FrameStore the frames are converted straight
-        into the static rgb buffer (no intermediate fp32 batch)."""
+        into the static rgb buffer (no intermediate fp32 batch).  Multi-view datasets: every view of the timesteps, each frame carrying
+        ITS timestep -- the same frame-index expansion as GlobalTracker.get_sample."""
         tr = self.tr
-        idx = torch.as_tensor(np.asarray(timesteps), device=self.sample["timestep_index"].device)
         if tr.frames is None:
             return self.update_sample(tr.get_sample(timesteps, device_index=True))
+        ts = np.asarray(timesteps).reshape(-1)
+        if tr._frames_of is not None:
+            fidx = np.concatenate([tr._frames_of[int(t)] for t in ts])
+            ts = tr.frame_timestep[fidx]
+        else:
+            fidx = ts
+        dev = self.sample["timestep_index"].device
+        idx = torch.as_tensor(fidx, device=dev)
         if idx.shape != self.sample["timestep_index"].shape:
             raise ValueError("GraphedStep.update_timesteps: batch size differs from the captured one")
         tr.frames.batch(idx, out=self.sample["rgb"])
         self.sample["lmk2d"].copy_(tr.dataset["lmk2d"][idx])
-        self.sample["timestep_index"].copy_(idx)
+        self.sample["timestep_index"].copy_(torch.as_tensor(ts, device=dev))
         for k in ("intrinsic", "extrinsic"):
             if k in self.sample:
                 self.sample[k].copy_(tr.dataset[k][idx])
@@ -1223,11 +1228,8 @@ class GraphedStep:
     def __call__(self):
         if isinstance(self.opt, NV.HipAdam):
             self.opt.sync_lr()                                     # lr schedulers act on the host copy
-        # Replays go to a stream of our own, never the null stream: on ROCm 7.2 the memset nodes that torch's reductions
-        # record (semaphore clears) were observed out of order with their kernels when a graph is launched on stream 0.
-        # ... and never any stream but the step's own launch stream (see __init__: the runtime's graph launch is only safe there).
         cur = torch.cuda.current_stream()
-        if cur.cuda_stream != self.stream.cuda_stream and os.environ.get("VHAP_GRAPH_NULL_STREAM") != "1":   # (env: debugging only)
+        if cur.cuda_stream != self.stream.cuda_stream:              # (inside replay_stream() the step's stream IS current)
             self.stream.wait_stream(cur)
             with torch.cuda.stream(self.stream):
                 self._replay()
@@ -1272,25 +1274,13 @@ class GraphedStep:
                 return
             if tr.dist is not None:
                 self.ns.n_global.copy_(tr.dist.all_reduce_sum(self.N.reshape(1)))
-            self.gB.replay()
+            self.gB.replay()                                               # pixel chain + the complete texture gradient
             # the gradients sit in contiguous buffers: collectives straight on them (ReduceOp.AVG), no staging copies
-            if getattr(self, "par", False):
-                cur = torch.cuda.current_stream()
-                self.tex_stream.wait_stream(cur)
-                with torch.cuda.stream(self.tex_stream):
-                    self.gBt.replay()                                      # texture gradient, next to ...
-                    work = tr.dist.all_reduce_mean_(self.ns.g["tex_extra"], async_op=True) if self.ns.tex_bwd_on else None
-                self.gB2.replay()                                          # ... the geometry chain; the collective runs under its tail
-                tr.dist.all_reduce_mean_(self.ns.param_grad_flat)
-                if work is not None:
-                    work.wait()
-                cur.wait_stream(self.tex_stream)
-            else:
-                work = tr.dist.all_reduce_mean_(self.ns.g["tex_extra"], async_op=True) if self.ns.tex_bwd_on else None
-                self.gB2.replay()                                          # runs under the texture collective
-                tr.dist.all_reduce_mean_(self.ns.param_grad_flat)
-                if work is not None:
-                    work.wait()
+            work = tr.dist.all_reduce_mean_(self.ns.g["tex_extra"], async_op=True) if self.ns.tex_bwd_on else None
+            self.gB2.replay()                                              # geometry chain: runs under the texture collective
+            tr.dist.all_reduce_mean_(self.ns.param_grad_flat)
+            if work is not None:
+                work.wait()
             self.gA.replay()
             return
         if self.N is not None:
