@@ -501,6 +501,10 @@ int vhap_camera_fwd(const float* K, const float* RT, int B, int K_batched, int R
                     float near_plane, float far_plane, float* mvp, vhap_stream_t stream);
 int vhap_camera_bwd(const float* RT, const float* d_mvp, int B, int RT_batched, int H, int W, float* d_K,
                     vhap_stream_t stream);
+/* monocular case, vhap_camera_bwd + vhap_focal_bwd in one launch: d_focal_accum[0] += scale * sum_b (d_K[b].fx + d_K[b].fy), summed in
+ * frame order (K = (f, f, cx, cy), f = focal_length * scale; tracker.py:148-157) */
+int vhap_camera_focal_bwd(const float* RT, const float* d_mvp, int B, int RT_batched, int H, int W, float scale,
+                          float* d_focal_accum, vhap_stream_t stream);
 /* the uncalibrated camera (tracker.py:148-157): K = (f, f, cx, cy) with f = focal_length[0] * focal_scale (device scalar x max(H, W)) */
 int vhap_camera_focal_fwd(const float* focal_length, float focal_scale, float cx, float cy, const float* RT, int B,
                           int RT_batched, int H, int W, float near_plane, float far_plane, float* mvp,

@@ -86,8 +86,14 @@ def optimize_iter(P, optimizer, model, topo, cfg, sample, stage, tex_painted, uv
     optimizer.step()
     out = {k: float(v.detach()) for k, v in log.items()}
     out["total"] = float(E.detach())
-    if "diffuse_detach_normal" in extras:             # reg_diffuse = w (relu(max - 1) + ...) has a kink at max = 1: tests keep away from it
-        out["diffuse_max"] = float(extras["diffuse_detach_normal"].detach().max())
+    if "diffuse_detach_normal" in extras:
+        # reg_diffuse = w (relu(max(diffuse) - 1) + ...) (tracker.py:547-550): the max runs over pixels AND colour channels, and its gradient
+        # goes to the arg-max element only -- where two channels' maxima meet, the gradient w.r.t. `lights` jumps from one column to the
+        # other.  Reported so that trajectory tests can keep off that ridge (tests/test_fit_parity_gpu.py).
+        d = extras["diffuse_detach_normal"].detach()
+        per_channel = torch.sort(d.reshape(-1, d.shape[-1]).max(dim=0).values, descending=True).values
+        out["diffuse_max"] = float(per_channel[0])
+        out["diffuse_channel_gap"] = float(per_channel[0] - per_channel[1])
     return out
 
 

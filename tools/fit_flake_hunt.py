@@ -11,7 +11,10 @@ either sign.  A missing stream / graph edge would look the same.  This tool sepa
   2. per step k and parameter: the spread of the step-k GRADIENT over runs that still share (bit for bit) the parameters of step k
      -- pure summation-order noise; a race (a kernel reading a buffer another branch has not finished) would show as a spread orders of
      magnitude above the fp32 round-off of the sums;
-  3. for every run whose exported `lights` leave the pack: the first step at which it left, the component that did it, that
+  3. for every run whose exported `lights` leave the pack (and for run 0): per step the oracle's max(diffuse) and how far the leading colour
+     channel's maximum is ahead of the second -- reg_diffuse = w (relu(max(diffuse) - 1) + ...) sends its gradient to the arg-max element
+     only, so the gradient w.r.t. `lights` is discontinuous where two channels' maxima meet; and
+  4. for every such run: the first step at which it left, the component that did it, that
      component's gradient in the run and in the oracle (evaluated at THE RUN'S OWN parameters of that step, same visibility), and the
      max-norm distance of the whole step-k gradient to the oracle's.
 
@@ -32,7 +35,9 @@ SMALL = ("lights", "shape", "focal_length", "rotation", "translation", "neck_pos
 def main():
     runs = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     K = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-    lights_scale = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0      # 1.0: the scene sits on the kink of reg_diffuse; 1.25: off it
+    # 1: near-white lights -- the fit runs onto the ridge of reg_diffuse's max over colour channels; "1.3,1.15,1.0": channels apart, off it
+    lights_scale = tuple(float(v) for v in sys.argv[3].split(",")) if len(sys.argv) > 3 else (1.0,)
+    tag = "x".join(f"{v:g}" for v in lights_scale)
     from oracle import energy_ref
     from tests.test_fit_parity_gpu import NAMES, _make
     from vhap_amd.step import NativeStep
@@ -65,7 +70,9 @@ def main():
         E, _, ex = energy_ref.total_energy(P, tm, topo, cfg, o_sample, stage, S["base_tex"], uvmask, (H, W), tid=tid)
         E.backward()
         out = {k: (P[k].grad if P[k].grad is not None else torch.zeros_like(P[k])) for k in NAMES}
-        out["_dmax"] = float(ex["diffuse_detach_normal"].detach().max())       # reg_diffuse's relu(max(diffuse) - 1) has its kink at 1
+        d = ex["diffuse_detach_normal"].detach()                                 # reg_diffuse: max over pixels AND channels, gradient to the arg-max only
+        pc = torch.sort(d.reshape(-1, d.shape[-1]).max(dim=0).values, descending=True).values
+        out["_dmax"], out["_gap"] = float(pc[0]), float(pc[0] - pc[1])
         return out
 
     for mode in ("eager", "captured"):
@@ -161,8 +168,8 @@ def main():
                     if n in g:
                         row.append(f"{n} cap {rel(g[n], go[n]):.1e} eag {rel(ge[n], go[n]):.1e} c-e {rel(g[n], ge[n]):.1e}")
                 dl = float((PR[r][k]["lights"] - PR[0][k]["lights"]).abs().max()) / lr_l
-                lines.append(f"   step {k}: " + " | ".join(row) + f" | tid diff {ndiff} px | lights vs run 0: {dl:.2f} lr | oracle max(diffuse) - 1 = "
-                             f"{go['_dmax'] - 1.0:+.2e}")
+                lines.append(f"   step {k}: " + " | ".join(row) + f" | tid diff {ndiff} px | lights vs run 0: {dl:.2f} lr | oracle max(diffuse) "
+                             f"{go['_dmax']:.4f}, leading channel ahead of the second by {go['_gap']:.2e}")
                 if r > 0 and k > 0:
                     # components of lights that this step moved the other way than run 0 did: their gradient in both runs and in the oracle
                     mv_r = PR[r][k]["lights"] - PR[r][k - 1]["lights"]
@@ -177,7 +184,7 @@ def main():
         del ns, ns_e, st
     reset()
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", f"fit_flake_hunt_lights_x{lights_scale:g}.txt"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", f"fit_flake_hunt_lights_{tag}.txt"), "w") as f:
         f.write("\n".join(lines) + "\n")
     print("\n".join(lines))
 

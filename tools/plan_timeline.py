@@ -24,9 +24,13 @@ def main():
     ap.add_argument("--reps", type=int, default=9)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "plan_timeline.txt"))
+    ap.add_argument("--two-pass-tex", action="store_true", help="A/B: texture gradient finish and its Adam update as two passes")
     args = ap.parse_args()
     import bench
+    from vhap_amd import step as vstep
     from vhap_amd.tracker import GraphedStep
+    if args.two_pass_tex:
+        vstep.FUSE_TEX_ADAM = False
     C = bench.CONFIGS[args.config]
     torch.cuda.set_device(0)
     tr, own, n_local, model, topo, gt = bench.build_tracker(C, 0, 1, "cuda:0", "weak")

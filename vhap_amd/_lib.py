@@ -84,6 +84,7 @@ SIGNATURES = {
     "vhap_camera_fwd": (c_i, [c_fp, c_fp] + [c_i] * 5 + [c_f, c_f, c_fp, c_fp]),
     "vhap_camera_focal_fwd": (c_i, [c_fp, c_f, c_f, c_f, c_fp] + [c_i] * 4 + [c_f, c_f, c_fp, c_fp]),
     "vhap_camera_bwd": (c_i, [c_fp, c_fp] + [c_i] * 4 + [c_fp, c_fp]),
+    "vhap_camera_focal_bwd": (c_i, [c_fp, c_fp] + [c_i] * 4 + [c_f, c_fp, c_fp]),
     "vhap_landmark_fwd": (c_i, [c_fp] * 5 + [c_i] * 8 + [c_f, c_i, c_i] + [c_fp] * 2 + [c_i, c_fp]),
     "vhap_landmark_bwd": (c_i, [c_fp] * 6 + [c_i] * 8 + [c_f, c_i, c_i] + [c_fp] * 3),
     "vhap_offset_reg_fwd": (c_i, [c_fp] * 8 + [c_i, c_i, c_f, c_f, c_f, c_fp, c_i, c_fp]),

@@ -78,6 +78,30 @@ __device__ __forceinline__ float vhap_wave_sum_dpp(float v) {
            (__int_as_float(__builtin_amdgcn_readlane(i, 32)) + __int_as_float(__builtin_amdgcn_readlane(i, 48)));
 }
 
+// the same reductions on 32-bit unsigned values (maximum / sum over the wave, result wave-uniform)
+template <int CTRL>
+__device__ __forceinline__ unsigned vhap_dpp_u(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+}
+__device__ __forceinline__ unsigned vhap_wave_max_u32_dpp(unsigned v) {
+    v = max(v, vhap_dpp_u<0xB1>(v));
+    v = max(v, vhap_dpp_u<0x4E>(v));
+    v = max(v, vhap_dpp_u<0x141>(v));
+    v = max(v, vhap_dpp_u<0x140>(v));
+    const int i = (int)v;
+    return max(max((unsigned)__builtin_amdgcn_readlane(i, 0), (unsigned)__builtin_amdgcn_readlane(i, 16)),
+               max((unsigned)__builtin_amdgcn_readlane(i, 32), (unsigned)__builtin_amdgcn_readlane(i, 48)));
+}
+__device__ __forceinline__ unsigned vhap_wave_sum_u32_dpp(unsigned v) {
+    v += vhap_dpp_u<0xB1>(v);
+    v += vhap_dpp_u<0x4E>(v);
+    v += vhap_dpp_u<0x141>(v);
+    v += vhap_dpp_u<0x140>(v);
+    const int i = (int)v;
+    return ((unsigned)__builtin_amdgcn_readlane(i, 0) + (unsigned)__builtin_amdgcn_readlane(i, 16)) +
+           ((unsigned)__builtin_amdgcn_readlane(i, 32) + (unsigned)__builtin_amdgcn_readlane(i, 48));
+}
+
 // Zero-fill / copy as ordinary kernel launches.  hipMemsetAsync / hipMemcpyAsync become memset / memcpy NODES under
 // stream capture, and on ROCm 7.2 those nodes were observed to run out of order with the neighbouring kernel nodes when
 // the graph is replayed on the null stream (stale accumulators, tools/debug_graph6.py) -- kernels nodes keep their order.

@@ -722,6 +722,46 @@ extern "C" int vhap_camera_focal_fwd(const float* focal_length, float focal_scal
     return VHAP_OK;
 }
 
+// camera backward of the monocular case in ONE launch: d(focal_length) += scale * sum_b (dK[b].fx + dK[b].fy)  (K = (f, f, cx, cy), f =
+// focal_length * scale: vhap_camera_bwd + vhap_focal_bwd, two launches on the tail of the step's geometry chain).  The per-frame values
+// meet in LDS and lane 0 adds them in frame order -- the same sum, in the same order, as the two-launch form.
+__global__ __launch_bounds__(64) void camera_focal_bwd_kernel(const float* __restrict__ RT, const float* __restrict__ d_mvp, int B, int rtstride,
+                                                              float h, float w, float scale, float* __restrict__ d_focal) {
+    __shared__ float part[64];
+    float s = 0.f;
+    for (int b0 = 0; b0 < B; b0 += 64) {
+        const int b = b0 + (int)threadIdx.x;
+        float v = 0.f;
+        if (b < B) {
+            const float* rt = RT + (size_t)b * rtstride;
+            const float* d = d_mvp + (size_t)b * 16;
+            float g0 = 0.f, g1 = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                g0 += d[c] * rt[c];
+                g1 += d[4 + c] * rt[4 + c];
+            }
+            v = g0 * 2.0f / w + g1 * 2.0f / h;
+        }
+        part[threadIdx.x] = v;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (int k = 0; k < min(64, B - b0); k++) s += part[k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) d_focal[0] += s * scale;
+}
+
+extern "C" int vhap_camera_focal_bwd(const float* RT, const float* d_mvp, int B, int RT_batched, int H, int W, float scale,
+                                     float* d_focal_accum, vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!RT || !d_mvp || !d_focal_accum) return VHAP_E_NULLPTR;
+    if (B <= 0 || H <= 0 || W <= 0) return VHAP_E_BADDIM;
+    camera_focal_bwd_kernel<<<1, 64, 0, vhap_stream(stream)>>>(RT, d_mvp, B, RT_batched ? 12 : 0, (float)H, (float)W, scale, d_focal_accum);
+    VHAP_LAUNCH_CHECK();
+    return VHAP_OK;
+}
+
 extern "C" int vhap_camera_bwd(const float* RT, const float* d_mvp, int B, int RT_batched, int H, int W, float* d_K, vhap_stream_t stream) {
     VHAP_ENTER();
     if (!RT || !d_mvp || !d_K) return VHAP_E_NULLPTR;

@@ -704,11 +704,19 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterParams P) {
             }
         }
         if (P.stats_part) {         // statistics of the diffuse regulariser (tracker.py:547-550): one partial per wave, no atomics
-            var = vhap_wave_sum(var);
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)mx, o, 64), hi = (unsigned)__shfl_xor((int)(unsigned)(mx >> 32), o, 64);
-                mx = sh_merge_max(mx, ((unsigned long long)hi << 32) | lo);
+            if (__ballot(cov) == 0ull && __ballot(in_img) == ~0ull) {
+                // a full background block (70 % of the waves): every lane shaded the same constant normal -- 64 identical values, whose
+                // tree sum is exactly 64 v and whose maximum is the value itself with 64 times its ties: no cross-lane traffic at all
+                var *= 64.0f;
+                mx = (mx & 0xffffffff00000000ull) | ((mx & 0xffffffffull) * 64ull);
+            } else {
+                // DPP reductions on the VALU (18 ds_bpermute per wave before): sum of the variances; the maximum of the ordered high
+                // words, then the tie counts of the lanes that hold it
+                var = vhap_wave_sum_dpp(var);
+                const unsigned hi = (unsigned)(mx >> 32);
+                const unsigned wmax = vhap_wave_max_u32_dpp(hi);
+                const unsigned ties = vhap_wave_sum_u32_dpp(hi == wmax ? (unsigned)mx : 0u);
+                mx = ((unsigned long long)wmax << 32) | ties;
             }
             if (lane == 0) P.stats_part[(size_t)blockIdx.x * 4 + wave] = make_uint4((unsigned)mx, (unsigned)(mx >> 32), __float_as_uint(var), 0u);
         }

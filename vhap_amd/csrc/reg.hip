@@ -202,6 +202,7 @@ struct TexAdam {
 // (Round 2's version was one texel per thread on a 1-D grid: a 64-bit division per texel, five scattered taps of the albedo, 2.7 TB/s
 // against the 5.9 TB/s of the Adam pass behind it -- 25 + 63 + 60 us on the tail of the step for fold + this + Adam.)
 constexpr int TEXB_ROWS = 16;
+constexpr int TEXB_MAXG = 12;         // mip levels gathered per texel (T <= 4096 whole; larger textures fold their coarsest levels first)
 template <bool ADAM>
 __global__ __launch_bounds__(RB) void tex_prep_bwd_kernel(TexCfg c, const float* __restrict__ albedo, const float* __restrict__ extra,
                                                           const unsigned char* __restrict__ res_mask, const float* __restrict__ d_albedo,
@@ -231,25 +232,48 @@ __global__ __launch_bounds__(RB) void tex_prep_bwd_kernel(TexCfg c, const float*
     };
     float up[3] = {0.f, 0.f, 0.f}, cur[3] = {0.f, 0.f, 0.f}, dn[3] = {0.f, 0.f, 0.f};
     if (tv) { load_row(y0 - 1, x, up); load_row(y0, x, cur); }
-#pragma unroll 4
-    for (int r = 0; r < TEXB_ROWS; r++) {
+    // (restrict-qualified copies: stores through members of a by-value struct are otherwise assumed to alias every later load, which
+    // pins each row's loads behind the previous row's stores)
+    float* __restrict__ const adam_p = A.p;
+    float* __restrict__ const adam_m = A.m;
+    float* __restrict__ const adam_v = A.v;
+    // the mip levels to gather: (offset, shift, weight) per slot, uniform.  ALWAYS TEXB_MAXG slots -- the ones beyond n_gather re-read the
+    // last level with weight 0 (g + 0 * m == g exactly) -- so that the loads of a texel are one unconditional, independent batch (a
+    // run-time trip count made every level wait for its own load: eleven memory latencies per texel)
+    size_t g_off[TEXB_MAXG];
+    int g_sh[TEXB_MAXG];
+    float g_sc[TEXB_MAXG];
+    {
+        size_t off = 0;
+        float sc = 0.25f;
+#pragma unroll
+        for (int u = 0; u < TEXB_MAXG; u++) {
+            const int l = u + 1;
+            const bool on = l <= n_gather;
+            g_off[u] = on ? off : (u > 0 ? g_off[u - 1] : 0);
+            g_sh[u] = on ? l : (u > 0 ? g_sh[u - 1] : 0);
+            g_sc[u] = on ? sc : 0.f;
+            if (on) off += (size_t)(T >> l) * (T >> l) * 3;
+            sc *= 0.25f;
+        }
+    }
+    const int nrows = min(TEXB_ROWS, T - y0);
+    for (int r = 0; r < nrows; r++) {
         const int y = y0 + r;
-        if (y >= T) break;
         const size_t i = (size_t)y * T + x;
         if (tv) load_row(y + 1, x, dn);
         float g[3] = {0.f, 0.f, 0.f};
         if (in_x) {
             if (d_albedo) { g[0] = d_albedo[3 * i]; g[1] = d_albedo[3 * i + 1]; g[2] = d_albedo[3 * i + 2]; }
             if (d_mips) {
-                size_t off = 0;
-                float sc = 0.25f;
-                for (int l = 1; l <= n_gather; l++) {
-                    const int tl = T >> l;
-                    const float* m = d_mips + off + 3 * ((size_t)(y >> l) * tl + (x >> l));
-                    g[0] += sc * m[0]; g[1] += sc * m[1]; g[2] += sc * m[2];
-                    off += (size_t)tl * tl * 3;
-                    sc *= 0.25f;
+                float m[TEXB_MAXG][3];
+#pragma unroll
+                for (int u = 0; u < TEXB_MAXG; u++) {
+                    const float* q = d_mips + g_off[u] + 3 * ((size_t)(y >> g_sh[u]) * (T >> g_sh[u]) + (x >> g_sh[u]));
+                    m[u][0] = q[0]; m[u][1] = q[1]; m[u][2] = q[2];
                 }
+#pragma unroll
+                for (int u = 0; u < TEXB_MAXG; u++) { g[0] += g_sc[u] * m[u][0]; g[1] += g_sc[u] * m[u][1]; g[2] += g_sc[u] * m[u][2]; }    // level order
             }
         }
         if (tv) {
@@ -275,7 +299,7 @@ __global__ __launch_bounds__(RB) void tex_prep_bwd_kernel(TexCfg c, const float*
             const bool res = gres != 0.f && res_mask && res_mask[i];
             if (res || ADAM) {
 #pragma unroll
-                for (int k = 0; k < 3; k++) ex[k] = extra[k * plane + i];
+                for (int k = 0; k < 3; k++) ex[k] = ADAM ? adam_p[k * plane + i] : extra[k * plane + i];    // (ADAM: `extra` IS the parameter being updated)
             }
             if (res) {
 #pragma unroll
@@ -287,12 +311,12 @@ __global__ __launch_bounds__(RB) void tex_prep_bwd_kernel(TexCfg c, const float*
                 for (int k = 0; k < 3; k++) {
                     const size_t j = k * plane + i;
                     const float gi = g[k];
-                    const float m0 = A.m[j];
+                    const float m0 = adam_m[j];
                     const float mi = m0 + (gi - m0) * (1.0f - A.beta1);              // lerp, like torch
-                    const float vi = A.beta2 * A.v[j] + (1.0f - A.beta2) * gi * gi;
-                    A.m[j] = mi;
-                    A.v[j] = vi;
-                    A.p[j] = ex[k] - step_size * mi / (sqrtf(vi) / bc2s + A.eps);
+                    const float vi = A.beta2 * adam_v[j] + (1.0f - A.beta2) * gi * gi;
+                    adam_m[j] = mi;
+                    adam_v[j] = vi;
+                    adam_p[j] = ex[k] - step_size * mi / (sqrtf(vi) / bc2s + A.eps);
                 }
             }
         }
@@ -403,7 +427,7 @@ extern "C" int vhap_tex_prep_bwd(const float* albedo_hwc, const float* extra, co
                                  float* d_extra, vhap_stream_t stream) {
     VHAP_ENTER();
     if (!albedo_hwc || !extra || !d_terms || !d_extra) return VHAP_E_NULLPTR;
-    if (T <= 0 || n_gather < 0 || (d_mips_hwc && n_gather > 0 && (T & ((1 << n_gather) - 1)))) return VHAP_E_BADDIM;
+    if (T <= 0 || n_gather < 0 || n_gather > TEXB_MAXG || (d_mips_hwc && n_gather > 0 && (T & ((1 << n_gather) - 1)))) return VHAP_E_BADDIM;
     TexCfg c{T, s_tv, s_res};
     tex_prep_bwd_kernel<false><<<dim3(vhap_cdiv(T, RB), vhap_cdiv(T, TEXB_ROWS)), RB, 0, vhap_stream(stream)>>>(
         c, albedo_hwc, extra, res_mask, d_albedo_hwc, n_gather > 0 ? d_mips_hwc : nullptr, n_gather, d_terms, d_extra, TexAdam{}, 0);
@@ -417,7 +441,7 @@ extern "C" int vhap_tex_prep_bwd_adam(const float* albedo_hwc, float* extra, con
                                       float beta1, float beta2, float eps, int call_flags, vhap_stream_t stream) {
     VHAP_ENTER();
     if (!albedo_hwc || !extra || !d_terms || !d_extra || !exp_avg || !exp_avg_sq || !lr_device || !step_device) return VHAP_E_NULLPTR;
-    if (T <= 0 || n_gather < 0 || (d_mips_hwc && n_gather > 0 && (T & ((1 << n_gather) - 1)))) return VHAP_E_BADDIM;
+    if (T <= 0 || n_gather < 0 || n_gather > TEXB_MAXG || (d_mips_hwc && n_gather > 0 && (T & ((1 << n_gather) - 1)))) return VHAP_E_BADDIM;
     TexCfg c{T, s_tv, s_res};
     tex_prep_bwd_kernel<true><<<dim3(vhap_cdiv(T, RB), vhap_cdiv(T, TEXB_ROWS)), RB, 0, vhap_stream(stream)>>>(
         c, albedo_hwc, extra, res_mask, d_albedo_hwc, n_gather > 0 ? d_mips_hwc : nullptr, n_gather, d_terms, d_extra,

@@ -225,7 +225,7 @@ def offset_reg(om, offset, w_lap, w_abs, w_rigid):
 def _n_gather(T):
     """Mip levels whose fold is fused into vhap_tex_prep_bwd (gathered per texel) instead of separate read-modify-write passes."""
     n = 0
-    while T % (1 << (n + 1)) == 0 and (T >> (n + 1)) >= 1:
+    while n < 12 and T % (1 << (n + 1)) == 0 and (T >> (n + 1)) >= 1:      # (12 = TEXB_MAXG of csrc/reg.hip: every level up to T = 4096)
         n += 1
     return n
 

@@ -24,6 +24,8 @@ from .ops import _hook, _p, _stream
 
 PRE = _lib.CALL_ACC_PREZEROED        # per-call flag (ABI 2): this call's small accumulators were cleared by the arena clear
 
+FUSE_TEX_ADAM = True     # the texture's Adam update inside the gradient-finishing pass (tools flip it to time the two-pass form)
+
 LOG_NAMES = ("lmk", "photo", "smooth_pose", "reg_joint", "smooth_joint", "reg_expr", "smooth_expr", "reg_shape", "reg_tex_tv",
              "reg_tex_res_clusters", "reg_diffuse", "reg_offset_lap", "reg_offset", "reg_offset_rigid", "rest", "total")
 
@@ -556,7 +558,7 @@ class NativeStep:
         ng = _n_gather(T) if has_mips else 0
         if has_mips and ng < L.vhap_texture_num_levels(T, T):      # (texture sizes whose coarse levels cannot be gathered: fold them first)
             _chk(L.vhap_texture_mip_fold(_p(d_tex), _p(d_mips), 1, T, T, 3, ng, st), "vhap_texture_mip_fold")
-        fu = optimizer.fused_update_args(tr.tex_extra) if (optimizer is not None and hasattr(optimizer, "fused_update_args")) else None
+        fu = optimizer.fused_update_args(tr.tex_extra) if (FUSE_TEX_ADAM and optimizer is not None and hasattr(optimizer, "fused_update_args")) else None
         if fu is not None:
             m, v, lr, step, b1, b2, eps = fu
             flags = _lib.CALL_ADAM_STEP_ADVANCED if self.step_optimizer is not None else 0
@@ -641,6 +643,9 @@ class NativeStep:
                                            _p(acc[12:16]) if self.want_reg else 0, self.B, self.H, self.W, _p(self.g["lights"]), _stream()),
              "vhap_deferred_lights_reduce")
         self._clear_delta()
+        if self.one_graph:            # the next step's forward accumulators: their last reader of THIS step is the reduction above
+            self.accF.zero_()
+            self._acc_clean = True
 
     def _clear_delta(self):
         if self.aa_inplace:
@@ -660,8 +665,8 @@ class NativeStep:
         B, H, W, V, J = self.B, self.H, self.W, self.V, self.J
         st = _stream()
         if not self.calibrated:                                       # the focal length is a parameter only without calibration (tracker.py:148-157)
-            _chk(L.vhap_camera_bwd(_p(self.RT), _p(self.d_mvp), B, 0, H, W, _p(self.d_K), st), "vhap_camera_bwd")
-            _chk(L.vhap_focal_bwd(_p(self.d_K), B, self.focal_scale, _p(g["focal_length"]), st), "vhap_focal_bwd")
+            _chk(L.vhap_camera_focal_bwd(_p(self.RT), _p(self.d_mvp), B, 0, H, W, self.focal_scale, _p(g["focal_length"]), st),
+                 "vhap_camera_focal_bwd")
         _chk(L.vhap_flame_skin_bwd(_p(g["d_verts"]), 0, _p(self.v_posed), _p(self.A), _p(fb.w), _p(fb.basisT), B, V, fb.Vp, fb.Kb, fb.Kp,
                                    _p(self.g_posed), _p(self.g_shaped), 0, _p(g["d_coef"]), _p(g["d_A"]), _p(g["d_t"]), PRE, st),
              "vhap_flame_skin_bwd")
@@ -701,14 +706,16 @@ class NativeStep:
                                     fb.Vp, fb.Kb, fb.Kp, _p(self.vn_scratch), _p(self.g_posed), _p(self.g_shaped), _p(g["d_coef"]), _p(g["d_A"]),
                                     _p(g["d_t"]), _p(self.d_mvp), _p(g["static_offset"]) if self.has_offset else 0, PRE, st), "vhap_verts_bwd_fused")
         if not self.calibrated:
-            _chk(L.vhap_camera_bwd(_p(self.RT), _p(self.d_mvp), B, 0, H, W, _p(self.d_K), st), "vhap_camera_bwd")
-            _chk(L.vhap_focal_bwd(_p(self.d_K), B, self.focal_scale, _p(g["focal_length"]), st), "vhap_focal_bwd")
+            # the camera backward (d_mvp -> d focal_length: one tiny launch) feeds nothing but Adam: beside the per-frame backward, not ahead of it
+            self._side(lambda: _chk(L.vhap_camera_focal_bwd(_p(self.RT), _p(self.d_mvp), B, 0, H, W, self.focal_scale, _p(g["focal_length"]),
+                                                            _stream()), "vhap_camera_focal_bwd"), self.side2)
         _chk(L.vhap_frame_prep_bwd(_p(self.ts), _p(tr.shape), _p(tr.expr), _p(tr.rotation), _p(tr.translation), _p(tr.neck_pose),
                                    _p(tr.jaw_pose), _p(tr.eyes_pose), _p(fm.JS), _p(fm.jreg_idx), _p(fm.jreg_w), fm.jreg_n,
                                    _p(tr.static_offset), fm.parents, self.weights, _p(self.Jrest), _p(g["d_coef"]), _p(g["d_A"]), _p(g["d_t"]),
                                    _p(self.ones), B, self.Bp, self.N, self.NS, self.NE, J, fb.Kp, V, _p(g["shape"]), _p(g["expr"]),
                                    _p(g["rotation"]), _p(g["translation"]), _p(g["neck_pose"]), _p(g["jaw_pose"]), _p(g["eyes_pose"]),
                                    _p(g["static_offset"]) if self.has_offset else 0, st), "vhap_frame_prep_bwd")
+        self._flush()                                                 # (the camera backward: forked behind the vertex stage, issued behind the per-frame backward's launch)
 
     def backward(self, world_size=1, part="all", optimizer=None):
         """part = 'all': the whole backward as one DAG of up to three branches (one GPU).  `optimizer`: a HipAdam whose texture update is
@@ -756,9 +763,6 @@ class NativeStep:
                 torch.cuda.current_stream().wait_stream(self.side2)
             if self.step_optimizer is not None:                       # every other parameter: next to the tail of the texture branch
                 self.step_optimizer.step(skip=(self.tr.tex_extra,), advanced=True)
-            if self.one_graph:                                        # the next step's forward accumulators (this chain has slack here)
-                self.accF.zero_()
-                self._acc_clean = True
             self._join()
         elif part == "pixel_tex":
             self._bwd_pixel(world_size)
@@ -777,6 +781,8 @@ class NativeStep:
                     early.record()
             self._bwd_uv()
             self._bwd_geometry(early)
+            if self.overlap:
+                torch.cuda.current_stream().wait_stream(self.side2)  # (the camera backward)
             self._join()
         else:
             raise ValueError(part)

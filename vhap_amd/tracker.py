@@ -760,28 +760,65 @@ class GlobalTracker(FlameTracker):
         direct = isinstance(dataloader, ShuffledBatches) and self.frames is not None and self.dist is None
         H, W = self.image_size
         for epoch_i in range(self.cfg.pipeline[stage].num_epochs):
-            for s in (dataloader.index_batches() if direct else dataloader):
-                if direct:
-                    ts = s
-                    n = len(ts) if self._frames_of is None else sum(len(self._frames_of[int(t)]) for t in ts)
-                    st = self._graphed.get((stage, (n, 3, H, W), float(lr_scale)))
-                    if st is None or (opt is not None and st.opt is not opt):
-                        st = step_for(self.get_sample(ts, device_index=True), opt)
+            if direct:
+                # the whole pass's frame indices / timesteps in ONE upload; per step only device-side slices of them
+                batches = []
+                for ts in dataloader.index_batches():
+                    ts = np.asarray(ts).reshape(-1)
+                    if self._frames_of is not None:
+                        fidx = np.concatenate([self._frames_of[int(t)] for t in ts])
+                        ts_f = self.frame_timestep[fidx]
                     else:
-                        self.get_train_parameters(stage)
-                        st.update_timesteps(ts)
-                else:
+                        fidx = ts_f = ts
+                    batches.append((ts, fidx, ts_f))
+                fidx_dev = torch.as_tensor(np.concatenate([b[1] for b in batches]), device=self.device)
+                tsf_dev = torch.as_tensor(np.concatenate([b[2] for b in batches]), device=self.device)
+                ctx, cur_st, o = None, None, 0
+                try:
+                    for ts, fidx, _ in batches:
+                        n = len(fidx)
+                        st = self._graphed.get((stage, (n, 3, H, W), float(lr_scale)))
+                        fresh = st is None or (opt is not None and st.opt is not opt)
+                        if fresh:
+                            if ctx is not None:
+                                ctx.__exit__(None, None, None)
+                                ctx, cur_st = None, None
+                            st = step_for(self.get_sample(ts, device_index=True), opt)
+                        if opt is None:
+                            opt = st.opt
+                            if not getattr(st, "fresh", False):
+                                _reset_optimizer(opt)
+                            for grp in opt.param_groups:          # a scheduler of a previous call may have decayed them
+                                grp["lr"] = grp["initial_lr"] if "initial_lr" in grp else grp["lr"]
+                            sched = torch.optim.lr_scheduler.ExponentialLR(opt, gamma=0.9)
+                        st.fresh = False
+                        if st is not cur_st:                      # the step's own stream stays current across the steps of a pass: no stream hop per step
+                            if ctx is not None:
+                                ctx.__exit__(None, None, None)
+                            ctx = st.replay_stream()
+                            ctx.__enter__()
+                            cur_st = st
+                        if not fresh:
+                            self.get_train_parameters(stage)
+                            st.update_timesteps(ts, fidx_dev[o:o + n], tsf_dev[o:o + n])
+                        o += n
+                        st()
+                finally:
+                    if ctx is not None:
+                        ctx.__exit__(None, None, None)
+            else:
+                for s in dataloader:
                     st = step_for(s, opt)                          # one optimiser (one Adam state) for every batch shape of this call
-                if opt is None:
-                    opt = st.opt
-                    if not getattr(st, "fresh", False):
-                        _reset_optimizer(opt)
-                    for grp in opt.param_groups:                  # a scheduler of a previous call may have decayed them
-                        grp["lr"] = grp["initial_lr"] if "initial_lr" in grp else grp["lr"]
-                    sched = torch.optim.lr_scheduler.ExponentialLR(opt, gamma=0.9)
-                st.fresh = False
-                with st.replay_stream():
-                    st()
+                    if opt is None:
+                        opt = st.opt
+                        if not getattr(st, "fresh", False):
+                            _reset_optimizer(opt)
+                        for grp in opt.param_groups:              # a scheduler of a previous call may have decayed them
+                            grp["lr"] = grp["initial_lr"] if "initial_lr" in grp else grp["lr"]
+                        sched = torch.optim.lr_scheduler.ExponentialLR(opt, gamma=0.9)
+                    st.fresh = False
+                    with st.replay_stream():
+                        st()
             sched.step()
             if evaluate_every and (epoch_i + 1) % evaluate_every == 0:
                 self.evaluate()
@@ -1191,29 +1228,34 @@ class GraphedStep:
         finally:
             tracker._split = None
 
-    def update_timesteps(self, timesteps):
+    def update_timesteps(self, timesteps, frame_index_dev=None, timestep_dev=None):
         """Feed the batch of these timesteps from the tracker's dataset; with a uint8 FrameStore the frames are converted straight
         into the static rgb buffer (no intermediate fp32 batch).  Multi-view datasets: every view of the timesteps, each frame carrying
-        ITS timestep -- the same frame-index expansion as GlobalTracker.get_sample."""
+        ITS timestep -- the same frame-index expansion as GlobalTracker.get_sample.  `frame_index_dev` / `timestep_dev`: the frame
+        indices and their timesteps already on the device (optimize_stage uploads a whole pass of shuffled batches at once: a per-step
+        host-to-device copy of the indices would stall the launch queue every step)."""
         tr = self.tr
         if tr.frames is None:
             return self.update_sample(tr.get_sample(timesteps, device_index=True))
-        ts = np.asarray(timesteps).reshape(-1)
-        if tr._frames_of is not None:
-            fidx = np.concatenate([tr._frames_of[int(t)] for t in ts])
-            ts = tr.frame_timestep[fidx]
-        else:
-            fidx = ts
         dev = self.sample["timestep_index"].device
-        idx = torch.as_tensor(fidx, device=dev)
+        if frame_index_dev is None:
+            ts = np.asarray(timesteps).reshape(-1)
+            if tr._frames_of is not None:
+                fidx = np.concatenate([tr._frames_of[int(t)] for t in ts])
+                ts = tr.frame_timestep[fidx]
+            else:
+                fidx = ts
+            frame_index_dev = torch.as_tensor(fidx, device=dev)
+            timestep_dev = torch.as_tensor(ts, device=dev)
+        idx = frame_index_dev
         if idx.shape != self.sample["timestep_index"].shape:
             raise ValueError("GraphedStep.update_timesteps: batch size differs from the captured one")
         tr.frames.batch(idx, out=self.sample["rgb"])
-        self.sample["lmk2d"].copy_(tr.dataset["lmk2d"][idx])
-        self.sample["timestep_index"].copy_(torch.as_tensor(ts, device=dev))
+        torch.index_select(tr.dataset["lmk2d"], 0, idx, out=self.sample["lmk2d"])
+        self.sample["timestep_index"].copy_(timestep_dev)
         for k in ("intrinsic", "extrinsic"):
             if k in self.sample:
-                self.sample[k].copy_(tr.dataset[k][idx])
+                torch.index_select(tr.dataset[k], 0, idx, out=self.sample[k])
 
     def update_sample(self, sample):
         """Feed a new batch of the SAME shapes: copied into the static buffers the graphs read."""
