@@ -1,4 +1,4 @@
-"""Per-step kernel table from a rocprofv3 --kernel-trace CSV of bench.py: one graph-replayed step, kernels in launch order
+"""Per-step kernel table from a rocprofv3 --kernel-trace CSV of bench.py: one replayed step (frame_prep_fwd to the kernel before the next one), kernels in launch order
 grouped by name (count, total us).  usage: python tools/step_profile.py <kernel_trace.csv | results.db> [--seq | --timeline]
 (rocprofv3 --kernel-trace writes a rocpd .db unless --output-format csv is given; both are read)
 (--timeline: start offset, duration, HW queue and name of every kernel of the step -- shows what overlaps with what)"""
@@ -20,7 +20,7 @@ first = "frame_prep_fwd" if any("frame_prep_fwd" in r["Kernel_Name"] for r in ro
 starts = [i for i, r in enumerate(rows) if first in r["Kernel_Name"]]
 k = int(sys.argv[sys.argv.index("--step") + 1]) if "--step" in sys.argv else len(starts) // 2
 s, e = starts[k], starts[k + 1]            # one step well inside the timed graph replays (bench.py issues a few eager steps at the end)
-seq = rows[s - 1:e - 1]
+seq = rows[s:e]
 dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
 
 

@@ -457,21 +457,15 @@ class NativeStep:
         if self.disturb_on:
             self._disturb(st)
         self._flush()
+        sort_branch = None
         if self.tb_ids:
             # the counting sort of the pixels by uv tile (for the texture gradient) needs only the tile ids the rasteriser wrote and the
-            # disturbance's keep mask (replaced pixels pass no gradient): on the side branch NOW, next to the rest of the forward pass,
-            # instead of on the backward's critical path
-            self._sort_fork = None
-
+            # disturbance's keep mask (replaced pixels pass no gradient): beside the pixel chain instead of on the backward's critical path
             def sort_branch():
-                if self.one_graph:
-                    # everything the energy assembly needs from this branch is in front of this point; the sort itself is only needed by the
-                    # backward's texture chain, which runs on this very stream: the forward does not wait for it
-                    self._sort_fork = torch.cuda.Event()
-                    self._sort_fork.record()
                 _chk(L.vhap_texbin_sort_ids(_p(self.tile_ids), _p(self.keep) if self.disturb_on else 0, T, T, B, H, W,
                                             _p(self.texbin_work), self.texbin_work.numel(), _stream()), "vhap_texbin_sort_ids")
-            self._side(sort_branch)
+            if not self.one_graph:
+                self._side(sort_branch)                           # (eager / sharded: next to the rest of the forward pass)
         self.aa_in = color
         if self.aa_inplace:
             if self._aa_det is not None or self._pending:
@@ -491,13 +485,15 @@ class NativeStep:
         if self.energy_fused:
             # one GPU: the photometric sum's last workgroup assembles the energy and the upstream gradient (no single-thread launches -- and
             # no cross-queue hand-overs -- between the forward and the backward pass)
-            if self.tb_ids and getattr(self, "_sort_fork", None) is not None:
-                torch.cuda.current_stream().wait_event(self._sort_fork)
-            else:
-                self._join()
+            self._join()          # the side branch: texture assembly, landmarks, statistics, arena clear, antialias pair discovery
             _chk(L.vhap_photo_fwd_total(_p(self.rgba_aa), _p(self.rgb), B, H, W, _p(acc[16:19]), _p(acc[0:6]), _p(acc[6:7]) if self.w_lmk else 0,
                                         _p(acc[7:9]), _p(acc[9:12]), _p(acc[12:16]), self.w_lmk, self.w_reg, self.w_photo,
                                         _p(self.log), _p(self.d_sum), _p(self.gmax_bound), _p(self.photo_work), PRE, st), "vhap_photo_fwd_total")
+            if sort_branch is not None and self.one_graph:
+                # captured step: the sort is needed only by the backward's texture chain, ~250 us from here.  Forked BEHIND the photometric
+                # sum -- next to it, it cost that bandwidth-bound reduction 20 us on the critical path (47 vs 26 us) -- it runs beside the
+                # shading backward (issued by the backward's first _flush)
+                self._side(sort_branch)
             return
         _chk(L.vhap_photo_fwd(_p(self.rgba_aa), _p(self.rgb), B, H, W, _p(acc[16:18]), PRE, st), "vhap_photo_fwd")
         self._join()
@@ -747,7 +743,7 @@ class NativeStep:
                 if self.overlap:
                     self._early_ev = torch.cuda.Event()
                     self._early_ev.record()
-            self._side(early_branch)
+            self._side(early_branch, self.side2)                     # (the other side stream: the texture-gradient sort may still be on the first)
             self._bwd_pixel(world_size, after_first=self._flush)
             # fork as soon as d_albedo exists: the texture gradient (uv-binned accumulation, then ONE pass that gathers the pyramid, adds the
             # regulariser gradients and applies the Adam update) on the side branch, the geometry chain on this one
