@@ -315,6 +315,11 @@ int vhap_antialias_inplace_fwd(float* color, const float* rast, const float* pos
  * colours (render_nvdiffrast.py:424-460 runs between the two); `blend` (edge analysis, in-place update) needs the final colours. */
 int vhap_antialias_inplace_detect(const float* rast, const float* pos, const int32_t* tri, const int32_t* opp, int B,
                                   int H, int W, int V, int F, int32_t* work, vhap_stream_t stream);
+/* detect in ITS two halves (silhouette + pairs == detect): the silhouette flags are a property of the geometry alone, so a step executor
+ * computes them beside the rasteriser and only the pixel-pair discovery behind it */
+int vhap_antialias_inplace_silhouette(const float* pos, const int32_t* tri, const int32_t* opp, int B, int H, int W, int V, int F,
+                                      int32_t* work, vhap_stream_t stream);
+int vhap_antialias_inplace_pairs(const float* rast, int B, int H, int W, int F, int32_t* work, vhap_stream_t stream);
 int vhap_antialias_inplace_blend(float* color, const float* rast, const float* pos, const int32_t* tri,
                                  const int32_t* opp, int B, int H, int W, int V, int F, int32_t* work,
                                  vhap_stream_t stream);

@@ -88,8 +88,8 @@ def optimize_iter(P, optimizer, model, topo, cfg, sample, stage, tex_painted, uv
     out["total"] = float(E.detach())
     if "diffuse_detach_normal" in extras:
         # reg_diffuse = w (relu(max(diffuse) - 1) + ...) (tracker.py:547-550): the max runs over pixels AND colour channels, and its gradient
-        # goes to the arg-max element only -- where two channels' maxima meet, the gradient w.r.t. `lights` jumps from one column to the
-        # other.  Reported so that trajectory tests can keep off that ridge (tests/test_fit_parity_gpu.py).
+        # goes to the arg-max element only.  Reported (maximum, lead of the first channel over the second) so that trajectory records show
+        # whether the max term was active and how far the fit is from a tie between channels.
         d = extras["diffuse_detach_normal"].detach()
         per_channel = torch.sort(d.reshape(-1, d.shape[-1]).max(dim=0).values, descending=True).values
         out["diffuse_max"] = float(per_channel[0])

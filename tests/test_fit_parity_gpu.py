@@ -25,19 +25,17 @@ Stated tolerances (fp32 product vs fp64 oracle):
   every exported array to 5e-3 in relative L2 (measured <= 1.0e-3), static_offset at the full learning rates -- it moves by its own
   size in these 10 steps -- to 5e-2 (measured 2.1e-2); energies along the trajectory to 5e-3 (measured <= 2.8e-4, 2e-7 while the two
   visibilities still agree).
-  the ridge of the energy: round 2 saw one run in five of the full-learning-rate trajectory end with `lights` 3.4e-2 (update L2) from the
-  oracle instead of 4e-5, and widened every bound to twice the oracle's own fp32-vs-fp64 spread.  Round 3 hunted it down
-  (tools/fit_flake_hunt.py, profiles/r03_fit_flake_hunt_*.txt: 40-60 runs x 2 executors, per-step gradients against the oracle at each
-  run's OWN parameters, eager re-evaluation of every suspicious step): no race -- the captured and the eagerly issued step give the same
-  gradient at the same parameters, bit for bit on `lights` -- but a RIDGE: reg_diffuse = w (relu(max(diffuse) - 1) + ...)
-  (tracker.py:547-550) takes its max over pixels AND colour channels and sends its gradient to the arg-max element alone.  Under
-  near-white lights the three channels' maxima are close; the regulariser pushes the leading one down until it MEETS the second
-  (3-6 steps here), and from then on the arg-max channel -- the column of `lights` that receives w d(diffuse)/d(lights), 97 % of the
-  gradient's max-norm in those runs -- is decided by the last bit of a float comparison: summation-order noise on the GPU, fp32 vs fp64
-  against the oracle.  The reference's torch.max has the same ridge.  These trajectory tests therefore start from lights with well
-  separated channels (scaled by 1.3 / 1.15 / 1.0: the leading channel's maximum stays > 0.03 above the second for the 10 steps --
-  asserted on the oracle's trajectory) and hold every array to the tight bounds above with no escape hatch; what happens ON the ridge
-  is in the committed record.
+  history: round 2 saw one run in five of the full-learning-rate trajectory end with `lights` 3.4e-2 (update L2) from the oracle instead
+  of 4e-5, blamed summation-order noise amplified by Adam, and widened every bound to twice the oracle's own fp32-vs-fp64 spread.
+  Round 3 hunted it down (tools/fit_flake_hunt.py, profiles/r03_fit_flake_hunt_*.txt: 40-60 runs x 2 executors, the gradient of every
+  step against the oracle at each run's OWN parameters, eager re-evaluation of every suspicious step): no race -- the captured and the
+  eagerly issued step give the same gradient at the same parameters, bit for bit on `lights` -- and no noise either, but a BUG: the
+  backward re-computes every pixel's diffuse value and routes reg_diffuse's max-gradient (tracker.py:547-550: relu(diffuse.max() - 1))
+  to the pixels whose value EQUALS the maximum the forward recorded; the forward kernel and the backward kernel contracted
+  different products of that arithmetic into fmas, so at about one parameter state in five the re-computed maximum missed the recorded
+  one by an ulp and the whole max term (up to 97 % of the gradient's max-norm on the affected rows of `lights`) silently vanished for
+  that step.  The shading arithmetic is now explicit round-to-nearest intrinsics in every kernel (csrc/shade_common.h); the escape
+  hatch is gone: every array is held to the tight bounds above.
 The measured values are written to gpurun_out/fit_parity_*.txt for the record."""
 import os
 
@@ -52,7 +50,7 @@ pytestmark = pytest.mark.gpu
 NAMES = ("shape", "expr", "rotation", "neck_pose", "jaw_pose", "eyes_pose", "translation", "tex_extra", "lights", "static_offset",
          "focal_length")
 
-LIGHTS_OFF_THE_RIDGE = (1.3, 1.15, 1.0)      # per colour channel (module docstring: the ridge of reg_diffuse's max)
+LIGHTS_SCALE = 1.0       # (a scalar, or one factor per colour channel: tools/fit_flake_hunt.py varies it)
 
 
 def _record(name, lines):
@@ -232,7 +230,7 @@ def _trajectory(S, stage, lr_scale, K, H, W, ts, same_visibility):
 
 @pytest.fixture(scope="module")
 def small(flame_model):
-    return _make(flame_model, 128, 128, 3, 256, seed=23, lights_scale=LIGHTS_OFF_THE_RIDGE)
+    return _make(flame_model, 128, 128, 3, 256, seed=23, lights_scale=LIGHTS_SCALE)
 
 
 @pytest.mark.parametrize("stage,lr_scale", [("rgb_global_tracking", 0.1), ("rgb_init_offset", 1.0)])
@@ -244,7 +242,7 @@ def test_ten_steps_export_matches_oracle_fit(small, stage, lr_scale, same_visibi
     assert set(hip) == set(ora), (sorted(hip), sorted(ora))              # same npz schema (tracker.py:1158-1218)
     lines = [f"stage {stage} lr_scale {lr_scale} K {K} same_visibility {same_visibility}; oracle max(diffuse) / gap to the second channel per step: "
              + " ".join(f"{d:.3f}/{g:.3f}" for d, g in dmax)]
-    assert min(g for _, g in dmax) > 0.03 and min(d for d, _ in dmax) > 1.05, f"the trajectory must stay off the ridge of reg_diffuse: {dmax}"
+    assert max(d for d, _ in dmax) > 1.0, "reg_diffuse's max term must be active (its gradient path is what this guards)"
     fails = []
     e_bound = 5e-4 if same_visibility else 5e-3          # (measured <= 1e-6 / 2.2e-5)
     for i, (a, b) in enumerate(zip(E_hip, E_ora)):

@@ -3,20 +3,23 @@
 Round 2 saw ONE run (of five) of tests/test_fit_parity_gpu.py's same-visibility rgb_init_offset trajectory end with `lights` 1e-3 (max-norm) /
 3.4e-2 (update L2) away from the oracle instead of the usual 1.5e-6 / 4e-5.  Explanation offered then: the gradient sums are float
 atomics in arbitrary order, and Adam's g / (|g| + eps) turns a component whose gradient sits inside that noise into a full +-lr step of
-either sign.  A missing stream / graph edge would look the same.  This tool separates the two:
+either sign.  A missing stream / graph edge would look the same.  This tool separates the candidates:
 
-  1. R trajectories of K steps from the SAME start, each in three executors -- eager NativeStep (side streams + events: what the failing
-     test ran), the captured step replayed by the plan executor (what ships) -- recording after EVERY step the gradient of every small
+  1. R trajectories of K steps from the SAME start, in two executors -- eager NativeStep (side streams + events: what the failing test
+     ran) and the captured step replayed by the plan executor (what ships) -- recording after EVERY step the gradient of every small
      parameter and, for run 0 and for outliers, every parameter;
   2. per step k and parameter: the spread of the step-k GRADIENT over runs that still share (bit for bit) the parameters of step k
      -- pure summation-order noise; a race (a kernel reading a buffer another branch has not finished) would show as a spread orders of
      magnitude above the fp32 round-off of the sums;
-  3. for every run whose exported `lights` leave the pack (and for run 0): per step the oracle's max(diffuse) and how far the leading colour
-     channel's maximum is ahead of the second -- reg_diffuse = w (relu(max(diffuse) - 1) + ...) sends its gradient to the arg-max element
-     only, so the gradient w.r.t. `lights` is discontinuous where two channels' maxima meet; and
-  4. for every such run: the first step at which it left, the component that did it, that
-     component's gradient in the run and in the oracle (evaluated at THE RUN'S OWN parameters of that step, same visibility), and the
-     max-norm distance of the whole step-k gradient to the oracle's.
+  3. for run 0 and every run whose exported `lights` leave the pack: per step the gradient the run computed AND an eager re-evaluation
+     at the same parameters, each against the oracle at those parameters (same visibility); the oracle's max(diffuse) and the lead of its
+     first colour channel over the second (reg_diffuse's max term); the components of `lights` a step moved differently from run 0,
+     with their gradients.
+
+What it found (profiles/r03_fit_flake_hunt_*.txt): before the fix, at about one parameter state in five the `lights` gradient of BOTH
+executors was 90-97 % (max-norm) off the oracle's -- bit-identically in the two executors, so no race and no noise: the max term of
+reg_diffuse was missing, because the backward's re-computed diffuse values did not bit-match the maximum recorded by the forward (fma
+contraction differed between the two kernels; csrc/shade_common.h now pins the arithmetic).
 
     python tools/fit_flake_hunt.py [runs=60] [K=10]        -> gpurun_out/fit_flake_hunt.txt
 """

@@ -1,0 +1,33 @@
+#!/bin/bash
+# round 3, GPU call 5: the SH-arithmetic fix (flake hunts must be clean now), forward chain (camera first, silhouette early), hoisted mip gathers
+set +e
+O=gpurun_out/r3c5
+mkdir -p $O
+R="$GRAFT_REPO_ROOT"
+cd "$R"
+export PYTHONUNBUFFERED=1
+echo "== flake hunt (white lights / tinted lights), after the fix"
+timeout 600 python tools/fit_flake_hunt.py 40 10 1.0 > $O/flake_white.log 2>&1 ; echo rc=$?
+timeout 600 python tools/fit_flake_hunt.py 40 10 1.3,1.15,1.0 > $O/flake_tinted.log 2>&1 ; echo rc=$?
+grep -h "runs whose\|^lights:" $O/flake_white.log $O/flake_tinted.log
+echo "== plan timeline" ; timeout 300 python tools/plan_timeline.py --out $O/plan_timeline.txt > $O/plan_timeline.log 2>&1 ; echo rc=$?
+grep -E "untimed|host enqueue|sum of" $O/plan_timeline.txt; tail -2 $O/plan_timeline.log
+echo "== kbench"
+timeout 300 python tools/kbench.py --only tex_finish,adam,disturb,antialias > $O/kbench.txt 2>&1 ; echo rc=$?
+tail -8 $O/kbench.txt
+echo "== pytest gpu"
+timeout 1500 python -m pytest tests -m gpu -q --durations=5 > $O/pytest_gpu.log 2>&1 ; echo rc=$?
+tail -12 $O/pytest_gpu.log
+echo "== bench"
+timeout 600 python bench.py --no-cpu-baseline > $O/bench.json 2> $O/bench.err ; echo rc=$?
+python -c "import json; d=json.load(open('$O/bench.json')); r=d['roofline']; print(d['value'], d['ms_per_step'], r['frac'], r['frac_in_step_deferred'], r['frac_isolated'], r['us_in_step'], r['us_in_step_deferred'], d.get('stage_fps',{}).get('value'))"
+tail -2 $O/bench.err
+echo "== rocprofv3 kernel trace of bench"
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof -o step -- python $R/bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-stage > $R/$O/bench_rocprof.json 2> $R/$O/rocprof.err ; echo rc=$?
+cd "$R"
+KT=$(ls $O/prof/*kernel_trace.csv 2>/dev/null | head -1)
+[ -n "$KT" ] && python tools/step_profile.py $KT > $O/step_per_kernel.txt 2>&1 && python tools/step_profile.py $KT --timeline > $O/step_timeline.txt 2>&1
+cp $O/prof/*kernel_stats.csv $O/step_kernel_stats.csv 2>/dev/null
+head -4 $O/step_per_kernel.txt
+rm -rf $O/prof

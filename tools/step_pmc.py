@@ -3,6 +3,9 @@ Run twice on the GPU box (the counters do not fit one pass, /opt/skills/guides/M
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python tools/step_pmc.py
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python tools/step_pmc.py
 then   python tools/step_pmc.py --report gpurun_out/pmc_fetch gpurun_out/pmc_write  > profiles/rNN_step_pmc.json
+MFMA utilisation of the FLAME contractions (north_star asks for it), a third pass over the same script:
+    rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc_mfma -- python tools/step_pmc.py
+    python tools/step_pmc.py --report-mfma gpurun_out/pmc_mfma > profiles/rNN_flame_mfma_pmc.json
 The step is issued as the NativeStep's eager launch sequence (the same kernels the captured graph replays; counter collection serialises
 kernels anyway), NREP times after a warm-up, between two marker launches; two calibration kernels with known byte counts (a 256 MiB fill and
 a 256 MiB copy) give the scale of the raw counters."""
@@ -13,6 +16,32 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 NREP = 4
 CAL_BYTES = 256 << 20
+
+if "--report-mfma" in sys.argv:
+    import csv
+    d = sys.argv[sys.argv.index("--report-mfma") + 1]
+    f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
+    acc = {}
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0]
+        if "flame_" not in k and "verts_bwd_fused" not in k:
+            continue
+        e = acc.setdefault(k, {})
+        e.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    out = {"note": "per launch (mean over the launches of the run).  MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs); "
+                   "GRBM_GUI_ACTIVE under counter collection includes the profiler's per-dispatch serialisation, so this is a LOWER bound -- "
+                   "the FLAME contractions are skinny fp32 GEMMs (M = 16 frames, [16,436] x [436,15429]) bound by the 27 MB read of the "
+                   "blendshape basis, not by the matrix cores: MFMA is used for its exact-fp32 16x16x4 tile"}
+    for k, e in acc.items():
+        m = {c: sum(v) / len(v) for c, v in e.items()}
+        m["launches"] = max(len(v) for v in e.values())
+        if m.get("GRBM_GUI_ACTIVE"):
+            m["MfmaUtil_percent_lower_bound"] = 100.0 * m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (m["GRBM_GUI_ACTIVE"] * 1024)
+        if "SQ_INSTS_VALU_MFMA_MOPS_F32" in m:
+            m["mfma_flops"] = m["SQ_INSTS_VALU_MFMA_MOPS_F32"] * 512
+        out[k] = m
+    print(json.dumps(out, indent=1))
+    sys.exit(0)
 
 if "--report" in sys.argv:
     import csv
@@ -81,10 +110,10 @@ fill = lambda n: L.vhap_debug_fill(ctypes.c_void_p(a.data_ptr()), ctypes.c_size_
 copy = lambda n: L.vhap_debug_copy(ctypes.c_void_p(b.data_ptr()), ctypes.c_void_p(a.data_ptr()), ctypes.c_size_t(n), ctypes.c_void_p(0))
 
 
-def step():
+def step():                                                 # the captured step's kernels, one chain: the texture's Adam update rides in its gradient pass
     ns.forward()
-    ns.backward(1)
-    opt.step()
+    ns.backward(1, optimizer=opt)
+    opt.step(skip=(tr.tex_extra,))
 
 
 for _ in range(2):

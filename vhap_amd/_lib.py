@@ -55,6 +55,8 @@ SIGNATURES = {
     "vhap_antialias_inplace_work_ints": (c_sz, [c_i] * 4),
     "vhap_antialias_inplace_fwd": (c_i, [c_fp] * 5 + [c_i] * 5 + [c_fp, c_fp]),
     "vhap_antialias_inplace_detect": (c_i, [c_fp] * 4 + [c_i] * 5 + [c_fp, c_fp]),
+    "vhap_antialias_inplace_silhouette": (c_i, [c_fp] * 3 + [c_i] * 5 + [c_fp, c_fp]),
+    "vhap_antialias_inplace_pairs": (c_i, [c_fp] + [c_i] * 4 + [c_fp, c_fp]),
     "vhap_antialias_inplace_blend": (c_i, [c_fp] * 5 + [c_i] * 5 + [c_fp, c_fp]),
     "vhap_antialias_photo_bwd": (c_i, [c_fp] * 9 + [c_i] * 5 + [c_fp, c_fp, c_fp]),
     "vhap_antialias_clear_delta": (c_i, [c_fp, c_i, c_i, c_i, c_fp, c_fp]),

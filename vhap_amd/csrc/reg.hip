@@ -257,6 +257,22 @@ __global__ __launch_bounds__(RB) void tex_prep_bwd_kernel(TexCfg c, const float*
             sc *= 0.25f;
         }
     }
+    // levels 4 and up cover 16 x 16 texels and more per texel of theirs: over the 16 rows of this strip (y0 is a multiple of 16) a lane
+    // reads the SAME texel of each of them -- fetched and summed once per strip, not once per row (8 of the 12 gathers of a texel)
+    static_assert(TEXB_ROWS == 16 && TEXB_MAXG > 3, "hoisting of the coarse levels assumes 16-row strips");
+    float coarse[3] = {0.f, 0.f, 0.f};
+    if (d_mips && in_x) {
+        float m[TEXB_MAXG - 3][3];
+#pragma unroll
+        for (int u = 3; u < TEXB_MAXG; u++) {
+            const float* q = d_mips + g_off[u] + 3 * ((size_t)(y0 >> g_sh[u]) * (T >> g_sh[u]) + (x >> g_sh[u]));
+            m[u - 3][0] = q[0]; m[u - 3][1] = q[1]; m[u - 3][2] = q[2];
+        }
+#pragma unroll
+        for (int u = 3; u < TEXB_MAXG; u++) {          // level order
+            coarse[0] += g_sc[u] * m[u - 3][0]; coarse[1] += g_sc[u] * m[u - 3][1]; coarse[2] += g_sc[u] * m[u - 3][2];
+        }
+    }
     const int nrows = min(TEXB_ROWS, T - y0);
     for (int r = 0; r < nrows; r++) {
         const int y = y0 + r;
@@ -266,14 +282,15 @@ __global__ __launch_bounds__(RB) void tex_prep_bwd_kernel(TexCfg c, const float*
         if (in_x) {
             if (d_albedo) { g[0] = d_albedo[3 * i]; g[1] = d_albedo[3 * i + 1]; g[2] = d_albedo[3 * i + 2]; }
             if (d_mips) {
-                float m[TEXB_MAXG][3];
+                float m[3][3];
 #pragma unroll
-                for (int u = 0; u < TEXB_MAXG; u++) {
+                for (int u = 0; u < 3; u++) {
                     const float* q = d_mips + g_off[u] + 3 * ((size_t)(y >> g_sh[u]) * (T >> g_sh[u]) + (x >> g_sh[u]));
                     m[u][0] = q[0]; m[u][1] = q[1]; m[u][2] = q[2];
                 }
 #pragma unroll
-                for (int u = 0; u < TEXB_MAXG; u++) { g[0] += g_sc[u] * m[u][0]; g[1] += g_sc[u] * m[u][1]; g[2] += g_sc[u] * m[u][2]; }    // level order
+                for (int u = 0; u < 3; u++) { g[0] += g_sc[u] * m[u][0]; g[1] += g_sc[u] * m[u][1]; g[2] += g_sc[u] * m[u][2]; }    // levels 1-3
+                g[0] += coarse[0]; g[1] += coarse[1]; g[2] += coarse[2];
             }
         }
         if (tv) {

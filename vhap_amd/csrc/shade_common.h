@@ -9,16 +9,22 @@ struct SH9 {
     float v[9];
 };
 
+// Every product and sum below is an explicit round-to-nearest intrinsic, i.e. NEVER contracted into an fma: the diffuse value of a pixel
+// is computed by the forward pass (raster.hip mode 2 / pixel.hip), which records its maximum for the diffuse regulariser, and RE-computed by
+// the backward (deferred.hip, pixel.hip), which routes the regulariser's max-gradient to the pixels whose value EQUALS the recorded
+// maximum (tracker.py:547-550: relu(diffuse.max() - 1)).  Left to the compiler, the contraction decisions of two kernels differ, the
+// re-computed maximum misses the recorded one by an ulp in a fifth of the evaluations, and the max term silently vanishes from d(lights)
+// -- round 2's "flaky" fit parity (profiles/r03_fit_flake_hunt_*.txt).
 __device__ __forceinline__ void sh_basis(float x, float y, float z, const float* __restrict__ sc, SH9& b) {
     b.v[0] = sc[0];
-    b.v[1] = x * sc[1];
-    b.v[2] = y * sc[2];
-    b.v[3] = z * sc[3];
-    b.v[4] = x * y * sc[4];
-    b.v[5] = x * z * sc[5];
-    b.v[6] = y * z * sc[6];
-    b.v[7] = (x * x - y * y) * sc[7];
-    b.v[8] = (3.0f * z * z - 1.0f) * sc[8];
+    b.v[1] = __fmul_rn(x, sc[1]);
+    b.v[2] = __fmul_rn(y, sc[2]);
+    b.v[3] = __fmul_rn(z, sc[3]);
+    b.v[4] = __fmul_rn(__fmul_rn(x, y), sc[4]);
+    b.v[5] = __fmul_rn(__fmul_rn(x, z), sc[5]);
+    b.v[6] = __fmul_rn(__fmul_rn(y, z), sc[6]);
+    b.v[7] = __fmul_rn(__fsub_rn(__fmul_rn(x, x), __fmul_rn(y, y)), sc[7]);
+    b.v[8] = __fmul_rn(__fsub_rn(__fmul_rn(__fmul_rn(3.0f, z), z), 1.0f), sc[8]);
 }
 
 // order-preserving float -> unsigned (negative ? ~u : u | sign)
@@ -37,13 +43,15 @@ __device__ __forceinline__ unsigned long long sh_merge_max(unsigned long long a,
 // raw normal -> normalised direction (x, y, z), 1 / max(|r|, 1e-10), diffuse colour d[3]; l [9,3] lights, sc [9] constants
 __device__ __forceinline__ void sh_diffuse(float nx, float ny, float nz, const float* __restrict__ sc, const float* __restrict__ l, SH9& b,
                                            float& x, float& y, float& z, float& inv, float (&d)[3]) {
-    inv = 1.0f / sqrtf(fmaxf(nx * nx + ny * ny + nz * nz, 1e-20f));
-    x = nx * inv; y = ny * inv; z = nz * inv;
+    inv = __fdiv_rn(1.0f, __fsqrt_rn(fmaxf(__fadd_rn(__fadd_rn(__fmul_rn(nx, nx), __fmul_rn(ny, ny)), __fmul_rn(nz, nz)), 1e-20f)));
+    x = __fmul_rn(nx, inv); y = __fmul_rn(ny, inv); z = __fmul_rn(nz, inv);
     sh_basis(x, y, z, sc, b);
     d[0] = d[1] = d[2] = 0.f;
 #pragma unroll
     for (int k = 0; k < 9; k++) {
-        d[0] += b.v[k] * l[3 * k]; d[1] += b.v[k] * l[3 * k + 1]; d[2] += b.v[k] * l[3 * k + 2];
+        d[0] = __fadd_rn(d[0], __fmul_rn(b.v[k], l[3 * k]));
+        d[1] = __fadd_rn(d[1], __fmul_rn(b.v[k], l[3 * k + 1]));
+        d[2] = __fadd_rn(d[2], __fmul_rn(b.v[k], l[3 * k + 2]));
     }
 }
 

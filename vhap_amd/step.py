@@ -325,6 +325,9 @@ class NativeStep:
         self._acc_clean = False
         so = tr.static_offset
         self._tex_ready = None
+        # the camera first, alone (one tiny workgroup per frame, ~5 us): beside the bandwidth-bound texture assembly it took 50 us, and the
+        # skinning kernel behind the per-frame stage waited for it
+        self._camera_forward()
         early_tex = self.photometric and self.deferred and self.overlap
         if early_tex:
             # deferred shading: the rasteriser itself samples the texture, so the texture assembly + pyramid (~75 us, bandwidth-bound) heads the
@@ -336,15 +339,11 @@ class NativeStep:
                 self._tex_ready = torch.cuda.Event()
                 self._tex_ready.record()
             self._side(tex_branch)
-        # the camera (one tiny workgroup per frame) does not depend on the per-frame stage: side by side instead of 5-28 us ahead of it
-        self._side(self._camera_forward, self.side2)
         _chk(L.vhap_frame_prep_fwd(_p(self.ts), _p(tr.shape), _p(tr.expr), _p(tr.rotation), _p(tr.translation), _p(tr.neck_pose),
                                    _p(tr.jaw_pose), _p(tr.eyes_pose), _p(fm.JT), _p(fm.JS), _p(fm.jreg_idx), _p(fm.jreg_w), fm.jreg_n,
                                    _p(so), fm.parents, self.weights, B, self.Bp, self.N, self.NS, self.NE, J, fb.Kp, V,
                                    _p(self.coef), _p(self.A), _p(self.transl), _p(self.Jrest), _p(acc), PRE, st), "vhap_frame_prep_fwd")
         self._flush()
-        if self.overlap:
-            torch.cuda.current_stream().wait_stream(self.side2)
         if self.photometric:                                      # skinning fused with the world -> clip transform (one launch, same bits)
             _chk(L.vhap_flame_skin_clip_fwd(_p(self.coef), _p(fb.basis), _p(self.A), _p(fb.w), _p(fb.templ), _p(so), _p(self.transl), _p(self.mvp),
                                             B, V, fb.Vp, fb.K, fb.Kb, fb.Kp, _p(self.verts), _p(self.v_shaped), _p(self.v_posed), _p(self.clip), st),
@@ -369,6 +368,11 @@ class NativeStep:
                 self._tex_forward()
             if self.w_lmk:                                        # needs only verts + mvp: off the rasteriser's critical path
                 self._landmark_forward()
+            if self.aa_inplace and self.overlap:
+                # the antialiasing's silhouette flags are a property of the clip-space geometry alone: beside the rasteriser, so that only
+                # the pixel-pair discovery is left for the gap between the rasteriser and the blend
+                _chk(L.vhap_antialias_inplace_silhouette(_p(self.clip), _p(self.tri), _p(self.opp), B, H, W, V, F, _p(self.aa_work), _stream()),
+                     "vhap_antialias_inplace_silhouette")
             self.arena.zero_()                                    # ONE launch clears every gradient accumulator of the backward
             self._arena_clean = True
             if self.step_optimizer is not None:
@@ -439,20 +443,18 @@ class NativeStep:
             self._join()
         _chk(raster(((1 | 4) if self.bin_split else 1) | stats_later), "vhap_raster_shade_fwd")   # VHAP_RASTER_WS_CLEAN (| VHAP_RASTER_PREBINNED)
         _hook("raster_interp_fwd", "end")
-        if stats_later:
-            self._side(lambda: _chk(L.vhap_raster_shade_stats(B, F, H, W, _p(self.ws), self.ws_bytes, self.ws_cap, 1, _p(acc[12:16]), _stream()),
-                                    "vhap_raster_shade_stats"))
-
-        # the antialiasing's pair discovery needs the rasteriser's output only, not the colours: beside the colour disturbance (143 us of
-        # the main chain) instead of behind it -- 60 us less on the critical path
+        # the antialiasing's pair discovery needs the rasteriser's output only, not the colours: beside the colour disturbance instead of
+        # behind it (and ahead of the statistics reduction on the side stream: the blend waits for it, the energy assembly for the other)
         self._aa_det = None
         if self.aa_inplace and self.overlap:
             def detect_branch():
-                _chk(L.vhap_antialias_inplace_detect(_p(self.rast), _p(self.clip), _p(self.tri), _p(self.opp), B, H, W, V, F, _p(self.aa_work),
-                                                     _stream()), "vhap_antialias_inplace_detect")
+                _chk(L.vhap_antialias_inplace_pairs(_p(self.rast), B, H, W, F, _p(self.aa_work), _stream()), "vhap_antialias_inplace_pairs")
                 self._aa_det = torch.cuda.Event()
                 self._aa_det.record()
             self._side(detect_branch)                             # (on the texture branch's stream: idle here)
+        if stats_later:
+            self._side(lambda: _chk(L.vhap_raster_shade_stats(B, F, H, W, _p(self.ws), self.ws_bytes, self.ws_cap, 1, _p(acc[12:16]), _stream()),
+                                    "vhap_raster_shade_stats"))
         color = self.rgba
         if self.disturb_on:
             self._disturb(st)
