@@ -59,6 +59,10 @@ int vhap_stream_destroy(vhap_stream_t stream);
 #define VHAP_CALL_ADAM_KEEP_STEP 4
 #define VHAP_CALL_ADAM_STEP_ADVANCED 16
 #define VHAP_CALL_TEXBIN_COUNTED 8      /* (internal to vhap_texture_grad_binned_counted) */
+/*   VHAP_CALL_OFFSET_PER_FRAME    vhap_frame_prep_fwd / _bwd, vhap_flame_skin_fwd / _clip_fwd: the vertex offset argument is [B,V,3] -- one row
+ *                                 per frame of the batch (static_offset + dynamic_offset[timesteps], `use_dynamic_offset`, tracker.py:213-235)
+ *                                 -- instead of one [V,3] offset shared by the batch; g_offset of vhap_frame_prep_bwd is then [B,V,3] too */
+#define VHAP_CALL_OFFSET_PER_FRAME 32
 
 /* ---------------------------------------------------------------------------------------------
  * Rasterize: replaces dr.rasterize(glctx, pos, tri, resolution)  (render_nvdiffrast.py:254,257)
@@ -385,13 +389,13 @@ int vhap_photo_fwd_total(const float* pred_rgba, const float* gt_nchw, int B, in
 int vhap_flame_skin_fwd(const float* coef, const float* basis, const float* A,
                         const float* lbs_weights, const float* v_template, const float* offset,
                         const float* transl, int B, int V, int Vp, int K, int Kb, int Kp,
-                        float* verts, float* v_shaped, float* v_posed, vhap_stream_t stream);
+                        float* verts, float* v_shaped, float* v_posed, int call_flags, vhap_stream_t stream);
 /* same, fused with vhap_transform_fwd: also writes clip [B,V,4] = [verts;1] @ mvp^T (mvp [B,4,4]) -- bit-identical to the two calls */
 int vhap_flame_skin_clip_fwd(const float* coef, const float* basis, const float* A,
                              const float* lbs_weights, const float* v_template, const float* offset,
                              const float* transl, const float* mvp, int B, int V, int Vp, int K, int Kb,
                              int Kp, float* verts, float* v_shaped, float* v_posed, float* clip,
-                             vhap_stream_t stream);
+                             int call_flags, vhap_stream_t stream);
 size_t vhap_flame_bwd_partial_floats(int B, int Vp, int Kp);
 int vhap_flame_skin_bwd(const float* d_verts, const float* d_vshaped, const float* v_posed,
                         const float* A, const float* lbs_weights, const float* basisT, int B, int V,
@@ -499,7 +503,7 @@ int vhap_frame_prep_bwd(const int64_t* timesteps, const float* shape, const floa
                         const float* d_terms, int B, int Bp, int N, int NS, int NE, int J, int Kp, int V,
                         float* g_shape, float* g_expr, float* g_rotation, float* g_translation,
                         float* g_neck, float* g_jaw, float* g_eyes, float* g_offset,
-                        vhap_stream_t stream);
+                        int call_flags, vhap_stream_t stream);
 /* mvp [B,4,4] = P(K) [RT; 0 0 0 1] (render_nvdiffrast.py:102-160); K [B,4] = fx, fy, cx, cy (or one row shared
  * when K_batched == 0), RT [B,3,4] (or one shared); d_K [B,4] overwritten */
 int vhap_camera_fwd(const float* K, const float* RT, int B, int K_batched, int RT_batched, int H, int W,
@@ -588,7 +592,8 @@ int vhap_adam_advance(int32_t* step_device, vhap_stream_t stream);
  * (tracker.py:430-439), the static-offset gradient summed over frames and the focal-length gradient (tracker.py:141-157).
  *
  * vhap_energy_finalize: log[VHAP_LOG_COUNT] <- the weighted terms (any input may be NULL = term absent); log[VHAP_LOG_REST] = sum
- *   of everything but the photometric term.
+ *   of everything but the photometric term.  frame_terms [6], tex_terms [2], off_terms [4] = (Laplacian, L1, rigidity as
+ *   vhap_offset_reg_fwd writes them, then reg_offset_dynamic as vhap_offset_dynamic_reg adds it; 0 without a dynamic offset).
  * vhap_energy_total: inv_n = world_size / (3 n_global); log[PHOTO] = w_photo * photo2[0] * inv_n; log[TOTAL]; d_sum[0] = w_photo * inv_n
  *   (the upstream gradient handed to vhap_photo_bwd).
  * ------------------------------------------------------------------------------------------- */
@@ -596,7 +601,7 @@ enum {
     VHAP_LOG_LMK = 0, VHAP_LOG_PHOTO = 1, VHAP_LOG_SMOOTH_POSE = 2, VHAP_LOG_REG_JOINT = 3, VHAP_LOG_SMOOTH_JOINT = 4,
     VHAP_LOG_REG_EXPR = 5, VHAP_LOG_SMOOTH_EXPR = 6, VHAP_LOG_REG_SHAPE = 7, VHAP_LOG_TEX_TV = 8, VHAP_LOG_TEX_RES = 9,
     VHAP_LOG_REG_DIFFUSE = 10, VHAP_LOG_OFF_LAP = 11, VHAP_LOG_OFF_ABS = 12, VHAP_LOG_OFF_RIGID = 13, VHAP_LOG_REST = 14,
-    VHAP_LOG_TOTAL = 15, VHAP_LOG_COUNT = 16
+    VHAP_LOG_TOTAL = 15, VHAP_LOG_OFF_DYNAMIC = 16 /* reg_offset_dynamic: part of REST and TOTAL */, VHAP_LOG_COUNT = 17
 };
 int vhap_energy_finalize(const float* frame_terms, const float* lmk_energy, const float* tex_terms,
                          const float* off_terms, const float* shade_stats, float w_landmark,
@@ -610,6 +615,16 @@ int vhap_energy_total_bound(float* log, const float* photo2, const float* n_glob
                             float* d_sum, const float* shade_stats, float* gmax_bound, vhap_stream_t stream);
 /* out_accum[i] += sum_b x[b][i]  (x [B,n]) */
 int vhap_sum_frames(const float* x, int B, int n, float* out_accum, vhap_stream_t stream);
+/* ---- per-frame vertex offsets (`use_dynamic_offset`, vhap/config/base.py:69; tracker.py:213-235, 552-600) ----------------------------
+ * vhap_offset_dynamic_reg: reg_offset_dynamic = scale * sum_{b,v,c} (dyn[ts[b]] - dyn[prev(ts[b])])^2, prev(t) = max(t - 1, 0) (the caller
+ *   folds weight / (B V 3) into `scale`); energy_accum[0] += the term (or NULL); d_dyn [N,V,3] += its gradient to BOTH rows (or NULL),
+ *   scaled by d_term[0] (or 1 if NULL).
+ * vhap_offset_grad_finish: the gradient w.r.t. the per-frame combined offset, g_a + g_b (each [B,V,3], g_b may be NULL), goes to
+ *   d_static [V,3] += its sum over the frames (or NULL) and d_dyn[ts[b]] [N,V,3] += its row b (or NULL). */
+int vhap_offset_dynamic_reg(const float* dyn, const int64_t* timesteps, int B, int N, int V, float scale, const float* d_term,
+                            float* energy_accum, float* d_dyn, vhap_stream_t stream);
+int vhap_offset_grad_finish(const float* g_a, const float* g_b, const int64_t* timesteps, int B, int N, int V, float* d_static,
+                            float* d_dyn, vhap_stream_t stream);
 /* d_focal_accum[0] += scale * sum_b (d_K[b][0] + d_K[b][1])   (K = (f, f, cx, cy), f = focal_length * scale) */
 int vhap_focal_bwd(const float* d_K, int B, float scale, float* d_focal_accum, vhap_stream_t stream);
 

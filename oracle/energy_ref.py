@@ -78,8 +78,13 @@ def regularization_energy(P, ts, w, stage, opt, tex_painted, uvmask_res, v_cano,
     if "lights" in opt:
         d = diffuse_nchw
         log["reg_diffuse"] = w.reg_diffuse * (F.relu(d.max() - 1) + d.var(dim=1).mean())
-    if ("static_offset" in opt or "dynamic_offset" in opt) and P.get("static_offset") is not None:
-        off = P["static_offset"]
+    if ("static_offset" in opt or "dynamic_offset" in opt) and (P.get("static_offset") is not None or P.get("dynamic_offset") is not None):
+        # tracker.py:552-600: the regularised offset is static_offset (+ dynamic_offset[timesteps]): [1,V,3], or [B,V,3] per frame
+        off = 0
+        if P.get("static_offset") is not None:
+            off = off + P["static_offset"]
+        if P.get("dynamic_offset") is not None:
+            off = off + P["dynamic_offset"][ts]
         V = off.shape[1]
         L = _laplacian(V, topo).to(dtype)
         v0 = (v_cano - off).detach()
@@ -92,6 +97,9 @@ def regularization_energy(P, ts, w, stage, opt, tex_painted, uvmask_res, v_cano,
             vids = torch.from_numpy(topo.get_vid_by_region([region]))
             rigid = rigid + off[:, vids, :].var(dim=-2).mean()
         log["reg_offset_rigid"] = w.reg_offset_rigid * rigid
+        if w.reg_offset_dynamic is not None and P.get("dynamic_offset") is not None and "dynamic_offset" in opt:
+            # tracker.py:594-600: temporal smoothness of the dynamic offset (the previous timestep is NOT detached here)
+            log["reg_offset_dynamic"] = w.reg_offset_dynamic * ((P["dynamic_offset"][ts] - P["dynamic_offset"][prev]) ** 2).mean()
     return log
 
 
@@ -107,7 +115,8 @@ def total_energy(P, model, topo, cfg, sample, stage, tex_painted, uvmask_res, im
     tm = model
     verts, v_cano, lmks = R.flame_forward(
         tm, P["shape"][None].expand(B, -1), P["expr"][ts], P["rotation"][ts], P["neck_pose"][ts], P["jaw_pose"][ts],
-        P["eyes_pose"][ts], P["translation"][ts], static_offset=P.get("static_offset"))
+        P["eyes_pose"][ts], P["translation"][ts], static_offset=P.get("static_offset"),
+        dynamic_offset=P["dynamic_offset"][ts] if P.get("dynamic_offset") is not None else None)
     if "intrinsic" in sample and "extrinsic" in sample:      # calibrated capture (tracker.py:141-147): per-view K [B,3,3] | [B,4], RT [B,3,4]
         K = sample["intrinsic"].to(dtype)
         RT = sample["extrinsic"].to(dtype)

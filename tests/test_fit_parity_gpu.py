@@ -62,7 +62,7 @@ def _record(name, lines):
         pass
 
 
-def _make(flame_model, H, W, N, T, seed, lights_scale=1.0):
+def _make(flame_model, H, W, N, T, seed, lights_scale=1.0, dynamic_offset=False):
     from vhap_amd.config import BaseTrackingConfig
     from vhap_amd.flame import FlameHead
     from vhap_amd.render_hip import HipDiffRenderer
@@ -71,6 +71,7 @@ def _make(flame_model, H, W, N, T, seed, lights_scale=1.0):
     model, topo = flame_model
     cfg = BaseTrackingConfig()
     cfg.model.tex_resolution = T
+    cfg.model.use_dynamic_offset = bool(dynamic_offset)
     gt = make_scene_params(N, seed=seed, image_size=(H, W))
     head = FlameHead(model, topo).cuda()
     rend = HipDiffRenderer(lighting_type="SH").cuda()
@@ -86,6 +87,8 @@ def _make(flame_model, H, W, N, T, seed, lights_scale=1.0):
         tr.translation[:, 2] += 0.45
         tr.jaw_pose[:, 0] += 0.1
         tr.lights.mul_(torch.as_tensor(lights_scale, dtype=torch.float32, device=tr.lights.device))     # scalar, or one factor per colour channel
+        if dynamic_offset:
+            tr.dynamic_offset.add_((torch.randn(tr.dynamic_offset.shape, generator=g) * 5e-4).cuda())
     tm = {k: torch.from_numpy(np.asarray(v)) for k, v in model.items()}
     for k in ("v_template", "shapedirs", "posedirs", "J_regressor", "lbs_weights", "lmk_bary_coords", "verts_uvs"):
         tm[k] = tm[k].double()

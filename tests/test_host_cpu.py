@@ -199,3 +199,30 @@ def test_multiview_dataset_is_grouped_by_timestep_on_cpu(flame_model):
     assert rep["lmk"].shape == (NT,) and np.isfinite(rep["lmk"]).all()
     with pytest.raises(ValueError):
         GlobalTracker(cfg, model, topo, make_texture(0, 16), dict(data, timestep_index=torch.from_numpy(ft + 1)))   # timestep 0 has no frame
+
+
+def test_sh_diffuse_is_not_contracted(tmp_path):
+    """The diffuse regulariser's max-gradient is routed by BIT equality between the forward's recorded maximum and the backward's
+    re-computation (csrc/shade_common.h): no multiply-add inside sh_diffuse may be contracted, in any kernel.  Disassemble a probe."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "probe.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-I", os.path.join(root, "vhap_amd", "csrc"), "-I", os.path.join(root, "include"),
+                    "-S", "--cuda-device-only", "-o", str(out), os.path.join(root, "tests", "probes", "sh_probe.hip")], check=True,
+                   capture_output=True)
+    text = out.read_text()
+    fused = re.compile(r"\bv_(fma|fmac|mad|mac|pk_fma|dot)\w*")
+
+    def count(name):
+        body = text[text.index(f"\n{name}:"):]
+        body = body[:body.index("s_endpgm")]
+        return len(fused.findall(body)), len(re.findall(r"\bv_(pk_)?mul_f32", body))
+    f_full, m_full = count("k_full")
+    f_norm, _ = count("k_norm")
+    assert f_norm > 0 and m_full > 0
+    assert f_full == f_norm, f"sh_diffuse contains {f_full - f_norm} contracted multiply-add(s)"

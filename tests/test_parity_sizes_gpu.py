@@ -186,3 +186,63 @@ def test_ten_steps_at_baseline_size_match_oracle_fit(flame_model):
             fails.append(f"{k}: L2 rel {l2:.2e}")
     _record("fit_parity_10_steps_512_T2048.txt", lines + fails)
     assert not fails, fails
+
+
+@pytest.mark.parametrize("stage", ["rgb_sequential_tracking", "rgb_global_tracking"])
+def test_native_step_with_dynamic_offset_matches_oracle(flame_model, stage):
+    """`use_dynamic_offset` (base.py:69; tracker.py:213-235, 552-600) on the NativeStep: one vertex-offset row per frame
+    (static_offset + dynamic_offset[timesteps]) through skinning and joint regression, the offset regularisers per frame, the temporal term
+    reg_offset_dynamic -- energy terms and gradients (incl. d dynamic_offset) against the oracle, whose dynamic-offset terms are pinned on
+    the reference (tests/test_energy_golden.py::test_dynamic_offset_regularisers_match_reference).  Three frames and BOTH offsets: more than
+    the reference can run (its in-place offset sum raises for B > 1), the same mathematics."""
+    from vhap_amd.step import NativeStep
+    H = W = 128
+    Tt = 256
+    S = _make(flame_model, H, W, 4, Tt, seed=41, dynamic_offset=True)
+    tr, cfg, topo, tm = S["tr"], S["cfg"], S["topo"], S["tm"]
+    assert tr.dynamic_offset is not None and NativeStep.supported(tr, stage)
+    tr.render.disturb_rate_fg = tr.render.disturb_rate_bg = None
+    tr.get_train_parameters(stage)
+    ts = np.array([2, 0, 3])
+    sample = tr.get_sample(ts, device_index=True)
+    ns = NativeStep(tr, sample, stage)
+    assert ns.dyn and ns.deferred
+    ns.forward()
+    ns.backward(1)
+    torch.cuda.synchronize()
+    names = NAMES + ("dynamic_offset",)
+    tid = (ns.rast[..., 3].long() - 1).cpu()
+    P = {k: getattr(tr, k).detach().cpu().double().requires_grad_() for k in names}
+    o_sample = {"rgb": sample["rgb"].cpu(), "lmk2d": sample["lmk2d"].cpu(), "timestep_index": ts}
+    Eo, logo, _ = energy_ref.total_energy(P, tm, topo, cfg, o_sample, stage, S["base_tex"], tr._uvmask_res().cpu().double(), (H, W), tid=tid)
+    Eo.backward()
+    log_n = {k: float(v) for k, v in ns.log_dict().items()}
+    lines, fails = [f"dynamic offset, {len(ts)} x {H}x{W}, T = {Tt}, stage {stage}"], []
+    assert "reg_offset_dynamic" in logo and float(logo["reg_offset_dynamic"]) > 0
+    for k, b in logo.items():
+        b = float(b.detach())
+        e = abs(log_n[k] - b) / max(abs(b), 1e-3)
+        lines.append(f"term {k}: {e:.2e}")
+        if e > 5e-5:
+            fails.append(f"term {k}: {log_n[k]} vs {b}")
+    g_n = {k: ns.g[k].detach().clone().reshape(getattr(tr, k).shape) for k in names if k in ns.g}
+    worst = _compare_grads(P, g_n, lines, "dyn", 5e-4, 0.999999, fails)
+    if worst > 5e-4:
+        fails.append(f"gradients: worst rel {worst:.2e}")
+    assert float(P["dynamic_offset"].grad.abs().max()) > 0 and float(g_n["dynamic_offset"][1].abs().max()) == 0     # timestep 1 is not in the batch
+    # ... and the same step captured and replayed: the plan executor must cope with its per-frame launches
+    from vhap_amd.tracker import GraphedStep
+    opt = tr.configure_optimizer(tr.get_train_parameters(stage), lr_scale=0.1)
+    before = tr.dynamic_offset.detach().clone()
+    st = GraphedStep(tr, sample, opt, stage, warmup=0)
+    assert st.ns is not None and st.ns.dyn and st.gF.plan is not None
+    E0 = float(st())
+    for _ in range(4):
+        E1 = float(st())
+    torch.cuda.synchronize()
+    assert abs(E0 - float(Eo.detach())) <= 1e-4 * abs(float(Eo.detach())) and E1 < E0
+    if "dynamic_offset" in cfg.pipeline[stage].optimizable_params:
+        moved = (tr.dynamic_offset - before).abs().amax(dim=(1, 2)).cpu().numpy()
+        assert moved[2] > 0 and moved[0] > 0 and moved[3] > 0
+    _record(f"parity_native_dynamic_offset_{stage}.txt", lines + fails)
+    assert not fails, fails

@@ -106,7 +106,7 @@ def geometry_head():
                           _p(fm.JT), _p(fm.JS), _p(fm.jreg_idx), _p(fm.jreg_w), fm.jreg_n, _p(so), fm.parents, ns.weights, B, ns.Bp, ns.N, ns.NS, ns.NE,
                           ns.J, fb.Kp, V, _p(ns.coef), _p(ns.A), _p(ns.transl), _p(ns.Jrest), _p(acc), PRE, st())
     L.vhap_flame_skin_clip_fwd(_p(ns.coef), _p(fb.basis), _p(ns.A), _p(fb.w), _p(fb.templ), _p(so), _p(ns.transl), _p(ns.mvp), B, V, fb.Vp, fb.K, fb.Kb,
-                               fb.Kp, _p(ns.verts), _p(ns.v_shaped), _p(ns.v_posed), _p(ns.clip), st())
+                               fb.Kp, _p(ns.verts), _p(ns.v_shaped), _p(ns.v_posed), _p(ns.clip), 0, st())
 
 
 calls["geometry tail (vnormal_bwd .. frame_prep_bwd)"] = geometry_tail

@@ -70,8 +70,8 @@ SIGNATURES = {
     "vhap_shade_bwd": (c_i, [c_fp] * 9 + [c_i] * 3 + [c_fp] * 4),
     "vhap_photo_fwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp, c_i, c_fp]),
     "vhap_photo_bwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
-    "vhap_flame_skin_fwd": (c_i, [c_fp] * 7 + [c_i] * 6 + [c_fp] * 4),
-    "vhap_flame_skin_clip_fwd": (c_i, [c_fp] * 8 + [c_i] * 6 + [c_fp] * 5),
+    "vhap_flame_skin_fwd": (c_i, [c_fp] * 7 + [c_i] * 6 + [c_fp] * 3 + [c_i, c_fp]),
+    "vhap_flame_skin_clip_fwd": (c_i, [c_fp] * 8 + [c_i] * 6 + [c_fp] * 4 + [c_i, c_fp]),
     "vhap_flame_bwd_partial_floats": (c_sz, [c_i] * 3),
     "vhap_flame_skin_bwd": (c_i, [c_fp] * 6 + [c_i] * 5 + [c_fp] * 6 + [c_i, c_fp]),
     "vhap_verts_bwd_fused": (c_i, [c_fp] * 14 + [c_i] * 5 + [c_fp] * 8 + [c_i, c_fp]),
@@ -82,7 +82,9 @@ SIGNATURES = {
     "vhap_vnormal_fwd_saved": (c_i, [c_fp] * 4 + [c_i, c_i, c_fp, c_fp, c_fp]),
     "vhap_vnormal_bwd_saved": (c_i, [c_fp] * 7 + [c_i, c_i, c_i, c_fp, c_fp, c_fp]),
     "vhap_frame_prep_fwd": (c_i, [c_fp] * 12 + [c_i] + [c_fp] * 3 + [c_i] * 8 + [c_fp] * 5 + [c_i, c_fp]),
-    "vhap_frame_prep_bwd": (c_i, [c_fp] * 11 + [c_i] + [c_fp] * 8 + [c_i] * 8 + [c_fp] * 9),
+    "vhap_frame_prep_bwd": (c_i, [c_fp] * 11 + [c_i] + [c_fp] * 8 + [c_i] * 8 + [c_fp] * 8 + [c_i, c_fp]),
+    "vhap_offset_dynamic_reg": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_f, c_fp, c_fp, c_fp, c_fp]),
+    "vhap_offset_grad_finish": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
     "vhap_camera_fwd": (c_i, [c_fp, c_fp] + [c_i] * 5 + [c_f, c_f, c_fp, c_fp]),
     "vhap_camera_focal_fwd": (c_i, [c_fp, c_f, c_f, c_f, c_fp] + [c_i] * 4 + [c_f, c_f, c_fp, c_fp]),
     "vhap_camera_bwd": (c_i, [c_fp, c_fp] + [c_i] * 4 + [c_fp, c_fp]),
@@ -117,7 +119,7 @@ SIGNATURES = {
 
 ABI_VERSION = 4
 # call_flags of include/vhap_hip.h (per-call arguments since ABI 2; the library keeps no mutable state)
-CALL_ACC_PREZEROED, CALL_AA_PASSTHROUGH_DONE, CALL_ADAM_KEEP_STEP, CALL_ADAM_STEP_ADVANCED = 1, 2, 4, 16
+CALL_ACC_PREZEROED, CALL_AA_PASSTHROUGH_DONE, CALL_ADAM_KEEP_STEP, CALL_ADAM_STEP_ADVANCED, CALL_OFFSET_PER_FRAME = 1, 2, 4, 16, 32
 
 _lib = None
 

@@ -21,11 +21,14 @@ __device__ inline void finalize(const float* frame_terms, const float* lmk, cons
         const float mx = decode_ordered(shade_stats[1]);
         v[VHAP_LOG_REG_DIFFUSE] = w_reg_diffuse * (fmaxf(mx - 1.0f, 0.0f) + __uint_as_float(shade_stats[2]) / npix);
     }
-    if (off_terms)
+    if (off_terms) {          // [4]: Laplacian, L1, rigidity, temporal smoothness of the dynamic offset
         for (int i = 0; i < 3; i++) v[VHAP_LOG_OFF_LAP + i] = off_terms[i];
+        v[VHAP_LOG_OFF_DYNAMIC] = off_terms[3];
+    }
     float rest = 0.f;
     for (int i = 0; i < VHAP_LOG_REST; i++)
         if (i != VHAP_LOG_PHOTO) rest += v[i];
+    rest += v[VHAP_LOG_OFF_DYNAMIC];
     v[VHAP_LOG_REST] = rest;
     for (int i = 0; i < VHAP_LOG_COUNT; i++) log[i] = v[i];
 }
@@ -61,6 +64,7 @@ __device__ inline void finalize_total_wave(const float* frame_terms, const float
     else if (i == VHAP_LOG_TEX_TV) { if (tex_terms) v = tex_terms[0]; }
     else if (i == VHAP_LOG_TEX_RES) { if (tex_terms) v = tex_terms[1]; }
     else if (i >= VHAP_LOG_OFF_LAP && i < VHAP_LOG_OFF_LAP + 3) { if (off_terms) v = off_terms[i - VHAP_LOG_OFF_LAP]; }
+    else if (i == VHAP_LOG_OFF_DYNAMIC) { if (off_terms) v = off_terms[3]; }
     float mx = 4.0f;
     if (shade_stats) {
         const unsigned s1 = shade_stats[1], s2 = shade_stats[2];
@@ -73,6 +77,7 @@ __device__ inline void finalize_total_wave(const float* frame_terms, const float
         const float vk = __shfl(v, k, 64);
         if (k != VHAP_LOG_PHOTO) rest += vk;
     }
+    rest += __shfl(v, VHAP_LOG_OFF_DYNAMIC, 64);
     const float g = w_photo * (world / (3.0f * n_global));
     const float photo = g * photo_sum;
     if (i == VHAP_LOG_PHOTO) v = photo;

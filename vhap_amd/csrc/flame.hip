@@ -31,7 +31,8 @@ __global__ __launch_bounds__(256) void flame_skin_fwd_kernel(const float* __rest
                                                              const float* __restrict__ transl, int B, int V, int Vp, int K,
                                                              int Kb, int Kp, float* __restrict__ verts,
                                                              float* __restrict__ v_shaped, float* __restrict__ v_posed,
-                                                             const float* __restrict__ mvp, float4* __restrict__ clip) {
+                                                             const float* __restrict__ mvp, float4* __restrict__ clip,
+                                                             long long offset_stride) {
     __shared__ float sA[16 * NJ * 12];
     __shared__ float sT[16 * 3];
     __shared__ float sM[16 * 16];              // per-frame world -> clip matrices (fused vhap_transform_fwd), when clip != null
@@ -73,8 +74,10 @@ __global__ __launch_bounds__(256) void flame_skin_fwd_kernel(const float* __rest
     // epilogue on wave 0: lane (li = vertex, lk) holds frames lk*4 + r
     const int v = v0 + li;
     if (v >= V) return;
+    // offset_stride == 0: ONE offset [V,3] for the batch (static_offset); > 0: an offset row per frame (static + dynamic_offset[timesteps],
+    // tracker.py:213-235) -- added per frame below
     float tx = templ[3 * v], ty = templ[3 * v + 1], tz = templ[3 * v + 2];
-    if (offset) { tx += offset[3 * v]; ty += offset[3 * v + 1]; tz += offset[3 * v + 2]; }
+    if (offset && offset_stride == 0) { tx += offset[3 * v]; ty += offset[3 * v + 1]; tz += offset[3 * v + 2]; }
     float wj[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; j++) wj[j] = w[(size_t)v * NJ + j];
@@ -88,8 +91,12 @@ __global__ __launch_bounds__(256) void flame_skin_fwd_kernel(const float* __rest
             sh[c] = (red[0][0][c][lane][r] + red[0][1][c][lane][r]) + (red[0][2][c][lane][r] + red[0][3][c][lane][r]);
             po[c] = (red[1][0][c][lane][r] + red[1][1][c][lane][r]) + (red[1][2][c][lane][r] + red[1][3][c][lane][r]);
         }
-        const float sx = tx + sh[0], sy = ty + sh[1], sz = tz + sh[2];
+        float sx = tx + sh[0], sy = ty + sh[1], sz = tz + sh[2];
         const size_t o = ((size_t)f * V + v) * 3;
+        if (offset && offset_stride != 0) {
+            const float* of = offset + (size_t)f * offset_stride + 3 * v;
+            sx += of[0]; sy += of[1]; sz += of[2];
+        }
         v_shaped[o] = sx; v_shaped[o + 1] = sy; v_shaped[o + 2] = sz;
         const float px = sx + po[0], py = sy + po[1], pz = sz + po[2];
         float T[12];
@@ -454,13 +461,14 @@ __global__ __launch_bounds__(256) void verts_bwd_fused_kernel(const float* __res
 
 extern "C" int vhap_flame_skin_fwd(const float* coef, const float* basis, const float* A, const float* lbs_weights,
                                    const float* v_template, const float* offset, const float* transl, int B, int V, int Vp,
-                                   int K, int Kb, int Kp, float* verts, float* v_shaped, float* v_posed, vhap_stream_t stream) {
+                                   int K, int Kb, int Kp, float* verts, float* v_shaped, float* v_posed, int call_flags, vhap_stream_t stream) {
     VHAP_ENTER();
     if (!coef || !basis || !A || !lbs_weights || !v_template || !transl || !verts || !v_shaped || !v_posed) return VHAP_E_NULLPTR;
     if (B <= 0 || V <= 0 || Vp < V || Vp % 64 || K <= 0 || K % 4 || Kb % 4 || Kb > K || Kp < K) return VHAP_E_BADDIM;
     flame_skin_fwd_kernel<<<dim3(Vp / 16, (B + 15) / 16), 256, 0, vhap_stream(stream)>>>(coef, basis, A, lbs_weights, v_template, offset,
                                                                                         transl, B, V, Vp, K, Kb, Kp, verts, v_shaped,
-                                                                                        v_posed, nullptr, nullptr);
+                                                                                        v_posed, nullptr, nullptr,
+                                                                                        (call_flags & VHAP_CALL_OFFSET_PER_FRAME) ? 3ll * V : 0ll);
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;
 }
@@ -468,14 +476,15 @@ extern "C" int vhap_flame_skin_fwd(const float* coef, const float* basis, const 
 extern "C" int vhap_flame_skin_clip_fwd(const float* coef, const float* basis, const float* A, const float* lbs_weights,
                                         const float* v_template, const float* offset, const float* transl, const float* mvp, int B,
                                         int V, int Vp, int K, int Kb, int Kp, float* verts, float* v_shaped, float* v_posed,
-                                        float* clip, vhap_stream_t stream) {
+                                        float* clip, int call_flags, vhap_stream_t stream) {
     VHAP_ENTER();
     if (!coef || !basis || !A || !lbs_weights || !v_template || !transl || !verts || !v_shaped || !v_posed || !mvp || !clip)
         return VHAP_E_NULLPTR;
     if (B <= 0 || V <= 0 || Vp < V || Vp % 64 || K <= 0 || K % 4 || Kb % 4 || Kb > K || Kp < K) return VHAP_E_BADDIM;
     flame_skin_fwd_kernel<<<dim3(Vp / 16, (B + 15) / 16), 256, 0, vhap_stream(stream)>>>(coef, basis, A, lbs_weights, v_template, offset,
                                                                                         transl, B, V, Vp, K, Kb, Kp, verts, v_shaped,
-                                                                                        v_posed, mvp, reinterpret_cast<float4*>(clip));
+                                                                                        v_posed, mvp, reinterpret_cast<float4*>(clip),
+                                                                                        (call_flags & VHAP_CALL_OFFSET_PER_FRAME) ? 3ll * V : 0ll);
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;
 }

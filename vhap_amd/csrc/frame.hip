@@ -115,6 +115,7 @@ struct FrameIn {
     const float *JT, *JS, *Jw, *offset;     // [J,3], [3J, NS+NE], [M,J] weights of the M vertices with a non-zero J_regressor column, [V,3] or null
     const int* Jv;                          // [M] their vertex ids
     int M;
+    long long offset_stride;                // 0: one offset [V,3] for the batch; 3 V: an offset row per frame of the batch ([B,V,3])
 };
 
 __device__ __forceinline__ void gather_pose(const FrameIn& in, long long t, float* pose /*15*/) {
@@ -188,7 +189,8 @@ __global__ __launch_bounds__(FP_THREADS) void frame_prep_fwd_kernel(FrameCfg cfg
         if (in.offset) {        // J_regressor is sparse (a few hundred non-zero columns): compact list instead of a walk over all V
             for (int m = tid; m < in.M; m += FP_THREADS) {
                 const int v = in.Jv[m];
-                const float o0 = in.offset[3 * v], o1 = in.offset[3 * v + 1], o2 = in.offset[3 * v + 2];
+                const float* of = in.offset + (size_t)blockIdx.x * in.offset_stride + 3 * v;
+                const float o0 = of[0], o1 = of[1], o2 = of[2];
 #pragma unroll
                 for (int j = 0; j < MAXJ; j++) {
                     if (j < cfg.J) {
@@ -506,7 +508,8 @@ __global__ __launch_bounds__(FP_THREADS) void frame_prep_bwd_kernel(FrameCfg cfg
                 const float wv = in.Jw[(size_t)m * cfg.J + j];
                 a[0] += wv * dJl[3 * j]; a[1] += wv * dJl[3 * j + 1]; a[2] += wv * dJl[3 * j + 2];
             }
-            atomicAdd(&g.offset[3 * v], a[0]); atomicAdd(&g.offset[3 * v + 1], a[1]); atomicAdd(&g.offset[3 * v + 2], a[2]);
+            float* go = g.offset + (size_t)blockIdx.x * in.offset_stride + 3 * v;      // (per-frame offsets: this frame's row of the gradient)
+            atomicAdd(&go[0], a[0]); atomicAdd(&go[1], a[1]); atomicAdd(&go[2], a[2]);
         }
     }
 }
@@ -536,7 +539,8 @@ extern "C" int vhap_frame_prep_fwd(const int64_t* timesteps, const float* shape,
     if (static_offset && jreg_n > 0 && (!jreg_idx || !jreg_w)) return VHAP_E_NULLPTR;
     FrameCfg cfg;
     if (!make_cfg(cfg, B, Bp, N, NS, NE, J, Kp, V, parents, weights)) return VHAP_E_BADDIM;
-    FrameIn in{reinterpret_cast<const long long*>(timesteps), shape, expr, rotation, translation, neck, jaw, eyes, JT, JS, jreg_w, static_offset, jreg_idx, jreg_n};
+    FrameIn in{reinterpret_cast<const long long*>(timesteps), shape, expr, rotation, translation, neck, jaw, eyes, JT, JS, jreg_w, static_offset, jreg_idx, jreg_n,
+               (call_flags & VHAP_CALL_OFFSET_PER_FRAME) ? 3ll * V : 0ll};
     hipStream_t st = vhap_stream(stream);
     VHAP_ZERO_ACC(terms, 6 * sizeof(float), st);
     const bool flame_tree = J == 5 && parents[1] == 0 && parents[2] == 1 && parents[3] == 1 && parents[4] == 1;
@@ -552,13 +556,14 @@ extern "C" int vhap_frame_prep_bwd(const int64_t* timesteps, const float* shape,
                                    const int32_t* parents, const float* weights, const float* Jrest, const float* d_coef, const float* d_A,
                                    const float* d_transl, const float* d_terms, int B, int Bp, int N, int NS, int NE, int J, int Kp,
                                    int V, float* g_shape, float* g_expr, float* g_rotation, float* g_translation, float* g_neck,
-                                   float* g_jaw, float* g_eyes, float* g_offset, vhap_stream_t stream) {
+                                   float* g_jaw, float* g_eyes, float* g_offset, int call_flags, vhap_stream_t stream) {
     VHAP_ENTER();
     if (!timesteps || !shape || !expr || !rotation || !translation || !neck || !jaw || !eyes || !JS || !Jrest) return VHAP_E_NULLPTR;
     if (g_offset && (!static_offset || (jreg_n > 0 && (!jreg_idx || !jreg_w)))) return VHAP_E_NULLPTR;
     FrameCfg cfg;
     if (!make_cfg(cfg, B, Bp, N, NS, NE, J, Kp, V, parents, weights)) return VHAP_E_BADDIM;
-    FrameIn in{reinterpret_cast<const long long*>(timesteps), shape, expr, rotation, translation, neck, jaw, eyes, nullptr, JS, jreg_w, static_offset, jreg_idx, jreg_n};
+    FrameIn in{reinterpret_cast<const long long*>(timesteps), shape, expr, rotation, translation, neck, jaw, eyes, nullptr, JS, jreg_w, static_offset, jreg_idx, jreg_n,
+               (call_flags & VHAP_CALL_OFFSET_PER_FRAME) ? 3ll * V : 0ll};
     FrameGrad g{g_shape, g_expr, g_rotation, g_translation, g_neck, g_jaw, g_eyes, g_offset};
     const bool flame_tree = J == 5 && parents[1] == 0 && parents[2] == 1 && parents[3] == 1 && parents[4] == 1;
     if (flame_tree) frame_prep_bwd_kernel<5><<<B, FP_THREADS, 0, vhap_stream(stream)>>>(cfg, in, Jrest, d_coef, d_A, d_transl, d_terms, g);

@@ -342,6 +342,49 @@ __global__ __launch_bounds__(RB) void tex_prep_bwd_kernel(TexCfg c, const float*
     }
 }
 
+// ---- per-frame vertex offsets (use_dynamic_offset) ----
+// reg_offset_dynamic (tracker.py:594-600): temporal smoothness of the dynamic offset; the previous timestep's row is NOT detached
+__global__ __launch_bounds__(RB) void offset_dynamic_reg_kernel(const float* __restrict__ dyn, const long long* __restrict__ ts, int B, int N, int V,
+                                                                float scale, const float* __restrict__ d_term, float* __restrict__ energy,
+                                                                float* __restrict__ d_dyn) {
+    __shared__ float red[4];
+    const int n = V * 3;
+    const int i = blockIdx.x * RB + threadIdx.x, b = blockIdx.y;
+    const long long t = ts[b], p = t > 0 ? t - 1 : 0;
+    float e = 0.f;
+    if (i < n && t >= 0 && t < N) {
+        const float d = dyn[(size_t)t * n + i] - dyn[(size_t)p * n + i];
+        e = d * d;
+        if (d_dyn && t != p) {
+            const float g = 2.0f * scale * (d_term ? d_term[0] : 1.0f) * d;
+            atomicAdd(&d_dyn[(size_t)t * n + i], g);
+            atomicAdd(&d_dyn[(size_t)p * n + i], -g);
+        }
+    }
+    if (energy) {
+        e = block_sum256(e, red);
+        if (threadIdx.x == 0 && e != 0.f) atomicAdd(energy, e * scale);
+    }
+}
+
+// d_static[v] += sum_b (g_a + g_b)[b][v] ; d_dyn[ts[b]][v] += (g_a + g_b)[b][v]   (frames of one timestep -- multi-view -- add up: atomics)
+__global__ __launch_bounds__(RB) void offset_grad_finish_kernel(const float* __restrict__ g_a, const float* __restrict__ g_b,
+                                                                const long long* __restrict__ ts, int B, int N, int V,
+                                                                float* __restrict__ d_static, float* __restrict__ d_dyn) {
+    const int n = V * 3;
+    const int i = blockIdx.x * RB + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int b = 0; b < B; b++) {
+        float g = g_a[(size_t)b * n + i];
+        if (g_b) g += g_b[(size_t)b * n + i];
+        s += g;
+        const long long t = ts[b];
+        if (d_dyn && t >= 0 && t < N && g != 0.f) atomicAdd(&d_dyn[(size_t)t * n + i], g);
+    }
+    if (d_static) d_static[i] += s;
+}
+
 // ---- Adam ----
 struct AdamTable {
     float* p[VHAP_ADAM_MAX_TENSORS];
@@ -463,6 +506,28 @@ extern "C" int vhap_tex_prep_bwd_adam(const float* albedo_hwc, float* extra, con
     tex_prep_bwd_kernel<true><<<dim3(vhap_cdiv(T, RB), vhap_cdiv(T, TEXB_ROWS)), RB, 0, vhap_stream(stream)>>>(
         c, albedo_hwc, extra, res_mask, d_albedo_hwc, n_gather > 0 ? d_mips_hwc : nullptr, n_gather, d_terms, d_extra,
         TexAdam{extra, exp_avg, exp_avg_sq, lr_device, step_device, beta1, beta2, eps}, (call_flags & VHAP_CALL_ADAM_STEP_ADVANCED) ? 0 : 1);
+    VHAP_LAUNCH_CHECK();
+    return VHAP_OK;
+}
+
+extern "C" int vhap_offset_dynamic_reg(const float* dyn, const int64_t* timesteps, int B, int N, int V, float scale, const float* d_term,
+                                       float* energy_accum, float* d_dyn, vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!dyn || !timesteps || (!energy_accum && !d_dyn)) return VHAP_E_NULLPTR;
+    if (B <= 0 || B > 65535 || N <= 0 || V <= 0) return VHAP_E_BADDIM;
+    offset_dynamic_reg_kernel<<<dim3(vhap_cdiv(3ll * V, RB), B), RB, 0, vhap_stream(stream)>>>(dyn, reinterpret_cast<const long long*>(timesteps), B, N, V,
+                                                                                              scale, d_term, energy_accum, d_dyn);
+    VHAP_LAUNCH_CHECK();
+    return VHAP_OK;
+}
+
+extern "C" int vhap_offset_grad_finish(const float* g_a, const float* g_b, const int64_t* timesteps, int B, int N, int V, float* d_static,
+                                       float* d_dyn, vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!g_a || !timesteps || (!d_static && !d_dyn)) return VHAP_E_NULLPTR;
+    if (B <= 0 || N <= 0 || V <= 0) return VHAP_E_BADDIM;
+    offset_grad_finish_kernel<<<vhap_cdiv(3ll * V, RB), RB, 0, vhap_stream(stream)>>>(g_a, g_b, reinterpret_cast<const long long*>(timesteps), B, N, V, d_static,
+                                                                                     d_dyn);
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;
 }

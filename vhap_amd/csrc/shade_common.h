@@ -9,23 +9,44 @@ struct SH9 {
     float v[9];
 };
 
-// Every product and sum below is an explicit round-to-nearest intrinsic, i.e. NEVER contracted into an fma: the diffuse value of a pixel
-// is computed by the forward pass (raster.hip mode 2 / pixel.hip), which records its maximum for the diffuse regulariser, and RE-computed by
-// the backward (deferred.hip, pixel.hip), which routes the regulariser's max-gradient to the pixels whose value EQUALS the recorded
-// maximum (tracker.py:547-550: relu(diffuse.max() - 1)).  Left to the compiler, the contraction decisions of two kernels differ, the
-// re-computed maximum misses the recorded one by an ulp in a fifth of the evaluations, and the max term silently vanishes from d(lights)
-// -- round 2's "flaky" fit parity (profiles/r03_fit_flake_hunt_*.txt).
+// Contraction is OFF for sh_basis / sh_diffuse (and every operation is a plain operator INSIDE the pragma region -- the __fmul_rn / __fadd_rn
+// "intrinsics" of the HIP headers are ordinary inline functions compiled under the header's own contraction mode and fuse again after
+// inlining): the diffuse value of a pixel is computed by the forward pass (raster.hip mode 2 / pixel.hip), which records its maximum for
+// the diffuse regulariser, and RE-computed by the backward (deferred.hip, pixel.hip), which routes the regulariser's max-gradient to
+// the pixels whose value EQUALS the recorded maximum (tracker.py:547-550: relu(diffuse.max() - 1)).  Left to the compiler, the
+// contraction decisions of two kernels differ, the re-computed maximum misses the recorded one by an ulp in a fifth of the evaluations,
+// and the max term silently vanishes from d(lights) -- round 2's "flaky" fit parity (profiles/r03_fit_flake_hunt_*.txt).
+// tests/test_host_cpu.py::test_sh_diffuse_is_not_contracted disassembles a probe kernel and counts the fused instructions.
+#pragma clang fp contract(off)
 __device__ __forceinline__ void sh_basis(float x, float y, float z, const float* __restrict__ sc, SH9& b) {
     b.v[0] = sc[0];
-    b.v[1] = __fmul_rn(x, sc[1]);
-    b.v[2] = __fmul_rn(y, sc[2]);
-    b.v[3] = __fmul_rn(z, sc[3]);
-    b.v[4] = __fmul_rn(__fmul_rn(x, y), sc[4]);
-    b.v[5] = __fmul_rn(__fmul_rn(x, z), sc[5]);
-    b.v[6] = __fmul_rn(__fmul_rn(y, z), sc[6]);
-    b.v[7] = __fmul_rn(__fsub_rn(__fmul_rn(x, x), __fmul_rn(y, y)), sc[7]);
-    b.v[8] = __fmul_rn(__fsub_rn(__fmul_rn(__fmul_rn(3.0f, z), z), 1.0f), sc[8]);
+    b.v[1] = x * sc[1];
+    b.v[2] = y * sc[2];
+    b.v[3] = z * sc[3];
+    b.v[4] = (x * y) * sc[4];
+    b.v[5] = (x * z) * sc[5];
+    b.v[6] = (y * z) * sc[6];
+    b.v[7] = ((x * x) - (y * y)) * sc[7];
+    b.v[8] = (((3.0f * z) * z) - 1.0f) * sc[8];
 }
+
+// raw normal -> normalised direction (x, y, z), 1 / max(|r|, 1e-10), diffuse colour d[3]; l [9,3] lights, sc [9] constants
+__device__ __forceinline__ void sh_diffuse(float nx, float ny, float nz, const float* __restrict__ sc, const float* __restrict__ l, SH9& b,
+                                           float& x, float& y, float& z, float& inv, float (&d)[3]) {
+    const float l2 = ((nx * nx) + (ny * ny)) + (nz * nz);
+    inv = 1.0f / __builtin_sqrtf(fmaxf(l2, 1e-20f));
+    x = nx * inv; y = ny * inv; z = nz * inv;
+    sh_basis(x, y, z, sc, b);
+    d[0] = d[1] = d[2] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const float t0 = b.v[k] * l[3 * k], t1 = b.v[k] * l[3 * k + 1], t2 = b.v[k] * l[3 * k + 2];
+        d[0] = d[0] + t0;
+        d[1] = d[1] + t1;
+        d[2] = d[2] + t2;
+    }
+}
+#pragma clang fp contract(fast)
 
 // order-preserving float -> unsigned (negative ? ~u : u | sign)
 __device__ __forceinline__ unsigned sh_f2ord(float f) {
@@ -38,21 +59,6 @@ __device__ __forceinline__ unsigned sh_f2ord(float f) {
 __device__ __forceinline__ unsigned long long sh_merge_max(unsigned long long a, unsigned long long b) {
     const unsigned ha = (unsigned)(a >> 32), hb = (unsigned)(b >> 32);
     return ha > hb ? a : (hb > ha ? b : a + (b & 0xffffffffull));
-}
-
-// raw normal -> normalised direction (x, y, z), 1 / max(|r|, 1e-10), diffuse colour d[3]; l [9,3] lights, sc [9] constants
-__device__ __forceinline__ void sh_diffuse(float nx, float ny, float nz, const float* __restrict__ sc, const float* __restrict__ l, SH9& b,
-                                           float& x, float& y, float& z, float& inv, float (&d)[3]) {
-    inv = __fdiv_rn(1.0f, __fsqrt_rn(fmaxf(__fadd_rn(__fadd_rn(__fmul_rn(nx, nx), __fmul_rn(ny, ny)), __fmul_rn(nz, nz)), 1e-20f)));
-    x = __fmul_rn(nx, inv); y = __fmul_rn(ny, inv); z = __fmul_rn(nz, inv);
-    sh_basis(x, y, z, sc, b);
-    d[0] = d[1] = d[2] = 0.f;
-#pragma unroll
-    for (int k = 0; k < 9; k++) {
-        d[0] = __fadd_rn(d[0], __fmul_rn(b.v[k], l[3 * k]));
-        d[1] = __fadd_rn(d[1], __fmul_rn(b.v[k], l[3 * k + 1]));
-        d[2] = __fadd_rn(d[2], __fmul_rn(b.v[k], l[3 * k + 2]));
-    }
 }
 
 // gradient of the diffuse colour w.r.t. the RAW normal: gd[3] = d L / d diffuse -> (gnx, gny, gnz)

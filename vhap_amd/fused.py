@@ -56,7 +56,7 @@ class _FlameSkin(torch.autograd.Function):
         v_shaped = torch.empty_like(verts)
         v_posed = torch.empty_like(verts)
         _chk(_lib.lib().vhap_flame_skin_fwd(_p(coef), _p(fb.basis), _p(A), _p(fb.w), _p(fb.templ), _p(offset), _p(transl), B, V,
-                                            fb.Vp, fb.K, fb.Kb, fb.Kp, _p(verts), _p(v_shaped), _p(v_posed), _stream()),
+                                            fb.Vp, fb.K, fb.Kb, fb.Kp, _p(verts), _p(v_shaped), _p(v_posed), 0, _stream()),
              "vhap_flame_skin_fwd")
         ctx.fb = fb
         ctx.has_offset = offset is not None

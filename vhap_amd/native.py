@@ -89,7 +89,7 @@ class _FramePrep(torch.autograd.Function):
         _chk(_lib.lib().vhap_frame_prep_bwd(_p(ts), _p(shape), _p(expr), _p(rotation), _p(translation), _p(neck), _p(jaw), _p(eyes),
                                             _p(fm.JS), _p(fm.jreg_idx), _p(fm.jreg_w), fm.jreg_n, _p(offset), fm.parents, ctx.weights, _p(Jrest), _p(c(d_coef)),
                                             _p(c(d_A)), _p(c(d_transl)), _p(c(d_terms)), B, Bp, N, NS, NE, fm.J, fb.Kp, fm.V,
-                                            *[_p(g) for g in grads], _stream()), "vhap_frame_prep_bwd")
+                                            *[_p(g) for g in grads], 0, _stream()), "vhap_frame_prep_bwd")
         return (None, None, None, *grads)
 
 

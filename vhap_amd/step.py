@@ -27,7 +27,7 @@ PRE = _lib.CALL_ACC_PREZEROED        # per-call flag (ABI 2): this call's small 
 FUSE_TEX_ADAM = True     # the texture's Adam update inside the gradient-finishing pass (tools flip it to time the two-pass form)
 
 LOG_NAMES = ("lmk", "photo", "smooth_pose", "reg_joint", "smooth_joint", "reg_expr", "smooth_expr", "reg_shape", "reg_tex_tv",
-             "reg_tex_res_clusters", "reg_diffuse", "reg_offset_lap", "reg_offset", "reg_offset_rigid", "rest", "total")
+             "reg_tex_res_clusters", "reg_diffuse", "reg_offset_lap", "reg_offset", "reg_offset_rigid", "rest", "total", "reg_offset_dynamic")
 
 
 def _chk(rc, what):
@@ -49,7 +49,7 @@ class NativeStep:
         the sample, tracker.py:141-157) and the landmark-only stages (lmk_init_*, lmk_*_tracking: no pixel chain at all)."""
         cfg = tracker.cfg
         photometric = isinstance(cfg.pipeline[stage], PhotometricStageConfig) and cfg.w.photo is not None
-        return tracker._native_ok(stage) and (not photometric or cfg.render.background_train in ("target", "white", "black"))
+        return tracker._native_ok(stage, dynamic_offset_ok=True) and (not photometric or cfg.render.background_train in ("target", "white", "black"))
 
     def __init__(self, tracker, sample, stage):
         tr = self.tr = tracker
@@ -68,6 +68,10 @@ class NativeStep:
         self.photometric = isinstance(cfg.pipeline[stage], PhotometricStageConfig) and w.photo is not None
         self.calibrated = bool(tr.calibrated)
         self.has_offset = tr.static_offset is not None
+        # `use_dynamic_offset` (base.py:69; tracker.py:213-235, 552-600): the kernels read ONE offset row per frame of the batch,
+        # off_b = static_offset + dynamic_offset[timesteps] (VHAP_CALL_OFFSET_PER_FRAME), and the offset regularisers run per frame
+        self.dyn = getattr(tr, "dynamic_offset", None) is not None
+        self.off_flag = _lib.CALL_OFFSET_PER_FRAME if self.dyn else 0
         if self.calibrated:                                          # static sample tensors: read by every forward (new batches are copied in)
             self.K_in, self.RT_in = sample["intrinsic"], sample["extrinsic"]
         self.lmk2d = sample["lmk2d"].float().contiguous()
@@ -99,8 +103,11 @@ class NativeStep:
         self.tex_scales = (float((tr._w_tv() if tex_on else None) or 0.0) / (3.0 * T * (T - 1)),
                            float((w.reg_tex_res_clusters if tex_on else None) or 0.0) / (3.0 * T * T))
         off_on = bool(o["static_offset"] or o["dynamic_offset"])
-        self.off_scales = (float((w.reg_offset_lap if off_on else None) or 0.0) / V, float((w.reg_offset if off_on else None) or 0.0) / (3 * V),
-                           float((w.reg_offset_rigid if off_on else None) or 0.0) / 3.0)
+        nb = B if self.dyn else 1                                  # (per-frame offsets: the regularisers' means run over the frames too)
+        self.off_scales = (float((w.reg_offset_lap if off_on else None) or 0.0) / (V * nb),
+                           float((w.reg_offset if off_on else None) or 0.0) / (3 * V * nb),
+                           float((w.reg_offset_rigid if off_on else None) or 0.0) / (3.0 * nb))
+        self.dyn_scale = float((w.reg_offset_dynamic if (self.dyn and o["dynamic_offset"]) else None) or 0.0) / (3.0 * V * B)
         self.w_lmk = float(w.landmark or 0.0)
         self.want_reg = bool(o["lights"]) and w.reg_diffuse is not None
         self.w_reg = float(w.reg_diffuse or 0.0) if self.want_reg else 0.0
@@ -161,19 +168,25 @@ class NativeStep:
             # one-launch binning available (raster.hip: LDS_BIN_LIMIT bins, MAX_FRAG x 1024 triangles): binning and rasterisation can be split
             nfrag = (self.F + 1023) // 1024
             self.bin_split = ((W + 7) // 8) * ((H + 7) // 8) <= 16384 and nfrag <= 32 and self.ws_cap // (B * nfrag) >= 1
-        # forward accumulators: frame terms [0:6], landmark [6], texture terms [7:9], offset terms [9:12], shade stats [12:16], photo [16:18]
+        # forward accumulators: frame terms [0:6], landmark [6], texture terms [7:9], shade stats [12:16], photo [16:19], offset terms [20:24]
         self.accF = torch.zeros(32, **f32)
-        self.log = torch.zeros(16, **f32)
+        self.log = torch.zeros(len(LOG_NAMES), **f32)
+        if self.dyn:
+            self.off_b = E(B, V, 3)
         self.n_global = self.accF[17:18]                      # replaced by the all-reduced count under frame sharding
         # ---- backward: one arena for everything that is accumulated into ----
         params = {"shape": tr.shape, "expr": tr.expr, "rotation": tr.rotation, "translation": tr.translation, "neck_pose": tr.neck_pose,
                   "jaw_pose": tr.jaw_pose, "eyes_pose": tr.eyes_pose, "lights": tr.lights}
         if self.has_offset:
             params["static_offset"] = tr.static_offset
+        if self.dyn:
+            params["dynamic_offset"] = tr.dynamic_offset
         if not self.calibrated:
             params["focal_length"] = tr.focal_length
         sizes = {k: p.numel() for k, p in params.items()}
         extra = {"d_verts": B * V * 3, "d_A": B * J * 12, "d_t": B * 3, "d_coef": Bp * fb.Kp}
+        if self.dyn:
+            extra["d_off_b"] = B * V * 3                           # per-frame offset gradient besides the skinning part: joint regression + regularisers
         if self.photometric:
             extra.update({"d_clip": B * V * 4, "d_vn": B * V * 3, "d_tex": self.albedo_tex.numel() + self.mips.numel()})
             if self.deferred:
@@ -281,10 +294,16 @@ class NativeStep:
                                      _p(acc[7:9]), PRE, st), "vhap_tex_prep_fwd")
             if self.photometric:
                 _chk(L.vhap_texture_mip_build(_p(self.albedo_tex), 1, T, T, 3, _p(self.mips), st), "vhap_texture_mip_build")
-        if self.has_offset and any(self.off_scales):
+        if (self.has_offset or self.dyn) and any(self.off_scales):
             om = self.om
-            _chk(L.vhap_offset_reg_fwd(_p(tr.static_offset), _p(om.ptr), _p(om.col), _p(om.val), _p(om.w_lap), _p(om.w_abs), _p(om.rptr),
-                                       _p(om.ridx), om.V, om.nreg, *self.off_scales, _p(acc[9:12]), PRE, st), "vhap_offset_reg_fwd")
+            # the regularised offset (tracker.py:552-559): static_offset, or -- dynamic offsets -- one combined row per frame (means over the frames
+            # too: the scales carry 1 / B)
+            for off in (self.off_b.unbind(0) if self.dyn else (tr.static_offset,)):
+                _chk(L.vhap_offset_reg_fwd(_p(off), _p(om.ptr), _p(om.col), _p(om.val), _p(om.w_lap), _p(om.w_abs), _p(om.rptr),
+                                           _p(om.ridx), om.V, om.nreg, *self.off_scales, _p(acc[20:24]), PRE, st), "vhap_offset_reg_fwd")
+        if self.dyn and self.dyn_scale:
+            _chk(L.vhap_offset_dynamic_reg(_p(tr.dynamic_offset), _p(self.ts), self.B, self.N, self.V, self.dyn_scale, 0, _p(acc[23:24]), 0, st),
+                 "vhap_offset_dynamic_reg")
 
     def _camera_forward(self):
         L, tr, B, H, W = self.L, self.tr, self.B, self.H, self.W
@@ -324,6 +343,11 @@ class NativeStep:
             acc.zero_()                                               # ONE launch clears every forward accumulator
         self._acc_clean = False
         so = tr.static_offset
+        if self.dyn:                                              # one offset row per frame: static_offset + dynamic_offset[timesteps]
+            torch.index_select(tr.dynamic_offset, 0, self.ts, out=self.off_b)
+            if self.has_offset:
+                self.off_b.add_(tr.static_offset)
+            so = self.off_b
         self._tex_ready = None
         # the camera first, alone (one tiny workgroup per frame, ~5 us): beside the bandwidth-bound texture assembly it took 50 us, and the
         # skinning kernel behind the per-frame stage waited for it
@@ -342,15 +366,16 @@ class NativeStep:
         _chk(L.vhap_frame_prep_fwd(_p(self.ts), _p(tr.shape), _p(tr.expr), _p(tr.rotation), _p(tr.translation), _p(tr.neck_pose),
                                    _p(tr.jaw_pose), _p(tr.eyes_pose), _p(fm.JT), _p(fm.JS), _p(fm.jreg_idx), _p(fm.jreg_w), fm.jreg_n,
                                    _p(so), fm.parents, self.weights, B, self.Bp, self.N, self.NS, self.NE, J, fb.Kp, V,
-                                   _p(self.coef), _p(self.A), _p(self.transl), _p(self.Jrest), _p(acc), PRE, st), "vhap_frame_prep_fwd")
+                                   _p(self.coef), _p(self.A), _p(self.transl), _p(self.Jrest), _p(acc), PRE | self.off_flag, st), "vhap_frame_prep_fwd")
         self._flush()
         if self.photometric:                                      # skinning fused with the world -> clip transform (one launch, same bits)
             _chk(L.vhap_flame_skin_clip_fwd(_p(self.coef), _p(fb.basis), _p(self.A), _p(fb.w), _p(fb.templ), _p(so), _p(self.transl), _p(self.mvp),
-                                            B, V, fb.Vp, fb.K, fb.Kb, fb.Kp, _p(self.verts), _p(self.v_shaped), _p(self.v_posed), _p(self.clip), st),
-                 "vhap_flame_skin_clip_fwd")
+                                            B, V, fb.Vp, fb.K, fb.Kb, fb.Kp, _p(self.verts), _p(self.v_shaped), _p(self.v_posed), _p(self.clip),
+                                            self.off_flag, st), "vhap_flame_skin_clip_fwd")
         else:
             _chk(L.vhap_flame_skin_fwd(_p(self.coef), _p(fb.basis), _p(self.A), _p(fb.w), _p(fb.templ), _p(so), _p(self.transl), B, V, fb.Vp,
-                                       fb.K, fb.Kb, fb.Kp, _p(self.verts), _p(self.v_shaped), _p(self.v_posed), st), "vhap_flame_skin_fwd")
+                                       fb.K, fb.Kb, fb.Kp, _p(self.verts), _p(self.v_shaped), _p(self.v_posed), self.off_flag, st),
+                 "vhap_flame_skin_fwd")
         if not self.photometric:
             # landmark-only stage (lmk_init_*, lmk_*_tracking): no pixel chain, a handful of latency-bound launches
             self._tex_forward()
@@ -358,7 +383,7 @@ class NativeStep:
                 self._landmark_forward()
             self.arena.zero_()
             self._arena_clean = True
-            _chk(L.vhap_energy_finalize(_p(acc[0:6]), _p(acc[6:7]) if self.w_lmk else 0, _p(acc[7:9]), _p(acc[9:12]), 0, self.w_lmk, 0.0,
+            _chk(L.vhap_energy_finalize(_p(acc[0:6]), _p(acc[6:7]) if self.w_lmk else 0, _p(acc[7:9]), _p(acc[20:24]), 0, self.w_lmk, 0.0,
                                         B, H, W, _p(self.log), st), "vhap_energy_finalize")
             return
         # fork here, not at the top: next to the bandwidth-bound texture assembly the two latency-bound kernels above take 3x as long,
@@ -402,7 +427,7 @@ class NativeStep:
         _chk(L.vhap_antialias_fwd(_p(color), _p(self.rast), _p(self.clip), _p(self.tri), _p(self.opp), B, H, W, 4, V, F, _p(self.rgba_aa),
                                   _p(self.aa_work), st), "vhap_antialias_fwd")
         _chk(L.vhap_photo_fwd(_p(self.rgba_aa), _p(self.rgb), B, H, W, _p(acc[16:18]), PRE, st), "vhap_photo_fwd")
-        _chk(L.vhap_energy_finalize(_p(acc[0:6]), _p(acc[6:7]) if self.w_lmk else 0, _p(acc[7:9]), _p(acc[9:12]),
+        _chk(L.vhap_energy_finalize(_p(acc[0:6]), _p(acc[6:7]) if self.w_lmk else 0, _p(acc[7:9]), _p(acc[20:24]),
                                     _p(acc[12:16]) if self.want_reg else 0, self.w_lmk, self.w_reg, B, H, W, _p(self.log), st),
              "vhap_energy_finalize")
 
@@ -489,7 +514,7 @@ class NativeStep:
             # no cross-queue hand-overs -- between the forward and the backward pass)
             self._join()          # the side branch: texture assembly, landmarks, statistics, arena clear, antialias pair discovery
             _chk(L.vhap_photo_fwd_total(_p(self.rgba_aa), _p(self.rgb), B, H, W, _p(acc[16:19]), _p(acc[0:6]), _p(acc[6:7]) if self.w_lmk else 0,
-                                        _p(acc[7:9]), _p(acc[9:12]), _p(acc[12:16]), self.w_lmk, self.w_reg, self.w_photo,
+                                        _p(acc[7:9]), _p(acc[20:24]), _p(acc[12:16]), self.w_lmk, self.w_reg, self.w_photo,
                                         _p(self.log), _p(self.d_sum), _p(self.gmax_bound), _p(self.photo_work), PRE, st), "vhap_photo_fwd_total")
             if sort_branch is not None and self.one_graph:
                 # captured step: the sort is needed only by the backward's texture chain, ~250 us from here.  Forked BEHIND the photometric
@@ -499,7 +524,7 @@ class NativeStep:
             return
         _chk(L.vhap_photo_fwd(_p(self.rgba_aa), _p(self.rgb), B, H, W, _p(acc[16:18]), PRE, st), "vhap_photo_fwd")
         self._join()
-        _chk(L.vhap_energy_finalize(_p(acc[0:6]), _p(acc[6:7]) if self.w_lmk else 0, _p(acc[7:9]), _p(acc[9:12]),
+        _chk(L.vhap_energy_finalize(_p(acc[0:6]), _p(acc[6:7]) if self.w_lmk else 0, _p(acc[7:9]), _p(acc[20:24]),
                                     _p(acc[12:16]) if self.want_reg else 0, self.w_lmk, self.w_reg, B, H, W, _p(self.log), st),
              "vhap_energy_finalize")
 
@@ -581,10 +606,15 @@ class NativeStep:
                  "vhap_landmark_bwd")
         else:
             self.d_mvp.zero_()
-        if self.has_offset and any(self.off_scales):
-            _chk(L.vhap_offset_reg_bwd(_p(tr.static_offset), _p(om.ptr), _p(om.col), _p(om.val), _p(om.w_lap), _p(om.w_abs), _p(om.rptr),
-                                       _p(om.ridx), om.V, om.nreg, *self.off_scales, _p(self.ones), _p(g["static_offset"]), st),
-                 "vhap_offset_reg_bwd")
+        if (self.has_offset or self.dyn) and any(self.off_scales):
+            pairs = zip(self.off_b.unbind(0), g["d_off_b"].view(B, V, 3).unbind(0)) if self.dyn else ((tr.static_offset, g["static_offset"]),)
+            for off, d_off in pairs:
+                _chk(L.vhap_offset_reg_bwd(_p(off), _p(om.ptr), _p(om.col), _p(om.val), _p(om.w_lap), _p(om.w_abs), _p(om.rptr),
+                                           _p(om.ridx), om.V, om.nreg, *self.off_scales, _p(self.ones), _p(d_off), st),
+                     "vhap_offset_reg_bwd")
+        if self.dyn and self.dyn_scale:
+            _chk(L.vhap_offset_dynamic_reg(_p(tr.dynamic_offset), _p(self.ts), B, self.N, V, self.dyn_scale, _p(self.ones), 0,
+                                           _p(g["dynamic_offset"]), st), "vhap_offset_dynamic_reg")
 
     def _bwd_pixel(self, world_size, after_first=None):
         """energy total -> photometric -> antialias -> shading backward (-> d_albedo, d_normal per pixel)"""
@@ -657,6 +687,24 @@ class NativeStep:
         _chk(L.vhap_texture_bwd(_p(self.albedo_tex), _p(self.mips), 1, T, T, 3, _p(self.texc), _p(self.texd), _p(self.d_albedo), B, H, W,
                                 0, 0, _p(self.d_texc), _p(self.d_texd), _stream()), "vhap_texture_bwd")
 
+    def _frame_prep_bwd(self, st):
+        """per-frame parameters (+ the joint-regression part of the offset gradient); with dynamic offsets: then the offset gradient of every
+        frame -- skinning part g_shaped + d_off_b (joint regression, regularisers) -- to static_offset (summed) and dynamic_offset[timesteps]"""
+        L, tr, fb, fm, g = self.L, self.tr, self.fb, self.fm, self.g
+        B, V, J = self.B, self.V, self.J
+        off_in = self.off_b if self.dyn else tr.static_offset
+        g_off = g["d_off_b"] if self.dyn else (g["static_offset"] if self.has_offset else None)
+        _chk(L.vhap_frame_prep_bwd(_p(self.ts), _p(tr.shape), _p(tr.expr), _p(tr.rotation), _p(tr.translation), _p(tr.neck_pose),
+                                   _p(tr.jaw_pose), _p(tr.eyes_pose), _p(fm.JS), _p(fm.jreg_idx), _p(fm.jreg_w), fm.jreg_n,
+                                   _p(off_in), fm.parents, self.weights, _p(self.Jrest), _p(g["d_coef"]), _p(g["d_A"]), _p(g["d_t"]),
+                                   _p(self.ones), B, self.Bp, self.N, self.NS, self.NE, J, fb.Kp, V, _p(g["shape"]), _p(g["expr"]),
+                                   _p(g["rotation"]), _p(g["translation"]), _p(g["neck_pose"]), _p(g["jaw_pose"]), _p(g["eyes_pose"]),
+                                   _p(g_off), self.off_flag, st), "vhap_frame_prep_bwd")
+        if self.dyn:
+            _chk(L.vhap_offset_grad_finish(_p(self.g_shaped), _p(g["d_off_b"]), _p(self.ts), B, self.N, V,
+                                           _p(g["static_offset"]) if self.has_offset else 0, _p(g["dynamic_offset"]), st),
+                 "vhap_offset_grad_finish")
+
     def _bwd_params(self):
         """d_verts, d_mvp -> camera -> skinning -> per-frame parameters (the tail shared by photometric and landmark-only stages)"""
         L, tr, fb, fm, g = self.L, self.tr, self.fb, self.fm, self.g
@@ -668,14 +716,9 @@ class NativeStep:
         _chk(L.vhap_flame_skin_bwd(_p(g["d_verts"]), 0, _p(self.v_posed), _p(self.A), _p(fb.w), _p(fb.basisT), B, V, fb.Vp, fb.Kb, fb.Kp,
                                    _p(self.g_posed), _p(self.g_shaped), 0, _p(g["d_coef"]), _p(g["d_A"]), _p(g["d_t"]), PRE, st),
              "vhap_flame_skin_bwd")
-        if self.has_offset:
+        if self.has_offset and not self.dyn:
             _chk(L.vhap_sum_frames(_p(self.g_shaped), B, V * 3, _p(g["static_offset"]), st), "vhap_sum_frames")
-        _chk(L.vhap_frame_prep_bwd(_p(self.ts), _p(tr.shape), _p(tr.expr), _p(tr.rotation), _p(tr.translation), _p(tr.neck_pose),
-                                   _p(tr.jaw_pose), _p(tr.eyes_pose), _p(fm.JS), _p(fm.jreg_idx), _p(fm.jreg_w), fm.jreg_n,
-                                   _p(tr.static_offset), fm.parents, self.weights, _p(self.Jrest), _p(g["d_coef"]), _p(g["d_A"]), _p(g["d_t"]),
-                                   _p(self.ones), B, self.Bp, self.N, self.NS, self.NE, J, fb.Kp, V, _p(g["shape"]), _p(g["expr"]),
-                                   _p(g["rotation"]), _p(g["translation"]), _p(g["neck_pose"]), _p(g["jaw_pose"]), _p(g["eyes_pose"]),
-                                   _p(g["static_offset"]) if self.has_offset else 0, st), "vhap_frame_prep_bwd")
+        self._frame_prep_bwd(st)
 
     def _bwd_geometry(self, early=None, after_first=None):
         """G-buffer backward -> vertex normals -> clip transform -> camera -> skinning -> per-frame parameters"""
@@ -702,17 +745,13 @@ class NativeStep:
         _chk(L.vhap_verts_bwd_fused(_p(self.verts), _p(self.csr.tri), _p(self.csr.ptr), _p(self.csr.idx), _p(self.vn), _p(self.vn_inv), _p(g["d_vn"]),
                                     _p(self.mvp), _p(g["d_clip"]), _p(g["d_verts"]), _p(self.v_posed), _p(self.A), _p(fb.w), _p(fb.basisT), B, V,
                                     fb.Vp, fb.Kb, fb.Kp, _p(self.vn_scratch), _p(self.g_posed), _p(self.g_shaped), _p(g["d_coef"]), _p(g["d_A"]),
-                                    _p(g["d_t"]), _p(self.d_mvp), _p(g["static_offset"]) if self.has_offset else 0, PRE, st), "vhap_verts_bwd_fused")
+                                    _p(g["d_t"]), _p(self.d_mvp), _p(g["static_offset"]) if (self.has_offset and not self.dyn) else 0, PRE, st),
+             "vhap_verts_bwd_fused")
         if not self.calibrated:
             # the camera backward (d_mvp -> d focal_length: one tiny launch) feeds nothing but Adam: beside the per-frame backward, not ahead of it
             self._side(lambda: _chk(L.vhap_camera_focal_bwd(_p(self.RT), _p(self.d_mvp), B, 0, H, W, self.focal_scale, _p(g["focal_length"]),
                                                             _stream()), "vhap_camera_focal_bwd"), self.side2)
-        _chk(L.vhap_frame_prep_bwd(_p(self.ts), _p(tr.shape), _p(tr.expr), _p(tr.rotation), _p(tr.translation), _p(tr.neck_pose),
-                                   _p(tr.jaw_pose), _p(tr.eyes_pose), _p(fm.JS), _p(fm.jreg_idx), _p(fm.jreg_w), fm.jreg_n,
-                                   _p(tr.static_offset), fm.parents, self.weights, _p(self.Jrest), _p(g["d_coef"]), _p(g["d_A"]), _p(g["d_t"]),
-                                   _p(self.ones), B, self.Bp, self.N, self.NS, self.NE, J, fb.Kp, V, _p(g["shape"]), _p(g["expr"]),
-                                   _p(g["rotation"]), _p(g["translation"]), _p(g["neck_pose"]), _p(g["jaw_pose"]), _p(g["eyes_pose"]),
-                                   _p(g["static_offset"]) if self.has_offset else 0, st), "vhap_frame_prep_bwd")
+        self._frame_prep_bwd(st)
         self._flush()                                                 # (the camera backward: forked behind the vertex stage, issued behind the per-frame backward's launch)
 
     def backward(self, world_size=1, part="all", optimizer=None):

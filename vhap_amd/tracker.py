@@ -381,9 +381,11 @@ class FlameTracker:
         return E_total, log_dict, verts, faces, lmks, albedos, result_dict
 
     # ---- native step: the whole energy through fused HIP stages (vhap_amd.native / fused / ops) ----
-    def _native_ok(self, stage):
+    def _native_ok(self, stage, dynamic_offset_ok=False):
+        """`dynamic_offset_ok`: the caller handles per-frame vertex offsets (vhap_amd/step.py::NativeStep does; the autograd formulation
+        over the fused stages, _compute_energy_native, does not -- `use_dynamic_offset` then takes the host formulation)"""
         return (self.fused and self.native and stage is not None and str(self.device).startswith("cuda") and
-                not self.cfg.model.use_dynamic_offset and self.render.lighting_type == "SH" and
+                (dynamic_offset_ok or not self.cfg.model.use_dynamic_offset) and self.render.lighting_type == "SH" and
                 self.render.lighting_space == "world" and len(self.flame._parents) == 5 and
                 self.cfg.model.tex_extra and self.cfg.model.residual_tex)
 
