@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VHAP_ABI_VERSION 4
+#define VHAP_ABI_VERSION 5
 
 #define VHAP_OK 0
 #define VHAP_E_NULLPTR (-1)   /* a required pointer is NULL */
@@ -659,7 +659,19 @@ int vhap_plan_info(vhap_plan_t plan, int* n_nodes, int* n_streams, int* n_events
 /* text dump, one line per node in launch order ("index stream kernel <- predecessors | waits | records"); returns the bytes needed */
 size_t vhap_plan_describe(vhap_plan_t plan, char* buf, size_t cap);
 int vhap_plan_node_name(vhap_plan_t plan, int node, char* buf, size_t cap);
-int vhap_plan_launch(vhap_plan_t plan, vhap_stream_t stream);
+/* call_flags: 0, or VHAP_CALL_PLAN_DEFER_JOIN -- the replay does NOT make `stream` wait for the plan's side streams at its end: what
+ * vhap_plan_open_tails lists keeps running while the caller enqueues more work on `stream`.  The NEXT replay of the same plan is ordered
+ * behind that work wherever it matters through the side streams themselves (they are in order); the caller asserts that nothing it
+ * enqueues on `stream` before the next vhap_plan_join (or the next joined replay) touches what those open tails read or write.  The step
+ * host uses it to start step k+1's geometry chain under step k's texture update (vhap_amd/tracker.py::GraphedStep). */
+#define VHAP_CALL_PLAN_DEFER_JOIN 64
+int vhap_plan_launch(vhap_plan_t plan, vhap_stream_t stream, int call_flags);
+int vhap_plan_join(vhap_plan_t plan, vhap_stream_t stream);
+/* the nodes a DEFER_JOIN replay leaves un-joined (indices into launch order, at most `cap` written); returns their number */
+int vhap_plan_open_tails(vhap_plan_t plan, int* nodes, int cap);
+/* the nodes of the NEXT replay that are not ordered behind those open tails (not on a stream carrying one, not downstream of a node that
+ * is): together with whatever the caller enqueues between the replays, these are what must not conflict with the open tails */
+int vhap_plan_free_heads(vhap_plan_t plan, int* nodes, int cap);
 /* one replay with every node bracketed by timing events; blocks until done.  start_us[k] (relative to the head of the replay) and
  * dur_us[k] of node k, n >= number of nodes.  For per-kernel numbers inside the step (bench.py's roofline line), not for the step time. */
 int vhap_plan_launch_timed(vhap_plan_t plan, vhap_stream_t stream, float* start_us, float* dur_us, int n);

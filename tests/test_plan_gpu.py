@@ -1,0 +1,68 @@
+"""The step plan executor's deferred join (include/vhap_hip.h VHAP_CALL_PLAN_DEFER_JOIN; vhap_amd/tracker.py::GraphedStep.replay_stream):
+inside a loop of replays step k+1's geometry chain starts under step k's texture tail.  The condition is structural and checked here on the
+plan of the shipped step; the result must be the joined loop's."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from test_fit_parity_gpu import NAMES, _make, _record
+
+pytestmark = pytest.mark.gpu
+
+
+def _update_rel(a, b, start):
+    return float(np.linalg.norm((a - b).ravel()) / max(np.linalg.norm((b - start).ravel()), 1e-12))
+
+
+def test_deferred_join_loop_matches_joined_loop(flame_model):
+    from vhap_amd.tracker import GraphedStep
+    H = W = 128
+    stage, K = "rgb_global_tracking", 12
+    S = _make(flame_model, H, W, 3, 256, seed=29)
+    tr = S["tr"]
+    tr.render.disturb_rate_fg = tr.render.disturb_rate_bg = None
+    start = {k: getattr(tr, k).detach().clone() for k in NAMES}
+    sample = tr.get_sample(np.array([0, 1, 2]), device_index=True)
+    opt = tr.configure_optimizer(tr.get_train_parameters(stage), lr_scale=0.1)
+    st = GraphedStep(tr, sample, opt, stage, warmup=0)
+    assert st.ns is not None and st.single and st.gF.plan is not None
+    tails, heads = st.gF.open_tails(), st.gF.free_heads()
+    lines = ["open tails: " + ", ".join(t.split("(")[0] for t in tails), "free heads: " + ", ".join(t.split("(")[0] for t in heads)]
+    assert st.defer_join, lines                       # the shipped step qualifies: this test must exercise the deferred path
+    assert tails and all(any(o in t for o in st.TEX_TAIL) for t in tails)
+    assert all(any(o in t for o in st.GEOMETRY_HEAD) for t in heads)
+
+    def run(deferred):
+        with torch.no_grad():
+            for k in NAMES:
+                getattr(tr, k).copy_(start[k])
+        opt.reset_state()
+        E = []
+        if deferred:
+            with st.replay_stream():
+                for _ in range(K):
+                    E.append(st().clone())             # (the energy lives on the launch stream: readable without a join)
+        else:
+            for _ in range(K):
+                E.append(st().clone())
+        torch.cuda.synchronize()
+        return [float(e) for e in E], {k: getattr(tr, k).detach().cpu().numpy().copy() for k in NAMES}
+
+    E_j, P_j = run(False)
+    E_d, P_d = run(True)
+    E_j2, P_j2 = run(False)                           # the joined loop against itself: the noise floor (atomics -> Adam)
+    s0 = {k: v.cpu().numpy() for k, v in start.items()}
+    fails = []
+    for i, (a, b) in enumerate(zip(E_d, E_j)):
+        if abs(a - b) > 2e-4 * abs(b):
+            fails.append(f"energy at step {i}: deferred {a} joined {b}")
+    for k in NAMES:
+        d, floor = _update_rel(P_d[k], P_j[k], s0[k]), _update_rel(P_j2[k], P_j[k], s0[k])
+        lines.append(f"{k}: deferred vs joined {d:.2e}   joined vs joined {floor:.2e}")
+        if d > max(10 * floor, 2e-3):
+            fails.append(f"{k}: {d:.2e} (floor {floor:.2e})")
+    assert E_d[-1] < E_d[0]
+    _record("plan_deferred_join.txt", lines + fails)
+    assert not fails, fails

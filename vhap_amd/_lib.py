@@ -113,11 +113,14 @@ SIGNATURES = {
     "vhap_plan_info": (c_i, [c_fp] + [ctypes.POINTER(c_i)] * 3),
     "vhap_plan_describe": (c_sz, [c_fp, ctypes.c_char_p, c_sz]),
     "vhap_plan_node_name": (c_i, [c_fp, c_i, ctypes.c_char_p, c_sz]),
-    "vhap_plan_launch": (c_i, [c_fp, c_fp]),
+    "vhap_plan_launch": (c_i, [c_fp, c_fp, c_i]),
+    "vhap_plan_join": (c_i, [c_fp, c_fp]),
+    "vhap_plan_open_tails": (c_i, [c_fp, ctypes.POINTER(c_i), c_i]),
+    "vhap_plan_free_heads": (c_i, [c_fp, ctypes.POINTER(c_i), c_i]),
     "vhap_plan_launch_timed": (c_i, [c_fp, c_fp, ctypes.POINTER(c_f), ctypes.POINTER(c_f), c_i]),
 }
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 # call_flags of include/vhap_hip.h (per-call arguments since ABI 2; the library keeps no mutable state)
 CALL_ACC_PREZEROED, CALL_AA_PASSTHROUGH_DONE, CALL_ADAM_KEEP_STEP, CALL_ADAM_STEP_ADVANCED, CALL_OFFSET_PER_FRAME = 1, 2, 4, 16, 32
 

@@ -34,6 +34,7 @@ struct PlanNode {
     std::vector<int> waits;             // events to wait for before the launch
     int record = -1;                    // event to record behind the launch
     std::vector<int> deps;              // predecessor nodes (launch order indices)
+    bool open_tail = false;             // side-stream node with no path to a later node of stream 0 (see vhap_plan_launch, DEFER_JOIN)
     std::string name;
 };
 
@@ -46,6 +47,7 @@ struct vhap_plan {
     hipEvent_t start = nullptr;         // recorded on the launch stream at the head of a replay: the side streams' roots wait for it
     std::vector<hipEvent_t> tails;      // one per side stream: the launch stream waits for them at the end of a replay
     std::vector<hipEvent_t> tev;        // timing events (2 per node + 1), created by the first timed launch
+    bool tails_open = false;            // the last launch deferred its join
     int device = 0;
 };
 
@@ -228,6 +230,27 @@ extern "C" int vhap_plan_from_graph(void* hip_graph, int max_streams, vhap_plan_
             nd.waits.push_back(p->nodes[d].record);
         }
     }
+    // ---- open tails: side-stream nodes that nothing on stream 0 waits for, directly, through a successor, or through a LATER node of
+    //      their own stream -- what a DEFER_JOIN replay leaves running when stream 0's last node has finished ----
+    {
+        std::vector<char> covered(n, 0), later(ns, 0);
+        for (size_t k = n; k-- > 0;) {
+            PlanNode& nd = p->nodes[k];
+            if (nd.stream == 0 || later[nd.stream]) covered[k] = 1;
+            if (covered[k]) {
+                later[nd.stream] = 1;
+                for (int d : nd.deps) covered[d] = 1;             // (deps precede k in launch order: visited later in this reverse sweep)
+            }
+        }
+        // a dependency marked covered above may sit on a side stream: everything before it on that stream is covered too
+        std::fill(later.begin(), later.end(), 0);
+        for (size_t k = n; k-- > 0;) {
+            PlanNode& nd = p->nodes[k];
+            if (covered[k]) later[nd.stream] = 1;
+            else if (later[nd.stream]) covered[k] = 1;
+            nd.open_tail = !covered[k];
+        }
+    }
     bool ok = true;
     for (auto& e : p->events) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&p->start, hipEventDisableTiming) == hipSuccess;
@@ -290,7 +313,7 @@ extern "C" int vhap_plan_node_name(vhap_plan_t plan, int node, char* buf, size_t
     return VHAP_OK;
 }
 
-static int plan_launch(vhap_plan* p, hipStream_t launch, bool timed) {
+static int plan_launch(vhap_plan* p, hipStream_t launch, bool timed, bool defer_join = false) {
     const size_t n = p->nodes.size();
 #define PLAN_HIP(x) do { if ((x) != hipSuccess) return VHAP_E_HIP; } while (0)
     if (timed && p->tev.empty()) {
@@ -312,16 +335,64 @@ static int plan_launch(vhap_plan* p, hipStream_t launch, bool timed) {
     }
     for (size_t s = 0; s < p->streams.size(); s++) {
         PLAN_HIP(hipEventRecord(p->tails[s], p->streams[s]));
-        PLAN_HIP(hipStreamWaitEvent(launch, p->tails[s], 0));
+        if (!defer_join) PLAN_HIP(hipStreamWaitEvent(launch, p->tails[s], 0));
     }
+    p->tails_open = defer_join && !p->streams.empty();
 #undef PLAN_HIP
     return VHAP_OK;
 }
 
-extern "C" int vhap_plan_launch(vhap_plan_t plan, vhap_stream_t stream) {
+extern "C" int vhap_plan_launch(vhap_plan_t plan, vhap_stream_t stream, int call_flags) {
     VHAP_ENTER();
     if (!plan) return VHAP_E_NULLPTR;
-    return plan_launch(plan, vhap_stream(stream), false);
+    return plan_launch(plan, vhap_stream(stream), false, (call_flags & VHAP_CALL_PLAN_DEFER_JOIN) != 0);
+}
+
+// `stream` waits for the side-stream work of the last replay (no-op when that replay joined itself)
+extern "C" int vhap_plan_join(vhap_plan_t plan, vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!plan) return VHAP_E_NULLPTR;
+    if (plan->tails_open) {
+        for (size_t s = 0; s < plan->streams.size(); s++)
+            if (hipStreamWaitEvent(vhap_stream(stream), plan->tails[s], 0) != hipSuccess) return VHAP_E_HIP;
+        plan->tails_open = false;
+    }
+    return VHAP_OK;
+}
+
+// nodes of the NEXT replay that are not ordered behind the open tails of a DEFER_JOIN replay: neither on a stream that carries an open
+// tail (streams are in order) nor downstream of a node that is
+extern "C" int vhap_plan_free_heads(vhap_plan_t plan, int* nodes, int cap) {
+    if (!plan) return VHAP_E_NULLPTR;
+    const size_t n = plan->nodes.size();
+    std::vector<char> tail_stream(plan->streams.size() + 1, 0), ordered(n, 0);
+    for (const PlanNode& nd : plan->nodes) if (nd.open_tail) tail_stream[nd.stream] = 1;
+    int m = 0;
+    for (size_t k = 0; k < n; k++) {
+        const PlanNode& nd = plan->nodes[k];
+        bool o = tail_stream[nd.stream] != 0;
+        for (int d : nd.deps) o = o || ordered[d];
+        // (stream order inside the replay: a later node of a stream follows its earlier ones)
+        for (size_t j = 0; j < k && !o; j++) o = plan->nodes[j].stream == nd.stream && ordered[j];
+        ordered[k] = o;
+        if (!o) {
+            if (nodes && m < cap) nodes[m] = (int)k;
+            m++;
+        }
+    }
+    return m;
+}
+
+// nodes a DEFER_JOIN replay leaves un-joined: indices into launch order, at most `cap` written; returns their number
+extern "C" int vhap_plan_open_tails(vhap_plan_t plan, int* nodes, int cap) {
+    if (!plan) return VHAP_E_NULLPTR;
+    int m = 0;
+    for (size_t k = 0; k < plan->nodes.size(); k++)
+        if (plan->nodes[k].open_tail) {
+            if (nodes && m < cap) nodes[m] = (int)k;
+            m++;
+        }
+    return m;
 }
 
 // One replay with every node bracketed by timing events; BLOCKS until it has finished.  start_us[k] = start of node k relative to the

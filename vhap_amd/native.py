@@ -410,6 +410,9 @@ class HipAdam(torch.optim.Optimizer):
         self._lr_host = None
         self.sync_lr()
 
+    def lr_changed(self):
+        return [float(g["lr"]) for g in self.param_groups] != self._lr_host
+
     def sync_lr(self):
         lrs = [float(g["lr"]) for g in self.param_groups]
         if lrs != self._lr_host:

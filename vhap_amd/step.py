@@ -280,8 +280,9 @@ class NativeStep:
                 fn()
         self._pending = []
 
-    def _tex_forward(self):
-        """texture assembly + pyramid + the offset regularisers: independent of the geometry chain until the texture is sampled"""
+    def _tex_forward(self, ready=None):
+        """texture assembly + pyramid + the offset regularisers: independent of the geometry chain until the texture is sampled.
+        `ready()` is called behind the pyramid -- what the rasteriser waits for -- ahead of the offset regularisers."""
         L, tr, T, acc = self.L, self.tr, self.T, self.accF
         st = _stream()
         if self.tex_fwd_on and self.photometric and T % 2 == 0 and self.mips.numel() > 0:
@@ -294,6 +295,8 @@ class NativeStep:
                                      _p(acc[7:9]), PRE, st), "vhap_tex_prep_fwd")
             if self.photometric:
                 _chk(L.vhap_texture_mip_build(_p(self.albedo_tex), 1, T, T, 3, _p(self.mips), st), "vhap_texture_mip_build")
+        if ready is not None:
+            ready()
         if (self.has_offset or self.dyn) and any(self.off_scales):
             om = self.om
             # the regularised offset (tracker.py:552-559): static_offset, or -- dynamic offsets -- one combined row per frame (means over the frames
@@ -358,11 +361,10 @@ class NativeStep:
             # critical path together with the geometry chain: start it at once on the side branch.  (Measured alternatives: forked after the
             # per-frame stage, the skinning kernel -- 27 MB of basis -- runs 70 us instead of 26 next to the texture assembly and the
             # rasteriser starts 25 us later; forked after the skinning, the rasteriser waits for the pyramid.)
-            def tex_branch():
-                self._tex_forward()
+            def tex_ready():
                 self._tex_ready = torch.cuda.Event()
                 self._tex_ready.record()
-            self._side(tex_branch)
+            self._side(lambda: self._tex_forward(ready=tex_ready))
         _chk(L.vhap_frame_prep_fwd(_p(self.ts), _p(tr.shape), _p(tr.expr), _p(tr.rotation), _p(tr.translation), _p(tr.neck_pose),
                                    _p(tr.jaw_pose), _p(tr.eyes_pose), _p(fm.JT), _p(fm.JS), _p(fm.jreg_idx), _p(fm.jreg_w), fm.jreg_n,
                                    _p(so), fm.parents, self.weights, B, self.Bp, self.N, self.NS, self.NE, J, fb.Kp, V,

@@ -1039,10 +1039,38 @@ class CapturedPlan:
     def pool(self):
         return self.g.pool()
 
-    def replay(self):
+    def replay(self, defer_join=False):
+        """`defer_join`: the replay leaves its open tails (open_tails()) running -- the current stream does not wait for them; join() does."""
         if self.plan is None:
             return self.g.replay()
-        _lib.check(_lib.lib().vhap_plan_launch(self.plan, torch.cuda.current_stream().cuda_stream), "vhap_plan_launch")
+        _lib.check(_lib.lib().vhap_plan_launch(self.plan, torch.cuda.current_stream().cuda_stream,
+                                               _lib.CALL_PLAN_DEFER_JOIN if defer_join else 0), "vhap_plan_launch")
+
+    def join(self):
+        if self.plan is not None:
+            _lib.check(_lib.lib().vhap_plan_join(self.plan, torch.cuda.current_stream().cuda_stream), "vhap_plan_join")
+
+    def _names(self, fn):
+        if self.plan is None:
+            return []
+        L = _lib.lib()
+        n = fn(self.plan, None, 0)
+        idx = (ctypes.c_int * max(n, 1))()
+        fn(self.plan, idx, n)
+        buf = ctypes.create_string_buffer(512)
+        out = []
+        for k in range(n):
+            L.vhap_plan_node_name(self.plan, idx[k], buf, 512)
+            out.append(buf.value.decode())
+        return out
+
+    def open_tails(self):
+        """Kernel names of the nodes a defer_join replay leaves un-joined."""
+        return self._names(_lib.lib().vhap_plan_open_tails)
+
+    def free_heads(self):
+        """Kernel names of the nodes of the next replay that are NOT ordered behind those open tails."""
+        return self._names(_lib.lib().vhap_plan_free_heads)
 
     def describe(self):
         if self.plan is None:
@@ -1096,8 +1124,12 @@ class GraphedStep:
     A new batch is fed by copying into `self.sample` (same shapes) -- exactly the sequential-tracking pattern.
     Replays always go to the step's own launch stream."""
 
+    TEX_TAIL = ("texgrad_tile_kernel", "tex_prep_bwd_kernel")
+    GEOMETRY_HEAD = ("camera_fwd_kernel", "frame_prep_fwd_kernel", "flame_skin_fwd_kernel", "flame_skin_clip_fwd_kernel", "bin_build_kernel")
+
     def __init__(self, tracker, sample, optimizer, stage, warmup=2, unroll=1):
         assert tracker.fused, "graph capture needs the fused (sync-free) path"
+        self.defer_join, self._in_loop = False, False
         self.tr, self.opt, self.stage = tracker, optimizer, stage
         dev = tracker.device
         self.params = [p for g in optimizer.param_groups for p in g["params"]]
@@ -1199,6 +1231,19 @@ class GraphedStep:
                     ns.backward(world, part="geometry")
                 with self.gA.capture(pool=pool, **cap):
                     optimizer.step()
+            # Step k+1 under step k's texture tail: inside replay_stream() the single-GPU plan is replayed WITHOUT joining its side
+            # streams at the end when all it leaves open is the texture gradient's tile pass and the texture finish + Adam -- they touch the
+            # texture, its gradient pyramid, its Adam state and the pixel chain's (texc, texd, d_albedo) only; the next replay's texture
+            # chain follows them on the same side stream, and its launch-stream kernels up to the rasteriser (which waits for that chain:
+            # camera, per-frame parameters, skinning, binning) touch none of it.  Any other open tail -> joined replays.
+            # The condition is checked on the plan itself: open tails within TEX_TAIL, and every node of the next replay that is not
+            # ordered behind them (by stream order or a dependency) within GEOMETRY_HEAD.  What the host enqueues between two replays
+            # (a new batch into the sample buffers; a changed learning rate -- __call__ joins first) is covered the same way.
+            self.defer_join = False
+            if self.single and self.gF.plan is not None and os.environ.get("VHAP_DEFER_JOIN", "1") != "0":
+                tails, heads = self.gF.open_tails(), self.gF.free_heads()
+                within = lambda names, ok: all(any(o in t for o in ok) for t in names)
+                self.defer_join = len(tails) > 0 and within(tails, self.TEX_TAIL) and within(heads, self.GEOMETRY_HEAD)
             self.E = ns.log[15]
             self.log_dict = ns.log_dict()
             # (one GPU: the forward accumulators are cleared at the END of the captured step -- the photometric sum / count of the last step
@@ -1271,6 +1316,8 @@ class GraphedStep:
 
     def __call__(self):
         if isinstance(self.opt, NV.HipAdam):
+            if self.defer_join and self.opt.lr_changed():
+                self.join()                                        # (the open texture tail of the last replay reads the lr table)
             self.opt.sync_lr()                                     # lr schedulers act on the host copy
         cur = torch.cuda.current_stream()
         if cur.cuda_stream != self.stream.cuda_stream:              # (inside replay_stream() the step's stream IS current)
@@ -1295,20 +1342,30 @@ class GraphedStep:
                 step.stream.wait_stream(self.cur)
                 self.ctx = torch.cuda.stream(step.stream)
                 self.ctx.__enter__()
+                step._in_loop = True
                 return step
 
             def __exit__(self, *a):
+                step._in_loop = False
+                step.join()
                 self.ctx.__exit__(*a)
                 self.cur.wait_stream(step.stream)
                 return False
         return _Ctx()
 
+    def join(self):
+        """The step's stream waits for what the last replay left running (replays inside replay_stream() defer their join)."""
+        if self.defer_join:
+            with torch.cuda.stream(self.stream):
+                self.gF.join()
+
     def _replay(self):
         tr = self.tr
+        if self.ns is not None and self.single:
+            self.gF.replay(defer_join=self.defer_join and self._in_loop)
+            return
         self.gF.replay()
         if self.ns is not None:
-            if self.single:
-                return
             if getattr(self, "lmk_only", False):
                 self.gB.replay()
                 tr.dist.all_reduce_mean_(self.ns.param_grad_flat)
