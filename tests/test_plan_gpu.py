@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from test_fit_parity_gpu import NAMES, _make, _record
+from tests.test_fit_parity_gpu import NAMES, _make, _record
 
 pytestmark = pytest.mark.gpu
 
