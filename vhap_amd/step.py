@@ -347,9 +347,9 @@ class NativeStep:
         self._acc_clean = False
         so = tr.static_offset
         if self.dyn:                                              # one offset row per frame: static_offset + dynamic_offset[timesteps]
-            torch.index_select(tr.dynamic_offset, 0, self.ts, out=self.off_b)
+            torch.index_select(tr.dynamic_offset.detach(), 0, self.ts, out=self.off_b)
             if self.has_offset:
-                self.off_b.add_(tr.static_offset)
+                self.off_b.add_(tr.static_offset.detach())
             so = self.off_b
         self._tex_ready = None
         # the camera first, alone (one tiny workgroup per frame, ~5 us): beside the bandwidth-bound texture assembly it took 50 us, and the

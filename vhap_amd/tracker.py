@@ -1124,7 +1124,9 @@ class GraphedStep:
     A new batch is fed by copying into `self.sample` (same shapes) -- exactly the sequential-tracking pattern.
     Replays always go to the step's own launch stream."""
 
-    TEX_TAIL = ("texgrad_tile_kernel", "tex_prep_bwd_kernel")
+    # (the texture gradient's sort -- workspace clear, count, scan, scatter -- its tile pass, the texture finish + Adam: the side chain of the
+    # backward that nothing on the launch stream waits for)
+    TEX_TAIL = ("vhap_zero_words_kernel", "texbin_pass_kernel", "texbin_scan_kernel", "texgrad_tile_kernel", "tex_prep_bwd_kernel")
     GEOMETRY_HEAD = ("camera_fwd_kernel", "frame_prep_fwd_kernel", "flame_skin_fwd_kernel", "flame_skin_clip_fwd_kernel", "bin_build_kernel")
 
     def __init__(self, tracker, sample, optimizer, stage, warmup=2, unroll=1):
@@ -1233,7 +1235,8 @@ class GraphedStep:
                     optimizer.step()
             # Step k+1 under step k's texture tail: inside replay_stream() the single-GPU plan is replayed WITHOUT joining its side
             # streams at the end when all it leaves open is the texture gradient's tile pass and the texture finish + Adam -- they touch the
-            # texture, its gradient pyramid, its Adam state and the pixel chain's (texc, texd, d_albedo) only; the next replay's texture
+            # texture, its gradient pyramid, its Adam state, the sort's workspace and the pixel chain's (tile ids, keep mask, texc, texd,
+            # d_albedo) only; the next replay's texture
             # chain follows them on the same side stream, and its launch-stream kernels up to the rasteriser (which waits for that chain:
             # camera, per-frame parameters, skinning, binning) touch none of it.  Any other open tail -> joined replays.
             # The condition is checked on the plan itself: open tails within TEX_TAIL, and every node of the next replay that is not
