@@ -226,3 +226,21 @@ def test_sh_diffuse_is_not_contracted(tmp_path):
     f_norm, _ = count("k_norm")
     assert f_norm > 0 and m_full > 0
     assert f_full == f_norm, f"sh_diffuse contains {f_full - f_norm} contracted multiply-add(s)"
+
+
+def test_every_library_attribute_the_package_uses_exists():
+    """Static check (no GPU needed): every `_lib.NAME` / `L.vhap_*` the package's modules refer to exists in vhap_amd/_lib.py and in the
+    header's symbol table -- a misspelt constant or entry point otherwise only shows on the GPU box."""
+    import glob
+    from vhap_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    missing = []
+    for path in glob.glob(os.path.join(root, "vhap_amd", "*.py")) + [os.path.join(root, "bench.py")] + glob.glob(os.path.join(root, "tools", "*.py")):
+        src = open(path).read()
+        for name in set(re.findall(r"\b_lib\.([A-Za-z_][A-Za-z0-9_]*)", src)) | set(re.findall(r"\b_vl\.([A-Za-z_][A-Za-z0-9_]*)", src)):
+            if not hasattr(_lib, name):
+                missing.append(f"{os.path.basename(path)}: _lib.{name}")
+        for name in set(re.findall(r"\b(?:L|lib\(\))\.(vhap_[a-z0-9_]+)", src)) - {"vhap_debug_set_flags", "vhap_debug_fill", "vhap_debug_copy"}:
+            if name not in _lib.SIGNATURES:
+                missing.append(f"{os.path.basename(path)}: {name}")
+    assert not missing, missing

@@ -123,6 +123,7 @@ SIGNATURES = {
 ABI_VERSION = 5
 # call_flags of include/vhap_hip.h (per-call arguments since ABI 2; the library keeps no mutable state)
 CALL_ACC_PREZEROED, CALL_AA_PASSTHROUGH_DONE, CALL_ADAM_KEEP_STEP, CALL_ADAM_STEP_ADVANCED, CALL_OFFSET_PER_FRAME = 1, 2, 4, 16, 32
+CALL_PLAN_DEFER_JOIN = 64
 
 _lib = None
 
