@@ -25,12 +25,16 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "plan_timeline.txt"))
     ap.add_argument("--two-pass-tex", action="store_true", help="A/B: texture gradient finish and its Adam update as two passes")
+    ap.add_argument("--debug-flags", type=int, default=0, help="library debug flags (65536: plan edge events with the system-scope fence)")
     args = ap.parse_args()
     import bench
     from vhap_amd import step as vstep
     from vhap_amd.tracker import GraphedStep
     if args.two_pass_tex:
         vstep.FUSE_TEX_ADAM = False
+    if args.debug_flags:
+        from vhap_amd import _lib
+        _lib.debug_set_flags(args.debug_flags)
     C = bench.CONFIGS[args.config]
     torch.cuda.set_device(0)
     tr, own, n_local, model, topo, gt = bench.build_tracker(C, 0, 1, "cuda:0", "weak")

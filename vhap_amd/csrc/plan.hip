@@ -251,9 +251,14 @@ extern "C" int vhap_plan_from_graph(void* hip_graph, int max_streams, vhap_plan_
             nd.open_tail = !covered[k];
         }
     }
+    // Edge events order kernels of ONE device: no system-scope fence (hipEventDisableSystemFence).  A default event makes its record a
+    // cache write-back / invalidate towards the host, and the next kernel of the recording stream waits for it: ~8 us at every one of the
+    // ~10 records on the step's main chain.  The tail events (what a host-side synchronisation of the launch stream eventually stands on)
+    // keep the system fence.  (debug flag 65536: A/B, every event with the fence)
+    const unsigned edge_flags = hipEventDisableTiming | ((vhap_g_debug_flags & 65536) ? 0u : (unsigned)hipEventDisableSystemFence);
     bool ok = true;
-    for (auto& e : p->events) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipEventCreateWithFlags(&p->start, hipEventDisableTiming) == hipSuccess;
+    for (auto& e : p->events) ok = ok && hipEventCreateWithFlags(&e, edge_flags) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&p->start, edge_flags) == hipSuccess;
     p->streams.assign(ns - 1, nullptr);
     p->tails.assign(ns - 1, nullptr);
     for (int s = 0; s + 1 < ns && ok; s++) {
