@@ -352,10 +352,13 @@ class NativeStep:
                 self.off_b.add_(tr.static_offset.detach())
             so = self.off_b
         self._tex_ready = None
-        # the camera first, alone (one tiny workgroup per frame, ~5 us): beside the bandwidth-bound texture assembly it took 50 us, and the
-        # skinning kernel behind the per-frame stage waited for it
-        self._camera_forward()
         early_tex = self.photometric and self.deferred and self.overlap
+        # the camera first, alone (one tiny workgroup per frame, ~5 us): beside the bandwidth-bound texture assembly it took 50 us, and the
+        # skinning kernel behind the per-frame stage waited for it.  (The texture branch below is FORKED ahead of it -- a root of the captured
+        # step: no event record between the camera and the per-frame stage, ~6 us on the main chain -- but issued behind the per-frame
+        # stage's launch, see _side.)
+        if not early_tex:
+            self._camera_forward()
         if early_tex:
             # deferred shading: the rasteriser itself samples the texture, so the texture assembly + pyramid (~75 us, bandwidth-bound) heads the
             # critical path together with the geometry chain: start it at once on the side branch.  (Measured alternatives: forked after the
@@ -365,6 +368,7 @@ class NativeStep:
                 self._tex_ready = torch.cuda.Event()
                 self._tex_ready.record()
             self._side(lambda: self._tex_forward(ready=tex_ready))
+            self._camera_forward()
         _chk(L.vhap_frame_prep_fwd(_p(self.ts), _p(tr.shape), _p(tr.expr), _p(tr.rotation), _p(tr.translation), _p(tr.neck_pose),
                                    _p(tr.jaw_pose), _p(tr.eyes_pose), _p(fm.JT), _p(fm.JS), _p(fm.jreg_idx), _p(fm.jreg_w), fm.jreg_n,
                                    _p(so), fm.parents, self.weights, B, self.Bp, self.N, self.NS, self.NE, J, fb.Kp, V,
@@ -473,15 +477,20 @@ class NativeStep:
         # the antialiasing's pair discovery needs the rasteriser's output only, not the colours: beside the colour disturbance instead of
         # behind it (and ahead of the statistics reduction on the side stream: the blend waits for it, the energy assembly for the other)
         self._aa_det = None
+        stats = lambda: _chk(L.vhap_raster_shade_stats(B, F, H, W, _p(self.ws), self.ws_bytes, self.ws_cap, 1, _p(acc[12:16]), _stream()),
+                             "vhap_raster_shade_stats")
         if self.aa_inplace and self.overlap:
             def detect_branch():
                 _chk(L.vhap_antialias_inplace_pairs(_p(self.rast), B, H, W, F, _p(self.aa_work), _stream()), "vhap_antialias_inplace_pairs")
+                if stats_later:
+                    # ONE hand-over back to the main chain for both: the blend waits for the pair list AND the statistics (17 us more, well
+                    # inside its slack), and the photometric sum behind it needs no wait of its own (~8 us on the main chain)
+                    stats()
                 self._aa_det = torch.cuda.Event()
                 self._aa_det.record()
             self._side(detect_branch)                             # (on the texture branch's stream: idle here)
-        if stats_later:
-            self._side(lambda: _chk(L.vhap_raster_shade_stats(B, F, H, W, _p(self.ws), self.ws_bytes, self.ws_cap, 1, _p(acc[12:16]), _stream()),
-                                    "vhap_raster_shade_stats"))
+        elif stats_later:
+            self._side(stats)
         color = self.rgba
         if self.disturb_on:
             self._disturb(st)
