@@ -20,10 +20,9 @@ constexpr int DB_NW = DB_T / 64;
 // (rast -> triangle -> vertices / normals / uvs -> texture taps) and several waves per SIMD overlap those round trips.  The [9,3] lights
 // gradient is reduced per wave (DPP, on the VALU) and per workgroup, added into one of DB_SLOTS rows of `part` (short atomic chains), and a
 // second tiny launch sums the rows into d_lights.
-// MINW: minimum waves per SIMD the register allocation must allow (112 VGPRs = 4 waves as compiled freely; 5 waves = 96 VGPRs with seven
-// spilled dwords -- A/B behind debug flag 131072, tools/plan_timeline.py --debug-flags)
-template <int MINW>
-__global__ __launch_bounds__(DB_T, MINW) void deferred_shade_bwd_kernel(const DeferredParams P) {
+// (112 VGPRs = 4 waves per SIMD.  Forced to 5 waves -- 96 VGPRs, seven spilled dwords -- it takes the same time, 168 vs 167 us in the step:
+// profiles/r03_call10_plan_timeline_w5.txt.)
+__global__ __launch_bounds__(DB_T) void deferred_shade_bwd_kernel(const DeferredParams P) {
     __shared__ float s_l[27], s_c[9];
     __shared__ float red[DB_NW * 4][27];
     __shared__ int s_nbg;
@@ -221,8 +220,7 @@ extern "C" int vhap_deferred_shade_bwd(const float* pos, const int32_t* tri, con
     const long long npix = (long long)B * H * W;
     const int blocks = (int)((npix + DB_T - 1) / DB_T);
     hipStream_t st = vhap_stream(stream);
-    if (vhap_g_debug_flags & 131072) deferred_shade_bwd_kernel<5><<<blocks, DB_T, 0, st>>>(P);
-    else deferred_shade_bwd_kernel<4><<<blocks, DB_T, 0, st>>>(P);
+    deferred_shade_bwd_kernel<<<blocks, DB_T, 0, st>>>(P);
     VHAP_LAUNCH_CHECK();
     if (d_lights) {
         vhap_deferred_lights_reduce_kernel<<<27, DB_SLOTS, 0, st>>>(work, lights, sh_const, d_reg, reinterpret_cast<const unsigned*>(stats),
