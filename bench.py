@@ -406,7 +406,7 @@ def main():
                                    "executor around the two kernel nodes, on the stream they run on (median of 9 replays; sum of the two kernel "
                                    "durations = what a rocprofv3 kernel trace of the replays shows).  frac_in_step_deferred: the step AS SHIPPED "
                                    "replaces the pass by bin_build + raster_kernel<2>, which also samples the texture, shades and composites (3 more "
-                                   "kernels of the reference pipeline) and writes 33 instead of 68 B/px -- reported against the same fixed 292 MB.  "
+                                   "kernels of the reference pipeline) and writes 35 instead of 68 B/px -- reported against the same fixed 292 MB.  "
                                    "frac_isolated: 20 back-to-back RI-fwd passes on the step's geometry, replayed 5x, HIP events around the 20.  "
                                    "traffic: PMC bytes of the newest committed measurement of the same launch sequence (a file under profiles/, "
                                    "not observed by this run).",

@@ -4,7 +4,7 @@ Run twice on the GPU box (the counters do not fit one pass, /opt/skills/guides/M
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python tools/step_pmc.py
 then   python tools/step_pmc.py --report gpurun_out/pmc_fetch gpurun_out/pmc_write  > profiles/rNN_step_pmc.json
 MFMA utilisation of the FLAME contractions (north_star asks for it), a third pass over the same script:
-    rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc_mfma -- python tools/step_pmc.py
+    rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/pmc_mfma -- python tools/step_pmc.py
     python tools/step_pmc.py --report-mfma gpurun_out/pmc_mfma > profiles/rNN_flame_mfma_pmc.json
 The step is issued as the NativeStep's eager launch sequence (the same kernels the captured graph replays; counter collection serialises
 kernels anyway), NREP times after a warm-up, between two marker launches; two calibration kernels with known byte counts (a 256 MiB fill and
@@ -23,7 +23,7 @@ if "--report-mfma" in sys.argv:
     f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
     acc = {}
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0]
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
         if "flame_" not in k and "verts_bwd_fused" not in k:
             continue
         e = acc.setdefault(k, {})
