@@ -261,8 +261,12 @@ extern "C" int vhap_plan_from_graph(void* hip_graph, int max_streams, vhap_plan_
     ok = ok && hipEventCreateWithFlags(&p->start, edge_flags) == hipSuccess;
     p->streams.assign(ns - 1, nullptr);
     p->tails.assign(ns - 1, nullptr);
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     for (int s = 0; s + 1 < ns && ok; s++) {
-        ok = ok && hipStreamCreateWithFlags(&p->streams[s], hipStreamNonBlocking) == hipSuccess;
+        // (debug flag 524288: A/B, the side streams at the LOWEST priority -- the launch stream carries the dependency chain of the step)
+        if (vhap_g_debug_flags & 524288) ok = ok && hipStreamCreateWithPriority(&p->streams[s], hipStreamNonBlocking, prio_least) == hipSuccess;
+        else ok = ok && hipStreamCreateWithFlags(&p->streams[s], hipStreamNonBlocking) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&p->tails[s], hipEventDisableTiming) == hipSuccess;
     }
     if (!ok) { destroy(p); return VHAP_E_HIP; }
