@@ -224,6 +224,10 @@ struct TexAdam {
 // saved albedo in registers (one load per texel + two halo rows per strip), the horizontal neighbours come from the adjacent lanes
 // (one halo load per wave side).  The mip part of the texture gradient is GATHERED: level l contributes 4^-l of its texel
 // d_mips[l][y >> l][x >> l] -- with n_gather = every level this replaces the whole fold cascade (vhap_texture_mip_fold).
+// (A software-pipelined variant -- 16 rows unrolled, the record of row r + 1 requested before row r is computed, waves overlapping by two
+// columns instead of halo loads -- runs this pass in 95 instead of 106 us ALONE and makes the step 28 us SLOWER: the pass is the open tail
+// that overlaps the next step's latency-bound geometry head, and a deeper memory queue starves that head.  With the side streams at the
+// lowest priority the two variants tie.  profiles/r03_call15_finish_kernel_x_priority.txt)
 // (Round 2's version was one texel per thread on a 1-D grid: a 64-bit division per texel, five scattered taps of the albedo, 2.7 TB/s
 // against the 5.9 TB/s of the Adam pass behind it -- 25 + 63 + 60 us on the tail of the step for fold + this + Adam.)
 constexpr int TEXB_ROWS = 16;
@@ -364,154 +368,6 @@ __global__ __launch_bounds__(RB) void tex_prep_bwd_kernel(TexCfg c, const float*
         }
 #pragma unroll
         for (int k = 0; k < 3; k++) { up[k] = cur[k]; cur[k] = dn[k]; }
-    }
-}
-
-// ---- the same pass, software-pipelined: the shape the captured step runs (every input present, T a multiple of 16, Adam applied) ----
-// The general kernel above issues a row's loads, waits, computes, stores, and only then touches the next row (a rolled loop with three
-// dependent waits per row: ~40 serial memory round trips per thread; 4.0 TB/s through occupancy alone).  Here the 16 rows are unrolled, the
-// record of row r + 1 (its 25 dwords: next albedo row, pixel gradient, the three fine pyramid levels -- re-fetched only when their texel
-// changes --, parameter, both Adam moments, mask) is requested before row r is computed, and waves overlap by TWO columns (lanes 0 and 63
-// hold the neighbours' columns and store nothing: 62 owned columns per wave) so that the horizontal TV neighbours come from shuffles alone
-// -- no halo loads, no divergent branch in the loop.  Same arithmetic in the same order as the general kernel.
-constexpr int TEXF_WCOLS = 62;
-constexpr int TEXF_BCOLS = (RB / 64) * TEXF_WCOLS;
-
-struct TexFRow {
-    float dn[3];        // albedo row y + 1
-    float g[3];         // d_albedo row y
-    float ex[3], am[3], av[3];
-    unsigned mask;
-};
-
-__global__ __launch_bounds__(RB) void tex_finish_adam_kernel(TexCfg c, const float* __restrict__ albedo, const unsigned char* __restrict__ res_mask,
-                                                             const float* __restrict__ d_albedo, const float* __restrict__ d_mips, int n_gather,
-                                                             const float* __restrict__ d_terms, float* __restrict__ d_extra, const TexAdam A,
-                                                             int step_add) {
-    const int T = c.T;
-    const size_t plane = (size_t)T * T;
-    const float gtv = 2.0f * c.s_tv * d_terms[0], gres = 2.0f * c.s_res * d_terms[1];
-    const float st = (float)(A.step[0] + step_add);
-    const float bc1 = 1.0f - powf(A.beta1, st);
-    const float bc2s = sqrtf(1.0f - powf(A.beta2, st));
-    const float step_size = A.lr[0] / bc1;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int x = blockIdx.x * TEXF_BCOLS + wave * TEXF_WCOLS + lane - 1, y0 = blockIdx.y * TEXB_ROWS;    // lane 0: the column left of the wave's
-    const bool in_x = x >= 0 && x < T;
-    const bool own = in_x && lane >= 1 && lane <= TEXF_WCOLS;
-    const int xc = min(max(x, 0), T - 1);                     // clamped column: every lane issues every load, values are masked by selects
-    float* __restrict__ const adam_p = A.p;
-    float* __restrict__ const adam_m = A.m;
-    float* __restrict__ const adam_v = A.v;
-    // pyramid slots as in the general kernel: levels 1..3 per row, 4.. hoisted per strip
-    size_t g_off[TEXB_MAXG];
-    int g_sh[TEXB_MAXG];
-    float g_sc[TEXB_MAXG];
-    {
-        size_t off = 0;
-        float sc = 0.25f;
-#pragma unroll
-        for (int u = 0; u < TEXB_MAXG; u++) {
-            const int l = u + 1;
-            const bool on = l <= n_gather;
-            g_off[u] = on ? off : (u > 0 ? g_off[u - 1] : 0);
-            g_sh[u] = on ? l : (u > 0 ? g_sh[u - 1] : 0);
-            g_sc[u] = on ? sc : 0.f;
-            if (on) off += (size_t)(T >> l) * (T >> l) * 3;
-            sc *= 0.25f;
-        }
-    }
-    auto mip_load = [&](int u, int y, float* m) {
-        const float* q = d_mips + g_off[u] + 3 * ((size_t)(y >> g_sh[u]) * (T >> g_sh[u]) + (xc >> g_sh[u]));
-        m[0] = q[0]; m[1] = q[1]; m[2] = q[2];
-    };
-    auto alb_load = [&](int y, float* a) {                    // zero outside the texture (its terms are masked out anyway)
-        const int yc = min(max(y, 0), T - 1);
-        const float* q = albedo + 3 * ((size_t)yc * T + xc);
-        const bool ok = in_x && y >= 0 && y < T;
-        const float a0 = q[0], a1 = q[1], a2 = q[2];
-        a[0] = ok ? a0 : 0.f; a[1] = ok ? a1 : 0.f; a[2] = ok ? a2 : 0.f;
-    };
-    auto row_load = [&](int y) {
-        TexFRow R;
-        alb_load(y + 1, R.dn);
-        const size_t i = (size_t)y * T + xc;
-        R.g[0] = d_albedo[3 * i]; R.g[1] = d_albedo[3 * i + 1]; R.g[2] = d_albedo[3 * i + 2];
-#pragma unroll
-        for (int k = 0; k < 3; k++) {
-            R.ex[k] = adam_p[k * plane + i];
-            R.am[k] = adam_m[k * plane + i];
-            R.av[k] = adam_v[k * plane + i];
-        }
-        R.mask = res_mask[i];
-        return R;
-    };
-    float coarse[3] = {0.f, 0.f, 0.f};
-    {
-        float m[TEXB_MAXG - 3][3];
-#pragma unroll
-        for (int u = 3; u < TEXB_MAXG; u++) mip_load(u, y0, m[u - 3]);
-#pragma unroll
-        for (int u = 3; u < TEXB_MAXG; u++) {          // level order
-            coarse[0] += g_sc[u] * m[u - 3][0]; coarse[1] += g_sc[u] * m[u - 3][1]; coarse[2] += g_sc[u] * m[u - 3][2];
-        }
-    }
-    float up[3], cur[3], m1[3], m2[3], m3[3];
-    alb_load(y0 - 1, up);
-    alb_load(y0, cur);
-    mip_load(0, y0, m1); mip_load(1, y0, m2); mip_load(2, y0, m3);
-    TexFRow R = row_load(y0);
-#pragma unroll
-    for (int r = 0; r < TEXB_ROWS; r++) {
-        const int y = y0 + r;
-        const size_t i = (size_t)y * T + xc;
-        // ---- requests of row r + 1 (level l of the pyramid changes its texel every 2^l rows; y0 is a multiple of 16) ----
-        TexFRow N = R;
-        float n1[3] = {m1[0], m1[1], m1[2]}, n2[3] = {m2[0], m2[1], m2[2]}, n3[3] = {m3[0], m3[1], m3[2]};
-        if (r + 1 < TEXB_ROWS) {
-            N = row_load(y + 1);
-            if (((r + 1) & 1) == 0) mip_load(0, y + 1, n1);
-            if (((r + 1) & 3) == 0) mip_load(1, y + 1, n2);
-            if (((r + 1) & 7) == 0) mip_load(2, y + 1, n3);
-        }
-        // ---- row r ----
-        float g[3] = {R.g[0], R.g[1], R.g[2]};
-        g[0] += g_sc[0] * m1[0]; g[1] += g_sc[0] * m1[1]; g[2] += g_sc[0] * m1[2];
-        g[0] += g_sc[1] * m2[0]; g[1] += g_sc[1] * m2[1]; g[2] += g_sc[1] * m2[2];
-        g[0] += g_sc[2] * m3[0]; g[1] += g_sc[2] * m3[1]; g[2] += g_sc[2] * m3[2];
-        g[0] += coarse[0]; g[1] += coarse[1]; g[2] += coarse[2];
-        if (gtv != 0.f) {
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const float lf = __shfl_up(cur[k], 1, 64), rt = __shfl_down(cur[k], 1, 64);
-                float acc = 0.f;
-                if (y + 1 < T) acc += cur[k] - R.dn[k];
-                if (y > 0) acc += cur[k] - up[k];
-                if (x + 1 < T) acc += cur[k] - rt;
-                if (x > 0) acc += cur[k] - lf;
-                g[k] += gtv * acc;
-            }
-        }
-        if (gres != 0.f && R.mask) {
-#pragma unroll
-            for (int k = 0; k < 3; k++) g[k] += gres * R.ex[k];
-        }
-        if (own) {
-            d_extra[i] = g[0]; d_extra[plane + i] = g[1]; d_extra[2 * plane + i] = g[2];
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const size_t j = k * plane + i;
-                const float gi = g[k];
-                const float mi = R.am[k] + (gi - R.am[k]) * (1.0f - A.beta1);              // lerp, like torch
-                const float vi = A.beta2 * R.av[k] + (1.0f - A.beta2) * gi * gi;
-                adam_m[j] = mi;
-                adam_v[j] = vi;
-                adam_p[j] = R.ex[k] - step_size * mi / (sqrtf(vi) / bc2s + A.eps);
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 3; k++) { up[k] = cur[k]; cur[k] = R.dn[k]; m1[k] = n1[k]; m2[k] = n2[k]; m3[k] = n3[k]; }
-        R = N;
     }
 }
 
@@ -680,13 +536,6 @@ extern "C" int vhap_tex_prep_bwd_adam(const float* albedo_hwc, float* extra, con
     if (!albedo_hwc || !extra || !d_terms || !d_extra || !exp_avg || !exp_avg_sq || !lr_device || !step_device) return VHAP_E_NULLPTR;
     if (T <= 0 || n_gather < 0 || n_gather > TEXB_MAXG || (d_mips_hwc && n_gather > 0 && (T & ((1 << n_gather) - 1)))) return VHAP_E_BADDIM;
     TexCfg c{T, s_tv, s_res};
-    if (res_mask && d_albedo_hwc && d_mips_hwc && n_gather >= 3 && T % TEXB_ROWS == 0 && !(vhap_g_debug_flags & 262144)) {     // (flag: A/B, the general kernel)
-        tex_finish_adam_kernel<<<dim3(vhap_cdiv(T, TEXF_BCOLS), T / TEXB_ROWS), RB, 0, vhap_stream(stream)>>>(
-            c, albedo_hwc, res_mask, d_albedo_hwc, d_mips_hwc, n_gather, d_terms, d_extra,
-            TexAdam{extra, exp_avg, exp_avg_sq, lr_device, step_device, beta1, beta2, eps}, (call_flags & VHAP_CALL_ADAM_STEP_ADVANCED) ? 0 : 1);
-        VHAP_LAUNCH_CHECK();
-        return VHAP_OK;
-    }
     tex_prep_bwd_kernel<true><<<dim3(vhap_cdiv(T, RB), vhap_cdiv(T, TEXB_ROWS)), RB, 0, vhap_stream(stream)>>>(
         c, albedo_hwc, extra, res_mask, d_albedo_hwc, n_gather > 0 ? d_mips_hwc : nullptr, n_gather, d_terms, d_extra,
         TexAdam{extra, exp_avg, exp_avg_sq, lr_device, step_device, beta1, beta2, eps}, (call_flags & VHAP_CALL_ADAM_STEP_ADVANCED) ? 0 : 1);

@@ -1126,8 +1126,7 @@ class GraphedStep:
 
     # (the texture gradient's sort -- workspace clear, count, scan, scatter -- its tile pass, the texture finish + Adam: the side chain of the
     # backward that nothing on the launch stream waits for)
-    TEX_TAIL = ("vhap_zero_words_kernel", "texbin_pass_kernel", "texbin_scan_kernel", "texgrad_tile_kernel", "tex_prep_bwd_kernel",
-                "tex_finish_adam_kernel")
+    TEX_TAIL = ("vhap_zero_words_kernel", "texbin_pass_kernel", "texbin_scan_kernel", "texgrad_tile_kernel", "tex_prep_bwd_kernel")
     GEOMETRY_HEAD = ("camera_fwd_kernel", "frame_prep_fwd_kernel", "flame_skin_fwd_kernel", "flame_skin_clip_fwd_kernel", "bin_build_kernel")
 
     def __init__(self, tracker, sample, optimizer, stage, warmup=2, unroll=1):
