@@ -104,7 +104,7 @@ __device__ __forceinline__ unsigned vhap_wave_sum_u32_dpp(unsigned v) {
 
 // Zero-fill / copy as ordinary kernel launches.  hipMemsetAsync / hipMemcpyAsync become memset / memcpy NODES under
 // stream capture, and on ROCm 7.2 those nodes were observed to run out of order with the neighbouring kernel nodes when
-// the graph is replayed on the null stream (stale accumulators, tools/debug_graph6.py) -- kernels nodes keep their order.
+// the graph is replayed on the null stream (stale accumulators) -- kernel nodes keep their order.
 // `bytes` must be a multiple of 4 and `p` 4-byte aligned.
 static __global__ __launch_bounds__(256) void vhap_zero_words_kernel(uint32_t* __restrict__ p, size_t nwords) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (size_t)gridDim.x * 256) p[i] = 0u;
