@@ -66,3 +66,59 @@ def test_deferred_join_loop_matches_joined_loop(flame_model):
     assert E_d[-1] < E_d[0]
     _record("plan_deferred_join.txt", lines + fails)
     assert not fails, fails
+
+
+def test_deferred_join_at_baseline_size_repeated():
+    """The same comparison where the overlap is largest -- BASELINE config 2 (16 x 512^2, T = 2048: the texture tail is ~300 us, the next
+    step's geometry head runs underneath it), disturbance ON (in-kernel random numbers: counter-based, the same in both loops), five
+    deferred loops of 12 steps against the joined loop.  A race between a step's open tail and the next step's head would show as an
+    occasional excursion; the bound is the joined loop's own run-to-run spread."""
+    import bench
+    from vhap_amd.tracker import GraphedStep
+    C = bench.CONFIGS[2]
+    tr, own, n_local, model, topo, gt = bench.build_tracker(C, 0, 1, "cuda:0", "weak")
+    stage, K = bench.STAGE, 12
+    opt = tr.configure_optimizer(tr.get_train_parameters(stage), lr_scale=0.1)
+    sample = tr.get_sample(own, device_index=True)
+    st = GraphedStep(tr, sample, opt, stage, warmup=0)
+    assert st.single and st.defer_join
+    names = [k for k in NAMES if getattr(tr, k, None) is not None]
+    start = {k: getattr(tr, k).detach().clone() for k in names}
+    rng0 = tr.render._rng_state.clone()                         # the in-kernel random numbers are a function of this counter: same draws in every loop
+
+    def run(deferred):
+        with torch.no_grad():
+            for k in names:
+                getattr(tr, k).copy_(start[k])
+        opt.reset_state()
+        tr.render._rng_state.copy_(rng0)
+        E = []
+        if deferred:
+            with st.replay_stream():
+                for _ in range(K):
+                    E.append(st().clone())
+        else:
+            for _ in range(K):
+                E.append(st().clone())
+        torch.cuda.synchronize()
+        return np.array([float(e) for e in E]), {k: getattr(tr, k).detach().cpu().numpy().copy() for k in names}
+
+    s0 = {k: v.cpu().numpy() for k, v in start.items()}
+    E_j, P_j = run(False)
+    E_j2, P_j2 = run(False)
+    floor = {k: _update_rel(P_j2[k], P_j[k], s0[k]) for k in names}
+    e_floor = float(np.abs(E_j2 - E_j).max() / np.abs(E_j).max())
+    lines = [f"config 2, {K} steps; joined vs joined: energy {e_floor:.2e}, " + " ".join(f"{k} {v:.1e}" for k, v in floor.items())]
+    fails = []
+    for rep in range(5):
+        E_d, P_d = run(True)
+        e = float(np.abs(E_d - E_j).max() / np.abs(E_j).max())
+        worst = {k: _update_rel(P_d[k], P_j[k], s0[k]) for k in names}
+        lines.append(f"deferred loop {rep}: energy {e:.2e}, " + " ".join(f"{k} {v:.1e}" for k, v in worst.items()))
+        if e > max(10 * e_floor, 1e-4):
+            fails.append(f"loop {rep}: energy {e:.2e}")
+        for k, v in worst.items():
+            if v > max(20 * floor[k], 5e-3):
+                fails.append(f"loop {rep}: {k} {v:.2e} (floor {floor[k]:.2e})")
+    _record("plan_deferred_join_cfg2.txt", lines + fails)
+    assert not fails, fails
