@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VHAP_ABI_VERSION 5
+#define VHAP_ABI_VERSION 6
 
 #define VHAP_OK 0
 #define VHAP_E_NULLPTR (-1)   /* a required pointer is NULL */
@@ -162,8 +162,11 @@ int vhap_raster_shade_stats(int B, int F, int H, int W, void* workspace, size_t 
  *         histogram (the count pass of the binning) is filled in here, from registers; follow with vhap_texture_grad_binned_counted()
  *   tile_ids [B,H,W] uint16 (may be NULL): the uv tile (of vhap_texture_grad_binned) each pixel's texture gradient falls into, 0xFFFF = none --
  *         follow with vhap_texture_grad_binned_ids(), whose sorting passes then read 2 B per pixel instead of uv + d_albedo
+ *   call_flags: VHAP_CALL_DELTA_UNSCALED -- d_delta holds the antialias backward's colour part per unit of d_sum (written by
+ *         vhap_photo_fwd_total's antialias job, which runs beside the photometric sum and therefore cannot know d_sum): multiplied here
  * Replaces vhap_photo_bwd (optionally) + vhap_shade_bwd + the d_uv / d_uv_da part of vhap_texture_bwd (and the re-reading of five
  * G-buffer images). */
+#define VHAP_CALL_DELTA_UNSCALED 128
 size_t vhap_deferred_shade_bwd_work_floats(int B, int H, int W);
 /* d_lights == NULL with a work table: only the partial sums are accumulated into `work`; finish later (off the critical path) with this */
 int vhap_deferred_lights_reduce(const float* work, const float* lights, const float* sh_const, const float* d_reg,
@@ -176,7 +179,7 @@ int vhap_deferred_shade_bwd(const float* pos, const int32_t* tri, const float* v
                             const float* stats, int B, int V, int VT, int F, int H, int W, float* texc, float* texd,
                             float* d_albedo, float* d_normal, float* d_texc, float* d_texd,
                             float* d_lights, float* work, size_t work_floats, void* texbin_work,
-                            uint16_t* tile_ids, vhap_stream_t stream);
+                            uint16_t* tile_ids, int call_flags, vhap_stream_t stream);
 
 /* vhap_deferred_shade_bwd FUSED with vhap_gbuffer_bwd: the gradients w.r.t. the interpolated normal / uv / uv derivatives never leave
  * registers -- they go straight through the barycentric chain into d_pos [B,V,4] and d_vnormal [B,V,3] (both ACCUMULATED, per-tile LDS
@@ -367,13 +370,17 @@ int vhap_photo_bwd(const float* pred_rgba, const float* gt_nchw, const float* d_
  * log[VHAP_LOG_COUNT], d_sum and gmax_bound (either may be NULL) from the stage accumulators (any of frame_terms .. shade_stats may be
  * NULL = term absent), so that no single-thread launch sits between the forward and the backward pass.  out3 = (sum, count, ticket): three
  * words, zero on entry (cleared here unless VHAP_CALL_ACC_PREZEROED), the ticket word is left at zero; work: VHAP_PHOTO_WORK_FLOATS floats
- * of scratch (per-workgroup partial sums: the totals are summed in a fixed order, i.e. bit-reproducible). */
+ * of scratch (per-workgroup partial sums: the totals are summed in a fixed order, i.e. bit-reproducible).
+ * aa_work + d_delta_unscaled (both or neither): the colour part of the in-place antialiasing's backward for this loss (what
+ * vhap_antialias_photo_bwd adds into d_delta), per unit of d_sum, computed by extra workgroups of the SAME launch -- it needs the final image
+ * and the pair list like the sum, and nothing of the sum's result; hand d_delta to vhap_deferred_shade_bwd with VHAP_CALL_DELTA_UNSCALED and
+ * call vhap_antialias_photo_bwd with d_delta = NULL for the position part (off the critical path). */
 #define VHAP_PHOTO_WORK_FLOATS 1024
 int vhap_photo_fwd_total(const float* pred_rgba, const float* gt_nchw, int B, int H, int W, float* out3,
                          const float* frame_terms, const float* lmk_energy, const float* tex_terms,
                          const float* off_terms, const float* shade_stats, float w_landmark, float w_reg_diffuse,
-                         float w_photo, float* log, float* d_sum, float* gmax_bound, float* work, int call_flags,
-                         vhap_stream_t stream);
+                         float w_photo, float* log, float* d_sum, float* gmax_bound, float* work,
+                         const int32_t* aa_work, float* d_delta_unscaled, int call_flags, vhap_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * FLAME geometry (vhap_amd/csrc/flame.hip): replaces lbs.blend_shapes (vhap/model/lbs.py:218-239), the

@@ -115,7 +115,7 @@ def test_deferred_kernels_match_the_separate_passes(flame_model, monkeypatch, B,
     assert L.vhap_deferred_shade_bwd(_p(ns.clip), _p(ns.tri), _p(ns.vn), _p(ns.uv), _p(ns.tri_uv), _p(ns.albedo_tex), _p(ns.mips), T, T,
                                      _p(tr.lights), _p(ns.sh_const), _p(ns.rast), _p(ns.d_color), 0, 0, 0, 0, _p(ns.keep), _p(ns.c_reg),
                                      _p(ns.accF[12:16]), B, V, ns.uv.shape[0], F, H, W, _p(texc), _p(texd), _p(d_alb), _p(d_n), _p(d_tc),
-                                     _p(d_td), _p(d_lights), _p(work), work.numel(), 0, 0, _stream()) == 0
+                                     _p(d_td), _p(d_lights), _p(work), work.numel(), 0, 0, 0, _stream()) == 0
     torch.cuda.synchronize()
     m = cov[..., None]
     assert torch.equal((texc * m).view(torch.int32), (ns.texc * m).view(torch.int32)), "re-computed uv differs from the G-buffer's"

@@ -56,7 +56,7 @@ def deferred_bwd(tb):
                                      _p(tr.lights), _p(ns.sh_const), _p(ns.rast), *ns._upstream(), _p(ns.keep) if ns.disturb_on else 0,
                                      _p(ns.c_reg) if ns.want_reg else 0, _p(acc[12:16]) if ns.want_reg else 0, B, V, ns.uv.shape[0], F, H, W,
                                      _p(ns.texc), _p(ns.texd), _p(ns.d_albedo), _p(ns.d_normal), _p(ns.d_texc), _p(ns.d_texd), 0,
-                                     _p(ns.def_work), ns.def_work.numel(), _p(ns.texbin_work) if tb else 0, 0, st())
+                                     _p(ns.def_work), ns.def_work.numel(), _p(ns.texbin_work) if tb else 0, 0, ns.delta_flag, st())
 
 
 calls = {

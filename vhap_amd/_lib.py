@@ -33,7 +33,7 @@ SIGNATURES = {
     "vhap_energy_total_bound": (c_i, [c_fp, c_fp, c_fp, c_f, c_i, c_fp, c_fp, c_fp, c_fp]),
     "vhap_deferred_shade_bwd_work_floats": (c_sz, [c_i] * 3),
     "vhap_deferred_lights_reduce": (c_i, [c_fp] * 5 + [c_i] * 3 + [c_fp, c_fp]),
-    "vhap_deferred_shade_bwd": (c_i, [c_fp] * 7 + [c_i, c_i] + [c_fp] * 11 + [c_i] * 6 + [c_fp] * 8 + [c_sz, c_fp, c_fp, c_fp]),
+    "vhap_deferred_shade_bwd": (c_i, [c_fp] * 7 + [c_i, c_i] + [c_fp] * 11 + [c_i] * 6 + [c_fp] * 8 + [c_sz, c_fp, c_fp, c_i, c_fp]),
     "vhap_deferred_gbuffer_bwd": (c_i, [c_fp] * 7 + [c_i, c_i] + [c_fp] * 12 + [c_i] * 6 + [c_fp] * 7 + [c_sz, c_fp, c_fp, c_fp]),
     "vhap_raster_bwd": (c_i, [c_fp] * 5 + [c_i] * 5 + [c_fp, c_fp]),
     "vhap_gbuffer_bwd": (c_i, [c_fp] * 12 + [c_i] * 5 + [c_fp] * 3),
@@ -106,7 +106,7 @@ SIGNATURES = {
     "vhap_adam_advance": (c_i, [c_fp, c_fp]),
     "vhap_raster_bin_vnormal": (c_i, [c_fp, c_fp, c_fp] + [c_i] * 5 + [c_fp, c_sz, c_sz, c_i] + [c_fp] * 6),
     "vhap_raster_shade_stats": (c_i, [c_i] * 4 + [c_fp, c_sz, c_sz, c_i, c_fp, c_fp]),
-    "vhap_photo_fwd_total": (c_i, [c_fp, c_fp, c_i, c_i, c_i] + [c_fp] * 6 + [c_f] * 3 + [c_fp] * 4 + [c_i, c_fp]),
+    "vhap_photo_fwd_total": (c_i, [c_fp, c_fp, c_i, c_i, c_i] + [c_fp] * 6 + [c_f] * 3 + [c_fp] * 4 + [c_fp, c_fp, c_i, c_fp]),
     "vhap_frame_ingest": (c_i, [c_fp, c_fp, c_fp] + [c_i] * 5 + [c_fp] * 4),
     "vhap_plan_from_graph": (c_i, [c_fp, c_i, ctypes.POINTER(ctypes.c_void_p)]),
     "vhap_plan_destroy": (c_i, [c_fp]),
@@ -120,10 +120,11 @@ SIGNATURES = {
     "vhap_plan_launch_timed": (c_i, [c_fp, c_fp, ctypes.POINTER(c_f), ctypes.POINTER(c_f), c_i]),
 }
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 # call_flags of include/vhap_hip.h (per-call arguments since ABI 2; the library keeps no mutable state)
 CALL_ACC_PREZEROED, CALL_AA_PASSTHROUGH_DONE, CALL_ADAM_KEEP_STEP, CALL_ADAM_STEP_ADVANCED, CALL_OFFSET_PER_FRAME = 1, 2, 4, 16, 32
 CALL_PLAN_DEFER_JOIN = 64
+CALL_DELTA_UNSCALED = 128
 
 _lib = None
 

@@ -19,6 +19,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "aa_items.h"
 
 namespace {
 
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(256) void aa_bwd_kernel(const float* __restrict__ c
 // ORIGINAL colours of both pixels of every pair, so it runs in two tiny passes over the pair list: `blend2` analyses the candidates and
 // records (pair, alpha, c0, c1); `apply` adds the deltas into the image itself.  The backward takes the original colours from the record.
 // item (12 ints): {pixel index of p0, d | use1 << 1 | edge << 2, alpha bits, frame, c0[4], c1[4]}
-constexpr int ITEM2 = 12;
+constexpr int ITEM2 = AA_ITEM2;     // (aa_items.h: the photometric sum's launch reads the list too)
 __global__ __launch_bounds__(256) void aa_blend2_kernel(const float4* __restrict__ color, const float4* __restrict__ rast,
                                                         const float4* __restrict__ pos, const int* __restrict__ tri,
                                                         const int* __restrict__ opp, const unsigned* __restrict__ cand, int H, int W,

@@ -208,7 +208,7 @@ extern "C" int vhap_deferred_shade_bwd(const float* pos, const int32_t* tri, con
                                        const float* d_sum, const float* d_delta, const float* keep, const float* d_reg, const float* stats,
                                        int B, int V, int VT, int F, int H, int W, float* texc, float* texd, float* d_albedo,
                                        float* d_normal, float* d_texc, float* d_texd, float* d_lights, float* work, size_t work_floats,
-                                       void* texbin_work, uint16_t* tile_ids, vhap_stream_t stream) {
+                                       void* texbin_work, uint16_t* tile_ids, int call_flags, vhap_stream_t stream) {
     VHAP_ENTER();
     if (!d_normal || !d_texc || !d_texd) return VHAP_E_NULLPTR;
     DeferredParams P{};
@@ -217,6 +217,7 @@ extern "C" int vhap_deferred_shade_bwd(const float* pos, const int32_t* tri, con
                                           texbin_work, tile_ids))
         return e;
     P.d_normal = d_normal; P.d_texc = reinterpret_cast<float2*>(d_texc); P.d_texd = reinterpret_cast<float4*>(d_texd);
+    P.delta_unscaled = (call_flags & VHAP_CALL_DELTA_UNSCALED) ? 1 : 0;
     const long long npix = (long long)B * H * W;
     const int blocks = (int)((npix + DB_T - 1) / DB_T);
     hipStream_t st = vhap_stream(stream);

@@ -29,6 +29,7 @@ struct DeferredParams {
     const float* gt;         // [B,3,H,W] target (image space)
     const float* d_sum;      // device scalar: d E / d sum|gt - pred|
     const float4* d_delta;   // optional with the on-the-fly gradient: sparse additional colour gradient (antialias backward), zero elsewhere
+    int delta_unscaled;      // d_delta is per unit of the upstream gradient d_sum (VHAP_CALL_DELTA_UNSCALED): multiplied here
     const float* keep;
     const float* d_reg;
     const unsigned* stats;
@@ -101,7 +102,11 @@ __device__ __forceinline__ DeferredGrad deferred_pixel(const DeferredParams& P, 
         const float4 p = P.pred[pi];
         auto sg = [](float e) { return e > 0.f ? 1.0f : (e < 0.f ? -1.0f : 0.0f); };
         g = make_float4(-sg(gp[0] - p.x) * gs, -sg(gp[HW] - p.y) * gs, -sg(gp[2 * HW] - p.z) * gs, 0.0f);
-        if (P.d_delta) { const float4 e = P.d_delta[pi]; g.x += e.x; g.y += e.y; g.z += e.z; }
+        if (P.d_delta) {
+            const float4 e = P.d_delta[pi];
+            const float k = P.delta_unscaled ? gs : 1.0f;
+            g.x += k * e.x; g.y += k * e.y; g.z += k * e.z;
+        }
     }
     if (P.keep) { const float k = P.keep[pi]; g.x *= k; g.y *= k; g.z *= k; }     // backward of the colour disturbance, folded in
     const float4* PV = P.pos + (size_t)b * P.V;

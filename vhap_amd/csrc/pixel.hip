@@ -11,6 +11,7 @@
 // One thread per pixel, 16-byte accesses where the layout allows, block reduction + one atomic per
 // block for the scalar / [9,3] outputs.
 #include "common.h"
+#include "aa_items.h"
 #include "energy_common.h"
 
 namespace {
@@ -284,6 +285,11 @@ struct PhotoTotal {
     float w_lmk, w_reg_diffuse, w_photo;
     float *log, *d_sum, *gmax_bound;
     float* part;       // [2 x gridDim.x] per-workgroup partial sums
+    // optional: the colour part of the antialias backward for this loss (aa_items.h), UNSCALED, as `aa_blocks` extra workgroups of this launch --
+    // it needs the final image and the pair list, like the sum itself, and nothing of the sum's result
+    const int* aa_work;
+    float* d_delta;
+    int aa_blocks;
 };
 template <bool TOTAL>
 __global__ __launch_bounds__(PB) void photo_fwd_kernel(const float4* __restrict__ pred, const float* __restrict__ gt, int B, int H,
@@ -291,7 +297,20 @@ __global__ __launch_bounds__(PB) void photo_fwd_kernel(const float4* __restrict_
     __shared__ float rs[NW], rn[NW];
     float s = 0.f, n = 0.f;
     const unsigned npix = (unsigned)B * H * W, HW = (unsigned)H * W;
-    for (unsigned pi = blockIdx.x * PB + threadIdx.x; pi < npix; pi += gridDim.x * PB) {
+    unsigned nblk = gridDim.x, bid = blockIdx.x;     // workgroups of the sum, this one's index among them
+    if constexpr (TOTAL) {
+        // the antialias job takes the FIRST block indices: dispatched first, its latency-bound item loop runs under the streaming sum
+        const unsigned ab = (unsigned)E.aa_blocks;
+        if (blockIdx.x < ab) {                       // a grid-stride loop over the pair list
+            const int count = E.aa_work[0];
+            for (int i = (int)blockIdx.x * PB + (int)threadIdx.x; i < count; i += (int)ab * PB)
+                aa_colour_bwd_item(E.aa_work, i, pred, gt, H, W, E.d_delta);
+            return;
+        }
+        nblk -= ab;
+        bid -= ab;
+    }
+    for (unsigned pi = bid * PB + threadIdx.x; pi < npix; pi += nblk * PB) {
         const unsigned b = pi / HW, rem = pi - b * HW;
         const unsigned y = rem / (unsigned)W, x = rem - y * (unsigned)W;
         const float* g = gt + (size_t)b * 3 * HW + (size_t)(H - 1 - y) * W + x;
@@ -312,10 +331,10 @@ __global__ __launch_bounds__(PB) void photo_fwd_kernel(const float4* __restrict_
             if constexpr (TOTAL) {
                 // per-workgroup partials + a ticket instead of two contended float atomics per workgroup: the sums come out in a fixed
                 // order (bit-reproducible energy) and the kernel's tail is one round of 64-lane loads instead of ~1500 serialised atomics
-                E.part[2 * blockIdx.x] = a;
-                E.part[2 * blockIdx.x + 1] = c;
+                E.part[2 * bid] = a;
+                E.part[2 * bid + 1] = c;
                 __threadfence();
-                last = atomicAdd(reinterpret_cast<unsigned*>(out + 2), 1u) == gridDim.x - 1;
+                last = atomicAdd(reinterpret_cast<unsigned*>(out + 2), 1u) == nblk - 1;
             } else {
                 atomicAdd(&out[0], a);
                 atomicAdd(&out[1], c);
@@ -325,7 +344,7 @@ __global__ __launch_bounds__(PB) void photo_fwd_kernel(const float4* __restrict_
             if (__shfl(last, 0, 64)) {                 // the workgroup that finished last: its first wave assembles the energy
                 __threadfence();
                 float sum = 0.f, cnt = 0.f;
-                for (unsigned i = lane; i < gridDim.x; i += 64) {
+                for (unsigned i = lane; i < nblk; i += 64) {
                     sum += __hip_atomic_load(&E.part[2 * i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     cnt += __hip_atomic_load(&E.part[2 * i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -414,16 +433,19 @@ extern "C" int vhap_photo_fwd(const float* pred_rgba, const float* gt_nchw, int 
 extern "C" int vhap_photo_fwd_total(const float* pred_rgba, const float* gt_nchw, int B, int H, int W, float* out3, const float* frame_terms,
                                     const float* lmk_energy, const float* tex_terms, const float* off_terms, const float* shade_stats,
                                     float w_landmark, float w_reg_diffuse, float w_photo, float* log, float* d_sum, float* gmax_bound,
-                                    float* work, int call_flags, vhap_stream_t stream) {
+                                    float* work, const int32_t* aa_work, float* d_delta_unscaled, int call_flags, vhap_stream_t stream) {
     VHAP_ENTER();
     if (!pred_rgba || !gt_nchw || !out3 || !log || !work) return VHAP_E_NULLPTR;
     if (int e = check_img(B, H, W)) return e;
     hipStream_t st = vhap_stream(stream);
     VHAP_ZERO_ACC(out3, 12, st);
     const long long npix = (long long)B * H * W;
+    if ((aa_work == nullptr) != (d_delta_unscaled == nullptr)) return VHAP_E_NULLPTR;
+    const int aa_blocks = aa_work ? 64 : 0;
     const PhotoTotal E{frame_terms, lmk_energy, tex_terms, off_terms, reinterpret_cast<const unsigned*>(shade_stats), w_landmark, w_reg_diffuse,
-                       w_photo, log, d_sum, gmax_bound, work};
-    photo_fwd_kernel<true><<<min(vhap_cdiv(npix, PB), MAX_BLOCKS), PB, 0, st>>>(reinterpret_cast<const float4*>(pred_rgba), gt_nchw, B, H, W, out3, E);
+                       w_photo, log, d_sum, gmax_bound, work, aa_work, d_delta_unscaled, aa_blocks};
+    photo_fwd_kernel<true><<<min(vhap_cdiv(npix, PB), MAX_BLOCKS) + aa_blocks, PB, 0, st>>>(reinterpret_cast<const float4*>(pred_rgba), gt_nchw, B, H, W,
+                                                                                              out3, E);
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;
 }

@@ -148,8 +148,16 @@ class NativeStep:
         # one GPU: energy assembly + upstream gradient in the epilogue of the photometric sum (under sharding the pixel count is all-reduced
         # between the passes, so the two glue launches stay)
         self.energy_fused = self.deferred and (tracker.dist is None or tracker.dist.world_size == 1)
+        # one GPU, in-place antialiasing: the colour part of the antialias backward is computed UNSCALED by extra workgroups of the photometric
+        # sum's launch (it needs the final image, not the sum), the shading backward multiplies it by the upstream gradient, and the position
+        # part runs on the side chain -- no antialias kernel between the photometric sum and the shading backward (20 us + a hand-over)
+        self.aa_early_bwd = False
+        self.delta_flag = 0
         # antialiasing in place + photometric gradient on the fly: no copy of the image, no dense gradient images (d_rgba_aa / d_color)
         self.aa_inplace = self.deferred
+        self.aa_early_bwd = self.energy_fused and self.aa_inplace
+        self.delta_flag = _lib.CALL_DELTA_UNSCALED if self.aa_early_bwd else 0
+        self._delta_dirty = False
         if self.photometric:
             self.clip, self.vn, self.vn_inv = E(B, V, 4), E(B, V, 3), E(B, V)
             self.rast, self.texc, self.texd = E(B, H, W, 4), E(B, H, W, 2), E(B, H, W, 4)
@@ -345,6 +353,8 @@ class NativeStep:
         if not self._acc_clean:
             acc.zero_()                                               # ONE launch clears every forward accumulator
         self._acc_clean = False
+        if self._delta_dirty:                                         # (eager use only: a forward whose backward never came left its antialias
+            self._clear_delta()                                       # colour gradients in d_delta; its pair list is still intact here)
         so = tr.static_offset
         if self.dyn:                                              # one offset row per frame: static_offset + dynamic_offset[timesteps]
             torch.index_select(tr.dynamic_offset.detach(), 0, self.ts, out=self.off_b)
@@ -526,7 +536,10 @@ class NativeStep:
             self._join()          # the side branch: texture assembly, landmarks, statistics, arena clear, antialias pair discovery
             _chk(L.vhap_photo_fwd_total(_p(self.rgba_aa), _p(self.rgb), B, H, W, _p(acc[16:19]), _p(acc[0:6]), _p(acc[6:7]) if self.w_lmk else 0,
                                         _p(acc[7:9]), _p(acc[20:24]), _p(acc[12:16]), self.w_lmk, self.w_reg, self.w_photo,
-                                        _p(self.log), _p(self.d_sum), _p(self.gmax_bound), _p(self.photo_work), PRE, st), "vhap_photo_fwd_total")
+                                        _p(self.log), _p(self.d_sum), _p(self.gmax_bound), _p(self.photo_work),
+                                        _p(self.aa_work) if self.aa_early_bwd else 0, _p(self.d_delta) if self.aa_early_bwd else 0, PRE, st),
+                 "vhap_photo_fwd_total")
+            self._delta_dirty = self.aa_early_bwd
             if sort_branch is not None and self.one_graph:
                 # captured step: the sort is needed only by the backward's texture chain, ~250 us from here.  Forked BEHIND the photometric
                 # sum -- next to it, it cost that bandwidth-bound reduction 20 us on the critical path (47 vs 26 us) -- it runs beside the
@@ -610,6 +623,12 @@ class NativeStep:
         L, tr, g, om = self.L, self.tr, self.g, self.om
         B, H, W, V = self.B, self.H, self.W, self.V
         st = _stream()
+        if self.photometric and self.aa_early_bwd:
+            # the POSITION part of the antialias backward (silhouette edges -> clip-space vertices); the colour part was computed beside the
+            # photometric sum.  Needs the upstream gradient d_sum, nothing else of the backward: here, off the pixel chain
+            _chk(L.vhap_antialias_photo_bwd(_p(self.rgba_aa), _p(self.rgb), _p(self.d_sum), _p(self.rast), _p(self.clip), _p(self.tri), _p(self.opp),
+                                            _p(self.aa_work), _p(self.vert_mask), B, H, W, V, self.F, 0, _p(g["d_clip"]), st),
+                 "vhap_antialias_photo_bwd")
         if self.w_lmk:
             l0, l1, b0, b1, boost = self.lmk_cfg
             _chk(L.vhap_landmark_bwd(_p(self.verts), _p(self.lm.vidx), _p(self.lm.bary), _p(self.mvp), _p(self.lmk2d), _p(self.c_lmk), B, V,
@@ -637,7 +656,10 @@ class NativeStep:
         else:
             _chk(L.vhap_energy_total_bound(_p(self.log), _p(acc[16:18]), _p(self.n_global), self.w_photo, int(world_size), _p(self.d_sum),
                                            _p(acc[12:16]), _p(self.gmax_bound), st), "vhap_energy_total_bound")
-        if self.aa_inplace:
+        early_aa = self.aa_inplace and self.aa_early_bwd       # (nothing to do here: see aa_early_bwd)
+        if early_aa:
+            pass
+        elif self.aa_inplace:
             # no dense gradient images: the loss gradient is evaluated on the fly (here at the pixels of the antialias pair list, in the
             # shading backward everywhere); the sparse colour part of the antialias backward travels in d_delta
             _chk(L.vhap_antialias_photo_bwd(_p(self.rgba_aa), _p(self.rgb), _p(self.d_sum), _p(self.rast), _p(self.clip), _p(self.tri), _p(self.opp),
@@ -648,7 +670,7 @@ class NativeStep:
             _chk(L.vhap_antialias_bwd(_p(self.aa_in), _p(self.rast), _p(self.clip), _p(self.tri), _p(self.opp), _p(self.d_rgba_aa), _p(self.aa_work),
                                       _p(self.vert_mask), B, H, W, 4, V, F, _p(self.d_color), _p(g["d_clip"]),
                                       _lib.CALL_AA_PASSTHROUGH_DONE, st), "vhap_antialias_bwd")   # d_color already holds the pass-through copy of d_rgba_aa
-        if after_first is not None:
+        if after_first is not None and not early_aa:
             after_first()
         # (the backward of the disturbance -- d_rgba = d_color * keep -- is folded into the shading backward)
         if self.deferred:
@@ -658,8 +680,10 @@ class NativeStep:
                                            _p(self.keep) if self.disturb_on else 0, _p(self.c_reg) if self.want_reg else 0,
                                            _p(acc[12:16]) if self.want_reg else 0, B, V, self.uv.shape[0], F, H, W, _p(self.texc), _p(self.texd),
                                            _p(self.d_albedo), _p(self.d_normal), _p(self.d_texc), _p(self.d_texd), 0,
-                                           _p(self.def_work), self.def_work.numel(), 0, 0, st),
+                                           _p(self.def_work), self.def_work.numel(), 0, 0, self.delta_flag, st),
                  "vhap_deferred_shade_bwd")
+            if after_first is not None and early_aa:          # (the main chain's kernel first, then the side branches forked behind the sum)
+                after_first()
             return
         _chk(L.vhap_shade_bwd(_p(self.normal), _p(self.albedo_px), _p(self.rast), _p(tr.lights), _p(self.sh_const), _p(self.d_color),
                               _p(self.keep) if self.disturb_on else 0, _p(self.c_reg) if self.want_reg else 0,
@@ -689,6 +713,7 @@ class NativeStep:
     def _clear_delta(self):
         if self.aa_inplace:
             _chk(self.L.vhap_antialias_clear_delta(_p(self.aa_work), self.B, self.H, self.W, _p(self.d_delta), _stream()), "vhap_antialias_clear_delta")
+            self._delta_dirty = False
 
     def _bwd_uv(self):
         """gradient w.r.t. the texture coordinates and their screen-space derivatives (input of the G-buffer backward)"""
