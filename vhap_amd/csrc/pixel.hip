@@ -441,10 +441,12 @@ extern "C" int vhap_photo_fwd_total(const float* pred_rgba, const float* gt_nchw
     VHAP_ZERO_ACC(out3, 12, st);
     const long long npix = (long long)B * H * W;
     if ((aa_work == nullptr) != (d_delta_unscaled == nullptr)) return VHAP_E_NULLPTR;
-    const int aa_blocks = aa_work ? 64 : 0;
+    // the sum's MAX_BLOCKS workgroups of 1024 threads are exactly what the chip holds at once (2 per CU): the antialias job's workgroups are
+    // taken OUT of that budget -- added on top, they delayed as many of the sum's workgroups to a second round (62 instead of 45 us)
+    const int aa_blocks = aa_work ? 32 : 0;
     const PhotoTotal E{frame_terms, lmk_energy, tex_terms, off_terms, reinterpret_cast<const unsigned*>(shade_stats), w_landmark, w_reg_diffuse,
                        w_photo, log, d_sum, gmax_bound, work, aa_work, d_delta_unscaled, aa_blocks};
-    photo_fwd_kernel<true><<<min(vhap_cdiv(npix, PB), MAX_BLOCKS) + aa_blocks, PB, 0, st>>>(reinterpret_cast<const float4*>(pred_rgba), gt_nchw, B, H, W,
+    photo_fwd_kernel<true><<<min(vhap_cdiv(npix, PB), MAX_BLOCKS - aa_blocks) + aa_blocks, PB, 0, st>>>(reinterpret_cast<const float4*>(pred_rgba), gt_nchw, B, H, W,
                                                                                               out3, E);
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;
