@@ -1,7 +1,7 @@
 #!/bin/bash
-# round 3, GPU call 19: the antialias job inside the sum's workgroup budget
+# round 3, GPU call 20: the antialias job inside the sum's workgroup budget
 set +e
-O=gpurun_out/r3c19
+O=gpurun_out/r3c20
 mkdir -p $O
 cd "$GRAFT_REPO_ROOT"
 export PYTHONUNBUFFERED=1

@@ -443,7 +443,7 @@ extern "C" int vhap_photo_fwd_total(const float* pred_rgba, const float* gt_nchw
     if ((aa_work == nullptr) != (d_delta_unscaled == nullptr)) return VHAP_E_NULLPTR;
     // the sum's MAX_BLOCKS workgroups of 1024 threads are exactly what the chip holds at once (2 per CU): the antialias job's workgroups are
     // taken OUT of that budget -- added on top, they delayed as many of the sum's workgroups to a second round (62 instead of 45 us)
-    const int aa_blocks = aa_work ? 32 : 0;
+    const int aa_blocks = aa_work ? 64 : 0;      // (65 536 threads: one item each for the pair lists of the BASELINE configs; 32 took two rounds, 58 us)
     const PhotoTotal E{frame_terms, lmk_energy, tex_terms, off_terms, reinterpret_cast<const unsigned*>(shade_stats), w_landmark, w_reg_diffuse,
                        w_photo, log, d_sum, gmax_bound, work, aa_work, d_delta_unscaled, aa_blocks};
     photo_fwd_kernel<true><<<min(vhap_cdiv(npix, PB), MAX_BLOCKS - aa_blocks) + aa_blocks, PB, 0, st>>>(reinterpret_cast<const float4*>(pred_rgba), gt_nchw, B, H, W,
