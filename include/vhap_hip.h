@@ -372,7 +372,7 @@ int vhap_photo_bwd(const float* pred_rgba, const float* gt_nchw, const float* d_
  * words, zero on entry (cleared here unless VHAP_CALL_ACC_PREZEROED), the ticket word is left at zero; work: VHAP_PHOTO_WORK_FLOATS floats
  * of scratch (per-workgroup partial sums: the totals are summed in a fixed order, i.e. bit-reproducible).
  * aa_work + d_delta_unscaled (both or neither): the colour part of the in-place antialiasing's backward for this loss (what
- * vhap_antialias_photo_bwd adds into d_delta), per unit of d_sum, computed by extra workgroups of the SAME launch -- it needs the final image
+ * vhap_antialias_photo_bwd adds into d_delta), per unit of d_sum, computed by the SAME launch ahead of the sum -- it needs the final image
  * and the pair list like the sum, and nothing of the sum's result; hand d_delta to vhap_deferred_shade_bwd with VHAP_CALL_DELTA_UNSCALED and
  * call vhap_antialias_photo_bwd with d_delta = NULL for the position part (off the critical path). */
 #define VHAP_PHOTO_WORK_FLOATS 1024

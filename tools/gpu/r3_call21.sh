@@ -1,7 +1,7 @@
 #!/bin/bash
-# round 3, GPU call 20: the antialias job inside the sum's workgroup budget
+# round 3, GPU call 21: the antialias job inside the sum's workgroup budget
 set +e
-O=gpurun_out/r3c20
+O=gpurun_out/r3c21
 mkdir -p $O
 cd "$GRAFT_REPO_ROOT"
 export PYTHONUNBUFFERED=1

@@ -285,11 +285,10 @@ struct PhotoTotal {
     float w_lmk, w_reg_diffuse, w_photo;
     float *log, *d_sum, *gmax_bound;
     float* part;       // [2 x gridDim.x] per-workgroup partial sums
-    // optional: the colour part of the antialias backward for this loss (aa_items.h), UNSCALED, as `aa_blocks` extra workgroups of this launch --
-    // it needs the final image and the pair list, like the sum itself, and nothing of the sum's result
+    // optional: the colour part of the antialias backward for this loss (aa_items.h), UNSCALED, done by this launch -- it needs the final
+    // image and the pair list, like the sum itself, and nothing of the sum's result
     const int* aa_work;
     float* d_delta;
-    int aa_blocks;
 };
 template <bool TOTAL>
 __global__ __launch_bounds__(PB) void photo_fwd_kernel(const float4* __restrict__ pred, const float* __restrict__ gt, int B, int H,
@@ -297,18 +296,15 @@ __global__ __launch_bounds__(PB) void photo_fwd_kernel(const float4* __restrict_
     __shared__ float rs[NW], rn[NW];
     float s = 0.f, n = 0.f;
     const unsigned npix = (unsigned)B * H * W, HW = (unsigned)H * W;
-    unsigned nblk = gridDim.x, bid = blockIdx.x;     // workgroups of the sum, this one's index among them
+    const unsigned nblk = gridDim.x, bid = blockIdx.x;
     if constexpr (TOTAL) {
-        // the antialias job takes the FIRST block indices: dispatched first, its latency-bound item loop runs under the streaming sum
-        const unsigned ab = (unsigned)E.aa_blocks;
-        if (blockIdx.x < ab) {                       // a grid-stride loop over the pair list
+        // the antialias job (aa_items.h): every thread takes its share of the pair list FIRST -- at most one item each for the BASELINE
+        // configurations: three dependent loads, then fire-and-forget atomics -- and goes on to the sum.  (As dedicated workgroups of this
+        // launch the job cost the sum 14 us: the chip holds exactly the sum's 512 workgroups of 1024 threads at once.)
+        if (E.aa_work) {
             const int count = E.aa_work[0];
-            for (int i = (int)blockIdx.x * PB + (int)threadIdx.x; i < count; i += (int)ab * PB)
-                aa_colour_bwd_item(E.aa_work, i, pred, gt, H, W, E.d_delta);
-            return;
+            for (int i = (int)(bid * PB + threadIdx.x); i < count; i += (int)(nblk * PB)) aa_colour_bwd_item(E.aa_work, i, pred, gt, H, W, E.d_delta);
         }
-        nblk -= ab;
-        bid -= ab;
     }
     for (unsigned pi = bid * PB + threadIdx.x; pi < npix; pi += nblk * PB) {
         const unsigned b = pi / HW, rem = pi - b * HW;
@@ -441,12 +437,9 @@ extern "C" int vhap_photo_fwd_total(const float* pred_rgba, const float* gt_nchw
     VHAP_ZERO_ACC(out3, 12, st);
     const long long npix = (long long)B * H * W;
     if ((aa_work == nullptr) != (d_delta_unscaled == nullptr)) return VHAP_E_NULLPTR;
-    // the sum's MAX_BLOCKS workgroups of 1024 threads are exactly what the chip holds at once (2 per CU): the antialias job's workgroups are
-    // taken OUT of that budget -- added on top, they delayed as many of the sum's workgroups to a second round (62 instead of 45 us)
-    const int aa_blocks = aa_work ? 64 : 0;      // (65 536 threads: one item each for the pair lists of the BASELINE configs; 32 took two rounds, 58 us)
     const PhotoTotal E{frame_terms, lmk_energy, tex_terms, off_terms, reinterpret_cast<const unsigned*>(shade_stats), w_landmark, w_reg_diffuse,
-                       w_photo, log, d_sum, gmax_bound, work, aa_work, d_delta_unscaled, aa_blocks};
-    photo_fwd_kernel<true><<<min(vhap_cdiv(npix, PB), MAX_BLOCKS - aa_blocks) + aa_blocks, PB, 0, st>>>(reinterpret_cast<const float4*>(pred_rgba), gt_nchw, B, H, W,
+                       w_photo, log, d_sum, gmax_bound, work, aa_work, d_delta_unscaled};
+    photo_fwd_kernel<true><<<min(vhap_cdiv(npix, PB), MAX_BLOCKS), PB, 0, st>>>(reinterpret_cast<const float4*>(pred_rgba), gt_nchw, B, H, W,
                                                                                               out3, E);
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;
