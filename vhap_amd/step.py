@@ -5,10 +5,14 @@ The autograd formulation (vhap_amd.tracker.FlameTracker._compute_energy_native) 
 glue: ~70 launches of a few microseconds each that zero-fill gradient buffers, add gradient contributions, multiply by scalar
 weights, concatenate and sum the energy terms and copy gradients.  Here every buffer is allocated once, all accumulators live in
 two arenas cleared by ONE launch each, the kernels accumulate straight into the parameters' .grad storage, and the energy is
-assembled by two one-thread kernels (vhap_energy_finalize / vhap_energy_total).  Same kernels, same arithmetic, same results
-(tests/test_native_gpu.py::test_native_step_matches_autograd_step).
+assembled in the epilogue of the photometric sum (one GPU; under frame sharding by two one-thread kernels, vhap_energy_finalize /
+vhap_energy_total, around the all-reduce of the pixel count).  Same kernels, same arithmetic, same results
+(tests/test_native_gpu.py::test_native_step_matches_autograd_step); every stage kind and model option of the pipeline, dynamic
+offsets included.
 
-Used by vhap_amd.tracker.GraphedStep when NativeStep.supported(); torch only provides memory, streams and the collectives.
+The call sequence is laid out over up to three streams (main chain = the dependency chain of the algorithm; the texture chain and a
+chain of small latency-bound launches beside it: _side / _flush) and is what vhap_amd.tracker.GraphedStep records once and the
+library's plan executor replays (csrc/plan.hip); torch only provides memory, streams and the collectives.
 """
 import ctypes
 import os
