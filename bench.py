@@ -127,7 +127,8 @@ def cpu_baseline(C, tr, sample, model, topo, n_timed=3, budget_s=100.0):
     `n_timed` steps (fewer if the budget runs out: a step is ~15 s on 16 cores)."""
     from oracle import energy_ref, fit_ref
     H, W = C["H"], C["W"]
-    cores = min(os.cpu_count() or 1, 16)                       # more threads only add contention for this op mix
+    n_host = os.cpu_count() or 1
+    cores = min(n_host, 16)                                    # more threads only add contention for this op mix
     torch.set_num_threads(cores)
     os.environ["OMP_NUM_THREADS"] = str(cores)
     dt = torch.float32
@@ -164,10 +165,76 @@ def cpu_baseline(C, tr, sample, model, topo, n_timed=3, budget_s=100.0):
         if time.time() - t_start > budget_s and times:
             break
     med = float(np.median(times))
-    return {"value": nb / med, "unit": "frames/s", "cores": cores, "kind": "port",
+    return {"value": nb / med, "unit": "frames/s", "cores": cores, "host_cores": n_host, "kind": "port",
             "sample": f"median of {len(times)} timed whole steps after 1 warm-up ({', '.join(f'{t:.1f}' for t in times)} s) of the quoted "
                       f"configuration ({nb}-frame batch, {H}x{W}, T={TEX}, stage {STAGE}: forward with colour disturbance + backward + Adam, "
                       f"TV / mip pyramid cost included) of the CPU oracle restatement (torch-CPU fp32 + C rasteriser, {cores} threads)"}
+
+
+def parity_vs_oracle(C, tr, sample, model, topo):
+    """Parity of the timed step at the batch it was timed on (OUTSIDE the timed region): the shipped NativeStep --
+    deferred shading, in-place antialiasing, uv-binned texture gradient, colour disturbance ON -- evaluated once more at the parameters
+    the timed loop ended on, its disturbance draws INJECTED (the same pool kernels, fed draws the oracle can replay instead of the
+    in-kernel generator), against ONE float64 evaluation of the CPU oracle on the same frames, same draws and the HIP triangle ids (the
+    rasteriser is compared bit for bit in tests/test_raster_gpu.py).  -> {energy_rel, worst_term_rel, worst_grad_rel, min_grad_cos, ...}:
+    relative error of the total energy / of the worst energy term, and the worst gradient error as a fraction of that gradient's
+    max-norm over every trained parameter."""
+    from oracle import energy_ref
+    from vhap_amd.step import NativeStep
+    H, W = C["H"], C["W"]
+    t0 = time.time()
+    cores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    cfg = tr.cfg
+    B = sample["rgb"].shape[0]
+    tr.get_train_parameters(STAGE)
+    dist = tr.render.make_disturbance((B, H, W), tr.device, generator=torch.Generator(tr.device).manual_seed(1234))
+    ns = NativeStep(tr, sample, STAGE)
+    assert ns.deferred and ns.aa_inplace and ns.disturb_on and ns.photometric
+    ns.injected = dist
+    ns.forward()
+    ns.backward(1)
+    torch.cuda.synchronize()
+    names = ["shape", "expr", "rotation", "neck_pose", "jaw_pose", "eyes_pose", "translation", "tex_extra", "lights", "static_offset"]
+    if not tr.calibrated:
+        names.append("focal_length")
+    log_n = {k: float(v) for k, v in ns.log_dict().items()}
+    g_n = {k: ns.g[k].detach().cpu().double().reshape(-1) for k in names if k in ns.g}
+    tid = (ns.rast[..., 3].long() - 1).cpu()
+    disturbed = float(1 - ns.keep.mean())
+    del ns
+    tm = {k: torch.from_numpy(np.asarray(v)) for k, v in model.items()}
+    for k in ("v_template", "shapedirs", "posedirs", "J_regressor", "lbs_weights", "lmk_bary_coords", "verts_uvs"):
+        tm[k] = tm[k].double()
+    P = {k: getattr(tr, k).detach().cpu().double().requires_grad_() for k in names}
+    o_sample = {"rgb": sample["rgb"].cpu(), "lmk2d": sample["lmk2d"].cpu(), "timestep_index": sample["timestep_index"].cpu().numpy()}
+    for k in ("intrinsic", "extrinsic"):
+        if k in sample:
+            o_sample[k] = sample[k].cpu()
+    ncl = int(topo.fid2cid.max()) + 1
+    o_dist = dict(w_fg=dist["w_fg"].cpu(), w_bg=dist["w_bg"].cpu(), idx=[dist["idx"].cpu()] * ncl,
+                  fid2cid=torch.from_numpy(topo.fid2cid.astype(np.int64)))
+    base_tex = tr.flame_tex_painted().detach().cpu().double()
+    Eo, logo, _ = energy_ref.total_energy(P, tm, topo, cfg, o_sample, STAGE, base_tex, tr._uvmask_res().cpu().double(), (H, W),
+                                          disturb=o_dist, tid=tid)
+    Eo.backward()
+    Eo = float(Eo.detach())
+    terms = {k: abs(log_n[k] - float(b.detach())) / max(abs(float(b.detach())), 1e-3) for k, b in logo.items()}
+    grads, cos = {}, {}
+    for k in names:
+        b = P[k].grad
+        if b is None or float(b.abs().max()) == 0 or k not in g_n:
+            continue
+        a, b = g_n[k], b.reshape(-1)
+        grads[k] = float((a - b).abs().max() / b.abs().max())
+        cos[k] = float((a @ b) / (a.norm() * b.norm() + 1e-300))
+    wt, wg = max(terms, key=terms.get), max(grads, key=grads.get)
+    return {"energy_rel": abs(log_n["total"] - Eo) / abs(Eo), "worst_term_rel": terms[wt], "worst_term": wt,
+            "worst_grad_rel": grads[wg], "worst_grad": wg, "min_grad_cos": min(cos.values()), "grad_rel": grads,
+            "energy_hip": log_n["total"], "energy_oracle": Eo, "frames": B, "disturbed_fraction": disturbed,
+            "oracle": f"oracle/energy_ref.total_energy in float64 on {cores} host threads, same frames, same injected disturbance draws, "
+                      "HIP triangle ids; gradients as a fraction of each gradient's max-norm",
+            "seconds": time.time() - t0}
 
 
 def time_ri_in_step(tr, sample, optimizer, deferred, n=9):
@@ -287,6 +354,7 @@ def main():
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo for single-GPU tests of the multi-rank path)")
     ap.add_argument("--unroll", type=int, default=1, help="steps per graph launch on one GPU (1 = what the stage really does)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle evaluation of the timed step's batch (parity)")
     ap.add_argument("--no-stage", action="store_true", help="skip the end-to-end stage measurement (stage_fps)")
     ap.add_argument("--eager", action="store_true", help="run optimize_iter eagerly instead of replaying the captured hipGraphs")
     args = ap.parse_args()
@@ -412,6 +480,11 @@ def main():
                                    "not observed by this run).",
                          "alg_bytes_per_launch": alg},
         }
+        if world == 1 and not args.no_parity:
+            try:
+                out["parity"] = parity_vs_oracle(C, tr, sample, model, topo)
+            except Exception as e:                               # noqa: BLE001 -- reported, never sinks the throughput number
+                out["parity"] = {"energy_rel": None, "worst_grad_rel": None, "error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(C, tr, sample, model, topo)

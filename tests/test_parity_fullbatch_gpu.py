@@ -1,0 +1,29 @@
+"""The step AS SHIPPED against the oracle at the BATCH sizes BASELINE.json names:
+
+    config 2   16 x 512 x 512 monocular, T = 2048, rgb_global_tracking
+    config 3    8 x 1024 x 1024 monocular, T = 2048, static_offset TRAINED (rgb_init_offset)
+    config 4   16 calibrated views of one timestep, 802 x 550, T = 2048, the NeRSemble configuration
+
+Every energy term and the gradient w.r.t. every parameter of NativeStep (deferred shading, in-place antialiasing, uv-binned texture gradient,
+colour disturbance ON with injected draws) against ONE fp64 oracle evaluation each (same triangle ids: the rasteriser is compared bit for
+bit at these batches in tests/test_raster_gpu.py).  What the full batch exercises that B <= 2 does not: the disturbance's colour pools over
+the whole batch (render_nvdiffrast.py:424-460), the batch-global photometric normaliser (tracker.py:439), diffuse.max() over 16 frames
+(:549), the uv-binned texture gradient summed over all frames.  Tolerances as in tests/test_parity_sizes_gpu.py (terms 5e-5; gradients
+5e-4 of the max-norm at config 2, 3e-3 at configs 3 / 4).  One oracle evaluation takes 1 - 3 minutes on the host cores."""
+import pytest
+
+from tests.test_parity_sizes_gpu import run_config2, run_config3, run_config4
+
+pytestmark = pytest.mark.gpu
+
+
+def test_full_batch_config2_16x512(flame_model):
+    run_config2(flame_model, 16, "parity_fullbatch_cfg2.txt")
+
+
+def test_full_batch_config3_8x1024_static_offset(flame_model):
+    run_config3(flame_model, 8, "parity_fullbatch_cfg3.txt")
+
+
+def test_full_batch_config4_16_views_802x550(flame_model):
+    run_config4(flame_model, 16, "parity_fullbatch_cfg4.txt")

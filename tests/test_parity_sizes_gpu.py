@@ -81,46 +81,55 @@ def _native_vs_oracle(tr, cfg, topo, tm, base_tex, sample, o_sample, stage, imag
     return fails
 
 
-def test_shipped_native_step_with_injected_disturbance_config2_size(flame_model):
+def run_config2(flame_model, B, record):
+    """BASELINE config 2 at batch B (tests/test_parity_fullbatch_gpu.py runs B = 16, the batch BASELINE names)."""
     H = W = 512
-    S = _make(flame_model, H, W, 2, T, seed=17)
+    S = _make(flame_model, H, W, B, T, seed=17)
     tr = S["tr"]
-    ts = np.array([0, 1])
+    ts = np.arange(B)
     sample = tr.get_sample(ts, device_index=True)
     o_sample = {"rgb": sample["rgb"].cpu(), "lmk2d": sample["lmk2d"].cpu(), "timestep_index": ts}
     lines = []
     fails = _native_vs_oracle(tr, S["cfg"], S["topo"], S["tm"], S["base_tex"], sample, o_sample, "rgb_global_tracking", (H, W), NAMES, lines,
                               "cfg2", seed=12)
-    _record("parity_native_injected_cfg2.txt", lines + fails)
+    _record(record, lines + fails)
     assert not fails, fails
 
 
-def test_shipped_native_step_config3_size_static_offset_trained(flame_model):
+def test_shipped_native_step_with_injected_disturbance_config2_size(flame_model):
+    run_config2(flame_model, 2, "parity_native_injected_cfg2.txt")
+
+
+def run_config3(flame_model, B, record):
     """BASELINE config 3: 1024 x 1024 with static_offset trained (stage rgb_init_offset: the offset regularisers, the full learning-rate
-    stage) -- one frame of it (the oracle needs ~20 s per megapixel)."""
+    stage) at batch B (the oracle needs ~20 s per megapixel)."""
     H = W = 1024
-    S = _make(flame_model, H, W, 1, T, seed=29)
+    S = _make(flame_model, H, W, B, T, seed=29)
     tr = S["tr"]
-    ts = np.array([0])
+    ts = np.arange(B)
     sample = tr.get_sample(ts, device_index=True)
     o_sample = {"rgb": sample["rgb"].cpu(), "lmk2d": sample["lmk2d"].cpu(), "timestep_index": ts}
     lines = []
     fails = _native_vs_oracle(tr, S["cfg"], S["topo"], S["tm"], S["base_tex"], sample, o_sample, "rgb_init_offset", (H, W), NAMES, lines,
                               "cfg3", seed=5, grad_bound=3e-3)
-    _record("parity_native_injected_cfg3.txt", lines + fails)
+    _record(record, lines + fails)
     assert not fails, fails
 
 
-def test_shipped_native_step_config4_size_calibrated_views(flame_model):
+def test_shipped_native_step_config3_size_static_offset_trained(flame_model):
+    run_config3(flame_model, 1, "parity_native_injected_cfg3.txt")
+
+
+def run_config4(flame_model, NV, record):
     """BASELINE config 4: calibrated views (K [B,3,3], RT [B,3,4]) of ONE timestep at 802 x 550 under the NeRSemble configuration
-    (w.landmark 3, reg_tex_tv 1e5, jawline landmarks off): two views on the arc of vhap_amd.synthetic.arc_cameras."""
+    (w.landmark 3, reg_tex_tv 1e5, jawline landmarks off): NV views on the arc of vhap_amd.synthetic.arc_cameras."""
     from vhap_amd.config import nersemble_config
     from vhap_amd.flame import FlameHead
     from vhap_amd.render_hip import HipDiffRenderer
     from vhap_amd.synthetic import make_multiview_dataset, make_scene_params, make_texture
     from vhap_amd.tracker import GlobalTracker
     model, topo = flame_model
-    H, W, NV = 802, 550, 2
+    H, W = 802, 550
     cfg = nersemble_config()
     cfg.model.tex_resolution = T
     gt = make_scene_params(1, seed=3, image_size=(H, W))
@@ -148,8 +157,12 @@ def test_shipped_native_step_config4_size_calibrated_views(flame_model):
     lines = []
     fails = _native_vs_oracle(tr, cfg, topo, tm, torch.from_numpy(base_tex)[None].double(), sample, o_sample, "rgb_global_tracking", (H, W),
                               names, lines, "cfg4", seed=21, grad_bound=3e-3)
-    _record("parity_native_injected_cfg4.txt", lines + fails)
+    _record(record, lines + fails)
     assert not fails, fails
+
+
+def test_shipped_native_step_config4_size_calibrated_views(flame_model):
+    run_config4(flame_model, 2, "parity_native_injected_cfg4.txt")
 
 
 def test_ten_steps_at_baseline_size_match_oracle_fit(flame_model):

@@ -122,3 +122,54 @@ def test_deferred_join_at_baseline_size_repeated():
                 fails.append(f"loop {rep}: {k} {v:.2e} (floor {floor[k]:.2e})")
     _record("plan_deferred_join_cfg2.txt", lines + fails)
     assert not fails, fails
+
+
+def test_stage_loop_with_a_new_batch_every_step_deferred_vs_joined(flame_model, monkeypatch):
+    """What a user runs (tracker.py:1376-1416): GlobalTracker.optimize_stage over shuffled batches of a resident FrameStore -- a NEW batch
+    is ingested into the captured step's static buffers BETWEEN replays, while (deferred join) the previous step's texture tail is still
+    open, and the learning rate changes every epoch.  The stage with the deferred join against the same stage with VHAP_DEFER_JOIN=0
+    (same shuffles, same in-kernel random numbers: the disturbance is ON): every exported array inside the joined stage's own
+    run-to-run spread.  """
+    from vhap_amd.ingest import FrameStore
+    from vhap_amd.tracker import GlobalTracker, ShuffledBatches
+    H = W = 256
+    N, B, T, stage, epochs = 24, 4, 512, "rgb_global_tracking", 3
+    S = _make(flame_model, H, W, N, T, seed=7)
+    tr0, cfg = S["tr"], S["cfg"]
+    u8 = (tr0.dataset["rgb"].permute(0, 2, 3, 1).clamp(0, 1) * 255).round().to(torch.uint8).contiguous()
+    names = [k for k in NAMES if getattr(tr0, k, None) is not None]
+    start = {k: getattr(tr0, k).detach().clone() for k in names}
+    keep_epochs = cfg.pipeline[stage].num_epochs
+    cfg.pipeline[stage].num_epochs = epochs
+
+    def run(defer):
+        monkeypatch.setenv("VHAP_DEFER_JOIN", "1" if defer else "0")
+        data = {"frames": FrameStore(u8, device="cuda"), "lmk2d": tr0.dataset["lmk2d"].clone()}
+        tr = GlobalTracker(cfg, S["model"], S["topo"], tr0.flame_tex_painted()[0].cpu().numpy(), data)
+        with torch.no_grad():
+            for k in names:
+                getattr(tr, k).copy_(start[k])
+        tr.render._rng_state = torch.full((1,), 12345, dtype=torch.int32, device="cuda")   # same in-kernel draws in every run
+        loader = ShuffledBatches(tr, B, device_index=True, generator=torch.Generator().manual_seed(3))
+        tr.optimize_stage(stage, dataloader=loader, lr_scale=0.1)
+        torch.cuda.synchronize()
+        st = next(iter(tr._graphed.values()))
+        assert st.single and st.gF.plan is not None and st.defer_join == defer, (st.defer_join, defer)
+        assert tr.global_step == epochs * (N // B)
+        return {k: getattr(tr, k).detach().cpu().numpy().copy() for k in names}
+
+    try:
+        P_j, P_d, P_j2 = run(False), run(True), run(False)
+    finally:
+        cfg.pipeline[stage].num_epochs = keep_epochs
+    s0 = {k: v.cpu().numpy() for k, v in start.items()}
+    lines, fails = [f"optimize_stage({stage}): {N} frames {H}x{W}, batches of {B}, {epochs} epochs = {epochs * (N // B)} steps, a new batch every step"], []
+    for k in names:
+        if float(np.abs(P_j[k] - s0[k]).max()) == 0:
+            continue
+        d, floor = _update_rel(P_d[k], P_j[k], s0[k]), _update_rel(P_j2[k], P_j[k], s0[k])
+        lines.append(f"{k}: deferred vs joined {d:.2e}   joined vs joined {floor:.2e}")
+        if d > max(10 * floor, 2e-3):
+            fails.append(f"{k}: {d:.2e} (floor {floor:.2e})")
+    _record("plan_deferred_join_stage_loop.txt", lines + fails)
+    assert not fails, fails
