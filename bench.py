@@ -202,6 +202,10 @@ def parity_vs_oracle(C, tr, sample, model, topo):
     g_n = {k: ns.g[k].detach().cpu().double().reshape(-1) for k in names if k in ns.g}
     tid = (ns.rast[..., 3].long() - 1).cpu()
     disturbed = float(1 - ns.keep.mean())
+    # the L1 term's kinks: residuals of ~1e-7 round to opposite signs in float32 and float64 at a handful of the batch's 12.6 M pixel
+    # channels, and each flips its pixel's whole contribution to d(tex_extra); the oracle takes the HIP side of them (both are
+    # subgradients of |x| at 0; energy unchanged) -- counted and reported (tools/diag_texgrad.py, tests/test_parity_sizes_gpu.py)
+    res_hip = (ns.rgba_aa[..., :3].detach().flip(1) - sample["rgb"].permute(0, 2, 3, 1)).cpu()
     del ns
     tm = {k: torch.from_numpy(np.asarray(v)) for k, v in model.items()}
     for k in ("v_template", "shapedirs", "posedirs", "J_regressor", "lbs_weights", "lmk_bary_coords", "verts_uvs"):
@@ -215,9 +219,10 @@ def parity_vs_oracle(C, tr, sample, model, topo):
     o_dist = dict(w_fg=dist["w_fg"].cpu(), w_bg=dist["w_bg"].cpu(), idx=[dist["idx"].cpu()] * ncl,
                   fid2cid=torch.from_numpy(topo.fid2cid.astype(np.int64)))
     base_tex = tr.flame_tex_painted().detach().cpu().double()
-    Eo, logo, _ = energy_ref.total_energy(P, tm, topo, cfg, o_sample, STAGE, base_tex, tr._uvmask_res().cpu().double(), (H, W),
-                                          disturb=o_dist, tid=tid)
+    Eo, logo, ex = energy_ref.total_energy(P, tm, topo, cfg, o_sample, STAGE, base_tex, tr._uvmask_res().cpu().double(), (H, W),
+                                           disturb=o_dist, tid=tid, photo_sign_from=res_hip)
     Eo.backward()
+    n_kink = int((torch.sign(ex["rgba"][..., :3].detach() - o_sample["rgb"].permute(0, 2, 3, 1).double()) != torch.sign(res_hip.double())).sum())
     Eo = float(Eo.detach())
     terms = {k: abs(log_n[k] - float(b.detach())) / max(abs(float(b.detach())), 1e-3) for k, b in logo.items()}
     grads, cos = {}, {}
@@ -231,9 +236,10 @@ def parity_vs_oracle(C, tr, sample, model, topo):
     wt, wg = max(terms, key=terms.get), max(grads, key=grads.get)
     return {"energy_rel": abs(log_n["total"] - Eo) / abs(Eo), "worst_term_rel": terms[wt], "worst_term": wt,
             "worst_grad_rel": grads[wg], "worst_grad": wg, "min_grad_cos": min(cos.values()), "grad_rel": grads,
-            "energy_hip": log_n["total"], "energy_oracle": Eo, "frames": B, "disturbed_fraction": disturbed,
+            "energy_hip": log_n["total"], "energy_oracle": Eo, "frames": B, "disturbed_fraction": disturbed, "l1_kink_pixels": n_kink,
             "oracle": f"oracle/energy_ref.total_energy in float64 on {cores} host threads, same frames, same injected disturbance draws, "
-                      "HIP triangle ids; gradients as a fraction of each gradient's max-norm",
+                      "HIP triangle ids, HIP side of the L1 kinks (l1_kink_pixels residuals of ~1e-7 have opposite signs in fp32 / fp64); "
+                      "gradients as a fraction of each gradient's max-norm",
             "seconds": time.time() - t0}
 
 

@@ -104,9 +104,10 @@ def regularization_energy(P, ts, w, stage, opt, tex_painted, uvmask_res, v_cano,
 
 
 def total_energy(P, model, topo, cfg, sample, stage, tex_painted, uvmask_res, image_size, dtype=torch.float64,
-                 disturb=None, tid=None):
+                 disturb=None, tid=None, photo_sign_from=None):
     """P: dict of parameter tensors (leaf, requires_grad) named like the GlobalTracker attributes.
     `tid`: optional [B,H,W] triangle ids (-1 = none) to use instead of rasterising (golden-vector comparisons fix the visibility).
+    `photo_sign_from`: optional residual image of another evaluation: the L1 term takes that evaluation's side of its kinks (R.photometric_energy).
     Returns (E_total, log_dict, extras)."""
     H, W = image_size
     ts = np.asarray(sample["timestep_index"])
@@ -152,7 +153,7 @@ def total_energy(P, model, topo, cfg, sample, stage, tex_painted, uvmask_res, im
         out = R.render_rgba(rast, db, verts, clip, faces, uv, tm["faces_uv"], tex, P["lights"][None],
                             sample["rgb"].to(dtype).permute(0, 2, 3, 1), torch.from_numpy(topo.opp.astype(np.int64)),
                             R.sh_const(dtype), tex_detach_mask=tmask, aa_detach_vid=amask, disturb=disturb)
-        log["photo"] = w.photo * R.photometric_energy(sample["rgb"].to(dtype), out["rgba"])
+        log["photo"] = w.photo * R.photometric_energy(sample["rgb"].to(dtype), out["rgba"], sign_from=photo_sign_from)
         extras.update(out)
         extras["tid"] = tid
     if stage is not None:

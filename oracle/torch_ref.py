@@ -545,11 +545,19 @@ def landmark_energy(pred_lmks, lmk2d, RT, K, image_size, use_jawline=True):
     return (diff.abs().sum(-1) * conf).mean()
 
 
-def photometric_energy(gt_rgb_nchw, rgba_nhwc_flipped):
-    """tracker.py:430-439: sum|gt - pred| / (3 * #{alpha > 0})."""
+def photometric_energy(gt_rgb_nchw, rgba_nhwc_flipped, sign_from=None):
+    """tracker.py:430-439: sum|gt - pred| / (3 * #{alpha > 0}).
+    `sign_from` ([B,H,W,3] image space, the residual pred - gt of ANOTHER evaluation of the same state; diagnostics / parity tests only):
+    |x| is evaluated as sign(sign_from) * x, i.e. at a residual that rounds to the other side of zero in the other evaluation (|x| ~ 1e-8)
+    the oracle takes THAT side of the kink -- both signs are subgradients of |x| at 0; the value moves by <= 2 |x| per such element."""
     pred = rgba_nhwc_flipped.permute(0, 3, 1, 2)
     mask = (pred[:, 3:4].detach() > 0).expand(-1, 3, -1, -1)
-    return (gt_rgb_nchw - pred[:, :3]).abs().sum() / mask.sum()
+    x = pred[:, :3] - gt_rgb_nchw
+    if sign_from is not None:
+        sg = torch.sign(sign_from.to(x.dtype).permute(0, 3, 1, 2))
+        sg = torch.where(sg == 0, torch.sign(x.detach()), sg)
+        return (sg * x).sum() / mask.sum()
+    return x.abs().sum() / mask.sum()
 
 
 def tex_tv_energy(tex_chw):

@@ -53,16 +53,27 @@ def _native_vs_oracle(tr, cfg, topo, tm, base_tex, sample, o_sample, stage, imag
     tid = (ns.rast[..., 3].long() - 1).cpu()
     cov = float((tid >= 0).float().mean())
     assert 0.03 < cov < 0.97, cov
+    # the L1 term's kinks: the residual pred - gt of the HIP evaluation (image space).  A handful of the 4-8 M pixel channels of a full
+    # batch have |residual| ~ 1e-7 and round to opposite signs in float32 and float64; each flips its pixel's WHOLE contribution to the few
+    # texels it samples (d tex_extra: 4.8e-4 of the max-norm at 16 x 512^2 from TWO such pixels, 4.5e-6 once the oracle takes the same
+    # side; tools/diag_texgrad.py -> profiles/r04_texgrad_kink_diagnosis_cfg2.txt).  Both signs are subgradients of |x| at 0: the oracle is
+    # handed the HIP residual's signs -- the same decomposition as the triangle ids (energy unchanged to 1e-13)
+    res_hip = (ns.rgba_aa[..., :3].detach().flip(1) - sample["rgb"].permute(0, 2, 3, 1)).cpu()
     log_n = {k: float(v) for k, v in ns.log_dict().items()}
     g_n = {k: ns.g[k].detach().clone().reshape(getattr(tr, k).shape) for k in names if k in ns.g}
     P = {k: getattr(tr, k).detach().cpu().double().requires_grad_() for k in names}
     ncl = int(topo.fid2cid.max()) + 1
     o_dist = dict(w_fg=dist["w_fg"].cpu(), w_bg=dist["w_bg"].cpu(), idx=[dist["idx"].cpu()] * ncl,
                   fid2cid=torch.from_numpy(topo.fid2cid.astype(np.int64)))
-    Eo, logo, _ = energy_ref.total_energy(P, tm, topo, cfg, o_sample, stage, base_tex, uvmask, (H, W), disturb=o_dist, tid=tid)
+    Eo, logo, ex = energy_ref.total_energy(P, tm, topo, cfg, o_sample, stage, base_tex, uvmask, (H, W), disturb=o_dist, tid=tid,
+                                           photo_sign_from=res_hip)
     Eo.backward()
+    res_ora = ex["rgba"][..., :3].detach() - sample["rgb"].permute(0, 2, 3, 1).cpu().double()
+    n_kink = int((torch.sign(res_ora) != torch.sign(res_hip.double())).sum())
     fails = []
-    lines.append(f"{tag}: {B} x {H}x{W}, T = {T}, stage {stage}, coverage {cov:.3f}, disturbed {float(1 - keep.mean()):.3f}")
+    lines.append(f"{tag}: {B} x {H}x{W}, T = {T}, stage {stage}, coverage {cov:.3f}, disturbed {float(1 - keep.mean()):.3f}, "
+                 f"L1 residuals on opposite sides of zero in the two evaluations: {n_kink} of {res_hip.numel()}")
+    assert n_kink <= 1e-5 * res_hip.numel(), n_kink
     for k, b in logo.items():
         b = float(b.detach())
         e = abs(log_n[k] - b) / max(abs(b), 1e-3)

@@ -22,8 +22,9 @@ def main():
     from vhap_amd.synthetic import arc_cameras, make_flame_model, make_texture, smooth_noise
     T = 2048
     model, topo = make_flame_model(seed=0)
-    H, W, B, stage, calibrated = {"cfg2": (512, 512, 2, "rgb_global_tracking", False), "cfg3": (1024, 1024, 1, "rgb_init_offset", False),
-                                  "cfg4": (802, 550, 2, "rgb_global_tracking", True)}[which]
+    BS = int(sys.argv[2]) if len(sys.argv) > 2 else None
+    H, W, B, stage, calibrated = {"cfg2": (512, 512, BS or 2, "rgb_global_tracking", False), "cfg3": (1024, 1024, BS or 1, "rgb_init_offset", False),
+                                  "cfg4": (802, 550, BS or 2, "rgb_global_tracking", True)}[which]
     cfg = nersemble_config() if calibrated else BaseTrackingConfig()
     cfg.model.tex_resolution = T
     g = torch.Generator().manual_seed(29)

@@ -421,8 +421,12 @@ struct RasterParams {
     unsigned long long* prof; // VHAP_RASTER_PROFILE: (first start, last end) stamps of this kernel, PROF_SLOTS pairs; or null
 };
 
+// Residency (MI355X_MICROARCH.md, "Residency"): 256-thread workgroups per CU = min(8, 800 / (ceil(sgpr / 16) * 16 + 16), VGPR limit).  Left to
+// itself the compiler takes 94-100 SGPRs for modes 0 / 1 (6 workgroups per CU instead of 8); capped at 80 it parks 19 of them in VGPR lanes, and
+// 8 waves per SIMD cost mode 1 one VGPR (63 -> 64).  Measured (profiles/r04_call2_raster_residency_ab_*.txt): mode 1 81.0 -> 79.1 us alone,
+// 91 -> 84 us in the step.  Mode 2 (73 VGPRs) stays at 6 waves per SIMD: forced to 8 it spills 8 VGPRs to scratch and runs 104 -> 123 us.
 template <int MODE>
-__global__ __launch_bounds__(256) void raster_kernel(const RasterParams P) {
+__global__ __launch_bounds__(256, MODE == 2 ? 1 : 8) __attribute__((amdgpu_num_sgpr(80))) void raster_kernel(const RasterParams P) {
     constexpr bool INTERP = MODE >= 1;
     prof_begin(P.prof);
     const unsigned L = vhap_xcd_remap(blockIdx.x, gridDim.x);
@@ -479,6 +483,9 @@ __global__ __launch_bounds__(256) void raster_kernel(const RasterParams P) {
         }
     }
 
+    // (experiments, debug flags 32 / 64: the pass as two concurrent launches -- 32: blocks without candidates leave at once, 64: only those store)
+    if ((P.debug & 32) && n == 0u) return;
+    if ((P.debug & 64) && n != 0u) return;
     unsigned long long best = ~0ull;  // (ordered z/w test value << 32) | triangle id
 
     const int bx1 = bx0 + BLK - 1, by1 = by0 + BLK - 1;
