@@ -483,7 +483,8 @@ __global__ __launch_bounds__(256, MODE == 2 ? 1 : 8) __attribute__((amdgpu_num_s
         }
     }
 
-    // (experiments, debug flags 32 / 64: the pass as two concurrent launches -- 32: blocks without candidates leave at once, 64: only those store)
+    // (experiment, profiles/r04_call4_split_launch_probe.txt -- debug flags 32 / 64: the pass as two launches, 32: blocks without candidates
+    // leave at once, 64: only those store)
     if ((P.debug & 32) && n == 0u) return;
     if ((P.debug & 64) && n != 0u) return;
     unsigned long long best = ~0ull;  // (ordered z/w test value << 32) | triangle id
