@@ -275,7 +275,7 @@ def time_ri_in_step(tr, sample, optimizer, deferred, n=9):
             os.environ["VHAP_DEFERRED"] = keep
 
 
-def stage_fps(C, tr_ref, model, topo, gt, n_frames=64, epochs=3):
+def stage_fps(C, tr_ref, model, topo, gt, n_frames=256, epochs=5):
     """The stage END TO END (tracker.py:1376-1416): GlobalTracker.optimize_stage('rgb_global_tracking') over shuffled batches of a
     sequence resident in HBM as uint8 (ingest.FrameStore) -- a new batch every step (vhap_frame_ingest into the captured step's static
     buffers + the landmark / index copies), the ExponentialLR schedule, the host loop -- not replays of one resident batch.  The
@@ -456,7 +456,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic", "timed_region_s": dt, "n_ranks_seen": n_ranks_seen,
             "stage_fps": ({"value": stage[0], "unit": "frames/s", "steps": stage[1],
-                           "what": "GlobalTracker.optimize_stage('rgb_global_tracking') end to end over shuffled batches of a 64-frame sequence "
+                           "what": "GlobalTracker.optimize_stage('rgb_global_tracking') end to end over shuffled batches of a 256-frame sequence (5 epochs) "
                                    "resident as uint8 (vhap_frame_ingest into the captured step's buffers, landmark / index hand-over, "
                                    "ExponentialLR, host loop): a NEW batch every step, like tracker.py:1376-1385"} if stage else None),
             "config": {"workload": f"BASELINE config {args.config}: {C['name']}; stage rgb_global_tracking (photometric + landmark + TV + all "

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VHAP_ABI_VERSION 6
+#define VHAP_ABI_VERSION 7
 
 #define VHAP_OK 0
 #define VHAP_E_NULLPTR (-1)   /* a required pointer is NULL */
@@ -592,6 +592,9 @@ int vhap_adam_step(int n_tensors, float* const* params, const float* const* grad
 /* step_device[0] += 1 (one tiny launch): advance the counter at the HEAD of a step, then issue the step's vhap_adam_step calls with
  * VHAP_CALL_ADAM_STEP_ADVANCED. */
 int vhap_adam_advance(int32_t* step_device, vhap_stream_t stream);
+/* dst_device[0..n) = values_host[0..n), n <= 16, as ONE tiny launch whose kernel arguments carry the values: the learning-rate table of
+ * vhap_adam_step after a scheduler step (torch.optim.lr_scheduler.ExponentialLR, tracker.py:1399-1413) without a host-blocking copy. */
+int vhap_set_floats(float* dst_device, const float* values_host, int n, vhap_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Step glue (vhap_amd/csrc/step.hip, misc.hip) for an executor that chains the stages itself instead of torch autograd

@@ -594,6 +594,26 @@ extern "C" int vhap_adam_step(int n_tensors, float* const* params, const float* 
     return VHAP_OK;
 }
 
+// n <= 16 floats handed over BY VALUE (kernel arguments): a learning-rate table changes once per epoch, and neither a pageable
+// hipMemcpy (blocks the host until the stream has drained: the whole queue of replays) nor a pinned staging buffer (lifetime) is
+// wanted for 2 - 12 numbers
+struct FloatVals {
+    float v[16];
+};
+static __global__ void set_floats_kernel(float* __restrict__ dst, FloatVals vals, int n) {
+    if ((int)threadIdx.x < n) dst[threadIdx.x] = vals.v[threadIdx.x];
+}
+extern "C" int vhap_set_floats(float* dst_device, const float* values_host, int n, vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!dst_device || !values_host) return VHAP_E_NULLPTR;
+    if (n <= 0 || n > 16) return VHAP_E_BADDIM;
+    FloatVals v{};
+    for (int i = 0; i < n; i++) v.v[i] = values_host[i];
+    set_floats_kernel<<<1, 64, 0, vhap_stream(stream)>>>(dst_device, v, n);
+    VHAP_LAUNCH_CHECK();
+    return VHAP_OK;
+}
+
 extern "C" int vhap_adam_advance(int32_t* step_device, vhap_stream_t stream) {
     VHAP_ENTER();
     if (!step_device) return VHAP_E_NULLPTR;

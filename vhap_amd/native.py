@@ -416,7 +416,12 @@ class HipAdam(torch.optim.Optimizer):
     def sync_lr(self):
         lrs = [float(g["lr"]) for g in self.param_groups]
         if lrs != self._lr_host:
-            self._lr_dev.copy_(torch.tensor(lrs, dtype=torch.float32), non_blocking=False)
+            if len(lrs) <= 16:
+                # one tiny launch on the current stream, the values in its kernel arguments: a pageable host-to-device copy would block
+                # the host until every replay queued on this stream has run (a stage loop changes the rates once per epoch)
+                _chk(_lib.lib().vhap_set_floats(_p(self._lr_dev), (ctypes.c_float * len(lrs))(*lrs), len(lrs), _stream()), "vhap_set_floats")
+            else:
+                self._lr_dev.copy_(torch.tensor(lrs, dtype=torch.float32), non_blocking=False)
             self._lr_host = lrs
 
     def reset_state(self, lr_scale_base=None):

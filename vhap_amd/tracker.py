@@ -761,10 +761,11 @@ class GlobalTracker(FlameTracker):
         # buffers -- instead of through a materialised fp32 batch and a 50 MB copy per step
         direct = isinstance(dataloader, ShuffledBatches) and self.frames is not None and self.dist is None
         H, W = self.image_size
-        for epoch_i in range(self.cfg.pipeline[stage].num_epochs):
-            if direct:
-                # the whole pass's frame indices / timesteps in ONE upload; per step only device-side slices of them
-                batches = []
+        n_epochs = self.cfg.pipeline[stage].num_epochs
+        if direct:
+            def draw_epoch():
+                """the batches of one pass: (timesteps, frame indices, timestep of every frame)"""
+                out = []
                 for ts in dataloader.index_batches():
                     ts = np.asarray(ts).reshape(-1)
                     if self._frames_of is not None:
@@ -772,19 +773,42 @@ class GlobalTracker(FlameTracker):
                         ts_f = self.frame_timestep[fidx]
                     else:
                         fidx = ts_f = ts
-                    batches.append((ts, fidx, ts_f))
-                fidx_dev = torch.as_tensor(np.concatenate([b[1] for b in batches]), device=self.device)
-                tsf_dev = torch.as_tensor(np.concatenate([b[2] for b in batches]), device=self.device)
-                ctx, cur_st, o = None, None, 0
-                try:
+                    out.append((ts, fidx, ts_f))
+                return out
+
+            def upload(batches):
+                return (torch.as_tensor(np.concatenate([b[1] for b in batches]), device=self.device),
+                        torch.as_tensor(np.concatenate([b[2] for b in batches]), device=self.device))
+            # Without evaluation passes in between, the shuffles of ALL epochs are drawn ahead (the same draws in the same order) and their
+            # frame indices / timesteps go up in ONE upload, and the step's own stream stays current across the epochs: an upload is a
+            # blocking copy -- at an epoch boundary it waited for every queued replay and the GPU then idled until the host had caught up
+            # (profiles/r04_stage_timeline_*.txt) -- per step only device-side slices of the table are touched
+            ahead = not evaluate_every
+            plan = [draw_epoch() for _ in range(n_epochs)] if ahead else None
+            if ahead and plan:
+                fidx_dev, tsf_dev = upload([b for ep in plan for b in ep])
+            ctx, cur_st, o = None, None, 0
+
+            def leave():
+                nonlocal ctx, cur_st
+                if ctx is not None:
+                    ctx.__exit__(None, None, None)
+                ctx, cur_st = None, None
+            try:
+                for epoch_i in range(n_epochs):
+                    if ahead:
+                        batches = plan[epoch_i]
+                    else:
+                        batches = draw_epoch()
+                        leave()
+                        fidx_dev, tsf_dev = upload(batches)
+                        o = 0
                     for ts, fidx, _ in batches:
                         n = len(fidx)
                         st = self._graphed.get((stage, (n, 3, H, W), float(lr_scale)))
                         fresh = st is None or (opt is not None and st.opt is not opt)
                         if fresh:
-                            if ctx is not None:
-                                ctx.__exit__(None, None, None)
-                                ctx, cur_st = None, None
+                            leave()
                             st = step_for(self.get_sample(ts, device_index=True), opt)
                         if opt is None:
                             opt = st.opt
@@ -795,8 +819,7 @@ class GlobalTracker(FlameTracker):
                             sched = torch.optim.lr_scheduler.ExponentialLR(opt, gamma=0.9)
                         st.fresh = False
                         if st is not cur_st:                      # the step's own stream stays current across the steps of a pass: no stream hop per step
-                            if ctx is not None:
-                                ctx.__exit__(None, None, None)
+                            leave()
                             ctx = st.replay_stream()
                             ctx.__enter__()
                             cur_st = st
@@ -805,22 +828,26 @@ class GlobalTracker(FlameTracker):
                             st.update_timesteps(ts, fidx_dev[o:o + n], tsf_dev[o:o + n])
                         o += n
                         st()
-                finally:
-                    if ctx is not None:
-                        ctx.__exit__(None, None, None)
-            else:
-                for s in dataloader:
-                    st = step_for(s, opt)                          # one optimiser (one Adam state) for every batch shape of this call
-                    if opt is None:
-                        opt = st.opt
-                        if not getattr(st, "fresh", False):
-                            _reset_optimizer(opt)
-                        for grp in opt.param_groups:              # a scheduler of a previous call may have decayed them
-                            grp["lr"] = grp["initial_lr"] if "initial_lr" in grp else grp["lr"]
-                        sched = torch.optim.lr_scheduler.ExponentialLR(opt, gamma=0.9)
-                    st.fresh = False
-                    with st.replay_stream():
-                        st()
+                    sched.step()
+                    if evaluate_every and (epoch_i + 1) % evaluate_every == 0:
+                        leave()
+                        self.evaluate()
+            finally:
+                leave()
+            return opt
+        for epoch_i in range(n_epochs):
+            for s in dataloader:
+                st = step_for(s, opt)                          # one optimiser (one Adam state) for every batch shape of this call
+                if opt is None:
+                    opt = st.opt
+                    if not getattr(st, "fresh", False):
+                        _reset_optimizer(opt)
+                    for grp in opt.param_groups:              # a scheduler of a previous call may have decayed them
+                        grp["lr"] = grp["initial_lr"] if "initial_lr" in grp else grp["lr"]
+                    sched = torch.optim.lr_scheduler.ExponentialLR(opt, gamma=0.9)
+                st.fresh = False
+                with st.replay_stream():
+                    st()
             sched.step()
             if evaluate_every and (epoch_i + 1) % evaluate_every == 0:
                 self.evaluate()
