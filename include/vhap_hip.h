@@ -682,6 +682,12 @@ int vhap_plan_open_tails(vhap_plan_t plan, int* nodes, int cap);
 /* the nodes of the NEXT replay that are not ordered behind those open tails (not on a stream carrying one, not downstream of a node that
  * is): together with whatever the caller enqueues between the replays, these are what must not conflict with the open tails */
 int vhap_plan_free_heads(vhap_plan_t plan, int* nodes, int cap);
+/* vhap_plan_node_handle: the captured graph's node behind plan node `node` (identity only).  vhap_capture_nodes: the nodes of the graph
+ * `stream` is capturing into right now (at most `cap` handles written; returns their number, 0: not capturing) -- read after every call of
+ * a capture, it tells the host which call created which plan node, hence which buffers the node touches (the deferred join is decided on
+ * those: vhap_amd/tracker.py, _lib.AccessLog). */
+void* vhap_plan_node_handle(vhap_plan_t plan, int node);
+int vhap_capture_nodes(vhap_stream_t stream, void** nodes, int cap);
 /* one replay with every node bracketed by timing events; blocks until done.  start_us[k] (relative to the head of the replay) and
  * dur_us[k] of node k, n >= number of nodes.  For per-kernel numbers inside the step (bench.py's roofline line), not for the step time. */
 int vhap_plan_launch_timed(vhap_plan_t plan, vhap_stream_t stream, float* start_us, float* dur_us, int n);

@@ -30,9 +30,15 @@ def test_deferred_join_loop_matches_joined_loop(flame_model):
     assert st.ns is not None and st.single and st.gF.plan is not None
     tails, heads = st.gF.open_tails(), st.gF.free_heads()
     lines = ["open tails: " + ", ".join(t.split("(")[0] for t in tails), "free heads: " + ", ".join(t.split("(")[0] for t in heads)]
-    assert st.defer_join, lines                       # the shipped step qualifies: this test must exercise the deferred path
-    assert tails and all(any(o in t for o in st.TEX_TAIL) for t in tails)
-    assert all(any(o in t for o in st.GEOMETRY_HEAD) for t in heads)
+    lines += ["decision on the buffers the nodes touch (CapturedPlan.deferred_join_hazards):"] + ["  " + r for r in st.defer_report]
+    assert st.defer_join, "\n".join(lines)           # the shipped step qualifies: this test must exercise the deferred path
+    # the decision is made on byte ranges; the kernel names are the cross-check of what the shipped step is expected to leave open / start early
+    assert tails and all(any(o in t for o in st.TEX_TAIL) for t in tails), lines
+    assert all(any(o in t for o in st.GEOMETRY_HEAD) for t in heads), lines
+    assert not any("UNKNOWN" in r for r in st.defer_report) and "disjoint" in st.defer_report[-1], lines
+    # ... and it must say NO when the host writes, between replays, into something an open tail touches (here: the texture parameter)
+    ok, why = st.gF.deferred_join_hazards(st._access, [(tr.tex_extra.data_ptr(), 64)])
+    assert not ok and "overlap" in why[-1], why
 
     def run(deferred):
         with torch.no_grad():

@@ -118,6 +118,8 @@ SIGNATURES = {
     "vhap_plan_join": (c_i, [c_fp, c_fp]),
     "vhap_plan_open_tails": (c_i, [c_fp, ctypes.POINTER(c_i), c_i]),
     "vhap_plan_free_heads": (c_i, [c_fp, ctypes.POINTER(c_i), c_i]),
+    "vhap_plan_node_handle": (c_fp, [c_fp, c_i]),
+    "vhap_capture_nodes": (c_i, [c_fp, ctypes.POINTER(ctypes.c_void_p), c_i]),
     "vhap_plan_launch_timed": (c_i, [c_fp, c_fp, ctypes.POINTER(c_f), ctypes.POINTER(c_f), c_i]),
 }
 
@@ -163,6 +165,69 @@ def check(code, what=""):
     if code != 0:
         msg = lib().vhap_strerror(code).decode()
         raise VhapHipError(f"{what}: {msg} ({code})")
+    if ACCESS is not None:
+        ACCESS.close(what)
+
+
+# ---- which buffers does a captured node touch? -------------------------------------------------------------------------------------
+# The deferred join of a step plan (tracker.GraphedStep) lets the next replay's head run under the previous replay's open tail: safe iff
+# the two touch disjoint memory.  That is decided on the BUFFERS, not on kernel names: while a step is being captured, every device
+# pointer handed to a C-ABI call is recorded (ops._p -> AccessLog.touch) together with the number of nodes the capture held before and
+# after the call (vhap_capture_node_count), so that every node of the plan maps back to the call that created it and to the byte ranges
+# that call was given.  Nodes no recorded call accounts for (the host framework's own fills / copies inside the capture) are UNKNOWN: a
+# plan with an unknown node among its open tails or free heads does not defer.
+ACCESS = None
+
+
+class AccessLog:
+    CAP = 4096
+
+    def __init__(self):
+        self.owner = {}               # graph node handle -> (call name, [(address, bytes), ...]) | None (a node no recorded call created)
+        self._cur = None
+        self._buf = (ctypes.c_void_p * self.CAP)()
+
+    def _new_nodes(self):
+        """handles of the nodes the capture has gained since the last look"""
+        n = int(lib().vhap_capture_nodes(torch.cuda.current_stream().cuda_stream, self._buf, self.CAP))
+        return [h for h in (self._buf[i] for i in range(min(n, self.CAP))) if h not in self.owner]
+
+    def touch(self, t):
+        if self._cur is None:         # first pointer of a call: whatever appeared since the last call closed was not created by a recorded call
+            for h in self._new_nodes():
+                self.owner[h] = None
+            self._cur = []
+        if t.numel():
+            self._cur.append((t.data_ptr(), t.numel() * t.element_size()))
+
+    def close(self, what):
+        ranges = self._cur if self._cur is not None else []
+        for h in self._new_nodes():
+            self.owner[h] = (what, ranges)
+        self._cur = None
+
+    def ranges_of_node(self, handle):
+        """(call name, byte ranges) of the call that created the graph node `handle` (None: no recorded call did)"""
+        return self.owner.get(handle)
+
+    def __enter__(self):
+        global ACCESS
+        self._prev, ACCESS = ACCESS, self
+        return self
+
+    def __exit__(self, *a):
+        global ACCESS
+        ACCESS = self._prev
+        return False
+
+
+def ranges_overlap(a, b):
+    """first overlapping pair of two lists of (address, bytes), or None"""
+    for pa, na in a:
+        for pb, nb in b:
+            if pa < pb + nb and pb < pa + na:
+                return (pa, na), (pb, nb)
+    return None
 
 
 # ---- streams of our own ----------------------------------------------------------------------------------------------------------

@@ -14,8 +14,8 @@
 //   * any node can be bracketed by timing events (vhap_plan_launch_timed): the in-step duration of a kernel without a profiler and
 //     without in-kernel clock stamps (HIP refuses to read event-record nodes of a hipGraph replay).
 //
-// Only what a captured step contains is supported: kernel, memset (1-D / 2-D) and empty nodes; anything else -> VHAP_E_UNSUPPORTED and the
-// caller keeps the graph.  The plan borrows the graph's kernel-argument storage: the hipGraph_t must outlive the plan.
+// Only what a captured step contains is supported: kernel, memset (1-D / 2-D), flat device-to-device memcpy and empty nodes; anything else ->
+// VHAP_E_UNSUPPORTED and the caller keeps the graph.  The plan borrows the graph's kernel-argument storage: the hipGraph_t must outlive the plan.
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -27,9 +27,14 @@
 namespace {
 
 struct PlanNode {
-    int type = 0;                       // 0 kernel, 1 memset, 2 empty
+    int type = 0;                       // 0 kernel, 1 memset, 2 empty, 3 memcpy (1-D, device to device)
+    int raw = 0;                        // index in the graph's own node list
+    hipGraphNode_t handle = nullptr;    // the captured graph's node (identity only: what a host that watched the capture grow knows it by)
     hipKernelNodeParams kp{};
     hipMemsetParams ms{};
+    void* cp_dst = nullptr;
+    const void* cp_src = nullptr;
+    size_t cp_bytes = 0;
     int stream = 0;                     // 0 = the launch stream, k > 0 = plan stream k - 1
     std::vector<int> waits;             // events to wait for before the launch
     int record = -1;                    // event to record behind the launch
@@ -89,8 +94,9 @@ hipError_t launch_node(const PlanNode& n, hipStream_t st) {
             if (m.elementSize == 2) return hipMemsetD16Async(reinterpret_cast<hipDeviceptr_t>(m.dst), (unsigned short)m.value, m.width, st);
             return hipMemsetAsync(m.dst, (int)(m.value & 0xff), m.width, st);
         }
-        return hipMemset2DAsync(m.dst, m.pitch, (int)(m.value & 0xff), m.width * m.elementSize, m.height, st);
+        return hipMemset2DAsync(m.dst, m.pitch, (int)(m.value & 0xff), m.width * m.elementSize, m.height, st);   // (byte-uniform values only: checked at build)
     }
+    if (n.type == 3) return hipMemcpyAsync(n.cp_dst, n.cp_src, n.cp_bytes, hipMemcpyDeviceToDevice, st);
     return hipSuccess;
 }
 
@@ -117,6 +123,8 @@ extern "C" int vhap_plan_from_graph(void* hip_graph, int max_streams, vhap_plan_
         hipGraphNodeType t;
         if (hipGraphNodeGetType(gn[i], &t) != hipSuccess) return VHAP_E_HIP;
         PlanNode& nd = raw[i];
+        nd.raw = (int)i;
+        nd.handle = gn[i];
         if (t == hipGraphNodeTypeKernel) {
             nd.type = 0;
             if (hipGraphKernelNodeGetParams(gn[i], &nd.kp) != hipSuccess) return VHAP_E_HIP;
@@ -127,11 +135,37 @@ extern "C" int vhap_plan_from_graph(void* hip_graph, int max_streams, vhap_plan_
             nd.type = 1;
             if (hipGraphMemsetNodeGetParams(gn[i], &nd.ms) != hipSuccess) return VHAP_E_HIP;
             nd.name = "memset";
+            // a 2-D memset is replayed through hipMemset2DAsync, which fills BYTES: 16- / 32-bit elements only with a byte-uniform value
+            if (nd.ms.height > 1 && nd.ms.elementSize > 1) {
+                const unsigned v = nd.ms.value, b0 = v & 0xffu;
+                const bool uniform = nd.ms.elementSize == 2 ? ((v >> 8) & 0xffu) == b0
+                                                            : (((v >> 8) & 0xffu) == b0 && ((v >> 16) & 0xffu) == b0 && ((v >> 24) & 0xffu) == b0);
+                if (!uniform) {
+                    fprintf(stderr, "vhap_plan_from_graph: node %zu is a 2-D memset of %u-byte elements with a non-uniform byte pattern\n", i, nd.ms.elementSize);
+                    return VHAP_E_UNSUPPORTED;
+                }
+            }
+        } else if (t == hipGraphNodeTypeMemcpy) {
+            // same-layout copy_ / clone of the host framework inside a captured stage: a contiguous device-to-device copy, replayed as one
+            hipMemcpy3DParms cp{};
+            if (hipGraphMemcpyNodeGetParams(gn[i], &cp) != hipSuccess) return VHAP_E_HIP;
+            const bool flat = cp.kind == hipMemcpyDeviceToDevice && !cp.srcArray && !cp.dstArray && cp.extent.height <= 1 && cp.extent.depth <= 1 &&
+                              cp.srcPos.x == 0 && cp.srcPos.y == 0 && cp.srcPos.z == 0 && cp.dstPos.x == 0 && cp.dstPos.y == 0 && cp.dstPos.z == 0 &&
+                              cp.srcPtr.ptr && cp.dstPtr.ptr;
+            if (!flat) {
+                fprintf(stderr, "vhap_plan_from_graph: node %zu is a memcpy node that is not a flat device-to-device copy\n", i);
+                return VHAP_E_UNSUPPORTED;
+            }
+            nd.type = 3;
+            nd.cp_dst = cp.dstPtr.ptr;
+            nd.cp_src = cp.srcPtr.ptr;
+            nd.cp_bytes = cp.extent.width;
+            nd.name = "memcpy";
         } else if (t == hipGraphNodeTypeEmpty) {
             nd.type = 2;
             nd.name = "empty";
         } else {
-            fprintf(stderr, "vhap_plan_from_graph: node %zu is a %s node (only kernel / memset / empty nodes are supported)\n", i, node_type_name(t));
+            fprintf(stderr, "vhap_plan_from_graph: node %zu is a %s node (only kernel / memset / flat memcpy / empty nodes are supported)\n", i, node_type_name(t));
             return VHAP_E_UNSUPPORTED;
         }
         size_t nd_deps = 0;
@@ -322,9 +356,19 @@ extern "C" int vhap_plan_node_name(vhap_plan_t plan, int node, char* buf, size_t
     return VHAP_OK;
 }
 
+// an error in the middle of a replay: whatever was enqueued on the side streams is joined back into the launch stream (best effort), so that
+// the caller's stream order covers everything that was issued, and the plan reports no open tails
+static int plan_abort(vhap_plan* p, hipStream_t launch) {
+    (void)hipGetLastError();
+    for (size_t s = 0; s < p->streams.size(); s++)
+        if (hipEventRecord(p->tails[s], p->streams[s]) == hipSuccess) (void)hipStreamWaitEvent(launch, p->tails[s], 0);
+    p->tails_open = false;
+    return VHAP_E_HIP;
+}
+
 static int plan_launch(vhap_plan* p, hipStream_t launch, bool timed, bool defer_join = false) {
     const size_t n = p->nodes.size();
-#define PLAN_HIP(x) do { if ((x) != hipSuccess) return VHAP_E_HIP; } while (0)
+#define PLAN_HIP(x) do { if ((x) != hipSuccess) return plan_abort(p, launch); } while (0)
     if (timed && p->tev.empty()) {
         p->tev.assign(2 * n + 1, nullptr);
         for (auto& e : p->tev) PLAN_HIP(hipEventCreate(&e));
@@ -369,27 +413,54 @@ extern "C" int vhap_plan_join(vhap_plan_t plan, vhap_stream_t stream) {
     return VHAP_OK;
 }
 
-// nodes of the NEXT replay that are not ordered behind the open tails of a DEFER_JOIN replay: neither on a stream that carries an open
-// tail (streams are in order) nor downstream of a node that is
+// nodes of the NEXT replay that are not ordered behind the open tails of a DEFER_JOIN replay.  Stream order places a node only behind the
+// tails of its OWN stream: with open tails on several side streams a node is ordered iff, for EVERY stream that carries an open tail, it
+// sits on that stream or (transitively, through dependencies or the stream order inside the replay) follows a node that does.
 extern "C" int vhap_plan_free_heads(vhap_plan_t plan, int* nodes, int cap) {
     if (!plan) return VHAP_E_NULLPTR;
     const size_t n = plan->nodes.size();
-    std::vector<char> tail_stream(plan->streams.size() + 1, 0), ordered(n, 0);
-    for (const PlanNode& nd : plan->nodes) if (nd.open_tail) tail_stream[nd.stream] = 1;
+    const int ns = (int)plan->streams.size() + 1;
+    unsigned tail_mask = 0u;                                   // streams with an open tail (ns <= 8)
+    for (const PlanNode& nd : plan->nodes) if (nd.open_tail) tail_mask |= 1u << nd.stream;
+    std::vector<unsigned> behind(n, 0u), last_on(ns, 0u);      // behind[k]: streams node k is ordered behind; last_on[s]: the same for stream s's latest node
     int m = 0;
     for (size_t k = 0; k < n; k++) {
         const PlanNode& nd = plan->nodes[k];
-        bool o = tail_stream[nd.stream] != 0;
-        for (int d : nd.deps) o = o || ordered[d];
-        // (stream order inside the replay: a later node of a stream follows its earlier ones)
-        for (size_t j = 0; j < k && !o; j++) o = plan->nodes[j].stream == nd.stream && ordered[j];
-        ordered[k] = o;
-        if (!o) {
+        unsigned b = (1u << nd.stream) | last_on[nd.stream];   // its own stream, and whatever its stream predecessor already follows
+        for (int d : nd.deps) b |= behind[d];
+        behind[k] = b;
+        last_on[nd.stream] = b;
+        if ((b & tail_mask) != tail_mask) {
             if (nodes && m < cap) nodes[m] = (int)k;
             m++;
         }
     }
     return m;
+}
+
+// the captured graph's node behind plan node k (identity only), and the nodes the graph `stream` is capturing into holds right now (at most
+// `cap` handles written; returns their number, 0: not capturing): a host that reads the latter after every call of a capture knows which
+// call created which node -- the order of a graph's node list is the runtime's business -- hence which buffers a plan node touches
+extern "C" void* vhap_plan_node_handle(vhap_plan_t plan, int node) {
+    if (!plan || node < 0 || node >= (int)plan->nodes.size()) return nullptr;
+    return plan->nodes[node].handle;
+}
+
+extern "C" int vhap_capture_nodes(vhap_stream_t stream, void** nodes, int cap) {
+    VHAP_ENTER();
+    hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+    hipGraph_t g = nullptr;
+    unsigned long long id = 0;
+    if (hipStreamGetCaptureInfo_v2(vhap_stream(stream), &status, &id, &g, nullptr, nullptr) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (status != hipStreamCaptureStatusActive || !g) return 0;
+    size_t n = 0;
+    if (hipGraphGetNodes(g, nullptr, &n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (nodes && cap > 0 && n > 0) {
+        std::vector<hipGraphNode_t> gn(n);
+        if (hipGraphGetNodes(g, gn.data(), &n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+        for (size_t i = 0; i < n && (int)i < cap; i++) nodes[i] = gn[i];
+    }
+    return (int)n;
 }
 
 // nodes a DEFER_JOIN replay leaves un-joined: indices into launch order, at most `cap` written; returns their number

@@ -478,6 +478,11 @@ class HipAdam(torch.optim.Optimizer):
                 p.grad = p.grad.contiguous()
         n = len(sel)
         P = ctypes.c_void_p * n
+        if _lib.ACCESS is not None:       # (the tensors travel as pointer tables: tell a recording capture what this call touches)
+            for i in sel:
+                q = t["ps"][i]
+                for x in (q, q.grad, self.state[q]["exp_avg"], self.state[q]["exp_avg_sq"]):
+                    _lib.ACCESS.touch(x)
         pick = lambda arr, ty: (ty * n)(*[arr[i] for i in sel])
         G = P(*[t["ps"][i].grad.data_ptr() for i in sel])
         g0 = self.param_groups[0]

@@ -53,7 +53,11 @@ def _i32c(t):
 
 
 def _p(t):
-    return 0 if t is None else t.data_ptr()
+    if t is None:
+        return 0
+    if _lib.ACCESS is not None:          # (a step capture is recording which buffers its calls touch: _lib.AccessLog)
+        _lib.ACCESS.touch(t)
+    return t.data_ptr()
 
 
 class RasterizeHipContext:

@@ -1077,19 +1077,52 @@ class CapturedPlan:
         if self.plan is not None:
             _lib.check(_lib.lib().vhap_plan_join(self.plan, torch.cuda.current_stream().cuda_stream), "vhap_plan_join")
 
-    def _names(self, fn):
+    def _indices(self, fn):
         if self.plan is None:
             return []
-        L = _lib.lib()
         n = fn(self.plan, None, 0)
         idx = (ctypes.c_int * max(n, 1))()
         fn(self.plan, idx, n)
+        return [int(idx[k]) for k in range(n)]
+
+    def node_name(self, k):
         buf = ctypes.create_string_buffer(512)
-        out = []
-        for k in range(n):
-            L.vhap_plan_node_name(self.plan, idx[k], buf, 512)
-            out.append(buf.value.decode())
-        return out
+        _lib.lib().vhap_plan_node_name(self.plan, k, buf, 512)
+        return buf.value.decode()
+
+    def _names(self, fn):
+        return [self.node_name(k) for k in self._indices(fn)]
+
+    def deferred_join_hazards(self, log, extra_head_ranges=()):
+        """May the next replay's head run under this replay's open tails?  Decided on the BUFFERS (`log`: the _lib.AccessLog recorded while
+        this plan's graph was captured): every node a DEFER_JOIN replay leaves open, and every node of the next replay that is not ordered
+        behind all of them (plus `extra_head_ranges`: what the host writes between replays), maps back to the C-ABI call that created it
+        and to the byte ranges that call was given; the two sets must not overlap.  -> (ok, report lines)."""
+        L = _lib.lib()
+        lines, ok = [], True
+        sets = {}
+        for kind, fn in (("open tail", L.vhap_plan_open_tails), ("free head", L.vhap_plan_free_heads)):
+            rs = []
+            for k in self._indices(fn):
+                hit = log.ranges_of_node(L.vhap_plan_node_handle(self.plan, k))
+                name = self.node_name(k).split("(")[0]
+                if hit is None:
+                    ok = False
+                    lines.append(f"{kind} {k} {name}: created by no recorded call (UNKNOWN buffers): no deferred join")
+                else:
+                    lines.append(f"{kind} {k} {name} <- {hit[0]}: {len(hit[1])} buffers, {sum(n for _, n in hit[1])} bytes")
+                    rs += hit[1]
+            sets[kind] = rs
+        if not sets["open tail"]:
+            return False, lines + ["no open tails: nothing to defer"]
+        clash = _lib.ranges_overlap(sets["open tail"], sets["free head"] + list(extra_head_ranges))
+        if clash is not None:
+            ok = False
+            lines.append(f"open tails and free heads / host writes overlap: {clash[0][1]} bytes at {clash[0][0]:#x} vs {clash[1][1]} bytes at {clash[1][0]:#x}")
+        else:
+            lines.append(f"open tails ({len(sets['open tail'])} buffers) and free heads + host writes "
+                         f"({len(sets['free head']) + len(extra_head_ranges)} buffers) are disjoint")
+        return ok, lines
 
     def open_tails(self):
         """Kernel names of the nodes a defer_join replay leaves un-joined."""
@@ -1151,8 +1184,9 @@ class GraphedStep:
     A new batch is fed by copying into `self.sample` (same shapes) -- exactly the sequential-tracking pattern.
     Replays always go to the step's own launch stream."""
 
-    # (the texture gradient's sort -- workspace clear, count, scan, scatter -- its tile pass, the texture finish + Adam: the side chain of the
-    # backward that nothing on the launch stream waits for)
+    # What the shipped photometric step is EXPECTED to leave open / start early (documentation and the tests' cross-check; the decision
+    # itself is made on the buffers: CapturedPlan.deferred_join_hazards): the texture gradient's sort -- workspace clear, count, scan,
+    # scatter -- its tile pass, the texture finish + Adam; and the geometry head
     TEX_TAIL = ("vhap_zero_words_kernel", "texbin_pass_kernel", "texbin_scan_kernel", "texgrad_tile_kernel", "tex_prep_bwd_kernel")
     GEOMETRY_HEAD = ("camera_fwd_kernel", "frame_prep_fwd_kernel", "flame_skin_fwd_kernel", "flame_skin_clip_fwd_kernel", "bin_build_kernel")
 
@@ -1229,7 +1263,8 @@ class GraphedStep:
                     ns.one_graph = True
                     ns.accF.zero_()
                     ns._acc_clean = True
-                with self.gF.capture(**cap):
+                self._access = _lib.AccessLog()
+                with self._access, self.gF.capture(**cap):
                     for _ in range(self.unroll):
                         ns.forward()
                         if split:
@@ -1261,19 +1296,18 @@ class GraphedStep:
                 with self.gA.capture(pool=pool, **cap):
                     optimizer.step()
             # Step k+1 under step k's texture tail: inside replay_stream() the single-GPU plan is replayed WITHOUT joining its side
-            # streams at the end when all it leaves open is the texture gradient's tile pass and the texture finish + Adam -- they touch the
-            # texture, its gradient pyramid, its Adam state, the sort's workspace and the pixel chain's (tile ids, keep mask, texc, texd,
-            # d_albedo) only; the next replay's texture
-            # chain follows them on the same side stream, and its launch-stream kernels up to the rasteriser (which waits for that chain:
-            # camera, per-frame parameters, skinning, binning) touch none of it.  Any other open tail -> joined replays.
-            # The condition is checked on the plan itself: open tails within TEX_TAIL, and every node of the next replay that is not
-            # ordered behind them (by stream order or a dependency) within GEOMETRY_HEAD.  What the host enqueues between two replays
-            # (a new batch into the sample buffers; a changed learning rate -- __call__ joins first) is covered the same way.
-            self.defer_join = False
+            # streams at the end -- what it leaves open (the texture gradient's sort, tile pass, finish + Adam on the side stream) keeps
+            # running while the next replay's launch-stream kernels up to the rasteriser (camera, per-frame parameters, skinning, binning)
+            # start; the next replay's texture chain follows the tail on its own stream, and the rasteriser waits for that chain.
+            # Whether that is safe is decided on the BUFFERS the nodes touch, recorded call by call during the capture (_lib.AccessLog):
+            # the open tails' byte ranges must be disjoint from those of every node of the next replay that is not ordered behind them
+            # (vhap_plan_free_heads: per tail stream) and from what the host writes between two replays (a new batch into the sample
+            # buffers); a node no recorded call accounts for -> joined replays.  A changed learning rate (the tail reads the table) joins
+            # first (__call__).
+            self.defer_join, self.defer_report = False, ["deferred join not considered (sharded step, hipGraph fallback or VHAP_DEFER_JOIN=0)"]
             if self.single and self.gF.plan is not None and os.environ.get("VHAP_DEFER_JOIN", "1") != "0":
-                tails, heads = self.gF.open_tails(), self.gF.free_heads()
-                within = lambda names, ok: all(any(o in t for o in ok) for t in names)
-                self.defer_join = len(tails) > 0 and within(tails, self.TEX_TAIL) and within(heads, self.GEOMETRY_HEAD)
+                host_writes = [(t.data_ptr(), t.numel() * t.element_size()) for t in self.sample.values()]
+                self.defer_join, self.defer_report = self.gF.deferred_join_hazards(self._access, host_writes)
             self.E = ns.log[15]
             self.log_dict = ns.log_dict()
             # (one GPU: the forward accumulators are cleared at the END of the captured step -- the photometric sum / count of the last step
