@@ -585,6 +585,14 @@ int vhap_tex_prep_bwd_adam(const float* albedo_hwc, float* extra, const uint8_t*
                            int T, float s_tv, float s_res, float* d_extra, float* exp_avg, float* exp_avg_sq,
                            const float* lr_device, const int32_t* step_device, float beta1, float beta2, float eps,
                            int call_flags, vhap_stream_t stream);
+/* vhap_tex_prep_bwd_adam on the ROW STRIP [row0, row0 + nrows) of the texture (multiples of 16): frame sharding over N GPUs lets rank r
+ * finish and update rows [r T / N, (r + 1) T / N) only -- d_albedo_strip = the strip's [nrows, T, 3] slice of the level-0 gradient with the
+ * whole pyramid folded into it (vhap_texture_mip_fold(stop_level = 0)), e.g. the output of a reduce-scatter; albedo_hwc, extra, res_mask,
+ * d_extra, exp_avg, exp_avg_sq are the FULL arrays (rows outside the strip are not touched).  New in this build. */
+int vhap_tex_prep_bwd_adam_rows(const float* albedo_hwc, float* extra, const uint8_t* res_mask, const float* d_albedo_strip,
+                                const float* d_terms, int T, int row0, int nrows, float s_tv, float s_res, float* d_extra, float* exp_avg,
+                                float* exp_avg_sq, const float* lr_device, const int32_t* step_device, float beta1, float beta2, float eps,
+                                int call_flags, vhap_stream_t stream);
 int vhap_adam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                    float* const* exp_avg_sq, const int64_t* numel, const int32_t* lr_index,
                    const float* lr_device, int32_t* step_device, float beta1, float beta2, float eps,

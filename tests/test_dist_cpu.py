@@ -231,3 +231,40 @@ def test_two_rank_multiview_views_of_one_timestep_split_over_ranks():
         assert torch.equal(ret[0][1][k], ret[1][1][k]), f"replicas disagree on {k}"
         d = float((ret[0][1][k] - params[k]).abs().max())
         assert d <= 5e-5 * max(1.0, float(params[k].abs().max())), (k, d)     # measured <= 1.1e-5 (fp32 summation order + Adam)
+
+
+def _worker_tex(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vhap_amd.dist import FrameShardContext
+    ctx = FrameShardContext()
+    T = 32
+    g = torch.Generator().manual_seed(7 + rank)
+    grad = torch.randn(T, T, 3, generator=g)                       # this rank's level-0 texture gradient (HWC, like the kernels')
+    tex = torch.arange(3 * T * T, dtype=torch.float32).reshape(3, T, T).clone()      # the replicated parameter (CHW)
+    n = T // world
+    strip = torch.zeros(n, T, 3)
+    ctx.reduce_scatter_mean(grad.view(-1).clone(), strip.view(-1)).wait()
+    # "Adam" on this rank's rows only, then the rows travel
+    tex[:, rank * n:(rank + 1) * n] -= 0.5 * strip.permute(2, 0, 1)
+    for w in ctx.all_gather_rows(tex, rank * n, n, async_op=True):
+        w.wait()
+    ret[rank] = (grad, tex)
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_texture_update_collectives():
+    """The sharded texture update (reduce-scatter of the level-0 gradient -> each rank updates its rows -> all-gather of the rows) on the
+    CPU over gloo equals: mean gradient, update of the whole texture, on every rank."""
+    world = 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ret = mp.Manager().dict()
+    mp.spawn(_worker_tex, args=(world, port, ret), nprocs=world, join=True)
+    T = 32
+    mean = 0.5 * (ret[0][0] + ret[1][0])
+    want = torch.arange(3 * T * T, dtype=torch.float32).reshape(3, T, T) - 0.5 * mean.permute(2, 0, 1)
+    assert torch.equal(ret[0][1], ret[1][1]), "replicas disagree"
+    assert torch.allclose(ret[0][1], want, rtol=0, atol=1e-6)

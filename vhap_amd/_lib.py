@@ -98,6 +98,7 @@ SIGNATURES = {
     "vhap_texture_mip_build_from": (c_i, [c_fp, c_i, c_i, c_i, c_i, c_fp, c_i, c_fp]),
     "vhap_tex_prep_bwd": (c_i, [c_fp] * 5 + [c_i, c_fp, c_i, c_f, c_f] + [c_fp] * 2),
     "vhap_tex_prep_bwd_adam": (c_i, [c_fp] * 5 + [c_i, c_fp, c_i, c_f, c_f] + [c_fp] * 5 + [c_f, c_f, c_f, c_i, c_fp]),
+    "vhap_tex_prep_bwd_adam_rows": (c_i, [c_fp] * 5 + [c_i, c_i, c_i, c_f, c_f] + [c_fp] * 5 + [c_f, c_f, c_f, c_i, c_fp]),
     "vhap_energy_finalize": (c_i, [c_fp] * 5 + [c_f, c_f, c_i, c_i, c_i, c_fp, c_fp]),
     "vhap_energy_total": (c_i, [c_fp, c_fp, c_fp, c_f, c_i, c_fp, c_fp]),
     "vhap_sum_frames": (c_i, [c_fp, c_i, c_i, c_fp, c_fp]),

@@ -236,7 +236,7 @@ template <bool ADAM>
 __global__ __launch_bounds__(RB) void tex_prep_bwd_kernel(TexCfg c, const float* __restrict__ albedo, const float* __restrict__ extra,
                                                           const unsigned char* __restrict__ res_mask, const float* __restrict__ d_albedo,
                                                           const float* __restrict__ d_mips, int n_gather, const float* __restrict__ d_terms,
-                                                          float* __restrict__ d_extra, const TexAdam A, int step_add) {
+                                                          float* __restrict__ d_extra, const TexAdam A, int step_add, int y_base) {
     const int T = c.T;
     const size_t plane = (size_t)T * T;
     const float gtv = 2.0f * c.s_tv * d_terms[0], gres = 2.0f * c.s_res * d_terms[1];
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(RB) void tex_prep_bwd_kernel(TexCfg c, const float*
         bc2s = sqrtf(1.0f - powf(A.beta2, st));
         step_size = A.lr[0] / bc1;
     }
-    const int x = blockIdx.x * RB + threadIdx.x, y0 = blockIdx.y * TEXB_ROWS;
+    const int x = blockIdx.x * RB + threadIdx.x, y0 = y_base + blockIdx.y * TEXB_ROWS;     // (y_base: the first row of a ROW STRIP of the texture)
     const int lane = threadIdx.x & 63;
     const bool in_x = x < T;
     const bool tv = gtv != 0.f;
@@ -523,7 +523,7 @@ extern "C" int vhap_tex_prep_bwd(const float* albedo_hwc, const float* extra, co
     if (T <= 0 || n_gather < 0 || n_gather > TEXB_MAXG || (d_mips_hwc && n_gather > 0 && (T & ((1 << n_gather) - 1)))) return VHAP_E_BADDIM;
     TexCfg c{T, s_tv, s_res};
     tex_prep_bwd_kernel<false><<<dim3(vhap_cdiv(T, RB), vhap_cdiv(T, TEXB_ROWS)), RB, 0, vhap_stream(stream)>>>(
-        c, albedo_hwc, extra, res_mask, d_albedo_hwc, n_gather > 0 ? d_mips_hwc : nullptr, n_gather, d_terms, d_extra, TexAdam{}, 0);
+        c, albedo_hwc, extra, res_mask, d_albedo_hwc, n_gather > 0 ? d_mips_hwc : nullptr, n_gather, d_terms, d_extra, TexAdam{}, 0, 0);
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;
 }
@@ -538,7 +538,28 @@ extern "C" int vhap_tex_prep_bwd_adam(const float* albedo_hwc, float* extra, con
     TexCfg c{T, s_tv, s_res};
     tex_prep_bwd_kernel<true><<<dim3(vhap_cdiv(T, RB), vhap_cdiv(T, TEXB_ROWS)), RB, 0, vhap_stream(stream)>>>(
         c, albedo_hwc, extra, res_mask, d_albedo_hwc, n_gather > 0 ? d_mips_hwc : nullptr, n_gather, d_terms, d_extra,
-        TexAdam{extra, exp_avg, exp_avg_sq, lr_device, step_device, beta1, beta2, eps}, (call_flags & VHAP_CALL_ADAM_STEP_ADVANCED) ? 0 : 1);
+        TexAdam{extra, exp_avg, exp_avg_sq, lr_device, step_device, beta1, beta2, eps}, (call_flags & VHAP_CALL_ADAM_STEP_ADVANCED) ? 0 : 1, 0);
+    VHAP_LAUNCH_CHECK();
+    return VHAP_OK;
+}
+
+// The same pass on a ROW STRIP [row0, row0 + nrows) of the texture (frame sharding over N GPUs: rank r finishes and updates rows
+// [r T / N, (r + 1) T / N) -- the level-0 gradient arrives reduce-scattered, the updated rows go out in an all-gather; the finish + Adam
+// pass, 124 us and 497 MB for the whole texture, shrinks N-fold).  d_albedo_strip: the strip's [nrows, T, 3] slice of the level-0
+// gradient (the whole pyramid folded into it: vhap_texture_mip_fold(stop_level = 0)); everything else as vhap_tex_prep_bwd_adam, full size.
+extern "C" int vhap_tex_prep_bwd_adam_rows(const float* albedo_hwc, float* extra, const uint8_t* res_mask, const float* d_albedo_strip,
+                                           const float* d_terms, int T, int row0, int nrows, float s_tv, float s_res, float* d_extra,
+                                           float* exp_avg, float* exp_avg_sq, const float* lr_device, const int32_t* step_device, float beta1,
+                                           float beta2, float eps, int call_flags, vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!albedo_hwc || !extra || !d_albedo_strip || !d_terms || !d_extra || !exp_avg || !exp_avg_sq || !lr_device || !step_device) return VHAP_E_NULLPTR;
+    if (T <= 0 || row0 < 0 || nrows <= 0 || row0 + nrows > T || (row0 % TEXB_ROWS) || (nrows % TEXB_ROWS)) return VHAP_E_BADDIM;
+    TexCfg c{T, s_tv, s_res};
+    // (the kernel indexes the gradient by absolute row: hand it the address row 0 WOULD have; only the strip's rows are dereferenced)
+    const float* d_base = d_albedo_strip - (size_t)row0 * T * 3;
+    tex_prep_bwd_kernel<true><<<dim3(vhap_cdiv(T, RB), nrows / TEXB_ROWS), RB, 0, vhap_stream(stream)>>>(
+        c, albedo_hwc, extra, res_mask, d_base, nullptr, 0, d_terms, d_extra,
+        TexAdam{extra, exp_avg, exp_avg_sq, lr_device, step_device, beta1, beta2, eps}, (call_flags & VHAP_CALL_ADAM_STEP_ADVANCED) ? 0 : 1, row0);
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;
 }

@@ -76,6 +76,36 @@ class FrameShardContext:
         t.mul_(1.0 / self.world_size)
         return None
 
+    class _Done:
+        """handle of a collective that has already completed (gloo: synchronous)"""
+        def wait(self):
+            return True
+
+    def reduce_scatter_mean(self, full, out, async_op=False):
+        """out (this rank's 1/N slice, contiguous) = mean over ranks of the matching slice of `full` (contiguous, N equal slices).  RCCL:
+        ONE reduce-scatter (ReduceOp.AVG) -- half the wire traffic of the all-reduce the slice would otherwise come from; gloo has no
+        reduce-scatter: all-reduce, scale, copy the slice (the CPU / single-GPU tests: same numbers).  -> handle with wait()."""
+        n = self.world_size
+        assert full.is_contiguous() and out.is_contiguous() and full.numel() == n * out.numel()
+        if dist.get_backend(self.group) == "nccl":
+            work = dist.reduce_scatter_tensor(out, full, op=dist.ReduceOp.AVG, group=self.group, async_op=async_op)
+            return work if async_op else self._Done()
+        dist.all_reduce(full, op=dist.ReduceOp.SUM, group=self.group)
+        out.copy_(full.view(n, -1)[self.rank].view_as(out)).mul_(1.0 / n)
+        return self._Done()
+
+    def all_gather_rows(self, planes, row0, nrows, async_op=False):
+        """planes [C, T, W] (contiguous): every rank owns the rows [r * nrows, (r + 1) * nrows) of each plane and has just updated ITS rows
+        [row0, row0 + nrows); afterwards every rank holds all rows.  One all-gather per plane straight into the plane (a plane's row
+        strips are its N equal contiguous chunks); the input is a copy of the strip.  -> list of handles with wait()."""
+        assert planes.is_contiguous() and row0 == self.rank * nrows and planes.shape[1] == nrows * self.world_size
+        works = []
+        for c in range(planes.shape[0]):
+            src = planes[c, row0:row0 + nrows].clone()
+            w = dist.all_gather_into_tensor(planes[c], src, group=self.group, async_op=async_op)
+            works.append(w if async_op and w is not None else self._Done())
+        return works
+
     def average_gradients(self, params):
         """One flat-bucket all-reduce of every gradient (missing grads count as zero)."""
         params = [p for p in params if p.requires_grad]

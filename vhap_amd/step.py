@@ -622,6 +622,23 @@ class NativeStep:
              "vhap_tex_prep_bwd")
         return False
 
+    def tex_fold(self):
+        """the whole gradient pyramid folded into its level 0 (frame sharding: only level 0 -- 50 MB of the pyramid's 67 -- is exchanged)"""
+        if not (self.tex_bwd_on and self.photometric and self.mips.numel() > 0):
+            return
+        n0 = self.albedo_tex.numel()
+        _chk(self.L.vhap_texture_mip_fold(_p(self.g["d_tex"][:n0]), _p(self.g["d_tex"][n0:]), 1, self.T, self.T, 3, 0, _stream()),
+             "vhap_texture_mip_fold")
+
+    def tex_finish_rows(self, optimizer, d_strip, row0, nrows):
+        """tex_finish() + Adam on the row strip [row0, row0 + nrows) of the texture from `d_strip` [nrows, T, 3], this rank's slice of the
+        rank-averaged, folded level-0 gradient (frame sharding: vhap_tex_prep_bwd_adam_rows)."""
+        tr, T, g = self.tr, self.T, self.g
+        m, v, lr, step, b1, b2, eps = optimizer.fused_update_args(tr.tex_extra)
+        _chk(self.L.vhap_tex_prep_bwd_adam_rows(_p(self.albedo_tex), _p(tr.tex_extra), _p(self.nm["res_mask"]), _p(d_strip), _p(self.ones), T,
+                                                int(row0), int(nrows), *self.tex_scales, _p(g["tex_extra"]), _p(m), _p(v), _p(lr), _p(step),
+                                                b1, b2, eps, 0, _stream()), "vhap_tex_prep_bwd_adam_rows")
+
     def _bwd_early(self):
         """landmark and offset-regulariser gradients: they depend on nothing the pixel chain produces (pure launch latency)"""
         L, tr, g, om = self.L, self.tr, self.g, self.om
@@ -845,6 +862,8 @@ class NativeStep:
             self._bwd_pixel(world_size)
             self._side(self._bwd_pixel_finish, self.side2)
             self._tex_backward()
+            if self.split_tex:                                        # (sharded texture update: the exchange is on level 0 of the pyramid)
+                self.tex_fold()
             self._flush()
             if self.overlap:
                 torch.cuda.current_stream().wait_stream(self.side2)

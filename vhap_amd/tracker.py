@@ -1285,6 +1285,21 @@ class GraphedStep:
                 # Frame sharding.  The big collective is the texture gradient (50 MB at T = 2048).  The backward is captured in two plans:
                 # 'pixel_tex' makes that gradient final first, its asynchronous all-reduce is launched, and 'geometry' (G-buffer backward,
                 # normals, skinning, per-frame parameters: ~0.3 ms) runs underneath it; the small gradients follow in a second collective.
+                # SHARDED TEXTURE UPDATE (round 4): the texture gradient is not all-reduced and the 50 MB texture not updated N times over.
+                # 'pixel_tex' stops at the gradient pyramid and folds it into level 0; a reduce-scatter hands rank r the mean of rows
+                # [r T / N, (r + 1) T / N); the Adam plan finishes and updates THOSE rows (vhap_tex_prep_bwd_adam_rows: 1 / N of the 124 us /
+                # 497 MB pass) and an asynchronous all-gather of the updated rows runs until the next step's forward needs the texture.
+                # Same bytes on the wire as the all-reduce it replaces (a ring all-reduce IS this reduce-scatter + all-gather).
+                T = int(tracker.tex_extra.shape[-1]) if tracker.tex_extra is not None else 0
+                tex = tracker.tex_extra
+                self.tex_sharded = bool(ns.tex_bwd_on and tex is not None and any(p is tex for p in self.params) and T % (16 * world) == 0 and
+                                        isinstance(optimizer, NV.HipAdam) and os.environ.get("VHAP_TEX_SHARDED", "1") != "0")
+                if self.tex_sharded:
+                    ns.split_tex = True
+                    self.tex_rows = T // world
+                    self.tex_row0 = tracker.dist.rank * self.tex_rows
+                    self.tex_strip = torch.zeros(self.tex_rows, T, 3, device=dev)        # reduce-scatter output: this rank's rows of the level-0 gradient
+                    self._tex_gather = None
                 with self.gF.capture(**cap):
                     ns.forward()
                 pool = self.gF.pool()
@@ -1294,7 +1309,11 @@ class GraphedStep:
                 with self.gB2.capture(pool=pool, **cap):
                     ns.backward(world, part="geometry")
                 with self.gA.capture(pool=pool, **cap):
-                    optimizer.step()
+                    if self.tex_sharded:
+                        ns.tex_finish_rows(optimizer, self.tex_strip, self.tex_row0, self.tex_rows)      # (reads the step counter + 1 ...)
+                        optimizer.step(skip=(tex,))                                                      # (... which this call then advances)
+                    else:
+                        optimizer.step()
             # Step k+1 under step k's texture tail: inside replay_stream() the single-GPU plan is replayed WITHOUT joining its side
             # streams at the end -- what it leaves open (the texture gradient's sort, tile pass, finish + Adam on the side stream) keeps
             # running while the next replay's launch-stream kernels up to the rasteriser (camera, per-frame parameters, skinning, binning)
@@ -1388,6 +1407,7 @@ class GraphedStep:
             self.stream.wait_stream(cur)
             with torch.cuda.stream(self.stream):
                 self._replay()
+                self.wait_texture()                                # (a lone step: the caller may read the texture next)
             cur.wait_stream(self.stream)
         else:
             self._replay()
@@ -1419,12 +1439,22 @@ class GraphedStep:
 
     def join(self):
         """The step's stream waits for what the last replay left running (replays inside replay_stream() defer their join)."""
+        with torch.cuda.stream(self.stream):
+            self.wait_texture()
         if self.defer_join:
             with torch.cuda.stream(self.stream):
                 self.gF.join()
 
+    def wait_texture(self):
+        """The all-gather of the texture rows the last sharded step updated: the current stream waits for it (no-op otherwise).  Called at the
+        head of the next replay and by join(): anything that reads tex_extra after a sharded step must come behind it."""
+        works, self._tex_gather = getattr(self, "_tex_gather", None), None
+        for w in works or ():
+            w.wait()
+
     def _replay(self):
         tr = self.tr
+        self.wait_texture()
         if self.ns is not None and self.single:
             self.gF.replay(defer_join=self.defer_join and self._in_loop)
             return
@@ -1441,6 +1471,16 @@ class GraphedStep:
                 self.ns.n_global.copy_(tr.dist.all_reduce_sum(self.N.reshape(1)))
             self.gB.replay()                                               # pixel chain + the complete texture gradient
             # the gradients sit in contiguous buffers: collectives straight on them (ReduceOp.AVG), no staging copies
+            if getattr(self, "tex_sharded", False):
+                n0 = self.ns.albedo_tex.numel()
+                work = tr.dist.reduce_scatter_mean(self.ns.g["d_tex"][:n0], self.tex_strip.view(-1), async_op=True)   # level 0, pyramid folded in
+                self.gB2.replay()                                          # geometry chain: runs under the texture collective
+                tr.dist.all_reduce_mean_(self.ns.param_grad_flat)
+                work.wait()
+                self.gA.replay()                                           # this rank's rows of the texture + every other parameter
+                # the updated rows travel while the host comes round to the next step (whose forward waits: wait_texture)
+                self._tex_gather = tr.dist.all_gather_rows(tr.tex_extra.detach(), self.tex_row0, self.tex_rows, async_op=True)
+                return
             work = tr.dist.all_reduce_mean_(self.ns.g["tex_extra"], async_op=True) if self.ns.tex_bwd_on else None
             self.gB2.replay()                                              # geometry chain: runs under the texture collective
             tr.dist.all_reduce_mean_(self.ns.param_grad_flat)
