@@ -253,6 +253,9 @@ int vhap_texture_bwd(const float* tex, const float* mips, int TB, int Ht, int Wt
                      vhap_stream_t stream);
 int vhap_texture_mip_fold(float* d_tex, float* d_mips, int TB, int Ht, int Wt, int C, int stop_level,
                           vhap_stream_t stream);
+/* the same result as vhap_texture_mip_fold(stop_level = 0) for ONE texture (TB = 1) in one gathering pass: level 0 += sum_l 4^-l level_l
+ * (the pyramid above level 0 is left as it is) */
+int vhap_texture_mip_fold_gather(float* d_tex, const float* d_mips, int Ht, int Wt, int C, vhap_stream_t stream);
 /* The d_tex / d_mips part of vhap_texture_bwd for ONE SHARED texture (TB == 1; the reference's expanded batch of copies,
  * tracker.py:234) through uv-space binning: the covered pixels (d_out != 0) of all frames are counting-sorted by the uv tile
  * they sample, one workgroup per tile accumulates them in LDS and every touched texel is flushed once -- an order of
@@ -589,10 +592,28 @@ int vhap_tex_prep_bwd_adam(const float* albedo_hwc, float* extra, const uint8_t*
  * finish and update rows [r T / N, (r + 1) T / N) only -- d_albedo_strip = the strip's [nrows, T, 3] slice of the level-0 gradient with the
  * whole pyramid folded into it (vhap_texture_mip_fold(stop_level = 0)), e.g. the output of a reduce-scatter; albedo_hwc, extra, res_mask,
  * d_extra, exp_avg, exp_avg_sq are the FULL arrays (rows outside the strip are not touched).  New in this build. */
+/* vhap_tex_prep_bwd / vhap_tex_prep_bwd_adam with one more output, d_base [3,T,T] (may be NULL): d(base texture) = d(albedo) WITHOUT the
+ * residual's own regulariser (reg_tex_res_clusters acts on tex_extra only, tracker.py:538-541) -- the input of vhap_tex_pca_bwd. */
+int vhap_tex_prep_bwd_base(const float* albedo_hwc, const float* extra, const uint8_t* res_mask, const float* d_albedo_hwc,
+                           const float* d_mips_hwc, int n_gather, const float* d_terms, int T, float s_tv, float s_res, float* d_extra,
+                           float* d_base, vhap_stream_t stream);
+int vhap_tex_prep_bwd_adam_base(const float* albedo_hwc, float* extra, const uint8_t* res_mask, const float* d_albedo_hwc,
+                                const float* d_mips_hwc, int n_gather, const float* d_terms, int T, float s_tv, float s_res, float* d_extra,
+                                float* exp_avg, float* exp_avg_sq, const float* lr_device, const int32_t* step_device, float beta1, float beta2,
+                                float eps, float* d_base, int call_flags, vhap_stream_t stream);
 int vhap_tex_prep_bwd_adam_rows(const float* albedo_hwc, float* extra, const uint8_t* res_mask, const float* d_albedo_strip,
                                 const float* d_terms, int T, int row0, int nrows, float s_tv, float s_res, float* d_extra, float* exp_avg,
                                 float* exp_avg_sq, const float* lr_device, const int32_t* step_device, float beta1, float beta2, float eps,
                                 int call_flags, vhap_stream_t stream);
+/* FLAME PCA texture model (flame.py:665-688 FlameTexPCA, tracker.py:241-244, 519-521; the tex_painted = False configuration):
+ *   fwd: src [S,S,3] = mean + basis [S*S*3, n] . code [n]  (0..255, B G R);  base [3,T,T] = clamp(nearest_resize(src)[R,G,B] / 255, 0, 1) -- takes
+ *        the place of the painted texture in vhap_tex_prep_fwd; term_accum (may be NULL) += s_reg * sum(code^2)   (s_reg = w.reg_tex_pca / n)
+ *   bwd: d_code [n] ACCUMULATED from d_base [3,T,T] (= d albedo without the residual regulariser: the optional d_base output of
+ *        vhap_tex_prep_bwd) through the clamp and the resize, + the regulariser's gradient (d_term[0], NULL = 1); g_work: [S*S*3] floats. */
+int vhap_tex_pca_fwd(const float* mean, const float* basis, const float* code, int n, int S, int T, float s_reg, float* src, float* base,
+                     float* term_accum, vhap_stream_t stream);
+int vhap_tex_pca_bwd(const float* basis, const float* src, const float* d_base, const float* code, int n, int S, int T, float s_reg,
+                     const float* d_term, float* g_work, float* d_code, vhap_stream_t stream);
 int vhap_adam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                    float* const* exp_avg_sq, const int64_t* numel, const int32_t* lr_index,
                    const float* lr_device, int32_t* step_device, float beta1, float beta2, float eps,
@@ -610,7 +631,7 @@ int vhap_set_floats(float* dst_device, const float* values_host, int n, vhap_str
  * (tracker.py:430-439), the static-offset gradient summed over frames and the focal-length gradient (tracker.py:141-157).
  *
  * vhap_energy_finalize: log[VHAP_LOG_COUNT] <- the weighted terms (any input may be NULL = term absent); log[VHAP_LOG_REST] = sum
- *   of everything but the photometric term.  frame_terms [6], tex_terms [2], off_terms [4] = (Laplacian, L1, rigidity as
+ *   of everything but the photometric term.  frame_terms [6], tex_terms [3] (TV, residual, PCA code regulariser), off_terms [4] = (Laplacian, L1, rigidity as
  *   vhap_offset_reg_fwd writes them, then reg_offset_dynamic as vhap_offset_dynamic_reg adds it; 0 without a dynamic offset).
  * vhap_energy_total: inv_n = world_size / (3 n_global); log[PHOTO] = w_photo * photo2[0] * inv_n; log[TOTAL]; d_sum[0] = w_photo * inv_n
  *   (the upstream gradient handed to vhap_photo_bwd).
@@ -619,7 +640,8 @@ enum {
     VHAP_LOG_LMK = 0, VHAP_LOG_PHOTO = 1, VHAP_LOG_SMOOTH_POSE = 2, VHAP_LOG_REG_JOINT = 3, VHAP_LOG_SMOOTH_JOINT = 4,
     VHAP_LOG_REG_EXPR = 5, VHAP_LOG_SMOOTH_EXPR = 6, VHAP_LOG_REG_SHAPE = 7, VHAP_LOG_TEX_TV = 8, VHAP_LOG_TEX_RES = 9,
     VHAP_LOG_REG_DIFFUSE = 10, VHAP_LOG_OFF_LAP = 11, VHAP_LOG_OFF_ABS = 12, VHAP_LOG_OFF_RIGID = 13, VHAP_LOG_REST = 14,
-    VHAP_LOG_TOTAL = 15, VHAP_LOG_OFF_DYNAMIC = 16 /* reg_offset_dynamic: part of REST and TOTAL */, VHAP_LOG_COUNT = 17
+    VHAP_LOG_TOTAL = 15, VHAP_LOG_OFF_DYNAMIC = 16 /* reg_offset_dynamic: part of REST and TOTAL */,
+    VHAP_LOG_TEX_PCA = 17 /* reg_tex_pca (tex_terms[2]): part of REST and TOTAL */, VHAP_LOG_COUNT = 18
 };
 int vhap_energy_finalize(const float* frame_terms, const float* lmk_energy, const float* tex_terms,
                          const float* off_terms, const float* shade_stats, float w_landmark,

@@ -104,12 +104,16 @@ def regularization_energy(P, ts, w, stage, opt, tex_painted, uvmask_res, v_cano,
 
 
 def total_energy(P, model, topo, cfg, sample, stage, tex_painted, uvmask_res, image_size, dtype=torch.float64,
-                 disturb=None, tid=None, photo_sign_from=None):
+                 disturb=None, tid=None, photo_sign_from=None, tex_pca_space=None):
     """P: dict of parameter tensors (leaf, requires_grad) named like the GlobalTracker attributes.
     `tid`: optional [B,H,W] triangle ids (-1 = none) to use instead of rasterising (golden-vector comparisons fix the visibility).
     `photo_sign_from`: optional residual image of another evaluation: the L1 term takes that evaluation's side of its kinks (R.photometric_energy).
+    `tex_pca_space`: dict(mean [S*S*3], basis [S*S*3, n]) -- the tex_painted = False configuration (tracker.py:241-244, 519-521): the base
+    texture is the FLAME PCA texture of P["tex_pca"] instead of `tex_painted`, and reg_tex_pca is added when the texture is trained.
     Returns (E_total, log_dict, extras)."""
     H, W = image_size
+    if tex_pca_space is not None:
+        tex_painted = R.tex_pca_texture(tex_pca_space["mean"].to(dtype), tex_pca_space["basis"].to(dtype), P["tex_pca"], P["tex_extra"].shape[-1])
     ts = np.asarray(sample["timestep_index"])
     prev = np.clip(ts - 1, 0, P["expr"].shape[0] - 1)
     B = len(ts)
@@ -159,5 +163,7 @@ def total_energy(P, model, topo, cfg, sample, stage, tex_painted, uvmask_res, im
     if stage is not None:
         d = extras["diffuse_detach_normal"].permute(0, 3, 1, 2) if "lights" in opt else None
         log.update(regularization_energy(P, ts, w, stage, opt, tex_painted, uvmask_res, v_cano, d, topo, dtype))
+    if tex_pca_space is not None and st is not None and "texture" in opt:
+        log["reg_tex_pca"] = w.reg_tex_pca * (P["tex_pca"] ** 2).mean()          # tracker.py:519-521 (std_tex = 1)
     E = torch.stack(list(log.values())).sum()
     return E, log, extras

@@ -560,6 +560,15 @@ def photometric_energy(gt_rgb_nchw, rgba_nhwc_flipped, sign_from=None):
     return x.abs().sum() / mask.sum()
 
 
+def tex_pca_texture(mean, basis, code, tex_size):
+    """flame.py:665-688 FlameTexPCA.forward for ONE code [n]: mean [S*S*3] + basis [S*S*3, n] . code on an S x S x 3 grid in 0..255 (B G R)
+    -> nearest resize to tex_size, channels to R G B, / 255, clamp(0, 1) -> [1, 3, T, T]."""
+    S = int(round((mean.numel() // 3) ** 0.5))
+    tex = (mean.reshape(-1) + basis @ code).reshape(1, S, S, 3).permute(0, 3, 1, 2)
+    tex = F.interpolate(tex, [tex_size, tex_size])
+    return (tex[:, [2, 1, 0], :, :] / 255.0).clamp(0, 1)
+
+
 def tex_tv_energy(tex_chw):
     """tracker.py:526-531 (mean over [3, (T-1)*T] of tv_y + tv_x)."""
     tv_y = (tex_chw[..., :-1, :] - tex_chw[..., 1:, :]) ** 2

@@ -45,6 +45,7 @@ SIGNATURES = {
     "vhap_texture_fwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp]),
     "vhap_texture_bwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_i] + [c_fp] * 5),
     "vhap_texture_mip_fold": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_i, c_i, c_fp]),
+    "vhap_texture_mip_fold_gather": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp]),
     "vhap_texture_grad_binned_work_bytes": (c_sz, [c_i, c_i, c_i]),
     "vhap_texture_grad_binned": (c_i, [c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_sz, c_fp]),
     "vhap_texture_grad_binned_ids": (c_i, [c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_sz, c_fp]),
@@ -98,6 +99,10 @@ SIGNATURES = {
     "vhap_texture_mip_build_from": (c_i, [c_fp, c_i, c_i, c_i, c_i, c_fp, c_i, c_fp]),
     "vhap_tex_prep_bwd": (c_i, [c_fp] * 5 + [c_i, c_fp, c_i, c_f, c_f] + [c_fp] * 2),
     "vhap_tex_prep_bwd_adam": (c_i, [c_fp] * 5 + [c_i, c_fp, c_i, c_f, c_f] + [c_fp] * 5 + [c_f, c_f, c_f, c_i, c_fp]),
+    "vhap_tex_prep_bwd_base": (c_i, [c_fp] * 5 + [c_i, c_fp, c_i, c_f, c_f] + [c_fp] * 3),
+    "vhap_tex_prep_bwd_adam_base": (c_i, [c_fp] * 5 + [c_i, c_fp, c_i, c_f, c_f] + [c_fp] * 5 + [c_f, c_f, c_f, c_fp, c_i, c_fp]),
+    "vhap_tex_pca_fwd": (c_i, [c_fp] * 3 + [c_i, c_i, c_i, c_f] + [c_fp] * 4),
+    "vhap_tex_pca_bwd": (c_i, [c_fp] * 4 + [c_i, c_i, c_i, c_f] + [c_fp] * 4),
     "vhap_tex_prep_bwd_adam_rows": (c_i, [c_fp] * 5 + [c_i, c_i, c_i, c_f, c_f] + [c_fp] * 5 + [c_f, c_f, c_f, c_i, c_fp]),
     "vhap_energy_finalize": (c_i, [c_fp] * 5 + [c_f, c_f, c_i, c_i, c_i, c_fp, c_fp]),
     "vhap_energy_total": (c_i, [c_fp, c_fp, c_fp, c_f, c_i, c_fp, c_fp]),

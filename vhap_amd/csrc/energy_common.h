@@ -16,7 +16,7 @@ __device__ inline void finalize(const float* frame_terms, const float* lmk, cons
     if (lmk) v[VHAP_LOG_LMK] = w_lmk * lmk[0];
     if (frame_terms)
         for (int i = 0; i < 6; i++) v[VHAP_LOG_SMOOTH_POSE + i] = frame_terms[i];
-    if (tex_terms) { v[VHAP_LOG_TEX_TV] = tex_terms[0]; v[VHAP_LOG_TEX_RES] = tex_terms[1]; }
+    if (tex_terms) { v[VHAP_LOG_TEX_TV] = tex_terms[0]; v[VHAP_LOG_TEX_RES] = tex_terms[1]; v[VHAP_LOG_TEX_PCA] = tex_terms[2]; }   // tex_terms[3]
     if (shade_stats) {
         const float mx = decode_ordered(shade_stats[1]);
         v[VHAP_LOG_REG_DIFFUSE] = w_reg_diffuse * (fmaxf(mx - 1.0f, 0.0f) + __uint_as_float(shade_stats[2]) / npix);
@@ -29,6 +29,7 @@ __device__ inline void finalize(const float* frame_terms, const float* lmk, cons
     for (int i = 0; i < VHAP_LOG_REST; i++)
         if (i != VHAP_LOG_PHOTO) rest += v[i];
     rest += v[VHAP_LOG_OFF_DYNAMIC];
+    rest += v[VHAP_LOG_TEX_PCA];
     v[VHAP_LOG_REST] = rest;
     for (int i = 0; i < VHAP_LOG_COUNT; i++) log[i] = v[i];
 }
@@ -63,6 +64,7 @@ __device__ inline void finalize_total_wave(const float* frame_terms, const float
     else if (i >= VHAP_LOG_SMOOTH_POSE && i < VHAP_LOG_SMOOTH_POSE + 6) { if (frame_terms) v = frame_terms[i - VHAP_LOG_SMOOTH_POSE]; }
     else if (i == VHAP_LOG_TEX_TV) { if (tex_terms) v = tex_terms[0]; }
     else if (i == VHAP_LOG_TEX_RES) { if (tex_terms) v = tex_terms[1]; }
+    else if (i == VHAP_LOG_TEX_PCA) { if (tex_terms) v = tex_terms[2]; }
     else if (i >= VHAP_LOG_OFF_LAP && i < VHAP_LOG_OFF_LAP + 3) { if (off_terms) v = off_terms[i - VHAP_LOG_OFF_LAP]; }
     else if (i == VHAP_LOG_OFF_DYNAMIC) { if (off_terms) v = off_terms[3]; }
     float mx = 4.0f;
@@ -78,6 +80,7 @@ __device__ inline void finalize_total_wave(const float* frame_terms, const float
         if (k != VHAP_LOG_PHOTO) rest += vk;
     }
     rest += __shfl(v, VHAP_LOG_OFF_DYNAMIC, 64);
+    rest += __shfl(v, VHAP_LOG_TEX_PCA, 64);
     const float g = w_photo * (world / (3.0f * n_global));
     const float photo = g * photo_sum;
     if (i == VHAP_LOG_PHOTO) v = photo;

@@ -236,7 +236,8 @@ template <bool ADAM>
 __global__ __launch_bounds__(RB) void tex_prep_bwd_kernel(TexCfg c, const float* __restrict__ albedo, const float* __restrict__ extra,
                                                           const unsigned char* __restrict__ res_mask, const float* __restrict__ d_albedo,
                                                           const float* __restrict__ d_mips, int n_gather, const float* __restrict__ d_terms,
-                                                          float* __restrict__ d_extra, const TexAdam A, int step_add, int y_base) {
+                                                          float* __restrict__ d_extra, const TexAdam A, int step_add, int y_base,
+                                                          float* __restrict__ d_base) {
     const int T = c.T;
     const size_t plane = (size_t)T * T;
     const float gtv = 2.0f * c.s_tv * d_terms[0], gres = 2.0f * c.s_res * d_terms[1];
@@ -341,6 +342,8 @@ __global__ __launch_bounds__(RB) void tex_prep_bwd_kernel(TexCfg c, const float*
             }
         }
         if (in_x) {
+            // d(base texture) = d(albedo) without the residual's own regulariser: what the PCA texture model's backward takes (vhap_tex_pca_bwd)
+            if (d_base) { d_base[i] = g[0]; d_base[plane + i] = g[1]; d_base[2 * plane + i] = g[2]; }
             float ex[3] = {0.f, 0.f, 0.f};
             const bool res = gres != 0.f && res_mask && res_mask[i];
             if (res || ADAM) {
@@ -518,12 +521,19 @@ extern "C" int vhap_tex_prep_mip1_fwd(const float* painted, const float* extra, 
 extern "C" int vhap_tex_prep_bwd(const float* albedo_hwc, const float* extra, const uint8_t* res_mask, const float* d_albedo_hwc,
                                  const float* d_mips_hwc, int n_gather, const float* d_terms, int T, float s_tv, float s_res,
                                  float* d_extra, vhap_stream_t stream) {
+    return vhap_tex_prep_bwd_base(albedo_hwc, extra, res_mask, d_albedo_hwc, d_mips_hwc, n_gather, d_terms, T, s_tv, s_res, d_extra, nullptr, stream);
+}
+
+// ... with d_base [3,T,T] (may be NULL): d(base texture) = d(albedo) without the residual's own regulariser (PCA texture model)
+extern "C" int vhap_tex_prep_bwd_base(const float* albedo_hwc, const float* extra, const uint8_t* res_mask, const float* d_albedo_hwc,
+                                      const float* d_mips_hwc, int n_gather, const float* d_terms, int T, float s_tv, float s_res,
+                                      float* d_extra, float* d_base, vhap_stream_t stream) {
     VHAP_ENTER();
     if (!albedo_hwc || !extra || !d_terms || !d_extra) return VHAP_E_NULLPTR;
     if (T <= 0 || n_gather < 0 || n_gather > TEXB_MAXG || (d_mips_hwc && n_gather > 0 && (T & ((1 << n_gather) - 1)))) return VHAP_E_BADDIM;
     TexCfg c{T, s_tv, s_res};
     tex_prep_bwd_kernel<false><<<dim3(vhap_cdiv(T, RB), vhap_cdiv(T, TEXB_ROWS)), RB, 0, vhap_stream(stream)>>>(
-        c, albedo_hwc, extra, res_mask, d_albedo_hwc, n_gather > 0 ? d_mips_hwc : nullptr, n_gather, d_terms, d_extra, TexAdam{}, 0, 0);
+        c, albedo_hwc, extra, res_mask, d_albedo_hwc, n_gather > 0 ? d_mips_hwc : nullptr, n_gather, d_terms, d_extra, TexAdam{}, 0, 0, d_base);
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;
 }
@@ -532,13 +542,21 @@ extern "C" int vhap_tex_prep_bwd_adam(const float* albedo_hwc, float* extra, con
                                       const float* d_mips_hwc, int n_gather, const float* d_terms, int T, float s_tv, float s_res,
                                       float* d_extra, float* exp_avg, float* exp_avg_sq, const float* lr_device, const int32_t* step_device,
                                       float beta1, float beta2, float eps, int call_flags, vhap_stream_t stream) {
+    return vhap_tex_prep_bwd_adam_base(albedo_hwc, extra, res_mask, d_albedo_hwc, d_mips_hwc, n_gather, d_terms, T, s_tv, s_res, d_extra, exp_avg,
+                                       exp_avg_sq, lr_device, step_device, beta1, beta2, eps, nullptr, call_flags, stream);
+}
+
+extern "C" int vhap_tex_prep_bwd_adam_base(const float* albedo_hwc, float* extra, const uint8_t* res_mask, const float* d_albedo_hwc,
+                                           const float* d_mips_hwc, int n_gather, const float* d_terms, int T, float s_tv, float s_res,
+                                           float* d_extra, float* exp_avg, float* exp_avg_sq, const float* lr_device, const int32_t* step_device,
+                                           float beta1, float beta2, float eps, float* d_base, int call_flags, vhap_stream_t stream) {
     VHAP_ENTER();
     if (!albedo_hwc || !extra || !d_terms || !d_extra || !exp_avg || !exp_avg_sq || !lr_device || !step_device) return VHAP_E_NULLPTR;
     if (T <= 0 || n_gather < 0 || n_gather > TEXB_MAXG || (d_mips_hwc && n_gather > 0 && (T & ((1 << n_gather) - 1)))) return VHAP_E_BADDIM;
     TexCfg c{T, s_tv, s_res};
     tex_prep_bwd_kernel<true><<<dim3(vhap_cdiv(T, RB), vhap_cdiv(T, TEXB_ROWS)), RB, 0, vhap_stream(stream)>>>(
         c, albedo_hwc, extra, res_mask, d_albedo_hwc, n_gather > 0 ? d_mips_hwc : nullptr, n_gather, d_terms, d_extra,
-        TexAdam{extra, exp_avg, exp_avg_sq, lr_device, step_device, beta1, beta2, eps}, (call_flags & VHAP_CALL_ADAM_STEP_ADVANCED) ? 0 : 1, 0);
+        TexAdam{extra, exp_avg, exp_avg_sq, lr_device, step_device, beta1, beta2, eps}, (call_flags & VHAP_CALL_ADAM_STEP_ADVANCED) ? 0 : 1, 0, d_base);
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;
 }
@@ -559,7 +577,7 @@ extern "C" int vhap_tex_prep_bwd_adam_rows(const float* albedo_hwc, float* extra
     const float* d_base = d_albedo_strip - (size_t)row0 * T * 3;
     tex_prep_bwd_kernel<true><<<dim3(vhap_cdiv(T, RB), nrows / TEXB_ROWS), RB, 0, vhap_stream(stream)>>>(
         c, albedo_hwc, extra, res_mask, d_base, nullptr, 0, d_terms, d_extra,
-        TexAdam{extra, exp_avg, exp_avg_sq, lr_device, step_device, beta1, beta2, eps}, (call_flags & VHAP_CALL_ADAM_STEP_ADVANCED) ? 0 : 1, row0);
+        TexAdam{extra, exp_avg, exp_avg_sq, lr_device, step_device, beta1, beta2, eps}, (call_flags & VHAP_CALL_ADAM_STEP_ADVANCED) ? 0 : 1, row0, nullptr);
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;
 }

@@ -877,6 +877,51 @@ extern "C" int vhap_texture_mip_fold(float* d_tex, float* d_mips, int TB, int Ht
     return VHAP_OK;
 }
 
+// The whole pyramid folded into level 0 in ONE pass by GATHERING: texel (y, x) of level 0 += sum_l 4^-l level_l[y >> l][x >> l] -- exactly
+// what the cascade of vhap_texture_mip_fold(stop_level = 0) leaves there, without its L dependent read-modify-write launches (74 us at
+// T = 2048; this pass: one read + one write of level 0 and cache hits on the 17 MB above it).  The loads of a texel are one unconditional
+// batch over a compile-time bound (levels beyond L re-read the last one with weight 0).  TB = 1.
+template <int C>
+__global__ __launch_bounds__(256) void mip_fold_gather_kernel(float* __restrict__ d_tex, const float* __restrict__ d_mips, const TexDesc D) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= D.W) return;
+    float g[C];
+    float* p = d_tex + ((size_t)y * D.W + x) * C;
+#pragma unroll
+    for (int c = 0; c < C; c++) g[c] = p[c];
+    float m[MAX_LEVELS][C], sc[MAX_LEVELS];
+    float w = 0.25f;
+#pragma unroll
+    for (int u = 0; u < MAX_LEVELS; u++) {
+        const int l = min(u + 1, D.L);
+        const float* q = d_mips + D.off[l] + ((size_t)(y >> l) * (D.W >> l) + (x >> l)) * C;
+#pragma unroll
+        for (int c = 0; c < C; c++) m[u][c] = q[c];
+        sc[u] = u + 1 <= D.L ? w : 0.f;
+        w *= 0.25f;
+    }
+#pragma unroll
+    for (int u = 0; u < MAX_LEVELS; u++)
+#pragma unroll
+        for (int c = 0; c < C; c++) g[c] += sc[u] * m[u][c];
+#pragma unroll
+    for (int c = 0; c < C; c++) p[c] = g[c];
+}
+
+extern "C" int vhap_texture_mip_fold_gather(float* d_tex, const float* d_mips, int Ht, int Wt, int C, vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (int e = check_tex(1, Ht, Wt, C)) return e;
+    if (!d_tex || !d_mips) return VHAP_E_NULLPTR;
+    const TexDesc D = make_desc(1, Ht, Wt, C);
+    if (D.L == 0) return VHAP_OK;
+    return dispatch_C(C, [&](auto c) {
+        constexpr int CC = decltype(c)::value;
+        mip_fold_gather_kernel<CC><<<dim3(vhap_cdiv(Wt, 256), Ht), 256, 0, vhap_stream(stream)>>>(d_tex, d_mips, D);
+        VHAP_LAUNCH_CHECK();
+        return VHAP_OK;
+    });
+}
+
 extern "C" int vhap_texture_fwd(const float* tex, const float* mips, int TB, int Ht, int Wt, int C, const float* uv,
                                 const float* uv_da, int B, int H, int W, float* out, vhap_stream_t stream) {
     VHAP_ENTER();

@@ -162,6 +162,34 @@ class FlameTexPainted(nn.Module):
         return self.tex_painted
 
 
+class FlameTexPCA(nn.Module):
+    """flame.py:665-688 -- the FLAME PCA texture space (`tex_painted = False`): texture = mean + basis . code on a 512 x 512 x 3 grid in
+    0..255, B G R; forward(texcode [B, n]) -> [B, 3, T, T]: nearest resize to the working resolution, channels to R G B, / 255, clamp.
+    `tex_space`: a path to FLAME_texture.npz (`mean`, `tex_dir`) or a mapping with those two arrays (tests: a synthetic space of the same
+    layout -- the licensed file is not in this container)."""
+
+    def __init__(self, tex_params, tex_size=512, tex_space=None):
+        super().__init__()
+        self.tex_size = int(tex_size)
+        space = np.load(tex_space) if isinstance(tex_space, (str, bytes)) or hasattr(tex_space, "__fspath__") else tex_space
+        mean = np.asarray(space["mean"], np.float32).reshape(1, -1)
+        n_all = int(np.asarray(space["tex_dir"]).shape[-1])
+        basis = np.asarray(space["tex_dir"], np.float32).reshape(-1, n_all)[:, :tex_params]
+        self.src_size = int(round((mean.shape[1] // 3) ** 0.5))
+        assert self.src_size * self.src_size * 3 == mean.shape[1] == basis.shape[0]
+        self.register_buffer("texture_mean", torch.from_numpy(mean)[None, ...])                           # [1, 1, S*S*3]
+        self.register_buffer("texture_basis", torch.from_numpy(np.ascontiguousarray(basis))[None, ...])   # [1, S*S*3, n]
+
+    def forward(self, texcode):
+        S = self.src_size
+        texture = self.texture_mean + (self.texture_basis * texcode[:, None, :]).sum(-1)
+        texture = texture.reshape(texcode.shape[0], S, S, 3).permute(0, 3, 1, 2)
+        texture = torch.nn.functional.interpolate(texture, [self.tex_size, self.tex_size])
+        texture = texture[:, [2, 1, 0], :, :]
+        texture = texture / 255.0
+        return texture.clamp(0, 1)
+
+
 class FlameUvMask(nn.Module):
     """flame.py:1057-1070."""
 

@@ -31,7 +31,8 @@ PRE = _lib.CALL_ACC_PREZEROED        # per-call flag (ABI 2): this call's small 
 FUSE_TEX_ADAM = True     # the texture's Adam update inside the gradient-finishing pass (tools flip it to time the two-pass form)
 
 LOG_NAMES = ("lmk", "photo", "smooth_pose", "reg_joint", "smooth_joint", "reg_expr", "smooth_expr", "reg_shape", "reg_tex_tv",
-             "reg_tex_res_clusters", "reg_diffuse", "reg_offset_lap", "reg_offset", "reg_offset_rigid", "rest", "total", "reg_offset_dynamic")
+             "reg_tex_res_clusters", "reg_diffuse", "reg_offset_lap", "reg_offset", "reg_offset_rigid", "rest", "total", "reg_offset_dynamic",
+             "reg_tex_pca")
 
 
 def _chk(rc, what):
@@ -53,7 +54,8 @@ class NativeStep:
         the sample, tracker.py:141-157) and the landmark-only stages (lmk_init_*, lmk_*_tracking: no pixel chain at all)."""
         cfg = tracker.cfg
         photometric = isinstance(cfg.pipeline[stage], PhotometricStageConfig) and cfg.w.photo is not None
-        return tracker._native_ok(stage, dynamic_offset_ok=True) and (not photometric or cfg.render.background_train in ("target", "white", "black"))
+        return tracker._native_ok(stage, dynamic_offset_ok=True, tex_pca_ok=True) and \
+            (not photometric or cfg.render.background_train in ("target", "white", "black"))
 
     def __init__(self, tracker, sample, stage):
         tr = self.tr = tracker
@@ -104,6 +106,18 @@ class NativeStep:
         if self.painted.shape[-1] != T:
             self.painted = torch.nn.functional.interpolate(self.painted[None], (T, T), mode="bilinear")[0].contiguous()
         tex_on = bool(o["texture"])
+        # the FLAME PCA texture model (tex_painted = False; flame.py:665-688): `painted` is re-assembled from tex_pca at the head of every
+        # step (vhap_tex_pca_fwd) and the code gets its gradient from d(base texture) (vhap_tex_pca_bwd)
+        self.pca = tr.flame_tex_pca
+        if self.pca is not None:
+            if int(self.pca.tex_size) != T:
+                raise NotImplementedError("the PCA texture model at a resolution other than tex_resolution")
+            S, n = self.pca.src_size, int(tr.tex_pca.shape[0])
+            self.pca_mean = self.pca.texture_mean.reshape(-1).contiguous()
+            self.pca_basis = self.pca.texture_basis[0].contiguous()              # [S*S*3, n]
+            self.pca_src, self.pca_work = E(S * S * 3), E(S * S * 3)
+            self.pca_train = tex_on
+            self.pca_scale = float((w.reg_tex_pca if tex_on else None) or 0.0) / n
         self.tex_scales = (float((tr._w_tv() if tex_on else None) or 0.0) / (3.0 * T * (T - 1)),
                            float((w.reg_tex_res_clusters if tex_on else None) or 0.0) / (3.0 * T * T))
         off_on = bool(o["static_offset"] or o["dynamic_offset"])
@@ -189,6 +203,8 @@ class NativeStep:
         # ---- backward: one arena for everything that is accumulated into ----
         params = {"shape": tr.shape, "expr": tr.expr, "rotation": tr.rotation, "translation": tr.translation, "neck_pose": tr.neck_pose,
                   "jaw_pose": tr.jaw_pose, "eyes_pose": tr.eyes_pose, "lights": tr.lights}
+        if self.pca is not None:
+            params["tex_pca"] = tr.tex_pca
         if self.has_offset:
             params["static_offset"] = tr.static_offset
         if self.dyn:
@@ -220,6 +236,8 @@ class NativeStep:
         if self.tex_bwd_on:
             self.g["tex_extra"] = torch.zeros_like(tr.tex_extra)      # overwritten by tex_prep_bwd, never accumulated
             self.params["tex_extra"] = tr.tex_extra
+            if self.pca is not None:
+                self.d_base = torch.zeros_like(tr.tex_extra)          # d(base texture): overwritten by the same pass
         for k, p in self.params.items():                              # the optimiser and the gradient all-reduce see these
             p.grad = self.g[k]
         # scratch that is overwritten
@@ -297,14 +315,17 @@ class NativeStep:
         `ready()` is called behind the pyramid -- what the rasteriser waits for -- ahead of the offset regularisers."""
         L, tr, T, acc = self.L, self.tr, self.T, self.accF
         st = _stream()
+        if self.pca is not None and self.tex_fwd_on:
+            _chk(L.vhap_tex_pca_fwd(_p(self.pca_mean), _p(self.pca_basis), _p(tr.tex_pca), int(tr.tex_pca.shape[0]), self.pca.src_size, T,
+                                    self.pca_scale, _p(self.pca_src), _p(self.painted), _p(acc[9:10]), st), "vhap_tex_pca_fwd")
         if self.tex_fwd_on and self.photometric and T % 2 == 0 and self.mips.numel() > 0:
             # texture assembly + TV / residual energies + level 1 of the pyramid in one pass; the rest of the pyramid four levels per launch
             _chk(L.vhap_tex_prep_mip1_fwd(_p(self.painted), _p(tr.tex_extra), _p(self.nm["res_mask"]), T, *self.tex_scales, _p(self.albedo_tex),
-                                          _p(self.mips), _p(acc[7:9]), PRE, st), "vhap_tex_prep_mip1_fwd")
+                                          _p(self.mips), _p(acc[7:10]), PRE, st), "vhap_tex_prep_mip1_fwd")
             _chk(L.vhap_texture_mip_build_from(_p(self.albedo_tex), 1, T, T, 3, _p(self.mips), 2, st), "vhap_texture_mip_build_from")
         elif self.tex_fwd_on:
             _chk(L.vhap_tex_prep_fwd(_p(self.painted), _p(tr.tex_extra), _p(self.nm["res_mask"]), T, *self.tex_scales, _p(self.albedo_tex),
-                                     _p(acc[7:9]), PRE, st), "vhap_tex_prep_fwd")
+                                     _p(acc[7:10]), PRE, st), "vhap_tex_prep_fwd")
             if self.photometric:
                 _chk(L.vhap_texture_mip_build(_p(self.albedo_tex), 1, T, T, 3, _p(self.mips), st), "vhap_texture_mip_build")
         if ready is not None:
@@ -403,7 +424,7 @@ class NativeStep:
                 self._landmark_forward()
             self.arena.zero_()
             self._arena_clean = True
-            _chk(L.vhap_energy_finalize(_p(acc[0:6]), _p(acc[6:7]) if self.w_lmk else 0, _p(acc[7:9]), _p(acc[20:24]), 0, self.w_lmk, 0.0,
+            _chk(L.vhap_energy_finalize(_p(acc[0:6]), _p(acc[6:7]) if self.w_lmk else 0, _p(acc[7:10]), _p(acc[20:24]), 0, self.w_lmk, 0.0,
                                         B, H, W, _p(self.log), st), "vhap_energy_finalize")
             return
         # fork here, not at the top: next to the bandwidth-bound texture assembly the two latency-bound kernels above take 3x as long,
@@ -447,7 +468,7 @@ class NativeStep:
         _chk(L.vhap_antialias_fwd(_p(color), _p(self.rast), _p(self.clip), _p(self.tri), _p(self.opp), B, H, W, 4, V, F, _p(self.rgba_aa),
                                   _p(self.aa_work), st), "vhap_antialias_fwd")
         _chk(L.vhap_photo_fwd(_p(self.rgba_aa), _p(self.rgb), B, H, W, _p(acc[16:18]), PRE, st), "vhap_photo_fwd")
-        _chk(L.vhap_energy_finalize(_p(acc[0:6]), _p(acc[6:7]) if self.w_lmk else 0, _p(acc[7:9]), _p(acc[20:24]),
+        _chk(L.vhap_energy_finalize(_p(acc[0:6]), _p(acc[6:7]) if self.w_lmk else 0, _p(acc[7:10]), _p(acc[20:24]),
                                     _p(acc[12:16]) if self.want_reg else 0, self.w_lmk, self.w_reg, B, H, W, _p(self.log), st),
              "vhap_energy_finalize")
 
@@ -539,7 +560,7 @@ class NativeStep:
             # no cross-queue hand-overs -- between the forward and the backward pass)
             self._join()          # the side branch: texture assembly, landmarks, statistics, arena clear, antialias pair discovery
             _chk(L.vhap_photo_fwd_total(_p(self.rgba_aa), _p(self.rgb), B, H, W, _p(acc[16:19]), _p(acc[0:6]), _p(acc[6:7]) if self.w_lmk else 0,
-                                        _p(acc[7:9]), _p(acc[20:24]), _p(acc[12:16]), self.w_lmk, self.w_reg, self.w_photo,
+                                        _p(acc[7:10]), _p(acc[20:24]), _p(acc[12:16]), self.w_lmk, self.w_reg, self.w_photo,
                                         _p(self.log), _p(self.d_sum), _p(self.gmax_bound), _p(self.photo_work),
                                         _p(self.aa_work) if self.aa_early_bwd else 0, _p(self.d_delta) if self.aa_early_bwd else 0, PRE, st),
                  "vhap_photo_fwd_total")
@@ -552,7 +573,7 @@ class NativeStep:
             return
         _chk(L.vhap_photo_fwd(_p(self.rgba_aa), _p(self.rgb), B, H, W, _p(acc[16:18]), PRE, st), "vhap_photo_fwd")
         self._join()
-        _chk(L.vhap_energy_finalize(_p(acc[0:6]), _p(acc[6:7]) if self.w_lmk else 0, _p(acc[7:9]), _p(acc[20:24]),
+        _chk(L.vhap_energy_finalize(_p(acc[0:6]), _p(acc[6:7]) if self.w_lmk else 0, _p(acc[7:10]), _p(acc[20:24]),
                                     _p(acc[12:16]) if self.want_reg else 0, self.w_lmk, self.w_reg, B, H, W, _p(self.log), st),
              "vhap_energy_finalize")
 
@@ -599,9 +620,17 @@ class NativeStep:
         afterwards).  -> True when the update was applied."""
         L, tr, T, g = self.L, self.tr, self.T, self.g
         st = _stream()
+        d_base = _p(self.d_base) if self.pca is not None else 0       # (PCA texture model: d(base texture) comes out of the same pass)
+
+        def pca_bwd():
+            if self.pca is not None:
+                _chk(L.vhap_tex_pca_bwd(_p(self.pca_basis), _p(self.pca_src), _p(self.d_base), _p(tr.tex_pca), int(tr.tex_pca.shape[0]),
+                                        self.pca.src_size, T, self.pca_scale, _p(self.ones), _p(self.pca_work), _p(g["tex_pca"]), _stream()),
+                     "vhap_tex_pca_bwd")
         if not self.photometric:                                      # only the TV / residual gradients (a landmark stage that trains the texture)
-            _chk(L.vhap_tex_prep_bwd(_p(self.albedo_tex), _p(tr.tex_extra), _p(self.nm["res_mask"]), 0, 0, 0, _p(self.ones), T, *self.tex_scales,
-                                     _p(g["tex_extra"]), st), "vhap_tex_prep_bwd")
+            _chk(L.vhap_tex_prep_bwd_base(_p(self.albedo_tex), _p(tr.tex_extra), _p(self.nm["res_mask"]), 0, 0, 0, _p(self.ones), T, *self.tex_scales,
+                                          _p(g["tex_extra"]), d_base, st), "vhap_tex_prep_bwd")
+            pca_bwd()
             return False
         n0 = self.albedo_tex.numel()
         d_tex, d_mips = g["d_tex"][:n0], g["d_tex"][n0:]
@@ -613,13 +642,15 @@ class NativeStep:
         if fu is not None:
             m, v, lr, step, b1, b2, eps = fu
             flags = _lib.CALL_ADAM_STEP_ADVANCED if self.step_optimizer is not None else 0
-            _chk(L.vhap_tex_prep_bwd_adam(_p(self.albedo_tex), _p(tr.tex_extra), _p(self.nm["res_mask"]), _p(d_tex),
-                                          _p(d_mips) if has_mips else 0, ng, _p(self.ones), T, *self.tex_scales, _p(g["tex_extra"]), _p(m), _p(v),
-                                          _p(lr), _p(step), b1, b2, eps, flags, st), "vhap_tex_prep_bwd_adam")
+            _chk(L.vhap_tex_prep_bwd_adam_base(_p(self.albedo_tex), _p(tr.tex_extra), _p(self.nm["res_mask"]), _p(d_tex),
+                                               _p(d_mips) if has_mips else 0, ng, _p(self.ones), T, *self.tex_scales, _p(g["tex_extra"]), _p(m), _p(v),
+                                               _p(lr), _p(step), b1, b2, eps, d_base, flags, st), "vhap_tex_prep_bwd_adam")
+            pca_bwd()
             return True
-        _chk(L.vhap_tex_prep_bwd(_p(self.albedo_tex), _p(tr.tex_extra), _p(self.nm["res_mask"]), _p(d_tex),
-                                 _p(d_mips) if has_mips else 0, ng, _p(self.ones), T, *self.tex_scales, _p(g["tex_extra"]), st),
+        _chk(L.vhap_tex_prep_bwd_base(_p(self.albedo_tex), _p(tr.tex_extra), _p(self.nm["res_mask"]), _p(d_tex),
+                                      _p(d_mips) if has_mips else 0, ng, _p(self.ones), T, *self.tex_scales, _p(g["tex_extra"]), d_base, st),
              "vhap_tex_prep_bwd")
+        pca_bwd()
         return False
 
     def tex_fold(self):
@@ -627,8 +658,8 @@ class NativeStep:
         if not (self.tex_bwd_on and self.photometric and self.mips.numel() > 0):
             return
         n0 = self.albedo_tex.numel()
-        _chk(self.L.vhap_texture_mip_fold(_p(self.g["d_tex"][:n0]), _p(self.g["d_tex"][n0:]), 1, self.T, self.T, 3, 0, _stream()),
-             "vhap_texture_mip_fold")
+        _chk(self.L.vhap_texture_mip_fold_gather(_p(self.g["d_tex"][:n0]), _p(self.g["d_tex"][n0:]), self.T, self.T, 3, _stream()),
+             "vhap_texture_mip_fold_gather")
 
     def tex_finish_rows(self, optimizer, d_strip, row0, nrows):
         """tex_finish() + Adam on the row strip [row0, row0 + nrows) of the texture from `d_strip` [nrows, T, 3], this rank's slice of the
@@ -849,6 +880,10 @@ class NativeStep:
                 done = self._tex_backward(optimizer)
                 if optimizer is not None and self.tex_bwd_on and not done:
                     optimizer.step(only=(self.tr.tex_extra,), advance=False, advanced=self.step_optimizer is not None)
+                if self.step_optimizer is not None and self.pca is not None and self.tex_bwd_on:
+                    # the PCA code's gradient is the LAST thing the texture chain produces (vhap_tex_pca_bwd): its update belongs here,
+                    # not into the launch stream's Adam call, which runs long before
+                    self.step_optimizer.step(only=(self.tr.tex_pca,), advanced=True)
             self._side(tex_chain)
             self._side(self._bwd_pixel_finish, self.side2)            # (nothing downstream reads these two: beside the geometry chain, not ahead of it)
             self._bwd_uv()
@@ -856,7 +891,8 @@ class NativeStep:
             if self.overlap:
                 torch.cuda.current_stream().wait_stream(self.side2)
             if self.step_optimizer is not None:                       # every other parameter: next to the tail of the texture branch
-                self.step_optimizer.step(skip=(self.tr.tex_extra,), advanced=True)
+                late = (self.tr.tex_extra, self.tr.tex_pca) if (self.pca is not None and self.tex_bwd_on) else (self.tr.tex_extra,)
+                self.step_optimizer.step(skip=late, advanced=True)
             self._join()
         elif part == "pixel_tex":
             self._bwd_pixel(world_size)

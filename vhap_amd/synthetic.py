@@ -111,6 +111,22 @@ def make_texture(seed=0, size=2048):
     return np.clip(base + 0.35 * (n - 0.5), 0, 1).astype(np.float32)
 
 
+def make_tex_space(seed=0, S=512, n=200):
+    """Procedural stand-in for FLAME_texture.npz (flame.py:665-680): `mean` [S,S,3] and `tex_dir` [S,S,3,n] in 0..255 units, channels
+    B G R -- a skin-coloured mean and smooth basis images of decaying amplitude; the mean is pushed outside 0..255 in two corners so that
+    the model's clamp is exercised."""
+    rng = np.random.default_rng(seed + 3000)
+    mean = (np.array([132.0, 153.0, 199.0], np.float32)[None, None, :] +
+            60.0 * (smooth_noise(rng, (3, S, S), octaves=4).transpose(1, 2, 0) - 0.5)).astype(np.float32)
+    mean[: S // 16, : S // 16] += 150.0
+    mean[-S // 16:, -S // 16:] -= 220.0
+    tex_dir = np.empty((S, S, 3, n), np.float32)
+    for k in range(n):
+        lo = smooth_noise(rng, (3, S // 8, S // 8), octaves=3).transpose(1, 2, 0) - 0.5
+        tex_dir[..., k] = np.kron(lo, np.ones((8, 8, 1), np.float32))[:S, :S] * (40.0 / (1.0 + 0.05 * k))
+    return {"mean": mean, "tex_dir": tex_dir}
+
+
 def make_scene_params(n_frames, seed=0, image_size=(512, 512), translation_z=0.45, n_shape=N_SHAPE, n_expr=N_EXPR):
     """Ground-truth per-frame FLAME parameters of a synthetic monocular video."""
     rng = np.random.default_rng(seed + 2000)

@@ -23,7 +23,7 @@ from .config import BaseTrackingConfig, PhotometricStageConfig
 from . import _lib
 from . import fused as FU
 from . import native as NV
-from .flame import FlameHead, FlameTexPainted, FlameUvMask
+from .flame import FlameHead, FlameTexPainted, FlameTexPCA, FlameUvMask
 from .lbs import batch_rodrigues
 from .render_hip import HipDiffRenderer
 
@@ -38,7 +38,14 @@ class FlameTracker:
         self.cfg = cfg
         self.device = cfg.device
         self.flame = FlameHead(flame_model, topo, cfg.model.n_shape, cfg.model.n_expr).to(self.device)
-        self.flame_tex_painted = FlameTexPainted(base_texture).to(self.device)
+        # tracker.py:57-60: the painted base texture, or (tex_painted = False) the FLAME PCA texture space -- `base_texture` is then the
+        # texture space: a path to FLAME_texture.npz or a mapping with `mean` / `tex_dir`
+        self.flame_tex_pca = None
+        if cfg.model.tex_painted:
+            self.flame_tex_painted = FlameTexPainted(base_texture).to(self.device)
+        else:
+            self.flame_tex_pca = FlameTexPCA(cfg.model.n_tex, tex_size=cfg.model.tex_resolution, tex_space=base_texture).to(self.device)
+            self.flame_tex_painted = lambda: self.flame_tex_pca(self.tex_pca[None, :]).detach()     # (read-only views of the current base texture)
         self.flame_uvmask = FlameUvMask(topo).to(self.device)
         if cfg.render.backend != "hip":
             raise NotImplementedError(f"Unknown renderer backend: {cfg.render.backend}")
@@ -123,6 +130,8 @@ class FlameTracker:
     def get_base_texture(self):
         if self.cfg.model.tex_extra and not self.cfg.model.residual_tex:
             return self.tex_extra[None, ...]
+        if self.flame_tex_pca is not None:                        # tracker.py:243-244
+            return self.flame_tex_pca(self.tex_pca[None, :])
         return self.flame_tex_painted()
 
     def get_albedo(self):
@@ -229,6 +238,8 @@ class FlameTracker:
                 log["smooth_expr"] = self.compute_expr_smooth_energy(timesteps)
         if self.opt_dict["shape"]:
             log["reg_shape"] = w.reg_shape * (self.shape ** 2).mean()
+        if self.opt_dict["texture"] and self.flame_tex_pca is not None:        # tracker.py:519-521 (std_tex = 1)
+            log["reg_tex_pca"] = w.reg_tex_pca * (self.tex_pca ** 2).mean()
         if self.opt_dict["texture"] and self.cfg.model.tex_extra and self.cfg.model.residual_tex:
             if w.reg_tex_tv is not None:
                 tex = self.get_albedo()[0]
@@ -381,10 +392,12 @@ class FlameTracker:
         return E_total, log_dict, verts, faces, lmks, albedos, result_dict
 
     # ---- native step: the whole energy through fused HIP stages (vhap_amd.native / fused / ops) ----
-    def _native_ok(self, stage, dynamic_offset_ok=False):
-        """`dynamic_offset_ok`: the caller handles per-frame vertex offsets (vhap_amd/step.py::NativeStep does; the autograd formulation
-        over the fused stages, _compute_energy_native, does not -- `use_dynamic_offset` then takes the host formulation)"""
+    def _native_ok(self, stage, dynamic_offset_ok=False, tex_pca_ok=False):
+        """`dynamic_offset_ok` / `tex_pca_ok`: the caller handles per-frame vertex offsets / the PCA texture model (vhap_amd/step.py::NativeStep
+        does; the autograd formulation over the fused stages, _compute_energy_native, does not -- those configurations then take the host
+        formulation)"""
         return (self.fused and self.native and stage is not None and str(self.device).startswith("cuda") and
+                (tex_pca_ok or self.flame_tex_pca is None) and
                 (dynamic_offset_ok or not self.cfg.model.use_dynamic_offset) and self.render.lighting_type == "SH" and
                 self.render.lighting_space == "world" and len(self.flame._parents) == 5 and
                 self.cfg.model.tex_extra and self.cfg.model.residual_tex)
@@ -591,6 +604,8 @@ class GlobalTracker(FlameTracker):
         self.translation, self.rotation = z(N, 3), z(N, 3)
         self.tex_pca = z(m.n_tex)
         train = [self.shape, self.translation, self.rotation, self.neck_pose, self.jaw_pose, self.eyes_pose, self.expr]
+        if not m.tex_painted:                                     # tracker.py:1312-1313
+            train.append(self.tex_pca)
         self.tex_extra = None
         if m.tex_extra:
             self.tex_extra = z(3, m.tex_resolution, m.tex_resolution)
@@ -629,6 +644,8 @@ class GlobalTracker(FlameTracker):
             params["cam"] = [self.focal_length]
         if o["shape"]:
             params["shape"] = [self.shape]
+        if o["texture"] and not m.tex_painted:                    # tracker.py:1485-1487
+            params["tex"] = [self.tex_pca]
         if o["texture"] and m.tex_extra:
             params["tex_extra"] = [self.tex_extra]
         if o["static_offset"] and m.use_static_offset:
@@ -890,6 +907,8 @@ class GlobalTracker(FlameTracker):
         }
         if not self.calibrated:
             out["focal_length"] = c(self.focal_length)
+        if not self.cfg.model.tex_painted:                        # tracker.py:1184-1186
+            out["tex"] = c(self.tex_pca)
         if self.cfg.model.tex_extra:
             out["tex_extra"] = c(self.tex_extra)
         if self.lights is not None:
@@ -924,6 +943,8 @@ class GlobalTracker(FlameTracker):
             load_param(self.lights, report["lights"])
         if not self.calibrated:
             load_param(self.focal_length, report["focal_length"])
+        if not self.cfg.model.tex_painted and "tex" in report:    # tracker.py:107-109
+            load_param(self.tex_pca, report["tex"])
         if self.cfg.model.tex_extra and "tex_extra" in report:
             load_param(self.tex_extra, report["tex_extra"])
         if self.cfg.model.use_static_offset and "static_offset" in report:
@@ -1292,7 +1313,7 @@ class GraphedStep:
                 # Same bytes on the wire as the all-reduce it replaces (a ring all-reduce IS this reduce-scatter + all-gather).
                 T = int(tracker.tex_extra.shape[-1]) if tracker.tex_extra is not None else 0
                 tex = tracker.tex_extra
-                self.tex_sharded = bool(ns.tex_bwd_on and tex is not None and any(p is tex for p in self.params) and T % (16 * world) == 0 and
+                self.tex_sharded = bool(ns.tex_bwd_on and ns.pca is None and tex is not None and any(p is tex for p in self.params) and T % (16 * world) == 0 and
                                         isinstance(optimizer, NV.HipAdam) and os.environ.get("VHAP_TEX_SHARDED", "1") != "0")
                 if self.tex_sharded:
                     ns.split_tex = True
