@@ -680,6 +680,15 @@ int vhap_focal_bwd(const float* d_K, int B, float scale, float* d_focal_accum, v
 enum { VHAP_BG_NONE = 0, VHAP_BG_WHITE = 1, VHAP_BG_BLACK = 2 };
 int vhap_frame_ingest(const unsigned char* rgb_u8, const unsigned char* alpha_u8, const long long* index, int N, int B, int H, int W,
                       int bg_mode, float* rgb_out, float* alpha_out, int* bad_index, vhap_stream_t stream);
+/* Batch feed (the per-step hand-over of a stage loop, tracker.py:1376-1385, as a node of the captured step): batch number cursor[0] of a
+ * table uploaded once per pass -- frame_table / ts_table [capacity, n] int64: frame index and timestep of every frame of every batch, in the
+ * order the batches are taken -- is gathered into the step's static buffers frame_out / ts_out [n] and, for up to three per-frame row arrays
+ * rowsK [N, widthK] (landmarks, intrinsics, extrinsics; NULL = unused), outK [n, widthK]; then cursor[0] += 1 (a second tiny launch).
+ * cursor [2] int32: next batch, number of batches in the table (past the end the last batch is taken again).
+ * vhap_frame_ingest(index = frame_out) follows as an ordinary node.  The host resets the cursor when it uploads a new table. */
+int vhap_batch_feed(const long long* frame_table, const long long* ts_table, int* cursor, int n, int capacity, int N,
+                    const float* rows0, float* out0, int width0, const float* rows1, float* out1, int width1,
+                    const float* rows2, float* out2, int width2, long long* frame_out, long long* ts_out, vhap_stream_t stream);
 
 /* ---- Step plans: the library's own executor for a captured step (vhap/model/tracker.py:1391-1416 runs the same
  * optimize_iter 50-500 times per stage) -------------------------------------------------------------------------------------------

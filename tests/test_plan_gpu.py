@@ -148,8 +148,9 @@ def test_stage_loop_with_a_new_batch_every_step_deferred_vs_joined(flame_model, 
     keep_epochs = cfg.pipeline[stage].num_epochs
     cfg.pipeline[stage].num_epochs = epochs
 
-    def run(defer):
+    def run(defer, feed=True):
         monkeypatch.setenv("VHAP_DEFER_JOIN", "1" if defer else "0")
+        monkeypatch.setenv("VHAP_STEP_FEED", "1" if feed else "0")
         data = {"frames": FrameStore(u8, device="cuda"), "lmk2d": tr0.dataset["lmk2d"].clone()}
         tr = GlobalTracker(cfg, S["model"], S["topo"], tr0.flame_tex_painted()[0].cpu().numpy(), data)
         with torch.no_grad():
@@ -160,12 +161,13 @@ def test_stage_loop_with_a_new_batch_every_step_deferred_vs_joined(flame_model, 
         tr.optimize_stage(stage, dataloader=loader, lr_scale=0.1)
         torch.cuda.synchronize()
         st = next(iter(tr._graphed.values()))
-        assert st.single and st.gF.plan is not None and st.defer_join == defer, (st.defer_join, defer)
+        assert st.single and st.gF.plan is not None and st.defer_join == defer, (st.defer_join, defer, st.defer_report)
+        assert (st.feed is not None) == feed                         # the captured step gathers its own batches (vhap_batch_feed) / is fed by the host
         assert tr.global_step == epochs * (N // B)
         return {k: getattr(tr, k).detach().cpu().numpy().copy() for k in names}
 
     try:
-        P_j, P_d, P_j2 = run(False), run(True), run(False)
+        P_j, P_d, P_j2, P_h = run(False), run(True), run(False), run(True, feed=False)
     finally:
         cfg.pipeline[stage].num_epochs = keep_epochs
     s0 = {k: v.cpu().numpy() for k, v in start.items()}
@@ -174,8 +176,11 @@ def test_stage_loop_with_a_new_batch_every_step_deferred_vs_joined(flame_model, 
         if float(np.abs(P_j[k] - s0[k]).max()) == 0:
             continue
         d, floor = _update_rel(P_d[k], P_j[k], s0[k]), _update_rel(P_j2[k], P_j[k], s0[k])
-        lines.append(f"{k}: deferred vs joined {d:.2e}   joined vs joined {floor:.2e}")
+        h = _update_rel(P_h[k], P_j[k], s0[k])                  # fed by the host between replays instead of by the step's own feed node
+        lines.append(f"{k}: deferred vs joined {d:.2e}   joined vs joined {floor:.2e}   host-fed (deferred) vs joined {h:.2e}")
         if d > max(10 * floor, 2e-3):
             fails.append(f"{k}: {d:.2e} (floor {floor:.2e})")
+        if h > max(10 * floor, 2e-3):
+            fails.append(f"{k}: host-fed {h:.2e} (floor {floor:.2e})")
     _record("plan_deferred_join_stage_loop.txt", lines + fails)
     assert not fails, fails

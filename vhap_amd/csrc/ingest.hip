@@ -112,3 +112,62 @@ extern "C" int vhap_frame_ingest(const unsigned char* rgb_u8, const unsigned cha
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;
 }
+
+
+// ---- batch feed: the per-step hand-over of a stage loop as a NODE of the captured step ----
+// A stage replays one captured step hundreds of times, each time on another batch of the resident sequence (tracker.py:1376-1385).  The
+// host used to enqueue, between two replays, the frame ingest and the copies of the batch's timesteps / landmarks / cameras into the
+// step's static buffers: four small launches on the launch stream, in front of the step's first kernel.  Here the whole table of a pass
+// -- frame index and timestep of every frame of every batch, in the order the batches will be taken -- is uploaded once, and the step
+// itself begins with this gather: batch number cursor[0] of the table -> the static index / timestep buffers (+ up to three per-frame
+// row arrays: landmarks, intrinsics, extrinsics), then the cursor is advanced.  The frame ingest (vhap_frame_ingest on the index buffer)
+// is an ordinary node of the step after it.  One replay = one step on the next batch, nothing else to enqueue.
+namespace {
+
+struct FeedRows {
+    const float* src[3];     // [N, width] per-frame rows (null: unused)
+    float* dst[3];           // [n, width]
+    int width[3];
+};
+
+__global__ __launch_bounds__(128) void batch_feed_kernel(const long long* __restrict__ frame_table, const long long* __restrict__ ts_table,
+                                                         const int* __restrict__ cursor, int n, int capacity, long long* __restrict__ frame_out,
+                                                         long long* __restrict__ ts_out, const FeedRows R, int N) {
+    const int i = blockIdx.x;
+    // cursor[0] = next batch, cursor[1] = batches in the table: past its end the LAST batch is taken again (a table of one batch = the same
+    // batch for every replay: the sequential-tracking pattern)
+    const int c = min(max(cursor[0], 0), min(max(cursor[1], 1), capacity) - 1);
+    long long f = frame_table[(size_t)c * n + i];
+    if (threadIdx.x == 0) {
+        frame_out[i] = f;
+        ts_out[i] = ts_table[(size_t)c * n + i];
+    }
+    if (f < 0) f += N;
+    f = f < 0 ? 0 : (f >= N ? N - 1 : f);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        if (!R.src[k]) continue;
+        const float* s = R.src[k] + (size_t)f * R.width[k];
+        float* d = R.dst[k] + (size_t)i * R.width[k];
+        for (int j = threadIdx.x; j < R.width[k]; j += 128) d[j] = s[j];
+    }
+}
+__global__ void batch_feed_advance_kernel(int* cursor) { cursor[0] += 1; }
+
+}  // namespace
+
+extern "C" int vhap_batch_feed(const long long* frame_table, const long long* ts_table, int* cursor, int n, int capacity, int N,
+                               const float* rows0, float* out0, int width0, const float* rows1, float* out1, int width1,
+                               const float* rows2, float* out2, int width2, long long* frame_out, long long* ts_out, vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!frame_table || !ts_table || !cursor || !frame_out || !ts_out) return VHAP_E_NULLPTR;
+    if (n <= 0 || n > 65535 || capacity <= 0 || N <= 0 || width0 < 0 || width1 < 0 || width2 < 0) return VHAP_E_BADDIM;
+    if ((rows0 && !out0) || (rows1 && !out1) || (rows2 && !out2)) return VHAP_E_NULLPTR;
+    FeedRows R{{rows0, rows1, rows2}, {out0, out1, out2}, {width0, width1, width2}};
+    hipStream_t st = vhap_stream(stream);
+    batch_feed_kernel<<<n, 128, 0, st>>>(frame_table, ts_table, cursor, n, capacity, frame_out, ts_out, R, N);
+    VHAP_LAUNCH_CHECK();
+    batch_feed_advance_kernel<<<1, 1, 0, st>>>(cursor);
+    VHAP_LAUNCH_CHECK();
+    return VHAP_OK;
+}

@@ -272,6 +272,7 @@ class NativeStep:
         self.step_optimizer = None    # a HipAdam whose WHOLE update is issued inside forward()/backward() (GraphedStep, one GPU): counter advanced
                                       # at the head of the step, texture update behind its gradient, the rest before the final join
         self.split_tex = False        # True: stop at the gradient pyramid, the caller runs tex_finish() later (pyramid-level exchange under sharding)
+        self.feed = None              # dict set by GraphedStep.enable_feed(): the step begins by gathering its batch from an uploaded table (vhap_batch_feed)
         # streams of the library's own (never torch's pool: see _lib.private_stream), shared by every step of this thread
         self.side = _lib.private_stream("side", dev)
         self.side2 = _lib.private_stream("side2", dev)
@@ -309,6 +310,26 @@ class NativeStep:
             with torch.cuda.stream(stream):
                 fn()
         self._pending = []
+
+    def _feed_batch(self):
+        """The step's own batch hand-over (vhap_batch_feed): the next batch of the uploaded table -> timesteps, frame indices, landmarks
+        (+ per-view cameras) in the static buffers the kernels read; the frame ingest follows on the texture branch (its output, the target
+        image, is first read by the rasteriser, which waits for that branch)."""
+        f, L, tr = self.feed, self.L, self.tr
+        rows = [(tr.dataset["lmk2d"], self.lmk2d)]
+        if self.calibrated:
+            rows += [(tr.dataset["intrinsic"], self.K_in), (tr.dataset["extrinsic"], self.RT_in)]
+        args = []
+        for src, dst in rows:
+            assert src.is_contiguous() and dst.is_contiguous() and src.dtype == dst.dtype == torch.float32
+            args += [_p(src), _p(dst), int(src[0].numel())]
+        args += [0, 0, 0] * (3 - len(rows))
+        _chk(L.vhap_batch_feed(_p(f["frames"]), _p(f["ts"]), _p(f["cursor"]), self.B, f["capacity"], int(tr.dataset["lmk2d"].shape[0]), *args,
+                               _p(f["frame_index"]), _p(self.ts), _stream()), "vhap_batch_feed")
+
+        def ingest():
+            tr.frames.batch(f["frame_index"], out=self.rgb)
+        self._side(ingest)
 
     def _tex_forward(self, ready=None):
         """texture assembly + pyramid + the offset regularisers: independent of the geometry chain until the texture is sampled.
@@ -380,6 +401,8 @@ class NativeStep:
         self._acc_clean = False
         if self._delta_dirty:                                         # (eager use only: a forward whose backward never came left its antialias
             self._clear_delta()                                       # colour gradients in d_delta; its pair list is still intact here)
+        if self.feed is not None:
+            self._feed_batch()
         so = tr.static_offset
         if self.dyn:                                              # one offset row per frame: static_offset + dynamic_offset[timesteps]
             torch.index_select(tr.dynamic_offset.detach(), 0, self.ts, out=self.off_b)

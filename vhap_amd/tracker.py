@@ -743,8 +743,9 @@ class GlobalTracker(FlameTracker):
                         self.evaluate()
             return optimizer
 
-        def step_for(smp, opt=None):
-            """the captured step for this batch shape; `opt`: share this optimiser (a ragged last batch of the same stage call)"""
+        def step_for(smp, opt=None, feed=False):
+            """the captured step for this batch shape; `opt`: share this optimiser (a ragged last batch of the same stage call); `feed`: a
+            step that gathers its own batches from an uploaded table (dataloader stages over a resident FrameStore)"""
             if not torch.is_tensor(smp["timestep_index"]):
                 smp = dict(smp, timestep_index=torch.as_tensor(np.asarray(smp["timestep_index"]), device=self.device))
             key = (stage, tuple(smp["rgb"].shape), float(lr_scale))
@@ -755,7 +756,7 @@ class GlobalTracker(FlameTracker):
                 params = self.get_train_parameters(stage)
                 if opt is None:
                     opt = self.configure_optimizer(params, lr_scale=lr_scale)
-                st = self._graphed[key] = GraphedStep(self, smp, opt, stage, warmup=0)
+                st = self._graphed[key] = GraphedStep(self, smp, opt, stage, warmup=0, feed=feed)
                 st.fresh = True
             else:
                 self.get_train_parameters(stage)
@@ -805,28 +806,45 @@ class GlobalTracker(FlameTracker):
             if ahead and plan:
                 fidx_dev, tsf_dev = upload([b for ep in plan for b in ep])
             ctx, cur_st, o = None, None, 0
+            fed = {}                      # self-feeding steps (GraphedStep.feed) -> batches left in the table they were last given
 
             def leave():
                 nonlocal ctx, cur_st
                 if ctx is not None:
                     ctx.__exit__(None, None, None)
                 ctx, cur_st = None, None
+
+            def table_for(st, batches_left, o0):
+                """the batches of shape st.feed['n'] among `batches_left` (in order) as one table: device slices of the upload"""
+                n, parts_f, parts_t, oo = st.feed["n"], [], [], o0
+                for _, fidx, _ in batches_left:
+                    if len(fidx) == n:
+                        parts_f.append(fidx_dev[oo:oo + n])
+                        parts_t.append(tsf_dev[oo:oo + n])
+                    oo += len(fidx)
+                    if len(parts_f) == st.feed["capacity"]:
+                        break
+                st.feed_upload(torch.cat(parts_f), torch.cat(parts_t))
+                return len(parts_f)
             try:
                 for epoch_i in range(n_epochs):
                     if ahead:
                         batches = plan[epoch_i]
+                        rest = [b for ep in plan[epoch_i:] for b in ep]
                     else:
                         batches = draw_epoch()
                         leave()
                         fidx_dev, tsf_dev = upload(batches)
                         o = 0
-                    for ts, fidx, _ in batches:
+                        rest = list(batches)
+                        fed = {}
+                    for bi, (ts, fidx, _) in enumerate(batches):
                         n = len(fidx)
                         st = self._graphed.get((stage, (n, 3, H, W), float(lr_scale)))
                         fresh = st is None or (opt is not None and st.opt is not opt)
                         if fresh:
                             leave()
-                            st = step_for(self.get_sample(ts, device_index=True), opt)
+                            st = step_for(self.get_sample(ts, device_index=True), opt, feed=True)
                         if opt is None:
                             opt = st.opt
                             if not getattr(st, "fresh", False):
@@ -840,8 +858,12 @@ class GlobalTracker(FlameTracker):
                             ctx = st.replay_stream()
                             ctx.__enter__()
                             cur_st = st
-                        if not fresh:
-                            self.get_train_parameters(stage)
+                        self.get_train_parameters(stage)
+                        if st.feed is not None:
+                            if not fed.get(st):                    # ONE table per (upload, step): every later batch of this shape, in order
+                                fed[st] = table_for(st, rest[bi:], o)       # (at most GraphedStep.FEED_CAPACITY batches: then the next table)
+                            fed[st] -= 1
+                        elif not fresh:
                             st.update_timesteps(ts, fidx_dev[o:o + n], tsf_dev[o:o + n])
                         o += n
                         st()
@@ -994,6 +1016,13 @@ class GlobalTracker(FlameTracker):
         photo = (photo_s / photo_n.clamp_min(1)).cpu().numpy() if w.photo is not None else photo_s.cpu().numpy()
         lmk = (lmk_s / lmk_n.clamp_min(1)).cpu().numpy()
         return {"photo": photo, "lmk": lmk, "mean_photo": float(photo.mean()), "mean_lmk": float(lmk.mean())}
+
+
+def _set_ints(dst, values):
+    """dst (int32 device tensor) = values, as one tiny launch carrying them in its arguments (no blocking copy: vhap_set_floats on the bits)"""
+    bits = np.asarray(values, np.int32).view(np.float32)
+    _lib.check(_lib.lib().vhap_set_floats(dst.data_ptr(), (ctypes.c_float * len(bits))(*bits.tolist()), len(bits),
+                                          torch.cuda.current_stream().cuda_stream), "vhap_set_floats")
 
 
 def _reset_optimizer(opt):
@@ -1211,8 +1240,11 @@ class GraphedStep:
     TEX_TAIL = ("vhap_zero_words_kernel", "texbin_pass_kernel", "texbin_scan_kernel", "texgrad_tile_kernel", "tex_prep_bwd_kernel")
     GEOMETRY_HEAD = ("camera_fwd_kernel", "frame_prep_fwd_kernel", "flame_skin_fwd_kernel", "flame_skin_clip_fwd_kernel", "bin_build_kernel")
 
-    def __init__(self, tracker, sample, optimizer, stage, warmup=2, unroll=1):
+    def __init__(self, tracker, sample, optimizer, stage, warmup=2, unroll=1, feed=False):
+        """`feed`: (dataloader stages over a resident FrameStore) let the captured step gather its own batch from an uploaded table --
+        feed_upload() -- instead of being fed by the host between replays; see _enable_feed."""
         assert tracker.fused, "graph capture needs the fused (sync-free) path"
+        self.feed, self._want_feed = None, bool(feed)
         self.defer_join, self._in_loop = False, False
         self.tr, self.opt, self.stage = tracker, optimizer, stage
         dev = tracker.device
@@ -1284,6 +1316,7 @@ class GraphedStep:
                     ns.one_graph = True
                     ns.accF.zero_()
                     ns._acc_clean = True
+                self._enable_feed()
                 self._access = _lib.AccessLog()
                 with self._access, self.gF.capture(**cap):
                     for _ in range(self.unroll):
@@ -1347,6 +1380,8 @@ class GraphedStep:
             self.defer_join, self.defer_report = False, ["deferred join not considered (sharded step, hipGraph fallback or VHAP_DEFER_JOIN=0)"]
             if self.single and self.gF.plan is not None and os.environ.get("VHAP_DEFER_JOIN", "1") != "0":
                 host_writes = [(t.data_ptr(), t.numel() * t.element_size()) for t in self.sample.values()]
+                if getattr(self, "feed", None) is not None:          # (a table upload between two replays)
+                    host_writes += [(self.feed[k].data_ptr(), self.feed[k].numel() * self.feed[k].element_size()) for k in ("frames", "ts", "cursor")]
                 self.defer_join, self.defer_report = self.gF.deferred_join_hazards(self._access, host_writes)
             self.E = ns.log[15]
             self.log_dict = ns.log_dict()
@@ -1379,6 +1414,53 @@ class GraphedStep:
         finally:
             tracker._split = None
 
+    FEED_CAPACITY = 4096          # batches per uploaded table
+
+    def _enable_feed(self):
+        """Frames resident as uint8 (FrameStore), one GPU, photometric stage with the early texture branch: the captured step feeds itself
+        (NativeStep._feed_batch) from a table of batches uploaded once per pass (feed_upload) -- nothing but the replay is enqueued per step.
+        Off: VHAP_STEP_FEED=0 (the host enqueues ingest + index copies between replays: update_timesteps)."""
+        tr, ns = self.tr, self.ns
+        self.feed = None
+        if not self._want_feed or tr.frames is None or not self.single or ns is None or not (ns.photometric and ns.deferred and ns.overlap) or ns.dyn or \
+                tr.frames.alpha is not None or os.environ.get("VHAP_STEP_FEED", "1") == "0":
+            return
+        dev, n = self.sample["timestep_index"].device, int(self.sample["timestep_index"].shape[0])
+        if not (ns.ts.data_ptr() == self.sample["timestep_index"].data_ptr() and ns.lmk2d.data_ptr() == self.sample["lmk2d"].data_ptr() and
+                ns.rgb.data_ptr() == self.sample["rgb"].data_ptr() and tr.dataset["lmk2d"].is_contiguous() and tr.dataset["lmk2d"].dtype == torch.float32):
+            return                                                  # (the step reads copies, not the static sample buffers)
+        if ns.calibrated and not (ns.K_in.is_contiguous() and ns.RT_in.is_contiguous() and tr.dataset["intrinsic"].is_contiguous() and
+                                  tr.dataset["extrinsic"].is_contiguous() and ns.K_in.dtype == ns.RT_in.dtype == torch.float32 and
+                                  tr.dataset["intrinsic"].dtype == tr.dataset["extrinsic"].dtype == torch.float32):
+            return
+        cap = self.FEED_CAPACITY
+        self.feed = {"frames": torch.zeros(cap * n, dtype=torch.int64, device=dev), "ts": torch.zeros(cap * n, dtype=torch.int64, device=dev),
+                     "cursor": torch.tensor([0, 1], dtype=torch.int32, device=dev), "frame_index": torch.zeros(n, dtype=torch.int64, device=dev),
+                     "capacity": cap, "n": n}
+        # until a table is uploaded: a table of ONE batch, the one the step was built on (taken again by every replay)
+        self.feed["ts"][:n] = self.sample["timestep_index"]
+        self.feed["frames"][:n] = self._frame_index_of(self.sample["timestep_index"])
+        ns.feed = self.feed
+
+    def _frame_index_of(self, timestep_dev):
+        tr = self.tr
+        if tr._frames_of is None:
+            return timestep_dev
+        ts = timestep_dev.cpu().numpy()
+        # multi-view: the frames of a batch are all views of its timesteps in order -- recover them from the distinct timesteps
+        uniq = list(dict.fromkeys(int(t) for t in ts))
+        return torch.as_tensor(np.concatenate([tr._frames_of[t] for t in uniq]), device=timestep_dev.device)
+
+    def feed_upload(self, frame_index_dev, timestep_dev):
+        """The batches this step will take, in order: [m * n] frame indices / timesteps (device tensors).  Resets the cursor."""
+        f = self.feed
+        m = frame_index_dev.numel() // f["n"]
+        if m > f["capacity"] or frame_index_dev.numel() != m * f["n"]:
+            raise ValueError("GraphedStep.feed_upload: table too large or not a whole number of batches")
+        f["frames"][:m * f["n"]].copy_(frame_index_dev)
+        f["ts"][:m * f["n"]].copy_(timestep_dev)
+        _set_ints(f["cursor"], (0, m))
+
     def update_timesteps(self, timesteps, frame_index_dev=None, timestep_dev=None):
         """Feed the batch of these timesteps from the tracker's dataset; with a uint8 FrameStore the frames are converted straight
         into the static rgb buffer (no intermediate fp32 batch).  Multi-view datasets: every view of the timesteps, each frame carrying
@@ -1389,6 +1471,16 @@ class GraphedStep:
         if tr.frames is None:
             return self.update_sample(tr.get_sample(timesteps, device_index=True))
         dev = self.sample["timestep_index"].device
+        if self.feed is not None:                                  # a self-feeding step: a table of this one batch
+            if frame_index_dev is None:
+                timestep_dev = torch.as_tensor(np.asarray(timesteps).reshape(-1), device=dev) if not torch.is_tensor(timesteps) else timesteps
+                if tr._frames_of is not None:
+                    fidx = np.concatenate([tr._frames_of[int(t)] for t in np.asarray(timestep_dev.cpu()).reshape(-1)])
+                    frame_index_dev = torch.as_tensor(fidx, device=dev)
+                    timestep_dev = torch.as_tensor(tr.frame_timestep[fidx], device=dev)
+                else:
+                    frame_index_dev = timestep_dev
+            return self.feed_upload(frame_index_dev, timestep_dev)
         if frame_index_dev is None:
             ts = np.asarray(timesteps).reshape(-1)
             if tr._frames_of is not None:
@@ -1410,6 +1502,8 @@ class GraphedStep:
 
     def update_sample(self, sample):
         """Feed a new batch of the SAME shapes: copied into the static buffers the graphs read."""
+        if self.feed is not None:      # (a self-feeding step re-gathers its batch from the frame store: hand it the timesteps)
+            return self.update_timesteps(sample["timestep_index"])
         for k, dst in self.sample.items():
             src = sample[k]
             if not torch.is_tensor(src):
