@@ -567,6 +567,17 @@ int vhap_offset_reg_bwd(const float* offset, const int32_t* lap_ptr, const int32
                         const int32_t* region_ptr, const int32_t* region_idx, int V, int n_regions,
                         float s_lap, float s_abs, float s_rigid, const float* d_terms, float* d_offset,
                         vhap_stream_t stream);
+/* `use_dynamic_offset` (base.py:69; tracker.py:213-235, 552-600): vhap_offset_combine: off_b [B,V,3] = (static_offset [V,3] | NULL) +
+ * dynamic_offset [N,V,3][timesteps[b]]; vhap_offset_reg_fwd_batch / _bwd_batch: the three terms of vhap_offset_reg_fwd / _bwd for all B
+ * per-frame offsets in one launch (terms accumulated over the frames: the caller's scales carry the 1 / B; d_offset [B,V,3] ACCUMULATED). */
+int vhap_offset_combine(const float* static_offset, const float* dynamic_offset, const int64_t* timesteps, int B, int N, int V, float* out,
+                        vhap_stream_t stream);
+int vhap_offset_reg_fwd_batch(const float* offset, const int32_t* lap_ptr, const int32_t* lap_col, const float* lap_val, const float* w_lap,
+                              const float* w_abs, const int32_t* region_ptr, const int32_t* region_idx, int B, int V, int n_regions, float s_lap,
+                              float s_abs, float s_rigid, float* terms, int call_flags, vhap_stream_t stream);
+int vhap_offset_reg_bwd_batch(const float* offset, const int32_t* lap_ptr, const int32_t* lap_col, const float* lap_val, const float* w_lap,
+                              const float* w_abs, const int32_t* region_ptr, const int32_t* region_idx, int B, int V, int n_regions, float s_lap,
+                              float s_abs, float s_rigid, const float* d_terms, float* d_offset, vhap_stream_t stream);
 int vhap_tex_prep_fwd(const float* painted, const float* extra, const uint8_t* res_mask, int T, float s_tv,
                       float s_res, float* albedo_hwc, float* terms, int call_flags, vhap_stream_t stream);
 /* vhap_tex_prep_fwd that also writes level 1 of the pyramid (mips_hwc: the buffer of vhap_texture_mip_build, whose first (T/2)^2 x 3

@@ -94,6 +94,9 @@ SIGNATURES = {
     "vhap_landmark_bwd": (c_i, [c_fp] * 6 + [c_i] * 8 + [c_f, c_i, c_i] + [c_fp] * 3),
     "vhap_offset_reg_fwd": (c_i, [c_fp] * 8 + [c_i, c_i, c_f, c_f, c_f, c_fp, c_i, c_fp]),
     "vhap_offset_reg_bwd": (c_i, [c_fp] * 8 + [c_i, c_i, c_f, c_f, c_f, c_fp, c_fp, c_fp]),
+    "vhap_offset_combine": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp]),
+    "vhap_offset_reg_fwd_batch": (c_i, [c_fp] * 8 + [c_i, c_i, c_i, c_f, c_f, c_f, c_fp, c_i, c_fp]),
+    "vhap_offset_reg_bwd_batch": (c_i, [c_fp] * 8 + [c_i, c_i, c_i, c_f, c_f, c_f, c_fp, c_fp, c_fp]),
     "vhap_tex_prep_fwd": (c_i, [c_fp] * 3 + [c_i, c_f, c_f] + [c_fp] * 2 + [c_i, c_fp]),
     "vhap_tex_prep_mip1_fwd": (c_i, [c_fp] * 3 + [c_i, c_f, c_f] + [c_fp] * 3 + [c_i, c_fp]),
     "vhap_texture_mip_build_from": (c_i, [c_fp, c_i, c_i, c_i, c_i, c_fp, c_i, c_fp]),

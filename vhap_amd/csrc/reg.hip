@@ -33,9 +33,11 @@ __global__ __launch_bounds__(RB) void offset_reg_kernel(OffCfg c, const float* _
                                                         const float* __restrict__ w_lap, const float* __restrict__ w_abs,
                                                         const int* __restrict__ reg_ptr, const int* __restrict__ reg_idx,
                                                         float* __restrict__ terms, const float* __restrict__ d_terms,
-                                                        float* __restrict__ d_off) {
+                                                        float* __restrict__ d_off, long long frame_stride) {
     __shared__ float red[4];
     const bool bwd = d_terms != nullptr;
+    off += (size_t)blockIdx.y * frame_stride;           // (per-frame offsets, `use_dynamic_offset`: one grid row per frame, shared accumulators)
+    if (d_off) d_off += (size_t)blockIdx.y * frame_stride;
     if ((int)blockIdx.x < c.nbv) {
         const int v = blockIdx.x * RB + threadIdx.x;
         float e_lap = 0.f, e_abs = 0.f;
@@ -468,7 +470,62 @@ extern "C" int vhap_offset_reg_fwd(const float* offset, const int32_t* lap_ptr, 
     VHAP_ZERO_ACC(terms, 3 * sizeof(float), st);
     OffCfg c{V, n_regions, vhap_cdiv(V, RB), s_lap, s_abs, s_rigid};
     offset_reg_kernel<<<c.nbv + n_regions, RB, 0, st>>>(c, offset, lap_ptr, lap_col, lap_val, w_lap, w_abs, region_ptr, region_idx, terms, nullptr,
-                                                      nullptr);
+                                                      nullptr, 0);
+    VHAP_LAUNCH_CHECK();
+    return VHAP_OK;
+}
+
+// The same terms for B per-frame offsets [B,V,3] in ONE launch (`use_dynamic_offset`: static_offset + dynamic_offset[timesteps], tracker.py:552-600;
+// the scales carry the 1 / B of the means over the frames): `terms` accumulates over the frames, d_offset is [B,V,3].
+extern "C" int vhap_offset_reg_fwd_batch(const float* offset, const int32_t* lap_ptr, const int32_t* lap_col, const float* lap_val,
+                                         const float* w_lap, const float* w_abs, const int32_t* region_ptr, const int32_t* region_idx, int B,
+                                         int V, int n_regions, float s_lap, float s_abs, float s_rigid, float* terms, int call_flags,
+                                         vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!offset || !lap_ptr || !lap_col || !lap_val || !terms) return VHAP_E_NULLPTR;
+    if (n_regions > 0 && (!region_ptr || !region_idx)) return VHAP_E_NULLPTR;
+    if (B <= 0 || B > 65535 || V <= 0 || n_regions < 0) return VHAP_E_BADDIM;
+    hipStream_t st = vhap_stream(stream);
+    VHAP_ZERO_ACC(terms, 3 * sizeof(float), st);
+    OffCfg c{V, n_regions, vhap_cdiv(V, RB), s_lap, s_abs, s_rigid};
+    offset_reg_kernel<<<dim3(c.nbv + n_regions, B), RB, 0, st>>>(c, offset, lap_ptr, lap_col, lap_val, w_lap, w_abs, region_ptr, region_idx, terms,
+                                                                nullptr, nullptr, 3ll * V);
+    VHAP_LAUNCH_CHECK();
+    return VHAP_OK;
+}
+
+extern "C" int vhap_offset_reg_bwd_batch(const float* offset, const int32_t* lap_ptr, const int32_t* lap_col, const float* lap_val,
+                                         const float* w_lap, const float* w_abs, const int32_t* region_ptr, const int32_t* region_idx, int B,
+                                         int V, int n_regions, float s_lap, float s_abs, float s_rigid, const float* d_terms, float* d_offset,
+                                         vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!offset || !lap_ptr || !lap_col || !lap_val || !d_terms || !d_offset) return VHAP_E_NULLPTR;
+    if (n_regions > 0 && (!region_ptr || !region_idx)) return VHAP_E_NULLPTR;
+    if (B <= 0 || B > 65535 || V <= 0 || n_regions < 0) return VHAP_E_BADDIM;
+    OffCfg c{V, n_regions, vhap_cdiv(V, RB), s_lap, s_abs, s_rigid};
+    offset_reg_kernel<<<dim3(c.nbv + n_regions, B), RB, 0, vhap_stream(stream)>>>(c, offset, lap_ptr, lap_col, lap_val, w_lap, w_abs, region_ptr,
+                                                                                 region_idx, nullptr, d_terms, d_offset, 3ll * V);
+    VHAP_LAUNCH_CHECK();
+    return VHAP_OK;
+}
+
+// off_b [B,V,3] = (static_offset [V,3] or 0) + dynamic_offset[timesteps[b]] (tracker.py:555-559): the per-frame offset rows of a step in one
+// launch of the library's own (a host framework's index_select + add would be two nodes the deferred-join decision cannot see into)
+static __global__ __launch_bounds__(RB) void offset_combine_kernel(const float* __restrict__ stat, const float* __restrict__ dyn,
+                                                                   const long long* __restrict__ ts, int N, int n3, float* __restrict__ out) {
+    const int i = blockIdx.x * RB + threadIdx.x, b = blockIdx.y;
+    if (i >= n3) return;
+    long long t = ts[b];
+    t = t < 0 ? 0 : (t >= N ? N - 1 : t);
+    out[(size_t)b * n3 + i] = (stat ? stat[i] : 0.f) + dyn[(size_t)t * n3 + i];
+}
+extern "C" int vhap_offset_combine(const float* static_offset, const float* dynamic_offset, const int64_t* timesteps, int B, int N, int V,
+                                   float* out, vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!dynamic_offset || !timesteps || !out) return VHAP_E_NULLPTR;
+    if (B <= 0 || B > 65535 || N <= 0 || V <= 0) return VHAP_E_BADDIM;
+    offset_combine_kernel<<<dim3(vhap_cdiv(3ll * V, RB), B), RB, 0, vhap_stream(stream)>>>(static_offset, dynamic_offset,
+                                                                                          reinterpret_cast<const long long*>(timesteps), N, 3 * V, out);
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;
 }
@@ -483,7 +540,7 @@ extern "C" int vhap_offset_reg_bwd(const float* offset, const int32_t* lap_ptr, 
     if (V <= 0 || n_regions < 0) return VHAP_E_BADDIM;
     OffCfg c{V, n_regions, vhap_cdiv(V, RB), s_lap, s_abs, s_rigid};
     offset_reg_kernel<<<c.nbv + n_regions, RB, 0, vhap_stream(stream)>>>(c, offset, lap_ptr, lap_col, lap_val, w_lap, w_abs, region_ptr, region_idx,
-                                                                         nullptr, d_terms, d_offset);
+                                                                         nullptr, d_terms, d_offset, 0);
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;
 }

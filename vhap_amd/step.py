@@ -355,8 +355,12 @@ class NativeStep:
             om = self.om
             # the regularised offset (tracker.py:552-559): static_offset, or -- dynamic offsets -- one combined row per frame (means over the frames
             # too: the scales carry 1 / B)
-            for off in (self.off_b.unbind(0) if self.dyn else (tr.static_offset,)):
-                _chk(L.vhap_offset_reg_fwd(_p(off), _p(om.ptr), _p(om.col), _p(om.val), _p(om.w_lap), _p(om.w_abs), _p(om.rptr),
+            if self.dyn:                                           # one launch for the B per-frame rows
+                _chk(L.vhap_offset_reg_fwd_batch(_p(self.off_b), _p(om.ptr), _p(om.col), _p(om.val), _p(om.w_lap), _p(om.w_abs), _p(om.rptr),
+                                                 _p(om.ridx), self.B, om.V, om.nreg, *self.off_scales, _p(acc[20:24]), PRE, st),
+                     "vhap_offset_reg_fwd_batch")
+            else:
+                _chk(L.vhap_offset_reg_fwd(_p(tr.static_offset), _p(om.ptr), _p(om.col), _p(om.val), _p(om.w_lap), _p(om.w_abs), _p(om.rptr),
                                            _p(om.ridx), om.V, om.nreg, *self.off_scales, _p(acc[20:24]), PRE, st), "vhap_offset_reg_fwd")
         if self.dyn and self.dyn_scale:
             _chk(L.vhap_offset_dynamic_reg(_p(tr.dynamic_offset), _p(self.ts), self.B, self.N, self.V, self.dyn_scale, 0, _p(acc[23:24]), 0, st),
@@ -405,9 +409,8 @@ class NativeStep:
             self._feed_batch()
         so = tr.static_offset
         if self.dyn:                                              # one offset row per frame: static_offset + dynamic_offset[timesteps]
-            torch.index_select(tr.dynamic_offset.detach(), 0, self.ts, out=self.off_b)
-            if self.has_offset:
-                self.off_b.add_(tr.static_offset.detach())
+            _chk(L.vhap_offset_combine(_p(tr.static_offset) if self.has_offset else 0, _p(tr.dynamic_offset), _p(self.ts), B, self.N, V,
+                                       _p(self.off_b), st), "vhap_offset_combine")
             so = self.off_b
         self._tex_ready = None
         early_tex = self.photometric and self.deferred and self.overlap
@@ -712,10 +715,13 @@ class NativeStep:
         else:
             self.d_mvp.zero_()
         if (self.has_offset or self.dyn) and any(self.off_scales):
-            pairs = zip(self.off_b.unbind(0), g["d_off_b"].view(B, V, 3).unbind(0)) if self.dyn else ((tr.static_offset, g["static_offset"]),)
-            for off, d_off in pairs:
-                _chk(L.vhap_offset_reg_bwd(_p(off), _p(om.ptr), _p(om.col), _p(om.val), _p(om.w_lap), _p(om.w_abs), _p(om.rptr),
-                                           _p(om.ridx), om.V, om.nreg, *self.off_scales, _p(self.ones), _p(d_off), st),
+            if self.dyn:
+                _chk(L.vhap_offset_reg_bwd_batch(_p(self.off_b), _p(om.ptr), _p(om.col), _p(om.val), _p(om.w_lap), _p(om.w_abs), _p(om.rptr),
+                                                 _p(om.ridx), B, om.V, om.nreg, *self.off_scales, _p(self.ones), _p(g["d_off_b"]), st),
+                     "vhap_offset_reg_bwd_batch")
+            else:
+                _chk(L.vhap_offset_reg_bwd(_p(tr.static_offset), _p(om.ptr), _p(om.col), _p(om.val), _p(om.w_lap), _p(om.w_abs), _p(om.rptr),
+                                           _p(om.ridx), om.V, om.nreg, *self.off_scales, _p(self.ones), _p(g["static_offset"]), st),
                      "vhap_offset_reg_bwd")
         if self.dyn and self.dyn_scale:
             _chk(L.vhap_offset_dynamic_reg(_p(tr.dynamic_offset), _p(self.ts), B, self.N, V, self.dyn_scale, _p(self.ones), 0,
