@@ -92,7 +92,14 @@ class NativeStep:
         Bp = self.Bp = (B + 15) // 16 * 16
         o = tr.opt_dict
         f32 = dict(dtype=torch.float32, device=dev)
-        E = lambda *s: torch.empty(*s, **f32)
+        # VHAP_POISON=1 (debugging): every buffer that is allocated uninitialised starts as NaN / 0x7f7f7f7f instead of whatever the allocator
+        # hands out -- a read-before-write shows up at once instead of as a first-run-vs-later-run difference
+        poison = os.environ.get("VHAP_POISON", "0") == "1"
+        E = (lambda *s: torch.full(tuple(int(x) for x in (s[0] if len(s) == 1 and isinstance(s[0], (tuple, list)) else s)), float("nan"), **f32)) if poison \
+            else (lambda *s: torch.empty(*s, **f32))
+        Ei = (lambda n, dt: torch.full((int(n),) if not isinstance(n, tuple) else n, 0x7f, dtype=torch.uint8, device=dev).view(dt) if dt != torch.uint8
+              else torch.full(n if isinstance(n, tuple) else (int(n),), 0x7f, dtype=dt, device=dev)) if poison else \
+            (lambda n, dt: torch.empty(n, dtype=dt, device=dev))
         # ---- static tables ----
         mesh = tr.render._mesh(fl.faces)
         self.tri, self.opp, self.csr = mesh["tri"], mesh["opp"].int().contiguous(), mesh["csr"]
@@ -186,10 +193,11 @@ class NativeStep:
                 self.rgba_aa = E(B, H, W, 4)
             if self.disturb_on:
                 self.keep = E(B, H, W)                               # (the disturbance itself is in place: pools of copies, csrc/disturb.hip)
-                self.dist_ws = torch.empty(L.vhap_disturb_workspace_ints(B, H, W), dtype=torch.int32, device=dev)
-                self.cid = torch.empty(B, H, W, dtype=torch.uint8, device=dev)
-            self.aa_work = torch.empty((L.vhap_antialias_inplace_work_ints if self.aa_inplace else L.vhap_antialias_work_ints)(B, H, W, self.F),
-                                       dtype=torch.int32, device=dev)
+                self.dist_ws = Ei(int(L.vhap_disturb_workspace_ints(B, H, W)) * 4, torch.int32) if poison else \
+                    torch.empty(L.vhap_disturb_workspace_ints(B, H, W), dtype=torch.int32, device=dev)
+                self.cid = Ei((B, H, W), torch.uint8)
+            n_aa = int((L.vhap_antialias_inplace_work_ints if self.aa_inplace else L.vhap_antialias_work_ints)(B, H, W, self.F))
+            self.aa_work = Ei(n_aa * 4, torch.int32) if poison else torch.empty(n_aa, dtype=torch.int32, device=dev)
             self.ws, self.ws_bytes, self.ws_cap, _ = tr.render.glctx.acquire(B, self.F, H, W, self.rgb.device)
             # one-launch binning available (raster.hip: LDS_BIN_LIMIT bins, MAX_FRAG x 1024 triangles): binning and rasterisation can be split
             nfrag = (self.F + 1023) // 1024
@@ -253,7 +261,7 @@ class NativeStep:
             # instead of uv + d_albedo (20 B/px, twice)
             self.tb_ids = self.deferred and self.tex_bwd_on and T <= 2048
             if self.tb_ids:
-                self.tile_ids = torch.empty(B, H, W, dtype=torch.int16, device=dev)
+                self.tile_ids = Ei(B * H * W * 2, torch.int16).view(B, H, W) if poison else torch.empty(B, H, W, dtype=torch.int16, device=dev)
             self.vn_scratch = E(B, V, 3)
             if self.deferred:
                 self.def_work = self.g["def_work"]
