@@ -300,3 +300,32 @@ def test_c_abi_is_reentrant_across_threads(tracker):
         tr.render.disturb_rate_fg, tr.render.disturb_rate_bg = rates
         for p in tr._train_tensors:
             p.grad = None
+
+
+def test_native_step_reads_nothing_before_writing_it(flame_model, monkeypatch):
+    """Every buffer NativeStep allocates uninitialised (torch.empty) is filled with NaN / 0x7f7f7f7f instead (VHAP_POISON=1): energies and
+    gradients of a forward + backward must come out as with ordinary allocations -- a read-before-write would surface as NaN (or as a
+    first-run-vs-later-run difference in a long-lived process, which is how such a bug would otherwise be met)."""
+    from tests.test_fit_parity_gpu import _make
+    from vhap_amd.step import NativeStep
+    stage = "rgb_global_tracking"
+    out = []
+    for poison in ("0", "1"):
+        monkeypatch.setenv("VHAP_POISON", poison)
+        S = _make(flame_model, 128, 128, 3, 256, seed=11)
+        tr = S["tr"]
+        tr.render._rng_state = torch.full((1,), 99, dtype=torch.int32, device="cuda")
+        tr.get_train_parameters(stage)
+        ns = NativeStep(tr, tr.get_sample(np.arange(3), device_index=True), stage)
+        assert ns.disturb_on and ns.deferred
+        for _ in range(2):                                       # twice: the second pass meets whatever the first one left behind
+            ns.forward()
+            ns.backward(1)
+        torch.cuda.synchronize()
+        out.append(({k: float(v) for k, v in ns.log_dict().items()}, {k: ns.g[k].detach().cpu().clone() for k in ("shape", "expr", "lights", "tex_extra", "static_offset")}))
+    (la, ga), (lb, gb) = out
+    for k in la:
+        assert np.isfinite(lb[k]) and abs(la[k] - lb[k]) <= 1e-5 * max(abs(la[k]), 1e-3), (k, la[k], lb[k])
+    for k in ga:
+        assert torch.isfinite(gb[k]).all(), k
+        assert float((ga[k] - gb[k]).abs().max()) <= 1e-3 * float(ga[k].abs().max()) + 1e-12, k
