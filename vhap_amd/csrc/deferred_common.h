@@ -93,33 +93,41 @@ __device__ __forceinline__ DeferredGrad deferred_pixel(const DeferredParams& P, 
     const unsigned HW = (unsigned)P.H * P.W;
     o.i0 = P.tri[3 * t]; o.i1 = P.tri[3 * t + 1]; o.i2 = P.tri[3 * t + 2];
     o.j0 = P.tri_uv[3 * t]; o.j1 = P.tri_uv[3 * t + 1]; o.j2 = P.tri_uv[3 * t + 2];
-    float4 g;
-    if (P.d_rgba) {
-        g = P.d_rgba[pi];
-    } else {                          // d sum|gt - pred| / d pred = -sign(gt - pred) (tracker.py:430-439), scaled by d_sum
-        const float gs = P.d_sum[0];
-        const float* gp = P.gt + (size_t)b * 3 * HW + (size_t)(P.H - 1 - py) * P.W + px;
-        const float4 p = P.pred[pi];
-        auto sg = [](float e) { return e > 0.f ? 1.0f : (e < 0.f ? -1.0f : 0.0f); };
-        g = make_float4(-sg(gp[0] - p.x) * gs, -sg(gp[HW] - p.y) * gs, -sg(gp[2 * HW] - p.z) * gs, 0.0f);
-        if (P.d_delta) {
-            const float4 e = P.d_delta[pi];
-            const float k = P.delta_unscaled ? gs : 1.0f;
-            g.x += k * e.x; g.y += k * e.y; g.z += k * e.z;
-        }
-    }
-    if (P.keep) { const float k = P.keep[pi]; g.x *= k; g.y *= k; g.z *= k; }     // backward of the colour disturbance, folded in
     const float4* PV = P.pos + (size_t)b * P.V;
     o.p0 = PV[o.i0]; o.p1 = PV[o.i1]; o.p2 = PV[o.i2];
     const float fx = __fmaf_rn(P.xs, (float)px, P.xo), fy = __fmaf_rn(P.ys, (float)py, P.yo);
     const Frag fr = shade_frag(o.p0, o.p1, o.p2, fx, fy);
     const float4 o_db = frag_db(o.p0, o.p1, o.p2, fr, P.xs, P.ys);
     const FragAttr at = frag_attr(P.vnormal + (size_t)b * P.V * 3, P.uv, o.i0, o.i1, o.i2, o.j0, o.j1, o.j2, fr, o_db);
-    P.texc[pi] = make_float2(at.tu, at.tv);
-    P.texd[pi] = at.td;
+    // The texture taps and every load that depends on the pixel index alone (the upstream gradient's inputs) are ISSUED together here and
+    // consumed below: behind their own uniform branches the compiler waited for each in turn (pred / gt -> d_delta -> keep -> level
+    // offset -> taps -> level offset -> taps: seven dependent round trips where one does, of the ~11 a covered wave walked through at
+    // 75 % of its cycles in s_waitcnt -- profiles/r04_call22_step_sq_pmc.json).
+    const TexFetch<3> tf = tex_fetch<3>(P.tex, P.mips, P.D, 0, make_float2(at.tu, at.tv), at.td);
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f), pr = g, e = g;
+    float gs = 0.f, gt0 = 0.f, gt1 = 0.f, gt2 = 0.f, kp = 1.0f;
+    const bool fly = P.d_rgba == nullptr;
+    if (fly) {
+        const float* gp = P.gt + (size_t)b * 3 * HW + (size_t)(P.H - 1 - py) * P.W + px;
+        gs = P.d_sum[0];
+        pr = P.pred[pi];
+        gt0 = gp[0]; gt1 = gp[HW]; gt2 = gp[2 * HW];
+        if (P.d_delta) e = P.d_delta[pi];
+    } else {
+        g = P.d_rgba[pi];
+    }
+    if (P.keep) kp = P.keep[pi];
+    P.texc[pi] = make_float2(at.tu, at.tv);      // (stores after the batch of loads: one in-order counter covers both on gfx9, and the
+    P.texd[pi] = at.td;                          //  wait for the loads must not also wait for these)
     SH9 bsh;
     float x, y, z, inv, d[3];
     sh_diffuse(at.n0, at.n1, at.n2, s_c, s_l, bsh, x, y, z, inv, d);
+    if (fly) {                        // d sum|gt - pred| / d pred = -sign(gt - pred) (tracker.py:430-439), scaled by d_sum
+        auto sg = [](float v) { return v > 0.f ? 1.0f : (v < 0.f ? -1.0f : 0.0f); };
+        const float k = P.delta_unscaled ? gs : 1.0f;   // (e = 0 without d_delta)
+        g = make_float4(-sg(gt0 - pr.x) * gs + k * e.x, -sg(gt1 - pr.y) * gs + k * e.y, -sg(gt2 - pr.z) * gs + k * e.z, 0.0f);
+    }
+    g.x *= kp; g.y *= kp; g.z *= kp;                     // backward of the colour disturbance, folded in (kp = 1 without it)
     const float ga[3] = {g.x * d[0], g.y * d[1], g.z * d[2]};                     // d L / d albedo
     float* da = P.d_albedo + 3 * (size_t)pi;
     da[0] = ga[0]; da[1] = ga[1]; da[2] = ga[2];
@@ -127,7 +135,7 @@ __device__ __forceinline__ DeferredGrad deferred_pixel(const DeferredParams& P, 
     tb_tile = ((P.tb_counts || P.tile_ids) && tb_g != 0.f) ? tile_of(make_float2(at.tu, at.tv), P.NT) : -1;   // criterion / tile of texbin_pass_kernel
     if (P.tile_ids) P.tile_ids[pi] = (unsigned short)(tb_tile < 0 ? 0xFFFF : tb_tile);
     float alb[3];
-    tex_sample_bwd_uv<3>(P.tex, P.mips, P.D, 0, make_float2(at.tu, at.tv), at.td, ga, nullptr, nullptr, o.guv, o.gda, true, alb);
+    tex_bwd_uv<3>(tf, P.D, ga, o.guv, o.gda, alb);
     const float gd[3] = {g.x * alb[0], g.y * alb[1], g.z * alb[2]};               // photometric part of d L / d diffuse
     const float l2 = at.n0 * at.n0 + at.n1 * at.n1 + at.n2 * at.n2;
     sh_normal_bwd(x, y, z, inv, !(l2 > 1e-20f), s_c, s_l, gd, o.gn[0], o.gn[1], o.gn[2]);

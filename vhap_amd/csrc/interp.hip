@@ -392,37 +392,61 @@ __global__ __launch_bounds__(GT * GT) void gbuffer_bwd_tiled_kernel(const float4
     int i0 = 0, i1 = 0, i2 = 0;
     bool have = false;
     if (cov) {
+        // A covered wave's life is a chain of dependent gathers (75 % of its cycles at s_waitcnt, profiles/r04_call22_step_sq_pmc.json), so
+        // the loads are ISSUED in two batches -- everything addressed by the pixel or the triangle id, then everything addressed by a
+        // vertex -- and consumed afterwards.  Written in the order of use, each optional input sat behind its own uniform branch and the
+        // compiler waited for them one after the other: nine round trips where three do.
+        const bool want_n = d_normal && vnormal, want_uv = uv && (d_texc || d_texd);
         i0 = tri[3 * t]; i1 = tri[3 * t + 1]; i2 = tri[3 * t + 2];
+        // (an absent optional input is read from a valid stand-in address and discarded by a uniform select: a branch around the load
+        // ends in a join, where the compiler waits for it)
+        const int* a_tuv = want_uv ? tri_uv : tri;
+        const float4* a_rast = d_rast ? d_rast : rast;
+        const float4* a_db = d_db ? d_db : rast;
+        const float* a_n = want_n ? d_normal : reinterpret_cast<const float*>(rast);
+        const float2* a_texc = want_uv && d_texc ? d_texc : reinterpret_cast<const float2*>(rast);
+        const float4* a_texd = want_uv && d_texd ? d_texd : rast;
+        const unsigned char* a_ng = want_uv && d_texc && uv_nograd ? uv_nograd : reinterpret_cast<const unsigned char*>(tri);
+        const int j0 = a_tuv[3 * t], j1 = a_tuv[3 * t + 1], j2 = a_tuv[3 * t + 2];
+        const float4 l_rast = a_rast[pi], l_db = a_db[pi], l_texd = a_texd[pi];
+        const float2 l_texc = a_texc[pi];
+        const float l_n0 = a_n[3 * pi], l_n1 = a_n[3 * pi + 1], l_n2 = a_n[3 * pi + 2];
+        const unsigned char l_ng = a_ng[t];
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 q_rast = d_rast ? l_rast : zero4, q_db = d_db ? l_db : zero4, q_texd = want_uv && d_texd ? l_texd : zero4;
+        const float2 q_texc = want_uv && d_texc ? l_texc : make_float2(0.f, 0.f);
+        const float gn0 = want_n ? l_n0 : 0.f, gn1 = want_n ? l_n1 : 0.f, gn2 = want_n ? l_n2 : 0.f;
+        const unsigned char nograd = want_uv && d_texc && uv_nograd ? l_ng : (unsigned char)0;
         if ((unsigned)i0 < (unsigned)V && (unsigned)i1 < (unsigned)V && (unsigned)i2 < (unsigned)V) {
             have = true;
             const float4* P = pos + (size_t)b * V;
             const float4 p0 = P[i0], p1 = P[i1], p2 = P[i2];
+            float n0[3], n1[3], n2[3];
+            const float* N = want_n ? vnormal + (size_t)b * V * 3 : reinterpret_cast<const float*>(P);      // (stand-in: 3 i + c < 4 V)
+#pragma unroll
+            for (int c = 0; c < 3; c++) { n0[c] = N[3 * i0 + c]; n1[c] = N[3 * i1 + c]; n2[c] = N[3 * i2 + c]; }
+            const float2* U = want_uv ? uv : reinterpret_cast<const float2*>(P);                             // (stand-in: j = a vertex index here)
+            const float2 u0 = U[j0], u1 = U[j1], u2 = U[j2];
             const float b0 = r.x, b1 = r.y, b2 = (1.0f - b0) - b1;
-            float g0 = 0.f, g1 = 0.f;
-            float4 gd = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (d_rast) { const float4 q = d_rast[pi]; g0 = q.x; g1 = q.y; }
-            if (d_db) gd = d_db[pi];
-            if (d_normal && vnormal) {
-                const float* N = vnormal + (size_t)b * V * 3;
-                const float* gn = d_normal + 3 * pi;
+            float g0 = q_rast.x, g1 = q_rast.y;
+            float4 gd = q_db;
+            if (want_n) {
+                const float gnv[3] = {gn0, gn1, gn2};
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
-                    const float v = gn[c];
-                    const float n2 = N[3 * i2 + c];
+                    const float v = gnv[c];
                     acc[9 + c] = b0 * v; acc[12 + c] = b1 * v; acc[15 + c] = b2 * v;
-                    g0 += v * (N[3 * i0 + c] - n2); g1 += v * (N[3 * i1 + c] - n2);
+                    g0 += v * (n0[c] - n2[c]); g1 += v * (n1[c] - n2[c]);
                 }
             }
-            if (uv && (d_texc || d_texd)) {
-                const float2 u0 = uv[tri_uv[3 * t]], u1 = uv[tri_uv[3 * t + 1]], u2 = uv[tri_uv[3 * t + 2]];
+            if (want_uv) {
                 const float2 e0 = make_float2(u0.x - u2.x, u0.y - u2.y), e1 = make_float2(u1.x - u2.x, u1.y - u2.y);
-                if (d_texc && !(uv_nograd && uv_nograd[t])) {
-                    const float2 gt = d_texc[pi];
-                    g0 += gt.x * e0.x + gt.y * e0.y;
-                    g1 += gt.x * e1.x + gt.y * e1.y;
+                if (d_texc && !nograd) {
+                    g0 += q_texc.x * e0.x + q_texc.y * e0.y;
+                    g1 += q_texc.x * e1.x + q_texc.y * e1.y;
                 }
                 if (d_texd) {
-                    const float4 q = d_texd[pi];
+                    const float4 q = q_texd;
                     gd.x += q.x * e0.x + q.z * e0.y; gd.z += q.x * e1.x + q.z * e1.y;
                     gd.y += q.y * e0.x + q.w * e0.y; gd.w += q.y * e1.x + q.w * e1.y;
                 }

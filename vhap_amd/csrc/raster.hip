@@ -424,9 +424,10 @@ struct RasterParams {
 // Residency (MI355X_MICROARCH.md, "Residency"): 256-thread workgroups per CU = min(8, 800 / (ceil(sgpr / 16) * 16 + 16), VGPR limit).  Left to
 // itself the compiler takes 94-100 SGPRs for modes 0 / 1 (6 workgroups per CU instead of 8); capped at 80 it parks 19 of them in VGPR lanes, and
 // 8 waves per SIMD cost mode 1 one VGPR (63 -> 64).  Measured (profiles/r04_call2_raster_residency_ab_*.txt): mode 1 81.0 -> 79.1 us alone,
-// 91 -> 84 us in the step.  Mode 2 (73 VGPRs) stays at 6 waves per SIMD: forced to 8 it spills 8 VGPRs to scratch and runs 104 -> 123 us.
+// 91 -> 84 us in the step.  Mode 2 is held at 6 waves per SIMD (74 VGPRs; with the mip offsets computed in closed form -- tex_sample.h, level_off -- it
+// takes 81 left to itself: 5 waves, 111 us against 104.7): forced to 8 it spills 8 VGPRs to scratch and runs 104 -> 123 us.
 template <int MODE>
-__global__ __launch_bounds__(256, MODE == 2 ? 1 : 8) __attribute__((amdgpu_num_sgpr(80))) void raster_kernel(const RasterParams P) {
+__global__ __launch_bounds__(256, MODE == 2 ? 6 : 8) __attribute__((amdgpu_num_sgpr(80))) void raster_kernel(const RasterParams P) {
     constexpr bool INTERP = MODE >= 1;
     prof_begin(P.prof);
     const unsigned L = vhap_xcd_remap(blockIdx.x, gridDim.x);
@@ -685,6 +686,8 @@ __global__ __launch_bounds__(256, MODE == 2 ? 1 : 8) __attribute__((amdgpu_num_s
             float4 o_rgba;
             if (cov) {
                 float alb[3];
+                // (the two levels' taps one after the other: fetched in one batch -- tex_fetch, as the shading backward does -- this kernel needs
+                // 81 VGPRs and, held to 6 waves per SIMD, runs 107 us against 104.7: profiles/r04_call26_load_batching_ab.txt)
                 tex_sample<3>(P.tex, P.mips, P.D, 0, make_float2(at.tu, at.tv), at.td, alb);
                 o_rgba = make_float4(alb[0] * d[0], alb[1] * d[1], alb[2] * d[2], 1.0f);
             } else if (P.bg_image) {

@@ -2,6 +2,7 @@
 // deferred-shading kernels (raster.hip: forward inside the rasteriser; deferred.hip: backward), so that all of them compute the
 // same bits.  Semantics: header of texture.hip (dr.texture, 'linear-mipmap-linear', boundary 'wrap', render_nvdiffrast.py:399).
 #pragma once
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -27,6 +28,8 @@ TexDesc make_desc(int TB, int H, int W, int C) {
     d.off[0] = 0;
     for (int l = 1; l <= d.L; l++) {
         d.off[l] = o;
+        // (device code computes this offset in closed form: level_off)
+        if (o != (long long)(((unsigned)(H * W) - ((unsigned)(H * W) >> (2 * (l - 1)))) / 3u) * C) abort();
         o += (long long)(H >> l) * (W >> l) * C;
     }
     d.per_tex = o;
@@ -94,11 +97,19 @@ __device__ __forceinline__ LevelSel select_level(const float4 da, int Wt, int Ht
     return s;
 }
 
+// off[l] for a level chosen per lane, by arithmetic: indexing the table with a lane-varying l makes the compiler fetch it from the
+// kernel-argument segment with a global load -- one more dependent round trip in front of each level's taps (two per sample; found in the
+// ISA of the pixel kernels, profiles/r04_call22_step_sq_pmc.json: they sit at s_waitcnt 60-80 % of their wave-cycles).  H and W are
+// divisible by 2^L (num_levels), so (H >> k)(W >> k) = HW >> 2k exactly and off[l] = C * sum_{k=1..l-1} HW / 4^k = C * (HW - HW / 4^(l-1)) / 3.
+__device__ __forceinline__ size_t level_off(const TexDesc& D, int l) {
+    const unsigned M = (unsigned)D.H * (unsigned)D.W;
+    return (size_t)((M - (M >> (2 * (l - 1)))) / 3u) * (unsigned)D.C;
+}
 __device__ __forceinline__ const float* level_ptr(const float* tex, const float* mips, const TexDesc& D, int tb, int l) {
-    return l == 0 ? tex + (size_t)tb * D.H * D.W * D.C : mips + (size_t)tb * D.per_tex + D.off[l];
+    return l == 0 ? tex + (size_t)tb * D.H * D.W * D.C : mips + (size_t)tb * D.per_tex + level_off(D, l);
 }
 __device__ __forceinline__ float* level_ptr_w(float* tex, float* mips, const TexDesc& D, int tb, int l) {
-    return l == 0 ? tex + (size_t)tb * D.H * D.W * D.C : mips + (size_t)tb * D.per_tex + D.off[l];
+    return l == 0 ? tex + (size_t)tb * D.H * D.W * D.C : mips + (size_t)tb * D.per_tex + level_off(D, l);
 }
 
 template <int C>
@@ -154,6 +165,104 @@ TexBinWs texbin_layout(long long npix) {
     return l;
 }
 
+
+// ---- fetch / finish split of one trilinear sample, for the pixel kernels (raster.hip mode 2, deferred.hip).  A covered wave's life is
+// a chain of dependent gathers, so ALL eight taps are issued in one batch (the coarser level's too: l0 + 1 <= L is a valid level
+// whatever the blend factor; it was fetched behind a per-lane branch, a round trip of its own) and the caller may issue further
+// independent loads before it consumes them.  tex_value / tex_bwd_uv evaluate the same expressions as tex_sample / bilinear_bwd.
+template <int C>
+struct TexFetch {
+    LevelSel s;
+    Taps t0, t1;
+    int w0, h0, w1, h1;
+    float a0[4][C], a1[4][C];
+};
+template <int C>
+__device__ __forceinline__ TexFetch<C> tex_fetch(const float* __restrict__ tex, const float* __restrict__ mips, const TexDesc& D, int tb,
+                                                 const float2 c, const float4 da) {
+    TexFetch<C> f;
+    f.s = select_level(da, D.W, D.H, D.L);
+    f.w0 = D.W >> f.s.l0; f.h0 = D.H >> f.s.l0;
+    f.t0 = make_taps(c.x, c.y, f.w0, f.h0, C);
+    const float* T0 = level_ptr(tex, mips, D, tb, f.s.l0);
+#pragma unroll
+    for (int k = 0; k < C; k++) {
+        f.a0[0][k] = T0[f.t0.i00 + k]; f.a0[1][k] = T0[f.t0.i10 + k]; f.a0[2][k] = T0[f.t0.i01 + k]; f.a0[3][k] = T0[f.t0.i11 + k];
+    }
+    // (no branch: a join would make the compiler wait for the taps at the end of the block.  Without mip levels -- L = 0, uniform --
+    // the "coarser" level is level 0 again: valid addresses, values never used)
+    const int l1 = f.s.two ? f.s.l0 + 1 : f.s.l0;
+    f.w1 = D.W >> l1; f.h1 = D.H >> l1;
+    f.t1 = make_taps(c.x, c.y, f.w1, f.h1, C);
+    const float* T1 = level_ptr(tex, mips, D, tb, l1);
+#pragma unroll
+    for (int k = 0; k < C; k++) {
+        f.a1[0][k] = T1[f.t1.i00 + k]; f.a1[1][k] = T1[f.t1.i10 + k]; f.a1[2][k] = T1[f.t1.i01 + k]; f.a1[3][k] = T1[f.t1.i11 + k];
+    }
+    return f;
+}
+template <int C>
+__device__ __forceinline__ void tex_value(const TexFetch<C>& f, float (&res)[C]) {
+    const bool two = f.s.two && f.s.f > 0.0f;
+#pragma unroll
+    for (int k = 0; k < C; k++) {
+        const float top = f.a0[0][k] + f.t0.fx * (f.a0[1][k] - f.a0[0][k]);
+        const float bot = f.a0[2][k] + f.t0.fx * (f.a0[3][k] - f.a0[2][k]);
+        const float r0 = top + f.t0.fy * (bot - top);
+        const float top1 = f.a1[0][k] + f.t1.fx * (f.a1[1][k] - f.a1[0][k]);
+        const float bot1 = f.a1[2][k] + f.t1.fx * (f.a1[3][k] - f.a1[2][k]);
+        const float c1 = top1 + f.t1.fy * (bot1 - top1);
+        res[k] = two ? (1.0f - f.s.f) * r0 + f.s.f * c1 : r0;
+    }
+}
+template <int C>
+__device__ __forceinline__ void bilinear_fetched(const float (&a)[4][C], const Taps& t, const float (&g)[C], float wgt, float& gfx, float& gfy,
+                                                 float (&val)[C]) {
+    gfx = 0.f;
+    gfy = 0.f;
+#pragma unroll
+    for (int k = 0; k < C; k++) {
+        const float a00 = a[0][k], a10 = a[1][k], a01 = a[2][k], a11 = a[3][k];
+        const float top = a00 + t.fx * (a10 - a00), bot = a01 + t.fx * (a11 - a01);
+        val[k] = top + t.fy * (bot - top);
+        const float gk = g[k] * wgt;
+        gfx += gk * ((1.f - t.fy) * (a10 - a00) + t.fy * (a11 - a01));
+        gfy += gk * (bot - top);
+    }
+}
+// gradient w.r.t. uv and uv_da of the fetched sample for the upstream gradient g[C] (tex_sample_bwd_uv without gradient images)
+template <int C>
+__device__ __forceinline__ void tex_bwd_uv(const TexFetch<C>& f, const TexDesc& D, const float (&g)[C], float2& guv, float4& gda,
+                                           float (&val)[C]) {
+    const LevelSel& s = f.s;
+    const bool two = s.two && s.f > 0.0f;
+    float gfx0, gfy0, c0[C], gfx1, gfy1, c1[C];
+    bilinear_fetched<C>(f.a0, f.t0, g, two ? 1.0f - s.f : 1.0f, gfx0, gfy0, c0);
+    bilinear_fetched<C>(f.a1, f.t1, g, s.f, gfx1, gfy1, c1);
+    guv.x = gfx0 * (float)f.w0;
+    guv.y = gfy0 * (float)f.h0;
+    gda = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (two) {
+        guv.x += gfx1 * (float)f.w1;
+        guv.y += gfy1 * (float)f.h1;
+    }
+#pragma unroll
+    for (int k = 0; k < C; k++) val[k] = two ? (1.0f - s.f) * c0[k] + s.f * c1[k] : c0[k];
+    if (two && s.diff) {
+        float gf = 0.f;
+#pragma unroll
+        for (int k = 0; k < C; k++) gf += g[k] * (c1[k] - c0[k]);
+        const float glam = gf * 0.5f / (s.lambda * 0.69314718056f);
+        const float q = s.l2n_sqrt > 0.f ? 0.5f / s.l2n_sqrt : 0.f;
+        const float gl2n = glam * q;
+        const float gA = 0.5f * glam + gl2n * 0.5f * (s.A - s.B);
+        const float gB = 0.5f * glam - gl2n * 0.5f * (s.A - s.B);
+        const float gC = gl2n * 2.0f * s.Cq;
+        const float gsx = 2.f * s.sx * gA + s.sy * gC, gsy = 2.f * s.sy * gB + s.sx * gC;
+        const float gtx = 2.f * s.tx * gA + s.ty * gC, gty = 2.f * s.ty * gB + s.tx * gC;
+        gda = make_float4(gsx * (float)D.W, gsy * (float)D.W, gtx * (float)D.H, gty * (float)D.H);
+    }
+}
 
 // value of ONE trilinear sample (the body of texture_fwd_kernel): res[C]
 template <int C>
