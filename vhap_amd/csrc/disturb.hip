@@ -39,6 +39,37 @@ __device__ __forceinline__ int pixel_cluster(const ClusterSrc& s, long long p) {
     const int fid = (int)s.rast[p].w;
     return s.fid2cid[min(max(fid, 0), s.nfid - 1)];
 }
+// the clusters of a thread's PPT pixels (p0 + it * stride; -1 past the end), ALL loads issued before the first is consumed: called per
+// iteration, each value is load -> wait -> ballot, PPT round trips in series in kernels that are a few microseconds of work otherwise
+template <int N>
+__device__ __forceinline__ void pixel_clusters(const ClusterSrc& s, long long p0, int stride, long long n, int (&c)[N]) {
+    if (s.cid) {
+        unsigned char v[N];
+#pragma unroll
+        for (int it = 0; it < N; it++) { const long long p = p0 + (long long)it * stride; v[it] = s.cid[p < n ? p : n - 1]; }
+#pragma unroll
+        for (int it = 0; it < N; it++) c[it] = p0 + (long long)it * stride < n ? (int)v[it] : -1;
+    } else {
+        float w[N];
+#pragma unroll
+        for (int it = 0; it < N; it++) { const long long p = p0 + (long long)it * stride; w[it] = s.rast[p < n ? p : n - 1].w; }
+#pragma unroll
+        for (int it = 0; it < N; it++) c[it] = s.fid2cid[min(max((int)w[it], 0), s.nfid - 1)];
+#pragma unroll
+        for (int it = 0; it < N; it++) if (!(p0 + (long long)it * stride < n)) c[it] = -1;
+    }
+}
+// start of every cluster's pool = the totals of the clusters before it: all MAXC totals in one batch (a loop to the lane's own cluster is
+// up to 15 dependent round trips)
+__device__ __forceinline__ int cluster_start(const int* __restrict__ totals, int c) {
+    int tv[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) tv[k] = totals[k];
+    int start = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) start += k < c ? tv[k] : 0;
+    return start;
+}
 
 // counter-based random bits (two rounds of the murmur3 finaliser over a Weyl-mixed key): statistically ample for a
 // colour-dither; one stream per (call, pixel, draw)
@@ -59,10 +90,11 @@ __global__ __launch_bounds__(DB) void disturb_count_kernel(const ClusterSrc src,
     if (rng_state && blockIdx.x == 0 && threadIdx.x == 0) rng_state[0] += 1u;
     if (lane < MAXC) cnt[wave][lane] = 0;
     // a wave holds 64 consecutive pixels (one or two clusters, rarely more): loop over the cluster values present, not over all clusters
+    int cs[PPT];
+    pixel_clusters<PPT>(src, (long long)blockIdx.x * DPIX + threadIdx.x, DB, n, cs);
 #pragma unroll
     for (int it = 0; it < PPT; it++) {
-        const long long p = (long long)blockIdx.x * DPIX + it * DB + threadIdx.x;
-        int c = p < n ? pixel_cluster(src, p) : -1;
+        int c = cs[it];
         if (c >= ncl) c = -1;                       // (ids outside the configured clusters are left alone)
         unsigned long long todo = __ballot(c >= 0);
         while (todo) {
@@ -127,17 +159,17 @@ __global__ __launch_bounds__(DB) void disturb_scatter_kernel(const ClusterSrc sr
     __shared__ int wcnt[PPT][NW][MAXC];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x < MAXC) {
-        int start = 0;                               // start of the cluster's pool = the totals of the clusters before it
-        for (int k = 0; k < (int)threadIdx.x; k++) start += totals[k];
-        base[threadIdx.x] = start + block_prefix[(size_t)blockIdx.x * MAXC + threadIdx.x];
+        const int pre = block_prefix[(size_t)blockIdx.x * MAXC + threadIdx.x];
+        base[threadIdx.x] = cluster_start(totals, (int)threadIdx.x) + pre;
     }
     for (int i = threadIdx.x; i < PPT * NW * MAXC; i += DB) (&wcnt[0][0][0])[i] = 0;
     __syncthreads();
     int key[PPT];                                   // cluster << 8 | rank in the wave's 64 pixels (-1: not sorted)
+    int cs[PPT];
+    pixel_clusters<PPT>(src, (long long)blockIdx.x * DPIX + threadIdx.x, DB, n, cs);
 #pragma unroll
     for (int it = 0; it < PPT; it++) {
-        const long long p = (long long)blockIdx.x * DPIX + it * DB + threadIdx.x;
-        int c = p < n ? pixel_cluster(src, p) : -1;
+        int c = cs[it];
         if (c >= ncl) c = -1;                       // (ids outside the configured clusters are left alone)
         int rank = 0;
         unsigned long long todo = __ballot(c >= 0);
@@ -167,11 +199,20 @@ __global__ __launch_bounds__(DB) void disturb_scatter_kernel(const ClusterSrc sr
         *cell = incl - v;
     }
     __syncthreads();
+    // the copy: all of the thread's colours requested, then stored (clamped addresses: pixels past the end / outside the clusters are not stored)
+    float4 col[PPT];
+#pragma unroll
+    for (int it = 0; it < PPT; it++) {
+        const long long p = (long long)blockIdx.x * DPIX + it * DB + threadIdx.x;
+        col[it] = rgba[p < n ? p : n - 1];
+    }
+#pragma unroll
+    for (int it = 0; it < PPT; it++) asm volatile("" ::"v"(col[it].x), "v"(col[it].y), "v"(col[it].z), "v"(col[it].w));   // (or the compiler sinks each load into its `if` below)
 #pragma unroll
     for (int it = 0; it < PPT; it++) {
         if (key[it] < 0) continue;
         const int c = key[it] >> 8, rank = key[it] & 255;
-        pool[base[c] + wcnt[it][wave][c] + rank] = rgba[(long long)blockIdx.x * DPIX + it * DB + threadIdx.x];
+        pool[base[c] + wcnt[it][wave][c] + rank] = col[it];
     }
 }
 
@@ -187,10 +228,9 @@ __global__ __launch_bounds__(256) void disturb_apply_kernel(const float4* __rest
                                                             float* __restrict__ keep) {
     __shared__ int s_tot[MAXC], s_start[MAXC];
     if (threadIdx.x < MAXC) {
-        int start = 0;
-        for (int k = 0; k < (int)threadIdx.x; k++) start += totals[k];
-        s_start[threadIdx.x] = start;
-        s_tot[threadIdx.x] = totals[threadIdx.x];
+        const int own = totals[threadIdx.x];
+        s_start[threadIdx.x] = cluster_start(totals, (int)threadIdx.x);
+        s_tot[threadIdx.x] = own;
     }
     __syncthreads();
     const long long n = (long long)B * H * W;

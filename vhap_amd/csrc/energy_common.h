@@ -59,17 +59,23 @@ __device__ inline void finalize_total_wave(const float* frame_terms, const float
                                            const unsigned* shade_stats, float w_lmk, float w_reg_diffuse, float npix, float photo_sum,
                                            float n_global, float w_photo, float world, float* log, float* d_sum, float* gmax_bound) {
     const int i = threadIdx.x & 63;
+    // every lane's term through ONE load (address select), the two statistics words next to it: as an else-if chain with a load per arm
+    // this was eight dependent round trips on the tail of the kernel the whole backward waits for
+    const float* src = nullptr;
+    if (i == VHAP_LOG_LMK) src = lmk;
+    else if (i >= VHAP_LOG_SMOOTH_POSE && i < VHAP_LOG_SMOOTH_POSE + 6) src = frame_terms ? frame_terms + (i - VHAP_LOG_SMOOTH_POSE) : nullptr;
+    else if (i == VHAP_LOG_TEX_TV) src = tex_terms;
+    else if (i == VHAP_LOG_TEX_RES) src = tex_terms ? tex_terms + 1 : nullptr;
+    else if (i == VHAP_LOG_TEX_PCA) src = tex_terms ? tex_terms + 2 : nullptr;
+    else if (i >= VHAP_LOG_OFF_LAP && i < VHAP_LOG_OFF_LAP + 3) src = off_terms ? off_terms + (i - VHAP_LOG_OFF_LAP) : nullptr;
+    else if (i == VHAP_LOG_OFF_DYNAMIC) src = off_terms ? off_terms + 3 : nullptr;
+    const unsigned* st = shade_stats ? shade_stats : reinterpret_cast<const unsigned*>(log);      // (stand-in address, values unused)
+    const unsigned s1 = st[1], s2 = st[2];
     float v = 0.f;
-    if (i == VHAP_LOG_LMK) { if (lmk) v = w_lmk * lmk[0]; }
-    else if (i >= VHAP_LOG_SMOOTH_POSE && i < VHAP_LOG_SMOOTH_POSE + 6) { if (frame_terms) v = frame_terms[i - VHAP_LOG_SMOOTH_POSE]; }
-    else if (i == VHAP_LOG_TEX_TV) { if (tex_terms) v = tex_terms[0]; }
-    else if (i == VHAP_LOG_TEX_RES) { if (tex_terms) v = tex_terms[1]; }
-    else if (i == VHAP_LOG_TEX_PCA) { if (tex_terms) v = tex_terms[2]; }
-    else if (i >= VHAP_LOG_OFF_LAP && i < VHAP_LOG_OFF_LAP + 3) { if (off_terms) v = off_terms[i - VHAP_LOG_OFF_LAP]; }
-    else if (i == VHAP_LOG_OFF_DYNAMIC) { if (off_terms) v = off_terms[3]; }
+    if (src) v = *src;
+    if (i == VHAP_LOG_LMK) v = w_lmk * v;
     float mx = 4.0f;
     if (shade_stats) {
-        const unsigned s1 = shade_stats[1], s2 = shade_stats[2];
         mx = decode_ordered(s1);
         if (i == VHAP_LOG_REG_DIFFUSE) v = w_reg_diffuse * (fmaxf(mx - 1.0f, 0.0f) + __uint_as_float(s2) / npix);
         mx = fmaxf(mx, 1.0f);

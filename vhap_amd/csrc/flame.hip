@@ -39,13 +39,39 @@ __global__ __launch_bounds__(256) void flame_skin_fwd_kernel(const float* __rest
     __shared__ float red[2][4][3][64][4];      // [phase][wave][component][lane][r]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int v0 = blockIdx.x * 16, b0 = blockIdx.y * 16;
-    for (int i = tid; i < 16 * NJ * 12; i += 256) {
-        const int f = i / (NJ * 12);
-        sA[i] = (b0 + f < B) ? A[(size_t)(b0 + f) * NJ * 12 + (i - f * NJ * 12)] : 0.f;
+    {   // one batch of loads (frames past the end clamped and zeroed afterwards), then the LDS writes
+        constexpr int NA = (16 * NJ * 12 + 255) / 256;
+        float ra[NA];
+#pragma unroll
+        for (int u = 0; u < NA; u++) {
+            const int i = min(tid + 256 * u, 16 * NJ * 12 - 1), f = i / (NJ * 12);
+            ra[u] = A[(size_t)min(b0 + f, B - 1) * NJ * 12 + (i - f * NJ * 12)];
+        }
+        const int tt = min(tid, 47);
+        const float rt = transl[(size_t)min(b0 + tt / 3, B - 1) * 3 + tt % 3];
+        const float rm = *(clip ? mvp + (size_t)min(b0 + tid / 16, B - 1) * 16 + tid % 16 : transl);
+#pragma unroll
+        for (int u = 0; u < NA; u++) {
+            const int i = tid + 256 * u;
+            if (i < 16 * NJ * 12) sA[i] = (b0 + i / (NJ * 12) < B) ? ra[u] : 0.f;
+        }
+        if (tid < 48) sT[tid] = (b0 + tid / 3 < B) ? rt : 0.f;
+        if (clip) sM[tid] = (b0 + tid / 16 < B) ? rm : 0.f;
     }
-    if (tid < 48) sT[tid] = (b0 + tid / 3 < B) ? transl[(size_t)(b0 + tid / 3) * 3 + tid % 3] : 0.f;
-    if (clip) sM[tid] = (b0 + tid / 16 < B) ? mvp[(size_t)(b0 + tid / 16) * 16 + tid % 16] : 0.f;
     const int li = lane & 15, lk = lane >> 4;
+    // the epilogue's per-vertex inputs, requested before the contraction (clamped vertex / frame, stand-in address for an absent offset):
+    // after it they were three more dependent round trips on the wave that finishes the tile
+    const int vq = min(v0 + li, V - 1);
+    const float* ofs = offset ? offset + 3 * vq : templ + 3 * vq;
+    const float e_t0 = templ[3 * vq], e_t1 = templ[3 * vq + 1], e_t2 = templ[3 * vq + 2];
+    float e_w[NJ], e_o[4][3];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) e_w[j] = w[(size_t)vq * NJ + j];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const float* q = ofs + (size_t)min(b0 + lk * 4 + r, B - 1) * offset_stride;      // (stride 0: the one shared row, four times)
+        e_o[r][0] = q[0]; e_o[r][1] = q[1]; e_o[r][2] = q[2];
+    }
     const float* cf = coef + (size_t)(b0 + li) * Kp + lk;
     const size_t cs = (size_t)K * Vp;  // component stride
     auto run = [&](int k_begin, int k_end, int phase) {
@@ -54,13 +80,26 @@ __global__ __launch_bounds__(256) void flame_skin_fwd_kernel(const float* __rest
         const int per = (steps + 3) / 4;
         const int s0 = min(wave * per, steps), s1 = min(s0 + per, steps);
         f32x4 acc[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#pragma unroll 4
-        for (int st = s0; st < s1; st++) {
-            const int k = k_begin + 4 * st;
-            const float a = cf[k];
-            const float* bp = basis + (size_t)(k + lk) * Vp + v0 + li;
+        // eight K steps per trip, their 32 operand loads issued before the first MFMA (`#pragma unroll 4` on the one-step loop did not
+        // unroll it -- run-time bounds inside a lambda -- and a wave walked its 25 steps as 25 dependent round trips: the whole kernel)
+        constexpr int KU = 8;
+        for (int st = s0; st < s1; st += KU) {
+            float a[KU], bv[KU][3];
 #pragma unroll
-            for (int c = 0; c < 3; c++) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bp[c * cs], acc[c], 0, 0, 0);
+            for (int u = 0; u < KU; u++) {
+                const int k = k_begin + 4 * min(st + u, s1 - 1);
+                const float* bp = basis + (size_t)(k + lk) * Vp + v0 + li;
+                a[u] = cf[k];
+#pragma unroll
+                for (int c = 0; c < 3; c++) bv[u][c] = bp[c * cs];
+            }
+#pragma unroll
+            for (int u = 0; u < KU; u++) {
+                if (st + u < s1) {
+#pragma unroll
+                    for (int c = 0; c < 3; c++) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], bv[u][c], acc[c], 0, 0, 0);
+                }
+            }
         }
 #pragma unroll
         for (int c = 0; c < 3; c++)
@@ -76,11 +115,11 @@ __global__ __launch_bounds__(256) void flame_skin_fwd_kernel(const float* __rest
     if (v >= V) return;
     // offset_stride == 0: ONE offset [V,3] for the batch (static_offset); > 0: an offset row per frame (static + dynamic_offset[timesteps],
     // tracker.py:213-235) -- added per frame below
-    float tx = templ[3 * v], ty = templ[3 * v + 1], tz = templ[3 * v + 2];
-    if (offset && offset_stride == 0) { tx += offset[3 * v]; ty += offset[3 * v + 1]; tz += offset[3 * v + 2]; }
+    float tx = e_t0, ty = e_t1, tz = e_t2;
+    if (offset && offset_stride == 0) { tx += e_o[0][0]; ty += e_o[0][1]; tz += e_o[0][2]; }
     float wj[NJ];
 #pragma unroll
-    for (int j = 0; j < NJ; j++) wj[j] = w[(size_t)v * NJ + j];
+    for (int j = 0; j < NJ; j++) wj[j] = e_w[j];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const int fl = lk * 4 + r, f = b0 + fl;
@@ -93,10 +132,7 @@ __global__ __launch_bounds__(256) void flame_skin_fwd_kernel(const float* __rest
         }
         float sx = tx + sh[0], sy = ty + sh[1], sz = tz + sh[2];
         const size_t o = ((size_t)f * V + v) * 3;
-        if (offset && offset_stride != 0) {
-            const float* of = offset + (size_t)f * offset_stride + 3 * v;
-            sx += of[0]; sy += of[1]; sz += of[2];
-        }
+        if (offset && offset_stride != 0) { sx += e_o[r][0]; sy += e_o[r][1]; sz += e_o[r][2]; }
         v_shaped[o] = sx; v_shaped[o + 1] = sy; v_shaped[o + 2] = sz;
         const float px = sx + po[0], py = sy + po[1], pz = sz + po[2];
         float T[12];
@@ -196,21 +232,33 @@ __global__ __launch_bounds__(256) void flame_coef_bwd_kernel(const float* __rest
     const int vend = min(vbeg + v_per_wave, V);
     const bool bvalid = b0 + li < B;
     const size_t cs = (size_t)Vp * Kp;
-    const float* gp = G + (size_t)(b0 + li) * V * 3;
+    const float* gp = G + (size_t)min(b0 + li, B - 1) * V * 3;      // (rows past the batch: clamped, zeroed at the MFMA)
     const float* bp = basisT + (size_t)nt * 16 + li;
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int v0 = vbeg; v0 < vend; v0 += 4) {
-        const int v = v0 + lk;
-        const bool ok = v < vend;
-        float a[3], bb[3];
+    // eight 4-vertex steps per trip, their 48 operand loads issued before the first MFMA (clamped vertices, zeroed afterwards): the
+    // one-step loop did not unroll (`#pragma unroll 4`, run-time bounds) and every step was a dependent round trip
+    constexpr int VU = 8;
+    const int vlast = max(vend - 1, vbeg);
+    for (int v0 = vbeg; v0 < vend; v0 += 4 * VU) {
+        float a[VU][3], bb[VU][3];
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
-            a[c] = (ok && bvalid) ? gp[(size_t)v * 3 + c] : 0.f;
-            bb[c] = ok ? bp[c * cs + (size_t)v * Kp] : 0.f;
+        for (int u = 0; u < VU; u++) {
+            const int v = min(v0 + 4 * u + lk, vlast);
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                a[u][c] = gp[(size_t)v * 3 + c];
+                bb[u][c] = bp[c * cs + (size_t)v * Kp];
+            }
         }
 #pragma unroll
-        for (int c = 0; c < 3; c++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c], bb[c], acc, 0, 0, 0);
+        for (int u = 0; u < VU; u++) {
+            if (v0 + 4 * u < vend) {
+                const bool ok = v0 + 4 * u + lk < vend;
+#pragma unroll
+                for (int c = 0; c < 3; c++)
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32((ok && bvalid) ? a[u][c] : 0.f, ok ? bb[u][c] : 0.f, acc, 0, 0, 0);
+            }
+        }
     }
 #pragma unroll
     for (int r = 0; r < 4; r++) red[wave][lane][r] = acc[r];
@@ -385,38 +433,64 @@ __global__ __launch_bounds__(256) void verts_bwd_fused_kernel(const float* __res
         const float* P = verts + (size_t)b * V * 3;
         const float* G = d_nraw + (size_t)b * V * 3;
         const size_t o = ((size_t)b * V + v) * 3;
-        float gx = 0.f, gy = 0.f, gz = 0.f;
-        if (d_verts_in) { gx = d_verts_in[o]; gy = d_verts_in[o + 1]; gz = d_verts_in[o + 2]; }
-        // vertex-normal backward, pass 2 (see vnormal_bwd2_kernel)
-        for (int k = vc_ptr[v]; k < vc_ptr[v + 1]; k++) {
-            const int c = vc_idx[k], t = c / 3, i = c - 3 * t;
-            const int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
-            const float hx = G[3 * i0] + G[3 * i1] + G[3 * i2], hy = G[3 * i0 + 1] + G[3 * i1 + 1] + G[3 * i2 + 1],
-                        hz = G[3 * i0 + 2] + G[3 * i1 + 2] + G[3 * i2 + 2];
-            const float ax = P[3 * i1] - P[3 * i0], ay = P[3 * i1 + 1] - P[3 * i0 + 1], az = P[3 * i1 + 2] - P[3 * i0 + 2];
-            const float bx = P[3 * i2] - P[3 * i0], by = P[3 * i2 + 1] - P[3 * i0 + 1], bz = P[3 * i2 + 2] - P[3 * i0 + 2];
-            const float d1x = by * hz - bz * hy, d1y = bz * hx - bx * hz, d1z = bx * hy - by * hx;   // e2 x g
-            const float d2x = hy * az - hz * ay, d2y = hz * ax - hx * az, d2z = hx * ay - hy * ax;   // g x e1
-            if (i == 0) { gx -= d1x + d2x; gy -= d1y + d2y; gz -= d1z + d2z; }
-            else if (i == 1) { gx += d1x; gy += d1y; gz += d1z; }
-            else { gx += d2x; gy += d2y; gz += d2z; }
+        // every load that depends on the vertex alone is requested now and consumed after the walk over the incident faces
+        const int k0 = vc_ptr[v], k1 = vc_ptr[v + 1];
+        const float* dvi = d_verts_in ? d_verts_in + o : P + 3 * v;            // (stand-in address for the optional input)
+        const float r_dv0 = dvi[0], r_dv1 = dvi[1], r_dv2 = dvi[2];
+        const float4 gc = d_clip[(size_t)b * V + v];
+        const float vx = P[3 * v], vy = P[3 * v + 1], vz = P[3 * v + 2];
+        const float px = v_posed[o], py = v_posed[o + 1], pz = v_posed[o + 2];
+        float wj[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; j++) wj[j] = w[(size_t)v * NJ + j];
+        float gx = d_verts_in ? r_dv0 : 0.f, gy = d_verts_in ? r_dv1 : 0.f, gz = d_verts_in ? r_dv2 : 0.f;
+        // vertex-normal backward, pass 2 (see vnormal_bwd2_kernel).  The incident faces FOUR at a time: corner ids -> vertex ids ->
+        // normals' gradients and positions are three dependent round trips per face, and one face per trip (valence ~6) made this kernel
+        // ~20 of them in series; the contributions are added in the order of the corner list, as before.
+        constexpr int FB = 4;
+        for (int k = k0; k < k1; k += FB) {
+            int cc[FB], ii[FB][3];
+            float g_[FB][3][3], p_[FB][3][3];
+#pragma unroll
+            for (int u = 0; u < FB; u++) cc[u] = vc_idx[k + u < k1 ? k + u : k1 - 1];
+#pragma unroll
+            for (int u = 0; u < FB; u++) {
+                const int t = cc[u] / 3;
+                ii[u][0] = tri[3 * t]; ii[u][1] = tri[3 * t + 1]; ii[u][2] = tri[3 * t + 2];
+            }
+#pragma unroll
+            for (int u = 0; u < FB; u++)
+#pragma unroll
+                for (int q = 0; q < 3; q++)
+#pragma unroll
+                    for (int c = 0; c < 3; c++) { g_[u][q][c] = G[3 * ii[u][q] + c]; p_[u][q][c] = P[3 * ii[u][q] + c]; }
+#pragma unroll
+            for (int u = 0; u < FB; u++) {
+                if (k + u >= k1) break;
+                const int i = cc[u] - 3 * (cc[u] / 3);
+                const float hx = g_[u][0][0] + g_[u][1][0] + g_[u][2][0], hy = g_[u][0][1] + g_[u][1][1] + g_[u][2][1],
+                            hz = g_[u][0][2] + g_[u][1][2] + g_[u][2][2];
+                const float ax = p_[u][1][0] - p_[u][0][0], ay = p_[u][1][1] - p_[u][0][1], az = p_[u][1][2] - p_[u][0][2];
+                const float bx = p_[u][2][0] - p_[u][0][0], by = p_[u][2][1] - p_[u][0][1], bz = p_[u][2][2] - p_[u][0][2];
+                const float d1x = by * hz - bz * hy, d1y = bz * hx - bx * hz, d1z = bx * hy - by * hx;   // e2 x g
+                const float d2x = hy * az - hz * ay, d2y = hz * ax - hx * az, d2z = hx * ay - hy * ax;   // g x e1
+                if (i == 0) { gx -= d1x + d2x; gy -= d1y + d2y; gz -= d1z + d2z; }
+                else if (i == 1) { gx += d1x; gy += d1y; gz += d1z; }
+                else { gx += d2x; gy += d2y; gz += d2z; }
+            }
         }
         // clip transform backward (see transform_bwd_kernel)
-        const float4 gc = d_clip[(size_t)b * V + v];
         gx += sM[0] * gc.x + sM[4] * gc.y + sM[8] * gc.z + sM[12] * gc.w;
         gy += sM[1] * gc.x + sM[5] * gc.y + sM[9] * gc.z + sM[13] * gc.w;
         gz += sM[2] * gc.x + sM[6] * gc.y + sM[10] * gc.z + sM[14] * gc.w;
         {
-            const float x = P[3 * v], y = P[3 * v + 1], z = P[3 * v + 2];
+            const float x = vx, y = vy, z = vz;
             const float gg[4] = {gc.x, gc.y, gc.z, gc.w};
 #pragma unroll
             for (int r = 0; r < 4; r++) { acc[4 * r] = gg[r] * x; acc[4 * r + 1] = gg[r] * y; acc[4 * r + 2] = gg[r] * z; acc[4 * r + 3] = gg[r]; }
         }
         // skinning backward (see flame_skin_bwd_kernel)
-        const float px = v_posed[o], py = v_posed[o + 1], pz = v_posed[o + 2];
-        float wj[NJ], T[12];
-#pragma unroll
-        for (int j = 0; j < NJ; j++) wj[j] = w[(size_t)v * NJ + j];
+        float T[12];
 #pragma unroll
         for (int q = 0; q < 12; q++) {
             float s_ = 0.f;

@@ -156,6 +156,16 @@ __global__ __launch_bounds__(FP_THREADS) void frame_prep_fwd_kernel(FrameCfg cfg
         return;
     }
     const long long t = in.ts[b], p = t > 0 ? t - 1 : 0;
+    // what depends on the timestep alone is requested NOW and consumed after the joint regression (clamped lanes instead of branches: a
+    // branch around a load ends in a join, where the compiler waits for it): the pose rows of this and the previous timestep, JT
+    const int spc = tid < 2 * 18 ? tid : 2 * 18 - 1, sp_which = spc / 18, sp_i = spc - 18 * sp_which;
+    const long long sp_ts = sp_which ? p : t;
+    const float* sp_src = sp_i < 3 ? in.rotation + 3 * sp_ts + sp_i
+                        : (sp_i < 6 ? in.neck + 3 * sp_ts + (sp_i - 3)
+                        : (sp_i < 9 ? in.jaw + 3 * sp_ts + (sp_i - 6)
+                        : (sp_i < 15 ? in.eyes + 6 * sp_ts + (sp_i - 9) : in.translation + 3 * sp_ts + (sp_i - 15))));
+    const float sp_v = *sp_src;
+    const float jt_v = in.JT[tid < 3 * cfg.J ? tid : 3 * cfg.J - 1];
     float e_reg = 0.f, e_smooth = 0.f, e_shape = 0.f;
     for (int k = tid; k < cfg.Kp; k += FP_THREADS) {
         float v = 0.f;
@@ -180,24 +190,29 @@ __global__ __launch_bounds__(FP_THREADS) void frame_prep_fwd_kernel(FrameCfg cfg
         float part[3 * MAXJ];
 #pragma unroll
         for (int o = 0; o < 3 * MAXJ; o++) part[o] = 0.f;
+        // (the loads are UNCONDITIONAL -- rows past 3J re-read the last one into sums nobody reads: a load behind `if (o < 3J)` is its own
+        // basic block, load -> wait -> fma, and this kernel is one workgroup per frame with nothing to hide a round trip behind: 15 of them
+        // per slice, in series, were most of its 34 us)
+        const int NO = JT ? 3 * JT : 3 * MAXJ, last = 3 * cfg.J - 1;
         for (int k = tid; k < NB; k += FP_THREADS) {
             const float bk = beta[k];
+            float js[3 * MAXJ];
 #pragma unroll
-            for (int o = 0; o < 3 * MAXJ; o++)
-                if (o < 3 * cfg.J) part[o] += in.JS[(size_t)o * NB + k] * bk;
+            for (int o = 0; o < NO; o++) js[o] = in.JS[(size_t)(o < last ? o : last) * NB + k];
+#pragma unroll
+            for (int o = 0; o < NO; o++) part[o] += js[o] * bk;
         }
         if (in.offset) {        // J_regressor is sparse (a few hundred non-zero columns): compact list instead of a walk over all V
+            const int NJ = JT ? JT : MAXJ;
             for (int m = tid; m < in.M; m += FP_THREADS) {
                 const int v = in.Jv[m];
+                float wv[MAXJ];
+#pragma unroll
+                for (int j = 0; j < NJ; j++) wv[j] = in.Jw[(size_t)m * cfg.J + (j < cfg.J ? j : cfg.J - 1)];
                 const float* of = in.offset + (size_t)blockIdx.x * in.offset_stride + 3 * v;
                 const float o0 = of[0], o1 = of[1], o2 = of[2];
 #pragma unroll
-                for (int j = 0; j < MAXJ; j++) {
-                    if (j < cfg.J) {
-                        const float wv = in.Jw[(size_t)m * cfg.J + j];
-                        part[3 * j] += wv * o0; part[3 * j + 1] += wv * o1; part[3 * j + 2] += wv * o2;
-                    }
-                }
+                for (int j = 0; j < NJ; j++) { part[3 * j] += wv[j] * o0; part[3 * j + 1] += wv[j] * o1; part[3 * j + 2] += wv[j] * o2; }
             }
         }
         __shared__ float wred[FP_THREADS / 64][3 * MAXJ];
@@ -209,28 +224,17 @@ __global__ __launch_bounds__(FP_THREADS) void frame_prep_fwd_kernel(FrameCfg cfg
         }
         __syncthreads();
         if (tid < 3 * cfg.J) {
-            float a = in.JT[tid];
+            float a = jt_v;
 #pragma unroll
             for (int w = 0; w < FP_THREADS / 64; w++) a += wred[w][tid];
             Jl[tid] = a;
         }
     }
+    __shared__ float spose[2][3 * MAXJ + 3];   // [current | previous]: 15 pose values + translation
+    if (tid < 2 * 18) spose[sp_which][sp_i] = sp_v;
     __syncthreads();
     if (tid < 3 * cfg.J) Jrest[(size_t)b * 3 * cfg.J + tid] = Jl[tid];
-    if (tid < 3) transl[3 * b + tid] = in.translation[3 * t + tid];
-    __shared__ float spose[2][3 * MAXJ + 3];   // [current | previous]: 15 pose values + translation
-    if (tid < 2 * 18) {
-        const int which = tid / 18, i = tid - 18 * which;
-        const long long tt = which ? p : t;
-        float v;
-        if (i < 3) v = in.rotation[3 * tt + i];
-        else if (i < 6) v = in.neck[3 * tt + i - 3];
-        else if (i < 9) v = in.jaw[3 * tt + i - 6];
-        else if (i < 15) v = in.eyes[6 * tt + i - 9];
-        else v = in.translation[3 * tt + i - 15];
-        spose[which][i] = v;
-    }
-    __syncthreads();
+    if (tid < 3) transl[3 * b + tid] = spose[0][15 + tid];
     // ---- lanes 0..J-1: one joint each (Rodrigues, pose feature, ||R - I||^2) -- the same code once instead of J unrolled
     // copies on one lane: these kernels run ONE wave per frame through tens of KB of straight-line code, instruction fetch
     // of cold code was most of their time ----
@@ -339,21 +343,28 @@ __global__ __launch_bounds__(FP_THREADS) void frame_prep_bwd_kernel(FrameCfg cfg
     const float* drow = d_coef ? d_coef + (size_t)b * cfg.Kp : nullptr;
     // stage every small per-frame input in LDS with parallel loads; lane 0 then runs the serial algebra out of LDS
     __shared__ float spose[2][18], sJ[3 * MAXJ], sdA[12 * MAXJ], sdpf[9 * MAXJ], sdt[3];
-    if (tid < 36) {
-        const int which = tid / 18, i = tid - 18 * which;
+    // (ONE batch of loads -- clamped lanes and stand-in addresses instead of branches, see frame_prep_fwd_kernel -- then the LDS writes:
+    // as five branchy staging loops this was nine dependent round trips before the first flop)
+    {
+        const int spc = tid < 36 ? tid : 35, which = spc / 18, i = spc - 18 * which;
         const long long tt = which ? p : t;
-        float v;
-        if (i < 3) v = in.rotation[3 * tt + i];
-        else if (i < 6) v = in.neck[3 * tt + i - 3];
-        else if (i < 9) v = in.jaw[3 * tt + i - 6];
-        else if (i < 15) v = in.eyes[6 * tt + i - 9];
-        else v = in.translation[3 * tt + i - 15];
-        spose[which][i] = v;
+        const float* sp_src = i < 3 ? in.rotation + 3 * tt + i
+                            : (i < 6 ? in.neck + 3 * tt + (i - 3)
+                            : (i < 9 ? in.jaw + 3 * tt + (i - 6)
+                            : (i < 15 ? in.eyes + 6 * tt + (i - 9) : in.translation + 3 * tt + (i - 15))));
+        const float* jr = Jrest + (size_t)b * 3 * cfg.J;                   // (also the stand-in address of an absent input)
+        const int nA = 12 * cfg.J;                                         // <= 96 < FP_THREADS, like 3 J and P = 9 (J - 1)
+        const float r_sp = *sp_src;
+        const float r_J = jr[tid < 3 * cfg.J ? tid : 3 * cfg.J - 1];
+        const float r_dA = *(d_A ? d_A + (size_t)b * nA + (tid < nA ? tid : nA - 1) : jr);
+        const float r_pf = *(drow && cfg.P > 0 ? drow + NB + (tid < cfg.P ? tid : cfg.P - 1) : jr);
+        const float r_dt = *(d_transl ? d_transl + 3 * b + (tid < 3 ? tid : 2) : jr);
+        if (tid < 36) spose[which][i] = r_sp;
+        if (tid < 3 * cfg.J) sJ[tid] = r_J;
+        if (tid < nA) sdA[tid] = d_A ? r_dA : 0.f;
+        if (tid < cfg.P) sdpf[tid] = drow ? r_pf : 0.f;
+        if (tid < 3) sdt[tid] = d_transl ? r_dt : 0.f;
     }
-    for (int i = tid; i < 3 * cfg.J; i += FP_THREADS) sJ[i] = Jrest[(size_t)b * 3 * cfg.J + i];
-    for (int i = tid; i < 12 * cfg.J; i += FP_THREADS) sdA[i] = d_A ? d_A[(size_t)b * cfg.J * 12 + i] : 0.f;
-    for (int i = tid; i < cfg.P; i += FP_THREADS) sdpf[i] = drow ? drow[NB + i] : 0.f;
-    if (tid < 3) sdt[tid] = d_transl ? d_transl[3 * b + tid] : 0.f;
     __syncthreads();
     // lanes 0..J-1: R_j (one Rodrigues per lane, SIMD) -> LDS;  lane 0: chain forward + reverse -> dR_j in LDS;
     // lanes 0..J-1: reverse of Rodrigues + the direct pose terms + the scatter (see frame_prep_fwd_kernel for why)
@@ -487,29 +498,46 @@ __global__ __launch_bounds__(FP_THREADS) void frame_prep_bwd_kernel(FrameCfg cfg
     __syncthreads();
     // betas: blend-kernel gradient + joint regression + L2 / smoothness
     const float ke = 2.0f * iB / (float)cfg.NE;
-    for (int k = tid; k < NB; k += FP_THREADS) {
-        float d = drow ? drow[k] : 0.f;
-        for (int o = 0; o < 3 * cfg.J; o++) d += in.JS[(size_t)o * NB + k] * dJl[o];
-        if (k < cfg.NS) {
-            if (b == 0) d += 2.0f * w[VHAP_FW_REG_SHAPE] * dt_[5] * in.shape[k] / (float)cfg.NS;
-            if (g.shape) atomicAdd(&g.shape[k], d);
-        } else if (g.expr) {
-            const int e = k - cfg.NS;
-            const float x = in.expr[t * cfg.NE + e];
-            d += ke * (w[VHAP_FW_REG_EXPR] * dt_[3] * x + w[VHAP_FW_SMOOTH_EXPR] * dt_[4] * (x - in.expr[p * cfg.NE + e]));
-            atomicAdd(&g.expr[t * cfg.NE + e], d);
-        }
-    }
-    if (g.offset && in.offset) {
-        for (int m = tid; m < in.M; m += FP_THREADS) {
-            const int v = in.Jv[m];
-            float a[3] = {0.f, 0.f, 0.f};
-            for (int j = 0; j < cfg.J; j++) {
-                const float wv = in.Jw[(size_t)m * cfg.J + j];
-                a[0] += wv * dJl[3 * j]; a[1] += wv * dJl[3 * j + 1]; a[2] += wv * dJl[3 * j + 2];
+    {
+        const int NO = JT ? 3 * JT : 3 * MAXJ, last = 3 * cfg.J - 1;
+        float dj[3 * MAXJ];
+#pragma unroll
+        for (int o = 0; o < NO; o++) dj[o] = o <= last ? dJl[o] : 0.f;
+        for (int k = tid; k < NB; k += FP_THREADS) {
+            // all of this slice's loads first (compile-time trip count, unconditional: a run-time `o < 3J` loop is load -> wait -> fma 15 times)
+            const bool is_shape = k < cfg.NS;
+            const int e = is_shape ? 0 : k - cfg.NS;
+            float js[3 * MAXJ];
+#pragma unroll
+            for (int o = 0; o < NO; o++) js[o] = in.JS[(size_t)(o < last ? o : last) * NB + k];
+            const float r_d = *(drow ? drow + k : in.JS + k);                                       // (stand-in: JS has NB columns)
+            const float r_a = *(is_shape ? in.shape + k : in.expr + t * cfg.NE + e);
+            const float r_p = *(is_shape ? in.shape + k : in.expr + p * cfg.NE + e);
+            float d = drow ? r_d : 0.f;
+#pragma unroll
+            for (int o = 0; o < NO; o++) d += js[o] * dj[o];
+            if (is_shape) {
+                if (b == 0) d += 2.0f * w[VHAP_FW_REG_SHAPE] * dt_[5] * r_a / (float)cfg.NS;
+                if (g.shape) atomicAdd(&g.shape[k], d);
+            } else if (g.expr) {
+                const float x = r_a;
+                d += ke * (w[VHAP_FW_REG_EXPR] * dt_[3] * x + w[VHAP_FW_SMOOTH_EXPR] * dt_[4] * (x - r_p));
+                atomicAdd(&g.expr[t * cfg.NE + e], d);
             }
-            float* go = g.offset + (size_t)blockIdx.x * in.offset_stride + 3 * v;      // (per-frame offsets: this frame's row of the gradient)
-            atomicAdd(&go[0], a[0]); atomicAdd(&go[1], a[1]); atomicAdd(&go[2], a[2]);
+        }
+        if (g.offset && in.offset) {
+            const int NJ = JT ? JT : MAXJ;
+            for (int m = tid; m < in.M; m += FP_THREADS) {
+                const int v = in.Jv[m];
+                float wv[MAXJ];
+#pragma unroll
+                for (int j = 0; j < NJ; j++) wv[j] = in.Jw[(size_t)m * cfg.J + (j < cfg.J ? j : cfg.J - 1)];
+                float a[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < NJ; j++) { a[0] += wv[j] * dj[3 * j]; a[1] += wv[j] * dj[3 * j + 1]; a[2] += wv[j] * dj[3 * j + 2]; }
+                float* go = g.offset + (size_t)blockIdx.x * in.offset_stride + 3 * v;      // (per-frame offsets: this frame's row of the gradient)
+                atomicAdd(&go[0], a[0]); atomicAdd(&go[1], a[1]); atomicAdd(&go[2], a[2]);
+            }
         }
     }
 }

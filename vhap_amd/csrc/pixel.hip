@@ -306,13 +306,32 @@ __global__ __launch_bounds__(PB) void photo_fwd_kernel(const float4* __restrict_
             for (int i = (int)(bid * PB + threadIdx.x); i < count; i += (int)(nblk * PB)) aa_colour_bwd_item(E.aa_work, i, pred, gt, H, W, E.d_delta);
         }
     }
-    for (unsigned pi = bid * PB + threadIdx.x; pi < npix; pi += nblk * PB) {
-        const unsigned b = pi / HW, rem = pi - b * HW;
-        const unsigned y = rem / (unsigned)W, x = rem - y * (unsigned)W;
-        const float* g = gt + (size_t)b * 3 * HW + (size_t)(H - 1 - y) * W + x;
-        const float4 p = pred[pi];
-        s += fabsf(g[0] - p.x) + fabsf(g[HW] - p.y) + fabsf(g[2 * HW] - p.z);
-        n += p.w > 0.0f ? 1.0f : 0.0f;
+    // four pixels per trip, their sixteen loads issued before the first is consumed (clamped addresses past the end): one pixel per trip
+    // is load -> wait -> add with a run-time trip count, eight round trips in series per thread at 16 x 512^2.  The order of the
+    // additions into s is the one-pixel-per-trip order.
+    constexpr int PU = 4;
+    const unsigned stride = nblk * PB;
+    for (unsigned long long q0 = bid * PB + threadIdx.x; q0 < npix; q0 += (unsigned long long)PU * stride) {
+        const unsigned p0 = (unsigned)q0;
+        float4 pv[PU];
+        float g0[PU], g1[PU], g2[PU];
+#pragma unroll
+        for (int u = 0; u < PU; u++) {
+            const unsigned long long pq = (unsigned long long)p0 + (unsigned long long)u * stride;
+            const unsigned pi = pq < npix ? (unsigned)pq : npix - 1;
+            const unsigned b = pi / HW, rem = pi - b * HW;
+            const unsigned y = rem / (unsigned)W, x = rem - y * (unsigned)W;
+            const float* g = gt + (size_t)b * 3 * HW + (size_t)(H - 1 - y) * W + x;
+            pv[u] = pred[pi];
+            g0[u] = g[0]; g1[u] = g[HW]; g2[u] = g[2 * HW];
+        }
+#pragma unroll
+        for (int u = 0; u < PU; u++) {
+            if ((unsigned long long)p0 + (unsigned long long)u * stride < npix) {
+                s += fabsf(g0[u] - pv[u].x) + fabsf(g1[u] - pv[u].y) + fabsf(g2[u] - pv[u].z);
+                n += pv[u].w > 0.0f ? 1.0f : 0.0f;
+            }
+        }
     }
     s = vhap_wave_sum(s);
     n = vhap_wave_sum(n);

@@ -526,23 +526,46 @@ __global__ __launch_bounds__(256) void texbin_pass_kernel(const float2* __restri
     __syncthreads();
     int tile[TG_PPT];
     const long long p0 = (long long)blockIdx.x * (256 * TG_PPT) + tid;
+    // (tile_ids path: the thread's TG_PPT ids in one batch of loads, then -- count pass -- the gradients of its covered pixels in a second one,
+    // uncovered lanes re-reading pixel 0: one pixel per trip was id -> wait -> gradient -> wait, 2 x TG_PPT round trips in series)
+    unsigned short ids[TG_PPT];
+    float kp[TG_PPT];
+#pragma unroll
+    for (int k = 0; k < TG_PPT; k++) tile[k] = -1;
+    if (tile_ids) {
+#pragma unroll
+        for (int k = 0; k < TG_PPT; k++) {
+            const long long p = p0 + (long long)k * 256, pc = p < npix ? p : npix - 1;
+            ids[k] = tile_ids[pc];
+            kp[k] = *(keep ? keep + pc : reinterpret_cast<const float*>(tile_ids));       // (stand-in address, value unused)
+        }
+#pragma unroll
+        for (int k = 0; k < TG_PPT; k++) {
+            const long long p = p0 + (long long)k * 256;
+            tile[k] = (p < npix && ids[k] != 0xFFFF && !(keep && kp[k] == 0.f)) ? (int)ids[k] : -1;   // (keep == 0: colour replaced, no gradient)
+        }
+        if (!SCATTER && d_out) {
+            float gm[TG_PPT];
+#pragma unroll
+            for (int k = 0; k < TG_PPT; k++) {
+                const long long q = tile[k] >= 0 ? p0 + (long long)k * 256 : 0;
+                float m = 0.f;
+#pragma unroll
+                for (int c = 0; c < C; c++) m = fmaxf(m, fabsf(d_out[q * C + c]));
+                gm[k] = m;
+            }
+#pragma unroll
+            for (int k = 0; k < TG_PPT; k++)
+                if (tile[k] >= 0) atomicMax(&shb[tile[k]], __float_as_uint(gm[k]));
+        }
+#pragma unroll
+        for (int k = 0; k < TG_PPT; k++)
+            if (tile[k] >= 0) atomicAdd(&shc[tile[k]], 1u);
+    }
 #pragma unroll
     for (int k = 0; k < TG_PPT; k++) {
         const long long p = p0 + (long long)k * 256;
-        tile[k] = -1;
-        if (p < npix && tile_ids) {
-            const int tl = (int)tile_ids[p];
-            if (tl != 0xFFFF && !(keep && keep[p] == 0.f)) {       // (keep == 0: the pixel's colour was replaced, no gradient reaches its texels)
-                tile[k] = tl;
-                atomicAdd(&shc[tl], 1u);
-                if (!SCATTER && d_out) {
-                    float gmax = 0.f;
-#pragma unroll
-                    for (int c = 0; c < C; c++) gmax = fmaxf(gmax, fabsf(d_out[p * C + c]));
-                    atomicMax(&shb[tl], __float_as_uint(gmax));
-                }
-            }
-        } else if (p < npix) {
+        if (!tile_ids && p < npix) {
             float gmax = 0.f;
 #pragma unroll
             for (int c = 0; c < C; c++) gmax = fmaxf(gmax, fabsf(d_out[p * C + c]));
@@ -626,6 +649,10 @@ __global__ __launch_bounds__(256) void texgrad_tile_kernel(const TexDesc D, cons
     const unsigned beg = offsets[t], end = offsets[t + 1];
     if (beg == end) return;
     for (int i = tid; i < G.cells * C; i += 256) tg_vals[i] = 0ull;
+    // the per-level tile geometry in LDS: indexed with a per-lane level, the kernel-argument arrays are fetched with GLOBAL loads -- three
+    // dependent round trips in front of every level's LDS atomics (like TexDesc::off, tex_sample.h: level_off)
+    __shared__ int s_nx[MAX_LEVELS + 1], s_ny[MAX_LEVELS + 1], s_off[MAX_LEVELS + 1];
+    if (tid <= MAX_LEVELS) { s_nx[tid] = G.nx[tid]; s_ny[tid] = G.ny[tid]; s_off[tid] = G.off[tid]; }
     __shared__ unsigned s_tmax;
     unsigned tmax_bits;
     if (tilemax) {
@@ -666,12 +693,13 @@ __global__ __launch_bounds__(256) void texgrad_tile_kernel(const TexDesc D, cons
         const int lx = x0 - tile_lo(tx, G.NT, w), ly = y0 - tile_lo(ty, G.NT, h);
         const float w00 = (1.f - fx) * (1.f - fy), w10 = fx * (1.f - fy), w01 = (1.f - fx) * fy, w11 = fx * fy;
         const float wq[4] = {w00, w10, w01, w11};
-        const bool local = lx >= 0 && ly >= 0 && lx + 1 < G.nx[l] && ly + 1 < G.ny[l];
+        const int nxl = s_nx[l], nyl = s_ny[l], offl = s_off[l];
+        const bool local = lx >= 0 && ly >= 0 && lx + 1 < nxl && ly + 1 < nyl;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int dx = q & 1, dy = q >> 1;
             if (local) {
-                unsigned long long* cell = tg_vals + (size_t)(G.off[l] + (ly + dy) * G.nx[l] + lx + dx) * C;
+                unsigned long long* cell = tg_vals + (size_t)(offl + (ly + dy) * nxl + lx + dx) * C;
 #pragma unroll
                 for (int k = 0; k < C; k++) {
                     const float val = wq[q] * (g[k] * wgt);
@@ -709,12 +737,11 @@ __global__ __launch_bounds__(256) void texgrad_tile_kernel(const TexDesc D, cons
         float2 c[TG_UNR];
         float4 da[TG_UNR];
 #pragma unroll
-        for (int u = 0; u < TG_UNR; u++) {
-            if (!ok[u]) continue;
+        for (int u = 0; u < TG_UNR; u++) {      // (unconditional: lanes past the end re-read pixel 0; a load per `if (ok)` is a round trip each)
 #pragma unroll
             for (int k = 0; k < C; k++) g[u][k] = d_out[p[u] * C + k];
             c[u] = uv[p[u]];
-            if (uv_da) da[u] = uv_da[p[u]];
+            da[u] = *(uv_da ? uv_da + p[u] : reinterpret_cast<const float4*>(uv));
         }
 #pragma unroll
         for (int u = 0; u < TG_UNR; u++) {

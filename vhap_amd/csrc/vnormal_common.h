@@ -7,12 +7,33 @@
 __device__ __forceinline__ void vhap_vnormal_vertex(const float* __restrict__ P, const int* __restrict__ tri, const int* __restrict__ vc_ptr,
                                                     const int* __restrict__ vc_idx, int v, float* __restrict__ o, float* __restrict__ inv_len) {
     float nx = 0.f, ny = 0.f, nz = 0.f;
-    for (int k = vc_ptr[v]; k < vc_ptr[v + 1]; k++) {
-        const int t = vc_idx[k] / 3;
-        const int i0 = tri[3 * t], i1 = tri[3 * t + 1], i2 = tri[3 * t + 2];
-        const float ax = P[3 * i1] - P[3 * i0], ay = P[3 * i1 + 1] - P[3 * i0 + 1], az = P[3 * i1 + 2] - P[3 * i0 + 2];
-        const float bx = P[3 * i2] - P[3 * i0], by = P[3 * i2 + 1] - P[3 * i0 + 1], bz = P[3 * i2 + 2] - P[3 * i0 + 2];
-        nx += ay * bz - az * by; ny += az * bx - ax * bz; nz += ax * by - ay * bx;
+    // the incident faces FOUR at a time (corner ids -> vertex ids -> positions: three dependent round trips per batch instead of per
+    // face -- at valence ~6 this walk was ~18 of them in series and set the duration of the launch it rides in); summed in list order
+    constexpr int FB = 4;
+    const int k0 = vc_ptr[v], k1 = vc_ptr[v + 1];
+    for (int k = k0; k < k1; k += FB) {
+        int cc[FB], ii[FB][3];
+        float p_[FB][3][3];
+#pragma unroll
+        for (int u = 0; u < FB; u++) cc[u] = vc_idx[k + u < k1 ? k + u : k1 - 1];
+#pragma unroll
+        for (int u = 0; u < FB; u++) {
+            const int t = cc[u] / 3;
+            ii[u][0] = tri[3 * t]; ii[u][1] = tri[3 * t + 1]; ii[u][2] = tri[3 * t + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < FB; u++)
+#pragma unroll
+            for (int q = 0; q < 3; q++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) p_[u][q][c] = P[3 * ii[u][q] + c];
+#pragma unroll
+        for (int u = 0; u < FB; u++) {
+            if (k + u >= k1) break;
+            const float ax = p_[u][1][0] - p_[u][0][0], ay = p_[u][1][1] - p_[u][0][1], az = p_[u][1][2] - p_[u][0][2];
+            const float bx = p_[u][2][0] - p_[u][0][0], by = p_[u][2][1] - p_[u][0][1], bz = p_[u][2][2] - p_[u][0][2];
+            nx += ay * bz - az * by; ny += az * bx - ax * bz; nz += ax * by - ay * bx;
+        }
     }
     float l2 = nx * nx + ny * ny + nz * nz;
     const bool fallback = !(l2 > 1e-20f);
