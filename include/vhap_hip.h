@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VHAP_ABI_VERSION 7
+#define VHAP_ABI_VERSION 8
 
 #define VHAP_OK 0
 #define VHAP_E_NULLPTR (-1)   /* a required pointer is NULL */
@@ -528,6 +528,31 @@ int vhap_camera_focal_bwd(const float* RT, const float* d_mvp, int B, int RT_bat
 int vhap_camera_focal_fwd(const float* focal_length, float focal_scale, float cx, float cy, const float* RT, int B,
                           int RT_batched, int H, int W, float near_plane, float far_plane, float* mvp,
                           vhap_stream_t stream);
+/* vhap_frame_prep_fwd + vhap_camera_focal_fwd / vhap_frame_prep_bwd + vhap_camera_focal_bwd in ONE launch each (the camera is one more
+ * workgroup of the per-frame kernel: FlameHead.forward and the camera set-up of the reference, tracker.py:141-157, are independent of each
+ * other, and as launches of their own the two camera kernels sat on the step's critical path -- 7 us at its head, an event record and a
+ * wait at its tail).  Same arguments, same results (bit for bit) as the two calls. */
+int vhap_frame_prep_fwd_camera(const int64_t* timesteps, const float* shape, const float* expr,
+                               const float* rotation, const float* translation, const float* neck,
+                               const float* jaw, const float* eyes, const float* JT, const float* JS,
+                               const int32_t* jreg_idx, const float* jreg_w, int jreg_n,
+                               const float* static_offset, const int32_t* parents,
+                               const float* weights, int B, int Bp, int N, int NS, int NE, int J, int Kp, int V,
+                               float* coef, float* A, float* transl, float* Jrest, float* terms, int call_flags,
+                               const float* focal_length, float focal_scale, float cx, float cy, const float* RT,
+                               int RT_batched, int H, int W, float near_plane, float far_plane, float* mvp,
+                               vhap_stream_t stream);
+int vhap_frame_prep_bwd_camera(const int64_t* timesteps, const float* shape, const float* expr,
+                               const float* rotation, const float* translation, const float* neck,
+                               const float* jaw, const float* eyes, const float* JS, const int32_t* jreg_idx,
+                               const float* jreg_w, int jreg_n, const float* static_offset,
+                               const int32_t* parents, const float* weights,
+                               const float* Jrest, const float* d_coef, const float* d_A, const float* d_transl,
+                               const float* d_terms, int B, int Bp, int N, int NS, int NE, int J, int Kp, int V,
+                               float* g_shape, float* g_expr, float* g_rotation, float* g_translation,
+                               float* g_neck, float* g_jaw, float* g_eyes, float* g_offset, int call_flags,
+                               const float* RT, const float* d_mvp, int RT_batched, int H, int W, float focal_scale,
+                               float* d_focal_accum, vhap_stream_t stream);
 /* Landmark energy (lbs.vertices2landmarks, vhap/model/lbs.py:60-98 + compute_lmk_energy, tracker.py:347-389):
  * mean over B x [l0,l1) of (|du| + |dv|) conf, with conf x boost for landmarks [boost0,boost1).
  *   lmk_vidx [L,3] int32 vertex ids of each landmark's triangle, lmk_bary [L,3], lmk2d [B,L2,3] = u, v, confidence (pixels)

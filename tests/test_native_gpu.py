@@ -329,3 +329,31 @@ def test_native_step_reads_nothing_before_writing_it(flame_model, monkeypatch):
     for k in ga:
         assert torch.isfinite(gb[k]).all(), k
         assert float((ga[k] - gb[k]).abs().max()) <= 1e-3 * float(ga[k].abs().max()) + 1e-12, k
+
+
+def test_camera_rides_in_the_per_frame_launches_bit_exact(tracker):
+    """vhap_frame_prep_fwd_camera / vhap_frame_prep_bwd_camera (the uncalibrated camera as one more workgroup of the per-frame kernels) ==
+    vhap_camera_focal_fwd / vhap_camera_focal_bwd on the same buffers, bit for bit."""
+    from vhap_amd import _lib
+    from vhap_amd.ops import _p, _stream
+    from vhap_amd.step import NativeStep, _chk
+    tr = tracker
+    stage = "rgb_global_tracking"
+    try:
+        ns = NativeStep(tr, tr.get_sample(np.array([0, 2, 3]), device_index=True), stage)
+        assert not ns.calibrated
+        ns.forward()
+        ns.backward(1)
+        torch.cuda.synchronize()
+        L, B, H, W = _lib.lib(), ns.B, ns.H, ns.W
+        mvp = torch.full_like(ns.mvp, float("nan"))
+        _chk(L.vhap_camera_focal_fwd(_p(tr.focal_length), ns.focal_scale, 0.5 * W, 0.5 * H, _p(ns.RT), B, 0, H, W, 0.1, 10.0, _p(mvp), _stream()),
+             "vhap_camera_focal_fwd")
+        d_f = torch.zeros_like(ns.g["focal_length"])
+        _chk(L.vhap_camera_focal_bwd(_p(ns.RT), _p(ns.d_mvp), B, 0, H, W, ns.focal_scale, _p(d_f), _stream()), "vhap_camera_focal_bwd")
+        torch.cuda.synchronize()
+        assert torch.equal(mvp, ns.mvp)
+        assert float(ns.d_mvp.abs().max()) > 0 and torch.equal(d_f, ns.g["focal_length"])
+    finally:
+        for p in tr._train_tensors:
+            p.grad = None

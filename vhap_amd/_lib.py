@@ -84,6 +84,10 @@ SIGNATURES = {
     "vhap_vnormal_bwd_saved": (c_i, [c_fp] * 7 + [c_i, c_i, c_i, c_fp, c_fp, c_fp]),
     "vhap_frame_prep_fwd": (c_i, [c_fp] * 12 + [c_i] + [c_fp] * 3 + [c_i] * 8 + [c_fp] * 5 + [c_i, c_fp]),
     "vhap_frame_prep_bwd": (c_i, [c_fp] * 11 + [c_i] + [c_fp] * 8 + [c_i] * 8 + [c_fp] * 8 + [c_i, c_fp]),
+    "vhap_frame_prep_fwd_camera": (c_i, [c_fp] * 12 + [c_i] + [c_fp] * 3 + [c_i] * 8 + [c_fp] * 5 + [c_i] +
+                                   [c_fp, c_f, c_f, c_f, c_fp, c_i, c_i, c_i, c_f, c_f, c_fp, c_fp]),
+    "vhap_frame_prep_bwd_camera": (c_i, [c_fp] * 11 + [c_i] + [c_fp] * 8 + [c_i] * 8 + [c_fp] * 8 + [c_i] +
+                                   [c_fp, c_fp, c_i, c_i, c_i, c_f, c_fp, c_fp]),
     "vhap_offset_dynamic_reg": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_f, c_fp, c_fp, c_fp, c_fp]),
     "vhap_offset_grad_finish": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
     "vhap_camera_fwd": (c_i, [c_fp, c_fp] + [c_i] * 5 + [c_f, c_f, c_fp, c_fp]),
@@ -133,7 +137,7 @@ SIGNATURES = {
     "vhap_plan_launch_timed": (c_i, [c_fp, c_fp, ctypes.POINTER(c_f), ctypes.POINTER(c_f), c_i]),
 }
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 # call_flags of include/vhap_hip.h (per-call arguments since ABI 2; the library keeps no mutable state)
 CALL_ACC_PREZEROED, CALL_AA_PASSTHROUGH_DONE, CALL_ADAM_KEEP_STEP, CALL_ADAM_STEP_ADVANCED, CALL_OFFSET_PER_FRAME = 1, 2, 4, 16, 32
 CALL_PLAN_DEFER_JOIN = 64

@@ -25,6 +25,10 @@ constexpr int DB = 256;   // threads per counting-sort workgroup
 constexpr int PPT = 8;    // pixels per thread: a workgroup owns DB * PPT consecutive pixels (2048: 2048 workgroups at 16x512^2, all resident)
 constexpr int DPIX = DB * PPT;
 constexpr int PB = 1024;  // threads of the single prefix workgroup
+#ifndef VHAP_DISTURB_APT
+#define VHAP_DISTURB_APT 1
+#endif
+constexpr int APT = VHAP_DISTURB_APT;   // pixels per thread of the apply pass
 
 // cluster of pixel p: from the compact one-byte cluster image when the shading kernel wrote one (4 MB instead of a 67 MB pass over
 // the rasteriser output at 16x512^2), else through the triangle id of rast and the fid -> cluster table
@@ -233,34 +237,65 @@ __global__ __launch_bounds__(256) void disturb_apply_kernel(const float4* __rest
         s_tot[threadIdx.x] = own;
     }
     __syncthreads();
+    // APT pixels per thread (p0 + it * 256), three batches of loads: clusters, (injected draws,) the drawn colours.  The kernel is a random
+    // 16-byte gather over a 67 MB pool and sits at s_waitcnt for 84 % of its wave-cycles (profiles/r04_call22_step_sq_pmc.json) -- but
+    // four gathers in flight per lane instead of one change nothing (59.3 vs 58.2 us, profiles/r04_call29_apply_photo_ab.txt): it is bound
+    // by the 64-byte sectors the gather drags in (253 MB read for 67 MB used), not by the round trip.  APT = 1 is shipped.
     const long long n = (long long)B * H * W;
-    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (p >= n) return;
-    int c = pixel_cluster(src, p);
-    if (c >= MAXC) c = 1;                           // (treated like 'face in no cluster': never disturbed)
-    int w;
-    unsigned long long pick;
+    const long long p0 = (long long)blockIdx.x * (256 * APT) + threadIdx.x;
+    int cs[APT];
+    pixel_clusters<APT>(src, p0, 256, n, cs);
+    int wd[APT];
+    unsigned long long pick[APT];
     if (rng_state) {     // in-kernel random numbers: Bernoulli(rate) and a 32-bit index draw per pixel
         const unsigned seed = rng_state[0];
-        const float u = (float)(rnd32(seed, (unsigned)p, 0u) >> 8) * (1.0f / 16777216.0f);
-        w = c == 0 ? (u < rate_bg) : (c == 1 ? 0 : (u < rate_fg));
-        pick = rnd32(seed, (unsigned)p, 1u);
+#pragma unroll
+        for (int it = 0; it < APT; it++) {
+            const unsigned p = (unsigned)(p0 + (long long)it * 256);
+            const int c = cs[it] >= MAXC ? 1 : cs[it];
+            const float u = (float)(rnd32(seed, p, 0u) >> 8) * (1.0f / 16777216.0f);
+            wd[it] = c == 0 ? (u < rate_bg) : (c == 1 ? 0 : (u < rate_fg));
+            pick[it] = rnd32(seed, p, 1u);
+        }
     } else {
-        w = c == 0 ? w_bg[p] : (c == 1 ? 0 : w_fg[p]);
-        pick = (unsigned long long)idx[p];
+        int r_fg[APT], r_bg[APT];
+        long long r_ix[APT];
+#pragma unroll
+        for (int it = 0; it < APT; it++) {
+            const long long p = p0 + (long long)it * 256, pc = p < n ? p : n - 1;
+            r_fg[it] = w_fg[pc]; r_bg[it] = w_bg[pc]; r_ix[it] = idx[pc];
+        }
+#pragma unroll
+        for (int it = 0; it < APT; it++) {
+            const int c = cs[it] >= MAXC ? 1 : cs[it];
+            wd[it] = c == 0 ? r_bg[it] : (c == 1 ? 0 : r_fg[it]);
+            pick[it] = (unsigned long long)r_ix[it];
+        }
     }
-    const int nc = s_tot[c];
-    float k = 1.0f;
-    if (w != 0 && nc > 0) {
+    bool dis[APT];
+    float4 col[APT];
+#pragma unroll
+    for (int it = 0; it < APT; it++) {
+        const long long p = p0 + (long long)it * 256;
+        int c = cs[it];                                 // (-1 past the end)
+        if (c >= MAXC) c = 1;                           // (treated like 'face in no cluster': never disturbed)
+        const int nc = c >= 0 ? s_tot[c] : 0;
+        dis[it] = p < n && wd[it] != 0 && nc > 0;
         // injected indices: idx % n like the reference's randint-then-index (a 64-bit division per disturbed pixel -- parity path only);
         // in-kernel draws: floor(r * n / 2^32), the same distribution without a division
-        const int j = rng_state ? (int)((pick * (unsigned long long)nc) >> 32) : (int)(pick % (unsigned long long)nc);
-        out[p] = pool[s_start[c] + j];
-        k = 0.0f;
-    } else if (!INPLACE) {
-        out[p] = rgba[p];   // after compositing, background pixels of `rgba` already hold the background colour
+        const int j = !dis[it] ? 0 : (rng_state ? (int)((pick[it] * (unsigned long long)nc) >> 32) : (int)(pick[it] % (unsigned long long)nc));
+        const float4* q = dis[it] ? pool + (s_start[c] + j) : (INPLACE ? pool : rgba + (p < n ? p : n - 1));
+        col[it] = *q;                                   // (in place, an undisturbed pixel re-reads pool[0]: unused)
     }
-    keep[p] = k;
+#pragma unroll
+    for (int it = 0; it < APT; it++) asm volatile("" ::"v"(col[it].x), "v"(col[it].y), "v"(col[it].z), "v"(col[it].w));
+#pragma unroll
+    for (int it = 0; it < APT; it++) {
+        const long long p = p0 + (long long)it * 256;
+        if (p >= n) continue;
+        if (dis[it] || !INPLACE) out[p] = col[it];      // (not in place: after compositing, background pixels of `rgba` already hold the background colour)
+        keep[p] = dis[it] ? 0.0f : 1.0f;
+    }
 }
 
 __global__ __launch_bounds__(256) void disturb_bwd_kernel(const float4* __restrict__ d_out, const float* __restrict__ keep, long long n,
@@ -305,10 +340,10 @@ static int disturb_run(const float* rgba, const float* rast, const uint8_t* cid,
     disturb_scatter_kernel<<<nblocks, DB, 0, st>>>(src, in, ncl, n, block_counts, totals, pool);
     VHAP_LAUNCH_CHECK();
     if (out == rgba)
-        disturb_apply_kernel<true><<<vhap_cdiv(n, 256), 256, 0, st>>>(in, B, H, W, src, w_fg, w_bg, reinterpret_cast<const long long*>(idx),
+        disturb_apply_kernel<true><<<vhap_cdiv(n, 256 * APT), 256, 0, st>>>(in, B, H, W, src, w_fg, w_bg, reinterpret_cast<const long long*>(idx),
                                                                      rng_state, rate_fg, rate_bg, totals, pool, reinterpret_cast<float4*>(out), keep);
     else
-        disturb_apply_kernel<false><<<vhap_cdiv(n, 256), 256, 0, st>>>(in, B, H, W, src, w_fg, w_bg, reinterpret_cast<const long long*>(idx),
+        disturb_apply_kernel<false><<<vhap_cdiv(n, 256 * APT), 256, 0, st>>>(in, B, H, W, src, w_fg, w_bg, reinterpret_cast<const long long*>(idx),
                                                                       rng_state, rate_fg, rate_bg, totals, pool, reinterpret_cast<float4*>(out), keep);
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;

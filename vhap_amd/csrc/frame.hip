@@ -109,6 +109,61 @@ __device__ __forceinline__ void rodrigues_bwd(const float* r, const Mat3& dR, fl
 // (dynamic indexing), which costs ~50 us of serial latency per launch.
 __device__ __forceinline__ constexpr int flame_parent(int j) { return j == 0 ? -1 : (j == 1 ? 0 : 1); }
 
+// The uncalibrated camera (tracker.py:148-157) rides in the per-frame launches as ONE more workgroup (vhap_frame_prep_fwd_camera /
+// vhap_frame_prep_bwd_camera): its forward is a 7 us single-wave kernel at the head of the step's critical path, its backward a
+// side-stream launch whose event record and wait sat in front of the last two kernels of the step.
+struct CamFwdJob {
+    const float *focal, *RT;          // focal == null: no job
+    float fscale, cx, cy, h, w, near, far;
+    int B, rtstride;
+    float* mvp;
+};
+struct CamBwdJob {
+    const float *RT, *d_mvp;          // RT == null: no job
+    float h, w, scale;
+    int B, rtstride;
+    float* d_focal;
+};
+// mvp = P(K) [RT; 0 0 0 1], one lane per (frame, column): the body of camera_fwd_kernel for K = (f, f, cx, cy), f = focal[0] * fscale
+__device__ __forceinline__ void camera_focal_fwd_item(const CamFwdJob& c, int i) {
+    const int b = i >> 2, col = i & 3;
+    const float f = c.focal[0] * c.fscale;
+    const float* rt = c.RT + (size_t)b * c.rtstride;
+    const float mv0 = rt[col], mv1 = rt[4 + col], mv2 = rt[8 + col], mv3 = col == 3 ? 1.0f : 0.0f;
+    float* m = c.mvp + (size_t)b * 16;
+    const float w = c.w, h = c.h, near = c.near, far = c.far;
+    m[col] = f * 2.0f / w * mv0 + (w - 2.0f * c.cx) / w * mv2;
+    m[4 + col] = f * 2.0f / h * mv1 + (h - 2.0f * c.cy) / h * mv2;
+    m[8 + col] = -(far + near) / (far - near) * mv2 + (-2.0f * far * near / (far - near)) * mv3;
+    m[12 + col] = -mv2;
+}
+// d(focal_length) += scale * sum_b (dK[b].fx + dK[b].fy): the body of camera_focal_bwd_kernel, run by the first 64 threads of a workgroup
+// (every thread of the workgroup must call: barriers inside).  part: 64 floats of LDS.
+__device__ __forceinline__ void camera_focal_bwd_block(const CamBwdJob& c, float* part) {
+    float s = 0.f;
+    for (int b0 = 0; b0 < c.B; b0 += 64) {
+        const int b = b0 + (int)threadIdx.x;
+        float v = 0.f;
+        if (threadIdx.x < 64 && b < c.B) {
+            const float* rt = c.RT + (size_t)b * c.rtstride;
+            const float* d = c.d_mvp + (size_t)b * 16;
+            float g0 = 0.f, g1 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                g0 += d[k] * rt[k];
+                g1 += d[4 + k] * rt[4 + k];
+            }
+            v = g0 * 2.0f / c.w + g1 * 2.0f / c.h;
+        }
+        if (threadIdx.x < 64) part[threadIdx.x] = v;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (int k = 0; k < min(64, c.B - b0); k++) s += part[k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) c.d_focal[0] += s * c.scale;
+}
+
 struct FrameIn {
     const long long* ts;
     const float *shape, *expr, *rotation, *translation, *neck, *jaw, *eyes;
@@ -144,20 +199,34 @@ __device__ __forceinline__ float block_sum(float v, float* red /*[FP_THREADS/64]
 template <int JT>   // JT = 5: FLAME tree, fully unrolled; JT = 0: generic tree from cfg.parents
 __global__ __launch_bounds__(FP_THREADS) void frame_prep_fwd_kernel(FrameCfg cfg, FrameIn in, float* __restrict__ coef,
                                                                     float* __restrict__ A, float* __restrict__ transl,
-                                                                    float* __restrict__ Jrest, float* __restrict__ terms) {
-    __shared__ float beta[1024];
+                                                                    float* __restrict__ Jrest, float* __restrict__ terms, const CamFwdJob cam) {
     __shared__ float Jl[3 * MAXJ];
     __shared__ float red[FP_THREADS / 64];
     const int b = blockIdx.x, tid = threadIdx.x;
+    if (b == cfg.Bp) {          // the workgroup behind the frames': the camera (launched only with a job)
+        for (int i = tid; i < cam.B * 4; i += FP_THREADS) camera_focal_fwd_item(cam, i);
+        return;
+    }
     const int NB = cfg.NS + cfg.NE;
     float* row = coef + (size_t)b * cfg.Kp;
     if (b >= cfg.B) {   // padding rows of the MFMA tile
         for (int k = tid; k < cfg.Kp; k += FP_THREADS) row[k] = 0.f;
         return;
     }
+    // ---- all global loads of this kernel in two levels: what needs nothing (the offset list's first slice, JT) and the timestep index;
+    // then what needs those (pose rows, coefficient slices with their JS columns, the listed vertices' offsets).  One workgroup per frame
+    // has nothing to hide a round trip behind, and next to the bandwidth-bound texture assembly a round trip is 2-4 us: as separate
+    // loops (coefficients -> three block sums -> JS slices -> vertex list -> weights / offsets) the kernel was ~8 of them long. ----
+    const int NO = JT ? 3 * JT : 3 * MAXJ, NJ = JT ? JT : MAXJ, last = 3 * cfg.J - 1;
+    const bool has_off = in.offset != nullptr && in.M > 0;
+    const int m0 = has_off ? min(tid, in.M - 1) : 0;
+    const int jv0 = *(has_off ? in.Jv + m0 : reinterpret_cast<const int*>(in.JT));           // (stand-in address: value unused)
+    float wv0[MAXJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) wv0[j] = *(has_off ? in.Jw + (size_t)m0 * cfg.J + (j < cfg.J ? j : cfg.J - 1) : in.JT);
+    const float jt_v = in.JT[tid < 3 * cfg.J ? tid : 3 * cfg.J - 1];
     const long long t = in.ts[b], p = t > 0 ? t - 1 : 0;
-    // what depends on the timestep alone is requested NOW and consumed after the joint regression (clamped lanes instead of branches: a
-    // branch around a load ends in a join, where the compiler waits for it): the pose rows of this and the previous timestep, JT
+    // (clamped lanes instead of branches: a branch around a load ends in a join, where the compiler waits for it)
     const int spc = tid < 2 * 18 ? tid : 2 * 18 - 1, sp_which = spc / 18, sp_i = spc - 18 * sp_which;
     const long long sp_ts = sp_which ? p : t;
     const float* sp_src = sp_i < 3 ? in.rotation + 3 * sp_ts + sp_i
@@ -165,46 +234,47 @@ __global__ __launch_bounds__(FP_THREADS) void frame_prep_fwd_kernel(FrameCfg cfg
                         : (sp_i < 9 ? in.jaw + 3 * sp_ts + (sp_i - 6)
                         : (sp_i < 15 ? in.eyes + 6 * sp_ts + (sp_i - 9) : in.translation + 3 * sp_ts + (sp_i - 15))));
     const float sp_v = *sp_src;
-    const float jt_v = in.JT[tid < 3 * cfg.J ? tid : 3 * cfg.J - 1];
+    const float* of0 = has_off ? in.offset + (size_t)blockIdx.x * in.offset_stride + 3 * jv0 : in.JT;
+    const float of0x = of0[0], of0y = of0[1], of0z = of0[2];
     float e_reg = 0.f, e_smooth = 0.f, e_shape = 0.f;
+    float part[3 * MAXJ];
+#pragma unroll
+    for (int o = 0; o < 3 * MAXJ; o++) part[o] = 0.f;
+    // coefficient row + rest joints J = JT + JS betas: a lane's coefficient k and column k of JS in the same trip (rows of JS past 3J
+    // re-read the last one into sums nobody reads; coefficients past NB re-read the last one, unused)
     for (int k = tid; k < cfg.Kp; k += FP_THREADS) {
+        const int kc = k < NB ? k : NB - 1;
+        const bool is_shape = kc < cfg.NS;
+        const float a = *(is_shape ? in.shape + kc : in.expr + t * cfg.NE + (kc - cfg.NS));
+        const float pr = *(is_shape ? in.shape + kc : in.expr + p * cfg.NE + (kc - cfg.NS));
+        float js[3 * MAXJ];
+#pragma unroll
+        for (int o = 0; o < NO; o++) js[o] = in.JS[(size_t)(o < last ? o : last) * NB + kc];
         float v = 0.f;
-        if (k < cfg.NS) {
-            v = in.shape[k];
-            e_shape += v * v;
-        } else if (k < NB) {
-            v = in.expr[t * cfg.NE + (k - cfg.NS)];
-            const float d = v - in.expr[p * cfg.NE + (k - cfg.NS)];
-            e_reg += v * v;
-            e_smooth += d * d;
+        if (k < NB) {
+            v = a;
+            if (is_shape) {
+                e_shape += v * v;
+            } else {
+                const float d = v - pr;
+                e_reg += v * v;
+                e_smooth += d * d;
+            }
+#pragma unroll
+            for (int o = 0; o < NO; o++) part[o] += js[o] * v;
         }
-        if (k < NB) beta[k] = v;
         if (k < NB || k >= NB + cfg.P) row[k] = v;
     }
     e_reg = block_sum(e_reg, red);
     e_smooth = block_sum(e_smooth, red);
     e_shape = block_sum(e_shape, red);
-    // rest joints J = JT + JS betas (+ J_regressor offset): every lane takes a strided slice of the reduction axis for ALL 3J
-    // outputs (independent loads, no dependent chain), then 3J block reductions
     {
-        float part[3 * MAXJ];
+        if (has_off) {          // (+ J_regressor offset.)  J_regressor is sparse (a few hundred non-zero columns): compact list instead of a walk over all V
+            if (tid < in.M) {
 #pragma unroll
-        for (int o = 0; o < 3 * MAXJ; o++) part[o] = 0.f;
-        // (the loads are UNCONDITIONAL -- rows past 3J re-read the last one into sums nobody reads: a load behind `if (o < 3J)` is its own
-        // basic block, load -> wait -> fma, and this kernel is one workgroup per frame with nothing to hide a round trip behind: 15 of them
-        // per slice, in series, were most of its 34 us)
-        const int NO = JT ? 3 * JT : 3 * MAXJ, last = 3 * cfg.J - 1;
-        for (int k = tid; k < NB; k += FP_THREADS) {
-            const float bk = beta[k];
-            float js[3 * MAXJ];
-#pragma unroll
-            for (int o = 0; o < NO; o++) js[o] = in.JS[(size_t)(o < last ? o : last) * NB + k];
-#pragma unroll
-            for (int o = 0; o < NO; o++) part[o] += js[o] * bk;
-        }
-        if (in.offset) {        // J_regressor is sparse (a few hundred non-zero columns): compact list instead of a walk over all V
-            const int NJ = JT ? JT : MAXJ;
-            for (int m = tid; m < in.M; m += FP_THREADS) {
+                for (int j = 0; j < NJ; j++) { part[3 * j] += wv0[j] * of0x; part[3 * j + 1] += wv0[j] * of0y; part[3 * j + 2] += wv0[j] * of0z; }
+            }
+            for (int m = tid + FP_THREADS; m < in.M; m += FP_THREADS) {        // (lists longer than the workgroup: the general loop)
                 const int v = in.Jv[m];
                 float wv[MAXJ];
 #pragma unroll
@@ -330,8 +400,13 @@ template <int JT>
 __global__ __launch_bounds__(FP_THREADS) void frame_prep_bwd_kernel(FrameCfg cfg, FrameIn in, const float* __restrict__ Jrest,
                                                                     const float* __restrict__ d_coef, const float* __restrict__ d_A,
                                                                     const float* __restrict__ d_transl,
-                                                                    const float* __restrict__ d_terms, FrameGrad g) {
+                                                                    const float* __restrict__ d_terms, FrameGrad g, const CamBwdJob cam) {
     __shared__ float dJl[3 * MAXJ];
+    if ((int)blockIdx.x == cfg.B) {      // the workgroup behind the frames': the camera backward (launched only with a job)
+        __shared__ float cam_part[64];
+        camera_focal_bwd_block(cam, cam_part);
+        return;
+    }
     const int b = blockIdx.x, tid = threadIdx.x;
     const int NB = cfg.NS + cfg.NE;
     const long long t = in.ts[b], p = t > 0 ? t - 1 : 0;
@@ -543,7 +618,7 @@ __global__ __launch_bounds__(FP_THREADS) void frame_prep_bwd_kernel(FrameCfg cfg
 }
 
 bool make_cfg(FrameCfg& c, int B, int Bp, int N, int NS, int NE, int J, int Kp, int V, const int32_t* parents, const float* weights) {
-    if (B <= 0 || Bp < B || N <= 0 || NS < 0 || NE < 0 || J <= 0 || J > MAXJ || NS + NE > 1024 || NS + NE + 9 * (J - 1) > Kp || !parents) return false;
+    if (B <= 0 || Bp < B || N <= 0 || NS < 0 || NE < 0 || NS + NE < 1 || J <= 0 || J > MAXJ || NS + NE > 1024 || NS + NE + 9 * (J - 1) > Kp || !parents) return false;
     c.B = B; c.Bp = Bp; c.N = N; c.NS = NS; c.NE = NE; c.J = J; c.P = 9 * (J - 1); c.Kp = Kp; c.V = V;
     for (int j = 0; j < MAXJ; j++) c.parents[j] = j < J ? parents[j] : -1;
     for (int j = 1; j < J; j++)
@@ -554,13 +629,12 @@ bool make_cfg(FrameCfg& c, int B, int Bp, int N, int NS, int NE, int J, int Kp, 
 
 }  // namespace
 
-extern "C" int vhap_frame_prep_fwd(const int64_t* timesteps, const float* shape, const float* expr, const float* rotation,
-                                   const float* translation, const float* neck, const float* jaw, const float* eyes,
-                                   const float* JT, const float* JS, const int32_t* jreg_idx, const float* jreg_w, int jreg_n,
-                                   const float* static_offset, const int32_t* parents, const float* weights, int B, int Bp, int N,
-                                   int NS, int NE, int J, int Kp, int V, float* coef, float* A, float* transl, float* Jrest, float* terms,
-                                   int call_flags, vhap_stream_t stream) {
-    VHAP_ENTER();
+static int frame_prep_fwd_run(const int64_t* timesteps, const float* shape, const float* expr, const float* rotation,
+                              const float* translation, const float* neck, const float* jaw, const float* eyes,
+                              const float* JT, const float* JS, const int32_t* jreg_idx, const float* jreg_w, int jreg_n,
+                              const float* static_offset, const int32_t* parents, const float* weights, int B, int Bp, int N,
+                              int NS, int NE, int J, int Kp, int V, float* coef, float* A, float* transl, float* Jrest, float* terms,
+                              int call_flags, vhap_stream_t stream, const CamFwdJob& cam) {
     if (!timesteps || !shape || !expr || !rotation || !translation || !neck || !jaw || !eyes || !JT || !JS || !coef || !A ||
         !transl || !Jrest || !terms)
         return VHAP_E_NULLPTR;
@@ -572,8 +646,58 @@ extern "C" int vhap_frame_prep_fwd(const int64_t* timesteps, const float* shape,
     hipStream_t st = vhap_stream(stream);
     VHAP_ZERO_ACC(terms, 6 * sizeof(float), st);
     const bool flame_tree = J == 5 && parents[1] == 0 && parents[2] == 1 && parents[3] == 1 && parents[4] == 1;
-    if (flame_tree) frame_prep_fwd_kernel<5><<<Bp, FP_THREADS, 0, st>>>(cfg, in, coef, A, transl, Jrest, terms);
-    else frame_prep_fwd_kernel<0><<<Bp, FP_THREADS, 0, st>>>(cfg, in, coef, A, transl, Jrest, terms);
+    const int nwg = Bp + (cam.focal ? 1 : 0);
+    if (flame_tree) frame_prep_fwd_kernel<5><<<nwg, FP_THREADS, 0, st>>>(cfg, in, coef, A, transl, Jrest, terms, cam);
+    else frame_prep_fwd_kernel<0><<<nwg, FP_THREADS, 0, st>>>(cfg, in, coef, A, transl, Jrest, terms, cam);
+    VHAP_LAUNCH_CHECK();
+    return VHAP_OK;
+}
+
+extern "C" int vhap_frame_prep_fwd(const int64_t* timesteps, const float* shape, const float* expr, const float* rotation,
+                                   const float* translation, const float* neck, const float* jaw, const float* eyes,
+                                   const float* JT, const float* JS, const int32_t* jreg_idx, const float* jreg_w, int jreg_n,
+                                   const float* static_offset, const int32_t* parents, const float* weights, int B, int Bp, int N,
+                                   int NS, int NE, int J, int Kp, int V, float* coef, float* A, float* transl, float* Jrest, float* terms,
+                                   int call_flags, vhap_stream_t stream) {
+    VHAP_ENTER();
+    return frame_prep_fwd_run(timesteps, shape, expr, rotation, translation, neck, jaw, eyes, JT, JS, jreg_idx, jreg_w, jreg_n, static_offset, parents,
+                              weights, B, Bp, N, NS, NE, J, Kp, V, coef, A, transl, Jrest, terms, call_flags, stream, CamFwdJob{});
+}
+
+extern "C" int vhap_frame_prep_fwd_camera(const int64_t* timesteps, const float* shape, const float* expr, const float* rotation,
+                                          const float* translation, const float* neck, const float* jaw, const float* eyes,
+                                          const float* JT, const float* JS, const int32_t* jreg_idx, const float* jreg_w, int jreg_n,
+                                          const float* static_offset, const int32_t* parents, const float* weights, int B, int Bp, int N,
+                                          int NS, int NE, int J, int Kp, int V, float* coef, float* A, float* transl, float* Jrest,
+                                          float* terms, int call_flags, const float* focal_length, float focal_scale, float cx, float cy,
+                                          const float* RT, int RT_batched, int H, int W, float near_plane, float far_plane, float* mvp,
+                                          vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!focal_length || !RT || !mvp) return VHAP_E_NULLPTR;
+    if (H <= 0 || W <= 0 || !(far_plane > near_plane)) return VHAP_E_BADDIM;
+    const CamFwdJob cam{focal_length, RT, focal_scale, cx, cy, (float)H, (float)W, near_plane, far_plane, B, RT_batched ? 12 : 0, mvp};
+    return frame_prep_fwd_run(timesteps, shape, expr, rotation, translation, neck, jaw, eyes, JT, JS, jreg_idx, jreg_w, jreg_n, static_offset, parents,
+                              weights, B, Bp, N, NS, NE, J, Kp, V, coef, A, transl, Jrest, terms, call_flags, stream, cam);
+}
+
+static int frame_prep_bwd_run(const int64_t* timesteps, const float* shape, const float* expr, const float* rotation,
+                              const float* translation, const float* neck, const float* jaw, const float* eyes,
+                              const float* JS, const int32_t* jreg_idx, const float* jreg_w, int jreg_n, const float* static_offset,
+                              const int32_t* parents, const float* weights, const float* Jrest, const float* d_coef, const float* d_A,
+                              const float* d_transl, const float* d_terms, int B, int Bp, int N, int NS, int NE, int J, int Kp,
+                              int V, float* g_shape, float* g_expr, float* g_rotation, float* g_translation, float* g_neck,
+                              float* g_jaw, float* g_eyes, float* g_offset, int call_flags, vhap_stream_t stream, const CamBwdJob& cam) {
+    if (!timesteps || !shape || !expr || !rotation || !translation || !neck || !jaw || !eyes || !JS || !Jrest) return VHAP_E_NULLPTR;
+    if (g_offset && (!static_offset || (jreg_n > 0 && (!jreg_idx || !jreg_w)))) return VHAP_E_NULLPTR;
+    FrameCfg cfg;
+    if (!make_cfg(cfg, B, Bp, N, NS, NE, J, Kp, V, parents, weights)) return VHAP_E_BADDIM;
+    FrameIn in{reinterpret_cast<const long long*>(timesteps), shape, expr, rotation, translation, neck, jaw, eyes, nullptr, JS, jreg_w, static_offset, jreg_idx, jreg_n,
+               (call_flags & VHAP_CALL_OFFSET_PER_FRAME) ? 3ll * V : 0ll};
+    FrameGrad g{g_shape, g_expr, g_rotation, g_translation, g_neck, g_jaw, g_eyes, g_offset};
+    const bool flame_tree = J == 5 && parents[1] == 0 && parents[2] == 1 && parents[3] == 1 && parents[4] == 1;
+    const int nwg = B + (cam.RT ? 1 : 0);
+    if (flame_tree) frame_prep_bwd_kernel<5><<<nwg, FP_THREADS, 0, vhap_stream(stream)>>>(cfg, in, Jrest, d_coef, d_A, d_transl, d_terms, g, cam);
+    else frame_prep_bwd_kernel<0><<<nwg, FP_THREADS, 0, vhap_stream(stream)>>>(cfg, in, Jrest, d_coef, d_A, d_transl, d_terms, g, cam);
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;
 }
@@ -586,18 +710,27 @@ extern "C" int vhap_frame_prep_bwd(const int64_t* timesteps, const float* shape,
                                    int V, float* g_shape, float* g_expr, float* g_rotation, float* g_translation, float* g_neck,
                                    float* g_jaw, float* g_eyes, float* g_offset, int call_flags, vhap_stream_t stream) {
     VHAP_ENTER();
-    if (!timesteps || !shape || !expr || !rotation || !translation || !neck || !jaw || !eyes || !JS || !Jrest) return VHAP_E_NULLPTR;
-    if (g_offset && (!static_offset || (jreg_n > 0 && (!jreg_idx || !jreg_w)))) return VHAP_E_NULLPTR;
-    FrameCfg cfg;
-    if (!make_cfg(cfg, B, Bp, N, NS, NE, J, Kp, V, parents, weights)) return VHAP_E_BADDIM;
-    FrameIn in{reinterpret_cast<const long long*>(timesteps), shape, expr, rotation, translation, neck, jaw, eyes, nullptr, JS, jreg_w, static_offset, jreg_idx, jreg_n,
-               (call_flags & VHAP_CALL_OFFSET_PER_FRAME) ? 3ll * V : 0ll};
-    FrameGrad g{g_shape, g_expr, g_rotation, g_translation, g_neck, g_jaw, g_eyes, g_offset};
-    const bool flame_tree = J == 5 && parents[1] == 0 && parents[2] == 1 && parents[3] == 1 && parents[4] == 1;
-    if (flame_tree) frame_prep_bwd_kernel<5><<<B, FP_THREADS, 0, vhap_stream(stream)>>>(cfg, in, Jrest, d_coef, d_A, d_transl, d_terms, g);
-    else frame_prep_bwd_kernel<0><<<B, FP_THREADS, 0, vhap_stream(stream)>>>(cfg, in, Jrest, d_coef, d_A, d_transl, d_terms, g);
-    VHAP_LAUNCH_CHECK();
-    return VHAP_OK;
+    return frame_prep_bwd_run(timesteps, shape, expr, rotation, translation, neck, jaw, eyes, JS, jreg_idx, jreg_w, jreg_n, static_offset, parents,
+                              weights, Jrest, d_coef, d_A, d_transl, d_terms, B, Bp, N, NS, NE, J, Kp, V, g_shape, g_expr, g_rotation,
+                              g_translation, g_neck, g_jaw, g_eyes, g_offset, call_flags, stream, CamBwdJob{});
+}
+
+extern "C" int vhap_frame_prep_bwd_camera(const int64_t* timesteps, const float* shape, const float* expr, const float* rotation,
+                                          const float* translation, const float* neck, const float* jaw, const float* eyes,
+                                          const float* JS, const int32_t* jreg_idx, const float* jreg_w, int jreg_n,
+                                          const float* static_offset, const int32_t* parents, const float* weights, const float* Jrest,
+                                          const float* d_coef, const float* d_A, const float* d_transl, const float* d_terms, int B, int Bp,
+                                          int N, int NS, int NE, int J, int Kp, int V, float* g_shape, float* g_expr, float* g_rotation,
+                                          float* g_translation, float* g_neck, float* g_jaw, float* g_eyes, float* g_offset, int call_flags,
+                                          const float* RT, const float* d_mvp, int RT_batched, int H, int W, float focal_scale,
+                                          float* d_focal_accum, vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!RT || !d_mvp || !d_focal_accum) return VHAP_E_NULLPTR;
+    if (H <= 0 || W <= 0) return VHAP_E_BADDIM;
+    const CamBwdJob cam{RT, d_mvp, (float)H, (float)W, focal_scale, B, RT_batched ? 12 : 0, d_focal_accum};
+    return frame_prep_bwd_run(timesteps, shape, expr, rotation, translation, neck, jaw, eyes, JS, jreg_idx, jreg_w, jreg_n, static_offset, parents,
+                              weights, Jrest, d_coef, d_A, d_transl, d_terms, B, Bp, N, NS, NE, J, Kp, V, g_shape, g_expr, g_rotation,
+                              g_translation, g_neck, g_jaw, g_eyes, g_offset, call_flags, stream, cam);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -14,6 +14,9 @@
 #include "aa_items.h"
 #include "energy_common.h"
 
+#ifndef VHAP_PHOTO_PU
+#define VHAP_PHOTO_PU 4
+#endif
 namespace {
 
 // Reducing kernels: PB-thread workgroups, at most MAX_BLOCKS of them.  Every workgroup ends with ONE atomic per output;
@@ -306,10 +309,10 @@ __global__ __launch_bounds__(PB) void photo_fwd_kernel(const float4* __restrict_
             for (int i = (int)(bid * PB + threadIdx.x); i < count; i += (int)(nblk * PB)) aa_colour_bwd_item(E.aa_work, i, pred, gt, H, W, E.d_delta);
         }
     }
-    // four pixels per trip, their sixteen loads issued before the first is consumed (clamped addresses past the end): one pixel per trip
+    // PU pixels per trip (4 shipped; 8 measured the same, profiles/r04_call29_apply_photo_ab.txt), their 4 PU loads issued before the first is consumed (clamped addresses past the end): one pixel per trip
     // is load -> wait -> add with a run-time trip count, eight round trips in series per thread at 16 x 512^2.  The order of the
     // additions into s is the one-pixel-per-trip order.
-    constexpr int PU = 4;
+    constexpr int PU = VHAP_PHOTO_PU;
     const unsigned stride = nblk * PB;
     for (unsigned long long q0 = bid * PB + threadIdx.x; q0 < npix; q0 += (unsigned long long)PU * stride) {
         const unsigned p0 = (unsigned)q0;

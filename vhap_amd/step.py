@@ -73,6 +73,8 @@ class NativeStep:
         self.rgb = sample["rgb"].contiguous()                        # [B,3,H,W] image space (static: new batches are copied in)
         self.photometric = isinstance(cfg.pipeline[stage], PhotometricStageConfig) and w.photo is not None
         self.calibrated = bool(tr.calibrated)
+        # monocular: the camera's forward / backward ride in the per-frame launches (VHAP_CAMERA_FUSED=0: as launches of their own, for A/B)
+        self.cam_fused = (not self.calibrated) and os.environ.get("VHAP_CAMERA_FUSED", "1") != "0"
         self.has_offset = tr.static_offset is not None
         # `use_dynamic_offset` (base.py:69; tracker.py:213-235, 552-600): the kernels read ONE offset row per frame of the batch,
         # off_b = static_offset + dynamic_offset[timesteps] (VHAP_CALL_OFFSET_PER_FRAME), and the offset regularisers run per frame
@@ -426,7 +428,9 @@ class NativeStep:
         # skinning kernel behind the per-frame stage waited for it.  (The texture branch below is FORKED ahead of it -- a root of the captured
         # step: no event record between the camera and the per-frame stage, ~6 us on the main chain -- but issued behind the per-frame
         # stage's launch, see _side.)
-        if not early_tex:
+        # (monocular: the camera rides in the per-frame launch as one more workgroup, vhap_frame_prep_fwd_camera -- no launch of its own)
+        cam_fused = self.cam_fused
+        if not early_tex and not cam_fused:
             self._camera_forward()
         if early_tex:
             # deferred shading: the rasteriser itself samples the texture, so the texture assembly + pyramid (~75 us, bandwidth-bound) heads the
@@ -437,11 +441,18 @@ class NativeStep:
                 self._tex_ready = torch.cuda.Event()
                 self._tex_ready.record()
             self._side(lambda: self._tex_forward(ready=tex_ready))
-            self._camera_forward()
-        _chk(L.vhap_frame_prep_fwd(_p(self.ts), _p(tr.shape), _p(tr.expr), _p(tr.rotation), _p(tr.translation), _p(tr.neck_pose),
-                                   _p(tr.jaw_pose), _p(tr.eyes_pose), _p(fm.JT), _p(fm.JS), _p(fm.jreg_idx), _p(fm.jreg_w), fm.jreg_n,
-                                   _p(so), fm.parents, self.weights, B, self.Bp, self.N, self.NS, self.NE, J, fb.Kp, V,
-                                   _p(self.coef), _p(self.A), _p(self.transl), _p(self.Jrest), _p(acc), PRE | self.off_flag, st), "vhap_frame_prep_fwd")
+            if not cam_fused:
+                self._camera_forward()
+        fp_args = (_p(self.ts), _p(tr.shape), _p(tr.expr), _p(tr.rotation), _p(tr.translation), _p(tr.neck_pose),
+                   _p(tr.jaw_pose), _p(tr.eyes_pose), _p(fm.JT), _p(fm.JS), _p(fm.jreg_idx), _p(fm.jreg_w), fm.jreg_n,
+                   _p(so), fm.parents, self.weights, B, self.Bp, self.N, self.NS, self.NE, J, fb.Kp, V,
+                   _p(self.coef), _p(self.A), _p(self.transl), _p(self.Jrest), _p(acc), PRE | self.off_flag)
+        if cam_fused:
+            H, W = self.H, self.W
+            _chk(L.vhap_frame_prep_fwd_camera(*fp_args, _p(tr.focal_length), self.focal_scale, 0.5 * W, 0.5 * H, _p(self.RT), 0, H, W, 0.1, 10.0,
+                                              _p(self.mvp), st), "vhap_frame_prep_fwd_camera")
+        else:
+            _chk(L.vhap_frame_prep_fwd(*fp_args, st), "vhap_frame_prep_fwd")
         self._flush()
         if self.photometric:                                      # skinning fused with the world -> clip transform (one launch, same bits)
             _chk(L.vhap_flame_skin_clip_fwd(_p(self.coef), _p(fb.basis), _p(self.A), _p(fb.w), _p(fb.templ), _p(so), _p(self.transl), _p(self.mvp),
@@ -812,19 +823,25 @@ class NativeStep:
         _chk(L.vhap_texture_bwd(_p(self.albedo_tex), _p(self.mips), 1, T, T, 3, _p(self.texc), _p(self.texd), _p(self.d_albedo), B, H, W,
                                 0, 0, _p(self.d_texc), _p(self.d_texd), _stream()), "vhap_texture_bwd")
 
-    def _frame_prep_bwd(self, st):
+    def _frame_prep_bwd(self, st, camera=False):
         """per-frame parameters (+ the joint-regression part of the offset gradient); with dynamic offsets: then the offset gradient of every
-        frame -- skinning part g_shaped + d_off_b (joint regression, regularisers) -- to static_offset (summed) and dynamic_offset[timesteps]"""
+        frame -- skinning part g_shaped + d_off_b (joint regression, regularisers) -- to static_offset (summed) and dynamic_offset[timesteps].
+        camera: the uncalibrated camera's backward (d_mvp -> d focal_length) rides in the same launch as one more workgroup"""
         L, tr, fb, fm, g = self.L, self.tr, self.fb, self.fm, self.g
         B, V, J = self.B, self.V, self.J
         off_in = self.off_b if self.dyn else tr.static_offset
         g_off = g["d_off_b"] if self.dyn else (g["static_offset"] if self.has_offset else None)
-        _chk(L.vhap_frame_prep_bwd(_p(self.ts), _p(tr.shape), _p(tr.expr), _p(tr.rotation), _p(tr.translation), _p(tr.neck_pose),
-                                   _p(tr.jaw_pose), _p(tr.eyes_pose), _p(fm.JS), _p(fm.jreg_idx), _p(fm.jreg_w), fm.jreg_n,
-                                   _p(off_in), fm.parents, self.weights, _p(self.Jrest), _p(g["d_coef"]), _p(g["d_A"]), _p(g["d_t"]),
-                                   _p(self.ones), B, self.Bp, self.N, self.NS, self.NE, J, fb.Kp, V, _p(g["shape"]), _p(g["expr"]),
-                                   _p(g["rotation"]), _p(g["translation"]), _p(g["neck_pose"]), _p(g["jaw_pose"]), _p(g["eyes_pose"]),
-                                   _p(g_off), self.off_flag, st), "vhap_frame_prep_bwd")
+        fp_args = (_p(self.ts), _p(tr.shape), _p(tr.expr), _p(tr.rotation), _p(tr.translation), _p(tr.neck_pose),
+                   _p(tr.jaw_pose), _p(tr.eyes_pose), _p(fm.JS), _p(fm.jreg_idx), _p(fm.jreg_w), fm.jreg_n,
+                   _p(off_in), fm.parents, self.weights, _p(self.Jrest), _p(g["d_coef"]), _p(g["d_A"]), _p(g["d_t"]),
+                   _p(self.ones), B, self.Bp, self.N, self.NS, self.NE, J, fb.Kp, V, _p(g["shape"]), _p(g["expr"]),
+                   _p(g["rotation"]), _p(g["translation"]), _p(g["neck_pose"]), _p(g["jaw_pose"]), _p(g["eyes_pose"]),
+                   _p(g_off), self.off_flag)
+        if camera:
+            _chk(L.vhap_frame_prep_bwd_camera(*fp_args, _p(self.RT), _p(self.d_mvp), 0, self.H, self.W, self.focal_scale, _p(g["focal_length"]), st),
+                 "vhap_frame_prep_bwd_camera")
+        else:
+            _chk(L.vhap_frame_prep_bwd(*fp_args, st), "vhap_frame_prep_bwd")
         if self.dyn:
             _chk(L.vhap_offset_grad_finish(_p(self.g_shaped), _p(g["d_off_b"]), _p(self.ts), B, self.N, V,
                                            _p(g["static_offset"]) if self.has_offset else 0, _p(g["dynamic_offset"]), st),
@@ -835,15 +852,15 @@ class NativeStep:
         L, tr, fb, fm, g = self.L, self.tr, self.fb, self.fm, self.g
         B, H, W, V, J = self.B, self.H, self.W, self.V, self.J
         st = _stream()
-        if not self.calibrated:                                       # the focal length is a parameter only without calibration (tracker.py:148-157)
-            _chk(L.vhap_camera_focal_bwd(_p(self.RT), _p(self.d_mvp), B, 0, H, W, self.focal_scale, _p(g["focal_length"]), st),
-                 "vhap_camera_focal_bwd")
         _chk(L.vhap_flame_skin_bwd(_p(g["d_verts"]), 0, _p(self.v_posed), _p(self.A), _p(fb.w), _p(fb.basisT), B, V, fb.Vp, fb.Kb, fb.Kp,
                                    _p(self.g_posed), _p(self.g_shaped), 0, _p(g["d_coef"]), _p(g["d_A"]), _p(g["d_t"]), PRE, st),
              "vhap_flame_skin_bwd")
         if self.has_offset and not self.dyn:
             _chk(L.vhap_sum_frames(_p(self.g_shaped), B, V * 3, _p(g["static_offset"]), st), "vhap_sum_frames")
-        self._frame_prep_bwd(st)
+        if not self.calibrated and not self.cam_fused:                # (the focal length is a parameter only without calibration, tracker.py:148-157)
+            _chk(L.vhap_camera_focal_bwd(_p(self.RT), _p(self.d_mvp), B, 0, H, W, self.focal_scale, _p(g["focal_length"]), st),
+                 "vhap_camera_focal_bwd")
+        self._frame_prep_bwd(st, camera=self.cam_fused)
 
     def _bwd_geometry(self, early=None, after_first=None):
         """G-buffer backward -> vertex normals -> clip transform -> camera -> skinning -> per-frame parameters"""
@@ -872,12 +889,13 @@ class NativeStep:
                                     fb.Vp, fb.Kb, fb.Kp, _p(self.vn_scratch), _p(self.g_posed), _p(self.g_shaped), _p(g["d_coef"]), _p(g["d_A"]),
                                     _p(g["d_t"]), _p(self.d_mvp), _p(g["static_offset"]) if (self.has_offset and not self.dyn) else 0, PRE, st),
              "vhap_verts_bwd_fused")
-        if not self.calibrated:
-            # the camera backward (d_mvp -> d focal_length: one tiny launch) feeds nothing but Adam: beside the per-frame backward, not ahead of it
+        # the camera backward (d_mvp -> d focal_length, a single wave) feeds nothing but Adam: one more workgroup of the per-frame backward (as a
+        # launch of its own on a side branch its event record delayed the per-frame backward and Adam waited for a second event)
+        if not self.calibrated and not self.cam_fused:
             self._side(lambda: _chk(L.vhap_camera_focal_bwd(_p(self.RT), _p(self.d_mvp), B, 0, H, W, self.focal_scale, _p(g["focal_length"]),
                                                             _stream()), "vhap_camera_focal_bwd"), self.side2)
-        self._frame_prep_bwd(st)
-        self._flush()                                                 # (the camera backward: forked behind the vertex stage, issued behind the per-frame backward's launch)
+        self._frame_prep_bwd(st, camera=self.cam_fused)
+        self._flush()
 
     def backward(self, world_size=1, part="all", optimizer=None):
         """part = 'all': the whole backward as one DAG of up to three branches (one GPU).  `optimizer`: a HipAdam whose texture update is
