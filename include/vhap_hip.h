@@ -416,7 +416,9 @@ int vhap_flame_skin_bwd(const float* d_verts, const float* d_vshaped, const floa
  * vhap_flame_skin_bwd + vhap_sum_frames.  The gradient w.r.t. the world-space vertices is assembled in registers from d_verts_in [B,V,3]
  * (may be NULL: e.g. the landmark part), the vertex-normal backward of d_vn and M^T d_clip, and chained through the skinning backward
  * without being written back.  d_A / d_transl / d_mvp [B,16] (may be NULL) / d_offset [V,3] (may be NULL: sum over frames of g_shaped)
- * are ACCUMULATED; g_posed / g_shaped / d_coef as vhap_flame_skin_bwd (VHAP_CALL_ACC_PREZEROED applies to d_coef); scratch [B,V,3]. */
+ * are ACCUMULATED; g_posed / g_shaped / d_coef as vhap_flame_skin_bwd (VHAP_CALL_ACC_PREZEROED applies to d_coef); scratch [B,V,3] (kept in
+ * the signature, no longer written: since ABI 8 the normalisation's backward is re-derived per gathered vertex inside the vertex kernel, two
+ * launches instead of three). */
 int vhap_verts_bwd_fused(const float* verts, const int32_t* tri, const int32_t* vc_ptr, const int32_t* vc_idx,
                          const float* vn, const float* inv_len, const float* d_vn, const float* mvp,
                          const float* d_clip, const float* d_verts_in, const float* v_posed, const float* A,

@@ -413,7 +413,8 @@ __global__ __launch_bounds__(256) void vnormal_bwd2_kernel(const float* __restri
 constexpr int VB_NRED = 16 + NJ * 12 + 3;
 __global__ __launch_bounds__(256) void verts_bwd_fused_kernel(const float* __restrict__ verts, const int* __restrict__ tri,
                                                               const int* __restrict__ vc_ptr, const int* __restrict__ vc_idx,
-                                                              const float* __restrict__ d_nraw, const float* __restrict__ M,
+                                                              const float* __restrict__ vn, const float* __restrict__ inv_len,
+                                                              const float* __restrict__ d_vn, const float* __restrict__ M,
                                                               const float4* __restrict__ d_clip, const float* __restrict__ d_verts_in,
                                                               const float* __restrict__ v_posed, const float* __restrict__ A,
                                                               const float* __restrict__ w, int V, float* __restrict__ g_posed,
@@ -431,7 +432,12 @@ __global__ __launch_bounds__(256) void verts_bwd_fused_kernel(const float* __res
     for (int i = 0; i < VB_NRED; i++) acc[i] = 0.f;
     if (v < V) {
         const float* P = verts + (size_t)b * V * 3;
-        const float* G = d_nraw + (size_t)b * V * 3;
+        // pass 1 of the vertex-normal backward (d_vn -> gradient of the raw normal, through the normalisation: vnormal_bwd1_saved_kernel) is
+        // re-done per gathered vertex from what the forward saved -- 7 floats instead of 3 per vertex of an incident face, and one launch
+        // (6 us + a hand-over on the step's tail) less
+        const float* UN = vn + (size_t)b * V * 3;
+        const float* IL = inv_len + (size_t)b * V;
+        const float* DN = d_vn + (size_t)b * V * 3;
         const size_t o = ((size_t)b * V + v) * 3;
         // every load that depends on the vertex alone is requested now and consumed after the walk over the incident faces
         const int k0 = vc_ptr[v], k1 = vc_ptr[v + 1];
@@ -450,7 +456,7 @@ __global__ __launch_bounds__(256) void verts_bwd_fused_kernel(const float* __res
         constexpr int FB = 4;
         for (int k = k0; k < k1; k += FB) {
             int cc[FB], ii[FB][3];
-            float g_[FB][3][3], p_[FB][3][3];
+            float g_[FB][3][3], p_[FB][3][3], u_[FB][3][3], il_[FB][3];
 #pragma unroll
             for (int u = 0; u < FB; u++) cc[u] = vc_idx[k + u < k1 ? k + u : k1 - 1];
 #pragma unroll
@@ -463,7 +469,20 @@ __global__ __launch_bounds__(256) void verts_bwd_fused_kernel(const float* __res
 #pragma unroll
                 for (int q = 0; q < 3; q++)
 #pragma unroll
-                    for (int c = 0; c < 3; c++) { g_[u][q][c] = G[3 * ii[u][q] + c]; p_[u][q][c] = P[3 * ii[u][q] + c]; }
+                    for (int c = 0; c < 3; c++) { g_[u][q][c] = DN[3 * ii[u][q] + c]; u_[u][q][c] = UN[3 * ii[u][q] + c]; p_[u][q][c] = P[3 * ii[u][q] + c]; }
+#pragma unroll
+            for (int u = 0; u < FB; u++)
+#pragma unroll
+                for (int q = 0; q < 3; q++) il_[u][q] = IL[ii[u][q]];
+#pragma unroll
+            for (int u = 0; u < FB; u++)
+#pragma unroll
+                for (int q = 0; q < 3; q++) {          // d_vn -> d_nraw, the expressions of vnormal_bwd1_saved_kernel
+                    const float dx = g_[u][q][0], dy = g_[u][q][1], dz = g_[u][q][2];
+                    const float ux = u_[u][q][0], uy = u_[u][q][1], uz = u_[u][q][2];
+                    const float dot = ux * dx + uy * dy + uz * dz;
+                    g_[u][q][0] = (dx - ux * dot) * il_[u][q]; g_[u][q][1] = (dy - uy * dot) * il_[u][q]; g_[u][q][2] = (dz - uz * dot) * il_[u][q];
+                }
 #pragma unroll
             for (int u = 0; u < FB; u++) {
                 if (k + u >= k1) break;
@@ -604,9 +623,8 @@ extern "C" int vhap_verts_bwd_fused(const float* verts, const int32_t* tri, cons
         return VHAP_E_NULLPTR;
     if (B <= 0 || V <= 0 || B > 65535 || Vp < V || Vp % 64 || Kb % 16 || Kp % 16 || Kp / 16 > 32) return VHAP_E_BADDIM;
     hipStream_t st = vhap_stream(stream);
-    vnormal_bwd1_saved_kernel<<<vhap_cdiv((long long)B * V, 256), 256, 0, st>>>(vn, inv_len, d_vn, B * V, scratch);
-    VHAP_LAUNCH_CHECK();
-    verts_bwd_fused_kernel<<<dim3(vhap_cdiv(V, 256), B), 256, 0, st>>>(verts, tri, vc_ptr, vc_idx, scratch, mvp, reinterpret_cast<const float4*>(d_clip),
+    // (`scratch` -- [B,V,3], the gradient of the raw normals -- is no longer written: the kernel re-derives it per gathered vertex)
+    verts_bwd_fused_kernel<<<dim3(vhap_cdiv(V, 256), B), 256, 0, st>>>(verts, tri, vc_ptr, vc_idx, vn, inv_len, d_vn, mvp, reinterpret_cast<const float4*>(d_clip),
                                                                        d_verts_in, v_posed, A, lbs_weights, V, g_posed, g_shaped, d_A, d_transl,
                                                                        d_mvp, d_offset);
     VHAP_LAUNCH_CHECK();
