@@ -225,7 +225,7 @@ def parity_vs_oracle(C, tr, sample, model, topo):
     n_kink = int((torch.sign(ex["rgba"][..., :3].detach() - o_sample["rgb"].permute(0, 2, 3, 1).double()) != torch.sign(res_hip.double())).sum())
     Eo = float(Eo.detach())
     terms = {k: abs(log_n[k] - float(b.detach())) / max(abs(float(b.detach())), 1e-3) for k, b in logo.items()}
-    grads, cos = {}, {}
+    grads, cos, tex_diag = {}, {}, None
     for k in names:
         b = P[k].grad
         if b is None or float(b.abs().max()) == 0 or k not in g_n:
@@ -233,9 +233,20 @@ def parity_vs_oracle(C, tr, sample, model, topo):
         a, b = g_n[k], b.reshape(-1)
         grads[k] = float((a - b).abs().max() / b.abs().max())
         cos[k] = float((a @ b) / (a.norm() * b.norm() + 1e-300))
+        if k == "tex_extra":
+            # how the distance is distributed over the texel channels: a discrete decision taken differently in float32 and float64 (an
+            # antialias pair analysed the other way, a kink not on record) moves the few dozen channels one pixel samples; an arithmetic
+            # defect would move thousands.  (At trained states single parameters show 1e-3 .. 1e-2 -- DESIGN section 7.)
+            try:
+                dlt = (a - b).abs() / b.abs().max()
+                tex_diag = {"over_1e-4": int((dlt > 1e-4).sum()), "over_1e-3": int((dlt > 1e-3).sum()), "of": int(dlt.numel()),
+                            "rel_without_the_worst_32": float(dlt.topk(min(33, dlt.numel())).values[-1])}
+            except Exception as e:                       # (diagnostics must never cost the bench line)
+                tex_diag = {"error": repr(e)}
     wt, wg = max(terms, key=terms.get), max(grads, key=grads.get)
     return {"energy_rel": abs(log_n["total"] - Eo) / abs(Eo), "worst_term_rel": terms[wt], "worst_term": wt,
             "worst_grad_rel": grads[wg], "worst_grad": wg, "min_grad_cos": min(cos.values()), "grad_rel": grads,
+            "tex_extra_texel_channels": tex_diag,
             "energy_hip": log_n["total"], "energy_oracle": Eo, "frames": B, "disturbed_fraction": disturbed, "l1_kink_pixels": n_kink,
             "oracle": f"oracle/energy_ref.total_energy in float64 on {cores} host threads, same frames, same injected disturbance draws, "
                       "HIP triangle ids, HIP side of the L1 kinks (l1_kink_pixels residuals of ~1e-7 have opposite signs in fp32 / fp64); "
@@ -302,14 +313,19 @@ def stage_fps(C, tr_ref, model, topo, gt, n_frames=256, epochs=5):
         tr.optimize_stage(STAGE, dataloader=loader, lr_scale=0.1)
         torch.cuda.synchronize()
         cfg.pipeline[STAGE].num_epochs = epochs
-        t0 = time.perf_counter()
-        tr.optimize_stage(STAGE, dataloader=loader, lr_scale=0.1)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        # three timed stages, the MEDIAN reported (all three listed): 80 steps are ~75 ms of wall-clock on a host the GPU box shares with
+        # other jobs (load average 12-18 during round 4's calls), and one stage measured 14.1 k and 17.5 k frames/s a minute apart
+        # (profiles/r04_call35_stage_fps_noise.txt)
+        dts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            tr.optimize_stage(STAGE, dataloader=loader, lr_scale=0.1)
+            torch.cuda.synchronize()
+            dts.append(time.perf_counter() - t0)
     finally:
         cfg.pipeline[STAGE].num_epochs = keep
     steps = epochs * len(loader)
-    return n_frames * epochs / dt, steps
+    return n_frames * epochs / sorted(dts)[1], steps, [n_frames * epochs / d for d in dts]
 
 
 def time_ri_isolated(tr, sample, C, stream):
@@ -455,7 +471,7 @@ def main():
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic", "timed_region_s": dt, "n_ranks_seen": n_ranks_seen,
-            "stage_fps": ({"value": stage[0], "unit": "frames/s", "steps": stage[1],
+            "stage_fps": ({"value": stage[0], "unit": "frames/s", "steps": stage[1], "runs": stage[2], "estimator": "median of three timed stages",
                            "what": "GlobalTracker.optimize_stage('rgb_global_tracking') end to end over shuffled batches of a 256-frame sequence (5 epochs) "
                                    "resident as uint8 (vhap_frame_ingest into the captured step's buffers, landmark / index hand-over, "
                                    "ExponentialLR, host loop): a NEW batch every step, like tracker.py:1376-1385"} if stage else None),
@@ -503,5 +519,31 @@ def main():
         torch.distributed.destroy_process_group()
 
 
+def _supervised():
+    """One GPU: the measurement runs in a child process and is repeated (once, then once more on eager launches) if that process DIES -- a
+    runtime error thrown out of a destructor during a stream capture cannot be caught in Python and took one of ~60 bench runs of round 4
+    with it (profiles/r04_call33_capture_abort.txt; the capture now runs with the collector off, vhap_amd/tracker.py).  The timed region
+    is inside the child and unchanged; a run that prints its JSON line is never repeated.  Multi-rank launches (torch.distributed.run
+    owns the processes) run main() directly."""
+    import subprocess
+    argv = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, VHAP_BENCH_CHILD="1")
+    rc = 1
+    for attempt, extra in enumerate(([], [], ["--eager"])):
+        if extra and any(a in sys.argv for a in extra):
+            break
+        p = subprocess.run(argv + extra, env=env, stdout=subprocess.PIPE, text=True)
+        rc = p.returncode
+        lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        if rc == 0 and lines:
+            sys.stdout.write(p.stdout)
+            sys.stdout.flush()
+            return 0
+        print(f"[bench] attempt {attempt + 1} ended with exit code {rc} and no result line; repeating", file=sys.stderr, flush=True)
+    return rc or 1
+
+
 if __name__ == "__main__":
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not os.environ.get("VHAP_BENCH_CHILD"):
+        sys.exit(_supervised())
     main()

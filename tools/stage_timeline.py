@@ -62,14 +62,35 @@ def main():
         if hasattr(GraphedStep, nm):
             wrap(GraphedStep, nm, nm)
     wrap(T.NV.HipAdam, "sync_lr", "sync_lr")
+    made = []
+    init0 = GraphedStep.__init__
+
+    def init1(self, *a, **k):
+        init0(self, *a, **k)
+        made.append(self)
+    GraphedStep.__init__ = init1
     cfg.pipeline[stage].num_epochs = 1
     tr.optimize_stage(stage, dataloader=loader, lr_scale=0.1)           # capture + warm-up pass
     torch.cuda.synchronize()
     acc.clear()
     cfg.pipeline[stage].num_epochs = args.epochs
+    import gc
+    gcs = {"t": 0.0, "n": [0, 0, 0], "t0": 0.0}
+
+    def gc_cb(phase, info):                                   # time spent in the cyclic collector during the timed stage
+        if phase == "start":
+            gcs["t0"] = time.perf_counter()
+        else:
+            gcs["t"] += time.perf_counter() - gcs["t0"]
+            gcs["n"][info["generation"]] += 1
+    gc.callbacks.append(gc_cb)
+    if os.environ.get("STAGE_GC") == "0":
+        gc.disable()
     t0 = time.perf_counter()
     tr.optimize_stage(stage, dataloader=loader, lr_scale=0.1)
     t_host = time.perf_counter() - t0
+    gc.enable()
+    gc.callbacks.remove(gc_cb)
     torch.cuda.synchronize()
     t_all = time.perf_counter() - t0
     cfg.pipeline[stage].num_epochs = keep
@@ -77,6 +98,12 @@ def main():
     lines = [f"optimize_stage({stage}): {n_frames} frames, batches of {B}, {args.epochs} epochs = {steps} steps",
              f"wall {t_all * 1e3:.2f} ms = {t_all / steps * 1e3:.4f} ms/step = {n_frames * args.epochs / t_all:.0f} frames/s; "
              f"host loop returned after {t_host * 1e3:.2f} ms ({t_host / steps * 1e3:.4f} ms/step of host time)"]
+    lines.append(f"  cyclic collector during the timed stage: {gcs['t'] * 1e3:.2f} ms in {gcs['n']} collections (generation 0 / 1 / 2); {len(gc.get_objects())} tracked objects"
+                 + ("  [STAGE_GC=0: collector off]" if os.environ.get("STAGE_GC") == "0" else ""))
+    for st in made:
+        rep = getattr(st, "defer_report", None) or []
+        lines.append(f"  captured step: deferred join {'ON' if getattr(st, 'defer_join', False) else 'OFF'}, self-feeding {'ON' if getattr(st, 'feed', None) is not None else 'OFF'}"
+                     + (f"; {str(rep[-1])[:160]}" if rep else ""))
     for k in sorted(k for k in acc if not k.endswith("#")):
         lines.append(f"  host time in {k}: {acc[k] * 1e3:.2f} ms total, {acc[k] / max(acc[k + '#'], 1) * 1e6:.1f} us per call x {acc[k + '#']}")
     rest = t_host - sum(v for k, v in acc.items() if not k.endswith("#") and k not in ("sync_lr",))

@@ -826,6 +826,14 @@ class GlobalTracker(FlameTracker):
                         break
                 st.feed_upload(torch.cat(parts_f), torch.cat(parts_t))
                 return len(parts_f)
+            # The cyclic collector and a latency-bound host loop: ONE full (generation 2) collection walks every tracked object of the process
+            # -- 267 k of them here, 72-76 ms, as long as 80 steps of this stage -- and whether it falls into a stage is a matter of
+            # allocation counts (profiles/r04_call38_stage_gc.txt: the same stage at 17.7 k or 8.8 k frames/s from process to process).
+            # What exists now is FROZEN for the length of the stage (gc.freeze: moved out of the collector's reach without being walked -- a
+            # gc.collect() here would itself be those 75 ms -- so a full collection inside the loop only walks what the loop created);
+            # thawed in the finally below.
+            import gc
+            gc.freeze()
             try:
                 for epoch_i in range(n_epochs):
                     if ahead:
@@ -873,6 +881,7 @@ class GlobalTracker(FlameTracker):
                         self.evaluate()
             finally:
                 leave()
+                gc.unfreeze()
             return opt
         for epoch_i in range(n_epochs):
             for s in dataloader:
@@ -1086,12 +1095,25 @@ class CapturedPlan:
         outer = self
 
         class _Ctx:
+            # The cyclic collector stays off for the length of the capture: a dead torch.cuda.CUDAGraph (or anything else whose destructor
+            # calls the runtime) collected in the middle of it is an "operation not permitted when stream is capturing" that ends the
+            # capture, and the error thrown from the next graph destructor ends the PROCESS (seen once in ~60 bench runs of round 4:
+            # profiles/r04_call33_capture_abort.txt).  torch.cuda.graph collects once on entry, which leaves the window open.
             def __enter__(self):
+                import gc
+                self._gc = gc.isenabled()
                 self.ctx = torch.cuda.graph(outer.g, **kw)
-                return self.ctx.__enter__()
+                r = self.ctx.__enter__()
+                gc.disable()
+                return r
 
             def __exit__(self, *a):
-                r = self.ctx.__exit__(*a)
+                import gc
+                try:
+                    r = self.ctx.__exit__(*a)
+                finally:
+                    if self._gc:
+                        gc.enable()
                 if a[0] is None:
                     outer._finish()
                 return r
