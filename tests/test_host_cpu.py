@@ -244,3 +244,45 @@ def test_every_library_attribute_the_package_uses_exists():
             if name not in _lib.SIGNATURES:
                 missing.append(f"{os.path.basename(path)}: {name}")
     assert not missing, missing
+
+
+def test_latency_bound_kernels_issue_their_loads_in_batches():
+    """The kernels whose duration IS their chain of dependent round trips (one workgroup per frame, a few hundred workgroups, or a gather
+    chain per pixel) keep their loads batched: load groups read off the gfx950 ISA (tools/isa_hops.py; groups ~ loads means load -> wait ->
+    use one at a time).  Round 4 found 38 groups in the per-frame forward, 80 in the uv binning, 32 in the antialias detect pass, ~20 in
+    the vertex stage -- an `if (ptr)` around an optional input, a run-time trip count or a `#pragma unroll` that does not unroll is enough to
+    bring them back, and nothing else in the suite would notice (the results are the same)."""
+    import shutil
+    import sys
+    if not (os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("hipcc")):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import isa_hops
+    files = [os.path.join(root, "vhap_amd", "csrc", f) for f in ("frame.hip", "flame.hip", "interp.hip", "deferred.hip", "disturb.hip", "antialias.hip", "pixel.hip")]
+    got = isa_hops.table(files)
+    limit = {"frame_prep_fwd_kernel<5>": 9, "frame_prep_bwd_kernel<5>": 12, "verts_bwd_fused_kernel": 17, "flame_skin_fwd_kernel": 11,
+             "flame_coef_bwd_kernel": 11, "deferred_shade_bwd_kernel": 11, "gbuffer_bwd_tiled_kernel": 8, "aa_detect_kernel<4>": 13,
+             "disturb_count_kernel": 7, "disturb_scatter_kernel": 9, "disturb_apply_kernel<true>": 9, "photo_fwd_kernel<true>": 8}
+    for k, lim in limit.items():
+        assert k in got, (k, sorted(got))
+        groups, loads = got[k]
+        assert groups <= lim, f"{k}: {groups} load groups for {loads} loads (limit {lim}): a batch of loads has fallen apart (python tools/isa_hops.py)"
+
+
+def test_mip_level_offsets_closed_form_matches_the_table():
+    """tex_sample.h: level_off() -- the device's arithmetic form of TexDesc::off (a per-lane index into the kernel-argument table is a global
+    load) -- against the table make_desc() builds, for every texture shape with up to 14 levels the library accepts (make_desc itself aborts
+    on a mismatch; this is the same check without a GPU or a process to lose)."""
+    def num_levels(h, w):
+        n = 0
+        while h > 1 and w > 1 and h % 2 == 0 and w % 2 == 0 and n < 14:
+            h, w, n = h >> 1, w >> 1, n + 1
+        return n
+    for h in (1, 2, 6, 8, 24, 96, 512, 1024, 2048, 3 * 1024, 4096, 16384):
+        for w in (1, 2, 4, 10, 64, 160, 512, 2048, 5 * 512, 16384):
+            for c in (1, 3, 4):
+                o, m = 0, h * w
+                for l in range(1, num_levels(h, w) + 1):
+                    assert o == ((m - (m >> (2 * (l - 1)))) // 3) * c, (h, w, c, l)
+                    o += (h >> l) * (w >> l) * c
