@@ -286,3 +286,26 @@ def test_mip_level_offsets_closed_form_matches_the_table():
                 for l in range(1, num_levels(h, w) + 1):
                     assert o == ((m - (m >> (2 * (l - 1)))) // 3) * c, (h, w, c, l)
                     o += (h >> l) * (w >> l) * c
+
+
+def test_bench_supervisor_repeats_a_dead_child_and_relays_the_result_line(monkeypatch, capsys):
+    """bench.py on one GPU runs its measurement in a child process: a child that dies without a result line is repeated, the first result
+    line is relayed unchanged, and the last attempt falls back to eager launches."""
+    import subprocess
+    import sys
+    import types
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    calls = []
+
+    def fake_run(argv, env=None, stdout=None, text=None):
+        calls.append(list(argv))
+        if len(calls) < 3:
+            return types.SimpleNamespace(returncode=-6, stdout="")          # SIGABRT: terminate() out of a destructor
+        return types.SimpleNamespace(returncode=0, stdout='{"metric": "frames_per_s", "value": 1.0}\n')
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "4"])
+    assert bench._supervised() == 0
+    assert len(calls) == 3 and calls[0][-2:] == ["--steps", "4"] and calls[2][-1] == "--eager" and "--eager" not in calls[1]
+    assert capsys.readouterr().out == '{"metric": "frames_per_s", "value": 1.0}\n'

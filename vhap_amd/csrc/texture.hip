@@ -741,7 +741,7 @@ __global__ __launch_bounds__(256) void texgrad_tile_kernel(const TexDesc D, cons
 #pragma unroll
             for (int k = 0; k < C; k++) g[u][k] = d_out[p[u] * C + k];
             c[u] = uv[p[u]];
-            da[u] = *(uv_da ? uv_da + p[u] : reinterpret_cast<const float4*>(uv));
+            da[u] = *(uv_da ? uv_da + p[u] : reinterpret_cast<const float4*>(offsets));      // (stand-in: >= 65 words, value unused)
         }
 #pragma unroll
         for (int u = 0; u < TG_UNR; u++) {
