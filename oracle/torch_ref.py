@@ -549,13 +549,18 @@ def photometric_energy(gt_rgb_nchw, rgba_nhwc_flipped, sign_from=None):
     """tracker.py:430-439: sum|gt - pred| / (3 * #{alpha > 0}).
     `sign_from` ([B,H,W,3] image space, the residual pred - gt of ANOTHER evaluation of the same state; diagnostics / parity tests only):
     |x| is evaluated as sign(sign_from) * x, i.e. at a residual that rounds to the other side of zero in the other evaluation (|x| ~ 1e-8)
-    the oracle takes THAT side of the kink -- both signs are subgradients of |x| at 0; the value moves by <= 2 |x| per such element."""
+    the oracle takes THAT side of the kink -- both signs are subgradients of |x| at 0; the value moves by <= 2 |x| per such element.
+    Where the other evaluation's residual is EXACTLY zero (a float32 prediction that equals the target bit for bit: about once per
+    10^7 pixel channels, i.e. in every other full-batch evaluation) its subgradient is 0 -- torch.abs and the HIP kernels both take
+    sign(0) = 0 -- and so is the one taken here: until round 4 this case fell back to sign(x) of THIS evaluation, and the one pixel it
+    concerns showed as 5e-3 .. 8e-3 of d(tex_extra)'s max-norm in 32 + 32 texel channels (tools/trained_state_spread.py: oracle float32 vs
+    oracle float64, no HIP involved; profiles/r04_trained_state_spread_cpu.txt).  Background pixels -- prediction = target in both
+    evaluations -- are exactly zero on both sides and contribute nothing either way."""
     pred = rgba_nhwc_flipped.permute(0, 3, 1, 2)
     mask = (pred[:, 3:4].detach() > 0).expand(-1, 3, -1, -1)
     x = pred[:, :3] - gt_rgb_nchw
     if sign_from is not None:
         sg = torch.sign(sign_from.to(x.dtype).permute(0, 3, 1, 2))
-        sg = torch.where(sg == 0, torch.sign(x.detach()), sg)
         return (sg * x).sum() / mask.sum()
     return x.abs().sum() / mask.sum()
 

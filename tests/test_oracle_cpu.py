@@ -282,3 +282,22 @@ def test_texture_oracle_against_independent_torch_implementations():
         inner = ((uv > 0.2) & (uv < 0.8)).all(-1)
         got = R.texture(tex, uv, da, filter_mode="linear-mipmap-linear")
         assert torch.allclose(got[inner], want[inner], atol=1e-10), s
+
+
+def test_photometric_sign_from_takes_the_other_evaluations_subgradient_also_at_exact_zero():
+    """oracle/torch_ref.photometric_energy(sign_from=...): the L1 term's derivative is the OTHER evaluation's sign wherever that is
+    +-1 (a kink taken on its side) and ZERO where the other evaluation's residual is exactly zero -- sign(0) = 0 is what torch.abs and the
+    HIP kernels take there; falling back to this evaluation's own sign put one pixel's whole contribution between the two gradients
+    (round 4: d(tex_extra) 5e-3 .. 8e-3 apart at trained states, tools/trained_state_spread.py)."""
+    from oracle import torch_ref as R
+    gt = torch.full((1, 3, 1, 4), 0.5, dtype=torch.float64)
+    pred = torch.tensor([0.5 + 3e-9, 0.5 - 2e-9, 0.7, 0.5 + 1e-9], dtype=torch.float64)
+    rgba = torch.cat([pred.reshape(1, 1, 4, 1).expand(1, 1, 4, 3), torch.ones(1, 1, 4, 1, dtype=torch.float64)], -1).clone().requires_grad_()
+    # the float32 evaluation of the same state: pixel 0 rounds to the other side, pixel 1 to the same, pixel 3 to EXACTLY zero
+    other = torch.tensor([-1e-8, -1e-8, 0.2, 0.0]).reshape(1, 1, 4, 1).expand(1, 1, 4, 3)
+    E = R.photometric_energy(gt, rgba, sign_from=other)
+    E.backward()
+    g = rgba.grad[0, 0, :, 0] * 12.0                      # (3 channels x 4 pixels with alpha > 0 in the denominator)
+    assert torch.equal(g, torch.tensor([-1.0, -1.0, 1.0, 0.0], dtype=torch.float64))
+    E0 = R.photometric_energy(gt, rgba.detach())
+    assert abs(float(E) - float(E0)) < 1e-8               # the value moves by <= 2 |x| per kink element

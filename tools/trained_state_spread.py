@@ -6,6 +6,9 @@ L1 kink (photo_sign_from), exactly what the HIP-vs-oracle comparison does -- and
 the distribution of d(tex_extra)'s distance over the texel channels.
 
     python tools/trained_state_spread.py [B=2] [steps ...=0 40 100]
+    PLANT=K python tools/trained_state_spread.py 2 0     K covered pixel channels of the TARGET are set to the float32 prediction bit for bit first (exactly-zero
+                                                         float32 residuals, which a fit reaches by itself about once per 10^7 channels); OLD_ZERO=1: the oracle's
+                                                         handling of that case before the fix (fall back to the float64 sign)
 """
 import os
 import sys
@@ -77,6 +80,32 @@ def main():
                 line += f"; texel channels over 1e-4: {int((d > 1e-4).sum())}, over 1e-3: {int((d > 1e-3).sum())}, without the worst 32: {float(d.topk(33).values[-1]):.2e}"
             print(line, flush=True)
 
+    if os.environ.get("OLD_ZERO") == "1":                 # (the sign_from handling of an exactly-zero residual before round 4's fix)
+        from oracle import torch_ref as R
+
+        def old_photo(gt_rgb_nchw, rgba_nhwc_flipped, sign_from=None):
+            pred = rgba_nhwc_flipped.permute(0, 3, 1, 2)
+            mask = (pred[:, 3:4].detach() > 0).expand(-1, 3, -1, -1)
+            x = pred[:, :3] - gt_rgb_nchw
+            if sign_from is None:
+                return x.abs().sum() / mask.sum()
+            sg = torch.sign(sign_from.to(x.dtype).permute(0, 3, 1, 2))
+            sg = torch.where(sg == 0, torch.sign(x.detach()), sg)
+            return (sg * x).sum() / mask.sum()
+        R.photometric_energy = old_photo
+    K = int(os.environ.get("PLANT", "0"))
+    if K:
+        P32 = {k: v.detach().float() for k, v in P.items()}
+        with torch.no_grad():
+            _, _, ex = energy_ref.total_energy(P32, tm_of(torch.float32), topo, cfg, sample, stage, base.float(), uvm.float(), (H, W), dtype=torch.float32)
+        rgba = ex["rgba"].detach()
+        cov = (rgba[..., 3] > 0).nonzero()
+        pick = cov[torch.randperm(cov.shape[0], generator=torch.Generator().manual_seed(5))[:K]]
+        tgt = sample["rgb"].permute(0, 2, 3, 1).clone()
+        for i, (b, y, x) in enumerate(pick.tolist()):
+            tgt[b, y, x, i % 3] = rgba[b, y, x, i % 3]
+        sample["rgb"] = tgt.permute(0, 3, 1, 2).contiguous()
+        print(f"planted: {K} covered pixel channels of the target := the float32 prediction" + ("  [OLD_ZERO=1: the oracle's zero handling before the fix]" if os.environ.get("OLD_ZERO") == "1" else ""), flush=True)
     t0, step = time.time(), 0
     for m in sorted(marks):
         while step < m:
