@@ -225,12 +225,13 @@ def parity_vs_oracle(C, tr, sample, model, topo):
     n_kink = int((torch.sign(ex["rgba"][..., :3].detach() - o_sample["rgb"].permute(0, 2, 3, 1).double()) != torch.sign(res_hip.double())).sum())
     Eo = float(Eo.detach())
     terms = {k: abs(log_n[k] - float(b.detach())) / max(abs(float(b.detach())), 1e-3) for k, b in logo.items()}
-    grads, cos, tex_diag = {}, {}, None
+    grads, cos, tex_diag, gnorm = {}, {}, None, {}
     for k in names:
         b = P[k].grad
         if b is None or float(b.abs().max()) == 0 or k not in g_n:
             continue
         a, b = g_n[k], b.reshape(-1)
+        gnorm[k] = float(b.abs().max())                          # (a scalar gradient that converges to zero makes its own relative error large)
         grads[k] = float((a - b).abs().max() / b.abs().max())
         cos[k] = float((a @ b) / (a.norm() * b.norm() + 1e-300))
         if k == "tex_extra":
@@ -246,7 +247,7 @@ def parity_vs_oracle(C, tr, sample, model, topo):
     wt, wg = max(terms, key=terms.get), max(grads, key=grads.get)
     return {"energy_rel": abs(log_n["total"] - Eo) / abs(Eo), "worst_term_rel": terms[wt], "worst_term": wt,
             "worst_grad_rel": grads[wg], "worst_grad": wg, "min_grad_cos": min(cos.values()), "grad_rel": grads,
-            "tex_extra_texel_channels": tex_diag,
+            "tex_extra_texel_channels": tex_diag, "grad_max_norm": gnorm,
             "energy_hip": log_n["total"], "energy_oracle": Eo, "frames": B, "disturbed_fraction": disturbed, "l1_kink_pixels": n_kink,
             "oracle": f"oracle/energy_ref.total_energy in float64 on {cores} host threads, same frames, same injected disturbance draws, "
                       "HIP triangle ids, HIP side of the L1 kinks (l1_kink_pixels residuals of ~1e-7 have opposite signs in fp32 / fp64); "
