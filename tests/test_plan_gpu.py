@@ -158,8 +158,11 @@ def test_stage_loop_with_a_new_batch_every_step_deferred_vs_joined(flame_model, 
                 getattr(tr, k).copy_(start[k])
         tr.render._rng_state = torch.full((1,), 12345, dtype=torch.int32, device="cuda")   # same in-kernel draws in every run
         loader = ShuffledBatches(tr, B, device_index=True, generator=torch.Generator().manual_seed(3))
+        import gc
+        frozen = gc.get_freeze_count()
         tr.optimize_stage(stage, dataloader=loader, lr_scale=0.1)
         torch.cuda.synchronize()
+        assert gc.get_freeze_count() <= frozen and gc.isenabled()   # (the stage loop freezes the process's objects out of the collector's reach, and thaws them)
         st = next(iter(tr._graphed.values()))
         assert st.single and st.gF.plan is not None and st.defer_join == defer, (st.defer_join, defer, st.defer_report)
         assert (st.feed is not None) == feed                         # the captured step gathers its own batches (vhap_batch_feed) / is fed by the host
