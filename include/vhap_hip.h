@@ -181,20 +181,6 @@ int vhap_deferred_shade_bwd(const float* pos, const int32_t* tri, const float* v
                             float* d_lights, float* work, size_t work_floats, void* texbin_work,
                             uint16_t* tile_ids, int call_flags, vhap_stream_t stream);
 
-/* vhap_deferred_shade_bwd FUSED with vhap_gbuffer_bwd: the gradients w.r.t. the interpolated normal / uv / uv derivatives never leave
- * registers -- they go straight through the barycentric chain into d_pos [B,V,4] and d_vnormal [B,V,3] (both ACCUMULATED, per-tile LDS
- * vertex tables as in vhap_gbuffer_bwd); uv_nograd_faces as there.  Same arguments otherwise; still writes texc / texd / d_albedo for
- * the texture-gradient accumulation. */
-int vhap_deferred_gbuffer_bwd(const float* pos, const int32_t* tri, const float* vnormal, const float* uv,
-                              const int32_t* tri_uv, const float* tex, const float* mips, int Ht, int Wt,
-                              const float* lights, const float* sh_const, const float* rast,
-                              const float* d_rgba, const float* pred_rgba, const float* gt_nchw,
-                              const float* d_sum, const float* d_delta, const float* keep, const float* d_reg,
-                              const float* stats, const uint8_t* uv_nograd_faces, int B, int V, int VT, int F, int H, int W,
-                              float* texc, float* texd, float* d_albedo, float* d_pos, float* d_vnormal,
-                              float* d_lights, float* work, size_t work_floats, void* texbin_work,
-                              uint16_t* tile_ids, vhap_stream_t stream);
-
 /* Triangle-parallel backward of the fused G-buffer pass (vhap_raster_interp_fwd): chains the gradients of
  * normal [B,H,W,3], texc [B,H,W,2], texd [B,H,W,4] (and, optionally, direct gradients of rast / rast_db) into
  * d_pos [B,V,4] and d_vnormal [B,V,3] (both ACCUMULATED, caller zero-fills) with one set of atomics per
@@ -285,7 +271,6 @@ int vhap_texture_grad_binned_sorted(int Ht, int Wt, int C, const float* uv, cons
 int vhap_texture_grad_binned_counted(int Ht, int Wt, int C, const float* uv, const float* uv_da,
                                      const float* d_out, int B, int H, int W, float* d_tex, float* d_mips,
                                      void* work, size_t work_bytes, vhap_stream_t stream);
-
 /* ---------------------------------------------------------------------------------------------
  * Antialias: replaces dr.antialias(color, rast, pos, tri)  (:465).
  *   opp [F,3] int32 = static edge->opposite-vertex table (-1 = boundary edge) built once on the
@@ -320,13 +305,10 @@ size_t vhap_antialias_inplace_work_ints(int B, int H, int W, int F);
 int vhap_antialias_inplace_fwd(float* color, const float* rast, const float* pos, const int32_t* tri,
                                const int32_t* opp, int B, int H, int W, int V, int F, int32_t* work,
                                vhap_stream_t stream);
-/* The same pass as two calls, detect + blend == vhap_antialias_inplace_fwd: `detect` (silhouette flags and pixel-pair discovery) reads
- * only rast and the geometry, NOT the colours, so it can be issued right behind the rasteriser, beside whatever still produces the
- * colours (render_nvdiffrast.py:424-460 runs between the two); `blend` (edge analysis, in-place update) needs the final colours. */
-int vhap_antialias_inplace_detect(const float* rast, const float* pos, const int32_t* tri, const int32_t* opp, int B,
-                                  int H, int W, int V, int F, int32_t* work, vhap_stream_t stream);
-/* detect in ITS two halves (silhouette + pairs == detect): the silhouette flags are a property of the geometry alone, so a step executor
- * computes them beside the rasteriser and only the pixel-pair discovery behind it */
+/* The same pass in pieces, silhouette + pairs + blend == vhap_antialias_inplace_fwd.  The silhouette flags are a property of the geometry
+ * alone and the pixel-pair discovery reads only rast, NOT the colours: a step executor computes the flags beside the rasteriser and the
+ * pairs right behind it, beside whatever still produces the colours (render_nvdiffrast.py:424-460 runs between the two); `blend` (edge
+ * analysis, in-place update) needs the final colours. */
 int vhap_antialias_inplace_silhouette(const float* pos, const int32_t* tri, const int32_t* opp, int B, int H, int W, int V, int F,
                                       int32_t* work, vhap_stream_t stream);
 int vhap_antialias_inplace_pairs(const float* rast, int B, int H, int W, int F, int32_t* work, vhap_stream_t stream);
@@ -464,11 +446,6 @@ int vhap_disturb_fwd(const float* rgba, const float* rast, const int32_t* fid2ci
 int vhap_disturb_fwd_rng(const float* rgba, const float* rast, const int32_t* fid2cid, int nfid, int ncl,
                          float rate_fg, float rate_bg, uint32_t* rng_state, int B, int H, int W,
                          int32_t* workspace, float* out, float* keep, vhap_stream_t stream);
-/* same, reading the per-pixel cluster from the one-byte image `cid` [B,H,W] that vhap_shade_fwd writes (fid2cid / cid arguments
- * there) instead of going through `rast` and the table: 4 MB instead of 67 MB per pass at 16x512^2 */
-int vhap_disturb_fwd_rng_cid(const float* rgba, const uint8_t* cid, int ncl, float rate_fg, float rate_bg,
-                             uint32_t* rng_state, int B, int H, int W, int32_t* workspace, float* out,
-                             float* keep, vhap_stream_t stream);
 /* the step executor's form: IN PLACE on rgba, clusters from the one-byte image `cid`; random numbers drawn in-kernel (rng_state != NULL,
  * w_fg / w_bg / idx ignored) or INJECTED (rng_state == NULL: w_fg / w_bg / idx as in vhap_disturb_fwd -- the same kernels, so that a
  * step replayed with the oracle's random numbers exercises the code that ships) */
@@ -522,7 +499,7 @@ int vhap_camera_fwd(const float* K, const float* RT, int B, int K_batched, int R
                     float near_plane, float far_plane, float* mvp, vhap_stream_t stream);
 int vhap_camera_bwd(const float* RT, const float* d_mvp, int B, int RT_batched, int H, int W, float* d_K,
                     vhap_stream_t stream);
-/* monocular case, vhap_camera_bwd + vhap_focal_bwd in one launch: d_focal_accum[0] += scale * sum_b (d_K[b].fx + d_K[b].fy), summed in
+/* monocular case, vhap_camera_bwd and the sum over the batch in one launch: d_focal_accum[0] += scale * sum_b (d_K[b].fx + d_K[b].fy), summed in
  * frame order (K = (f, f, cx, cy), f = focal_length * scale; tracker.py:148-157) */
 int vhap_camera_focal_bwd(const float* RT, const float* d_mvp, int B, int RT_batched, int H, int W, float scale,
                           float* d_focal_accum, vhap_stream_t stream);
@@ -703,9 +680,6 @@ int vhap_offset_dynamic_reg(const float* dyn, const int64_t* timesteps, int B, i
                             float* energy_accum, float* d_dyn, vhap_stream_t stream);
 int vhap_offset_grad_finish(const float* g_a, const float* g_b, const int64_t* timesteps, int B, int N, int V, float* d_static,
                             float* d_dyn, vhap_stream_t stream);
-/* d_focal_accum[0] += scale * sum_b (d_K[b][0] + d_K[b][1])   (K = (f, f, cx, cy), f = focal_length * scale) */
-int vhap_focal_bwd(const float* d_K, int B, float scale, float* d_focal_accum, vhap_stream_t stream);
-
 /* ---- frame ingest --------------------------------------------------------------------------------------
  * Replaces, per batch and on the device, the reference's per-image host transforms video_dataset.py:253-259 (apply_transforms):
  * :302-323 apply_background_color (fp64 compositing over 'white' / 'black', truncating uint8 cast) and :261-268 apply_to_tensor

@@ -34,7 +34,6 @@ SIGNATURES = {
     "vhap_deferred_shade_bwd_work_floats": (c_sz, [c_i] * 3),
     "vhap_deferred_lights_reduce": (c_i, [c_fp] * 5 + [c_i] * 3 + [c_fp, c_fp]),
     "vhap_deferred_shade_bwd": (c_i, [c_fp] * 7 + [c_i, c_i] + [c_fp] * 11 + [c_i] * 6 + [c_fp] * 8 + [c_sz, c_fp, c_fp, c_i, c_fp]),
-    "vhap_deferred_gbuffer_bwd": (c_i, [c_fp] * 7 + [c_i, c_i] + [c_fp] * 12 + [c_i] * 6 + [c_fp] * 7 + [c_sz, c_fp, c_fp, c_fp]),
     "vhap_raster_bwd": (c_i, [c_fp] * 5 + [c_i] * 5 + [c_fp, c_fp]),
     "vhap_gbuffer_bwd": (c_i, [c_fp] * 12 + [c_i] * 5 + [c_fp] * 3),
     "vhap_interp_fwd": (c_i, [c_fp, c_i, c_fp, c_fp, c_fp] + [c_i] * 6 + [c_fp, c_fp, c_fp]),
@@ -48,14 +47,13 @@ SIGNATURES = {
     "vhap_texture_mip_fold_gather": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp]),
     "vhap_texture_grad_binned_work_bytes": (c_sz, [c_i, c_i, c_i]),
     "vhap_texture_grad_binned": (c_i, [c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_sz, c_fp]),
-    "vhap_texture_grad_binned_ids": (c_i, [c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_sz, c_fp]),
     "vhap_texture_grad_binned_counted": (c_i, [c_i, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_sz, c_fp]),
+    "vhap_texture_grad_binned_ids": (c_i, [c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_sz, c_fp]),
     "vhap_antialias_work_ints": (c_sz, [c_i] * 4),
     "vhap_antialias_fwd": (c_i, [c_fp] * 5 + [c_i] * 6 + [c_fp, c_fp, c_fp]),
     "vhap_antialias_bwd": (c_i, [c_fp] * 8 + [c_i] * 6 + [c_fp, c_fp, c_i, c_fp]),
     "vhap_antialias_inplace_work_ints": (c_sz, [c_i] * 4),
     "vhap_antialias_inplace_fwd": (c_i, [c_fp] * 5 + [c_i] * 5 + [c_fp, c_fp]),
-    "vhap_antialias_inplace_detect": (c_i, [c_fp] * 4 + [c_i] * 5 + [c_fp, c_fp]),
     "vhap_antialias_inplace_silhouette": (c_i, [c_fp] * 3 + [c_i] * 5 + [c_fp, c_fp]),
     "vhap_antialias_inplace_pairs": (c_i, [c_fp] + [c_i] * 4 + [c_fp, c_fp]),
     "vhap_antialias_inplace_blend": (c_i, [c_fp] * 5 + [c_i] * 5 + [c_fp, c_fp]),
@@ -64,7 +62,6 @@ SIGNATURES = {
     "vhap_disturb_workspace_ints": (c_sz, [c_i] * 3),
     "vhap_disturb_fwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
     "vhap_disturb_fwd_rng": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_f, c_f, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
-    "vhap_disturb_fwd_rng_cid": (c_i, [c_fp, c_fp, c_i, c_f, c_f, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
     "vhap_disturb_inplace": (c_i, [c_fp, c_fp, c_i, c_fp, c_fp, c_fp, c_f, c_f, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
     "vhap_disturb_bwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp]),
     "vhap_shade_fwd": (c_i, [c_fp] * 8 + [c_i] * 4 + [c_fp] * 3 + [c_i, c_fp]),
@@ -114,7 +111,6 @@ SIGNATURES = {
     "vhap_energy_finalize": (c_i, [c_fp] * 5 + [c_f, c_f, c_i, c_i, c_i, c_fp, c_fp]),
     "vhap_energy_total": (c_i, [c_fp, c_fp, c_fp, c_f, c_i, c_fp, c_fp]),
     "vhap_sum_frames": (c_i, [c_fp, c_i, c_i, c_fp, c_fp]),
-    "vhap_focal_bwd": (c_i, [c_fp, c_i, c_f, c_fp, c_fp]),
     "vhap_adam_step": (c_i, [c_i] + [c_fp] * 8 + [c_f, c_f, c_f, c_i, c_fp]),
     "vhap_adam_advance": (c_i, [c_fp, c_fp]),
     "vhap_set_floats": (c_i, [c_fp, ctypes.POINTER(c_f), c_i, c_fp]),

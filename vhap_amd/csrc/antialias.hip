@@ -600,28 +600,10 @@ extern "C" int vhap_antialias_inplace_fwd(float* color, const float* rast, const
     return VHAP_OK;
 }
 
-// The same pass in two calls: `detect` (silhouette flags + pixel-pair discovery) reads only the rasteriser's output and the geometry --
-// NOT the colours -- so a step executor issues it right behind the rasteriser, beside whatever still produces the colours (the colour
-// disturbance), and `blend` (edge analysis + in-place colour update) once the colours are final.  detect + blend == vhap_antialias_inplace_fwd.
-extern "C" int vhap_antialias_inplace_detect(const float* rast, const float* pos, const int32_t* tri, const int32_t* opp, int B, int H, int W,
-                                             int V, int F, int32_t* work, vhap_stream_t stream) {
-    VHAP_ENTER();
-    if (!rast || !pos || !tri || !opp || !work) return VHAP_E_NULLPTR;
-    if (B <= 0 || H <= 0 || W <= 0 || V <= 0 || F <= 0 || (long long)B * H * W >= (1ll << 30)) return VHAP_E_BADDIM;
-    const long long npix = (long long)B * H * W;
-    hipStream_t st = vhap_stream(stream);
-    unsigned char* sil = reinterpret_cast<unsigned char*>(work + 4 + (size_t)ITEM2 * 2 * (size_t)npix);
-    unsigned* cand = reinterpret_cast<unsigned*>(work + 4 + (size_t)ITEM2 * 2 * (size_t)npix + ((size_t)B * F + 3) / 4);
-    aa_silhouette_kernel<<<vhap_cdiv((long long)B * F, 256), 256, 0, st>>>(reinterpret_cast<const float4*>(pos), tri, opp, B, V, F, H, W, sil, work);
-    VHAP_LAUNCH_CHECK();
-    aa_detect_kernel<4><<<vhap_cdiv(npix, DET_T * DET_PPT), DET_T, 0, st>>>(nullptr, reinterpret_cast<const float4*>(rast), sil, B, H, W, F, nullptr,
-                                                                          work, cand, 0);
-    VHAP_LAUNCH_CHECK();
-    return VHAP_OK;
-}
 
-// `detect` in its two halves, for a step executor that wants the silhouette flags (geometry only: they need neither the rasteriser's
-// output nor the colours) out of the way BEFORE the rasteriser has finished: silhouette + pairs == detect.
+// The forward in pieces (silhouette + pairs + blend == vhap_antialias_inplace_fwd), for a step executor that wants the silhouette flags
+// (geometry only: they need neither the rasteriser's output nor the colours) out of the way BEFORE the rasteriser has finished and the
+// pixel-pair discovery (rast only) beside whatever still produces the colours.
 extern "C" int vhap_antialias_inplace_silhouette(const float* pos, const int32_t* tri, const int32_t* opp, int B, int H, int W, int V, int F,
                                                  int32_t* work, vhap_stream_t stream) {
     VHAP_ENTER();

@@ -7,9 +7,9 @@
 // (render_nvdiffrast.py:386-421, 399) and emits what the two remaining consumers need: (uv, uv_da, d_albedo) for the texture-gradient
 // accumulation and (d_normal, d_uv, d_uv_da) for the G-buffer backward; d_lights is reduced per workgroup.  One pass instead of
 // vhap_photo_bwd + vhap_shade_bwd + vhap_texture_bwd(uv part), and none of normal / texc / texd / albedo / rast_db is read back from HBM.
-// (interp.hip holds the variant fused with the G-buffer backward: vhap_deferred_gbuffer_bwd.)
+// (A variant fused with the G-buffer backward -- the gradients of the interpolants never leaving registers -- was measured in round 3:
+// VALU-bound, no gain; removed in round 4, last in commit 2579046.)
 #include "deferred_common.h"
-#include "gbuffer_tile.h"
 
 namespace {
 
@@ -64,81 +64,6 @@ __global__ __launch_bounds__(DB_T) void deferred_shade_bwd_kernel(const Deferred
     }
     if (!P.part) return;
     deferred_lights_epilogue<DB_NW>(P, gl, red, any, R.on ? __popcll(__ballot(valid && !cov)) : 0, &s_nbg);
-}
-
-// ---- fused with the G-buffer backward: the gradients w.r.t. the interpolated normal / uv / uv derivatives stay in registers and go
-// straight into the barycentric chain and the per-tile vertex table (gbuffer_tile.h); one gather of the triangle's vertices serves both
-// halves.  One workgroup = one 16x16 pixel tile.
-__global__ __launch_bounds__(GT * GT) void deferred_gbuffer_bwd_kernel(const DeferredParams P, const unsigned char* __restrict__ uv_nograd,
-                                                                       float* __restrict__ d_pos, float* __restrict__ d_vnormal) {
-    __shared__ GbTile S;
-    __shared__ float s_l[27], s_c[9];
-    __shared__ float red[GT * GT / 64 * 4][27];
-    __shared__ int s_nbg;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int px = blockIdx.x * GT + (tid & (GT - 1)), py = blockIdx.y * GT + (tid >> 4), b = blockIdx.z;
-    const int H = P.H, W = P.W, V = P.V;
-    const bool inside = px < W && py < H;
-    const unsigned pi = (unsigned)(((size_t)b * H + (inside ? py : 0)) * W + (inside ? px : 0));
-    const float4 r = inside ? P.rast[pi] : make_float4(0.f, 0.f, 0.f, 0.f);
-    const int t = (int)r.w - 1;
-    const bool cov = inside && t >= 0 && t < P.F;
-    if (inside && !cov) {                    // background: nothing flows (its colour is the detached target / a constant)
-        float* da = P.d_albedo + 3 * (size_t)pi;
-        da[0] = 0.f; da[1] = 0.f; da[2] = 0.f;
-        if (P.tile_ids) P.tile_ids[pi] = (unsigned short)0xFFFF;
-    }
-    const unsigned npix = (unsigned)P.B * (unsigned)H * (unsigned)W;
-    const DiffuseReg R = diffuse_reg(P.d_reg, P.stats, npix);
-    if (__syncthreads_or(cov ? 1 : 0) == 0) {             // background tile: only its pixel count matters (diffuse regulariser)
-        if (R.on && P.part && tid == 0) {
-            const int nin = min(GT, W - (int)blockIdx.x * GT) * min(GT, H - (int)blockIdx.y * GT);
-            atomicAdd(&P.part[(size_t)((blockIdx.x + blockIdx.y * 7u + blockIdx.z * 13u) % DB_SLOTS) * DB_ROW + 27], (float)nin);
-        }
-        return;
-    }
-    if (tid < 27) s_l[tid] = P.lights[tid];
-    if (tid < 9) s_c[tid] = P.sh_const[tid];
-    if (tid == 0) s_nbg = 0;
-    gb_tile_init(S);
-    __syncthreads();
-    float acc[18], gl[27];
-#pragma unroll
-    for (int k = 0; k < 18; k++) acc[k] = 0.f;
-#pragma unroll
-    for (int k = 0; k < 27; k++) gl[k] = 0.f;
-    int i0 = 0, i1 = 0, i2 = 0;
-    int tb_tile = -1;
-    float tb_g = 0.f;
-    if (cov) {
-        const DeferredGrad o = deferred_pixel(P, R, s_l, s_c, pi, (unsigned)b, (unsigned)py, (unsigned)px, t, gl, tb_tile, tb_g);
-        i0 = o.i0; i1 = o.i1; i2 = o.i2;
-        const float b0 = r.x, b1 = r.y, b2 = (1.0f - b0) - b1;
-        float g0 = 0.f, g1 = 0.f;
-        float4 gd = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float* N = P.vnormal + (size_t)b * V * 3;
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const float v = o.gn[c];
-            const float n2 = N[3 * i2 + c];
-            acc[9 + c] = b0 * v; acc[12 + c] = b1 * v; acc[15 + c] = b2 * v;
-            g0 += v * (N[3 * i0 + c] - n2); g1 += v * (N[3 * i1 + c] - n2);
-        }
-        const float2 u0 = P.uv[o.j0], u1 = P.uv[o.j1], u2 = P.uv[o.j2];
-        const float2 e0 = make_float2(u0.x - u2.x, u0.y - u2.y), e1 = make_float2(u1.x - u2.x, u1.y - u2.y);
-        if (!(uv_nograd && uv_nograd[t])) {                  // texc.detach() on masked faces (render_nvdiffrast.py:391-396)
-            g0 += o.guv.x * e0.x + o.guv.y * e0.y;
-            g1 += o.guv.x * e1.x + o.guv.y * e1.y;
-        }
-        gd.x += o.gda.x * e0.x + o.gda.z * e0.y; gd.z += o.gda.x * e1.x + o.gda.z * e1.y;
-        gd.y += o.gda.y * e0.x + o.gda.w * e0.y; gd.w += o.gda.y * e1.x + o.gda.w * e1.y;
-        gb_chain(o.p0, o.p1, o.p2, b0, b1, px, py, H, W, g0, g1, gd, acc);
-    }
-    const bool any = __ballot(cov) != 0ull;
-    if (any && P.tb_counts) deferred_tile_histogram(P, tb_tile, tb_g, lane);
-    gb_tile_commit(S, acc, cov, i0, i1, i2, b, V, d_pos, d_vnormal, 0);
-    if (!P.part) return;
-    deferred_lights_epilogue<GT * GT / 64>(P, gl, red, any, R.on ? __popcll(__ballot(inside && !cov)) : 0, &s_nbg);
 }
 
 }  // namespace
@@ -226,32 +151,6 @@ extern "C" int vhap_deferred_shade_bwd(const float* pos, const int32_t* tri, con
     if (d_lights) {
         vhap_deferred_lights_reduce_kernel<<<27, DB_SLOTS, 0, st>>>(work, lights, sh_const, d_reg, reinterpret_cast<const unsigned*>(stats),
                                                                     (unsigned)npix, d_lights);
-        VHAP_LAUNCH_CHECK();
-    }
-    return VHAP_OK;
-}
-
-extern "C" int vhap_deferred_gbuffer_bwd(const float* pos, const int32_t* tri, const float* vnormal, const float* uv, const int32_t* tri_uv,
-                                         const float* tex, const float* mips, int Ht, int Wt, const float* lights, const float* sh_const,
-                                         const float* rast, const float* d_rgba, const float* pred_rgba, const float* gt_nchw,
-                                         const float* d_sum, const float* d_delta, const float* keep, const float* d_reg, const float* stats,
-                                         const uint8_t* uv_nograd_faces, int B, int V, int VT, int F, int H, int W, float* texc, float* texd,
-                                         float* d_albedo, float* d_pos, float* d_vnormal, float* d_lights, float* work, size_t work_floats,
-                                         void* texbin_work, uint16_t* tile_ids, vhap_stream_t stream) {
-    VHAP_ENTER();
-    if (!d_pos || !d_vnormal) return VHAP_E_NULLPTR;
-    DeferredParams P{};
-    if (int e = vhap_fill_deferred_params(P, pos, tri, vnormal, uv, tri_uv, tex, mips, Ht, Wt, lights, sh_const, rast, d_rgba, pred_rgba, gt_nchw,
-                                          d_sum, d_delta, keep, d_reg, stats, B, V, VT, F, H, W, texc, texd, d_albedo, d_lights, work, work_floats,
-                                          texbin_work, tile_ids))
-        return e;
-    if (B > 65535) return VHAP_E_BADDIM;
-    hipStream_t st = vhap_stream(stream);
-    deferred_gbuffer_bwd_kernel<<<dim3(vhap_cdiv(W, GT), vhap_cdiv(H, GT), B), GT * GT, 0, st>>>(P, uv_nograd_faces, d_pos, d_vnormal);
-    VHAP_LAUNCH_CHECK();
-    if (d_lights) {
-        vhap_deferred_lights_reduce_kernel<<<27, DB_SLOTS, 0, st>>>(work, lights, sh_const, d_reg, reinterpret_cast<const unsigned*>(stats),
-                                                                    (unsigned)((long long)B * H * W), d_lights);
         VHAP_LAUNCH_CHECK();
     }
     return VHAP_OK;

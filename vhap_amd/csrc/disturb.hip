@@ -365,13 +365,6 @@ extern "C" int vhap_disturb_fwd_rng(const float* rgba, const float* rast, const 
                        stream);
 }
 
-extern "C" int vhap_disturb_fwd_rng_cid(const float* rgba, const uint8_t* cid, int ncl, float rate_fg, float rate_bg, uint32_t* rng_state,
-                                        int B, int H, int W, int32_t* workspace, float* out, float* keep, vhap_stream_t stream) {
-    VHAP_ENTER();
-    if (!rng_state || !cid) return VHAP_E_NULLPTR;
-    return disturb_run(rgba, nullptr, cid, nullptr, 0, ncl, nullptr, nullptr, nullptr, rng_state, rate_fg, rate_bg, B, H, W, workspace, out, keep,
-                       stream);
-}
 
 extern "C" int vhap_disturb_inplace(float* rgba, const uint8_t* cid, int ncl, const int32_t* w_fg, const int32_t* w_bg, const int64_t* idx,
                                     float rate_fg, float rate_bg, uint32_t* rng_state, int B, int H, int W, int32_t* workspace, float* keep,

@@ -889,7 +889,7 @@ extern "C" int vhap_camera_focal_fwd(const float* focal_length, float focal_scal
 }
 
 // camera backward of the monocular case in ONE launch: d(focal_length) += scale * sum_b (dK[b].fx + dK[b].fy)  (K = (f, f, cx, cy), f =
-// focal_length * scale: vhap_camera_bwd + vhap_focal_bwd, two launches on the tail of the step's geometry chain).  The per-frame values
+// focal_length * scale: until round 3 vhap_camera_bwd + a summing kernel, two launches on the tail of the step's geometry chain).  The per-frame values
 // meet in LDS and lane 0 adds them in frame order -- the same sum, in the same order, as the two-launch form.
 __global__ __launch_bounds__(64) void camera_focal_bwd_kernel(const float* __restrict__ RT, const float* __restrict__ d_mvp, int B, int rtstride,
                                                               float h, float w, float scale, float* __restrict__ d_focal) {

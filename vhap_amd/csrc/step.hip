@@ -30,13 +30,6 @@ __global__ __launch_bounds__(256) void sum_frames_kernel(const float* __restrict
     out[i] += s;
 }
 
-__global__ void focal_bwd_kernel(const float* __restrict__ d_K, int B, float scale, float* __restrict__ d_focal) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    float s = 0.f;
-    for (int b = 0; b < B; b++) s += d_K[4 * b] + d_K[4 * b + 1];
-    d_focal[0] += s * scale;
-}
-
 }  // namespace
 
 extern "C" int vhap_energy_finalize(const float* frame_terms, const float* lmk_energy, const float* tex_terms, const float* off_terms,
@@ -79,11 +72,3 @@ extern "C" int vhap_sum_frames(const float* x, int B, int n, float* out_accum, v
     return VHAP_OK;
 }
 
-extern "C" int vhap_focal_bwd(const float* d_K, int B, float scale, float* d_focal_accum, vhap_stream_t stream) {
-    VHAP_ENTER();
-    if (!d_K || !d_focal_accum) return VHAP_E_NULLPTR;
-    if (B <= 0) return VHAP_E_BADDIM;
-    focal_bwd_kernel<<<1, 64, 0, vhap_stream(stream)>>>(d_K, B, scale, d_focal_accum);
-    VHAP_LAUNCH_CHECK();
-    return VHAP_OK;
-}
