@@ -259,11 +259,13 @@ def test_latency_bound_kernels_issue_their_loads_in_batches():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(root, "tools"))
     import isa_hops
-    files = [os.path.join(root, "vhap_amd", "csrc", f) for f in ("frame.hip", "flame.hip", "interp.hip", "deferred.hip", "disturb.hip", "antialias.hip", "pixel.hip")]
+    files = [os.path.join(root, "vhap_amd", "csrc", f) for f in ("frame.hip", "flame.hip", "interp.hip", "deferred.hip", "disturb.hip", "antialias.hip", "pixel.hip",
+                                                                 "raster.hip")]
     got = isa_hops.table(files)
     limit = {"frame_prep_fwd_kernel<5>": 9, "frame_prep_bwd_kernel<5>": 12, "verts_bwd_fused_kernel": 17, "flame_skin_fwd_kernel": 11,
              "flame_coef_bwd_kernel": 11, "deferred_shade_bwd_kernel": 11, "gbuffer_bwd_tiled_kernel": 8, "aa_detect_kernel<4>": 13,
-             "disturb_count_kernel": 7, "disturb_scatter_kernel": 9, "disturb_apply_kernel<true>": 9, "photo_fwd_kernel<true>": 8}
+             "disturb_count_kernel": 7, "disturb_scatter_kernel": 9, "disturb_apply_kernel<true>": 9, "photo_fwd_kernel<true>": 8,
+             "bin_build_kernel": 12, "vnormal_fwd_kernel": 10}
     for k, lim in limit.items():
         assert k in got, (k, sorted(got))
         groups, loads = got[k]
