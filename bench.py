@@ -545,6 +545,6 @@ def _supervised():
 
 
 if __name__ == "__main__":
-    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not os.environ.get("VHAP_BENCH_CHILD"):
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not os.environ.get("VHAP_BENCH_CHILD") and not {"-h", "--help"} & set(sys.argv[1:]):
         sys.exit(_supervised())
     main()
