@@ -536,9 +536,17 @@ def _supervised():
         p = subprocess.run(argv + extra, env=env, stdout=subprocess.PIPE, text=True)
         rc = p.returncode
         lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
-        if rc == 0 and lines:
+        done = False
+        for l in lines:                                   # (a complete result line counts even if the process then dies on its way out)
+            try:
+                done = done or "value" in json.loads(l)
+            except ValueError:
+                pass
+        if done:
             sys.stdout.write(p.stdout)
             sys.stdout.flush()
+            if rc:
+                print(f"[bench] the measuring process printed its result and then ended with exit code {rc}", file=sys.stderr, flush=True)
             return 0
         print(f"[bench] attempt {attempt + 1} ended with exit code {rc} and no result line; repeating", file=sys.stderr, flush=True)
     return rc or 1
