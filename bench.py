@@ -11,6 +11,9 @@ new shuffled batch every step in the reference, tracker.py:1376-1385).  Workload
     2 (default, the configuration `metric` is quoted on): monocular 512x512, 16 frames per batch
     3: monocular 1024x1024, 8 frames per batch, static offset
     4: NeRSemble-like, 16 calibrated views of one timestep, 802x550
+    5: config 2 x N INDEPENDENT subjects, one per GPU (seeds 0..N-1): replicas only -- no gradient exchange, no data-path collective
+       (the process group is used for the start / stop barrier and the max-over-ranks time alone)
+`python bench.py --gpus N` without a torchrun environment launches its own N ranks (torch.distributed.run, 127.0.0.1, a free port).
 N > 1, --scaling weak (default): every rank fits its own batch of the same size (global batch x N); --scaling strong: the batch (frames or
 views) is split B/N per rank.  The shared-parameter gradients are averaged over RCCL each step (vhap_amd.dist).
 Prints ONE JSON line on rank 0.  `roofline`: the fused rasterize+interpolate pass (bin_build + raster kernel behind
@@ -42,6 +45,8 @@ CONFIGS = {
     2: dict(B=16, H=512, W=512, kind="monocular", name="monocular 512x512, 16 frames per batch"),
     3: dict(B=8, H=1024, W=1024, kind="monocular", name="monocular 1024x1024, 8 frames per batch, static offset"),
     4: dict(B=16, H=802, W=550, kind="multiview", name="NeRSemble-like: 16 calibrated views of one timestep, 802x550"),
+    5: dict(B=16, H=512, W=512, kind="monocular", independent=True,
+            name="monocular 512x512, 16 frames per batch, one INDEPENDENT subject per GPU (replicas only, no gradient exchange)"),
 }
 
 
@@ -49,7 +54,8 @@ def ri_alg_bytes_per_frame(H, W):
     return 429364 + 68 * H * W           # geometry reads + 68 B/px of G-buffer writes
 
 
-def build_tracker(C, rank, world, device, scaling):
+def build_tracker(C, rank, world, device, scaling, subject=0):
+    """`subject`: seed offset of the synthetic subject (config 5: one subject per rank, each a single-process fit)."""
     from vhap_amd.config import BaseTrackingConfig, nersemble_config
     from vhap_amd.flame import FlameHead
     from vhap_amd.render_hip import HipDiffRenderer
@@ -59,8 +65,8 @@ def build_tracker(C, rank, world, device, scaling):
     model, topo = make_flame_model(seed=0)
     head = FlameHead(model, topo).to(device)
     rend = HipDiffRenderer(lighting_type="SH").to(device)
-    tex_gt = make_texture(1, TEX)
-    g = torch.Generator().manual_seed(123)                     # mid-fit state: ground truth + noise (same on all ranks)
+    tex_gt = make_texture(1 + subject, TEX)
+    g = torch.Generator().manual_seed(123 + subject)                     # mid-fit state: ground truth + noise (same on all ranks)
     if C["kind"] == "multiview":
         cfg = nersemble_config()
         cfg.device = device
@@ -85,10 +91,10 @@ def build_tracker(C, rank, world, device, scaling):
         cfg.device = device
         n_local = B // world if scaling == "strong" else B
         n_total = n_local * world
-        gt = make_scene_params(n_total, seed=0, image_size=(H, W))
+        gt = make_scene_params(n_total, seed=subject, image_size=(H, W))
         own = np.arange(rank * n_local, (rank + 1) * n_local)
         gt_own = {k: (v[own] if (isinstance(v, np.ndarray) and v.ndim >= 1 and v.shape[0] == n_total) else v) for k, v in gt.items()}
-        d_own = make_dataset(rend, head, gt_own, (H, W), device, seed=rank, tex=tex_gt)
+        d_own = make_dataset(rend, head, gt_own, (H, W), device, seed=rank + subject, tex=tex_gt)
         data = {"rgb": torch.zeros(n_total, 3, H, W, device=device), "lmk2d": torch.zeros(n_total, d_own["lmk2d"].shape[1], 3, device=device)}
         data["rgb"][own] = d_own["rgb"]
         data["lmk2d"][own] = d_own["lmk2d"]
@@ -372,7 +378,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json config number (default 2)")
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS), help="BASELINE.json config number (default 2); 5 = one independent subject per GPU")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL; gloo for single-GPU tests of the multi-rank path)")
     ap.add_argument("--unroll", type=int, default=1, help="steps per graph launch on one GPU (1 = what the stage really does)")
@@ -387,36 +393,48 @@ def main():
     C = CONFIGS[args.config]
 
     from vhap_amd import dist as vdist
+    independent = bool(C.get("independent"))
     rank, world, local = vdist.init_from_env(args.backend)
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    if args.scaling == "strong" and C["B"] % world:
-        raise SystemExit(f"--scaling strong: {C['B']} frames do not split over {world} ranks")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} "
+                         "(or without a torchrun environment: bench.py then launches its own ranks)")
+    if args.scaling == "strong" and (C["B"] % world or independent):
+        raise SystemExit(f"--scaling strong: {C['B']} frames do not split over {world} ranks" if not independent else
+                         "--config 5 is replicas only (one independent subject per GPU): weak scaling by construction")
     local = local % max(torch.cuda.device_count(), 1)            # (gloo on one GPU: every rank on the only device)
     torch.cuda.set_device(local)
     device = f"cuda:{local}"
-    tr, own, n_local, model, topo, gt = build_tracker(C, rank, world, device, args.scaling)
+    if independent:                                              # every rank = a single-process fit of ITS subject
+        tr, own, n_local, model, topo, gt = build_tracker(C, 0, 1, device, "weak", subject=rank)
+    else:
+        tr, own, n_local, model, topo, gt = build_tracker(C, rank, world, device, args.scaling)
     n_ranks_seen = 1
-    if world > 1:
-        vdist.attach(tr)
+    group_up = torch.distributed.is_available() and torch.distributed.is_initialized()
+    if group_up and not independent:
+        ctx = vdist.attach(tr)                                   # world > 1, or a one-rank group under VHAP_FORCE_DIST=1
+        if not ctx.probe() and rank == 0:
+            print("[bench] the collective library refused reduce-scatter / all-gather / ReduceOp.AVG on this box: the texture update falls "
+                  "back to all-reduce + replicated finish (VHAP_TEX_SHARDED=0)", file=sys.stderr, flush=True)
+    if group_up:
         # every rank contributes a one: the sum is the number of ranks the collective library really connected (the driver checks it
         # against --gpus)
         ones = torch.ones(1, device=device if torch.distributed.get_backend() == "nccl" else "cpu")
         torch.distributed.all_reduce(ones)
         n_ranks_seen = int(ones.item())
+    sharded = tr.dist is not None and tr.dist.sharded
     optimizer = tr.configure_optimizer(tr.get_train_parameters(STAGE), lr_scale=0.1)
     sample = tr.get_sample(own, device_index=True)
     assert sample["rgb"].shape[0] == n_local
     step = None
     if not args.eager:
         from vhap_amd.tracker import GraphedStep
-        unroll = args.unroll if (world == 1 and args.steps % args.unroll == 0 and args.warmup % args.unroll == 0) else 1
+        unroll = args.unroll if (not sharded and args.steps % args.unroll == 0 and args.warmup % args.unroll == 0) else 1
         ok, why = 1, ""
         try:
             step = GraphedStep(tr, sample, optimizer, STAGE, unroll=unroll)
         except Exception as e:                                   # a failed capture must not sink the run: same work, eager launches
             ok, why, step = 0, f"{type(e).__name__}: {e}", None
-        if world > 1:                                            # all ranks take the same path
+        if world > 1 and not independent:                        # all ranks take the same path
             flag = torch.tensor([ok], dtype=torch.int32, device=device if torch.distributed.get_backend() == "nccl" else "cpu")
             torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
             if int(flag) == 0:
@@ -425,7 +443,7 @@ def main():
             print(f"[bench] captured step unavailable ({why or 'another rank failed'}); running the eager step", file=sys.stderr, flush=True)
 
     def barrier():
-        if world > 1:
+        if group_up:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -443,7 +461,7 @@ def main():
             run()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if group_up:
         t = torch.tensor([dt], dtype=torch.float64, device=device if torch.distributed.get_backend() == "nccl" else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t)
@@ -452,7 +470,7 @@ def main():
         alg = ri_alg_bytes_per_frame(H, W) * n_local
         ri_iso, cov = time_ri_isolated(tr, sample, C, step.stream if step is not None else torch.cuda.Stream())
         fused = sep = None
-        if world == 1:
+        if world == 1 and not sharded:
             try:
                 fused = time_ri_in_step(tr, sample, optimizer, deferred=True)
                 sep = time_ri_in_step(tr, sample, optimizer, deferred=False)
@@ -461,7 +479,7 @@ def main():
         ri_step = sum(sep) if sep else ri_iso
         traffic, traffic_src = pmc_traffic() if args.config == 2 and n_local == 16 else (None, None)
         stage = None
-        if world == 1 and not args.no_stage and C["kind"] == "monocular":
+        if world == 1 and not sharded and not args.no_stage and C["kind"] == "monocular":
             try:
                 stage = stage_fps(C, tr, model, topo, gt)
             except Exception as e:                               # noqa: BLE001 -- must never sink the throughput number
@@ -480,8 +498,14 @@ def main():
                                    "regularisers, colour disturbance on), FLAME topology V=5143 F=10144, texture 2048x2048, fwd+bwd+Adam, "
                                    "one step per replay of the captured plan",
                        "global_batch": n_local * world, "frames_per_gpu": n_local,
-                       "parallelism": f"dp{world} {args.scaling} (frame-sharded; per step one scalar all-reduce + two gradient all-reduces over "
-                                      f"{'RCCL' if world > 1 and torch.distributed.get_backend() == 'nccl' else 'the process group'})",
+                       "parallelism": (f"{world} independent replicas (one subject per GPU, seeds 0..{world - 1}; no gradient exchange, no data-path collective)"
+                                       if independent else
+                                       f"dp{world} {args.scaling} (frame-sharded; per step one scalar all-reduce, a reduce-scatter + all-gather of the "
+                                       f"texture rows and one small-gradient all-reduce over "
+                                       f"{'RCCL' if group_up and torch.distributed.get_backend() == 'nccl' else 'the process group'}"
+                                       f"{'; ONE rank forced through the sharded step (VHAP_FORCE_DIST=1)' if sharded and world == 1 else ''})"
+                                       if sharded else "one GPU, one process"),
+                       "sharded_step": bool(sharded), "tex_sharded": bool(getattr(step, "tex_sharded", False)) if step is not None else False,
                        "coverage": cov, "captured_step": step is not None, "unroll": per_call},
             "roofline": {"bound": "hbm", "achieved": alg / ri_step / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": alg / ri_step / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
@@ -515,7 +539,7 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {type(e).__name__}: {e}"}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if group_up:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
@@ -524,8 +548,10 @@ def _supervised():
     """One GPU: the measurement runs in a child process and is repeated (once, then once more on eager launches) if that process DIES -- a
     runtime error thrown out of a destructor during a stream capture cannot be caught in Python and took one of ~60 bench runs of round 4
     with it (profiles/r04_call33_capture_abort.txt; the capture now runs with the collector off, vhap_amd/tracker.py).  The timed region
-    is inside the child and unchanged; a run that prints its JSON line is never repeated.  Multi-rank launches (torch.distributed.run
-    owns the processes) run main() directly."""
+    is inside the child and unchanged; a run that prints its JSON line is never repeated.  What happened is PART of the line: `supervisor`
+    = {attempts, child_exit_code, fallback} (fallback "--eager" = the number is an eager-launch measurement), and a child that printed
+    its line and then died still makes this process exit non-zero.  Multi-rank launches (torch.distributed.run owns the processes) run
+    main() directly."""
     import subprocess
     argv = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ, VHAP_BENCH_CHILD="1")
@@ -535,24 +561,60 @@ def _supervised():
             break
         p = subprocess.run(argv + extra, env=env, stdout=subprocess.PIPE, text=True)
         rc = p.returncode
-        lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
-        done = False
-        for l in lines:                                   # (a complete result line counts even if the process then dies on its way out)
-            try:
-                done = done or "value" in json.loads(l)
-            except ValueError:
-                pass
+        out_lines, done = [], False
+        for l in p.stdout.splitlines():                   # (a complete result line counts even if the process then dies on its way out)
+            if l.startswith("{"):
+                try:
+                    d = json.loads(l)
+                    if "value" in d:
+                        d["supervisor"] = {"attempts": attempt + 1, "child_exit_code": rc, "fallback": (extra[0] if extra else None)}
+                        l, done = json.dumps(d), True
+                except ValueError:
+                    pass
+            out_lines.append(l)
         if done:
-            sys.stdout.write(p.stdout)
+            sys.stdout.write("\n".join(out_lines) + "\n")
             sys.stdout.flush()
             if rc:
                 print(f"[bench] the measuring process printed its result and then ended with exit code {rc}", file=sys.stderr, flush=True)
-            return 0
+            return rc
         print(f"[bench] attempt {attempt + 1} ended with exit code {rc} and no result line; repeating", file=sys.stderr, flush=True)
     return rc or 1
 
 
+def _self_launch(n):
+    """`python bench.py --gpus N` outside a torchrun environment: become `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` (one rank per GPU; rank 0 prints the one JSON line)."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    argv = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execv(sys.executable, argv)
+
+
+def _gpus_arg(argv):
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            return int(argv[i + 1])
+        if a.startswith("--gpus="):
+            return int(a.split("=", 1)[1])
+    return 1
+
+
 if __name__ == "__main__":
+    if not {"-h", "--help"} & set(sys.argv[1:]) and "WORLD_SIZE" not in os.environ and not os.environ.get("VHAP_BENCH_CHILD"):
+        try:
+            n = _gpus_arg(sys.argv[1:])
+        except ValueError:
+            n = 1                                          # (argparse reports it)
+        if n > 1:
+            _self_launch(n)
+        sys.exit(_supervised())
     if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not os.environ.get("VHAP_BENCH_CHILD") and not {"-h", "--help"} & set(sys.argv[1:]):
         sys.exit(_supervised())
     main()

@@ -268,3 +268,77 @@ def test_two_rank_sharded_texture_update_collectives():
     want = torch.arange(3 * T * T, dtype=torch.float32).reshape(3, T, T) - 0.5 * mean.permute(2, 0, 1)
     assert torch.equal(ret[0][1], ret[1][1]), "replicas disagree"
     assert torch.allclose(ret[0][1], want, rtol=0, atol=1e-6)
+
+
+def _worker_probe(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.pop("VHAP_TEX_SHARDED", None)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vhap_amd.dist import FrameShardContext
+    ctx = FrameShardContext()
+    ok = ctx.probe()
+    # a library that refuses a collective (every rank raises at the same call: an unsupported op / dtype is refused before anything goes
+    # on the wire) selects the replicated texture update, and nobody dies
+    def boom(*a, **k):
+        raise RuntimeError("collective refused")
+    ctx.reduce_scatter_mean = boom
+    ok2 = ctx.probe()
+    ret[rank] = (ok, ok2, os.environ.get("VHAP_TEX_SHARDED"), ctx.sharded)
+    dist.destroy_process_group()
+
+
+def test_collective_probe_agrees_on_a_fallback():
+    """FrameShardContext.probe(): every collective of the sharded texture update once on small tensors; a refusal selects
+    VHAP_TEX_SHARDED=0 on every rank (bench.py then prints a note instead of dying: VERDICT r4 item 1d)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ret = mp.Manager().dict()
+    mp.spawn(_worker_probe, args=(2, port, ret), nprocs=2, join=True)
+    for r in range(2):
+        assert ret[r] == (True, False, "0", True), ret[r]
+
+
+def test_forced_one_rank_group(monkeypatch):
+    """VHAP_FORCE_DIST=1: a single process gets a world-size-1 group and its context reports `sharded` (the four-plan step with real
+    collectives on the one GPU a developer has -- the GPU half is tests/test_dist_gpu.py)."""
+    from vhap_amd import dist as vdist
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        monkeypatch.delenv(k, raising=False)
+    assert vdist.init_from_env("gloo") == (0, 1, 0) and not dist.is_initialized()
+    monkeypatch.setenv("VHAP_FORCE_DIST", "1")
+    try:
+        assert vdist.init_from_env("gloo") == (0, 1, 0) and dist.is_initialized() and dist.get_world_size() == 1
+        ctx = vdist.FrameShardContext()
+        assert ctx.sharded and ctx.world_size == 1
+        out = torch.empty(8)
+        ctx.reduce_scatter_mean(torch.arange(8.0), out, async_op=True).wait()
+        assert torch.equal(out, torch.arange(8.0))
+        monkeypatch.setenv("VHAP_FORCE_DIST", "0")
+        assert not vdist.FrameShardContext().sharded
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        os.environ.pop("MASTER_PORT", None)
+
+
+def test_bench_launches_its_own_ranks(monkeypatch):
+    """`python bench.py --gpus N` outside a torchrun environment must become a torch.distributed.run launch of N ranks (VERDICT r4
+    missing 1: it exited with an error); inside one (WORLD_SIZE set) it must not re-launch."""
+    import importlib.util
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench._gpus_arg(["--steps", "3", "--gpus", "8"]) == 8 and bench._gpus_arg(["--gpus=4"]) == 4 and bench._gpus_arg([]) == 1
+    seen = {}
+    monkeypatch.setattr(os, "execv", lambda exe, argv: seen.update(exe=exe, argv=argv))
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "5", "--warmup", "2", "--config", "5"])
+    bench._self_launch(8)
+    a = seen["argv"]
+    assert a[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nproc-per-node=8" in a and "--nnodes=1" in a
+    assert a[a.index("--master-addr") + 1] == "127.0.0.1" and int(a[a.index("--master-port") + 1]) > 0
+    assert a[-8:] == ["--gpus", "8", "--steps", "5", "--warmup", "2", "--config", "5"] and a[-9].endswith("bench.py")
+    assert 5 in bench.CONFIGS and bench.CONFIGS[5].get("independent")

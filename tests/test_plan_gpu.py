@@ -254,3 +254,19 @@ def test_multiview_stage_loop_self_feeding_step_matches_host_fed(flame_model, mo
             fails.append(f"{k}: {d:.2e} (floor {floor:.2e})")
     _record("plan_stage_loop_multiview_feed.txt", lines + fails)
     assert not fails, fails
+
+
+def test_set_ints_passes_bits_under_flush_denormal():
+    """The self-feeding step's int32 cursor (0, m) is written by a launch carrying the ints in its arguments.  Small ints are float32
+    SUBNORMALS: any float conversion on a host thread in FTZ / DAZ mode (torch.set_flush_denormal(True)) would flush them to 0 and the
+    stage would silently train on batch 0 (round-4 advisor finding).  The bits must arrive, NaN patterns included."""
+    from vhap_amd.tracker import _set_ints
+    vals = (0, 80, 1, 0x7fc00001, -1, 0x7f800001, 5, -2 ** 31)         # subnormals, a quiet and a signalling NaN pattern, -0.0
+    dst = torch.full((len(vals),), 77, dtype=torch.int32, device="cuda")
+    torch.set_flush_denormal(True)
+    try:
+        _set_ints(dst, vals)
+        torch.cuda.synchronize()
+    finally:
+        torch.set_flush_denormal(False)
+    assert dst.cpu().tolist() == list(vals)

@@ -8,6 +8,7 @@
 //                instead of ~12 full-size elementwise launches.
 //   adam       : one launch for every parameter tensor of the step (torch.optim.Adam semantics, tracker.py:159-211).
 #include "common.h"
+#include <string.h>
 
 namespace {
 
@@ -704,7 +705,7 @@ extern "C" int vhap_set_floats(float* dst_device, const float* values_host, int 
     if (!dst_device || !values_host) return VHAP_E_NULLPTR;
     if (n <= 0 || n > 16) return VHAP_E_BADDIM;
     FloatVals v{};
-    for (int i = 0; i < n; i++) v.v[i] = values_host[i];
+    memcpy(v.v, values_host, sizeof(float) * n);      // bits, not values: callers also pass int32 patterns (subnormals / NaNs as floats)
     set_floats_kernel<<<1, 64, 0, vhap_stream(stream)>>>(dst_device, v, n);
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;

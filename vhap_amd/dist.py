@@ -25,7 +25,15 @@ class FrameShardContext:
         self.group = group
         self.rank = dist.get_rank(group)
         self.world_size = dist.get_world_size(group)
+        # a ONE-rank group can still be made to take the sharded step (four plans with the collectives in between) -- VHAP_FORCE_DIST=1:
+        # the RCCL calls (ReduceOp.AVG reduce-scatter, all-gather, asynchronous handles) then run for real on the one GPU a developer has
+        self.force = os.environ.get("VHAP_FORCE_DIST", "0") == "1"
         self._flat = None
+
+    @property
+    def sharded(self):
+        """True when the step runs in its frame-sharded form (collectives between the plans)."""
+        return self.world_size > 1 or self.force
 
     # ---- sharding ----
     def shard_slice(self, n):
@@ -51,6 +59,47 @@ class FrameShardContext:
             else:
                 out[k] = v
         return out
+
+    def probe(self):
+        """Try every collective the sharded texture update issues, once, on small tensors, BEFORE a step is captured: reduce-scatter
+        with ReduceOp.AVG, all-gather into a tensor, an asynchronous averaged all-reduce.  A collective library that refuses one of them
+        (an unsupported op is refused on every rank at the same call, before anything is on the wire; the verdict is agreed by an
+        all-reduce all the same) must not end the job -- the step then takes the all-reduce + replicated
+        finish form (VHAP_TEX_SHARDED=0).  -> True when the sharded texture update can be used."""
+        ok = 1
+        try:
+            dev = "cuda" if dist.get_backend(self.group) == "nccl" else "cpu"
+            n = self.world_size
+            full = torch.arange(16 * n, dtype=torch.float32, device=dev)
+            out = torch.empty(16, dtype=torch.float32, device=dev)
+            self.reduce_scatter_mean(full, out, async_op=True).wait()
+            planes = torch.zeros(2, 4 * n, 8, dtype=torch.float32, device=dev)
+            planes[:, 4 * self.rank:4 * self.rank + 4] = float(self.rank + 1)
+            for w in self.all_gather_rows(planes, 4 * self.rank, 4, async_op=True):
+                w.wait()
+            ones = torch.ones(4, dtype=torch.float32, device=dev)
+            w = self.all_reduce_mean_(ones, async_op=True)
+            if w is not None:
+                w.wait()
+            if dev == "cuda":
+                torch.cuda.synchronize()
+            want = torch.arange(16 * n, dtype=torch.float32).view(n, 16)[self.rank]
+            if not (torch.allclose(out.cpu(), want) and all(float(planes[0, 4 * r, 0]) == r + 1 for r in range(n)) and
+                    torch.allclose(ones.cpu(), torch.ones(4))):
+                ok = 0
+        except Exception as e:                                   # noqa: BLE001 -- whatever the library raises
+            import sys
+            print(f"[vhap_amd.dist] rank {self.rank}: collective probe failed: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+            ok = 0
+        try:
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if dist.get_backend(self.group) == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            ok = int(flag.item())
+        except Exception:                                        # noqa: BLE001
+            ok = 0
+        if not ok:
+            os.environ["VHAP_TEX_SHARDED"] = "0"
+        return bool(ok)
 
     # ---- collectives ----
     def all_reduce_sum(self, t):
@@ -135,12 +184,21 @@ class FrameShardContext:
 
 
 def init_from_env(backend=None):
-    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun); returns (rank, world, local_rank)."""
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun); returns (rank, world, local_rank).  A single process
+    gets no group -- unless VHAP_FORCE_DIST=1, which creates a world-size-1 group (RCCL on a GPU) so that the sharded step and its
+    collectives can be run on one device (tests/test_dist_gpu.py, bench.py)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("VHAP_FORCE_DIST", "0") == "1"
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1 and "MASTER_PORT" not in os.environ:
+            import socket
+            s = socket.socket()
+            s.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+            s.close()
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"

@@ -174,7 +174,7 @@ class NativeStep:
         self.tb_ids = False
         # one GPU: energy assembly + upstream gradient in the epilogue of the photometric sum (under sharding the pixel count is all-reduced
         # between the passes, so the two glue launches stay)
-        self.energy_fused = self.deferred and (tracker.dist is None or tracker.dist.world_size == 1)
+        self.energy_fused = self.deferred and (tracker.dist is None or not tracker.dist.sharded)
         # one GPU, in-place antialiasing: the colour part of the antialias backward is computed UNSCALED by extra workgroups of the photometric
         # sum's launch (it needs the final image, not the sum), the shading backward multiplies it by the upstream gradient, and the position
         # part runs on the side chain -- no antialias kernel between the photometric sum and the shading backward (20 us + a hand-over)

@@ -1029,8 +1029,11 @@ class GlobalTracker(FlameTracker):
 
 def _set_ints(dst, values):
     """dst (int32 device tensor) = values, as one tiny launch carrying them in its arguments (no blocking copy: vhap_set_floats on the bits)"""
-    bits = np.asarray(values, np.int32).view(np.float32)
-    _lib.check(_lib.lib().vhap_set_floats(dst.data_ptr(), (ctypes.c_float * len(bits))(*bits.tolist()), len(bits),
+    # the BITS travel, never a float value: small ints are float32 subnormals (flushed to zero by a host thread in FTZ / DAZ mode --
+    # torch.set_flush_denormal(True) -- on any int -> float -> double -> float conversion) and some patterns are NaNs
+    raw = np.ascontiguousarray(np.asarray(values, np.int32)).tobytes()
+    n = len(raw) // 4
+    _lib.check(_lib.lib().vhap_set_floats(dst.data_ptr(), (ctypes.c_float * n).from_buffer_copy(raw), n,
                                           torch.cuda.current_stream().cuda_stream), "vhap_set_floats")
 
 
@@ -1322,9 +1325,9 @@ class GraphedStep:
         if self.ns is not None:
             ns = self.ns
             world = tracker.dist.world_size if tracker.dist is not None else 1
-            if world > 1:
+            self.single = tracker.dist is None or not tracker.dist.sharded      # (a one-rank group takes the sharded form under VHAP_FORCE_DIST)
+            if not self.single:
                 ns.n_global = torch.ones(1, device=dev)             # receives the all-reduced alpha count before every backward replay
-            self.single = world == 1
             if self.single:
                 # nothing happens between the passes on one GPU: ONE plan per step.  `unroll` > 1: that many consecutive steps per replay
                 self.unroll = max(1, int(unroll))
