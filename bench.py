@@ -506,7 +506,8 @@ def main():
                                        f"{'; ONE rank forced through the sharded step (VHAP_FORCE_DIST=1)' if sharded and world == 1 else ''})"
                                        if sharded else "one GPU, one process"),
                        "sharded_step": bool(sharded), "tex_sharded": bool(getattr(step, "tex_sharded", False)) if step is not None else False,
-                       "coverage": cov, "captured_step": step is not None, "unroll": per_call},
+                       "coverage": cov, "captured_step": step is not None, "unroll": per_call,
+                       "deferred_join": bool(getattr(step, "defer_join", False)) if step is not None else False},
             "roofline": {"bound": "hbm", "achieved": alg / ri_step / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": alg / ri_step / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
                          "frac_in_step": (alg / sum(sep) / HBM_PEAK) if sep else None,

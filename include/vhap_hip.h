@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VHAP_ABI_VERSION 8
+#define VHAP_ABI_VERSION 9
 
 #define VHAP_OK 0
 #define VHAP_E_NULLPTR (-1)   /* a required pointer is NULL */
@@ -91,6 +91,12 @@ int vhap_stream_destroy(vhap_stream_t stream);
 /* VHAP_RASTER_STATS_LATER (vhap_raster_shade_fwd): leave the reduction of the per-wave shading statistics to a later
  * vhap_raster_shade_stats call on the same workspace (nothing on the pixel chain reads them before the energy is assembled). */
 #define VHAP_RASTER_STATS_LATER 16
+/* VHAP_RASTER_PREFILL (ABI 9): EARLY STORES.  The binning launch also reduces, per frame, the 8x8-block bounding box of the clip positions
+ * and stores the output of every block outside it (zeros; deferred shading: the background composite) with workgroups of its own; the
+ * raster kernel's waves of those blocks leave at once.  A single call (binning + raster) always does this.  Split calls do it when BOTH
+ * carry the flag: the VHAP_RASTER_BIN_ONLY call then needs the output pointers (vhap_raster_bin_vnormal_prefill), the
+ * VHAP_RASTER_PREBINNED call reads the boxes from `workspace`.  Results are bit-identical with and without. */
+#define VHAP_RASTER_PREFILL 32
 size_t vhap_raster_profile_offset(int B, int F, int H, int W, size_t pair_capacity);
 size_t vhap_raster_workspace_bytes(int B, int F, int H, int W, size_t pair_capacity);
 int vhap_raster_fwd(const float* pos, const int32_t* tri, int B, int V, int F, int H, int W,
@@ -142,6 +148,16 @@ int vhap_raster_shade_fwd(const float* pos, const int32_t* tri, const float* vno
 int vhap_raster_bin_vnormal(const float* pos, const int32_t* tri, const int32_t* tri_uv, int B, int V, int F, int H, int W,
                             void* workspace, size_t workspace_bytes, size_t pair_capacity, int flags, const float* verts,
                             const int32_t* vc_ptr, const int32_t* vc_idx, float* vn, float* inv_len, vhap_stream_t stream);
+/* vhap_raster_bin_vnormal + the early stores of the deferred-shading pass (VHAP_RASTER_PREFILL, above): rast / rgba (background composite:
+ * bg_image [B,3,H,W] image space or bg_color[3]) / cid (fid2cid[0]) / tile_ids (0xFFFF) of every block outside the frame's geometry box.
+ * Follow with vhap_raster_shade_fwd(..., VHAP_RASTER_PREBINNED | VHAP_RASTER_PREFILL) on the same outputs and workspace.
+ * Replaces (reference): the background part of dr.rasterize + the composite, render_nvdiffrast.py:254,405-421. */
+int vhap_raster_bin_vnormal_prefill(const float* pos, const int32_t* tri, const int32_t* tri_uv, int B, int V, int F, int H, int W,
+                                    void* workspace, size_t workspace_bytes, size_t pair_capacity, int flags, const float* verts,
+                                    const int32_t* vc_ptr, const int32_t* vc_idx, float* vn, float* inv_len,
+                                    const float* bg_image, const float* bg_color, const int32_t* fid2cid, int nfid,
+                                    float* rast, float* rgba, uint8_t* cid, uint16_t* tile_ids, vhap_stream_t stream);
+
 /* The statistics reduction a vhap_raster_shade_fwd(..., VHAP_RASTER_STATS_LATER) call left out: same sizes, workspace and flags. */
 int vhap_raster_shade_stats(int B, int F, int H, int W, void* workspace, size_t workspace_bytes, size_t pair_capacity, int flags,
                             float* stats, vhap_stream_t stream);

@@ -8,7 +8,7 @@ Every energy term and the gradient w.r.t. every parameter of NativeStep (deferre
 colour disturbance ON with injected draws) against ONE fp64 oracle evaluation each (same triangle ids: the rasteriser is compared bit for
 bit at these batches in tests/test_raster_gpu.py).  What the full batch exercises that B <= 2 does not: the disturbance's colour pools over
 the whole batch (render_nvdiffrast.py:424-460), the batch-global photometric normaliser (tracker.py:439), diffuse.max() over 16 frames
-(:549), the uv-binned texture gradient summed over all frames.  Tolerances as in tests/test_parity_sizes_gpu.py (terms 5e-5; gradients
+(:549), the uv-binned texture gradient summed over all frames.  Tolerances as in tests/test_parity_sizes_gpu.py (terms 5e-6; gradients per parameter against the float32 oracle's own spread on the same batch, and
 5e-4 of the max-norm at config 2, 3e-3 at configs 3 / 4).  One oracle evaluation takes 1 - 3 minutes on the host cores."""
 import pytest
 

@@ -12,8 +12,9 @@ of the in-kernel generator) -- every energy term and the gradient w.r.t. every p
 and K = 10 optimiser steps at 2 x 512 x 512, T = 2048 against the oracle's fit loop (fp64 + torch.optim.Adam).
 
 Same visibility throughout (the oracle is handed the triangle ids the HIP rasteriser produced: the rasteriser itself is compared bit for
-bit at these sizes in tests/test_raster_gpu.py).  Stated tolerances, fp32 product vs fp64 oracle: energy terms 5e-5 relative (measured
-<= 1.3e-6); gradients, as a fraction of their max-norm and with cosine >= 0.999999: 5e-4 at 2 x 512^2 (measured <= 1.8e-4), 3e-3 at
+bit at these sizes in tests/test_raster_gpu.py).  Stated tolerances, fp32 product vs fp64 oracle: energy terms 5e-6 relative (measured
+<= 1.3e-6); gradients: PER PARAMETER against the float32 oracle's own distance from the float64 oracle on the same batch (see
+_native_vs_oracle), and as absolute ceilings, as a fraction of their max-norm and with cosine >= 0.999999: 5e-4 at 2 x 512^2 (measured <= 1.8e-4), 3e-3 at
 1024^2 and at 802 x 550 (measured <= 7.2e-4, one array -- static_offset at 1024^2 -- 2.7e-3).  The yardstick is what fp32 arithmetic
 itself costs on this energy: the ORACLE evaluated in float32 instead of float64 (same triangle ids, torch-CPU) lands 1e-4 .. 9e-4 from
 its own float64 gradient on the geometry parameters at all three sizes, 2.3e-3 on `lights` at 802 x 550
@@ -32,8 +33,18 @@ pytestmark = pytest.mark.gpu
 T = 2048
 
 
-def _native_vs_oracle(tr, cfg, topo, tm, base_tex, sample, o_sample, stage, image_size, names, lines, tag, seed, grad_bound=5e-4):
-    """-> list of failures.  NativeStep (as the captured step runs it) with injected disturbance vs energy_ref.total_energy."""
+TERM_BOUND = 5e-6        # energy terms, relative (measured <= 1.3e-6 at every size)
+SPREAD_FACTOR = 1.5      # a gradient may stand at most this many times further from the float64 oracle than the float32 ORACLE does ...
+SPREAD_FLOOR = 2e-5      # ... or this fraction of its max-norm, where float32 torch-CPU happens to land closer than that
+
+
+def _native_vs_oracle(tr, cfg, topo, tm, base_tex, sample, o_sample, stage, image_size, names, lines, tag, seed, grad_bound=5e-4, spread=True):
+    """-> list of failures.  NativeStep (as the captured step runs it) with injected disturbance vs energy_ref.total_energy.
+    `spread`: the gradient gate is MEASURED, per parameter, on this very batch: the oracle is evaluated once more in
+    float32 (same triangle ids, same disturbance draws, same side of the L1 kinks) and
+        err(HIP, oracle fp64)  <=  max(SPREAD_FACTOR * err(oracle fp32, oracle fp64), SPREAD_FLOOR)
+    is asserted for every trained parameter, errors as fractions of the float64 gradient's max-norm; `grad_bound` stays as an absolute
+    ceiling on top of it."""
     from vhap_amd.step import NativeStep
     H, W = image_size
     B = sample["rgb"].shape[0]
@@ -73,20 +84,41 @@ def _native_vs_oracle(tr, cfg, topo, tm, base_tex, sample, o_sample, stage, imag
     fails = []
     lines.append(f"{tag}: {B} x {H}x{W}, T = {T}, stage {stage}, coverage {cov:.3f}, disturbed {float(1 - keep.mean()):.3f}, "
                  f"L1 residuals on opposite sides of zero in the two evaluations: {n_kink} of {res_hip.numel()}")
-    assert n_kink <= 1e-5 * res_hip.numel(), n_kink
+    # observed: 0 - 5 per batch (round-4 advisor: 1e-5 * numel would have hidden a small systematic sign defect); every one of them must be a
+    # residual that IS zero to rounding in the float64 evaluation
+    flip = torch.sign(res_ora) != torch.sign(res_hip.double())
+    assert n_kink <= 16, n_kink
+    assert n_kink == 0 or float(res_ora[flip].abs().max()) < 1e-6, float(res_ora[flip].abs().max())
     for k, b in logo.items():
         b = float(b.detach())
         e = abs(log_n[k] - b) / max(abs(b), 1e-3)
         lines.append(f"{tag} term {k}: {e:.2e}")
-        if e > 5e-5:
+        if e > TERM_BOUND:
             fails.append(f"{tag} term {k}: {log_n[k]} vs {b}")
     e = abs(log_n["total"] - float(Eo.detach())) / abs(float(Eo.detach()))
     lines.append(f"{tag} total: {e:.2e}")
-    if e > 5e-5:
+    if e > TERM_BOUND:
         fails.append(f"{tag} total energy: {log_n['total']} vs {float(Eo.detach())}")
     worst = _compare_grads(P, g_n, lines, tag, grad_bound, 0.999999, fails)
     if worst > grad_bound:
         fails.append(f"{tag} gradients: worst rel {worst:.2e} (bound {grad_bound:.0e})")
+    if spread:
+        P32 = {k: getattr(tr, k).detach().cpu().float().requires_grad_() for k in names}
+        tm32 = {k: (v.float() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in tm.items()}
+        E32, _, _ = energy_ref.total_energy(P32, tm32, topo, cfg, o_sample, stage, base_tex.float(), uvmask.float(), (H, W), dtype=torch.float32,
+                                            disturb=o_dist, tid=tid, photo_sign_from=res_hip)
+        E32.backward()
+        for k in names:
+            g64 = P[k].grad
+            if g64 is None or float(g64.abs().max()) == 0 or k not in g_n or P32[k].grad is None:
+                continue
+            nrm = float(g64.abs().max())
+            e_hip = float((g_n[k].detach().cpu().double().reshape(-1) - g64.reshape(-1)).abs().max()) / nrm
+            e_32 = float((P32[k].grad.double().reshape(-1) - g64.reshape(-1)).abs().max()) / nrm
+            allowed = max(SPREAD_FACTOR * e_32, SPREAD_FLOOR)
+            lines.append(f"{tag} spread {k}: HIP {e_hip:.2e}  oracle-fp32 {e_32:.2e}  allowed {allowed:.2e}  {'ok' if e_hip <= allowed else 'OVER'}")
+            if e_hip > allowed:
+                fails.append(f"{tag} grad {k}: HIP is {e_hip:.2e} from the float64 oracle, the float32 oracle {e_32:.2e} (x{SPREAD_FACTOR} = {allowed:.2e})")
     assert float(P["tex_extra"].grad.abs().max()) > 0
     tr.render.disturb_rate_fg, tr.render.disturb_rate_bg = cr.disturb_rate_fg, cr.disturb_rate_bg
     return fails
@@ -179,7 +211,7 @@ def test_shipped_native_step_config4_size_calibrated_views(flame_model):
 def test_ten_steps_at_baseline_size_match_oracle_fit(flame_model):
     """K = 10 optimiser steps (tracker.py:1418-1462) at 2 x 512 x 512, T = 2048, the step as captured (disturbance off: its in-kernel
     draws cannot be replayed; the injected form is covered above), against the oracle's fit loop; every exported array
-    (tracker.py:1152-1218) to SURVEY 8(c)'s 1e-3 in relative L2, energies along the trajectory to 5e-5."""
+    (tracker.py:1152-1218) to SURVEY 8(c)'s 1e-3 in relative L2, energies along the trajectory to 5e-6."""
     from tests.test_fit_parity_gpu import _trajectory
     H = W = 512
     S = _make(flame_model, H, W, 2, T, seed=17)
@@ -191,7 +223,7 @@ def test_ten_steps_at_baseline_size_match_oracle_fit(flame_model):
     for i, (a, b) in enumerate(zip(E_hip, E_ora)):
         e = abs(a - b) / abs(b)
         lines.append(f"step {i}: E hip {a:.6f} oracle {b:.6f} rel {e:.2e}")
-        if e > 5e-5:
+        if e > TERM_BOUND:
             fails.append(f"energy at step {i}: {a} vs {b}")
     assert E_hip[-1] < E_hip[0] and E_ora[-1] < E_ora[0]
     for k in sorted(hip):
@@ -247,7 +279,7 @@ def test_native_step_with_dynamic_offset_matches_oracle(flame_model, stage):
         b = float(b.detach())
         e = abs(log_n[k] - b) / max(abs(b), 1e-3)
         lines.append(f"term {k}: {e:.2e}")
-        if e > 5e-5:
+        if e > TERM_BOUND:
             fails.append(f"term {k}: {log_n[k]} vs {b}")
     g_n = {k: ns.g[k].detach().clone().reshape(getattr(tr, k).shape) for k in names if k in ns.g}
     worst = _compare_grads(P, g_n, lines, "dyn", 5e-4, 0.999999, fails)

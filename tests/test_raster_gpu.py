@@ -10,6 +10,16 @@ from tests.scenes import head_scene, near_plane_scene
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _poisoned_outputs():
+    """every rasteriser output starts as NaN: since round 5 two launches share the stores (the binning launch's early stores outside the
+    geometry box, the raster kernel inside it) -- a block neither writes must not inherit a correct value from recycled memory"""
+    from vhap_amd import ops
+    ops.POISON_OUTPUTS = True
+    yield
+    ops.POISON_OUTPUTS = False
+
+
 def _gpu_raster(pos, tri, res):
     from vhap_amd import ops
     ctx = ops.RasterizeHipContext()
@@ -201,3 +211,67 @@ def test_bad_arguments_raise():
     with pytest.raises(RuntimeError):
         ops.raster_fwd(ctx, pos.cpu(), tri.cpu(), (64, 64))
     assert _lib.lib().vhap_raster_fwd(0, 0, 1, 1, 1, 8, 8, 0, 0, 0, 0, 0, 0, 0) == -1
+
+
+def test_early_stores_outside_the_geometry_box(flame_model):
+    """VHAP_RASTER_PREFILL (round 5): the binning launch stores every 8x8 block outside the frame's vertex bounding box, the raster kernel
+    skips those blocks.  (a) same bits with the early stores on and off (debug flag 8192), all three kernel modes through the ops;
+    (b) the binning launch ALONE (vhap_raster_bin_vnormal_prefill on NaN-filled outputs) writes a large part of the frame, only
+    background, exactly the composite the raster kernel would have written; (c) a frame with a vertex behind the near plane is left to
+    the raster kernel entirely."""
+    import ctypes
+    from vhap_amd import _lib, ops
+    model, topo = flame_model
+    B, H, W = 3, 256, 200
+    sc = head_scene(model, B, H, W, seed=11)
+    pos = sc["clip"].numpy().astype(np.float32).copy()
+    pos[2, 17, 2] = -pos[2, 17, 3] - 0.5                          # frame 2: one vertex behind the near plane -> no statement about it
+    tri = topo.faces.astype(np.int32)
+    ref = oracle.rasterize(pos, tri, (H, W))
+    got_on = _gpu_raster(pos, tri, (H, W))
+    _lib.debug_set_flags(8192)
+    try:
+        got_off = _gpu_raster(pos, tri, (H, W))
+    finally:
+        _lib.debug_set_flags(0)
+    _assert_raster_equal(got_on, ref, "early stores on")
+    _assert_raster_equal(got_off, ref, "early stores off")
+    # (b), (c): the binning launch alone
+    L = _lib.lib()
+    dev = "cuda"
+    V, F = pos.shape[1], tri.shape[0]
+    from vhap_amd.fused import MeshCSR
+    csr = MeshCSR.from_faces(torch.from_numpy(tri).cuda())
+    ctx = ops.RasterizeHipContext()
+    ws, nbytes, cap, flags = ctx.acquire(B, F, H, W, torch.device(dev))
+    t = lambda a: torch.from_numpy(a).to(dev)
+    posd, trid = t(pos), t(tri)
+    verts = posd[..., :3].contiguous()
+    vn, inv = torch.empty(B, V, 3, device=dev), torch.empty(B, V, device=dev)
+    bg = torch.rand(B, 3, H, W, device=dev)
+    fid2cid = torch.arange(F + 1, dtype=torch.int32, device=dev) % 7 + 1
+    nan = float("nan")
+    rast, rgba = torch.full((B, H, W, 4), nan, device=dev), torch.full((B, H, W, 4), nan, device=dev)
+    cid = torch.full((B, H, W), 99, dtype=torch.uint8, device=dev)
+    tile_ids = torch.full((B, H, W), 1234, dtype=torch.int16, device=dev)
+    p = lambda x: x.data_ptr()
+    rc = L.vhap_raster_bin_vnormal_prefill(p(posd), p(trid), p(trid), B, V, F, H, W, p(ws), nbytes, cap, flags, p(verts), p(csr.ptr), p(csr.idx),
+                                           p(vn), p(inv), p(bg), 0, p(fid2cid), F + 1, p(rast), p(rgba), p(cid), p(tile_ids),
+                                           torch.cuda.current_stream().cuda_stream)
+    _lib.check(rc, "vhap_raster_bin_vnormal_prefill")
+    torch.cuda.synchronize()
+    written = ~torch.isnan(rast[..., 0])
+    frac = written.float().mean(dim=(1, 2)).cpu().numpy()
+    assert 0.25 < frac[0] < 0.95 and 0.25 < frac[1] < 0.95, frac
+    assert frac[2] == 0.0, frac                                   # (c)
+    ids = torch.from_numpy(ref[0][..., 3]).to(dev)
+    assert bool((ids[written] == 0).all()), "an early store landed on a covered pixel"
+    assert bool((rast[written] == 0).all())
+    want = torch.cat([bg.permute(0, 2, 3, 1).flip(1), torch.zeros(B, H, W, 1, device=dev)], dim=-1)
+    assert torch.equal(rgba[written], want[written])
+    assert bool((cid[written] == int(fid2cid[0])).all()) and bool((cid[~written] == 99).all())
+    assert bool((tile_ids[written] == -1).all()) and bool((tile_ids[~written] == 1234).all())
+    assert bool(torch.isnan(rgba[~written]).all())
+    # whole 8x8 blocks only
+    blk = written[:, :H - H % 8, :W - W % 8].reshape(B, H // 8, 8, W // 8, 8).float().mean(dim=(2, 4))
+    assert bool(((blk == 0) | (blk == 1)).all())

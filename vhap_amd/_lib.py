@@ -115,6 +115,7 @@ SIGNATURES = {
     "vhap_adam_advance": (c_i, [c_fp, c_fp]),
     "vhap_set_floats": (c_i, [c_fp, ctypes.POINTER(c_f), c_i, c_fp]),
     "vhap_raster_bin_vnormal": (c_i, [c_fp, c_fp, c_fp] + [c_i] * 5 + [c_fp, c_sz, c_sz, c_i] + [c_fp] * 6),
+    "vhap_raster_bin_vnormal_prefill": (c_i, [c_fp, c_fp, c_fp] + [c_i] * 5 + [c_fp, c_sz, c_sz, c_i] + [c_fp] * 5 + [c_fp, c_fp, c_fp, c_i] + [c_fp] * 5),
     "vhap_raster_shade_stats": (c_i, [c_i] * 4 + [c_fp, c_sz, c_sz, c_i, c_fp, c_fp]),
     "vhap_photo_fwd_total": (c_i, [c_fp, c_fp, c_i, c_i, c_i] + [c_fp] * 6 + [c_f] * 3 + [c_fp] * 4 + [c_fp, c_fp, c_i, c_fp]),
     "vhap_frame_ingest": (c_i, [c_fp, c_fp, c_fp] + [c_i] * 5 + [c_fp] * 4),
@@ -133,7 +134,7 @@ SIGNATURES = {
     "vhap_plan_launch_timed": (c_i, [c_fp, c_fp, ctypes.POINTER(c_f), ctypes.POINTER(c_f), c_i]),
 }
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 # call_flags of include/vhap_hip.h (per-call arguments since ABI 2; the library keeps no mutable state)
 CALL_ACC_PREZEROED, CALL_AA_PASSTHROUGH_DONE, CALL_ADAM_KEEP_STEP, CALL_ADAM_STEP_ADVANCED, CALL_OFFSET_PER_FRAME = 1, 2, 4, 16, 32
 CALL_PLAN_DEFER_JOIN = 64

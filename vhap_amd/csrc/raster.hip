@@ -25,6 +25,7 @@
 #include "shade_common.h"
 #include "tex_sample.h"
 #include "vnormal_common.h"
+#include <algorithm>
 
 #pragma clang fp contract(off)  // bit-exact op order vs the oracle: only explicit fma() fuses
 
@@ -286,14 +287,119 @@ struct VnJob {                 // vertex normals computed by extra workgroups of
     float *vn, *inv_len;       // [B,V,3], [B,V] (may be null)
 };
 
+// EARLY STORES of the blocks no triangle can touch (round 5).  Two thirds of a head frame's 8x8 blocks are background, and more than half
+// lie outside the screen-space bounding box of the frame's vertices -- a property of the clip positions alone.  Their output (zeros; in
+// mode 2 the background composite) needs nothing from the binning, yet it used to be stored by raster waves that first waited for it.
+// Extra workgroups of the BINNING launch -- which is latency-bound and leaves the memory system idle -- now reduce that bounding box
+// (every workgroup for itself: 80 KB of positions out of the L2, no cross-workgroup hand-over), publish it for the raster kernel and
+// store every block outside it; the raster kernel's waves of those blocks leave at once.  A frame with a vertex behind the near plane
+// or at w <= 0 gets the whole frame as its box (clipped pieces project anywhere): nothing is prefilled there.
+struct PrefillJob {
+    int mode;                  // -1: no prefill; 0 / 1 / 2: the raster kernel's mode (which outputs exist)
+    int npre;                  // prefill workgroups per frame
+    int first;                 // blockIdx.x of the first one
+    int nwx;                   // 32x8 tiles per block row
+    int4* bbox;                // [B] (bx0, bx1, by0, by1) in 8x8 blocks, inclusive; bx0 > bx1: nothing is drawn in this frame
+    float *rast, *rast_db, *normal, *texc, *texd;
+    float* rgba;               // mode 2
+    const float* bg_image;
+    float bg_r, bg_g, bg_b;
+    unsigned char* cid;
+    const int* fid2cid;
+    unsigned short* tile_ids;
+};
+
+__device__ __forceinline__ void prefill_frame(const float* __restrict__ pos, int V, int H, int W, int nbx, int nby, const PrefillJob pj, int b, int p) {
+    __shared__ int red[BIN_THREADS / 64][5];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float hw = 8.0f * (float)W, hh = 8.0f * (float)H;
+    int mnx = 0x7fffffff, mxx = -0x7fffffff - 1, mny = 0x7fffffff, mxy = -0x7fffffff - 1, full = 0;
+    const float4* PV = reinterpret_cast<const float4*>(pos) + (size_t)b * V;
+    for (int v = threadIdx.x; v < V; v += BIN_THREADS) {
+        const float4 q = PV[v];
+        int sx, sy;
+        if (!(q.w > 0.0f) || !(__fadd_rn(q.z, q.w) >= 0.0f)) full = 1;          // near-plane pieces / dropped triangles: no statement about this frame
+        else if (snap_vertex(q, hw, hh, sx, sy)) {                                 // (a vertex beyond the guard band: its triangles are dropped, tri_bbox)
+            mnx = min(mnx, sx); mxx = max(mxx, sx);
+            mny = min(mny, sy); mxy = max(mxy, sy);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        mnx = min(mnx, __shfl_xor(mnx, o, 64)); mxx = max(mxx, __shfl_xor(mxx, o, 64));
+        mny = min(mny, __shfl_xor(mny, o, 64)); mxy = max(mxy, __shfl_xor(mxy, o, 64));
+        full |= __shfl_xor(full, o, 64);
+    }
+    if (lane == 0) { red[wave][0] = mnx; red[wave][1] = mxx; red[wave][2] = mny; red[wave][3] = mxy; red[wave][4] = full; }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < BIN_THREADS / 64; w++) {
+        mnx = min(mnx, red[w][0]); mxx = max(mxx, red[w][1]);
+        mny = min(mny, red[w][2]); mxy = max(mxy, red[w][3]);
+        full |= red[w][4];
+    }
+    // the union of the triangles' pixel boxes (tri_bbox: the same monotone formulas on the extreme snapped coordinates)
+    int4 bb = make_int4(1, 0, 1, 0);
+    if (full) bb = make_int4(0, nbx - 1, 0, nby - 1);
+    else if (mnx <= mxx) {
+        const int px0 = max((mnx - 8 + 15) >> 4, 0), px1 = min((mxx - 8) >> 4, W - 1);
+        const int py0 = max((mny - 8 + 15) >> 4, 0), py1 = min((mxy - 8) >> 4, H - 1);
+        if (px0 <= px1 && py0 <= py1) bb = make_int4(px0 / BLK, px1 / BLK, py0 / BLK, py1 / BLK);
+    }
+    if (p == 0 && threadIdx.x == 0) pj.bbox[b] = bb;
+    if (full) return;
+    // 16 waves = four 32x8 tiles per pass; a wave = one 8x8 block with the raster kernel's lane -> pixel map (same store shapes)
+    const int ntile = pj.nwx * nby;
+    const int dxp = lane & 7, dyp = lane >> 3;
+    int cid0 = 0;
+    if (pj.mode == 2 && pj.cid) cid0 = pj.fid2cid[0];
+    for (int q = p * (BIN_THREADS / 256) + (wave >> 2); q < ntile; q += pj.npre * (BIN_THREADS / 256)) {
+        const int wy = q / pj.nwx, wx = q - wy * pj.nwx;
+        const int bx = wx * WG_BLOCKS + (wave & 3), by = wy;
+        if (bx >= nbx) continue;
+        if (!(bx < bb.x || bx > bb.y || by < bb.z || by > bb.w)) continue;       // inside the box: the raster kernel's block
+        const int px = bx * BLK + dxp, py = by * BLK + dyp;
+        if (px >= W || py >= H) continue;
+        const size_t pidx = ((size_t)b * H + py) * W + px;
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        reinterpret_cast<float4*>(pj.rast)[pidx] = z4;
+        if (pj.mode == 2) {
+            float4 o;
+            if (pj.bg_image) {
+                const size_t HW = (size_t)H * W;
+                const float* g = pj.bg_image + (size_t)b * 3 * HW + (size_t)(H - 1 - py) * W + px;
+                o = make_float4(g[0], g[HW], g[2 * HW], 0.0f);
+            } else {
+                o = make_float4(pj.bg_r, pj.bg_g, pj.bg_b, 0.0f);
+            }
+            reinterpret_cast<float4*>(pj.rgba)[pidx] = o;
+            if (pj.cid) pj.cid[pidx] = (unsigned char)cid0;
+            if (pj.tile_ids) pj.tile_ids[pidx] = (unsigned short)0xFFFF;
+        } else {
+            if (pj.rast_db) reinterpret_cast<float4*>(pj.rast_db)[pidx] = z4;
+            if (pj.mode == 1) {
+                float* no = pj.normal + 3 * pidx;
+                no[0] = 0.f; no[1] = 0.f; no[2] = 0.f;
+                reinterpret_cast<float2*>(pj.texc)[pidx] = make_float2(0.f, 0.f);
+                reinterpret_cast<float4*>(pj.texd)[pidx] = z4;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(BIN_THREADS) void bin_build_kernel(const float* __restrict__ pos, const int* __restrict__ tri,
                                                                 const int* __restrict__ tri_uv, int V, int F, int H, int W,
                                                                 int nbx, int nby, unsigned* __restrict__ trange,
                                                                 TriRecord* __restrict__ records, uint2* __restrict__ frag,
                                                                 unsigned* __restrict__ list, unsigned region, unsigned long long* prof,
-                                                                int nfrag, const VnJob vj) {
+                                                                int nfrag, const VnJob vj, const PrefillJob pj) {
     extern __shared__ __attribute__((aligned(16))) unsigned lb[];     // [nbin]: counts, then write cursors
     prof_begin(prof);
+    if (pj.mode >= 0 && (int)blockIdx.x >= pj.first) {
+        prefill_frame(pos, V, H, W, nbx, nby, pj, blockIdx.y, (int)blockIdx.x - pj.first);
+        prof_end(prof);
+        return;
+    }
     if ((int)blockIdx.x >= nfrag) {
         // vhap_raster_bin_vnormal: the workgroups behind the binning ones compute the frame's vertex normals (independent work the raster
         // kernel needs too -- one launch instead of two on two queues with a hand-over each)
@@ -419,6 +525,7 @@ struct RasterParams {
     unsigned short* tile_ids; // [B,H,W] or null: uv tile of the texture-gradient binning (texbin) each pixel samples, 0xFFFF = background
     int NT;
     unsigned long long* prof; // VHAP_RASTER_PROFILE: (first start, last end) stamps of this kernel, PROF_SLOTS pairs; or null
+    const int4* bbox;         // [B] block box of each frame's geometry when the binning launch prefilled everything outside it (PrefillJob), or null
 };
 
 // Residency (MI355X_MICROARCH.md, "Residency"): 256-thread workgroups per CU = min(8, 800 / (ceil(sgpr / 16) * 16 + 16), VGPR limit).  Left to
@@ -452,13 +559,36 @@ __global__ __launch_bounds__(256, MODE == 2 ? 6 : 8) __attribute__((amdgpu_num_s
     const bool in_img = px < P.W && py < P.H;
     const int H = P.H, W = P.W;
 
+    // a block outside the frame's geometry box was stored by the binning launch (prefill_frame): nothing to do here -- in mode 2 only the
+    // wave's share of the shading statistics (the constant background value), computed below without touching pixel memory
+    bool prefilled = false;
+    if (P.bbox) {
+        const int4 bb = P.bbox[b];
+        prefilled = __builtin_amdgcn_readfirstlane((bx < bb.x || bx > bb.y || by < bb.z || by > bb.w) ? 1 : 0) != 0;
+    }
+    if constexpr (MODE != 2) {
+        if (prefilled) { prof_end(P.prof); return; }
+    }
+
     const bool fragmented = P.frag != nullptr;
     const bool use_list = fragmented || P.hdr->total <= P.capacity;
     const size_t bin = (size_t)b * P.nbx * P.nby + (size_t)by * P.nbx + bx;
     __shared__ int4 sfr[4][MAX_FRAG];   // per wave: fragment f = (first work item, count | overflow flag, list offset / first triangle, -)
     unsigned n, off = 0u;
     int nfr = 0;                  // non-empty fragments of this bin (the mesh is coherent in triangle order: usually 1-3)
-    if (fragmented) {
+    // mode 2: the background colour of this pixel depends on its position alone -- requested ahead of the fragment descriptors, it is one
+    // round trip less for every wave that ends up background (a third of the waves inside the geometry box)
+    float bg0 = 0.f, bg1 = 0.f, bg2 = 0.f;
+    if constexpr (MODE == 2) {
+        if (P.bg_image && in_img && !prefilled && !(P.debug & 16384)) {
+            const size_t HW = (size_t)H * W;
+            const float* g = P.bg_image + (size_t)b * 3 * HW + (size_t)(H - 1 - py) * W + px;
+            bg0 = g[0]; bg1 = g[HW]; bg2 = g[2 * HW];
+        }
+    }
+    if (MODE == 2 && prefilled) {
+        n = 0u;
+    } else if (fragmented) {
         uint2 d = make_uint2(0u, 0u);
         if (lane < P.nfrag) d = P.frag[((size_t)b * P.nfrag + lane) * ((size_t)P.nbx * P.nby) + (size_t)by * P.nbx + bx];
         const unsigned c = d.y & ~FRAG_OVERFLOW;
@@ -690,17 +820,24 @@ __global__ __launch_bounds__(256, MODE == 2 ? 6 : 8) __attribute__((amdgpu_num_s
                 // 81 VGPRs and, held to 6 waves per SIMD, runs 107 us against 104.7: profiles/r04_call26_load_batching_ab.txt)
                 tex_sample<3>(P.tex, P.mips, P.D, 0, make_float2(at.tu, at.tv), at.td, alb);
                 o_rgba = make_float4(alb[0] * d[0], alb[1] * d[1], alb[2] * d[2], 1.0f);
+            } else if (prefilled) {
+                o_rgba = make_float4(0.f, 0.f, 0.f, 0.f);         // (stored by the binning launch)
             } else if (P.bg_image) {
-                const size_t HW = (size_t)H * W;
-                const float* g = P.bg_image + (size_t)b * 3 * HW + (size_t)(H - 1 - py) * W + px;
-                o_rgba = make_float4(g[0], g[HW], g[2 * HW], 0.0f);
+                if (P.debug & 16384) {                                  // (A/B switch: the loads behind the coverage loop, as before round 5)
+                    const size_t HW = (size_t)H * W;
+                    const float* g = P.bg_image + (size_t)b * 3 * HW + (size_t)(H - 1 - py) * W + px;
+                    bg0 = g[0]; bg1 = g[HW]; bg2 = g[2 * HW];
+                }
+                o_rgba = make_float4(bg0, bg1, bg2, 0.0f);
             } else {
                 o_rgba = make_float4(P.bg_r, P.bg_g, P.bg_b, 0.0f);
             }
-            reinterpret_cast<float4*>(P.rast)[pidx] = o_rast;
-            reinterpret_cast<float4*>(P.rgba)[pidx] = o_rgba;
-            if (P.cid) P.cid[pidx] = (unsigned char)P.fid2cid[min(max((int)o_rast.w, 0), P.nfid - 1)];
-            if (P.tile_ids) P.tile_ids[pidx] = (unsigned short)(cov ? tile_of(make_float2(at.tu, at.tv), P.NT) : 0xFFFF);
+            if (!prefilled) {
+                reinterpret_cast<float4*>(P.rast)[pidx] = o_rast;
+                reinterpret_cast<float4*>(P.rgba)[pidx] = o_rgba;
+                if (P.cid) P.cid[pidx] = (unsigned char)P.fid2cid[min(max((int)o_rast.w, 0), P.nfid - 1)];
+                if (P.tile_ids) P.tile_ids[pidx] = (unsigned short)(cov ? tile_of(make_float2(at.tu, at.tv), P.NT) : 0xFFFF);
+            }
             if (P.stats_part) {
                 const float mean = (d[0] + d[1] + d[2]) * (1.0f / 3.0f);
                 var = 0.5f * ((d[0] - mean) * (d[0] - mean) + (d[1] - mean) * (d[1] - mean) + (d[2] - mean) * (d[2] - mean));
@@ -810,7 +947,7 @@ __global__ __launch_bounds__(1024) void shade_stats_reduce_kernel(const uint4* _
 
 
 struct WsLayout {
-    size_t hdr, counts, cursors, offsets, trange, records, list, frag, stats, stats2, prof, total;
+    size_t hdr, counts, cursors, offsets, trange, records, list, frag, stats, stats2, prof, bbox, total;
 };
 
 WsLayout ws_layout(int B, int F, int nbin, size_t cap, size_t npart) {
@@ -828,6 +965,7 @@ WsLayout ws_layout(int B, int F, int nbin, size_t cap, size_t npart) {
     l.stats = o; o = al(o + sizeof(uint4) * npart);                 // per-wave shading-statistics partials (mode 2): 4 per raster workgroup
     l.stats2 = o; o = al(o + sizeof(uint4) * (STATS_BLOCKS + 1));    // second-level partials + the completion counter
     l.prof = o; o = al(o + sizeof(unsigned long long) * 2 * PROF_SLOTS * 2);      // VHAP_RASTER_PROFILE stamps: binning, then raster kernel
+    l.bbox = o; o = al(o + sizeof(int4) * (size_t)B);               // per-frame block box of the geometry (PrefillJob)
     l.total = o;
     return l;
 }
@@ -874,6 +1012,7 @@ int launch_raster(RasterParams P, void* ws, size_t ws_bytes, size_t cap, int fla
     if (((flags & (VHAP_RASTER_BIN_ONLY | VHAP_RASTER_PREBINNED)) || vj.verts) && !fragmented) return VHAP_E_UNSUPPORTED;   // split calls: one-launch binning only
     if (fragmented && prebinned) {
         P.frag = reinterpret_cast<uint2*>(w + l.frag);
+        if ((flags & VHAP_RASTER_PREFILL) && !(vhap_g_debug_flags & 8192)) P.bbox = reinterpret_cast<const int4*>(w + l.bbox);    // (the BIN_ONLY call prefilled with the same flag)
     } else if (fragmented) {
         // binning in ONE launch: per-workgroup regions of the pair list, fragment descriptors instead of global counters
         const size_t lds = sizeof(unsigned) * nbin;
@@ -887,11 +1026,28 @@ int launch_raster(RasterParams P, void* ws, size_t ws_bytes, size_t cap, int fla
             prof_init_kernel<<<vhap_cdiv(2 * PROF_SLOTS, 256), 256, 0, st>>>(prof_bin, 2 * PROF_SLOTS);
             VHAP_LAUNCH_CHECK();
         }
-        const dim3 gbv(gbin.x + (vj.verts ? vhap_cdiv(P.V, BIN_THREADS) : 0), B);
+        const int nvn = vj.verts ? vhap_cdiv(P.V, BIN_THREADS) : 0;
+        PrefillJob pj{};
+        pj.mode = -1;
+        // one call (binning + raster): always; split calls: when BOTH carry VHAP_RASTER_PREFILL (the BIN_ONLY call then needs the outputs)
+        if (P.rast && (!(flags & VHAP_RASTER_BIN_ONLY) || (flags & VHAP_RASTER_PREFILL)) && !(vhap_g_debug_flags & 8192)) {   // (8192: A/B switch)
+            pj.mode = MODE;
+            // ~2 workgroups of 1024 threads per CU over the batch; at least one pass of four tiles each
+            const int ntile = P.nwx * P.nby;
+            pj.npre = std::max(1, std::min((ntile + 3) / 4, (512 + B - 1) / B));
+            pj.first = (int)gbin.x + nvn;
+            pj.nwx = P.nwx;
+            pj.bbox = reinterpret_cast<int4*>(w + l.bbox);
+            pj.rast = P.rast; pj.rast_db = P.rast_db; pj.normal = P.normal; pj.texc = P.texc; pj.texd = P.texd;
+            pj.rgba = P.rgba; pj.bg_image = P.bg_image; pj.bg_r = P.bg_r; pj.bg_g = P.bg_g; pj.bg_b = P.bg_b;
+            pj.cid = P.cid; pj.fid2cid = P.fid2cid; pj.tile_ids = P.tile_ids;
+        }
+        const dim3 gbv(gbin.x + nvn + (pj.mode >= 0 ? pj.npre : 0), B);
         bin_build_kernel<<<gbv, BIN_THREADS, lds, st>>>(P.pos, P.tri, P.tri_uv, P.V, F, P.H, P.W, P.nbx, P.nby, trange, records, frag, list,
-                                                       (unsigned)region, prof_bin, nfrag, vj);
+                                                       (unsigned)region, prof_bin, nfrag, vj, pj);
         VHAP_LAUNCH_CHECK();
         P.frag = frag;
+        if (pj.mode >= 0) P.bbox = pj.bbox;
     } else {
         // header, counts and cursors are contiguous: one zero-fill launch -- skipped when the caller vouches that the workspace was
         // zero-initialised once and only ever used by completed calls of this function (every call leaves it clean again)
@@ -1025,6 +1181,28 @@ extern "C" int vhap_raster_bin_vnormal(const float* pos, const int32_t* tri, con
     P.pos = pos; P.tri = tri; P.tri_uv = tri_uv;
     P.B = B; P.V = V; P.F = F; P.H = H; P.W = W;
     return launch_raster<2>(P, workspace, workspace_bytes, pair_capacity, (flags & ~VHAP_RASTER_PREBINNED) | VHAP_RASTER_BIN_ONLY,
+                            vhap_stream(stream), nullptr, VnJob{verts, vc_ptr, vc_idx, vn, inv_len});
+}
+
+// vhap_raster_bin_vnormal + the EARLY STORES of the deferred-shading pass (PrefillJob): further workgroups of the same launch store rast /
+// rgba (background composite) / cid / tile_ids of every 8x8 block outside the frame's geometry box; the vhap_raster_shade_fwd call that
+// follows must carry VHAP_RASTER_PREBINNED | VHAP_RASTER_PREFILL and the same output pointers.
+extern "C" int vhap_raster_bin_vnormal_prefill(const float* pos, const int32_t* tri, const int32_t* tri_uv, int B, int V, int F, int H, int W,
+                                               void* workspace, size_t workspace_bytes, size_t pair_capacity, int flags, const float* verts,
+                                               const int32_t* vc_ptr, const int32_t* vc_idx, float* vn, float* inv_len,
+                                               const float* bg_image, const float* bg_color, const int32_t* fid2cid, int nfid,
+                                               float* rast, float* rgba, uint8_t* cid, uint16_t* tile_ids, vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!pos || !tri || !tri_uv || !verts || !vc_ptr || !vc_idx || !vn || !rast || !rgba || (!bg_image && !bg_color)) return VHAP_E_NULLPTR;
+    if (cid && (!fid2cid || nfid <= 0)) return VHAP_E_NULLPTR;
+    if (int e = check_dims(B, V, F, H, W)) return e;
+    RasterParams P{};
+    P.pos = pos; P.tri = tri; P.tri_uv = tri_uv;
+    P.B = B; P.V = V; P.F = F; P.H = H; P.W = W;
+    P.rast = rast; P.rgba = rgba; P.cid = cid; P.fid2cid = fid2cid; P.nfid = nfid; P.tile_ids = tile_ids;
+    P.bg_image = bg_image;
+    if (!bg_image && bg_color) { P.bg_r = bg_color[0]; P.bg_g = bg_color[1]; P.bg_b = bg_color[2]; }
+    return launch_raster<2>(P, workspace, workspace_bytes, pair_capacity, (flags & ~VHAP_RASTER_PREBINNED) | VHAP_RASTER_BIN_ONLY | VHAP_RASTER_PREFILL,
                             vhap_stream(stream), nullptr, VnJob{verts, vc_ptr, vc_idx, vn, inv_len});
 }
 

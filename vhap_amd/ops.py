@@ -117,6 +117,15 @@ def _check_raster_args(pos, tri, resolution):
     return H, W
 
 
+POISON_OUTPUTS = False        # tests: raster outputs start as NaN, so that a pixel no workgroup stores cannot pass for a correct one
+
+
+def _out(*shape, device=None):
+    if POISON_OUTPUTS:
+        return torch.full(shape, float("nan"), dtype=torch.float32, device=device)
+    return torch.empty(*shape, dtype=torch.float32, device=device)
+
+
 def raster_fwd(ctx, pos, tri, resolution, with_db=True):
     """Forward only (no autograd).  Returns rast [B,H,W,4], rast_db [B,H,W,4] or None."""
     _chk_cuda(pos, tri)
@@ -125,8 +134,8 @@ def raster_fwd(ctx, pos, tri, resolution, with_db=True):
     B, V, _ = pos.shape
     F = tri.shape[0]
     ws, nbytes, cap, flags = ctx.acquire(B, F, H, W, pos.device)
-    rast = torch.empty(B, H, W, 4, dtype=torch.float32, device=pos.device)
-    db = torch.empty_like(rast) if with_db else None
+    rast = _out(B, H, W, 4, device=pos.device)
+    db = _out(B, H, W, 4, device=pos.device) if with_db else None
     rc = _lib.lib().vhap_raster_fwd(_p(pos), _p(tri), B, V, F, H, W, _p(rast), _p(db), _p(ws), nbytes, cap, flags, _stream())
     _lib.check(rc, "vhap_raster_fwd")
     return rast, db
@@ -143,11 +152,8 @@ def raster_interp_fwd(ctx, pos, tri, vnormal, uv, tri_uv, resolution):
         raise ValueError("raster_interp_fwd: vnormal [B,V,3], uv [VT,2], tri_uv [F,3] expected")
     ws, nbytes, cap, flags = ctx.acquire(B, F, H, W, pos.device)
     dev = pos.device
-    rast = torch.empty(B, H, W, 4, dtype=torch.float32, device=dev)
-    db = torch.empty_like(rast)
-    normal = torch.empty(B, H, W, 3, dtype=torch.float32, device=dev)
-    texc = torch.empty(B, H, W, 2, dtype=torch.float32, device=dev)
-    texd = torch.empty_like(rast)
+    rast, db = _out(B, H, W, 4, device=dev), _out(B, H, W, 4, device=dev)
+    normal, texc, texd = _out(B, H, W, 3, device=dev), _out(B, H, W, 2, device=dev), _out(B, H, W, 4, device=dev)
     _hook("raster_interp_fwd", "begin")
     rc = _lib.lib().vhap_raster_interp_fwd(_p(pos), _p(tri), _p(vnormal), _p(uv), _p(tri_uv), B, V, uv.shape[0], F, H, W,
                                            _p(rast), _p(db), _p(normal), _p(texc), _p(texd), _p(ws), nbytes, cap, flags, _stream())

@@ -539,7 +539,19 @@ class NativeStep:
         # fixed-point scale of the texture-gradient accumulation is derived from the measured diffuse maximum whatever the stage trains.
         # Their reduction (only the energy assembly reads it) runs beside the pixel chain instead of inside it
         stats_later = 16 if self.overlap else 0
-        if self.bin_split:
+        # EARLY STORES (VHAP_RASTER_PREFILL): the binning launch also stores every 8x8 block outside the frame's geometry box (rast zeros, the
+        # background composite, cluster byte, tile id); the raster kernel's waves of those blocks leave at once.  Not with a self-feeding
+        # step: its target image is written on the texture branch, which the binning launch does not wait for.
+        prefill = 32 if (self.bin_split and self.feed is None and os.environ.get("VHAP_PREFILL", "1") != "0") else 0
+        if self.bin_split and prefill:
+            _chk(L.vhap_raster_bin_vnormal_prefill(_p(self.clip), _p(self.tri), _p(self.tri_uv), B, V, F, H, W, _p(self.ws), self.ws_bytes, self.ws_cap,
+                                                   1, _p(self.verts), _p(self.csr.ptr), _p(self.csr.idx), _p(self.vn), _p(self.vn_inv),
+                                                   _p(self.rgb) if self.bg_col is None else 0,
+                                                   ctypes.cast(self.bg_col, ctypes.c_void_p) if self.bg_col is not None else 0,
+                                                   _p(self.fid2cid) if self.disturb_on else 0, self.fid2cid.numel() if self.disturb_on else 0,
+                                                   _p(self.rast), _p(self.rgba), _p(self.cid) if self.disturb_on else 0,
+                                                   _p(self.tile_ids) if self.tb_ids else 0, st), "vhap_raster_bin_vnormal_prefill")
+        elif self.bin_split:
             # binning + vertex normals in ONE launch (independent work, both inputs of the raster kernel): no fork / join -- a hand-over
             # between streams costs ~10 us each way on this critical path
             _chk(L.vhap_raster_bin_vnormal(_p(self.clip), _p(self.tri), _p(self.tri_uv), B, V, F, H, W, _p(self.ws), self.ws_bytes, self.ws_cap,
@@ -552,7 +564,7 @@ class NativeStep:
             cur.wait_event(self._tex_ready)
         else:
             self._join()
-        _chk(raster(((1 | 4) if self.bin_split else 1) | stats_later), "vhap_raster_shade_fwd")   # VHAP_RASTER_WS_CLEAN (| VHAP_RASTER_PREBINNED)
+        _chk(raster(((1 | 4) if self.bin_split else 1) | stats_later | prefill), "vhap_raster_shade_fwd")   # VHAP_RASTER_WS_CLEAN (| VHAP_RASTER_PREBINNED | _PREFILL)
         _hook("raster_interp_fwd", "end")
         # the antialiasing's pair discovery needs the rasteriser's output only, not the colours: beside the colour disturbance instead of
         # behind it (and ahead of the statistics reduction on the side stream: the blend waits for it, the energy assembly for the other)
@@ -582,6 +594,11 @@ class NativeStep:
             def sort_branch():
                 _chk(L.vhap_texbin_sort_ids(_p(self.tile_ids), _p(self.keep) if self.disturb_on else 0, T, T, B, H, W,
                                             _p(self.texbin_work), self.texbin_work.numel(), _stream()), "vhap_texbin_sort_ids")
+                if prefill and self.overlap:
+                    # with early stores the NEXT step's binning launch writes tile_ids: the sort (the only reader off the main chain) must be
+                    # ordered ahead of this step's last main-chain kernel, or it counts as an open tail of a deferred join (tracker.GraphedStep)
+                    self._sort_done = torch.cuda.Event()
+                    self._sort_done.record()
             if not self.one_graph:
                 self._side(sort_branch)                           # (eager / sharded: next to the rest of the forward pass)
         self.aa_in = color
@@ -945,6 +962,9 @@ class NativeStep:
             self._bwd_geometry(True, after_first=self._flush)
             if self.overlap:
                 torch.cuda.current_stream().wait_stream(self.side2)
+            if getattr(self, "_sort_done", None) is not None:          # (early stores: see _forward_deferred; long complete by now)
+                torch.cuda.current_stream().wait_event(self._sort_done)
+                self._sort_done = None
             if self.step_optimizer is not None:                       # every other parameter: next to the tail of the texture branch
                 late = (self.tr.tex_extra, self.tr.tex_pca) if (self.pca is not None and self.tex_bwd_on) else (self.tr.tex_extra,)
                 self.step_optimizer.step(skip=late, advanced=True)
