@@ -282,6 +282,7 @@ def time_ri_in_step(tr, sample, optimizer, deferred, n=9):
                 b = [d for nm, _, d in rec if "bin_build" in nm]
                 r = [d for nm, _, d in rec if "raster_kernel" in nm]
                 assert len(b) == 1 and len(r) == 1, [nm for nm, _, _ in rec]
+                b[0] += sum(d for nm, _, d in rec if "frame_bbox" in nm)      # (early stores: the 3 us launch that reduces the geometry boxes is part of the pass)
                 bins.append(b[0])
                 rasts.append(r[0])
         del st

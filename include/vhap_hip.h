@@ -93,9 +93,10 @@ int vhap_stream_destroy(vhap_stream_t stream);
 #define VHAP_RASTER_STATS_LATER 16
 /* VHAP_RASTER_PREFILL (ABI 9): EARLY STORES.  The binning launch also reduces, per frame, the 8x8-block bounding box of the clip positions
  * and stores the output of every block outside it (zeros; deferred shading: the background composite) with workgroups of its own; the
- * raster kernel's waves of those blocks leave at once.  A single call (binning + raster) always does this.  Split calls do it when BOTH
- * carry the flag: the VHAP_RASTER_BIN_ONLY call then needs the output pointers (vhap_raster_bin_vnormal_prefill), the
- * VHAP_RASTER_PREBINNED call reads the boxes from `workspace`.  Results are bit-identical with and without. */
+ * raster kernel's waves of those blocks leave at once.  Opt-in: measured on MI355X it makes the pass LONGER (csrc/raster.hip,
+ * profiles/r05_call3_early_stores_v2_ab.txt); kept as a switch with its parity test.  Split calls do it when BOTH carry the flag: the
+ * VHAP_RASTER_BIN_ONLY call then needs the output pointers (vhap_raster_bin_vnormal_prefill), the VHAP_RASTER_PREBINNED call reads
+ * the boxes from `workspace`.  Results are bit-identical with and without. */
 #define VHAP_RASTER_PREFILL 32
 size_t vhap_raster_profile_offset(int B, int F, int H, int W, size_t pair_capacity);
 size_t vhap_raster_workspace_bytes(int B, int F, int H, int W, size_t pair_capacity);

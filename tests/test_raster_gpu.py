@@ -214,8 +214,9 @@ def test_bad_arguments_raise():
 
 
 def test_early_stores_outside_the_geometry_box(flame_model):
-    """VHAP_RASTER_PREFILL (round 5): the binning launch stores every 8x8 block outside the frame's vertex bounding box, the raster kernel
-    skips those blocks.  (a) same bits with the early stores on and off (debug flag 8192), all three kernel modes through the ops;
+    """VHAP_RASTER_PREFILL (round 5, opt-in: a measured loss, csrc/raster.hip): the binning launch stores every 8x8 block outside the frame's
+    vertex bounding box, the raster kernel skips those blocks.  (a) same bits with the early stores on and off, kernel modes 0 and 1
+    through the ops (mode 2: tests/test_deferred_gpu.py under VHAP_PREFILL=1);
     (b) the binning launch ALONE (vhap_raster_bin_vnormal_prefill on NaN-filled outputs) writes a large part of the frame, only
     background, exactly the composite the raster kernel would have written; (c) a frame with a vertex behind the near plane is left to
     the raster kernel entirely."""
@@ -228,14 +229,21 @@ def test_early_stores_outside_the_geometry_box(flame_model):
     pos[2, 17, 2] = -pos[2, 17, 3] - 0.5                          # frame 2: one vertex behind the near plane -> no statement about it
     tri = topo.faces.astype(np.int32)
     ref = oracle.rasterize(pos, tri, (H, W))
-    got_on = _gpu_raster(pos, tri, (H, W))
-    _lib.debug_set_flags(8192)
-    try:
-        got_off = _gpu_raster(pos, tri, (H, W))
-    finally:
-        _lib.debug_set_flags(0)
-    _assert_raster_equal(got_on, ref, "early stores on")
+    got_off = _gpu_raster(pos, tri, (H, W))
+    ctx = ops.RasterizeHipContext()
+    acquire = ctx.acquire
+    ctx.acquire = lambda *a: acquire(*a)[:3] + (acquire(*a)[3] | 32,)      # VHAP_RASTER_PREFILL on the one-call path
+    rast, db = ops.raster_fwd(ctx, torch.from_numpy(pos).cuda(), torch.from_numpy(tri).cuda(), (H, W))
+    torch.cuda.synchronize()
+    _assert_raster_equal((rast.cpu().numpy(), db.cpu().numpy()), ref, "early stores on")
     _assert_raster_equal(got_off, ref, "early stores off")
+    vn_ = torch.randn(B, pos.shape[1], 3, device="cuda")
+    uv_ = torch.rand(pos.shape[1], 2, device="cuda")
+    g_on = ops.raster_interp_fwd(ctx, torch.from_numpy(pos).cuda(), torch.from_numpy(tri).cuda(), vn_, uv_, torch.from_numpy(tri).cuda(), (H, W))
+    g_off = ops.raster_interp_fwd(ops.RasterizeHipContext(), torch.from_numpy(pos).cuda(), torch.from_numpy(tri).cuda(), vn_, uv_,
+                                  torch.from_numpy(tri).cuda(), (H, W))
+    for a_, b_ in zip(g_on, g_off):
+        assert torch.equal(a_, b_) and not bool(torch.isnan(a_).any())
     # (b), (c): the binning launch alone
     L = _lib.lib()
     dev = "cuda"

@@ -287,19 +287,26 @@ struct VnJob {                 // vertex normals computed by extra workgroups of
     float *vn, *inv_len;       // [B,V,3], [B,V] (may be null)
 };
 
-// EARLY STORES of the blocks no triangle can touch (round 5).  Two thirds of a head frame's 8x8 blocks are background, and more than half
-// lie outside the screen-space bounding box of the frame's vertices -- a property of the clip positions alone.  Their output (zeros; in
-// mode 2 the background composite) needs nothing from the binning, yet it used to be stored by raster waves that first waited for it.
-// Extra workgroups of the BINNING launch -- which is latency-bound and leaves the memory system idle -- now reduce that bounding box
-// (every workgroup for itself: 80 KB of positions out of the L2, no cross-workgroup hand-over), publish it for the raster kernel and
-// store every block outside it; the raster kernel's waves of those blocks leave at once.  A frame with a vertex behind the near plane
-// or at w <= 0 gets the whole frame as its box (clipped pieces project anywhere): nothing is prefilled there.
+// EARLY STORES of the blocks no triangle can touch (round 5; OPT-IN, off in the shipped step: it loses).  Two thirds of a head frame's 8x8
+// blocks are background, and more than half lie outside the screen-space bounding box of the frame's vertices -- a property of the clip
+// positions alone.  Their output (zeros; in mode 2 the background composite) needs nothing from the binning, yet it is stored by raster
+// waves that first wait for it.  With VHAP_RASTER_PREFILL a 3 us launch reduces that box per frame, extra workgroups of the BINNING launch --
+// latency-bound, the memory system idle -- store every block outside it, and the raster kernel's waves of those blocks leave at once.
+// A frame with a vertex behind the near plane or at w <= 0 gets the whole frame as its box (clipped pieces project anywhere).
+// MEASURED (16 x 512^2, 52 % of the blocks outside the boxes = 148 MB of the pass's 285 MB of stores):
+//   v1 (every prefill workgroup reduces the box itself, block-shaped stores, 512 workgroups): binning launch 18 -> 41 us, raster<1> 84 -> 68 us
+//   v2 (box from its own launch, row-run stores, one round of 256 workgroups):               binning launch 18 -> 47 us, raster<1> 79 -> 66 us
+// i.e. the pass gets 7 - 16 us LONGER (frac 0.36 -> 0.33), and raster<2> 107 -> 98 us for +31 us of binning launch: the step does not
+// move (0.888 vs 0.884 ms).  Why: sixteen-wave workgroups beside the binning ones store at 3.4 TB/s, not at the 5.4 TB/s the raster
+// kernel's 8192 resident waves reach, and the raster kernel is bound by the dependent round trips of its COVERED waves (descriptor ->
+// list -> record -> winner's vertices, each inflated by the store traffic), not by the background waves' stores: taking half of the
+// blocks away shortens it by a sixth.  Bit-exact either way (tests/test_raster_gpu.py::test_early_stores_outside_the_geometry_box).
 struct PrefillJob {
     int mode;                  // -1: no prefill; 0 / 1 / 2: the raster kernel's mode (which outputs exist)
     int npre;                  // prefill workgroups per frame
     int first;                 // blockIdx.x of the first one
     int nwx;                   // 32x8 tiles per block row
-    int4* bbox;                // [B] (bx0, bx1, by0, by1) in 8x8 blocks, inclusive; bx0 > bx1: nothing is drawn in this frame
+    const int4* bbox;          // [B] (bx0, bx1, by0, by1) in 8x8 blocks, inclusive; bx0 > bx1: nothing is drawn in this frame (frame_bbox_kernel)
     float *rast, *rast_db, *normal, *texc, *texd;
     float* rgba;               // mode 2
     const float* bg_image;
@@ -309,8 +316,12 @@ struct PrefillJob {
     unsigned short* tile_ids;
 };
 
-__device__ __forceinline__ void prefill_frame(const float* __restrict__ pos, int V, int H, int W, int nbx, int nby, const PrefillJob pj, int b, int p) {
+// The frame's geometry box: one workgroup per frame, ahead of the binning launch (3 us; a step executor that already transforms the
+// vertices can produce the same box in that kernel's epilogue instead).
+__global__ __launch_bounds__(BIN_THREADS) void frame_bbox_kernel(const float* __restrict__ pos, int V, int H, int W, int nbx, int nby,
+                                                                 int4* __restrict__ bbox) {
     __shared__ int red[BIN_THREADS / 64][5];
+    const int b = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float hw = 8.0f * (float)W, hh = 8.0f * (float)H;
     int mnx = 0x7fffffff, mxx = -0x7fffffff - 1, mny = 0x7fffffff, mxy = -0x7fffffff - 1, full = 0;
@@ -332,6 +343,7 @@ __device__ __forceinline__ void prefill_frame(const float* __restrict__ pos, int
     }
     if (lane == 0) { red[wave][0] = mnx; red[wave][1] = mxx; red[wave][2] = mny; red[wave][3] = mxy; red[wave][4] = full; }
     __syncthreads();
+    if (threadIdx.x != 0) return;
 #pragma unroll
     for (int w = 0; w < BIN_THREADS / 64; w++) {
         mnx = min(mnx, red[w][0]); mxx = max(mxx, red[w][1]);
@@ -346,27 +358,32 @@ __device__ __forceinline__ void prefill_frame(const float* __restrict__ pos, int
         const int py0 = max((mny - 8 + 15) >> 4, 0), py1 = min((mxy - 8) >> 4, H - 1);
         if (px0 <= px1 && py0 <= py1) bb = make_int4(px0 / BLK, px1 / BLK, py0 / BLK, py1 / BLK);
     }
-    if (p == 0 && threadIdx.x == 0) pj.bbox[b] = bb;
-    if (full) return;
-    // 16 waves = four 32x8 tiles per pass; a wave = one 8x8 block with the raster kernel's lane -> pixel map (same store shapes)
-    const int ntile = pj.nwx * nby;
-    const int dxp = lane & 7, dyp = lane >> 3;
+    bbox[b] = bb;
+}
+
+// Early stores of one frame by workgroup p of pj.npre: a wave takes 64 consecutive pixels of ONE row at a time -- every output is then
+// one contiguous run per store instruction (1 KB of rast, 768 B of normals, ...), the friendliest shape there is for the write path --
+// and a lane stores its pixel iff the pixel's 8x8 block lies outside the box.
+__device__ __forceinline__ void prefill_frame(int H, int W, const PrefillJob pj, int b, int p) {
+    const int4 bb = pj.bbox[b];
+    if (bb.x == 0 && bb.z == 0 && bb.y >= (W + BLK - 1) / BLK - 1 && bb.w >= (H + BLK - 1) / BLK - 1) return;      // the box is the frame
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nseg = (W + 63) >> 6;
+    const int nitem = H * nseg;
     int cid0 = 0;
     if (pj.mode == 2 && pj.cid) cid0 = pj.fid2cid[0];
-    for (int q = p * (BIN_THREADS / 256) + (wave >> 2); q < ntile; q += pj.npre * (BIN_THREADS / 256)) {
-        const int wy = q / pj.nwx, wx = q - wy * pj.nwx;
-        const int bx = wx * WG_BLOCKS + (wave & 3), by = wy;
-        if (bx >= nbx) continue;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const size_t HW = (size_t)H * W;
+    for (int it = p * (BIN_THREADS / 64) + wave; it < nitem; it += pj.npre * (BIN_THREADS / 64)) {
+        const int py = it / nseg, px = (it - py * nseg) * 64 + lane;
+        const int by = py >> 3, bx = px >> 3;
+        if (px >= W) continue;
         if (!(bx < bb.x || bx > bb.y || by < bb.z || by > bb.w)) continue;       // inside the box: the raster kernel's block
-        const int px = bx * BLK + dxp, py = by * BLK + dyp;
-        if (px >= W || py >= H) continue;
         const size_t pidx = ((size_t)b * H + py) * W + px;
-        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
         reinterpret_cast<float4*>(pj.rast)[pidx] = z4;
         if (pj.mode == 2) {
             float4 o;
             if (pj.bg_image) {
-                const size_t HW = (size_t)H * W;
                 const float* g = pj.bg_image + (size_t)b * 3 * HW + (size_t)(H - 1 - py) * W + px;
                 o = make_float4(g[0], g[HW], g[2 * HW], 0.0f);
             } else {
@@ -396,7 +413,7 @@ __global__ __launch_bounds__(BIN_THREADS) void bin_build_kernel(const float* __r
     extern __shared__ __attribute__((aligned(16))) unsigned lb[];     // [nbin]: counts, then write cursors
     prof_begin(prof);
     if (pj.mode >= 0 && (int)blockIdx.x >= pj.first) {
-        prefill_frame(pos, V, H, W, nbx, nby, pj, blockIdx.y, (int)blockIdx.x - pj.first);
+        prefill_frame(H, W, pj, blockIdx.y, (int)blockIdx.x - pj.first);
         prof_end(prof);
         return;
     }
@@ -1029,15 +1046,19 @@ int launch_raster(RasterParams P, void* ws, size_t ws_bytes, size_t cap, int fla
         const int nvn = vj.verts ? vhap_cdiv(P.V, BIN_THREADS) : 0;
         PrefillJob pj{};
         pj.mode = -1;
-        // one call (binning + raster): always; split calls: when BOTH carry VHAP_RASTER_PREFILL (the BIN_ONLY call then needs the outputs)
-        if (P.rast && (!(flags & VHAP_RASTER_BIN_ONLY) || (flags & VHAP_RASTER_PREFILL)) && !(vhap_g_debug_flags & 8192)) {   // (8192: A/B switch)
+        // only on request (VHAP_RASTER_PREFILL; split calls: BOTH carry it, the BIN_ONLY call then needs the outputs): measured, it LOSES on
+        // MI355X -- profiles/r05_call2_early_stores_v1_ab.txt, r05_call3_early_stores_v2_ab.txt
+        if (P.rast && (flags & VHAP_RASTER_PREFILL) && !(vhap_g_debug_flags & 8192)) {   // (8192: A/B switch)
             pj.mode = MODE;
-            // ~2 workgroups of 1024 threads per CU over the batch; at least one pass of four tiles each
-            const int ntile = P.nwx * P.nby;
-            pj.npre = std::max(1, std::min((ntile + 3) / 4, (512 + B - 1) / B));
+            // ONE round of workgroups over the chip together with the binning (and vertex-normal) ones: they all start at once
+            const int room = 2 * 256 - (int)gbin.x * B - nvn * B;
+            pj.npre = std::max(1, std::min(room / B, 64));
             pj.first = (int)gbin.x + nvn;
             pj.nwx = P.nwx;
-            pj.bbox = reinterpret_cast<int4*>(w + l.bbox);
+            int4* bbox = reinterpret_cast<int4*>(w + l.bbox);
+            frame_bbox_kernel<<<B, BIN_THREADS, 0, st>>>(P.pos, P.V, P.H, P.W, P.nbx, P.nby, bbox);
+            VHAP_LAUNCH_CHECK();
+            pj.bbox = bbox;
             pj.rast = P.rast; pj.rast_db = P.rast_db; pj.normal = P.normal; pj.texc = P.texc; pj.texd = P.texd;
             pj.rgba = P.rgba; pj.bg_image = P.bg_image; pj.bg_r = P.bg_r; pj.bg_g = P.bg_g; pj.bg_b = P.bg_b;
             pj.cid = P.cid; pj.fid2cid = P.fid2cid; pj.tile_ids = P.tile_ids;

@@ -542,7 +542,8 @@ class NativeStep:
         # EARLY STORES (VHAP_RASTER_PREFILL): the binning launch also stores every 8x8 block outside the frame's geometry box (rast zeros, the
         # background composite, cluster byte, tile id); the raster kernel's waves of those blocks leave at once.  Not with a self-feeding
         # step: its target image is written on the texture branch, which the binning launch does not wait for.
-        prefill = 32 if (self.bin_split and self.feed is None and os.environ.get("VHAP_PREFILL", "1") != "0") else 0
+        # OFF by default: measured, the binning launch grows by more than the raster kernel shrinks (csrc/raster.hip, PrefillJob).
+        prefill = 32 if (self.bin_split and self.feed is None and os.environ.get("VHAP_PREFILL", "0") == "1") else 0
         if self.bin_split and prefill:
             _chk(L.vhap_raster_bin_vnormal_prefill(_p(self.clip), _p(self.tri), _p(self.tri_uv), B, V, F, H, W, _p(self.ws), self.ws_bytes, self.ws_cap,
                                                    1, _p(self.verts), _p(self.csr.ptr), _p(self.csr.idx), _p(self.vn), _p(self.vn_inv),
