@@ -709,6 +709,21 @@ int vhap_offset_grad_finish(const float* g_a, const float* g_b, const int64_t* t
 enum { VHAP_BG_NONE = 0, VHAP_BG_WHITE = 1, VHAP_BG_BLACK = 2 };
 int vhap_frame_ingest(const unsigned char* rgb_u8, const unsigned char* alpha_u8, const long long* index, int N, int B, int H, int W,
                       int bg_mode, float* rgb_out, float* alpha_out, int* bad_index, vhap_stream_t stream);
+
+/* Frame preparation, applied ONCE when decoded frames enter the resident store (ABI 9).
+ * vhap_frame_color_correct -- NeRSembleDataset.apply_color_correction (vhap/data/nersemble_dataset.py:160-171): per frame f the affine colour
+ *   transform of camera cam_of_frame[f] (null: camera 0): out = uint8(clip(rgb / 255 @ A[:3,:3] + A[:3,3], 0, 1) * 255), fp64, the matmul as
+ *   numpy's dgemm evaluates it (an FMA chain over the input channels), truncating cast.  ccm [n_cam, 12] doubles = rows 0..2 of A, four
+ *   columns each.  rgb_u8 / rgb_out [N,H,W,3] uint8 (in place allowed).
+ * vhap_frame_resize_u8 -- VideoDataset.apply_scale_factor (vhap/data/video_dataset.py:266-300): PIL Image.resize((w, h), BILINEAR) of N
+ *   8-bit images [N,H,W,C] -> [N,h,w,C] (C = 3 rgb, 1 alpha map).  The fixed-point coefficient tables are Pillow's (Resample.c
+ *   precompute_coeffs + normalize_coeffs_8bpc), computed by the caller: bounds_* [2 * out] = (first tap, tap count), coef_* [out * ksize];
+ *   ksize 0 = that axis keeps its size (Pillow skips the pass). */
+int vhap_frame_color_correct(const unsigned char* rgb_u8, const int32_t* cam_of_frame, const double* ccm, int n_cam, int N, int H, int W,
+                             unsigned char* rgb_out, vhap_stream_t stream);
+int vhap_frame_resize_u8(const unsigned char* src_u8, int N, int H, int W, int C, unsigned char* dst_u8, int h, int w,
+                         const int32_t* bounds_x, const int32_t* coef_x, int ksize_x, const int32_t* bounds_y, const int32_t* coef_y,
+                         int ksize_y, vhap_stream_t stream);
 /* Batch feed (the per-step hand-over of a stage loop, tracker.py:1376-1385, as a node of the captured step): batch number cursor[0] of a
  * table uploaded once per pass -- frame_table / ts_table [capacity, n] int64: frame index and timestep of every frame of every batch, in the
  * order the batches are taken -- is gathered into the step's static buffers frame_out / ts_out [n] and, for up to three per-frame row arrays

@@ -181,3 +181,36 @@ def test_fused_pyramid_build_is_bit_identical(T):
     assert torch.equal(a0, a1)
     assert torch.equal(m0.view(torch.int32), m1.view(torch.int32)), int((m0 != m1).sum())
     assert torch.allclose(t0, t1, rtol=1e-5, atol=0) and float(t0[0]) > 0 and float(t0[1]) > 0
+
+
+@pytest.mark.parametrize("bg", ["target", "white"])
+def test_deferred_step_with_early_stores_is_bit_identical(flame_model, monkeypatch, bg):
+    """VHAP_PREFILL=1 (opt-in, csrc/raster.hip PrefillJob): the binning launch stores the blocks outside each frame's geometry box, raster
+    kernel mode 2 skips them and contributes only their (constant) share of the shading statistics -- every buffer the forward leaves
+    behind and the energy log must have the same bits as without."""
+    from vhap_amd.step import NativeStep
+    B, H, W, T = 3, 200, 168, 256
+    stage = "rgb_global_tracking"
+    out = {}
+    for pf in ("0", "1"):
+        monkeypatch.setenv("VHAP_PREFILL", pf)
+        tr = _tracker(flame_model, B, H, W, T, seed=7, disturb=False)
+        tr.cfg.render.background_train = bg
+        tr.get_train_parameters(stage)
+        ns = NativeStep(tr, tr.get_sample(np.arange(B), device_index=True), stage)
+        assert ns.deferred
+        for buf in (ns.rast, ns.rgba):
+            buf.fill_(float("nan"))
+        ns.forward()
+        ns.backward(1)
+        torch.cuda.synchronize()
+        out[pf] = dict(rast=ns.rast.clone(), rgba=ns.rgba.clone(), tile=ns.tile_ids.clone() if ns.tb_ids else None, log=ns.log.clone(),
+                       stats=ns.accF[12:16].clone(), g={k: v.clone() for k, v in ns.g.items() if torch.is_tensor(v)})
+    a, b = out["0"], out["1"]
+    assert not bool(torch.isnan(b["rast"]).any()) and not bool(torch.isnan(b["rgba"]).any())
+    assert torch.equal(a["rast"].view(torch.int32), b["rast"].view(torch.int32))
+    assert torch.equal(a["stats"].view(torch.int32), b["stats"].view(torch.int32)), "shading statistics differ"
+    assert a["tile"] is None or torch.equal(a["tile"], b["tile"])
+    # (rgba went through the in-place antialiasing: float atomics on shared pixels -- equal up to their order)
+    assert float((a["rgba"] - b["rgba"]).abs().max()) <= 1e-6
+    assert float((a["log"] - b["log"]).abs().max()) <= 1e-5 * float(a["log"].abs().max())

@@ -124,3 +124,116 @@ def test_tracker_on_uint8_store_matches_fp32_dataset(flame_model):
     # (the two fits are separate runs of kernels that accumulate with float atomics: equal up to summation order, amplified over 6 steps)
     np.testing.assert_allclose(e_a, e_b, rtol=3e-4)
     assert float((x_a - x_b).abs().max()) <= 2e-3 * float(x_a.abs().max()) + 1e-6
+
+
+# ---- round 5: the transforms ahead of the compositing -- per-camera colour correction, scale-factor resize ----
+GOLD_CC = os.path.join(os.path.dirname(__file__), "golden", "ingest_cc_golden.npz")
+SF_CASES = 5
+
+
+def test_oracle_color_correction_and_resize_match_reference_golden():
+    """oracle/ingest_oracle.c against vectors the reference's OWN methods produced (tools/make_golden_ingest.py:
+    NeRSembleDataset.apply_color_correction, VideoDataset.apply_scale_factor with PIL), and -- where PIL is importable -- against PIL live."""
+    from oracle import ingest_ref as R
+    g = np.load(GOLD_CC)
+    A = g["ccm"]
+    for cam in range(A.shape[0]):
+        assert np.array_equal(R.apply_color_correction(g["cc_rgb"][cam], A[cam]), g["cc_out"][cam])
+        assert np.array_equal(R.apply_color_correction(g["cc_sweep_in"], A[cam]), g["cc_sweep_out"][cam])
+        assert np.array_equal(R.apply_color_correction(g["cc_triples_in"], A[cam]), g["cc_triples_out"][cam])
+    assert np.array_equal(g["cc_sweep_out"][0], g["cc_sweep_in"])              # the identity transform returns every 8-bit value
+    assert (g["cc_triples_out"][3] == 0).any() and (g["cc_triples_out"][3] == 255).any()      # the clip is exercised at both ends
+    for i in range(SF_CASES):
+        sf, nds = g[f"sf{i}_cfg"]
+        out = R.apply_scale_factor(g[f"sf{i}_in_rgb"], g[f"sf{i}_in_alpha_map"], float(sf), int(nds) or None, g[f"sf{i}_in_lmk2d"],
+                                   g[f"sf{i}_in_intrinsic"])
+        for k in ("rgb", "alpha_map", "lmk2d", "intrinsic"):
+            assert np.array_equal(out[k], g[f"sf{i}_out_{k}"]), (i, k)
+        assert out["scale_factor"] == float(g[f"sf{i}_out_scale"])
+    try:
+        from PIL import Image
+    except ImportError:
+        return
+    rng = np.random.default_rng(4)
+    for H, W, h, w in [(61, 47, 30, 23), (48, 64, 48, 20), (33, 90, 11, 90), (200, 150, 66, 50)]:
+        img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        assert np.array_equal(R.pil_resize(img, h, w), np.array(Image.fromarray(img).resize((w, h), resample=Image.BILINEAR)))
+
+
+def test_host_resampling_tables_match_the_oracle():
+    """vhap_amd.ingest.pil_bilinear_coeffs (the product's host-side restatement of Pillow's precompute_coeffs + normalize_coeffs_8bpc,
+    what vhap_frame_resize_u8 is fed) against the C oracle's independent one."""
+    import ctypes
+    import oracle
+    from vhap_amd.ingest import pil_bilinear_coeffs, scale_item_properties
+    ip = ctypes.POINTER(ctypes.c_int32)
+    for n_in, n_out in [(550, 275), (802, 401), (3208, 802), (100, 33), (64, 63), (17, 5), (2200, 550), (9, 1)]:
+        b, k, ks = pil_bilinear_coeffs(n_in, n_out)
+        bb, kk = np.zeros(2 * n_out, np.int32), np.zeros(n_out * ks, np.int32)
+        assert oracle.lib().oracle_pil_coeffs(n_in, n_out, bb.ctypes.data_as(ip), kk.ctypes.data_as(ip), n_out * ks) == ks
+        assert np.array_equal(b, bb) and np.array_equal(k, kk)
+    g = np.load(GOLD_CC)
+    for i in range(SF_CASES):
+        sf, nds = g[f"sf{i}_cfg"]
+        h, w = g[f"sf{i}_out_rgb"].shape[:2]
+        got = scale_item_properties({"scale_factor": float(sf) / (nds or 1), "image_size": (h, w)}, g[f"sf{i}_in_lmk2d"], g[f"sf{i}_in_intrinsic"])
+        assert np.array_equal(got["lmk2d"], g[f"sf{i}_out_lmk2d"]) and np.array_equal(got["intrinsic"], g[f"sf{i}_out_intrinsic"])
+
+
+@pytest.mark.gpu
+def test_hip_color_correction_and_resize_match_reference_golden():
+    """FrameStore.from_decoded (vhap_frame_color_correct, vhap_frame_resize_u8) against the reference-made golden, bit for bit: every
+    camera's transform on the sample image, the exhaustive per-channel sweeps, 16 384 random triples; every scale-factor case incl. the
+    alpha map stored at n_downsample_rgb times the rgb's size; then the composited fp32 batch of the whole chain."""
+    import torch
+    from oracle import ingest_ref as R
+    from vhap_amd.ingest import FrameStore
+    g = np.load(GOLD_CC)
+    A = g["ccm"]
+    n_cam = A.shape[0]
+    st = FrameStore.from_decoded(g["cc_rgb"], camera_index=np.arange(n_cam), color_correction=A)
+    assert np.array_equal(st.rgb.cpu().numpy(), g["cc_out"])
+    for cam in range(n_cam):
+        for key in ("cc_sweep", "cc_triples"):
+            src = g[key + "_in"]
+            st = FrameStore.from_decoded(src[None], camera_index=[cam], color_correction=A[:, :3])       # ([n_cam,3,4] form)
+            assert np.array_equal(st.rgb.cpu().numpy()[0], g[key + "_out"][cam]), (cam, key)
+    for i in range(SF_CASES):
+        sf, nds = g[f"sf{i}_cfg"]
+        st = FrameStore.from_decoded(g[f"sf{i}_in_rgb"][None], g[f"sf{i}_in_alpha_map"][None], "white", scale_factor=float(sf),
+                                     n_downsample_rgb=int(nds) or None)
+        assert np.array_equal(st.rgb.cpu().numpy()[0], g[f"sf{i}_out_rgb"]), i
+        assert np.array_equal(st.alpha.cpu().numpy()[0], g[f"sf{i}_out_alpha_map"]), i
+        assert st.prepared["scale_factor"] == float(g[f"sf{i}_out_scale"]) and st.prepared["image_size"] == g[f"sf{i}_out_rgb"].shape[:2]
+        out, a = st.batch()
+        want, want_a = R.frame_ingest(g[f"sf{i}_out_rgb"][None], g[f"sf{i}_out_alpha_map"][None], None, "white")
+        assert np.array_equal(out.cpu().numpy(), want) and np.array_equal(a.cpu().numpy(), want_a)
+    with pytest.raises(AssertionError):
+        FrameStore.from_decoded(g["cc_rgb"], scale_factor=1.5)
+    with pytest.raises(ValueError):
+        FrameStore.from_decoded(g["cc_rgb"], color_correction=A)                # four transforms, no camera index
+
+
+@pytest.mark.gpu
+def test_hip_frame_preparation_vs_oracle_at_nersemble_size():
+    """BASELINE config 4's ingest: 16 views 802 x 550 (3208 x 2200 / n_downsample_rgb 4), one colour transform per camera, alpha maps at
+    full size, 'white' background -- and the same with scale_factor 0.5 on top -- against the C oracle, bit for bit."""
+    import torch
+    from oracle import ingest_ref as R
+    from vhap_amd.ingest import FrameStore
+    rng = np.random.default_rng(16)
+    N, H, W = 16, 802, 550
+    rgb = rng.integers(0, 256, (N, H, W, 3), dtype=np.uint8)
+    alpha = (rng.random((N, 2 * H, 2 * W)) * 1.4 * 255).clip(0, 255).astype(np.uint8)          # (stored at twice the rgb's size here)
+    A = np.tile(np.eye(4), (N, 1, 1))
+    A[:, :3, :3] += rng.standard_normal((N, 3, 3)) * 0.06
+    A[:, :3, 3] = rng.standard_normal((N, 3)) * 0.02
+    cams = rng.permutation(N)
+    for sf in (1.0, 0.5):
+        st = FrameStore.from_decoded(rgb, alpha, "white", camera_index=cams, color_correction=A, scale_factor=sf, n_downsample_rgb=2)
+        h, w = int(H * sf), int(W * sf)
+        want_rgb = np.stack([R.pil_resize(R.apply_color_correction(rgb[i], A[cams[i]]), h, w) for i in range(N)])
+        want_a = np.stack([R.pil_resize(alpha[i], h, w) for i in range(N)])
+        assert np.array_equal(st.rgb.cpu().numpy(), want_rgb) and np.array_equal(st.alpha.cpu().numpy(), want_a)
+        out, _ = st.batch(torch.arange(N, device="cuda"))
+        assert np.array_equal(out.cpu().numpy(), R.frame_ingest(want_rgb, want_a, None, "white")[0])

@@ -119,6 +119,8 @@ SIGNATURES = {
     "vhap_raster_shade_stats": (c_i, [c_i] * 4 + [c_fp, c_sz, c_sz, c_i, c_fp, c_fp]),
     "vhap_photo_fwd_total": (c_i, [c_fp, c_fp, c_i, c_i, c_i] + [c_fp] * 6 + [c_f] * 3 + [c_fp] * 4 + [c_fp, c_fp, c_i, c_fp]),
     "vhap_frame_ingest": (c_i, [c_fp, c_fp, c_fp] + [c_i] * 5 + [c_fp] * 4),
+    "vhap_frame_color_correct": (c_i, [c_fp, c_fp, c_fp] + [c_i] * 4 + [c_fp, c_fp]),
+    "vhap_frame_resize_u8": (c_i, [c_fp] + [c_i] * 4 + [c_fp, c_i, c_i, c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_fp]),
     "vhap_batch_feed": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i] + [c_fp, c_fp, c_i] * 3 + [c_fp, c_fp, c_fp]),
     "vhap_plan_from_graph": (c_i, [c_fp, c_i, ctypes.POINTER(ctypes.c_void_p)]),
     "vhap_plan_destroy": (c_i, [c_fp]),
