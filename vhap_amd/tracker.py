@@ -593,6 +593,14 @@ class GlobalTracker(FlameTracker):
         self._graphed = {}
         self.init_params()
 
+    @classmethod
+    def from_reference_config(cls, ref_cfg, **kw):
+        """`GlobalTracker(cfg)` of the reference (vhap/model/tracker.py:1221-1261, vhap/track.py:16-21) from the REFERENCE's config object:
+        the dataset opened through the reference's own class (`cfg.data._target`, imported from the user's checkout), FLAME from the
+        licensed pickles, the frames resident as uint8.  Keyword arguments: vhap_amd.reference_adapter.tracker_from_reference_config."""
+        from .reference_adapter import tracker_from_reference_config
+        return tracker_from_reference_config(cls, ref_cfg, **kw)
+
     def init_params(self):
         """tracker.py:1279-1341."""
         dev, m = self.device, self.cfg.model
