@@ -237,3 +237,68 @@ def test_hip_frame_preparation_vs_oracle_at_nersemble_size():
         assert np.array_equal(st.rgb.cpu().numpy(), want_rgb) and np.array_equal(st.alpha.cpu().numpy(), want_a)
         out, _ = st.batch(torch.arange(N, device="cuda"))
         assert np.array_equal(out.cpu().numpy(), R.frame_ingest(want_rgb, want_a, None, "white")[0])
+
+
+class _DuckDataset:
+    """The slice of the reference's dataset interface vhap_amd.reference_adapter reads (video_dataset.py:209-259, nersemble_dataset.py:
+    160-171): cfg, items, __getitem__ -> apply_transforms, color_correction -- with the ORACLE's restatements as the host transforms (the
+    reference's own classes play this part in tests/test_reference_adapter.py, where the checkout exists)."""
+    batchify_all_views = False
+    img_to_tensor = False
+
+    def __init__(self, cfg, rgb, alpha, lmk, cams, A, K, RT):
+        self.cfg, self.rgb, self.alpha, self.lmk, self.cams, self.K, self.RT = cfg, rgb, alpha, lmk, cams, K, RT
+        self.color_correction = {c: A[i] for i, c in enumerate(cams)}
+        nt = len(rgb) // len(cams)
+        self.items = [{"timestep_index": t, "camera_id": c} for t in range(nt) for c in cams]
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        it = dict(self.items[i], rgb=self.rgb[i].copy(), alpha_map=self.alpha[i].copy(), lmk2d=self.lmk[i].copy(),
+                  intrinsic=self.K.copy(), extrinsic=self.RT[i % len(self.cams)].copy())
+        return self.apply_transforms(it)
+
+    def apply_transforms(self, it):
+        from oracle import ingest_ref as R
+        c = self.cfg
+        if c.use_color_correction:
+            it["rgb"] = R.apply_color_correction(it["rgb"], self.color_correction[it["camera_id"]])
+        sc = R.apply_scale_factor(it["rgb"], it["alpha_map"], c.scale_factor, c.n_downsample_rgb, it["lmk2d"], it["intrinsic"])
+        it.update(rgb=sc["rgb"], alpha_map=sc["alpha_map"], lmk2d=sc["lmk2d"], intrinsic=sc["intrinsic"])
+        it["rgb"] = R.apply_background_color(it["rgb"], it["alpha_map"], c.background_color)
+        return it
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bg,sf,nds", [("white", 0.5, 2), (None, 1.0, 2), ("black", 0.6, None)])
+def test_adapter_device_preparation_equals_host_transforms(bg, sf, nds):
+    """reference_adapter.frames_from_reference_dataset: device_prepare=True (decoder output uploaded; colour correction, scale factor and
+    compositing on the device) gives the fit the SAME batch, bit for bit, as device_prepare=False (the dataset's own host transforms),
+    and the same landmarks / intrinsics -- multi-view layout, alpha maps at n_downsample_rgb times the rgb's size."""
+    import types
+    import torch
+    from vhap_amd.reference_adapter import frames_from_reference_dataset
+    rng = np.random.default_rng(9)
+    cams = ["a", "b", "c"]
+    nt, H, W = 2, 44, 60
+    N = nt * len(cams)
+    up = nds or 1
+    rgb = rng.integers(0, 256, (N, H, W, 3), dtype=np.uint8)
+    alpha = rng.integers(0, 256, (N, H * up, W * up), dtype=np.uint8)
+    lmk = np.concatenate([rng.random((N, 68, 2)).astype(np.float32), np.ones((N, 68, 1), np.float32)], -1)
+    A = np.tile(np.eye(4), (3, 1, 1))
+    A[:, :3, :3] += rng.standard_normal((3, 3, 3)) * 0.05
+    K = np.array([[900.0, 0, 400.5], [0, 910.0, 300.25], [0, 0, 1]], np.float32)
+    RT = rng.standard_normal((3, 3, 4)).astype(np.float32)
+    cfg = types.SimpleNamespace(use_color_correction=True, scale_factor=sf, n_downsample_rgb=nds, background_color=bg, calibrated=True,
+                                use_alpha_map=True)
+    host = frames_from_reference_dataset(_DuckDataset(cfg, rgb, alpha, lmk, cams, A, K, RT), "cuda", device_prepare=False)
+    dev = frames_from_reference_dataset(_DuckDataset(cfg, rgb, alpha, lmk, cams, A, K, RT), "cuda", device_prepare=True)
+    a, _ = host["frames"].batch()
+    b, _ = dev["frames"].batch()
+    assert a.shape == (N, 3, int(H * sf), int(W * sf)) and torch.equal(a, b)
+    for k in ("lmk2d", "intrinsic", "extrinsic"):
+        assert torch.equal(host[k], dev[k]), k
+    assert list(dev["timestep_index"]) == [0, 0, 0, 1, 1, 1] and list(dev["camera_index"]) == [0, 1, 2] * 2
