@@ -127,14 +127,17 @@ def pmc_traffic():
         return None, None
 
 
-def cpu_baseline(C, tr, sample, model, topo, n_timed=3, budget_s=100.0):
+CPU_BASELINE_THREADS = 16          # the best of a 16 / 64 / 256-thread sweep on the GPU box's host (tools/cpu_baseline_sweep.py -> profiles/r05_cpu_baseline_thread_sweep.txt)
+
+
+def cpu_baseline(C, tr, sample, model, topo, n_timed=3, budget_s=100.0, cores=None):
     """The CPU oracle restatement (torch-CPU fp32 + C rasteriser) of the SAME step: ONE whole batch of the quoted configuration --
     forward with the colour disturbance on, backward to every parameter, torch.optim.Adam: one warm-up step, then the median of
     `n_timed` steps (fewer if the budget runs out: a step is ~15 s on 16 cores)."""
     from oracle import energy_ref, fit_ref
     H, W = C["H"], C["W"]
     n_host = os.cpu_count() or 1
-    cores = min(n_host, 16)                                    # more threads only add contention for this op mix
+    cores = min(n_host, int(cores or os.environ.get("VHAP_CPU_BASELINE_THREADS", CPU_BASELINE_THREADS)))
     torch.set_num_threads(cores)
     os.environ["OMP_NUM_THREADS"] = str(cores)
     dt = torch.float32
@@ -513,6 +516,9 @@ def main():
                          "frac": alg / ri_step / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
                          "frac_in_step": (alg / sum(sep) / HBM_PEAK) if sep else None,
                          "frac_in_step_deferred": (alg / sum(fused) / HBM_PEAK) if fused else None,
+                         # the pass AS THE SHIPPED STEP RUNS IT (bin_build + raster_kernel<2>: rasterise + interpolate + texture + shade +
+                         # composite in one kernel, 35 B/px written) against the same fixed 292 MB: first-class, next to `frac`
+                         "frac_shipped": (alg / sum(fused) / HBM_PEAK) if fused else None,
                          "frac_isolated": alg / ri_iso / HBM_PEAK,
                          "us_per_launch": ri_step * 1e6, "us_per_launch_isolated": ri_iso * 1e6,
                          "us_in_step": {"bin_build": sep[0] * 1e6, "raster_kernel<1>": sep[1] * 1e6} if sep else None,
