@@ -9,6 +9,7 @@ host time), so it is a two-part record:
         HipAdam; dumps the start state, the frames (resident as uint8, as the frame store holds them), per-step triangle ids and
         energies, and the arrays GlobalTracker.save_result exports.
     python tools/fullbatch_trajectory.py cpu  gpurun_out/traj_cfgN.npz --record profiles/r05_trajectory_cfgN.txt   (anywhere; no GPU)
+    python tools/fullbatch_trajectory.py both --config N --record ... --threads 64       (one process: the dump is ~100 MiB, too big to travel)
         the oracle's fit loop (oracle/fit_ref.py: energy_ref.total_energy in float64 + torch.optim.Adam) from the same start on the same
         frames and the same visibility; compares energies per step and every exported array (relative L2 of the array and of its UPDATE).
 
@@ -108,10 +109,17 @@ def gpu_part(which, out, K):
         dump["start_" + k] = v
     for k, v in tr.save_result().items():
         dump["export_" + k] = np.asarray(v)
+    print(f"config {which}: {K} steps in {time.time() - t0:.1f} s, E {E[0]:.6f} -> {E[-1]:.6f}, coverage {float(dump['coverage']):.3f}", flush=True)
+    if out is None:
+        return dump
     os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
-    np.savez_compressed(out, **dump)
-    print(f"config {which}: {K} steps in {time.time() - t0:.1f} s, E {E[0]:.6f} -> {E[-1]:.6f}, coverage {float(dump['coverage']):.3f}, "
-          f"{os.path.getsize(out) / 2 ** 20:.1f} MiB -> {out}")
+    np.savez_compressed(out, **dump)             # (~100 MiB: the start and the exported 2048^2 textures are 50 MB each)
+    print(f"{os.path.getsize(out) / 2 ** 20:.1f} MiB -> {out}")
+    return dump
+
+
+class _Files(dict):
+    files = property(lambda self: list(self.keys()))
 
 
 def cpu_part(path, record, threads):
@@ -120,7 +128,7 @@ def cpu_part(path, record, threads):
     from vhap_amd.topology import FlameTopology  # noqa: F401  (import check: the oracle side needs no HIP library)
     if threads:
         torch.set_num_threads(threads)
-    d = np.load(path)
+    d = _Files(path) if isinstance(path, dict) else np.load(path)
     which, K = int(d["config"]), int(d["K"])
     c = CFG[which]
     H, W, stage = c["H"], c["W"], c["stage"]
@@ -200,8 +208,16 @@ if __name__ == "__main__":
     c.add_argument("dump")
     c.add_argument("--record", default=None)
     c.add_argument("--threads", type=int, default=0)
+    b = sub.add_parser("both", help="the two halves in one process, nothing written but the record (the dump is ~100 MiB: more than a "
+                                    "GPU box hands back)")
+    b.add_argument("--config", type=int, choices=sorted(CFG), required=True)
+    b.add_argument("--steps", type=int, default=K_DEFAULT)
+    b.add_argument("--record", default=None)
+    b.add_argument("--threads", type=int, default=0)
     a = ap.parse_args()
     if a.cmd == "gpu":
         gpu_part(a.config, a.out, a.steps)
+    elif a.cmd == "both":
+        sys.exit(cpu_part(gpu_part(a.config, None, a.steps), a.record, a.threads))
     else:
         sys.exit(cpu_part(a.dump, a.record, a.threads))

@@ -593,16 +593,9 @@ __global__ __launch_bounds__(256, MODE == 2 ? 6 : 8) __attribute__((amdgpu_num_s
     __shared__ int4 sfr[4][MAX_FRAG];   // per wave: fragment f = (first work item, count | overflow flag, list offset / first triangle, -)
     unsigned n, off = 0u;
     int nfr = 0;                  // non-empty fragments of this bin (the mesh is coherent in triangle order: usually 1-3)
-    // mode 2: the background colour of this pixel depends on its position alone -- requested ahead of the fragment descriptors, it is one
-    // round trip less for every wave that ends up background (a third of the waves inside the geometry box)
-    float bg0 = 0.f, bg1 = 0.f, bg2 = 0.f;
-    if constexpr (MODE == 2) {
-        if (P.bg_image && in_img && !prefilled && !(P.debug & 16384)) {
-            const size_t HW = (size_t)H * W;
-            const float* g = P.bg_image + (size_t)b * 3 * HW + (size_t)(H - 1 - py) * W + px;
-            bg0 = g[0]; bg1 = g[HW]; bg2 = g[2 * HW];
-        }
-    }
+    // (round 5, measured and dropped: the three background-image loads of mode 2 issued HERE, ahead of the fragment descriptors -- one round
+    // trip less for every background wave -- change nothing: raster<2> 106.2 vs 104.1 us, step 0.8876 vs 0.8858 ms, 77 instead of 74
+    // VGPRs; profiles/r05_call4_log.txt "debug 0 / debug 16384")
     if (MODE == 2 && prefilled) {
         n = 0u;
     } else if (fragmented) {
@@ -840,12 +833,9 @@ __global__ __launch_bounds__(256, MODE == 2 ? 6 : 8) __attribute__((amdgpu_num_s
             } else if (prefilled) {
                 o_rgba = make_float4(0.f, 0.f, 0.f, 0.f);         // (stored by the binning launch)
             } else if (P.bg_image) {
-                if (P.debug & 16384) {                                  // (A/B switch: the loads behind the coverage loop, as before round 5)
-                    const size_t HW = (size_t)H * W;
-                    const float* g = P.bg_image + (size_t)b * 3 * HW + (size_t)(H - 1 - py) * W + px;
-                    bg0 = g[0]; bg1 = g[HW]; bg2 = g[2 * HW];
-                }
-                o_rgba = make_float4(bg0, bg1, bg2, 0.0f);
+                const size_t HW = (size_t)H * W;
+                const float* g = P.bg_image + (size_t)b * 3 * HW + (size_t)(H - 1 - py) * W + px;
+                o_rgba = make_float4(g[0], g[HW], g[2 * HW], 0.0f);
             } else {
                 o_rgba = make_float4(P.bg_r, P.bg_g, P.bg_b, 0.0f);
             }
