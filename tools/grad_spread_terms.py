@@ -83,7 +83,7 @@ def run(tag, NV=2, H=802, W=550, mutate=None, deferred=True):
 
 if __name__ == "__main__":
     def no_lmk(cfg):
-        cfg.w.landmark = None
+        cfg.w.landmark = 1e-9
     run("all terms")
     run("landmark term off", mutate=no_lmk)
     run("separate passes (VHAP_DEFERRED=0)", deferred=False)
