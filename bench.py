@@ -391,6 +391,15 @@ def main():
     ap.add_argument("--no-stage", action="store_true", help="skip the end-to-end stage measurement (stage_fps)")
     ap.add_argument("--eager", action="store_true", help="run optimize_iter eagerly instead of replaying the captured hipGraphs")
     args = ap.parse_args()
+    # ONE JSON line on stdout, nothing else: libraries below Python write there too (RCCL prints a version banner on its first communicator:
+    # profiles/r05_call6_rccl_banner_on_stdout.txt).  File descriptor 1 is pointed at stderr for the whole run; the result line goes to the
+    # saved descriptor.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line):
+        os.write(result_fd, (line + "\n").encode())
     if os.environ.get("VHAP_DEBUG"):                            # profiling-only A/B switches of the library (tools/ab_env.sh)
         from vhap_amd import _lib as _vl
         _vl.debug_set_flags(int(os.environ["VHAP_DEBUG"]))
@@ -546,7 +555,7 @@ def main():
             except Exception as e:                               # the baseline must never sink the GPU number
                 out["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
                                        "sample": f"failed: {type(e).__name__}: {e}"}
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
     if group_up:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

@@ -78,9 +78,10 @@ def configure_optimizer(P, cfg, stage, lr_scale=1.0, calibrated=False):
     return torch.optim.Adam([{"params": g["params"], "lr": g["lr"]} for g in groups], lr=cfg.lr.base * lr_scale)
 
 
-def optimize_iter(P, optimizer, model, topo, cfg, sample, stage, tex_painted, uvmask_res, image_size, disturb=None, tid=None):
+def optimize_iter(P, optimizer, model, topo, cfg, sample, stage, tex_painted, uvmask_res, image_size, disturb=None, tid=None, dtype=torch.float64):
     """One step of tracker.py:1418-1462: energy, zero_grad, backward, Adam.  Returns the log dict (floats)."""
-    E, log, extras = energy_ref.total_energy(P, model, topo, cfg, sample, stage, tex_painted, uvmask_res, image_size, disturb=disturb, tid=tid)
+    E, log, extras = energy_ref.total_energy(P, model, topo, cfg, sample, stage, tex_painted, uvmask_res, image_size, dtype=dtype,
+                                             disturb=disturb, tid=tid)
     optimizer.zero_grad()
     E.backward()
     optimizer.step()

@@ -122,7 +122,7 @@ class _Files(dict):
     files = property(lambda self: list(self.keys()))
 
 
-def cpu_part(path, record, threads):
+def cpu_part(path, record, threads, dtype=torch.float64, save=None):
     from oracle import fit_ref
     from vhap_amd.synthetic import make_flame_model, make_texture
     from vhap_amd.topology import FlameTopology  # noqa: F401  (import check: the oracle side needs no HIP library)
@@ -137,27 +137,28 @@ def cpu_part(path, record, threads):
     model, topo = make_flame_model(seed=0)
     tm = {k: torch.from_numpy(np.asarray(v)) for k, v in model.items()}
     for k in ("v_template", "shapedirs", "posedirs", "J_regressor", "lbs_weights", "lmk_bary_coords", "verts_uvs"):
-        tm[k] = tm[k].double()
+        tm[k] = tm[k].to(dtype)
     names = [n for n in NAMES if not (calibrated and n == "focal_length")]
     start = {k: d["start_" + k] for k in names}
-    P = {k: torch.from_numpy(start[k]).double().requires_grad_() for k in names}
+    P = {k: torch.from_numpy(start[k]).to(dtype).requires_grad_() for k in names}
     rgb = (torch.from_numpy(d["frames_u8"]).permute(0, 3, 1, 2).to(torch.float32) / 255)      # vhap_frame_ingest: float32(u8) / 255
     o_sample = {"rgb": rgb, "lmk2d": torch.from_numpy(d["lmk2d"]), "timestep_index": d["timestep_index"]}
     for k in ("intrinsic", "extrinsic"):
         if k in d.files:
             o_sample[k] = torch.from_numpy(d[k])
-    base_tex = torch.from_numpy(make_texture(0, T))[None].double()
-    uvm = torch.from_numpy(topo.get_uvmask_by_region(list(cfg.w.reg_tex_res_for)).astype(np.float64))[None]
+    base_tex = torch.from_numpy(make_texture(0, T))[None].to(dtype)
+    uvm = torch.from_numpy(topo.get_uvmask_by_region(list(cfg.w.reg_tex_res_for)).astype(np.float64))[None].to(dtype)
     if uvm.shape[-1] != T:
         uvm = torch.nn.functional.interpolate(uvm[None], (T, T))[0]
     opt = fit_ref.configure_optimizer(P, cfg, stage, lr_scale=c["lr_scale"], calibrated=calibrated)
     lines = [f"BASELINE config {which}: {rgb.shape[0]} x {H}x{W}, T = {T}, stage {stage}, lr_scale {c['lr_scale']}, K = {K} steps, same visibility "
              f"(HIP triangle ids per step), colour disturbance off, frames resident as uint8; coverage {float(d['coverage']):.3f}; "
-             f"oracle: energy_ref.total_energy float64 + torch.optim.Adam on {torch.get_num_threads()} host threads"]
+             f"oracle: energy_ref.total_energy {str(dtype).split('.')[-1]} + torch.optim.Adam on {torch.get_num_threads()} host threads"]
     E_ora, fails = [], []
     t0 = time.time()
     for i in range(K):
-        o = fit_ref.optimize_iter(P, opt, tm, topo, cfg, o_sample, stage, base_tex, uvm, (H, W), tid=torch.from_numpy(d[f"tid_{i}"].astype(np.int64)))
+        o = fit_ref.optimize_iter(P, opt, tm, topo, cfg, o_sample, stage, base_tex, uvm, (H, W), tid=torch.from_numpy(d[f"tid_{i}"].astype(np.int64)),
+                                  dtype=dtype)
         E_ora.append(o["total"])
         a = float(d["E_hip"][i])
         e = abs(a - o["total"]) / abs(o["total"])
@@ -166,6 +167,8 @@ def cpu_part(path, record, threads):
         if e > 5e-6:
             fails.append(f"energy at step {i}: rel {e:.2e} > 5e-6")
     exp = fit_ref.export(P, (H, W), calibrated=calibrated)
+    if save:
+        np.savez(save, E=np.array(E_ora), **{"export_" + k: np.asarray(v) for k, v in exp.items()})
     worst = 0.0
     for k in sorted(exp):
         if "export_" + k not in d.files:
@@ -208,6 +211,14 @@ if __name__ == "__main__":
     c.add_argument("dump")
     c.add_argument("--record", default=None)
     c.add_argument("--threads", type=int, default=0)
+    c.add_argument("--dtype", choices=("float64", "float32"), default="float64", help="float32: the YARDSTICK -- how far plain fp32 arithmetic "
+                   "(the same oracle, same visibility) drifts from the float64 fit; compare with `yardstick`")
+    c.add_argument("--save", default=None, help="write the oracle's exported arrays (npz) for `yardstick`")
+    y = sub.add_parser("yardstick", help="float32-oracle fit vs float64-oracle fit (two --save files of `cpu`) next to HIP vs float64")
+    y.add_argument("dump")
+    y.add_argument("exp64")
+    y.add_argument("exp32")
+    y.add_argument("--record", default=None)
     b = sub.add_parser("both", help="the two halves in one process, nothing written but the record (the dump is ~100 MiB: more than a "
                                     "GPU box hands back)")
     b.add_argument("--config", type=int, choices=sorted(CFG), required=True)
@@ -219,5 +230,23 @@ if __name__ == "__main__":
         gpu_part(a.config, a.out, a.steps)
     elif a.cmd == "both":
         sys.exit(cpu_part(gpu_part(a.config, None, a.steps), a.record, a.threads))
+    elif a.cmd == "yardstick":
+        d, e64, e32 = np.load(a.dump), np.load(a.exp64), np.load(a.exp32)
+        lines = [f"BASELINE config {int(d['config'])}, {int(d['K'])} steps: distance from the float64-oracle fit of (a) the HIP fit, (b) the SAME oracle "
+                 "run in float32 (same frames, same triangle ids) -- relative L2 of each exported array, and of its update"]
+        for k in sorted(e64.files):
+            if not k.startswith("export_") or k[7:] in ("timestep_id", "n_processed_frames", "image_size") or k not in d.files or "start_" + k[7:] not in d.files:
+                continue
+            b_, s0 = np.asarray(e64[k], np.float64), np.asarray(d["start_" + k[7:]], np.float64).reshape(e64[k].shape)
+            if float(np.abs(b_ - s0).max()) == 0:
+                continue
+            row = []
+            for a_ in (np.asarray(d[k], np.float64), np.asarray(e32[k], np.float64)):
+                row += [np.linalg.norm(a_ - b_) / max(np.linalg.norm(b_), 1e-300), np.linalg.norm(a_ - b_) / max(np.linalg.norm(b_ - s0), 1e-300)]
+            lines.append(f"{k[7:]:14s} HIP: L2 rel {row[0]:.2e} update {row[1]:.2e}    oracle-fp32: L2 rel {row[2]:.2e} update {row[3]:.2e}    "
+                         f"HIP / oracle-fp32 = {row[0] / max(row[2], 1e-300):.2f}")
+        print("\n".join(lines))
+        if a.record:
+            open(a.record, "w").write("\n".join(lines) + "\n")
     else:
-        sys.exit(cpu_part(a.dump, a.record, a.threads))
+        sys.exit(cpu_part(a.dump, a.record, a.threads, dtype=getattr(torch, a.dtype), save=a.save))
