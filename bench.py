@@ -32,6 +32,12 @@ import os
 import sys
 import time
 
+# HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and two streams on one queue run in series.  The
+# sharded step has five streams of its own plus the collective library's: with four queues RCCL's stream shared the launch stream's queue and
+# the reduce-scatter sat IN FRONT of the geometry plan instead of under it (profiles/r05_call7_sharded_step_timeline.txt).  Read by the
+# runtime when it initialises, i.e. before the first HIP call: set here, ahead of `import torch`.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 

@@ -107,6 +107,11 @@ class FrameShardContext:
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
+    def all_reduce_sum_(self, t):
+        """in place (no clone): t = sum over ranks of t"""
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
     def broadcast_int(self, value, src=0):
         """The same Python int on every rank (rank `src`'s)."""
         dev = "cuda" if dist.get_backend(self.group) == "nccl" else "cpu"
@@ -146,11 +151,16 @@ class FrameShardContext:
     def all_gather_rows(self, planes, row0, nrows, async_op=False):
         """planes [C, T, W] (contiguous): every rank owns the rows [r * nrows, (r + 1) * nrows) of each plane and has just updated ITS rows
         [row0, row0 + nrows); afterwards every rank holds all rows.  One all-gather per plane straight into the plane (a plane's row
-        strips are its N equal contiguous chunks); the input is a copy of the strip.  -> list of handles with wait()."""
+        strips are its N equal contiguous chunks).  -> list of handles with wait()."""
         assert planes.is_contiguous() and row0 == self.rank * nrows and planes.shape[1] == nrows * self.world_size
         works = []
+        nccl = dist.get_backend(self.group) == "nccl"
         for c in range(planes.shape[0]):
-            src = planes[c, row0:row0 + nrows].clone()
+            # RCCL gathers IN PLACE when the input is the rank's own slot of the output (sendbuff == recvbuff + rank * count): no staging
+            # copy of the strip; gloo is handed a copy
+            src = planes[c, row0:row0 + nrows]
+            if not nccl:
+                src = src.clone()
             w = dist.all_gather_into_tensor(planes[c], src, group=self.group, async_op=async_op)
             works.append(w if async_op and w is not None else self._Done())
         return works

@@ -973,6 +973,20 @@ class NativeStep:
         elif part == "pixel_tex":
             self._bwd_pixel(world_size)
             self._side(self._bwd_pixel_finish, self.side2)
+            if self.split_tex and self.overlap:
+                # sharded texture update: the texture gradient (tile accumulation, then the pyramid folded into level 0 -- what is exchanged)
+                # is a SIDE chain of this plan and its open tail: the caller replays the plan with a deferred join, lets its communication
+                # stream wait for the tail and launches the reduce-scatter there, while the launch stream goes straight on to the geometry
+                # plan -- tile accumulation, fold and collective all run UNDER the G-buffer backward, as the tile accumulation does on one
+                # GPU (round 5: issued on the launch stream they sat in series with it, profiles/r05_call7_sharded_step_timeline.txt)
+                def tex_chain():
+                    self._tex_backward()
+                    self.tex_fold()
+                self._side(tex_chain)
+                self._flush()
+                torch.cuda.current_stream().wait_stream(self.side2)
+                self._join()                                           # (ends the capture's fork; a deferred-join replay leaves it out)
+                return
             self._tex_backward()
             if self.split_tex:                                        # (sharded texture update: the exchange is on level 0 of the pyramid)
                 self.tex_fold()

@@ -1387,6 +1387,7 @@ class GraphedStep:
                     self.tex_row0 = tracker.dist.rank * self.tex_rows
                     self.tex_strip = torch.zeros(self.tex_rows, T, 3, device=dev)        # reduce-scatter output: this rank's rows of the level-0 gradient
                     self._tex_gather = None
+                    self.comm = _lib.private_stream("comm", dev)                         # carries the texture collective (see _replay)
                 with self.gF.capture(**cap):
                     ns.forward()
                 pool = self.gF.pool()
@@ -1616,19 +1617,33 @@ class GraphedStep:
                 self.gA.replay()
                 return
             if tr.dist is not None:
-                self.ns.n_global.copy_(tr.dist.all_reduce_sum(self.N.reshape(1)))
-            self.gB.replay()                                               # pixel chain + the complete texture gradient
+                self.ns.n_global.copy_(self.N.reshape(1))                  # (in place on the step's own buffer: one launch, no clone)
+                tr.dist.all_reduce_sum_(self.ns.n_global)
             # the gradients sit in contiguous buffers: collectives straight on them (ReduceOp.AVG), no staging copies
             if getattr(self, "tex_sharded", False):
                 n0 = self.ns.albedo_tex.numel()
-                work = tr.dist.reduce_scatter_mean(self.ns.g["d_tex"][:n0], self.tex_strip.view(-1), async_op=True)   # level 0, pyramid folded in
-                self.gB2.replay()                                          # geometry chain: runs under the texture collective
+                if self.ns.overlap and self.gB.plan is not None:
+                    # the pixel chain on the launch stream; the texture gradient's tile accumulation + fold are the plan's open tail on its
+                    # side stream.  The COMMUNICATION stream waits for that tail and carries the reduce-scatter; the launch stream goes on
+                    # to the geometry plan at once: gradient accumulation, fold and collective run under the G-buffer backward
+                    self.gB.replay(defer_join=True)
+                    cur = torch.cuda.current_stream()
+                    with torch.cuda.stream(self.comm):
+                        self.gB.join()
+                        work = tr.dist.reduce_scatter_mean(self.ns.g["d_tex"][:n0], self.tex_strip.view(-1), async_op=True)
+                    self.gB2.replay()
+                    cur.wait_stream(self.comm)                             # (the plan's other side chain: lights gradient, delta clear)
+                else:
+                    self.gB.replay()                                       # pixel chain + the complete texture gradient
+                    work = tr.dist.reduce_scatter_mean(self.ns.g["d_tex"][:n0], self.tex_strip.view(-1), async_op=True)   # level 0, pyramid folded in
+                    self.gB2.replay()                                      # geometry chain: runs under the texture collective
                 tr.dist.all_reduce_mean_(self.ns.param_grad_flat)
                 work.wait()
                 self.gA.replay()                                           # this rank's rows of the texture + every other parameter
                 # the updated rows travel while the host comes round to the next step (whose forward waits: wait_texture)
                 self._tex_gather = tr.dist.all_gather_rows(tr.tex_extra.detach(), self.tex_row0, self.tex_rows, async_op=True)
                 return
+            self.gB.replay()                                               # pixel chain + the complete texture gradient
             work = tr.dist.all_reduce_mean_(self.ns.g["tex_extra"], async_op=True) if self.ns.tex_bwd_on else None
             self.gB2.replay()                                              # geometry chain: runs under the texture collective
             tr.dist.all_reduce_mean_(self.ns.param_grad_flat)
