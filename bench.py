@@ -32,12 +32,9 @@ import os
 import sys
 import time
 
-# HIP multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4), and two streams on one queue run in series.  The
-# sharded step has five streams of its own plus the collective library's: with four queues RCCL's stream shared the launch stream's queue and
-# the reduce-scatter sat IN FRONT of the geometry plan instead of under it (profiles/r05_call7_sharded_step_timeline.txt).  Read by the
-# runtime when it initialises, i.e. before the first HIP call: set here, ahead of `import torch`.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
+# (GPU_MAX_HW_QUEUES: HIP multiplexes a process's streams onto 4 hardware queues by default and two streams on one queue run in series --
+# in the sharded step RCCL's stream shares the launch stream's queue.  Raising it to 8 was measured and is NOT done: the one-plan step
+# goes from 0.869 to 1.117 ms and the sharded one from 1.240 to 2.496 ms (profiles/r05_call8_hw_queues_4_vs_8.txt).)
 import numpy as np
 import torch
 
