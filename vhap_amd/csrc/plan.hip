@@ -72,13 +72,47 @@ const char* node_type_name(hipGraphNodeType t) {
     }
 }
 
+// The plans' side streams come from ONE pool per host thread and device (side stream k of every plan of this thread is the same HIP
+// stream), created on first use and kept for the life of the thread.  HIP multiplexes a process's streams onto four hardware queues and two
+// streams on one queue run in series: with streams of its own per plan, the four plans of a sharded step (forward / pixel + texture /
+// geometry / Adam) held eight, the texture gradient's side chain landed on the LAUNCH stream's queue and the reduce-scatter queued up in
+// front of the geometry plan it was meant to run under (profiles/r05_call9_sharded_step_timeline.txt).  Plans of one thread replay in
+// stream order anyway; sharing adds ordering only between replays that would otherwise overlap on a side stream.
+struct SidePool {
+    int device = -1;
+    bool least_priority = false;
+    std::vector<hipStream_t> streams;
+};
+thread_local std::vector<SidePool> g_side_pools;
+
+hipStream_t pool_stream(int k, bool least_priority) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    SidePool* pool = nullptr;
+    for (auto& sp : g_side_pools) if (sp.device == dev && sp.least_priority == least_priority) pool = &sp;
+    if (!pool) {
+        g_side_pools.push_back(SidePool{dev, least_priority, {}});
+        pool = &g_side_pools.back();
+    }
+    while ((int)pool->streams.size() <= k) {
+        hipStream_t st = nullptr;
+        int prio_least = 0, prio_greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+        const hipError_t e = least_priority ? hipStreamCreateWithPriority(&st, hipStreamNonBlocking, prio_least)
+                                            : hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        if (e != hipSuccess) return nullptr;
+        pool->streams.push_back(st);
+    }
+    return pool->streams[k];
+}
+
 void destroy(vhap_plan* p) {
     if (!p) return;
     for (auto e : p->events) if (e) (void)hipEventDestroy(e);
     for (auto e : p->tails) if (e) (void)hipEventDestroy(e);
     for (auto e : p->tev) if (e) (void)hipEventDestroy(e);
     if (p->start) (void)hipEventDestroy(p->start);
-    for (auto s : p->streams) if (s) (void)hipStreamDestroy(s);
+    // (the side streams belong to the thread's pool)
     delete p;
 }
 
@@ -295,12 +329,10 @@ extern "C" int vhap_plan_from_graph(void* hip_graph, int max_streams, vhap_plan_
     ok = ok && hipEventCreateWithFlags(&p->start, edge_flags) == hipSuccess;
     p->streams.assign(ns - 1, nullptr);
     p->tails.assign(ns - 1, nullptr);
-    int prio_least = 0, prio_greatest = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     for (int s = 0; s + 1 < ns && ok; s++) {
         // (debug flag 524288: A/B, the side streams at the LOWEST priority -- the launch stream carries the dependency chain of the step)
-        if (vhap_g_debug_flags & 524288) ok = ok && hipStreamCreateWithPriority(&p->streams[s], hipStreamNonBlocking, prio_least) == hipSuccess;
-        else ok = ok && hipStreamCreateWithFlags(&p->streams[s], hipStreamNonBlocking) == hipSuccess;
+        p->streams[s] = pool_stream(s, (vhap_g_debug_flags & 524288) != 0);
+        ok = ok && p->streams[s] != nullptr;
         ok = ok && hipEventCreateWithFlags(&p->tails[s], hipEventDisableTiming) == hipSuccess;
     }
     if (!ok) { destroy(p); return VHAP_E_HIP; }
