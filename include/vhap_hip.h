@@ -758,6 +758,11 @@ int vhap_plan_node_name(vhap_plan_t plan, int node, char* buf, size_t cap);
  * enqueues on `stream` before the next vhap_plan_join (or the next joined replay) touches what those open tails read or write.  The step
  * host uses it to start step k+1's geometry chain under step k's texture update (vhap_amd/tracker.py::GraphedStep). */
 #define VHAP_CALL_PLAN_DEFER_JOIN 64
+/* The side streams of every plan of one host thread come from one pool (side stream k of a plan = pool stream base + k, base 0 unless
+ * vhap_plan_set_side_base was called on this thread before the plan was created; ABI 9).  vhap_plan_touch_side_streams issues a 4-byte fill
+ * on pool streams 0 .. n - 1 in order: HIP binds a stream to a hardware queue at its first command. */
+int vhap_plan_set_side_base(int base);
+int vhap_plan_touch_side_streams(int n, void* scratch_4_bytes);
 int vhap_plan_launch(vhap_plan_t plan, vhap_stream_t stream, int call_flags);
 int vhap_plan_join(vhap_plan_t plan, vhap_stream_t stream);
 /* the nodes a DEFER_JOIN replay leaves un-joined (indices into launch order, at most `cap` written); returns their number */

@@ -84,6 +84,7 @@ struct SidePool {
     std::vector<hipStream_t> streams;
 };
 thread_local std::vector<SidePool> g_side_pools;
+thread_local int g_side_base = 0;       // vhap_plan_set_side_base: the pool index of the NEXT plan's first side stream
 
 hipStream_t pool_stream(int k, bool least_priority) {
     int dev = 0;
@@ -331,12 +332,36 @@ extern "C" int vhap_plan_from_graph(void* hip_graph, int max_streams, vhap_plan_
     p->tails.assign(ns - 1, nullptr);
     for (int s = 0; s + 1 < ns && ok; s++) {
         // (debug flag 524288: A/B, the side streams at the LOWEST priority -- the launch stream carries the dependency chain of the step)
-        p->streams[s] = pool_stream(s, (vhap_g_debug_flags & 524288) != 0);
+        p->streams[s] = pool_stream(g_side_base + s, (vhap_g_debug_flags & 524288) != 0);
         ok = ok && p->streams[s] != nullptr;
         ok = ok && hipEventCreateWithFlags(&p->tails[s], hipEventDisableTiming) == hipSuccess;
     }
     if (!ok) { destroy(p); return VHAP_E_HIP; }
     *out = p;
+    return VHAP_OK;
+}
+
+// Which pool streams the NEXT plan created on this thread takes: its side stream k = pool stream base + k.  Two plans replayed back to
+// back whose side chains must overlap (the sharded step's pixel plan leaves its texture chain running under the geometry plan) take
+// different ones.  vhap_plan_touch_side_streams: a 4-byte fill on pool streams 0 .. n - 1, in order -- HIP binds a stream to one of
+// its four hardware queues at the stream's FIRST command, round-robin; a host that touches its launch stream, these and its communication
+// stream one after the other gets them onto four different queues.
+extern "C" int vhap_plan_set_side_base(int base) {
+    if (base < 0 || base > 8) return VHAP_E_BADDIM;
+    g_side_base = base;
+    return VHAP_OK;
+}
+
+extern "C" int vhap_plan_touch_side_streams(int n, void* scratch_4_bytes) {
+    VHAP_ENTER();
+    if (!scratch_4_bytes) return VHAP_E_NULLPTR;
+    if (n < 0 || n > 8) return VHAP_E_BADDIM;
+    for (int k = 0; k < n; k++) {
+        hipStream_t st = pool_stream(k, (vhap_g_debug_flags & 524288) != 0);
+        if (!st) return VHAP_E_HIP;
+        vhap_zero_async(scratch_4_bytes, 4, st);
+        VHAP_LAUNCH_CHECK();
+    }
     return VHAP_OK;
 }
 

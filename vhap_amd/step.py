@@ -994,15 +994,20 @@ class NativeStep:
             if self.overlap:
                 torch.cuda.current_stream().wait_stream(self.side2)
         elif part == "geometry":
-            early = None
-            self._fork()
-            with self._branch():
+            # like part 'all': the early branch (landmarks, offset regularisers, the antialiasing's position part) is marked here but issued
+            # behind the G-buffer backward's launch, so that the plan executor keeps the G-buffer backward -- the chain the step waits for --
+            # on the LAUNCH stream and gives the side stream to the early branch (captured first, the early branch took the launch stream
+            # and the G-buffer backward a side stream shared with the pixel plan's texture chain: round 5)
+            self._early_ev = None
+
+            def early_branch():
                 self._bwd_early()
                 if self.overlap:
-                    early = torch.cuda.Event()
-                    early.record()
+                    self._early_ev = torch.cuda.Event()
+                    self._early_ev.record()
+            self._side(early_branch)
             self._bwd_uv()
-            self._bwd_geometry(early)
+            self._bwd_geometry(True, after_first=self._flush)
             if self.overlap:
                 torch.cuda.current_stream().wait_stream(self.side2)  # (the camera backward)
             self._join()

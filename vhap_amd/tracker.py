@@ -1097,9 +1097,10 @@ class CapturedPlan:
 
     MAX_STREAMS = 4
 
-    def __init__(self):
+    def __init__(self, side_base=0):
         self.g = torch.cuda.CUDAGraph(keep_graph=True)
         self.plan = None
+        self.side_base = int(side_base)      # the plan's side stream k = the thread's pool stream side_base + k (vhap_plan_set_side_base)
         self.fallback = os.environ.get("VHAP_EXECUTOR", "plan") == "graph"     # (A/B and debugging: the runtime's own graph launch)
 
     def capture(self, **kw):
@@ -1136,7 +1137,11 @@ class CapturedPlan:
             return
         L = _lib.lib()
         h = ctypes.c_void_p()
-        rc = L.vhap_plan_from_graph(self.g.raw_cuda_graph(), self.MAX_STREAMS, ctypes.byref(h))
+        _lib.check(L.vhap_plan_set_side_base(self.side_base), "vhap_plan_set_side_base")
+        try:
+            rc = L.vhap_plan_from_graph(self.g.raw_cuda_graph(), self.MAX_STREAMS, ctypes.byref(h))
+        finally:
+            L.vhap_plan_set_side_base(0)
         if rc == -5:                                               # VHAP_E_UNSUPPORTED
             import warnings
             warnings.warn("CapturedPlan: the captured step holds a node type the plan executor does not replay; using hipGraphLaunch")
@@ -1388,6 +1393,20 @@ class GraphedStep:
                     self.tex_strip = torch.zeros(self.tex_rows, T, 3, device=dev)        # reduce-scatter output: this rank's rows of the level-0 gradient
                     self._tex_gather = None
                     self.comm = _lib.private_stream("comm", dev)                         # carries the texture collective (see _replay)
+                if self.tex_sharded and ns.overlap:
+                    # the pixel plan leaves its texture chain running under the geometry plan: it takes the pool's SECOND side stream (the
+                    # geometry plan's one side chain takes the first); and the four streams the sharded loop keeps busy -- launch, two
+                    # side streams, communication -- are touched one after the other, which puts them on four different hardware
+                    # queues (HIP binds a stream to a queue at its first command, round-robin over GPU_MAX_HW_QUEUES = 4)
+                    self.gB = CapturedPlan(side_base=1)
+                    scratch = torch.zeros(4, dtype=torch.int32, device=dev)
+                    torch.cuda.synchronize(dev)
+                    with torch.cuda.stream(self.stream):
+                        scratch[:1].zero_()
+                    _lib.check(_lib.lib().vhap_plan_touch_side_streams(2, scratch[1:].data_ptr()), "vhap_plan_touch_side_streams")
+                    with torch.cuda.stream(self.comm):
+                        scratch[3:].zero_()
+                    torch.cuda.synchronize(dev)
                 with self.gF.capture(**cap):
                     ns.forward()
                 pool = self.gF.pool()
@@ -1598,6 +1617,9 @@ class GraphedStep:
         """The all-gather of the texture rows the last sharded step updated: the current stream waits for it (no-op otherwise).  Called at the
         head of the next replay and by join(): anything that reads tex_extra after a sharded step must come behind it."""
         works, self._tex_gather = getattr(self, "_tex_gather", None), None
+        if works == "comm":
+            torch.cuda.current_stream().wait_stream(self.comm)
+            return
         for w in works or ():
             w.wait()
 
@@ -1626,13 +1648,22 @@ class GraphedStep:
                     # the pixel chain on the launch stream; the texture gradient's tile accumulation + fold are the plan's open tail on its
                     # side stream.  The COMMUNICATION stream waits for that tail and carries the reduce-scatter; the launch stream goes on
                     # to the geometry plan at once: gradient accumulation, fold and collective run under the G-buffer backward
+                    # (the collective as a SYNCHRONOUS call with the communication stream current: c10d then issues it on that stream -- one
+                    # of ours, on a hardware queue of its own -- or, in builds that keep a stream of their own for it, hands over from / to it)
                     self.gB.replay(defer_join=True)
                     cur = torch.cuda.current_stream()
                     with torch.cuda.stream(self.comm):
                         self.gB.join()
-                        work = tr.dist.reduce_scatter_mean(self.ns.g["d_tex"][:n0], self.tex_strip.view(-1), async_op=True)
+                        work = tr.dist.reduce_scatter_mean(self.ns.g["d_tex"][:n0], self.tex_strip.view(-1), async_op=False)
                     self.gB2.replay()
-                    cur.wait_stream(self.comm)                             # (the plan's other side chain: lights gradient, delta clear)
+                    tr.dist.all_reduce_mean_(self.ns.param_grad_flat)
+                    cur.wait_stream(self.comm)                             # the reduce-scatter; and the plan's other side chain (lights gradient, delta clear)
+                    self.gA.replay()
+                    with torch.cuda.stream(self.comm):                     # the updated rows travel on the communication stream ...
+                        self.comm.wait_stream(cur)
+                        tr.dist.all_gather_rows(tr.tex_extra.detach(), self.tex_row0, self.tex_rows, async_op=False)
+                    self._tex_gather = "comm"                              # (... and the next replay's launch stream waits for it: wait_texture)
+                    return
                 else:
                     self.gB.replay()                                       # pixel chain + the complete texture gradient
                     work = tr.dist.reduce_scatter_mean(self.ns.g["d_tex"][:n0], self.tex_strip.view(-1), async_op=True)   # level 0, pyramid folded in
