@@ -292,7 +292,9 @@ def test_mip_level_offsets_closed_form_matches_the_table():
 
 def test_bench_supervisor_repeats_a_dead_child_and_relays_the_result_line(monkeypatch, capsys):
     """bench.py on one GPU runs its measurement in a child process: a child that dies without a result line is repeated, the first result
-    line is relayed unchanged, and the last attempt falls back to eager launches."""
+    line is relayed with what happened recorded IN it (`supervisor`: attempts, the child's exit code, the '--eager' fallback -- round-4
+    advisor: a crash in the captured path must not be replaced silently by an eager-mode number), and a child that printed its line and
+    then died makes the supervisor exit non-zero."""
     import subprocess
     import sys
     import types
@@ -310,4 +312,12 @@ def test_bench_supervisor_repeats_a_dead_child_and_relays_the_result_line(monkey
     monkeypatch.setattr(sys, "argv", ["bench.py", "--steps", "4"])
     assert bench._supervised() == 0
     assert len(calls) == 3 and calls[0][-2:] == ["--steps", "4"] and calls[2][-1] == "--eager" and "--eager" not in calls[1]
-    assert capsys.readouterr().out == '{"metric": "frames_per_s", "value": 1.0}\n'
+    import json
+    line = json.loads(capsys.readouterr().out)
+    assert line == {"metric": "frames_per_s", "value": 1.0, "supervisor": {"attempts": 3, "child_exit_code": 0, "fallback": "--eager"}}
+    calls.clear()
+    monkeypatch.setattr(subprocess, "run", lambda argv, env=None, stdout=None, text=None: types.SimpleNamespace(
+        returncode=-11, stdout='{"metric": "frames_per_s", "value": 2.0}\n'))
+    assert bench._supervised() == -11
+    line = json.loads(capsys.readouterr().out)
+    assert line["value"] == 2.0 and line["supervisor"] == {"attempts": 1, "child_exit_code": -11, "fallback": None}
