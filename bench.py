@@ -522,6 +522,7 @@ def main():
                                        f"{'; ONE rank forced through the sharded step (VHAP_FORCE_DIST=1)' if sharded and world == 1 else ''})"
                                        if sharded else "one GPU, one process"),
                        "sharded_step": bool(sharded), "tex_sharded": bool(getattr(step, "tex_sharded", False)) if step is not None else False,
+                       "tex_first": bool(getattr(step, "tex_first", False)) if step is not None else False,
                        "coverage": cov, "captured_step": step is not None, "unroll": per_call,
                        "deferred_join": bool(getattr(step, "defer_join", False)) if step is not None else False},
             "roofline": {"bound": "hbm", "achieved": alg / ri_step / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",

@@ -219,9 +219,10 @@ def test_bench_multi_rank_path_runs_under_torchrun_with_gloo():
     assert out["config"]["captured_step"] is True and out["value"] > 0 and np.isfinite(out["roofline"]["frac"])
 
 
-def _worker_rccl_one_rank(rank, world, port, T, ret, lr_scale, n_steps, tex_sharded):
+def _worker_rccl_one_rank(rank, world, port, T, ret, lr_scale, n_steps, tex_sharded, tex_first=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), VHAP_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0",
-                      VHAP_TEX_SHARDED="1" if tex_sharded else "0", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+                      VHAP_TEX_SHARDED="1" if tex_sharded else "0", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0",
+                      VHAP_SHARD_TEX_FIRST="1" if tex_first else "0")
     from vhap_amd import dist as vdist
     assert vdist.init_from_env("nccl") == (0, 1, 0)
     assert dist.is_initialized() and dist.get_backend() == "nccl" and dist.get_world_size() == 1
@@ -232,6 +233,7 @@ def _worker_rccl_one_rank(rank, world, port, T, ret, lr_scale, n_steps, tex_shar
     opt = tr.configure_optimizer(tr.get_train_parameters("rgb_global_tracking"), lr_scale=lr_scale)
     st = GraphedStep(tr, tr.get_sample(np.arange(4), device_index=True), opt, "rgb_global_tracking", warmup=0)
     assert st.ns is not None and not st.single and st.tex_sharded == tex_sharded and not st.ns.energy_fused
+    assert st.tex_path == tex_sharded and st.tex_first == (tex_sharded and tex_first)
     with st.replay_stream():
         E = [float(st()) for _ in range(n_steps)]
     torch.cuda.synchronize()
@@ -240,21 +242,23 @@ def _worker_rccl_one_rank(rank, world, port, T, ret, lr_scale, n_steps, tex_shar
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("tex_sharded", [True, False])
-def test_one_rank_rccl_sharded_step_matches_unsharded(tex_sharded):
+@pytest.mark.parametrize("tex_sharded,tex_first", [(True, False), (True, True), (False, False)])
+def test_one_rank_rccl_sharded_step_matches_unsharded(tex_sharded, tex_first):
     """The sharded step against REAL RCCL on the one GPU there is: a world-size-1 `nccl` group, VHAP_FORCE_DIST=1 --
     forward plan, scalar all-reduce, pixel + texture plan, asynchronous reduce_scatter_tensor(ReduceOp.AVG) of the folded level-0
     gradient, geometry plan under it, all_reduce(ReduceOp.AVG) of the arena, row finish + Adam, asynchronous all_gather_into_tensor
     waited at the head of the next replay -- must reproduce the one-plan step: energies of 3 steps, the last gradients, the fitted
     parameters.  (One rank: the collectives are identities, so what is compared is their placement, the asynchronous handles and the
-    four-plan form of the step, with the transport RCCL's.)  tex_sharded=False: the all-reduce + replicated finish fallback."""
+    four-plan form of the step, with the transport RCCL's.)  tex_sharded=False: the all-reduce + replicated finish fallback.  tex_first:
+    the geometry plan waits for the folded texture gradient and runs under the reduce-scatter (the 8-GPU ordering) instead of beside the
+    tile accumulation."""
     T = 128
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ret = mp.Manager().dict()
-    mp.spawn(_worker_rccl_one_rank, args=(1, port, T, ret, 0.1, 3, tex_sharded), nprocs=1, join=True)
+    mp.spawn(_worker_rccl_one_rank, args=(1, port, T, ret, 0.1, 3, tex_sharded, tex_first), nprocs=1, join=True)
     E_s, g_s, p_s = ret[0]
     tr = _build(T)
     from vhap_amd.tracker import GraphedStep

@@ -724,14 +724,16 @@ class NativeStep:
         _chk(self.L.vhap_texture_mip_fold_gather(_p(self.g["d_tex"][:n0]), _p(self.g["d_tex"][n0:]), self.T, self.T, 3, _stream()),
              "vhap_texture_mip_fold_gather")
 
-    def tex_finish_rows(self, optimizer, d_strip, row0, nrows):
+    def tex_finish_rows(self, optimizer, d_strip, row0, nrows, advanced=False):
         """tex_finish() + Adam on the row strip [row0, row0 + nrows) of the texture from `d_strip` [nrows, T, 3], this rank's slice of the
-        rank-averaged, folded level-0 gradient (frame sharding: vhap_tex_prep_bwd_adam_rows)."""
+        rank-averaged, folded level-0 gradient (frame sharding: vhap_tex_prep_bwd_adam_rows).  advanced: the step counter was advanced at
+        the head of the step (HipAdam.advance) -- this piece of the update may then run on any stream, before or after the others."""
         tr, T, g = self.tr, self.T, self.g
         m, v, lr, step, b1, b2, eps = optimizer.fused_update_args(tr.tex_extra)
         _chk(self.L.vhap_tex_prep_bwd_adam_rows(_p(self.albedo_tex), _p(tr.tex_extra), _p(self.nm["res_mask"]), _p(d_strip), _p(self.ones), T,
                                                 int(row0), int(nrows), *self.tex_scales, _p(g["tex_extra"]), _p(m), _p(v), _p(lr), _p(step),
-                                                b1, b2, eps, 0, _stream()), "vhap_tex_prep_bwd_adam_rows")
+                                                b1, b2, eps, _lib.CALL_ADAM_STEP_ADVANCED if advanced else 0, _stream()),
+             "vhap_tex_prep_bwd_adam_rows")
 
     def _bwd_early(self):
         """landmark and offset-regulariser gradients: they depend on nothing the pixel chain produces (pure launch latency)"""

@@ -1407,6 +1407,17 @@ class GraphedStep:
                     with torch.cuda.stream(self.comm):
                         scratch[3:].zero_()
                     torch.cuda.synchronize(dev)
+                # the texture's own path -- tile accumulation, fold, reduce-scatter, row finish + Adam, all-gather -- runs on the side / the
+                # communication stream from end to end; the step counter is advanced at the head of the step so that the two pieces of
+                # the Adam update (this rank's texture rows there, everything else on the launch stream) need no order between them
+                self.tex_path = bool(self.tex_sharded and ns.overlap and hasattr(optimizer, "advance"))
+                # texture first (8 GPUs: the exchange is the critical path -- reduce-scatter and all-gather are ~0.15 ms each on xGMI): the
+                # geometry plan starts when the gradient is folded and runs under the reduce-scatter, instead of sharing the chip with
+                # the tile accumulation (69 us alone, 174 us next to the G-buffer backward).  Default from the world size.
+                tf = os.environ.get("VHAP_SHARD_TEX_FIRST")
+                self.tex_first = self.tex_path and (world >= 4 if tf is None else tf == "1")
+                if self.tex_path:
+                    ns.step_optimizer = optimizer                   # (the forward's side branch issues optimizer.advance())
                 with self.gF.capture(**cap):
                     ns.forward()
                 pool = self.gF.pool()
@@ -1415,12 +1426,19 @@ class GraphedStep:
                     ns.backward(world, part="pixel_tex")
                 with self.gB2.capture(pool=pool, **cap):
                     ns.backward(world, part="geometry")
-                with self.gA.capture(pool=pool, **cap):
-                    if self.tex_sharded:
-                        ns.tex_finish_rows(optimizer, self.tex_strip, self.tex_row0, self.tex_rows)      # (reads the step counter + 1 ...)
-                        optimizer.step(skip=(tex,))                                                      # (... which this call then advances)
-                    else:
-                        optimizer.step()
+                if self.tex_path:
+                    self.gAt = CapturedPlan()
+                    with self.gAt.capture(pool=pool, **cap):
+                        ns.tex_finish_rows(optimizer, self.tex_strip, self.tex_row0, self.tex_rows, advanced=True)
+                    with self.gA.capture(pool=pool, **cap):
+                        optimizer.step(skip=(tex,), advanced=True)
+                else:
+                    with self.gA.capture(pool=pool, **cap):
+                        if self.tex_sharded:
+                            ns.tex_finish_rows(optimizer, self.tex_strip, self.tex_row0, self.tex_rows)      # (reads the step counter + 1 ...)
+                            optimizer.step(skip=(tex,))                                                      # (... which this call then advances)
+                        else:
+                            optimizer.step()
             # Step k+1 under step k's texture tail: inside replay_stream() the single-GPU plan is replayed WITHOUT joining its side
             # streams at the end -- what it leaves open (the texture gradient's sort, tile pass, finish + Adam on the side stream) keeps
             # running while the next replay's launch-stream kernels up to the rasteriser (camera, per-frame parameters, skinning, binning)
@@ -1644,25 +1662,30 @@ class GraphedStep:
             # the gradients sit in contiguous buffers: collectives straight on them (ReduceOp.AVG), no staging copies
             if getattr(self, "tex_sharded", False):
                 n0 = self.ns.albedo_tex.numel()
-                if self.ns.overlap and self.gB.plan is not None:
-                    # the pixel chain on the launch stream; the texture gradient's tile accumulation + fold are the plan's open tail on its
-                    # side stream.  The COMMUNICATION stream waits for that tail and carries the reduce-scatter; the launch stream goes on
-                    # to the geometry plan at once: gradient accumulation, fold and collective run under the G-buffer backward
-                    # (the collective as a SYNCHRONOUS call with the communication stream current: c10d then issues it on that stream -- one
-                    # of ours, on a hardware queue of its own -- or, in builds that keep a stream of their own for it, hands over from / to it)
+                if getattr(self, "tex_path", False) and self.gB.plan is not None:
+                    # The pixel chain on the launch stream; the texture gradient's tile accumulation + fold are the pixel plan's open tail
+                    # on a side stream.  The COMMUNICATION stream (one of ours, on a hardware queue of its own) waits for that tail and then
+                    # carries the texture's whole way home: reduce-scatter -> finish + Adam of this rank's rows -> all-gather.  The
+                    # collectives are SYNCHRONOUS calls with that stream current: c10d issues them on it (builds that keep a stream of
+                    # their own hand over from / to it).  The launch stream runs the geometry plan, the small all-reduce and the Adam
+                    # update of everything else meanwhile, and meets the texture again at the head of the next step (wait_texture).
                     self.gB.replay(defer_join=True)
                     cur = torch.cuda.current_stream()
+                    folded = torch.cuda.Event()
                     with torch.cuda.stream(self.comm):
-                        self.gB.join()
-                        work = tr.dist.reduce_scatter_mean(self.ns.g["d_tex"][:n0], self.tex_strip.view(-1), async_op=False)
+                        self.gB.join()                                     # the folded gradient; and the plan's other side chain (lights gradient, delta clear)
+                        folded.record()
+                        tr.dist.reduce_scatter_mean(self.ns.g["d_tex"][:n0], self.tex_strip.view(-1), async_op=False)
+                        self.gAt.replay()
+                        tr.dist.all_gather_rows(tr.tex_extra.detach(), self.tex_row0, self.tex_rows, async_op=False)
+                    if self.tex_first:
+                        cur.wait_event(folded)                             # geometry under the reduce-scatter, not beside the tile accumulation
                     self.gB2.replay()
                     tr.dist.all_reduce_mean_(self.ns.param_grad_flat)
-                    cur.wait_stream(self.comm)                             # the reduce-scatter; and the plan's other side chain (lights gradient, delta clear)
+                    if not self.tex_first:
+                        cur.wait_event(folded)
                     self.gA.replay()
-                    with torch.cuda.stream(self.comm):                     # the updated rows travel on the communication stream ...
-                        self.comm.wait_stream(cur)
-                        tr.dist.all_gather_rows(tr.tex_extra.detach(), self.tex_row0, self.tex_rows, async_op=False)
-                    self._tex_gather = "comm"                              # (... and the next replay's launch stream waits for it: wait_texture)
+                    self._tex_gather = "comm"                              # (the next replay's launch stream waits for the all-gather: wait_texture)
                     return
                 else:
                     self.gB.replay()                                       # pixel chain + the complete texture gradient
