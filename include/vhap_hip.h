@@ -763,6 +763,8 @@ int vhap_plan_node_name(vhap_plan_t plan, int node, char* buf, size_t cap);
  * on pool streams 0 .. n - 1 in order: HIP binds a stream to a hardware queue at its first command. */
 int vhap_plan_set_side_base(int base);
 int vhap_plan_touch_side_streams(int n, void* scratch_4_bytes);
+/* pool stream k waits for what is enqueued on `other` now (an external dependency of ONE side chain of the next replay) */
+int vhap_plan_side_stream_wait(int k, vhap_stream_t other);
 int vhap_plan_launch(vhap_plan_t plan, vhap_stream_t stream, int call_flags);
 int vhap_plan_join(vhap_plan_t plan, vhap_stream_t stream);
 /* the nodes a DEFER_JOIN replay leaves un-joined (indices into launch order, at most `cap` written); returns their number */

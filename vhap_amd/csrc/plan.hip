@@ -352,6 +352,21 @@ extern "C" int vhap_plan_set_side_base(int base) {
     return VHAP_OK;
 }
 
+// Pool stream k of this thread waits for everything enqueued on `other` so far -- and nothing else does.  The sharded step uses it at the
+// head of a replay: only the forward plan's texture chain (its first side stream) needs the all-gathered texture, the geometry head on the
+// launch stream starts under the transfer.
+extern "C" int vhap_plan_side_stream_wait(int k, vhap_stream_t other) {
+    VHAP_ENTER();
+    if (k < 0 || k > 8) return VHAP_E_BADDIM;
+    hipStream_t st = pool_stream(k, (vhap_g_debug_flags & 524288) != 0);
+    if (!st) return VHAP_E_HIP;
+    thread_local hipEvent_t ev = nullptr;
+    if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return VHAP_E_HIP;
+    if (hipEventRecord(ev, vhap_stream(other)) != hipSuccess) return VHAP_E_HIP;
+    if (hipStreamWaitEvent(st, ev, 0) != hipSuccess) return VHAP_E_HIP;
+    return VHAP_OK;
+}
+
 extern "C" int vhap_plan_touch_side_streams(int n, void* scratch_4_bytes) {
     VHAP_ENTER();
     if (!scratch_4_bytes) return VHAP_E_NULLPTR;

@@ -1643,6 +1643,13 @@ class GraphedStep:
 
     def _replay(self):
         tr = self.tr
+        if getattr(self, "_tex_gather", None) == "comm" and self._in_loop and self.gF.plan is not None and self.gF.side_base == 0 and \
+                os.environ.get("VHAP_SHARD_PRECISE_WAIT", "1") != "0":
+            # only the forward plan's TEXTURE CHAIN (a root of the plan on its first side stream: assembly + pyramid, then the arena clear and
+            # the step counter behind it) needs the all-gathered texture: that stream waits for the communication stream, the launch stream's
+            # geometry head (per-frame stage, skinning, binning) starts under the transfer
+            _lib.check(_lib.lib().vhap_plan_side_stream_wait(0, self.comm.cuda_stream), "vhap_plan_side_stream_wait")
+            self._tex_gather = None
         self.wait_texture()
         if self.ns is not None and self.single:
             self.gF.replay(defer_join=self.defer_join and self._in_loop)
