@@ -1,16 +1,18 @@
 """Frame-sharded data parallelism for the photometric fit (new in this build: the reference is
 single-process, single-GPU -- SURVEY.md section 2 rows 16-17, section 8(e)).
 
-One process per GPU.  Every rank holds a replica of all parameters and optimiser state and works on
-a contiguous slice of the frame batch (monocular: frames; NeRSemble: views).  Per Adam step:
-  1. one scalar all-reduce for the batch-global photometric normaliser #(alpha > 0)
-     (tracker.py:439 divides by the count over the WHOLE batch), issued before backward;
-  2. ONE all-reduce (average) of a flat bucket holding every trained gradient -- tex_extra
-     (50.3 MB at T=2048) dominates, static_offset / shape / lights / focal / per-frame rows ride along.
-The per-rank energy is defined so that its mean over ranks equals the single-GPU energy (equal
-shards): batch means become local means, the photometric numerator is multiplied by world_size
-through the normaliser.  Replicas stay bit-identical because every rank applies the same averaged
-gradient with the same Adam state.  The colour disturbance draws its pools from the local shard only.
+One process per GPU.  Every rank holds a replica of all parameters and works on a contiguous slice of the frame batch (monocular:
+frames; NeRSemble: views).  Per Adam step of the captured step (tracker.GraphedStep):
+  1. one scalar all-reduce for the batch-global photometric normaliser #(alpha > 0) (tracker.py:439 divides by the count over the
+     WHOLE batch), between the forward and the backward plan;
+  2. the texture gradient (50.3 MB at T = 2048): reduce-scatter (ReduceOp.AVG) of its folded level 0 -> each rank finishes and
+     Adam-updates ITS rows with its slice of the optimiser state -> all-gather of the updated rows; all three on a communication
+     stream of the step's own, beside the geometry backward (all-reduce + replicated update as the fallback: VHAP_TEX_SHARDED=0);
+  3. one small all-reduce (average) of the arena slice holding every other trained gradient (~90 KB).
+The eager `optimize_iter` averages one flat bucket of all gradients instead (`average_gradients`).
+The per-rank energy is defined so that its mean over ranks equals the single-GPU energy (equal shards): batch means become local
+means, the photometric numerator is multiplied by world_size through the normaliser.  Replicas stay bit-identical because every rank
+applies the same averaged gradient with the same Adam state.  The colour disturbance draws its pools from the local shard only.
 Backend: 'nccl' (= RCCL over xGMI on ROCm) on GPUs, 'gloo' in the CPU tests.
 """
 import os
