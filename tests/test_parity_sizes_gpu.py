@@ -144,7 +144,7 @@ def _native_vs_oracle(tr, cfg, topo, tm, base_tex, sample, o_sample, stage, imag
     return fails
 
 
-def run_config2(flame_model, B, record):
+def run_config2(flame_model, B, record, spread=True):
     """BASELINE config 2 at batch B (tests/test_parity_fullbatch_gpu.py runs B = 16, the batch BASELINE names)."""
     H = W = 512
     S = _make(flame_model, H, W, B, T, seed=17)
@@ -154,7 +154,7 @@ def run_config2(flame_model, B, record):
     o_sample = {"rgb": sample["rgb"].cpu(), "lmk2d": sample["lmk2d"].cpu(), "timestep_index": ts}
     lines = []
     fails = _native_vs_oracle(tr, S["cfg"], S["topo"], S["tm"], S["base_tex"], sample, o_sample, "rgb_global_tracking", (H, W), NAMES, lines,
-                              "cfg2", seed=12)
+                              "cfg2", seed=12, spread=spread)
     _record(record, lines + fails)
     assert not fails, fails
 
@@ -163,7 +163,7 @@ def test_shipped_native_step_with_injected_disturbance_config2_size(flame_model)
     run_config2(flame_model, 2, "parity_native_injected_cfg2.txt")
 
 
-def run_config3(flame_model, B, record):
+def run_config3(flame_model, B, record, spread=True):
     """BASELINE config 3: 1024 x 1024 with static_offset trained (stage rgb_init_offset: the offset regularisers, the full learning-rate
     stage) at batch B (the oracle needs ~20 s per megapixel)."""
     H = W = 1024
@@ -174,7 +174,7 @@ def run_config3(flame_model, B, record):
     o_sample = {"rgb": sample["rgb"].cpu(), "lmk2d": sample["lmk2d"].cpu(), "timestep_index": ts}
     lines = []
     fails = _native_vs_oracle(tr, S["cfg"], S["topo"], S["tm"], S["base_tex"], sample, o_sample, "rgb_init_offset", (H, W), NAMES, lines,
-                              "cfg3", seed=5, grad_bound=3e-3)
+                              "cfg3", seed=5, grad_bound=3e-3, spread=spread)
     _record(record, lines + fails)
     assert not fails, fails
 
@@ -183,7 +183,7 @@ def test_shipped_native_step_config3_size_static_offset_trained(flame_model):
     run_config3(flame_model, 1, "parity_native_injected_cfg3.txt")
 
 
-def run_config4(flame_model, NV, record):
+def run_config4(flame_model, NV, record, spread=True):
     """BASELINE config 4: calibrated views (K [B,3,3], RT [B,3,4]) of ONE timestep at 802 x 550 under the NeRSemble configuration
     (w.landmark 3, reg_tex_tv 1e5, jawline landmarks off): NV views on the arc of vhap_amd.synthetic.arc_cameras."""
     from vhap_amd.config import nersemble_config
@@ -219,7 +219,7 @@ def run_config4(flame_model, NV, record):
     names = [n for n in NAMES if n != "focal_length"]
     lines = []
     fails = _native_vs_oracle(tr, cfg, topo, tm, torch.from_numpy(base_tex)[None].double(), sample, o_sample, "rgb_global_tracking", (H, W),
-                              names, lines, "cfg4", seed=21, grad_bound=3e-3)
+                              names, lines, "cfg4", seed=21, grad_bound=3e-3, spread=spread)
     _record(record, lines + fails)
     assert not fails, fails
 
