@@ -217,9 +217,11 @@ class AccessLog:
             self._cur.append((t.data_ptr(), t.numel() * t.element_size()))
 
     def close(self, what):
-        ranges = self._cur if self._cur is not None else []
+        # a call that handed over no recorded pointer (raw data_ptr() arguments, or none at all) cannot vouch for the nodes that appeared
+        # since the last look: they stay UNKNOWN (None) -- a plan with an unknown node among its open tails or free heads does not defer
+        owner = (what, self._cur) if self._cur is not None else None
         for h in self._new_nodes():
-            self.owner[h] = (what, ranges)
+            self.owner[h] = owner
         self._cur = None
 
     def ranges_of_node(self, handle):

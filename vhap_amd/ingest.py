@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .ops import _stream
+from .ops import _p, _stream
 
 BG_MODES = {None: 0, "white": 1, "black": 2}
 
@@ -53,9 +53,10 @@ class FrameStore:
             alpha_out = torch.empty(B, 1, H, W, dtype=torch.float32, device=self.rgb.device)
         assert out.is_contiguous() and tuple(out.shape) == (B, 3, H, W) and out.dtype == torch.float32
         assert alpha_out is None or (alpha_out.is_contiguous() and tuple(alpha_out.shape) == (B, 1, H, W))
+        # (pointers through ops._p: a step capture records which buffers each of its calls touches -- _lib.AccessLog -- and a call that
+        # hands over raw addresses leaves its node UNKNOWN, which keeps a plan from deferring its join)
         _lib.check(_lib.lib().vhap_frame_ingest(
-            self.rgb.data_ptr(), 0 if self.alpha is None else self.alpha.data_ptr(), 0 if idx is None else idx.data_ptr(), N, B, H, W,
-            BG_MODES[self.background_color], out.data_ptr(), 0 if alpha_out is None else alpha_out.data_ptr(), self._bad.data_ptr(),
+            _p(self.rgb), _p(self.alpha), _p(idx), N, B, H, W, BG_MODES[self.background_color], _p(out), _p(alpha_out), _p(self._bad),
             _stream()), "vhap_frame_ingest")
         if check and int(self._bad.item()):
             self._bad.zero_()

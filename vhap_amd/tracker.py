@@ -1546,7 +1546,10 @@ class GraphedStep:
             if frame_index_dev is None:
                 timestep_dev = torch.as_tensor(np.asarray(timesteps).reshape(-1), device=dev) if not torch.is_tensor(timesteps) else timesteps
                 if tr._frames_of is not None:
-                    fidx = np.concatenate([tr._frames_of[int(t)] for t in np.asarray(timestep_dev.cpu()).reshape(-1)])
+                    # (multi-view: every view of the DISTINCT timesteps, in order -- a per-frame timestep list, e.g. a sample's own
+                    # `timestep_index`, names each timestep once per view)
+                    uniq = list(dict.fromkeys(int(t) for t in np.asarray(timestep_dev.cpu()).reshape(-1)))
+                    fidx = np.concatenate([tr._frames_of[t] for t in uniq])
                     frame_index_dev = torch.as_tensor(fidx, device=dev)
                     timestep_dev = torch.as_tensor(tr.frame_timestep[fidx], device=dev)
                 else:
