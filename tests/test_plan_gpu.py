@@ -235,6 +235,12 @@ def test_multiview_stage_loop_self_feeding_step_matches_host_fed(flame_model, mo
         assert st.single and (st.feed is not None) == feed and tr.global_step == 3 * NT
         if feed:
             assert st.ns.calibrated and st.feed["n"] == NV
+            # a full SAMPLE handed to a self-feeding step (update_sample): its `timestep_index` names the timestep once per VIEW -- the table
+            # must hold that timestep's views once, not once per entry (round-4 advisor finding)
+            st.update_sample(tr.get_sample(np.array([2]), device_index=True))
+            torch.cuda.synchronize()
+            assert st.feed["cursor"].cpu().tolist() == [0, 1]
+            assert st.feed["frames"][:NV].cpu().tolist() == list(tr._frames_of[2]) and st.feed["ts"][:NV].cpu().tolist() == [2] * NV
         return start, {k: getattr(tr, k).detach().cpu().numpy().copy() for k in start}
 
     try:
