@@ -214,7 +214,11 @@ class AccessLog:
                 self.owner[h] = None
             self._cur = []
         if t.numel():
-            self._cur.append((t.data_ptr(), t.numel() * t.element_size()))
+            if t.is_contiguous():
+                self._cur.append((t.data_ptr(), t.numel() * t.element_size()))
+            else:                     # a strided view: numel * element_size under-reports what a kernel may touch -- its whole storage, conservatively
+                st = t.untyped_storage()
+                self._cur.append((st.data_ptr(), st.nbytes()))
 
     def close(self, what):
         # a call that handed over no recorded pointer (raw data_ptr() arguments, or none at all) cannot vouch for the nodes that appeared
