@@ -1703,6 +1703,8 @@ class GraphedStep:
                     self.gB2.replay()                                      # geometry chain: runs under the texture collective
                 tr.dist.all_reduce_mean_(self.ns.param_grad_flat)
                 work.wait()
+                if getattr(self, "tex_path", False):                       # (captured as a plan of its own, replayed here when the executor is not in use)
+                    self.gAt.replay()
                 self.gA.replay()                                           # this rank's rows of the texture + every other parameter
                 # the updated rows travel while the host comes round to the next step (whose forward waits: wait_texture)
                 self._tex_gather = tr.dist.all_gather_rows(tr.tex_extra.detach(), self.tex_row0, self.tex_rows, async_op=True)
