@@ -54,7 +54,6 @@ def run(tag, NV=2, H=802, W=550, mutate=None, deferred=True):
     ns.backward(1)
     torch.cuda.synchronize()
     tid = (ns.rast[..., 3].long() - 1).cpu()
-    pred = ns.rgba_aa if ns.aa_inplace or True else None
     res_hip = (ns.rgba_aa[..., :3].detach().flip(1) - sample["rgb"].permute(0, 2, 3, 1)).cpu()
     g_n = {k: ns.g[k].detach().cpu().double().reshape(-1) for k in names if k in ns.g}
     uvm = tr._uvmask_res().cpu()
