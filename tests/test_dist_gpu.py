@@ -318,3 +318,47 @@ def test_bench_one_rank_forced_through_rccl(monkeypatch):
     out, _ = _run_bench(["--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-parity", "--no-stage"])
     assert out["n_gpus"] == 1 and out["config"]["sharded_step"] is True and out["config"]["tex_sharded"] is True
     assert "RCCL" in out["config"]["parallelism"] and out["value"] > 0
+
+
+def _diffuse_terms(tr, frames):
+    from vhap_amd.tracker import GraphedStep
+    with torch.no_grad():
+        tr.lights[0] += 0.6                                        # max(diffuse) > 1: the relu branch of reg_diffuse is ACTIVE
+        tr.lights[1:4] += torch.tensor([[0.5, 0.3, 0.2], [-0.4, 0.2, 0.5], [0.3, -0.5, 0.4]], device=tr.lights.device)   # directional + tinted: the
+        # maximum sits on the head (the background shades the constant band only) and depends on the poses of the shard's frames
+    stage = "rgb_global_tracking"
+    opt = tr.configure_optimizer(tr.get_train_parameters(stage), lr_scale=0.0)
+    st = GraphedStep(tr, tr.get_sample(np.asarray(frames), device_index=True), opt, stage, warmup=0)
+    assert st.ns is not None and st.ns.want_reg
+    st()
+    torch.cuda.synchronize()
+    return {k: float(v) for k, v in st.log_dict.items()}
+
+
+def _worker_diffuse(rank, world, port, T, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vhap_amd import dist as vdist
+    tr = _build(T)
+    vdist.attach(tr)
+    ret[rank] = _diffuse_terms(tr, [0, 1] if rank == 0 else [2, 3])
+    dist.destroy_process_group()
+
+
+def test_two_rank_reg_diffuse_is_the_per_shard_term():
+    """The DOCUMENTED semantics of the one term that is not a sum over frames: reg_diffuse =
+    w (relu(max(diffuse) - 1) + mean variance) takes its maximum over the frames of the RANK'S SHARD.  With the relu branch active
+    (lights boosted), each rank's reg_diffuse term equals the single-process term of the step run on that rank's frames alone, and the
+    two ranks' terms differ -- i.e. the test would notice a batch-global maximum."""
+    T = 128
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ret = mp.Manager().dict()
+    mp.spawn(_worker_diffuse, args=(2, port, T, ret), nprocs=2, join=True)
+    alone = [_diffuse_terms(_build(T), fr) for fr in ([0, 1], [2, 3])]
+    for r in range(2):
+        a, b = ret[r]["reg_diffuse"], alone[r]["reg_diffuse"]
+        assert b > 0 and abs(a - b) <= 1e-6 * abs(b), (r, a, b)
+    assert abs(alone[0]["reg_diffuse"] - alone[1]["reg_diffuse"]) > 1e-4 * abs(alone[0]["reg_diffuse"]), alone
