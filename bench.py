@@ -361,7 +361,10 @@ def time_ri_isolated(tr, sample, C, stream):
         torch.cuda.synchronize()
         from vhap_amd.tracker import CapturedPlan
         g = CapturedPlan()
-        with g.capture(stream=stream):
+        # (with a process group alive its helper threads -- RCCL watchdog, heartbeat -- issue runtime calls of their own: keep those from
+        # invalidating this thread's capture, as GraphedStep does)
+        cap = dict(capture_error_mode="thread_local") if (torch.distributed.is_available() and torch.distributed.is_initialized()) else {}
+        with g.capture(stream=stream, **cap):
             for _ in range(NREP):
                 ops.raster_interp_fwd(tr.render.glctx, pos, tri, vn, tr._verts_uv_flipped, tri_uv, (H, W))
         ms = []
