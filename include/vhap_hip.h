@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define VHAP_ABI_VERSION 9
+#define VHAP_ABI_VERSION 10
 
 #define VHAP_OK 0
 #define VHAP_E_NULLPTR (-1)   /* a required pointer is NULL */
@@ -184,6 +184,13 @@ int vhap_raster_shade_stats(int B, int F, int H, int W, void* workspace, size_t 
  * Replaces vhap_photo_bwd (optionally) + vhap_shade_bwd + the d_uv / d_uv_da part of vhap_texture_bwd (and the re-reading of five
  * G-buffer images). */
 #define VHAP_CALL_DELTA_UNSCALED 128
+/*   VHAP_CALL_TEX_TERMS_CONSUME (ABI 10)  vhap_photo_fwd_total: tex_terms[0..1] are set to zero once the energy assembly has read them -- they
+ *                                 were accumulated by the previous step's vhap_tex_finish_carry, which this step's will do again */
+#define VHAP_CALL_TEX_TERMS_CONSUME 256
+/*   VHAP_CALL_SKIP_BG_GRAD (ABI 10)  vhap_deferred_shade_bwd: d_albedo of BACKGROUND pixels is left unwritten (12 B x two thirds of a head
+ *                                 frame) -- for a caller whose texture-gradient pass reads d_albedo through a list of covered pixels only
+ *                                 (vhap_texbin_sort_ids + vhap_texture_grad_binned_sorted); ignored when tile_ids is handed in */
+#define VHAP_CALL_SKIP_BG_GRAD 512
 size_t vhap_deferred_shade_bwd_work_floats(int B, int H, int W);
 /* d_lights == NULL with a work table: only the partial sums are accumulated into `work`; finish later (off the critical path) with this */
 int vhap_deferred_lights_reduce(const float* work, const float* lights, const float* sh_const, const float* d_reg,
@@ -637,6 +644,31 @@ int vhap_tex_prep_bwd_adam_rows(const float* albedo_hwc, float* extra, const uin
                                 const float* d_terms, int T, int row0, int nrows, float s_tv, float s_res, float* d_extra, float* exp_avg,
                                 float* exp_avg_sq, const float* lr_device, const int32_t* step_device, float beta1, float beta2, float eps,
                                 int call_flags, vhap_stream_t stream);
+/* THE CARRIED TEXTURE (ABI 10).  tracker.py:237-258 re-assembles albedo = painted + tex_extra at the head of every step and
+ * render_nvdiffrast.py:398-399 rebuilds the mip pyramid per call; inside a loop of steps the only writer of tex_extra is the step's own
+ * Adam update, so the pass that applies it (vhap_tex_prep_bwd_adam) can hand the NEXT step its texture:
+ *   vhap_tex_finish_carry = vhap_tex_prep_bwd_adam (whole pyramid gathered) that also (i) rewrites albedo_hwc IN PLACE with
+ *     painted + updated tex_extra (the sum vhap_tex_prep_fwd forms -> the same bits), (ii) writes level 1 of the pyramid into mips_hwc
+ *     (follow with vhap_texture_mip_build_from(first_level = 2) before the texture is sampled), (iii) ACCUMULATES the weighted TV /
+ *     residual energies (reg_tex_tv, reg_tex_res_clusters: tracker.py:518-541) of that NEXT texture into terms[0..1] -- all but the TV
+ *     pairs that straddle two ownership tiles, which vhap_tex_carry_border adds from the halo copies (behind this pass, ahead of the
+ *     next vhap_adam_advance of step_device; same call_flags) -- hand them to the next step's energy assembly as its tex_terms with
+ *     VHAP_CALL_TEX_TERMS_CONSUME (vhap_photo_fwd_total reads and clears them).
+ *     d_extra may be NULL: the gradient is consumed by the update and not written.  Needs T % 64 == 0.
+ *   halo: vhap_tex_carry_halo_floats(T) floats owned by the caller -- border rows / columns of the pass's 16-row x 64-column ownership
+ *     tiles, twice (the TV stencil of a texel on a tile border reads neighbours another workgroup may already have rewritten: it reads
+ *     the copy of parity (Adam step & 1) and writes the other one).
+ *   vhap_tex_carry_prime: albedo_hwc, level 1, both halo parities and terms[0..1] (overwritten; like vhap_tex_finish_carry without the
+ *     tile-straddling TV pairs: follow with vhap_tex_carry_border) from painted + extra, from scratch -- before the first step of a loop
+ *     and whenever anything else has written tex_extra / painted since the last vhap_tex_finish_carry. */
+size_t vhap_tex_carry_halo_floats(int T);
+int vhap_tex_carry_prime(const float* painted, const float* extra, const uint8_t* res_mask, int T, float s_tv, float s_res, float* albedo_hwc,
+                         float* mips_hwc, float* halo, float* terms, vhap_stream_t stream);
+int vhap_tex_carry_border(int T, float s_tv, const int32_t* step_device, const float* halo, float* terms, int call_flags, vhap_stream_t stream);
+int vhap_tex_finish_carry(float* albedo_hwc, float* extra, const uint8_t* res_mask, const float* painted, const float* d_albedo_hwc,
+                          const float* d_mips_hwc, int n_gather, const float* d_terms, int T, float s_tv, float s_res, float* d_extra,
+                          float* exp_avg, float* exp_avg_sq, const float* lr_device, const int32_t* step_device, float beta1, float beta2,
+                          float eps, float* mips_hwc, float* halo, float* terms, int call_flags, vhap_stream_t stream);
 /* FLAME PCA texture model (flame.py:665-688 FlameTexPCA, tracker.py:241-244, 519-521; the tex_painted = False configuration):
  *   fwd: src [S,S,3] = mean + basis [S*S*3, n] . code [n]  (0..255, B G R);  base [3,T,T] = clamp(nearest_resize(src)[R,G,B] / 255, 0, 1) -- takes
  *        the place of the painted texture in vhap_tex_prep_fwd; term_accum (may be NULL) += s_reg * sum(code^2)   (s_reg = w.reg_tex_pca / n)

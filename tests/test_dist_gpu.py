@@ -78,7 +78,11 @@ def _step(tr, frames, stage="rgb_global_tracking", shard=None, lr_scale=0.0, n_s
     sample = tr.get_sample(np.asarray(frames), device_index=True)
     if shard is not None:                                          # this rank's slice of the views of the timestep
         sample = {k: (v[shard] if torch.is_tensor(v) else v) for k, v in sample.items()}
-    st = GraphedStep(tr, sample, opt, stage, warmup=0)
+    os.environ["VHAP_TEX_KEEP_GRAD"] = "1"                         # (the carried texture's finish pass consumes the gradient unless asked: it is compared below)
+    try:
+        st = GraphedStep(tr, sample, opt, stage, warmup=0)
+    finally:
+        os.environ.pop("VHAP_TEX_KEEP_GRAD", None)
     assert st.ns is not None, "the sharded step must run through NativeStep"
     E = float(st())
     for _ in range(n_steps - 1):
@@ -260,27 +264,52 @@ def test_one_rank_rccl_sharded_step_matches_unsharded(tex_sharded, tex_first):
     ret = mp.Manager().dict()
     mp.spawn(_worker_rccl_one_rank, args=(1, port, T, ret, 0.1, 3, tex_sharded, tex_first), nprocs=1, join=True)
     E_s, g_s, p_s = ret[0]
-    tr = _build(T)
     from vhap_amd.tracker import GraphedStep
-    opt = tr.configure_optimizer(tr.get_train_parameters("rgb_global_tracking"), lr_scale=0.1)
-    st = GraphedStep(tr, tr.get_sample(np.arange(4), device_index=True), opt, "rgb_global_tracking", warmup=0)
-    assert st.single
-    with st.replay_stream():
-        E_1 = [float(st()) for _ in range(3)]
-    torch.cuda.synchronize()
+
+    def one_plan():
+        tr = _build(T)
+        opt = tr.configure_optimizer(tr.get_train_parameters("rgb_global_tracking"), lr_scale=0.1)
+        st = GraphedStep(tr, tr.get_sample(np.arange(4), device_index=True), opt, "rgb_global_tracking", warmup=0)
+        assert st.single
+        with st.replay_stream():
+            E = [float(st()) for _ in range(3)]
+        torch.cuda.synchronize()
+        return E, tr
+    E_1, tr = one_plan()
+    E_2, tr2 = one_plan()                                  # the one-plan step against itself: the noise floor (atomics order -> Adam)
     start = _build(T)
-    for a, b in zip(E_s, E_1):
-        assert abs(a - b) <= 2e-5 * abs(b), (E_s, E_1)
+    # With one rank the collectives are identities: what differs between the two forms is the order of atomic additions (and the fold +
+    # strip finish instead of the gathered finish).  The bounds are 3 x the measured spread of the one-plan step against ITSELF, with floors
+    # at what that spread has been seen at (round-5 review, weak 3: 2e-3 / 30 % of the update would not notice a wrong bias correction
+    # on a small group); the measured numbers go on record (profiles/r06_dist_one_rank_rccl_*.txt: energies 8e-8, gradients <= 3e-6,
+    # parameters <= 6e-5 of the update, the one-plan step against itself the same).
+    lines = [f"one-rank RCCL sharded step (tex_sharded={tex_sharded}, tex_first={tex_first}) vs the one-plan step, T = {T}, 3 steps"]
+    fails = []
+    for i, (a, b, c) in enumerate(zip(E_s, E_1, E_2)):
+        e, floor = abs(a - b) / abs(b), abs(c - b) / abs(b)
+        lines.append(f"energy step {i}: sharded vs one-plan {e:.2e}   one-plan vs one-plan {floor:.2e}")
+        if e > max(3 * floor, 1e-6):
+            fails.append(f"energy step {i}: {e:.2e} (floor {floor:.2e})")
     for k in NAMES:
-        g1 = getattr(tr, k).grad
+        g1, g2 = getattr(tr, k).grad, getattr(tr2, k).grad
         if g1 is None or float(g1.abs().max()) == 0:
             continue
-        rel = float((g_s[k] - g1.cpu()).abs().max() / g1.abs().max())
-        assert rel < 2e-3, f"grad {k}: sharded (RCCL, one rank) vs one-plan step {rel:.3e}"
-        moved = float((getattr(tr, k).detach().cpu() - getattr(start, k).detach().cpu()).abs().max())
+        nrm = float(g1.abs().max())
+        rel, floor = float((g_s[k] - g1.cpu()).abs().max()) / nrm, float((g2 - g1).abs().max()) / nrm
+        lines.append(f"grad {k}: sharded vs one-plan {rel:.2e}   one-plan vs one-plan {floor:.2e}")
+        if rel > max(3 * floor, 2e-5):
+            fails.append(f"grad {k}: {rel:.2e} (floor {floor:.2e})")
+    for k in NAMES:
+        p1, p2, p0 = getattr(tr, k).detach().cpu(), getattr(tr2, k).detach().cpu(), getattr(start, k).detach().cpu()
+        moved = float((p1 - p0).abs().max())
         if moved:
-            relp = float((p_s[k] - getattr(tr, k).detach().cpu()).abs().max()) / moved
-            assert relp < (2e-2 if k == "tex_extra" else 0.3), f"{k}: {relp:.3e} of the update"
+            relp, floor = float((p_s[k] - p1).abs().max()) / moved, float((p2 - p1).abs().max()) / moved
+            lines.append(f"{k}: sharded vs one-plan {relp:.2e} of the update   one-plan vs one-plan {floor:.2e}")
+            if relp > max(3 * floor, 3e-4):
+                fails.append(f"{k}: {relp:.2e} of the update (floor {floor:.2e})")
+    from tests.test_fit_parity_gpu import _record
+    _record(f"dist_one_rank_rccl_{int(tex_sharded)}{int(tex_first)}.txt", lines + fails)
+    assert not fails, (fails, lines)
 
 
 def _run_bench(extra, timeout=900):
@@ -310,6 +339,17 @@ def test_bench_config5_independent_subjects():
     out, _ = _run_bench(["--gpus", "2", "--steps", "4", "--warmup", "2", "--backend", "gloo", "--config", "5", "--no-cpu-baseline"])
     assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["config"]["global_batch"] == 32
     assert out["config"]["sharded_step"] is False and "independent replicas" in out["config"]["parallelism"] and out["value"] > 0
+
+
+def test_bench_config4_views_sharded_over_two_ranks():
+    """BASELINE config 4 as BASELINE.json defines it -- the 16 calibrated views of one timestep sharded over the ranks (strong scaling), the
+    gradients of the shared parameters all-reduced -- through bench.py's own launcher (round-5 review, missing 5: the multi-rank bench legs
+    in the suite were configs 2 and 5 only)."""
+    out, _ = _run_bench(["--gpus", "2", "--config", "4", "--scaling", "strong", "--steps", "4", "--warmup", "2", "--backend", "gloo",
+                         "--no-cpu-baseline"])
+    assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["scaling"] == "strong"
+    assert out["config"]["global_batch"] == 16 and out["config"]["frames_per_gpu"] == 8 and out["config"]["sharded_step"] is True
+    assert "802" in out["config"]["workload"] and out["config"]["captured_step"] is True and out["value"] > 0
 
 
 def test_bench_one_rank_forced_through_rccl(monkeypatch):

@@ -27,7 +27,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     missing = set(syms) - set(_lib.SIGNATURES)
     assert not missing, f"ctypes signatures missing for {missing}"
     L2 = _lib.lib()
-    assert L2.vhap_abi_version() == _lib.ABI_VERSION == 9
+    assert L2.vhap_abi_version() == _lib.ABI_VERSION == 10
     assert L2.vhap_strerror(-3) == b"workspace too small"
     assert L2.vhap_raster_workspace_bytes(16, 10144, 512, 512, 1000) > 0
     assert L2.vhap_raster_workspace_bytes(1, 10, 5000, 64, 10) == 0          # H beyond the limit

@@ -1,8 +1,8 @@
 """Performance guards ("tests never assert performance -- nothing fails if raster_kernel<1> regresses to 120 us").
-Deliberately loose -- boxes differ by +-8 % and the suite shares a host with other jobs -- but tight enough to catch the kind of
-regression a kernel redesign produces: the round-4 rasteriser experiments that were reverted measured 100-125 us for the pass
-(fraction 0.29-0.36 -> the guard at 0.30 catches the worse half), and a step that loses its deferred join or its plan executor lands
-at 0.95-1.05 ms."""
+Boxes differ by +-4 % and the suite shares a host with other jobs, so each guard takes the best of several measurements and sits just
+under the worst box on record: isolated RI-fwd 0.36-0.41 of the peak over rounds 3-6 (guard 0.36: a 10 % slower kernel fails on every
+box), the captured step 0.86-0.90 ms (guard 0.95 ms: a step that loses its deferred join, its plan executor or the carried texture
+lands at 0.93-1.05 ms).  Round-5 review, weak 11: the first version (0.30 / 1.10 ms) let a 20 % regression through."""
 import importlib.util
 import os
 
@@ -27,19 +27,19 @@ def bench_state():
 
 
 def test_ri_fwd_pass_isolated_fraction_of_hbm_peak(bench_state):
-    """bin_build + raster_kernel<1> (vhap_raster_interp_fwd) alone on the chip at 16 x 512^2: >= 0.30 of 8 TB/s against the 292 MB of
-    SURVEY 8(d) (measured 0.36-0.41 over rounds 3-5)."""
+    """bin_build + raster_kernel<1> (vhap_raster_interp_fwd) alone on the chip at 16 x 512^2: >= 0.36 of 8 TB/s against the 292 MB of
+    SURVEY 8(d) (measured 0.36-0.41 over rounds 3-6)."""
     bench, C, tr, opt, sample = bench_state
     best = 0.0
-    for _ in range(3):                                         # (the best of three: the guard is about the kernel, not about the neighbours)
+    for _ in range(5):                                         # (the best of five: the guard is about the kernel, not about the neighbours)
         t, cov = bench.time_ri_isolated(tr, sample, C, torch.cuda.Stream())
         best = max(best, bench.ri_alg_bytes_per_frame(C["H"], C["W"]) * C["B"] / t / bench.HBM_PEAK)
     assert 0.2 < cov < 0.4
-    assert best >= 0.30, f"RI-fwd isolated: {best:.3f} of the HBM peak"
+    assert best >= 0.36, f"RI-fwd isolated: {best:.3f} of the HBM peak"
 
 
 def test_captured_step_time_at_the_quoted_config(bench_state):
-    """One optimiser step (fwd + bwd + Adam, disturbance on) of BASELINE config 2 as bench.py times it: <= 1.10 ms (measured 0.87-0.90)."""
+    """One optimiser step (fwd + bwd + Adam, disturbance on) of BASELINE config 2 as bench.py times it: <= 0.95 ms (measured 0.86-0.90)."""
     import time
     from vhap_amd.tracker import GraphedStep
     bench, C, tr, opt, sample = bench_state
@@ -49,11 +49,11 @@ def test_captured_step_time_at_the_quoted_config(bench_state):
     with step.replay_stream():
         for _ in range(20):
             step()
-        for _ in range(3):
+        for _ in range(5):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(100):
                 step()
             torch.cuda.synchronize()
             best = min(best, (time.perf_counter() - t0) / 100)
-    assert best <= 1.10e-3, f"{best * 1e3:.3f} ms per step"
+    assert best <= 0.95e-3, f"{best * 1e3:.3f} ms per step"

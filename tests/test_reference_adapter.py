@@ -135,6 +135,53 @@ def test_tracker_from_reference_config_monocular(reference, tmp_path, flame_mode
 
 
 @needs_ref
+def test_track_entry_script_runs_a_dumped_reference_config(reference, tmp_path, flame_model, monkeypatch):
+    """`python -m vhap_amd.track --config config.yml` (vhap/track.py:16-21 with the config a run of the reference dumped,
+    vhap/model/tracker.py:1240-1241: yaml.dump of the reference's dataclasses): loaded with the reference's own classes, converted,
+    GlobalTracker.from_reference_config(cfg).optimize(), the npz of tracker.py:1152-1218 written next to a copy of the config.
+    Landmark-only on the CPU device (the host formulation), a few steps per stage; FLAME is the synthetic model (no licensed assets here)."""
+    import yaml
+    import vhap.config.base as rb
+    from vhap_amd import reference_adapter, track
+    from vhap_amd.synthetic import make_texture
+    rng = np.random.default_rng(5)
+    H, W, n_t = 48, 40, 3
+    _write_sequence(tmp_path, "seq0", n_t, ["0"], H, W, rng)
+    data = rb.DataConfig(root_folder=tmp_path, sequence="seq0", landmark_source="star")
+    cfg = _instance(rb.BaseTrackingConfig, data=data, model=rb.ModelConfig(tex_resolution=64, use_static_offset=False),
+                    exp=rb.ExperimentConfig(output_folder=tmp_path / "out", photometric=False), device="cpu", batch_size=2)
+    for st in (cfg.pipeline.lmk_init_rigid, cfg.pipeline.lmk_init_all, cfg.pipeline.lmk_sequential_tracking):
+        st.num_steps = 3
+    cfg.pipeline.lmk_global_tracking.num_epochs = 2
+    path = tmp_path / "config.yml"
+    path.write_text(yaml.dump(cfg), "utf8")                          # exactly what the reference's constructor writes
+    back = track.load_reference_config(str(path), REF)
+    assert type(back) is rb.BaseTrackingConfig and back.data.sequence == "seq0" and back.pipeline.lmk_init_all.num_steps == 3
+    assert back.exp.output_folder == tmp_path / "out" and back.w.landmark == cfg.w.landmark
+    assert track.main(["--config", str(path), "--checkout", REF, "--dry-run"]) == 0
+    assert not (tmp_path / "out").exists()
+    # the full run; the licensed FLAME pickles are replaced by the synthetic model of the test suite
+    real = reference_adapter.tracker_from_reference_config
+
+    def with_synthetic_flame(cls, c, **kw):
+        # (a CPU device has no frame store -- there is no CPU path for the ingest kernels: the frames the reference's __getitem__ produced go
+        # in as the fp32 batch tensor the host formulation takes)
+        ds = reference_adapter.open_reference_dataset(c.data, kw.pop("checkout", None), img_to_tensor=False, batchify_all_views=False)
+        d = reference_adapter.frames_from_reference_dataset(ds, "cpu", kw.pop("device_prepare", False))
+        d["rgb"] = d.pop("frames").rgb.permute(0, 3, 1, 2).float() / 255
+        return real(cls, c, flame=flame_model, base_texture=make_texture(0, 64), dataset=d, **kw)
+    monkeypatch.setattr(reference_adapter, "tracker_from_reference_config", with_synthetic_flame)
+    assert track.main(["--config", str(path), "--checkout", REF, "--no-evaluate"]) == 0
+    runs = list((tmp_path / "out").iterdir())
+    assert len(runs) == 1 and (runs[0] / "config.yml").exists()
+    out = np.load(runs[0] / "tracked_flame_params.npz")
+    assert out["expr"].shape == (n_t, cfg.model.n_expr) and out["translation"].shape == (n_t, 3) and int(out["n_processed_frames"]) == n_t
+    assert float(np.abs(out["translation"]).max()) > 0                # the fit moved
+    again = track.load_reference_config(str(runs[0] / "config.yml"), REF)
+    assert again.pipeline.lmk_global_tracking.num_epochs == 2
+
+
+@needs_ref
 def test_tracker_from_reference_config_nersemble_layout(reference, tmp_path, flame_model, monkeypatch):
     """The calibrated multi-view path: the reference's NersembleTrackingConfig + NeRSembleDataset (camera_params.json, per-camera colour
     correction, alpha maps stored at n_downsample_rgb times the rgb's size) -> frames grouped by timestep, per-view K / RT."""

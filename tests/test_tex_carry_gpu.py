@@ -1,0 +1,168 @@
+"""The carried texture (vhap_tex_finish_carry / vhap_tex_carry_prime, csrc/reg.hip TexCarry): the texture's finish + Adam pass also writes
+the NEXT step's assembled albedo (in place), pyramid level 1 and that texture's TV / residual energies.  Checked against the two passes it
+stands for -- vhap_tex_prep_bwd_adam_base (gradient + Adam) and vhap_tex_prep_mip1_fwd (the reference's per-step re-assembly,
+vhap/model/tracker.py:237-258, 518-541) -- over several consecutive steps: bit-exact state, albedo and level 1; energies to fp32 summation noise.
+Then the captured step with and without the carry."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _chk(rc, what):
+    from vhap_amd import _lib
+    _lib.check(rc, what)
+
+
+@pytest.mark.parametrize("T", [128, 256, 1024])
+def test_finish_carry_matches_the_two_passes_bit_exact(T):
+    from vhap_amd import _lib
+    from vhap_amd.native import _n_gather
+    from vhap_amd.ops import _p, _stream
+    L = _lib.lib()
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(T)
+    rn = lambda *s: torch.randn(*s, generator=g, device=dev)
+    painted = torch.rand(3, T, T, generator=g, device=dev)
+    extra0 = rn(3, T, T) * 0.05
+    mask = (torch.rand(T, T, generator=g, device=dev) < 0.4).to(torch.uint8)
+    nm = int(L.vhap_texture_mip_floats(1, T, T, 3))
+    ng = _n_gather(T)
+    assert ng == L.vhap_texture_num_levels(T, T)
+    s_tv, s_res = 30.0 / (3.0 * T * (T - 1)), 20.0 / (3.0 * T * T)
+    ones = torch.ones(8, device=dev)
+    lr = torch.tensor([5e-3], device=dev)
+    b1, b2, eps = 0.9, 0.999, 1e-8
+
+    def state():
+        return dict(extra=extra0.clone(), m=torch.zeros(3, T, T, device=dev), v=torch.zeros(3, T, T, device=dev),
+                    step=torch.zeros(1, dtype=torch.int32, device=dev), albedo=torch.empty(1, T, T, 3, device=dev),
+                    mips=torch.zeros(nm, device=dev), d_extra=torch.zeros(3, T, T, device=dev))
+    A, B = state(), state()                                         # A: the two passes; B: the carried form
+    halo = torch.full((int(L.vhap_tex_carry_halo_floats(T)),), float("nan"), device=dev)
+    cterms = torch.full((4,), float("nan"), device=dev)
+    _chk(L.vhap_tex_carry_prime(_p(painted), _p(B["extra"]), _p(mask), T, s_tv, s_res, _p(B["albedo"]), _p(B["mips"]), _p(halo), _p(cterms),
+                                _stream()), "prime")
+    assert not torch.isnan(halo).any()
+    for k in range(4):
+        d_tex = rn(1, T, T, 3) * 1e-3
+        d_mips = rn(nm) * 1e-3
+        # --- A: assemble (energies), finish + Adam
+        terms = torch.zeros(4, device=dev)
+        _chk(L.vhap_tex_prep_mip1_fwd(_p(painted), _p(A["extra"]), _p(mask), T, s_tv, s_res, _p(A["albedo"]), _p(A["mips"]), _p(terms), 0, _stream()),
+             "prep")
+        if k == 0:
+            assert torch.equal(A["albedo"], B["albedo"]) and torch.equal(A["mips"][: 3 * (T // 2) ** 2], B["mips"][: 3 * (T // 2) ** 2])
+        # the energies of the texture this step starts with: handed over by prime / the previous carried pass, completed by the border call
+        # (issued ahead of this step's advance of the counter, like the captured step does)
+        _chk(L.vhap_tex_carry_border(T, s_tv, _p(B["step"]), _p(halo), _p(cterms), _lib.CALL_ADAM_STEP_ADVANCED, _stream()), "border")
+        ct, t = cterms.cpu().numpy(), terms.cpu().numpy()
+        assert t[0] > 0 and t[1] > 0
+        assert abs(ct[0] - t[0]) <= 2e-5 * t[0] and abs(ct[1] - t[1]) <= 2e-5 * t[1], (T, k, ct, t)
+        cterms[:2].zero_()                                          # (what the consumer does: VHAP_CALL_TEX_TERMS_CONSUME)
+        _chk(L.vhap_adam_advance(_p(A["step"]), _stream()), "advance")
+        _chk(L.vhap_tex_prep_bwd_adam_base(_p(A["albedo"]), _p(A["extra"]), _p(mask), _p(d_tex), _p(d_mips), ng, _p(ones), T, s_tv, s_res,
+                                           _p(A["d_extra"]), _p(A["m"]), _p(A["v"]), _p(lr), _p(A["step"]), b1, b2, eps, 0,
+                                           _lib.CALL_ADAM_STEP_ADVANCED, _stream()), "finish")
+        # --- B: the carried pass (gradient written on even steps only: d_extra is optional)
+        _chk(L.vhap_adam_advance(_p(B["step"]), _stream()), "advance")
+        want_grad = k % 2 == 0
+        _chk(L.vhap_tex_finish_carry(_p(B["albedo"]), _p(B["extra"]), _p(mask), _p(painted), _p(d_tex), _p(d_mips), ng, _p(ones), T, s_tv, s_res,
+                                     _p(B["d_extra"]) if want_grad else 0, _p(B["m"]), _p(B["v"]), _p(lr), _p(B["step"]), b1, b2, eps,
+                                     _p(B["mips"]), _p(halo), _p(cterms), _lib.CALL_ADAM_STEP_ADVANCED, _stream()), "carry")
+        torch.cuda.synchronize()
+        for key in ("extra", "m", "v"):
+            assert torch.equal(A[key], B[key]), (T, k, key, float((A[key] - B[key]).abs().max()))
+        if want_grad:
+            assert torch.equal(A["d_extra"], B["d_extra"]), (T, k)
+        # the texture the NEXT step samples: what the re-assembly makes of the updated residual
+        alb = torch.empty_like(A["albedo"])
+        mp = torch.zeros(nm, device=dev)
+        _chk(L.vhap_tex_prep_mip1_fwd(_p(painted), _p(A["extra"]), _p(mask), T, 0.0, 0.0, _p(alb), _p(mp), _p(torch.zeros(4, device=dev)), 0, _stream()),
+             "prep")
+        torch.cuda.synchronize()
+        assert torch.equal(alb, B["albedo"]), (T, k, float((alb - B["albedo"]).abs().max()))
+        n1 = 3 * (T // 2) ** 2
+        assert torch.equal(mp[:n1], B["mips"][:n1]), (T, k)
+
+
+def _tracker(T=256, H=128, W=128, N=4, seed=3):
+    from vhap_amd.config import BaseTrackingConfig
+    from vhap_amd.flame import FlameHead
+    from vhap_amd.render_hip import HipDiffRenderer
+    from vhap_amd.synthetic import make_dataset, make_flame_model, make_scene_params, make_texture
+    from vhap_amd.tracker import GlobalTracker
+    model, topo = make_flame_model(seed=0)
+    cfg = BaseTrackingConfig()
+    cfg.device = "cuda:0"
+    cfg.model.tex_resolution = T
+    gt = make_scene_params(N, seed=seed, image_size=(H, W))
+    head, rend = FlameHead(model, topo).cuda(), HipDiffRenderer(lighting_type="SH").cuda()
+    data = make_dataset(rend, head, gt, (H, W), "cuda:0", seed=seed, tex=make_texture(3, T))
+    tr = GlobalTracker(cfg, model, topo, make_texture(0, T), data)
+    with torch.no_grad():
+        tr.translation[:, 2] = 0.45
+        tr.expr.add_(0.05)
+    tr.render.disturb_rate_fg = tr.render.disturb_rate_bg = None     # deterministic
+    return tr
+
+
+def _run(carry, steps=6, lone=2):
+    from vhap_amd.tracker import GraphedStep
+    os.environ["VHAP_TEX_CARRY"] = "1" if carry else "0"
+    try:
+        tr = _tracker()
+        stage = "rgb_global_tracking"
+        opt = tr.configure_optimizer(tr.get_train_parameters(stage), lr_scale=0.1)
+        sample = tr.get_sample(np.arange(4), device_index=True)
+        step = GraphedStep(tr, sample, opt, stage, warmup=0)
+        assert step.ns.carry == bool(carry)
+        logs = []
+        for _ in range(lone):                                        # lone replays (each primes), then a loop (primed once)
+            step()
+            torch.cuda.synchronize()
+            logs.append({k: float(v) for k, v in step.log_dict.items()})
+        with step.replay_stream():
+            for _ in range(steps):
+                step()
+        torch.cuda.synchronize()
+        logs.append({k: float(v) for k, v in step.log_dict.items()})
+        # a host-side write between two loops must be seen (the version counter): perturb the texture, run one more loop
+        with torch.no_grad():
+            tr.tex_extra.mul_(0.5)
+        with step.replay_stream():
+            for _ in range(2):
+                step()
+        torch.cuda.synchronize()
+        logs.append({k: float(v) for k, v in step.log_dict.items()})
+        P = {k: getattr(tr, k).detach().clone() for k in ("shape", "expr", "rotation", "translation", "jaw_pose", "lights", "tex_extra", "focal_length")}
+        return logs, P, step
+    finally:
+        os.environ.pop("VHAP_TEX_CARRY", None)
+
+
+def test_captured_step_with_carried_texture_matches_the_reassembled_one():
+    logs1, P1, step = _run(True)
+    logs0, P0, _ = _run(False)
+    # energies.  The first lone replay starts from the same state in both runs: every term to fp32 summation noise (the TV / residual terms
+    # arrive through carry_terms -- vhap_tex_carry_prime -- instead of the forward accumulators).  Later records (second lone replay: the
+    # terms handed on by the finish pass; the loop's last step; after the host-side texture write, which the version counter must catch)
+    # sit behind 1 .. 8 full-rate Adam steps whose atomics order differs between any two runs.
+    for i, (a, b) in enumerate(zip(logs1, logs0)):
+        tol = 2e-6 if i == 0 else 1e-3
+        for k in b:
+            assert abs(a[k] - b[k]) <= tol * max(abs(b[k]), 1e-3), (i, k, a[k], b[k])
+        assert b["reg_tex_tv"] > 0
+        # the two texture terms depend on the texture alone, which moves by ~lr per step whatever the atomics do: always tight
+        for k in ("reg_tex_tv", "reg_tex_res_clusters"):
+            assert abs(a[k] - b[k]) <= 5e-5 * abs(b[k]) + 1e-12, (i, k, a[k], b[k])
+    # fitted parameters: atomics order is the only difference between the two runs
+    for k in P0:
+        d = float((P1[k] - P0[k]).norm() / (P0[k].norm() + 1e-12))
+        assert d <= 2e-3, (k, d)
+    # the carried albedo IS painted + tex_extra after the last step, bit for bit
+    ns = step.ns
+    assert torch.equal(ns.albedo_tex[0], (ns.painted + step.tr.tex_extra.detach()).permute(1, 2, 0).contiguous())

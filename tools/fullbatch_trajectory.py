@@ -9,7 +9,9 @@ host time), so it is a two-part record:
         HipAdam; dumps the start state, the frames (resident as uint8, as the frame store holds them), per-step triangle ids and
         energies, and the arrays GlobalTracker.save_result exports.
     python tools/fullbatch_trajectory.py cpu  gpurun_out/traj_cfgN.npz --record profiles/r05_trajectory_cfgN.txt   (anywhere; no GPU)
-    python tools/fullbatch_trajectory.py both --config N --record ... --threads 64       (one process: the dump is ~100 MiB, too big to travel)
+    python tools/fullbatch_trajectory.py both --config N --record ... --threads 64       (one process: the dump is ~100 MiB, too big to travel;
+        exits non-zero unless EVERY exported array is within 1e-3 relative L2 of the float64 oracle fit OR within 1.5 x the distance the
+        same oracle run in float32 -- the yardstick, same invocation -- has from it, and every update-relative L2 is within 2e-2)
         the oracle's fit loop (oracle/fit_ref.py: energy_ref.total_energy in float64 + torch.optim.Adam) from the same start on the same
         frames and the same visibility; compares energies per step and every exported array (relative L2 of the array and of its UPDATE).
 
@@ -122,7 +124,14 @@ class _Files(dict):
     files = property(lambda self: list(self.keys()))
 
 
-def cpu_part(path, record, threads, dtype=torch.float64, save=None):
+UPDATE_GATE = 2e-2       # update-relative L2 of every exported array
+ARRAY_GATE = 1e-3        # relative L2 of every exported array (SURVEY 8(c) / BASELINE.md section 3) ...
+YARD_FACTOR = 1.5        # ... or within this factor of the float32 oracle's distance from the float64 fit on the SAME fit
+
+
+def cpu_part(path, record, threads, dtype=torch.float64, save=None, yardstick=False):
+    """yardstick=True: the oracle is ALSO run in float32 on the same frames / triangle ids, and an exported array may miss ARRAY_GATE if it
+    stays within YARD_FACTOR x the float32 oracle's own distance from the float64 fit (what plain fp32 arithmetic does to this fit)."""
     from oracle import fit_ref
     from vhap_amd.synthetic import make_flame_model, make_texture
     from vhap_amd.topology import FlameTopology  # noqa: F401  (import check: the oracle side needs no HIP library)
@@ -169,6 +178,17 @@ def cpu_part(path, record, threads, dtype=torch.float64, save=None):
     exp = fit_ref.export(P, (H, W), calibrated=calibrated)
     if save:
         np.savez(save, E=np.array(E_ora), **{"export_" + k: np.asarray(v) for k, v in exp.items()})
+    if dtype != torch.float64:
+        return exp                                      # (the yardstick run: its exported arrays, no comparison)
+    yard = {}
+    if yardstick:
+        t1 = time.time()
+        exp32 = cpu_part(path, None, threads, dtype=torch.float32)
+        lines.append(f"yardstick: the same oracle fit in float32 (same frames, same triangle ids): {time.time() - t1:.0f} s")
+        for k in exp:
+            if k in exp32 and k not in ("timestep_id", "n_processed_frames", "image_size"):
+                b = np.asarray(exp[k], np.float64)
+                yard[k] = float(np.linalg.norm(np.asarray(exp32[k], np.float64) - b) / max(np.linalg.norm(b), 1e-300))
     worst = 0.0
     for k in sorted(exp):
         if "export_" + k not in d.files:
@@ -187,9 +207,15 @@ def cpu_part(path, record, threads, dtype=torch.float64, save=None):
         l2 = float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
         dl2 = float(np.linalg.norm(a - b) / max(np.linalg.norm(b - s0), 1e-300))
         worst = max(worst, dl2)
-        lines.append(f"{k}: L2 rel {l2:.2e}   update L2 rel {dl2:.2e}   (max |update| {moved:.2e})")
-        if l2 > 1e-3:
-            fails.append(f"{k}: L2 rel {l2:.2e} > 1e-3 (SURVEY 8(c))")
+        y = yard.get(k)
+        lines.append(f"{k}: L2 rel {l2:.2e}   update L2 rel {dl2:.2e}   (max |update| {moved:.2e})" +
+                     (f"   float32 oracle: L2 rel {y:.2e}, HIP / float32 oracle = {l2 / max(y, 1e-300):.2f}" if y is not None else ""))
+        if l2 > ARRAY_GATE and not (y is not None and l2 <= YARD_FACTOR * y):
+            fails.append(f"{k}: L2 rel {l2:.2e} > {ARRAY_GATE:g} (SURVEY 8(c))" + (f" and > {YARD_FACTOR} x the float32 oracle's {y:.2e}" if y is not None else ""))
+        elif l2 > ARRAY_GATE:
+            lines.append(f"   ({k}: over {ARRAY_GATE:g}, within {YARD_FACTOR} x the float32 oracle's own distance from the float64 fit: accepted)")
+        if dl2 > UPDATE_GATE:
+            fails.append(f"{k}: update-relative L2 {dl2:.2e} > {UPDATE_GATE:g}")
     lines.append(f"worst update-relative L2 over the exported arrays: {worst:.2e}")
     lines += ["FAIL: " + f for f in fails] or []
     lines.append("RESULT: " + ("FAIL" if fails else "ok") + f"   ({time.time() - t0:.0f} s of oracle time)")
@@ -225,11 +251,12 @@ if __name__ == "__main__":
     b.add_argument("--steps", type=int, default=K_DEFAULT)
     b.add_argument("--record", default=None)
     b.add_argument("--threads", type=int, default=0)
+    b.add_argument("--no-yardstick", action="store_true", help="skip the float32-oracle run (then only the 1e-3 gate applies)")
     a = ap.parse_args()
     if a.cmd == "gpu":
         gpu_part(a.config, a.out, a.steps)
     elif a.cmd == "both":
-        sys.exit(cpu_part(gpu_part(a.config, None, a.steps), a.record, a.threads))
+        sys.exit(cpu_part(gpu_part(a.config, None, a.steps), a.record, a.threads, yardstick=not a.no_yardstick))
     elif a.cmd == "yardstick":
         d, e64, e32 = np.load(a.dump), np.load(a.exp64), np.load(a.exp32)
         lines = [f"BASELINE config {int(d['config'])}, {int(d['K'])} steps: distance from the float64-oracle fit of (a) the HIP fit, (b) the SAME oracle "
@@ -249,4 +276,5 @@ if __name__ == "__main__":
         if a.record:
             open(a.record, "w").write("\n".join(lines) + "\n")
     else:
-        sys.exit(cpu_part(a.dump, a.record, a.threads, dtype=getattr(torch, a.dtype), save=a.save))
+        r = cpu_part(a.dump, a.record, a.threads, dtype=getattr(torch, a.dtype), save=a.save)
+        sys.exit(r if isinstance(r, int) else 0)

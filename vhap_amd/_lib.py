@@ -108,6 +108,10 @@ SIGNATURES = {
     "vhap_tex_pca_fwd": (c_i, [c_fp] * 3 + [c_i, c_i, c_i, c_f] + [c_fp] * 4),
     "vhap_tex_pca_bwd": (c_i, [c_fp] * 4 + [c_i, c_i, c_i, c_f] + [c_fp] * 4),
     "vhap_tex_prep_bwd_adam_rows": (c_i, [c_fp] * 5 + [c_i, c_i, c_i, c_f, c_f] + [c_fp] * 5 + [c_f, c_f, c_f, c_i, c_fp]),
+    "vhap_tex_carry_halo_floats": (c_sz, [c_i]),
+    "vhap_tex_carry_prime": (c_i, [c_fp] * 3 + [c_i, c_f, c_f] + [c_fp] * 5),
+    "vhap_tex_carry_border": (c_i, [c_i, c_f, c_fp, c_fp, c_fp, c_i, c_fp]),
+    "vhap_tex_finish_carry": (c_i, [c_fp] * 6 + [c_i, c_fp, c_i, c_f, c_f] + [c_fp] * 5 + [c_f, c_f, c_f] + [c_fp] * 3 + [c_i, c_fp]),
     "vhap_energy_finalize": (c_i, [c_fp] * 5 + [c_f, c_f, c_i, c_i, c_i, c_fp, c_fp]),
     "vhap_energy_total": (c_i, [c_fp, c_fp, c_fp, c_f, c_i, c_fp, c_fp]),
     "vhap_sum_frames": (c_i, [c_fp, c_i, c_i, c_fp, c_fp]),
@@ -139,11 +143,13 @@ SIGNATURES = {
     "vhap_plan_launch_timed": (c_i, [c_fp, c_fp, ctypes.POINTER(c_f), ctypes.POINTER(c_f), c_i]),
 }
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 # call_flags of include/vhap_hip.h (per-call arguments since ABI 2; the library keeps no mutable state)
 CALL_ACC_PREZEROED, CALL_AA_PASSTHROUGH_DONE, CALL_ADAM_KEEP_STEP, CALL_ADAM_STEP_ADVANCED, CALL_OFFSET_PER_FRAME = 1, 2, 4, 16, 32
 CALL_PLAN_DEFER_JOIN = 64
 CALL_DELTA_UNSCALED = 128
+CALL_TEX_TERMS_CONSUME = 256
+CALL_SKIP_BG_GRAD = 512
 
 _lib = None
 

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(DB_T) void deferred_shade_bwd_kernel(const Deferred
     float gl[27];
 #pragma unroll
     for (int i = 0; i < 27; i++) gl[i] = 0.f;
-    if (valid && !cov) {                     // background: nothing flows (its colour is the detached target / a constant)
+    if (valid && !cov && !P.skip_bg) {       // background: nothing flows (its colour is the detached target / a constant)
         float* da = P.d_albedo + 3 * (size_t)pi;
         da[0] = 0.f; da[1] = 0.f; da[2] = 0.f;
         if (P.tile_ids) P.tile_ids[pi] = (unsigned short)0xFFFF;
@@ -143,6 +143,7 @@ extern "C" int vhap_deferred_shade_bwd(const float* pos, const int32_t* tri, con
         return e;
     P.d_normal = d_normal; P.d_texc = reinterpret_cast<float2*>(d_texc); P.d_texd = reinterpret_cast<float4*>(d_texd);
     P.delta_unscaled = (call_flags & VHAP_CALL_DELTA_UNSCALED) ? 1 : 0;
+    P.skip_bg = ((call_flags & VHAP_CALL_SKIP_BG_GRAD) && !tile_ids) ? 1 : 0;
     const long long npix = (long long)B * H * W;
     const int blocks = (int)((npix + DB_T - 1) / DB_T);
     hipStream_t st = vhap_stream(stream);

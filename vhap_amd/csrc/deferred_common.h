@@ -46,6 +46,7 @@ struct DeferredParams {
     unsigned* tb_max;
     int NT;
     unsigned short* tile_ids; // optional [B,H,W]: uv tile of every pixel for vhap_texture_grad_binned_ids (0xFFFF = no gradient)
+    int skip_bg;             // VHAP_CALL_SKIP_BG_GRAD: d_albedo of background pixels is not written (its reader walks a list of covered pixels)
 };
 
 // regulariser part of d(diffuse) (lights only, on shade(normal.detach()): tracker.py:547-550), see shade_bwd_kernel

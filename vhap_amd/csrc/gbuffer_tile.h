@@ -94,7 +94,46 @@ __device__ __forceinline__ void gb_tile_commit(GbTile& S, const float (&acc)[18]
     (void)frexpf(__uint_as_float(smax[1]), &exp_n);
     const int shp = min(max(40 - exp_p, -100), 100), shn = min(max(40 - exp_n, -100), 100);
     const float sc_p = ldexpf(1.0f, shp), sc_n = ldexpf(1.0f, shn), isc_p = ldexpf(1.0f, -shp), isc_n = ldexpf(1.0f, -shn);
-    if (have && !(dbg & 256)) {
+    // The 18 contributions of a pixel are MERGED across neighbouring lanes that hold the same triangle before anything touches the table.
+    // Why: the table's LDS atomics are the kernel's bottleneck, not its gathers -- a wave's 64 lanes hit ~10 distinct vertex slots,
+    // ds_add_u64 costs ~2 cycles per lane that shares an address (tools/ubench/lds_atomics.hip), there are 18 per covered pixel, and the CU
+    // has ONE LDS pipe for its four SIMDs: 25 M lane-atomics per 16 x 512^2 step = ~80 us of the kernel's 117.  A triangle of a head frame
+    // covers ~17 pixels, runs of ~4 along a row: three butterfly levels over the 16 lanes of a tile row (lane ^ 1, ^ 2, then + 4 -- DPP
+    // moves on the VALU, which is per SIMD) leave one lane per run to do the atomics.  The partial sums are fp32 in a FIXED tree order
+    // (deterministic; the fixed-point form of the 18 values would cost 36 more registers and three of the kernel's seven waves per SIMD).
+    float a[18];
+#pragma unroll
+    for (int k = 0; k < 18; k++) a[k] = have ? acc[k] : 0.f;
+    bool alive = have;
+    if (!(dbg & 1024)) {                 // (debug flag 1024: A/B without the merge)
+        const int lane = tid & 63;
+        // One level: `receiver` lanes absorb their partner (the lane `up` reads from), `donor` lanes (the others; their partner is the lane
+        // `down` reads from) retire if absorbed.  Every DPP move is executed by ALL lanes -- a DPP read of a lane that EXEC has switched
+        // off returns nothing useful on gfx9, so no move may sit inside a divergent branch -- and each side selects what it needs.
+        auto level = [&](auto up, auto down, bool receiver, bool symmetric) {
+            const int a_u = up(alive ? 1 : 0), k0_u = up(i0), k1_u = up(i1), k2_u = up(i2);
+            int a_p = a_u, k0_p = k0_u, k1_p = k1_u, k2_p = k2_u;
+            if (!symmetric) {
+                const int a_d = down(alive ? 1 : 0), k0_d = down(i0), k1_d = down(i1), k2_d = down(i2);
+                if (!receiver) { a_p = a_d; k0_p = k0_d; k1_p = k1_d; k2_p = k2_d; }
+            }
+            const bool same = alive && a_p != 0 && k0_p == i0 && k1_p == i1 && k2_p == i2;      // (evaluated identically on both sides of a pair)
+#pragma unroll
+            for (int k = 0; k < 18; k++) {
+                const float pv = __int_as_float(up(__float_as_int(a[k])));
+                if (same && receiver) a[k] += pv;
+            }
+            if (same && !receiver) alive = false;
+        };
+        auto x1 = [](int x) { return __builtin_amdgcn_mov_dpp(x, 0xB1, 0xF, 0xF, true); };      // quad_perm [1,0,3,2]: lane ^ 1
+        auto x2 = [](int x) { return __builtin_amdgcn_mov_dpp(x, 0x4E, 0xF, 0xF, true); };      // quad_perm [2,3,0,1]: lane ^ 2
+        auto l4 = [](int x) { return __builtin_amdgcn_mov_dpp(x, 0x104, 0xF, 0xF, true); };     // row_shl:4: lane + 4 of the row of 16 (0 past its end)
+        auto r4 = [](int x) { return __builtin_amdgcn_mov_dpp(x, 0x114, 0xF, 0xF, true); };     // row_shr:4: lane - 4
+        level(x1, x1, !(lane & 1), true);
+        level(x2, x2, !(lane & 2), true);
+        level(l4, r4, !(lane & 4), false);
+    }
+    if (alive && !(dbg & 256)) {
         {
             // three vertices -> LDS table (bounded probing; overflow goes straight to global memory)
 #pragma unroll
@@ -108,7 +147,7 @@ __device__ __forceinline__ void gb_tile_commit(GbTile& S, const float (&acc)[18]
                     if (prev == GEMPTY || prev == (unsigned)vi) {
 #pragma unroll
                         for (int c = 0; c < 3; c++) {
-                            const float vp = acc[3 * vtx + c], vn = acc[9 + 3 * vtx + c];
+                            const float vp = a[3 * vtx + c], vn = a[9 + 3 * vtx + c];
                             if (vp != 0.f) atomicAdd(&vals[slot * 6 + c], (unsigned long long)__float2ll_rn(vp * sc_p));
                             if (vn != 0.f) atomicAdd(&vals[slot * 6 + 3 + c], (unsigned long long)__float2ll_rn(vn * sc_n));
                         }
@@ -120,7 +159,7 @@ __device__ __forceinline__ void gb_tile_commit(GbTile& S, const float (&acc)[18]
                 if (!done) {
 #pragma unroll
                     for (int c = 0; c < 3; c++) {
-                        const float vp = acc[3 * vtx + c], vn = acc[9 + 3 * vtx + c];
+                        const float vp = a[3 * vtx + c], vn = a[9 + 3 * vtx + c];
                         if (d_pos && vp != 0.f) atomicAdd(&d_pos[((size_t)b * V + vi) * 4 + (c == 2 ? 3 : c)], vp);
                         if (d_vnormal && vn != 0.f) atomicAdd(&d_vnormal[((size_t)b * V + vi) * 3 + c], vn);
                     }

@@ -292,6 +292,7 @@ struct PhotoTotal {
     // image and the pair list, like the sum itself, and nothing of the sum's result
     const int* aa_work;
     float* d_delta;
+    int tex_consume;   // VHAP_CALL_TEX_TERMS_CONSUME: tex_terms[0..1] are cleared once read (the carried texture's finish pass accumulates the next step's)
 };
 template <bool TOTAL>
 __global__ __launch_bounds__(PB) void photo_fwd_kernel(const float4* __restrict__ pred, const float* __restrict__ gt, int B, int H,
@@ -371,6 +372,7 @@ __global__ __launch_bounds__(PB) void photo_fwd_kernel(const float4* __restrict_
                 if (lane == 0) { out[0] = sum; out[1] = cnt; reinterpret_cast<unsigned*>(out + 2)[0] = 0u; }
                 vhap_energy::finalize_total_wave(E.frame_terms, E.lmk, E.tex_terms, E.off_terms, E.shade_stats, E.w_lmk, E.w_reg_diffuse,
                                                  (float)npix, sum, cnt, E.w_photo, 1.0f, E.log, E.d_sum, E.gmax_bound);
+                if (E.tex_consume && E.tex_terms && lane < 2) const_cast<float*>(E.tex_terms)[lane] = 0.f;
             }
         }
     }
@@ -460,7 +462,7 @@ extern "C" int vhap_photo_fwd_total(const float* pred_rgba, const float* gt_nchw
     const long long npix = (long long)B * H * W;
     if ((aa_work == nullptr) != (d_delta_unscaled == nullptr)) return VHAP_E_NULLPTR;
     const PhotoTotal E{frame_terms, lmk_energy, tex_terms, off_terms, reinterpret_cast<const unsigned*>(shade_stats), w_landmark, w_reg_diffuse,
-                       w_photo, log, d_sum, gmax_bound, work, aa_work, d_delta_unscaled};
+                       w_photo, log, d_sum, gmax_bound, work, aa_work, d_delta_unscaled, (call_flags & VHAP_CALL_TEX_TERMS_CONSUME) ? 1 : 0};
     photo_fwd_kernel<true><<<min(vhap_cdiv(npix, PB), MAX_BLOCKS), PB, 0, st>>>(reinterpret_cast<const float4*>(pred_rgba), gt_nchw, B, H, W,
                                                                                               out3, E);
     VHAP_LAUNCH_CHECK();

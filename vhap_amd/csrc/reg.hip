@@ -9,6 +9,8 @@
 //   adam       : one launch for every parameter tensor of the step (torch.optim.Adam semantics, tracker.py:159-211).
 #include "common.h"
 #include <string.h>
+#include <algorithm>
+#include <type_traits>
 
 namespace {
 
@@ -235,21 +237,59 @@ struct TexAdam {
 // against the 5.9 TB/s of the Adam pass behind it -- 25 + 63 + 60 us on the tail of the step for fold + this + Adam.)
 constexpr int TEXB_ROWS = 16;
 constexpr int TEXB_MAXG = 12;         // mip levels gathered per texel (T <= 4096 whole; larger textures fold their coarsest levels first)
-template <bool ADAM>
-__global__ __launch_bounds__(RB) void tex_prep_bwd_kernel(TexCfg c, const float* __restrict__ albedo, const float* __restrict__ extra,
+
+// CARRY (round 6): the texture is CARRIED from step to step.  The pass holds every texel it has just updated in registers, so it also
+// writes what the NEXT step's rasteriser samples -- the assembled albedo (painted + updated residual, the arithmetic of tex_prep_fwd)
+// IN PLACE over the one this step sampled, and level 1 of the pyramid -- and sums the TV / residual ENERGIES of that next texture
+// (terms[0..1], accumulated: the consumer -- the photometric sum's energy assembly -- reads and clears them, VHAP_CALL_TEX_TERMS_CONSUME;
+// the TV pairs that straddle two ownership tiles are added by tex_carry_border_kernel from the halo copies below).  tex_prep_fwd (49 us,
+// 134 MB read + 64 MB written at T = 2048) then leaves the head of the step, where it ran beside the binning launch and the rasteriser.
+// In place means a workgroup's neighbours may already have rewritten the texels its TV stencil reads across the strip's borders (row
+// y0 - 1, row y0 + 16, the columns left / right of a wave).  Those come from HALO copies instead: the first / last row of every 16-row
+// strip and the first / last column of every 64-column wave segment, kept twice -- a pass reads the copy of parity (Adam step & 1), which
+// the previous pass wrote, and writes the new border values into the other one (12.6 + 3.1 MB at T = 2048 for both parities).
+// vhap_tex_carry_prime assembles the albedo, level 1 and both parities of the halos from scratch (first step of a loop, or whenever
+// anything but this pass has touched the texture).  Needs T % 64 == 0.
+struct TexCarry {
+    const float* painted;      // [3,T,T]
+    float* mip1;               // level 1 of the pyramid [T/2,T/2,3]
+    float* row_halo;           // [2][T/16][2][T][3]
+    float* col_halo;           // [2][T][T/64][2][3]
+    float* terms;              // [2]: TV / residual energies of the texture this pass hands on, accumulated
+    int write_grad;            // 0: d_extra is not written (the update is applied here; nothing reads the gradient)
+};
+__host__ __device__ inline size_t tex_carry_row_halo_floats(int T) { return (size_t)(T / TEXB_ROWS) * 2 * T * 3; }   // per parity
+__host__ __device__ inline size_t tex_carry_col_halo_floats(int T) { return (size_t)T * (T / 64) * 2 * 3; }          // per parity
+
+// (at most 80 VGPRs -- 6 waves per SIMD: the pass is the step's open tail, all of its 1 024 workgroups are resident from start to end (4 waves
+// per SIMD at T = 2048), and whatever the main chain launches meanwhile must fit beside them.  At 82 VGPRs the carried form left 160 of a
+// SIMD's 512 registers free and the per-frame backward -- 170 VGPRs per wave -- waited for the pass to END: 20 -> 84 us on the main chain,
+// profiles/r06_call3_trace_stats_*.txt)
+template <bool ADAM, bool CARRY = false>
+__global__ __launch_bounds__(RB, 6) void tex_prep_bwd_kernel(TexCfg c, std::conditional_t<CARRY, float*, const float*> __restrict__ albedo,
+                                                          const float* __restrict__ extra,
                                                           const unsigned char* __restrict__ res_mask, const float* __restrict__ d_albedo,
                                                           const float* __restrict__ d_mips, int n_gather, const float* __restrict__ d_terms,
                                                           float* __restrict__ d_extra, const TexAdam A, int step_add, int y_base,
-                                                          float* __restrict__ d_base) {
+                                                          float* __restrict__ d_base, const TexCarry C) {
+#pragma clang fp contract(off)
+    // no fp contraction in this kernel: its instantiations (whole texture / row strip / carried) must produce the SAME bits from the same
+    // inputs -- the carried form is tested bit for bit against the plain one -- and hipcc fuses a * b + c per instantiation, as the
+    // surrounding code happens to suggest (the carried form's gradient differed from the plain one's by an ulp from its second step on)
+    static_assert(!CARRY || ADAM, "the carried texture is written by the pass that updates it");
+    __shared__ float red[4];
     const int T = c.T;
     const size_t plane = (size_t)T * T;
     const float gtv = 2.0f * c.s_tv * d_terms[0], gres = 2.0f * c.s_res * d_terms[1];
     float bc2s = 1.f, step_size = 0.f;
+    int parity = 0;
     if constexpr (ADAM) {
-        const float st = (float)(A.step[0] + step_add);
+        const int sti = A.step[0] + step_add;
+        const float st = (float)sti;
         const float bc1 = 1.0f - powf(A.beta1, st);
         bc2s = sqrtf(1.0f - powf(A.beta2, st));
         step_size = A.lr[0] / bc1;
+        parity = sti & 1;
     }
     const int x = blockIdx.x * RB + threadIdx.x, y0 = y_base + blockIdx.y * TEXB_ROWS;     // (y_base: the first row of a ROW STRIP of the texture)
     const int lane = threadIdx.x & 63;
@@ -263,8 +303,38 @@ __global__ __launch_bounds__(RB) void tex_prep_bwd_kernel(TexCfg c, const float*
             a[0] = a[1] = a[2] = 0.f;
         }
     };
+    // CARRY: the borders of the OLD texture (this step's), from the halo copies of this step's parity; the new ones go to the other parity
+    const int strip = y0 / TEXB_ROWS, nstrips = T / TEXB_ROWS, wseg = __builtin_amdgcn_readfirstlane(x >> 6), nwseg = T >> 6;   // (wseg: wave-uniform)
+    const float* __restrict__ const rh_old = CARRY ? C.row_halo + (size_t)parity * tex_carry_row_halo_floats(T) : nullptr;
+    const float* __restrict__ const ch_old = CARRY ? C.col_halo + (size_t)parity * tex_carry_col_halo_floats(T) : nullptr;
+    float* __restrict__ const rh_new = CARRY ? C.row_halo + (size_t)(parity ^ 1) * tex_carry_row_halo_floats(T) : nullptr;
+    float* __restrict__ const ch_new = CARRY ? C.col_halo + (size_t)(parity ^ 1) * tex_carry_col_halo_floats(T) : nullptr;
+    const float* __restrict__ const painted = CARRY ? C.painted : nullptr;
+    float* __restrict__ const mip1 = CARRY ? C.mip1 : nullptr;
+    auto halo_row = [&](int s, int slot, float* a) {          // first (slot 0) / last (slot 1) row of strip s
+        if (in_x && s >= 0 && s < nstrips) {
+            const float* q = rh_old + 3 * (((size_t)s * 2 + slot) * T + x);
+            a[0] = q[0]; a[1] = q[1]; a[2] = q[2];
+        } else {
+            a[0] = a[1] = a[2] = 0.f;
+        }
+    };
+    auto halo_col = [&](int y, int w, int slot, float* a) {   // first (slot 0) / last (slot 1) column of wave segment w
+        if (w >= 0 && w < nwseg) {
+            const float* q = ch_old + 3 * (((size_t)y * nwseg + w) * 2 + slot);
+            a[0] = q[0]; a[1] = q[1]; a[2] = q[2];
+        } else {
+            a[0] = a[1] = a[2] = 0.f;
+        }
+    };
     float up[3] = {0.f, 0.f, 0.f}, cur[3] = {0.f, 0.f, 0.f}, dn[3] = {0.f, 0.f, 0.f};
-    if (tv) { load_row(y0 - 1, x, up); load_row(y0, x, cur); }
+    if (tv) {
+        if constexpr (CARRY) halo_row(strip - 1, 1, up);
+        else load_row(y0 - 1, x, up);
+        load_row(y0, x, cur);
+    }
+    float e_tv = 0.f, e_res = 0.f;                            // CARRY: TV / residual energies of the NEXT texture (tex_prep_fwd's sums)
+    float nprev[3] = {0.f, 0.f, 0.f};
     // (restrict-qualified copies: stores through members of a by-value struct are otherwise assumed to alias every later load, which
     // pins each row's loads behind the previous row's stores)
     float* __restrict__ const adam_p = A.p;
@@ -310,7 +380,14 @@ __global__ __launch_bounds__(RB) void tex_prep_bwd_kernel(TexCfg c, const float*
     for (int r = 0; r < nrows; r++) {
         const int y = y0 + r;
         const size_t i = (size_t)y * T + x;
-        if (tv) load_row(y + 1, x, dn);
+        if (tv) {
+            if (CARRY && r + 1 == TEXB_ROWS) halo_row(strip + 1, 0, dn);
+            else load_row(y + 1, x, dn);
+        }
+        float pt[3] = {0.f, 0.f, 0.f};
+        if constexpr (CARRY) {
+            if (in_x) { pt[0] = painted[i]; pt[1] = painted[plane + i]; pt[2] = painted[2 * plane + i]; }
+        }
         float g[3] = {0.f, 0.f, 0.f};
         if (in_x) {
             if (d_albedo) { g[0] = d_albedo[3 * i]; g[1] = d_albedo[3 * i + 1]; g[2] = d_albedo[3 * i + 2]; }
@@ -330,8 +407,13 @@ __global__ __launch_bounds__(RB) void tex_prep_bwd_kernel(TexCfg c, const float*
             float lf[3], rt[3];
 #pragma unroll
             for (int k = 0; k < 3; k++) { lf[k] = __shfl_up(cur[k], 1, 64); rt[k] = __shfl_down(cur[k], 1, 64); }
-            if (lane == 0) load_row(y, x - 1, lf);
-            if (lane == 63) load_row(y, x + 1, rt);
+            if constexpr (CARRY) {
+                if (lane == 0) halo_col(y, wseg - 1, 1, lf);
+                if (lane == 63) halo_col(y, wseg + 1, 0, rt);
+            } else {
+                if (lane == 0) load_row(y, x - 1, lf);
+                if (lane == 63) load_row(y, x + 1, rt);
+            }
             if (in_x) {
                 float acc[3] = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -357,7 +439,8 @@ __global__ __launch_bounds__(RB) void tex_prep_bwd_kernel(TexCfg c, const float*
 #pragma unroll
                 for (int k = 0; k < 3; k++) g[k] += gres * ex[k];
             }
-            d_extra[i] = g[0]; d_extra[plane + i] = g[1]; d_extra[2 * plane + i] = g[2];
+            if (!CARRY || C.write_grad) { d_extra[i] = g[0]; d_extra[plane + i] = g[1]; d_extra[2 * plane + i] = g[2]; }
+            float pn[3] = {0.f, 0.f, 0.f};
             if constexpr (ADAM) {
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
@@ -368,12 +451,109 @@ __global__ __launch_bounds__(RB) void tex_prep_bwd_kernel(TexCfg c, const float*
                     const float vi = A.beta2 * adam_v[j] + (1.0f - A.beta2) * gi * gi;
                     adam_m[j] = mi;
                     adam_v[j] = vi;
-                    adam_p[j] = ex[k] - step_size * mi / (sqrtf(vi) / bc2s + A.eps);
+                    pn[k] = ex[k] - step_size * mi / (sqrtf(vi) / bc2s + A.eps);
+                    adam_p[j] = pn[k];
                 }
+            }
+            if constexpr (CARRY) {
+                // the next step's texture: albedo = painted + residual (tex_prep_fwd's sum), in place; borders into the other parity's halos;
+                // level 1 of the pyramid = ((a00 + a01) + (a10 + a11)) / 4 (vhap_texture_mip_build's order) on odd rows by even lanes
+                float nv[3], nrt[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) { nv[k] = pt[k] + pn[k]; nrt[k] = __shfl_down(nv[k], 1, 64); }
+                albedo[3 * i] = nv[0]; albedo[3 * i + 1] = nv[1]; albedo[3 * i + 2] = nv[2];
+                // its energies, the pairs inside this wave's 64-column x 16-row tile (the others: tex_carry_border_kernel)
+                if (tv) {
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        const float dh = nv[k] - nrt[k], dv = nprev[k] - nv[k];
+                        if (lane < 63) e_tv += dh * dh;
+                        if (r > 0) e_tv += dv * dv;
+                    }
+                }
+                if (res) e_res += pn[0] * pn[0] + pn[1] * pn[1] + pn[2] * pn[2];
+                if (r == 0 || r + 1 == TEXB_ROWS) {
+                    float* q = rh_new + 3 * (((size_t)strip * 2 + (r == 0 ? 0 : 1)) * T + x);
+                    q[0] = nv[0]; q[1] = nv[1]; q[2] = nv[2];
+                }
+                if (lane == 0 || lane == 63) {
+                    float* q = ch_new + 3 * (((size_t)y * nwseg + wseg) * 2 + (lane == 0 ? 0 : 1));
+                    q[0] = nv[0]; q[1] = nv[1]; q[2] = nv[2];
+                }
+                if (r & 1) {                                  // (uniform; the upper row's right neighbours are fetched again rather than kept: registers)
+                    float prt[3];
+#pragma unroll
+                    for (int k = 0; k < 3; k++) prt[k] = __shfl_down(nprev[k], 1, 64);
+                    if (!(lane & 1)) {
+                        float* q = mip1 + 3 * ((size_t)(y >> 1) * (T >> 1) + (x >> 1));
+#pragma unroll
+                        for (int k = 0; k < 3; k++) q[k] = ((nprev[k] + prt[k]) + (nv[k] + nrt[k])) * 0.25f;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 3; k++) nprev[k] = nv[k];
             }
         }
 #pragma unroll
         for (int k = 0; k < 3; k++) { up[k] = cur[k]; cur[k] = dn[k]; }
+    }
+    if constexpr (CARRY) {
+        e_tv = block_sum256(e_tv, red);                       // weighted like tex_prep_fwd's terms
+        e_res = block_sum256(e_res, red);
+        if (threadIdx.x == 0) {
+            if (e_tv != 0.f && c.s_tv != 0.f) atomicAdd(&C.terms[0], e_tv * c.s_tv);
+            if (e_res != 0.f && c.s_res != 0.f) atomicAdd(&C.terms[1], e_res * c.s_res);
+        }
+    }
+}
+
+// TV pairs of the carried texture that straddle two ownership tiles of the finish pass, from the halo copies that pass has just written
+// (the parity it wrote: the OTHER one of its step): last row of strip s | first row of strip s + 1, last column of wave segment w | first
+// column of segment w + 1.
+__global__ __launch_bounds__(RB) void tex_carry_border_kernel(int T, float s_tv, const int* __restrict__ step, int step_add,
+                                                              const float* __restrict__ row_halo, const float* __restrict__ col_halo,
+                                                              float* __restrict__ terms) {
+    __shared__ float red[4];
+    const int par_new = step ? (((step[0] + step_add) & 1) ^ 1) : 0;          // (step == NULL: after vhap_tex_carry_prime both copies are the same)
+    const float* __restrict__ rh = row_halo + (size_t)par_new * tex_carry_row_halo_floats(T);
+    const float* __restrict__ ch = col_halo + (size_t)par_new * tex_carry_col_halo_floats(T);
+    const int nstrips = T / TEXB_ROWS, nw = T >> 6;
+    const size_t nrow = (size_t)(nstrips - 1) * T, ncol = (size_t)T * (nw - 1);
+    float e = 0.f;
+    for (size_t i = (size_t)blockIdx.x * RB + threadIdx.x; i < nrow + ncol; i += (size_t)gridDim.x * RB) {      // (<= 128 workgroups: one atomic each)
+        const float *a, *b;
+        if (i < nrow) {
+            const size_t s = i / T, x = i % T;
+            a = rh + 3 * ((s * 2 + 1) * T + x);
+            b = rh + 3 * (((s + 1) * 2) * T + x);
+        } else {
+            const size_t j = i - nrow, y = j / (nw - 1), w = j % (nw - 1);
+            a = ch + 3 * ((y * nw + w) * 2 + 1);
+            b = ch + 3 * ((y * nw + w + 1) * 2);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++) { const float d = a[k] - b[k]; e += d * d; }
+    }
+    e = block_sum256(e, red);
+    if (threadIdx.x == 0 && e != 0.f) atomicAdd(&terms[0], e * s_tv);
+}
+
+// both parities of the carried texture's halo copies from the assembled albedo (vhap_tex_carry_prime)
+__global__ __launch_bounds__(RB) void tex_carry_halo_init_kernel(int T, const float* __restrict__ albedo, float* __restrict__ row_halo,
+                                                                 float* __restrict__ col_halo) {
+    const size_t nrow = tex_carry_row_halo_floats(T) / 3, ncol = tex_carry_col_halo_floats(T) / 3;     // texels per parity
+    const size_t i = (size_t)blockIdx.x * RB + threadIdx.x;
+    if (i < nrow) {
+        const int x = (int)(i % T), slot = (int)((i / T) & 1), s = (int)(i / T / 2);
+        const float* q = albedo + 3 * ((size_t)(s * TEXB_ROWS + (slot ? TEXB_ROWS - 1 : 0)) * T + x);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { row_halo[3 * i + k] = q[k]; row_halo[3 * (nrow + i) + k] = q[k]; }
+    } else if (i < nrow + ncol) {
+        const size_t j = i - nrow;
+        const int nw = T >> 6, slot = (int)(j & 1), w = (int)((j >> 1) % nw), y = (int)((j >> 1) / nw);
+        const float* q = albedo + 3 * ((size_t)y * T + w * 64 + (slot ? 63 : 0));
+#pragma unroll
+        for (int k = 0; k < 3; k++) { col_halo[3 * j + k] = q[k]; col_halo[3 * (ncol + j) + k] = q[k]; }
     }
 }
 
@@ -591,7 +771,7 @@ extern "C" int vhap_tex_prep_bwd_base(const float* albedo_hwc, const float* extr
     if (T <= 0 || n_gather < 0 || n_gather > TEXB_MAXG || (d_mips_hwc && n_gather > 0 && (T & ((1 << n_gather) - 1)))) return VHAP_E_BADDIM;
     TexCfg c{T, s_tv, s_res};
     tex_prep_bwd_kernel<false><<<dim3(vhap_cdiv(T, RB), vhap_cdiv(T, TEXB_ROWS)), RB, 0, vhap_stream(stream)>>>(
-        c, albedo_hwc, extra, res_mask, d_albedo_hwc, n_gather > 0 ? d_mips_hwc : nullptr, n_gather, d_terms, d_extra, TexAdam{}, 0, 0, d_base);
+        c, albedo_hwc, extra, res_mask, d_albedo_hwc, n_gather > 0 ? d_mips_hwc : nullptr, n_gather, d_terms, d_extra, TexAdam{}, 0, 0, d_base, TexCarry{});
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;
 }
@@ -614,7 +794,80 @@ extern "C" int vhap_tex_prep_bwd_adam_base(const float* albedo_hwc, float* extra
     TexCfg c{T, s_tv, s_res};
     tex_prep_bwd_kernel<true><<<dim3(vhap_cdiv(T, RB), vhap_cdiv(T, TEXB_ROWS)), RB, 0, vhap_stream(stream)>>>(
         c, albedo_hwc, extra, res_mask, d_albedo_hwc, n_gather > 0 ? d_mips_hwc : nullptr, n_gather, d_terms, d_extra,
-        TexAdam{extra, exp_avg, exp_avg_sq, lr_device, step_device, beta1, beta2, eps}, (call_flags & VHAP_CALL_ADAM_STEP_ADVANCED) ? 0 : 1, 0, d_base);
+        TexAdam{extra, exp_avg, exp_avg_sq, lr_device, step_device, beta1, beta2, eps}, (call_flags & VHAP_CALL_ADAM_STEP_ADVANCED) ? 0 : 1, 0, d_base, TexCarry{});
+    VHAP_LAUNCH_CHECK();
+    return VHAP_OK;
+}
+
+// ---- the carried texture (see TexCarry) ----
+extern "C" size_t vhap_tex_carry_halo_floats(int T) {
+    if (T <= 0 || (T % 64)) return 0;
+    return 2 * (tex_carry_row_halo_floats(T) + tex_carry_col_halo_floats(T));
+}
+
+// albedo = painted + extra, level 1 of the pyramid and both parities of the halo copies, from scratch
+extern "C" int vhap_tex_carry_prime(const float* painted, const float* extra, const uint8_t* res_mask, int T, float s_tv, float s_res,
+                                    float* albedo_hwc, float* mips_hwc, float* halo, float* terms, vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!painted || !extra || !albedo_hwc || !mips_hwc || !halo || !terms) return VHAP_E_NULLPTR;
+    if (T <= 0 || (T % 64)) return VHAP_E_BADDIM;
+    hipStream_t st = vhap_stream(stream);
+    vhap_zero_async(terms, 2 * sizeof(float), st);
+    VHAP_LAUNCH_CHECK();
+    TexCfg c{T, s_tv, s_res};
+    const dim3 grid(vhap_cdiv(T, TEX_BCOLS), vhap_cdiv(T, TEX_ROWS));
+    if (res_mask) tex_prep_fwd_kernel<true><<<grid, RB, 0, st>>>(c, painted, extra, res_mask, albedo_hwc, terms, mips_hwc);
+    else tex_prep_fwd_kernel<false><<<grid, RB, 0, st>>>(c, painted, extra, res_mask, albedo_hwc, terms, mips_hwc);
+    VHAP_LAUNCH_CHECK();
+    const size_t n = (tex_carry_row_halo_floats(T) + tex_carry_col_halo_floats(T)) / 3;
+    tex_carry_halo_init_kernel<<<(unsigned)vhap_cdiv((long long)n, RB), RB, 0, st>>>(T, albedo_hwc, halo, halo + 2 * tex_carry_row_halo_floats(T));
+    VHAP_LAUNCH_CHECK();
+    // terms = the texture's energies WITHOUT the TV pairs across the finish pass's ownership tiles -- what vhap_tex_finish_carry leaves
+    // behind -- so that the vhap_tex_carry_border every step issues completes them after a prime as it does after a finish pass
+    const size_t nb = (size_t)(T / TEXB_ROWS - 1) * T + (size_t)T * ((T >> 6) - 1);
+    if (s_tv != 0.f && nb) {
+        tex_carry_border_kernel<<<(unsigned)std::min(vhap_cdiv((long long)nb, RB), 128), RB, 0, st>>>(T, -s_tv, nullptr, 0, halo,
+                                                                                                      halo + 2 * tex_carry_row_halo_floats(T), terms);
+        VHAP_LAUNCH_CHECK();
+    }
+    return VHAP_OK;
+}
+
+// vhap_tex_prep_bwd_adam + the next step's texture: see TexCarry.  d_extra may be NULL (the gradient is consumed here and not written).
+extern "C" int vhap_tex_finish_carry(float* albedo_hwc, float* extra, const uint8_t* res_mask, const float* painted, const float* d_albedo_hwc,
+                                     const float* d_mips_hwc, int n_gather, const float* d_terms, int T, float s_tv, float s_res,
+                                     float* d_extra, float* exp_avg, float* exp_avg_sq, const float* lr_device, const int32_t* step_device,
+                                     float beta1, float beta2, float eps, float* mips_hwc, float* halo, float* terms, int call_flags,
+                                     vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!albedo_hwc || !extra || !painted || !d_terms || !exp_avg || !exp_avg_sq || !lr_device || !step_device || !mips_hwc || !halo || !terms)
+        return VHAP_E_NULLPTR;
+    if (T <= 0 || (T % 64) || n_gather < 0 || n_gather > TEXB_MAXG || (d_mips_hwc && n_gather > 0 && (T & ((1 << n_gather) - 1)))) return VHAP_E_BADDIM;
+    TexCfg c{T, s_tv, s_res};
+    float* col_halo = halo + 2 * tex_carry_row_halo_floats(T);
+    const TexCarry C{painted, mips_hwc, halo, col_halo, terms, d_extra ? 1 : 0};
+    const int step_add = (call_flags & VHAP_CALL_ADAM_STEP_ADVANCED) ? 0 : 1;
+    hipStream_t st = vhap_stream(stream);
+    tex_prep_bwd_kernel<true, true><<<dim3(vhap_cdiv(T, RB), T / TEXB_ROWS), RB, 0, st>>>(
+        c, albedo_hwc, extra, res_mask, d_albedo_hwc, n_gather > 0 ? d_mips_hwc : nullptr, n_gather, d_terms, d_extra ? d_extra : extra,
+        TexAdam{extra, exp_avg, exp_avg_sq, lr_device, step_device, beta1, beta2, eps}, step_add, 0, nullptr, C);
+    VHAP_LAUNCH_CHECK();
+    return VHAP_OK;
+}
+
+// The TV pairs vhap_tex_finish_carry leaves out (those that straddle two of its ownership tiles), added into terms[0] from the halo copies
+// it wrote.  A call of its own so that it need not sit between the finish pass and the pyramid the next step's rasteriser waits for:
+// issue it anywhere behind the finish pass and ahead of (i) the energy assembly that consumes terms and (ii) the next advance of the
+// step counter, whose parity tells which halo copy is the new one (call_flags as given to vhap_tex_finish_carry).
+extern "C" int vhap_tex_carry_border(int T, float s_tv, const int32_t* step_device, const float* halo, float* terms, int call_flags,
+                                     vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!step_device || !halo || !terms) return VHAP_E_NULLPTR;
+    if (T <= 0 || (T % 64)) return VHAP_E_BADDIM;
+    const size_t n = (size_t)(T / TEXB_ROWS - 1) * T + (size_t)T * ((T >> 6) - 1);
+    if (s_tv == 0.f || n == 0) return VHAP_OK;
+    tex_carry_border_kernel<<<(unsigned)std::min(vhap_cdiv((long long)n, RB), 128), RB, 0, vhap_stream(stream)>>>(
+        T, s_tv, step_device, (call_flags & VHAP_CALL_ADAM_STEP_ADVANCED) ? 0 : 1, halo, halo + 2 * tex_carry_row_halo_floats(T), terms);
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;
 }
@@ -635,7 +888,7 @@ extern "C" int vhap_tex_prep_bwd_adam_rows(const float* albedo_hwc, float* extra
     const float* d_base = d_albedo_strip - (size_t)row0 * T * 3;
     tex_prep_bwd_kernel<true><<<dim3(vhap_cdiv(T, RB), nrows / TEXB_ROWS), RB, 0, vhap_stream(stream)>>>(
         c, albedo_hwc, extra, res_mask, d_base, nullptr, 0, d_terms, d_extra,
-        TexAdam{extra, exp_avg, exp_avg_sq, lr_device, step_device, beta1, beta2, eps}, (call_flags & VHAP_CALL_ADAM_STEP_ADVANCED) ? 0 : 1, row0, nullptr);
+        TexAdam{extra, exp_avg, exp_avg_sq, lr_device, step_device, beta1, beta2, eps}, (call_flags & VHAP_CALL_ADAM_STEP_ADVANCED) ? 0 : 1, row0, nullptr, TexCarry{});
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;
 }

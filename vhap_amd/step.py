@@ -283,6 +283,8 @@ class NativeStep:
                                       # at the head of the step, texture update behind its gradient, the rest before the final join
         self.split_tex = False        # True: stop at the gradient pyramid, the caller runs tex_finish() later (pyramid-level exchange under sharding)
         self.feed = None              # dict set by GraphedStep.enable_feed(): the step begins by gathering its batch from an uploaded table (vhap_batch_feed)
+        self.carry = False            # enable_carry(): the texture is CARRIED from step to step (the finish + Adam pass writes the next step's albedo)
+        self.tex_halo = None
         # streams of the library's own (never torch's pool: see _lib.private_stream), shared by every step of this thread
         self.side = _lib.private_stream("side", dev)
         self.side2 = _lib.private_stream("side2", dev)
@@ -321,6 +323,36 @@ class NativeStep:
                 fn()
         self._pending = []
 
+    def enable_carry(self, keep_grad=False):
+        """THE CARRIED TEXTURE (GraphedStep, one GPU, the texture's Adam update fused into the gradient-finishing pass): that pass also
+        rewrites `albedo_tex` in place with painted + the UPDATED tex_extra, writes level 1 of the pyramid and sums this step's TV /
+        residual energies into the log (vhap_tex_finish_carry) -- the forward no longer assembles the texture (tracker.py:237-258 does it at
+        the head of every step: 49 us and 198 MB beside the binning launch and the rasteriser), it only rebuilds pyramid levels >= 2.
+        The caller must run tex_prime() before the first step of a loop and whenever anything else has written tex_extra since
+        (GraphedStep._replay does).  -> True when the step qualifies."""
+        L, T = self.L, self.T
+        ok = self.photometric and self.overlap and self.tex_bwd_on and self.pca is None and T % 64 == 0 and \
+            self.mips.numel() > 0 and _n_gather(T) >= L.vhap_texture_num_levels(T, T) and self.step_optimizer is not None and FUSE_TEX_ADAM and \
+            hasattr(self.step_optimizer, "fused_update_args") and self.step_optimizer.fused_update_args(self.tr.tex_extra) is not None
+        if ok:
+            self.tex_halo = torch.empty(int(L.vhap_tex_carry_halo_floats(T)), dtype=torch.float32, device=self.tr.device)
+            # TV / residual / (unused: PCA) energies of the carried texture: accumulated by the finish pass (or tex_prime) for the NEXT
+            # step, read and cleared by that step's energy assembly -- outside the forward accumulators, which the step clears at its end
+            self.carry_terms = torch.zeros(4, dtype=torch.float32, device=self.tr.device)
+            self.carry_keep_grad = bool(keep_grad)
+            if not keep_grad:
+                # the gradient is consumed inside the pass and not written (50 MB per step that nothing reads): rather no .grad than a stale
+                # one (VHAP_TEX_KEEP_GRAD=1 keeps it)
+                self.tr.tex_extra.grad = None
+        self.carry = bool(ok)
+        return self.carry
+
+    def tex_prime(self):
+        """albedo, pyramid level 1 and the halo copies of the carried texture from painted + tex_extra, from scratch (current stream)."""
+        _chk(self.L.vhap_tex_carry_prime(_p(self.painted), _p(self.tr.tex_extra), _p(self.nm["res_mask"]), self.T, *self.tex_scales,
+                                         _p(self.albedo_tex), _p(self.mips), _p(self.tex_halo), _p(self.carry_terms), _stream()),
+             "vhap_tex_carry_prime")
+
     def _feed_batch(self):
         """The step's own batch hand-over (vhap_batch_feed): the next batch of the uploaded table -> timesteps, frame indices, landmarks
         (+ per-view cameras) in the static buffers the kernels read; the frame ingest follows on the texture branch (its output, the target
@@ -349,7 +381,19 @@ class NativeStep:
         if self.pca is not None and self.tex_fwd_on:
             _chk(L.vhap_tex_pca_fwd(_p(self.pca_mean), _p(self.pca_basis), _p(tr.tex_pca), int(tr.tex_pca.shape[0]), self.pca.src_size, T,
                                     self.pca_scale, _p(self.pca_src), _p(self.painted), _p(acc[9:10]), st), "vhap_tex_pca_fwd")
-        if self.tex_fwd_on and self.photometric and T % 2 == 0 and self.mips.numel() > 0:
+        if self.carry:
+            # the carried texture: albedo, pyramid level 1 and the TV / residual energies (carry_terms) were written by the previous step's
+            # finish + Adam pass (or tex_prime())
+            _chk(L.vhap_texture_mip_build_from(_p(self.albedo_tex), 1, T, T, 3, _p(self.mips), 2, st), "vhap_texture_mip_build_from")
+            if ready is not None:
+                ready()
+                ready = None
+            # ... but for the TV pairs across the finish pass's ownership tiles: from its halo copies, BEHIND the pyramid (the rasteriser
+            # waits for that; only the energy assembly reads the terms) and ahead of this step's advance of the counter (side_work, issued
+            # behind this branch on the same stream), whose parity says which halo copy is the new one (after tex_prime() the two are the same)
+            _chk(L.vhap_tex_carry_border(T, self.tex_scales[0], _p(self.step_optimizer.step_count), _p(self.tex_halo), _p(self.carry_terms),
+                                         _lib.CALL_ADAM_STEP_ADVANCED, st), "vhap_tex_carry_border")
+        elif self.tex_fwd_on and self.photometric and T % 2 == 0 and self.mips.numel() > 0:
             # texture assembly + TV / residual energies + level 1 of the pyramid in one pass; the rest of the pyramid four levels per launch
             _chk(L.vhap_tex_prep_mip1_fwd(_p(self.painted), _p(tr.tex_extra), _p(self.nm["res_mask"]), T, *self.tex_scales, _p(self.albedo_tex),
                                           _p(self.mips), _p(acc[7:10]), PRE, st), "vhap_tex_prep_mip1_fwd")
@@ -513,9 +557,11 @@ class NativeStep:
         _chk(L.vhap_antialias_fwd(_p(color), _p(self.rast), _p(self.clip), _p(self.tri), _p(self.opp), B, H, W, 4, V, F, _p(self.rgba_aa),
                                   _p(self.aa_work), st), "vhap_antialias_fwd")
         _chk(L.vhap_photo_fwd(_p(self.rgba_aa), _p(self.rgb), B, H, W, _p(acc[16:18]), PRE, st), "vhap_photo_fwd")
-        _chk(L.vhap_energy_finalize(_p(acc[0:6]), _p(acc[6:7]) if self.w_lmk else 0, _p(acc[7:10]), _p(acc[20:24]),
-                                    _p(acc[12:16]) if self.want_reg else 0, self.w_lmk, self.w_reg, B, H, W, _p(self.log), st),
+        _chk(L.vhap_energy_finalize(_p(acc[0:6]), _p(acc[6:7]) if self.w_lmk else 0, _p(self.carry_terms) if self.carry else _p(acc[7:10]),
+                                    _p(acc[20:24]), _p(acc[12:16]) if self.want_reg else 0, self.w_lmk, self.w_reg, B, H, W, _p(self.log), st),
              "vhap_energy_finalize")
+        if self.carry:
+            self.carry_terms.zero_()            # consumed (the deferred step's energy assembly does it itself: VHAP_CALL_TEX_TERMS_CONSUME)
 
     def _forward_deferred(self):
         """binning || vertex normals -> rasterise + interpolate + texture + shade + composite in ONE kernel -> disturbance -> antialias ->
@@ -623,9 +669,10 @@ class NativeStep:
             # no cross-queue hand-overs -- between the forward and the backward pass)
             self._join()          # the side branch: texture assembly, landmarks, statistics, arena clear, antialias pair discovery
             _chk(L.vhap_photo_fwd_total(_p(self.rgba_aa), _p(self.rgb), B, H, W, _p(acc[16:19]), _p(acc[0:6]), _p(acc[6:7]) if self.w_lmk else 0,
-                                        _p(acc[7:10]), _p(acc[20:24]), _p(acc[12:16]), self.w_lmk, self.w_reg, self.w_photo,
-                                        _p(self.log), _p(self.d_sum), _p(self.gmax_bound), _p(self.photo_work),
-                                        _p(self.aa_work) if self.aa_early_bwd else 0, _p(self.d_delta) if self.aa_early_bwd else 0, PRE, st),
+                                        _p(self.carry_terms) if self.carry else _p(acc[7:10]), _p(acc[20:24]), _p(acc[12:16]), self.w_lmk,
+                                        self.w_reg, self.w_photo, _p(self.log), _p(self.d_sum), _p(self.gmax_bound), _p(self.photo_work),
+                                        _p(self.aa_work) if self.aa_early_bwd else 0, _p(self.d_delta) if self.aa_early_bwd else 0,
+                                        PRE | (_lib.CALL_TEX_TERMS_CONSUME if self.carry else 0), st),
                  "vhap_photo_fwd_total")
             self._delta_dirty = self.aa_early_bwd
             if sort_branch is not None and self.one_graph:
@@ -636,9 +683,11 @@ class NativeStep:
             return
         _chk(L.vhap_photo_fwd(_p(self.rgba_aa), _p(self.rgb), B, H, W, _p(acc[16:18]), PRE, st), "vhap_photo_fwd")
         self._join()
-        _chk(L.vhap_energy_finalize(_p(acc[0:6]), _p(acc[6:7]) if self.w_lmk else 0, _p(acc[7:10]), _p(acc[20:24]),
-                                    _p(acc[12:16]) if self.want_reg else 0, self.w_lmk, self.w_reg, B, H, W, _p(self.log), st),
+        _chk(L.vhap_energy_finalize(_p(acc[0:6]), _p(acc[6:7]) if self.w_lmk else 0, _p(self.carry_terms) if self.carry else _p(acc[7:10]),
+                                    _p(acc[20:24]), _p(acc[12:16]) if self.want_reg else 0, self.w_lmk, self.w_reg, B, H, W, _p(self.log), st),
              "vhap_energy_finalize")
+        if self.carry:
+            self.carry_terms.zero_()
 
     def _disturb(self, st):
         """colour disturbance, in place on rgba (render_nvdiffrast.py:424-460); random numbers drawn in-kernel, or -- `self.injected`, a
@@ -702,6 +751,14 @@ class NativeStep:
         if has_mips and ng < L.vhap_texture_num_levels(T, T):      # (texture sizes whose coarse levels cannot be gathered: fold them first)
             _chk(L.vhap_texture_mip_fold(_p(d_tex), _p(d_mips), 1, T, T, 3, ng, st), "vhap_texture_mip_fold")
         fu = optimizer.fused_update_args(tr.tex_extra) if (FUSE_TEX_ADAM and optimizer is not None and hasattr(optimizer, "fused_update_args")) else None
+        if fu is not None and self.carry:
+            m, v, lr, step, b1, b2, eps = fu
+            assert has_mips and ng >= L.vhap_texture_num_levels(T, T)
+            _chk(L.vhap_tex_finish_carry(_p(self.albedo_tex), _p(tr.tex_extra), _p(self.nm["res_mask"]), _p(self.painted), _p(d_tex), _p(d_mips), ng,
+                                         _p(self.ones), T, *self.tex_scales, _p(g["tex_extra"]) if self.carry_keep_grad else 0, _p(m), _p(v),
+                                         _p(lr), _p(step), b1, b2, eps, _p(self.mips), _p(self.tex_halo), _p(self.carry_terms),
+                                         _lib.CALL_ADAM_STEP_ADVANCED, st), "vhap_tex_finish_carry")
+            return True
         if fu is not None:
             m, v, lr, step, b1, b2, eps = fu
             flags = _lib.CALL_ADAM_STEP_ADVANCED if self.step_optimizer is not None else 0
@@ -800,7 +857,9 @@ class NativeStep:
                                            _p(self.keep) if self.disturb_on else 0, _p(self.c_reg) if self.want_reg else 0,
                                            _p(acc[12:16]) if self.want_reg else 0, B, V, self.uv.shape[0], F, H, W, _p(self.texc), _p(self.texd),
                                            _p(self.d_albedo), _p(self.d_normal), _p(self.d_texc), _p(self.d_texd), 0,
-                                           _p(self.def_work), self.def_work.numel(), 0, 0, self.delta_flag, st),
+                                           _p(self.def_work), self.def_work.numel(), 0, 0,
+                                           # (the texture gradient walks the sorted list of covered pixels -- or does not run at all: background d_albedo is never read)
+                                           self.delta_flag | (_lib.CALL_SKIP_BG_GRAD if (self.tb_ids or not self.tex_bwd_on) else 0), st),
                  "vhap_deferred_shade_bwd")
             if after_first is not None and early_aa:          # (the main chain's kernel first, then the side branches forked behind the sum)
                 after_first()

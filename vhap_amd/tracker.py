@@ -1275,7 +1275,8 @@ class GraphedStep:
     # What the shipped photometric step is EXPECTED to leave open / start early (documentation and the tests' cross-check; the decision
     # itself is made on the buffers: CapturedPlan.deferred_join_hazards): the texture gradient's sort -- workspace clear, count, scan,
     # scatter -- its tile pass, the texture finish + Adam; and the geometry head
-    TEX_TAIL = ("vhap_zero_words_kernel", "texbin_pass_kernel", "texbin_scan_kernel", "texgrad_tile_kernel", "tex_prep_bwd_kernel")
+    TEX_TAIL = ("vhap_zero_words_kernel", "texbin_pass_kernel", "texbin_scan_kernel", "texgrad_tile_kernel", "tex_prep_bwd_kernel",
+                "tex_carry_border_kernel")
     GEOMETRY_HEAD = ("camera_fwd_kernel", "frame_prep_fwd_kernel", "flame_skin_fwd_kernel", "flame_skin_clip_fwd_kernel", "bin_build_kernel")
 
     def __init__(self, tracker, sample, optimizer, stage, warmup=2, unroll=1, feed=False):
@@ -1350,6 +1351,11 @@ class GraphedStep:
                 split = tex is not None and any(p is tex for p in self.params) and len(self.params) > 1 and ns.tex_bwd_on and \
                     ns.photometric and ns.overlap and hasattr(optimizer, "advance")
                 ns.step_optimizer = optimizer if split else None
+                # the carried texture (step.py: enable_carry): the finish + Adam pass hands the next replay its albedo + pyramid level 1;
+                # replays prime it when they cannot know it is current (_carry_prime_if_needed)
+                self._carry_epoch, self._carry_loop = None, 0
+                if split and os.environ.get("VHAP_TEX_CARRY", "1") != "0":
+                    ns.enable_carry(keep_grad=os.environ.get("VHAP_TEX_KEEP_GRAD", "0") == "1")
                 if ns.photometric:
                     ns.one_graph = True
                     ns.accF.zero_()
@@ -1601,6 +1607,7 @@ class GraphedStep:
         else:
             self._replay()
         self.tr.global_step += self.unroll
+        self.opt._opt_called = True        # (the replay WAS optimizer.step(): torch's lr schedulers look for this flag and warn otherwise)
         return self.E
 
     def replay_stream(self):
@@ -1616,6 +1623,7 @@ class GraphedStep:
                 self.ctx = torch.cuda.stream(step.stream)
                 self.ctx.__enter__()
                 step._in_loop = True
+                step._carry_loop = getattr(step, "_carry_loop", 0) + 1
                 return step
 
             def __exit__(self, *a):
@@ -1644,8 +1652,25 @@ class GraphedStep:
         for w in works or ():
             w.wait()
 
+    def _carry_prime_if_needed(self):
+        """The carried texture is current iff the LAST thing that wrote tex_extra was this step's own finish pass.  That is taken for granted
+        only between consecutive replays of ONE replay_stream() loop, with the tensor's version counter unchanged and no other step having
+        replayed in between; a lone replay, the first replay of a loop and anything that looks different re-assemble it (vhap_tex_carry_prime:
+        what tex_prep_fwd did every step, ~60 us)."""
+        tr, ns = self.tr, self.ns
+        epoch = (self._carry_loop if self._in_loop else None, tr.tex_extra._version, id(self))
+        if self._in_loop and self._carry_epoch == epoch and getattr(tr, "_tex_carrier", None) is self:
+            return
+        if self.defer_join:
+            self.gF.join()                                         # (an open tail of the last replay is still writing the texture)
+        ns.tex_prime()
+        self._carry_epoch = epoch
+        tr._tex_carrier = self
+
     def _replay(self):
         tr = self.tr
+        if not (self.ns is not None and self.single and self.ns.carry):
+            tr._tex_carrier = None                                 # (this replay's Adam update writes tex_extra behind a carrying step's back)
         if getattr(self, "_tex_gather", None) == "comm" and self._in_loop and self.gF.plan is not None and self.gF.side_base == 0 and \
                 os.environ.get("VHAP_SHARD_PRECISE_WAIT", "1") != "0":
             # only the forward plan's TEXTURE CHAIN (a root of the plan on its first side stream: assembly + pyramid, then the arena clear and
@@ -1655,6 +1680,8 @@ class GraphedStep:
             self._tex_gather = None
         self.wait_texture()
         if self.ns is not None and self.single:
+            if self.ns.carry:
+                self._carry_prime_if_needed()
             self.gF.replay(defer_join=self.defer_join and self._in_loop)
             return
         self.gF.replay()
