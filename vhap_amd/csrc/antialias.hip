@@ -144,101 +144,121 @@ __global__ __launch_bounds__(256) void aa_silhouette_kernel(const float4* __rest
 //   detect: stream over the pixels -- out = color, and every neighbouring pair whose front triangle has a silhouette edge is
 //           appended to a compact candidate list (one atomic per wave);
 //   blend:  one lane per candidate: analyse(), blend, append the work item for the backward.
-constexpr int DET_T = 1024, DET_PPT = 4;      // detect: 1024 lanes x 4 pixels per workgroup
+// 256-thread workgroups (round 6; they were 1 024 threads with 32 KB of LDS): a 1 024-thread workgroup needs sixteen free wave slots on
+// ONE CU at the same moment, and beside the disturbance's colour-pool kernels -- which is where this pass runs -- it waited for them to
+// drain: 98 us in the step for 33 us of work, and the blend waits for it (profiles/r06_call8_step_timeline.txt).  A workgroup still owns
+// DET_CHUNKS x 1 024 consecutive pixels and keeps its candidates in LDS until the list could overflow, so the returning atomic on the
+// ONE global counter is as rare as before.
+constexpr int DET_T = 256, DET_PPT = 4, DET_CHUNKS = 4;      // detect: 256 lanes x 4 pixels per chunk, 4 chunks per workgroup
+constexpr int DET_LCAP = 2 * DET_T * DET_PPT * 2;            // LDS candidate slots (16 KB): room for two full chunks
 template <int C>
 __global__ __launch_bounds__(DET_T) void aa_detect_kernel(const float* __restrict__ color, const float4* __restrict__ rast,
                                                           const unsigned char* __restrict__ sil, int B, int H, int W, int F,
                                                           float* __restrict__ out, int* __restrict__ work, unsigned* __restrict__ cand,
                                                           int dbg) {
-    // candidates are compacted per workgroup in LDS first: a returning atomic on ONE global counter serialises (~12 ns each),
-    // so it is issued once per 4096 pixels, not once per wave
-    __shared__ unsigned lcand[2 * DET_T * DET_PPT];
+    __shared__ unsigned lcand[DET_LCAP];
     __shared__ int lcount, gbase;
     if (threadIdx.x == 0) lcount = 0;
     __syncthreads();
     const unsigned npix = (unsigned)B * H * W;             // < 2^30 (checked by the entry point): 32-bit index math
     const unsigned HW = (unsigned)H * W;
     const int lane = threadIdx.x & 63;
-    // Three batches of loads for the thread's DET_PPT pixels -- the pixel's own rast word, its two neighbours' and its colour; then the
-    // silhouette bytes of the pairs that need one -- instead of eight dependent round trips per pixel (rast -> neighbour -> flag, twice,
-    // and the colour copy between them): this pass is 4 MB of flags and 130 MB of streaming, and it was 32 round trips long.
-    float zw0[DET_PPT][2], zw1[DET_PPT][2][2];
-    float colc[DET_PPT][C];
-#pragma unroll
-    for (int it = 0; it < DET_PPT; it++) {
-        const unsigned pi = (blockIdx.x * DET_PPT + it) * DET_T + threadIdx.x;
-        const unsigned pc = pi < npix ? pi : npix - 1u;
-        const unsigned px1 = min(pc + 1u, npix - 1u), py1 = min(pc + (unsigned)W, npix - 1u);
-        zw0[it][0] = rast[pc].z; zw0[it][1] = rast[pc].w;
-        zw1[it][0][0] = rast[px1].z; zw1[it][0][1] = rast[px1].w;
-        zw1[it][1][0] = rast[py1].z; zw1[it][1][1] = rast[py1].w;
-        if (out) {
-            if constexpr (C == 4) {
-                const float4 v4 = reinterpret_cast<const float4*>(color)[pc];
-                colc[it][0] = v4.x; colc[it][1] = v4.y; colc[it][2] = v4.z; colc[it][3] = v4.w;
-            } else {
-#pragma unroll
-                for (int k = 0; k < C; k++) colc[it][k] = color[(size_t)pc * C + k];
-            }
+    auto flush = [&]() {                                   // (all threads; lcount settled by a barrier before the call, nobody adds to it meanwhile)
+        const int n = lcount;
+        __syncthreads();
+        if (n != 0) {                                      // (uniform)
+            if (threadIdx.x == 0) gbase = atomicAdd(&work[1], n);
+            __syncthreads();
+            for (int i = threadIdx.x; i < n; i += DET_T) cand[gbase + i] = lcand[i];
+            __syncthreads();
+            if (threadIdx.x == 0) lcount = 0;
+            __syncthreads();
         }
-    }
-    int cnd[DET_PPT][2];
-    unsigned sv[DET_PPT][2];
-    const unsigned char* sil_q = sil ? sil : reinterpret_cast<const unsigned char*>(rast);      // (stand-in address: values unused)
+    };
+    for (int ch = 0; ch < DET_CHUNKS; ch++) {
+        const unsigned base = ((unsigned)blockIdx.x * DET_CHUNKS + (unsigned)ch) * (DET_PPT * DET_T);
+        if (base >= npix) break;                           // (uniform)
+        // Three batches of loads for the thread's DET_PPT pixels -- the pixel's own rast word, its two neighbours' and its colour; then the
+        // silhouette bytes of the pairs that need one -- instead of eight dependent round trips per pixel (rast -> neighbour -> flag, twice,
+        // and the colour copy between them): this pass is 4 MB of flags and 130 MB of streaming, and it was 32 round trips long.
+        float zw0[DET_PPT][2], zw1[DET_PPT][2][2];
+        float colc[DET_PPT][C];
 #pragma unroll
-    for (int it = 0; it < DET_PPT; it++) {
-        const unsigned pi = (blockIdx.x * DET_PPT + it) * DET_T + threadIdx.x;
-        const bool live = pi < npix;
-        const unsigned b = live ? pi / HW : 0u;
-        const unsigned rem = pi - b * HW;
-        const int py = (int)(rem / (unsigned)W), px = (int)(rem - (unsigned)py * W);
-        const int t0 = (int)zw0[it][1] - 1;
+        for (int it = 0; it < DET_PPT; it++) {
+            const unsigned pi = base + it * DET_T + threadIdx.x;
+            const unsigned pc = pi < npix ? pi : npix - 1u;
+            const unsigned px1 = min(pc + 1u, npix - 1u), py1 = min(pc + (unsigned)W, npix - 1u);
+            zw0[it][0] = rast[pc].z; zw0[it][1] = rast[pc].w;
+            zw1[it][0][0] = rast[px1].z; zw1[it][0][1] = rast[px1].w;
+            zw1[it][1][0] = rast[py1].z; zw1[it][1][1] = rast[py1].w;
+            if (out) {
+                if constexpr (C == 4) {
+                    const float4 v4 = reinterpret_cast<const float4*>(color)[pc];
+                    colc[it][0] = v4.x; colc[it][1] = v4.y; colc[it][2] = v4.z; colc[it][3] = v4.w;
+                } else {
 #pragma unroll
-        for (int d = 0; d < 2; d++) {
-            bool c = false;
-            int tf = 0;
-            if (live && !(d == 0 ? px + 1 >= W : py + 1 >= H) && !(dbg & 1024)) {
-                const int t1 = (int)zw1[it][d][1] - 1;
-                if (t0 != t1 && t0 < F && t1 < F) {
-                    // the triangle analyse() will pick: the nearer one; a background pixel never wins
-                    tf = (t0 >= 0 && t1 >= 0) ? (zw0[it][0] < zw1[it][d][0] ? t0 : t1) : (t0 >= 0 ? t0 : t1);
-                    c = true;
+                    for (int k = 0; k < C; k++) colc[it][k] = color[(size_t)pc * C + k];
                 }
             }
-            cnd[it][d] = c ? 1 : 0;
-            sv[it][d] = (unsigned)sil_q[c && sil ? (size_t)b * F + tf : (size_t)0];
         }
-    }
+        int cnd[DET_PPT][2];
+        unsigned sv[DET_PPT][2];
+        const unsigned char* sil_q = sil ? sil : reinterpret_cast<const unsigned char*>(rast);      // (stand-in address: values unused)
 #pragma unroll
-    for (int it = 0; it < DET_PPT; it++) {
-        const unsigned pi = (blockIdx.x * DET_PPT + it) * DET_T + threadIdx.x;
-        const bool live = pi < npix;
-        if (live && out) {
-            if constexpr (C == 4) {
-                reinterpret_cast<float4*>(out)[pi] = make_float4(colc[it][0], colc[it][1], colc[it][2], colc[it][3]);
-            } else {
+        for (int it = 0; it < DET_PPT; it++) {
+            const unsigned pi = base + it * DET_T + threadIdx.x;
+            const bool live = pi < npix;
+            const unsigned b = live ? pi / HW : 0u;
+            const unsigned rem = pi - b * HW;
+            const int py = (int)(rem / (unsigned)W), px = (int)(rem - (unsigned)py * W);
+            const int t0 = (int)zw0[it][1] - 1;
 #pragma unroll
-                for (int k = 0; k < C; k++) out[(size_t)pi * C + k] = colc[it][k];
+            for (int d = 0; d < 2; d++) {
+                bool c = false;
+                int tf = 0;
+                if (live && !(d == 0 ? px + 1 >= W : py + 1 >= H) && !(dbg & 1024)) {
+                    const int t1 = (int)zw1[it][d][1] - 1;
+                    if (t0 != t1 && t0 < F && t1 < F) {
+                        // the triangle analyse() will pick: the nearer one; a background pixel never wins
+                        tf = (t0 >= 0 && t1 >= 0) ? (zw0[it][0] < zw1[it][d][0] ? t0 : t1) : (t0 >= 0 ? t0 : t1);
+                        c = true;
+                    }
+                }
+                cnd[it][d] = c ? 1 : 0;
+                sv[it][d] = (unsigned)sil_q[c && sil ? (size_t)b * F + tf : (size_t)0];
             }
         }
 #pragma unroll
-        for (int d = 0; d < 2; d++) {
-            const bool c = cnd[it][d] != 0 && (sil == nullptr || sv[it][d] != 0u);
-            const unsigned long long m = __ballot(c);
-            if (m == 0ull) continue;
-            const int leader = __ffsll((long long)m) - 1;
-            int base = 0;
-            if (lane == leader) base = atomicAdd(&lcount, __popcll(m));
-            base = __shfl(base, leader, 64);
-            if (c) lcand[base + __popcll(m & ((1ull << lane) - 1ull))] = (pi << 1) | (unsigned)d;
+        for (int it = 0; it < DET_PPT; it++) {
+            const unsigned pi = base + it * DET_T + threadIdx.x;
+            const bool live = pi < npix;
+            if (live && out) {
+                if constexpr (C == 4) {
+                    reinterpret_cast<float4*>(out)[pi] = make_float4(colc[it][0], colc[it][1], colc[it][2], colc[it][3]);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < C; k++) out[(size_t)pi * C + k] = colc[it][k];
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < 2; d++) {
+                const bool c = cnd[it][d] != 0 && (sil == nullptr || sv[it][d] != 0u);
+                const unsigned long long m = __ballot(c);
+                if (m == 0ull) continue;
+                const int leader = __ffsll((long long)m) - 1;
+                int lbase = 0;
+                if (lane == leader) lbase = atomicAdd(&lcount, __popcll(m));
+                lbase = __shfl(lbase, leader, 64);
+                if (c) lcand[lbase + __popcll(m & ((1ull << lane) - 1ull))] = (pi << 1) | (unsigned)d;
+            }
         }
+        __syncthreads();
+        // a chunk adds at most 2 x DET_T x DET_PPT candidates: hand the list over when the next chunk might not fit
+        const int lc = lcount;
+        __syncthreads();                                   // (every thread has read the SAME count before the next chunk's waves add to it)
+        if (lc > DET_LCAP - 2 * DET_T * DET_PPT) flush();
     }
-    __syncthreads();
-    const int n = lcount;
-    if (n == 0) return;
-    if (threadIdx.x == 0) gbase = atomicAdd(&work[1], n);
-    __syncthreads();
-    for (int i = threadIdx.x; i < n; i += DET_T) cand[gbase + i] = lcand[i];
+    flush();
 }
 
 template <int C>
@@ -539,7 +559,7 @@ extern "C" int vhap_antialias_fwd(const float* color, const float* rast, const f
     const int dbg = vhap_g_debug_flags;
     return dispatch_C(C, [&](auto c) {
         constexpr int CC = decltype(c)::value;
-        aa_detect_kernel<CC><<<vhap_cdiv(npix, DET_T * DET_PPT), DET_T, 0, st>>>(color, reinterpret_cast<const float4*>(rast), (dbg & 2048) ? nullptr : sil, B, H, W,
+        aa_detect_kernel<CC><<<vhap_cdiv(npix, DET_T * DET_PPT * DET_CHUNKS), DET_T, 0, st>>>(color, reinterpret_cast<const float4*>(rast), (dbg & 2048) ? nullptr : sil, B, H, W,
                                                                    F, out, work, cand, dbg);
         VHAP_LAUNCH_CHECK();
         aa_blend_kernel<CC><<<1024, 256, 0, st>>>(color, reinterpret_cast<const float4*>(rast), reinterpret_cast<const float4*>(pos), tri, opp,
@@ -589,7 +609,7 @@ extern "C" int vhap_antialias_inplace_fwd(float* color, const float* rast, const
     unsigned* cand = reinterpret_cast<unsigned*>(work + 4 + (size_t)ITEM2 * 2 * (size_t)npix + ((size_t)B * F + 3) / 4);
     aa_silhouette_kernel<<<vhap_cdiv((long long)B * F, 256), 256, 0, st>>>(reinterpret_cast<const float4*>(pos), tri, opp, B, V, F, H, W, sil, work);
     VHAP_LAUNCH_CHECK();
-    aa_detect_kernel<4><<<vhap_cdiv(npix, DET_T * DET_PPT), DET_T, 0, st>>>(nullptr, reinterpret_cast<const float4*>(rast), sil, B, H, W, F, nullptr,
+    aa_detect_kernel<4><<<vhap_cdiv(npix, DET_T * DET_PPT * DET_CHUNKS), DET_T, 0, st>>>(nullptr, reinterpret_cast<const float4*>(rast), sil, B, H, W, F, nullptr,
                                                                           work, cand, 0);
     VHAP_LAUNCH_CHECK();
     aa_blend2_kernel<<<1024, 256, 0, st>>>(reinterpret_cast<const float4*>(color), reinterpret_cast<const float4*>(rast),
@@ -624,7 +644,7 @@ extern "C" int vhap_antialias_inplace_pairs(const float* rast, int B, int H, int
     const long long npix = (long long)B * H * W;
     unsigned char* sil = reinterpret_cast<unsigned char*>(work + 4 + (size_t)ITEM2 * 2 * (size_t)npix);
     unsigned* cand = reinterpret_cast<unsigned*>(work + 4 + (size_t)ITEM2 * 2 * (size_t)npix + ((size_t)B * F + 3) / 4);
-    aa_detect_kernel<4><<<vhap_cdiv(npix, DET_T * DET_PPT), DET_T, 0, vhap_stream(stream)>>>(nullptr, reinterpret_cast<const float4*>(rast), sil, B, H, W, F,
+    aa_detect_kernel<4><<<vhap_cdiv(npix, DET_T * DET_PPT * DET_CHUNKS), DET_T, 0, vhap_stream(stream)>>>(nullptr, reinterpret_cast<const float4*>(rast), sil, B, H, W, F,
                                                                                             nullptr, work, cand, 0);
     VHAP_LAUNCH_CHECK();
     return VHAP_OK;

@@ -98,7 +98,7 @@ __device__ __forceinline__ void gb_tile_commit(GbTile& S, const float (&acc)[18]
     // Why: the table's LDS atomics are the kernel's bottleneck, not its gathers -- a wave's 64 lanes hit ~10 distinct vertex slots,
     // ds_add_u64 costs ~2 cycles per lane that shares an address (tools/ubench/lds_atomics.hip), there are 18 per covered pixel, and the CU
     // has ONE LDS pipe for its four SIMDs: 25 M lane-atomics per 16 x 512^2 step = ~80 us of the kernel's 117.  A triangle of a head frame
-    // covers ~17 pixels, runs of ~4 along a row: three butterfly levels over the 16 lanes of a tile row (lane ^ 1, ^ 2, then + 4 -- DPP
+    // covers ~17 pixels, runs of ~4 along a row: four butterfly levels over the 16 lanes of a tile row (lane ^ 1, ^ 2, then + 4, + 8 -- DPP
     // moves on the VALU, which is per SIMD) leave one lane per run to do the atomics.  The partial sums are fp32 in a FIXED tree order
     // (deterministic; the fixed-point form of the 18 values would cost 36 more registers and three of the kernel's seven waves per SIMD).
     float a[18];
@@ -132,6 +132,9 @@ __device__ __forceinline__ void gb_tile_commit(GbTile& S, const float (&acc)[18]
         level(x1, x1, !(lane & 1), true);
         level(x2, x2, !(lane & 2), true);
         level(l4, r4, !(lane & 4), false);
+        auto l8 = [](int x) { return __builtin_amdgcn_mov_dpp(x, 0x108, 0xF, 0xF, true); };     // row_shl:8 / row_shr:8: the two halves of a tile row
+        auto r8 = [](int x) { return __builtin_amdgcn_mov_dpp(x, 0x118, 0xF, 0xF, true); };     // (runs longer than 8 pixels: the 1024^2 frames)
+        level(l8, r8, !(lane & 8), false);
     }
     if (alive && !(dbg & 256)) {
         {
