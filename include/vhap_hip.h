@@ -797,6 +797,10 @@ int vhap_plan_set_side_base(int base);
 int vhap_plan_touch_side_streams(int n, void* scratch_4_bytes);
 /* pool stream k waits for what is enqueued on `other` now (an external dependency of ONE side chain of the next replay) */
 int vhap_plan_side_stream_wait(int k, vhap_stream_t other);
+/* The calling thread's side-stream pools, destroyed (every device; each stream synchronised first): for short-lived worker threads that
+ * created plans.  Plans of this thread must not be replayed afterwards.  All plans created on one thread SHARE its pool streams (side stream k of
+ * every plan is the same HIP stream): replays of unrelated plans serialise behind each other's open tails on those streams.  (ABI 10) */
+int vhap_plan_pool_release(void);
 int vhap_plan_launch(vhap_plan_t plan, vhap_stream_t stream, int call_flags);
 int vhap_plan_join(vhap_plan_t plan, vhap_stream_t stream);
 /* the nodes a DEFER_JOIN replay leaves un-joined (indices into launch order, at most `cap` written); returns their number */

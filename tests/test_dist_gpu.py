@@ -238,6 +238,12 @@ def _worker_rccl_one_rank(rank, world, port, T, ret, lr_scale, n_steps, tex_shar
     st = GraphedStep(tr, tr.get_sample(np.arange(4), device_index=True), opt, "rgb_global_tracking", warmup=0)
     assert st.ns is not None and not st.single and st.tex_sharded == tex_sharded and not st.ns.energy_fused
     assert st.tex_path == tex_sharded and st.tex_first == (tex_sharded and tex_first)
+    if tex_sharded:
+        # the precise wait (only the forward plan's texture chain waits for the communication stream) is DECIDED on the buffers the
+        # captured calls were given: yes for the shipped step, and the same check says no for a buffer the geometry head reads
+        assert st._precise_ok, st._precise_report
+        bad = st.gF.nodes_touching_not_behind(st._accessF, [(tr.shape.data_ptr(), 4)], 1)
+        assert bad and any("frame_prep" in nm for _, nm, _ in bad), bad
     with st.replay_stream():
         E = [float(st()) for _ in range(n_steps)]
     torch.cuda.synchronize()

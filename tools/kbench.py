@@ -17,6 +17,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--config", type=int, default=2)
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--only", default="")
+ap.add_argument("--cold", action="store_true", help="every timed call starts with cold caches (1 GiB written in between: L2 and the 256 MB "
+                "Infinity Cache hold nothing of the call's inputs) -- what a kernel sees inside the step, where ~1 GB of other traffic "
+                "flows between its producer and it; the median of --reps single calls")
 args = ap.parse_args()
 C = bench.CONFIGS[args.config]
 tr, own, n_local, model, topo, gt = bench.build_tracker(C, 0, 1, "cuda:0", "weak")
@@ -71,6 +74,10 @@ calls = {
     "antialias_inplace_fwd": lambda: L.vhap_antialias_inplace_fwd(_p(ns.aa_in), _p(ns.rast), _p(ns.clip), _p(ns.tri), _p(ns.opp), B, H, W, V, F,
                                                                   _p(ns.aa_work), st()),
     "photo_fwd": lambda: L.vhap_photo_fwd(_p(ns.rgba_aa), _p(ns.rgb), B, H, W, _p(acc[16:18]), PRE, st()),
+    "photo_fwd_total (sum + energy assembly + antialias colour job: the shipped launch)": (lambda: L.vhap_photo_fwd_total(
+        _p(ns.rgba_aa), _p(ns.rgb), B, H, W, _p(acc[16:19]), _p(acc[0:6]), _p(acc[6:7]) if ns.w_lmk else 0, _p(acc[7:10]), _p(acc[20:24]), _p(acc[12:16]),
+        ns.w_lmk, ns.w_reg, ns.w_photo, _p(ns.log), _p(ns.d_sum), _p(ns.gmax_bound), _p(ns.photo_work), _p(ns.aa_work) if ns.aa_early_bwd else 0,
+        _p(ns.d_delta) if ns.aa_early_bwd else 0, 0, st())) if ns.deferred else None,
     "antialias_photo_bwd + clear": lambda: (L.vhap_antialias_photo_bwd(_p(ns.rgba_aa), _p(ns.rgb), _p(ns.d_sum), _p(ns.rast), _p(ns.clip), _p(ns.tri),
                                                                      _p(ns.opp), _p(ns.aa_work), _p(ns.vert_mask), B, H, W, V, F, _p(ns.d_delta),
                                                                      _p(g["d_clip"]), st()), ns._clear_delta()),
@@ -119,6 +126,20 @@ for name, fn in calls.items():
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
+    if args.cold:
+        if "scratch" not in globals():
+            scratch = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
+        ts = []
+        for _ in range(args.reps):
+            scratch.fill_(1.0)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            fn()
+            b.record()
+            b.synchronize()
+            ts.append(a.elapsed_time(b) * 1e3)
+        print(f"{float(np.median(ts)):9.1f} us  {name}   (cold caches, median of {args.reps})")
+        continue
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(args.reps):

@@ -131,6 +131,7 @@ SIGNATURES = {
     "vhap_plan_set_side_base": (c_i, [c_i]),
     "vhap_plan_touch_side_streams": (c_i, [c_i, c_fp]),
     "vhap_plan_side_stream_wait": (c_i, [c_i, c_fp]),
+    "vhap_plan_pool_release": (c_i, []),
     "vhap_plan_info": (c_i, [c_fp] + [ctypes.POINTER(c_i)] * 3),
     "vhap_plan_describe": (c_sz, [c_fp, ctypes.c_char_p, c_sz]),
     "vhap_plan_node_name": (c_i, [c_fp, c_i, ctypes.c_char_p, c_sz]),

@@ -82,19 +82,22 @@ struct SidePool {
     int device = -1;
     bool least_priority = false;
     std::vector<hipStream_t> streams;
+    hipEvent_t wait_ev = nullptr;       // vhap_plan_side_stream_wait's event: one per pool, i.e. per (thread, device)
 };
 thread_local std::vector<SidePool> g_side_pools;
 thread_local int g_side_base = 0;       // vhap_plan_set_side_base: the pool index of the NEXT plan's first side stream
 
-hipStream_t pool_stream(int k, bool least_priority) {
+SidePool* side_pool(bool least_priority) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    SidePool* pool = nullptr;
-    for (auto& sp : g_side_pools) if (sp.device == dev && sp.least_priority == least_priority) pool = &sp;
-    if (!pool) {
-        g_side_pools.push_back(SidePool{dev, least_priority, {}});
-        pool = &g_side_pools.back();
-    }
+    for (auto& sp : g_side_pools) if (sp.device == dev && sp.least_priority == least_priority) return &sp;
+    g_side_pools.push_back(SidePool{dev, least_priority, {}, nullptr});
+    return &g_side_pools.back();
+}
+
+hipStream_t pool_stream(int k, bool least_priority) {
+    SidePool* pool = side_pool(least_priority);
+    if (!pool) return nullptr;
     while ((int)pool->streams.size() <= k) {
         hipStream_t st = nullptr;
         int prio_least = 0, prio_greatest = 0;
@@ -358,13 +361,34 @@ extern "C" int vhap_plan_set_side_base(int base) {
 extern "C" int vhap_plan_side_stream_wait(int k, vhap_stream_t other) {
     VHAP_ENTER();
     if (k < 0 || k > 8) return VHAP_E_BADDIM;
-    hipStream_t st = pool_stream(k, (vhap_g_debug_flags & 524288) != 0);
-    if (!st) return VHAP_E_HIP;
-    thread_local hipEvent_t ev = nullptr;
-    if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return VHAP_E_HIP;
-    if (hipEventRecord(ev, vhap_stream(other)) != hipSuccess) return VHAP_E_HIP;
-    if (hipStreamWaitEvent(st, ev, 0) != hipSuccess) return VHAP_E_HIP;
+    const bool lp = (vhap_g_debug_flags & 524288) != 0;
+    hipStream_t st = pool_stream(k, lp);
+    SidePool* pool = side_pool(lp);
+    if (!st || !pool) return VHAP_E_HIP;
+    // (the event belongs to the pool of the CURRENT device: a thread that drives two devices must not record one device's event on the
+    // other's stream -- round-5 advisor)
+    if (!pool->wait_ev && hipEventCreateWithFlags(&pool->wait_ev, hipEventDisableTiming) != hipSuccess) return VHAP_E_HIP;
+    if (hipEventRecord(pool->wait_ev, vhap_stream(other)) != hipSuccess) return VHAP_E_HIP;
+    if (hipStreamWaitEvent(st, pool->wait_ev, 0) != hipSuccess) return VHAP_E_HIP;
     return VHAP_OK;
+}
+
+// The calling thread's side-stream pools (every device), destroyed: for short-lived worker threads that created plans -- the pools otherwise
+// live as long as the thread's storage and their HIP streams are never returned.  No plan of this thread may be replayed afterwards
+// (plans hold the pool's stream handles); create new plans instead.  Synchronises each stream first.
+extern "C" int vhap_plan_pool_release(void) {
+    VHAP_ENTER();
+    int rc = VHAP_OK;
+    for (auto& sp : g_side_pools) {
+        for (auto st : sp.streams) {
+            if (hipStreamSynchronize(st) != hipSuccess) rc = VHAP_E_HIP;
+            if (hipStreamDestroy(st) != hipSuccess) rc = VHAP_E_HIP;
+        }
+        if (sp.wait_ev && hipEventDestroy(sp.wait_ev) != hipSuccess) rc = VHAP_E_HIP;
+    }
+    g_side_pools.clear();
+    (void)hipGetLastError();
+    return rc;
 }
 
 extern "C" int vhap_plan_touch_side_streams(int n, void* scratch_4_bytes) {

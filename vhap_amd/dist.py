@@ -99,9 +99,16 @@ class FrameShardContext:
             ok = int(flag.item())
         except Exception:                                        # noqa: BLE001
             ok = 0
-        if not ok:
-            os.environ["VHAP_TEX_SHARDED"] = "0"
+        self.tex_sharded_ok = bool(ok)                            # (on the context, not in the environment: round-5 advisor)
         return bool(ok)
+
+    def tex_sharded_usable(self):
+        """probe()'s verdict, probing on first use: GraphedStep asks before it captures a sharded texture path, so that library users
+        (optimize_stage under torchrun) get the documented fallback instead of a refusal inside the first replay.  Every rank reaches
+        this at the same point of the same call sequence."""
+        if getattr(self, "tex_sharded_ok", None) is None:
+            self.probe()
+        return self.tex_sharded_ok
 
     # ---- collectives ----
     def all_reduce_sum(self, t):

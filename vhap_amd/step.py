@@ -182,7 +182,12 @@ class NativeStep:
         self.delta_flag = 0
         # antialiasing in place + photometric gradient on the fly: no copy of the image, no dense gradient images (d_rgba_aa / d_color)
         self.aa_inplace = self.deferred
-        self.aa_early_bwd = self.energy_fused and self.aa_inplace
+        # the photometric sum's launch assembles the energy and does the antialias colour job whenever the step is deferred; under frame
+        # sharding its total / upstream gradient are provisional (local pixel count) and vhap_energy_total_bound redoes them behind the
+        # count's all-reduce -- what matters there is that no energy_finalize launch and no antialias backward (22 us) sit on the chain
+        # between the sum and the shading backward (round 6: 83 us of glue in the sharded step, 6 us in the one-plan step)
+        self.photo_total = self.deferred
+        self.aa_early_bwd = self.photo_total and self.aa_inplace
         self.delta_flag = _lib.CALL_DELTA_UNSCALED if self.aa_early_bwd else 0
         self._delta_dirty = False
         if self.photometric:
@@ -281,6 +286,7 @@ class NativeStep:
         self.injected = None          # dict(w_fg, w_bg, idx): random numbers of the colour disturbance handed in (parity tests) instead of drawn in-kernel
         self.step_optimizer = None    # a HipAdam whose WHOLE update is issued inside forward()/backward() (GraphedStep, one GPU): counter advanced
                                       # at the head of the step, texture update behind its gradient, the rest before the final join
+        self.fold_outside = False     # (with split_tex, GraphedStep's texture path: tex_fold() is issued by the caller, not inside the pixel plan)
         self.split_tex = False        # True: stop at the gradient pyramid, the caller runs tex_finish() later (pyramid-level exchange under sharding)
         self.feed = None              # dict set by GraphedStep.enable_feed(): the step begins by gathering its batch from an uploaded table (vhap_batch_feed)
         self.carry = False            # enable_carry(): the texture is CARRIED from step to step (the finish + Adam pass writes the next step's albedo)
@@ -664,9 +670,9 @@ class NativeStep:
             _chk(L.vhap_antialias_fwd(_p(color), _p(self.rast), _p(self.clip), _p(self.tri), _p(self.opp), B, H, W, 4, V, F, _p(self.rgba_aa),
                                       _p(self.aa_work), st), "vhap_antialias_fwd")
         self._flush()
-        if self.energy_fused:
-            # one GPU: the photometric sum's last workgroup assembles the energy and the upstream gradient (no single-thread launches -- and
-            # no cross-queue hand-overs -- between the forward and the backward pass)
+        if self.photo_total:
+            # the photometric sum's last workgroup assembles the energy and the upstream gradient (no single-thread launches -- and
+            # no cross-queue hand-overs -- between the forward and the backward pass; sharded: redone behind the count's all-reduce)
             self._join()          # the side branch: texture assembly, landmarks, statistics, arena clear, antialias pair discovery
             _chk(L.vhap_photo_fwd_total(_p(self.rgba_aa), _p(self.rgb), B, H, W, _p(acc[16:19]), _p(acc[0:6]), _p(acc[6:7]) if self.w_lmk else 0,
                                         _p(self.carry_terms) if self.carry else _p(acc[7:10]), _p(acc[20:24]), _p(acc[12:16]), self.w_lmk,
@@ -1042,7 +1048,8 @@ class NativeStep:
                 # GPU (round 5: issued on the launch stream they sat in series with it, profiles/r05_call7_sharded_step_timeline.txt)
                 def tex_chain():
                     self._tex_backward()
-                    self.tex_fold()
+                    if not self.fold_outside:                          # (fold_outside: the caller folds on its communication stream, so that a
+                        self.tex_fold()                                # geometry plan that waits for the TILE pass need not wait for the fold)
                 self._side(tex_chain)
                 self._flush()
                 torch.cuda.current_stream().wait_stream(self.side2)

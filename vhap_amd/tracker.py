@@ -1212,6 +1212,32 @@ class CapturedPlan:
                          f"({len(sets['free head']) + len(extra_head_ranges)} buffers) are disjoint")
         return ok, lines
 
+    def nodes_touching_not_behind(self, log, ranges, stream_index=1):
+        """Nodes of this plan that touch any of `ranges` [(address, bytes)] -- by the byte ranges of the C-ABI call that created them (`log`, the
+        _lib.AccessLog of the capture); a node no recorded call accounts for counts as touching -- and are NOT ordered behind the plan's
+        stream `stream_index` (1 = its first side stream): neither on it, nor behind one of its nodes through dependencies or stream order.
+        What a caller needs to know before it lets ONLY that stream wait for a producer of those buffers (GraphedStep: the all-gathered
+        texture).  -> [(node index, kernel name, call name | 'UNKNOWN')]"""
+        L = _lib.lib()
+        rows = []
+        for line in self.describe().splitlines():
+            head, _, rest = line.partition("<-")
+            parts = head.split()
+            if len(parts) < 2 or not parts[0].isdigit():
+                continue
+            deps = [int(t) for t in rest.split("|")[0].split() if t.isdigit()]
+            rows.append((int(parts[0]), int(parts[1][1:]), deps))
+        behind, last_on, bad = {}, {}, []
+        for k, st, deps in rows:
+            b = st == stream_index or any(behind.get(d, False) for d in deps) or behind.get(last_on.get(st), False)
+            behind[k] = b
+            last_on[st] = k
+            hit = log.ranges_of_node(L.vhap_plan_node_handle(self.plan, k))
+            touches = hit is None or _lib.ranges_overlap(hit[1], ranges) is not None
+            if touches and not b:
+                bad.append((k, self.node_name(k).split("(")[0], "UNKNOWN" if hit is None else hit[0]))
+        return bad
+
     def open_tails(self):
         """Kernel names of the nodes a defer_join replay leaves un-joined."""
         return self._names(_lib.lib().vhap_plan_open_tails)
@@ -1392,6 +1418,8 @@ class GraphedStep:
                 tex = tracker.tex_extra
                 self.tex_sharded = bool(ns.tex_bwd_on and ns.pca is None and tex is not None and any(p is tex for p in self.params) and T % (16 * world) == 0 and
                                         isinstance(optimizer, NV.HipAdam) and os.environ.get("VHAP_TEX_SHARDED", "1") != "0")
+                if self.tex_sharded and not tracker.dist.tex_sharded_usable():   # (every collective of the path once, on small tensors, all ranks together)
+                    self.tex_sharded = False
                 if self.tex_sharded:
                     ns.split_tex = True
                     self.tex_rows = T // world
@@ -1422,9 +1450,16 @@ class GraphedStep:
                 # the tile accumulation (69 us alone, 174 us next to the G-buffer backward).  Default from the world size.
                 tf = os.environ.get("VHAP_SHARD_TEX_FIRST")
                 self.tex_first = self.tex_path and (world >= 4 if tf is None else tf == "1")
+                # texture first, round 6: the geometry plan waits for the TILE accumulation only (two LDS-bound kernels beside each other:
+                # 147 + 114 us, alone 70 + 97) -- the fold of the gradient pyramid (47 us of streaming) is issued on the communication
+                # stream in front of the reduce-scatter and runs beside the G-buffer backward
+                # (measured at world size 1, profiles/r06_call12_sharded_ab.txt: the fold then takes 103 us beside the G-buffer backward
+                # instead of 47 alone and the backward 134 instead of 114 -- no gain; off unless VHAP_SHARD_FOLD_OUTSIDE=1)
+                ns.fold_outside = bool(self.tex_first) and os.environ.get("VHAP_SHARD_FOLD_OUTSIDE", "0") == "1"
                 if self.tex_path:
                     ns.step_optimizer = optimizer                   # (the forward's side branch issues optimizer.advance())
-                with self.gF.capture(**cap):
+                self._accessF = _lib.AccessLog()
+                with self._accessF, self.gF.capture(**cap):
                     ns.forward()
                 pool = self.gF.pool()
                 self.gB2 = CapturedPlan()
@@ -1454,6 +1489,23 @@ class GraphedStep:
             # (vhap_plan_free_heads: per tail stream) and from what the host writes between two replays (a new batch into the sample
             # buffers); a node no recorded call accounts for -> joined replays.  A changed learning rate (the tail reads the table) joins
             # first (__call__).
+            # THE PRECISE WAIT of the sharded texture path (_replay): only the forward plan's first side stream waits for the communication
+            # stream (reduce-scatter, row finish + Adam, all-gather).  That is safe iff every node of the forward plan that touches what
+            # the communication stream reads or writes -- the texture parameter and its Adam state, the assembled albedo (the row finish
+            # reads it), the gradient pyramid (the arena clear zeroes the reduce-scatter's input), the strip, the step counter
+            # (advanced by the forward plan, read by the row finish) -- sits on that stream or behind it.  Checked HERE, on the buffers
+            # the captured calls were given, not assumed from the capture order (round-5 advisor); otherwise the launch stream waits.
+            self._precise_ok, self._precise_report = False, ["not a sharded texture path"]
+            if getattr(self, "tex_path", False) and self.gF.plan is not None:
+                tex = tracker.tex_extra
+                st_t = optimizer.state[tex]
+                touched = [tex, ns.albedo_tex, ns.g["d_tex"], self.tex_strip, st_t["exp_avg"], st_t["exp_avg_sq"], ns.g["tex_extra"],
+                           optimizer.step_count]
+                ranges = [(t.data_ptr(), t.numel() * t.element_size()) for t in touched if t is not None and t.numel()]
+                bad = self.gF.nodes_touching_not_behind(self._accessF, ranges, stream_index=1)
+                self._precise_ok = not bad
+                self._precise_report = [f"node {k} {nm} <- {call}: touches a buffer of the texture path but is not ordered behind side stream 0"
+                                        for k, nm, call in bad] or ["every forward-plan node that touches the texture path's buffers is on / behind side stream 0"]
             self.defer_join, self.defer_report = False, ["deferred join not considered (sharded step, hipGraph fallback or VHAP_DEFER_JOIN=0)"]
             if self.single and self.gF.plan is not None and os.environ.get("VHAP_DEFER_JOIN", "1") != "0":
                 host_writes = [(t.data_ptr(), t.numel() * t.element_size()) for t in self.sample.values()]
@@ -1562,9 +1614,12 @@ class GraphedStep:
                     frame_index_dev = timestep_dev
             return self.feed_upload(frame_index_dev, timestep_dev)
         if frame_index_dev is None:
-            ts = np.asarray(timesteps).reshape(-1)
+            ts = np.asarray(timesteps.cpu() if torch.is_tensor(timesteps) else timesteps).reshape(-1)
             if tr._frames_of is not None:
-                fidx = np.concatenate([tr._frames_of[int(t)] for t in ts])
+                # (multi-view: every view of the DISTINCT timesteps, in order -- the same normalisation as the self-feeding branch above: a
+                # per-frame timestep list, e.g. a sample's own `timestep_index`, names each timestep once per view)
+                uniq = list(dict.fromkeys(int(t) for t in ts))
+                fidx = np.concatenate([tr._frames_of[t] for t in uniq])
                 ts = tr.frame_timestep[fidx]
             else:
                 fidx = ts
@@ -1594,8 +1649,12 @@ class GraphedStep:
 
     def __call__(self):
         if isinstance(self.opt, NV.HipAdam):
-            if self.defer_join and self.opt.lr_changed():
-                self.join()                                        # (the open texture tail of the last replay reads the lr table)
+            if self.opt.lr_changed() and (self.defer_join or getattr(self, "_tex_gather", None) is not None):
+                # the open texture tail of the last replay reads the lr table -- on a side stream (one GPU), or on the communication
+                # stream behind the reduce-scatter (sharded texture path: the row finish + Adam plan): the write below must come behind it
+                self.join()
+                if torch.cuda.current_stream().cuda_stream != self.stream.cuda_stream:
+                    torch.cuda.current_stream().wait_stream(self.stream)
             self.opt.sync_lr()                                     # lr schedulers act on the host copy
         cur = torch.cuda.current_stream()
         if cur.cuda_stream != self.stream.cuda_stream:              # (inside replay_stream() the step's stream IS current)
@@ -1672,7 +1731,7 @@ class GraphedStep:
         if not (self.ns is not None and self.single and self.ns.carry):
             tr._tex_carrier = None                                 # (this replay's Adam update writes tex_extra behind a carrying step's back)
         if getattr(self, "_tex_gather", None) == "comm" and self._in_loop and self.gF.plan is not None and self.gF.side_base == 0 and \
-                os.environ.get("VHAP_SHARD_PRECISE_WAIT", "1") != "0":
+                getattr(self, "_precise_ok", False) and os.environ.get("VHAP_SHARD_PRECISE_WAIT", "1") != "0":
             # only the forward plan's TEXTURE CHAIN (a root of the plan on its first side stream: assembly + pyramid, then the arena clear and
             # the step counter behind it) needs the all-gathered texture: that stream waits for the communication stream, the launch stream's
             # geometry head (per-frame stage, skinning, binning) starts under the transfer
@@ -1710,8 +1769,10 @@ class GraphedStep:
                     cur = torch.cuda.current_stream()
                     folded = torch.cuda.Event()
                     with torch.cuda.stream(self.comm):
-                        self.gB.join()                                     # the folded gradient; and the plan's other side chain (lights gradient, delta clear)
-                        folded.record()
+                        self.gB.join()                                     # the gradient pyramid (tex_first: not yet folded); and the plan's other side chain (lights gradient, delta clear)
+                        folded.record()                                    # (tex_first: the tile accumulation is done -- what the geometry plan waits for)
+                        if self.ns.fold_outside:
+                            self.ns.tex_fold()
                         tr.dist.reduce_scatter_mean(self.ns.g["d_tex"][:n0], self.tex_strip.view(-1), async_op=False)
                         self.gAt.replay()
                         tr.dist.all_gather_rows(tr.tex_extra.detach(), self.tex_row0, self.tex_rows, async_op=False)
@@ -1726,6 +1787,8 @@ class GraphedStep:
                     return
                 else:
                     self.gB.replay()                                       # pixel chain + the complete texture gradient
+                    if self.ns.fold_outside:
+                        self.ns.tex_fold()
                     work = tr.dist.reduce_scatter_mean(self.ns.g["d_tex"][:n0], self.tex_strip.view(-1), async_op=True)   # level 0, pyramid folded in
                     self.gB2.replay()                                      # geometry chain: runs under the texture collective
                 tr.dist.all_reduce_mean_(self.ns.param_grad_flat)
