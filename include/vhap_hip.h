@@ -648,8 +648,9 @@ int vhap_tex_prep_bwd_adam_rows(const float* albedo_hwc, float* extra, const uin
  * render_nvdiffrast.py:398-399 rebuilds the mip pyramid per call; inside a loop of steps the only writer of tex_extra is the step's own
  * Adam update, so the pass that applies it (vhap_tex_prep_bwd_adam) can hand the NEXT step its texture:
  *   vhap_tex_finish_carry = vhap_tex_prep_bwd_adam (whole pyramid gathered) that also (i) rewrites albedo_hwc IN PLACE with
- *     painted + updated tex_extra (the sum vhap_tex_prep_fwd forms -> the same bits), (ii) writes level 1 of the pyramid into mips_hwc
- *     (follow with vhap_texture_mip_build_from(first_level = 2) before the texture is sampled), (iii) ACCUMULATES the weighted TV /
+ *     painted + updated tex_extra (the sum vhap_tex_prep_fwd forms -> the same bits), (ii) writes levels 1 AND 2 of the pyramid into mips_hwc
+ *     (follow with vhap_texture_mip_build_from(first_level = 3) before the texture is sampled; after vhap_tex_carry_prime, which writes
+ *     level 1 only: first_level = 2), (iii) ACCUMULATES the weighted TV /
  *     residual energies (reg_tex_tv, reg_tex_res_clusters: tracker.py:518-541) of that NEXT texture into terms[0..1] -- all but the TV
  *     pairs that straddle two ownership tiles, which vhap_tex_carry_border adds from the halo copies (behind this pass, ahead of the
  *     next vhap_adam_advance of step_device; same call_flags) -- hand them to the next step's energy assembly as its tex_terms with

@@ -266,10 +266,14 @@ def test_c_abi_is_reentrant_across_threads(tracker):
             with torch.cuda.stream(stream):
                 c = color.clone().requires_grad_()
                 (ops.antialias(c, rast, pos, tri, opp=ns.opp) * w).sum().backward()
-                stream.synchronize()
-                return c.grad.clone()
+                g = c.grad.clone()
+                stream.synchronize()       # (behind the clone: the caller reads the result on ITS stream, which does not wait for this one --
+                return g                   #  the copy used to be enqueued after the synchronisation: a full-suite run failed on it once in three)
         want = aa_grad(torch.cuda.Stream())
         assert float((want - w).abs().max()) < 10.0 and float(want.abs().max()) > 0     # pass-through part present
+        want2 = aa_grad(torch.cuda.Stream())             # (the reference itself must be reproducible on THIS thread before another one is judged by it)
+        assert float((want2 - want).abs().max()) <= 1e-5, ("main thread, two calls", float((want2 - want).abs().max()),
+                                                            float((want - w).abs().max()), float((want2 - w).abs().max()))
         errs, stop = [], threading.Event()
 
         def worker():
@@ -279,7 +283,7 @@ def test_c_abi_is_reentrant_across_threads(tracker):
                     got = aa_grad(s)
                     d = float((got - want).abs().max())      # (float atomics: the last bit depends on the order; a lost pass-through is O(1))
                     if not d <= 1e-5:
-                        errs.append(d)
+                        errs.append((d, float((got - w).abs().max()), float((want - w).abs().max()), int(((got - want).abs() > 1e-5).sum())))
             except Exception as e:          # noqa: BLE001
                 errs.append(repr(e))
         th = threading.Thread(target=worker)

@@ -87,6 +87,11 @@ def test_finish_carry_matches_the_two_passes_bit_exact(T):
         assert torch.equal(alb, B["albedo"]), (T, k, float((alb - B["albedo"]).abs().max()))
         n1 = 3 * (T // 2) ** 2
         assert torch.equal(mp[:n1], B["mips"][:n1]), (T, k)
+        # ... and level 2, which the carried pass writes as well (the step builds the pyramid from level 3 up)
+        _chk(L.vhap_texture_mip_build_from(_p(alb), 1, T, T, 3, _p(mp), 2, _stream()), "mips")
+        torch.cuda.synchronize()
+        n2 = n1 + 3 * (T // 4) ** 2
+        assert torch.equal(mp[n1:n2], B["mips"][n1:n2]), (T, k, float((mp[n1:n2] - B["mips"][n1:n2]).abs().max()))
 
 
 def _tracker(T=256, H=128, W=128, N=4, seed=3):

@@ -252,7 +252,7 @@ constexpr int TEXB_MAXG = 12;         // mip levels gathered per texel (T <= 409
 // anything but this pass has touched the texture).  Needs T % 64 == 0.
 struct TexCarry {
     const float* painted;      // [3,T,T]
-    float* mip1;               // level 1 of the pyramid [T/2,T/2,3]
+    float* mip1;               // levels 1 and 2 of the pyramid ([T/2,T/2,3] then [T/4,T/4,3]: the head of the vhap_texture_mip_build buffer)
     float* row_halo;           // [2][T/16][2][T][3]
     float* col_halo;           // [2][T][T/64][2][3]
     float* terms;              // [2]: TV / residual energies of the texture this pass hands on, accumulated
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(RB, 6) void tex_prep_bwd_kernel(TexCfg c, std::cond
         load_row(y0, x, cur);
     }
     float e_tv = 0.f, e_res = 0.f;                            // CARRY: TV / residual energies of the NEXT texture (tex_prep_fwd's sums)
-    float nprev[3] = {0.f, 0.f, 0.f};
+    float nprev[3] = {0.f, 0.f, 0.f}, m1up[3] = {0.f, 0.f, 0.f};
     // (restrict-qualified copies: stores through members of a by-value struct are otherwise assumed to alias every later load, which
     // pins each row's loads behind the previous row's stores)
     float* __restrict__ const adam_p = A.p;
@@ -481,13 +481,33 @@ __global__ __launch_bounds__(RB, 6) void tex_prep_bwd_kernel(TexCfg c, std::cond
                     q[0] = nv[0]; q[1] = nv[1]; q[2] = nv[2];
                 }
                 if (r & 1) {                                  // (uniform; the upper row's right neighbours are fetched again rather than kept: registers)
-                    float prt[3];
+                    float prt[3], m1[3];
 #pragma unroll
-                    for (int k = 0; k < 3; k++) prt[k] = __shfl_down(nprev[k], 1, 64);
+                    for (int k = 0; k < 3; k++) {
+                        prt[k] = __shfl_down(nprev[k], 1, 64);
+                        m1[k] = ((nprev[k] + prt[k]) + (nv[k] + nrt[k])) * 0.25f;      // (meaningful on even lanes)
+                    }
                     if (!(lane & 1)) {
                         float* q = mip1 + 3 * ((size_t)(y >> 1) * (T >> 1) + (x >> 1));
+                        q[0] = m1[0]; q[1] = m1[1]; q[2] = m1[2];
+                    }
+                    // level 2 from the level-1 texels of two consecutive odd rows (lanes 4j hold the even level-1 column, lanes 4j + 2 the
+                    // odd one: DPP quad_perm [2,3,0,1], issued by every lane), same ((a + b) + (c + d)) / 4 as vhap_texture_mip_build:
+                    // the pyramid build of the next step then starts from 3 MB instead of 12.6
+                    if ((r & 3) == 1) {
+                        m1up[0] = m1[0]; m1up[1] = m1[1]; m1up[2] = m1[2];
+                    } else {
+                        float m2[3];
 #pragma unroll
-                        for (int k = 0; k < 3; k++) q[k] = ((nprev[k] + prt[k]) + (nv[k] + nrt[k])) * 0.25f;
+                        for (int k = 0; k < 3; k++) {
+                            const float up_hi = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(m1up[k]), 0x4E, 0xF, 0xF, true));
+                            const float dn_hi = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(m1[k]), 0x4E, 0xF, 0xF, true));
+                            m2[k] = ((m1up[k] + up_hi) + (m1[k] + dn_hi)) * 0.25f;
+                        }
+                        if (!(lane & 3)) {
+                            float* q = mip1 + 3 * ((size_t)(T >> 1) * (T >> 1)) + 3 * ((size_t)(y >> 2) * (T >> 2) + (x >> 2));
+                            q[0] = m2[0]; q[1] = m2[1]; q[2] = m2[2];
+                        }
                     }
                 }
 #pragma unroll

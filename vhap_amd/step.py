@@ -39,6 +39,17 @@ def _chk(rc, what):
     _lib.check(rc, what)
 
 
+def _zero(t):
+    """t.zero_() as a RECORDED call: the host framework's fill becomes a node of the captured step like any other, and the decisions taken
+    on the buffers a plan's nodes touch (deferred join, the sharded step's precise wait) know what it writes instead of treating it as
+    UNKNOWN."""
+    if _lib.ACCESS is not None:
+        _lib.ACCESS.touch(t)
+    t.zero_()
+    if _lib.ACCESS is not None:
+        _lib.ACCESS.close("torch.Tensor.zero_")
+
+
 class _Null:
     def __enter__(self):
         return self
@@ -286,6 +297,7 @@ class NativeStep:
         self.injected = None          # dict(w_fg, w_bg, idx): random numbers of the colour disturbance handed in (parity tests) instead of drawn in-kernel
         self.step_optimizer = None    # a HipAdam whose WHOLE update is issued inside forward()/backward() (GraphedStep, one GPU): counter advanced
                                       # at the head of the step, texture update behind its gradient, the rest before the final join
+        self.sort_in_backward = False  # (GraphedStep's sharded texture path: the uv-tile sort is forked by the pixel plan, not by the forward plan)
         self.fold_outside = False     # (with split_tex, GraphedStep's texture path: tex_fold() is issued by the caller, not inside the pixel plan)
         self.split_tex = False        # True: stop at the gradient pyramid, the caller runs tex_finish() later (pyramid-level exchange under sharding)
         self.feed = None              # dict set by GraphedStep.enable_feed(): the step begins by gathering its batch from an uploaded table (vhap_batch_feed)
@@ -358,6 +370,8 @@ class NativeStep:
         _chk(self.L.vhap_tex_carry_prime(_p(self.painted), _p(self.tr.tex_extra), _p(self.nm["res_mask"]), self.T, *self.tex_scales,
                                          _p(self.albedo_tex), _p(self.mips), _p(self.tex_halo), _p(self.carry_terms), _stream()),
              "vhap_tex_carry_prime")
+        # (the captured step builds the pyramid from level 3 up -- the finish pass hands it levels 1 and 2 --: level 2 of a primed texture here)
+        _chk(self.L.vhap_texture_mip_build_from(_p(self.albedo_tex), 1, self.T, self.T, 3, _p(self.mips), 2, _stream()), "vhap_texture_mip_build_from")
 
     def _feed_batch(self):
         """The step's own batch hand-over (vhap_batch_feed): the next batch of the uploaded table -> timesteps, frame indices, landmarks
@@ -390,7 +404,7 @@ class NativeStep:
         if self.carry:
             # the carried texture: albedo, pyramid level 1 and the TV / residual energies (carry_terms) were written by the previous step's
             # finish + Adam pass (or tex_prime())
-            _chk(L.vhap_texture_mip_build_from(_p(self.albedo_tex), 1, T, T, 3, _p(self.mips), 2, st), "vhap_texture_mip_build_from")
+            _chk(L.vhap_texture_mip_build_from(_p(self.albedo_tex), 1, T, T, 3, _p(self.mips), 3, st), "vhap_texture_mip_build_from")   # (levels 1, 2: the finish pass)
             if ready is not None:
                 ready()
                 ready = None
@@ -461,7 +475,7 @@ class NativeStep:
         st = _stream()
         acc = self.accF
         if not self._acc_clean:
-            acc.zero_()                                               # ONE launch clears every forward accumulator
+            _zero(acc)                                                # ONE launch clears every forward accumulator
         self._acc_clean = False
         if self._delta_dirty:                                         # (eager use only: a forward whose backward never came left its antialias
             self._clear_delta()                                       # colour gradients in d_delta; its pair list is still intact here)
@@ -517,7 +531,7 @@ class NativeStep:
             self._tex_forward()
             if self.w_lmk:
                 self._landmark_forward()
-            self.arena.zero_()
+            _zero(self.arena)
             self._arena_clean = True
             _chk(L.vhap_energy_finalize(_p(acc[0:6]), _p(acc[6:7]) if self.w_lmk else 0, _p(acc[7:10]), _p(acc[20:24]), 0, self.w_lmk, 0.0,
                                         B, H, W, _p(self.log), st), "vhap_energy_finalize")
@@ -534,7 +548,7 @@ class NativeStep:
                 # the pixel-pair discovery is left for the gap between the rasteriser and the blend
                 _chk(L.vhap_antialias_inplace_silhouette(_p(self.clip), _p(self.tri), _p(self.opp), B, H, W, V, F, _p(self.aa_work), _stream()),
                      "vhap_antialias_inplace_silhouette")
-            self.arena.zero_()                                    # ONE launch clears every gradient accumulator of the backward
+            _zero(self.arena)                                     # ONE launch clears every gradient accumulator of the backward
             self._arena_clean = True
             if self.step_optimizer is not None:
                 self.step_optimizer.advance()
@@ -567,7 +581,7 @@ class NativeStep:
                                     _p(acc[20:24]), _p(acc[12:16]) if self.want_reg else 0, self.w_lmk, self.w_reg, B, H, W, _p(self.log), st),
              "vhap_energy_finalize")
         if self.carry:
-            self.carry_terms.zero_()            # consumed (the deferred step's energy assembly does it itself: VHAP_CALL_TEX_TERMS_CONSUME)
+            _zero(self.carry_terms)             # consumed (the deferred step's energy assembly does it itself: VHAP_CALL_TEX_TERMS_CONSUME)
 
     def _forward_deferred(self):
         """binning || vertex normals -> rasterise + interpolate + texture + shade + composite in ONE kernel -> disturbance -> antialias ->
@@ -652,8 +666,14 @@ class NativeStep:
                     # ordered ahead of this step's last main-chain kernel, or it counts as an open tail of a deferred join (tracker.GraphedStep)
                     self._sort_done = torch.cuda.Event()
                     self._sort_done.record()
-            if not self.one_graph:
-                self._side(sort_branch)                           # (eager / sharded: next to the rest of the forward pass)
+            self._sort_fn = None
+            if self.sort_in_backward:
+                # sharded texture path: the forward is a plan of its own that ENDS with the photometric sum -- forked here, the sort has
+                # nothing of the main chain left to run beside and the executor put its four launches (45 us) ON the launch stream ahead of
+                # the sum (profiles/r06_call12_step_timeline_sharded_tf1.txt); the pixel plan forks it beside the shading backward instead
+                self._sort_fn = sort_branch
+            elif not self.one_graph:
+                self._side(sort_branch)                           # (eager: next to the rest of the forward pass)
         self.aa_in = color
         if self.aa_inplace:
             if self._aa_det is not None or self._pending:
@@ -693,7 +713,7 @@ class NativeStep:
                                     _p(acc[20:24]), _p(acc[12:16]) if self.want_reg else 0, self.w_lmk, self.w_reg, B, H, W, _p(self.log), st),
              "vhap_energy_finalize")
         if self.carry:
-            self.carry_terms.zero_()
+            _zero(self.carry_terms)
 
     def _disturb(self, st):
         """colour disturbance, in place on rgba (render_nvdiffrast.py:424-460); random numbers drawn in-kernel, or -- `self.injected`, a
@@ -815,7 +835,7 @@ class NativeStep:
                                      self.lm.L, self.lmk2d.shape[1], l0, l1, b0, b1, boost, H, W, _p(g["d_verts"]), _p(self.d_mvp), st),
                  "vhap_landmark_bwd")
         else:
-            self.d_mvp.zero_()
+            _zero(self.d_mvp)
         if (self.has_offset or self.dyn) and any(self.off_scales):
             if self.dyn:
                 _chk(L.vhap_offset_reg_bwd_batch(_p(self.off_b), _p(om.ptr), _p(om.col), _p(om.val), _p(om.w_lap), _p(om.w_abs), _p(om.rptr),
@@ -892,7 +912,7 @@ class NativeStep:
              "vhap_deferred_lights_reduce")
         self._clear_delta()
         if self.one_graph:            # the next step's forward accumulators: their last reader of THIS step is the reduction above
-            self.accF.zero_()
+            _zero(self.accF)
             self._acc_clean = True
 
     def _clear_delta(self):
@@ -991,7 +1011,7 @@ class NativeStep:
         gradient -- then 'geometry' (everything else), which runs underneath it."""
         if part in ("all", "pixel_tex"):
             if not getattr(self, "_arena_clean", False):              # (normally done on the forward's side branch already)
-                self.arena.zero_()
+                _zero(self.arena)
             self._arena_clean = False
         if not self.photometric:
             # landmark-only stage: E = landmark + regularisers; one short serial chain ('geometry' of a sharded split is empty)
@@ -1038,6 +1058,8 @@ class NativeStep:
                 self.step_optimizer.step(skip=late, advanced=True)
             self._join()
         elif part == "pixel_tex":
+            if getattr(self, "_sort_fn", None) is not None and self.sort_in_backward:
+                self._side(self._sort_fn)                              # (forked at the head of the plan: beside the shading backward)
             self._bwd_pixel(world_size)
             self._side(self._bwd_pixel_finish, self.side2)
             if self.split_tex and self.overlap:

@@ -1367,7 +1367,7 @@ class GraphedStep:
             world = tracker.dist.world_size if tracker.dist is not None else 1
             self.single = tracker.dist is None or not tracker.dist.sharded      # (a one-rank group takes the sharded form under VHAP_FORCE_DIST)
             if not self.single:
-                ns.n_global = torch.ones(1, device=dev)             # receives the all-reduced alpha count before every backward replay
+                ns.n_global = ns.accF[17:18]                        # the alpha count: all-reduced IN PLACE before every backward replay
             if self.single:
                 # nothing happens between the passes on one GPU: ONE plan per step.  `unroll` > 1: that many consecutive steps per replay
                 self.unroll = max(1, int(unroll))
@@ -1458,6 +1458,7 @@ class GraphedStep:
                 ns.fold_outside = bool(self.tex_first) and os.environ.get("VHAP_SHARD_FOLD_OUTSIDE", "0") == "1"
                 if self.tex_path:
                     ns.step_optimizer = optimizer                   # (the forward's side branch issues optimizer.advance())
+                    ns.sort_in_backward = True                      # (the uv-tile sort beside the shading backward, like the one-plan step)
                 self._accessF = _lib.AccessLog()
                 with self._accessF, self.gF.capture(**cap):
                     ns.forward()
@@ -1753,7 +1754,8 @@ class GraphedStep:
                 self.gA.replay()
                 return
             if tr.dist is not None:
-                self.ns.n_global.copy_(self.N.reshape(1))                  # (in place on the step's own buffer: one launch, no clone)
+                # the alpha count summed over the ranks IN PLACE on the forward accumulator (ns.n_global is that word: no copy launch on the
+                # chain between the photometric sum and the shading backward); nothing else reads the local count afterwards
                 tr.dist.all_reduce_sum_(self.ns.n_global)
             # the gradients sit in contiguous buffers: collectives straight on them (ReduceOp.AVG), no staging copies
             if getattr(self, "tex_sharded", False):
