@@ -17,6 +17,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--config", type=int, default=2)
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--only", default="")
+ap.add_argument("--debug-flags", type=int, default=0, help="vhap_debug_set_flags for the timed calls (A/B switches inside kernels)")
 ap.add_argument("--cold", action="store_true", help="every timed call starts with cold caches (1 GiB written in between: L2 and the 256 MB "
                 "Infinity Cache hold nothing of the call's inputs) -- what a kernel sees inside the step, where ~1 GB of other traffic "
                 "flows between its producer and it; the median of --reps single calls")
@@ -119,6 +120,8 @@ def geometry_head():
 calls["geometry tail (vnormal_bwd .. frame_prep_bwd)"] = geometry_tail
 calls["frame_prep+skin (geometry head)"] = geometry_head
 only = [s for s in args.only.split(",") if s]
+if args.debug_flags:
+    _lib.debug_set_flags(args.debug_flags)
 print(f"config {args.config}: B={B} {H}x{W} T={T}; un-contended, {args.reps} repetitions back to back")
 for name, fn in calls.items():
     if fn is None or (only and not any(o in name for o in only)):

@@ -101,6 +101,13 @@ for p in [p for g in opt.param_groups for p in g["params"]]:
 opt._build()
 opt.sync_lr()
 ns = NativeStep(tr, sample, bench.STAGE)
+# the step AS SHIPPED since round 6: the whole Adam update issued inside the step, the texture carried (the finish pass writes the next step's
+# albedo / pyramid levels 1-2; no tex_prep_fwd at the head) -- VHAP_TEX_CARRY=0: the round-5 form
+CARRY = os.environ.get("VHAP_TEX_CARRY", "1") != "0"
+if CARRY:
+    ns.step_optimizer = opt
+    assert ns.enable_carry()
+    ns.tex_prime()
 ns.overlap = False                                          # one stream: the counters are per kernel, the order does not matter
 L = ctypes.CDLL(_lib.SO_PATH)
 L.vhap_debug_fill.restype = L.vhap_debug_copy.restype = ctypes.c_int
@@ -113,7 +120,8 @@ copy = lambda n: L.vhap_debug_copy(ctypes.c_void_p(b.data_ptr()), ctypes.c_void_
 def step():                                                 # the captured step's kernels, one chain: the texture's Adam update rides in its gradient pass
     ns.forward()
     ns.backward(1, optimizer=opt)
-    opt.step(skip=(tr.tex_extra,))
+    if not CARRY:                                           # (carried: step_optimizer is set -- backward() issues the rest of the update itself)
+        opt.step(skip=(tr.tex_extra,))
 
 
 for _ in range(2):

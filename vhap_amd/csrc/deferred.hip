@@ -47,6 +47,16 @@ __global__ __launch_bounds__(DB_T) void deferred_shade_bwd_kernel(const Deferred
         da[0] = 0.f; da[1] = 0.f; da[2] = 0.f;
         if (P.tile_ids) P.tile_ids[pi] = (unsigned short)0xFFFF;
     }
+    // a workgroup without a covered pixel (two thirds of them on a head frame) has nothing to reduce: it leaves here -- its background pixels'
+    // share of the lights regulariser is one count -- instead of walking the epilogue's LDS rows and barriers with 27 zeros per lane
+    if (__syncthreads_or(cov ? 1 : 0) == 0) {
+        if (P.part && R.on && threadIdx.x == 0) {
+            const unsigned n_bg = min((unsigned)DB_T, npix - min(npix, blockIdx.x * (unsigned)DB_T));
+            float* row = P.part + (size_t)(((unsigned)blockIdx.x + (unsigned)blockIdx.y * 7u + (unsigned)blockIdx.z * 13u) % DB_SLOTS) * DB_ROW;
+            if (n_bg) atomicAdd(&row[27], (float)n_bg);
+        }
+        return;
+    }
     const bool any = __ballot(cov) != 0ull;
     if (any) {
         int tb_tile = -1;
