@@ -819,6 +819,28 @@ int vhap_capture_nodes(vhap_stream_t stream, void** nodes, int cap);
  * dur_us[k] of node k, n >= number of nodes.  For per-kernel numbers inside the step (bench.py's roofline line), not for the step time. */
 int vhap_plan_launch_timed(vhap_plan_t plan, vhap_stream_t stream, float* start_us, float* dur_us, int n);
 
+/* -------------------------------------------------------------------------------------------
+ * Landmark detection on ROCm (ABI 10): the building blocks of the 2-D landmark network.
+ * Reference: vhap/model/tracker.py:1263-1277 -> vhap/util/landmark_detector_fa.py:41-46 `face_alignment.FaceAlignment(TWO_HALF_D, 'sfd',
+ * flip_input=True)` -- the third-party `face_alignment` package (absent from the reference checkout), whose network is the published FAN
+ * (Bulat & Tzimiropoulos, ICCV 2017).  Host side: vhap_amd/landmarks.py.
+ *   vhap_conv2d_nhwc: fp32 convolution on the matrix cores (exact-fp32 MFMA), NHWC.  `in` / `out` point at the FIRST CHANNEL of a channel slice of
+ *     a [N,H,W,in_channel_stride] / [N,Ho,Wo,out_channel_stride] buffer (Ho = (H + 2 pad - KH) / stride + 1); weight [KH,KW,Cin,Cout]; bias [Cout] or
+ *     NULL; in_scale / in_shift [Cin] or both NULL: the input is read as v * in_scale[ci] + in_shift[ci] (an inference BatchNorm), then through a ReLU
+ *     with VHAP_CONV_IN_RELU -- zero padding applies to the activated input; VHAP_CONV_OUT_RELU: ReLU on the way out; VHAP_CONV_ACCUMULATE: out += .
+ *   vhap_nhwc_avgpool2: 2x2 / stride-2 average pool.  vhap_nhwc_upsample2_add: out = skip + nearest-neighbour x2 of low ([N,H/2,W/2,C]).
+ *   vhap_nhwc_add: out = (a + b) + c over n floats (c may be NULL).
+ * ------------------------------------------------------------------------------------------- */
+#define VHAP_CONV_IN_RELU 1
+#define VHAP_CONV_OUT_RELU 2
+#define VHAP_CONV_ACCUMULATE 4
+int vhap_conv2d_nhwc(const float* in, int in_channel_stride, int N, int H, int W, int Cin, const float* weight, const float* bias,
+                     const float* in_scale, const float* in_shift, int KH, int KW, int stride, int pad, float* out, int out_channel_stride,
+                     int Cout, int call_flags, vhap_stream_t stream);
+int vhap_nhwc_avgpool2(const float* in, int N, int H, int W, int C, float* out, vhap_stream_t stream);
+int vhap_nhwc_upsample2_add(const float* skip, const float* low, int N, int H, int W, int C, float* out, vhap_stream_t stream);
+int vhap_nhwc_add(const float* a, const float* b, const float* c, long long n, float* out, vhap_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

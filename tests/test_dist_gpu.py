@@ -304,7 +304,10 @@ def test_one_rank_rccl_sharded_step_matches_unsharded(tex_sharded, tex_first):
         rel, floor = float((g_s[k] - g1.cpu()).abs().max()) / nrm, float((g2 - g1).abs().max()) / nrm
         lines.append(f"grad {k}: sharded vs one-plan {rel:.2e}   one-plan vs one-plan {floor:.2e}")
         if rel > max(3 * floor, 2e-5):
-            fails.append(f"grad {k}: {rel:.2e} (floor {floor:.2e})")
+            d = ((g_s[k] - g1.cpu()).abs() / nrm).reshape(-1)
+            off = torch.nonzero(d > max(10 * floor, 1e-5)).reshape(-1)
+            fails.append(f"grad {k}: {rel:.2e} (floor {floor:.2e}); {off.numel()} of {d.numel()} elements off by more than 10 x the floor"
+                         f" (first: {off[:12].tolist()})")
     for k in NAMES:
         p1, p2, p0 = getattr(tr, k).detach().cpu(), getattr(tr2, k).detach().cpu(), getattr(start, k).detach().cpu()
         moved = float((p1 - p0).abs().max())

@@ -453,7 +453,10 @@ def test_stage_scheduler_matches_reference(flame_model):
                                                    lr_scale=0.1, evaluate_every=10))):
         tr = tracker(9)
         calls = []
-        tr.optimize_iter = lambda sample, optimizer, stage, calls=calls: calls.append([g["lr"] for g in optimizer.param_groups])
+        def stub_iter(sample, optimizer, stage, calls=calls):
+            calls.append([g["lr"] for g in optimizer.param_groups])
+            optimizer._opt_called = True                     # (the stub stands for optimizer.step(): what torch's schedulers look for before they warn)
+        tr.optimize_iter = stub_iter
         tr.evaluate = lambda calls=calls, **kw: calls.append(["evaluate", None])
         tr.optimize_stage(stage, graphed=False, **kw)
         want = ref["stage_calls"][stage]

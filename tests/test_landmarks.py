@@ -1,0 +1,207 @@
+"""Landmark detection on ROCm (vhap/util/landmark_detector_fa.py, vhap/model/tracker.py:1263-1277): the 2-D landmark
+network on the matrix cores (vhap_amd/landmarks.py, csrc/conv.hip) against the torch restatement of the published FAN (oracle/fan_ref.py)
+with SEEDED RANDOM weights -- the package the reference drives and its weights are third-party downloads absent here ("parity unpinned"
+against the package itself; pinned on the restatement) -- and the host-side pre- / post-processing and npz layout."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import fan_ref
+
+
+# ---------------------------------------------------------------- CPU: host logic and the oracle ----------------------------------------------------------------
+def test_mirror_table_and_decoding_match_the_restatement():
+    from vhap_amd import landmarks as LM
+    assert np.array_equal(LM.MIRROR_68[LM.MIRROR_68], np.arange(68)) and int((LM.MIRROR_68 != np.arange(68)).sum()) == 58
+    rng = np.random.default_rng(0)
+    hm = rng.standard_normal((3, 68, 64, 64)).astype(np.float32)
+    hm[0, 0] = 0; hm[0, 0, 0, 5] = 1.0                                  # a peak on the border: no sub-pixel shift
+    hm[0, 1] = 0; hm[0, 1, 10, 20] = 1.0; hm[0, 1, 10, 21] = 0.5; hm[0, 1, 9, 20] = 0.25   # towards +x and -y
+    center, scale = np.array([301.5, 212.25]), 1.37
+    p_ref, i_ref = fan_ref.heatmaps_to_points(hm, center, scale)
+    p, i, peak = LM.heatmaps_to_points(torch.from_numpy(hm), center, scale)
+    assert np.allclose(p, p_ref, atol=0) and np.allclose(i, i_ref, rtol=0, atol=1e-9)
+    assert np.allclose(p[0, 0], [5.5, 0.5]) and np.allclose(p[0, 1], [20.75, 10.25]) and peak[0, 1] == 1.0
+    c_ref, s_ref = fan_ref.box_center_scale([10.0, 20.0, 110.0, 220.0, 0.9])
+    c, s = LM.box_center_scale([10.0, 20.0, 110.0, 220.0, 0.9])
+    assert np.allclose(c, c_ref) and s == s_ref and np.allclose(c, [60.0, 96.0]) and np.isclose(s, 300.0 / 195.0)
+
+
+def test_crop_is_the_window_around_the_centre():
+    from vhap_amd import landmarks as LM
+    yy, xx = np.meshgrid(np.arange(300), np.arange(400), indexing="ij")
+    img = np.stack([xx // 2, yy // 2, (xx + yy) // 4], -1).astype(np.uint8)          # a ramp: the crop's values say where they came from
+    # a window of 200 * scale = 256 image pixels around (200, 150): crop pixel (u, v) shows image pixel ~ (72 + u, 22 + v) (the package's window is
+    # 255 pixels resized to 256: within a pixel of that)
+    c = LM.crop_face(img, np.array([200.0, 150.0]), 256.0 / 200.0, 256, device="cpu")
+    assert c.shape == (3, 256, 256) and float(c.max()) <= 1.0
+    for u, v in ((0, 0), (128, 128), (255, 255), (40, 200)):
+        assert abs(float(c[0, v, u]) * 255 * 2 - (72.5 + u)) <= 2.0 and abs(float(c[1, v, u]) * 255 * 2 - (22.5 + v)) <= 2.0, (u, v)
+    # a window that leaves the image: zeros outside
+    c = LM.crop_face(img + 1, np.array([10.0, 10.0]), 256.0 / 200.0, 256, device="cpu")
+    assert float(c[:, :100, :100].abs().max()) == 0.0 and float(c[:, 140:, 140:].min()) > 0
+
+
+def test_annotate_landmarks_writes_the_reference_layout(tmp_path):
+    """vhap/util/landmark_detector_fa.py:168-190: one npz per camera, `face_landmark_2d` [T,68,3] and `bounding_box` [T,5], timesteps sorted."""
+    from vhap_amd import landmarks as LM
+
+    class Det:
+        def detect_single_image(self, img):
+            v = float(img[0, 0, 0])
+            if v == 3:                                                  # no face on this frame
+                return [], np.zeros([68, 3]) - 1
+            return [np.array([0.1, 0.2, 0.3, 0.4, 0.9])], np.full((68, 3), v)
+
+    class DS:
+        items = [dict(rgb=np.full((8, 8, 3), t, np.uint8), timestep_id=f"{t:05d}", camera_id=c) for c in ("a", "b") for t in (2, 0, 3, 1)]
+        def __len__(self): return len(self.items)
+        def __getitem__(self, i): return self.items[i]
+        def get_property_path(self, name, camera_id=None): return tmp_path / name / f"{camera_id}.npz"
+
+    paths = LM.annotate_landmarks(DS(), Det())
+    assert sorted(paths) == ["a", "b"]
+    z = np.load(paths["a"])
+    assert sorted(z.files) == ["bounding_box", "face_landmark_2d"] and z["face_landmark_2d"].shape == (4, 68, 3) and z["bounding_box"].shape == (4, 5)
+    assert [float(z["face_landmark_2d"][i, 0, 0]) for i in range(4)] == [0.0, 1.0, 2.0, -1.0]
+    assert np.allclose(z["bounding_box"][3], -1) and np.allclose(z["bounding_box"][0], [0.1, 0.2, 0.3, 0.4, 0.9])
+
+
+def test_restated_network_has_the_published_shape():
+    """four stacks of 68 heat maps at a quarter of the input resolution; ~24 M parameters; the package's parameter names"""
+    net = fan_ref.random_fan(seed=1, num_modules=4)
+    n = sum(p.numel() for p in net.parameters())
+    assert 23.5e6 < n < 24.5e6, n
+    names = set(net.state_dict())
+    for k in ("conv1.weight", "conv1.bias", "bn1.running_mean", "conv2.downsample.2.weight", "conv3.bn3.weight", "m0.b2_plus_1.conv3.weight",
+              "m3.b1_4.bn1.running_var", "top_m_2.conv1.weight", "conv_last3.bias", "bn_end0.weight", "l3.weight", "bl2.bias", "al0.weight"):
+        assert k in names, k
+    assert "bl3.weight" not in names and "conv3.downsample.2.weight" not in names
+    with torch.no_grad():
+        out = fan_ref.random_fan(seed=2, num_modules=1)(torch.rand(1, 3, 64, 64))
+    assert len(out) == 1 and out[0].shape == (1, 68, 16, 16)
+
+
+def test_no_cpu_path():
+    from vhap_amd import landmarks as LM
+    sd = fan_ref.random_fan(seed=0, num_modules=1).state_dict()
+    with pytest.raises(RuntimeError):
+        LM.FAN2D(sd, num_modules=1, device="cpu")
+
+
+# ---------------------------------------------------------------- GPU: the kernels against torch fp32 ----------------------------------------------------------------
+def _rel(a, b):
+    return float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,H,W,Cin,Cout,K,stride,pad", [(2, 16, 20, 32, 32, 3, 1, 1), (1, 64, 64, 256, 128, 3, 1, 1), (3, 8, 8, 68, 256, 1, 1, 0),
+                                                          (2, 64, 48, 3, 64, 7, 2, 3), (1, 32, 32, 256, 68, 1, 1, 0), (1, 4, 4, 64, 64, 3, 1, 1)])
+def test_conv_matches_torch(N, H, W, Cin, Cout, K, stride, pad):
+    from vhap_amd import _lib
+    from vhap_amd.ops import _p, _stream
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(N * 1000 + Cin + Cout + K)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    sc, sh = 1 + 0.2 * torch.randn(Cin, generator=g), 0.3 * torch.randn(Cin, generator=g)
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    wd = w.permute(2, 3, 1, 0).contiguous().cuda()
+    Ho, Wo = (H + 2 * pad - K) // stride + 1, (W + 2 * pad - K) // stride + 1
+    bd, scd, shd = b.cuda(), sc.cuda(), sh.cuda()             # (held: a temporary's memory is handed to the next allocation)
+    for in_act, bias, out_relu, acc in ((False, True, False, False), (True, False, False, False), (True, True, True, True)):
+        xin = torch.relu(x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)) if in_act else x
+        ref = torch.nn.functional.conv2d(xin, w, b if bias else None, stride=stride, padding=pad)
+        prev = torch.randn(N, Cout, Ho, Wo, generator=g)
+        if acc:
+            ref = ref + prev
+        if out_relu:
+            ref = torch.relu(ref)
+        out = (prev if acc else torch.full((N, Cout, Ho, Wo), float("nan"))).permute(0, 2, 3, 1).contiguous().cuda()
+        flags = (_lib.CONV_IN_RELU if in_act else 0) | (_lib.CONV_OUT_RELU if out_relu else 0) | (_lib.CONV_ACCUMULATE if acc else 0)
+        rc = L.vhap_conv2d_nhwc(_p(xd), Cin, N, H, W, Cin, _p(wd), _p(bd) if bias else 0, _p(scd) if in_act else 0,
+                                _p(shd) if in_act else 0, K, K, stride, pad, _p(out), Cout, Cout, flags, _stream())
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert _rel(out.cpu().permute(0, 3, 1, 2), ref) <= 2e-6, (in_act, bias, out_relu, acc)
+
+
+@pytest.mark.gpu
+def test_conv_on_channel_slices_and_the_elementwise_glue():
+    from vhap_amd import _lib
+    from vhap_amd.ops import _p, _stream
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(5)
+    N, H, W = 2, 12, 10
+    buf = torch.randn(N, H, W, 96, generator=g).cuda()                  # read channels [16, 48), write channels [64, 80) of the same buffer
+    keep = buf.clone()
+    w = torch.randn(16, 32, 3, 3, generator=g) / 17.0
+    rc = L.vhap_conv2d_nhwc(buf.data_ptr() + 4 * 16, 96, N, H, W, 32, _p(w.permute(2, 3, 1, 0).contiguous().cuda()), 0, 0, 0, 3, 3, 1, 1,
+                            buf.data_ptr() + 4 * 64, 96, 16, 0, _stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.conv2d(keep[..., 16:48].cpu().permute(0, 3, 1, 2), w, padding=1).permute(0, 2, 3, 1)
+    assert _rel(buf[..., 64:80].cpu(), ref) <= 2e-6
+    assert torch.equal(buf[..., :64], keep[..., :64]) and torch.equal(buf[..., 80:], keep[..., 80:])
+    x = torch.randn(2, 8, 6, 20, generator=g).cuda()
+    out = torch.empty(2, 4, 3, 20).cuda()
+    assert L.vhap_nhwc_avgpool2(_p(x), 2, 8, 6, 20, _p(out), _stream()) == 0
+    assert _rel(out.cpu(), torch.nn.functional.avg_pool2d(x.cpu().permute(0, 3, 1, 2), 2, stride=2).permute(0, 2, 3, 1)) <= 1e-7
+    up = torch.empty_like(x)
+    assert L.vhap_nhwc_upsample2_add(_p(x), _p(out), 2, 8, 6, 20, _p(up), _stream()) == 0
+    want = x.cpu() + torch.nn.functional.interpolate(out.cpu().permute(0, 3, 1, 2), scale_factor=2, mode="nearest").permute(0, 2, 3, 1)
+    assert torch.equal(up.cpu(), want)
+    a, b, c = (torch.randn(1000, generator=g).cuda() for _ in range(3))
+    o = torch.empty(1000).cuda()
+    assert L.vhap_nhwc_add(_p(a), _p(b), _p(c), 1000, _p(o), _stream()) == 0
+    assert torch.equal(o.cpu(), (a.cpu() + b.cpu()) + c.cpu())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("num_modules,res", [(1, 64), (4, 256)])
+def test_network_matches_the_torch_restatement(num_modules, res):
+    """the whole network -- stem, residual blocks, hourglasses, intermediate supervision feeding the next stack -- against torch fp32 on the CPU,
+    seeded random weights, non-trivial BatchNorm statistics: every stack's heat maps to 2e-4 of their max-norm; arg-max landmarks identical"""
+    from vhap_amd import landmarks as LM
+    net = fan_ref.random_fan(seed=3 + num_modules, num_modules=num_modules)
+    x = torch.rand(2, 3, res, res, generator=torch.Generator().manual_seed(9))
+    with torch.no_grad():
+        ref = net(x)
+    fan = LM.FAN2D(net.state_dict(), num_modules=num_modules)
+    out = fan(x.cuda())
+    torch.cuda.synchronize()
+    assert len(out) == num_modules
+    for i, (a, b) in enumerate(zip(out, ref)):
+        assert a.shape == b.shape == (2, 68, res // 4, res // 4)
+        assert _rel(a.cpu(), b) <= 2e-4, (i, _rel(a.cpu(), b))
+    p_hip, _, _ = LM.heatmaps_to_points(out[-1])
+    p_ref, _ = fan_ref.heatmaps_to_points(ref[-1].numpy())
+    assert float(np.abs(p_hip - p_ref).max()) <= 0.5                   # (a quarter-pixel shift may flip where two neighbours tie to rounding)
+    assert float((np.abs(p_hip - p_ref) > 0).mean()) <= 0.02
+    with pytest.raises(RuntimeError):
+        fan(x)                                                        # a CPU tensor: no fallback
+
+
+@pytest.mark.gpu
+def test_detector_end_to_end_on_a_synthetic_frame():
+    """LandmarkDetectorFA.detect_single_image with the reference's return convention (landmark_detector_fa.py:48-78), flip averaging on: against
+    the same pipeline over the torch restatement (crop -> network on both orientations -> mirrored average -> decoding)"""
+    from vhap_amd import landmarks as LM
+    net = fan_ref.random_fan(seed=11, num_modules=2)
+    rng = np.random.default_rng(4)
+    img = rng.integers(0, 255, (360, 480, 3), dtype=np.uint8)
+    box = np.array([120.0, 60.0, 360.0, 330.0, 0.99])
+    det = LM.LandmarkDetectorFA(net.state_dict(), face_detector=lambda im: [box, np.array([0, 0, 50, 50, 0.2])], num_modules=2)
+    bbox, lmks = det.detect_single_image(img)
+    assert len(bbox) == 1 and np.allclose(bbox[0], [120 / 480, 60 / 360, 360 / 480, 330 / 360, 0.99]) and lmks.shape == (68, 3) and np.all(lmks[:, 2] == 1.0)
+    center, scale = fan_ref.box_center_scale(box)
+    x = LM.crop_face(img, center, scale, 256, device="cpu")[None]
+    with torch.no_grad():
+        hm = net(x)[-1] + torch.flip(net(torch.flip(x, dims=[3]))[-1], dims=[3])[:, torch.as_tensor(LM.MIRROR_68)]
+    _, want = fan_ref.heatmaps_to_points(hm.numpy(), center, scale)
+    got = lmks[:, :2] * np.array([480.0, 360.0])
+    assert float(np.abs(got - want[0]).max()) <= 0.5 * 200.0 * scale / 64.0 + 1e-6      # at most a quarter-pixel decision apart, in image pixels
+    assert float((np.abs(got - want[0]).max(-1) > 1e-3).mean()) <= 0.05
+    none = LM.LandmarkDetectorFA(net.state_dict(), face_detector=lambda im: [], num_modules=2).detect_single_image(img)
+    assert none[0] == [] and np.all(none[1] == -1)

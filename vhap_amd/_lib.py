@@ -126,6 +126,10 @@ SIGNATURES = {
     "vhap_frame_color_correct": (c_i, [c_fp, c_fp, c_fp] + [c_i] * 4 + [c_fp, c_fp]),
     "vhap_frame_resize_u8": (c_i, [c_fp] + [c_i] * 4 + [c_fp, c_i, c_i, c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_fp]),
     "vhap_batch_feed": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i] + [c_fp, c_fp, c_i] * 3 + [c_fp, c_fp, c_fp]),
+    "vhap_conv2d_nhwc": (c_i, [c_fp, c_i, c_i, c_i, c_i, c_i] + [c_fp] * 4 + [c_i] * 4 + [c_fp, c_i, c_i, c_i, c_fp]),
+    "vhap_nhwc_avgpool2": (c_i, [c_fp] + [c_i] * 4 + [c_fp, c_fp]),
+    "vhap_nhwc_upsample2_add": (c_i, [c_fp, c_fp] + [c_i] * 4 + [c_fp, c_fp]),
+    "vhap_nhwc_add": (c_i, [c_fp, c_fp, c_fp, ctypes.c_longlong, c_fp, c_fp]),
     "vhap_plan_from_graph": (c_i, [c_fp, c_i, ctypes.POINTER(ctypes.c_void_p)]),
     "vhap_plan_destroy": (c_i, [c_fp]),
     "vhap_plan_set_side_base": (c_i, [c_i]),
@@ -151,6 +155,7 @@ CALL_PLAN_DEFER_JOIN = 64
 CALL_DELTA_UNSCALED = 128
 CALL_TEX_TERMS_CONSUME = 256
 CALL_SKIP_BG_GRAD = 512
+CONV_IN_RELU, CONV_OUT_RELU, CONV_ACCUMULATE = 1, 2, 4
 
 _lib = None
 

@@ -172,3 +172,24 @@ def tracker_from_reference_config(cls, ref_cfg, dataset=None, flame=None, base_t
     if path is not None:                                            # tracker.py:1260-1261
         tr.load_from_tracked_flame_params(path)
     return tr
+
+
+def detect_landmarks(ref_cfg, weights, checkout=None, face_detector=None, device="cuda"):
+    """`GlobalTracker.detect_landmarks(cfg)` of the reference (vhap/model/tracker.py:1263-1277) over vhap_amd.landmarks: the dataset opened through
+    the reference's own class with `use_landmark = False`, and -- for `landmark_source == 'face-alignment'`, unless `cfg.exp.reuse_landmarks` finds
+    the file -- every frame annotated by the FAN network on the matrix cores, the npz written where the reference's dataset will look for it.
+    `weights`: the `face_alignment` package's state dict (or a path torch.load reads): a third-party download, like the reference's.
+    `face_detector`: callable(img) -> boxes (the package's `sfd` network is not built; None = the whole frame).  -> {camera_id: path} or None."""
+    import copy
+    from .landmarks import LandmarkDetectorFA, annotate_landmarks
+    cfg_data = copy.deepcopy(ref_cfg.data)
+    cfg_data.use_landmark = False
+    dataset = open_reference_dataset(cfg_data, checkout, batchify_all_views=False)
+    source = ref_cfg.data.landmark_source
+    if source == "face-alignment":
+        if ref_cfg.exp.reuse_landmarks and dataset.get_property_path("landmark2d/face-alignment", -1).exists():
+            return None
+        return annotate_landmarks(dataset, LandmarkDetectorFA(weights, face_detector=face_detector, device=device))
+    if source == "star":
+        raise NotImplementedError("the STAR detector (vhap/util/landmark_detector_star.py) is not built: provide landmark2d/STAR.npz")
+    raise ValueError(f"Unknown landmark source: {source}")

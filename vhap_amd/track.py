@@ -13,7 +13,8 @@ Two ways to hand over the REFERENCE's configuration (its classes are imported fr
 
 Then, like the reference: tracker = GlobalTracker.from_reference_config(cfg); tracker.optimize(); the result goes to
 <output folder>/<timestamp>/tracked_flame_params.npz (the schema of tracker.py:1152-1218) next to a copy of the config.
-Landmarks must exist on disk (`cfg.exp.reuse_landmarks`; the detectors are SURVEY 8(f) rank 4, not built) and the licensed FLAME assets at
+Landmarks must exist on disk (`cfg.exp.reuse_landmarks`) or `--landmark-weights <state dict of the face_alignment FAN>` runs the detection
+first (vhap_amd.landmarks: the network on the matrix cores; the package's face detector and the STAR detector are not built), and the licensed FLAME assets at
 the reference's paths (vhap/model/flame.py:38-46), relative to the working directory."""
 import argparse
 import os
@@ -64,6 +65,8 @@ def main(argv=None):
     ap.add_argument("--batch-size", type=int, default=None)
     ap.add_argument("--no-evaluate", action="store_true")
     ap.add_argument("--device-prepare", action="store_true", help="colour correction / scale factor / compositing on the device (bit-identical)")
+    ap.add_argument("--landmark-weights", default=None, help="state dict of the face_alignment package's FAN: run landmark detection first "
+                    "(tracker.py:1263-1277; landmark_source 'face-alignment'), on the matrix cores (vhap_amd.landmarks)")
     ap.add_argument("--dry-run", action="store_true", help="load + convert the configuration, print the stage plan, do not open data or fit")
     ap.add_argument("-h", "--help", action="store_true")
     a, rest = ap.parse_known_args(argv)
@@ -96,6 +99,9 @@ def main(argv=None):
           f"stages: {', '.join(stages)}", flush=True)
     if a.dry_run:
         return 0
+    if a.landmark_weights is not None:
+        from .reference_adapter import detect_landmarks
+        detect_landmarks(cfg, a.landmark_weights, checkout=a.checkout, device=mine.device)
     from .tracker import GlobalTracker
     tracker = GlobalTracker.from_reference_config(cfg, checkout=a.checkout, device_prepare=a.device_prepare)
     out_dir = Path(cfg.exp.output_folder) / datetime.now().strftime("%Y-%m-%d_%H-%M-%S")      # tracker.py:1231-1232
