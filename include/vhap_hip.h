@@ -837,6 +837,13 @@ int vhap_plan_launch_timed(vhap_plan_t plan, vhap_stream_t stream, float* start_
 int vhap_conv2d_nhwc(const float* in, int in_channel_stride, int N, int H, int W, int Cin, const float* weight, const float* bias,
                      const float* in_scale, const float* in_shift, int KH, int KW, int stride, int pad, float* out, int out_channel_stride,
                      int Cout, int call_flags, vhap_stream_t stream);
+/* vhap_conv2d_nhwc with a workspace (device floats, may be NULL = vhap_conv2d_nhwc): when the pixel x channel tiles alone would leave the chip empty
+ * (the deep levels of the hourglass: a handful of workgroups walking 72 K tiles each) the K tiles are split over up to 16 slices whose partial sums
+ * [slices][N*Ho*Wo][Cout] go through the workspace and are summed in slice order by a second launch (bias / accumulate / ReLU there).  The split
+ * is a function of the shapes and of workspace_floats only: the same call gives the same bits. */
+int vhap_conv2d_nhwc_ws(const float* in, int in_channel_stride, int N, int H, int W, int Cin, const float* weight, const float* bias,
+                        const float* in_scale, const float* in_shift, int KH, int KW, int stride, int pad, float* out, int out_channel_stride,
+                        int Cout, float* workspace, long long workspace_floats, int call_flags, vhap_stream_t stream);
 int vhap_nhwc_avgpool2(const float* in, int N, int H, int W, int C, float* out, vhap_stream_t stream);
 int vhap_nhwc_upsample2_add(const float* skip, const float* low, int N, int H, int W, int C, float* out, vhap_stream_t stream);
 int vhap_nhwc_add(const float* a, const float* b, const float* c, long long n, float* out, vhap_stream_t stream);

@@ -59,7 +59,18 @@ def test_annotate_landmarks_writes_the_reference_layout(tmp_path):
         def __getitem__(self, i): return self.items[i]
         def get_property_path(self, name, camera_id=None): return tmp_path / name / f"{camera_id}.npz"
 
+    class DetMany(Det):                                                 # the batched form (one pass of the network over several frames)
+        sizes = []
+        def detect_images(self, imgs):
+            self.sizes.append(len(imgs))
+            return [self.detect_single_image(im) for im in imgs]
+
     paths = LM.annotate_landmarks(DS(), Det())
+    many = LM.annotate_landmarks(DS(), DetMany(), property_name="many", batch_frames=3)
+    assert DetMany.sizes == [3, 3, 2]
+    for c in ("a", "b"):
+        za, zb = np.load(paths[c]), np.load(many[c])
+        assert all(np.array_equal(za[k], zb[k]) for k in za.files)
     assert sorted(paths) == ["a", "b"]
     z = np.load(paths["a"])
     assert sorted(z.files) == ["bounding_box", "face_landmark_2d"] and z["face_landmark_2d"].shape == (4, 68, 3) and z["bounding_box"].shape == (4, 5)
@@ -120,11 +131,27 @@ def test_conv_matches_torch(N, H, W, Cin, Cout, K, stride, pad):
             ref = torch.relu(ref)
         out = (prev if acc else torch.full((N, Cout, Ho, Wo), float("nan"))).permute(0, 2, 3, 1).contiguous().cuda()
         flags = (_lib.CONV_IN_RELU if in_act else 0) | (_lib.CONV_OUT_RELU if out_relu else 0) | (_lib.CONV_ACCUMULATE if acc else 0)
+        first = out.clone()
         rc = L.vhap_conv2d_nhwc(_p(xd), Cin, N, H, W, Cin, _p(wd), _p(bd) if bias else 0, _p(scd) if in_act else 0,
                                 _p(shd) if in_act else 0, K, K, stride, pad, _p(out), Cout, Cout, flags, _stream())
         assert rc == 0
         torch.cuda.synchronize()
         assert _rel(out.cpu().permute(0, 3, 1, 2), ref) <= 2e-6, (in_act, bias, out_relu, acc)
+        # the same call with a workspace: the K tiles split over several workgroups where the grid is small (every case here but the 64 x 64 one),
+        # partial sums added in slice order by a second launch -- twice: the same bits
+        ws = torch.full((1 << 20,), float("nan"), device="cuda")
+        outs = []
+        for _ in range(2):
+            o = first.clone()
+            rc = L.vhap_conv2d_nhwc_ws(_p(xd), Cin, N, H, W, Cin, _p(wd), _p(bd) if bias else 0, _p(scd) if in_act else 0,
+                                       _p(shd) if in_act else 0, K, K, stride, pad, _p(o), Cout, Cout, _p(ws), ws.numel(), flags, _stream())
+            assert rc == 0
+            torch.cuda.synchronize()
+            outs.append(o)
+        assert _rel(outs[0].cpu().permute(0, 3, 1, 2), ref) <= 2e-6, ("split", in_act, bias, out_relu, acc)
+        assert torch.equal(outs[0], outs[1])
+        if K * K * ((Cin + 31) // 32) >= 4 and N * Ho * Wo * Cout <= ws.numel() // 2:
+            assert not torch.isnan(ws[:N * Ho * Wo * Cout * 2]).any()       # (the split happened: two slices at least were written)
 
 
 @pytest.mark.gpu
@@ -205,3 +232,7 @@ def test_detector_end_to_end_on_a_synthetic_frame():
     assert float((np.abs(got - want[0]).max(-1) > 1e-3).mean()) <= 0.05
     none = LM.LandmarkDetectorFA(net.state_dict(), face_detector=lambda im: [], num_modules=2).detect_single_image(img)
     assert none[0] == [] and np.all(none[1] == -1)
+    # several frames in ONE pass of the network (what annotate_landmarks does): a frame's landmarks do not depend on its batch -- bit for bit
+    img2 = rng.integers(0, 255, (360, 480, 3), dtype=np.uint8)
+    both = det.detect_images([img, img2, img])
+    assert np.array_equal(both[0][1], lmks) and np.array_equal(both[2][1], lmks) and np.array_equal(both[1][1], det.detect_single_image(img2)[1])

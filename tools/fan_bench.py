@@ -17,6 +17,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=2)
 ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--torch", action="store_true")
+ap.add_argument("--no-split", action="store_true", help="no split-K workspace: every convolution as one launch")
 a = ap.parse_args()
 net = fan_ref.random_fan(seed=0, num_modules=4)
 flops = [0]
@@ -35,6 +36,8 @@ for h in hs:
     h.remove()
 fan = LM.FAN2D(net.state_dict())
 xd = x.cuda()
+if a.no_split:
+    LM._WS[str(xd.device)] = torch.empty(0, device=xd.device)
 out = fan(xd)
 torch.cuda.synchronize()
 err = float((out[-1].cpu() - ref[-1]).abs().max() / ref[-1].abs().max())
@@ -46,7 +49,7 @@ for _ in range(a.reps):
     torch.cuda.synchronize()
     ts.append(time.perf_counter() - t0)
 t = sorted(ts)[len(ts) // 2]
-print(f"FAN2D forward, batch {a.batch} x 256^2, 4 stacks: {flops[0] / 1e9:.1f} GFLOP, {t * 1e3:.2f} ms (median of {a.reps}) = {flops[0] / t / 1e12:.1f} TFLOP/s fp32 "
+print(f"FAN2D forward{' (no split-K)' if a.no_split else ''}, batch {a.batch} x 256^2, 4 stacks: {flops[0] / 1e9:.1f} GFLOP, {t * 1e3:.2f} ms (median of {a.reps}) = {flops[0] / t / 1e12:.1f} TFLOP/s fp32 "
       f"({a.batch / t:.0f} crops/s); last stack vs torch-CPU fp32: {err:.1e} of the max-norm")
 if a.torch:
     g = net.cuda()

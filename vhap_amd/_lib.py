@@ -127,6 +127,7 @@ SIGNATURES = {
     "vhap_frame_resize_u8": (c_i, [c_fp] + [c_i] * 4 + [c_fp, c_i, c_i, c_fp, c_fp, c_i, c_fp, c_fp, c_i, c_fp]),
     "vhap_batch_feed": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_i] + [c_fp, c_fp, c_i] * 3 + [c_fp, c_fp, c_fp]),
     "vhap_conv2d_nhwc": (c_i, [c_fp, c_i, c_i, c_i, c_i, c_i] + [c_fp] * 4 + [c_i] * 4 + [c_fp, c_i, c_i, c_i, c_fp]),
+    "vhap_conv2d_nhwc_ws": (c_i, [c_fp, c_i, c_i, c_i, c_i, c_i] + [c_fp] * 4 + [c_i] * 4 + [c_fp, c_i, c_i, c_fp, ctypes.c_longlong, c_i, c_fp]),
     "vhap_nhwc_avgpool2": (c_i, [c_fp] + [c_i] * 4 + [c_fp, c_fp]),
     "vhap_nhwc_upsample2_add": (c_i, [c_fp, c_fp] + [c_i] * 4 + [c_fp, c_fp]),
     "vhap_nhwc_add": (c_i, [c_fp, c_fp, c_fp, ctypes.c_longlong, c_fp, c_fp]),

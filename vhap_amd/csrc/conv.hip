@@ -35,6 +35,7 @@ struct ConvArgs {
     int Ho, Wo, Cout;
     int KH, KW, stride, pad;
     int out_relu, accumulate;
+    float* part;          // split K (gridDim.z slices of the K tiles): partial sums [gridDim.z][N*Ho*Wo][Cout], summed by conv_splitk_finish_kernel; or null
 };
 
 // One K tile = one filter tap x 32 input channels.  The tile pair of step t + 1 is fetched into registers BEFORE the 32 MFMA of step t and stored into the
@@ -70,7 +71,9 @@ __global__ __launch_bounds__(CV_T) void conv2d_nhwc_kernel(const ConvArgs a) {
     const bool vec_in = (a.in_cs & 3) == 0 && (reinterpret_cast<uintptr_t>(a.in) & 15) == 0;
     const bool vec_w = (a.Cout & 3) == 0 && (reinterpret_cast<uintptr_t>(a.w) & 15) == 0;
     constexpr bool act = ACT;                                // (a.in_scale != nullptr)
-    const int ctiles = (a.Cin + CV_BK - 1) / CV_BK, nt = a.KH * a.KW * ctiles;
+    const int ctiles = (a.Cin + CV_BK - 1) / CV_BK, nt_all = a.KH * a.KW * ctiles;
+    // this workgroup's slice of the K tiles (gridDim.z = 1: all of them)
+    const int t0 = (int)((long long)nt_all * blockIdx.z / gridDim.z), t1 = (int)((long long)nt_all * (blockIdx.z + 1) / gridDim.z);
 
     float av[8], wv[8], scv[8], shv[8];
     bool cur_ok = false, w_ok0 = false, w_ok1 = false;
@@ -161,25 +164,34 @@ __global__ __launch_bounds__(CV_T) void conv2d_nhwc_kernel(const ConvArgs a) {
             for (int j = 0; j < 4; j++) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av1, Bs[buf][kk * 4 + lk][j * 16 + li], acc[j], 0, 0, 0);
         }
     };
-    issue(0);
+    issue(t0);
     commit(0);
     __syncthreads();
-    for (int t = 0; t + 1 < nt; t++) {                      // (no branch between the loads and their use: the last step is peeled)
+    for (int t = t0; t + 1 < t1; t++) {                     // (no branch between the loads and their use: the last step is peeled)
         issue(t + 1);
         __builtin_amdgcn_sched_barrier(0);                  // (the scheduler otherwise pulls the activation -- and the wait for its loads -- up among the MFMA)
-        multiply(t & 1);
+        multiply((t - t0) & 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < 8; u++) asm volatile("" : "+v"(av[u]) : : "memory");   // (the fetched tile is not touched before this point)
-        commit((t + 1) & 1);                                // (its last readers passed the barrier that ended step t - 1)
+        commit((t + 1 - t0) & 1);                           // (its last readers passed the barrier that ended step t - 1)
         __syncthreads();
     }
-    multiply((nt - 1) & 1);
+    multiply((t1 - 1 - t0) & 1);
     // lane (li, lk) holds rows lk * 4 + r (pixels) of column li (channel) of each of the four column tiles
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const long long pi = p0 + wave * 16 + lk * 4 + r;
         if (pi >= npix) continue;
+        if (a.part) {                                       // split K: this slice's partial sums; bias / accumulate / ReLU in the finish pass
+            float* pp = a.part + ((size_t)blockIdx.z * npix + pi) * a.Cout;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int co = n0 + j * 16 + li;
+                if (co < a.Cout) pp[co] = acc[j][r];
+            }
+            continue;
+        }
         float* op = a.out + (size_t)pi * a.out_cs;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -191,6 +203,22 @@ __global__ __launch_bounds__(CV_T) void conv2d_nhwc_kernel(const ConvArgs a) {
             op[co] = v;
         }
     }
+}
+
+// the slices of a split-K convolution summed in slice order (deterministic), then the epilogue of the unsplit kernel
+__global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const float* __restrict__ part, int ks, long long npix, int Cout, const float* __restrict__ bias,
+                                                                 float* out, int out_cs, int out_relu, int accumulate) {
+    const long long n = npix * Cout, i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const long long pi = i / Cout;
+    const int co = (int)(i - pi * Cout);
+    float v = part[i];
+    for (int z = 1; z < ks; z++) v += part[(size_t)z * n + i];
+    v += bias ? bias[co] : 0.f;
+    float* op = out + (size_t)pi * out_cs + co;
+    if (accumulate) v += *op;
+    if (out_relu) v = fmaxf(v, 0.f);
+    *op = v;
 }
 
 __global__ __launch_bounds__(256) void nhwc_avgpool2_kernel(const float* __restrict__ in, int N, int H, int W, int C, float* __restrict__ out) {
@@ -226,22 +254,37 @@ __global__ __launch_bounds__(256) void nhwc_add_kernel(const float* a, const flo
 
 }  // namespace
 
-extern "C" int vhap_conv2d_nhwc(const float* in, int in_channel_stride, int N, int H, int W, int Cin, const float* weight, const float* bias,
-                                const float* in_scale, const float* in_shift, int KH, int KW, int stride, int pad, float* out,
-                                int out_channel_stride, int Cout, int call_flags, vhap_stream_t stream) {
+extern "C" int vhap_conv2d_nhwc_ws(const float* in, int in_channel_stride, int N, int H, int W, int Cin, const float* weight, const float* bias,
+                                   const float* in_scale, const float* in_shift, int KH, int KW, int stride, int pad, float* out,
+                                   int out_channel_stride, int Cout, float* workspace, long long workspace_floats, int call_flags,
+                                   vhap_stream_t stream) {
     VHAP_ENTER();
     if (!in || !weight || !out) return VHAP_E_NULLPTR;
     if ((in_scale == nullptr) != (in_shift == nullptr)) return VHAP_E_NULLPTR;
     if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad < 0 || in_channel_stride < Cin ||
-        out_channel_stride < Cout)
+        out_channel_stride < Cout || workspace_floats < 0)
         return VHAP_E_BADDIM;
     const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
     if (Ho <= 0 || Wo <= 0) return VHAP_E_BADDIM;
+    const long long npix = (long long)N * Ho * Wo;
+    const unsigned gx = (unsigned)vhap_cdiv(npix, CV_BM), gy = (unsigned)vhap_cdiv(Cout, CV_BN);
+    // Split K when the pixel x channel tiles alone leave the chip empty (the deep levels of the hourglass are 1 .. 64 tiles walking 72 K tiles
+    // one after the other): aim at ~768 workgroups, at least two K tiles per slice, what the workspace holds.  A function of the shapes and of
+    // the workspace size only: the same call gives the same sums.
+    int ks = 1;
+    if (workspace) {
+        const int nt = KH * KW * (int)vhap_cdiv(Cin, CV_BK);
+        const long long wgs = (long long)gx * gy;
+        long long want = (768 + wgs - 1) / wgs;
+        if (want > 16) want = 16;
+        if (want > nt / 2) want = nt / 2;
+        while (want > 1 && want * npix * Cout > workspace_floats) want--;
+        if (want > 1) ks = (int)want;
+    }
     ConvArgs a{in, in_channel_stride, N, H, W, Cin, weight, bias, in_scale, in_shift, (call_flags & VHAP_CONV_IN_RELU) ? 1 : 0,
                out, out_channel_stride, Ho, Wo, Cout, KH, KW, stride, pad, (call_flags & VHAP_CONV_OUT_RELU) ? 1 : 0,
-               (call_flags & VHAP_CONV_ACCUMULATE) ? 1 : 0};
-    const long long npix = (long long)N * Ho * Wo;
-    const dim3 grid((unsigned)vhap_cdiv(npix, CV_BM), (unsigned)vhap_cdiv(Cout, CV_BN));
+               (call_flags & VHAP_CONV_ACCUMULATE) ? 1 : 0, ks > 1 ? workspace : nullptr};
+    const dim3 grid(gx, gy, (unsigned)ks);
     const bool al16 = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(weight) | reinterpret_cast<uintptr_t>(in_scale) |
                         reinterpret_cast<uintptr_t>(in_shift)) & 15) == 0;
     const bool fast = al16 && Cin % CV_BK == 0 && (in_channel_stride & 3) == 0 && (Cout & 3) == 0;
@@ -249,7 +292,19 @@ extern "C" int vhap_conv2d_nhwc(const float* in, int in_channel_stride, int N, i
                   : (in_scale ? conv2d_nhwc_kernel<false, true> : conv2d_nhwc_kernel<false, false>);
     k<<<grid, CV_T, 0, vhap_stream(stream)>>>(a);
     VHAP_LAUNCH_CHECK();
+    if (ks > 1) {
+        conv_splitk_finish_kernel<<<(unsigned)vhap_cdiv(npix * Cout, 256), 256, 0, vhap_stream(stream)>>>(workspace, ks, npix, Cout, bias, out, out_channel_stride,
+                                                                                                         a.out_relu, a.accumulate);
+        VHAP_LAUNCH_CHECK();
+    }
     return VHAP_OK;
+}
+
+extern "C" int vhap_conv2d_nhwc(const float* in, int in_channel_stride, int N, int H, int W, int Cin, const float* weight, const float* bias,
+                                const float* in_scale, const float* in_shift, int KH, int KW, int stride, int pad, float* out,
+                                int out_channel_stride, int Cout, int call_flags, vhap_stream_t stream) {
+    return vhap_conv2d_nhwc_ws(in, in_channel_stride, N, H, W, Cin, weight, bias, in_scale, in_shift, KH, KW, stride, pad, out, out_channel_stride, Cout,
+                               nullptr, 0, call_flags, stream);
 }
 
 extern "C" int vhap_nhwc_avgpool2(const float* in, int N, int H, int W, int C, float* out, vhap_stream_t stream) {

@@ -6,13 +6,15 @@ flip_input=True)`, `annotate_landmarks` (:143-190) runs it over a dataset and wr
 `face_landmark_2d [T,68,3]` (x / w, y / h, confidence) and `bounding_box [T,5]`.  The package is absent from the reference checkout and from
 this image; its network is the published FAN (Bulat & Tzimiropoulos, ICCV 2017), restated for the tests in oracle/fan_ref.py.
 
-Built here (round 6, a START of the row -- what is and is not there):
-  * `FAN2D`: the network's forward as ~200 launches of `vhap_conv2d_nhwc` (exact-fp32 MFMA implicit GEMM; the blocks' pre-activation
+Built here (round 6 -- what is and is not there):
+  * `FAN2D`: the network's forward as ~200 launches of `vhap_conv2d_nhwc_ws` (exact-fp32 MFMA implicit GEMM, K split over workgroups where
+    the output is small; 4.0 ms for a crop and its mirror image, profiles/r06_fan_bench.txt; the blocks' pre-activation
     BatchNorm + ReLU fused into the staging of the input tile, the three convolutions of a block writing the channel slices of its concatenated
     output in place, the projected skip accumulated by the last launch) and the hourglass's elementwise glue (`vhap_nhwc_avgpool2`,
     `vhap_nhwc_upsample2_add`, `vhap_nhwc_add`).  Takes the package's state dict (same parameter names), so its weights load unchanged.
     There is NO eager / CPU fallback: CPU tensors raise.
-  * `LandmarkDetectorFA.detect_single_image(img)` with the reference's return convention, `annotate_landmarks(dataset, detector)` with the
+  * `LandmarkDetectorFA.detect_single_image(img)` with the reference's return convention (`detect_images(imgs)`: several frames and their
+    mirror images in ONE pass of the network -- a frame's result does not depend on its batch), `annotate_landmarks(dataset, detector)` with the
     reference's npz layout; crop / flip-averaging / heat-map decoding restated from the package's published behaviour.
   * NOT built: the face detector (`sfd`, a second third-party network): boxes are an input (`face_detector=` any callable, or the whole frame);
     the STAR detector (vhap/util/landmark_detector_star.py); the package's weights (a third-party download).
@@ -39,6 +41,18 @@ def _chk(rc, what):
     _lib.check(rc, what)
 
 
+_WS = {}
+
+
+def _workspace(device):
+    """the split-K workspace of vhap_conv2d_nhwc_ws, one per device (launches of one stream use it one after the other): 4 M floats hold the
+    partial sums of every layer the library splits at the detector's batch sizes (the largest: 4 slices of a 32 x 32 x 128 output, batch 4)"""
+    key = str(device)
+    if key not in _WS:
+        _WS[key] = torch.empty(1 << 22, dtype=torch.float32, device=device)
+    return _WS[key]
+
+
 class _Conv:
     """one convolution's device-side constants: weight [KH,KW,Cin,Cout], optional bias, optional input BatchNorm as (scale, shift)"""
 
@@ -61,10 +75,11 @@ class _Conv:
         """x, out: NHWC buffers; the convolution reads channels [x_off, x_off + cin) of x and writes [out_off, out_off + cout) of out"""
         N, H, W, Cs = x.shape
         assert x_cin == self.cin and x.is_cuda and out.is_cuda and x.dtype == out.dtype == torch.float32 and x.is_contiguous() and out.is_contiguous()
-        rc = _lib.lib().vhap_conv2d_nhwc(x.data_ptr() + 4 * x_off, Cs, N, H, W, self.cin, _p(self.w), _p(self.bias), _p(self.scale), _p(self.shift),
-                                         self.KH, self.KW, self.stride, self.pad, out.data_ptr() + 4 * out_off, out.shape[3], self.cout,
-                                         self.flags | (_lib.CONV_ACCUMULATE if accumulate else 0), _stream())
-        _chk(rc, "vhap_conv2d_nhwc")
+        ws = _workspace(x.device)
+        rc = _lib.lib().vhap_conv2d_nhwc_ws(x.data_ptr() + 4 * x_off, Cs, N, H, W, self.cin, _p(self.w), _p(self.bias), _p(self.scale), _p(self.shift),
+                                            self.KH, self.KW, self.stride, self.pad, out.data_ptr() + 4 * out_off, out.shape[3], self.cout,
+                                            _p(ws), ws.numel(), self.flags | (_lib.CONV_ACCUMULATE if accumulate else 0), _stream())
+        _chk(rc, "vhap_conv2d_nhwc_ws")
         return out
 
 
@@ -246,49 +261,81 @@ class LandmarkDetectorFA:
         self.net = FAN2D(weights, num_modules=num_modules, device=device)
         self.face_detector, self.flip_input, self.device = face_detector, bool(flip_input), device
 
-    def landmarks_from_box(self, img, box):
-        center, scale = box_center_scale(box)
-        x = crop_face(img, center, scale, 256, self.device)[None]
+    def landmarks_from_boxes(self, imgs, boxes):
+        """68 image-space landmarks per (frame, box): the crops of all frames AND their mirror images (flip_input) go through the network as ONE
+        batch -- the package runs two passes per frame; a sample's result does not depend on its batch."""
+        n = len(imgs)
+        cs = [box_center_scale(b) for b in boxes]
+        x = torch.stack([crop_face(img, c, s, 256, self.device) for img, (c, s) in zip(imgs, cs)])
+        if self.flip_input:
+            x = torch.cat([x, torch.flip(x, dims=[3])])
         hm = self.net(x)[-1]
         if self.flip_input:                                # the package averages the heat maps of the mirrored pass (left / right swapped back)
-            hm_f = self.net(torch.flip(x, dims=[3]))[-1]
-            hm = hm + torch.flip(hm_f, dims=[3])[:, torch.as_tensor(MIRROR_68, device=hm.device)]
-        _, pts_img, _ = heatmaps_to_points(hm, center, scale)
-        return pts_img[0]
+            hm = hm[:n] + torch.flip(hm[n:], dims=[3])[:, torch.as_tensor(MIRROR_68, device=hm.device)]
+        return [heatmaps_to_points(hm[i:i + 1], c, s)[1][0] for i, (c, s) in enumerate(cs)]
 
-    def detect_single_image(self, img):
-        """-> (bbox list, lmks [68,3]): x / w, y / h, confidence -- and all -1 when no face was found, like the reference"""
-        img = np.asarray(img)
+    def landmarks_from_box(self, img, box):
+        return self.landmarks_from_boxes([img], [box])[0]
+
+    def _boxes(self, img):
         h, w = img.shape[:2]
         boxes = [np.array([0.0, 0.0, float(w), float(h), 1.0])] if self.face_detector is None else [np.asarray(b, np.float64) for b in self.face_detector(img)]
-        if len(boxes) == 0:
-            return [], np.zeros([68, 3]) - 1
         if len(boxes) > 1:
             boxes = [boxes[int(np.argmax(np.array(boxes)[:, -1]))]]
-        lmks = self.landmarks_from_box(img, boxes[0])
+        return boxes
+
+    @staticmethod
+    def _normalised(img, box, lmks):
+        h, w = img.shape[:2]
         lmks = np.concatenate([lmks, np.ones_like(lmks[:, :1])], axis=1)
         lmks[:, 2:] = 0.0 if (lmks[:, :2] == -1).sum() > 0 else 1.0
         lmks[:, 0] /= w
         lmks[:, 1] /= h
-        box = boxes[0].copy()
+        box = box.copy()
         box[[0, 2]] /= w
         box[[1, 3]] /= h
         return [box], lmks
 
+    def detect_images(self, imgs):
+        """detect_single_image over several frames with ONE pass of the network: -> list of (bbox list, lmks [68,3])"""
+        imgs = [np.asarray(im) for im in imgs]
+        boxes = [self._boxes(im) for im in imgs]
+        have = [i for i, b in enumerate(boxes) if len(b)]
+        pts = self.landmarks_from_boxes([imgs[i] for i in have], [boxes[i][0] for i in have]) if have else []
+        out = [([], np.zeros([68, 3]) - 1) for _ in imgs]           # no face found: all -1, like the reference
+        for i, p in zip(have, pts):
+            out[i] = self._normalised(imgs[i], boxes[i][0], p)
+        return out
 
-def annotate_landmarks(dataset, detector, property_name="landmark2d/face-alignment"):
+    def detect_single_image(self, img):
+        """-> (bbox list, lmks [68,3]): x / w, y / h, confidence -- and all -1 when no face was found, like the reference"""
+        return self.detect_images([img])[0]
+
+
+def annotate_landmarks(dataset, detector, property_name="landmark2d/face-alignment", batch_frames=8):
     """vhap/util/landmark_detector_fa.py:143-190 with `detector` (a LandmarkDetectorFA of this module): every item of a reference dataset
     (items with 'rgb' [H,W,3] uint8, 'timestep_id', 'camera_id'; `get_property_path(name, camera_id=)`) -> one npz per camera with
     `face_landmark_2d [T,68,3]` and `bounding_box [T,5]`, timesteps in sorted order.  -> {camera_id: path}"""
     landmarks, bboxes = {}, {}
+    pending = []
+
+    def flush():
+        imgs = [np.asarray(it["rgb"]) for it in pending]
+        many = getattr(detector, "detect_images", None)
+        for item, (bbox, lmks) in zip(pending, many(imgs) if many is not None else [detector.detect_single_image(im) for im in imgs]):
+            cam, ts = item["camera_id"], item["timestep_id"]
+            landmarks.setdefault(cam, {})[ts] = lmks
+            bboxes.setdefault(cam, {})[ts] = bbox[0] if len(bbox) > 0 else np.zeros(5) - 1
+        pending.clear()
     for i in range(len(dataset)):
         item = dataset[i]
         if item is None:
             continue
-        bbox, lmks = detector.detect_single_image(np.asarray(item["rgb"]))
-        cam, ts = item["camera_id"], item["timestep_id"]
-        landmarks.setdefault(cam, {})[ts] = lmks
-        bboxes.setdefault(cam, {})[ts] = bbox[0] if len(bbox) > 0 else np.zeros(5) - 1
+        pending.append(item)
+        if len(pending) >= batch_frames:                   # (the reference goes frame by frame; the network fills the chip from ~8 frames = 16 crops on)
+            flush()
+    if pending:
+        flush()
     paths = {}
     for cam, per_ts in landmarks.items():
         order = sorted(per_ts.keys())
