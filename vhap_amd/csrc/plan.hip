@@ -22,6 +22,8 @@
 #include <string>
 #include <vector>
 
+#include <hip/hip_ext.h>
+
 #include "common.h"
 
 namespace {
@@ -53,6 +55,7 @@ struct vhap_plan {
     std::vector<hipEvent_t> tails;      // one per side stream: the launch stream waits for them at the end of a replay
     std::vector<hipEvent_t> tev;        // timing events (2 per node + 1), created by the first timed launch
     bool tails_open = false;            // the last launch deferred its join
+    bool tails_recorded = true;         // ... and recorded its tail events (false: vhap_plan_join records them)
     int device = 0;
 };
 
@@ -478,15 +481,28 @@ static int plan_launch(vhap_plan* p, hipStream_t launch, bool timed, bool defer_
         hipStream_t st = stream_of(p, nd.stream, launch);
         for (int e : nd.waits) PLAN_HIP(hipStreamWaitEvent(st, p->events[e], 0));
         if (timed) PLAN_HIP(hipEventRecord(p->tev[2 * k], st));
-        PLAN_HIP(launch_node(nd, st));
+        // An edge event recorded by a SEPARATE packet behind the kernel costs the recording stream ~5 us before its next kernel starts (the
+        // step's main chain records four).  A kernel node hands its edge event to the dispatch itself (hipExtLaunchKernel's stop event: the
+        // packet's own completion signal) -- debug flag 2097152: A/B, the separate record.
+        const bool bound = nd.record >= 0 && nd.type == 0 && !timed && !(vhap_g_debug_flags & 2097152);
+        if (bound)
+            PLAN_HIP(hipExtLaunchKernel(nd.kp.func, nd.kp.gridDim, nd.kp.blockDim, nd.kp.kernelParams, nd.kp.sharedMemBytes, st, nullptr,
+                                        p->events[nd.record], 0));
+        else
+            PLAN_HIP(launch_node(nd, st));
         if (timed) PLAN_HIP(hipEventRecord(p->tev[2 * k + 1], st));
-        if (nd.record >= 0) PLAN_HIP(hipEventRecord(p->events[nd.record], st));
+        if (nd.record >= 0 && !bound) PLAN_HIP(hipEventRecord(p->events[nd.record], st));
     }
-    for (size_t s = 0; s < p->streams.size(); s++) {
+    // The tail events: a joined replay records and waits here; a replay that defers its join leaves the record to vhap_plan_join (in-order
+    // streams: an event recorded later covers the same work) -- one packet less per side stream and replay, and none between the open tail
+    // and the next replay's first node on its stream.  (debug flag 4194304: A/B, record here in both cases)
+    const bool lazy_tails = defer_join && !(vhap_g_debug_flags & 4194304);
+    for (size_t s = 0; s < p->streams.size() && !lazy_tails; s++) {
         PLAN_HIP(hipEventRecord(p->tails[s], p->streams[s]));
         if (!defer_join) PLAN_HIP(hipStreamWaitEvent(launch, p->tails[s], 0));
     }
     p->tails_open = defer_join && !p->streams.empty();
+    p->tails_recorded = !lazy_tails;
 #undef PLAN_HIP
     return VHAP_OK;
 }
@@ -502,9 +518,12 @@ extern "C" int vhap_plan_join(vhap_plan_t plan, vhap_stream_t stream) {
     VHAP_ENTER();
     if (!plan) return VHAP_E_NULLPTR;
     if (plan->tails_open) {
-        for (size_t s = 0; s < plan->streams.size(); s++)
+        for (size_t s = 0; s < plan->streams.size(); s++) {
+            if (!plan->tails_recorded && hipEventRecord(plan->tails[s], plan->streams[s]) != hipSuccess) return VHAP_E_HIP;
             if (hipStreamWaitEvent(vhap_stream(stream), plan->tails[s], 0) != hipSuccess) return VHAP_E_HIP;
+        }
         plan->tails_open = false;
+        plan->tails_recorded = true;
     }
     return VHAP_OK;
 }
