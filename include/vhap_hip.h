@@ -846,6 +846,11 @@ int vhap_conv2d_nhwc_ws(const float* in, int in_channel_stride, int N, int H, in
                         int Cout, float* workspace, long long workspace_floats, int call_flags, vhap_stream_t stream);
 int vhap_nhwc_avgpool2(const float* in, int N, int H, int W, int C, float* out, vhap_stream_t stream);
 int vhap_nhwc_upsample2_add(const float* skip, const float* low, int N, int H, int W, int C, float* out, vhap_stream_t stream);
+/* The face detector of the same package (`face_detector='sfd'`, landmark_detector_fa.py:32,45,51: S3FD, Zhang et al., ICCV 2017 -- a VGG-16 trunk with six
+ * detection heads; host side: vhap_amd/face_detector.py) needs two more layer kinds: vhap_nhwc_maxpool2 = torch's max_pool2d(x, 2, 2) (floor mode:
+ * out [N, H/2, W/2, C]); vhap_nhwc_l2norm = its L2Norm layer, out[p, c] = in[p, c] / (sqrt(sum_c in[p, c]^2) + eps) * weight[c] over npix pixels. */
+int vhap_nhwc_maxpool2(const float* in, int N, int H, int W, int C, float* out, vhap_stream_t stream);
+int vhap_nhwc_l2norm(const float* in, long long npix, int C, const float* weight, float eps, float* out, vhap_stream_t stream);
 int vhap_nhwc_add(const float* a, const float* b, const float* c, long long n, float* out, vhap_stream_t stream);
 
 #ifdef __cplusplus

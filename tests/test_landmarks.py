@@ -107,7 +107,8 @@ def _rel(a, b):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("N,H,W,Cin,Cout,K,stride,pad", [(2, 16, 20, 32, 32, 3, 1, 1), (1, 64, 64, 256, 128, 3, 1, 1), (3, 8, 8, 68, 256, 1, 1, 0),
-                                                          (2, 64, 48, 3, 64, 7, 2, 3), (1, 32, 32, 256, 68, 1, 1, 0), (1, 4, 4, 64, 64, 3, 1, 1)])
+                                                          (2, 64, 48, 3, 64, 7, 2, 3), (1, 32, 32, 256, 68, 1, 1, 0), (1, 4, 4, 64, 64, 3, 1, 1),
+                                                          (2, 128, 128, 32, 256, 3, 1, 1), (1, 200, 180, 3, 256, 3, 1, 1)])   # (the last two: large enough for the 128-pixel form)
 def test_conv_matches_torch(N, H, W, Cin, Cout, K, stride, pad):
     from vhap_amd import _lib
     from vhap_amd.ops import _p, _stream
@@ -150,6 +151,16 @@ def test_conv_matches_torch(N, H, W, Cin, Cout, K, stride, pad):
             outs.append(o)
         assert _rel(outs[0].cpu().permute(0, 3, 1, 2), ref) <= 2e-6, ("split", in_act, bias, out_relu, acc)
         assert torch.equal(outs[0], outs[1])
+        if N * Ho * Wo * ((Cout + 63) // 64) >= 128 * 1024:
+            # the 128-pixel workgroups (debug flag 8388608; measured: no faster): the same sums in the same order as the shipped 64-pixel form -- the same bits
+            _lib.debug_set_flags(8388608)
+            o64 = first.clone()
+            rc = L.vhap_conv2d_nhwc(_p(xd), Cin, N, H, W, Cin, _p(wd), _p(bd) if bias else 0, _p(scd) if in_act else 0,
+                                    _p(shd) if in_act else 0, K, K, stride, pad, _p(o64), Cout, Cout, flags, _stream())
+            _lib.debug_set_flags(0)
+            assert rc == 0
+            torch.cuda.synchronize()
+            assert torch.equal(o64, out)
         if K * K * ((Cin + 31) // 32) >= 4 and N * Ho * Wo * Cout <= ws.numel() // 2:
             assert not torch.isnan(ws[:N * Ho * Wo * Cout * 2]).any()       # (the split happened: two slices at least were written)
 

@@ -19,6 +19,9 @@ ap.add_argument("--reps", type=int, default=10)
 ap.add_argument("--torch", action="store_true")
 ap.add_argument("--no-split", action="store_true", help="no split-K workspace: every convolution as one launch")
 a = ap.parse_args()
+if os.environ.get("VHAP_DEBUG"):                       # the library's A/B switches (8388608: 64-pixel workgroups everywhere)
+    from vhap_amd import _lib
+    _lib.debug_set_flags(int(os.environ["VHAP_DEBUG"]))
 net = fan_ref.random_fan(seed=0, num_modules=4)
 flops = [0]
 

@@ -130,6 +130,8 @@ SIGNATURES = {
     "vhap_conv2d_nhwc_ws": (c_i, [c_fp, c_i, c_i, c_i, c_i, c_i] + [c_fp] * 4 + [c_i] * 4 + [c_fp, c_i, c_i, c_fp, ctypes.c_longlong, c_i, c_fp]),
     "vhap_nhwc_avgpool2": (c_i, [c_fp] + [c_i] * 4 + [c_fp, c_fp]),
     "vhap_nhwc_upsample2_add": (c_i, [c_fp, c_fp] + [c_i] * 4 + [c_fp, c_fp]),
+    "vhap_nhwc_maxpool2": (c_i, [c_fp] + [c_i] * 4 + [c_fp, c_fp]),
+    "vhap_nhwc_l2norm": (c_i, [c_fp, ctypes.c_longlong, c_i, c_fp, ctypes.c_float, c_fp, c_fp]),
     "vhap_nhwc_add": (c_i, [c_fp, c_fp, c_fp, ctypes.c_longlong, c_fp, c_fp]),
     "vhap_plan_from_graph": (c_i, [c_fp, c_i, ctypes.POINTER(ctypes.c_void_p)]),
     "vhap_plan_destroy": (c_i, [c_fp]),

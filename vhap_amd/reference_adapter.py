@@ -174,14 +174,18 @@ def tracker_from_reference_config(cls, ref_cfg, dataset=None, flame=None, base_t
     return tr
 
 
-def detect_landmarks(ref_cfg, weights, checkout=None, face_detector=None, device="cuda"):
+def detect_landmarks(ref_cfg, weights, checkout=None, face_detector=None, device="cuda", face_detector_weights=None):
     """`GlobalTracker.detect_landmarks(cfg)` of the reference (vhap/model/tracker.py:1263-1277) over vhap_amd.landmarks: the dataset opened through
     the reference's own class with `use_landmark = False`, and -- for `landmark_source == 'face-alignment'`, unless `cfg.exp.reuse_landmarks` finds
     the file -- every frame annotated by the FAN network on the matrix cores, the npz written where the reference's dataset will look for it.
     `weights`: the `face_alignment` package's state dict (or a path torch.load reads): a third-party download, like the reference's.
-    `face_detector`: callable(img) -> boxes (the package's `sfd` network is not built; None = the whole frame).  -> {camera_id: path} or None."""
+    `face_detector`: callable(img) -> boxes, or `face_detector_weights`: the state dict of the package's `sfd` network (vhap_amd.face_detector.SFDDetector:
+    S3FD on the matrix cores); neither: the whole frame is the box.  -> {camera_id: path} or None."""
     import copy
     from .landmarks import LandmarkDetectorFA, annotate_landmarks
+    if face_detector is None and face_detector_weights is not None:
+        from .face_detector import SFDDetector
+        face_detector = SFDDetector(face_detector_weights, device=device)
     cfg_data = copy.deepcopy(ref_cfg.data)
     cfg_data.use_landmark = False
     dataset = open_reference_dataset(cfg_data, checkout, batchify_all_views=False)

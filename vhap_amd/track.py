@@ -14,7 +14,7 @@ Two ways to hand over the REFERENCE's configuration (its classes are imported fr
 Then, like the reference: tracker = GlobalTracker.from_reference_config(cfg); tracker.optimize(); the result goes to
 <output folder>/<timestamp>/tracked_flame_params.npz (the schema of tracker.py:1152-1218) next to a copy of the config.
 Landmarks must exist on disk (`cfg.exp.reuse_landmarks`) or `--landmark-weights <state dict of the face_alignment FAN>` runs the detection
-first (vhap_amd.landmarks: the network on the matrix cores; the package's face detector and the STAR detector are not built), and the licensed FLAME assets at
+first (vhap_amd.landmarks: the network on the matrix cores; `--face-detector-weights`: the package's `sfd` detector, vhap_amd.face_detector; the STAR detector is not built), and the licensed FLAME assets at
 the reference's paths (vhap/model/flame.py:38-46), relative to the working directory."""
 import argparse
 import os
@@ -67,6 +67,8 @@ def main(argv=None):
     ap.add_argument("--device-prepare", action="store_true", help="colour correction / scale factor / compositing on the device (bit-identical)")
     ap.add_argument("--landmark-weights", default=None, help="state dict of the face_alignment package's FAN: run landmark detection first "
                     "(tracker.py:1263-1277; landmark_source 'face-alignment'), on the matrix cores (vhap_amd.landmarks)")
+    ap.add_argument("--face-detector-weights", default=None, help="state dict of the package's `sfd` face detector (S3FD on the matrix cores, "
+                    "vhap_amd.face_detector); without it the whole frame is the face box")
     ap.add_argument("--dry-run", action="store_true", help="load + convert the configuration, print the stage plan, do not open data or fit")
     ap.add_argument("-h", "--help", action="store_true")
     a, rest = ap.parse_known_args(argv)
@@ -101,7 +103,7 @@ def main(argv=None):
         return 0
     if a.landmark_weights is not None:
         from .reference_adapter import detect_landmarks
-        detect_landmarks(cfg, a.landmark_weights, checkout=a.checkout, device=mine.device)
+        detect_landmarks(cfg, a.landmark_weights, checkout=a.checkout, device=mine.device, face_detector_weights=a.face_detector_weights)
     from .tracker import GlobalTracker
     tracker = GlobalTracker.from_reference_config(cfg, checkout=a.checkout, device_prepare=a.device_prepare)
     out_dir = Path(cfg.exp.output_folder) / datetime.now().strftime("%Y-%m-%d_%H-%M-%S")      # tracker.py:1231-1232
