@@ -127,6 +127,25 @@ def test_deferred_kernels_match_the_separate_passes(flame_model, monkeypatch, B,
     assert rel(d_tc * m, ns.d_texc * m) <= 1e-5 and rel(d_td * m, ns.d_texd * m) <= 1e-5
     assert float(ns.d_texd.abs().max()) > 0 and float(ns.d_texc.abs().max()) > 0
     assert rel(d_lights, ref_lights) <= 2e-5, (d_lights, ref_lights)
+    # the pass walks a frame as 16 x 16 tiles of 8 x 8 wave blocks (round 6) or -- widths 449 .. 512 -- in row order, 256 consecutive pixels per
+    # workgroup: forced either way (debug flags 16777216 row order, 268435456 tiles; 33554432: 64 x 4 tiles of 64 x 1 waves) every per-pixel output
+    # is the same bits and the lights gradient the same sum in another order
+    for flag in (16777216, 268435456, 33554432):
+        outs = [E(B, H, W, 2), E(B, H, W, 4), E(B, H, W, 3), E(B, H, W, 3), E(B, H, W, 2), E(B, H, W, 4)]
+        for t in outs:
+            t.zero_()
+        d_lights_t, work_t = torch.zeros(9, 3, device=dev), torch.zeros_like(work)
+        _lib.debug_set_flags(flag)
+        rc = L.vhap_deferred_shade_bwd(_p(ns.clip), _p(ns.tri), _p(ns.vn), _p(ns.uv), _p(ns.tri_uv), _p(ns.albedo_tex), _p(ns.mips), T, T,
+                                       _p(tr.lights), _p(ns.sh_const), _p(ns.rast), _p(ns.d_color), 0, 0, 0, 0, _p(ns.keep), _p(ns.c_reg),
+                                       _p(ns.accF[12:16]), B, V, ns.uv.shape[0], F, H, W, *[_p(t) for t in outs], _p(d_lights_t), _p(work_t),
+                                       work_t.numel(), 0, 0, 0, _stream())
+        _lib.debug_set_flags(0)
+        assert rc == 0
+        torch.cuda.synchronize()
+        for a, b in zip(outs, (texc, texd, d_alb, d_n, d_tc, d_td)):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32)), flag
+        assert rel(d_lights_t, d_lights) <= 2e-6
 
 
 def test_deferred_step_matches_separate_pass_step(flame_model, monkeypatch):

@@ -15,6 +15,7 @@ import bench  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--config", type=int, default=2)
+ap.add_argument("--shape", default="", help="B,H,W in place of the configuration's")
 ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--only", default="")
 ap.add_argument("--debug-flags", type=int, default=0, help="vhap_debug_set_flags for the timed calls (A/B switches inside kernels)")
@@ -22,7 +23,9 @@ ap.add_argument("--cold", action="store_true", help="every timed call starts wit
                 "Infinity Cache hold nothing of the call's inputs) -- what a kernel sees inside the step, where ~1 GB of other traffic "
                 "flows between its producer and it; the median of --reps single calls")
 args = ap.parse_args()
-C = bench.CONFIGS[args.config]
+C = dict(bench.CONFIGS[args.config])
+if args.shape:                                             # (a probe size, not a BASELINE configuration: B,H,W)
+    C["B"], C["H"], C["W"] = (int(v) for v in args.shape.split(","))
 tr, own, n_local, model, topo, gt = bench.build_tracker(C, 0, 1, "cuda:0", "weak")
 from vhap_amd import _lib  # noqa: E402
 from vhap_amd.ops import _p, _stream  # noqa: E402

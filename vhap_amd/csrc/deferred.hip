@@ -33,8 +33,32 @@ __global__ __launch_bounds__(DB_T) void deferred_shade_bwd_kernel(const Deferred
     const unsigned HW = (unsigned)P.H * P.W, npix = (unsigned)P.B * HW;
     const int lane = threadIdx.x & 63;
     const DiffuseReg R = diffuse_reg(P.d_reg, P.stats, npix);
-    const unsigned pi = blockIdx.x * DB_T + threadIdx.x;
-    const bool valid = pi < npix;
+    // Which pixel a thread takes: 256 consecutive pixels of a row per workgroup, or (P.tiled) a tile of the frame per workgroup and a block of it per
+    // wave.  In row order a 16 x 512^2 head batch leaves 16 % of the workgroups without a covered pixel, 40 % of all WAVES are background waves inside
+    // mixed workgroups -- resident until their workgroup's epilogue -- and the waves that work are 76 % full (profiles/r06_coverage_stats.txt); as tiles
+    // the mixed workgroups are the silhouette only.  Which is faster depends on the frame size: see the launch.
+    unsigned pi, wg_valid;
+    bool valid;
+    if (P.tiled) {
+        // tile shapes (workgroup / wave): 1 = 16 x 16 / 8 x 8, 2 = 64 x 4 / 64 x 1, 3 = 32 x 8 / 32 x 2, 4 = 16 x 16 / 16 x 4
+        const unsigned tw = P.tiled == 2 ? 64u : (P.tiled == 3 ? 32u : 16u), th = 256u / tw;
+        const unsigned tpf = (unsigned)P.tiles_x * P.tiles_y, b = blockIdx.x / tpf, tr = blockIdx.x - b * tpf;
+        const unsigned ty = tr / (unsigned)P.tiles_x, tx = tr - ty * (unsigned)P.tiles_x;
+        const unsigned wv = threadIdx.x >> 6, ln = (unsigned)lane;
+        unsigned lx, ly;
+        if (P.tiled == 1) { lx = (wv & 1u) * 8u + (ln & 7u); ly = (wv >> 1) * 8u + (ln >> 3); }
+        else if (P.tiled == 2) { lx = ln; ly = wv; }
+        else if (P.tiled == 3) { lx = ln & 31u; ly = wv * 2u + (ln >> 5); }
+        else { lx = ln & 15u; ly = wv * 4u + (ln >> 4); }
+        const unsigned px = tx * tw + lx, py = ty * th + ly;
+        valid = px < (unsigned)P.W && py < (unsigned)P.H;
+        pi = valid ? b * HW + py * (unsigned)P.W + px : 0u;
+        wg_valid = min(tw, (unsigned)P.W - tx * tw) * min(th, (unsigned)P.H - ty * th);
+    } else {
+        pi = blockIdx.x * DB_T + threadIdx.x;
+        valid = pi < npix;
+        wg_valid = min((unsigned)DB_T, npix - min(npix, blockIdx.x * (unsigned)DB_T));
+    }
     float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
     if (valid) r = P.rast[pi];
     const int t = (int)r.w - 1;
@@ -51,7 +75,7 @@ __global__ __launch_bounds__(DB_T) void deferred_shade_bwd_kernel(const Deferred
     // share of the lights regulariser is one count -- instead of walking the epilogue's LDS rows and barriers with 27 zeros per lane
     if (__syncthreads_or(cov ? 1 : 0) == 0) {
         if (P.part && R.on && threadIdx.x == 0) {
-            const unsigned n_bg = min((unsigned)DB_T, npix - min(npix, blockIdx.x * (unsigned)DB_T));
+            const unsigned n_bg = wg_valid;
             float* row = P.part + (size_t)(((unsigned)blockIdx.x + (unsigned)blockIdx.y * 7u + (unsigned)blockIdx.z * 13u) % DB_SLOTS) * DB_ROW;
             if (n_bg) atomicAdd(&row[27], (float)n_bg);
         }
@@ -155,7 +179,19 @@ extern "C" int vhap_deferred_shade_bwd(const float* pos, const int32_t* tri, con
     P.delta_unscaled = (call_flags & VHAP_CALL_DELTA_UNSCALED) ? 1 : 0;
     P.skip_bg = ((call_flags & VHAP_CALL_SKIP_BG_GRAD) && !tile_ids) ? 1 : 0;
     const long long npix = (long long)B * H * W;
-    const int blocks = (int)((npix + DB_T - 1) / DB_T);
+    // Row order or tiles, by measurement (the pass alone, us; profiles/r06_call31_shade_bwd_shapes.txt, r06_call32_shade_bwd_probe_sizes.txt):
+    //   16 x 512^2: row 149, tiles 168 | 16 x 504^2: 139 / 170 | 16 x 768x512 (W = 512): 249 / 263 | 16 x 520^2: 149 / 147 | 32 x 384^2: 171 / 146 |
+    //   16 x 640^2: 216 / 187 | 16 x 802x550: 210 / 191 | 16 x 768^2: 295 / 265 | 8 x 1000^2: 245 / 233 | 8 x 1024^2: 331 / 251
+    // (64x4/64x1, 32x8/32x2 and 16x16/16x4 never beat 16x16/8x8).  Tiles win everywhere but in a band of widths at and just below 512, where the
+    // 256-pixel row segments happen to cut a centred head into two workgroups with one idle wave each (and where every tiled shape is ~14 % slower
+    // than 8 pixels further on: a power-of-two row pitch) -- frames 449 .. 512 pixels wide stay in row order, all others run as tiles.
+    // debug flags: 16777216 row order, 268435456 tiles 16x16/8x8, 33554432 / 67108864 / 134217728 shapes 2 / 3 / 4, whatever the width
+    P.tiled = (vhap_g_debug_flags & 16777216) ? 0 : (vhap_g_debug_flags & 268435456) ? 1 : (vhap_g_debug_flags & 33554432) ? 2 :
+              (vhap_g_debug_flags & 67108864) ? 3 : (vhap_g_debug_flags & 134217728) ? 4 : ((W > 448 && W <= 512) ? 0 : 1);
+    const int tw = P.tiled == 2 ? 64 : (P.tiled == 3 ? 32 : 16), th = 256 / tw;
+    P.tiles_x = (W + tw - 1) / tw;
+    P.tiles_y = (H + th - 1) / th;
+    const int blocks = P.tiled ? B * P.tiles_x * P.tiles_y : (int)((npix + DB_T - 1) / DB_T);
     hipStream_t st = vhap_stream(stream);
     deferred_shade_bwd_kernel<<<blocks, DB_T, 0, st>>>(P);
     VHAP_LAUNCH_CHECK();
