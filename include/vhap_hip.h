@@ -204,6 +204,18 @@ int vhap_deferred_shade_bwd(const float* pos, const int32_t* tri, const float* v
                             float* d_albedo, float* d_normal, float* d_texc, float* d_texd,
                             float* d_lights, float* work, size_t work_floats, void* texbin_work,
                             uint16_t* tile_ids, int call_flags, vhap_stream_t stream);
+/* vhap_deferred_shade_bwd over the COVERED pixels only: thread k takes pixel covered_list[k], k < B*H*W - *n_background (both written on the device by
+ * vhap_disturb_inplace_list; the list in pixel order, so a wave is 64 consecutive covered pixels of a row).  On a head frame two thirds of the pixels are
+ * background, which the pass has nothing to do for: in row order 40 % of its waves were background waves held by mixed workgroups and the working
+ * waves 76 % full.  Requires VHAP_CALL_SKIP_BG_GRAD and tile_ids == NULL (nothing is written for background pixels); same results. */
+int vhap_deferred_shade_bwd_list(const float* pos, const int32_t* tri, const float* vnormal, const float* uv, const int32_t* tri_uv,
+                                 const float* tex, const float* mips, int Ht, int Wt, const float* lights, const float* sh_const,
+                                 const float* rast, const float* d_rgba, const float* pred_rgba, const float* gt_nchw,
+                                 const float* d_sum, const float* d_delta, const float* keep, const float* d_reg, const float* stats,
+                                 int B, int V, int VT, int F, int H, int W, float* texc, float* texd, float* d_albedo,
+                                 float* d_normal, float* d_texc, float* d_texd, float* d_lights, float* work, size_t work_floats,
+                                 void* texbin_work, uint16_t* tile_ids, const uint32_t* covered_list, const int32_t* n_background,
+                                 int call_flags, vhap_stream_t stream);
 
 /* Triangle-parallel backward of the fused G-buffer pass (vhap_raster_interp_fwd): chains the gradients of
  * normal [B,H,W,3], texc [B,H,W,2], texd [B,H,W,4] (and, optionally, direct gradients of rast / rast_db) into
@@ -476,6 +488,12 @@ int vhap_disturb_fwd_rng(const float* rgba, const float* rast, const int32_t* fi
 int vhap_disturb_inplace(float* rgba, const uint8_t* cid, int ncl, const int32_t* w_fg, const int32_t* w_bg, const int64_t* idx,
                          float rate_fg, float rate_bg, uint32_t* rng_state, int B, int H, int W, int32_t* workspace, float* keep,
                          vhap_stream_t stream);
+/* vhap_disturb_inplace that also writes the list of COVERED pixels (cluster != 0) in pixel order -- covered_list [B*H*W] uint32, of which the first
+ * B*H*W - *n_background are written -- and the number of background pixels: a by-product of the counting sort (one 4-byte store per covered pixel),
+ * for passes that have nothing to do on the background (vhap_deferred_shade_bwd_list). */
+int vhap_disturb_inplace_list(float* rgba, const uint8_t* cid, int ncl, const int32_t* w_fg, const int32_t* w_bg, const int64_t* idx,
+                              float rate_fg, float rate_bg, uint32_t* rng_state, int B, int H, int W, int32_t* workspace, float* keep,
+                              uint32_t* covered_list, int32_t* n_background, vhap_stream_t stream);
 int vhap_disturb_bwd(const float* d_out, const float* keep, int B, int H, int W, float* d_rgba,
                      vhap_stream_t stream);
 

@@ -177,6 +177,42 @@ def test_deferred_step_matches_separate_pass_step(flame_model, monkeypatch):
             assert float((a - b).abs().max()) <= 1e-4 * float(a.abs().max()) + 1e-12, (mode, k)
 
 
+@pytest.mark.parametrize("B,H,W", [(3, 96, 120), (2, 250, 203), (5, 512, 512)])
+def test_shading_backward_over_the_covered_pixel_list(flame_model, monkeypatch, B, H, W):
+    """vhap_disturb_inplace_list leaves the covered pixels in pixel order (+ the background count) as a by-product of its counting sort;
+    vhap_deferred_shade_bwd_list walks that list instead of the frame: the step's per-pixel gradient images are the same bits as with the pass over
+    the whole frame (VHAP_SHADE_LIST=0), the energies and the parameter gradients equal up to the order of the atomic additions."""
+    from vhap_amd.step import NativeStep
+    T, stage = 256, "rgb_global_tracking"
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("VHAP_SHADE_LIST", mode)
+        tr = _tracker(flame_model, B, H, W, T, seed=11, disturb=True)
+        tr.get_train_parameters(stage)
+        ns = NativeStep(tr, tr.get_sample(np.arange(B), device_index=True), stage)
+        ns.injected = tr.render.make_disturbance((B, H, W), torch.device("cuda"), generator=torch.Generator(device="cuda").manual_seed(3))   # the same draws in both modes
+        assert ns.deferred and ns.disturb_on and (ns.cov_list is not None) == (mode == "1")
+        ns.forward()
+        ns.backward(1)
+        torch.cuda.synchronize()
+        if mode == "1":
+            assert ns._cov_list_fresh
+            cov = torch.nonzero(ns.cid.reshape(-1) != 0).reshape(-1)
+            n_bg = int(ns.n_bg[0])
+            assert n_bg == ns.cid.numel() - cov.numel() and 0.05 < cov.numel() / ns.cid.numel() < 0.95
+            assert torch.equal(ns.cov_list[:cov.numel()].long(), cov), "the list is not the covered pixels in pixel order"
+        m = (ns.rast[..., 3] > 0)[..., None]
+        out[mode] = ({k: float(v) for k, v in ns.log_dict().items()}, {k: v.detach().clone() for k, v in ns.g.items() if k in ns.params},
+                     [torch.where(m, t, torch.zeros_like(t)) for t in (ns.d_normal, ns.d_texc, ns.d_texd, ns.d_albedo)])   # (background: never written)
+    (l0, g0, px0), (l1, g1, px1) = out["0"], out["1"]
+    for k, v in l0.items():                                       # (the forward pass is the same; its sums are atomic additions)
+        assert abs(v - l1[k]) <= 1e-6 * max(abs(v), 1e-4), (k, v, l1[k])
+    for a, b in zip(px0, px1):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    for k, a in g0.items():
+        assert float((a - g1[k]).abs().max()) <= 1e-4 * float(a.abs().max()) + 1e-12, (k, float((a - g1[k]).abs().max()) / float(a.abs().max()))
+
+
 @pytest.mark.parametrize("T", [2048, 256, 128, 96])
 def test_fused_pyramid_build_is_bit_identical(T):
     """vhap_tex_prep_mip1_fwd (level 1 written while the texture is assembled) + vhap_texture_mip_build_from (four levels per launch) ==

@@ -34,6 +34,7 @@ SIGNATURES = {
     "vhap_deferred_shade_bwd_work_floats": (c_sz, [c_i] * 3),
     "vhap_deferred_lights_reduce": (c_i, [c_fp] * 5 + [c_i] * 3 + [c_fp, c_fp]),
     "vhap_deferred_shade_bwd": (c_i, [c_fp] * 7 + [c_i, c_i] + [c_fp] * 11 + [c_i] * 6 + [c_fp] * 8 + [c_sz, c_fp, c_fp, c_i, c_fp]),
+    "vhap_deferred_shade_bwd_list": (c_i, [c_fp] * 7 + [c_i, c_i] + [c_fp] * 11 + [c_i] * 6 + [c_fp] * 8 + [c_sz, c_fp, c_fp, c_fp, c_fp, c_i, c_fp]),
     "vhap_raster_bwd": (c_i, [c_fp] * 5 + [c_i] * 5 + [c_fp, c_fp]),
     "vhap_gbuffer_bwd": (c_i, [c_fp] * 12 + [c_i] * 5 + [c_fp] * 3),
     "vhap_interp_fwd": (c_i, [c_fp, c_i, c_fp, c_fp, c_fp] + [c_i] * 6 + [c_fp, c_fp, c_fp]),
@@ -63,6 +64,7 @@ SIGNATURES = {
     "vhap_disturb_fwd": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_fp, c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
     "vhap_disturb_fwd_rng": (c_i, [c_fp, c_fp, c_fp, c_i, c_i, c_f, c_f, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp]),
     "vhap_disturb_inplace": (c_i, [c_fp, c_fp, c_i, c_fp, c_fp, c_fp, c_f, c_f, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp]),
+    "vhap_disturb_inplace_list": (c_i, [c_fp, c_fp, c_i, c_fp, c_fp, c_fp, c_f, c_f, c_fp, c_i, c_i, c_i, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "vhap_disturb_bwd": (c_i, [c_fp, c_fp, c_i, c_i, c_i, c_fp, c_fp]),
     "vhap_shade_fwd": (c_i, [c_fp] * 8 + [c_i] * 4 + [c_fp] * 3 + [c_i, c_fp]),
     "vhap_shade_bwd": (c_i, [c_fp] * 9 + [c_i] * 3 + [c_fp] * 4),

@@ -39,7 +39,16 @@ __global__ __launch_bounds__(DB_T) void deferred_shade_bwd_kernel(const Deferred
     // the mixed workgroups are the silhouette only.  Which is faster depends on the frame size: see the launch.
     unsigned pi, wg_valid;
     bool valid;
-    if (P.tiled) {
+    if (P.cov_list) {
+        // thread k takes the k-th covered pixel (pixel order: a wave is 64 consecutive covered pixels of a row, or the end of one row's run and the
+        // start of the next): no background lane, no background wave; workgroups past the list leave at once
+        const unsigned n_cov = npix - (unsigned)*P.n_bg, k = blockIdx.x * DB_T + threadIdx.x;
+        valid = k < n_cov;
+        pi = valid ? P.cov_list[k] : 0u;
+        wg_valid = 0u;
+        if (blockIdx.x == 0 && threadIdx.x == 0 && P.part && R.on && n_cov < npix)      // the background's share of the lights regulariser: one count
+            atomicAdd(&P.part[27], (float)(npix - n_cov));
+    } else if (P.tiled) {
         // tile shapes (workgroup / wave): 1 = 16 x 16 / 8 x 8, 2 = 64 x 4 / 64 x 1, 3 = 32 x 8 / 32 x 2, 4 = 16 x 16 / 16 x 4
         const unsigned tw = P.tiled == 2 ? 64u : (P.tiled == 3 ? 32u : 16u), th = 256u / tw;
         const unsigned tpf = (unsigned)P.tiles_x * P.tiles_y, b = blockIdx.x / tpf, tr = blockIdx.x - b * tpf;
@@ -161,6 +170,15 @@ extern "C" size_t vhap_deferred_shade_bwd_work_floats(int B, int H, int W) {
     return (size_t)DB_SLOTS * DB_ROW;
 }
 
+static int deferred_shade_bwd_run(const float* pos, const int32_t* tri, const float* vnormal, const float* uv, const int32_t* tri_uv,
+                                       const float* tex, const float* mips, int Ht, int Wt, const float* lights, const float* sh_const,
+                                       const float* rast, const float* d_rgba, const float* pred_rgba, const float* gt_nchw,
+                                       const float* d_sum, const float* d_delta, const float* keep, const float* d_reg, const float* stats,
+                                       int B, int V, int VT, int F, int H, int W, float* texc, float* texd, float* d_albedo,
+                                       float* d_normal, float* d_texc, float* d_texd, float* d_lights, float* work, size_t work_floats,
+                                       void* texbin_work, uint16_t* tile_ids, const uint32_t* covered_list, const int32_t* n_background,
+                                       int call_flags, vhap_stream_t stream);
+
 extern "C" int vhap_deferred_shade_bwd(const float* pos, const int32_t* tri, const float* vnormal, const float* uv, const int32_t* tri_uv,
                                        const float* tex, const float* mips, int Ht, int Wt, const float* lights, const float* sh_const,
                                        const float* rast, const float* d_rgba, const float* pred_rgba, const float* gt_nchw,
@@ -168,6 +186,34 @@ extern "C" int vhap_deferred_shade_bwd(const float* pos, const int32_t* tri, con
                                        int B, int V, int VT, int F, int H, int W, float* texc, float* texd, float* d_albedo,
                                        float* d_normal, float* d_texc, float* d_texd, float* d_lights, float* work, size_t work_floats,
                                        void* texbin_work, uint16_t* tile_ids, int call_flags, vhap_stream_t stream) {
+    return deferred_shade_bwd_run(pos, tri, vnormal, uv, tri_uv, tex, mips, Ht, Wt, lights, sh_const, rast, d_rgba, pred_rgba, gt_nchw, d_sum, d_delta,
+                                  keep, d_reg, stats, B, V, VT, F, H, W, texc, texd, d_albedo, d_normal, d_texc, d_texd, d_lights, work, work_floats,
+                                  texbin_work, tile_ids, nullptr, nullptr, call_flags, stream);
+}
+
+extern "C" int vhap_deferred_shade_bwd_list(const float* pos, const int32_t* tri, const float* vnormal, const float* uv, const int32_t* tri_uv,
+                                            const float* tex, const float* mips, int Ht, int Wt, const float* lights, const float* sh_const,
+                                            const float* rast, const float* d_rgba, const float* pred_rgba, const float* gt_nchw,
+                                            const float* d_sum, const float* d_delta, const float* keep, const float* d_reg, const float* stats,
+                                            int B, int V, int VT, int F, int H, int W, float* texc, float* texd, float* d_albedo,
+                                            float* d_normal, float* d_texc, float* d_texd, float* d_lights, float* work, size_t work_floats,
+                                            void* texbin_work, uint16_t* tile_ids, const uint32_t* covered_list, const int32_t* n_background,
+                                            int call_flags, vhap_stream_t stream) {
+    if (!covered_list || !n_background) return VHAP_E_NULLPTR;
+    if (!(call_flags & VHAP_CALL_SKIP_BG_GRAD) || tile_ids) return VHAP_E_BADDIM;       // (a pass over the covered pixels writes nothing for the background)
+    return deferred_shade_bwd_run(pos, tri, vnormal, uv, tri_uv, tex, mips, Ht, Wt, lights, sh_const, rast, d_rgba, pred_rgba, gt_nchw, d_sum, d_delta,
+                                  keep, d_reg, stats, B, V, VT, F, H, W, texc, texd, d_albedo, d_normal, d_texc, d_texd, d_lights, work, work_floats,
+                                  texbin_work, tile_ids, covered_list, n_background, call_flags, stream);
+}
+
+static int deferred_shade_bwd_run(const float* pos, const int32_t* tri, const float* vnormal, const float* uv, const int32_t* tri_uv,
+                                       const float* tex, const float* mips, int Ht, int Wt, const float* lights, const float* sh_const,
+                                       const float* rast, const float* d_rgba, const float* pred_rgba, const float* gt_nchw,
+                                       const float* d_sum, const float* d_delta, const float* keep, const float* d_reg, const float* stats,
+                                       int B, int V, int VT, int F, int H, int W, float* texc, float* texd, float* d_albedo,
+                                       float* d_normal, float* d_texc, float* d_texd, float* d_lights, float* work, size_t work_floats,
+                                       void* texbin_work, uint16_t* tile_ids, const uint32_t* covered_list, const int32_t* n_background,
+                                       int call_flags, vhap_stream_t stream) {
     VHAP_ENTER();
     if (!d_normal || !d_texc || !d_texd) return VHAP_E_NULLPTR;
     DeferredParams P{};
@@ -178,6 +224,8 @@ extern "C" int vhap_deferred_shade_bwd(const float* pos, const int32_t* tri, con
     P.d_normal = d_normal; P.d_texc = reinterpret_cast<float2*>(d_texc); P.d_texd = reinterpret_cast<float4*>(d_texd);
     P.delta_unscaled = (call_flags & VHAP_CALL_DELTA_UNSCALED) ? 1 : 0;
     P.skip_bg = ((call_flags & VHAP_CALL_SKIP_BG_GRAD) && !tile_ids) ? 1 : 0;
+    P.cov_list = covered_list;
+    P.n_bg = n_background;
     const long long npix = (long long)B * H * W;
     // Row order or tiles, by measurement (the pass alone, us; profiles/r06_call31_shade_bwd_shapes.txt, r06_call32_shade_bwd_probe_sizes.txt):
     //   16 x 512^2: row 149, tiles 168 | 16 x 504^2: 139 / 170 | 16 x 768x512 (W = 512): 249 / 263 | 16 x 520^2: 149 / 147 | 32 x 384^2: 171 / 146 |
@@ -191,7 +239,7 @@ extern "C" int vhap_deferred_shade_bwd(const float* pos, const int32_t* tri, con
     const int tw = P.tiled == 2 ? 64 : (P.tiled == 3 ? 32 : 16), th = 256 / tw;
     P.tiles_x = (W + tw - 1) / tw;
     P.tiles_y = (H + th - 1) / th;
-    const int blocks = P.tiled ? B * P.tiles_x * P.tiles_y : (int)((npix + DB_T - 1) / DB_T);
+    const int blocks = (P.tiled && !P.cov_list) ? B * P.tiles_x * P.tiles_y : (int)((npix + DB_T - 1) / DB_T);   // (a list: as many workgroups as a full list needs)
     hipStream_t st = vhap_stream(stream);
     deferred_shade_bwd_kernel<<<blocks, DB_T, 0, st>>>(P);
     VHAP_LAUNCH_CHECK();

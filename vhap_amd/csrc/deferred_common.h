@@ -49,6 +49,8 @@ struct DeferredParams {
     int skip_bg;             // VHAP_CALL_SKIP_BG_GRAD: d_albedo of background pixels is not written (its reader walks a list of covered pixels)
     int tiled;               // deferred_shade_bwd: 0 = a workgroup is 256 consecutive pixels of a row; 1 = a 16 x 16 tile, a wave an 8 x 8 block of it
     int tiles_x, tiles_y;    // (tiled) 16 x 16 tiles per frame
+    const unsigned* cov_list; // deferred_shade_bwd, optional: the covered pixels in pixel order (vhap_disturb_inplace_list) -- thread k takes pixel cov_list[k]
+    const int* n_bg;          // ... and the number of background pixels (device): npix - *n_bg entries
 };
 
 // regulariser part of d(diffuse) (lights only, on shade(normal.detach()): tracker.py:547-550), see shade_bwd_kernel

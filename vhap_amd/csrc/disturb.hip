@@ -155,7 +155,8 @@ __global__ __launch_bounds__(PB) void disturb_prefix_kernel(int* __restrict__ bl
 // phase of one overlaps the copy phase of another.
 __global__ __launch_bounds__(DB) void disturb_scatter_kernel(const ClusterSrc src, const float4* __restrict__ rgba,
                                                               int ncl, long long n, const int* __restrict__ block_prefix,
-                                                              const int* __restrict__ totals, float4* __restrict__ pool) {
+                                                              const int* __restrict__ totals, float4* __restrict__ pool,
+                                                              unsigned* __restrict__ cov_list, int* __restrict__ n_bg_out) {
     constexpr int NW = DB / 64;                     // waves
     constexpr int NE = PPT * NW;                    // (iteration, wave) counters per cluster: 32
     static_assert(NE == 32 && MAXC == 16, "the in-block scan below assumes 32 counters per cluster, two clusters per wave pass");
@@ -170,12 +171,14 @@ __global__ __launch_bounds__(DB) void disturb_scatter_kernel(const ClusterSrc sr
     __syncthreads();
     int key[PPT];                                   // cluster << 8 | rank in the wave's 64 pixels (-1: not sorted)
     int cs[PPT];
+    int bgb[PPT];                                   // background pixels of the wave in front of this lane (for the list of covered pixels)
     pixel_clusters<PPT>(src, (long long)blockIdx.x * DPIX + threadIdx.x, DB, n, cs);
 #pragma unroll
     for (int it = 0; it < PPT; it++) {
         int c = cs[it];
         if (c >= ncl) c = -1;                       // (ids outside the configured clusters are left alone)
         int rank = 0;
+        bgb[it] = __popcll(__ballot(c == 0) & ((1ull << lane) - 1ull));
         unsigned long long todo = __ballot(c >= 0);
         while (todo) {
             const int k = __builtin_amdgcn_readlane(c, __builtin_ctzll(todo));
@@ -217,6 +220,17 @@ __global__ __launch_bounds__(DB) void disturb_scatter_kernel(const ClusterSrc sr
         if (key[it] < 0) continue;
         const int c = key[it] >> 8, rank = key[it] & 255;
         pool[base[c] + wcnt[it][wave][c] + rank] = col[it];
+    }
+    // The list of covered pixels (cluster != 0) in pixel order, for passes that have nothing to do on the background (vhap_deferred_shade_bwd_list):
+    // entry number (pixels in front of p) - (background pixels in front of p) -- the blocks before this one (the prefix of cluster 0), the
+    // (iteration, wave) units of this block before p's (the in-block scan of cluster 0), the lanes of p's wave before p.
+    if (cov_list) {
+#pragma unroll
+        for (int it = 0; it < PPT; it++) {
+            const long long p = (long long)blockIdx.x * DPIX + it * DB + threadIdx.x;
+            if (p < n && cs[it] != 0) cov_list[p - (base[0] + wcnt[it][wave][0] + bgb[it])] = (unsigned)p;
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) *n_bg_out = totals[0];
     }
 }
 
@@ -318,8 +332,9 @@ extern "C" size_t vhap_disturb_workspace_ints(int B, int H, int W) {
 
 static int disturb_run(const float* rgba, const float* rast, const uint8_t* cid, const int32_t* fid2cid, int nfid, int ncl, const int32_t* w_fg,
                        const int32_t* w_bg, const int64_t* idx, uint32_t* rng_state, float rate_fg, float rate_bg, int B, int H, int W,
-                       int32_t* workspace, float* out, float* keep, vhap_stream_t stream) {
+                       int32_t* workspace, float* out, float* keep, vhap_stream_t stream, uint32_t* cov_list = nullptr, int32_t* n_bg_out = nullptr) {
     if (!rgba || !workspace || !out || !keep) return VHAP_E_NULLPTR;
+    if ((cov_list == nullptr) != (n_bg_out == nullptr)) return VHAP_E_NULLPTR;
     if (!cid && (!rast || !fid2cid)) return VHAP_E_NULLPTR;
     if (!rng_state && (!w_fg || !w_bg || !idx)) return VHAP_E_NULLPTR;
     if (B <= 0 || H <= 0 || W <= 0 || ncl <= 0 || ncl > MAXC || (!cid && nfid <= 0) || (long long)B * H * W >= (1ll << 31)) return VHAP_E_BADDIM;
@@ -337,7 +352,7 @@ static int disturb_run(const float* rgba, const float* rast, const uint8_t* cid,
     VHAP_LAUNCH_CHECK();
     disturb_prefix_kernel<<<MAXC, PB, 0, st>>>(block_counts, nblocks, totals);
     VHAP_LAUNCH_CHECK();
-    disturb_scatter_kernel<<<nblocks, DB, 0, st>>>(src, in, ncl, n, block_counts, totals, pool);
+    disturb_scatter_kernel<<<nblocks, DB, 0, st>>>(src, in, ncl, n, block_counts, totals, pool, cov_list, n_bg_out);
     VHAP_LAUNCH_CHECK();
     if (out == rgba)
         disturb_apply_kernel<true><<<vhap_cdiv(n, 256 * APT), 256, 0, st>>>(in, B, H, W, src, w_fg, w_bg, reinterpret_cast<const long long*>(idx),
@@ -372,6 +387,15 @@ extern "C" int vhap_disturb_inplace(float* rgba, const uint8_t* cid, int ncl, co
     VHAP_ENTER();
     if (!cid) return VHAP_E_NULLPTR;
     return disturb_run(rgba, nullptr, cid, nullptr, 0, ncl, w_fg, w_bg, idx, rng_state, rate_fg, rate_bg, B, H, W, workspace, rgba, keep, stream);
+}
+
+extern "C" int vhap_disturb_inplace_list(float* rgba, const uint8_t* cid, int ncl, const int32_t* w_fg, const int32_t* w_bg, const int64_t* idx,
+                                         float rate_fg, float rate_bg, uint32_t* rng_state, int B, int H, int W, int32_t* workspace, float* keep,
+                                         uint32_t* covered_list, int32_t* n_background, vhap_stream_t stream) {
+    VHAP_ENTER();
+    if (!cid || !covered_list || !n_background) return VHAP_E_NULLPTR;
+    return disturb_run(rgba, nullptr, cid, nullptr, 0, ncl, w_fg, w_bg, idx, rng_state, rate_fg, rate_bg, B, H, W, workspace, rgba, keep, stream,
+                       covered_list, n_background);
 }
 
 extern "C" int vhap_disturb_bwd(const float* d_out, const float* keep, int B, int H, int W, float* d_rgba, vhap_stream_t stream) {

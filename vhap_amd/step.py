@@ -163,6 +163,9 @@ class NativeStep:
             if not hasattr(r, "_fid2cid_i32") or r._fid2cid_i32.device != self.rgb.device:
                 r._fid2cid_i32 = r.fid2cid.int().contiguous()
             self.fid2cid, self.ncl, self.rng = r._fid2cid_i32, r._ncl, r._rng_state
+            if not hasattr(r, "_bg_cluster_is_background_only"):        # cluster 0 = the background and nothing else (fid 0 is "no triangle"): the
+                # disturbance's list of covered pixels (cluster != 0), which the shading backward walks, then misses no triangle.  One host read per renderer.
+                r._bg_cluster_is_background_only = bool(int(r._fid2cid_i32[0]) == 0 and (r._fid2cid_i32.numel() < 2 or int(r._fid2cid_i32[1:].min()) >= 1))
         self.K1, self.K0 = nm["K1"], nm["K0"]
         self.focal_scale = float(max(H, W))
         self.RT = E(B, 3, 4) if self.calibrated else tr.RT[None, :3, :].contiguous()
@@ -209,11 +212,15 @@ class NativeStep:
             self.rgba = E(B, H, W, 4)
             if not self.aa_inplace:
                 self.rgba_aa = E(B, H, W, 4)
+            self.cov_list, self.n_bg, self._cov_list_fresh = None, None, False
             if self.disturb_on:
                 self.keep = E(B, H, W)                               # (the disturbance itself is in place: pools of copies, csrc/disturb.hip)
                 self.dist_ws = Ei(int(L.vhap_disturb_workspace_ints(B, H, W)) * 4, torch.int32) if poison else \
                     torch.empty(L.vhap_disturb_workspace_ints(B, H, W), dtype=torch.int32, device=dev)
                 self.cid = Ei((B, H, W), torch.uint8)
+                if self.deferred and tr.render._bg_cluster_is_background_only and os.environ.get("VHAP_SHADE_LIST", "1") != "0":
+                    # the list of covered pixels the disturbance's counting sort leaves (+ the number of background pixels), for the shading backward
+                    self.cov_list, self.n_bg = torch.empty(B * H * W, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev)
             n_aa = int((L.vhap_antialias_inplace_work_ints if self.aa_inplace else L.vhap_antialias_work_ints)(B, H, W, self.F))
             self.aa_work = Ei(n_aa * 4, torch.int32) if poison else torch.empty(n_aa, dtype=torch.int32, device=dev)
             self.ws, self.ws_bytes, self.ws_cap, _ = tr.render.glctx.acquire(B, self.F, H, W, self.rgb.device)
@@ -474,6 +481,7 @@ class NativeStep:
         B, H, W, V, F, T, J = self.B, self.H, self.W, self.V, self.F, self.T, self.J
         st = _stream()
         acc = self.accF
+        self._cov_list_fresh = False
         if not self._acc_clean:
             _zero(acc)                                                # ONE launch clears every forward accumulator
         self._acc_clean = False
@@ -724,6 +732,15 @@ class NativeStep:
             w_fg, w_bg, idx = inj["w_fg"].int().contiguous(), inj["w_bg"].int().contiguous(), inj["idx"].long().contiguous()
             assert w_fg.numel() == w_bg.numel() == idx.numel() == B * H * W
             self._inj_keep = (w_fg, w_bg, idx)                    # (alive until the launch has run)
+        if self.cov_list is not None:
+            # the counting sort also leaves the list of covered pixels, in pixel order: the shading backward walks it (vhap_deferred_shade_bwd_list)
+            _chk(self.L.vhap_disturb_inplace_list(_p(self.rgba), _p(self.cid), self.ncl, _p(w_fg) if inj is not None else 0,
+                                                  _p(w_bg) if inj is not None else 0, _p(idx) if inj is not None else 0,
+                                                  float(self.rate_fg or 0.0), float(self.rate_bg or 0.0), 0 if inj is not None else _p(self.rng),
+                                                  B, H, W, _p(self.dist_ws), _p(self.keep), _p(self.cov_list), _p(self.n_bg), st),
+                 "vhap_disturb_inplace_list")
+            self._cov_list_fresh = True
+            return
         _chk(self.L.vhap_disturb_inplace(_p(self.rgba), _p(self.cid), self.ncl, _p(w_fg) if inj is not None else 0,
                                          _p(w_bg) if inj is not None else 0, _p(idx) if inj is not None else 0,
                                          float(self.rate_fg or 0.0), float(self.rate_bg or 0.0), 0 if inj is not None else _p(self.rng),
@@ -878,15 +895,19 @@ class NativeStep:
         # (the backward of the disturbance -- d_rgba = d_color * keep -- is folded into the shading backward)
         if self.deferred:
             # shading + texture-coordinate backward in one pass, from re-computed attributes (nothing of the forward's G-buffer is re-read)
-            _chk(L.vhap_deferred_shade_bwd(_p(self.clip), _p(self.tri), _p(self.vn), _p(self.uv), _p(self.tri_uv), _p(self.albedo_tex), _p(self.mips),
-                                           T, T, _p(tr.lights), _p(self.sh_const), _p(self.rast), *self._upstream(),
-                                           _p(self.keep) if self.disturb_on else 0, _p(self.c_reg) if self.want_reg else 0,
-                                           _p(acc[12:16]) if self.want_reg else 0, B, V, self.uv.shape[0], F, H, W, _p(self.texc), _p(self.texd),
-                                           _p(self.d_albedo), _p(self.d_normal), _p(self.d_texc), _p(self.d_texd), 0,
-                                           _p(self.def_work), self.def_work.numel(), 0, 0,
-                                           # (the texture gradient walks the sorted list of covered pixels -- or does not run at all: background d_albedo is never read)
-                                           self.delta_flag | (_lib.CALL_SKIP_BG_GRAD if (self.tb_ids or not self.tex_bwd_on) else 0), st),
-                 "vhap_deferred_shade_bwd")
+            # (the texture gradient walks the sorted list of covered pixels -- or does not run at all: background d_albedo is never read)
+            skip_bg = bool(self.tb_ids or not self.tex_bwd_on)
+            args = (_p(self.clip), _p(self.tri), _p(self.vn), _p(self.uv), _p(self.tri_uv), _p(self.albedo_tex), _p(self.mips),
+                    T, T, _p(tr.lights), _p(self.sh_const), _p(self.rast), *self._upstream(),
+                    _p(self.keep) if self.disturb_on else 0, _p(self.c_reg) if self.want_reg else 0,
+                    _p(acc[12:16]) if self.want_reg else 0, B, V, self.uv.shape[0], F, H, W, _p(self.texc), _p(self.texd),
+                    _p(self.d_albedo), _p(self.d_normal), _p(self.d_texc), _p(self.d_texd), 0, _p(self.def_work), self.def_work.numel(), 0, 0)
+            flags = self.delta_flag | (_lib.CALL_SKIP_BG_GRAD if skip_bg else 0)
+            if self.cov_list is not None and self._cov_list_fresh and skip_bg:
+                # over the covered pixels only, in the order the disturbance's counting sort listed them during this forward pass
+                _chk(L.vhap_deferred_shade_bwd_list(*args, _p(self.cov_list), _p(self.n_bg), flags, st), "vhap_deferred_shade_bwd_list")
+            else:
+                _chk(L.vhap_deferred_shade_bwd(*args, flags, st), "vhap_deferred_shade_bwd")
             if after_first is not None and early_aa:          # (the main chain's kernel first, then the side branches forked behind the sum)
                 after_first()
             return
