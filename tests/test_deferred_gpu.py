@@ -146,6 +146,26 @@ def test_deferred_kernels_match_the_separate_passes(flame_model, monkeypatch, B,
         for a, b in zip(outs, (texc, texd, d_alb, d_n, d_tc, d_td)):
             assert torch.equal(a.view(torch.int32), b.view(torch.int32)), flag
         assert rel(d_lights_t, d_lights) <= 2e-6
+    # ... and over a LIST of the covered pixels (vhap_deferred_shade_bwd_list; in the step the list is a by-product of the disturbance's counting sort):
+    # the same inputs, the same bits per pixel
+    covp = torch.nonzero(ns.cid.reshape(-1) != 0).reshape(-1).int()
+    assert torch.equal(ns.cid != 0, cov)
+    lst = torch.full((B * H * W,), -1, dtype=torch.int32, device=dev)
+    lst[:covp.numel()] = covp
+    n_bg_t = torch.tensor([B * H * W - covp.numel()], dtype=torch.int32, device=dev)
+    outs = [E(B, H, W, 2), E(B, H, W, 4), E(B, H, W, 3), E(B, H, W, 3), E(B, H, W, 2), E(B, H, W, 4)]
+    for t in outs:
+        t.zero_()
+    d_lights_l, work_l = torch.zeros(9, 3, device=dev), torch.zeros_like(work)
+    args = (_p(ns.clip), _p(ns.tri), _p(ns.vn), _p(ns.uv), _p(ns.tri_uv), _p(ns.albedo_tex), _p(ns.mips), T, T,
+            _p(tr.lights), _p(ns.sh_const), _p(ns.rast), _p(ns.d_color), 0, 0, 0, 0, _p(ns.keep), _p(ns.c_reg),
+            _p(ns.accF[12:16]), B, V, ns.uv.shape[0], F, H, W, *[_p(t) for t in outs], _p(d_lights_l), _p(work_l), work_l.numel(), 0, 0)
+    assert L.vhap_deferred_shade_bwd_list(*args, _p(lst), _p(n_bg_t), 0, _stream()) != 0        # (needs VHAP_CALL_SKIP_BG_GRAD: it writes nothing for the background)
+    assert L.vhap_deferred_shade_bwd_list(*args, _p(lst), _p(n_bg_t), _lib.CALL_SKIP_BG_GRAD, _stream()) == 0
+    torch.cuda.synchronize()
+    for a, b in zip(outs, (texc, texd, d_alb, d_n, d_tc, d_td)):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    assert rel(d_lights_l, d_lights) <= 2e-6
 
 
 def test_deferred_step_matches_separate_pass_step(flame_model, monkeypatch):
@@ -180,8 +200,8 @@ def test_deferred_step_matches_separate_pass_step(flame_model, monkeypatch):
 @pytest.mark.parametrize("B,H,W", [(3, 96, 120), (2, 250, 203), (5, 512, 512)])
 def test_shading_backward_over_the_covered_pixel_list(flame_model, monkeypatch, B, H, W):
     """vhap_disturb_inplace_list leaves the covered pixels in pixel order (+ the background count) as a by-product of its counting sort;
-    vhap_deferred_shade_bwd_list walks that list instead of the frame: the step's per-pixel gradient images are the same bits as with the pass over
-    the whole frame (VHAP_SHADE_LIST=0), the energies and the parameter gradients equal up to the order of the atomic additions."""
+    vhap_deferred_shade_bwd_list walks that list instead of the frame: the step's per-pixel gradient images agree with those of the pass over
+    the whole frame (VHAP_SHADE_LIST=0) to 1e-5, the energies and the parameter gradients equal up to the order of the atomic additions."""
     from vhap_amd.step import NativeStep
     T, stage = 256, "rgb_global_tracking"
     out = {}
@@ -207,8 +227,8 @@ def test_shading_backward_over_the_covered_pixel_list(flame_model, monkeypatch, 
     (l0, g0, px0), (l1, g1, px1) = out["0"], out["1"]
     for k, v in l0.items():                                       # (the forward pass is the same; its sums are atomic additions)
         assert abs(v - l1[k]) <= 1e-6 * max(abs(v), 1e-4), (k, v, l1[k])
-    for a, b in zip(px0, px1):
-        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    for a, b in zip(px0, px1):                                    # (two forward passes: the diffuse regulariser's statistics are atomic sums -- not the same bits)
+        assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()) and float(a.abs().max()) > 0
     for k, a in g0.items():
         assert float((a - g1[k]).abs().max()) <= 1e-4 * float(a.abs().max()) + 1e-12, (k, float((a - g1[k]).abs().max()) / float(a.abs().max()))
 
