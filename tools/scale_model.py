@@ -26,7 +26,7 @@ ONE GPU (a world-size-1 RCCL group runs the sharded step for real: every overhea
 """
 import argparse
 
-HEAD, TEX_ALONE, TEX_BESIDE, GEO, NEXT_HEAD, ONE_GPU = 0.58, 0.117, 0.215, 0.29, 0.095, 0.811
+HEAD, TEX_ALONE, TEX_BESIDE, GEO, NEXT_HEAD, ONE_GPU = 0.541, 0.114, 0.215, 0.274, 0.095, 0.777     # (the final tree: the shading backward over the list of covered pixels)
 ASSEMBLY, ASSEMBLY_CARRIED = 0.070, 0.020
 TEX_MB = 50.3
 FRAMES = 16
