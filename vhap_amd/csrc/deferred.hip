@@ -20,8 +20,10 @@ constexpr int DB_NW = DB_T / 64;
 // (rast -> triangle -> vertices / normals / uvs -> texture taps) and several waves per SIMD overlap those round trips.  The [9,3] lights
 // gradient is reduced per wave (DPP, on the VALU) and per workgroup, added into one of DB_SLOTS rows of `part` (short atomic chains), and a
 // second tiny launch sums the rows into d_lights.
-// (112 VGPRs = 4 waves per SIMD.  Forced to 5 waves -- 96 VGPRs, seven spilled dwords -- it takes the same time, 168 vs 167 us in the step:
+// (Round 3, 112 VGPRs = 4 waves per SIMD: forced to 5 waves -- 96 VGPRs, seven spilled dwords -- it took the same time, 168 vs 167 us in the step:
 // profiles/r03_call10_plan_timeline_w5.txt.)
+// (142 VGPRs = 3 waves per SIMD since round 4.  Held to 4 waves -- 128 VGPRs, 17 spilled dwords -- the list-driven step takes 0.786 instead of 0.757 ms, held
+// to 5 -- 96 VGPRs, 79 spilled -- 0.88: profiles/r06_call44_shade_bwd_waves_ab.txt.)
 __global__ __launch_bounds__(DB_T) void deferred_shade_bwd_kernel(const DeferredParams P) {
     __shared__ float s_l[27], s_c[9];
     __shared__ float red[DB_NW * 4][27];
