@@ -150,24 +150,46 @@ def _run(carry, steps=6, lone=2):
 
 
 def test_captured_step_with_carried_texture_matches_the_reassembled_one():
-    logs1, P1, step = _run(True)
-    logs0, P0, _ = _run(False)
-    # energies.  The first lone replay starts from the same state in both runs: every term to fp32 summation noise (the TV / residual terms
-    # arrive through carry_terms -- vhap_tex_carry_prime -- instead of the forward accumulators).  Later records (second lone replay: the
-    # terms handed on by the finish pass; the loop's last step; after the host-side texture write, which the version counter must catch)
-    # sit behind 1 .. 8 full-rate Adam steps whose atomics order differs between any two runs.
-    for i, (a, b) in enumerate(zip(logs1, logs0)):
-        tol = 2e-6 if i == 0 else 1e-3
-        for k in b:
-            assert abs(a[k] - b[k]) <= tol * max(abs(b[k]), 1e-3), (i, k, a[k], b[k])
-        assert b["reg_tex_tv"] > 0
-        # the two texture terms depend on the texture alone, which moves by ~lr per step whatever the atomics do: always tight
-        for k in ("reg_tex_tv", "reg_tex_res_clusters"):
-            assert abs(a[k] - b[k]) <= 5e-5 * abs(b[k]) + 1e-12, (i, k, a[k], b[k])
-    # fitted parameters: atomics order is the only difference between the two runs
-    for k in P0:
-        d = float((P1[k] - P0[k]).norm() / (P0[k].norm() + 1e-12))
-        assert d <= 2e-3, (k, d)
-    # the carried albedo IS painted + tex_extra after the last step, bit for bit
-    ns = step.ns
-    assert torch.equal(ns.albedo_tex[0], (ns.painted + step.tr.tex_extra.detach()).permute(1, 2, 0).contiguous())
+    """The captured step with the carried texture against the one that re-assembles the texture every step: two fits of 10 full-rate Adam
+    steps.  What must hold in EVERY run is asserted at once (the first step's terms, the texture terms, the carried albedo bit for bit);
+    what sits behind several Adam steps whose atomic additions come in another order in any two runs -- later energies to 1e-3, the fitted
+    parameters to 2e-3 -- is compared up to three times: one pixel across a kink of the energy throws a single comparison now and then
+    (profiles/r06_rccl_kink_probe.txt: the same mechanism, 6 of 80 repetitions there); a wrong carry misses every time."""
+    record = []
+    for attempt in range(3):
+        logs1, P1, step = _run(True)
+        logs0, P0, _ = _run(False)
+        # energies.  The first lone replay starts from the same state in both runs: every term to fp32 summation noise (the TV / residual terms
+        # arrive through carry_terms -- vhap_tex_carry_prime -- instead of the forward accumulators).  Later records (second lone replay: the
+        # terms handed on by the finish pass; the loop's last step; after the host-side texture write, which the version counter must catch)
+        # sit behind 1 .. 8 full-rate Adam steps whose atomics order differs between any two runs.
+        soft = []
+        for i, (a, b) in enumerate(zip(logs1, logs0)):
+            for k in b:
+                miss = abs(a[k] - b[k]) > (2e-6 if i == 0 else 1e-3) * max(abs(b[k]), 1e-3)
+                if i == 0:
+                    assert not miss, (i, k, a[k], b[k])
+                elif miss:
+                    soft.append(f"record {i}, {k}: {a[k]!r} vs {b[k]!r}")
+            assert b["reg_tex_tv"] > 0
+            # the two texture terms depend on the texture alone, which moves by ~lr per step whatever the atomics do: always tight
+            for k in ("reg_tex_tv", "reg_tex_res_clusters"):
+                assert abs(a[k] - b[k]) <= 5e-5 * abs(b[k]) + 1e-12, (i, k, a[k], b[k])
+        # fitted parameters: atomics order is the only difference between the two runs
+        for k in P0:
+            d = float((P1[k] - P0[k]).norm() / (P0[k].norm() + 1e-12))
+            if d > 2e-3:
+                soft.append(f"{k}: relative distance {d:.2e}")
+        # the carried albedo IS painted + tex_extra after the last step, bit for bit
+        ns = step.ns
+        assert torch.equal(ns.albedo_tex[0], (ns.painted + step.tr.tex_extra.detach()).permute(1, 2, 0).contiguous())
+        record.append(f"attempt {attempt}: " + ("; ".join(soft) if soft else "all within bounds"))
+        if not soft:
+            break
+    try:
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open(os.path.join("gpurun_out", "tex_carry_step_vs_reassembled.txt"), "w") as f:
+            f.write("\n".join(record) + "\n")
+    except OSError:
+        pass
+    assert not soft, record
