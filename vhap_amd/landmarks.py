@@ -45,9 +45,12 @@ _WS = {}
 
 
 def _workspace(device):
-    """the split-K workspace of vhap_conv2d_nhwc_ws, one per device (launches of one stream use it one after the other): 4 M floats hold the
+    """the split-K workspace of vhap_conv2d_nhwc_ws, one per device and stream (launches of one stream use it one after the other): 4 M floats hold the
     partial sums of every layer the library splits at the detector's batch sizes (the largest: 4 slices of a 32 x 32 x 128 output, batch 4)"""
     key = str(device)
+    if key in _WS:                                         # (tools/fan_bench.py --no-split plants an empty one under the device's name)
+        return _WS[key]
+    key = (key, torch.cuda.current_stream(device).cuda_stream)   # one per stream: two streams running networks side by side must not share partial sums
     if key not in _WS:
         _WS[key] = torch.empty(1 << 22, dtype=torch.float32, device=device)
     return _WS[key]
